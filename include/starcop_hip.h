@@ -1,0 +1,243 @@
+/*
+ * starcop_hip.h -- C ABI of libstarcop_hip.so (gfx950 / MI355X).
+ *
+ * The reference (spaceml-org/STARCOP) is pure Python on stock torch ops; it has
+ * no FFI of its own.  Each entry point below therefore replaces the *torch op
+ * sequence* the reference dispatches on its segmentation hot path, and cites the
+ * reference lines whose arithmetic it implements.  A reference maintainer binds
+ * these with ctypes; starcop_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative sc_status; it never
+ *     throws and never synchronises the device; the text of the last error on
+ *     the calling thread is returned by sc_last_error().
+ *   - all pointers are DEVICE pointers unless the parameter name ends in _host;
+ *     tensors are dense NCHW fp32 unless stated; `stream` is a hipStream_t
+ *     (pass torch.cuda.current_stream().cuda_stream).
+ *   - no hidden allocation: scratch is caller-provided.
+ */
+#ifndef STARCOP_HIP_H
+#define STARCOP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sc_stream;
+
+enum sc_status {
+  SC_OK = 0,
+  SC_ERR_ARG = -1,      /* bad shape / unsupported configuration  -> ValueError        */
+  SC_ERR_LAUNCH = -2,   /* HIP launch/runtime error               -> RuntimeError      */
+  SC_ERR_NOTPD = -3,    /* covariance not positive definite       -> LinAlgError       */
+  SC_ERR_NODEV = -4     /* no gfx950 device                       -> RuntimeError      */
+};
+
+/* how an activation tensor is read ("normalise on load") */
+enum sc_src_mode {
+  SC_SRC_RAW = 0,     /* v = x                                                              */
+  SC_SRC_AFFINE = 1,  /* v = act(x*c[0] + c[1])            eval/train BatchNorm + ReLU/ReLU6 */
+  SC_SRC_BNBWD = 2,   /* v = A*(pass(aux*c[0]+c[1]) ? x : 0) + B*aux + D,  (A,B,D)=c[2..4]  */
+                      /*     x = dL/d(act(BN(y))), aux = y : BatchNorm+activation backward  */
+  SC_SRC_NORM = 3     /* v = clamp((x-c[0])/c[1], c[2], c[3])   DataNormalizer.normalize_x  */
+};
+enum sc_act { SC_ACT_NONE = 0, SC_ACT_RELU = 1, SC_ACT_RELU6 = 2 };
+
+#define SC_CST 8          /* floats of per-channel constants per channel            */
+#define SC_STAT_SLOTS 32  /* atomics are spread over this many slots per channel     */
+
+typedef struct sc_src {
+  const float* x;    /* primary tensor  [N, C, H>>up, W>>up]                          */
+  const float* aux;  /* secondary tensor (SC_SRC_BNBWD) or NULL                       */
+  const float* cst;  /* per-channel constants [C][SC_CST] or NULL (SC_SRC_RAW)        */
+  int32_t C;         /* channels of this source                                       */
+  int32_t mode;      /* sc_src_mode                                                   */
+  int32_t act;       /* sc_act                                                        */
+  int32_t up;        /* 1: stored at half resolution, read with nearest x2 upsample   */
+} sc_src;
+
+/* ------------------------------------------------------------------------- */
+/* library                                                                    */
+const char* sc_last_error(void);
+int sc_version(void);
+int sc_device_check(void);   /* 0 iff the current device is gfx950 */
+
+/* ------------------------------------------------------------------------- */
+/* weights: pack OIHW -> kernel layouts (replaces nothing in the reference; it is
+ * the layout step torch's conv backends do internally).
+ *   fwd  : wpk[co_tile][ci][tap][co_in_tile]                (co_t = 32 or 64)
+ *   dgrad: same layout of the transposed+flipped filter: W'[ci][co][2-kh][2-kw]
+ */
+int sc_pack_weights(const float* w_oihw, float* wpk, int Cout, int Cin, int ks,
+                    int co_t, int transpose_flip, sc_stream stream);
+size_t sc_packed_weight_floats(int Cout, int Cin, int ks, int co_t, int transpose_flip);
+
+/* ------------------------------------------------------------------------- */
+/* dense conv (groups=1, stride 1, pad ks/2, ks in {1,3}) as implicit GEMM on fp32 MFMA.
+ * Replaces torch.nn.functional.conv2d (+ cat + interpolate(nearest) + batch_norm + relu/relu6
+ * of the producers) as dispatched by smp.Unet at starcop/models/model_module.py:244,
+ * and its backward-data when called with transpose_flip-packed weights.
+ *   input  = channel concat of nsrc (1|2) sources, each with its own prologue
+ *   output = out0 (channels [0,csplit)) and out1 (channels [csplit,Cout)); csplit==Cout -> single
+ *            out = acc (+ add0) (+ add1) (+ old out if accum flag)
+ *   stats  : if non-NULL, per-channel sum / sum-of-squares of acc are atomically
+ *            added to stats[slot][Cout][2] (double), slot in [0,SC_STAT_SLOTS)
+ */
+typedef struct sc_conv_args {
+  sc_src src[2];
+  int32_t nsrc;
+  const float* wpk;      /* packed weights, see sc_pack_weights                 */
+  int32_t N, H, W;       /* output (= input) spatial size                        */
+  int32_t Cout;
+  int32_t ks;            /* 1 or 3                                               */
+  int32_t co_t;          /* 32 or 64: cout tile the weights were packed for      */
+  float* out0; float* out1;
+  int32_t csplit;        /* == Cout when there is a single output                */
+  int32_t accum0, accum1;/* 1: out += result                                     */
+  const float* add0;     /* optional [N,Cout,H,W] tensors added in the epilogue  */
+  const float* add1;     /*   (only valid with csplit == Cout)                   */
+  double* stats;         /* [SC_STAT_SLOTS][Cout][2] or NULL                     */
+} sc_conv_args;
+int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream);
+
+/* weight gradient of the same conv: dW[co][ci][kh][kw] = sum_{n,y,x} dy * in.
+ *   dy  : one source (normally SC_SRC_BNBWD: g + y of the conv output), Cout channels
+ *   in  : concat of nsrc sources with the forward prologues, Cin channels
+ *   part: scratch [nslices][taps][Cout_pad32][Cin_pad32]; call sc_wgrad_workspace_floats
+ *   dw  : [Cout][Cin][ks][ks]  (overwritten)
+ */
+typedef struct sc_wgrad_args {
+  sc_src dy;
+  sc_src src[2];
+  int32_t nsrc;
+  int32_t N, H, W, Cout, Cin, ks;
+  float* part; size_t part_floats;
+  float* dw;
+} sc_wgrad_args;
+size_t sc_wgrad_workspace_floats(int N, int H, int W, int Cout, int Cin, int ks);
+int sc_conv2d_wgrad_mfma(const sc_wgrad_args* a, sc_stream stream);
+
+/* ------------------------------------------------------------------------- */
+/* depthwise 3x3 (groups=C, pad 1, stride 1|2): forward, backward-data, backward-weight */
+int sc_dwconv3x3_fwd(const sc_src* in, const float* w /*[C][3][3]*/, float* out,
+                     int N, int C, int Hin, int Win, int stride, double* stats, sc_stream stream);
+int sc_dwconv3x3_dgrad(const sc_src* dy, const float* w, float* dx, int accum,
+                       int N, int C, int Hin, int Win, int stride, sc_stream stream);
+int sc_dwconv3x3_wgrad(const sc_src* dy, const sc_src* in, double* dw_acc /*[C][9] zeroed*/,
+                       int N, int C, int Hin, int Win, int stride, sc_stream stream);
+int sc_cast_f64_f32(const double* in, float* out, size_t n, sc_stream stream);
+
+/* stem: conv 3x3 stride 2 pad 1, Cin<=8 -> 32, input read through its prologue
+ * (SC_SRC_NORM fuses DataNormalizer.normalize_x, starcop/data/normalizer_module.py:134-135) */
+int sc_stem_conv_fwd(const sc_src* in, const float* w /*[32][Cin][3][3]*/, float* out,
+                     int N, int Cin, int Hin, int Win, double* stats, sc_stream stream);
+size_t sc_stem_wgrad_workspace_floats(int N, int Cin, int Hin, int Win);
+int sc_stem_conv_wgrad(const sc_src* dy, const sc_src* in, float* part, size_t part_floats,
+                       float* dw, int N, int Cin, int Hin, int Win, sc_stream stream);
+
+/* segmentation head: conv 3x3 pad 1, Cin(16) -> 1, bias */
+int sc_head_conv_fwd(const sc_src* in, const float* w /*[1][Cin][3][3]*/, const float* bias,
+                     float* out, int N, int Cin, int H, int W, sc_stream stream);
+int sc_head_conv_dgrad(const float* dlogits, const float* w, float* gin,
+                       int N, int Cin, int H, int W, sc_stream stream);
+size_t sc_head_wgrad_workspace_floats(int N, int Cin, int H, int W);
+int sc_head_conv_wgrad(const float* dlogits, const sc_src* in, float* part, size_t part_floats,
+                       float* dw, float* dbias, int N, int Cin, int H, int W, sc_stream stream);
+
+/* ------------------------------------------------------------------------- */
+/* BatchNorm2d bookkeeping (torch.nn.BatchNorm2d inside smp/torchvision blocks)
+ * training=1: batch statistics from `stats` (count = N*H*W), running stats updated with
+ *             `momentum` (unbiased variance), cst_fwd = {scale, shift, mean, invstd,...}
+ * training=0: cst_fwd from running stats */
+int sc_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float momentum, float eps,
+                   int training, float* cst_fwd, int C, sc_stream stream);
+/* sums[slot][C][2] += { sum g_bn, sum g_bn * xhat }, g_bn = g * act'(BN(y)) */
+int sc_bn_bwd_reduce(const float* g, const float* y, const float* cst_fwd, int act,
+                     double* sums, int N, int C, int HW, sc_stream stream);
+/* dgamma, dbeta and the SC_SRC_BNBWD constants {scale, shift, A, B, D} */
+int sc_bn_bwd_finalize(const double* sums, double count, const float* cst_fwd,
+                       float* dgamma, float* dbeta, float* cst_bwd, int C, sc_stream stream);
+/* out = v(a) + v(b)   (residual add of an inverted-residual block; b may be NULL) */
+int sc_add_srcs(const sc_src* a, const sc_src* b, float* out, int N, int C, int HW, sc_stream stream);
+/* out[n,c,y,x] (+)= sum of the 2x2 block of in (backward of nearest x2 upsample) */
+int sc_downsum2x2(const float* in, float* out, int accum, int N, int C, int Hout, int Wout,
+                  sc_stream stream);
+int sc_fill_f64(double* p, double v, size_t n, sc_stream stream);
+int sc_apply_src(const sc_src* a, float* out, int N, int C, int HW, sc_stream stream);
+
+/* ------------------------------------------------------------------------- */
+/* loss (starcop/models/model_module.py:53-58,76-79): BCEWithLogits(pos_weight) * weight -> mean
+ *   loss_sum : double[1] (zeroed by caller) accumulates sum of per-pixel weighted loss
+ *   dlogits  : grad of mean(loss*weight) w.r.t. logits  (may be NULL)
+ *   loss_px  : per-pixel unweighted loss (may be NULL)  */
+int sc_bce_logits_weighted(const float* logits, const float* target, const float* weight,
+                           float pos_weight, size_t n, double* loss_sum, float* dlogits,
+                           float* loss_px, sc_stream stream);
+
+/* Adam (torch.optim.Adam defaults, model_module.py:174): one fused pass over flat buffers.
+ * bias corrections are computed on the host from the step count. */
+int sc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                 float lr, float beta1, float beta2, float eps, float weight_decay,
+                 float bias_correction1, float bias_correction2_sqrt, float grad_scale,
+                 const float* hp_dev /* optional device {lr, bc1, bc2_sqrt}: overrides the host values */,
+                 sc_stream stream);
+/* step[0] += 1 (device int64); hp_dev = {lr_dev[0], 1-beta1^step, sqrt(1-beta2^step)}: lets a captured
+ * hipGraph replay the optimiser step with the right bias corrections and a scheduler-driven lr */
+int sc_adam_prepare(int64_t* step, const float* lr_dev, float beta1, float beta2, float* hp_dev,
+                    sc_stream stream);
+
+/* masks (model_module.py:124,193-212,268-269):
+ *   prediction = sigmoid(logits); pred_binary = ge0 ? logits>=0 : sigmoid>0.5   (int64)
+ *   differences = 2*pred_binary + (target==1) (int64, if target)
+ *   tile_count[n] = sum pred_binary (int64, zeroed by caller);
+ *   then sc_pred_classification: cls[n] = count > 10*H*W/64^2 */
+int sc_threshold_masks(const float* logits, const float* target, int ge0, float* prediction,
+                       int64_t* pred_binary, int64_t* differences, int64_t* tile_count,
+                       int N, int HW, sc_stream stream);
+int sc_pred_classification(const int64_t* tile_count, int64_t* cls, int N, int H, int W,
+                           sc_stream stream);
+
+/* ------------------------------------------------------------------------- */
+/* mag1c (starcop/models/mag1c.py:177-348): see starcop_amd/csrc/mag1c.hip        */
+typedef struct sc_mag1c_args {
+  const void* x;            /* packed groups, band-major: for group g, x + xoff[g] holds [S][Ppad[g]] */
+  int32_t x_is_f64;         /* element type of x: 0 f32, 1 f64                                         */
+  const int64_t* xoff;      /* [G] element offsets                                                      */
+  const int32_t* P;         /* [G] pixels per group                                                     */
+  const int32_t* Ppad;      /* [G] row pitch (elements)                                                 */
+  const uint8_t* statmask;  /* optional per-pixel statistics mask, packed like a band row, or NULL       */
+  const int64_t* poff;      /* [G] offsets into per-pixel outputs                                       */
+  int32_t G, S;
+  const double* templ;      /* [S] unit absorption spectrum                                             */
+  int32_t num_iter;         /* -1: plain rmf()                                                           */
+  double alpha;
+  double cov_update_scaling;
+  int32_t albedo_override, zero_override, sparse_override, apply_scaling;
+  double* work;             /* scratch, sc_mag1c_workspace_doubles(G,S)                                   */
+  void* mf_out;             /* per-pixel outputs, same element type as x                                 */
+  void* albedo_out;
+  int32_t* status;          /* [G] 0 ok, 1 not positive definite                                         */
+} sc_mag1c_args;
+size_t sc_mag1c_workspace_doubles(int G, int S);
+int sc_mag1c_groups(const sc_mag1c_args* a, sc_stream stream);
+/* gather pixels of a (H,W,S) band-interleaved cube into the packed band-major group layout */
+int sc_mag1c_pack(const void* cube, int cube_is_f64, int S_total, int band0, int S,
+                  const int32_t* pix_index, size_t npix_total, const int64_t* xoff,
+                  const int32_t* Ppad, const int64_t* poff, const int32_t* P, int G,
+                  void* xpacked, int out_is_f64, sc_stream stream);
+/* scatter per-pixel results back: out[pix_index[i]] = val[i] */
+int sc_scatter(const void* val, int is_f64, const int32_t* pix_index, size_t n, void* out,
+               sc_stream stream);
+
+/* band ratio (starcop/data/feature_extration.py:37-56), c computed from trimmed sums on device */
+int sc_band_ratio(const float* background, const float* signal, float* out, size_t n,
+                  float c, float zero_value_out, sc_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STARCOP_HIP_H */

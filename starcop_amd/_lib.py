@@ -1,0 +1,173 @@
+"""ctypes binding of libstarcop_hip.so (the C ABI in include/starcop_hip.h).
+
+This is the binding a maintainer of the reference would add.
+There is NO fallback: if the shared library is missing, or the current device is
+not gfx950, every call raises.  Nothing here imports ``oracle``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstarcop_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+SC_CST = 8
+SC_STAT_SLOTS = 32
+
+SRC_RAW, SRC_AFFINE, SRC_BNBWD, SRC_NORM = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+
+
+class StarcopHipError(RuntimeError):
+    pass
+
+
+class sc_src(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("aux", C.c_void_p), ("cst", C.c_void_p),
+                ("C", C.c_int32), ("mode", C.c_int32), ("act", C.c_int32), ("up", C.c_int32)]
+
+
+class sc_conv_args(C.Structure):
+    _fields_ = [("src", sc_src * 2), ("nsrc", C.c_int32), ("wpk", C.c_void_p),
+                ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cout", C.c_int32),
+                ("ks", C.c_int32), ("co_t", C.c_int32),
+                ("out0", C.c_void_p), ("out1", C.c_void_p),
+                ("csplit", C.c_int32), ("accum0", C.c_int32), ("accum1", C.c_int32),
+                ("add0", C.c_void_p), ("add1", C.c_void_p), ("stats", C.c_void_p)]
+
+
+class sc_wgrad_args(C.Structure):
+    _fields_ = [("dy", sc_src), ("src", sc_src * 2), ("nsrc", C.c_int32),
+                ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("Cout", C.c_int32), ("Cin", C.c_int32), ("ks", C.c_int32),
+                ("part", C.c_void_p), ("part_floats", C.c_size_t), ("dw", C.c_void_p)]
+
+
+class sc_mag1c_args(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("x_is_f64", C.c_int32), ("xoff", C.c_void_p),
+                ("P", C.c_void_p), ("Ppad", C.c_void_p), ("statmask", C.c_void_p),
+                ("poff", C.c_void_p), ("G", C.c_int32), ("S", C.c_int32),
+                ("templ", C.c_void_p), ("num_iter", C.c_int32), ("alpha", C.c_double),
+                ("cov_update_scaling", C.c_double),
+                ("albedo_override", C.c_int32), ("zero_override", C.c_int32),
+                ("sparse_override", C.c_int32), ("apply_scaling", C.c_int32),
+                ("work", C.c_void_p), ("mf_out", C.c_void_p), ("albedo_out", C.c_void_p),
+                ("status", C.c_void_p)]
+
+
+_vp, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/starcop_hip.h declares
+SIGNATURES = {
+    "sc_last_error": (C.c_char_p, []),
+    "sc_version": (_i, []),
+    "sc_device_check": (_i, []),
+    "sc_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sc_packed_weight_floats": (_sz, [_i, _i, _i, _i, _i]),
+    "sc_conv2d_mfma": (_i, [C.POINTER(sc_conv_args), _vp]),
+    "sc_wgrad_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "sc_conv2d_wgrad_mfma": (_i, [C.POINTER(sc_wgrad_args), _vp]),
+    "sc_dwconv3x3_fwd": (_i, [C.POINTER(sc_src), _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sc_dwconv3x3_dgrad": (_i, [C.POINTER(sc_src), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "sc_dwconv3x3_wgrad": (_i, [C.POINTER(sc_src), C.POINTER(sc_src), _vp, _i, _i, _i, _i, _i, _vp]),
+    "sc_cast_f64_f32": (_i, [_vp, _vp, _sz, _vp]),
+    "sc_stem_conv_fwd": (_i, [C.POINTER(sc_src), _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "sc_stem_wgrad_workspace_floats": (_sz, [_i, _i, _i, _i]),
+    "sc_stem_conv_wgrad": (_i, [C.POINTER(sc_src), C.POINTER(sc_src), _vp, _sz, _vp, _i, _i, _i, _i, _vp]),
+    "sc_head_conv_fwd": (_i, [C.POINTER(sc_src), _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "sc_head_conv_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "sc_head_wgrad_workspace_floats": (_sz, [_i, _i, _i, _i]),
+    "sc_head_conv_wgrad": (_i, [_vp, C.POINTER(sc_src), _vp, _sz, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "sc_bn_finalize": (_i, [_vp, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _i, _vp]),
+    "sc_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "sc_bn_bwd_finalize": (_i, [_vp, _d, _vp, _vp, _vp, _vp, _i, _vp]),
+    "sc_add_srcs": (_i, [C.POINTER(sc_src), C.POINTER(sc_src), _vp, _i, _i, _i, _vp]),
+    "sc_apply_src": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _vp]),
+    "sc_downsum2x2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sc_fill_f64": (_i, [_vp, _d, _sz, _vp]),
+    "sc_bce_logits_weighted": (_i, [_vp, _vp, _vp, _f, _sz, _vp, _vp, _vp, _vp]),
+    "sc_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _f, _f, _vp, _vp]),
+    "sc_adam_prepare": (_i, [_vp, _vp, _f, _f, _vp, _vp]),
+    "sc_threshold_masks": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "sc_pred_classification": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    # MAG1C_SIGS
+    "sc_band_ratio": (_i, [_vp, _vp, _vp, _sz, _f, _f, _vp]),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile every HIP source for gfx950 into starcop_amd/libstarcop_hip.so (hipcc; no GPU needed)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, stdout=subprocess.DEVNULL)
+    r = subprocess.run(["make", "-C", CSRC, "-j", "4"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise StarcopHipError("building libstarcop_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+def load():
+    """dlopen the library and declare every entry point.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise StarcopHipError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C starcop_amd/csrc`).  starcop_amd has no CPU/torch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+_EXC = {-1: ValueError, -2: RuntimeError, -3: torch.linalg.LinAlgError, -4: RuntimeError}
+
+
+def check(rc):
+    """Map negative C status codes to the exception types the reference raises."""
+    if rc != 0:
+        msg = load().sc_last_error().decode("utf-8", "replace")
+        raise _EXC.get(rc, StarcopHipError)(f"libstarcop_hip: {msg} (status {rc})")
+
+
+_device_ok = {}
+
+
+def require_device(t=None):
+    """The product path runs on a gfx950 GPU only; anything else is a loud error."""
+    if not torch.cuda.is_available():
+        raise StarcopHipError("starcop_amd needs a ROCm GPU (gfx950); torch.cuda.is_available() is False")
+    if t is not None and not t.is_cuda:
+        raise StarcopHipError(f"starcop_amd kernels need device tensors, got a tensor on {t.device}")
+    dev = torch.cuda.current_device()
+    if dev not in _device_ok:
+        check(load().sc_device_check())
+        _device_ok[dev] = True
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def make_src(x, C_, mode=SRC_RAW, act=ACT_NONE, up=0, cst=None, aux=None):
+    s = sc_src()
+    s.x = x.data_ptr() if x is not None else None
+    s.aux = aux.data_ptr() if aux is not None else None
+    s.cst = cst.data_ptr() if cst is not None else None
+    s.C, s.mode, s.act, s.up = int(C_), int(mode), int(act), int(up)
+    return s

@@ -1,0 +1,586 @@
+// Dense NCHW conv2d (k in {1,3}, stride 1, pad k/2) as implicit GEMM on the fp32 MFMA
+// (v_mfma_f32_32x32x2_f32) of gfx950: forward, backward-data (same kernel, transposed+flipped
+// packed filter) and backward-weight.
+//
+// Replaces, for the smp.Unet built at starcop/models/model_module.py:244-251, the torch ops
+//   F.conv2d  +  (producer's) F.batch_norm / relu / relu6  +  F.interpolate(nearest, x2) + torch.cat
+// and their autograd backward.  Producers store RAW conv outputs; BatchNorm + activation (or the
+// BatchNorm/activation backward, or DataNormalizer) are applied while the tile is staged to LDS.
+//
+// GEMM view (forward):  D[co][pixel] = sum_{ci,tap} Wp[ci][tap][co] * patch[ci][pixel + d(tap)]
+//   A operand (32 x 2): lane l -> A[i = l&31 (cout)][k = l>>5 (ci of the pair)]
+//   B operand ( 2 x 32): lane l -> B[k = l>>5][j = l&31 (pixel in a 32-wide row segment)]
+//   D (32 x 32, 16 regs): col = l&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(l>>5) (cout)
+// Work-group = 4 waves; tile = (32*RM couts) x (4 rows x 32 cols | 128 flat pixels); wave w owns
+// pixel row w and all RM cout blocks.  K loop = chunks of 8 input channels, double-buffered in LDS,
+// global loads for chunk k+1 issued before the MFMAs of chunk k (register staged because of the
+// prologue), one barrier per chunk.
+#include "sc_common.h"
+
+namespace {
+
+struct ConvP {
+  SrcD s0, s1;
+  const float* wpk;
+  int N, H, W, Cout;
+  float* out0; float* out1;
+  int csplit, accum0, accum1;
+  const float* add0; const float* add1;
+  double* stats;
+};
+
+template <int KS, int RM>
+__global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
+  constexpr int TAPS = KS * KS;
+  constexpr int CO_T = 32 * RM;
+  constexpr int PR = (KS == 3) ? 6 : 4;
+  constexpr int PC = (KS == 3) ? 34 : 32;
+  constexpr int PCH = PR * PC;                 // patch floats per channel
+  constexpr int NE = (PCH + 31) / 32;          // patch elements per thread (32 threads per channel)
+  constexpr int WCH = 8 * TAPS * CO_T;         // weight floats per chunk
+  constexpr int NW = (WCH / 4 + 255) / 256;    // float4 per thread
+
+  __shared__ __attribute__((aligned(16))) float s_w[2][WCH];
+  __shared__ float s_p[2][8 * PCH];
+  __shared__ float s_red[4][CO_T][2];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int n = blockIdx.z, cot = blockIdx.y;
+  const int H = p.H, W = p.W;
+  int y0 = 0, x0 = 0, p0 = 0;
+  if (KS == 3) {
+    const int tiles_x = (W + 31) >> 5;
+    const int ty = blockIdx.x / tiles_x;
+    y0 = ty * 4;
+    x0 = (blockIdx.x - ty * tiles_x) * 32;
+  } else {
+    p0 = blockIdx.x * 128;
+  }
+  const int C0 = p.s0.C;
+  const int Cin = C0 + p.s1.C;
+  const int nk = Cin >> 3;
+  const float* wbase = p.wpk + (size_t)cot * Cin * (TAPS * CO_T);
+
+  floatx16 acc[RM];
+#pragma unroll
+  for (int m = 0; m < RM; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+  // ---- staging state (registers) ----
+  const int sci = tid >> 5;     // channel of the chunk this thread stages
+  const int sq = tid & 31;
+  float xv[NE], av[NE];
+  unsigned inb = 0;
+  float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float c4 = 0.f;
+  int smode = 0, sact = 0;
+  floatx4 wv[NW];
+
+  auto load_chunk = [&](int kc) {
+    const int c = kc * 8 + sci;
+    const bool second = c >= C0;
+    const int cs = second ? c - C0 : c;
+    const float* xp = second ? p.s1.x : p.s0.x;
+    const float* ap = second ? p.s1.aux : p.s0.aux;
+    const float* cp = second ? p.s1.cst : p.s0.cst;
+    const int Cs = second ? p.s1.C : p.s0.C;
+    const int up = second ? p.s1.up : p.s0.up;
+    smode = second ? p.s1.mode : p.s0.mode;
+    sact = second ? p.s1.act : p.s0.act;
+    if (smode != SC_SRC_RAW) {
+      c0 = *reinterpret_cast<const float4*>(cp + (size_t)cs * SC_CST);
+      c4 = cp[(size_t)cs * SC_CST + 4];
+    }
+    inb = 0;
+    if (KS == 3) {
+      const int Hs = H >> up, Ws = W >> up;
+      const size_t base = ((size_t)n * Cs + cs) * Hs * Ws;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int e = sq + 32 * i;
+        const int pr = e / PC, pc = e - pr * PC;
+        const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+        const bool ok = (e < PCH) && (y >= 0) && (y < H) && (x >= 0) && (x < W);
+        float xvv = 0.f, avv = 0.f;
+        if (ok) {
+          const size_t idx = base + (size_t)(y >> up) * Ws + (x >> up);
+          xvv = xp[idx];
+          if (smode == SC_SRC_BNBWD) avv = ap[idx];
+          inb |= 1u << i;
+        }
+        xv[i] = xvv; av[i] = avv;
+      }
+    } else {
+      const int HW = H * W;
+      const size_t base = ((size_t)n * Cs + cs) * HW;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int pix = p0 + sq + 32 * i;
+        const bool ok = pix < HW;
+        float xvv = 0.f, avv = 0.f;
+        if (ok) {
+          xvv = xp[base + pix];
+          if (smode == SC_SRC_BNBWD) avv = ap[base + pix];
+          inb |= 1u << i;
+        }
+        xv[i] = xvv; av[i] = avv;
+      }
+    }
+    const floatx4* wsrc = reinterpret_cast<const floatx4*>(wbase + (size_t)kc * WCH);
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int i4 = tid + 256 * j;
+      wv[j] = wsrc[i4 < WCH / 4 ? i4 : WCH / 4 - 1];   // clamped: unconditional load keeps wv in registers
+    }
+  };
+
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = sq + 32 * i;
+      if (e < PCH) {
+        const float v = ((inb >> i) & 1u) ? sc_prologue(smode, sact, xv[i], av[i], c0, c4) : 0.f;
+        s_p[buf][sci * PCH + e] = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int i4 = tid + 256 * j;
+      if (i4 < WCH / 4) *reinterpret_cast<floatx4*>(&s_w[buf][i4 * 4]) = wv[j];
+    }
+  };
+
+  auto compute_chunk = [&](int buf) {
+#pragma unroll
+    for (int cp = 0; cp < 4; ++cp) {
+      const int cil = 2 * cp + lhi;
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        float b;
+        if (KS == 3) {
+          const int kh = tap / 3, kw = tap - 3 * kh;
+          b = s_p[buf][cil * PCH + (wave + kh) * PC + l31 + kw];
+        } else {
+          b = s_p[buf][cil * PCH + wave * 32 + l31];
+        }
+#pragma unroll
+        for (int m = 0; m < RM; ++m) {
+          const float a = s_w[buf][(cil * TAPS + tap) * CO_T + m * 32 + l31];
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    const bool more = (kc + 1) < nk;
+    if (more) load_chunk(kc + 1);
+    compute_chunk(kc & 1);
+    if (more) store_chunk((kc + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  int oy = 0, ox = 0, opix = 0;
+  bool pix_ok;
+  if (KS == 3) {
+    oy = y0 + wave; ox = x0 + l31;
+    pix_ok = (oy < H) && (ox < W);
+    opix = oy * W + ox;
+  } else {
+    opix = p0 + wave * 32 + l31;
+    pix_ok = opix < H * W;
+  }
+  const size_t HWs = (size_t)H * W;
+  const bool want_stats = p.stats != nullptr;
+#pragma unroll
+  for (int m = 0; m < RM; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int col = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const int co = cot * CO_T + col;
+      float v = acc[m][r];
+      const bool ok = pix_ok && (co < p.Cout);
+      if (!ok) v = 0.f;
+      if (want_stats) {
+        const float s = half_sum32(v);
+        const float ss = half_sum32(v * v);
+        if (l31 == 0) { s_red[wave][col][0] = s; s_red[wave][col][1] = ss; }
+      }
+      if (ok) {
+        float* o; size_t idx; int accum;
+        if (co < p.csplit) {
+          idx = ((size_t)n * p.csplit + co) * HWs + opix; o = p.out0; accum = p.accum0;
+        } else {
+          idx = ((size_t)n * (p.Cout - p.csplit) + (co - p.csplit)) * HWs + opix; o = p.out1; accum = p.accum1;
+        }
+        if (p.add0) v += p.add0[idx];
+        if (p.add1) v += p.add1[idx];
+        if (accum) v += o[idx];
+        o[idx] = v;
+      }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    if (tid < CO_T * 2) {
+      const int col = tid >> 1, k = tid & 1;
+      const int co = cot * CO_T + col;
+      if (co < p.Cout) {
+        const float t = s_red[0][col][k] + s_red[1][col][k] + s_red[2][col][k] + s_red[3][col][k];
+        atomicAdd(&p.stats[((size_t)stat_slot() * p.Cout + co) * 2 + k], (double)t);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing
+__global__ void k_pack_weights(const float* __restrict__ w, float* __restrict__ wpk, int Cout, int Cin,
+                               int taps, int co_t, int tflip, size_t total) {
+  // destination-major: wpk[((mt*K + k)*taps + tap)*co_t + col]
+  //   forward : M = Cout, K = Cin,  value = w[((m*K + k)*taps) + tap]
+  //   dgrad   : M = Cin,  K = Cout, value = w[((k*M + m)*taps) + (taps-1-tap)]
+  const int M = tflip ? Cin : Cout, K = tflip ? Cout : Cin;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % co_t);
+    size_t r = i / co_t;
+    const int tap = (int)(r % taps); r /= taps;
+    const int k = (int)(r % K);
+    const int mt = (int)(r / K);
+    const int m = mt * co_t + col;
+    float v = 0.f;
+    if (m < M) v = tflip ? w[((size_t)k * M + m) * taps + (taps - 1 - tap)] : w[((size_t)m * K + k) * taps + tap];
+    wpk[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient.  GEMM view: D[co][ci] (per tap) = sum_pixels dy[co][pix] * in[ci][pix + d(tap)]
+//   A: lane -> dy_lds[co = l&31][pix = 2q + (l>>5)],  B: lane -> in_lds[ci = l&31][pix(+tap)]
+// Work-group tile (32*WM couts) x (32*WN cins), WK = 4/(WM*WN) waves split the pixel rows of a stage.
+struct WgradP {
+  SrcD dy, s0, s1;
+  int N, H, W, Cout, Cin;
+  float* part;
+  int nsl;          // K slices (gridDim.x)
+  int CoP, CiP;     // padded dims of the partial buffer
+};
+
+template <int KS, int WM, int WN>
+__global__ __launch_bounds__(256) void k_wgrad_mfma(const WgradP p) {
+  constexpr int TAPS = KS * KS;
+  constexpr int WK = 4 / (WM * WN);
+  constexpr int SR = (WK == 4) ? 4 : 2;        // pixel rows (of 32) per stage
+  constexpr int RW = SR / WK;                  // rows per wave
+  constexpr int COT = 32 * WM, CIT = 32 * WN;
+  constexpr int PA = SR * 32 + 1;              // dy pitch per channel (odd -> conflict-free)
+  constexpr int PRW = SR + (KS == 3 ? 2 : 0);
+  constexpr int PCW = (KS == 3) ? 34 : 32;
+  constexpr int PB = (PRW * PCW) | 1;
+  constexpr int NEA = COT * SR * 32;           // dy elements per stage
+  constexpr int NEB = CIT * PRW * PCW;         // input elements per stage
+
+  __shared__ float s_a[COT * PA];
+  __shared__ float s_b[CIT * PB];
+  __shared__ __attribute__((aligned(16))) float s_ca[COT * SC_CST];
+  __shared__ __attribute__((aligned(16))) float s_cb[CIT * SC_CST];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int wm = wave % WM, wn = (wave / WM) % WN, wk = wave / (WM * WN);
+  const int cit = blockIdx.y, cot = blockIdx.z;
+  const int H = p.H, W = p.W;
+  const int C0 = p.s0.C;
+
+  // per-WG constants -> LDS
+  for (int i = tid; i < COT * SC_CST; i += 256) {
+    const int ch = cot * COT + i / SC_CST;
+    s_ca[i] = (p.dy.cst && ch < p.Cout) ? p.dy.cst[(size_t)ch * SC_CST + (i % SC_CST)] : 0.f;
+  }
+  for (int i = tid; i < CIT * SC_CST; i += 256) {
+    const int ch = cit * CIT + i / SC_CST;
+    float v = 0.f;
+    if (ch < p.Cin) {
+      const bool second = ch >= C0;
+      const float* cp = second ? p.s1.cst : p.s0.cst;
+      if (cp) v = cp[(size_t)(second ? ch - C0 : ch) * SC_CST + (i % SC_CST)];
+    }
+    s_cb[i] = v;
+  }
+
+  floatx16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // stage enumeration
+  int tiles_x, tiles_y, per_img;
+  if (KS == 3) {
+    tiles_x = (W + 31) >> 5; tiles_y = (H + SR - 1) / SR; per_img = tiles_x * tiles_y;
+  } else {
+    tiles_x = 1; tiles_y = 1; per_img = (H * W + SR * 32 - 1) / (SR * 32);
+  }
+  const long T = (long)p.N * per_img;
+  const long t_begin = T * blockIdx.x / p.nsl, t_end = T * (blockIdx.x + 1) / p.nsl;
+
+  for (long t = t_begin; t < t_end; ++t) {
+    const int n = (int)(t / per_img);
+    const int rem = (int)(t - (long)n * per_img);
+    int y0 = 0, x0 = 0, p0 = 0;
+    if (KS == 3) { const int ty = rem / tiles_x; y0 = ty * SR; x0 = (rem - ty * tiles_x) * 32; }
+    else p0 = rem * SR * 32;
+    __syncthreads();   // previous stage fully consumed (also orders the constant stores)
+    // ---- stage dy ----
+    for (int i = tid; i < NEA; i += 256) {
+      const int chl = i / (SR * 32), px = i - chl * (SR * 32);
+      const int ch = cot * COT + chl;
+      float v = 0.f;
+      if (ch < p.Cout) {
+        bool ok; size_t idx;
+        if (KS == 3) {
+          const int y = y0 + (px >> 5), x = x0 + (px & 31);
+          ok = (y < H) && (x < W);
+          idx = (((size_t)n * p.Cout + ch) * H + y) * W + x;
+        } else {
+          const int pix = p0 + px;
+          ok = pix < H * W;
+          idx = ((size_t)n * p.Cout + ch) * H * W + pix;
+        }
+        if (ok) {
+          const float xg = p.dy.x[idx];
+          const float au = (p.dy.mode == SC_SRC_BNBWD) ? p.dy.aux[idx] : 0.f;
+          const float4 c0 = *reinterpret_cast<const float4*>(&s_ca[chl * SC_CST]);
+          v = sc_prologue(p.dy.mode, p.dy.act, xg, au, c0, s_ca[chl * SC_CST + 4]);
+        }
+      }
+      s_a[chl * PA + px] = v;
+    }
+    // ---- stage input patch ----
+    for (int i = tid; i < NEB; i += 256) {
+      const int chl = i / (PRW * PCW), e = i - chl * (PRW * PCW);
+      const int ch = cit * CIT + chl;
+      float v = 0.f;
+      if (ch < p.Cin) {
+        const bool second = ch >= C0;
+        const int cs = second ? ch - C0 : ch;
+        const float* xp = second ? p.s1.x : p.s0.x;
+        const int Cs = second ? p.s1.C : p.s0.C;
+        const int up = second ? p.s1.up : p.s0.up;
+        const int mode = second ? p.s1.mode : p.s0.mode;
+        const int act = second ? p.s1.act : p.s0.act;
+        bool ok; size_t idx;
+        if (KS == 3) {
+          const int pr = e / PCW, pc = e - pr * PCW;
+          const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+          ok = (y >= 0) && (y < H) && (x >= 0) && (x < W);
+          const int Hs = H >> up, Ws = W >> up;
+          idx = (((size_t)n * Cs + cs) * Hs + (y >> up)) * Ws + (x >> up);
+        } else {
+          const int pix = p0 + e;
+          ok = pix < H * W;
+          idx = ((size_t)n * Cs + cs) * H * W + pix;
+        }
+        if (ok) {
+          const float xg = xp[idx];
+          const float4 c0 = *reinterpret_cast<const float4*>(&s_cb[chl * SC_CST]);
+          v = sc_prologue(mode, act, xg, 0.f, c0, 0.f);
+        }
+      }
+      s_b[chl * PB + e] = v;
+    }
+    __syncthreads();
+    // ---- MFMA ----
+#pragma unroll
+    for (int rr0 = 0; rr0 < RW; ++rr0) {
+      const int rr = wk * RW + rr0;
+#pragma unroll 4
+      for (int q = 0; q < 16; ++q) {
+        const float a = s_a[(wm * 32 + l31) * PA + rr * 32 + 2 * q + lhi];
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+          float b;
+          if (KS == 3) {
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            b = s_b[(wn * 32 + l31) * PB + (rr + kh) * PCW + 2 * q + lhi + kw];
+          } else {
+            b = s_b[(wn * 32 + l31) * PB + rr * 32 + 2 * q + lhi];
+          }
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tap], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- partial store: part[((slice*WK + wk)*TAPS + tap)*CoP*CiP + co*CiP + ci] ----
+  const int ci = cit * CIT + wn * 32 + l31;
+  const size_t plane = (size_t)p.CoP * p.CiP;
+  float* pb = p.part + ((size_t)blockIdx.x * WK + wk) * TAPS * plane;
+#pragma unroll
+  for (int tap = 0; tap < TAPS; ++tap) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cot * COT + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (co < p.CoP && ci < p.CiP) pb[tap * plane + (size_t)co * p.CiP + ci] = acc[tap][r];
+    }
+  }
+}
+
+// dw[co][ci][tap] = sum_s part[s][tap][co][ci]
+__global__ void k_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int nparts, int taps,
+                               int Cout, int Cin, int CoP, int CiP) {
+  const size_t total = (size_t)taps * Cout * Cin;
+  const size_t plane = (size_t)CoP * CiP;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin);
+    size_t r = i / Cin;
+    const int co = (int)(r % Cout);
+    const int tap = (int)(r / Cout);
+    const float* src = part + (size_t)tap * plane + (size_t)co * CiP + ci;
+    float s = 0.f;
+    for (int k = 0; k < nparts; ++k) s += src[(size_t)k * taps * plane];
+    dw[((size_t)co * Cin + ci) * taps + tap] = s;
+  }
+}
+
+struct WgradPlan { int wm, wn, wk, sr, nsl, CoP, CiP, co_tiles, ci_tiles; long stages; };
+
+WgradPlan plan_wgrad(int N, int H, int W, int Cout, int Cin, int ks) {
+  WgradPlan pl;
+  if (Cout > 32 && Cin > 32) { pl.wm = 2; pl.wn = 2; }
+  else if (Cout > 32) { pl.wm = 2; pl.wn = 1; }
+  else if (Cin > 32) { pl.wm = 1; pl.wn = 2; }
+  else { pl.wm = 1; pl.wn = 1; }
+  pl.wk = 4 / (pl.wm * pl.wn);
+  pl.sr = (pl.wk == 4) ? 4 : 2;
+  pl.CoP = (Cout + 31) / 32 * 32;
+  pl.CiP = (Cin + 31) / 32 * 32;
+  pl.co_tiles = (Cout + 32 * pl.wm - 1) / (32 * pl.wm);
+  pl.ci_tiles = (Cin + 32 * pl.wn - 1) / (32 * pl.wn);
+  if (ks == 3) pl.stages = (long)N * ((W + 31) / 32) * ((H + pl.sr - 1) / pl.sr);
+  else pl.stages = (long)N * (((long)H * W + pl.sr * 32 - 1) / (pl.sr * 32));
+  long want = 1024 / ((long)pl.co_tiles * pl.ci_tiles);
+  if (want < 1) want = 1;
+  if (want > pl.stages) want = pl.stages;
+  if (want > 512) want = 512;
+  pl.nsl = (int)want;
+  return pl;
+}
+
+}  // namespace
+
+extern "C" size_t sc_packed_weight_floats(int Cout, int Cin, int ks, int co_t, int transpose_flip) {
+  const int M = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
+  const size_t mt = (M + co_t - 1) / co_t;
+  return mt * K * ks * ks * co_t;
+}
+
+extern "C" int sc_pack_weights(const float* w, float* wpk, int Cout, int Cin, int ks, int co_t,
+                               int transpose_flip, sc_stream stream) {
+  SC_REQUIRE(ks == 1 || ks == 3, "sc_pack_weights: ks must be 1 or 3 (got %d)", ks);
+  SC_REQUIRE(co_t == 32 || co_t == 64, "sc_pack_weights: co_t must be 32 or 64 (got %d)", co_t);
+  const size_t total = sc_packed_weight_floats(Cout, Cin, ks, co_t, transpose_flip);
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_pack_weights, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wpk, Cout, Cin,
+                     ks * ks, co_t, transpose_flip, total);
+  SC_LAUNCH_OK("sc_pack_weights");
+  return SC_OK;
+}
+
+extern "C" int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream) {
+  SC_REQUIRE(a != nullptr, "sc_conv2d_mfma: null args");
+  SC_REQUIRE(a->ks == 1 || a->ks == 3, "sc_conv2d_mfma: ks must be 1 or 3 (got %d)", a->ks);
+  SC_REQUIRE(a->co_t == 32 || a->co_t == 64, "sc_conv2d_mfma: co_t must be 32 or 64 (got %d)", a->co_t);
+  SC_REQUIRE(a->nsrc == 1 || a->nsrc == 2, "sc_conv2d_mfma: nsrc must be 1 or 2");
+  const int C0 = a->src[0].C, C1 = a->nsrc == 2 ? a->src[1].C : 0;
+  SC_REQUIRE(C0 > 0 && C0 % 8 == 0 && C1 % 8 == 0, "sc_conv2d_mfma: source channels must be multiples of 8 (got %d,%d)", C0, C1);
+  SC_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->Cout > 0, "sc_conv2d_mfma: bad shape");
+  SC_REQUIRE(a->csplit > 0 && a->csplit <= a->Cout, "sc_conv2d_mfma: bad csplit");
+  SC_REQUIRE(a->csplit == a->Cout || (a->add0 == nullptr && a->add1 == nullptr), "sc_conv2d_mfma: add tensors need a single output");
+  for (int s = 0; s < a->nsrc; ++s) {
+    SC_REQUIRE(a->src[s].up == 0 || (a->ks == 3 && a->H % 2 == 0 && a->W % 2 == 0), "sc_conv2d_mfma: upsampled source needs ks=3 and even H,W");
+    SC_REQUIRE(a->src[s].mode == SC_SRC_RAW || a->src[s].cst != nullptr, "sc_conv2d_mfma: source %d needs constants", s);
+    SC_REQUIRE(a->src[s].mode != SC_SRC_BNBWD || a->src[s].aux != nullptr, "sc_conv2d_mfma: BNBWD source needs aux");
+  }
+  ConvP p;
+  p.s0 = to_srcd(a->src[0]);
+  p.s1 = a->nsrc == 2 ? to_srcd(a->src[1]) : empty_srcd();
+  p.wpk = a->wpk; p.N = a->N; p.H = a->H; p.W = a->W; p.Cout = a->Cout;
+  p.out0 = a->out0; p.out1 = a->out1; p.csplit = a->csplit; p.accum0 = a->accum0; p.accum1 = a->accum1;
+  p.add0 = a->add0; p.add1 = a->add1; p.stats = a->stats;
+  const int co_tiles = (a->Cout + a->co_t - 1) / a->co_t;
+  dim3 grid;
+  if (a->ks == 3) grid = dim3(((a->W + 31) / 32) * ((a->H + 3) / 4), co_tiles, a->N);
+  else grid = dim3((a->H * a->W + 127) / 128, co_tiles, a->N);
+  hipStream_t st = (hipStream_t)stream;
+  if (a->ks == 3 && a->co_t == 64) hipLaunchKernelGGL((k_conv_mfma<3, 2>), grid, dim3(256), 0, st, p);
+  else if (a->ks == 3) hipLaunchKernelGGL((k_conv_mfma<3, 1>), grid, dim3(256), 0, st, p);
+  else if (a->co_t == 64) hipLaunchKernelGGL((k_conv_mfma<1, 2>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((k_conv_mfma<1, 1>), grid, dim3(256), 0, st, p);
+  SC_LAUNCH_OK("sc_conv2d_mfma");
+  return SC_OK;
+}
+
+extern "C" size_t sc_wgrad_workspace_floats(int N, int H, int W, int Cout, int Cin, int ks) {
+  const WgradPlan pl = plan_wgrad(N, H, W, Cout, Cin, ks);
+  const size_t E = (size_t)ks * ks * pl.CoP * pl.CiP;
+  const int nparts = pl.nsl * pl.wk;
+  return (size_t)nparts * E + sc_reduce_scratch_floats(nparts, E);
+}
+
+extern "C" int sc_conv2d_wgrad_mfma(const sc_wgrad_args* a, sc_stream stream) {
+  SC_REQUIRE(a != nullptr, "sc_conv2d_wgrad_mfma: null args");
+  SC_REQUIRE(a->ks == 1 || a->ks == 3, "sc_conv2d_wgrad_mfma: ks must be 1 or 3");
+  SC_REQUIRE(a->nsrc == 1 || a->nsrc == 2, "sc_conv2d_wgrad_mfma: nsrc must be 1 or 2");
+  const int C0 = a->src[0].C, C1 = a->nsrc == 2 ? a->src[1].C : 0;
+  SC_REQUIRE(C0 + C1 == a->Cin, "sc_conv2d_wgrad_mfma: source channels (%d+%d) != Cin %d", C0, C1, a->Cin);
+  SC_REQUIRE(a->dy.C == a->Cout, "sc_conv2d_wgrad_mfma: dy channels %d != Cout %d", a->dy.C, a->Cout);
+  SC_REQUIRE(a->dy.up == 0, "sc_conv2d_wgrad_mfma: dy cannot be upsampled");
+  SC_REQUIRE(a->dy.mode != SC_SRC_BNBWD || a->dy.aux != nullptr, "sc_conv2d_wgrad_mfma: BNBWD dy needs aux");
+  for (int s = 0; s < a->nsrc; ++s) {
+    SC_REQUIRE(a->src[s].mode != SC_SRC_BNBWD, "sc_conv2d_wgrad_mfma: input sources cannot be BNBWD");
+    SC_REQUIRE(a->src[s].up == 0 || (a->ks == 3 && a->H % 2 == 0 && a->W % 2 == 0), "sc_conv2d_wgrad_mfma: upsampled source needs ks=3, even H,W");
+  }
+  const WgradPlan pl = plan_wgrad(a->N, a->H, a->W, a->Cout, a->Cin, a->ks);
+  const size_t need = sc_wgrad_workspace_floats(a->N, a->H, a->W, a->Cout, a->Cin, a->ks);
+  SC_REQUIRE(a->part_floats >= need, "sc_conv2d_wgrad_mfma: workspace too small (%zu < %zu floats)", a->part_floats, need);
+  WgradP p;
+  p.dy = to_srcd(a->dy); p.s0 = to_srcd(a->src[0]); p.s1 = a->nsrc == 2 ? to_srcd(a->src[1]) : empty_srcd();
+  p.N = a->N; p.H = a->H; p.W = a->W; p.Cout = a->Cout; p.Cin = a->Cin; p.part = a->part;
+  p.nsl = pl.nsl; p.CoP = pl.CoP; p.CiP = pl.CiP;
+  dim3 grid(pl.nsl, pl.ci_tiles, pl.co_tiles);
+  hipStream_t st = (hipStream_t)stream;
+#define SC_WG(KS, WM, WN) hipLaunchKernelGGL((k_wgrad_mfma<KS, WM, WN>), grid, dim3(256), 0, st, p)
+  if (a->ks == 3) {
+    if (pl.wm == 2 && pl.wn == 2) SC_WG(3, 2, 2);
+    else if (pl.wm == 2) SC_WG(3, 2, 1);
+    else if (pl.wn == 2) SC_WG(3, 1, 2);
+    else SC_WG(3, 1, 1);
+  } else {
+    if (pl.wm == 2 && pl.wn == 2) SC_WG(1, 2, 2);
+    else if (pl.wm == 2) SC_WG(1, 2, 1);
+    else if (pl.wn == 2) SC_WG(1, 1, 2);
+    else SC_WG(1, 1, 1);
+  }
+#undef SC_WG
+  SC_LAUNCH_OK("sc_conv2d_wgrad_mfma");
+  // two-level reduction of the K-slice partials, then the layout change to OIHW
+  const size_t E = (size_t)a->ks * a->ks * pl.CoP * pl.CiP;
+  const int nparts = pl.nsl * pl.wk;
+  const float* rows; int nrows;
+  int rc = sc_reduce_rows_partial(a->part, nparts, E, a->part + (size_t)nparts * E, &rows, &nrows, st);
+  if (rc != SC_OK) return rc;
+  const size_t total = (size_t)a->ks * a->ks * a->Cout * a->Cin;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(256), 0, st, rows, a->dw, nrows, a->ks * a->ks, a->Cout,
+                     a->Cin, pl.CoP, pl.CiP);
+  SC_LAUNCH_OK("sc_wgrad_reduce");
+  return SC_OK;
+}

@@ -1,0 +1,415 @@
+// HBM-bound streaming kernels of the U-Net training/inference step: BatchNorm bookkeeping,
+// residual add, upsample backward, partial-sum reduction, loss, Adam, masks, band ratio.
+// Reference lines are cited at each entry point in include/starcop_hip.h.
+#include <stdarg.h>
+#include <string.h>
+#include "sc_common.h"
+
+// ------------------------------------------------------------------------------------------
+// error plumbing (thread-local message)
+static thread_local char g_err[512] = "";
+void sc_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* sc_last_error(void) { return g_err; }
+extern "C" int sc_version(void) { return 100; }
+extern "C" int sc_device_check(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { sc_set_error("sc_device_check: no HIP device"); return SC_ERR_NODEV; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { sc_set_error("sc_device_check: cannot query device"); return SC_ERR_NODEV; }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    sc_set_error("sc_device_check: device is %s, this library is built for gfx950 only", prop.gcnArchName);
+    return SC_ERR_NODEV;
+  }
+  return SC_OK;
+}
+
+namespace {
+
+template <int NV>
+__device__ __forceinline__ void block_sum_d(double (&v)[NV], double* s_tmp /* [4][NV] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const double s = wave_sum_d(v[k]);
+    if (lane == 0) s_tmp[wave * NV + k] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = s_tmp[k] + s_tmp[NV + k] + s_tmp[2 * NV + k] + s_tmp[3 * NV + k];
+}
+
+// ---------------------------------------------------------------- BatchNorm
+__global__ void k_bn_finalize(const double* __restrict__ stats, double count, const float* __restrict__ gamma,
+                              const float* __restrict__ beta, float* running_mean, float* running_var, float momentum,
+                              float eps, int training, float* __restrict__ cst, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double mean, var;
+  if (training) {
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < SC_STAT_SLOTS; ++k) {
+      s += stats[((size_t)k * C + c) * 2];
+      q += stats[((size_t)k * C + c) * 2 + 1];
+    }
+    mean = s / count;
+    var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+  } else {
+    mean = (double)running_mean[c];
+    var = (double)running_var[c];
+  }
+  const float meanf = (float)mean;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float scale = gamma[c] * invstd;
+  const float shift = beta[c] - meanf * scale;
+  float* o = cst + (size_t)c * SC_CST;
+  o[0] = scale; o[1] = shift; o[2] = meanf; o[3] = invstd; o[4] = 0.f; o[5] = 0.f; o[6] = 0.f; o[7] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ g, const float* __restrict__ y,
+                                                       const float* __restrict__ cst, int act, double* sums, int C, int HW) {
+  __shared__ double s_tmp[8];
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float scale = cst[(size_t)c * SC_CST], shift = cst[(size_t)c * SC_CST + 1];
+  const float mean = cst[(size_t)c * SC_CST + 2], invstd = cst[(size_t)c * SC_CST + 3];
+  const size_t base = ((size_t)n * C + c) * HW;
+  const int start = blockIdx.x * 4096;
+  const int end = min(start + 4096, HW);
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = start + threadIdx.x; i < end; i += 256) {
+    const float yv = y[base + i], gv = g[base + i];
+    const float yh = fmaf(yv, scale, shift);
+    bool pass = true;
+    if (act == SC_ACT_RELU) pass = yh > 0.f;
+    else if (act == SC_ACT_RELU6) pass = (yh > 0.f) && (yh < 6.f);
+    const float gb = pass ? gv : 0.f;
+    s1 += gb;
+    s2 = fmaf(gb, (yv - mean) * invstd, s2);
+  }
+  double v[2] = {(double)s1, (double)s2};
+  block_sum_d<2>(v, s_tmp);
+  if (threadIdx.x < 2) atomicAdd(&sums[((size_t)stat_slot() * C + c) * 2 + threadIdx.x], v[threadIdx.x]);
+}
+
+__global__ void k_bn_bwd_finalize(const double* __restrict__ sums, double count, const float* __restrict__ cst_fwd,
+                                  float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ cst_bwd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < SC_STAT_SLOTS; ++k) {
+    s1 += sums[((size_t)k * C + c) * 2];
+    s2 += sums[((size_t)k * C + c) * 2 + 1];
+  }
+  const double scale = cst_fwd[(size_t)c * SC_CST], mean = cst_fwd[(size_t)c * SC_CST + 2], invstd = cst_fwd[(size_t)c * SC_CST + 3];
+  if (dbeta) dbeta[c] = (float)s1;
+  if (dgamma) dgamma[c] = (float)s2;
+  const double c1 = s1 / count, c2 = s2 / count;
+  float* o = cst_bwd + (size_t)c * SC_CST;
+  o[0] = cst_fwd[(size_t)c * SC_CST];
+  o[1] = cst_fwd[(size_t)c * SC_CST + 1];
+  o[2] = (float)scale;                                         // A
+  o[3] = (float)(-scale * c2 * invstd);                        // B
+  o[4] = (float)(-scale * c1 + scale * c2 * invstd * mean);    // D
+  o[5] = 0.f; o[6] = 0.f; o[7] = 0.f;
+}
+
+// ---------------------------------------------------------------- elementwise over [N][C][HW]
+__device__ __forceinline__ float ld_src(const SrcD& s, size_t idx, float4 c0, float c4) {
+  const float x = s.x[idx];
+  if (s.mode == SC_SRC_RAW) return x;
+  const float au = (s.mode == SC_SRC_BNBWD) ? s.aux[idx] : 0.f;
+  return sc_prologue(s.mode, s.act, x, au, c0, c4);
+}
+
+__global__ __launch_bounds__(256) void k_add_srcs(const SrcD a, const SrcD b, int has_b, float* __restrict__ out, int C, int HW) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), b0 = a0; float a4 = 0.f, b4 = 0.f;
+  if (a.mode != SC_SRC_RAW) { a0 = *reinterpret_cast<const float4*>(a.cst + (size_t)c * SC_CST); a4 = a.cst[(size_t)c * SC_CST + 4]; }
+  if (has_b && b.mode != SC_SRC_RAW) { b0 = *reinterpret_cast<const float4*>(b.cst + (size_t)c * SC_CST); b4 = b.cst[(size_t)c * SC_CST + 4]; }
+  const size_t base = ((size_t)n * C + c) * HW;
+  const int start = blockIdx.x * 2048, end = min(start + 2048, HW);
+  for (int i = start + threadIdx.x; i < end; i += 256) {
+    float v = ld_src(a, base + i, a0, a4);
+    if (has_b) v += ld_src(b, base + i, b0, b4);
+    out[base + i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_downsum2x2(const float* __restrict__ in, float* __restrict__ out, int accum,
+                                                    int Hout, int Wout, size_t total) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wout);
+    size_t r = i / Wout;
+    const int y = (int)(r % Hout);
+    const size_t plane = r / Hout;
+    const float* p = in + (plane * (2 * Hout) + 2 * y) * (size_t)(2 * Wout) + 2 * x;
+    const float2 t0 = *reinterpret_cast<const float2*>(p);
+    const float2 t1 = *reinterpret_cast<const float2*>(p + 2 * Wout);
+    const float s = (t0.x + t0.y) + (t1.x + t1.y);
+    out[i] = accum ? out[i] + s : s;
+  }
+}
+
+__global__ void k_fill_f64(double* p, double v, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// out[r][i] = sum_{k<16} part[16r+k][i]
+__global__ __launch_bounds__(256) void k_reduce16(const float* __restrict__ part, int nparts, size_t E, float* __restrict__ out) {
+  const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+  if (i >= E) return;
+  const int r = blockIdx.y;
+  const int k0 = r * 16, k1 = min(k0 + 16, nparts);
+  float s = 0.f;
+#pragma unroll 16
+  for (int k = k0; k < k1; ++k) s += part[(size_t)k * E + i];
+  out[(size_t)r * E + i] = s;
+}
+
+// ---------------------------------------------------------------- loss / optimiser / masks
+__global__ __launch_bounds__(256) void k_bce(const float* __restrict__ z, const float* __restrict__ t, const float* __restrict__ w,
+                                             float pos_weight, size_t n, float inv_n, double* loss_sum, float* __restrict__ dz,
+                                             float* __restrict__ loss_px) {
+  __shared__ double s_tmp[4];
+  double acc = 0.0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float x = z[i], y = t[i];
+    const float wt = w ? w[i] : 1.f;
+    const float lw = fmaf(pos_weight - 1.f, y, 1.f);
+    const float sp = log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.f);      // softplus(-x)
+    const float l = (1.f - y) * x + lw * sp;
+    if (loss_px) loss_px[i] = l;
+    acc += (double)(l * wt);
+    if (dz) {
+      const float sg = 1.f / (1.f + expf(-x));
+      dz[i] = wt * (lw * sg - pos_weight * y) * inv_n;
+    }
+  }
+  double v[1] = {acc};
+  block_sum_d<1>(v, s_tmp);
+  if (threadIdx.x == 0 && loss_sum) atomicAdd(loss_sum, v[0]);
+}
+
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                                              float wd, float bc1, float bc2s, float gscale, const float* __restrict__ hp) {
+  if (hp) { lr = hp[0]; bc1 = hp[1]; bc2s = hp[2]; }
+  const float step = lr / bc1;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    // torch: exp_avg.lerp_(grad, 1-beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2s + eps;
+    p[i] = pi - step * (mi / denom);
+  }
+}
+
+__global__ void k_adam_prepare(long long* step, const float* lr_dev, float b1, float b2, float* hp) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const long long t = step[0] + 1;
+    step[0] = t;
+    hp[0] = lr_dev[0];
+    hp[1] = (float)(1.0 - pow((double)b1, (double)t));
+    hp[2] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_threshold(const float* __restrict__ z, const float* __restrict__ tgt, int ge0,
+                                                   float* __restrict__ pred, long long* __restrict__ pb,
+                                                   long long* __restrict__ diff, unsigned long long* tile_count, int HW) {
+  __shared__ double s_tmp[4];
+  const int n = blockIdx.y;
+  const size_t base = (size_t)n * HW;
+  const int start = blockIdx.x * 4096, end = min(start + 4096, HW);
+  int cnt = 0;
+  for (int i = start + threadIdx.x; i < end; i += 256) {
+    const float x = z[base + i];
+    const float sg = 1.f / (1.f + expf(-x));
+    const int b = ge0 ? (x >= 0.f) : (sg > 0.5f);
+    if (pred) pred[base + i] = sg;
+    if (pb) pb[base + i] = b;
+    if (diff) diff[base + i] = 2 * b + ((long long)tgt[base + i] == 1 ? 1 : 0);
+    cnt += b;
+  }
+  double v[1] = {(double)cnt};
+  block_sum_d<1>(v, s_tmp);
+  if (threadIdx.x == 0 && tile_count) atomicAdd(&tile_count[n], (unsigned long long)(v[0] + 0.5));
+}
+
+__global__ void k_pred_cls(const long long* __restrict__ cnt, long long* __restrict__ cls, int N, double thr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) cls[i] = ((double)cnt[i] > thr) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_band_ratio(const float* __restrict__ bg, const float* __restrict__ sig,
+                                                    float* __restrict__ out, size_t n, float c, float zero_val) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float b = bg[i], s = sig[i];
+    const float r = (c * s - b) / (b + 1e-6f);
+    out[i] = (s < 1e-6f && b < 1e-6f) ? zero_val : r;
+  }
+}
+
+inline int nblocks(size_t n, int cap = 2048) {
+  size_t b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > (size_t)cap ? cap : b));
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+size_t sc_reduce_scratch_floats(int nparts, size_t E) {
+  size_t tot = 0;
+  int np = nparts;
+  while (np > 1) { np = (np + 15) / 16; tot += (size_t)np * E; }
+  return tot;
+}
+
+int sc_reduce_rows_partial(const float* part, int nparts, size_t E, float* scratch, const float** rows_out, int* nrows_out,
+                           hipStream_t st) {
+  const float* cur = part;
+  int np = nparts;
+  while (np > 16) {
+    const int nn = (np + 15) / 16;
+    hipLaunchKernelGGL(k_reduce16, dim3((unsigned)((E + 255) / 256), nn), dim3(256), 0, st, cur, np, E, scratch);
+    SC_LAUNCH_OK("sc_reduce16");
+    cur = scratch; scratch += (size_t)nn * E; np = nn;
+  }
+  *rows_out = cur; *nrows_out = np;
+  return SC_OK;
+}
+
+int sc_reduce_rows(const float* part, int nparts, size_t E, float* scratch, float* out, hipStream_t st) {
+  const float* cur; int np;
+  int rc = sc_reduce_rows_partial(part, nparts, E, scratch, &cur, &np, st);
+  if (rc != SC_OK) return rc;
+  hipLaunchKernelGGL(k_reduce16, dim3((unsigned)((E + 255) / 256), 1), dim3(256), 0, st, cur, np, E, out);
+  SC_LAUNCH_OK("sc_reduce16(final)");
+  return SC_OK;
+}
+
+extern "C" int sc_bn_finalize(const double* stats, double count, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, float momentum, float eps, int training, float* cst_fwd, int C,
+                              sc_stream stream) {
+  SC_REQUIRE(C > 0 && cst_fwd && gamma && beta && running_mean && running_var, "sc_bn_finalize: null argument");
+  SC_REQUIRE(!training || (stats && count > 0), "sc_bn_finalize: training needs stats and count");
+  hipLaunchKernelGGL(k_bn_finalize, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, count, gamma, beta,
+                     running_mean, running_var, momentum, eps, training, cst_fwd, C);
+  SC_LAUNCH_OK("sc_bn_finalize");
+  return SC_OK;
+}
+
+extern "C" int sc_bn_bwd_reduce(const float* g, const float* y, const float* cst_fwd, int act, double* sums, int N, int C,
+                                int HW, sc_stream stream) {
+  SC_REQUIRE(g && y && cst_fwd && sums && N > 0 && C > 0 && HW > 0, "sc_bn_bwd_reduce: bad argument");
+  dim3 grid((HW + 4095) / 4096, C, N);
+  hipLaunchKernelGGL(k_bn_bwd_reduce, grid, dim3(256), 0, (hipStream_t)stream, g, y, cst_fwd, act, sums, C, HW);
+  SC_LAUNCH_OK("sc_bn_bwd_reduce");
+  return SC_OK;
+}
+
+extern "C" int sc_bn_bwd_finalize(const double* sums, double count, const float* cst_fwd, float* dgamma, float* dbeta,
+                                  float* cst_bwd, int C, sc_stream stream) {
+  SC_REQUIRE(sums && cst_fwd && cst_bwd && C > 0 && count > 0, "sc_bn_bwd_finalize: bad argument");
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, sums, count, cst_fwd,
+                     dgamma, dbeta, cst_bwd, C);
+  SC_LAUNCH_OK("sc_bn_bwd_finalize");
+  return SC_OK;
+}
+
+extern "C" int sc_add_srcs(const sc_src* a, const sc_src* b, float* out, int N, int C, int HW, sc_stream stream) {
+  SC_REQUIRE(a && a->C == C && (!b || b->C == C), "sc_add_srcs: channel mismatch");
+  SC_REQUIRE(a->up == 0 && (!b || b->up == 0), "sc_add_srcs: upsampled sources unsupported");
+  dim3 grid((HW + 2047) / 2048, C, N);
+  hipLaunchKernelGGL(k_add_srcs, grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*a), b ? to_srcd(*b) : empty_srcd(),
+                     b ? 1 : 0, out, C, HW);
+  SC_LAUNCH_OK("sc_add_srcs");
+  return SC_OK;
+}
+
+extern "C" int sc_apply_src(const sc_src* a, float* out, int N, int C, int HW, sc_stream stream) {
+  return sc_add_srcs(a, nullptr, out, N, C, HW, stream);
+}
+
+extern "C" int sc_downsum2x2(const float* in, float* out, int accum, int N, int C, int Hout, int Wout, sc_stream stream) {
+  SC_REQUIRE(in && out && N > 0 && C > 0 && Hout > 0 && Wout > 0, "sc_downsum2x2: bad argument");
+  const size_t total = (size_t)N * C * Hout * Wout;
+  hipLaunchKernelGGL(k_downsum2x2, dim3(nblocks(total, 4096)), dim3(256), 0, (hipStream_t)stream, in, out, accum, Hout, Wout, total);
+  SC_LAUNCH_OK("sc_downsum2x2");
+  return SC_OK;
+}
+
+extern "C" int sc_fill_f64(double* p, double v, size_t n, sc_stream stream) {
+  if (n == 0) return SC_OK;
+  hipLaunchKernelGGL(k_fill_f64, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, p, v, n);
+  SC_LAUNCH_OK("sc_fill_f64");
+  return SC_OK;
+}
+
+extern "C" int sc_bce_logits_weighted(const float* logits, const float* target, const float* weight, float pos_weight,
+                                      size_t n, double* loss_sum, float* dlogits, float* loss_px, sc_stream stream) {
+  SC_REQUIRE(logits && target && n > 0, "sc_bce_logits_weighted: bad argument");
+  hipLaunchKernelGGL(k_bce, dim3(nblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, logits, target, weight, pos_weight, n,
+                     (float)(1.0 / (double)n), loss_sum, dlogits, loss_px);
+  SC_LAUNCH_OK("sc_bce_logits_weighted");
+  return SC_OK;
+}
+
+extern "C" int sc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
+                            float bias_correction2_sqrt, float grad_scale, const float* hp_dev, sc_stream stream) {
+  SC_REQUIRE(param && grad && exp_avg && exp_avg_sq, "sc_adam_step: null argument");
+  if (n == 0) return SC_OK;
+  hipLaunchKernelGGL(k_adam, dim3(nblocks(n, 4096)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
+                     lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2_sqrt, grad_scale, hp_dev);
+  SC_LAUNCH_OK("sc_adam_step");
+  return SC_OK;
+}
+
+extern "C" int sc_adam_prepare(int64_t* step, const float* lr_dev, float beta1, float beta2, float* hp_dev, sc_stream stream) {
+  SC_REQUIRE(step && lr_dev && hp_dev, "sc_adam_prepare: null argument");
+  hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)step, lr_dev, beta1, beta2, hp_dev);
+  SC_LAUNCH_OK("sc_adam_prepare");
+  return SC_OK;
+}
+
+extern "C" int sc_threshold_masks(const float* logits, const float* target, int ge0, float* prediction, int64_t* pred_binary,
+                                  int64_t* differences, int64_t* tile_count, int N, int HW, sc_stream stream) {
+  SC_REQUIRE(logits && N > 0 && HW > 0, "sc_threshold_masks: bad argument");
+  SC_REQUIRE(!differences || target, "sc_threshold_masks: differences need a target");
+  dim3 grid((HW + 4095) / 4096, N);
+  hipLaunchKernelGGL(k_threshold, grid, dim3(256), 0, (hipStream_t)stream, logits, target, ge0, prediction,
+                     (long long*)pred_binary, (long long*)differences, (unsigned long long*)tile_count, HW);
+  SC_LAUNCH_OK("sc_threshold_masks");
+  return SC_OK;
+}
+
+extern "C" int sc_pred_classification(const int64_t* tile_count, int64_t* cls, int N, int H, int W, sc_stream stream) {
+  SC_REQUIRE(tile_count && cls && N > 0, "sc_pred_classification: bad argument");
+  // model_module.py:210-212: n_pixels = (10 * H * W) / 64**2 (float); sum > n_pixels
+  const double thr = (10.0 * (double)H * (double)W) / 4096.0;
+  hipLaunchKernelGGL(k_pred_cls, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const long long*)tile_count,
+                     (long long*)cls, N, thr);
+  SC_LAUNCH_OK("sc_pred_classification");
+  return SC_OK;
+}
+
+extern "C" int sc_band_ratio(const float* background, const float* signal, float* out, size_t n, float c,
+                             float zero_value_out, sc_stream stream) {
+  SC_REQUIRE(background && signal && out && n > 0, "sc_band_ratio: bad argument");
+  hipLaunchKernelGGL(k_band_ratio, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, background, signal, out, n, c, zero_value_out);
+  SC_LAUNCH_OK("sc_band_ratio");
+  return SC_OK;
+}

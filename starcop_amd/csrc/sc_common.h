@@ -1,0 +1,98 @@
+// Shared device/host helpers for libstarcop_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "starcop_hip.h"
+
+void sc_set_error(const char* fmt, ...);
+
+#define SC_REQUIRE(cond, ...)                 \
+  do {                                        \
+    if (!(cond)) {                            \
+      sc_set_error(__VA_ARGS__);              \
+      return SC_ERR_ARG;                      \
+    }                                         \
+  } while (0)
+
+#define SC_LAUNCH_OK(name)                                                        \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) {                                                      \
+      sc_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));        \
+      return SC_ERR_LAUNCH;                                                       \
+    }                                                                             \
+  } while (0)
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// device-side view of sc_src (passed by value inside kernel-argument structs)
+struct SrcD {
+  const float* x;
+  const float* aux;
+  const float* cst;
+  int C, mode, act, up;
+};
+
+static inline SrcD to_srcd(const sc_src& s) {
+  SrcD d;
+  d.x = s.x; d.aux = s.aux; d.cst = s.cst; d.C = s.C; d.mode = s.mode; d.act = s.act; d.up = s.up;
+  return d;
+}
+static inline SrcD empty_srcd() {
+  SrcD d;
+  d.x = nullptr; d.aux = nullptr; d.cst = nullptr; d.C = 0; d.mode = 0; d.act = 0; d.up = 0;
+  return d;
+}
+
+__device__ __forceinline__ float sc_actf(float v, int act) {
+  if (act == SC_ACT_RELU) return fmaxf(v, 0.f);
+  if (act == SC_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+  return v;
+}
+
+// "normalise on load": see enum sc_src_mode in starcop_hip.h
+__device__ __forceinline__ float sc_prologue(int mode, int act, float x, float aux, float4 c0, float c4) {
+  if (mode == SC_SRC_RAW) return x;
+  if (mode == SC_SRC_AFFINE) return sc_actf(fmaf(x, c0.x, c0.y), act);
+  if (mode == SC_SRC_BNBWD) {
+    const float yh = fmaf(aux, c0.x, c0.y);
+    bool pass = true;
+    if (act == SC_ACT_RELU) pass = yh > 0.f;
+    else if (act == SC_ACT_RELU6) pass = (yh > 0.f) && (yh < 6.f);
+    const float gm = pass ? x : 0.f;
+    return fmaf(gm, c0.z, fmaf(aux, c0.w, c4));
+  }
+  // SC_SRC_NORM: clamp((x - off) / fac, lo, hi)   (true division, as the reference does)
+  const float v = (x - c0.x) / c0.y;
+  return fminf(fmaxf(v, c0.z), c0.w);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float half_sum32(float v) {   // sum over the 32 lanes of each half-wave
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// sums nparts rows of E floats (part[k][i]) into out[i]; uses `scratch` (>= sc_reduce_scratch_floats)
+// for the intermediate levels.  Defined in elementwise.hip.
+size_t sc_reduce_scratch_floats(int nparts, size_t E);
+int sc_reduce_rows(const float* part, int nparts, size_t E, float* scratch, float* out, hipStream_t st);
+// like sc_reduce_rows but leaves <= 16 rows for a caller-side final kernel: returns the pointer/row count
+int sc_reduce_rows_partial(const float* part, int nparts, size_t E, float* scratch, const float** rows_out,
+                           int* nrows_out, hipStream_t st);
+
+__device__ __forceinline__ int stat_slot() {
+  return (int)((blockIdx.x + 7u * blockIdx.y + 13u * blockIdx.z) % SC_STAT_SLOTS);
+}

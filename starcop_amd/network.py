@@ -1,0 +1,564 @@
+"""HyperSTARCOP network: the MobileNetV2-encoder U-Net of ``smp.Unet('mobilenet_v2')`` executed
+by hand-written HIP kernels (libstarcop_hip.so) -- forward, backward, eval and train mode.
+
+Reference: ``configure_architecture`` builds ``smp.Unet(encoder_name='mobilenet_v2',
+encoder_weights=None, in_channels=C, classes=1, activation=None)``
+(/root/reference/starcop/models/model_module.py:224-256).  This module keeps
+
+  * the ``state_dict`` key names/shapes of that network (``encoder.features.N...``,
+    ``decoder.blocks.N.convK.M``, ``segmentation_head.0``) so reference checkpoints load,
+  * ordinary ``nn.Parameter`` tensors so ``torch.optim.Adam(network.parameters())`` works
+    (model_module.py:174), ``.train()/.eval()`` BatchNorm semantics, ``.to(device)``.
+
+The ``torch.nn`` sub-modules are parameter containers only: no torch op computes anything on the
+path.  Execution model ("normalise on load"): every convolution stores its RAW output and
+accumulates per-channel sum / sum-of-squares in its epilogue; BatchNorm + ReLU/ReLU6 of a producer
+are applied by the consumer while it stages tiles into LDS, nearest x2 upsampling and the skip
+concat are address arithmetic in the consumer, and the backward pass applies the BatchNorm /
+activation backward the same way (g, y -> dy on load).
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, SC_STAT_SLOTS, SRC_AFFINE, SRC_BNBWD,
+                   SRC_NORM, SRC_RAW, check, make_src, ptr, sc_conv_args, sc_wgrad_args, stream)
+
+MBV2_SETTINGS = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2),
+                 (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1))
+DECODER_CHANNELS = (256, 128, 64, 32, 16)
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter containers (names == smp / torchvision names)
+def _conv_bn_act(cin, cout, k, stride=1, groups=1, act="relu6"):
+    return nn.Sequential(nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, groups=groups, bias=False),
+                         nn.BatchNorm2d(cout, eps=BN_EPS, momentum=BN_MOMENTUM),
+                         nn.ReLU6() if act == "relu6" else nn.ReLU())
+
+
+class _InvertedResidual(nn.Module):
+    def __init__(self, cin, cout, stride, t):
+        super().__init__()
+        hid = cin * t
+        self.use_res_connect = stride == 1 and cin == cout
+        self.stride, self.expand = stride, t != 1
+        layers = []
+        if t != 1:
+            layers.append(_conv_bn_act(cin, hid, 1))
+        layers += [_conv_bn_act(hid, hid, 3, stride, groups=hid),
+                   nn.Conv2d(hid, cout, 1, bias=False),
+                   nn.BatchNorm2d(cout, eps=BN_EPS, momentum=BN_MOMENTUM)]
+        self.conv = nn.Sequential(*layers)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, in_channels):
+        super().__init__()
+        feats = [_conv_bn_act(in_channels, 32, 3, 2)]
+        cin = 32
+        for t, c, n, s in MBV2_SETTINGS:
+            for i in range(n):
+                feats.append(_InvertedResidual(cin, c, s if i == 0 else 1, t))
+                cin = c
+        feats.append(_conv_bn_act(cin, 1280, 1))
+        self.features = nn.Sequential(*feats)
+
+
+class _DecoderBlock(nn.Module):
+    def __init__(self, cin, cskip, cout):
+        super().__init__()
+        self.conv1 = _conv_bn_act(cin + cskip, cout, 3, act="relu")
+        self.conv2 = _conv_bn_act(cout, cout, 3, act="relu")
+
+
+class _Decoder(nn.Module):
+    def __init__(self):
+        super().__init__()
+        cins = (1280,) + DECODER_CHANNELS[:-1]
+        cskips = (96, 32, 24, 16, 0)
+        self.blocks = nn.ModuleList(_DecoderBlock(i, s, o) for i, s, o in zip(cins, cskips, DECODER_CHANNELS))
+
+
+# ----------------------------------------------------------------------------------------------
+class _T:
+    """An activation of the plan.  kind: 'input' | 'raw' (conv output, BN+act applied by readers) | 'fin'."""
+    __slots__ = ("name", "C", "shift", "kind", "bn", "act", "buf", "grad", "cst", "cstb", "stats", "bsums",
+                 "grad_written", "alias_grad_of", "res_grad")
+
+    def __init__(self, name, Cn, shift, kind, bn=None, act=ACT_NONE):
+        self.name, self.C, self.shift, self.kind, self.bn, self.act = name, Cn, shift, kind, bn, act
+        self.buf = self.grad = self.cst = self.cstb = self.stats = self.bsums = None
+        self.grad_written = False
+        self.alias_grad_of = None   # raw-linear tensor whose grad is the grad of the residual sum
+        self.res_grad = None        # 'fin' tensor z = self + ...: z.grad must be added to self.grad
+
+
+def _pick_cot(M):
+    if M <= 32:
+        return 32
+    p32, p64 = -(-M // 32) * 32, -(-M // 64) * 64
+    return 64 if p64 <= p32 * 1.15 else 32
+
+
+class HyperStarcopUNet(nn.Module):
+    """Drop-in for ``ModelModule.network`` (smp.Unet mobilenet_v2), running on libstarcop_hip.so."""
+
+    def __init__(self, in_channels=4, classes=1):
+        super().__init__()
+        if classes != 1:
+            raise ValueError("HyperStarcopUNet: the HIP segmentation head implements classes=1 "
+                             "(starcop/config.yaml:40 num_classes: 1)")
+        if not (1 <= in_channels <= 8):
+            raise ValueError("HyperStarcopUNet: in_channels must be in [1, 8]")
+        self.in_channels = in_channels
+        self.encoder = _Encoder(in_channels)
+        self.decoder = _Decoder()
+        self.segmentation_head = nn.Sequential(nn.Conv2d(DECODER_CHANNELS[-1], classes, 3, padding=1))
+        self.reset_parameters()
+        self._ops, self._tensors = self._build_ops()
+        self._plans = {}
+        self._pflat = self._gflat = None
+        self._pack_version = None
+
+    # -- init conventions of torchvision MobileNetV2 / smp initialize_decoder / initialize_head
+    def reset_parameters(self):
+        for m in self.encoder.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight); nn.init.zeros_(m.bias)
+        if self.in_channels != 3:
+            self.encoder.features[0][0].reset_parameters()
+        for m in self.decoder.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, mode="fan_in", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight); nn.init.zeros_(m.bias)
+        head = self.segmentation_head[0]
+        nn.init.xavier_uniform_(head.weight); nn.init.zeros_(head.bias)
+
+    # ------------------------------------------------------------------------------------------
+    def _build_ops(self):
+        ops, tensors = [], {}
+
+        def T(name, Cn, shift, kind, bn=None, act=ACT_NONE):
+            t = _T(name, Cn, shift, kind, bn, act)
+            tensors[name] = t
+            return t
+
+        x = T("x", self.in_channels, 0, "input")
+        f = self.encoder.features
+        cur = T("f0", 32, 1, "raw", f[0][1], ACT_RELU6)
+        ops.append(dict(type="stem", conv=f[0][0], ins=[x], out=cur))
+        skips = {}
+        for idx in range(1, 18):
+            blk = f[idx]
+            cin_t = cur
+            seq = blk.conv
+            j = 0
+            h = cur
+            if blk.expand:
+                e = T(f"f{idx}e", seq[0][0].out_channels, cur.shift, "raw", seq[0][1], ACT_RELU6)
+                ops.append(dict(type="pw", conv=seq[0][0], ins=[h], out=e))
+                h, j = e, 1
+            sh = h.shift + (1 if blk.stride == 2 else 0)
+            d = T(f"f{idx}d", seq[j][0].out_channels, sh, "raw", seq[j][1], ACT_RELU6)
+            ops.append(dict(type="dw", conv=seq[j][0], stride=blk.stride, ins=[h], out=d))
+            p = T(f"f{idx}p", seq[j + 1].out_channels, sh, "raw", seq[j + 2], ACT_NONE)
+            ops.append(dict(type="pw", conv=seq[j + 1], ins=[d], out=p))
+            if blk.use_res_connect:
+                z = T(f"f{idx}", p.C, sh, "fin")
+                ops.append(dict(type="add", ins=[cin_t, p], out=z))
+                cur = z
+            else:
+                cur = p
+            if idx in (1, 3, 6, 13):
+                skips[idx] = cur
+        last = T("f18", 1280, cur.shift, "raw", f[18][1], ACT_RELU6)
+        ops.append(dict(type="pw", conv=f[18][0], ins=[cur], out=last))
+        cur = last
+        skip_list = [skips[13], skips[6], skips[3], skips[1], None]
+        for b, blk in enumerate(self.decoder.blocks):
+            sh = cur.shift - 1
+            ins = [cur] + ([skip_list[b]] if skip_list[b] is not None else [])
+            o1 = T(f"d{b}a", blk.conv1[0].out_channels, sh, "raw", blk.conv1[1], ACT_RELU)
+            ops.append(dict(type="conv3", conv=blk.conv1[0], ins=ins, up=True, out=o1))
+            o2 = T(f"d{b}b", blk.conv2[0].out_channels, sh, "raw", blk.conv2[1], ACT_RELU)
+            ops.append(dict(type="conv3", conv=blk.conv2[0], ins=[o1], up=False, out=o2))
+            cur = o2
+        logits = T("logits", 1, 0, "fin")
+        ops.append(dict(type="head", conv=self.segmentation_head[0], ins=[cur], out=logits))
+        return ops, tensors
+
+    # ------------------------------------------------------------------------------------------
+    # flat parameter / gradient storage (one fused Adam pass, one RCCL all-reduce)
+    def _ensure_flat(self):
+        params = list(self.parameters())
+        dev = params[0].device
+        ok = self._pflat is not None and self._pflat.device == dev
+        if ok:
+            off = 0
+            base = self._pflat.data_ptr()
+            for p in params:
+                if p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
+                    ok = False
+                    break
+                off += p.numel()
+        if not ok:
+            total = sum(p.numel() for p in params)
+            flat = torch.empty(total, dtype=torch.float32, device=dev)
+            off = 0
+            for p in params:
+                n = p.numel()
+                flat[off:off + n].copy_(p.data.reshape(-1).float())
+                p.data = flat[off:off + n].view(p.shape)
+                off += n
+            self._pflat = flat
+            self._gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+            self._pack_version = None
+            self._plans = {}
+        return params
+
+    def mark_parameters_changed(self):
+        """Call after modifying parameters through raw pointers (fused Adam): packed filters are stale."""
+        self._pack_version = None
+
+    def flat_parameters(self):
+        self._ensure_flat()
+        return self._pflat
+
+    def flat_grads(self):
+        self._ensure_flat()
+        return self._gflat
+
+    def _grad_view(self, p):
+        off = (p.data_ptr() - self._pflat.data_ptr()) // 4
+        return self._gflat[off:off + p.numel()].view(p.shape)
+
+    # ------------------------------------------------------------------------------------------
+    class _Plan:
+        pass
+
+    def _get_plan(self, N, H, W, need_grad):
+        key = (N, H, W)
+        plan = self._plans.get(key)
+        dev = self._pflat.device
+        if plan is None:
+            plan = HyperStarcopUNet._Plan()
+            plan.N, plan.H, plan.W = N, H, W
+            plan.buf, plan.grad = {}, {}
+            f32 = dict(dtype=torch.float32, device=dev)
+            n_bn_ch = sum(t.C for t in self._tensors.values() if t.bn is not None)
+            plan.stats = torch.zeros(n_bn_ch * SC_STAT_SLOTS * 2, dtype=torch.float64, device=dev)
+            plan.bsums = torch.zeros(n_bn_ch * SC_STAT_SLOTS * 2, dtype=torch.float64, device=dev)
+            plan.cst, plan.cstb, plan.stats_v, plan.bsums_v = {}, {}, {}, {}
+            off = 0
+            for t in self._tensors.values():
+                if t.kind != "input":
+                    plan.buf[t.name] = torch.empty((N, t.C, H >> t.shift, W >> t.shift), **f32)
+                if t.bn is not None:
+                    n = t.C * SC_STAT_SLOTS * 2
+                    plan.stats_v[t.name] = plan.stats[off:off + n]
+                    plan.bsums_v[t.name] = plan.bsums[off:off + n]
+                    off += n
+                    plan.cst[t.name] = torch.zeros((t.C, SC_CST), **f32)
+                    plan.cstb[t.name] = torch.zeros((t.C, SC_CST), **f32)
+            plan.has_grad = False
+            self._plans[key] = plan
+        if need_grad and not plan.has_grad:
+            lib = _lib.load()
+            f32 = dict(dtype=torch.float32, device=dev)
+            ws, up = 0, 0
+            n_dw = 0
+            for op in self._ops:
+                o = op["out"]
+                Ho, Wo = H >> o.shift, W >> o.shift
+                if op["type"] != "head" and o.kind != "fin":
+                    plan.grad[o.name] = torch.empty((N, o.C, Ho, Wo), **f32)
+                if op["type"] == "add":
+                    plan.grad[o.name] = torch.empty((N, o.C, Ho, Wo), **f32)
+                conv = op.get("conv")
+                if op["type"] in ("pw", "conv3"):
+                    ws = max(ws, lib.sc_wgrad_workspace_floats(N, Ho, Wo, conv.out_channels, conv.in_channels,
+                                                               conv.kernel_size[0]))
+                    if op.get("up"):
+                        up = max(up, N * op["ins"][0].C * Ho * Wo)
+                elif op["type"] == "stem":
+                    ws = max(ws, lib.sc_stem_wgrad_workspace_floats(N, conv.in_channels, H, W))
+                elif op["type"] == "head":
+                    ws = max(ws, lib.sc_head_wgrad_workspace_floats(N, conv.in_channels, Ho, Wo))
+                elif op["type"] == "dw":
+                    n_dw += conv.out_channels * 9
+            plan.ws = torch.empty(ws, **f32)
+            plan.ws_floats = ws
+            plan.up_tmp = torch.empty(max(up, 1), **f32)
+            plan.dw_acc = torch.zeros(n_dw, dtype=torch.float64, device=dev)
+            plan.dlogits = torch.empty((N, 1, H, W), **f32)
+            plan.has_grad = True
+        return plan
+
+    # ------------------------------------------------------------------------------------------
+    def _pack_all(self, need_bwd):
+        """(Re)pack conv filters into the MFMA kernels' layouts when the parameters changed."""
+        lib = _lib.load()
+        ver = tuple(p._version for p in self.parameters())
+        pv = self._pack_version
+        if pv is not None and pv[0] == ver and (pv[1] or not need_bwd):
+            return
+        st = stream()
+        dev = self._pflat.device
+        if not hasattr(self, "_wpk"):
+            self._wpk = {}
+        for i, op in enumerate(self._ops):
+            if op["type"] not in ("pw", "conv3"):
+                continue
+            conv = op["conv"]
+            co, ci, ks = conv.out_channels, conv.in_channels, conv.kernel_size[0]
+            ent = self._wpk.get(i)
+            if ent is None or ent["f"].device != dev:
+                cf, cb = _pick_cot(co), _pick_cot(ci)
+                ent = dict(cot_f=cf, cot_b=cb,
+                           f=torch.empty(lib.sc_packed_weight_floats(co, ci, ks, cf, 0), dtype=torch.float32, device=dev),
+                           b=torch.empty(lib.sc_packed_weight_floats(co, ci, ks, cb, 1), dtype=torch.float32, device=dev))
+                self._wpk[i] = ent
+            check(lib.sc_pack_weights(ptr(conv.weight), ptr(ent["f"]), co, ci, ks, ent["cot_f"], 0, st))
+            if need_bwd:
+                check(lib.sc_pack_weights(ptr(conv.weight), ptr(ent["b"]), co, ci, ks, ent["cot_b"], 1, st))
+        self._pack_version = (ver, bool(need_bwd))
+
+    # ------------------------------------------------------------------------------------------
+    def _src_of(self, plan, t, up=0, x_cst=None):
+        if t.kind == "input":
+            if x_cst is None:
+                return make_src(plan.buf["x"], t.C, SRC_RAW)
+            return make_src(plan.buf["x"], t.C, SRC_NORM, cst=x_cst)
+        if t.kind == "raw":
+            return make_src(plan.buf[t.name], t.C, SRC_AFFINE, act=t.act, up=up, cst=plan.cst[t.name])
+        return make_src(plan.buf[t.name], t.C, SRC_RAW, up=up)
+
+    def _dy_src(self, plan, t):
+        return make_src(plan.grad[t.name], t.C, SRC_BNBWD, act=t.act, cst=plan.cstb[t.name], aux=plan.buf[t.name])
+
+    def _forward_impl(self, x, x_cst, training, need_grad):
+        """x: (N,C,H,W) fp32 device tensor (raw physical units if x_cst is given, else already normalised)."""
+        _lib.require_device(x)
+        lib = _lib.load()
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise ValueError(f"HyperStarcopUNet: expected (N,{self.in_channels},H,W) input, got {tuple(x.shape)}")
+        N, _, H, W = x.shape
+        if H % 32 or W % 32:
+            raise RuntimeError(f"Wrong input shape height={H}, width={W}. Expected image height and width "
+                               "divisible by 32.")
+        self._ensure_flat()
+        x = x.contiguous().float()
+        plan = self._get_plan(N, H, W, need_grad)
+        plan.buf["x"] = x
+        plan.x_cst = x_cst
+        self._pack_all(need_grad)
+        st = stream()
+        if training:
+            plan.stats.zero_()
+        for i, op in enumerate(self._ops):
+            ty, o = op["type"], op["out"]
+            Ho, Wo = H >> o.shift, W >> o.shift
+            stats = ptr(plan.stats_v[o.name]) if (training and o.bn is not None) else None
+            conv = op.get("conv")
+            if ty == "stem":
+                s = self._src_of(plan, op["ins"][0], x_cst=x_cst)
+                check(lib.sc_stem_conv_fwd(C.byref(s), ptr(conv.weight), ptr(plan.buf[o.name]), N, conv.in_channels,
+                                           H, W, stats, st))
+            elif ty == "dw":
+                tin = op["ins"][0]
+                s = self._src_of(plan, tin)
+                check(lib.sc_dwconv3x3_fwd(C.byref(s), ptr(conv.weight), ptr(plan.buf[o.name]), N, o.C,
+                                           H >> tin.shift, W >> tin.shift, op["stride"], stats, st))
+            elif ty in ("pw", "conv3"):
+                a = sc_conv_args()
+                ins = op["ins"]
+                a.nsrc = len(ins)
+                a.src[0] = self._src_of(plan, ins[0], up=1 if op.get("up") else 0)
+                if len(ins) == 2:
+                    a.src[1] = self._src_of(plan, ins[1])
+                ent = self._wpk[i]
+                a.wpk = ent["f"].data_ptr()
+                a.N, a.H, a.W, a.Cout = N, Ho, Wo, o.C
+                a.ks, a.co_t = conv.kernel_size[0], ent["cot_f"]
+                a.out0 = plan.buf[o.name].data_ptr(); a.out1 = None
+                a.csplit, a.accum0, a.accum1 = o.C, 0, 0
+                a.add0 = None; a.add1 = None
+                a.stats = plan.stats_v[o.name].data_ptr() if stats is not None else None
+                check(lib.sc_conv2d_mfma(C.byref(a), st))
+            elif ty == "add":
+                sa = self._src_of(plan, op["ins"][0])
+                sb = self._src_of(plan, op["ins"][1])
+                check(lib.sc_add_srcs(C.byref(sa), C.byref(sb), ptr(plan.buf[o.name]), N, o.C, Ho * Wo, st))
+            elif ty == "head":
+                s = self._src_of(plan, op["ins"][0])
+                check(lib.sc_head_conv_fwd(C.byref(s), ptr(conv.weight), ptr(conv.bias), ptr(plan.buf[o.name]),
+                                           N, conv.in_channels, Ho, Wo, st))
+            if o.bn is not None:
+                bn = o.bn
+                check(lib.sc_bn_finalize(stats, float(N * Ho * Wo), ptr(bn.weight), ptr(bn.bias),
+                                         ptr(bn.running_mean), ptr(bn.running_var), float(bn.momentum), float(bn.eps),
+                                         1 if training else 0, ptr(plan.cst[o.name]), o.C, st))
+                if training:
+                    bn.num_batches_tracked.add_(1)
+        plan.training = training
+        return plan
+
+    def _backward_impl(self, plan, dlogits):
+        """Fills the flat gradient buffer from dL/dlogits.  Needs the plan of a training-mode forward."""
+        lib = _lib.load()
+        st = stream()
+        N, H, W = plan.N, plan.H, plan.W
+        if not getattr(plan, "training", False):
+            raise RuntimeError("HyperStarcopUNet.backward: gradients need a train-mode forward (BatchNorm batch "
+                               "statistics); call .train() first")
+        dlogits = dlogits.contiguous()
+        plan.bsums.zero_()
+        plan.dw_acc.zero_()
+        written = set()
+        res_of = {}       # tensor name -> name of the residual sum z (z = t + ...)
+        for op in self._ops:
+            if op["type"] == "add":
+                res_of[op["ins"][0].name] = op["out"].name
+        gv = self._grad_view
+        dw_off = 0
+        dw_offs = {}
+        for i, op in enumerate(self._ops):
+            if op["type"] == "dw":
+                dw_offs[i] = dw_off
+                dw_off += op["conv"].out_channels * 9
+
+        def bn_backward(t):
+            Ho, Wo = H >> t.shift, W >> t.shift
+            check(lib.sc_bn_bwd_reduce(ptr(plan.grad[t.name]), ptr(plan.buf[t.name]), ptr(plan.cst[t.name]), t.act,
+                                       ptr(plan.bsums_v[t.name]), N, t.C, Ho * Wo, st))
+            check(lib.sc_bn_bwd_finalize(ptr(plan.bsums_v[t.name]), float(N * Ho * Wo), ptr(plan.cst[t.name]),
+                                         ptr(gv(t.bn.weight)), ptr(gv(t.bn.bias)), ptr(plan.cstb[t.name]), t.C, st))
+
+        for i in range(len(self._ops) - 1, -1, -1):
+            op = self._ops[i]
+            ty, o = op["type"], op["out"]
+            Ho, Wo = H >> o.shift, W >> o.shift
+            conv = op.get("conv")
+            if ty == "head":
+                tin = op["ins"][0]
+                s = self._src_of(plan, tin)
+                check(lib.sc_head_conv_wgrad(ptr(dlogits), C.byref(s), ptr(plan.ws), plan.ws_floats, ptr(gv(conv.weight)),
+                                             ptr(gv(conv.bias)), N, conv.in_channels, Ho, Wo, st))
+                check(lib.sc_head_conv_dgrad(ptr(dlogits), ptr(conv.weight), ptr(plan.grad[tin.name]), N,
+                                             conv.in_channels, Ho, Wo, st))
+                written.add(tin.name)
+                continue
+            if ty == "add":
+                # z = a + BN(p): dL/d(BN(p)) = dL/dz (alias); a receives dL/dz through its expand-conv dgrad epilogue
+                p_t = op["ins"][1]
+                plan.grad[p_t.name] = plan.grad[o.name]
+                written.add(p_t.name)
+                continue
+            bn_backward(o)
+            dy = self._dy_src(plan, o)
+            if ty == "stem":
+                s = self._src_of(plan, op["ins"][0], x_cst=plan.x_cst)
+                check(lib.sc_stem_conv_wgrad(C.byref(dy), C.byref(s), ptr(plan.ws), plan.ws_floats, ptr(gv(conv.weight)),
+                                             N, conv.in_channels, H, W, st))
+                continue
+            if ty == "dw":
+                tin = op["ins"][0]
+                Hi, Wi = H >> tin.shift, W >> tin.shift
+                s = self._src_of(plan, tin)
+                acc = plan.dw_acc[dw_offs[i]:dw_offs[i] + o.C * 9]
+                check(lib.sc_dwconv3x3_wgrad(C.byref(dy), C.byref(s), ptr(acc), N, o.C, Hi, Wi, op["stride"], st))
+                check(lib.sc_cast_f64_f32(ptr(acc), ptr(gv(conv.weight)), o.C * 9, st))
+                check(lib.sc_dwconv3x3_dgrad(C.byref(dy), ptr(conv.weight), ptr(plan.grad[tin.name]),
+                                             1 if tin.name in written else 0, N, o.C, Hi, Wi, op["stride"], st))
+                written.add(tin.name)
+                continue
+            # pw / conv3 : weight gradient
+            ins = op["ins"]
+            ks = conv.kernel_size[0]
+            wa = sc_wgrad_args()
+            wa.dy = dy
+            wa.nsrc = len(ins)
+            wa.src[0] = self._src_of(plan, ins[0], up=1 if op.get("up") else 0)
+            if len(ins) == 2:
+                wa.src[1] = self._src_of(plan, ins[1])
+            wa.N, wa.H, wa.W, wa.Cout, wa.Cin, wa.ks = N, Ho, Wo, o.C, conv.in_channels, ks
+            wa.part = plan.ws.data_ptr(); wa.part_floats = plan.ws_floats
+            wa.dw = gv(conv.weight).data_ptr()
+            check(lib.sc_conv2d_wgrad_mfma(C.byref(wa), st))
+            # data gradient
+            if ins[0].kind == "input":
+                continue
+            ent = self._wpk[i]
+            a = sc_conv_args()
+            a.nsrc = 1
+            a.src[0] = dy
+            a.wpk = ent["b"].data_ptr()
+            a.N, a.H, a.W, a.Cout = N, Ho, Wo, conv.in_channels
+            a.ks, a.co_t = ks, ent["cot_b"]
+            a.add0 = None; a.add1 = None; a.stats = None
+            a.accum0 = a.accum1 = 0
+            if op.get("up"):
+                t_up = ins[0]
+                a.out0 = plan.up_tmp.data_ptr()
+                a.csplit = t_up.C
+                if len(ins) == 2:
+                    t_sk = ins[1]
+                    a.out1 = plan.grad[t_sk.name].data_ptr()
+                    a.accum1 = 1 if t_sk.name in written else 0
+                    written.add(t_sk.name)
+                else:
+                    a.out1 = None
+                check(lib.sc_conv2d_mfma(C.byref(a), st))
+                check(lib.sc_downsum2x2(ptr(plan.up_tmp), ptr(plan.grad[t_up.name]), 1 if t_up.name in written else 0,
+                                        N, t_up.C, Ho // 2, Wo // 2, st))
+                written.add(t_up.name)
+            else:
+                tin = ins[0]
+                a.out0 = plan.grad[tin.name].data_ptr(); a.out1 = None
+                a.csplit = conv.in_channels
+                a.accum0 = 1 if tin.name in written else 0
+                z = res_of.get(tin.name)
+                if z is not None:
+                    a.add0 = plan.grad[z].data_ptr()
+                check(lib.sc_conv2d_mfma(C.byref(a), st))
+                written.add(tin.name)
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, x, normalizer_consts=None):
+        """(B,C,H,W) -> (B,1,H,W) logits.  ``normalizer_consts`` (C,8) fuses DataNormalizer.normalize_x into the stem."""
+        need_grad = torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters())
+        if need_grad:
+            self._ensure_flat()
+            return _UNetFunction.apply(self, x, normalizer_consts, *list(self.parameters()))
+        plan = self._forward_impl(x, normalizer_consts, self.training, False)
+        return plan.buf["logits"].clone()
+
+
+class _UNetFunction(torch.autograd.Function):
+    """Whole-network autograd node: backward runs the HIP backward pass into the flat grad buffer."""
+
+    @staticmethod
+    def forward(ctx, net, x, x_cst, *params):
+        plan = net._forward_impl(x, x_cst, True, True)
+        ctx.net, ctx.plan = net, plan
+        return plan.buf["logits"].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        net, plan = ctx.net, ctx.plan
+        net._backward_impl(plan, g.float())
+        grads = []
+        for p in net.parameters():
+            gv = net._grad_view(p)
+            if p.grad is not None and p.grad.data_ptr() == gv.data_ptr():
+                gv = gv.clone()     # caller is accumulating gradients across steps
+            grads.append(gv)
+        return (None, None, None) + tuple(grads)

@@ -1,0 +1,79 @@
+"""Fused Adam for the HIP network: one kernel over the flat parameter / gradient / moment buffers.
+
+Replaces ``torch.optim.Adam(self.network.parameters(), self.lr)`` (reference model_module.py:174; torch
+defaults betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False).  It *is* a ``torch.optim.Adam`` (so
+``ReduceLROnPlateau``, Lightning and ``state_dict()`` treat it as one; the per-parameter ``exp_avg`` /
+``exp_avg_sq`` state entries are views of the flat buffers) whose ``step()`` launches ``sc_adam_step``.
+Bias corrections and the learning rate live in device memory (``sc_adam_prepare``) so that a captured
+hipGraph of the training step replays correctly while the step count and the scheduler's lr change.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream
+
+
+class FusedAdam(torch.optim.Adam):
+    def __init__(self, network, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.network = network
+        params = network._ensure_flat()
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        flat = network.flat_parameters()
+        self._m = torch.zeros_like(flat)
+        self._v = torch.zeros_like(flat)
+        self._step_dev = torch.zeros(1, dtype=torch.int64, device=flat.device)
+        self._lr_dev = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        self._hp_dev = torch.zeros(4, dtype=torch.float32, device=flat.device)
+        self._lr_host = None
+        self._flat_ptr = flat.data_ptr()
+        off = 0
+        for p in params:
+            n = p.numel()
+            self.state[p] = {"step": self._step_dev.view(()),   # shared scalar step (tensor, like capturable Adam)
+                             "exp_avg": self._m[off:off + n].view(p.shape),
+                             "exp_avg_sq": self._v[off:off + n].view(p.shape)}
+            off += n
+
+    def _sync_lr(self):
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_host:
+            self._lr_dev.fill_(lr)
+            self._lr_host = lr
+
+    @torch.no_grad()
+    def step_flat(self, grad_scale=1.0):
+        """Adam update straight from the network's flat gradient buffer."""
+        net = self.network
+        flat = net.flat_parameters()
+        if flat.data_ptr() != self._flat_ptr:
+            raise RuntimeError("FusedAdam: the network's parameter storage moved (e.g. .to(device) after the optimiser "
+                               "was built); create the optimiser after moving the module")
+        g = net.flat_grads()
+        lib = _lib.load()
+        grp = self.param_groups[0]
+        b1, b2 = grp["betas"]
+        self._sync_lr()
+        st = stream()
+        check(lib.sc_adam_prepare(ptr(self._step_dev), ptr(self._lr_dev), float(b1), float(b2), ptr(self._hp_dev), st))
+        check(lib.sc_adam_step(ptr(flat), ptr(g), ptr(self._m), ptr(self._v), flat.numel(), 0.0, float(b1), float(b2),
+                               float(grp["eps"]), float(grp["weight_decay"]), 1.0, 1.0, float(grad_scale),
+                               ptr(self._hp_dev), st))
+        net.mark_parameters_changed()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        net = self.network
+        net._ensure_flat()
+        # gradients normally already live in the flat buffer (the autograd node returns views of it)
+        for p in net.parameters():
+            gv = net._grad_view(p)
+            if p.grad is None:
+                gv.zero_()
+            elif p.grad.data_ptr() != gv.data_ptr():
+                gv.copy_(p.grad)
+        self.step_flat()
+        return loss

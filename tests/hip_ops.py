@@ -1,0 +1,72 @@
+"""Thin test-side helpers that call the C ABI (include/starcop_hip.h) for single ops."""
+import ctypes as C
+
+import torch
+
+from starcop_amd import _lib
+from starcop_amd._lib import (ACT_NONE, SC_CST, SC_STAT_SLOTS, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, check,
+                              make_src, ptr, sc_conv_args, sc_wgrad_args, stream)
+
+DEV = "cuda"
+
+
+def cst_affine(scale, shift):
+    c = torch.zeros(scale.numel(), SC_CST, device=DEV)
+    c[:, 0], c[:, 1] = scale.to(DEV), shift.to(DEV)
+    return c
+
+
+def pack(w, co_t, tflip):
+    lib = _lib.load()
+    co, ci, ks = w.shape[0], w.shape[1], w.shape[2]
+    out = torch.empty(lib.sc_packed_weight_floats(co, ci, ks, co_t, tflip), device=DEV)
+    check(lib.sc_pack_weights(ptr(w), ptr(out), co, ci, ks, co_t, tflip, stream()))
+    return out
+
+
+def conv_mfma(srcs, wpk, N, H, W, Cout, ks, co_t, want_stats=False, csplit=None, add0=None, add1=None,
+              accum=None, outs=None):
+    lib = _lib.load()
+    a = sc_conv_args()
+    a.nsrc = len(srcs)
+    for i, s in enumerate(srcs):
+        a.src[i] = s
+    a.wpk = wpk.data_ptr()
+    a.N, a.H, a.W, a.Cout, a.ks, a.co_t = N, H, W, Cout, ks, co_t
+    csplit = Cout if csplit is None else csplit
+    if outs is None:
+        outs = [torch.empty(N, csplit, H, W, device=DEV)]
+        if csplit < Cout:
+            outs.append(torch.empty(N, Cout - csplit, H, W, device=DEV))
+    a.out0 = outs[0].data_ptr()
+    a.out1 = outs[1].data_ptr() if len(outs) > 1 else None
+    a.csplit = csplit
+    a.accum0, a.accum1 = (accum or (0, 0))
+    a.add0 = add0.data_ptr() if add0 is not None else None
+    a.add1 = add1.data_ptr() if add1 is not None else None
+    stats = torch.zeros(SC_STAT_SLOTS, Cout, 2, dtype=torch.float64, device=DEV) if want_stats else None
+    a.stats = stats.data_ptr() if want_stats else None
+    check(lib.sc_conv2d_mfma(C.byref(a), stream()))
+    return outs, stats
+
+
+def wgrad_mfma(dy, srcs, N, H, W, Cout, Cin, ks):
+    lib = _lib.load()
+    a = sc_wgrad_args()
+    a.dy = dy
+    a.nsrc = len(srcs)
+    for i, s in enumerate(srcs):
+        a.src[i] = s
+    a.N, a.H, a.W, a.Cout, a.Cin, a.ks = N, H, W, Cout, Cin, ks
+    n = lib.sc_wgrad_workspace_floats(N, H, W, Cout, Cin, ks)
+    ws = torch.empty(n, device=DEV)
+    a.part, a.part_floats = ws.data_ptr(), n
+    dw = torch.empty(Cout, Cin, ks, ks, device=DEV)
+    a.dw = dw.data_ptr()
+    check(lib.sc_conv2d_wgrad_mfma(C.byref(a), stream()))
+    return dw
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-3))

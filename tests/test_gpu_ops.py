@@ -1,0 +1,295 @@
+"""Per-kernel parity: every HIP op, called through the C ABI, against plain torch fp32 CPU ops on the
+same seeded inputs (tolerance 1e-4 relative to the max magnitude unless stated; integer outputs bit-exact)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from hip_ops import (DEV, conv_mfma, cst_affine, pack, relerr, wgrad_mfma)  # noqa: E402
+from starcop_amd import _lib  # noqa: E402
+from starcop_amd._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, SC_STAT_SLOTS, SRC_AFFINE, SRC_BNBWD, SRC_NORM,
+                              SRC_RAW, check, make_src, ptr, stream)  # noqa: E402
+
+TOL = 1e-4
+
+
+def act_ref(v, act):
+    return v if act == ACT_NONE else (F.relu(v) if act == ACT_RELU else F.relu6(v))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("ks,cin,cout,co_t,H,W", [
+    (3, 16, 16, 32, 32, 32), (3, 32, 64, 64, 32, 64), (3, 24, 96, 32, 12, 40), (3, 64, 40, 64, 36, 32),
+    (1, 16, 96, 32, 16, 16), (1, 96, 24, 32, 24, 20), (1, 160, 128, 64, 16, 16), (1, 24, 144, 32, 10, 13)])
+def test_conv_mfma_fwd_affine_stats(hip, ks, cin, cout, co_t, H, W):
+    N = 2
+    x, w = rnd(N, cin, H, W, seed=1), rnd(cout, cin, ks, ks, seed=2, scale=0.2)
+    sc, sh = rnd(cin, seed=3) * 0.5 + 1.0, rnd(cin, seed=4) * 0.3
+    act = ACT_RELU6
+    ref = F.conv2d(act_ref(x * sc[None, :, None, None] + sh[None, :, None, None], act), w, padding=ks // 2)
+    xd, wd = x.to(DEV), w.to(DEV)
+    src = make_src(xd, cin, SRC_AFFINE, act=act, cst=cst_affine(sc, sh))
+    (out,), stats = conv_mfma([src], pack(wd, co_t, 0), N, H, W, cout, ks, co_t, want_stats=True)
+    assert relerr(out, ref) < TOL
+    st = stats.sum(0).cpu()
+    assert relerr(st[:, 0], ref.double().sum((0, 2, 3))) < 1e-4
+    assert relerr(st[:, 1], (ref.double() ** 2).sum((0, 2, 3))) < 1e-4
+
+
+def test_conv_mfma_upsample_concat(hip):
+    """decoder conv1: input = cat(nearest_up2(prev), skip) (smp DecoderBlock.forward)."""
+    N, c0, c1, cout, H, W = 2, 24, 8, 48, 16, 64
+    prev, skip = rnd(N, c0, H // 2, W // 2, seed=1), rnd(N, c1, H, W, seed=2)
+    w = rnd(cout, c0 + c1, 3, 3, seed=3, scale=0.1)
+    sc0, sh0 = rnd(c0, seed=4) * 0.3 + 1, rnd(c0, seed=5) * 0.2
+    xin = torch.cat([F.interpolate(F.relu(prev * sc0[None, :, None, None] + sh0[None, :, None, None]),
+                                   scale_factor=2, mode="nearest"), skip], 1)
+    ref = F.conv2d(xin, w, padding=1)
+    s0 = make_src(prev.to(DEV), c0, SRC_AFFINE, act=ACT_RELU, up=1, cst=cst_affine(sc0, sh0))
+    s1 = make_src(skip.to(DEV), c1, SRC_RAW)
+    (out,), _ = conv_mfma([s0, s1], pack(w.to(DEV), 32, 0), N, H, W, cout, 3, 32)
+    assert relerr(out, ref) < TOL
+
+
+@pytest.mark.parametrize("ks,cin,cout,H,W", [(3, 32, 16, 32, 32), (3, 80, 32, 16, 32), (1, 96, 16, 16, 16), (1, 24, 144, 8, 16)])
+def test_conv_dgrad_bnbwd_split_add(hip, ks, cin, cout, H, W):
+    """backward-data = same kernel on the transposed+flipped filter; dy formed on load from (g, y)."""
+    N = 2
+    g, y = rnd(N, cout, H, W, seed=1), rnd(N, cout, H, W, seed=2)
+    w = rnd(cout, cin, ks, ks, seed=3, scale=0.2)
+    a, b = rnd(cout, seed=4) * 0.2 + 1, rnd(cout, seed=5) * 0.2
+    A, B, D = rnd(cout, seed=6), rnd(cout, seed=7) * 0.1, rnd(cout, seed=8) * 0.1
+    yh = y * a[None, :, None, None] + b[None, :, None, None]
+    dy = torch.where(yh > 0, g, torch.zeros(())) * A[None, :, None, None] + B[None, :, None, None] * y + D[None, :, None, None]
+    ref = F.conv_transpose2d(dy, w, padding=ks // 2)
+    cst = torch.zeros(cout, SC_CST); cst[:, 0], cst[:, 1], cst[:, 2], cst[:, 3], cst[:, 4] = a, b, A, B, D
+    src = make_src(g.to(DEV), cout, SRC_BNBWD, act=ACT_RELU, cst=cst.to(DEV), aux=y.to(DEV))
+    co_t = 32 if cin <= 32 else 64
+    wpk = pack(w.to(DEV), co_t, 1)
+    (out,), _ = conv_mfma([src], wpk, N, H, W, cin, ks, co_t)
+    assert relerr(out, ref) < TOL
+    # epilogue adds + accumulate
+    add0, old = rnd(N, cin, H, W, seed=9), rnd(N, cin, H, W, seed=10)
+    o = old.to(DEV).clone()
+    conv_mfma([src], wpk, N, H, W, cin, ks, co_t, add0=add0.to(DEV), accum=(1, 0), outs=[o])
+    assert relerr(o, ref + add0 + old) < TOL
+    # channel split
+    cs = cin // 2 if (cin // 2) % 8 == 0 else 8
+    outs, _ = conv_mfma([src], wpk, N, H, W, cin, ks, co_t, csplit=cs)
+    assert relerr(outs[0], ref[:, :cs]) < TOL and relerr(outs[1], ref[:, cs:]) < TOL
+
+
+@pytest.mark.parametrize("ks,cin,cout,H,W,two", [(3, 16, 16, 32, 32, False), (3, 32, 64, 16, 32, True), (3, 80, 48, 20, 36, True),
+                                                  (3, 64, 16, 8, 64, False), (1, 96, 24, 16, 16, False), (1, 24, 144, 16, 24, False),
+                                                  (1, 160, 320, 8, 8, False)])
+def test_conv_wgrad(hip, ks, cin, cout, H, W, two):
+    N = 3
+    g, y = rnd(N, cout, H, W, seed=1), rnd(N, cout, H, W, seed=2)
+    a, b = rnd(cout, seed=4) * 0.2 + 1, rnd(cout, seed=5) * 0.2
+    A, B, D = rnd(cout, seed=6), rnd(cout, seed=7) * 0.1, rnd(cout, seed=8) * 0.1
+    yh = y * a[None, :, None, None] + b[None, :, None, None]
+    dy = torch.where((yh > 0) & (yh < 6), g, torch.zeros(())) * A[None, :, None, None] + B[None, :, None, None] * y + D[None, :, None, None]
+    cst = torch.zeros(cout, SC_CST); cst[:, 0], cst[:, 1], cst[:, 2], cst[:, 3], cst[:, 4] = a, b, A, B, D
+    dys = make_src(g.to(DEV), cout, SRC_BNBWD, act=ACT_RELU6, cst=cst.to(DEV), aux=y.to(DEV))
+    if two:
+        c0 = cin - 8
+        prev, skip = rnd(N, c0, H // 2, W // 2, seed=11), rnd(N, 8, H, W, seed=12)
+        sc0, sh0 = rnd(c0, seed=13) * 0.3 + 1, rnd(c0, seed=14) * 0.2
+        xin = torch.cat([F.interpolate(F.relu(prev * sc0[None, :, None, None] + sh0[None, :, None, None]), scale_factor=2), skip], 1)
+        srcs = [make_src(prev.to(DEV), c0, SRC_AFFINE, act=ACT_RELU, up=1, cst=cst_affine(sc0, sh0)), make_src(skip.to(DEV), 8, SRC_RAW)]
+    else:
+        xin = rnd(N, cin, H, W, seed=11)
+        srcs = [make_src(xin.to(DEV), cin, SRC_RAW)]
+    xin = xin.clone().requires_grad_(False)
+    w = torch.zeros(cout, cin, ks, ks, requires_grad=True)
+    F.conv2d(xin, w, padding=ks // 2).backward(dy)
+    dw = wgrad_mfma(dys, srcs, N, H, W, cout, cin, ks)
+    assert relerr(dw, w.grad) < TOL
+
+
+@pytest.mark.parametrize("C_,H,W,stride", [(32, 32, 32, 1), (24, 20, 28, 2), (96, 16, 16, 2), (40, 7, 9, 1)])
+def test_depthwise(hip, C_, H, W, stride):
+    N = 2
+    x, w = rnd(N, C_, H, W, seed=1), rnd(C_, 1, 3, 3, seed=2, scale=0.3)
+    sc, sh = rnd(C_, seed=3) * 0.3 + 1, rnd(C_, seed=4) * 0.2
+    xa = F.relu6(x * sc[None, :, None, None] + sh[None, :, None, None]).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv2d(xa, wr, stride=stride, padding=1, groups=C_)
+    Ho, Wo = ref.shape[-2:]
+    lib = hip
+    src = make_src(x.to(DEV), C_, SRC_AFFINE, act=ACT_RELU6, cst=cst_affine(sc, sh))
+    out = torch.empty(N, C_, Ho, Wo, device=DEV)
+    stats = torch.zeros(SC_STAT_SLOTS, C_, 2, dtype=torch.float64, device=DEV)
+    wd = w.to(DEV)
+    check(lib.sc_dwconv3x3_fwd(C.byref(src), ptr(wd), ptr(out), N, C_, H, W, stride, ptr(stats), stream()))
+    assert relerr(out, ref) < TOL
+    assert relerr(stats.sum(0)[:, 0], ref.double().sum((0, 2, 3))) < 1e-4
+    dy = rnd(N, C_, Ho, Wo, seed=5)
+    ref.backward(dy)
+    dys = make_src(dy.to(DEV), C_, SRC_RAW)
+    dx = torch.empty(N, C_, H, W, device=DEV)
+    check(lib.sc_dwconv3x3_dgrad(C.byref(dys), ptr(wd), ptr(dx), 0, N, C_, H, W, stride, stream()))
+    assert relerr(dx, xa.grad) < TOL
+    acc = torch.zeros(C_ * 9, dtype=torch.float64, device=DEV)
+    check(lib.sc_dwconv3x3_wgrad(C.byref(dys), C.byref(src), ptr(acc), N, C_, H, W, stride, stream()))
+    assert relerr(acc.reshape(C_, 1, 3, 3), wr.grad) < TOL
+
+
+def test_stem_fused_normalizer(hip):
+    """stem conv reads raw products and applies clamp((x-off)/fac, lo, hi) on load (normalizer_module.py:134)."""
+    N, Cin, H, W = 2, 4, 64, 96
+    x = rnd(N, Cin, H, W, seed=1).abs() * torch.tensor([1500., 60., 60., 60.])[None, :, None, None]
+    w = rnd(32, Cin, 3, 3, seed=2, scale=0.3)
+    cst = torch.zeros(Cin, SC_CST)
+    cst[:, 0], cst[:, 1], cst[:, 2], cst[:, 3] = 0., torch.tensor([1750., 60., 60., 60.]), 0., 2.
+    xn = torch.clamp((x - 0) / cst[:, 1][None, :, None, None], 0, 2)
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv2d(xn, wr, stride=2, padding=1)
+    src = make_src(x.to(DEV), Cin, SRC_NORM, cst=cst.to(DEV))
+    out = torch.empty(N, 32, H // 2, W // 2, device=DEV)
+    stats = torch.zeros(SC_STAT_SLOTS, 32, 2, dtype=torch.float64, device=DEV)
+    check(hip.sc_stem_conv_fwd(C.byref(src), ptr(w.to(DEV)), ptr(out), N, Cin, H, W, ptr(stats), stream()))
+    assert relerr(out, ref) < TOL
+    assert relerr(stats.sum(0)[:, 1], (ref.double() ** 2).sum((0, 2, 3))) < 1e-4
+    dy = rnd(N, 32, H // 2, W // 2, seed=3)
+    ref.backward(dy)
+    n = hip.sc_stem_wgrad_workspace_floats(N, Cin, H, W)
+    ws, dw = torch.empty(n, device=DEV), torch.empty(32, Cin, 3, 3, device=DEV)
+    dys = make_src(dy.to(DEV), 32, SRC_RAW)
+    check(hip.sc_stem_conv_wgrad(C.byref(dys), C.byref(src), ptr(ws), n, ptr(dw), N, Cin, H, W, stream()))
+    assert relerr(dw, wr.grad) < TOL
+
+
+def test_head(hip):
+    N, Cin, H, W = 2, 16, 40, 72
+    x, w, b = rnd(N, Cin, H, W, seed=1), rnd(1, Cin, 3, 3, seed=2, scale=0.3), torch.tensor([0.37])
+    sc, sh = rnd(Cin, seed=3) * 0.3 + 1, rnd(Cin, seed=4) * 0.2
+    xa = F.relu(x * sc[None, :, None, None] + sh[None, :, None, None]).requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(xa, wr, br, padding=1)
+    src = make_src(x.to(DEV), Cin, SRC_AFFINE, act=ACT_RELU, cst=cst_affine(sc, sh))
+    out = torch.empty(N, 1, H, W, device=DEV)
+    wd = w.to(DEV)
+    check(hip.sc_head_conv_fwd(C.byref(src), ptr(wd), ptr(b.to(DEV)), ptr(out), N, Cin, H, W, stream()))
+    assert relerr(out, ref) < TOL
+    dl = rnd(N, 1, H, W, seed=5)
+    ref.backward(dl)
+    dld = dl.to(DEV)
+    gin = torch.empty(N, Cin, H, W, device=DEV)
+    check(hip.sc_head_conv_dgrad(ptr(dld), ptr(wd), ptr(gin), N, Cin, H, W, stream()))
+    assert relerr(gin, xa.grad) < TOL
+    n = hip.sc_head_wgrad_workspace_floats(N, Cin, H, W)
+    ws, dw, db = torch.empty(n, device=DEV), torch.empty(1, Cin, 3, 3, device=DEV), torch.empty(1, device=DEV)
+    check(hip.sc_head_conv_wgrad(ptr(dld), C.byref(src), ptr(ws), n, ptr(dw), ptr(db), N, Cin, H, W, stream()))
+    assert relerr(dw, wr.grad) < TOL and relerr(db, br.grad) < TOL
+
+
+def test_batchnorm_bookkeeping(hip):
+    """bn_finalize / bn_bwd_reduce / bn_bwd_finalize + the BNBWD prologue == autograd of F.batch_norm + relu6."""
+    N, C_, H, W = 3, 24, 16, 20
+    y = (rnd(N, C_, H, W, seed=1) * 2 + 1.5).requires_grad_(True)
+    gamma, beta = (rnd(C_, seed=2) * 0.2 + 1).requires_grad_(True), (rnd(C_, seed=3) * 0.5 + 1.0).requires_grad_(True)
+    rm, rv = torch.zeros(C_), torch.ones(C_)
+    z = F.relu6(F.batch_norm(y, rm, rv, gamma, beta, True, 0.1, 1e-5))
+    g = rnd(N, C_, H, W, seed=4)
+    z.backward(g)
+    yd = y.detach().to(DEV)
+    stats = torch.zeros(SC_STAT_SLOTS, C_, 2, dtype=torch.float64, device=DEV)
+    stats[3, :, 0] = yd.double().sum((0, 2, 3)); stats[7, :, 1] = (yd.double() ** 2).sum((0, 2, 3))
+    rmd, rvd = torch.zeros(C_, device=DEV), torch.ones(C_, device=DEV)
+    cst = torch.zeros(C_, SC_CST, device=DEV)
+    cnt = float(N * H * W)
+    check(hip.sc_bn_finalize(ptr(stats), cnt, ptr(gamma.detach().to(DEV)), ptr(beta.detach().to(DEV)), ptr(rmd), ptr(rvd),
+                             0.1, 1e-5, 1, ptr(cst), C_, stream()))
+    assert relerr(rmd, rm) < 1e-5 and relerr(rvd, rv) < 1e-5
+    src = make_src(yd, C_, SRC_AFFINE, act=ACT_RELU6, cst=cst)
+    zz = torch.empty_like(yd)
+    check(hip.sc_apply_src(C.byref(src), ptr(zz), N, C_, H * W, stream()))
+    assert relerr(zz, z) < 1e-5
+    sums = torch.zeros(SC_STAT_SLOTS, C_, 2, dtype=torch.float64, device=DEV)
+    gd = g.to(DEV)
+    check(hip.sc_bn_bwd_reduce(ptr(gd), ptr(yd), ptr(cst), ACT_RELU6, ptr(sums), N, C_, H * W, stream()))
+    dgm, dbt, cstb = torch.empty(C_, device=DEV), torch.empty(C_, device=DEV), torch.zeros(C_, SC_CST, device=DEV)
+    check(hip.sc_bn_bwd_finalize(ptr(sums), cnt, ptr(cst), ptr(dgm), ptr(dbt), ptr(cstb), C_, stream()))
+    assert relerr(dgm, gamma.grad) < TOL and relerr(dbt, beta.grad) < TOL
+    dsrc = make_src(gd, C_, SRC_BNBWD, act=ACT_RELU6, cst=cstb, aux=yd)
+    dyd = torch.empty_like(yd)
+    check(hip.sc_apply_src(C.byref(dsrc), ptr(dyd), N, C_, H * W, stream()))
+    assert relerr(dyd, y.grad) < TOL
+
+
+def test_downsum_and_add(hip):
+    N, C_, H, W = 2, 12, 8, 10
+    x = rnd(N, C_, 2 * H, 2 * W, seed=1)
+    ref = F.avg_pool2d(x, 2) * 4
+    out = torch.empty(N, C_, H, W, device=DEV)
+    check(hip.sc_downsum2x2(ptr(x.to(DEV)), ptr(out), 0, N, C_, H, W, stream()))
+    assert relerr(out, ref) < 1e-6
+    a, b = rnd(N, C_, H, W, seed=2), rnd(N, C_, H, W, seed=3)
+    sc, sh = rnd(C_, seed=4), rnd(C_, seed=5)
+    sa = make_src(a.to(DEV), C_, SRC_RAW)
+    sb = make_src(b.to(DEV), C_, SRC_AFFINE, act=ACT_NONE, cst=cst_affine(sc, sh))
+    o2 = torch.empty(N, C_, H, W, device=DEV)
+    check(hip.sc_add_srcs(C.byref(sa), C.byref(sb), ptr(o2), N, C_, H * W, stream()))
+    assert relerr(o2, a + b * sc[None, :, None, None] + sh[None, :, None, None]) < 1e-6
+
+
+def test_bce_loss_and_grad(hip):
+    n = 5000
+    z, t, w = (rnd(n, seed=1) * 3).requires_grad_(True), (rnd(n, seed=2) > 0.5).float(), rnd(n, seed=3).abs().clamp(0.1, 1)
+    for pw in (1.0, 15.0):
+        z.grad = None
+        l = F.binary_cross_entropy_with_logits(z, t, pos_weight=torch.tensor(pw), reduction="none")
+        (l * w).mean().backward()
+        acc = torch.zeros(1, dtype=torch.float64, device=DEV)
+        dz, px = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+        check(hip.sc_bce_logits_weighted(ptr(z.detach().to(DEV)), ptr(t.to(DEV)), ptr(w.to(DEV)), pw, n, ptr(acc), ptr(dz), ptr(px), stream()))
+        assert relerr(px, l) < 1e-5
+        assert abs(float(acc) / n - float((l * w).mean())) < 1e-5 * max(1.0, float((l * w).mean()))
+        assert relerr(dz, z.grad) < 1e-5
+
+
+def test_adam_matches_torch(hip):
+    n = 4097
+    p0, grads = rnd(n, seed=1), [rnd(n, seed=10 + i) for i in range(4)]
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-2)
+    p, m, v = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    step, lr_d, hp = torch.zeros(1, dtype=torch.int64, device=DEV), torch.full((1,), 1e-2, device=DEV), torch.zeros(4, device=DEV)
+    for g in grads:
+        pr.grad = g.clone(); opt.step()
+        check(hip.sc_adam_prepare(ptr(step), ptr(lr_d), 0.9, 0.999, ptr(hp), stream()))
+        check(hip.sc_adam_step(ptr(p), ptr(g.to(DEV)), ptr(m), ptr(v), n, 0.0, 0.9, 0.999, 1e-8, 0.0, 1.0, 1.0, 1.0, ptr(hp), stream()))
+    assert int(step) == 4
+    assert relerr(p, pr) < 1e-5
+
+
+def test_masks_bit_exact(hip):
+    """pred_binary / differences / pred_classification are integer outputs: bit-exact incl. ties (logit == 0,
+    count == threshold)."""
+    B, H, W = 3, 64, 64        # threshold = 10*64*64/64^2 = 10 pixels
+    z = rnd(B, 1, H, W, seed=1)
+    z[0] = -1.0; z[0, 0, 0, :10] = 1.0            # exactly 10 positives  -> NOT a plume tile (strict >)
+    z[1] = -1.0; z[1, 0, 0, :11] = 1.0            # 11 positives -> plume tile
+    z[2, 0, 0, :5] = 0.0                          # logit == 0: ">= 0" true, "sigmoid > .5" false
+    t = (rnd(B, 1, H, W, seed=2) > 0.3).float()
+    for ge0 in (0, 1):
+        pred = torch.empty(B, 1, H, W, device=DEV)
+        pb = torch.empty(B, 1, H, W, dtype=torch.int64, device=DEV)
+        df = torch.empty(B, 1, H, W, dtype=torch.int64, device=DEV)
+        cnt, cls = torch.zeros(B, dtype=torch.int64, device=DEV), torch.empty(B, dtype=torch.int64, device=DEV)
+        check(hip.sc_threshold_masks(ptr(z.to(DEV)), ptr(t.to(DEV)), ge0, ptr(pred), ptr(pb), ptr(df), ptr(cnt), B, H * W, stream()))
+        check(hip.sc_pred_classification(ptr(cnt), ptr(cls), B, H, W, stream()))
+        rb = (z >= 0).long() if ge0 else (torch.sigmoid(z) > .5).long()
+        assert torch.equal(pb.cpu(), rb)
+        assert torch.equal(df.cpu(), 2 * rb + (t.long() == 1).long())
+        assert torch.equal(cls.cpu(), (rb.sum((-1, -2)) > 10 * H * W / 64 ** 2).long().reshape(-1))
+        assert relerr(pred, torch.sigmoid(z)) < 1e-6
+    assert cls.cpu().tolist()[:2] == [0, 1]

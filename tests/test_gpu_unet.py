@@ -1,0 +1,144 @@
+"""Whole-network parity of the HIP HyperSTARCOP U-Net against the CPU oracle (oracle/unet_ref.py, plain torch
+fp32) on identical seeded tiles and weights: eval logits, train-mode (batch-stat BatchNorm) logits + running stats,
+parameter gradients, one fused Adam step, and the bit-exact masks.  Tolerance: 1e-4 relative to max |ref| for
+logits (BASELINE.json north_star), 1e-3 for gradients (SURVEY 8d parity gates)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from hip_ops import DEV, relerr  # noqa: E402
+from oracle.unet_ref import UnetMobileNetV2  # noqa: E402
+from starcop_amd import model_module as mm  # noqa: E402
+
+
+def synth_batch(B, H, W, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    mag = (torch.randn(B, 1, H, W, generator=g) * 400).clamp(0, 10000)
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    for b in range(0, B, 2):
+        mag[b, 0] += 2000 * torch.exp(-((yy - H / 2) ** 2 + (xx - W / 3) ** 2) / (2 * (H / 10) ** 2))
+    rgb = torch.rand(B, 3, H, W, generator=g) * 105 + 5
+    x = torch.cat([mag, rgb], 1)
+    y = (mag > 500).float()
+    w = (mag / 400).clamp(0.1, 1)
+    return {"input": x, "output": y, "weight_loss": w, "has_plume": (y.sum((1, 2, 3)) > 0).long(), "id": list(range(B))}
+
+
+def make_pair(seed=0, pos_weight=1.0, warm=True):
+    torch.manual_seed(seed)
+    model = mm.ModelModule(mm.default_settings(pos_weight=pos_weight))
+    ref = UnetMobileNetV2(4, 1)
+    ref.load_state_dict(model.network.state_dict())
+    if warm:   # non-trivial BN statistics / affine parameters
+        g = torch.Generator().manual_seed(seed + 1)
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+                m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+                m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+        model.network.load_state_dict(ref.state_dict())
+    return model.to(DEV), ref
+
+
+def ref_normalize(x):
+    fac = torch.tensor([1750., 60., 60., 60.])[None, :, None, None]
+    return torch.clamp(x / fac, 0, 2)
+
+
+def to_dev(b):
+    return {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()}
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 96, 160)])
+def test_eval_logits_and_masks(hip, B, H, W):
+    model, ref = make_pair()
+    model.eval(); ref.eval()
+    batch = synth_batch(B, H, W)
+    with torch.no_grad():
+        want = ref(ref_normalize(batch["input"]))
+        got = model(batch["input"].to(DEV))
+    assert relerr(got, want) < 1e-4
+    out = model.batch_with_preds(to_dev(batch))
+    near = (want.abs() < 1e-3)          # pixels where fp32 noise could legitimately flip the sign
+    pb_ref = (torch.sigmoid(want) > .5).long()
+    assert torch.equal(out["pred_binary"].cpu()[~near], pb_ref[~near])
+    assert relerr(out["input_norm"], ref_normalize(batch["input"])) < 1e-6
+    if int(near.sum()) == 0:
+        assert torch.equal(out["differences"].cpu(), 2 * pb_ref + (batch["output"] == 1).long())
+        assert torch.equal(out["pred_classification"].cpu(), (pb_ref.sum((-1, -2)) > 10 * H * W / 64 ** 2).long())
+
+
+def test_train_forward_backward_and_adam(hip):
+    B, H, W = 3, 64, 96
+    model, ref = make_pair(seed=3, pos_weight=1.0)
+    model.train(); ref.train()
+    batch = synth_batch(B, H, W, seed=5)
+    # ---- oracle: training_step semantics (model_module.py:69-88) + torch Adam
+    opt_ref = torch.optim.Adam(ref.parameters(), lr=1e-4)
+    logits_ref = ref(ref_normalize(batch["input"]))
+    loss_ref = (F.binary_cross_entropy_with_logits(logits_ref, batch["output"], pos_weight=torch.tensor(1.0), reduction="none")
+                * batch["weight_loss"]).mean()
+    opt_ref.zero_grad(); loss_ref.backward()
+    grads_ref = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    # ---- HIP: autograd path (what Lightning drives)
+    opt = model.configure_optimizers()["optimizer"]
+    loss = model.training_step(to_dev(batch), 0)
+    assert abs(float(loss) - float(loss_ref)) < 1e-4 * max(1.0, abs(float(loss_ref)))
+    logits = model.network._plans[(B, H, W)].buf["logits"]
+    assert relerr(logits, logits_ref) < 1e-4
+    opt.zero_grad(); loss.backward()
+    worst = 0.0
+    for k, p in model.network.named_parameters():
+        e = relerr(p.grad, grads_ref[k])
+        worst = max(worst, e)
+        assert e < 1e-3, f"gradient of {k}: rel err {e}"
+    # running statistics after one train-mode forward
+    sd, sdr = model.network.state_dict(), ref.state_dict()
+    for k in sd:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert relerr(sd[k], sdr[k]) < 1e-4, k
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(sdr[k]) == 1
+    # ---- optimiser step
+    opt_ref.step(); opt.step()
+    for k, p in model.network.named_parameters():
+        assert relerr(p, dict(ref.named_parameters())[k]) < 1e-5, k
+    print("worst grad rel err", worst)
+
+
+def test_fused_train_step_equals_autograd_path(hip):
+    """fused_train_step (no autograd graph, hipGraph-capturable) == training_step + backward + optimizer.step."""
+    B, H, W = 2, 64, 64
+    model_a, _ = make_pair(seed=7)
+    model_b = copy.deepcopy(model_a)
+    batch = to_dev(synth_batch(B, H, W, seed=9))
+    model_a.train(); model_b.train()
+    opt_a = model_a.configure_optimizers()["optimizer"]
+    for i in range(2):
+        loss = model_a.training_step(batch, i)
+        opt_a.zero_grad(); loss.backward(); opt_a.step()
+    opt_b = model_b.configure_optimizers()["optimizer"]
+    for i in range(2):
+        acc = model_b.fused_train_step(batch, opt_b)
+    assert abs(float(acc) / (B * H * W) - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+    for (k, pa), (_, pb) in zip(model_a.network.named_parameters(), model_b.network.named_parameters()):
+        assert relerr(pa, pb) < 1e-5, k
+
+
+def test_predict_odd_size(hip):
+    """predict(): reflect-pad to x32, forward, crop (padding.py:13-50) on a non-multiple-of-32 scene."""
+    model, ref = make_pair(seed=11)
+    model.eval(); ref.eval()
+    x = synth_batch(1, 70, 90, seed=2)["input"][0].numpy()
+    got = model.predict(x)
+    pad = np.pad(x, ((0, 0), (13, 13), (3, 3)), "reflect")
+    with torch.no_grad():
+        want = torch.sigmoid(ref(ref_normalize(torch.from_numpy(pad)[None])))[0, 0, 13:-13, 3:-3]
+    assert got.shape == (70, 90)
+    assert relerr(torch.from_numpy(got), want) < 1e-4
