@@ -1,0 +1,181 @@
+"""bench.py -- 512x512 hyperspectral tiles/s of the HyperSTARCOP train step (fwd + loss + bwd + Adam).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): the 4-channel (mag1c + RGB) MobileNetV2 U-Net, batch 16 per GPU, fp32,
+synthetic seeded tiles resident in HBM, random-init weights.  A step is exactly ModelModule.training_step +
+backward + Adam.step (reference model_module.py:69-88,172-185), executed by the HIP kernels with no autograd
+graph.  One JSON line on rank 0; see DESIGN.md "Measurement" for the roofline / cpu_baseline definitions.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def synth_batch(B, H, W, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    mag = (torch.randn(B, 1, H, W, generator=g) * 400).clamp(0, 10000)
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    for b in range(0, B, 2):     # planted Gaussian-blob plume in half of the tiles
+        cy, cx = float(torch.rand(1, generator=g)) * H, float(torch.rand(1, generator=g)) * W
+        mag[b, 0] += 2000 * torch.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * 20.0 ** 2))
+    ph = torch.rand(4, 3, generator=g) * 6.28
+    rgb = torch.zeros(B, 3, H, W)
+    for k in range(4):           # smooth field: sum of low-frequency cosines, spans the normaliser clip range
+        rgb += torch.cos(yy[None, None] * (k + 1) * 6.28 / H + ph[k][None, :, None, None]) * torch.cos(xx[None, None] * (k + 1) * 6.28 / W)
+    rgb = 57.5 + rgb * 13.0
+    x = torch.cat([mag, rgb], 1).float()
+    y = (mag > 500).float()
+    w = (mag / 400).clamp(0.1, 1)
+    return {"input": x.to(device), "output": y.to(device), "weight_loss": w.to(device)}
+
+
+def cpu_baseline(budget_s=25.0):
+    """The reference's CPU path (oracle restatement, torch CPU ops) timed on this box's host cores."""
+    import torch.nn.functional as F
+    from oracle.unet_ref import UnetMobileNetV2      # baseline leg only
+    torch.manual_seed(0)
+    B, H, W = 4, 512, 512
+    net = UnetMobileNetV2(4, 1).train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    b = synth_batch(B, H, W, 99, "cpu")
+    fac = torch.tensor([1750., 60., 60., 60.])[None, :, None, None]
+
+    def step():
+        logits = net(torch.clamp(b["input"] / fac, 0, 2))
+        loss = (F.binary_cross_entropy_with_logits(logits, b["output"], reduction="none") * b["weight_loss"]).mean()
+        opt.zero_grad(); loss.backward(); opt.step()
+
+    step()                                            # warm-up
+    t0 = time.perf_counter(); n = 0
+    while True:
+        step(); n += 1
+        if time.perf_counter() - t0 > budget_s * 0.6 or n >= 8:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(B * n / dt, 4), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} train steps of batch {B} x 4ch 512x512 fp32 (oracle/unet_ref.py + torch.optim.Adam) after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="tiles per GPU (weak scaling)")
+    ap.add_argument("--tile", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from starcop_amd import model_module as mm
+    from starcop_amd.parallel import GradSync
+    torch.manual_seed(1234)                               # identical init on every rank
+    model = mm.ModelModule(mm.default_settings(pos_weight=1)).to(dev).train()
+    opt = model.configure_optimizers()["optimizer"]
+    B, T = args.batch, args.tile
+    batch = synth_batch(B, T, T, 1234 + rank, dev)
+    sync = GradSync(world) if world > 1 else None
+    net = model.network
+
+    def step():
+        return model.fused_train_step(batch, opt, grad_sync=sync)
+
+    # ---- warm-up (also builds the plan); optionally capture the step into a hipGraph
+    graph = None
+    n_eager = max(1, min(2, args.warmup)) if args.graph else args.warmup
+    for _ in range(n_eager):
+        step()
+    torch.cuda.synchronize()
+    if args.graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            torch.cuda.synchronize()
+        except Exception as e:       # capture is an optimisation of launch overhead, never a correctness path
+            if rank == 0:
+                print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+    run = (graph.replay if graph is not None else step)
+    for _ in range(max(0, args.warmup - n_eager)):
+        run()
+
+    # ---- timed region
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(net._plans[(B, T, T)].loss_acc.item()) / (B * T * T)
+
+    # ---- roofline of the dominant kernel family, measured live with events on the launch stream (eager, instrumented)
+    roof = None
+    if rank == 0:
+        net.profile = {}
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        prof = net.collect_profile()
+        net.profile = None
+        fam = max(prof, key=lambda k: prof[k]["ms"])
+        tot_ms = sum(v["ms"] for v in prof.values())
+        d = prof[fam]
+        ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
+        roof = {"kernel": fam, "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": d["n"] // 3, "avg_launch_ms": round(d["ms"] / d["n"], 4),
+                "share_of_step_gpu_time": round(d["ms"] / tot_ms, 3),
+                "families_ms_per_step": {k: round(v["ms"] / 3, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}
+
+    if rank == 0:
+        tiles = world * B * args.steps
+        out = {"metric": "512x512 hyperspectral tiles/sec (train fwd+bwd)", "value": round(tiles / elapsed, 2), "unit": "tiles/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "configs[1]: HyperSTARCOP U-Net (smp.Unet mobilenet_v2, 4ch mag1c+RGB) train step "
+                                      "fwd+loss+bwd+Adam, 512x512 tiles, fp32 HIP kernels",
+                          "batch_per_gpu": B, "global_batch": B * world, "tile": [4, T, T],
+                          "parallelism": f"dp{world}", "hipgraph": graph is not None, "final_loss": round(loss, 6)},
+               "roofline": roof}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

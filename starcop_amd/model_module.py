@@ -115,12 +115,19 @@ class HipBCEWithLogitsLoss(torch.nn.Module):
         self.register_buffer("pos_weight", pos_weight.detach().clone() if isinstance(pos_weight, torch.Tensor)
                              else torch.tensor(float(pos_weight)))
 
+    def pos_weight_host(self):
+        """host copy of pos_weight, refreshed only when the buffer changes (no device sync per step)."""
+        key = (self.pos_weight._version, self.pos_weight.data_ptr())
+        if getattr(self, "_pw_key", None) != key:
+            self._pw_val, self._pw_key = float(self.pos_weight), key
+        return self._pw_val
+
     def forward(self, logits, target):
-        return _BCEFunction.apply(logits, target, None, float(self.pos_weight), self.reduction == "mean")
+        return _BCEFunction.apply(logits, target, None, self.pos_weight_host(), self.reduction == "mean")
 
     def weighted_mean(self, logits, target, weight):
         """mean(loss_none(logits, target) * weight) in one pass (model_module.py:76-79)."""
-        return _BCEFunction.apply(logits, target, weight, float(self.pos_weight), True)
+        return _BCEFunction.apply(logits, target, weight, self.pos_weight_host(), True)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -366,7 +373,7 @@ class ModelModule(_Base):
         if not hasattr(plan, "loss_acc"):
             plan.loss_acc = torch.zeros(1, dtype=torch.float64, device=x.device)
         plan.loss_acc.zero_()
-        check(lib.sc_bce_logits_weighted(ptr(logits), ptr(y), ptr(w), float(self.pos_weight), logits.numel(),
+        check(lib.sc_bce_logits_weighted(ptr(logits), ptr(y), ptr(w), self.loss_function.pos_weight_host(), logits.numel(),
                                          ptr(plan.loss_acc), ptr(plan.dlogits), None, stream()))
         net._backward_impl(plan, plan.dlogits)
         scale = 1.0

@@ -224,6 +224,28 @@ class HyperStarcopUNet(nn.Module):
             self._plans = {}
         return params
 
+    # -- optional per-kernel-family timing (bench.py roofline): events on the launch stream
+    profile = None
+
+    def _pb(self, fam, flop=0.0):
+        if self.profile is None:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return (fam, flop, e0, e1)
+
+    def _pe(self, tok):
+        if tok is not None:
+            tok[3].record()
+            self.profile.setdefault(tok[0], []).append(tok)
+
+    def collect_profile(self):
+        torch.cuda.synchronize()
+        out = {}
+        for fam, toks in (self.profile or {}).items():
+            out[fam] = {"ms": sum(t[2].elapsed_time(t[3]) for t in toks), "flop": sum(t[1] for t in toks), "n": len(toks)}
+        return out
+
     def mark_parameters_changed(self):
         """Call after modifying parameters through raw pointers (fused Adam): packed filters are stale."""
         self._pack_version = None
@@ -368,6 +390,13 @@ class HyperStarcopUNet(nn.Module):
             Ho, Wo = H >> o.shift, W >> o.shift
             stats = ptr(plan.stats_v[o.name]) if (training and o.bn is not None) else None
             conv = op.get("conv")
+            tok = None
+            if self.profile is not None:
+                if ty in ("pw", "conv3"):
+                    tok = self._pb(f"k_conv_mfma<{conv.kernel_size[0]}> (fwd+dgrad)",
+                                   2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * conv.kernel_size[0] ** 2)
+                else:
+                    tok = self._pb({"stem": "k_stem_*", "dw": "k_dw_*", "head": "k_head_*", "add": "elementwise/bn"}[ty])
             if ty == "stem":
                 s = self._src_of(plan, op["ins"][0], x_cst=x_cst)
                 check(lib.sc_stem_conv_fwd(C.byref(s), ptr(conv.weight), ptr(plan.buf[o.name]), N, conv.in_channels,
@@ -401,6 +430,7 @@ class HyperStarcopUNet(nn.Module):
                 s = self._src_of(plan, op["ins"][0])
                 check(lib.sc_head_conv_fwd(C.byref(s), ptr(conv.weight), ptr(conv.bias), ptr(plan.buf[o.name]),
                                            N, conv.in_channels, Ho, Wo, st))
+            self._pe(tok)
             if o.bn is not None:
                 bn = o.bn
                 check(lib.sc_bn_finalize(stats, float(N * Ho * Wo), ptr(bn.weight), ptr(bn.bias),
@@ -450,10 +480,12 @@ class HyperStarcopUNet(nn.Module):
             if ty == "head":
                 tin = op["ins"][0]
                 s = self._src_of(plan, tin)
+                tok = self._pb("k_head_*")
                 check(lib.sc_head_conv_wgrad(ptr(dlogits), C.byref(s), ptr(plan.ws), plan.ws_floats, ptr(gv(conv.weight)),
                                              ptr(gv(conv.bias)), N, conv.in_channels, Ho, Wo, st))
                 check(lib.sc_head_conv_dgrad(ptr(dlogits), ptr(conv.weight), ptr(plan.grad[tin.name]), N,
                                              conv.in_channels, Ho, Wo, st))
+                self._pe(tok)
                 written.add(tin.name)
                 continue
             if ty == "add":
@@ -462,22 +494,28 @@ class HyperStarcopUNet(nn.Module):
                 plan.grad[p_t.name] = plan.grad[o.name]
                 written.add(p_t.name)
                 continue
+            tok = self._pb("elementwise/bn")
             bn_backward(o)
+            self._pe(tok)
             dy = self._dy_src(plan, o)
             if ty == "stem":
                 s = self._src_of(plan, op["ins"][0], x_cst=plan.x_cst)
+                tok = self._pb("k_stem_*")
                 check(lib.sc_stem_conv_wgrad(C.byref(dy), C.byref(s), ptr(plan.ws), plan.ws_floats, ptr(gv(conv.weight)),
                                              N, conv.in_channels, H, W, st))
+                self._pe(tok)
                 continue
             if ty == "dw":
                 tin = op["ins"][0]
                 Hi, Wi = H >> tin.shift, W >> tin.shift
                 s = self._src_of(plan, tin)
                 acc = plan.dw_acc[dw_offs[i]:dw_offs[i] + o.C * 9]
+                tok = self._pb("k_dw_*")
                 check(lib.sc_dwconv3x3_wgrad(C.byref(dy), C.byref(s), ptr(acc), N, o.C, Hi, Wi, op["stride"], st))
                 check(lib.sc_cast_f64_f32(ptr(acc), ptr(gv(conv.weight)), o.C * 9, st))
                 check(lib.sc_dwconv3x3_dgrad(C.byref(dy), ptr(conv.weight), ptr(plan.grad[tin.name]),
                                              1 if tin.name in written else 0, N, o.C, Hi, Wi, op["stride"], st))
+                self._pe(tok)
                 written.add(tin.name)
                 continue
             # pw / conv3 : weight gradient
@@ -492,7 +530,10 @@ class HyperStarcopUNet(nn.Module):
             wa.N, wa.H, wa.W, wa.Cout, wa.Cin, wa.ks = N, Ho, Wo, o.C, conv.in_channels, ks
             wa.part = plan.ws.data_ptr(); wa.part_floats = plan.ws_floats
             wa.dw = gv(conv.weight).data_ptr()
+            flop = 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * ks * ks
+            tok = self._pb(f"k_wgrad_mfma<{ks}> (+reduce)", flop)
             check(lib.sc_conv2d_wgrad_mfma(C.byref(wa), st))
+            self._pe(tok)
             # data gradient
             if ins[0].kind == "input":
                 continue
@@ -505,6 +546,7 @@ class HyperStarcopUNet(nn.Module):
             a.ks, a.co_t = ks, ent["cot_b"]
             a.add0 = None; a.add1 = None; a.stats = None
             a.accum0 = a.accum1 = 0
+            tok = self._pb(f"k_conv_mfma<{ks}> (fwd+dgrad)", flop)
             if op.get("up"):
                 t_up = ins[0]
                 a.out0 = plan.up_tmp.data_ptr()
@@ -517,6 +559,7 @@ class HyperStarcopUNet(nn.Module):
                 else:
                     a.out1 = None
                 check(lib.sc_conv2d_mfma(C.byref(a), st))
+                self._pe(tok)
                 check(lib.sc_downsum2x2(ptr(plan.up_tmp), ptr(plan.grad[t_up.name]), 1 if t_up.name in written else 0,
                                         N, t_up.C, Ho // 2, Wo // 2, st))
                 written.add(t_up.name)
@@ -529,6 +572,7 @@ class HyperStarcopUNet(nn.Module):
                 if z is not None:
                     a.add0 = plan.grad[z].data_ptr()
                 check(lib.sc_conv2d_mfma(C.byref(a), st))
+                self._pe(tok)
                 written.add(tin.name)
 
     # ------------------------------------------------------------------------------------------

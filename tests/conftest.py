@@ -18,3 +18,16 @@ def hip():
     from starcop_amd import _lib
     _lib.require_device()
     return _lib.load()
+
+
+@pytest.fixture(autouse=True)
+def _release_device_tensors():
+    yield
+    try:
+        import hip_ops
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        hip_ops._KEEP.clear()
+    except Exception:
+        pass

@@ -8,11 +8,20 @@ from starcop_amd._lib import (ACT_NONE, SC_CST, SC_STAT_SLOTS, SRC_AFFINE, SRC_B
                               make_src, ptr, sc_conv_args, sc_wgrad_args, stream)
 
 DEV = "cuda"
+_KEEP = []      # device tensors referenced only through raw pointers must outlive the launch
+
+
+def dev(t):
+    """host tensor -> device tensor that stays alive until the end of the test"""
+    d = t.detach().to(DEV).contiguous()
+    _KEEP.append(d)
+    return d
 
 
 def cst_affine(scale, shift):
     c = torch.zeros(scale.numel(), SC_CST, device=DEV)
     c[:, 0], c[:, 1] = scale.to(DEV), shift.to(DEV)
+    _KEEP.append(c)
     return c
 
 

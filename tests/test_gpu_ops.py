@@ -8,7 +8,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from hip_ops import (DEV, conv_mfma, cst_affine, pack, relerr, wgrad_mfma)  # noqa: E402
+from hip_ops import (dev, DEV, conv_mfma, cst_affine, pack, relerr, wgrad_mfma)  # noqa: E402
 from starcop_amd import _lib  # noqa: E402
 from starcop_amd._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, SC_STAT_SLOTS, SRC_AFFINE, SRC_BNBWD, SRC_NORM,
                               SRC_RAW, check, make_src, ptr, stream)  # noqa: E402
@@ -27,14 +27,15 @@ def rnd(*shape, seed=0, scale=1.0):
 
 @pytest.mark.parametrize("ks,cin,cout,co_t,H,W", [
     (3, 16, 16, 32, 32, 32), (3, 32, 64, 64, 32, 64), (3, 24, 96, 32, 12, 40), (3, 64, 40, 64, 36, 32),
-    (1, 16, 96, 32, 16, 16), (1, 96, 24, 32, 24, 20), (1, 160, 128, 64, 16, 16), (1, 24, 144, 32, 10, 13)])
+    (1, 16, 96, 32, 16, 16), (1, 96, 24, 32, 24, 20), (1, 160, 128, 64, 16, 16), (1, 24, 144, 32, 10, 13),
+    (1, 320, 1280, 64, 2, 3), (1, 960, 160, 64, 2, 3), (3, 1376, 256, 64, 4, 6)])
 def test_conv_mfma_fwd_affine_stats(hip, ks, cin, cout, co_t, H, W):
     N = 2
     x, w = rnd(N, cin, H, W, seed=1), rnd(cout, cin, ks, ks, seed=2, scale=0.2)
     sc, sh = rnd(cin, seed=3) * 0.5 + 1.0, rnd(cin, seed=4) * 0.3
     act = ACT_RELU6
     ref = F.conv2d(act_ref(x * sc[None, :, None, None] + sh[None, :, None, None], act), w, padding=ks // 2)
-    xd, wd = x.to(DEV), w.to(DEV)
+    xd, wd = dev(x), dev(w)
     src = make_src(xd, cin, SRC_AFFINE, act=act, cst=cst_affine(sc, sh))
     (out,), stats = conv_mfma([src], pack(wd, co_t, 0), N, H, W, cout, ks, co_t, want_stats=True)
     assert relerr(out, ref) < TOL
@@ -52,13 +53,14 @@ def test_conv_mfma_upsample_concat(hip):
     xin = torch.cat([F.interpolate(F.relu(prev * sc0[None, :, None, None] + sh0[None, :, None, None]),
                                    scale_factor=2, mode="nearest"), skip], 1)
     ref = F.conv2d(xin, w, padding=1)
-    s0 = make_src(prev.to(DEV), c0, SRC_AFFINE, act=ACT_RELU, up=1, cst=cst_affine(sc0, sh0))
-    s1 = make_src(skip.to(DEV), c1, SRC_RAW)
-    (out,), _ = conv_mfma([s0, s1], pack(w.to(DEV), 32, 0), N, H, W, cout, 3, 32)
+    s0 = make_src(dev(prev), c0, SRC_AFFINE, act=ACT_RELU, up=1, cst=cst_affine(sc0, sh0))
+    s1 = make_src(dev(skip), c1, SRC_RAW)
+    (out,), _ = conv_mfma([s0, s1], pack(dev(w), 32, 0), N, H, W, cout, 3, 32)
     assert relerr(out, ref) < TOL
 
 
-@pytest.mark.parametrize("ks,cin,cout,H,W", [(3, 32, 16, 32, 32), (3, 80, 32, 16, 32), (1, 96, 16, 16, 16), (1, 24, 144, 8, 16)])
+@pytest.mark.parametrize("ks,cin,cout,H,W", [(3, 32, 16, 32, 32), (3, 80, 32, 16, 32), (1, 96, 16, 16, 16), (1, 24, 144, 8, 16),
+                                              (1, 320, 1280, 2, 3), (3, 256, 128, 4, 6)])
 def test_conv_dgrad_bnbwd_split_add(hip, ks, cin, cout, H, W):
     """backward-data = same kernel on the transposed+flipped filter; dy formed on load from (g, y)."""
     N = 2
@@ -70,15 +72,15 @@ def test_conv_dgrad_bnbwd_split_add(hip, ks, cin, cout, H, W):
     dy = torch.where(yh > 0, g, torch.zeros(())) * A[None, :, None, None] + B[None, :, None, None] * y + D[None, :, None, None]
     ref = F.conv_transpose2d(dy, w, padding=ks // 2)
     cst = torch.zeros(cout, SC_CST); cst[:, 0], cst[:, 1], cst[:, 2], cst[:, 3], cst[:, 4] = a, b, A, B, D
-    src = make_src(g.to(DEV), cout, SRC_BNBWD, act=ACT_RELU, cst=cst.to(DEV), aux=y.to(DEV))
+    src = make_src(dev(g), cout, SRC_BNBWD, act=ACT_RELU, cst=dev(cst), aux=dev(y))
     co_t = 32 if cin <= 32 else 64
-    wpk = pack(w.to(DEV), co_t, 1)
+    wpk = pack(dev(w), co_t, 1)
     (out,), _ = conv_mfma([src], wpk, N, H, W, cin, ks, co_t)
     assert relerr(out, ref) < TOL
     # epilogue adds + accumulate
     add0, old = rnd(N, cin, H, W, seed=9), rnd(N, cin, H, W, seed=10)
-    o = old.to(DEV).clone()
-    conv_mfma([src], wpk, N, H, W, cin, ks, co_t, add0=add0.to(DEV), accum=(1, 0), outs=[o])
+    o = dev(old).clone()
+    conv_mfma([src], wpk, N, H, W, cin, ks, co_t, add0=dev(add0), accum=(1, 0), outs=[o])
     assert relerr(o, ref + add0 + old) < TOL
     # channel split
     cs = cin // 2 if (cin // 2) % 8 == 0 else 8
@@ -88,7 +90,7 @@ def test_conv_dgrad_bnbwd_split_add(hip, ks, cin, cout, H, W):
 
 @pytest.mark.parametrize("ks,cin,cout,H,W,two", [(3, 16, 16, 32, 32, False), (3, 32, 64, 16, 32, True), (3, 80, 48, 20, 36, True),
                                                   (3, 64, 16, 8, 64, False), (1, 96, 24, 16, 16, False), (1, 24, 144, 16, 24, False),
-                                                  (1, 160, 320, 8, 8, False)])
+                                                  (1, 160, 320, 8, 8, False), (1, 320, 1280, 2, 3, False), (3, 256, 256, 4, 6, False)])
 def test_conv_wgrad(hip, ks, cin, cout, H, W, two):
     N = 3
     g, y = rnd(N, cout, H, W, seed=1), rnd(N, cout, H, W, seed=2)
@@ -97,16 +99,16 @@ def test_conv_wgrad(hip, ks, cin, cout, H, W, two):
     yh = y * a[None, :, None, None] + b[None, :, None, None]
     dy = torch.where((yh > 0) & (yh < 6), g, torch.zeros(())) * A[None, :, None, None] + B[None, :, None, None] * y + D[None, :, None, None]
     cst = torch.zeros(cout, SC_CST); cst[:, 0], cst[:, 1], cst[:, 2], cst[:, 3], cst[:, 4] = a, b, A, B, D
-    dys = make_src(g.to(DEV), cout, SRC_BNBWD, act=ACT_RELU6, cst=cst.to(DEV), aux=y.to(DEV))
+    dys = make_src(dev(g), cout, SRC_BNBWD, act=ACT_RELU6, cst=dev(cst), aux=dev(y))
     if two:
         c0 = cin - 8
         prev, skip = rnd(N, c0, H // 2, W // 2, seed=11), rnd(N, 8, H, W, seed=12)
         sc0, sh0 = rnd(c0, seed=13) * 0.3 + 1, rnd(c0, seed=14) * 0.2
         xin = torch.cat([F.interpolate(F.relu(prev * sc0[None, :, None, None] + sh0[None, :, None, None]), scale_factor=2), skip], 1)
-        srcs = [make_src(prev.to(DEV), c0, SRC_AFFINE, act=ACT_RELU, up=1, cst=cst_affine(sc0, sh0)), make_src(skip.to(DEV), 8, SRC_RAW)]
+        srcs = [make_src(dev(prev), c0, SRC_AFFINE, act=ACT_RELU, up=1, cst=cst_affine(sc0, sh0)), make_src(dev(skip), 8, SRC_RAW)]
     else:
         xin = rnd(N, cin, H, W, seed=11)
-        srcs = [make_src(xin.to(DEV), cin, SRC_RAW)]
+        srcs = [make_src(dev(xin), cin, SRC_RAW)]
     xin = xin.clone().requires_grad_(False)
     w = torch.zeros(cout, cin, ks, ks, requires_grad=True)
     F.conv2d(xin, w, padding=ks // 2).backward(dy)
@@ -114,7 +116,7 @@ def test_conv_wgrad(hip, ks, cin, cout, H, W, two):
     assert relerr(dw, w.grad) < TOL
 
 
-@pytest.mark.parametrize("C_,H,W,stride", [(32, 32, 32, 1), (24, 20, 28, 2), (96, 16, 16, 2), (40, 7, 9, 1)])
+@pytest.mark.parametrize("C_,H,W,stride", [(32, 32, 32, 1), (24, 20, 28, 2), (96, 16, 16, 2), (40, 7, 9, 1), (960, 2, 3, 1), (576, 4, 6, 2)])
 def test_depthwise(hip, C_, H, W, stride):
     N = 2
     x, w = rnd(N, C_, H, W, seed=1), rnd(C_, 1, 3, 3, seed=2, scale=0.3)
@@ -124,16 +126,16 @@ def test_depthwise(hip, C_, H, W, stride):
     ref = F.conv2d(xa, wr, stride=stride, padding=1, groups=C_)
     Ho, Wo = ref.shape[-2:]
     lib = hip
-    src = make_src(x.to(DEV), C_, SRC_AFFINE, act=ACT_RELU6, cst=cst_affine(sc, sh))
+    src = make_src(dev(x), C_, SRC_AFFINE, act=ACT_RELU6, cst=cst_affine(sc, sh))
     out = torch.empty(N, C_, Ho, Wo, device=DEV)
     stats = torch.zeros(SC_STAT_SLOTS, C_, 2, dtype=torch.float64, device=DEV)
-    wd = w.to(DEV)
+    wd = dev(w)
     check(lib.sc_dwconv3x3_fwd(C.byref(src), ptr(wd), ptr(out), N, C_, H, W, stride, ptr(stats), stream()))
     assert relerr(out, ref) < TOL
     assert relerr(stats.sum(0)[:, 0], ref.double().sum((0, 2, 3))) < 1e-4
     dy = rnd(N, C_, Ho, Wo, seed=5)
     ref.backward(dy)
-    dys = make_src(dy.to(DEV), C_, SRC_RAW)
+    dys = make_src(dev(dy), C_, SRC_RAW)
     dx = torch.empty(N, C_, H, W, device=DEV)
     check(lib.sc_dwconv3x3_dgrad(C.byref(dys), ptr(wd), ptr(dx), 0, N, C_, H, W, stride, stream()))
     assert relerr(dx, xa.grad) < TOL
@@ -152,17 +154,17 @@ def test_stem_fused_normalizer(hip):
     xn = torch.clamp((x - 0) / cst[:, 1][None, :, None, None], 0, 2)
     wr = w.clone().requires_grad_(True)
     ref = F.conv2d(xn, wr, stride=2, padding=1)
-    src = make_src(x.to(DEV), Cin, SRC_NORM, cst=cst.to(DEV))
+    src = make_src(dev(x), Cin, SRC_NORM, cst=dev(cst))
     out = torch.empty(N, 32, H // 2, W // 2, device=DEV)
     stats = torch.zeros(SC_STAT_SLOTS, 32, 2, dtype=torch.float64, device=DEV)
-    check(hip.sc_stem_conv_fwd(C.byref(src), ptr(w.to(DEV)), ptr(out), N, Cin, H, W, ptr(stats), stream()))
+    check(hip.sc_stem_conv_fwd(C.byref(src), ptr(dev(w)), ptr(out), N, Cin, H, W, ptr(stats), stream()))
     assert relerr(out, ref) < TOL
     assert relerr(stats.sum(0)[:, 1], (ref.double() ** 2).sum((0, 2, 3))) < 1e-4
     dy = rnd(N, 32, H // 2, W // 2, seed=3)
     ref.backward(dy)
     n = hip.sc_stem_wgrad_workspace_floats(N, Cin, H, W)
     ws, dw = torch.empty(n, device=DEV), torch.empty(32, Cin, 3, 3, device=DEV)
-    dys = make_src(dy.to(DEV), 32, SRC_RAW)
+    dys = make_src(dev(dy), 32, SRC_RAW)
     check(hip.sc_stem_conv_wgrad(C.byref(dys), C.byref(src), ptr(ws), n, ptr(dw), N, Cin, H, W, stream()))
     assert relerr(dw, wr.grad) < TOL
 
@@ -174,14 +176,14 @@ def test_head(hip):
     xa = F.relu(x * sc[None, :, None, None] + sh[None, :, None, None]).requires_grad_(True)
     wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
     ref = F.conv2d(xa, wr, br, padding=1)
-    src = make_src(x.to(DEV), Cin, SRC_AFFINE, act=ACT_RELU, cst=cst_affine(sc, sh))
+    src = make_src(dev(x), Cin, SRC_AFFINE, act=ACT_RELU, cst=cst_affine(sc, sh))
     out = torch.empty(N, 1, H, W, device=DEV)
-    wd = w.to(DEV)
-    check(hip.sc_head_conv_fwd(C.byref(src), ptr(wd), ptr(b.to(DEV)), ptr(out), N, Cin, H, W, stream()))
+    wd = dev(w)
+    check(hip.sc_head_conv_fwd(C.byref(src), ptr(wd), ptr(dev(b)), ptr(out), N, Cin, H, W, stream()))
     assert relerr(out, ref) < TOL
     dl = rnd(N, 1, H, W, seed=5)
     ref.backward(dl)
-    dld = dl.to(DEV)
+    dld = dev(dl)
     gin = torch.empty(N, Cin, H, W, device=DEV)
     check(hip.sc_head_conv_dgrad(ptr(dld), ptr(wd), ptr(gin), N, Cin, H, W, stream()))
     assert relerr(gin, xa.grad) < TOL
@@ -200,13 +202,13 @@ def test_batchnorm_bookkeeping(hip):
     z = F.relu6(F.batch_norm(y, rm, rv, gamma, beta, True, 0.1, 1e-5))
     g = rnd(N, C_, H, W, seed=4)
     z.backward(g)
-    yd = y.detach().to(DEV)
+    yd = dev(y)
     stats = torch.zeros(SC_STAT_SLOTS, C_, 2, dtype=torch.float64, device=DEV)
     stats[3, :, 0] = yd.double().sum((0, 2, 3)); stats[7, :, 1] = (yd.double() ** 2).sum((0, 2, 3))
     rmd, rvd = torch.zeros(C_, device=DEV), torch.ones(C_, device=DEV)
     cst = torch.zeros(C_, SC_CST, device=DEV)
     cnt = float(N * H * W)
-    check(hip.sc_bn_finalize(ptr(stats), cnt, ptr(gamma.detach().to(DEV)), ptr(beta.detach().to(DEV)), ptr(rmd), ptr(rvd),
+    check(hip.sc_bn_finalize(ptr(stats), cnt, ptr(dev(gamma)), ptr(dev(beta)), ptr(rmd), ptr(rvd),
                              0.1, 1e-5, 1, ptr(cst), C_, stream()))
     assert relerr(rmd, rm) < 1e-5 and relerr(rvd, rv) < 1e-5
     src = make_src(yd, C_, SRC_AFFINE, act=ACT_RELU6, cst=cst)
@@ -214,7 +216,7 @@ def test_batchnorm_bookkeeping(hip):
     check(hip.sc_apply_src(C.byref(src), ptr(zz), N, C_, H * W, stream()))
     assert relerr(zz, z) < 1e-5
     sums = torch.zeros(SC_STAT_SLOTS, C_, 2, dtype=torch.float64, device=DEV)
-    gd = g.to(DEV)
+    gd = dev(g)
     check(hip.sc_bn_bwd_reduce(ptr(gd), ptr(yd), ptr(cst), ACT_RELU6, ptr(sums), N, C_, H * W, stream()))
     dgm, dbt, cstb = torch.empty(C_, device=DEV), torch.empty(C_, device=DEV), torch.zeros(C_, SC_CST, device=DEV)
     check(hip.sc_bn_bwd_finalize(ptr(sums), cnt, ptr(cst), ptr(dgm), ptr(dbt), ptr(cstb), C_, stream()))
@@ -230,12 +232,12 @@ def test_downsum_and_add(hip):
     x = rnd(N, C_, 2 * H, 2 * W, seed=1)
     ref = F.avg_pool2d(x, 2) * 4
     out = torch.empty(N, C_, H, W, device=DEV)
-    check(hip.sc_downsum2x2(ptr(x.to(DEV)), ptr(out), 0, N, C_, H, W, stream()))
+    check(hip.sc_downsum2x2(ptr(dev(x)), ptr(out), 0, N, C_, H, W, stream()))
     assert relerr(out, ref) < 1e-6
     a, b = rnd(N, C_, H, W, seed=2), rnd(N, C_, H, W, seed=3)
     sc, sh = rnd(C_, seed=4), rnd(C_, seed=5)
-    sa = make_src(a.to(DEV), C_, SRC_RAW)
-    sb = make_src(b.to(DEV), C_, SRC_AFFINE, act=ACT_NONE, cst=cst_affine(sc, sh))
+    sa = make_src(dev(a), C_, SRC_RAW)
+    sb = make_src(dev(b), C_, SRC_AFFINE, act=ACT_NONE, cst=cst_affine(sc, sh))
     o2 = torch.empty(N, C_, H, W, device=DEV)
     check(hip.sc_add_srcs(C.byref(sa), C.byref(sb), ptr(o2), N, C_, H * W, stream()))
     assert relerr(o2, a + b * sc[None, :, None, None] + sh[None, :, None, None]) < 1e-6
@@ -250,7 +252,7 @@ def test_bce_loss_and_grad(hip):
         (l * w).mean().backward()
         acc = torch.zeros(1, dtype=torch.float64, device=DEV)
         dz, px = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
-        check(hip.sc_bce_logits_weighted(ptr(z.detach().to(DEV)), ptr(t.to(DEV)), ptr(w.to(DEV)), pw, n, ptr(acc), ptr(dz), ptr(px), stream()))
+        check(hip.sc_bce_logits_weighted(ptr(dev(z)), ptr(dev(t)), ptr(dev(w)), pw, n, ptr(acc), ptr(dz), ptr(px), stream()))
         assert relerr(px, l) < 1e-5
         assert abs(float(acc) / n - float((l * w).mean())) < 1e-5 * max(1.0, float((l * w).mean()))
         assert relerr(dz, z.grad) < 1e-5
@@ -261,12 +263,12 @@ def test_adam_matches_torch(hip):
     p0, grads = rnd(n, seed=1), [rnd(n, seed=10 + i) for i in range(4)]
     pr = p0.clone().requires_grad_(True)
     opt = torch.optim.Adam([pr], lr=1e-2)
-    p, m, v = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    p, m, v = dev(p0), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
     step, lr_d, hp = torch.zeros(1, dtype=torch.int64, device=DEV), torch.full((1,), 1e-2, device=DEV), torch.zeros(4, device=DEV)
     for g in grads:
         pr.grad = g.clone(); opt.step()
         check(hip.sc_adam_prepare(ptr(step), ptr(lr_d), 0.9, 0.999, ptr(hp), stream()))
-        check(hip.sc_adam_step(ptr(p), ptr(g.to(DEV)), ptr(m), ptr(v), n, 0.0, 0.9, 0.999, 1e-8, 0.0, 1.0, 1.0, 1.0, ptr(hp), stream()))
+        check(hip.sc_adam_step(ptr(p), ptr(dev(g)), ptr(m), ptr(v), n, 0.0, 0.9, 0.999, 1e-8, 0.0, 1.0, 1.0, 1.0, ptr(hp), stream()))
     assert int(step) == 4
     assert relerr(p, pr) < 1e-5
 
@@ -285,7 +287,7 @@ def test_masks_bit_exact(hip):
         pb = torch.empty(B, 1, H, W, dtype=torch.int64, device=DEV)
         df = torch.empty(B, 1, H, W, dtype=torch.int64, device=DEV)
         cnt, cls = torch.zeros(B, dtype=torch.int64, device=DEV), torch.empty(B, dtype=torch.int64, device=DEV)
-        check(hip.sc_threshold_masks(ptr(z.to(DEV)), ptr(t.to(DEV)), ge0, ptr(pred), ptr(pb), ptr(df), ptr(cnt), B, H * W, stream()))
+        check(hip.sc_threshold_masks(ptr(dev(z)), ptr(dev(t)), ge0, ptr(pred), ptr(pb), ptr(df), ptr(cnt), B, H * W, stream()))
         check(hip.sc_pred_classification(ptr(cnt), ptr(cls), B, H, W, stream()))
         rb = (z >= 0).long() if ge0 else (torch.sigmoid(z) > .5).long()
         assert torch.equal(pb.cpu(), rb)

@@ -75,29 +75,41 @@ def test_eval_logits_and_masks(hip, B, H, W):
 
 
 def test_train_forward_backward_and_adam(hip):
-    B, H, W = 3, 64, 96
+    """Gradients through 62 train-mode BatchNorms + ReLU(6) masks are ill-conditioned in fp32 (a mask flip is a
+    discrete change), so "truth" is the oracle evaluated in fp64 and the bar is: the HIP path is as close to it as
+    the reference's own fp32 CPU path is (<= max(1e-3, 3x the fp32 oracle's deviation))."""
+    B, H, W = 4, 128, 128
     model, ref = make_pair(seed=3, pos_weight=1.0)
     model.train(); ref.train()
+    ref64 = copy.deepcopy(ref).double()
     batch = synth_batch(B, H, W, seed=5)
-    # ---- oracle: training_step semantics (model_module.py:69-88) + torch Adam
+
+    def oracle_step(net, dt):
+        logits = net(ref_normalize(batch["input"]).to(dt))
+        loss = (F.binary_cross_entropy_with_logits(logits, batch["output"].to(dt), pos_weight=torch.tensor(1.0, dtype=dt),
+                                                   reduction="none") * batch["weight_loss"].to(dt)).mean()
+        net.zero_grad(); loss.backward()
+        return logits.detach(), loss.detach(), {k: p.grad.clone() for k, p in net.named_parameters()}
+
+    # ---- oracle: training_step semantics (model_module.py:69-88) + torch Adam, in fp32 (the reference path) and fp64
     opt_ref = torch.optim.Adam(ref.parameters(), lr=1e-4)
-    logits_ref = ref(ref_normalize(batch["input"]))
-    loss_ref = (F.binary_cross_entropy_with_logits(logits_ref, batch["output"], pos_weight=torch.tensor(1.0), reduction="none")
-                * batch["weight_loss"]).mean()
-    opt_ref.zero_grad(); loss_ref.backward()
-    grads_ref = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    logits_ref, loss_ref, g32 = oracle_step(ref, torch.float32)
+    logits64, loss64, g64 = oracle_step(ref64, torch.float64)
     # ---- HIP: autograd path (what Lightning drives)
     opt = model.configure_optimizers()["optimizer"]
     loss = model.training_step(to_dev(batch), 0)
-    assert abs(float(loss) - float(loss_ref)) < 1e-4 * max(1.0, abs(float(loss_ref)))
+    assert abs(float(loss.detach()) - float(loss64)) < 1e-4 * max(1.0, abs(float(loss64)))
     logits = model.network._plans[(B, H, W)].buf["logits"]
     assert relerr(logits, logits_ref) < 1e-4
+    assert relerr(logits, logits64) < 1e-4
     opt.zero_grad(); loss.backward()
-    worst = 0.0
+    bad, worst = [], 0.0
     for k, p in model.network.named_parameters():
-        e = relerr(p.grad, grads_ref[k])
-        worst = max(worst, e)
-        assert e < 1e-3, f"gradient of {k}: rel err {e}"
+        e_hip, e_ref = relerr(p.grad, g64[k]), relerr(g32[k], g64[k])
+        worst = max(worst, e_hip)
+        if not e_hip <= max(1e-3, 3 * e_ref):
+            bad.append((k, e_hip, e_ref))
+    assert not bad, f"{len(bad)} gradients further from the fp64 oracle than the fp32 reference path: {bad[:10]}"
     # running statistics after one train-mode forward
     sd, sdr = model.network.state_dict(), ref.state_dict()
     for k in sd:
@@ -105,11 +117,13 @@ def test_train_forward_backward_and_adam(hip):
             assert relerr(sd[k], sdr[k]) < 1e-4, k
         if k.endswith("num_batches_tracked"):
             assert int(sd[k]) == int(sdr[k]) == 1
-    # ---- optimiser step
+    # ---- optimiser step from identical gradients: fused Adam == torch.optim.Adam
+    for k, p in ref.named_parameters():
+        p.grad = dict(model.network.named_parameters())[k].grad.detach().cpu().clone()
     opt_ref.step(); opt.step()
     for k, p in model.network.named_parameters():
-        assert relerr(p, dict(ref.named_parameters())[k]) < 1e-5, k
-    print("worst grad rel err", worst)
+        assert relerr(p, dict(ref.named_parameters())[k]) < 1e-6, k
+    print("worst grad rel err vs fp64 oracle", worst)
 
 
 def test_fused_train_step_equals_autograd_path(hip):
