@@ -1,0 +1,95 @@
+"""CPU restatement of the small host-side pieces of the hot path (numpy).
+
+TEST INFRASTRUCTURE -- not product code.  PINNED against the reference's own outputs in tests/golden/
+(g4_normalizer, g5_masks, g6_padding, g7_metrics, g8_ratio; written by tests/golden/make_golden.py).
+
+  normalize_x / normalize_y   starcop/data/normalizer_module.py:7-74 (table), :134-144
+  pred_classification          starcop/models/model_module.py:210-212
+  differences                  starcop/models/model_module.py:268-269
+  find_padding / padded_predict starcop/models/utils/padding.py:5-50
+  confusion-matrix metrics     starcop/metrics.py:20-85
+  band ratio / weight_mag1c    starcop/data/feature_extration.py:32-56
+  emit_rescale                 starcop/emit_tools/emit_dataset.py:62-106
+"""
+import numpy as np
+
+NORM = {"mag1c": (0, 1750, 0, 2)}
+for _b in ("550nm", "640nm", "460nm"):
+    NORM[f"TOA_AVIRIS_{_b}"] = (0, 60, 0, 2)
+NORM.update({"TOA_AVIRIS_2004nm": (0, 1, 0, 2), "TOA_AVIRIS_2109nm": (0, 5, 0, 2), "TOA_AVIRIS_2310nm": (0, 4, 0, 2),
+             "TOA_AVIRIS_2350nm": (0, 3, 0, 2), "TOA_AVIRIS_2360nm": (0, 3, 0, 2),
+             "ratio_aviris_2350_2310_out": (0, 0.0625, -2., 2.), "ratio_aviris_2350_2360_out": (0, 0.0625, -2., 2.),
+             "ratio_aviris_2360_2310_out": (0, 0.0625, -2., 2.),
+             "ratio_wv3_B8_B8MLR_SanchezGarcia22_sum_c_out": (0, 0.0769, -2., 2.),
+             "ratio_wv3_B8_B8MLR_SanchezGarcia22_simplediv": (-0.5, 1, -2., 2.)})
+
+
+def normalize_x(x, products):
+    """(B,C,H,W) float32 -> float32; per-channel (x - offset) / factor clipped; unknown product: factor 1, clip +-10.
+    Integer table entries keep the arithmetic in float32, float entries promote to float64 first (torch type promotion
+    with the 0-dim-less parameter tensors of the reference), then the result is cast to float32."""
+    rows = [NORM.get(p, (0, 1, -10, 10)) for p in products]
+    as_int = all(isinstance(v, (int, np.integer)) for r in rows for v in r)
+    pdt = np.int64 if as_int else np.float64
+    off, fac, lo, hi = (np.array([r[i] for r in rows], dtype=pdt)[None, :, None, None] for i in range(4))
+    xx = x if as_int else x.astype(np.float64)
+    v = (xx - off) / fac if not as_int else (x - off.astype(np.float32)) / fac.astype(np.float32)
+    return np.clip(v, lo, hi).astype(np.float32)
+
+
+def pred_classification(pred_binary):
+    h, w = pred_binary.shape[-2:]
+    return (pred_binary.sum(axis=(-1, -2)) > (10 * h * w) / 64 ** 2).astype(np.int64)
+
+
+def differences(pred_binary, gt):
+    return 2 * pred_binary.astype(np.int64) + (gt == 1).astype(np.int64)
+
+
+def find_padding(v, divisor=8):
+    tgt = max(divisor, int(divisor * np.ceil(v / divisor)))
+    a = (tgt - v) // 2
+    return a, tgt - v - a
+
+
+def padded_predict(x, model, divisor=32):
+    (t, b), (l, r) = find_padding(x.shape[-2], divisor), find_padding(x.shape[-1], divisor)
+    out = model(np.pad(x, ((0, 0), (t, b), (l, r)), "reflect")[None])[0]
+    return out[..., t:t + x.shape[-2], l:l + x.shape[-1]]
+
+
+def metrics(cm):
+    cm = np.asarray(cm, dtype=np.float64)
+    tn, fp, fn, tp = cm[0, 0], cm[0, 1], cm[1, 0], cm[1, 1]
+    prec, rec = tp / (tp + fp), tp / (tp + fn)
+    tot = cm.sum()
+    exp_off = (cm.sum(1)[0] * cm.sum(0)[1] + cm.sum(1)[1] * cm.sum(0)[0]) / tot
+    return {"precision": prec, "recall": rec, "f1score": 2 * prec * rec / (prec + rec), "iou": tp / (tp + fn + fp),
+            "accuracy": (tp + tn) / tot, "cohen_kappa": 1 - (fp + fn) / exp_off,
+            "balanced_accuracy": 0.5 * (rec + tn / (tn + fp)), "TP": tp, "TN": tn, "FP": fp, "FN": fn, "FPR": fp / (fp + tn)}
+
+
+def trimmed(d, p=5):
+    lo, hi = np.percentile(d, p), np.percentile(d, 100 - p)
+    return d[(d >= lo) & (d <= hi)]
+
+
+def band_ratio(background, signal, p=5, zero_value_out=-0.6):
+    """(c*signal - background)/(background + 1e-6), c = trimmed-sum(background)/trimmed-sum(signal); 0/0 -> -0.6."""
+    c = trimmed(background.ravel(), p).sum() / trimmed(signal.ravel(), p).sum()
+    R = (c * signal - background) / (background + 1e-6)
+    R[(signal < 1e-6) & (background < 1e-6)] = zero_value_out
+    return R
+
+
+def weight_mag1c(m):
+    return np.clip(m / 400, 0.1, 1)
+
+
+def emit_rescale(mf, rgb):
+    """EMIT -> AVIRIS value range: crop to multiples of 32, clip(mf/240,0,2)*1750, clip(rgb/20,0,2)*60, nan_to_num."""
+    h, w = (mf.shape[0] // 32) * 32, (mf.shape[1] // 32) * 32
+    out = np.ones((4, h, w), dtype=np.float32)
+    out[0] = np.clip(mf[:h, :w] / 240., 0., 2.) * 1750.
+    out[1:] = np.clip(rgb[:, :h, :w] / 20., 0., 2.) * 60.
+    return np.nan_to_num(out)

@@ -120,10 +120,17 @@ def g1_filters(tpl):
         run(f"rmf_{tag}_mask", xa, templ24, ref_mag1c.rmf, alpha=1e-4, mask=mask)
         run(f"acr_{tag}_mask", xa, templ24, ref_mag1c.acrwl1mf, num_iter=30, alpha=1e-4, mask=mask)
         run(f"acr_{tag}_albedo", xa, templ24, ref_mag1c.acrwl1mf, num_iter=10, albedo_override=True)
-        run(f"acr_{tag}_zero", xa, templ24, ref_mag1c.acrwl1mf, num_iter=10, zero_override=True)
         run(f"acr_{tag}_sparse", xa, templ24, ref_mag1c.acrwl1mf, num_iter=10, sparse_override=True)
         run(f"acr_{tag}_cus", xa, templ24, ref_mag1c.acrwl1mf, num_iter=10, covariance_update_scaling=0.5)
         run(f"rmf_{tag}_noscale_zero", xa, templ24, ref_mag1c.rmf, zero_override=True, apply_scaling=False)
+    # fewer pixels than bands with alpha=0: singular covariance -> the reference raises LinAlgError (mag1c.py:251,323)
+    xs = synth_group(rng, 16, 24, templ24, np.float64)[None]
+    try:
+        ref_mag1c.acrwl1mf(torch.tensor(xs), torch.tensor(templ24), num_iter=2, alpha=0.0)
+        raised = False
+    except torch.linalg.LinAlgError:
+        raised = True
+    cases["singular_x"], cases["singular_t"], cases["singular_raises"] = xs, templ24, np.array(raised)
     np.savez_compressed(os.path.join(OUT, "g1_filters.npz"), **cases)
 
 
@@ -176,7 +183,8 @@ def g5_masks():
     (wandb, pytorch_lightning, torchmetrics, starcop.utils -> rasterio/fsspec) are stubbed."""
     _stub("wandb")
     _stub("pytorch_lightning", LightningModule=torch.nn.Module)
-    _stub("torchmetrics")
+    tm = _stub("torchmetrics")
+    tm.functional = _stub("torchmetrics.functional", mean_squared_error=None, mean_absolute_error=None)
     _stub("starcop.utils", get_filesystem=lambda p: None)
     from starcop.models import model_module as ref_mm
     rng = np.random.default_rng(9)
