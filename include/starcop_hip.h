@@ -202,36 +202,43 @@ int sc_pred_classification(const int64_t* tile_count, int64_t* cls, int N, int H
                            sc_stream stream);
 
 /* ------------------------------------------------------------------------- */
-/* mag1c (starcop/models/mag1c.py:177-348): see starcop_amd/csrc/mag1c.hip        */
+/* mag1c matched filters (starcop/models/mag1c.py: rmf :284-348, acrwl1mf :177-280), one work-group per
+ * group of pixels (a detector column / column block: func_by_groups :116-174, mag1c_emit.py:58-84).
+ * Pixels of a group are packed band-major: element (s, p) of group g is x[xoff[g] + s*Ppad[g] + p].
+ * All statistics, the Cholesky factorisation and the per-pixel filter run in fp64 whatever the element type.
+ * The covariance of the target-removed data is formed from the fixed scatter matrix of the group by the exact
+ * rank-2 identity  N*C_k = C_0 - v t^T - t v^T + q t t^T  (see DESIGN.md), so X is streamed, never re-multiplied. */
 typedef struct sc_mag1c_args {
-  const void* x;            /* packed groups, band-major: for group g, x + xoff[g] holds [S][Ppad[g]] */
-  int32_t x_is_f64;         /* element type of x: 0 f32, 1 f64                                         */
-  const int64_t* xoff;      /* [G] element offsets                                                      */
-  const int32_t* P;         /* [G] pixels per group                                                     */
-  const int32_t* Ppad;      /* [G] row pitch (elements)                                                 */
-  const uint8_t* statmask;  /* optional per-pixel statistics mask, packed like a band row, or NULL       */
-  const int64_t* poff;      /* [G] offsets into per-pixel outputs                                       */
-  int32_t G, S;
-  const double* templ;      /* [S] unit absorption spectrum                                             */
-  int32_t num_iter;         /* -1: plain rmf()                                                           */
-  double alpha;
+  const void* x;            /* packed groups (see above)                                                  */
+  int32_t x_is_f64;         /* element type of x / mf_out / albedo_out: 0 f32, 1 f64                      */
+  const int64_t* xoff;      /* [G] element offsets of each group in x                                     */
+  const int32_t* P;         /* [G] pixels per group                                                       */
+  const int32_t* Ppad;      /* [G] row pitch (elements)                                                   */
+  const int64_t* poff;      /* [G] offsets of each group in the per-pixel arrays                          */
+  const uint8_t* statmask;  /* optional per-pixel (packed order) mask of pixels that enter mean/covariance */
+  int32_t G, S;             /* groups, bands (S <= 128)                                                   */
+  int64_t npix;             /* total packed pixels (sum of P)                                             */
+  const double* templ;      /* [S] unit absorption spectrum                                               */
+  int32_t num_iter;         /* reweighted-L1 iterations; -1: plain rmf()                                  */
+  double alpha;             /* covariance shrinkage towards its diagonal (lerp)                           */
   double cov_update_scaling;
   int32_t albedo_override, zero_override, sparse_override, apply_scaling;
-  double* work;             /* scratch, sc_mag1c_workspace_doubles(G,S)                                   */
-  void* mf_out;             /* per-pixel outputs, same element type as x                                 */
-  void* albedo_out;
-  int32_t* status;          /* [G] 0 ok, 1 not positive definite                                         */
+  double* work;             /* scratch: sc_mag1c_workspace_doubles(G, S, npix)                            */
+  void* mf_out;             /* [npix] per-pixel outputs, element type of x                                */
+  void* albedo_out;         /* [npix]                                                                     */
+  int32_t* status;          /* [G] 0 ok, 1 covariance not positive definite (-> torch.linalg.LinAlgError) */
 } sc_mag1c_args;
-size_t sc_mag1c_workspace_doubles(int G, int S);
+size_t sc_mag1c_workspace_doubles(int G, int S, int64_t npix);
 int sc_mag1c_groups(const sc_mag1c_args* a, sc_stream stream);
-/* gather pixels of a (H,W,S) band-interleaved cube into the packed band-major group layout */
+/* gather the pixels of a (H,W,S_total) band-interleaved cube into the packed band-major layout:
+ * x[xoff[g] + s*Ppad[g] + p] = cube[pix_index[poff[g]+p]*S_total + band0 + s] */
 int sc_mag1c_pack(const void* cube, int cube_is_f64, int S_total, int band0, int S,
-                  const int32_t* pix_index, size_t npix_total, const int64_t* xoff,
-                  const int32_t* Ppad, const int64_t* poff, const int32_t* P, int G,
-                  void* xpacked, int out_is_f64, sc_stream stream);
-/* scatter per-pixel results back: out[pix_index[i]] = val[i] */
-int sc_scatter(const void* val, int is_f64, const int32_t* pix_index, size_t n, void* out,
-               sc_stream stream);
+                  const int64_t* pix_index, const int64_t* xoff, const int32_t* Ppad,
+                  const int64_t* poff, const int32_t* P, int G, void* xpacked, int out_is_f64,
+                  sc_stream stream);
+/* out[pix_index[i]] = val[i]  (results back to image order; fill the rest before calling) */
+int sc_scatter(const void* val, int val_is_f64, const int64_t* pix_index, size_t n, void* out,
+               int out_is_f64, sc_stream stream);
 
 /* band ratio (starcop/data/feature_extration.py:37-56), c computed from trimmed sums on device */
 int sc_band_ratio(const float* background, const float* signal, float* out, size_t n,

@@ -48,8 +48,8 @@ class sc_wgrad_args(C.Structure):
 
 class sc_mag1c_args(C.Structure):
     _fields_ = [("x", C.c_void_p), ("x_is_f64", C.c_int32), ("xoff", C.c_void_p),
-                ("P", C.c_void_p), ("Ppad", C.c_void_p), ("statmask", C.c_void_p),
-                ("poff", C.c_void_p), ("G", C.c_int32), ("S", C.c_int32),
+                ("P", C.c_void_p), ("Ppad", C.c_void_p), ("poff", C.c_void_p), ("statmask", C.c_void_p),
+                ("G", C.c_int32), ("S", C.c_int32), ("npix", C.c_int64),
                 ("templ", C.c_void_p), ("num_iter", C.c_int32), ("alpha", C.c_double),
                 ("cov_update_scaling", C.c_double),
                 ("albedo_override", C.c_int32), ("zero_override", C.c_int32),
@@ -93,7 +93,10 @@ SIGNATURES = {
     "sc_adam_prepare": (_i, [_vp, _vp, _f, _f, _vp, _vp]),
     "sc_threshold_masks": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "sc_pred_classification": (_i, [_vp, _vp, _i, _i, _i, _vp]),
-    # MAG1C_SIGS
+    "sc_mag1c_workspace_doubles": (_sz, [_i, _i, C.c_int64]),
+    "sc_mag1c_groups": (_i, [C.POINTER(sc_mag1c_args), _vp]),
+    "sc_mag1c_pack": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "sc_scatter": (_i, [_vp, _i, _vp, _sz, _vp, _i, _vp]),
     "sc_band_ratio": (_i, [_vp, _vp, _vp, _sz, _f, _f, _vp]),
 }
 

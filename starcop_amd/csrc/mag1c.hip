@@ -1,0 +1,384 @@
+// mag1c: robust / albedo-corrected reweighted-L1 matched filter, one work-group per pixel group.
+//
+// Reference arithmetic: starcop/models/mag1c.py  rmf :284-348, acrwl1mf :177-280 (constants :55-57),
+// group semantics: func_by_groups :116-174 and starcop/models/mag1c_emit.py:58-84.
+//
+// What is different from the reference's op sequence (same mathematics, see DESIGN.md "mag1c"):
+//   * the reference recomputes   C_k = (modx-mu)^T (modx-mu) / N   (2*P*S^2 flop, 31x per group) with
+//     modx_p = x_p - w_p*tau.  Because modx differs from x by a rank-1 term per pixel,
+//         N*C_k = C_0 - v tau^T - tau v^T + q tau tau^T,   C_0 = sum (x_p-xbar)(x_p-xbar)^T  (once, fp64 MFMA)
+//         v = sum_p w_p (x_p - xbar),  q = sum_p (w_p - wbar)^2,  mu_k = xbar - wbar*tau
+//     so every iteration streams X twice (per-pixel dot products; v = X w) instead of re-multiplying it.
+//   * every statistic, the Cholesky factorisation, both triangular solves and the per-pixel filter are
+//     evaluated in fp64 for fp32 and fp64 radiances alike (the reference filters fp32 data in fp32).
+// Layout: pixels of a group are packed band-major, x[s*Ppad + p]: a wave reads 64 consecutive pixels of one
+// band (coalesced), per-pixel spectral reductions are register loops, per-band reductions are wave shuffles.
+#include "sc_common.h"
+
+namespace {
+
+typedef double doublex4 __attribute__((ext_vector_type(4)));
+
+struct Mag1cP {
+  const void* x;
+  const long long* xoff; const int* P; const int* Ppad; const long long* poff;
+  const unsigned char* statmask;
+  int G, S;
+  long long npix;
+  const double* templ;
+  int num_iter;
+  double alpha, kscale;
+  int albedo_override, zero_override, sparse_override, apply_scaling;
+  double* workC;     // [G][S*S]  C_0 per group
+  double* mfw; double* Rw; double* wv;   // [npix] per-pixel state
+  void* mf_out; void* alb_out;
+  int* status;
+};
+
+constexpr int MAXS = 128;
+constexpr int VEC = 128;
+
+__device__ __forceinline__ double block_sum1(double v, double* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = wave_sum_d(v);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_mag1c(const Mag1cP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int g = blockIdx.x;
+  const int S = p.S, LDC = S + 1;
+  const int S16 = (S + 15) & ~15;
+  double* Cm = reinterpret_cast<double*>(smem);           // [S][LDC] working covariance / Cholesky factor
+  double* vec = Cm + (size_t)S * LDC;
+  double* xbar = vec, *tmpl = vec + VEC, *tau = vec + 2 * VEC, *mu = vec + 3 * VEC, *tnew = vec + 4 * VEC;
+  double* cit = vec + 5 * VEC, *vv = vec + 6 * VEC, *col = vec + 7 * VEC;
+  double* red = vec + 8 * VEC;       // [16]
+  double* stg = red + 16;            // [S16][17] staging for the scatter matrix
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int P = p.P[g], pitch = p.Ppad[g];
+  const T* X = reinterpret_cast<const T*>(p.x) + p.xoff[g];
+  const long long po = p.poff[g];
+  const unsigned char* mk = p.statmask ? p.statmask + po : nullptr;
+  double* mfw = p.mfw + po; double* Rw = p.Rw + po; double* wv = p.wv + po;
+  double* C0 = p.workC + (size_t)g * S * S;
+  const double N = (double)P;
+
+  // ---------------- phase A: band means over the statistics pixels
+  double nstat;
+  {
+    double c = 0.0;
+    for (int q = tid; q < P; q += 256) c += (mk == nullptr || mk[q]) ? 1.0 : 0.0;
+    nstat = block_sum1(c, red);
+  }
+  for (int s = wave; s < S; s += 4) {
+    double a = 0.0;
+    for (int q = lane; q < P; q += 64)
+      if (mk == nullptr || mk[q]) a += (double)X[(size_t)s * pitch + q];
+    a = wave_sum_d(a);
+    if (lane == 0) xbar[s] = a / nstat;
+  }
+  for (int s = tid; s < S; s += 256) tmpl[s] = p.templ[s];
+  __syncthreads();
+
+  // ---------------- phase B: C_0 = sum_p (x_p - xbar)(x_p - xbar)^T  on v_mfma_f64_16x16x4_f64
+  {
+    const int nb = S16 >> 4;
+    const int nblk = nb * (nb + 1) / 2;
+    doublex4 acc[9];
+#pragma unroll
+    for (int b = 0; b < 9; ++b) acc[b] = (doublex4){0.0, 0.0, 0.0, 0.0};
+    for (int c0 = 0; c0 < P; c0 += 16) {
+      __syncthreads();
+      for (int i = tid; i < S16 * 16; i += 256) {
+        const int s = i >> 4, k = i & 15, q = c0 + k;
+        double v = 0.0;
+        if (s < S && q < P && (mk == nullptr || mk[q])) v = (double)X[(size_t)s * pitch + q] - xbar[s];
+        stg[s * 17 + k] = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int b = 0; b < 9; ++b) {
+        const int blk = wave + 4 * b;
+        if (blk < nblk) {
+          // upper-triangular block index -> (bi <= bj)
+          int bi = 0, rem = blk;
+          while (rem >= nb - bi) { rem -= nb - bi; ++bi; }
+          const int bj = bi + rem;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const double a = stg[(bi * 16 + (lane & 15)) * 17 + kk * 4 + (lane >> 4)];
+            const double bb = stg[(bj * 16 + (lane & 15)) * 17 + kk * 4 + (lane >> 4)];
+            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[b], 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 9; ++b) {
+      const int blk = wave + 4 * b;
+      if (blk < nblk) {
+        int bi = 0, rem = blk;
+        while (rem >= nb - bi) { rem -= nb - bi; ++bi; }
+        const int bj = bi + rem;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = bi * 16 + (lane >> 4) + 4 * r, j = bj * 16 + (lane & 15);
+          if (i < S && j < S) { C0[(size_t)i * S + j] = acc[b][r]; C0[(size_t)j * S + i] = acc[b][r]; }
+        }
+      }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  // ---------------- phase C: rmf (it == 0) then the reweighted-L1 iterations
+  double sw = 0.0, sww = 0.0;
+  bool notpd = false;
+  const int last = p.num_iter < 0 ? 0 : p.num_iter;
+  for (int it = 0; it <= last; ++it) {
+    // (1) mean / target / covariance of the target-removed data
+    double wbar = 0.0, q = 0.0;
+    if (it > 0) { wbar = sw / nstat; q = sww - nstat * wbar * wbar; }
+    for (int s = tid; s < S; s += 256) {
+      const double m = (it > 0) ? xbar[s] - wbar * tau[s] : xbar[s];
+      mu[s] = m;
+      tnew[s] = tmpl[s] * m;
+    }
+    __syncthreads();
+    const double oma = 1.0 - p.alpha;
+    for (int i = tid; i < S * S; i += 256) {
+      const int r = i / S, c = i - r * S;
+      if (c <= r) {
+        double v = C0[i];
+        if (it > 0) v += -vv[r] * tau[c] - tau[r] * vv[c] + q * tau[r] * tau[c];
+        v /= N;
+        if (c != r) v *= oma;           // lerp towards the diagonal: C + alpha*(diag(C) - C)
+        Cm[r * LDC + c] = v;
+      }
+    }
+    __syncthreads();
+    // (2) Cholesky, lower, in place (right-looking; two barriers per column)
+    for (int j = 0; j < S; ++j) {
+      const double djj = Cm[j * LDC + j];
+      if (!(djj > 0.0)) notpd = true;
+      const double d = sqrt(djj);
+      for (int i = j + tid; i < S; i += 256) col[i] = (i == j) ? d : Cm[i * LDC + j] / d;
+      __syncthreads();
+      const int ti = tid >> 4, tk = tid & 15;
+      for (int i = j + 1 + ti; i < S; i += 16) {
+        const double ci = col[i];
+        for (int k = j + 1 + tk; k <= i; k += 16) Cm[i * LDC + k] -= ci * col[k];
+      }
+      for (int i = j + tid; i < S; i += 256) Cm[i * LDC + j] = col[i];
+      __syncthreads();
+    }
+    // (3) cit = C^{-1} tnew : forward and backward substitution by wave 0 (each lane owns rows lane, lane+64)
+    if (wave == 0) {
+      double b0 = lane < S ? tnew[lane] : 0.0;
+      double b1 = lane + 64 < S ? tnew[lane + 64] : 0.0;
+      for (int j = 0; j < S; ++j) {                       // L y = b
+        const double bj = __shfl(j < 64 ? b0 : b1, j & 63, 64);
+        const double yj = bj / Cm[j * LDC + j];
+        if (lane == (j & 63)) { if (j < 64) b0 = yj; else b1 = yj; }
+        if (lane > j && lane < S) b0 -= Cm[lane * LDC + j] * yj;
+        if (lane + 64 > j && lane + 64 < S) b1 -= Cm[(lane + 64) * LDC + j] * yj;
+      }
+      for (int j = S - 1; j >= 0; --j) {                  // L^T z = y
+        const double bj = __shfl(j < 64 ? b0 : b1, j & 63, 64);
+        const double zj = bj / Cm[j * LDC + j];
+        if (lane == (j & 63)) { if (j < 64) b0 = zj; else b1 = zj; }
+        if (lane < j) b0 -= Cm[j * LDC + lane] * zj;
+        if (lane + 64 < j) b1 -= Cm[j * LDC + lane + 64] * zj;
+      }
+      if (lane < S) cit[lane] = b0;
+      if (lane + 64 < S) cit[lane + 64] = b1;
+      // (4) normaliser = target . C^{-1} target ;  mu . cit ; mu . mu
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      if (lane < S) { a0 += tnew[lane] * b0; a1 += mu[lane] * b0; a2 += mu[lane] * mu[lane]; }
+      if (lane + 64 < S) { a0 += tnew[lane + 64] * b1; a1 += mu[lane + 64] * b1; a2 += mu[lane + 64] * mu[lane + 64]; }
+      a0 = wave_sum_d(a0); a1 = wave_sum_d(a1); a2 = wave_sum_d(a2);
+      if (lane == 0) { red[8] = a0; red[9] = a1; red[10] = a2; }
+    }
+    __syncthreads();
+    double norm = red[8];
+    const double mucit = red[9], mumu = red[10];
+    if (it > 0 && norm < 1.0) norm = 1.0;               // normalizer.clamp_(min=1) (mag1c.py:264-266)
+    // (5) per-pixel filter
+    double lsw = 0.0, lsww = 0.0;
+    for (int q0 = tid; q0 < P; q0 += 256) {
+      double dot = 0.0, dmu = 0.0;
+      if (it == 0 && !p.albedo_override) {
+        for (int s = 0; s < S; ++s) { const double xv = (double)X[(size_t)s * pitch + q0]; dot = fma(xv, cit[s], dot); dmu = fma(xv, mu[s], dmu); }
+      } else {
+        for (int s = 0; s < S; ++s) dot = fma((double)X[(size_t)s * pitch + q0], cit[s], dot);
+      }
+      const double score = dot - mucit;
+      double R, mf;
+      if (it == 0) {
+        R = p.albedo_override ? 1.0 : dmu / mumu;
+        mf = score / (R * norm);
+        if (!p.zero_override) mf = fmax(mf, 0.0);
+      } else {
+        R = Rw[q0];
+        const double reg = p.sparse_override ? 0.0 : 1.0 / (R * (mfw[q0] + 1e-9));
+        mf = fmax((score - reg) / (R * norm), 0.0);
+      }
+      mfw[q0] = mf;
+      if (it == 0) Rw[q0] = R;
+      const double w = (mk == nullptr || mk[q0]) ? p.kscale * R * mf : 0.0;
+      wv[q0] = w;
+      lsw += w; lsww += w * w;
+    }
+    if (it == last) break;
+    sw = block_sum1(lsw, red);
+    sww = block_sum1(lsww, red + 4);
+    __threadfence_block();
+    __syncthreads();
+    // (6) v = X w - xbar * sum(w);  tau <- current target
+    for (int s = wave; s < S; s += 4) {
+      double a = 0.0;
+      for (int q0 = lane; q0 < P; q0 += 64) a = fma((double)X[(size_t)s * pitch + q0], wv[q0], a);
+      a = wave_sum_d(a);
+      if (lane == 0) { vv[s] = a - xbar[s] * sw; tau[s] = tnew[s]; }
+    }
+    __syncthreads();
+  }
+  // ---------------- outputs
+  const double scale = (p.num_iter >= 0 || p.apply_scaling) ? 1e5 : 1.0;
+  T* mo = reinterpret_cast<T*>(p.mf_out) + po;
+  T* ao = reinterpret_cast<T*>(p.alb_out) + po;
+  for (int q0 = tid; q0 < P; q0 += 256) {
+    mo[q0] = (T)(mfw[q0] * scale);
+    ao[q0] = (T)Rw[q0];
+  }
+  if (tid == 0) p.status[g] = notpd ? 1 : 0;
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void k_mag1c_pack(const TI* __restrict__ cube, int S_total, int band0, int S,
+                                                    const long long* __restrict__ pix, const long long* __restrict__ xoff,
+                                                    const int* __restrict__ Ppad, const long long* __restrict__ poff,
+                                                    const int* __restrict__ P, TO* __restrict__ xp) {
+  // tile transpose through LDS: 64 pixels x up to 128 bands per step
+  __shared__ float s_t[64][MAXS + 1];
+  const int g = blockIdx.x;
+  const int np = P[g], pitch = Ppad[g];
+  TO* out = xp + xoff[g];
+  const long long* pg = pix + poff[g];
+  for (int q0 = blockIdx.y * 64; q0 < np; q0 += gridDim.y * 64) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * S; i += 256) {
+      const int k = i / S, s = i - k * S;
+      if (q0 + k < np) s_t[k][s] = (float)cube[(size_t)pg[q0 + k] * S_total + band0 + s];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * S; i += 256) {
+      const int s = i >> 6, k = i & 63;
+      if (q0 + k < np) out[(size_t)s * pitch + q0 + k] = (TO)s_t[k][s];
+    }
+  }
+}
+
+// fp64 cubes keep full precision: direct (uncoalesced-read) gather
+__global__ __launch_bounds__(256) void k_mag1c_pack_f64(const double* __restrict__ cube, int S_total, int band0, int S,
+                                                        const long long* __restrict__ pix, const long long* __restrict__ xoff,
+                                                        const int* __restrict__ Ppad, const long long* __restrict__ poff,
+                                                        const int* __restrict__ P, double* __restrict__ xp) {
+  const int g = blockIdx.x;
+  const int np = P[g], pitch = Ppad[g];
+  double* out = xp + xoff[g];
+  const long long* pg = pix + poff[g];
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < np * S; i += gridDim.y * 256) {
+    const int s = i / np, k = i - s * np;
+    out[(size_t)s * pitch + k] = cube[(size_t)pg[k] * S_total + band0 + s];
+  }
+}
+
+template <typename TI, typename TO>
+__global__ void k_scatter(const TI* __restrict__ val, const long long* __restrict__ pix, size_t n, TO* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[pix[i]] = (TO)val[i];
+}
+
+size_t mag1c_lds_bytes(int S) {
+  const int S16 = (S + 15) & ~15;
+  return ((size_t)S * (S + 1) + 8 * VEC + 16 + (size_t)S16 * 17) * sizeof(double);
+}
+
+}  // namespace
+
+extern "C" size_t sc_mag1c_workspace_doubles(int G, int S, int64_t npix) {
+  return (size_t)G * S * S + 3 * (size_t)npix;
+}
+
+extern "C" int sc_mag1c_groups(const sc_mag1c_args* a, sc_stream stream) {
+  SC_REQUIRE(a != nullptr, "sc_mag1c_groups: null args");
+  SC_REQUIRE(a->S >= 1 && a->S <= MAXS, "sc_mag1c_groups: number of bands must be in [1,%d] (got %d)", MAXS, a->S);
+  SC_REQUIRE(a->G >= 0 && a->npix >= 0, "sc_mag1c_groups: bad group / pixel count");
+  SC_REQUIRE(a->x && a->xoff && a->P && a->Ppad && a->poff && a->templ && a->work && a->mf_out && a->albedo_out && a->status,
+             "sc_mag1c_groups: null pointer argument");
+  if (a->G == 0) return SC_OK;
+  Mag1cP p;
+  p.x = a->x; p.xoff = (const long long*)a->xoff; p.P = a->P; p.Ppad = a->Ppad; p.poff = (const long long*)a->poff;
+  p.statmask = a->statmask; p.G = a->G; p.S = a->S; p.npix = a->npix; p.templ = a->templ; p.num_iter = a->num_iter;
+  p.alpha = a->alpha; p.kscale = a->cov_update_scaling;
+  p.albedo_override = a->albedo_override; p.zero_override = a->zero_override; p.sparse_override = a->sparse_override;
+  p.apply_scaling = a->apply_scaling;
+  p.workC = a->work;
+  p.mfw = a->work + (size_t)a->G * a->S * a->S; p.Rw = p.mfw + a->npix; p.wv = p.Rw + a->npix;
+  p.mf_out = a->mf_out; p.alb_out = a->albedo_out; p.status = a->status;
+  const size_t lds = mag1c_lds_bytes(a->S);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e;
+  if (a->x_is_f64) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) hipLaunchKernelGGL(k_mag1c<double>, dim3(a->G), dim3(256), lds, st, p);
+  } else {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) hipLaunchKernelGGL(k_mag1c<float>, dim3(a->G), dim3(256), lds, st, p);
+  }
+  if (e != hipSuccess) { sc_set_error("sc_mag1c_groups: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return SC_ERR_LAUNCH; }
+  SC_LAUNCH_OK("sc_mag1c_groups");
+  return SC_OK;
+}
+
+extern "C" int sc_mag1c_pack(const void* cube, int cube_is_f64, int S_total, int band0, int S, const int64_t* pix_index,
+                             const int64_t* xoff, const int32_t* Ppad, const int64_t* poff, const int32_t* P, int G,
+                             void* xpacked, int out_is_f64, sc_stream stream) {
+  SC_REQUIRE(cube && pix_index && xoff && Ppad && poff && P && xpacked, "sc_mag1c_pack: null pointer argument");
+  SC_REQUIRE(S >= 1 && S <= MAXS && band0 >= 0 && band0 + S <= S_total, "sc_mag1c_pack: bad band range");
+  if (G == 0) return SC_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(G, 8);
+  const long long* px = (const long long*)pix_index; const long long* xo = (const long long*)xoff; const long long* po = (const long long*)poff;
+  if (cube_is_f64) {
+    SC_REQUIRE(out_is_f64, "sc_mag1c_pack: fp64 cube needs an fp64 packed buffer");
+    hipLaunchKernelGGL(k_mag1c_pack_f64, grid, dim3(256), 0, st, (const double*)cube, S_total, band0, S, px, xo, Ppad, po, P, (double*)xpacked);
+  } else if (out_is_f64) {
+    hipLaunchKernelGGL((k_mag1c_pack<float, double>), grid, dim3(256), 0, st, (const float*)cube, S_total, band0, S, px, xo, Ppad, po, P, (double*)xpacked);
+  } else {
+    hipLaunchKernelGGL((k_mag1c_pack<float, float>), grid, dim3(256), 0, st, (const float*)cube, S_total, band0, S, px, xo, Ppad, po, P, (float*)xpacked);
+  }
+  SC_LAUNCH_OK("sc_mag1c_pack");
+  return SC_OK;
+}
+
+extern "C" int sc_scatter(const void* val, int val_is_f64, const int64_t* pix_index, size_t n, void* out, int out_is_f64,
+                          sc_stream stream) {
+  SC_REQUIRE(val && pix_index && out, "sc_scatter: null pointer argument");
+  if (n == 0) return SC_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  const long long* px = (const long long*)pix_index;
+  if (val_is_f64 && out_is_f64) hipLaunchKernelGGL((k_scatter<double, double>), dim3(blocks), dim3(256), 0, st, (const double*)val, px, n, (double*)out);
+  else if (val_is_f64) hipLaunchKernelGGL((k_scatter<double, float>), dim3(blocks), dim3(256), 0, st, (const double*)val, px, n, (float*)out);
+  else if (out_is_f64) hipLaunchKernelGGL((k_scatter<float, double>), dim3(blocks), dim3(256), 0, st, (const float*)val, px, n, (double*)out);
+  else hipLaunchKernelGGL((k_scatter<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)val, px, n, (float*)out);
+  SC_LAUNCH_OK("sc_scatter");
+  return SC_OK;
+}

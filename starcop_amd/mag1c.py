@@ -1,0 +1,277 @@
+"""mag1c matched filters on the MI355X: same function names / arguments as the reference module
+(/root/reference/starcop/models/mag1c.py: rmf :284, acrwl1mf :177, func_by_groups :117,
+get_mask_bad_bands :98, generate_template_from_bands :60) plus the two drivers' group semantics
+(starcop/process_aviris.py:189-219 -> :func:`acrwl1mf_by_groups`, starcop/models/mag1c_emit.py:40-90 ->
+:func:`mag1c_columns`).
+
+All groups of a scene are filtered by ONE launch of ``sc_mag1c_groups`` (a work-group per group, all 31
+covariance/Cholesky rounds inside the kernel); the host only sorts pixel indices by group (torch plumbing) and
+packs / scatters through ``sc_mag1c_pack`` / ``sc_scatter``.  There is no CPU fallback.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr, sc_mag1c_args, stream
+
+NODATA = -9999
+SCALING = 1e5
+EPSILON = 1e-9
+MAX_BANDS = 128
+DEFAULT_WAVELENGTH_RANGE = (2122, 2488)
+
+
+# ------------------------------------------------------------------------------------------------
+def _run_groups(cube2d, S_total, band0, S, pix_index, counts, template, num_iter, alpha, k, flags, statmask=None):
+    """cube2d: (npixels_image, S_total) device tensor (f32|f64, contiguous); pix_index: int64 device tensor of the packed
+    pixels (group after group); counts: python list / cpu tensor of pixels per group.  Returns (mf, albedo) packed."""
+    lib = _lib.load()
+    dev = cube2d.device
+    is64 = cube2d.dtype == torch.float64
+    counts_t = torch.as_tensor(counts, dtype=torch.int64)
+    G = int(counts_t.numel())
+    npix = int(counts_t.sum())
+    dt = cube2d.dtype
+    mf = torch.empty(npix, dtype=dt, device=dev)
+    alb = torch.empty(npix, dtype=dt, device=dev)
+    if G == 0 or npix == 0:
+        return mf, alb
+    if S > MAX_BANDS:
+        raise ValueError(f"mag1c: at most {MAX_BANDS} bands per filter (got {S})")
+    ppad = ((counts_t + 63) // 64) * 64
+    poff = torch.cumsum(counts_t, 0) - counts_t
+    xoff = torch.cumsum(ppad * S, 0) - ppad * S
+    total = int((ppad * S).sum())
+    xp = torch.zeros(total, dtype=dt, device=dev)
+    P_d = counts_t.to(torch.int32).to(dev)
+    ppad_d = ppad.to(torch.int32).to(dev)
+    poff_d, xoff_d = poff.to(dev), xoff.to(dev)
+    st = stream()
+    check(lib.sc_mag1c_pack(ptr(cube2d), 1 if is64 else 0, S_total, band0, S, ptr(pix_index), ptr(xoff_d), ptr(ppad_d),
+                            ptr(poff_d), ptr(P_d), G, ptr(xp), 1 if is64 else 0, st))
+    a = sc_mag1c_args()
+    a.x = xp.data_ptr(); a.x_is_f64 = 1 if is64 else 0
+    a.xoff = xoff_d.data_ptr(); a.P = P_d.data_ptr(); a.Ppad = ppad_d.data_ptr(); a.poff = poff_d.data_ptr()
+    a.statmask = statmask.data_ptr() if statmask is not None else None
+    a.G, a.S, a.npix = G, S, npix
+    templ = torch.as_tensor(template, dtype=torch.float64).to(dev).contiguous()
+    if templ.numel() != S:
+        raise ValueError(f"mag1c: template has {templ.numel()} bands, data has {S}")
+    a.templ = templ.data_ptr()
+    a.num_iter, a.alpha, a.cov_update_scaling = int(num_iter), float(alpha), float(k)
+    a.albedo_override, a.zero_override, a.sparse_override, a.apply_scaling = (int(bool(f)) for f in flags)
+    work = torch.empty(lib.sc_mag1c_workspace_doubles(G, S, npix), dtype=torch.float64, device=dev)
+    status = torch.zeros(G, dtype=torch.int32, device=dev)
+    a.work, a.mf_out, a.albedo_out, a.status = work.data_ptr(), mf.data_ptr(), alb.data_ptr(), status.data_ptr()
+    check(lib.sc_mag1c_groups(C.byref(a), st))
+    bad = torch.nonzero(status).reshape(-1)
+    if bad.numel():          # the reference's torch.linalg.cholesky raises (mag1c.py:251,323)
+        raise torch.linalg.LinAlgError(
+            f"linalg.cholesky: (Batch element {int(bad[0])}): The factorization could not be completed because the "
+            "input is not positive-definite")
+    return mf, alb
+
+
+def _batched(x, template, num_iter, alpha, k, flags, mask):
+    _lib.require_device(x)
+    if x.dim() != 3:
+        raise ValueError("x must be [batch, pixels, spectrum]")
+    if x.dtype not in (torch.float32, torch.float64):
+        x = x.float()
+    b, p, s = x.shape
+    x2 = x.contiguous().reshape(b * p, s)
+    pix = torch.arange(b * p, dtype=torch.int64, device=x.device)
+    sm = None
+    if mask is not None:
+        m = torch.as_tensor(mask).to(x.device)
+        m = torch.squeeze(m, 0) if m.dim() > 1 else m
+        assert m.shape == x.shape[1:2], f"Unexpected shape of mask: {m.shape} expected {x.shape[1:2]}"
+        sm = m.to(torch.uint8).repeat(b).contiguous()
+    mf, alb = _run_groups(x2, s, 0, s, pix, [p] * b, template, num_iter, alpha, k, flags, sm)
+    return mf.reshape(b, p, 1), alb.reshape(b, p, 1)
+
+
+@torch.no_grad()
+def rmf(x, template, alpha=0., zero_override=False, compute_energy=False, albedo_override=False, apply_scaling=True,
+        mask=None):
+    """Classic robust matched filter, [b, p, s] -> (mf [b, p, 1] ppm*m, albedo [b, p, 1])."""
+    if compute_energy:
+        raise NotImplementedError("compute_energy is a diagnostic of the reference, not part of the hot path")
+    return _batched(x, template, -1, alpha, 1.0, (albedo_override, zero_override, False, apply_scaling), mask)
+
+
+@torch.no_grad()
+def acrwl1mf(x, template, num_iter=30, albedo_override=False, zero_override=False, sparse_override=False,
+             covariance_update_scaling=1., alpha=0., compute_energy=False, mask=None):
+    """Albedo-corrected reweighted-L1 matched filter, [b, p, s] -> (mf [b, p, 1], albedo [b, p, 1])."""
+    if compute_energy:
+        raise NotImplementedError("compute_energy is a diagnostic of the reference, not part of the hot path")
+    return _batched(x, template, int(num_iter), alpha, covariance_update_scaling,
+                    (albedo_override, zero_override, sparse_override, True), mask)
+
+
+class Filter:
+    """Parameters of the per-group filter; what the reference passes as ``lambda x: acrwl1mf(x, spec, num_iter=30)``."""
+
+    def __init__(self, template, num_iter=30, alpha=0., albedo_override=False, zero_override=False, sparse_override=False,
+                 covariance_update_scaling=1.):
+        self.template, self.num_iter, self.alpha = template, num_iter, alpha
+        self.flags = (albedo_override, zero_override, sparse_override, True)
+        self.k = covariance_update_scaling
+
+    def __call__(self, x):
+        return acrwl1mf(x, self.template, num_iter=self.num_iter, alpha=self.alpha, albedo_override=self.flags[0],
+                        zero_override=self.flags[1], sparse_override=self.flags[2], covariance_update_scaling=self.k)
+
+
+@torch.no_grad()
+def func_by_groups(func, x, groups, mask=None, disable_pbar=True, samples_read=50, band_slice=None):
+    """(H, W, S) radiance + (H, W) integer groups -> (mf, albedo) (H, W) tensors, NODATA where not computed.
+
+    Every group id present under ``mask`` is filtered on its own valid pixels; groups with <= 10 valid pixels are
+    skipped (mag1c.py:166).  ``func`` should be a :class:`Filter` (all groups in one kernel launch); any other callable
+    is applied group by group as the reference does."""
+    x = torch.as_tensor(x)
+    _lib.require_device(x if x.is_cuda else None)
+    dev = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    x = x.to(dev)
+    if x.dtype not in (torch.float32, torch.float64):
+        x = x.float()
+    H, W, S_total = x.shape
+    b0, b1 = (0, S_total) if band_slice is None else (band_slice.start or 0, band_slice.stop or S_total)
+    groups_t = torch.as_tensor(np.asarray(groups)).to(dev).reshape(-1).long()
+    if mask is None:
+        mask_t = torch.all(x[..., b0:b1] > NODATA, dim=-1).reshape(-1)
+    else:
+        mask_t = torch.as_tensor(np.asarray(mask)).to(dev).reshape(-1).bool()
+    mf_out = torch.full((H * W,), NODATA, dtype=x.dtype, device=dev)
+    alb_out = torch.full((H * W,), NODATA, dtype=x.dtype, device=dev)
+    valid_idx = torch.nonzero(mask_t).reshape(-1)
+    if valid_idx.numel() == 0:
+        return mf_out.reshape(H, W), alb_out.reshape(H, W)
+    gv = groups_t[valid_idx]
+    order = torch.argsort(gv, stable=True)
+    pix_sorted = valid_idx[order]
+    uniq, counts = torch.unique_consecutive(gv[order], return_counts=True)
+    keep = counts > 10
+    starts = torch.cumsum(counts, 0) - counts
+    if isinstance(func, Filter):
+        sel = torch.repeat_interleave(keep, counts)
+        pix = pix_sorted[sel].contiguous()
+        cnt = counts[keep].cpu()
+        mf, alb = _run_groups(x.reshape(H * W, S_total).contiguous(), S_total, b0, b1 - b0, pix, cnt, func.template,
+                              func.num_iter, func.alpha, func.k, func.flags)
+        lib = _lib.load()
+        is64 = 1 if x.dtype == torch.float64 else 0
+        check(lib.sc_scatter(ptr(mf), is64, ptr(pix), pix.numel(), ptr(mf_out), is64, stream()))
+        check(lib.sc_scatter(ptr(alb), is64, ptr(pix), pix.numel(), ptr(alb_out), is64, stream()))
+    else:
+        xf = x.reshape(H * W, S_total)
+        for s0, c, k in zip(starts.tolist(), counts.tolist(), keep.tolist()):
+            if not k:
+                continue
+            pix = pix_sorted[s0:s0 + c]
+            mf, alb = func(xf[pix][:, b0:b1].unsqueeze(0))
+            mf_out[pix], alb_out[pix] = mf[0, :, 0].to(x.dtype), alb[0, :, 0].to(x.dtype)
+    return mf_out.reshape(H, W), alb_out.reshape(H, W)
+
+
+@torch.no_grad()
+def acrwl1mf_by_groups(x, template, groups, mask=None, num_iter=30, alpha=0., band_slice=None):
+    """AVIRIS-NG driver core (process_aviris.py:209-219): acrwl1mf(num_iter=30, alpha=0) per detector column."""
+    return func_by_groups(Filter(template, num_iter=num_iter, alpha=alpha), x, groups, mask, band_slice=band_slice)
+
+
+@torch.no_grad()
+def mag1c_columns(raw, template, fill_value=-9999.0, column_step=None, num_iter=30, covariance_lerp_alpha=1e-4,
+                  column_range=None):
+    """EMIT driver core (mag1c_emit.py:50-90): raw (rows, cols, S) float32 radiance; blocks of ``column_step`` columns
+    (None: whole image) are filtered independently in float64 on their valid pixels (no band equal to ``fill_value``);
+    returns float32 (rows, cols) mf and albedo filled with ``fill_value``.  ``column_range=(c0, c1)`` restricts the work
+    to a shard of column blocks (multi-GPU: groups are independent, no collective)."""
+    raw = torch.as_tensor(raw)
+    dev = raw.device if raw.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    _lib.require_device()
+    raw = raw.to(dev).float().contiguous()
+    rows, cols, S = raw.shape
+    step = column_step or cols
+    invalid = torch.any(raw == fill_value, dim=-1)
+    colgroup = (torch.arange(cols, device=dev) // step)[None, :].expand(rows, cols)
+    valid = ~invalid
+    if column_range is not None:
+        cr = torch.zeros(cols, dtype=torch.bool, device=dev)
+        cr[column_range[0]:column_range[1]] = True
+        valid = valid & cr[None, :]
+    mf_out = torch.full((rows * cols,), float(fill_value), dtype=torch.float32, device=dev)
+    alb_out = torch.full((rows * cols,), float(fill_value), dtype=torch.float32, device=dev)
+    vidx = torch.nonzero(valid.reshape(-1)).reshape(-1)
+    if vidx.numel() == 0:
+        return mf_out.reshape(rows, cols), alb_out.reshape(rows, cols)
+    gv = colgroup.reshape(-1)[vidx]
+    # pixel order inside a block follows the reference's boolean indexing raw[:, c0:c1][valid] (row-major)
+    order = torch.argsort(gv, stable=True)
+    pix = vidx[order].contiguous()
+    _, counts = torch.unique_consecutive(gv[order], return_counts=True)
+    x64 = raw.reshape(rows * cols, S).double()            # "Convert to float64 to avoid rounding errors" (:74-75)
+    mf, alb = _run_groups(x64, S, 0, S, pix, counts.cpu(), template, num_iter, covariance_lerp_alpha, 1.0,
+                          (False, False, False, True))
+    lib = _lib.load()
+    check(lib.sc_scatter(ptr(mf), 1, ptr(pix), pix.numel(), ptr(mf_out), 0, stream()))
+    check(lib.sc_scatter(ptr(alb), 1, ptr(pix), pix.numel(), ptr(alb_out), 0, stream()))
+    return mf_out.reshape(rows, cols), alb_out.reshape(rows, cols)
+
+
+# ------------------------------------------------------------------------------------------------
+def get_mask_bad_bands(wave):
+    """Bands to keep: 400..2485 nm without the water-vapour windows (1350,1420) and (1800,1945) nm."""
+    w = np.asarray(wave)
+    reject = (w < 400) | (w > 2485) | ((w > 1350) & (w < 1420)) | ((w > 1800) & (w < 1945))
+    return ~reject
+
+
+def _lut_paths(lut_dir=None):
+    cands = [lut_dir, os.environ.get("STARCOP_CH4_LUT_DIR"), os.path.join(os.path.dirname(__file__), "data")]
+    for d in cands:
+        if d and os.path.exists(os.path.join(d, "ch4.lut")) and os.path.exists(os.path.join(d, "ch4.hdr")):
+            return os.path.join(d, "ch4.hdr"), os.path.join(d, "ch4.lut")
+    raise FileNotFoundError(
+        "CH4 look-up table (ch4.hdr + ch4.lut, mag1c upstream, 1.8 MB) not found: pass lut_dir=... or set "
+        "STARCOP_CH4_LUT_DIR to the directory that holds them (starcop/models/ in the reference checkout)")
+
+
+def read_ch4_lut(lut_dir=None):
+    """ENVI BSQ float64 reader -> (radiance [7, n_wave], wavelengths [n_wave] nm)."""
+    hdr, dat = _lut_paths(lut_dir)
+    txt = open(hdr).read()
+    dims = {k: int(re.search(rf"{k}\s*=\s*(\d+)", txt).group(1)) for k in ("samples", "lines", "bands")}
+    wl = re.search(r"wavelength\s*=\s*\{([^}]*)\}", txt, re.S).group(1)
+    wave = np.array([float(v) for v in wl.replace("\n", " ").split(",") if v.strip()])
+    arr = np.fromfile(dat, dtype="<f8").reshape(dims["bands"], dims["lines"], dims["samples"])
+    return arr.transpose(1, 2, 0).squeeze(), wave
+
+
+def generate_template_from_bands(centers, fwhm, lut_dir=None):
+    """Unit CH4 absorption spectrum for a sensor's band set -> (K, 2) [center, spectrum] (one-off, host, fp64).
+    Bands that do not overlap the LUT's 1400-2522 nm span come back as NaN (the reference leaves them undefined)."""
+    centers, fwhm = np.asarray(centers, dtype=np.float64), np.asarray(fwhm, dtype=np.float64)
+    if np.any(~np.isfinite(centers)) or np.any(~np.isfinite(fwhm)):
+        raise RuntimeError("Band Wavelengths Centers/FWHM data contains non-finite data (NaN or Inf).")
+    if centers.shape[0] != fwhm.shape[0]:
+        raise RuntimeError("Length of band center wavelengths and band fwhm arrays must be equal.")
+    rads, wave = read_ch4_lut(lut_dir)
+    conc = np.array([0., 500., 1000., 2000., 4000., 8000., 16000.])
+    sigma2 = (fwhm / (2.0 * np.sqrt(2.0 * np.log(2.0)))) ** 2
+    resp = np.exp(-(wave[:, None] - centers[None, :]) ** 2 / (2 * sigma2)) / np.sqrt(2 * np.pi * sigma2)
+    mass = resp.sum(axis=0)
+    spectrum = np.full(centers.shape[0], np.nan)
+    inside = mass > 0
+    rs = rads @ (resp[:, inside] / mass[inside])
+    pos = np.all(rs > 0, axis=0)
+    design = np.stack([np.ones_like(conc), conc], axis=1)
+    coef = np.linalg.lstsq(design, np.log(rs[:, pos]), rcond=None)[0]
+    spectrum[np.flatnonzero(inside)[pos]] = coef[1] * SCALING
+    return np.stack([centers, spectrum], axis=1)
