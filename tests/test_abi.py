@@ -1,0 +1,67 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/starcop_hip.h declares
+(no compute calls here -- those are the -m gpu tests)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "starcop_hip.h")
+
+
+def declared_functions():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sc_[a-z0-9_]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from starcop_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.load()
+
+
+def test_header_symbols_are_exported(lib):
+    from starcop_amd import _lib
+    names = declared_functions()
+    assert len(names) >= 35
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in starcop_hip.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in starcop_amd/_lib.py"
+    assert set(_lib.SIGNATURES) == set(names)
+
+
+def test_pure_host_entry_points(lib):
+    assert lib.sc_version() >= 100
+    assert lib.sc_packed_weight_floats(256, 1376, 3, 64, 0) == 4 * 1376 * 9 * 64
+    assert lib.sc_packed_weight_floats(256, 1376, 3, 64, 1) == 22 * 256 * 9 * 64      # dgrad: 1376 -> 22 tiles of 64
+    assert lib.sc_wgrad_workspace_floats(16, 512, 512, 16, 32, 3) > 0
+    assert lib.sc_mag1c_workspace_doubles(4, 125, 2048) == 4 * 125 * 125 + 3 * 2048
+
+
+def test_struct_layouts_match_header():
+    from starcop_amd import _lib
+    assert ctypes.sizeof(_lib.sc_src) == 40
+    assert ctypes.sizeof(_lib.sc_conv_args) == 2 * 40 + 8 + 8 + 6 * 4 + 2 * 8 + 3 * 4 + 4 + 3 * 8
+
+
+def test_no_cpu_fallback():
+    """The product path fails loudly without a gfx950 device; it never routes to torch CPU ops or the oracle."""
+    import torch
+    from starcop_amd import _lib, model_module as mm
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    model = mm.ModelModule(mm.default_settings())
+    with pytest.raises(_lib.StarcopHipError):
+        model(torch.zeros(1, 4, 64, 64))
+    with pytest.raises(_lib.StarcopHipError):
+        model.normalizer.normalize_x(torch.zeros(1, 4, 8, 8))
+    import starcop_amd.mag1c as m1
+    with pytest.raises(_lib.StarcopHipError):
+        m1.acrwl1mf(torch.zeros(1, 32, 8), torch.ones(8))
+    src = "".join(open(os.path.join(ROOT, "starcop_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "starcop_amd")) if f.endswith(".py"))
+    assert "import oracle" not in src and "from oracle" not in src
