@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
   int smode = 0, sact = 0;
   floatx4 wv[NW];
 
+  float slo = 0.f, shi = 0.f;
   auto load_chunk = [&](int kc) {
     const int c = kc * 8 + sci;
     const bool second = c >= C0;
@@ -90,43 +91,41 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
     const int up = second ? p.s1.up : p.s0.up;
     smode = second ? p.s1.mode : p.s0.mode;
     sact = second ? p.s1.act : p.s0.act;
+    slo = sc_act_lo(sact); shi = sc_act_hi(sact);
     if (smode != SC_SRC_RAW) {
       c0 = *reinterpret_cast<const float4*>(cp + (size_t)cs * SC_CST);
       c4 = cp[(size_t)cs * SC_CST + 4];
+    } else {
+      c0 = make_float4(1.f, 0.f, 0.f, 0.f); c4 = 0.f;
     }
     inb = 0;
     if (KS == 3) {
       const int Hs = H >> up, Ws = W >> up;
-      const size_t base = ((size_t)n * Cs + cs) * Hs * Ws;
+      const float* xb = xp + ((size_t)n * Cs + cs) * Hs * Ws;
+      const float* ab = (smode == SC_SRC_BNBWD) ? ap + ((size_t)n * Cs + cs) * Hs * Ws : xb;
 #pragma unroll
       for (int i = 0; i < NE; ++i) {
         const int e = sq + 32 * i;
         const int pr = e / PC, pc = e - pr * PC;
         const int y = y0 - 1 + pr, x = x0 - 1 + pc;
         const bool ok = (e < PCH) && (y >= 0) && (y < H) && (x >= 0) && (x < W);
-        float xvv = 0.f, avv = 0.f;
-        if (ok) {
-          const size_t idx = base + (size_t)(y >> up) * Ws + (x >> up);
-          xvv = xp[idx];
-          if (smode == SC_SRC_BNBWD) avv = ap[idx];
-          inb |= 1u << i;
-        }
-        xv[i] = xvv; av[i] = avv;
+        const int off = ok ? (y >> up) * Ws + (x >> up) : 0;      // clamped: unconditional loads, no exec-mask branches
+        xv[i] = xb[off];
+        av[i] = ab[off];
+        inb |= ok ? (1u << i) : 0u;
       }
     } else {
       const int HW = H * W;
-      const size_t base = ((size_t)n * Cs + cs) * HW;
+      const float* xb = xp + ((size_t)n * Cs + cs) * HW;
+      const float* ab = (smode == SC_SRC_BNBWD) ? ap + ((size_t)n * Cs + cs) * HW : xb;
 #pragma unroll
       for (int i = 0; i < NE; ++i) {
         const int pix = p0 + sq + 32 * i;
         const bool ok = pix < HW;
-        float xvv = 0.f, avv = 0.f;
-        if (ok) {
-          xvv = xp[base + pix];
-          if (smode == SC_SRC_BNBWD) avv = ap[base + pix];
-          inb |= 1u << i;
-        }
-        xv[i] = xvv; av[i] = avv;
+        const int off = ok ? pix : 0;
+        xv[i] = xb[off];
+        av[i] = ab[off];
+        inb |= ok ? (1u << i) : 0u;
       }
     }
     const floatx4* wsrc = reinterpret_cast<const floatx4*>(wbase + (size_t)kc * WCH);
@@ -138,12 +137,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
   };
 
   auto store_chunk = [&](int buf) {
+    if (smode == SC_SRC_BNBWD) {
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const int e = sq + 32 * i;
-      if (e < PCH) {
-        const float v = ((inb >> i) & 1u) ? sc_prologue(smode, sact, xv[i], av[i], c0, c4) : 0.f;
-        s_p[buf][sci * PCH + e] = v;
+      for (int i = 0; i < NE; ++i) {
+        const int e = sq + 32 * i;
+        if (e < PCH) {
+          const float v = sc_pro_bnbwd(xv[i], av[i], c0.x, c0.y, c0.z, c0.w, c4, slo, shi);
+          s_p[buf][sci * PCH + e] = ((inb >> i) & 1u) ? v : 0.f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int e = sq + 32 * i;
+        if (e < PCH) {
+          const float v = sc_pro_affine(xv[i], c0.x, c0.y, slo, shi);
+          s_p[buf][sci * PCH + e] = ((inb >> i) & 1u) ? v : 0.f;
+        }
       }
     }
 #pragma unroll
@@ -274,7 +284,7 @@ struct WgradP {
 };
 
 template <int KS, int WM, int WN>
-__global__ __launch_bounds__(256) void k_wgrad_mfma(const WgradP p) {
+__global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradP p) {
   constexpr int TAPS = KS * KS;
   constexpr int WK = 4 / (WM * WN);
   constexpr int SR = (WK == 4) ? 4 : 2;        // pixel rows (of 32) per stage
@@ -284,8 +294,6 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const WgradP p) {
   constexpr int PRW = SR + (KS == 3 ? 2 : 0);
   constexpr int PCW = (KS == 3) ? 34 : 32;
   constexpr int PB = (PRW * PCW) | 1;
-  constexpr int NEA = COT * SR * 32;           // dy elements per stage
-  constexpr int NEB = CIT * PRW * PCW;         // input elements per stage
 
   __shared__ float s_a[COT * PA];
   __shared__ float s_b[CIT * PB];
@@ -303,15 +311,16 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const WgradP p) {
   // per-WG constants -> LDS
   for (int i = tid; i < COT * SC_CST; i += 256) {
     const int ch = cot * COT + i / SC_CST;
-    s_ca[i] = (p.dy.cst && ch < p.Cout) ? p.dy.cst[(size_t)ch * SC_CST + (i % SC_CST)] : 0.f;
+    s_ca[i] = (p.dy.cst && p.dy.mode != SC_SRC_RAW && ch < p.Cout) ? p.dy.cst[(size_t)ch * SC_CST + (i % SC_CST)] : ((i % SC_CST) == 0 ? 1.f : 0.f);
   }
   for (int i = tid; i < CIT * SC_CST; i += 256) {
     const int ch = cit * CIT + i / SC_CST;
-    float v = 0.f;
+    float v = (i % SC_CST) == 0 ? 1.f : 0.f;      // RAW == affine(1, 0)
     if (ch < p.Cin) {
       const bool second = ch >= C0;
       const float* cp = second ? p.s1.cst : p.s0.cst;
-      if (cp) v = cp[(size_t)(second ? ch - C0 : ch) * SC_CST + (i % SC_CST)];
+      const int md = second ? p.s1.mode : p.s0.mode;
+      if (cp && md != SC_SRC_RAW) v = cp[(size_t)(second ? ch - C0 : ch) * SC_CST + (i % SC_CST)];
     }
     s_cb[i] = v;
   }
@@ -323,82 +332,150 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const WgradP p) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   // stage enumeration
-  int tiles_x, tiles_y, per_img;
+  int tiles_x, per_img;
   if (KS == 3) {
-    tiles_x = (W + 31) >> 5; tiles_y = (H + SR - 1) / SR; per_img = tiles_x * tiles_y;
+    tiles_x = (W + 31) >> 5; per_img = tiles_x * ((H + SR - 1) / SR);
   } else {
-    tiles_x = 1; tiles_y = 1; per_img = (H * W + SR * 32 - 1) / (SR * 32);
+    tiles_x = 1; per_img = (H * W + SR * 32 - 1) / (SR * 32);
   }
   const long T = (long)p.N * per_img;
   const long t_begin = T * blockIdx.x / p.nsl, t_end = T * (blockIdx.x + 1) / p.nsl;
+  const int dymode = p.dy.mode, dyact = p.dy.act;
 
-  for (long t = t_begin; t < t_end; ++t) {
+  // ---- register-staged prefetch of one stage: all loads issued back to back (clamped addresses, no exec-mask
+  //      branches), consumed after the MFMAs with branch-free prologues.
+  // dy tile : thread owns pixel a_px of the stage and channels a_c0 + ACH*i   (address = base + i*stride)
+  // x patch : half-wave per channel (b_c0 + 8k), lane covers patch positions b_q + 32j
+  constexpr int APX = SR * 32, ACH = 256 / APX, NAI = COT / ACH;
+  constexpr int BPOS = PRW * PCW, NBJ = (BPOS + 31) / 32, NBK = CIT / 8;
+  const int a_px = tid % APX, a_c0 = tid / APX;
+  const int b_q = tid & 31, b_c0 = tid >> 5;
+  float ag[NAI], ay[NAI], bx[NBK][NBJ];
+  int sn = 0, sy0 = 0, sx0 = 0, sp0 = 0;     // coordinates of the prefetched stage
+
+  auto a_pix = [&](int y0, int x0, int p0, bool& ok) -> int {
+    if (KS == 3) {
+      const int y = y0 + (a_px >> 5), x = x0 + (a_px & 31);
+      ok = (y < H) && (x < W);
+      return y * W + x;
+    }
+    const int pix = p0 + a_px;
+    ok = pix < H * W;
+    return pix;
+  };
+  auto b_pos = [&](int j, int y0, int x0, int p0, int up, bool& ok) -> int {
+    const int e = b_q + 32 * j;
+    if (KS == 3) {
+      const int pr = e / PCW, pc = e - pr * PCW;
+      const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+      ok = (e < BPOS) && (y >= 0) && (y < H) && (x >= 0) && (x < W);
+      return (y >> up) * (W >> up) + (x >> up);
+    }
+    const int pix = p0 + e;
+    ok = (e < BPOS) && (pix < H * W);
+    return pix;
+  };
+
+  const float dlo = sc_act_lo(dyact), dhi = sc_act_hi(dyact);
+  auto load_stage = [&](long t) {
     const int n = (int)(t / per_img);
     const int rem = (int)(t - (long)n * per_img);
     int y0 = 0, x0 = 0, p0 = 0;
     if (KS == 3) { const int ty = rem / tiles_x; y0 = ty * SR; x0 = (rem - ty * tiles_x) * 32; }
     else p0 = rem * SR * 32;
-    __syncthreads();   // previous stage fully consumed (also orders the constant stores)
-    // ---- stage dy ----
-    for (int i = tid; i < NEA; i += 256) {
-      const int chl = i / (SR * 32), px = i - chl * (SR * 32);
-      const int ch = cot * COT + chl;
-      float v = 0.f;
-      if (ch < p.Cout) {
-        bool ok; size_t idx;
-        if (KS == 3) {
-          const int y = y0 + (px >> 5), x = x0 + (px & 31);
-          ok = (y < H) && (x < W);
-          idx = (((size_t)n * p.Cout + ch) * H + y) * W + x;
-        } else {
-          const int pix = p0 + px;
-          ok = pix < H * W;
-          idx = ((size_t)n * p.Cout + ch) * H * W + pix;
-        }
-        if (ok) {
-          const float xg = p.dy.x[idx];
-          const float au = (p.dy.mode == SC_SRC_BNBWD) ? p.dy.aux[idx] : 0.f;
-          const float4 c0 = *reinterpret_cast<const float4*>(&s_ca[chl * SC_CST]);
-          v = sc_prologue(p.dy.mode, p.dy.act, xg, au, c0, s_ca[chl * SC_CST + 4]);
-        }
+    sn = n; sy0 = y0; sx0 = x0; sp0 = p0;
+    const size_t HW = (size_t)H * W;
+    {
+      bool okp;
+      const int po = a_pix(y0, x0, p0, okp);
+      const int ch0 = cot * COT + a_c0;
+      const size_t base = ((size_t)n * p.Cout + ch0) * HW + (okp ? po : 0);
+      const float* gp = p.dy.x + base;
+      const float* yp = (dymode == SC_SRC_BNBWD) ? p.dy.aux + base : gp;
+#pragma unroll
+      for (int i = 0; i < NAI; ++i) {
+        const size_t o = (ch0 + ACH * i < p.Cout) ? (size_t)(ACH * i) * HW : 0;     // clamped, unconditional loads
+        ag[i] = gp[o];
+        ay[i] = yp[o];
       }
-      s_a[chl * PA + px] = v;
     }
-    // ---- stage input patch ----
-    for (int i = tid; i < NEB; i += 256) {
-      const int chl = i / (PRW * PCW), e = i - chl * (PRW * PCW);
-      const int ch = cit * CIT + chl;
-      float v = 0.f;
-      if (ch < p.Cin) {
+    {
+      int off0[NBJ], off1[NBJ];
+#pragma unroll
+      for (int j = 0; j < NBJ; ++j) {
+        bool ok;
+        const int o0 = b_pos(j, y0, x0, p0, p.s0.up, ok);
+        off0[j] = ok ? o0 : 0;
+        const int o1 = b_pos(j, y0, x0, p0, p.s1.up, ok);
+        off1[j] = ok ? o1 : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < NBK; ++k) {
+        const int chr = cit * CIT + b_c0 + 8 * k;
+        const int ch = chr < p.Cin ? chr : 0;
         const bool second = ch >= C0;
         const int cs = second ? ch - C0 : ch;
-        const float* xp = second ? p.s1.x : p.s0.x;
         const int Cs = second ? p.s1.C : p.s0.C;
         const int up = second ? p.s1.up : p.s0.up;
-        const int mode = second ? p.s1.mode : p.s0.mode;
-        const int act = second ? p.s1.act : p.s0.act;
-        bool ok; size_t idx;
-        if (KS == 3) {
-          const int pr = e / PCW, pc = e - pr * PCW;
-          const int y = y0 - 1 + pr, x = x0 - 1 + pc;
-          ok = (y >= 0) && (y < H) && (x >= 0) && (x < W);
-          const int Hs = H >> up, Ws = W >> up;
-          idx = (((size_t)n * Cs + cs) * Hs + (y >> up)) * Ws + (x >> up);
-        } else {
-          const int pix = p0 + e;
-          ok = pix < H * W;
-          idx = ((size_t)n * Cs + cs) * H * W + pix;
+        const float* xp = (second ? p.s1.x : p.s0.x) + ((size_t)n * Cs + cs) * ((size_t)(H >> up) * (W >> up));
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j) bx[k][j] = xp[second ? off1[j] : off0[j]];
+      }
+    }
+  };
+
+  auto store_stage = [&]() {
+    {
+      bool okp;
+      (void)a_pix(sy0, sx0, sp0, okp);
+      if (dymode == SC_SRC_BNBWD) {
+#pragma unroll
+        for (int i = 0; i < NAI; ++i) {
+          const int chl = a_c0 + ACH * i;
+          const float4 c0 = *reinterpret_cast<const float4*>(&s_ca[chl * SC_CST]);
+          const float v = sc_pro_bnbwd(ag[i], ay[i], c0.x, c0.y, c0.z, c0.w, s_ca[chl * SC_CST + 4], dlo, dhi);
+          s_a[chl * PA + a_px] = (okp && (cot * COT + chl < p.Cout)) ? v : 0.f;
         }
-        if (ok) {
-          const float xg = xp[idx];
-          const float4 c0 = *reinterpret_cast<const float4*>(&s_cb[chl * SC_CST]);
-          v = sc_prologue(mode, act, xg, 0.f, c0, 0.f);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NAI; ++i) {
+          const int chl = a_c0 + ACH * i;
+          const float2 c0 = *reinterpret_cast<const float2*>(&s_ca[chl * SC_CST]);
+          const float v = sc_pro_affine(ag[i], c0.x, c0.y, dlo, dhi);
+          s_a[chl * PA + a_px] = (okp && (cot * COT + chl < p.Cout)) ? v : 0.f;
         }
       }
-      s_b[chl * PB + e] = v;
     }
+    bool okj[NBJ];
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) (void)b_pos(j, sy0, sx0, sp0, 0, okj[j]);
+#pragma unroll
+    for (int k = 0; k < NBK; ++k) {
+      const int chl = b_c0 + 8 * k;
+      const int ch = cit * CIT + chl;
+      const bool second = ch >= C0;
+      const int act = second ? p.s1.act : p.s0.act;
+      const float lo = sc_act_lo(act), hi = sc_act_hi(act);
+      const float2 c0 = *reinterpret_cast<const float2*>(&s_cb[chl * SC_CST]);
+      const bool okc = ch < p.Cin;
+#pragma unroll
+      for (int j = 0; j < NBJ; ++j) {
+        const int e = b_q + 32 * j;
+        if (e < BPOS) s_b[chl * PB + e] = (okj[j] && okc) ? sc_pro_affine(bx[k][j], c0.x, c0.y, lo, hi) : 0.f;
+      }
+    }
+  };
+
+  if (t_begin < t_end) {
+    load_stage(t_begin);
+    __syncthreads();          // constants in LDS
+    store_stage();
     __syncthreads();
-    // ---- MFMA ----
+  }
+  for (long t = t_begin; t < t_end; ++t) {
+    const bool more = (t + 1) < t_end;
+    if (more) load_stage(t + 1);
+    // ---- MFMA on the staged tile ----
 #pragma unroll
     for (int rr0 = 0; rr0 < RW; ++rr0) {
       const int rr = wk * RW + rr0;
@@ -418,6 +495,9 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const WgradP p) {
         }
       }
     }
+    __syncthreads();
+    if (more) store_stage();
+    __syncthreads();
   }
   // ---- partial store: part[((slice*WK + wk)*TAPS + tap)*CoP*CiP + co*CiP + ci] ----
   const int ci = cit * CIT + wn * 32 + l31;

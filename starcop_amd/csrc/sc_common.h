@@ -69,6 +69,20 @@ __device__ __forceinline__ float sc_prologue(int mode, int act, float x, float a
   return fminf(fmaxf(v, c0.z), c0.w);
 }
 
+// ---- branch-free prologues for the hot kernels (mode is uniform per source; NORM is only used by the stem) ----
+// act limits: none -> (-inf, +inf), relu -> (0, +inf), relu6 -> (0, 6)
+__device__ __forceinline__ float sc_act_lo(int act) { return act == SC_ACT_NONE ? -__builtin_inff() : 0.f; }
+__device__ __forceinline__ float sc_act_hi(int act) { return act == SC_ACT_RELU6 ? 6.f : __builtin_inff(); }
+// SC_SRC_RAW is the affine form with scale 1, shift 0, no limits
+__device__ __forceinline__ float sc_pro_affine(float x, float sc, float sh, float lo, float hi) {
+  return fminf(fmaxf(fmaf(x, sc, sh), lo), hi);
+}
+__device__ __forceinline__ float sc_pro_bnbwd(float g, float y, float sc, float sh, float A, float B, float D, float lo, float hi) {
+  const float yh = fmaf(y, sc, sh);
+  const float gm = (yh > lo && yh < hi) ? g : 0.f;
+  return fmaf(gm, A, fmaf(y, B, D));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -227,9 +227,14 @@ class HyperStarcopUNet(nn.Module):
     # -- optional per-kernel-family timing (bench.py roofline): events on the launch stream
     profile = None
 
+    profile_detail = False
+    _cur_op = ""
+
     def _pb(self, fam, flop=0.0):
         if self.profile is None:
             return None
+        if self.profile_detail:
+            fam = f"{self._cur_op}|{fam}"
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         return (fam, flop, e0, e1)
@@ -391,6 +396,7 @@ class HyperStarcopUNet(nn.Module):
             stats = ptr(plan.stats_v[o.name]) if (training and o.bn is not None) else None
             conv = op.get("conv")
             tok = None
+            self._cur_op = o.name + ":fwd"
             if self.profile is not None:
                 if ty in ("pw", "conv3"):
                     tok = self._pb(f"k_conv_mfma<{conv.kernel_size[0]}> (fwd+dgrad)",
@@ -477,6 +483,7 @@ class HyperStarcopUNet(nn.Module):
             ty, o = op["type"], op["out"]
             Ho, Wo = H >> o.shift, W >> o.shift
             conv = op.get("conv")
+            self._cur_op = o.name + ":bwd"
             if ty == "head":
                 tin = op["ins"][0]
                 s = self._src_of(plan, tin)
