@@ -32,36 +32,43 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* s_tmp /* [4][NV
 }
 
 // ---------------------------------------------------------------- depthwise
+// One (n, c) plane tile per block: TW x TH outputs (TW in {32,16}, TH = 256/TW), one output per thread.  The input
+// patch is staged ONCE through LDS with the producer's BatchNorm+ReLU6 applied on the way (branch-free prologue,
+// clamped unconditional loads), so every HBM element is read once per tile and transformed once.
+template <int S, int TW>
 __global__ __launch_bounds__(256) void k_dw_fwd(const SrcD in, const float* __restrict__ w, float* __restrict__ out,
-                                                int C, int Hin, int Win, int Hout, int Wout, int stride, double* stats) {
+                                                int C, int Hin, int Win, int Hout, int Wout, double* stats) {
+  constexpr int TH = 256 / TW;
+  constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PWP = PW | 1;
+  __shared__ float s_x[PH * PWP];
   __shared__ float s_tmp[8];
   const int c = blockIdx.y, n = blockIdx.z;
-  const int tiles_x = (Wout + 15) >> 4;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int oy = ty * 16 + (threadIdx.x >> 4), ox = tx * 16 + (threadIdx.x & 15);
-  const bool ok = (oy < Hout) && (ox < Wout);
+  const int tiles_x = (Wout + TW - 1) / TW;
+  const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+  float sc = 1.f, sh = 0.f;
+  if (in.mode != SC_SRC_RAW) { sc = in.cst[(size_t)c * SC_CST]; sh = in.cst[(size_t)c * SC_CST + 1]; }
+  const float lo = sc_act_lo(in.act), hi = sc_act_hi(in.act);
+  const float* xb = in.x + ((size_t)n * C + c) * Hin * Win;
+  for (int e = threadIdx.x; e < PH * PW; e += 256) {
+    const int r = e / PW, cc = e - r * PW;
+    const int iy = ty0 * S - 1 + r, ix = tx0 * S - 1 + cc;
+    const bool ok = (iy >= 0) && (iy < Hin) && (ix >= 0) && (ix < Win);
+    const float v = sc_pro_affine(xb[ok ? iy * Win + ix : 0], sc, sh, lo, hi);
+    s_x[r * PWP + cc] = ok ? v : 0.f;
+  }
   float wk[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wk[t] = w[c * 9 + t];
-  float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f); float c4 = 0.f;
-  if (in.mode != SC_SRC_RAW) { c0 = *reinterpret_cast<const float4*>(in.cst + (size_t)c * SC_CST); c4 = in.cst[(size_t)c * SC_CST + 4]; }
-  const size_t ibase = ((size_t)n * C + c) * Hin * Win;
+  __syncthreads();
+  const int ty = threadIdx.x / TW, tx = threadIdx.x % TW;
+  const int oy = ty0 + ty, ox = tx0 + tx;
+  const bool ok = (oy < Hout) && (ox < Wout);
   float acc = 0.f;
-  if (ok) {
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int iy = oy * stride + kh - 1;
+  for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int ix = ox * stride + kw - 1;
-        if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
-          const float v = sc_prologue(in.mode, in.act, in.x[ibase + (size_t)iy * Win + ix], 0.f, c0, c4);
-          acc = fmaf(wk[kh * 3 + kw], v, acc);
-        }
-      }
-    }
-    out[((size_t)n * C + c) * Hout * Wout + (size_t)oy * Wout + ox] = acc;
-  }
+    for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kh * 3 + kw], s_x[(ty * S + kh) * PWP + tx * S + kw], acc);
+  if (ok) out[((size_t)n * C + c) * Hout * Wout + (size_t)oy * Wout + ox] = acc;
   if (stats) {
     float v[2] = {ok ? acc : 0.f, ok ? acc * acc : 0.f};
     block_sum<2>(v, s_tmp);
@@ -69,67 +76,107 @@ __global__ __launch_bounds__(256) void k_dw_fwd(const SrcD in, const float* __re
   }
 }
 
+// dy patch (BatchNorm/ReLU6 backward applied on load) staged once; dx tile = TW x TH input pixels
+template <int S, int TW>
 __global__ __launch_bounds__(256) void k_dw_dgrad(const SrcD dy, const float* __restrict__ w, float* __restrict__ dx,
-                                                  int accum, int C, int Hin, int Win, int Hout, int Wout, int stride) {
+                                                  int accum, int C, int Hin, int Win, int Hout, int Wout) {
+  constexpr int TH = 256 / TW;
+  constexpr int PH = (S == 1) ? TH + 2 : TH / 2 + 1, PW = (S == 1) ? TW + 2 : TW / 2 + 1, PWP = PW | 1;
+  __shared__ float s_d[PH * PWP];
   const int c = blockIdx.y, n = blockIdx.z;
-  const int tiles_x = (Win + 15) >> 4;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int iy = ty * 16 + (threadIdx.x >> 4), ix = tx * 16 + (threadIdx.x & 15);
-  if (iy >= Hin || ix >= Win) return;
-  float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f); float c4 = 0.f;
+  const int tiles_x = (Win + TW - 1) / TW;
+  const int iy0 = (blockIdx.x / tiles_x) * TH, ix0 = (blockIdx.x % tiles_x) * TW;
+  const int oyb = (S == 1) ? iy0 - 1 : iy0 / 2, oxb = (S == 1) ? ix0 - 1 : ix0 / 2;
+  float4 c0 = make_float4(1.f, 0.f, 0.f, 0.f); float c4 = 0.f;
   if (dy.mode != SC_SRC_RAW) { c0 = *reinterpret_cast<const float4*>(dy.cst + (size_t)c * SC_CST); c4 = dy.cst[(size_t)c * SC_CST + 4]; }
+  const float lo = sc_act_lo(dy.act), hi = sc_act_hi(dy.act);
   const size_t obase = ((size_t)n * C + c) * Hout * Wout;
+  const float* gb = dy.x + obase;
+  const float* yb = (dy.mode == SC_SRC_BNBWD) ? dy.aux + obase : gb;
+  const bool bnb = dy.mode == SC_SRC_BNBWD;
+  for (int e = threadIdx.x; e < PH * PW; e += 256) {
+    const int r = e / PW, cc = e - r * PW;
+    const int oy = oyb + r, ox = oxb + cc;
+    const bool ok = (oy >= 0) && (oy < Hout) && (ox >= 0) && (ox < Wout);
+    const int o = ok ? oy * Wout + ox : 0;
+    const float g = gb[o], yv = yb[o];
+    const float v = bnb ? sc_pro_bnbwd(g, yv, c0.x, c0.y, c0.z, c0.w, c4, lo, hi) : sc_pro_affine(g, c0.x, c0.y, lo, hi);
+    s_d[r * PWP + cc] = ok ? v : 0.f;
+  }
+  float wk[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wk[t] = w[c * 9 + t];
+  __syncthreads();
+  const int ty = threadIdx.x / TW, tx = threadIdx.x % TW;
+  const int iy = iy0 + ty, ix = ix0 + tx;
+  if (iy >= Hin || ix >= Win) return;
   float acc = 0.f;
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh) {
-    const int t = iy + 1 - kh;
-    if (t < 0 || (t % stride) != 0) continue;
-    const int oy = t / stride;
-    if (oy >= Hout) continue;
+    const int t = iy + 1 - kh;                 // = oy * S
+    if (S == 2 && (t & 1)) continue;
+    const int r = (S == 1 ? t : t / 2) - oyb;  // t >= -1 only when S == 1 (zero-padded patch row)
+    if (S == 2 && t < 0) continue;
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
       const int u = ix + 1 - kw;
-      if (u < 0 || (u % stride) != 0) continue;
-      const int ox = u / stride;
-      if (ox >= Wout) continue;
-      const size_t idx = obase + (size_t)oy * Wout + ox;
-      const float au = (dy.mode == SC_SRC_BNBWD) ? dy.aux[idx] : 0.f;
-      const float v = sc_prologue(dy.mode, dy.act, dy.x[idx], au, c0, c4);
-      acc = fmaf(w[c * 9 + kh * 3 + kw], v, acc);
+      if (S == 2 && ((u & 1) || u < 0)) continue;
+      const int cc = (S == 1 ? u : u / 2) - oxb;
+      acc = fmaf(wk[kh * 3 + kw], s_d[r * PWP + cc], acc);
     }
   }
   const size_t o = ((size_t)n * C + c) * Hin * Win + (size_t)iy * Win + ix;
   dx[o] = accum ? dx[o] + acc : acc;
 }
 
-__global__ __launch_bounds__(256) void k_dw_wgrad(const SrcD dy, const SrcD in, double* __restrict__ dw_acc, int C,
-                                                  int Hin, int Win, int Hout, int Wout, int stride) {
+// dW[c][tap] += sum over this block's (n, tile) list of dy * x; 9 double atomics per block
+template <int S, int TW>
+__global__ __launch_bounds__(256) void k_dw_wgrad(const SrcD dy, const SrcD in, double* __restrict__ dw_acc, int N, int C,
+                                                  int Hin, int Win, int Hout, int Wout) {
+  constexpr int TH = 256 / TW;
+  constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PWP = PW | 1;
+  __shared__ float s_x[PH * PWP];
   __shared__ float s_tmp[36];
-  const int c = blockIdx.y, n = blockIdx.z;
-  const int tiles_x = (Wout + 15) >> 4;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int oy = ty * 16 + (threadIdx.x >> 4), ox = tx * 16 + (threadIdx.x & 15);
-  const bool ok = (oy < Hout) && (ox < Wout);
+  const int c = blockIdx.y;
+  const int tiles_x = (Wout + TW - 1) / TW, tiles_y = (Hout + TH - 1) / TH;
+  const int per_img = tiles_x * tiles_y;
+  const long T = (long)N * per_img;
+  float xs = 1.f, xh = 0.f;
+  if (in.mode != SC_SRC_RAW) { xs = in.cst[(size_t)c * SC_CST]; xh = in.cst[(size_t)c * SC_CST + 1]; }
+  const float xlo = sc_act_lo(in.act), xhi = sc_act_hi(in.act);
+  float4 c0 = make_float4(1.f, 0.f, 0.f, 0.f); float c4 = 0.f;
+  if (dy.mode != SC_SRC_RAW) { c0 = *reinterpret_cast<const float4*>(dy.cst + (size_t)c * SC_CST); c4 = dy.cst[(size_t)c * SC_CST + 4]; }
+  const float dlo = sc_act_lo(dy.act), dhi = sc_act_hi(dy.act);
+  const bool bnb = dy.mode == SC_SRC_BNBWD;
+  const int ty = threadIdx.x / TW, tx = threadIdx.x % TW;
   float prod[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) prod[t] = 0.f;
-  if (ok) {
-    const float dyv = load_src(dy, ((size_t)n * C + c) * Hout * Wout + (size_t)oy * Wout + ox, c);
-    float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f); float c4 = 0.f;
-    if (in.mode != SC_SRC_RAW) { c0 = *reinterpret_cast<const float4*>(in.cst + (size_t)c * SC_CST); c4 = in.cst[(size_t)c * SC_CST + 4]; }
-    const size_t ibase = ((size_t)n * C + c) * Hin * Win;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int iy = oy * stride + kh - 1;
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int ix = ox * stride + kw - 1;
-        if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
-          const float v = sc_prologue(in.mode, in.act, in.x[ibase + (size_t)iy * Win + ix], 0.f, c0, c4);
-          prod[kh * 3 + kw] = dyv * v;
-        }
-      }
+  for (long t = blockIdx.x; t < T; t += gridDim.x) {
+    const int n = (int)(t / per_img);
+    const int rem = (int)(t - (long)n * per_img);
+    const int ty0 = (rem / tiles_x) * TH, tx0 = (rem % tiles_x) * TW;
+    const float* xb = in.x + ((size_t)n * C + c) * Hin * Win;
+    __syncthreads();
+    for (int e = threadIdx.x; e < PH * PW; e += 256) {
+      const int r = e / PW, cc = e - r * PW;
+      const int iy = ty0 * S - 1 + r, ix = tx0 * S - 1 + cc;
+      const bool ok = (iy >= 0) && (iy < Hin) && (ix >= 0) && (ix < Win);
+      const float v = sc_pro_affine(xb[ok ? iy * Win + ix : 0], xs, xh, xlo, xhi);
+      s_x[r * PWP + cc] = ok ? v : 0.f;
     }
+    const int oy = ty0 + ty, ox = tx0 + tx;
+    const bool ok = (oy < Hout) && (ox < Wout);
+    const size_t o = ((size_t)n * C + c) * Hout * Wout + (ok ? (size_t)oy * Wout + ox : 0);
+    const float g = dy.x[o];
+    const float yv = bnb ? dy.aux[o] : g;
+    float dyv = bnb ? sc_pro_bnbwd(g, yv, c0.x, c0.y, c0.z, c0.w, c4, dlo, dhi) : sc_pro_affine(g, c0.x, c0.y, dlo, dhi);
+    dyv = ok ? dyv : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) prod[kh * 3 + kw] = fmaf(dyv, s_x[(ty * S + kh) * PWP + tx * S + kw], prod[kh * 3 + kw]);
   }
   block_sum<9>(prod, s_tmp);
   if (threadIdx.x < 9) atomicAdd(&dw_acc[c * 9 + threadIdx.x], (double)prod[threadIdx.x]);
@@ -390,14 +437,23 @@ int head_blocks(int N, int H, int W) {
 
 }  // namespace
 
+#define SC_DW_DISPATCH(KERNEL, W_, ...)                                                               \
+  do {                                                                                                 \
+    if (stride == 1 && (W_) > 16) hipLaunchKernelGGL((KERNEL<1, 32>), grid32, dim3(256), 0, st, __VA_ARGS__);      \
+    else if (stride == 1) hipLaunchKernelGGL((KERNEL<1, 16>), grid16, dim3(256), 0, st, __VA_ARGS__);  \
+    else if ((W_) > 16) hipLaunchKernelGGL((KERNEL<2, 32>), grid32, dim3(256), 0, st, __VA_ARGS__);    \
+    else hipLaunchKernelGGL((KERNEL<2, 16>), grid16, dim3(256), 0, st, __VA_ARGS__);                   \
+  } while (0)
+
 extern "C" int sc_dwconv3x3_fwd(const sc_src* in, const float* w, float* out, int N, int C, int Hin, int Win,
                                 int stride, double* stats, sc_stream stream) {
   SC_REQUIRE(in && in->C == C, "sc_dwconv3x3_fwd: source channels != C");
   SC_REQUIRE(stride == 1 || stride == 2, "sc_dwconv3x3_fwd: stride must be 1 or 2");
-  SC_REQUIRE(in->mode != SC_SRC_BNBWD && in->up == 0, "sc_dwconv3x3_fwd: unsupported source mode");
+  SC_REQUIRE((in->mode == SC_SRC_RAW || in->mode == SC_SRC_AFFINE) && in->up == 0, "sc_dwconv3x3_fwd: unsupported source mode");
   const int Hout = (Hin - 1) / stride + 1, Wout = (Win - 1) / stride + 1;
-  dim3 grid(((Wout + 15) / 16) * ((Hout + 15) / 16), C, N);
-  hipLaunchKernelGGL(k_dw_fwd, grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), w, out, C, Hin, Win, Hout, Wout, stride, stats);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid32(((Wout + 31) / 32) * ((Hout + 7) / 8), C, N), grid16(((Wout + 15) / 16) * ((Hout + 15) / 16), C, N);
+  SC_DW_DISPATCH(k_dw_fwd, Wout, to_srcd(*in), w, out, C, Hin, Win, Hout, Wout, stats);
   SC_LAUNCH_OK("sc_dwconv3x3_fwd");
   return SC_OK;
 }
@@ -406,9 +462,12 @@ extern "C" int sc_dwconv3x3_dgrad(const sc_src* dy, const float* w, float* dx, i
                                   int Win, int stride, sc_stream stream) {
   SC_REQUIRE(dy && dy->C == C, "sc_dwconv3x3_dgrad: source channels != C");
   SC_REQUIRE(stride == 1 || stride == 2, "sc_dwconv3x3_dgrad: stride must be 1 or 2");
+  SC_REQUIRE(dy->mode != SC_SRC_NORM && dy->up == 0, "sc_dwconv3x3_dgrad: unsupported source mode");
+  SC_REQUIRE(dy->mode != SC_SRC_BNBWD || dy->aux != nullptr, "sc_dwconv3x3_dgrad: BNBWD source needs aux");
   const int Hout = (Hin - 1) / stride + 1, Wout = (Win - 1) / stride + 1;
-  dim3 grid(((Win + 15) / 16) * ((Hin + 15) / 16), C, N);
-  hipLaunchKernelGGL(k_dw_dgrad, grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*dy), w, dx, accum, C, Hin, Win, Hout, Wout, stride);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid32(((Win + 31) / 32) * ((Hin + 7) / 8), C, N), grid16(((Win + 15) / 16) * ((Hin + 15) / 16), C, N);
+  SC_DW_DISPATCH(k_dw_dgrad, Win, to_srcd(*dy), w, dx, accum, C, Hin, Win, Hout, Wout);
   SC_LAUNCH_OK("sc_dwconv3x3_dgrad");
   return SC_OK;
 }
@@ -417,9 +476,14 @@ extern "C" int sc_dwconv3x3_wgrad(const sc_src* dy, const sc_src* in, double* dw
                                   int stride, sc_stream stream) {
   SC_REQUIRE(dy && in && dy->C == C && in->C == C, "sc_dwconv3x3_wgrad: source channels != C");
   SC_REQUIRE(stride == 1 || stride == 2, "sc_dwconv3x3_wgrad: stride must be 1 or 2");
+  SC_REQUIRE((in->mode == SC_SRC_RAW || in->mode == SC_SRC_AFFINE) && in->up == 0 && dy->mode != SC_SRC_NORM && dy->up == 0,
+             "sc_dwconv3x3_wgrad: unsupported source mode");
   const int Hout = (Hin - 1) / stride + 1, Wout = (Win - 1) / stride + 1;
-  dim3 grid(((Wout + 15) / 16) * ((Hout + 15) / 16), C, N);
-  hipLaunchKernelGGL(k_dw_wgrad, grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*dy), to_srcd(*in), dw_acc, C, Hin, Win, Hout, Wout, stride);
+  hipStream_t st = (hipStream_t)stream;
+  const long t32 = (long)N * ((Wout + 31) / 32) * ((Hout + 7) / 8), t16 = (long)N * ((Wout + 15) / 16) * ((Hout + 15) / 16);
+  const long want = 4096 / C > 0 ? 4096 / C : 1;
+  dim3 grid32((unsigned)(t32 < want ? t32 : want), C), grid16((unsigned)(t16 < want ? t16 : want), C);
+  SC_DW_DISPATCH(k_dw_wgrad, Wout, to_srcd(*dy), to_srcd(*in), dw_acc, N, C, Hin, Win, Hout, Wout);
   SC_LAUNCH_OK("sc_dwconv3x3_wgrad");
   return SC_OK;
 }

