@@ -105,6 +105,8 @@ def main():
 
     # ---- warm-up (also builds the plan); optionally capture the step into a hipGraph
     graph = None
+    if world > 1:
+        args.graph = 0        # RCCL collectives stay outside stream capture; eager launches are GPU-bound anyway
     n_eager = max(1, min(2, args.warmup)) if args.graph else args.warmup
     for _ in range(n_eager):
         step()

@@ -47,7 +47,9 @@ enum sc_src_mode {
 enum sc_act { SC_ACT_NONE = 0, SC_ACT_RELU = 1, SC_ACT_RELU6 = 2 };
 
 #define SC_CST 8          /* floats of per-channel constants per channel            */
-#define SC_STAT_SLOTS 32  /* atomics are spread over this many slots per channel     */
+/* BatchNorm statistics are written as per-work-group partial rows [rows][C][2] (plain stores, no atomics,
+ * deterministic) and summed in fp64 by sc_bn_finalize / sc_bn_bwd_finalize.  rows = sc_stat_rows(kind, ...) */
+enum sc_stat_kind { SC_STAT_CONV3 = 0, SC_STAT_CONV1 = 1, SC_STAT_DW = 2, SC_STAT_STEM = 3, SC_STAT_BNBWD = 4 };
 
 typedef struct sc_src {
   const float* x;    /* primary tensor  [N, C, H>>up, W>>up]                          */
@@ -83,8 +85,8 @@ size_t sc_packed_weight_floats(int Cout, int Cin, int ks, int co_t, int transpos
  *   input  = channel concat of nsrc (1|2) sources, each with its own prologue
  *   output = out0 (channels [0,csplit)) and out1 (channels [csplit,Cout)); csplit==Cout -> single
  *            out = acc (+ add0) (+ add1) (+ old out if accum flag)
- *   stats  : if non-NULL, per-channel sum / sum-of-squares of acc are atomically
- *            added to stats[slot][Cout][2] (double), slot in [0,SC_STAT_SLOTS)
+ *   stats  : if non-NULL, per-channel sum / sum-of-squares of acc over each work-group's pixel tile are written to
+ *            stats[row][Cout][2] (float), row = n*tiles + tile, rows = sc_stat_rows(SC_STAT_CONV3|CONV1, N, H, W)
  */
 typedef struct sc_conv_args {
   sc_src src[2];
@@ -99,7 +101,7 @@ typedef struct sc_conv_args {
   int32_t accum0, accum1;/* 1: out += result                                     */
   const float* add0;     /* optional [N,Cout,H,W] tensors added in the epilogue  */
   const float* add1;     /*   (only valid with csplit == Cout)                   */
-  double* stats;         /* [SC_STAT_SLOTS][Cout][2] or NULL                     */
+  float* stats;          /* [rows][Cout][2] partial sums or NULL                 */
 } sc_conv_args;
 int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream);
 
@@ -123,7 +125,8 @@ int sc_conv2d_wgrad_mfma(const sc_wgrad_args* a, sc_stream stream);
 /* ------------------------------------------------------------------------- */
 /* depthwise 3x3 (groups=C, pad 1, stride 1|2): forward, backward-data, backward-weight */
 int sc_dwconv3x3_fwd(const sc_src* in, const float* w /*[C][3][3]*/, float* out,
-                     int N, int C, int Hin, int Win, int stride, double* stats, sc_stream stream);
+                     int N, int C, int Hin, int Win, int stride, float* stats /* rows: SC_STAT_DW on (Hout,Wout) */,
+                     sc_stream stream);
 int sc_dwconv3x3_dgrad(const sc_src* dy, const float* w, float* dx, int accum,
                        int N, int C, int Hin, int Win, int stride, sc_stream stream);
 int sc_dwconv3x3_wgrad(const sc_src* dy, const sc_src* in, double* dw_acc /*[C][9] zeroed*/,
@@ -133,7 +136,8 @@ int sc_cast_f64_f32(const double* in, float* out, size_t n, sc_stream stream);
 /* stem: conv 3x3 stride 2 pad 1, Cin<=8 -> 32, input read through its prologue
  * (SC_SRC_NORM fuses DataNormalizer.normalize_x, starcop/data/normalizer_module.py:134-135) */
 int sc_stem_conv_fwd(const sc_src* in, const float* w /*[32][Cin][3][3]*/, float* out,
-                     int N, int Cin, int Hin, int Win, double* stats, sc_stream stream);
+                     int N, int Cin, int Hin, int Win, float* stats /* rows: SC_STAT_STEM on (Hout,Wout) */,
+                     sc_stream stream);
 size_t sc_stem_wgrad_workspace_floats(int N, int Cin, int Hin, int Win);
 int sc_stem_conv_wgrad(const sc_src* dy, const sc_src* in, float* part, size_t part_floats,
                        float* dw, int N, int Cin, int Hin, int Win, sc_stream stream);
@@ -149,17 +153,19 @@ int sc_head_conv_wgrad(const float* dlogits, const sc_src* in, float* part, size
 
 /* ------------------------------------------------------------------------- */
 /* BatchNorm2d bookkeeping (torch.nn.BatchNorm2d inside smp/torchvision blocks)
- * training=1: batch statistics from `stats` (count = N*H*W), running stats updated with
+ * training=1: batch statistics from the `nrows` partial rows of `stats` (count = N*H*W), running stats updated with
  *             `momentum` (unbiased variance), cst_fwd = {scale, shift, mean, invstd,...}
  * training=0: cst_fwd from running stats */
-int sc_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+int sc_stat_rows(int kind, int N, int H, int W);
+int sc_bn_finalize(const float* stats, int nrows, double count, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps,
                    int training, float* cst_fwd, int C, sc_stream stream);
-/* sums[slot][C][2] += { sum g_bn, sum g_bn * xhat }, g_bn = g * act'(BN(y)) */
+/* sums[row][C][2] = { sum g_bn, sum g_bn * xhat } over the row's pixels, g_bn = g * act'(BN(y));
+ * rows = sc_stat_rows(SC_STAT_BNBWD, N, H, W) */
 int sc_bn_bwd_reduce(const float* g, const float* y, const float* cst_fwd, int act,
                      double* sums, int N, int C, int HW, sc_stream stream);
 /* dgamma, dbeta and the SC_SRC_BNBWD constants {scale, shift, A, B, D} */
-int sc_bn_bwd_finalize(const double* sums, double count, const float* cst_fwd,
+int sc_bn_bwd_finalize(const double* sums, int nrows, double count, const float* cst_fwd,
                        float* dgamma, float* dbeta, float* cst_bwd, int C, sc_stream stream);
 /* out = v(a) + v(b)   (residual add of an inverted-residual block; b may be NULL) */
 int sc_add_srcs(const sc_src* a, const sc_src* b, float* out, int N, int C, int HW, sc_stream stream);

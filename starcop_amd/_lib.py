@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libstarcop_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 SC_CST = 8
-SC_STAT_SLOTS = 32
+STAT_CONV3, STAT_CONV1, STAT_DW, STAT_STEM, STAT_BNBWD = 0, 1, 2, 3, 4
 
 SRC_RAW, SRC_AFFINE, SRC_BNBWD, SRC_NORM = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
@@ -81,9 +81,10 @@ SIGNATURES = {
     "sc_head_conv_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sc_head_wgrad_workspace_floats": (_sz, [_i, _i, _i, _i]),
     "sc_head_conv_wgrad": (_i, [_vp, C.POINTER(sc_src), _vp, _sz, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "sc_bn_finalize": (_i, [_vp, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _i, _vp]),
+    "sc_stat_rows": (_i, [_i, _i, _i, _i]),
+    "sc_bn_finalize": (_i, [_vp, _i, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _i, _vp]),
     "sc_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
-    "sc_bn_bwd_finalize": (_i, [_vp, _d, _vp, _vp, _vp, _vp, _i, _vp]),
+    "sc_bn_bwd_finalize": (_i, [_vp, _i, _d, _vp, _vp, _vp, _vp, _i, _vp]),
     "sc_add_srcs": (_i, [C.POINTER(sc_src), C.POINTER(sc_src), _vp, _i, _i, _i, _vp]),
     "sc_apply_src": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _vp]),
     "sc_downsum2x2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

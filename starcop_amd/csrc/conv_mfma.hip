@@ -26,7 +26,7 @@ struct ConvP {
   float* out0; float* out1;
   int csplit, accum0, accum1;
   const float* add0; const float* add1;
-  double* stats;
+  float* stats;
 };
 
 template <int KS, int RM>
@@ -37,11 +37,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
   constexpr int PC = (KS == 3) ? 34 : 32;
   constexpr int PCH = PR * PC;                 // patch floats per channel
   constexpr int NE = (PCH + 31) / 32;          // patch elements per thread (32 threads per channel)
-  constexpr int WCH = 8 * TAPS * CO_T;         // weight floats per chunk
+  constexpr int KC = (KS == 3) ? 8 : 16;       // input channels per K chunk (one barrier per chunk)
+  constexpr int NC = KC / 8;                   // channels staged per thread (8 half-waves, one channel each, NC rounds)
+  constexpr int WCH = KC * TAPS * CO_T;        // weight floats per chunk
   constexpr int NW = (WCH / 4 + 255) / 256;    // float4 per thread
 
   __shared__ __attribute__((aligned(16))) float s_w[2][WCH];
-  __shared__ float s_p[2][8 * PCH];
+  __shared__ float s_p[2][KC * PCH];
   __shared__ float s_red[4][CO_T][2];
 
   const int tid = threadIdx.x;
@@ -60,8 +62,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
   }
   const int C0 = p.s0.C;
   const int Cin = C0 + p.s1.C;
-  const int nk = Cin >> 3;
-  const float* wbase = p.wpk + (size_t)cot * Cin * (TAPS * CO_T);
+  const int nk = (Cin + KC - 1) / KC;          // packed filters are zero-padded to nk*KC input channels
+  const float* wbase = p.wpk + (size_t)cot * nk * WCH;
 
   floatx16 acc[RM];
 #pragma unroll
@@ -72,18 +74,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
   // ---- staging state (registers) ----
   const int sci = tid >> 5;     // channel of the chunk this thread stages
   const int sq = tid & 31;
-  float xv[NE], av[NE];
-  unsigned inb = 0;
-  float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float c4 = 0.f;
+  float xv[NC][NE], av[NC][NE];
+  unsigned inb = 0;                 // pixel validity is the same for every channel of the chunk
+  bool chok[NC];
+  float4 c0[NC];
+  float c4[NC];
   int smode = 0, sact = 0;
   floatx4 wv[NW];
 
   float slo = 0.f, shi = 0.f;
   auto load_chunk = [&](int kc) {
-    const int c = kc * 8 + sci;
-    const bool second = c >= C0;
-    const int cs = second ? c - C0 : c;
+    // the source (of a concat) is uniform per chunk: KC divides the first source's channel count when nsrc == 2
+    const bool second = kc * KC >= C0;
     const float* xp = second ? p.s1.x : p.s0.x;
     const float* ap = second ? p.s1.aux : p.s0.aux;
     const float* cp = second ? p.s1.cst : p.s0.cst;
@@ -92,40 +94,43 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
     smode = second ? p.s1.mode : p.s0.mode;
     sact = second ? p.s1.act : p.s0.act;
     slo = sc_act_lo(sact); shi = sc_act_hi(sact);
-    if (smode != SC_SRC_RAW) {
-      c0 = *reinterpret_cast<const float4*>(cp + (size_t)cs * SC_CST);
-      c4 = cp[(size_t)cs * SC_CST + 4];
-    } else {
-      c0 = make_float4(1.f, 0.f, 0.f, 0.f); c4 = 0.f;
-    }
+    const int Hs = H >> up, Ws = W >> up;
+    // per-thread pixel offsets of this tile (shared by the NC channels)
+    int off[NE];
     inb = 0;
-    if (KS == 3) {
-      const int Hs = H >> up, Ws = W >> up;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      bool ok;
+      if (KS == 3) {
+        const int e = sq + 32 * i;
+        const int pr = e / PC, pc = e - pr * PC;
+        const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+        ok = (e < PCH) && (y >= 0) && (y < H) && (x >= 0) && (x < W);
+        off[i] = ok ? (y >> up) * Ws + (x >> up) : 0;      // clamped: unconditional loads, no exec-mask branches
+      } else {
+        const int pix = p0 + sq + 32 * i;
+        ok = pix < H * W;
+        off[i] = ok ? pix : 0;
+      }
+      inb |= ok ? (1u << i) : 0u;
+    }
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+      const int cg = kc * KC + sci + 8 * cc;          // channel in concat space
+      chok[cc] = cg < Cin;
+      const int cs = chok[cc] ? (second ? cg - C0 : cg) : 0;
+      if (smode != SC_SRC_RAW) {
+        c0[cc] = *reinterpret_cast<const float4*>(cp + (size_t)cs * SC_CST);
+        c4[cc] = cp[(size_t)cs * SC_CST + 4];
+      } else {
+        c0[cc] = make_float4(1.f, 0.f, 0.f, 0.f); c4[cc] = 0.f;
+      }
       const float* xb = xp + ((size_t)n * Cs + cs) * Hs * Ws;
       const float* ab = (smode == SC_SRC_BNBWD) ? ap + ((size_t)n * Cs + cs) * Hs * Ws : xb;
 #pragma unroll
       for (int i = 0; i < NE; ++i) {
-        const int e = sq + 32 * i;
-        const int pr = e / PC, pc = e - pr * PC;
-        const int y = y0 - 1 + pr, x = x0 - 1 + pc;
-        const bool ok = (e < PCH) && (y >= 0) && (y < H) && (x >= 0) && (x < W);
-        const int off = ok ? (y >> up) * Ws + (x >> up) : 0;      // clamped: unconditional loads, no exec-mask branches
-        xv[i] = xb[off];
-        av[i] = ab[off];
-        inb |= ok ? (1u << i) : 0u;
-      }
-    } else {
-      const int HW = H * W;
-      const float* xb = xp + ((size_t)n * Cs + cs) * HW;
-      const float* ab = (smode == SC_SRC_BNBWD) ? ap + ((size_t)n * Cs + cs) * HW : xb;
-#pragma unroll
-      for (int i = 0; i < NE; ++i) {
-        const int pix = p0 + sq + 32 * i;
-        const bool ok = pix < HW;
-        const int off = ok ? pix : 0;
-        xv[i] = xb[off];
-        av[i] = ab[off];
-        inb |= ok ? (1u << i) : 0u;
+        xv[cc][i] = xb[off[i]];
+        av[cc][i] = ab[off[i]];
       }
     }
     const floatx4* wsrc = reinterpret_cast<const floatx4*>(wbase + (size_t)kc * WCH);
@@ -137,22 +142,26 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
   };
 
   auto store_chunk = [&](int buf) {
-    if (smode == SC_SRC_BNBWD) {
 #pragma unroll
-      for (int i = 0; i < NE; ++i) {
-        const int e = sq + 32 * i;
-        if (e < PCH) {
-          const float v = sc_pro_bnbwd(xv[i], av[i], c0.x, c0.y, c0.z, c0.w, c4, slo, shi);
-          s_p[buf][sci * PCH + e] = ((inb >> i) & 1u) ? v : 0.f;
+    for (int cc = 0; cc < NC; ++cc) {
+      const int chl = sci + 8 * cc;
+      if (smode == SC_SRC_BNBWD) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+          const int e = sq + 32 * i;
+          if (e < PCH) {
+            const float v = sc_pro_bnbwd(xv[cc][i], av[cc][i], c0[cc].x, c0[cc].y, c0[cc].z, c0[cc].w, c4[cc], slo, shi);
+            s_p[buf][chl * PCH + e] = (((inb >> i) & 1u) && chok[cc]) ? v : 0.f;
+          }
         }
-      }
-    } else {
+      } else {
 #pragma unroll
-      for (int i = 0; i < NE; ++i) {
-        const int e = sq + 32 * i;
-        if (e < PCH) {
-          const float v = sc_pro_affine(xv[i], c0.x, c0.y, slo, shi);
-          s_p[buf][sci * PCH + e] = ((inb >> i) & 1u) ? v : 0.f;
+        for (int i = 0; i < NE; ++i) {
+          const int e = sq + 32 * i;
+          if (e < PCH) {
+            const float v = sc_pro_affine(xv[cc][i], c0[cc].x, c0[cc].y, slo, shi);
+            s_p[buf][chl * PCH + e] = (((inb >> i) & 1u) && chok[cc]) ? v : 0.f;
+          }
         }
       }
     }
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
 
   auto compute_chunk = [&](int buf) {
 #pragma unroll
-    for (int cp = 0; cp < 4; ++cp) {
+    for (int cp = 0; cp < KC / 2; ++cp) {
       const int cil = 2 * cp + lhi;
 #pragma unroll
       for (int tap = 0; tap < TAPS; ++tap) {
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
       const int co = cot * CO_T + col;
       if (co < p.Cout) {
         const float t = s_red[0][col][k] + s_red[1][col][k] + s_red[2][col][k] + s_red[3][col][k];
-        atomicAdd(&p.stats[((size_t)stat_slot() * p.Cout + co) * 2 + k], (double)t);
+        p.stats[(stat_row() * p.Cout + co) * 2 + k] = t;
       }
     }
   }
@@ -253,8 +262,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
 // ------------------------------------------------------------------------------------------
 // weight packing
 __global__ void k_pack_weights(const float* __restrict__ w, float* __restrict__ wpk, int Cout, int Cin,
-                               int taps, int co_t, int tflip, size_t total) {
-  // destination-major: wpk[((mt*K + k)*taps + tap)*co_t + col]
+                               int taps, int co_t, int tflip, int Kpad, size_t total) {
+  // destination-major: wpk[((mt*Kpad + k)*taps + tap)*co_t + col], Kpad = K rounded up to the kernel's chunk size
   //   forward : M = Cout, K = Cin,  value = w[((m*K + k)*taps) + tap]
   //   dgrad   : M = Cin,  K = Cout, value = w[((k*M + m)*taps) + (taps-1-tap)]
   const int M = tflip ? Cin : Cout, K = tflip ? Cout : Cin;
@@ -262,11 +271,11 @@ __global__ void k_pack_weights(const float* __restrict__ w, float* __restrict__ 
     const int col = (int)(i % co_t);
     size_t r = i / co_t;
     const int tap = (int)(r % taps); r /= taps;
-    const int k = (int)(r % K);
-    const int mt = (int)(r / K);
+    const int k = (int)(r % Kpad);
+    const int mt = (int)(r / Kpad);
     const int m = mt * co_t + col;
     float v = 0.f;
-    if (m < M) v = tflip ? w[((size_t)k * M + m) * taps + (taps - 1 - tap)] : w[((size_t)m * K + k) * taps + tap];
+    if (m < M && k < K) v = tflip ? w[((size_t)k * M + m) * taps + (taps - 1 - tap)] : w[((size_t)m * K + k) * taps + tap];
     wpk[i] = v;
   }
 }
@@ -559,7 +568,9 @@ WgradPlan plan_wgrad(int N, int H, int W, int Cout, int Cin, int ks) {
 extern "C" size_t sc_packed_weight_floats(int Cout, int Cin, int ks, int co_t, int transpose_flip) {
   const int M = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
   const size_t mt = (M + co_t - 1) / co_t;
-  return mt * K * ks * ks * co_t;
+  const int kc = ks == 3 ? 8 : 16;
+  const size_t Kpad = (size_t)(K + kc - 1) / kc * kc;
+  return mt * Kpad * ks * ks * co_t;
 }
 
 extern "C" int sc_pack_weights(const float* w, float* wpk, int Cout, int Cin, int ks, int co_t,
@@ -568,8 +579,9 @@ extern "C" int sc_pack_weights(const float* w, float* wpk, int Cout, int Cin, in
   SC_REQUIRE(co_t == 32 || co_t == 64, "sc_pack_weights: co_t must be 32 or 64 (got %d)", co_t);
   const size_t total = sc_packed_weight_floats(Cout, Cin, ks, co_t, transpose_flip);
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  const int Kg = transpose_flip ? Cout : Cin, kc = ks == 3 ? 8 : 16;
   hipLaunchKernelGGL(k_pack_weights, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wpk, Cout, Cin,
-                     ks * ks, co_t, transpose_flip, total);
+                     ks * ks, co_t, transpose_flip, (Kg + kc - 1) / kc * kc, total);
   SC_LAUNCH_OK("sc_pack_weights");
   return SC_OK;
 }
@@ -581,6 +593,7 @@ extern "C" int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream) {
   SC_REQUIRE(a->nsrc == 1 || a->nsrc == 2, "sc_conv2d_mfma: nsrc must be 1 or 2");
   const int C0 = a->src[0].C, C1 = a->nsrc == 2 ? a->src[1].C : 0;
   SC_REQUIRE(C0 > 0 && C0 % 8 == 0 && C1 % 8 == 0, "sc_conv2d_mfma: source channels must be multiples of 8 (got %d,%d)", C0, C1);
+  SC_REQUIRE(a->nsrc == 1 || a->ks == 3, "sc_conv2d_mfma: a channel concat of two sources needs ks=3");
   SC_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->Cout > 0, "sc_conv2d_mfma: bad shape");
   SC_REQUIRE(a->csplit > 0 && a->csplit <= a->Cout, "sc_conv2d_mfma: bad csplit");
   SC_REQUIRE(a->csplit == a->Cout || (a->add0 == nullptr && a->add1 == nullptr), "sc_conv2d_mfma: add tensors need a single output");

@@ -37,7 +37,7 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* s_tmp /* [4][NV
 // clamped unconditional loads), so every HBM element is read once per tile and transformed once.
 template <int S, int TW>
 __global__ __launch_bounds__(256) void k_dw_fwd(const SrcD in, const float* __restrict__ w, float* __restrict__ out,
-                                                int C, int Hin, int Win, int Hout, int Wout, double* stats) {
+                                                int C, int Hin, int Win, int Hout, int Wout, float* stats) {
   constexpr int TH = 256 / TW;
   constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PWP = PW | 1;
   __shared__ float s_x[PH * PWP];
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_dw_fwd(const SrcD in, const float* __re
   if (stats) {
     float v[2] = {ok ? acc : 0.f, ok ? acc * acc : 0.f};
     block_sum<2>(v, s_tmp);
-    if (threadIdx.x < 2) atomicAdd(&stats[((size_t)stat_slot() * C + c) * 2 + threadIdx.x], (double)v[threadIdx.x]);
+    if (threadIdx.x < 2) stats[(stat_row() * C + c) * 2 + threadIdx.x] = v[threadIdx.x];
   }
 }
 
@@ -187,7 +187,7 @@ constexpr int STEM_CO = 32;
 constexpr int STEM_MAXCI = 8;
 
 __global__ __launch_bounds__(256) void k_stem_fwd(const SrcD in, const float* __restrict__ w, float* __restrict__ out,
-                                                  int Cin, int Hin, int Win, int Hout, int Wout, double* stats) {
+                                                  int Cin, int Hin, int Win, int Hout, int Wout, float* stats) {
   __shared__ float s_w[STEM_CO * STEM_MAXCI * 9];
   __shared__ float s_red[4][STEM_CO][2];
   const int n = blockIdx.z;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const SrcD in, const float* __
     if (threadIdx.x < STEM_CO * 2) {
       const int co = threadIdx.x >> 1, k = threadIdx.x & 1;
       const float t = s_red[0][co][k] + s_red[1][co][k] + s_red[2][co][k] + s_red[3][co][k];
-      atomicAdd(&stats[((size_t)stat_slot() * STEM_CO + co) * 2 + k], (double)t);
+      stats[(stat_row() * STEM_CO + co) * 2 + k] = t;
     }
   }
 }
@@ -446,7 +446,7 @@ int head_blocks(int N, int H, int W) {
   } while (0)
 
 extern "C" int sc_dwconv3x3_fwd(const sc_src* in, const float* w, float* out, int N, int C, int Hin, int Win,
-                                int stride, double* stats, sc_stream stream) {
+                                int stride, float* stats, sc_stream stream) {
   SC_REQUIRE(in && in->C == C, "sc_dwconv3x3_fwd: source channels != C");
   SC_REQUIRE(stride == 1 || stride == 2, "sc_dwconv3x3_fwd: stride must be 1 or 2");
   SC_REQUIRE((in->mode == SC_SRC_RAW || in->mode == SC_SRC_AFFINE) && in->up == 0, "sc_dwconv3x3_fwd: unsupported source mode");
@@ -497,7 +497,7 @@ extern "C" int sc_cast_f64_f32(const double* in, float* out, size_t n, sc_stream
 }
 
 extern "C" int sc_stem_conv_fwd(const sc_src* in, const float* w, float* out, int N, int Cin, int Hin, int Win,
-                                double* stats, sc_stream stream) {
+                                float* stats, sc_stream stream) {
   SC_REQUIRE(in && in->C == Cin, "sc_stem_conv_fwd: source channels != Cin");
   SC_REQUIRE(Cin >= 1 && Cin <= STEM_MAXCI, "sc_stem_conv_fwd: Cin must be in [1,%d] (got %d)", STEM_MAXCI, Cin);
   SC_REQUIRE(in->mode != SC_SRC_BNBWD && in->up == 0, "sc_stem_conv_fwd: unsupported source mode");

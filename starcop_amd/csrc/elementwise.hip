@@ -44,27 +44,33 @@ __device__ __forceinline__ void block_sum_d(double (&v)[NV], double* s_tmp /* [4
 }
 
 // ---------------------------------------------------------------- BatchNorm
-__global__ void k_bn_finalize(const double* __restrict__ stats, double count, const float* __restrict__ gamma,
-                              const float* __restrict__ beta, float* running_mean, float* running_var, float momentum,
-                              float eps, int training, float* __restrict__ cst, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// one block per channel: fp64 sum of the per-work-group partial rows, then the per-channel constants
+__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ stats, int nrows, double count,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* running_mean, float* running_var, float momentum, float eps,
+                                                     int training, float* __restrict__ cst, int C) {
+  __shared__ double s_tmp[8];
+  const int c = blockIdx.x;
   double mean, var;
   if (training) {
-    double s = 0.0, q = 0.0;
-    for (int k = 0; k < SC_STAT_SLOTS; ++k) {
-      s += stats[((size_t)k * C + c) * 2];
-      q += stats[((size_t)k * C + c) * 2 + 1];
+    double v[2] = {0.0, 0.0};
+    for (int r = threadIdx.x; r < nrows; r += 256) {
+      const float2 t = *reinterpret_cast<const float2*>(stats + ((size_t)r * C + c) * 2);
+      v[0] += (double)t.x; v[1] += (double)t.y;
     }
-    mean = s / count;
-    var = q / count - mean * mean;
+    block_sum_d<2>(v, s_tmp);
+    mean = v[0] / count;
+    var = v[1] / count - mean * mean;
     if (var < 0.0) var = 0.0;
-    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
-    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
   } else {
     mean = (double)running_mean[c];
     var = (double)running_var[c];
+  }
+  if (threadIdx.x != 0) return;
+  if (training) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
   }
   const float meanf = (float)mean;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -75,39 +81,56 @@ __global__ void k_bn_finalize(const double* __restrict__ stats, double count, co
 }
 
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ g, const float* __restrict__ y,
-                                                       const float* __restrict__ cst, int act, double* sums, int C, int HW) {
+                                                       const float* __restrict__ cst, int act, double* __restrict__ sums, int C, int HW) {
   __shared__ double s_tmp[8];
   const int c = blockIdx.y, n = blockIdx.z;
   const float scale = cst[(size_t)c * SC_CST], shift = cst[(size_t)c * SC_CST + 1];
   const float mean = cst[(size_t)c * SC_CST + 2], invstd = cst[(size_t)c * SC_CST + 3];
+  const float lo = sc_act_lo(act), hi = sc_act_hi(act);
   const size_t base = ((size_t)n * C + c) * HW;
   const int start = blockIdx.x * 4096;
   const int end = min(start + 4096, HW);
   float s1 = 0.f, s2 = 0.f;
-  for (int i = start + threadIdx.x; i < end; i += 256) {
-    const float yv = y[base + i], gv = g[base + i];
-    const float yh = fmaf(yv, scale, shift);
-    bool pass = true;
-    if (act == SC_ACT_RELU) pass = yh > 0.f;
-    else if (act == SC_ACT_RELU6) pass = (yh > 0.f) && (yh < 6.f);
-    const float gb = pass ? gv : 0.f;
-    s1 += gb;
-    s2 = fmaf(gb, (yv - mean) * invstd, s2);
+  if ((HW & 3) == 0) {
+    for (int i = start + threadIdx.x * 4; i < end; i += 1024) {
+      const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
+      const float4 gv = *reinterpret_cast<const float4*>(g + base + i);
+      const float ya[4] = {yv.x, yv.y, yv.z, yv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float yh = fmaf(ya[k], scale, shift);
+        const float gb = (yh > lo && yh < hi) ? ga[k] : 0.f;
+        s1 += gb;
+        s2 = fmaf(gb, (ya[k] - mean) * invstd, s2);
+      }
+    }
+  } else {
+    for (int i = start + threadIdx.x; i < end; i += 256) {
+      const float yv = y[base + i], gv = g[base + i];
+      const float yh = fmaf(yv, scale, shift);
+      const float gb = (yh > lo && yh < hi) ? gv : 0.f;
+      s1 += gb;
+      s2 = fmaf(gb, (yv - mean) * invstd, s2);
+    }
   }
   double v[2] = {(double)s1, (double)s2};
   block_sum_d<2>(v, s_tmp);
-  if (threadIdx.x < 2) atomicAdd(&sums[((size_t)stat_slot() * C + c) * 2 + threadIdx.x], v[threadIdx.x]);
+  if (threadIdx.x < 2) sums[(stat_row() * C + c) * 2 + threadIdx.x] = v[threadIdx.x];
 }
 
-__global__ void k_bn_bwd_finalize(const double* __restrict__ sums, double count, const float* __restrict__ cst_fwd,
-                                  float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ cst_bwd, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < SC_STAT_SLOTS; ++k) {
-    s1 += sums[((size_t)k * C + c) * 2];
-    s2 += sums[((size_t)k * C + c) * 2 + 1];
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const double* __restrict__ sums, int nrows, double count,
+                                                         const float* __restrict__ cst_fwd, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, float* __restrict__ cst_bwd, int C) {
+  __shared__ double s_tmp[8];
+  const int c = blockIdx.x;
+  double v[2] = {0.0, 0.0};
+  for (int r = threadIdx.x; r < nrows; r += 256) {
+    v[0] += sums[((size_t)r * C + c) * 2];
+    v[1] += sums[((size_t)r * C + c) * 2 + 1];
   }
+  block_sum_d<2>(v, s_tmp);
+  if (threadIdx.x != 0) return;
+  const double s1 = v[0], s2 = v[1];
   const double scale = cst_fwd[(size_t)c * SC_CST], mean = cst_fwd[(size_t)c * SC_CST + 2], invstd = cst_fwd[(size_t)c * SC_CST + 3];
   if (dbeta) dbeta[c] = (float)s1;
   if (dgamma) dgamma[c] = (float)s2;
@@ -300,12 +323,23 @@ int sc_reduce_rows(const float* part, int nparts, size_t E, float* scratch, floa
   return SC_OK;
 }
 
-extern "C" int sc_bn_finalize(const double* stats, double count, const float* gamma, const float* beta, float* running_mean,
-                              float* running_var, float momentum, float eps, int training, float* cst_fwd, int C,
-                              sc_stream stream) {
+extern "C" int sc_stat_rows(int kind, int N, int H, int W) {
+  switch (kind) {
+    case SC_STAT_CONV3: return N * ((W + 31) / 32) * ((H + 3) / 4);
+    case SC_STAT_CONV1: return N * ((H * W + 127) / 128);
+    case SC_STAT_DW: return N * (W > 16 ? ((W + 31) / 32) * ((H + 7) / 8) : ((W + 15) / 16) * ((H + 15) / 16));
+    case SC_STAT_STEM: return N * ((W + 15) / 16) * ((H + 15) / 16);
+    case SC_STAT_BNBWD: return N * ((H * W + 4095) / 4096);
+    default: return -1;
+  }
+}
+
+extern "C" int sc_bn_finalize(const float* stats, int nrows, double count, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, int training,
+                              float* cst_fwd, int C, sc_stream stream) {
   SC_REQUIRE(C > 0 && cst_fwd && gamma && beta && running_mean && running_var, "sc_bn_finalize: null argument");
-  SC_REQUIRE(!training || (stats && count > 0), "sc_bn_finalize: training needs stats and count");
-  hipLaunchKernelGGL(k_bn_finalize, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, count, gamma, beta,
+  SC_REQUIRE(!training || (stats && count > 0 && nrows > 0), "sc_bn_finalize: training needs stats rows and count");
+  hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, nrows, count, gamma, beta,
                      running_mean, running_var, momentum, eps, training, cst_fwd, C);
   SC_LAUNCH_OK("sc_bn_finalize");
   return SC_OK;
@@ -320,10 +354,10 @@ extern "C" int sc_bn_bwd_reduce(const float* g, const float* y, const float* cst
   return SC_OK;
 }
 
-extern "C" int sc_bn_bwd_finalize(const double* sums, double count, const float* cst_fwd, float* dgamma, float* dbeta,
-                                  float* cst_bwd, int C, sc_stream stream) {
-  SC_REQUIRE(sums && cst_fwd && cst_bwd && C > 0 && count > 0, "sc_bn_bwd_finalize: bad argument");
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, sums, count, cst_fwd,
+extern "C" int sc_bn_bwd_finalize(const double* sums, int nrows, double count, const float* cst_fwd, float* dgamma,
+                                  float* dbeta, float* cst_bwd, int C, sc_stream stream) {
+  SC_REQUIRE(sums && cst_fwd && cst_bwd && C > 0 && count > 0 && nrows > 0, "sc_bn_bwd_finalize: bad argument");
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(C), dim3(256), 0, (hipStream_t)stream, sums, nrows, count, cst_fwd,
                      dgamma, dbeta, cst_bwd, C);
   SC_LAUNCH_OK("sc_bn_bwd_finalize");
   return SC_OK;

@@ -107,6 +107,5 @@ int sc_reduce_rows(const float* part, int nparts, size_t E, float* scratch, floa
 int sc_reduce_rows_partial(const float* part, int nparts, size_t E, float* scratch, const float** rows_out,
                            int* nrows_out, hipStream_t st);
 
-__device__ __forceinline__ int stat_slot() {
-  return (int)((blockIdx.x + 7u * blockIdx.y + 13u * blockIdx.z) % SC_STAT_SLOTS);
-}
+// row of this work-group in a [rows][C][2] partial-statistics buffer (grid = (tiles, channel-tiles, N))
+__device__ __forceinline__ size_t stat_row() { return (size_t)blockIdx.z * gridDim.x + blockIdx.x; }

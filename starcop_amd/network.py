@@ -24,8 +24,8 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, SC_STAT_SLOTS, SRC_AFFINE, SRC_BNBWD,
-                   SRC_NORM, SRC_RAW, check, make_src, ptr, sc_conv_args, sc_wgrad_args, stream)
+from ._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD,
+                   STAT_CONV1, STAT_CONV3, STAT_DW, STAT_STEM, check, make_src, ptr, sc_conv_args, sc_wgrad_args, stream)
 
 MBV2_SETTINGS = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2),
                  (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1))
@@ -280,19 +280,19 @@ class HyperStarcopUNet(nn.Module):
             plan.N, plan.H, plan.W = N, H, W
             plan.buf, plan.grad = {}, {}
             f32 = dict(dtype=torch.float32, device=dev)
-            n_bn_ch = sum(t.C for t in self._tensors.values() if t.bn is not None)
-            plan.stats = torch.zeros(n_bn_ch * SC_STAT_SLOTS * 2, dtype=torch.float64, device=dev)
-            plan.bsums = torch.zeros(n_bn_ch * SC_STAT_SLOTS * 2, dtype=torch.float64, device=dev)
-            plan.cst, plan.cstb, plan.stats_v, plan.bsums_v = {}, {}, {}, {}
-            off = 0
-            for t in self._tensors.values():
-                if t.kind != "input":
+            lib = _lib.load()
+            plan.cst, plan.cstb, plan.stats_v, plan.bsums_v, plan.srows, plan.brows = {}, {}, {}, {}, {}, {}
+            kind_of = {"stem": STAT_STEM, "dw": STAT_DW, "conv3": STAT_CONV3, "pw": STAT_CONV1}
+            for op in self._ops:
+                t = op["out"]
+                if t.kind != "input" and t.name not in plan.buf:
                     plan.buf[t.name] = torch.empty((N, t.C, H >> t.shift, W >> t.shift), **f32)
                 if t.bn is not None:
-                    n = t.C * SC_STAT_SLOTS * 2
-                    plan.stats_v[t.name] = plan.stats[off:off + n]
-                    plan.bsums_v[t.name] = plan.bsums[off:off + n]
-                    off += n
+                    Ho, Wo = H >> t.shift, W >> t.shift
+                    # per-work-group partial rows [rows][C][2] (plain stores; summed in fp64 by the finalize kernels)
+                    plan.srows[t.name] = lib.sc_stat_rows(kind_of[op["type"]], N, Ho, Wo)
+                    plan.brows[t.name] = lib.sc_stat_rows(STAT_BNBWD, N, Ho, Wo)
+                    plan.stats_v[t.name] = torch.empty(plan.srows[t.name] * t.C * 2, **f32)
                     plan.cst[t.name] = torch.zeros((t.C, SC_CST), **f32)
                     plan.cstb[t.name] = torch.zeros((t.C, SC_CST), **f32)
             plan.has_grad = False
@@ -325,6 +325,9 @@ class HyperStarcopUNet(nn.Module):
             plan.ws_floats = ws
             plan.up_tmp = torch.empty(max(up, 1), **f32)
             plan.dw_acc = torch.zeros(n_dw, dtype=torch.float64, device=dev)
+            for t in self._tensors.values():
+                if t.bn is not None:
+                    plan.bsums_v[t.name] = torch.empty(plan.brows[t.name] * t.C * 2, dtype=torch.float64, device=dev)
             plan.dlogits = torch.empty((N, 1, H, W), **f32)
             plan.has_grad = True
         return plan
@@ -388,8 +391,6 @@ class HyperStarcopUNet(nn.Module):
         plan.x_cst = x_cst
         self._pack_all(need_grad)
         st = stream()
-        if training:
-            plan.stats.zero_()
         for i, op in enumerate(self._ops):
             ty, o = op["type"], op["out"]
             Ho, Wo = H >> o.shift, W >> o.shift
@@ -439,13 +440,20 @@ class HyperStarcopUNet(nn.Module):
             self._pe(tok)
             if o.bn is not None:
                 bn = o.bn
-                check(lib.sc_bn_finalize(stats, float(N * Ho * Wo), ptr(bn.weight), ptr(bn.bias),
+                check(lib.sc_bn_finalize(stats, plan.srows[o.name], float(N * Ho * Wo), ptr(bn.weight), ptr(bn.bias),
                                          ptr(bn.running_mean), ptr(bn.running_var), float(bn.momentum), float(bn.eps),
                                          1 if training else 0, ptr(plan.cst[o.name]), o.C, st))
-                if training:
-                    bn.num_batches_tracked.add_(1)
+        if training:      # one multi-tensor launch for the 62 step counters
+            torch._foreach_add_(self._nbt_list(), 1)
         plan.training = training
         return plan
+
+    def _nbt_list(self):
+        nbt = getattr(self, "_nbt", None)
+        if nbt is None or nbt[0].device != self._pflat.device:
+            nbt = [t.bn.num_batches_tracked for t in self._tensors.values() if t.bn is not None]
+            self._nbt = nbt
+        return nbt
 
     def _backward_impl(self, plan, dlogits):
         """Fills the flat gradient buffer from dL/dlogits.  Needs the plan of a training-mode forward."""
@@ -456,7 +464,6 @@ class HyperStarcopUNet(nn.Module):
             raise RuntimeError("HyperStarcopUNet.backward: gradients need a train-mode forward (BatchNorm batch "
                                "statistics); call .train() first")
         dlogits = dlogits.contiguous()
-        plan.bsums.zero_()
         plan.dw_acc.zero_()
         written = set()
         res_of = {}       # tensor name -> name of the residual sum z (z = t + ...)
@@ -475,7 +482,7 @@ class HyperStarcopUNet(nn.Module):
             Ho, Wo = H >> t.shift, W >> t.shift
             check(lib.sc_bn_bwd_reduce(ptr(plan.grad[t.name]), ptr(plan.buf[t.name]), ptr(plan.cst[t.name]), t.act,
                                        ptr(plan.bsums_v[t.name]), N, t.C, Ho * Wo, st))
-            check(lib.sc_bn_bwd_finalize(ptr(plan.bsums_v[t.name]), float(N * Ho * Wo), ptr(plan.cst[t.name]),
+            check(lib.sc_bn_bwd_finalize(ptr(plan.bsums_v[t.name]), plan.brows[t.name], float(N * Ho * Wo), ptr(plan.cst[t.name]),
                                          ptr(gv(t.bn.weight)), ptr(gv(t.bn.bias)), ptr(plan.cstb[t.name]), t.C, st))
 
         for i in range(len(self._ops) - 1, -1, -1):

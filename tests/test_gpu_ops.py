@@ -10,8 +10,8 @@ pytestmark = pytest.mark.gpu
 
 from hip_ops import (dev, DEV, conv_mfma, cst_affine, pack, relerr, wgrad_mfma)  # noqa: E402
 from starcop_amd import _lib  # noqa: E402
-from starcop_amd._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, SC_STAT_SLOTS, SRC_AFFINE, SRC_BNBWD, SRC_NORM,
-                              SRC_RAW, check, make_src, ptr, stream)  # noqa: E402
+from starcop_amd._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD,
+                              STAT_DW, STAT_STEM, check, make_src, ptr, stream)  # noqa: E402
 
 TOL = 1e-4
 
@@ -39,7 +39,7 @@ def test_conv_mfma_fwd_affine_stats(hip, ks, cin, cout, co_t, H, W):
     src = make_src(xd, cin, SRC_AFFINE, act=act, cst=cst_affine(sc, sh))
     (out,), stats = conv_mfma([src], pack(wd, co_t, 0), N, H, W, cout, ks, co_t, want_stats=True)
     assert relerr(out, ref) < TOL
-    st = stats.sum(0).cpu()
+    st = stats.double().sum(0).cpu()
     assert relerr(st[:, 0], ref.double().sum((0, 2, 3))) < 1e-4
     assert relerr(st[:, 1], (ref.double() ** 2).sum((0, 2, 3))) < 1e-4
 
@@ -128,11 +128,12 @@ def test_depthwise(hip, C_, H, W, stride):
     lib = hip
     src = make_src(dev(x), C_, SRC_AFFINE, act=ACT_RELU6, cst=cst_affine(sc, sh))
     out = torch.empty(N, C_, Ho, Wo, device=DEV)
-    stats = torch.zeros(SC_STAT_SLOTS, C_, 2, dtype=torch.float64, device=DEV)
+    stats = torch.full((lib.sc_stat_rows(STAT_DW, N, Ho, Wo), C_, 2), float("nan"), device=DEV)
     wd = dev(w)
     check(lib.sc_dwconv3x3_fwd(C.byref(src), ptr(wd), ptr(out), N, C_, H, W, stride, ptr(stats), stream()))
     assert relerr(out, ref) < TOL
-    assert relerr(stats.sum(0)[:, 0], ref.double().sum((0, 2, 3))) < 1e-4
+    assert relerr(stats.double().sum(0)[:, 0], ref.double().sum((0, 2, 3))) < 1e-4
+    assert relerr(stats.double().sum(0)[:, 1], (ref.double() ** 2).sum((0, 2, 3))) < 1e-4
     dy = rnd(N, C_, Ho, Wo, seed=5)
     ref.backward(dy)
     dys = make_src(dev(dy), C_, SRC_RAW)
@@ -156,10 +157,10 @@ def test_stem_fused_normalizer(hip):
     ref = F.conv2d(xn, wr, stride=2, padding=1)
     src = make_src(dev(x), Cin, SRC_NORM, cst=dev(cst))
     out = torch.empty(N, 32, H // 2, W // 2, device=DEV)
-    stats = torch.zeros(SC_STAT_SLOTS, 32, 2, dtype=torch.float64, device=DEV)
+    stats = torch.full((hip.sc_stat_rows(STAT_STEM, N, H // 2, W // 2), 32, 2), float("nan"), device=DEV)
     check(hip.sc_stem_conv_fwd(C.byref(src), ptr(dev(w)), ptr(out), N, Cin, H, W, ptr(stats), stream()))
     assert relerr(out, ref) < TOL
-    assert relerr(stats.sum(0)[:, 1], (ref.double() ** 2).sum((0, 2, 3))) < 1e-4
+    assert relerr(stats.double().sum(0)[:, 1], (ref.double() ** 2).sum((0, 2, 3))) < 1e-4
     dy = rnd(N, 32, H // 2, W // 2, seed=3)
     ref.backward(dy)
     n = hip.sc_stem_wgrad_workspace_floats(N, Cin, H, W)
@@ -203,23 +204,25 @@ def test_batchnorm_bookkeeping(hip):
     g = rnd(N, C_, H, W, seed=4)
     z.backward(g)
     yd = dev(y)
-    stats = torch.zeros(SC_STAT_SLOTS, C_, 2, dtype=torch.float64, device=DEV)
-    stats[3, :, 0] = yd.double().sum((0, 2, 3)); stats[7, :, 1] = (yd.double() ** 2).sum((0, 2, 3))
+    stats = torch.zeros(300, C_, 2, device=DEV)           # partial rows: any split of the sums over rows
+    stats[3, :, 0] = yd.double().sum((0, 2, 3)).float() - 5.0; stats[299, :, 0] = 5.0
+    stats[7, :, 1] = (yd.double() ** 2).sum((0, 2, 3)).float()
     rmd, rvd = torch.zeros(C_, device=DEV), torch.ones(C_, device=DEV)
     cst = torch.zeros(C_, SC_CST, device=DEV)
     cnt = float(N * H * W)
-    check(hip.sc_bn_finalize(ptr(stats), cnt, ptr(dev(gamma)), ptr(dev(beta)), ptr(rmd), ptr(rvd),
+    check(hip.sc_bn_finalize(ptr(stats), 300, cnt, ptr(dev(gamma)), ptr(dev(beta)), ptr(rmd), ptr(rvd),
                              0.1, 1e-5, 1, ptr(cst), C_, stream()))
     assert relerr(rmd, rm) < 1e-5 and relerr(rvd, rv) < 1e-5
     src = make_src(yd, C_, SRC_AFFINE, act=ACT_RELU6, cst=cst)
     zz = torch.empty_like(yd)
     check(hip.sc_apply_src(C.byref(src), ptr(zz), N, C_, H * W, stream()))
     assert relerr(zz, z) < 1e-5
-    sums = torch.zeros(SC_STAT_SLOTS, C_, 2, dtype=torch.float64, device=DEV)
+    nrows = hip.sc_stat_rows(STAT_BNBWD, N, H, W)
+    sums = torch.full((nrows, C_, 2), float("nan"), dtype=torch.float64, device=DEV)
     gd = dev(g)
     check(hip.sc_bn_bwd_reduce(ptr(gd), ptr(yd), ptr(cst), ACT_RELU6, ptr(sums), N, C_, H * W, stream()))
     dgm, dbt, cstb = torch.empty(C_, device=DEV), torch.empty(C_, device=DEV), torch.zeros(C_, SC_CST, device=DEV)
-    check(hip.sc_bn_bwd_finalize(ptr(sums), cnt, ptr(cst), ptr(dgm), ptr(dbt), ptr(cstb), C_, stream()))
+    check(hip.sc_bn_bwd_finalize(ptr(sums), nrows, cnt, ptr(cst), ptr(dgm), ptr(dbt), ptr(cstb), C_, stream()))
     assert relerr(dgm, gamma.grad) < TOL and relerr(dbt, beta.grad) < TOL
     dsrc = make_src(gd, C_, SRC_BNBWD, act=ACT_RELU6, cst=cstb, aux=yd)
     dyd = torch.empty_like(yd)
