@@ -70,7 +70,7 @@ int sc_device_check(void);   /* 0 iff the current device is gfx950 */
 /* ------------------------------------------------------------------------- */
 /* weights: pack OIHW -> kernel layouts (replaces nothing in the reference; it is
  * the layout step torch's conv backends do internally).
- *   fwd  : wpk[co_tile][ci][tap][co_in_tile]                (co_t = 32 or 64)
+ *   fwd  : wpk[co_tile][ci][tap][co_in_tile]                (co_t = 16, 32 or 64; ci zero-padded to the K chunk)
  *   dgrad: same layout of the transposed+flipped filter: W'[ci][co][2-kh][2-kw]
  */
 int sc_pack_weights(const float* w_oihw, float* wpk, int Cout, int Cin, int ks,
@@ -95,7 +95,7 @@ typedef struct sc_conv_args {
   int32_t N, H, W;       /* output (= input) spatial size                        */
   int32_t Cout;
   int32_t ks;            /* 1 or 3                                               */
-  int32_t co_t;          /* 32 or 64: cout tile the weights were packed for      */
+  int32_t co_t;          /* 16 (thin layers, ks=3, Cout<=16), 32 or 64: cout tile the weights were packed for */
   float* out0; float* out1;
   int32_t csplit;        /* == Cout when there is a single output                */
   int32_t accum0, accum1;/* 1: out += result                                     */

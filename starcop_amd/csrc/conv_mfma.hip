@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
       if (want_stats) {
         const float s = half_sum32(v);
         const float ss = half_sum32(v * v);
-        if (l31 == 0) { s_red[wave][col][0] = s; s_red[wave][col][1] = ss; }
+        if (l31 == SC_HALF_SUM_LANE) { s_red[wave][col][0] = s; s_red[wave][col][1] = ss; }
       }
       if (ok) {
         float* o; size_t idx; int accum;
@@ -255,6 +255,164 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
         const float t = s_red[0][col][k] + s_red[1][col][k] + s_red[2][col][k] + s_red[3][col][k];
         p.stats[(stat_row() * p.Cout + co) * 2 + k] = t;
       }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Thin layers (Cout <= 16: decoder.blocks.4.*): the same implicit GEMM on v_mfma_f32_16x16x4_f32 so that no MFMA row is
+// wasted.  A: lane -> W[co = l&15][ci = 4*kq + (l>>4)],  B: lane -> patch[ci = 4*kq + (l>>4)][pixel = 16*pb + (l&15)],
+// D (4 regs): col = l&15 (pixel), row = 4*(l>>4) + r (cout).  Tile = 16 couts x (4 rows x 32 px), wave w owns row w.
+__global__ __launch_bounds__(256, 2) void k_conv_mfma16(const ConvP p) {
+  constexpr int TAPS = 9, CO_T = 16, KC = 8;
+  constexpr int PR = 6, PC = 34, PCH = PR * PC, NE = (PCH + 31) / 32;
+  constexpr int WCH = KC * TAPS * CO_T;        // 1152 floats per chunk
+  constexpr int NW = (WCH / 4 + 255) / 256;    // 2
+
+  __shared__ __attribute__((aligned(16))) float s_w[2][WCH];
+  __shared__ float s_p[2][KC * PCH];
+  __shared__ float s_red[4][CO_T][2];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int n = blockIdx.z;
+  const int H = p.H, W = p.W;
+  const int tiles_x = (W + 31) >> 5;
+  const int ty = blockIdx.x / tiles_x;
+  const int y0 = ty * 4, x0 = (blockIdx.x - ty * tiles_x) * 32;
+  const int C0 = p.s0.C;
+  const int Cin = C0 + p.s1.C;
+  const int nk = (Cin + KC - 1) / KC;
+  const float* wbase = p.wpk;
+
+  floatx4 acc[2];
+  acc[0] = (floatx4){0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
+
+  const int sci = tid >> 5, sq = tid & 31;
+  float xv[NE], av[NE];
+  unsigned inb = 0;
+  float4 c0 = make_float4(1.f, 0.f, 0.f, 0.f);
+  float c4 = 0.f, slo = 0.f, shi = 0.f;
+  int smode = 0;
+  floatx4 wv[NW];
+
+  auto load_chunk = [&](int kc) {
+    const int cg = kc * KC + sci;
+    const bool second = cg >= C0;
+    const int cs = second ? cg - C0 : cg;
+    const float* xp = second ? p.s1.x : p.s0.x;
+    const float* ap = second ? p.s1.aux : p.s0.aux;
+    const float* cp = second ? p.s1.cst : p.s0.cst;
+    const int Cs = second ? p.s1.C : p.s0.C;
+    const int up = second ? p.s1.up : p.s0.up;
+    smode = second ? p.s1.mode : p.s0.mode;
+    const int sact = second ? p.s1.act : p.s0.act;
+    slo = sc_act_lo(sact); shi = sc_act_hi(sact);
+    if (smode != SC_SRC_RAW) { c0 = *reinterpret_cast<const float4*>(cp + (size_t)cs * SC_CST); c4 = cp[(size_t)cs * SC_CST + 4]; }
+    else { c0 = make_float4(1.f, 0.f, 0.f, 0.f); c4 = 0.f; }
+    const int Hs = H >> up, Ws = W >> up;
+    const float* xb = xp + ((size_t)n * Cs + cs) * Hs * Ws;
+    const float* ab = (smode == SC_SRC_BNBWD) ? ap + ((size_t)n * Cs + cs) * Hs * Ws : xb;
+    inb = 0;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = sq + 32 * i;
+      const int pr = e / PC, pc = e - pr * PC;
+      const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+      const bool ok = (e < PCH) && (y >= 0) && (y < H) && (x >= 0) && (x < W);
+      const int off = ok ? (y >> up) * Ws + (x >> up) : 0;
+      xv[i] = xb[off]; av[i] = ab[off];
+      inb |= ok ? (1u << i) : 0u;
+    }
+    const floatx4* wsrc = reinterpret_cast<const floatx4*>(wbase + (size_t)kc * WCH);
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int i4 = tid + 256 * j;
+      wv[j] = wsrc[i4 < WCH / 4 ? i4 : WCH / 4 - 1];
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    if (smode == SC_SRC_BNBWD) {
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int e = sq + 32 * i;
+        if (e < PCH) s_p[buf][sci * PCH + e] = ((inb >> i) & 1u) ? sc_pro_bnbwd(xv[i], av[i], c0.x, c0.y, c0.z, c0.w, c4, slo, shi) : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int e = sq + 32 * i;
+        if (e < PCH) s_p[buf][sci * PCH + e] = ((inb >> i) & 1u) ? sc_pro_affine(xv[i], c0.x, c0.y, slo, shi) : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int i4 = tid + 256 * j;
+      if (i4 < WCH / 4) *reinterpret_cast<floatx4*>(&s_w[buf][i4 * 4]) = wv[j];
+    }
+  };
+  auto compute_chunk = [&](int buf) {
+#pragma unroll
+    for (int kq = 0; kq < KC / 4; ++kq) {
+      const int cil = 4 * kq + lq;
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const float a = s_w[buf][(cil * TAPS + tap) * CO_T + l15];
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+          const float b = s_p[buf][cil * PCH + (wave + kh) * PC + pb * 16 + l15 + kw];
+          acc[pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[pb], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    const bool more = (kc + 1) < nk;
+    if (more) load_chunk(kc + 1);
+    compute_chunk(kc & 1);
+    if (more) store_chunk((kc + 1) & 1);
+    __syncthreads();
+  }
+
+  const int oy = y0 + wave;
+  const size_t HWs = (size_t)H * W;
+  const bool want_stats = p.stats != nullptr;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co = 4 * lq + r;
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+      const int ox = x0 + pb * 16 + l15;
+      float v = acc[pb][r];
+      const bool ok = (oy < H) && (ox < W) && (co < p.Cout);
+      if (!ok) v = 0.f;
+      s += v; ss = fmaf(v, v, ss);
+      if (ok) {
+        const size_t idx = ((size_t)n * p.Cout + co) * HWs + (size_t)oy * W + ox;
+        if (p.add0) v += p.add0[idx];
+        if (p.add1) v += p.add1[idx];
+        if (p.accum0) v += p.out0[idx];
+        p.out0[idx] = v;
+      }
+    }
+    if (want_stats) {      // 16-lane row sums (each row of 16 lanes = one cout)
+      SC_DPP_ADD(s, 0xB1, 0xF); SC_DPP_ADD(s, 0x4E, 0xF); SC_DPP_ADD(s, 0x141, 0xF); SC_DPP_ADD(s, 0x140, 0xF);
+      SC_DPP_ADD(ss, 0xB1, 0xF); SC_DPP_ADD(ss, 0x4E, 0xF); SC_DPP_ADD(ss, 0x141, 0xF); SC_DPP_ADD(ss, 0x140, 0xF);
+      if (l15 == 0) { s_red[wave][co][0] = s; s_red[wave][co][1] = ss; }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    if (tid < CO_T * 2) {
+      const int co = tid >> 1, k = tid & 1;
+      if (co < p.Cout) p.stats[(stat_row() * p.Cout + co) * 2 + k] = s_red[0][co][k] + s_red[1][co][k] + s_red[2][co][k] + s_red[3][co][k];
     }
   }
 }
@@ -522,6 +680,186 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradP p) {
   }
 }
 
+// Thin layers (Cout <= 16, ks = 3): weight gradient on v_mfma_f32_16x16x4_f32.  D[co][ci] per tap and ci block;
+// A: lane -> dy[co = l&15][px = 4q + (l>>4)],  B: lane -> in[ci = 16*cb + (l&15)][px + d(tap)];  D row = 4*(l>>4)+r (co),
+// col = l&15 (ci).  Stage = 4 rows x 32 px, wave w owns row w (its own K slice), LDS pitches == 2 (mod 32): conflict-free.
+template <int NCB>
+__global__ __launch_bounds__(256, 2) void k_wgrad_mfma16(const WgradP p) {
+  constexpr int TAPS = 9, SR = 4, COT = 16, CIT = 16 * NCB;
+  constexpr int PA = 130;
+  constexpr int PRW = 6, PCW = 34, BPOS = PRW * PCW, PB = 226;
+  constexpr int APX = 128, ACH = 2, NAI = COT / ACH;
+  constexpr int NBJ = (BPOS + 31) / 32, NBK = CIT / 8;
+
+  __shared__ float s_a[COT * PA];
+  __shared__ float s_b[CIT * PB];
+  __shared__ __attribute__((aligned(16))) float s_ca[COT * SC_CST];
+  __shared__ __attribute__((aligned(16))) float s_cb[CIT * SC_CST];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int cit = blockIdx.y;
+  const int H = p.H, W = p.W;
+  const int C0 = p.s0.C;
+
+  for (int i = tid; i < COT * SC_CST; i += 256) {
+    const int ch = i / SC_CST;
+    s_ca[i] = (p.dy.cst && p.dy.mode != SC_SRC_RAW && ch < p.Cout) ? p.dy.cst[(size_t)ch * SC_CST + (i % SC_CST)] : ((i % SC_CST) == 0 ? 1.f : 0.f);
+  }
+  for (int i = tid; i < CIT * SC_CST; i += 256) {
+    const int ch = cit * CIT + i / SC_CST;
+    float v = (i % SC_CST) == 0 ? 1.f : 0.f;
+    if (ch < p.Cin) {
+      const bool second = ch >= C0;
+      const float* cp = second ? p.s1.cst : p.s0.cst;
+      const int md = second ? p.s1.mode : p.s0.mode;
+      if (cp && md != SC_SRC_RAW) v = cp[(size_t)(second ? ch - C0 : ch) * SC_CST + (i % SC_CST)];
+    }
+    s_cb[i] = v;
+  }
+
+  floatx4 acc[TAPS][NCB];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int b = 0; b < NCB; ++b) acc[t][b] = (floatx4){0.f, 0.f, 0.f, 0.f};
+
+  const int tiles_x = (W + 31) >> 5;
+  const int per_img = tiles_x * ((H + SR - 1) / SR);
+  const long T = (long)p.N * per_img;
+  const long t_begin = T * blockIdx.x / p.nsl, t_end = T * (blockIdx.x + 1) / p.nsl;
+  const int dymode = p.dy.mode;
+  const float dlo = sc_act_lo(p.dy.act), dhi = sc_act_hi(p.dy.act);
+
+  const int a_px = tid % APX, a_c0 = tid / APX;
+  const int b_q = tid & 31, b_c0 = tid >> 5;
+  float ag[NAI], ay[NAI], bx[NBK][NBJ];
+  int sy0 = 0, sx0 = 0;
+
+  auto b_pos = [&](int j, int y0, int x0, int up, bool& ok) -> int {
+    const int e = b_q + 32 * j;
+    const int pr = e / PCW, pc = e - pr * PCW;
+    const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+    ok = (e < BPOS) && (y >= 0) && (y < H) && (x >= 0) && (x < W);
+    return (y >> up) * (W >> up) + (x >> up);
+  };
+
+  auto load_stage = [&](long t) {
+    const int n = (int)(t / per_img);
+    const int rem = (int)(t - (long)n * per_img);
+    const int ty = rem / tiles_x;
+    const int y0 = ty * SR, x0 = (rem - ty * tiles_x) * 32;
+    sy0 = y0; sx0 = x0;
+    const size_t HW = (size_t)H * W;
+    {
+      const int y = y0 + (a_px >> 5), x = x0 + (a_px & 31);
+      const bool okp = (y < H) && (x < W);
+      const size_t base = ((size_t)n * p.Cout + a_c0) * HW + (okp ? y * W + x : 0);
+      const float* gp = p.dy.x + base;
+      const float* yp = (dymode == SC_SRC_BNBWD) ? p.dy.aux + base : gp;
+#pragma unroll
+      for (int i = 0; i < NAI; ++i) {
+        const size_t o = (a_c0 + ACH * i < p.Cout) ? (size_t)(ACH * i) * HW : 0;
+        ag[i] = gp[o]; ay[i] = yp[o];
+      }
+    }
+    int off0[NBJ], off1[NBJ];
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) {
+      bool ok;
+      const int o0 = b_pos(j, y0, x0, p.s0.up, ok);
+      off0[j] = ok ? o0 : 0;
+      const int o1 = b_pos(j, y0, x0, p.s1.up, ok);
+      off1[j] = ok ? o1 : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < NBK; ++k) {
+      const int chr = cit * CIT + b_c0 + 8 * k;
+      const int ch = chr < p.Cin ? chr : 0;
+      const bool second = ch >= C0;
+      const int cs = second ? ch - C0 : ch;
+      const int Cs = second ? p.s1.C : p.s0.C;
+      const int up = second ? p.s1.up : p.s0.up;
+      const float* xp = (second ? p.s1.x : p.s0.x) + ((size_t)n * Cs + cs) * ((size_t)(H >> up) * (W >> up));
+#pragma unroll
+      for (int j = 0; j < NBJ; ++j) bx[k][j] = xp[second ? off1[j] : off0[j]];
+    }
+  };
+
+  auto store_stage = [&]() {
+    {
+      const int y = sy0 + (a_px >> 5), x = sx0 + (a_px & 31);
+      const bool okp = (y < H) && (x < W);
+#pragma unroll
+      for (int i = 0; i < NAI; ++i) {
+        const int chl = a_c0 + ACH * i;
+        const float4 c0 = *reinterpret_cast<const float4*>(&s_ca[chl * SC_CST]);
+        const float v = (dymode == SC_SRC_BNBWD) ? sc_pro_bnbwd(ag[i], ay[i], c0.x, c0.y, c0.z, c0.w, s_ca[chl * SC_CST + 4], dlo, dhi)
+                                                 : sc_pro_affine(ag[i], c0.x, c0.y, dlo, dhi);
+        s_a[chl * PA + a_px] = (okp && chl < p.Cout) ? v : 0.f;
+      }
+    }
+    bool okj[NBJ];
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) (void)b_pos(j, sy0, sx0, 0, okj[j]);
+#pragma unroll
+    for (int k = 0; k < NBK; ++k) {
+      const int chl = b_c0 + 8 * k;
+      const int ch = cit * CIT + chl;
+      const bool second = ch >= C0;
+      const int act = second ? p.s1.act : p.s0.act;
+      const float lo = sc_act_lo(act), hi = sc_act_hi(act);
+      const float2 c0 = *reinterpret_cast<const float2*>(&s_cb[chl * SC_CST]);
+      const bool okc = ch < p.Cin;
+#pragma unroll
+      for (int j = 0; j < NBJ; ++j) {
+        const int e = b_q + 32 * j;
+        if (e < BPOS) s_b[chl * PB + e] = (okj[j] && okc) ? sc_pro_affine(bx[k][j], c0.x, c0.y, lo, hi) : 0.f;
+      }
+    }
+  };
+
+  if (t_begin < t_end) {
+    load_stage(t_begin);
+    __syncthreads();
+    store_stage();
+    __syncthreads();
+  }
+  for (long t = t_begin; t < t_end; ++t) {
+    const bool more = (t + 1) < t_end;
+    if (more) load_stage(t + 1);
+    const int rr = wave;
+#pragma unroll 2
+    for (int q = 0; q < 8; ++q) {
+      const float a = s_a[l15 * PA + rr * 32 + 4 * q + lq];
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int kh = tap / 3, kw = tap - 3 * kh;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          const float b = s_b[(cb * 16 + l15) * PB + (rr + kh) * PCW + 4 * q + lq + kw];
+          acc[tap][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[tap][cb], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (more) store_stage();
+    __syncthreads();
+  }
+  const size_t plane = (size_t)p.CoP * p.CiP;
+  float* pb = p.part + ((size_t)blockIdx.x * 4 + wave) * TAPS * plane;
+#pragma unroll
+  for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = 4 * lq + r, ci = cit * CIT + cb * 16 + l15;
+        if (ci < p.CiP) pb[tap * plane + (size_t)co * p.CiP + ci] = acc[tap][cb][r];
+      }
+}
+
 // dw[co][ci][tap] = sum_s part[s][tap][co][ci]
 __global__ void k_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int nparts, int taps,
                                int Cout, int Cin, int CoP, int CiP) {
@@ -543,6 +881,17 @@ struct WgradPlan { int wm, wn, wk, sr, nsl, CoP, CiP, co_tiles, ci_tiles; long s
 
 WgradPlan plan_wgrad(int N, int H, int W, int Cout, int Cin, int ks) {
   WgradPlan pl;
+  if (ks == 3 && Cout <= 16) {          // thin layers: k_wgrad_mfma16<NCB>, 4 waves = 4 K slices
+    pl.wm = 0; pl.wn = Cin > 16 ? 2 : 1; pl.wk = 4; pl.sr = 4;
+    pl.CoP = 32; pl.CiP = (Cin + 31) / 32 * 32;
+    pl.co_tiles = 1; pl.ci_tiles = (Cin + 16 * pl.wn - 1) / (16 * pl.wn);
+    pl.stages = (long)N * ((W + 31) / 32) * ((H + 3) / 4);
+    long want = 2048 / pl.ci_tiles;
+    if (want < 1) want = 1;
+    if (want > pl.stages) want = pl.stages;
+    pl.nsl = (int)want;
+    return pl;
+  }
   if (Cout > 32 && Cin > 32) { pl.wm = 2; pl.wn = 2; }
   else if (Cout > 32) { pl.wm = 2; pl.wn = 1; }
   else if (Cin > 32) { pl.wm = 1; pl.wn = 2; }
@@ -576,7 +925,7 @@ extern "C" size_t sc_packed_weight_floats(int Cout, int Cin, int ks, int co_t, i
 extern "C" int sc_pack_weights(const float* w, float* wpk, int Cout, int Cin, int ks, int co_t,
                                int transpose_flip, sc_stream stream) {
   SC_REQUIRE(ks == 1 || ks == 3, "sc_pack_weights: ks must be 1 or 3 (got %d)", ks);
-  SC_REQUIRE(co_t == 32 || co_t == 64, "sc_pack_weights: co_t must be 32 or 64 (got %d)", co_t);
+  SC_REQUIRE(co_t == 16 || co_t == 32 || co_t == 64, "sc_pack_weights: co_t must be 16, 32 or 64 (got %d)", co_t);
   const size_t total = sc_packed_weight_floats(Cout, Cin, ks, co_t, transpose_flip);
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   const int Kg = transpose_flip ? Cout : Cin, kc = ks == 3 ? 8 : 16;
@@ -589,7 +938,9 @@ extern "C" int sc_pack_weights(const float* w, float* wpk, int Cout, int Cin, in
 extern "C" int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream) {
   SC_REQUIRE(a != nullptr, "sc_conv2d_mfma: null args");
   SC_REQUIRE(a->ks == 1 || a->ks == 3, "sc_conv2d_mfma: ks must be 1 or 3 (got %d)", a->ks);
-  SC_REQUIRE(a->co_t == 32 || a->co_t == 64, "sc_conv2d_mfma: co_t must be 32 or 64 (got %d)", a->co_t);
+  SC_REQUIRE(a->co_t == 16 || a->co_t == 32 || a->co_t == 64, "sc_conv2d_mfma: co_t must be 16, 32 or 64 (got %d)", a->co_t);
+  SC_REQUIRE(a->co_t != 16 || (a->ks == 3 && a->Cout <= 16 && a->csplit == a->Cout),
+             "sc_conv2d_mfma: co_t=16 is the thin-layer kernel: ks=3, Cout<=16, single output");
   SC_REQUIRE(a->nsrc == 1 || a->nsrc == 2, "sc_conv2d_mfma: nsrc must be 1 or 2");
   const int C0 = a->src[0].C, C1 = a->nsrc == 2 ? a->src[1].C : 0;
   SC_REQUIRE(C0 > 0 && C0 % 8 == 0 && C1 % 8 == 0, "sc_conv2d_mfma: source channels must be multiples of 8 (got %d,%d)", C0, C1);
@@ -613,7 +964,8 @@ extern "C" int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream) {
   if (a->ks == 3) grid = dim3(((a->W + 31) / 32) * ((a->H + 3) / 4), co_tiles, a->N);
   else grid = dim3((a->H * a->W + 127) / 128, co_tiles, a->N);
   hipStream_t st = (hipStream_t)stream;
-  if (a->ks == 3 && a->co_t == 64) hipLaunchKernelGGL((k_conv_mfma<3, 2>), grid, dim3(256), 0, st, p);
+  if (a->co_t == 16) hipLaunchKernelGGL(k_conv_mfma16, grid, dim3(256), 0, st, p);
+  else if (a->ks == 3 && a->co_t == 64) hipLaunchKernelGGL((k_conv_mfma<3, 2>), grid, dim3(256), 0, st, p);
   else if (a->ks == 3) hipLaunchKernelGGL((k_conv_mfma<3, 1>), grid, dim3(256), 0, st, p);
   else if (a->co_t == 64) hipLaunchKernelGGL((k_conv_mfma<1, 2>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((k_conv_mfma<1, 1>), grid, dim3(256), 0, st, p);
@@ -651,7 +1003,10 @@ extern "C" int sc_conv2d_wgrad_mfma(const sc_wgrad_args* a, sc_stream stream) {
   dim3 grid(pl.nsl, pl.ci_tiles, pl.co_tiles);
   hipStream_t st = (hipStream_t)stream;
 #define SC_WG(KS, WM, WN) hipLaunchKernelGGL((k_wgrad_mfma<KS, WM, WN>), grid, dim3(256), 0, st, p)
-  if (a->ks == 3) {
+  if (pl.wm == 0) {
+    if (pl.wn == 2) hipLaunchKernelGGL((k_wgrad_mfma16<2>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_wgrad_mfma16<1>), grid, dim3(256), 0, st, p);
+  } else if (a->ks == 3) {
     if (pl.wm == 2 && pl.wn == 2) SC_WG(3, 2, 2);
     else if (pl.wm == 2) SC_WG(3, 2, 1);
     else if (pl.wn == 2) SC_WG(3, 1, 2);

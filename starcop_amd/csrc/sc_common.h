@@ -93,11 +93,20 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-__device__ __forceinline__ float half_sum32(float v) {   // sum over the 32 lanes of each half-wave
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// sum over the 32 lanes of each half-wave with DPP adds (one VALU instruction each, no LDS crossbar traffic):
+// quad_perm, quad_perm, row_half_mirror, row_mirror -> 16-lane row sums in every lane; row_bcast15 into rows 1 and 3
+// -> lanes 16..31 hold the sum of lanes 0..31, lanes 48..63 the sum of lanes 32..63.  Read the result at (lane&31)==16.
+#define SC_DPP_ADD(v, ctrl, rmask) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xF, false))
+__device__ __forceinline__ float half_sum32(float v) {
+  SC_DPP_ADD(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
+  SC_DPP_ADD(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
+  SC_DPP_ADD(v, 0x141, 0xF);   // row_half_mirror
+  SC_DPP_ADD(v, 0x140, 0xF);   // row_mirror
+  SC_DPP_ADD(v, 0x142, 0xA);   // row_bcast15 -> rows 1, 3
   return v;
 }
+constexpr int SC_HALF_SUM_LANE = 16;
 
 // sums nparts rows of E floats (part[k][i]) into out[i]; uses `scratch` (>= sc_reduce_scratch_floats)
 // for the intermediate levels.  Defined in elementwise.hip.

@@ -98,7 +98,9 @@ class _T:
         self.res_grad = None        # 'fin' tensor z = self + ...: z.grad must be added to self.grad
 
 
-def _pick_cot(M):
+def _pick_cot(M, ks=1):
+    if M <= 16 and ks == 3:
+        return 16            # thin layers: v_mfma_f32_16x16x4_f32 kernel, no wasted MFMA rows
     if M <= 32:
         return 32
     p32, p64 = -(-M // 32) * 32, -(-M // 64) * 64
@@ -351,7 +353,7 @@ class HyperStarcopUNet(nn.Module):
             co, ci, ks = conv.out_channels, conv.in_channels, conv.kernel_size[0]
             ent = self._wpk.get(i)
             if ent is None or ent["f"].device != dev:
-                cf, cb = _pick_cot(co), _pick_cot(ci)
+                cf, cb = _pick_cot(co, ks), _pick_cot(ci, ks)
                 ent = dict(cot_f=cf, cot_b=cb,
                            f=torch.empty(lib.sc_packed_weight_floats(co, ci, ks, cf, 0), dtype=torch.float32, device=dev),
                            b=torch.empty(lib.sc_packed_weight_floats(co, ci, ks, cb, 1), dtype=torch.float32, device=dev))

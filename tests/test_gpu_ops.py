@@ -26,7 +26,7 @@ def rnd(*shape, seed=0, scale=1.0):
 
 
 @pytest.mark.parametrize("ks,cin,cout,co_t,H,W", [
-    (3, 16, 16, 32, 32, 32), (3, 32, 64, 64, 32, 64), (3, 24, 96, 32, 12, 40), (3, 64, 40, 64, 36, 32),
+    (3, 16, 16, 32, 32, 32), (3, 16, 16, 16, 32, 32), (3, 40, 16, 16, 12, 40), (3, 32, 8, 16, 36, 70), (3, 32, 64, 64, 32, 64), (3, 24, 96, 32, 12, 40), (3, 64, 40, 64, 36, 32),
     (1, 16, 96, 32, 16, 16), (1, 96, 24, 32, 24, 20), (1, 160, 128, 64, 16, 16), (1, 24, 144, 32, 10, 13),
     (1, 320, 1280, 64, 2, 3), (1, 960, 160, 64, 2, 3), (3, 1376, 256, 64, 4, 6)])
 def test_conv_mfma_fwd_affine_stats(hip, ks, cin, cout, co_t, H, W):
@@ -59,7 +59,7 @@ def test_conv_mfma_upsample_concat(hip):
     assert relerr(out, ref) < TOL
 
 
-@pytest.mark.parametrize("ks,cin,cout,H,W", [(3, 32, 16, 32, 32), (3, 80, 32, 16, 32), (1, 96, 16, 16, 16), (1, 24, 144, 8, 16),
+@pytest.mark.parametrize("ks,cin,cout,H,W", [(3, 32, 16, 32, 32), (3, 16, 16, 32, 64), (3, 16, 32, 20, 40), (3, 80, 32, 16, 32), (1, 96, 16, 16, 16), (1, 24, 144, 8, 16),
                                               (1, 320, 1280, 2, 3), (3, 256, 128, 4, 6)])
 def test_conv_dgrad_bnbwd_split_add(hip, ks, cin, cout, H, W):
     """backward-data = same kernel on the transposed+flipped filter; dy formed on load from (g, y)."""
@@ -73,7 +73,7 @@ def test_conv_dgrad_bnbwd_split_add(hip, ks, cin, cout, H, W):
     ref = F.conv_transpose2d(dy, w, padding=ks // 2)
     cst = torch.zeros(cout, SC_CST); cst[:, 0], cst[:, 1], cst[:, 2], cst[:, 3], cst[:, 4] = a, b, A, B, D
     src = make_src(dev(g), cout, SRC_BNBWD, act=ACT_RELU, cst=dev(cst), aux=dev(y))
-    co_t = 32 if cin <= 32 else 64
+    co_t = 16 if (cin <= 16 and ks == 3) else (32 if cin <= 32 else 64)
     wpk = pack(dev(w), co_t, 1)
     (out,), _ = conv_mfma([src], wpk, N, H, W, cin, ks, co_t)
     assert relerr(out, ref) < TOL
@@ -82,13 +82,15 @@ def test_conv_dgrad_bnbwd_split_add(hip, ks, cin, cout, H, W):
     o = dev(old).clone()
     conv_mfma([src], wpk, N, H, W, cin, ks, co_t, add0=dev(add0), accum=(1, 0), outs=[o])
     assert relerr(o, ref + add0 + old) < TOL
+    if co_t == 16:
+        return          # the thin-layer kernel has a single output
     # channel split
     cs = cin // 2 if (cin // 2) % 8 == 0 else 8
     outs, _ = conv_mfma([src], wpk, N, H, W, cin, ks, co_t, csplit=cs)
     assert relerr(outs[0], ref[:, :cs]) < TOL and relerr(outs[1], ref[:, cs:]) < TOL
 
 
-@pytest.mark.parametrize("ks,cin,cout,H,W,two", [(3, 16, 16, 32, 32, False), (3, 32, 64, 16, 32, True), (3, 80, 48, 20, 36, True),
+@pytest.mark.parametrize("ks,cin,cout,H,W,two", [(3, 16, 16, 32, 32, False), (3, 32, 16, 36, 70, True), (3, 48, 8, 20, 32, False), (3, 32, 64, 16, 32, True), (3, 80, 48, 20, 36, True),
                                                   (3, 64, 16, 8, 64, False), (1, 96, 24, 16, 16, False), (1, 24, 144, 16, 24, False),
                                                   (1, 160, 320, 8, 8, False), (1, 320, 1280, 2, 3, False), (3, 256, 256, 4, 6, False)])
 def test_conv_wgrad(hip, ks, cin, cout, H, W, two):
