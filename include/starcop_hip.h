@@ -142,7 +142,7 @@ size_t sc_stem_wgrad_workspace_floats(int N, int Cin, int Hin, int Win);
 int sc_stem_conv_wgrad(const sc_src* dy, const sc_src* in, float* part, size_t part_floats,
                        float* dw, int N, int Cin, int Hin, int Win, sc_stream stream);
 
-/* segmentation head: conv 3x3 pad 1, Cin(16) -> 1, bias */
+/* segmentation head: conv 3x3 pad 1, Cin -> 1, bias (fwd/dgrad: Cin <= 32; wgrad: Cin in {8, 16}) */
 int sc_head_conv_fwd(const sc_src* in, const float* w /*[1][Cin][3][3]*/, const float* bias,
                      float* out, int N, int Cin, int H, int W, sc_stream stream);
 int sc_head_conv_dgrad(const float* dlogits, const float* w, float* gin,

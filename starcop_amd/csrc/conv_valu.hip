@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_dw_dgrad(const SrcD dy, const float* __
 // dW[c][tap] += sum over this block's (n, tile) list of dy * x; 9 double atomics per block
 template <int S, int TW>
 __global__ __launch_bounds__(256) void k_dw_wgrad(const SrcD dy, const SrcD in, double* __restrict__ dw_acc, int N, int C,
-                                                  int Hin, int Win, int Hout, int Wout) {
+                                                  int Hin, int Win, int Hout, int Wout, int dy_bcast) {
   constexpr int TH = 256 / TW;
   constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PWP = PW | 1;
   __shared__ float s_x[PH * PWP];
@@ -145,7 +145,8 @@ __global__ __launch_bounds__(256) void k_dw_wgrad(const SrcD dy, const SrcD in, 
   if (in.mode != SC_SRC_RAW) { xs = in.cst[(size_t)c * SC_CST]; xh = in.cst[(size_t)c * SC_CST + 1]; }
   const float xlo = sc_act_lo(in.act), xhi = sc_act_hi(in.act);
   float4 c0 = make_float4(1.f, 0.f, 0.f, 0.f); float c4 = 0.f;
-  if (dy.mode != SC_SRC_RAW) { c0 = *reinterpret_cast<const float4*>(dy.cst + (size_t)c * SC_CST); c4 = dy.cst[(size_t)c * SC_CST + 4]; }
+  const int cd = dy_bcast ? 0 : c, Cd = dy_bcast ? 1 : C;      // dy_bcast: one dy plane shared by every channel (head conv)
+  if (dy.mode != SC_SRC_RAW) { c0 = *reinterpret_cast<const float4*>(dy.cst + (size_t)cd * SC_CST); c4 = dy.cst[(size_t)cd * SC_CST + 4]; }
   const float dlo = sc_act_lo(dy.act), dhi = sc_act_hi(dy.act);
   const bool bnb = dy.mode == SC_SRC_BNBWD;
   const int ty = threadIdx.x / TW, tx = threadIdx.x % TW;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void k_dw_wgrad(const SrcD dy, const SrcD in, 
     }
     const int oy = ty0 + ty, ox = tx0 + tx;
     const bool ok = (oy < Hout) && (ox < Wout);
-    const size_t o = ((size_t)n * C + c) * Hout * Wout + (ok ? (size_t)oy * Wout + ox : 0);
+    const size_t o = ((size_t)n * Cd + cd) * Hout * Wout + (ok ? (size_t)oy * Wout + ox : 0);
     const float g = dy.x[o];
     const float yv = bnb ? dy.aux[o] : g;
     float dyv = bnb ? sc_pro_bnbwd(g, yv, c0.x, c0.y, c0.z, c0.w, c4, dlo, dhi) : sc_pro_affine(g, c0.x, c0.y, dlo, dhi);
@@ -245,36 +246,69 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const SrcD in, const float* __
   }
 }
 
-// dW[co][ci][tap] = sum dy[co][oy][ox] * in[ci][2oy+kh-1][2ox+kw-1]; one partial row per block
-// tile = 8 x 32 output pixels; thread = (co = tid&31, group = tid>>5) owns combos j = group + 8k
+// dW[co][ci][tap] = sum dy[co][oy][ox] * in[ci][2oy+kh-1][2ox+kw-1] as a GEMM on v_mfma_f32_16x16x4_f32:
+//   D[co][j] (j = ci*9+tap, padded to 16*NJB) = sum_px A[co][px] * B[px][j];  A = dy tile (BatchNorm/ReLU6 backward
+//   applied on load), B gathered from the normalised input patch (lane j carries its own (ci,kh,kw) offset).
+// Tile = 4 output rows x 32 px, wave w owns row w and writes its own partial row (part[block*4 + w][co][j]).
+template <int NJB>
 __global__ __launch_bounds__(256) void k_stem_wgrad(const SrcD dy, const SrcD in, float* __restrict__ part, int N, int Cin,
                                                     int Hin, int Win, int Hout, int Wout) {
-  constexpr int TR = 8, TC = 32;
-  constexpr int IR = 2 * TR + 1, IC = 2 * TC + 1, ICP = IC + 2;
-  __shared__ float s_dy[STEM_CO * (TR * TC + 1)];
+  constexpr int TR = 4, TC = 32, PA = 130;
+  constexpr int IR = 2 * TR + 1, IC = 2 * TC + 1, ICP = 67;
+  __shared__ float s_dy[STEM_CO * PA];
   __shared__ float s_x[STEM_MAXCI * IR * ICP];
-  const int co = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int ncomb = Cin * 9;
-  constexpr int MAXK = (STEM_MAXCI * 9 + 7) / 8;
-  float acc[MAXK];
+  __shared__ __attribute__((aligned(16))) float s_c[STEM_CO * SC_CST];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int J = Cin * 9;
+  for (int i = tid; i < STEM_CO * SC_CST; i += 256)
+    s_c[i] = (dy.cst && dy.mode != SC_SRC_RAW) ? dy.cst[i] : ((i % SC_CST) == 0 ? 1.f : 0.f);
+  // per-lane gather offsets of the B operand
+  int boff[NJB]; bool bok[NJB];
 #pragma unroll
-  for (int k = 0; k < MAXK; ++k) acc[k] = 0.f;
+  for (int jb = 0; jb < NJB; ++jb) {
+    const int j = jb * 16 + l15;
+    bok[jb] = j < J;
+    const int jj = bok[jb] ? j : 0;
+    const int ci = jj / 9, tap = jj - ci * 9;
+    boff[jb] = (ci * IR + tap / 3) * ICP + (tap % 3);
+  }
+  floatx4 acc[2][NJB];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb) acc[cb][jb] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  const float dlo = sc_act_lo(dy.act), dhi = sc_act_hi(dy.act);
+  const bool bnb = dy.mode == SC_SRC_BNBWD;
   const int tiles_x = (Wout + TC - 1) / TC, tiles_y = (Hout + TR - 1) / TR;
   const long T = (long)N * tiles_x * tiles_y;
+  const size_t HWo = (size_t)Hout * Wout;
   for (long t = blockIdx.x; t < T; t += gridDim.x) {
     const int n = (int)(t / (tiles_x * tiles_y));
     const int rem = (int)(t - (long)n * tiles_x * tiles_y);
     const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
     const int oy0 = ty * TR, ox0 = tx * TC;
     __syncthreads();
-    for (int i = threadIdx.x; i < STEM_CO * TR * TC; i += 256) {
-      const int ch = i / (TR * TC), px = i - ch * (TR * TC);
-      const int oy = oy0 + px / TC, ox = ox0 + (px % TC);
-      float v = 0.f;
-      if (oy < Hout && ox < Wout) v = load_src(dy, ((size_t)n * STEM_CO + ch) * Hout * Wout + (size_t)oy * Wout + ox, ch);
-      s_dy[ch * (TR * TC + 1) + px] = v;
+    {   // dy tile: thread = pixel (tid & 127), channels (tid >> 7) + 2 i
+      const int px = tid & 127, c0i = tid >> 7;
+      const int oy = oy0 + (px >> 5), ox = ox0 + (px & 31);
+      const bool ok = (oy < Hout) && (ox < Wout);
+      const size_t base = ((size_t)n * STEM_CO + c0i) * HWo + (ok ? (size_t)oy * Wout + ox : 0);
+      const float* gp = dy.x + base;
+      const float* yp = bnb ? dy.aux + base : gp;
+      float g[16], yv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { g[i] = gp[(size_t)(2 * i) * HWo]; yv[i] = yp[(size_t)(2 * i) * HWo]; }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ch = c0i + 2 * i;
+        const float4 c0 = *reinterpret_cast<const float4*>(&s_c[ch * SC_CST]);
+        const float v = bnb ? sc_pro_bnbwd(g[i], yv[i], c0.x, c0.y, c0.z, c0.w, s_c[ch * SC_CST + 4], dlo, dhi)
+                            : sc_pro_affine(g[i], c0.x, c0.y, dlo, dhi);
+        s_dy[ch * PA + px] = ok ? v : 0.f;
+      }
     }
-    for (int i = threadIdx.x; i < Cin * IR * IC; i += 256) {
+    for (int i = tid; i < Cin * IR * IC; i += 256) {
       const int ci = i / (IR * IC), e = i - ci * (IR * IC);
       const int r = e / IC, cc = e - r * IC;
       const int iy = 2 * oy0 - 1 + r, ix = 2 * ox0 - 1 + cc;
@@ -283,58 +317,111 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const SrcD dy, const SrcD in
       s_x[(ci * IR + r) * ICP + cc] = v;
     }
     __syncthreads();
-    for (int px = 0; px < TR * TC; ++px) {
-      const float a = s_dy[co * (TR * TC + 1) + px];
-      const int py = px / TC, pxx = px % TC;
+    const int row = wave;
+#pragma unroll 2
+    for (int q = 0; q < 8; ++q) {
+      const int px = 4 * q + lq;
+      const float a0 = s_dy[l15 * PA + row * 32 + px];
+      const float a1 = s_dy[(16 + l15) * PA + row * 32 + px];
 #pragma unroll
-      for (int k = 0; k < MAXK; ++k) {
-        const int j = grp + 8 * k;
-        if (j < ncomb) {
-          const int ci = j / 9, tap = j - ci * 9;
-          const int kh = tap / 3, kw = tap - kh * 3;
-          acc[k] = fmaf(a, s_x[(ci * IR + 2 * py + kh) * ICP + 2 * pxx + kw], acc[k]);
-        }
+      for (int jb = 0; jb < NJB; ++jb) {
+        const float bv = s_x[boff[jb] + (2 * row) * ICP + 2 * px];
+        const float b = bok[jb] ? bv : 0.f;
+        acc[0][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][jb], 0, 0, 0);
+        acc[1][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][jb], 0, 0, 0);
       }
     }
   }
-  float* pr = part + (size_t)blockIdx.x * (STEM_CO * ncomb);
+  float* pr = part + ((size_t)blockIdx.x * 4 + wave) * (STEM_CO * J);
 #pragma unroll
-  for (int k = 0; k < MAXK; ++k) {
-    const int j = grp + 8 * k;
-    if (j < ncomb) pr[co * ncomb + j] = acc[k];   // [co][ci][tap] (OIHW order)
-  }
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = cb * 16 + 4 * lq + r, j = jb * 16 + l15;
+        if (j < J) pr[co * J + j] = acc[cb][jb][r];      // [co][ci][tap] (OIHW order)
+      }
 }
 
 // ---------------------------------------------------------------- head (3x3, Cin<=32 -> 1, bias)
 constexpr int HEAD_MAXCI = 32;
 constexpr int HT_R = 8, HT_C = 32;
 
+// stage the activated input patch [Cin][HT_R+2][PC] once (branch-free BatchNorm+ReLU prologue, clamped loads).
+// CIN > 0: every global load of the patch is issued before the first LDS store (one latency, not one per element).
+template <int PC, int CIN>
+__device__ __forceinline__ void head_stage_patch(const SrcD& in, float* s_in, int n, int Cin, int H, int W, int y0, int x0) {
+  constexpr int PR = HT_R + 2, PW = HT_C + 2;
+  const float lo = sc_act_lo(in.act), hi = sc_act_hi(in.act);
+  const bool raw = in.mode == SC_SRC_RAW;
+  if (CIN > 0) {
+    constexpr int NIT = ((CIN > 0 ? CIN : 1) * PR * PW + 255) / 256;
+    float xv[NIT], sc[NIT], sh[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = threadIdx.x + 256 * it;
+      const int ii = i < CIN * PR * PW ? i : 0;
+      const int ci = ii / (PR * PW), e = ii - ci * (PR * PW);
+      const int r = e / PW, cc = e - r * PW;
+      const int y = y0 - 1 + r, x = x0 - 1 + cc;
+      const bool ok = (y >= 0) && (y < H) && (x >= 0) && (x < W);
+      xv[it] = in.x[((size_t)n * CIN + ci) * H * W + (ok ? (size_t)y * W + x : 0)];
+      sc[it] = raw ? 1.f : in.cst[(size_t)ci * SC_CST];
+      sh[it] = raw ? 0.f : in.cst[(size_t)ci * SC_CST + 1];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = threadIdx.x + 256 * it;
+      if (i < CIN * PR * PW) {
+        const int ci = i / (PR * PW), e = i - ci * (PR * PW);
+        const int r = e / PW, cc = e - r * PW;
+        const int y = y0 - 1 + r, x = x0 - 1 + cc;
+        const bool ok = (y >= 0) && (y < H) && (x >= 0) && (x < W);
+        s_in[(ci * PR + r) * PC + cc] = ok ? sc_pro_affine(xv[it], sc[it], sh[it], lo, hi) : 0.f;
+      }
+    }
+    return;
+  }
+  for (int i = threadIdx.x; i < Cin * PR * PW; i += 256) {
+    const int ci = i / (PR * PW), e = i - ci * (PR * PW);
+    const int r = e / PW, cc = e - r * PW;
+    const int y = y0 - 1 + r, x = x0 - 1 + cc;
+    const bool ok = (y >= 0) && (y < H) && (x >= 0) && (x < W);
+    const float xv = in.x[((size_t)n * Cin + ci) * H * W + (ok ? (size_t)y * W + x : 0)];
+    const float sc = raw ? 1.f : in.cst[(size_t)ci * SC_CST], sh = raw ? 0.f : in.cst[(size_t)ci * SC_CST + 1];
+    s_in[(ci * PR + r) * PC + cc] = ok ? sc_pro_affine(xv, sc, sh, lo, hi) : 0.f;
+  }
+}
+
+// CIN > 0: compile-time channel count -> the 9*CIN filter taps are scalar (SGPR) operands; CIN == 0: generic, taps in LDS
+template <int CIN>
 __global__ __launch_bounds__(256) void k_head_fwd(const SrcD in, const float* __restrict__ w, const float* __restrict__ bias,
-                                                  float* __restrict__ out, int Cin, int H, int W) {
+                                                  float* __restrict__ out, int Cin_rt, int H, int W) {
   constexpr int PR = HT_R + 2, PC = HT_C + 2;
-  __shared__ float s_in[HEAD_MAXCI * PR * PC];
+  __shared__ float s_in[(CIN > 0 ? CIN : HEAD_MAXCI) * PR * PC];
   __shared__ float s_w[HEAD_MAXCI * 9];
+  const int Cin = CIN > 0 ? CIN : Cin_rt;
   const int n = blockIdx.z;
   const int tiles_x = (W + HT_C - 1) / HT_C;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int y0 = ty * HT_R, x0 = tx * HT_C;
-  for (int i = threadIdx.x; i < Cin * 9; i += 256) s_w[i] = w[i];
-  for (int i = threadIdx.x; i < Cin * PR * PC; i += 256) {
-    const int ci = i / (PR * PC), e = i - ci * (PR * PC);
-    const int r = e / PC, cc = e - r * PC;
-    const int y = y0 - 1 + r, x = x0 - 1 + cc;
-    float v = 0.f;
-    if (y >= 0 && y < H && x >= 0 && x < W) v = load_src(in, ((size_t)n * Cin + ci) * H * W + (size_t)y * W + x, ci);
-    s_in[i] = v;
-  }
+  if (CIN == 0) for (int i = threadIdx.x; i < Cin * 9; i += 256) s_w[i] = w[i];
+  head_stage_patch<PC, CIN>(in, s_in, n, Cin, H, W, y0, x0);
   __syncthreads();
   const int py = threadIdx.x >> 5, px = threadIdx.x & 31;
   const int y = y0 + py, x = x0 + px;
   if (y >= H || x >= W) return;
   float acc = bias ? bias[0] : 0.f;
-  for (int ci = 0; ci < Cin; ++ci) {
+  if (CIN > 0) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc = fmaf(s_w[ci * 9 + t], s_in[(ci * PR + py + t / 3) * PC + px + (t % 3)], acc);
+    for (int ci = 0; ci < (CIN > 0 ? CIN : 1); ++ci)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc = fmaf(w[ci * 9 + t], s_in[(ci * PR + py + t / 3) * PC + px + (t % 3)], acc);
+  } else {
+    for (int ci = 0; ci < Cin; ++ci)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc = fmaf(s_w[ci * 9 + t], s_in[(ci * PR + py + t / 3) * PC + px + (t % 3)], acc);
   }
   out[(size_t)n * H * W + (size_t)y * W + x] = acc;
 }
@@ -370,56 +457,13 @@ __global__ __launch_bounds__(256) void k_head_dgrad(const float* __restrict__ dl
   }
 }
 
-// part[block][Cin*9 + 1]: dW[ci][tap] then dbias
-__global__ __launch_bounds__(256) void k_head_wgrad(const float* __restrict__ dl, const SrcD in, float* __restrict__ part,
-                                                    int N, int Cin, int H, int W) {
-  constexpr int PR = HT_R + 2, PC = HT_C + 3;   // 35: odd pitch
-  __shared__ float s_in[HEAD_MAXCI * PR * PC];
-  __shared__ float s_dl[HT_R * HT_C];
-  const int nout = Cin * 9 + 1;
-  const int t_id = threadIdx.x;
-  const bool is_w = t_id < Cin * 9, is_b = t_id == Cin * 9;
-  const int ci = is_w ? t_id / 9 : 0, tap = is_w ? t_id - ci * 9 : 0;
-  const int kh = tap / 3, kw = tap - kh * 3;
-  float acc = 0.f;
-  const int tiles_x = (W + HT_C - 1) / HT_C, tiles_y = (H + HT_R - 1) / HT_R;
-  const long T = (long)N * tiles_x * tiles_y;
-  for (long t = blockIdx.x; t < T; t += gridDim.x) {
-    const int n = (int)(t / (tiles_x * tiles_y));
-    const int rem = (int)(t - (long)n * tiles_x * tiles_y);
-    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-    const int y0 = ty * HT_R, x0 = tx * HT_C;
-    __syncthreads();
-    for (int i = t_id; i < Cin * PR * (HT_C + 2); i += 256) {
-      const int c = i / (PR * (HT_C + 2)), e = i - c * (PR * (HT_C + 2));
-      const int r = e / (HT_C + 2), cc = e - r * (HT_C + 2);
-      const int y = y0 - 1 + r, x = x0 - 1 + cc;
-      float v = 0.f;
-      if (y >= 0 && y < H && x >= 0 && x < W) v = load_src(in, ((size_t)n * Cin + c) * H * W + (size_t)y * W + x, c);
-      s_in[(c * PR + r) * PC + cc] = v;
-    }
-    {
-      const int py = t_id >> 5, px = t_id & 31;
-      const int y = y0 + py, x = x0 + px;
-      s_dl[t_id] = (y < H && x < W) ? dl[(size_t)n * H * W + (size_t)y * W + x] : 0.f;
-    }
-    __syncthreads();
-    if (is_w) {
-      for (int px = 0; px < HT_R * HT_C; ++px) {
-        const int py = px >> 5, pxx = px & 31;
-        acc = fmaf(s_dl[px], s_in[(ci * PR + py + kh) * PC + pxx + kw], acc);
-      }
-    } else if (is_b) {
-      for (int px = 0; px < HT_R * HT_C; ++px) acc += s_dl[px];
-    }
-  }
-  if (is_w || is_b) part[(size_t)blockIdx.x * nout + t_id] = acc;
-}
-
-__global__ void k_split_head(const float* __restrict__ red, float* dw, float* dbias, int nw) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nw) dw[i] = red[i];
-  else if (i == nw && dbias) dbias[0] = red[nw];
+// sum of a float array into a double accumulator (bias gradient of the head = sum of dlogits)
+__global__ __launch_bounds__(256) void k_sum_f32_to_f64(const float* __restrict__ x, size_t n, double* acc) {
+  __shared__ float s_tmp[4];
+  float v[1] = {0.f};
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) v[0] += x[i];
+  block_sum<1>(v, s_tmp);
+  if (threadIdx.x == 0) atomicAdd(acc, (double)v[0]);
 }
 
 __global__ void k_cast_f64_f32(const double* __restrict__ in, float* __restrict__ out, size_t n) {
@@ -427,8 +471,8 @@ __global__ void k_cast_f64_f32(const double* __restrict__ in, float* __restrict_
 }
 
 int stem_blocks(int N, int Hout, int Wout) {
-  long T = (long)N * ((Wout + 31) / 32) * ((Hout + 7) / 8);
-  return (int)(T < 512 ? T : 512);
+  long T = (long)N * ((Wout + 31) / 32) * ((Hout + 3) / 4);
+  return (int)(T < 1024 ? T : 1024);
 }
 int head_blocks(int N, int H, int W) {
   long T = (long)N * ((W + HT_C - 1) / HT_C) * ((H + HT_R - 1) / HT_R);
@@ -483,7 +527,7 @@ extern "C" int sc_dwconv3x3_wgrad(const sc_src* dy, const sc_src* in, double* dw
   const long t32 = (long)N * ((Wout + 31) / 32) * ((Hout + 7) / 8), t16 = (long)N * ((Wout + 15) / 16) * ((Hout + 15) / 16);
   const long want = 4096 / C > 0 ? 4096 / C : 1;
   dim3 grid32((unsigned)(t32 < want ? t32 : want), C), grid16((unsigned)(t16 < want ? t16 : want), C);
-  SC_DW_DISPATCH(k_dw_wgrad, Wout, to_srcd(*dy), to_srcd(*in), dw_acc, N, C, Hin, Win, Hout, Wout);
+  SC_DW_DISPATCH(k_dw_wgrad, Wout, to_srcd(*dy), to_srcd(*in), dw_acc, N, C, Hin, Win, Hout, Wout, 0);
   SC_LAUNCH_OK("sc_dwconv3x3_wgrad");
   return SC_OK;
 }
@@ -510,7 +554,7 @@ extern "C" int sc_stem_conv_fwd(const sc_src* in, const float* w, float* out, in
 
 extern "C" size_t sc_stem_wgrad_workspace_floats(int N, int Cin, int Hin, int Win) {
   const int Hout = (Hin - 1) / 2 + 1, Wout = (Win - 1) / 2 + 1;
-  const int nb = stem_blocks(N, Hout, Wout);
+  const int nb = 4 * stem_blocks(N, Hout, Wout);      // one partial row per wave
   const size_t E = (size_t)STEM_CO * Cin * 9;
   return (size_t)nb * E + sc_reduce_scratch_floats(nb, E);
 }
@@ -523,18 +567,22 @@ extern "C" int sc_stem_conv_wgrad(const sc_src* dy, const sc_src* in, float* par
   const int Hout = (Hin - 1) / 2 + 1, Wout = (Win - 1) / 2 + 1;
   const int nb = stem_blocks(N, Hout, Wout);
   const size_t E = (size_t)STEM_CO * Cin * 9;
-  hipLaunchKernelGGL(k_stem_wgrad, dim3(nb), dim3(256), 0, (hipStream_t)stream, to_srcd(*dy), to_srcd(*in), part, N, Cin, Hin, Win, Hout, Wout);
+  hipStream_t st = (hipStream_t)stream;
+  const int njb = (Cin * 9 + 15) / 16;
+  if (njb <= 3) hipLaunchKernelGGL((k_stem_wgrad<3>), dim3(nb), dim3(256), 0, st, to_srcd(*dy), to_srcd(*in), part, N, Cin, Hin, Win, Hout, Wout);
+  else hipLaunchKernelGGL((k_stem_wgrad<5>), dim3(nb), dim3(256), 0, st, to_srcd(*dy), to_srcd(*in), part, N, Cin, Hin, Win, Hout, Wout);
   SC_LAUNCH_OK("sc_stem_conv_wgrad");
-  return sc_reduce_rows(part, nb, E, part + (size_t)nb * E, dw, (hipStream_t)stream);
+  return sc_reduce_rows(part, 4 * nb, E, part + (size_t)4 * nb * E, dw, st);
 }
 
 extern "C" int sc_head_conv_fwd(const sc_src* in, const float* w, const float* bias, float* out, int N, int Cin,
                                 int H, int W, sc_stream stream) {
   SC_REQUIRE(in && in->C == Cin, "sc_head_conv_fwd: source channels != Cin");
   SC_REQUIRE(Cin >= 1 && Cin <= HEAD_MAXCI, "sc_head_conv_fwd: Cin must be in [1,%d]", HEAD_MAXCI);
-  SC_REQUIRE(in->mode != SC_SRC_BNBWD && in->up == 0, "sc_head_conv_fwd: unsupported source mode");
+  SC_REQUIRE((in->mode == SC_SRC_RAW || in->mode == SC_SRC_AFFINE) && in->up == 0, "sc_head_conv_fwd: unsupported source mode");
   dim3 grid(((W + HT_C - 1) / HT_C) * ((H + HT_R - 1) / HT_R), 1, N);
-  hipLaunchKernelGGL(k_head_fwd, grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), w, bias, out, Cin, H, W);
+  if (Cin == 16) hipLaunchKernelGGL((k_head_fwd<16>), grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), w, bias, out, Cin, H, W);
+  else hipLaunchKernelGGL((k_head_fwd<0>), grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), w, bias, out, Cin, H, W);
   SC_LAUNCH_OK("sc_head_conv_fwd");
   return SC_OK;
 }
@@ -549,26 +597,36 @@ extern "C" int sc_head_conv_dgrad(const float* dlogits, const float* w, float* g
 }
 
 extern "C" size_t sc_head_wgrad_workspace_floats(int N, int Cin, int H, int W) {
-  const int nb = head_blocks(N, H, W);
-  const size_t E = (size_t)Cin * 9 + 1;
-  return (size_t)nb * E + sc_reduce_scratch_floats(nb, E) + E;
+  (void)N; (void)H; (void)W;
+  return 2 * ((size_t)Cin * 9 + 1) + 2;       // Cin*9 + 1 double accumulators
 }
 
+// dW[0][ci][tap] = sum_px dlogits[px] * act(in)[ci][px + d(tap)]: the depthwise weight-gradient kernel with the single
+// dlogits plane shared by all input channels; dbias = sum dlogits.
 extern "C" int sc_head_conv_wgrad(const float* dlogits, const sc_src* in, float* part, size_t part_floats, float* dw,
                                   float* dbias, int N, int Cin, int H, int W, sc_stream stream) {
   SC_REQUIRE(in && in->C == Cin, "sc_head_conv_wgrad: source channels != Cin");
-  SC_REQUIRE(Cin >= 1 && Cin * 9 + 1 <= 256, "sc_head_conv_wgrad: Cin must be in [1,28]");
+  SC_REQUIRE(Cin >= 1 && Cin <= HEAD_MAXCI, "sc_head_conv_wgrad: Cin must be in [1,%d]", HEAD_MAXCI);
+  SC_REQUIRE((in->mode == SC_SRC_RAW || in->mode == SC_SRC_AFFINE) && in->up == 0, "sc_head_conv_wgrad: unsupported source mode");
   SC_REQUIRE(part_floats >= sc_head_wgrad_workspace_floats(N, Cin, H, W), "sc_head_conv_wgrad: workspace too small");
-  const int nb = head_blocks(N, H, W);
-  const size_t E = (size_t)Cin * 9 + 1;
+  SC_REQUIRE(((uintptr_t)part & 7) == 0, "sc_head_conv_wgrad: workspace must be 8-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_head_wgrad, dim3(nb), dim3(256), 0, st, dlogits, to_srcd(*in), part, N, Cin, H, W);
+  double* acc = reinterpret_cast<double*>(part);
+  const size_t nacc = (size_t)Cin * 9 + 1;
+  if (hipMemsetAsync(acc, 0, nacc * sizeof(double), st) != hipSuccess) { sc_set_error("sc_head_conv_wgrad: memset failed"); return SC_ERR_LAUNCH; }
+  SrcD dy = empty_srcd();
+  dy.x = dlogits; dy.C = 1; dy.mode = SC_SRC_RAW;
+  const int stride = 1, Hout = H, Wout = W;
+  const long t32 = (long)N * ((Wout + 31) / 32) * ((Hout + 7) / 8), t16 = (long)N * ((Wout + 15) / 16) * ((Hout + 15) / 16);
+  const long want = 4096 / Cin > 0 ? 4096 / Cin : 1;
+  dim3 grid32((unsigned)(t32 < want ? t32 : want), Cin), grid16((unsigned)(t16 < want ? t16 : want), Cin);
+  SC_DW_DISPATCH(k_dw_wgrad, Wout, dy, to_srcd(*in), acc, N, Cin, H, W, Hout, Wout, 1);
   SC_LAUNCH_OK("sc_head_conv_wgrad");
-  float* scratch = part + (size_t)nb * E;
-  float* red = scratch + sc_reduce_scratch_floats(nb, E);
-  int rc = sc_reduce_rows(part, nb, E, scratch, red, st);
-  if (rc != SC_OK) return rc;
-  hipLaunchKernelGGL(k_split_head, dim3(((int)E + 255) / 256), dim3(256), 0, st, red, dw, dbias, Cin * 9);
-  SC_LAUNCH_OK("sc_head_split");
+  const size_t npx = (size_t)N * H * W;
+  hipLaunchKernelGGL(k_sum_f32_to_f64, dim3((unsigned)((npx + 4095) / 4096 > 512 ? 512 : (npx + 4095) / 4096)), dim3(256), 0, st, dlogits, npx, acc + Cin * 9);
+  SC_LAUNCH_OK("sc_head_conv_wgrad(bias)");
+  hipLaunchKernelGGL(k_cast_f64_f32, dim3(1), dim3(256), 0, st, acc, dw, (size_t)Cin * 9);
+  if (dbias) hipLaunchKernelGGL(k_cast_f64_f32, dim3(1), dim3(64), 0, st, acc + Cin * 9, dbias, (size_t)1);
+  SC_LAUNCH_OK("sc_head_conv_wgrad(cast)");
   return SC_OK;
 }

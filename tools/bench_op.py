@@ -19,6 +19,16 @@ flop = 2.0 * N * H * W * cin * cout * ks * ks
 
 
 def run():
+    if op == "headwgrad":
+        import ctypes as C
+        from starcop_amd import _lib
+        from starcop_amd._lib import check, ptr, stream
+        lib = _lib.load()
+        nws = lib.sc_head_wgrad_workspace_floats(N, cin, H, W)
+        ws = torch.empty(nws, device=DEV); dw = torch.empty(1, cin, 3, 3, device=DEV); db = torch.empty(1, device=DEV)
+        src = make_src(x, cin, SRC_AFFINE, act=ACT_RELU, cst=cin_cst)
+        check(lib.sc_head_conv_wgrad(ptr(g), C.byref(src), ptr(ws), nws, ptr(dw), ptr(db), N, cin, H, W, stream()))
+        return dw
     if op == "wgrad":
         dys = make_src(g, cout, SRC_BNBWD, act=ACT_RELU, cst=cst, aux=y)
         return wgrad_mfma(dys, [make_src(x, cin, SRC_AFFINE, act=ACT_RELU, cst=cin_cst)], N, H, W, cout, cin, ks)
