@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="tiles per GPU (weak scaling)")
     ap.add_argument("--tile", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay the step from a captured hipGraph (default: eager two-stream launches, measured faster)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

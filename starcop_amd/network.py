@@ -457,10 +457,32 @@ class HyperStarcopUNet(nn.Module):
             self._nbt = nbt
         return nbt
 
+    # weight gradients are off the critical path (nothing in the backward pass consumes them): they run on a second
+    # HIP stream, forked after each layer's BatchNorm-backward constants and joined before the optimiser, so they fill
+    # the CUs the small dgrad / reduce kernels of the dependency chain leave idle.
+    overlap_wgrad = True
+    _side_stream = None
+
     def _backward_impl(self, plan, dlogits):
         """Fills the flat gradient buffer from dL/dlogits.  Needs the plan of a training-mode forward."""
         lib = _lib.load()
         st = stream()
+        main = torch.cuda.current_stream()
+        side = None
+        if self.overlap_wgrad:
+            if self._side_stream is None or self._side_stream.device != main.device:
+                self._side_stream = torch.cuda.Stream(device=main.device)
+            side = self._side_stream
+
+        def wgrad_launch(fn):
+            """run fn(stream_handle) on the weight-gradient stream, ordered after everything queued on the main stream"""
+            if side is None:
+                fn(st)
+            else:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    fn(stream())
+
         N, H, W = plan.N, plan.H, plan.W
         if not getattr(plan, "training", False):
             raise RuntimeError("HyperStarcopUNet.backward: gradients need a train-mode forward (BatchNorm batch "
@@ -497,8 +519,9 @@ class HyperStarcopUNet(nn.Module):
                 tin = op["ins"][0]
                 s = self._src_of(plan, tin)
                 tok = self._pb("k_head_*")
-                check(lib.sc_head_conv_wgrad(ptr(dlogits), C.byref(s), ptr(plan.ws), plan.ws_floats, ptr(gv(conv.weight)),
-                                             ptr(gv(conv.bias)), N, conv.in_channels, Ho, Wo, st))
+                wgrad_launch(lambda sx: check(lib.sc_head_conv_wgrad(
+                    ptr(dlogits), C.byref(s), ptr(plan.ws), plan.ws_floats, ptr(gv(conv.weight)), ptr(gv(conv.bias)), N,
+                    conv.in_channels, Ho, Wo, sx)))
                 check(lib.sc_head_conv_dgrad(ptr(dlogits), ptr(conv.weight), ptr(plan.grad[tin.name]), N,
                                              conv.in_channels, Ho, Wo, st))
                 self._pe(tok)
@@ -517,8 +540,8 @@ class HyperStarcopUNet(nn.Module):
             if ty == "stem":
                 s = self._src_of(plan, op["ins"][0], x_cst=plan.x_cst)
                 tok = self._pb("k_stem_*")
-                check(lib.sc_stem_conv_wgrad(C.byref(dy), C.byref(s), ptr(plan.ws), plan.ws_floats, ptr(gv(conv.weight)),
-                                             N, conv.in_channels, H, W, st))
+                wgrad_launch(lambda sx: check(lib.sc_stem_conv_wgrad(C.byref(dy), C.byref(s), ptr(plan.ws), plan.ws_floats,
+                                                                     ptr(gv(conv.weight)), N, conv.in_channels, H, W, sx)))
                 self._pe(tok)
                 continue
             if ty == "dw":
@@ -527,8 +550,11 @@ class HyperStarcopUNet(nn.Module):
                 s = self._src_of(plan, tin)
                 acc = plan.dw_acc[dw_offs[i]:dw_offs[i] + o.C * 9]
                 tok = self._pb("k_dw_*")
-                check(lib.sc_dwconv3x3_wgrad(C.byref(dy), C.byref(s), ptr(acc), N, o.C, Hi, Wi, op["stride"], st))
-                check(lib.sc_cast_f64_f32(ptr(acc), ptr(gv(conv.weight)), o.C * 9, st))
+
+                def dw_wgrad(sx, dy=dy, s=s, acc=acc, conv=conv, o=o, Hi=Hi, Wi=Wi, stride=op["stride"]):
+                    check(lib.sc_dwconv3x3_wgrad(C.byref(dy), C.byref(s), ptr(acc), N, o.C, Hi, Wi, stride, sx))
+                    check(lib.sc_cast_f64_f32(ptr(acc), ptr(gv(conv.weight)), o.C * 9, sx))
+                wgrad_launch(dw_wgrad)
                 check(lib.sc_dwconv3x3_dgrad(C.byref(dy), ptr(conv.weight), ptr(plan.grad[tin.name]),
                                              1 if tin.name in written else 0, N, o.C, Hi, Wi, op["stride"], st))
                 self._pe(tok)
@@ -548,7 +574,7 @@ class HyperStarcopUNet(nn.Module):
             wa.dw = gv(conv.weight).data_ptr()
             flop = 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * ks * ks
             tok = self._pb(f"k_wgrad_mfma<{ks}> (+reduce)", flop)
-            check(lib.sc_conv2d_wgrad_mfma(C.byref(wa), st))
+            wgrad_launch(lambda sx: check(lib.sc_conv2d_wgrad_mfma(C.byref(wa), sx)))
             self._pe(tok)
             # data gradient
             if ins[0].kind == "input":
@@ -590,6 +616,8 @@ class HyperStarcopUNet(nn.Module):
                 check(lib.sc_conv2d_mfma(C.byref(a), st))
                 self._pe(tok)
                 written.add(tin.name)
+        if side is not None:
+            main.wait_stream(side)          # join: every weight gradient is in the flat buffer before Adam / all-reduce
 
     # ------------------------------------------------------------------------------------------
     def forward(self, x, normalizer_consts=None):

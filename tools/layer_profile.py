@@ -12,6 +12,7 @@ model = mm.ModelModule(mm.default_settings(pos_weight=1)).to(dev).train()
 opt = model.configure_optimizers()["optimizer"]
 batch = synth_batch(B, T, T, 1, dev)
 net = model.network
+net.overlap_wgrad = False     # serial launches: clean per-kernel timings
 for _ in range(3):
     model.fused_train_step(batch, opt)
 torch.cuda.synchronize()
