@@ -260,6 +260,257 @@ __global__ __launch_bounds__(256) void k_mag1c(const Mag1cP p) {
   if (tid == 0) p.status[g] = notpd ? 1 : 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// alpha == 0 (the AVIRIS-NG driver, process_aviris.py:210): no shrinkage, so C_k differs from C_0/N by an exact rank-2
+// term and C_k^{-1} t follows from ONE factorisation per group by the Woodbury identity:
+//   B0 = C_0^{-1} = W/N (W = (C_0/N)^{-1}, formed once: Cholesky -> triangular inverse -> X^T X),  U = [v tau],
+//   M = [[0,-1],[-1,q]]:  (C_0 + U M U^T)^{-1} b = B0 b - B0 U (M^{-1} + U^T B0 U)^{-1} U^T B0 b
+// Per iteration: two mat-vecs (W v, W t_new; W tau is last iteration's W t_new), a 2x2 solve, two streaming passes.
+template <typename T>
+__global__ __launch_bounds__(256) void k_mag1c_fast(const Mag1cP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int g = blockIdx.x;
+  const int S = p.S, LDC = S | 1;                           // odd pitch: conflict-free row-per-lane ds_read_b64
+  const int S16 = (S + 15) & ~15;
+  double* Cm = reinterpret_cast<double*>(smem);             // [S][LDC]: A -> L (lower) + X=L^{-1} (upper, transposed) -> W
+  double* vec = Cm + (size_t)S * LDC;
+  double* xbar = vec, *tmpl = vec + VEC, *tau = vec + 2 * VEC, *mu = vec + 3 * VEC, *tnew = vec + 4 * VEC;
+  double* cit = vec + 5 * VEC, *vv = vec + 6 * VEC, *col = vec + 7 * VEC;
+  double* p1 = vec + 8 * VEC, *p2 = vec + 9 * VEC, *p3 = vec + 10 * VEC;
+  double* red = vec + 11 * VEC;      // [16]
+  double* stg = red + 16;            // [S16][17]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int P = p.P[g], pitch = p.Ppad[g];
+  const T* X = reinterpret_cast<const T*>(p.x) + p.xoff[g];
+  const long long po = p.poff[g];
+  const unsigned char* mk = p.statmask ? p.statmask + po : nullptr;
+  double* mfw = p.mfw + po; double* Rw = p.Rw + po; double* wv = p.wv + po;
+  double* C0 = p.workC + (size_t)g * S * S;
+  const double N = (double)P;
+
+  // ---------------- phase A: band means
+  double nstat;
+  {
+    double c = 0.0;
+    for (int q = tid; q < P; q += 256) c += (mk == nullptr || mk[q]) ? 1.0 : 0.0;
+    nstat = block_sum1(c, red);
+  }
+  for (int s = wave; s < S; s += 4) {
+    double a = 0.0;
+    for (int q = lane; q < P; q += 64)
+      if (mk == nullptr || mk[q]) a += (double)X[(size_t)s * pitch + q];
+    a = wave_sum_d(a);
+    if (lane == 0) xbar[s] = a / nstat;
+  }
+  for (int s = tid; s < S; s += 256) tmpl[s] = p.templ[s];
+  __syncthreads();
+
+  // ---------------- phase B: C_0 on the fp64 MFMA, written as A = C_0/N straight into LDS (both triangles)
+  {
+    const int nb = S16 >> 4;
+    const int nblk = nb * (nb + 1) / 2;
+    doublex4 acc[9];
+#pragma unroll
+    for (int b = 0; b < 9; ++b) acc[b] = (doublex4){0.0, 0.0, 0.0, 0.0};
+    for (int c0 = 0; c0 < P; c0 += 16) {
+      __syncthreads();
+      for (int i = tid; i < S16 * 16; i += 256) {
+        const int s = i >> 4, k = i & 15, q = c0 + k;
+        double v = 0.0;
+        if (s < S && q < P && (mk == nullptr || mk[q])) v = (double)X[(size_t)s * pitch + q] - xbar[s];
+        stg[s * 17 + k] = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int b = 0; b < 9; ++b) {
+        const int blk = wave + 4 * b;
+        if (blk < nblk) {
+          int bi = 0, rem = blk;
+          while (rem >= nb - bi) { rem -= nb - bi; ++bi; }
+          const int bj = bi + rem;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const double a = stg[(bi * 16 + (lane & 15)) * 17 + kk * 4 + (lane >> 4)];
+            const double bb = stg[(bj * 16 + (lane & 15)) * 17 + kk * 4 + (lane >> 4)];
+            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[b], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 9; ++b) {
+      const int blk = wave + 4 * b;
+      if (blk < nblk) {
+        int bi = 0, rem = blk;
+        while (rem >= nb - bi) { rem -= nb - bi; ++bi; }
+        const int bj = bi + rem;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = bi * 16 + (lane >> 4) + 4 * r, j = bj * 16 + (lane & 15);
+          if (i < S && j < S) { Cm[i * LDC + j] = acc[b][r] / N; Cm[j * LDC + i] = acc[b][r] / N; }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---------------- Cholesky of A (lower, in place), once per group
+  bool notpd = false;
+  for (int j = 0; j < S; ++j) {
+    const double djj = Cm[j * LDC + j];
+    if (!(djj > 0.0)) notpd = true;
+    const double d = sqrt(djj);
+    for (int i = j + tid; i < S; i += 256) col[i] = (i == j) ? d : Cm[i * LDC + j] / d;
+    __syncthreads();
+    const int ti = tid >> 4, tk = tid & 15;
+    for (int i = j + 1 + ti; i < S; i += 16) {
+      const double ci = col[i];
+      for (int k = j + 1 + tk; k <= i; k += 16) Cm[i * LDC + k] -= ci * col[k];
+    }
+    for (int i = j + tid; i < S; i += 256) Cm[i * LDC + j] = col[i];
+    __syncthreads();
+  }
+  // ---------------- X = L^{-1}: thread j builds column j; X[i][j] (i > j) lives at Cm[j][i] (upper triangle), 1/L[j][j] in col[]
+  if (tid < S) col[tid] = 1.0 / Cm[tid * LDC + tid];
+  __syncthreads();
+  if (tid < S) {
+    const int j = tid;
+    for (int i = j + 1; i < S; ++i) {
+      double a = Cm[i * LDC + j] * col[j];                   // L[i][j] * X[j][j]
+      for (int k = j + 1; k < i; ++k) a = fma(Cm[i * LDC + k], Cm[j * LDC + k], a);
+      Cm[j * LDC + i] = -a * col[i];
+    }
+  }
+  __syncthreads();
+  // ---------------- W = X^T X -> global scratch (the C_0 slot), then back into LDS as a full symmetric matrix
+  for (int e = tid; e < S * S; e += 256) {
+    const int a = e / S, b = e - a * S;
+    if (b > a) continue;
+    // sum_{i >= a} X[i][a] X[i][b]   (a >= b);  X[i][c] = (i == c) ? col[c] : Cm[c][i]
+    double acc = (a == b) ? col[a] * col[a] : col[a] * Cm[b * LDC + a];
+    for (int i = a + 1; i < S; ++i) acc = fma(Cm[a * LDC + i], Cm[b * LDC + i], acc);
+    C0[(size_t)a * S + b] = acc; C0[(size_t)b * S + a] = acc;
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int e = tid; e < S * S; e += 256) { const int a = e / S, b = e - a * S; Cm[a * LDC + b] = C0[e]; }
+  for (int s = tid; s < S; s += 256) { p2[s] = 0.0; vv[s] = 0.0; tau[s] = 0.0; }
+  __syncthreads();
+
+  // ---------------- rmf (it == 0) then the reweighted-L1 iterations
+  double sw = 0.0, sww = 0.0;
+  const int last = p.num_iter < 0 ? 0 : p.num_iter;
+  for (int it = 0; it <= last; ++it) {
+    double wbar = 0.0, q = 0.0;
+    if (it > 0) { wbar = sw / nstat; q = sww - nstat * wbar * wbar; }
+    for (int s = tid; s < S; s += 256) {
+      const double m = (it > 0) ? xbar[s] - wbar * tau[s] : xbar[s];
+      mu[s] = m;
+      tnew[s] = tmpl[s] * m;
+    }
+    __syncthreads();
+    // p1 = W v (threads 0..127), p3 = W t_new (threads 128..255): one row per thread, 4 partial sums
+    {
+      const int r = tid & 127;
+      const double* u = (tid < 128) ? vv : tnew;
+      if (r < S) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int c = 0;
+        for (; c + 3 < S; c += 4) {
+          a0 = fma(Cm[r * LDC + c], u[c], a0); a1 = fma(Cm[r * LDC + c + 1], u[c + 1], a1);
+          a2 = fma(Cm[r * LDC + c + 2], u[c + 2], a2); a3 = fma(Cm[r * LDC + c + 3], u[c + 3], a3);
+        }
+        for (; c < S; ++c) a0 = fma(Cm[r * LDC + c], u[c], a0);
+        ((tid < 128) ? p1 : p3)[r] = (a0 + a1) + (a2 + a3);
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      double d[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // v.p1, v.p2, tau.p2, p1.b, p2.b, b.p3, mu.p1, mu.p2, mu.p3
+      for (int s = lane; s < S; s += 64) {
+        d[0] = fma(vv[s], p1[s], d[0]); d[1] = fma(vv[s], p2[s], d[1]); d[2] = fma(tau[s], p2[s], d[2]);
+        d[3] = fma(p1[s], tnew[s], d[3]); d[4] = fma(p2[s], tnew[s], d[4]); d[5] = fma(tnew[s], p3[s], d[5]);
+        d[6] = fma(mu[s], p1[s], d[6]); d[7] = fma(mu[s], p2[s], d[7]); d[8] = fma(mu[s], p3[s], d[8]);
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) d[k] = wave_sum_d(d[k]);
+      double mm = 0.0;
+      for (int s = lane; s < S; s += 64) mm = fma(mu[s], mu[s], mm);
+      mm = wave_sum_d(mm);
+      double y1 = 0.0, y2 = 0.0;
+      if (it > 0) {
+        // G = M^{-1} + U^T B0 U,  M^{-1} = [[-q,-1],[-1,0]],  B0 = W/N ;  G y = U^T B0 b
+        const double g11 = -q + d[0] / N, g12 = -1.0 + d[1] / N, g22 = d[2] / N;
+        const double z1 = d[3] / N, z2 = d[4] / N;
+        const double det = g11 * g22 - g12 * g12;
+        y1 = (z1 * g22 - z2 * g12) / det;
+        y2 = (g11 * z2 - g12 * z1) / det;
+      }
+      if (lane == 0) {
+        red[8] = d[5] - y1 * d[3] - y2 * d[4];            // normaliser  t . C^{-1} t
+        red[9] = d[8] - y1 * d[6] - y2 * d[7];            // mu . C^{-1} t
+        red[10] = mm; red[11] = y1; red[12] = y2;
+      }
+    }
+    __syncthreads();
+    {
+      const double y1 = red[11], y2 = red[12];
+      for (int s = tid; s < S; s += 256) cit[s] = p3[s] - y1 * p1[s] - y2 * p2[s];
+    }
+    __syncthreads();
+    double norm = red[8];
+    const double mucit = red[9], mumu = red[10];
+    if (!(norm == norm)) notpd = true;
+    if (it > 0 && norm < 1.0) norm = 1.0;
+    double lsw = 0.0, lsww = 0.0;
+    for (int q0 = tid; q0 < P; q0 += 256) {
+      double dot = 0.0, dmu = 0.0;
+      if (it == 0 && !p.albedo_override) {
+        for (int s = 0; s < S; ++s) { const double xv = (double)X[(size_t)s * pitch + q0]; dot = fma(xv, cit[s], dot); dmu = fma(xv, mu[s], dmu); }
+      } else {
+        for (int s = 0; s < S; ++s) dot = fma((double)X[(size_t)s * pitch + q0], cit[s], dot);
+      }
+      const double score = dot - mucit;
+      double R, mf;
+      if (it == 0) {
+        R = p.albedo_override ? 1.0 : dmu / mumu;
+        mf = score / (R * norm);
+        if (!p.zero_override) mf = fmax(mf, 0.0);
+      } else {
+        R = Rw[q0];
+        const double reg = p.sparse_override ? 0.0 : 1.0 / (R * (mfw[q0] + 1e-9));
+        mf = fmax((score - reg) / (R * norm), 0.0);
+      }
+      mfw[q0] = mf;
+      if (it == 0) Rw[q0] = R;
+      const double w = (mk == nullptr || mk[q0]) ? p.kscale * R * mf : 0.0;
+      wv[q0] = w;
+      lsw += w; lsww += w * w;
+    }
+    if (it == last) break;
+    sw = block_sum1(lsw, red);
+    sww = block_sum1(lsww, red + 4);
+    __threadfence_block();
+    __syncthreads();
+    for (int s = wave; s < S; s += 4) {
+      double a = 0.0;
+      for (int q0 = lane; q0 < P; q0 += 64) a = fma((double)X[(size_t)s * pitch + q0], wv[q0], a);
+      a = wave_sum_d(a);
+      if (lane == 0) { vv[s] = a - xbar[s] * sw; tau[s] = tnew[s]; p2[s] = p3[s]; }
+    }
+    __syncthreads();
+  }
+  const double scale = (p.num_iter >= 0 || p.apply_scaling) ? 1e5 : 1.0;
+  T* mo = reinterpret_cast<T*>(p.mf_out) + po;
+  T* ao = reinterpret_cast<T*>(p.alb_out) + po;
+  for (int q0 = tid; q0 < P; q0 += 256) {
+    mo[q0] = (T)(mfw[q0] * scale);
+    ao[q0] = (T)Rw[q0];
+  }
+  if (tid == 0) p.status[g] = notpd ? 1 : 0;
+}
+
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void k_mag1c_pack(const TI* __restrict__ cube, int S_total, int band0, int S,
                                                     const long long* __restrict__ pix, const long long* __restrict__ xoff,
@@ -307,7 +558,7 @@ __global__ void k_scatter(const TI* __restrict__ val, const long long* __restric
 
 size_t mag1c_lds_bytes(int S) {
   const int S16 = (S + 15) & ~15;
-  return ((size_t)S * (S + 1) + 8 * VEC + 16 + (size_t)S16 * 17) * sizeof(double);
+  return ((size_t)S * (S + 1) + 11 * VEC + 16 + (size_t)S16 * 17) * sizeof(double);
 }
 
 }  // namespace
@@ -335,7 +586,14 @@ extern "C" int sc_mag1c_groups(const sc_mag1c_args* a, sc_stream stream) {
   const size_t lds = mag1c_lds_bytes(a->S);
   hipStream_t st = (hipStream_t)stream;
   hipError_t e;
-  if (a->x_is_f64) {
+  const bool fast = a->alpha == 0.0;     // no shrinkage: one factorisation per group + Woodbury updates
+  if (fast && a->x_is_f64) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c_fast<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) hipLaunchKernelGGL(k_mag1c_fast<double>, dim3(a->G), dim3(256), lds, st, p);
+  } else if (fast) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c_fast<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) hipLaunchKernelGGL(k_mag1c_fast<float>, dim3(a->G), dim3(256), lds, st, p);
+  } else if (a->x_is_f64) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess) hipLaunchKernelGGL(k_mag1c<double>, dim3(a->G), dim3(256), lds, st, p);
   } else {
