@@ -78,8 +78,13 @@ __global__ __launch_bounds__(256) void k_mag1c(const Mag1cP p) {
   }
   for (int s = wave; s < S; s += 4) {
     double a = 0.0;
-    for (int q = lane; q < P; q += 64)
-      if (mk == nullptr || mk[q]) a += (double)X[(size_t)s * pitch + q];
+    for (int q = lane; q < P; q += 64 * 8) {
+      T xr[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xr[u] = X[(size_t)s * pitch + min(q + 64 * u, P - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int qq = q + 64 * u; if (qq < P && (mk == nullptr || mk[qq])) a += (double)xr[u]; }
+    }
     a = wave_sum_d(a);
     if (lane == 0) xbar[s] = a / nstat;
   }
@@ -152,14 +157,23 @@ __global__ __launch_bounds__(256) void k_mag1c(const Mag1cP p) {
     }
     __syncthreads();
     const double oma = 1.0 - p.alpha;
-    for (int i = tid; i < S * S; i += 256) {
-      const int r = i / S, c = i - r * S;
-      if (c <= r) {
-        double v = C0[i];
-        if (it > 0) v += -vv[r] * tau[c] - tau[r] * vv[c] + q * tau[r] * tau[c];
-        v /= N;
-        if (c != r) v *= oma;           // lerp towards the diagonal: C + alpha*(diag(C) - C)
-        Cm[r * LDC + c] = v;
+    for (int i0 = tid; i0 < S * S; i0 += 256 * 8) {
+      double c0v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c0v[u] = C0[min(i0 + 256 * u, S * S - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 256 * u;
+        if (i < S * S) {
+          const int r = i / S, c = i - r * S;
+          if (c <= r) {
+            double v = c0v[u];
+            if (it > 0) v += -vv[r] * tau[c] - tau[r] * vv[c] + q * tau[r] * tau[c];
+            v /= N;
+            if (c != r) v *= oma;           // lerp towards the diagonal: C + alpha*(diag(C) - C)
+            Cm[r * LDC + c] = v;
+          }
+        }
       }
     }
     __syncthreads();
@@ -213,10 +227,18 @@ __global__ __launch_bounds__(256) void k_mag1c(const Mag1cP p) {
     double lsw = 0.0, lsww = 0.0;
     for (int q0 = tid; q0 < P; q0 += 256) {
       double dot = 0.0, dmu = 0.0;
-      if (it == 0 && !p.albedo_override) {
-        for (int s = 0; s < S; ++s) { const double xv = (double)X[(size_t)s * pitch + q0]; dot = fma(xv, cit[s], dot); dmu = fma(xv, mu[s], dmu); }
-      } else {
-        for (int s = 0; s < S; ++s) dot = fma((double)X[(size_t)s * pitch + q0], cit[s], dot);
+      const bool need_mu = (it == 0) && !p.albedo_override;
+      for (int s0 = 0; s0 < S; s0 += 16) {            // 16 independent loads in flight per pixel, then the FMAs
+        T xr[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) xr[u] = X[(size_t)min(s0 + u, S - 1) * pitch + q0];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          if (s0 + u < S) {
+            dot = fma((double)xr[u], cit[s0 + u], dot);
+            if (need_mu) dmu = fma((double)xr[u], mu[s0 + u], dmu);
+          }
+        }
       }
       const double score = dot - mucit;
       double R, mf;
@@ -243,7 +265,13 @@ __global__ __launch_bounds__(256) void k_mag1c(const Mag1cP p) {
     // (6) v = X w - xbar * sum(w);  tau <- current target
     for (int s = wave; s < S; s += 4) {
       double a = 0.0;
-      for (int q0 = lane; q0 < P; q0 += 64) a = fma((double)X[(size_t)s * pitch + q0], wv[q0], a);
+      for (int q0 = lane; q0 < P; q0 += 64 * 8) {    // 16 independent loads in flight per lane
+        T xr[8]; double wr[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int qq = min(q0 + 64 * u, P - 1); xr[u] = X[(size_t)s * pitch + qq]; wr[u] = wv[qq]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (q0 + 64 * u < P) a = fma((double)xr[u], wr[u], a);
+      }
       a = wave_sum_d(a);
       if (lane == 0) { vv[s] = a - xbar[s] * sw; tau[s] = tnew[s]; }
     }
@@ -298,8 +326,13 @@ __global__ __launch_bounds__(256) void k_mag1c_fast(const Mag1cP p) {
   }
   for (int s = wave; s < S; s += 4) {
     double a = 0.0;
-    for (int q = lane; q < P; q += 64)
-      if (mk == nullptr || mk[q]) a += (double)X[(size_t)s * pitch + q];
+    for (int q = lane; q < P; q += 64 * 8) {
+      T xr[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xr[u] = X[(size_t)s * pitch + min(q + 64 * u, P - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int qq = q + 64 * u; if (qq < P && (mk == nullptr || mk[qq])) a += (double)xr[u]; }
+    }
     a = wave_sum_d(a);
     if (lane == 0) xbar[s] = a / nstat;
   }
@@ -466,10 +499,18 @@ __global__ __launch_bounds__(256) void k_mag1c_fast(const Mag1cP p) {
     double lsw = 0.0, lsww = 0.0;
     for (int q0 = tid; q0 < P; q0 += 256) {
       double dot = 0.0, dmu = 0.0;
-      if (it == 0 && !p.albedo_override) {
-        for (int s = 0; s < S; ++s) { const double xv = (double)X[(size_t)s * pitch + q0]; dot = fma(xv, cit[s], dot); dmu = fma(xv, mu[s], dmu); }
-      } else {
-        for (int s = 0; s < S; ++s) dot = fma((double)X[(size_t)s * pitch + q0], cit[s], dot);
+      const bool need_mu = (it == 0) && !p.albedo_override;
+      for (int s0 = 0; s0 < S; s0 += 16) {            // 16 independent loads in flight per pixel, then the FMAs
+        T xr[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) xr[u] = X[(size_t)min(s0 + u, S - 1) * pitch + q0];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          if (s0 + u < S) {
+            dot = fma((double)xr[u], cit[s0 + u], dot);
+            if (need_mu) dmu = fma((double)xr[u], mu[s0 + u], dmu);
+          }
+        }
       }
       const double score = dot - mucit;
       double R, mf;
@@ -495,7 +536,13 @@ __global__ __launch_bounds__(256) void k_mag1c_fast(const Mag1cP p) {
     __syncthreads();
     for (int s = wave; s < S; s += 4) {
       double a = 0.0;
-      for (int q0 = lane; q0 < P; q0 += 64) a = fma((double)X[(size_t)s * pitch + q0], wv[q0], a);
+      for (int q0 = lane; q0 < P; q0 += 64 * 8) {    // 16 independent loads in flight per lane
+        T xr[8]; double wr[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int qq = min(q0 + 64 * u, P - 1); xr[u] = X[(size_t)s * pitch + qq]; wr[u] = wv[qq]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (q0 + 64 * u < P) a = fma((double)xr[u], wr[u], a);
+      }
       a = wave_sum_d(a);
       if (lane == 0) { vv[s] = a - xbar[s] * sw; tau[s] = tnew[s]; p2[s] = p3[s]; }
     }

@@ -43,3 +43,9 @@ te = g3["emit_template_kept"][:, 1]
 raw = torch.from_numpy(cube(1280, 1242, te.size, te)).to(dev)
 dt = timeit(lambda: mag1c.mag1c_columns(raw, te, -9999.0, column_step=2), 3)
 print(f"EMIT 1280x1242x{te.size} fp64 column_step=2 (621 groups x 2560 px): {dt*1e3:.1f} ms/granule  {1280*1242/dt/1e6:.2f} Mpx/s  ({1280*1242/262144/dt:.2f} tile-eq/s)")
+
+# setup cost vs iteration cost (cfg3 shape)
+for ni in (0, 30):
+    dt = timeit(lambda: mag1c.acrwl1mf_by_groups(x, t125, groups, num_iter=ni), 3)
+    print(f"cfg3 num_iter={ni}: {dt*1e3:.2f} ms")
+xb = x.reshape(512 * 512, S)[None]
