@@ -246,9 +246,21 @@ int sc_mag1c_pack(const void* cube, int cube_is_f64, int S_total, int band0, int
 int sc_scatter(const void* val, int val_is_f64, const int64_t* pix_index, size_t n, void* out,
                int out_is_f64, sc_stream stream);
 
-/* band ratio (starcop/data/feature_extration.py:37-56), c computed from trimmed sums on device */
-int sc_band_ratio(const float* background, const float* signal, float* out, size_t n,
-                  float c, float zero_value_out, sc_stream stream);
+/* band-ratio feature (starcop/data/feature_extration.py:37-56).  For B tiles of n pixels:
+ *   sc_trimmed_sums : sums[b] = sum of x[b][i] with lower <= x <= upper, lower/upper = numpy.percentile(x[b], p / 100-p)
+ *                     (exact order statistics by radix select + numpy's linear interpolation)   == np.sum(no_outliers(x, p))
+ *   sc_band_ratio   : R = (c*signal - background)/(background + 1e-6), c = sum_bg/sum_sig per tile (device sums) or c_host;
+ *                     pixels with signal < 1e-6 and background < 1e-6 get zero_value_out                                    */
+size_t sc_trimmed_sum_workspace_bytes(int B);
+int sc_trimmed_sums(const float* x, int B, size_t n, double p, double* sums, void* work, size_t work_bytes,
+                    sc_stream stream);
+int sc_band_ratio(const float* background, const float* signal, float* out, int B, size_t n,
+                  const double* sum_bg, const double* sum_sig, float c_host, float zero_value_out,
+                  sc_stream stream);
+/* out = clip(x/div, lo, hi) * mult (+ nan_to_num): weight_mag1c (feature_extration.py:32-35: div 400, clip [0.1,1], mult 1)
+ * and the EMIT->AVIRIS rescale (emit_tools/emit_dataset.py:62-106: mf/240 -> [0,2] * 1750, rgb/20 -> [0,2] * 60) */
+int sc_clip_scale(const float* x, float* out, size_t n, float div, float lo, float hi, float mult,
+                  int nan_to_num, sc_stream stream);
 
 #ifdef __cplusplus
 }

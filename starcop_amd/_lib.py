@@ -98,7 +98,10 @@ SIGNATURES = {
     "sc_mag1c_groups": (_i, [C.POINTER(sc_mag1c_args), _vp]),
     "sc_mag1c_pack": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "sc_scatter": (_i, [_vp, _i, _vp, _sz, _vp, _i, _vp]),
-    "sc_band_ratio": (_i, [_vp, _vp, _vp, _sz, _f, _f, _vp]),
+    "sc_trimmed_sum_workspace_bytes": (_sz, [_i]),
+    "sc_trimmed_sums": (_i, [_vp, _i, _sz, _d, _vp, _vp, _sz, _vp]),
+    "sc_band_ratio": (_i, [_vp, _vp, _vp, _i, _sz, _vp, _vp, _f, _f, _vp]),
+    "sc_clip_scale": (_i, [_vp, _vp, _sz, _f, _f, _f, _f, _i, _vp]),
 }
 
 _lib = None

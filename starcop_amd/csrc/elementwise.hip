@@ -276,15 +276,6 @@ __global__ void k_pred_cls(const long long* __restrict__ cnt, long long* __restr
   if (i < N) cls[i] = ((double)cnt[i] > thr) ? 1 : 0;
 }
 
-__global__ __launch_bounds__(256) void k_band_ratio(const float* __restrict__ bg, const float* __restrict__ sig,
-                                                    float* __restrict__ out, size_t n, float c, float zero_val) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float b = bg[i], s = sig[i];
-    const float r = (c * s - b) / (b + 1e-6f);
-    out[i] = (s < 1e-6f && b < 1e-6f) ? zero_val : r;
-  }
-}
-
 inline int nblocks(size_t n, int cap = 2048) {
   size_t b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > (size_t)cap ? cap : b));
@@ -437,13 +428,5 @@ extern "C" int sc_pred_classification(const int64_t* tile_count, int64_t* cls, i
   hipLaunchKernelGGL(k_pred_cls, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const long long*)tile_count,
                      (long long*)cls, N, thr);
   SC_LAUNCH_OK("sc_pred_classification");
-  return SC_OK;
-}
-
-extern "C" int sc_band_ratio(const float* background, const float* signal, float* out, size_t n, float c,
-                             float zero_value_out, sc_stream stream) {
-  SC_REQUIRE(background && signal && out && n > 0, "sc_band_ratio: bad argument");
-  hipLaunchKernelGGL(k_band_ratio, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, background, signal, out, n, c, zero_value_out);
-  SC_LAUNCH_OK("sc_band_ratio");
   return SC_OK;
 }
