@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="tiles per GPU (weak scaling)")
     ap.add_argument("--tile", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", type=int, default=1, help="1: weight gradients on a second HIP stream (default); 0: serial "
+                    "launches (use for rocprofv3 per-kernel durations that match the roofline pass)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step from a captured hipGraph (default: eager two-stream launches, measured faster)")
     args = ap.parse_args()
 
@@ -99,6 +101,7 @@ def main():
     batch = synth_batch(B, T, T, 1234 + rank, dev)
     sync = GradSync(world) if world > 1 else None
     net = model.network
+    net.overlap_wgrad = bool(args.overlap)
 
     def step():
         return model.fused_train_step(batch, opt, grad_sync=sync)
@@ -147,17 +150,27 @@ def main():
     roof = None
     if rank == 0:
         net.profile = {}
+        overlap, net.overlap_wgrad = net.overlap_wgrad, False     # serial launches: a kernel's events bracket only itself
         for _ in range(3):
             step()
         torch.cuda.synchronize()
         prof = net.collect_profile()
-        net.profile = None
+        net.profile, net.overlap_wgrad = None, overlap
         fam = max(prof, key=lambda k: prof[k]["ms"])
         tot_ms = sum(v["ms"] for v in prof.values())
         d = prof[fam]
         ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
+        traffic, traffic_note = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_conv3.json")
+        if fam.startswith("k_conv_mfma<3>") and os.path.exists(pmc):
+            t = json.load(open(pmc))
+            traffic = round(t["hbm_bytes_per_launch_raw"])
+            traffic_note = ("HBM bytes per launch of k_conv_mfma<3,*> from committed rocprofv3 PMC passes (FETCH_SIZE raw + WRITE_SIZE, "
+                            "KiB->bytes; 4 B/lane loads: the gfx950 2x FETCH correction for 16 B/lane streams is not applied)")
         roof = {"kernel": fam, "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                "algorithmic_bytes_per_launch": round(d["bytes"] / d["n"]) if d.get("bytes") else None,
+                "algorithmic_flop_per_launch": round(d["flop"] / d["n"]),
                 "launches_per_step": d["n"] // 3, "avg_launch_ms": round(d["ms"] / d["n"], 4),
                 "share_of_step_gpu_time": round(d["ms"] / tot_ms, 3),
                 "families_ms_per_step": {k: round(v["ms"] / 3, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}

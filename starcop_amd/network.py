@@ -232,14 +232,14 @@ class HyperStarcopUNet(nn.Module):
     profile_detail = False
     _cur_op = ""
 
-    def _pb(self, fam, flop=0.0):
+    def _pb(self, fam, flop=0.0, nbytes=0.0):
         if self.profile is None:
             return None
         if self.profile_detail:
             fam = f"{self._cur_op}|{fam}"
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        return (fam, flop, e0, e1)
+        return (fam, flop, e0, e1, nbytes)
 
     def _pe(self, tok):
         if tok is not None:
@@ -250,7 +250,8 @@ class HyperStarcopUNet(nn.Module):
         torch.cuda.synchronize()
         out = {}
         for fam, toks in (self.profile or {}).items():
-            out[fam] = {"ms": sum(t[2].elapsed_time(t[3]) for t in toks), "flop": sum(t[1] for t in toks), "n": len(toks)}
+            out[fam] = {"ms": sum(t[2].elapsed_time(t[3]) for t in toks), "flop": sum(t[1] for t in toks), "n": len(toks),
+                        "bytes": sum(t[4] for t in toks)}
         return out
 
     def mark_parameters_changed(self):
@@ -402,8 +403,10 @@ class HyperStarcopUNet(nn.Module):
             self._cur_op = o.name + ":fwd"
             if self.profile is not None:
                 if ty in ("pw", "conv3"):
+                    src_elems = sum(t.C * (H >> t.shift) * (W >> t.shift) for t in op["ins"])
                     tok = self._pb(f"k_conv_mfma<{conv.kernel_size[0]}> (fwd+dgrad)",
-                                   2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * conv.kernel_size[0] ** 2)
+                                   2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * conv.kernel_size[0] ** 2,
+                                   4.0 * (N * src_elems + N * o.C * Ho * Wo + conv.weight.numel()))
                 else:
                     tok = self._pb({"stem": "k_stem_*", "dw": "k_dw_*", "head": "k_head_*", "add": "elementwise/bn"}[ty])
             if ty == "stem":
@@ -588,7 +591,9 @@ class HyperStarcopUNet(nn.Module):
             a.ks, a.co_t = ks, ent["cot_b"]
             a.add0 = None; a.add1 = None; a.stats = None
             a.accum0 = a.accum1 = 0
-            tok = self._pb(f"k_conv_mfma<{ks}> (fwd+dgrad)", flop)
+            # algorithmic bytes of the data gradient: g and y of the output once each, the input gradient once, the filter
+            tok = self._pb(f"k_conv_mfma<{ks}> (fwd+dgrad)", flop,
+                           4.0 * (2 * N * o.C * Ho * Wo + N * conv.in_channels * Ho * Wo + conv.weight.numel()))
             if op.get("up"):
                 t_up = ins[0]
                 a.out0 = plan.up_tmp.data_ptr()
