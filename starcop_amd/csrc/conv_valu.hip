@@ -32,13 +32,77 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* s_tmp /* [4][NV
 }
 
 // ---------------------------------------------------------------- depthwise
-// One (n, c) plane tile per block: TW x TH outputs (TW in {32,16}, TH = 256/TW), one output per thread.  The input
-// patch is staged ONCE through LDS with the producer's BatchNorm+ReLU6 applied on the way (branch-free prologue,
-// clamped unconditional loads), so every HBM element is read once per tile and transformed once.
-template <int S, int TW>
+// One (n, c) plane tile per block: TW x (TB*R) outputs (TB = 256/TW rows per pass, R passes), R outputs per thread.
+// The input patch is staged ONCE through LDS with the producer's BatchNorm+ReLU6 applied on the way (branch-free
+// prologue, clamped unconditional loads issued SC_DW_LB at a time), so every HBM element is read once per tile and
+// each thread keeps R stores + ~R*S*S loads in flight: these kernels are HBM-latency bound with small tiles.
+constexpr int SC_DW_LB = 8;
+
+template <int PH, int PW, int PWP, typename F>
+__device__ __forceinline__ void dw_stage(float* s, const float* __restrict__ xb, int y0, int x0, int Hin, int Win, F&& pro) {
+  constexpr int NE = PH * PW, NIT = (NE + 255) / 256;
+#pragma unroll
+  for (int i0 = 0; i0 < NIT; i0 += SC_DW_LB) {
+    float v[SC_DW_LB];
+#pragma unroll
+    for (int j = 0; j < SC_DW_LB; ++j) {
+      if (i0 + j < NIT) {
+        const int e = threadIdx.x + (i0 + j) * 256;
+        const int r = e / PW, cc = e - r * PW;
+        const int iy = y0 + r, ix = x0 + cc;
+        const bool ok = (e < NE) && (iy >= 0) && (iy < Hin) && (ix >= 0) && (ix < Win);
+        v[j] = xb[ok ? iy * Win + ix : 0];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < SC_DW_LB; ++j) {
+      if (i0 + j < NIT) {
+        const int e = threadIdx.x + (i0 + j) * 256;
+        const int r = e / PW, cc = e - r * PW;
+        const int iy = y0 + r, ix = x0 + cc;
+        const bool ok = (iy >= 0) && (iy < Hin) && (ix >= 0) && (ix < Win);
+        if (e < NE) s[r * PWP + cc] = ok ? pro(v[j]) : 0.f;
+      }
+    }
+  }
+}
+
+// same, for a BatchNorm-backward source: two tensors (g, y) per element
+template <int PH, int PW, int PWP, typename F>
+__device__ __forceinline__ void dw_stage2(float* s, const float* __restrict__ gb, const float* __restrict__ yb, int y0, int x0,
+                                          int Hin, int Win, F&& pro) {
+  constexpr int NE = PH * PW, NIT = (NE + 255) / 256, LB = SC_DW_LB / 2;
+#pragma unroll
+  for (int i0 = 0; i0 < NIT; i0 += LB) {
+    float g[LB], yv[LB];
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+      if (i0 + j < NIT) {
+        const int e = threadIdx.x + (i0 + j) * 256;
+        const int r = e / PW, cc = e - r * PW;
+        const int iy = y0 + r, ix = x0 + cc;
+        const bool ok = (e < NE) && (iy >= 0) && (iy < Hin) && (ix >= 0) && (ix < Win);
+        const int o = ok ? iy * Win + ix : 0;
+        g[j] = gb[o]; yv[j] = yb[o];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+      if (i0 + j < NIT) {
+        const int e = threadIdx.x + (i0 + j) * 256;
+        const int r = e / PW, cc = e - r * PW;
+        const int iy = y0 + r, ix = x0 + cc;
+        const bool ok = (iy >= 0) && (iy < Hin) && (ix >= 0) && (ix < Win);
+        if (e < NE) s[r * PWP + cc] = ok ? pro(g[j], yv[j]) : 0.f;
+      }
+    }
+  }
+}
+
+template <int S, int TW, int R>
 __global__ __launch_bounds__(256) void k_dw_fwd(const SrcD in, const float* __restrict__ w, float* __restrict__ out,
                                                 int C, int Hin, int Win, int Hout, int Wout, float* stats) {
-  constexpr int TH = 256 / TW;
+  constexpr int TB = 256 / TW, TH = TB * R;
   constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PWP = PW | 1;
   __shared__ float s_x[PH * PWP];
   __shared__ float s_tmp[8];
@@ -49,39 +113,41 @@ __global__ __launch_bounds__(256) void k_dw_fwd(const SrcD in, const float* __re
   if (in.mode != SC_SRC_RAW) { sc = in.cst[(size_t)c * SC_CST]; sh = in.cst[(size_t)c * SC_CST + 1]; }
   const float lo = sc_act_lo(in.act), hi = sc_act_hi(in.act);
   const float* xb = in.x + ((size_t)n * C + c) * Hin * Win;
-  for (int e = threadIdx.x; e < PH * PW; e += 256) {
-    const int r = e / PW, cc = e - r * PW;
-    const int iy = ty0 * S - 1 + r, ix = tx0 * S - 1 + cc;
-    const bool ok = (iy >= 0) && (iy < Hin) && (ix >= 0) && (ix < Win);
-    const float v = sc_pro_affine(xb[ok ? iy * Win + ix : 0], sc, sh, lo, hi);
-    s_x[r * PWP + cc] = ok ? v : 0.f;
-  }
+  dw_stage<PH, PW, PWP>(s_x, xb, ty0 * S - 1, tx0 * S - 1, Hin, Win, [&](float v) { return sc_pro_affine(v, sc, sh, lo, hi); });
   float wk[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wk[t] = w[c * 9 + t];
   __syncthreads();
   const int ty = threadIdx.x / TW, tx = threadIdx.x % TW;
-  const int oy = ty0 + ty, ox = tx0 + tx;
-  const bool ok = (oy < Hout) && (ox < Wout);
-  float acc = 0.f;
+  const int ox = tx0 + tx;
+  float* ob = out + ((size_t)n * C + c) * Hout * Wout;
+  float v[2] = {0.f, 0.f};
 #pragma unroll
-  for (int kh = 0; kh < 3; ++kh)
+  for (int k = 0; k < R; ++k) {
+    const int row = ty + k * TB, oy = ty0 + row;
+    float acc = 0.f;
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kh * 3 + kw], s_x[(ty * S + kh) * PWP + tx * S + kw], acc);
-  if (ok) out[((size_t)n * C + c) * Hout * Wout + (size_t)oy * Wout + ox] = acc;
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kh * 3 + kw], s_x[(row * S + kh) * PWP + tx * S + kw], acc);
+    if ((oy < Hout) && (ox < Wout)) {
+      ob[(size_t)oy * Wout + ox] = acc;
+      v[0] += acc; v[1] = fmaf(acc, acc, v[1]);
+    }
+  }
   if (stats) {
-    float v[2] = {ok ? acc : 0.f, ok ? acc * acc : 0.f};
     block_sum<2>(v, s_tmp);
     if (threadIdx.x < 2) stats[(stat_row() * C + c) * 2 + threadIdx.x] = v[threadIdx.x];
   }
 }
 
-// dy patch (BatchNorm/ReLU6 backward applied on load) staged once; dx tile = TW x TH input pixels
-template <int S, int TW>
+// dy patch (BatchNorm/ReLU6 backward applied on load) staged once; dx tile = TW x (TB*R) input pixels
+template <int S, int TW, int R>
 __global__ __launch_bounds__(256) void k_dw_dgrad(const SrcD dy, const float* __restrict__ w, float* __restrict__ dx,
                                                   int accum, int C, int Hin, int Win, int Hout, int Wout) {
-  constexpr int TH = 256 / TW;
+  constexpr int TB = 256 / TW, TH = TB * R;
   constexpr int PH = (S == 1) ? TH + 2 : TH / 2 + 1, PW = (S == 1) ? TW + 2 : TW / 2 + 1, PWP = PW | 1;
+  static_assert(S == 1 || (TH % 2 == 0 && TW % 2 == 0), "stride-2 tiles must be even");
   __shared__ float s_d[PH * PWP];
   const int c = blockIdx.y, n = blockIdx.z;
   const int tiles_x = (Win + TW - 1) / TW;
@@ -92,48 +158,52 @@ __global__ __launch_bounds__(256) void k_dw_dgrad(const SrcD dy, const float* __
   const float lo = sc_act_lo(dy.act), hi = sc_act_hi(dy.act);
   const size_t obase = ((size_t)n * C + c) * Hout * Wout;
   const float* gb = dy.x + obase;
-  const float* yb = (dy.mode == SC_SRC_BNBWD) ? dy.aux + obase : gb;
-  const bool bnb = dy.mode == SC_SRC_BNBWD;
-  for (int e = threadIdx.x; e < PH * PW; e += 256) {
-    const int r = e / PW, cc = e - r * PW;
-    const int oy = oyb + r, ox = oxb + cc;
-    const bool ok = (oy >= 0) && (oy < Hout) && (ox >= 0) && (ox < Wout);
-    const int o = ok ? oy * Wout + ox : 0;
-    const float g = gb[o], yv = yb[o];
-    const float v = bnb ? sc_pro_bnbwd(g, yv, c0.x, c0.y, c0.z, c0.w, c4, lo, hi) : sc_pro_affine(g, c0.x, c0.y, lo, hi);
-    s_d[r * PWP + cc] = ok ? v : 0.f;
-  }
+  if (dy.mode == SC_SRC_BNBWD)
+    dw_stage2<PH, PW, PWP>(s_d, gb, dy.aux + obase, oyb, oxb, Hout, Wout,
+                           [&](float g, float yv) { return sc_pro_bnbwd(g, yv, c0.x, c0.y, c0.z, c0.w, c4, lo, hi); });
+  else
+    dw_stage<PH, PW, PWP>(s_d, gb, oyb, oxb, Hout, Wout, [&](float g) { return sc_pro_affine(g, c0.x, c0.y, lo, hi); });
   float wk[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wk[t] = w[c * 9 + t];
   __syncthreads();
   const int ty = threadIdx.x / TW, tx = threadIdx.x % TW;
-  const int iy = iy0 + ty, ix = ix0 + tx;
-  if (iy >= Hin || ix >= Win) return;
-  float acc = 0.f;
+  const int ix = ix0 + tx;
+  float* db = dx + ((size_t)n * C + c) * Hin * Win;
+  float prev[R];
+  if (accum) {
 #pragma unroll
-  for (int kh = 0; kh < 3; ++kh) {
-    const int t = iy + 1 - kh;                 // = oy * S
-    if (S == 2 && (t & 1)) continue;
-    const int r = (S == 1 ? t : t / 2) - oyb;  // t >= -1 only when S == 1 (zero-padded patch row)
-    if (S == 2 && t < 0) continue;
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int u = ix + 1 - kw;
-      if (S == 2 && ((u & 1) || u < 0)) continue;
-      const int cc = (S == 1 ? u : u / 2) - oxb;
-      acc = fmaf(wk[kh * 3 + kw], s_d[r * PWP + cc], acc);
+    for (int k = 0; k < R; ++k) {
+      const int iy = iy0 + ty + k * TB;
+      prev[k] = (iy < Hin && ix < Win) ? db[(size_t)iy * Win + ix] : 0.f;
     }
   }
-  const size_t o = ((size_t)n * C + c) * Hin * Win + (size_t)iy * Win + ix;
-  dx[o] = accum ? dx[o] + acc : acc;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int iy = iy0 + ty + k * TB;
+    float acc = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int t = iy + 1 - kh;                 // = oy * S
+      if (S == 2 && ((t & 1) || t < 0)) continue;
+      const int r = (S == 1 ? t : t / 2) - oyb;  // t >= -1 only when S == 1 (zero-padded patch row)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int u = ix + 1 - kw;
+        if (S == 2 && ((u & 1) || u < 0)) continue;
+        const int cc = (S == 1 ? u : u / 2) - oxb;
+        acc = fmaf(wk[kh * 3 + kw], s_d[r * PWP + cc], acc);
+      }
+    }
+    if (iy < Hin && ix < Win) db[(size_t)iy * Win + ix] = accum ? prev[k] + acc : acc;
+  }
 }
 
 // dW[c][tap] += sum over this block's (n, tile) list of dy * x; 9 double atomics per block
-template <int S, int TW>
+template <int S, int TW, int R>
 __global__ __launch_bounds__(256) void k_dw_wgrad(const SrcD dy, const SrcD in, double* __restrict__ dw_acc, int N, int C,
                                                   int Hin, int Win, int Hout, int Wout, int dy_bcast) {
-  constexpr int TH = 256 / TW;
+  constexpr int TB = 256 / TW, TH = TB * R;
   constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PWP = PW | 1;
   __shared__ float s_x[PH * PWP];
   __shared__ float s_tmp[36];
@@ -158,26 +228,32 @@ __global__ __launch_bounds__(256) void k_dw_wgrad(const SrcD dy, const SrcD in, 
     const int rem = (int)(t - (long)n * per_img);
     const int ty0 = (rem / tiles_x) * TH, tx0 = (rem % tiles_x) * TW;
     const float* xb = in.x + ((size_t)n * C + c) * Hin * Win;
-    __syncthreads();
-    for (int e = threadIdx.x; e < PH * PW; e += 256) {
-      const int r = e / PW, cc = e - r * PW;
-      const int iy = ty0 * S - 1 + r, ix = tx0 * S - 1 + cc;
-      const bool ok = (iy >= 0) && (iy < Hin) && (ix >= 0) && (ix < Win);
-      const float v = sc_pro_affine(xb[ok ? iy * Win + ix : 0], xs, xh, xlo, xhi);
-      s_x[r * PWP + cc] = ok ? v : 0.f;
+    // this thread's R dy values first (their latency hides behind the patch staging)
+    const int ox = tx0 + tx;
+    const size_t dbase = ((size_t)n * Cd + cd) * Hout * Wout;
+    float g[R], yv[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int oy = ty0 + ty + k * TB;
+      const bool ok = (oy < Hout) && (ox < Wout);
+      const size_t o = dbase + (ok ? (size_t)oy * Wout + ox : 0);
+      g[k] = dy.x[o];
+      yv[k] = bnb ? dy.aux[o] : 0.f;
     }
-    const int oy = ty0 + ty, ox = tx0 + tx;
-    const bool ok = (oy < Hout) && (ox < Wout);
-    const size_t o = ((size_t)n * Cd + cd) * Hout * Wout + (ok ? (size_t)oy * Wout + ox : 0);
-    const float g = dy.x[o];
-    const float yv = bnb ? dy.aux[o] : g;
-    float dyv = bnb ? sc_pro_bnbwd(g, yv, c0.x, c0.y, c0.z, c0.w, c4, dlo, dhi) : sc_pro_affine(g, c0.x, c0.y, dlo, dhi);
-    dyv = ok ? dyv : 0.f;
+    __syncthreads();
+    dw_stage<PH, PW, PWP>(s_x, xb, ty0 * S - 1, tx0 * S - 1, Hin, Win, [&](float v) { return sc_pro_affine(v, xs, xh, xlo, xhi); });
     __syncthreads();
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+    for (int k = 0; k < R; ++k) {
+      const int row = ty + k * TB, oy = ty0 + row;
+      const bool ok = (oy < Hout) && (ox < Wout);
+      float dyv = bnb ? sc_pro_bnbwd(g[k], yv[k], c0.x, c0.y, c0.z, c0.w, c4, dlo, dhi) : sc_pro_affine(g[k], c0.x, c0.y, dlo, dhi);
+      dyv = ok ? dyv : 0.f;
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) prod[kh * 3 + kw] = fmaf(dyv, s_x[(ty * S + kh) * PWP + tx * S + kw], prod[kh * 3 + kw]);
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) prod[kh * 3 + kw] = fmaf(dyv, s_x[(row * S + kh) * PWP + tx * S + kw], prod[kh * 3 + kw]);
+    }
   }
   block_sum<9>(prod, s_tmp);
   if (threadIdx.x < 9) atomicAdd(&dw_acc[c * 9 + threadIdx.x], (double)prod[threadIdx.x]);
@@ -481,13 +557,22 @@ int head_blocks(int N, int H, int W) {
 
 }  // namespace
 
-#define SC_DW_DISPATCH(KERNEL, W_, ...)                                                               \
-  do {                                                                                                 \
-    if (stride == 1 && (W_) > 16) hipLaunchKernelGGL((KERNEL<1, 32>), grid32, dim3(256), 0, st, __VA_ARGS__);      \
-    else if (stride == 1) hipLaunchKernelGGL((KERNEL<1, 16>), grid16, dim3(256), 0, st, __VA_ARGS__);  \
-    else if ((W_) > 16) hipLaunchKernelGGL((KERNEL<2, 32>), grid32, dim3(256), 0, st, __VA_ARGS__);    \
-    else hipLaunchKernelGGL((KERNEL<2, 16>), grid16, dim3(256), 0, st, __VA_ARGS__);                   \
+// tile shape by plane width: (TW, R) = (64, 8) -> 64x32, (32, 4) -> 32x32, (16, 1) -> 16x16 outputs per block
+#define SC_DW_DISPATCH(KERNEL, W_, GRID, ...)                                                                      \
+  do {                                                                                                             \
+    const int tw_ = sc_dw_tile_w(W_);                                                                              \
+    if (stride == 1 && tw_ == 64) hipLaunchKernelGGL((KERNEL<1, 64, 8>), GRID, dim3(256), 0, st, __VA_ARGS__);     \
+    else if (stride == 1 && tw_ == 32) hipLaunchKernelGGL((KERNEL<1, 32, 4>), GRID, dim3(256), 0, st, __VA_ARGS__);\
+    else if (stride == 1) hipLaunchKernelGGL((KERNEL<1, 16, 1>), GRID, dim3(256), 0, st, __VA_ARGS__);             \
+    else if (tw_ == 64) hipLaunchKernelGGL((KERNEL<2, 64, 8>), GRID, dim3(256), 0, st, __VA_ARGS__);               \
+    else if (tw_ == 32) hipLaunchKernelGGL((KERNEL<2, 32, 4>), GRID, dim3(256), 0, st, __VA_ARGS__);               \
+    else hipLaunchKernelGGL((KERNEL<2, 16, 1>), GRID, dim3(256), 0, st, __VA_ARGS__);                              \
   } while (0)
+
+static inline long dw_tiles(int H, int W) {
+  const int tw = sc_dw_tile_w(W), th = sc_dw_tile_h(W);
+  return (long)((W + tw - 1) / tw) * ((H + th - 1) / th);
+}
 
 extern "C" int sc_dwconv3x3_fwd(const sc_src* in, const float* w, float* out, int N, int C, int Hin, int Win,
                                 int stride, float* stats, sc_stream stream) {
@@ -496,8 +581,8 @@ extern "C" int sc_dwconv3x3_fwd(const sc_src* in, const float* w, float* out, in
   SC_REQUIRE((in->mode == SC_SRC_RAW || in->mode == SC_SRC_AFFINE) && in->up == 0, "sc_dwconv3x3_fwd: unsupported source mode");
   const int Hout = (Hin - 1) / stride + 1, Wout = (Win - 1) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid32(((Wout + 31) / 32) * ((Hout + 7) / 8), C, N), grid16(((Wout + 15) / 16) * ((Hout + 15) / 16), C, N);
-  SC_DW_DISPATCH(k_dw_fwd, Wout, to_srcd(*in), w, out, C, Hin, Win, Hout, Wout, stats);
+  dim3 grid((unsigned)dw_tiles(Hout, Wout), C, N);
+  SC_DW_DISPATCH(k_dw_fwd, Wout, grid, to_srcd(*in), w, out, C, Hin, Win, Hout, Wout, stats);
   SC_LAUNCH_OK("sc_dwconv3x3_fwd");
   return SC_OK;
 }
@@ -510,8 +595,8 @@ extern "C" int sc_dwconv3x3_dgrad(const sc_src* dy, const float* w, float* dx, i
   SC_REQUIRE(dy->mode != SC_SRC_BNBWD || dy->aux != nullptr, "sc_dwconv3x3_dgrad: BNBWD source needs aux");
   const int Hout = (Hin - 1) / stride + 1, Wout = (Win - 1) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid32(((Win + 31) / 32) * ((Hin + 7) / 8), C, N), grid16(((Win + 15) / 16) * ((Hin + 15) / 16), C, N);
-  SC_DW_DISPATCH(k_dw_dgrad, Win, to_srcd(*dy), w, dx, accum, C, Hin, Win, Hout, Wout);
+  dim3 grid((unsigned)dw_tiles(Hin, Win), C, N);
+  SC_DW_DISPATCH(k_dw_dgrad, Win, grid, to_srcd(*dy), w, dx, accum, C, Hin, Win, Hout, Wout);
   SC_LAUNCH_OK("sc_dwconv3x3_dgrad");
   return SC_OK;
 }
@@ -524,10 +609,10 @@ extern "C" int sc_dwconv3x3_wgrad(const sc_src* dy, const sc_src* in, double* dw
              "sc_dwconv3x3_wgrad: unsupported source mode");
   const int Hout = (Hin - 1) / stride + 1, Wout = (Win - 1) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
-  const long t32 = (long)N * ((Wout + 31) / 32) * ((Hout + 7) / 8), t16 = (long)N * ((Wout + 15) / 16) * ((Hout + 15) / 16);
+  const long T = (long)N * dw_tiles(Hout, Wout);
   const long want = 4096 / C > 0 ? 4096 / C : 1;
-  dim3 grid32((unsigned)(t32 < want ? t32 : want), C), grid16((unsigned)(t16 < want ? t16 : want), C);
-  SC_DW_DISPATCH(k_dw_wgrad, Wout, to_srcd(*dy), to_srcd(*in), dw_acc, N, C, Hin, Win, Hout, Wout, 0);
+  dim3 grid((unsigned)(T < want ? T : want), C);
+  SC_DW_DISPATCH(k_dw_wgrad, Wout, grid, to_srcd(*dy), to_srcd(*in), dw_acc, N, C, Hin, Win, Hout, Wout, 0);
   SC_LAUNCH_OK("sc_dwconv3x3_wgrad");
   return SC_OK;
 }
@@ -617,10 +702,10 @@ extern "C" int sc_head_conv_wgrad(const float* dlogits, const sc_src* in, float*
   SrcD dy = empty_srcd();
   dy.x = dlogits; dy.C = 1; dy.mode = SC_SRC_RAW;
   const int stride = 1, Hout = H, Wout = W;
-  const long t32 = (long)N * ((Wout + 31) / 32) * ((Hout + 7) / 8), t16 = (long)N * ((Wout + 15) / 16) * ((Hout + 15) / 16);
+  const long T = (long)N * dw_tiles(Hout, Wout);
   const long want = 4096 / Cin > 0 ? 4096 / Cin : 1;
-  dim3 grid32((unsigned)(t32 < want ? t32 : want), Cin), grid16((unsigned)(t16 < want ? t16 : want), Cin);
-  SC_DW_DISPATCH(k_dw_wgrad, Wout, dy, to_srcd(*in), acc, N, Cin, H, W, Hout, Wout, 1);
+  dim3 grid((unsigned)(T < want ? T : want), Cin);
+  SC_DW_DISPATCH(k_dw_wgrad, Wout, grid, dy, to_srcd(*in), acc, N, Cin, H, W, Hout, Wout, 1);
   SC_LAUNCH_OK("sc_head_conv_wgrad");
   const size_t npx = (size_t)N * H * W;
   hipLaunchKernelGGL(k_sum_f32_to_f64, dim3((unsigned)((npx + 4095) / 4096 > 512 ? 512 : (npx + 4095) / 4096)), dim3(256), 0, st, dlogits, npx, acc + Cin * 9);

@@ -117,4 +117,7 @@ int sc_reduce_rows_partial(const float* part, int nparts, size_t E, float* scrat
                            int* nrows_out, hipStream_t st);
 
 // row of this work-group in a [rows][C][2] partial-statistics buffer (grid = (tiles, channel-tiles, N))
+// depthwise tile shape (outputs per block) by plane width; shared by the launchers and sc_stat_rows
+inline int sc_dw_tile_w(int W) { return W > 32 ? 64 : (W > 16 ? 32 : 16); }
+inline int sc_dw_tile_h(int W) { return W > 16 ? 32 : 16; }
 __device__ __forceinline__ size_t stat_row() { return (size_t)blockIdx.z * gridDim.x + blockIdx.x; }
