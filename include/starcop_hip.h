@@ -105,6 +105,17 @@ typedef struct sc_conv_args {
 } sc_conv_args;
 int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream);
 
+/* The same 3x3 convolution (forward, or backward-data with transpose_flip-packed filters) with fp32 accuracy on the
+ * bf16 matrix cores: every fp32 operand is split exactly into three bf16 terms while it is staged and the six partial
+ * products of weight >= 2^-24 are accumulated in fp32 (6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block, 2.7x the
+ * v_mfma_f32_32x32x2_f32 rate; error of the same order as one fp32 rounding per product).  Same arguments, prologues,
+ * epilogue and statistics rows (SC_STAT_CONV3) as sc_conv2d_mfma with ks = 3; co_t in {32, 64}; `wpk` must come from
+ * sc_pack_weights_bx3 (16-byte aligned).  A concat needs src[0].C % 16 == 0.
+ * Replaces the same torch.nn.functional.conv2d calls as sc_conv2d_mfma (starcop/models/model_module.py:244). */
+int sc_pack_weights_bx3(const float* w_oihw, float* wpk, int Cout, int Cin, int co_t, int transpose_flip, sc_stream stream);
+size_t sc_packed_weight_floats_bx3(int Cout, int Cin, int co_t, int transpose_flip);
+int sc_conv3x3_bx3(const sc_conv_args* a, sc_stream stream);
+
 /* weight gradient of the same conv: dW[co][ci][kh][kw] = sum_{n,y,x} dy * in.
  *   dy  : one source (normally SC_SRC_BNBWD: g + y of the conv output), Cout channels
  *   in  : concat of nsrc sources with the forward prologues, Cin channels

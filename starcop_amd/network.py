@@ -353,14 +353,25 @@ class HyperStarcopUNet(nn.Module):
             conv = op["conv"]
             co, ci, ks = conv.out_channels, conv.in_channels, conv.kernel_size[0]
             ent = self._wpk.get(i)
-            if ent is None or ent["f"].device != dev:
+            if ent is None or ent["f"].device != dev or ent["split"] != self.split_bf16:
                 cf, cb = _pick_cot(co, ks), _pick_cot(ci, ks)
-                ent = dict(cot_f=cf, cot_b=cb,
-                           f=torch.empty(lib.sc_packed_weight_floats(co, ci, ks, cf, 0), dtype=torch.float32, device=dev),
-                           b=torch.empty(lib.sc_packed_weight_floats(co, ci, ks, cb, 1), dtype=torch.float32, device=dev))
+                # 3x3 layers with >= 32 output channels run on the bf16 matrix cores with three-term split operands
+                # (fp32 accuracy, conv_bx3.hip); thin ones stay on the fp32 MFMA kernels
+                xf = self.split_bf16 and ks == 3 and cf >= 32
+                xb = self.split_bf16 and ks == 3 and cb >= 32
+                nf = lib.sc_packed_weight_floats_bx3(co, ci, cf, 0) if xf else lib.sc_packed_weight_floats(co, ci, ks, cf, 0)
+                nb = lib.sc_packed_weight_floats_bx3(co, ci, cb, 1) if xb else lib.sc_packed_weight_floats(co, ci, ks, cb, 1)
+                ent = dict(cot_f=cf, cot_b=cb, bx3_f=xf, bx3_b=xb, split=self.split_bf16,
+                           f=torch.empty(nf, dtype=torch.float32, device=dev),
+                           b=torch.empty(nb, dtype=torch.float32, device=dev))
                 self._wpk[i] = ent
-            check(lib.sc_pack_weights(ptr(conv.weight), ptr(ent["f"]), co, ci, ks, ent["cot_f"], 0, st))
-            if need_bwd:
+            if ent["bx3_f"]:
+                check(lib.sc_pack_weights_bx3(ptr(conv.weight), ptr(ent["f"]), co, ci, ent["cot_f"], 0, st))
+            else:
+                check(lib.sc_pack_weights(ptr(conv.weight), ptr(ent["f"]), co, ci, ks, ent["cot_f"], 0, st))
+            if need_bwd and ent["bx3_b"]:
+                check(lib.sc_pack_weights_bx3(ptr(conv.weight), ptr(ent["b"]), co, ci, ent["cot_b"], 1, st))
+            elif need_bwd:
                 check(lib.sc_pack_weights(ptr(conv.weight), ptr(ent["b"]), co, ci, ks, ent["cot_b"], 1, st))
         self._pack_version = (ver, bool(need_bwd))
 
@@ -433,7 +444,7 @@ class HyperStarcopUNet(nn.Module):
                 a.csplit, a.accum0, a.accum1 = o.C, 0, 0
                 a.add0 = None; a.add1 = None
                 a.stats = plan.stats_v[o.name].data_ptr() if stats is not None else None
-                check(lib.sc_conv2d_mfma(C.byref(a), st))
+                check((lib.sc_conv3x3_bx3 if ent["bx3_f"] else lib.sc_conv2d_mfma)(C.byref(a), st))
             elif ty == "add":
                 sa = self._src_of(plan, op["ins"][0])
                 sb = self._src_of(plan, op["ins"][1])
@@ -464,6 +475,7 @@ class HyperStarcopUNet(nn.Module):
     # HIP stream, forked after each layer's BatchNorm-backward constants and joined before the optimiser, so they fill
     # the CUs the small dgrad / reduce kernels of the dependency chain leave idle.
     overlap_wgrad = True
+    split_bf16 = True        # 3x3 convs with >= 32 output channels on the bf16 matrix cores (three-term split, fp32 accuracy)
     _side_stream = None
 
     def _backward_impl(self, plan, dlogits):
@@ -589,6 +601,7 @@ class HyperStarcopUNet(nn.Module):
             a.wpk = ent["b"].data_ptr()
             a.N, a.H, a.W, a.Cout = N, Ho, Wo, conv.in_channels
             a.ks, a.co_t = ks, ent["cot_b"]
+            conv_dgrad = lib.sc_conv3x3_bx3 if ent["bx3_b"] else lib.sc_conv2d_mfma
             a.add0 = None; a.add1 = None; a.stats = None
             a.accum0 = a.accum1 = 0
             # algorithmic bytes of the data gradient: g and y of the output once each, the input gradient once, the filter
@@ -605,7 +618,7 @@ class HyperStarcopUNet(nn.Module):
                     written.add(t_sk.name)
                 else:
                     a.out1 = None
-                check(lib.sc_conv2d_mfma(C.byref(a), st))
+                check(conv_dgrad(C.byref(a), st))
                 self._pe(tok)
                 check(lib.sc_downsum2x2(ptr(plan.up_tmp), ptr(plan.grad[t_up.name]), 1 if t_up.name in written else 0,
                                         N, t_up.C, Ho // 2, Wo // 2, st))
@@ -618,7 +631,7 @@ class HyperStarcopUNet(nn.Module):
                 z = res_of.get(tin.name)
                 if z is not None:
                     a.add0 = plan.grad[z].data_ptr()
-                check(lib.sc_conv2d_mfma(C.byref(a), st))
+                check(conv_dgrad(C.byref(a), st))
                 self._pe(tok)
                 written.add(tin.name)
         if side is not None:

@@ -33,8 +33,16 @@ def pack(w, co_t, tflip):
     return out
 
 
+def pack_bx3(w, co_t, tflip):
+    lib = _lib.load()
+    co, ci = w.shape[0], w.shape[1]
+    out = torch.empty(lib.sc_packed_weight_floats_bx3(co, ci, co_t, tflip), device=DEV)
+    check(lib.sc_pack_weights_bx3(ptr(w), ptr(out), co, ci, co_t, tflip, stream()))
+    return out
+
+
 def conv_mfma(srcs, wpk, N, H, W, Cout, ks, co_t, want_stats=False, csplit=None, add0=None, add1=None,
-              accum=None, outs=None):
+              accum=None, outs=None, bx3=False):
     lib = _lib.load()
     a = sc_conv_args()
     a.nsrc = len(srcs)
@@ -56,7 +64,7 @@ def conv_mfma(srcs, wpk, N, H, W, Cout, ks, co_t, want_stats=False, csplit=None,
     rows = lib.sc_stat_rows(STAT_CONV3 if ks == 3 else STAT_CONV1, N, H, W)
     stats = torch.full((rows, Cout, 2), float("nan"), device=DEV) if want_stats else None      # every entry must be written
     a.stats = stats.data_ptr() if want_stats else None
-    check(lib.sc_conv2d_mfma(C.byref(a), stream()))
+    check((lib.sc_conv3x3_bx3 if bx3 else lib.sc_conv2d_mfma)(C.byref(a), stream()))
     return outs, stats
 
 

@@ -8,7 +8,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from hip_ops import (dev, DEV, conv_mfma, cst_affine, pack, relerr, wgrad_mfma)  # noqa: E402
+from hip_ops import (dev, DEV, conv_mfma, cst_affine, pack, pack_bx3, relerr, wgrad_mfma)  # noqa: E402
 from starcop_amd import _lib  # noqa: E402
 from starcop_amd._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD,
                               STAT_DW, STAT_STEM, check, make_src, ptr, stream)  # noqa: E402
@@ -88,6 +88,71 @@ def test_conv_dgrad_bnbwd_split_add(hip, ks, cin, cout, H, W):
     cs = cin // 2 if (cin // 2) % 8 == 0 else 8
     outs, _ = conv_mfma([src], wpk, N, H, W, cin, ks, co_t, csplit=cs)
     assert relerr(outs[0], ref[:, :cs]) < TOL and relerr(outs[1], ref[:, cs:]) < TOL
+
+
+# ---- split-bf16 (three-term) 3x3 convolution: fp32 accuracy on the bf16 matrix cores -------------------------------
+BX3_TOL = 1e-5      # vs an fp64 reference; each case is also required to be no worse than 3x the fp32 MFMA kernel's error
+
+
+@pytest.mark.parametrize("cin,cout,co_t,H,W", [(16, 64, 64, 32, 32), (40, 16, 32, 12, 40), (32, 64, 64, 36, 70), (24, 96, 32, 20, 40),
+                                                (64, 40, 64, 37, 33), (1376, 256, 64, 4, 6), (8, 8, 32, 8, 8)])
+def test_conv_bx3_fwd_affine_stats(hip, cin, cout, co_t, H, W):
+    N = 2
+    x, w = rnd(N, cin, H, W, seed=1), rnd(cout, cin, 3, 3, seed=2, scale=0.2)
+    sc, sh = rnd(cin, seed=3) * 0.5 + 1.0, rnd(cin, seed=4) * 0.3
+    act = ACT_RELU6
+    xin = act_ref(x * sc[None, :, None, None] + sh[None, :, None, None], act)      # fp32, as the kernel's prologue
+    ref = F.conv2d(xin.double(), w.double(), padding=1)
+    src = make_src(dev(x), cin, SRC_AFFINE, act=act, cst=cst_affine(sc, sh))
+    (out,), stats = conv_mfma([src], pack_bx3(dev(w), co_t, 0), N, H, W, cout, 3, co_t, want_stats=True, bx3=True)
+    assert relerr(out, ref) < BX3_TOL
+    # not worse than the fp32 MFMA kernel on the same inputs
+    co32 = 32 if co_t == 32 else 64
+    (out32,), _ = conv_mfma([src], pack(dev(w), co32, 0), N, H, W, cout, 3, co32)
+    assert relerr(out, ref) < 3 * relerr(out32, ref) + 1e-7
+    st = stats.double().sum(0).cpu()
+    assert relerr(st[:, 0], ref.sum((0, 2, 3))) < 1e-5
+    assert relerr(st[:, 1], (ref ** 2).sum((0, 2, 3))) < 1e-5
+
+
+def test_conv_bx3_upsample_concat(hip):
+    N, c0, c1, cout, H, W = 2, 32, 24, 48, 16, 64
+    prev, skip = rnd(N, c0, H // 2, W // 2, seed=1), rnd(N, c1, H, W, seed=2)
+    w = rnd(cout, c0 + c1, 3, 3, seed=3, scale=0.1)
+    sc0, sh0 = rnd(c0, seed=4) * 0.3 + 1, rnd(c0, seed=5) * 0.2
+    xin = torch.cat([F.interpolate(F.relu(prev * sc0[None, :, None, None] + sh0[None, :, None, None]),
+                                   scale_factor=2, mode="nearest"), skip], 1)
+    ref = F.conv2d(xin.double(), w.double(), padding=1)
+    s0 = make_src(dev(prev), c0, SRC_AFFINE, act=ACT_RELU, up=1, cst=cst_affine(sc0, sh0))
+    s1 = make_src(dev(skip), c1, SRC_RAW)
+    for co_t in (32, 64):
+        (out,), _ = conv_mfma([s0, s1], pack_bx3(dev(w), co_t, 0), N, H, W, cout, 3, co_t, bx3=True)
+        assert relerr(out, ref) < BX3_TOL
+
+
+@pytest.mark.parametrize("cin,cout,H,W", [(32, 16, 32, 32), (16, 32, 20, 40), (80, 32, 16, 32), (256, 128, 4, 6), (152, 64, 24, 32)])
+def test_conv_bx3_dgrad_bnbwd_split_add(hip, cin, cout, H, W):
+    N = 2
+    g, y = rnd(N, cout, H, W, seed=1), rnd(N, cout, H, W, seed=2)
+    w = rnd(cout, cin, 3, 3, seed=3, scale=0.2)
+    a, b = rnd(cout, seed=4) * 0.2 + 1, rnd(cout, seed=5) * 0.2
+    A, B, D = rnd(cout, seed=6), rnd(cout, seed=7) * 0.1, rnd(cout, seed=8) * 0.1
+    yh = y * a[None, :, None, None] + b[None, :, None, None]
+    dy = torch.where(yh > 0, g, torch.zeros(())) * A[None, :, None, None] + B[None, :, None, None] * y + D[None, :, None, None]
+    ref = F.conv_transpose2d(dy.double(), w.double(), padding=1)
+    cst = torch.zeros(cout, SC_CST); cst[:, 0], cst[:, 1], cst[:, 2], cst[:, 3], cst[:, 4] = a, b, A, B, D
+    src = make_src(dev(g), cout, SRC_BNBWD, act=ACT_RELU, cst=dev(cst), aux=dev(y))
+    co_t = 32 if cin <= 32 else 64
+    wpk = pack_bx3(dev(w), co_t, 1)
+    (out,), _ = conv_mfma([src], wpk, N, H, W, cin, 3, co_t, bx3=True)
+    assert relerr(out, ref) < 1e-5          # dy itself is formed in fp32 (fma contraction differs from the host's)
+    add0, old = rnd(N, cin, H, W, seed=9), rnd(N, cin, H, W, seed=10)
+    o = dev(old).clone()
+    conv_mfma([src], wpk, N, H, W, cin, 3, co_t, add0=dev(add0), accum=(1, 0), outs=[o], bx3=True)
+    assert relerr(o, ref + add0.double() + old.double()) < 1e-5
+    cs = cin // 2 if (cin // 2) % 8 == 0 else 8
+    outs, _ = conv_mfma([src], wpk, N, H, W, cin, 3, co_t, csplit=cs, bx3=True)
+    assert relerr(outs[0], ref[:, :cs]) < 1e-5 and relerr(outs[1], ref[:, cs:]) < 1e-5
 
 
 @pytest.mark.parametrize("ks,cin,cout,H,W,two", [(3, 16, 16, 32, 32, False), (3, 32, 16, 36, 70, True), (3, 48, 8, 20, 32, False), (3, 32, 64, 16, 32, True), (3, 80, 48, 20, 36, True),
