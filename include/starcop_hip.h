@@ -132,6 +132,10 @@ typedef struct sc_wgrad_args {
 } sc_wgrad_args;
 size_t sc_wgrad_workspace_floats(int N, int H, int W, int Cout, int Cin, int ks);
 int sc_conv2d_wgrad_mfma(const sc_wgrad_args* a, sc_stream stream);
+/* the 3x3 weight gradient with split-bf16 operands on the bf16 matrix cores (see sc_conv3x3_bx3); same arguments,
+ * ks must be 3; workspace from sc_wgrad_bx3_workspace_floats */
+size_t sc_wgrad_bx3_workspace_floats(int N, int H, int W, int Cout, int Cin);
+int sc_conv3x3_wgrad_bx3(const sc_wgrad_args* a, sc_stream stream);
 
 /* ------------------------------------------------------------------------- */
 /* depthwise 3x3 (groups=C, pad 1, stride 1|2): forward, backward-data, backward-weight */

@@ -68,6 +68,8 @@ SIGNATURES = {
     "sc_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sc_packed_weight_floats": (_sz, [_i, _i, _i, _i, _i]),
     "sc_conv2d_mfma": (_i, [C.POINTER(sc_conv_args), _vp]),
+    "sc_wgrad_bx3_workspace_floats": (_sz, [_i, _i, _i, _i, _i]),
+    "sc_conv3x3_wgrad_bx3": (_i, [C.POINTER(sc_wgrad_args), _vp]),
     "sc_pack_weights_bx3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sc_packed_weight_floats_bx3": (_sz, [_i, _i, _i, _i]),
     "sc_conv3x3_bx3": (_i, [C.POINTER(sc_conv_args), _vp]),

@@ -329,6 +329,277 @@ __global__ void k_pack_weights_bx3(const float* __restrict__ w, unsigned short* 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient of the same convolution on the split-bf16 MFMA.
+// GEMM view (per tap):  D[co][ci] = sum_px dy[co][px] * in[ci][px + d(tap)],  K step = 16 pixels of one image row
+//   A (32 x 16): lane l -> dy[co = l&31][px = 16j + 8*(l>>5) .. +7]            (one 16-byte LDS read per term)
+//   B (16 x 32): lane l -> in[ci = l&31][px + kw .. +7]: an aligned 16-byte read + the next dword; kw = 1 is funnel-
+//                shifted in registers (v_alignbit), kw = 2 is a register renaming
+// Work-group = 12 waves; tile = (32*WM couts) x 64 cins x 9 taps; a stage = 2 image rows x 32 columns of one image.
+// Wave = one (cout block, cin block) pair x one filter row kh (3 taps, 48 accumulator registers);
+// WM = 2: 4 pairs x 3 kh, both rows of the stage; WM = 1: 2 pairs x 3 kh x 2 rows (two K parts).
+// The input rows live in a 4-slot ring per channel (slot = (row + 1) & 3): walking down a 32-column strip only the two
+// new rows are fetched per stage, every element is split into its three bf16 terms once.
+struct WgradXP {
+  SrcD dy, s0, s1;
+  int N, H, W, Cout, Cin;
+  float* part;
+  int nsl;          // K slices (gridDim.x)
+  int CoP, CiP;     // padded dims of the partial buffer
+};
+
+template <int WM>
+__global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
+  constexpr int NT = 768;
+  constexpr int COT = 32 * WM, CIT = 64, NPAIR = 2 * WM, KP = 4 / NPAIR;
+  constexpr int DYP = 72;              // dy pitch per cout in pixels (144 B: conflict-free 16-byte reads)
+  constexpr int XRP = 40;              // input row pitch in pixels (34 used)
+  constexpr int XCP = 4 * XRP + 8;     // input pitch per cin: 4 ring rows + pad (336 B: conflict-free)
+  constexpr int NDY = (COT * 32 + NT - 1) / NT;     // dy pixel pairs per thread per stage
+  constexpr int NXI = (2 * 17 * CIT + NT - 1) / NT; // input pixel pairs per thread per two rows
+
+  __shared__ __attribute__((aligned(16))) unsigned s_dy[3][COT * DYP / 2];
+  __shared__ __attribute__((aligned(16))) unsigned s_x[3][CIT * XCP / 2];
+  __shared__ __attribute__((aligned(16))) float s_ca[COT * SC_CST];
+  __shared__ __attribute__((aligned(16))) float s_cb[CIT * 4];      // scale, shift, lo, hi per cin
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int pair = wave % NPAIR, kh = (wave / NPAIR) % 3, kp = wave / (3 * NPAIR);
+  const int wm = pair % WM, wn = pair / WM;
+  const int cit = blockIdx.y, cot = blockIdx.z;
+  const int H = p.H, W = p.W;
+  const int C0 = p.s0.C;
+
+  for (int i = tid; i < COT * SC_CST; i += NT) {
+    const int ch = cot * COT + i / SC_CST;
+    s_ca[i] = (p.dy.cst && p.dy.mode != SC_SRC_RAW && ch < p.Cout) ? p.dy.cst[(size_t)ch * SC_CST + (i % SC_CST)] : ((i % SC_CST) == 0 ? 1.f : 0.f);
+  }
+  for (int i = tid; i < CIT; i += NT) {
+    const int ch = cit * CIT + i;
+    float sc = 1.f, sh = 0.f, lo = -__builtin_inff(), hi = __builtin_inff();
+    if (ch < p.Cin) {
+      const bool second = ch >= C0;
+      const float* cp = second ? p.s1.cst : p.s0.cst;
+      const int md = second ? p.s1.mode : p.s0.mode;
+      const int act = second ? p.s1.act : p.s0.act;
+      if (cp && md != SC_SRC_RAW) { sc = cp[(size_t)(second ? ch - C0 : ch) * SC_CST]; sh = cp[(size_t)(second ? ch - C0 : ch) * SC_CST + 1]; }
+      lo = sc_act_lo(act); hi = sc_act_hi(act);
+    }
+    s_cb[i * 4] = sc; s_cb[i * 4 + 1] = sh; s_cb[i * 4 + 2] = lo; s_cb[i * 4 + 3] = hi;
+  }
+
+  floatx16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // stage enumeration: strips (image, 32-column strip) outer, row pairs inner
+  const int tiles_x = (W + 31) >> 5, RS = (H + 1) >> 1;
+  const long T = (long)p.N * tiles_x * RS;
+  const long t_begin = T * blockIdx.x / p.nsl, t_end = T * (blockIdx.x + 1) / p.nsl;
+  const int dymode = p.dy.mode;
+  const float dlo = sc_act_lo(p.dy.act), dhi = sc_act_hi(p.dy.act);
+  const size_t HW = (size_t)H * W;
+
+  auto decode = [&](long t, int& n, int& y0, int& x0) {
+    const int strip = (int)(t / RS);
+    const int ty = (int)(t - (long)strip * RS);
+    n = strip / tiles_x;
+    x0 = (strip - n * tiles_x) * 32;
+    y0 = ty * 2;
+  };
+
+  // ---- dy: thread owns pixel pairs (co = item >> 5, row = (item >> 4) & 1, cols 2*(item & 15), +1) ----
+  float dg[NDY][2], dv[NDY][2];
+  auto dy_load = [&](int n, int y0, int x0) {
+#pragma unroll
+    for (int k = 0; k < NDY; ++k) {
+      const int it = tid + NT * k;
+      const int co = cot * COT + ((it >> 5) & (COT - 1)), row = (it >> 4) & 1, col = 2 * (it & 15);
+      const int y = y0 + row, x = x0 + col;
+      const bool okc = co < p.Cout && y < H;
+      const size_t base = ((size_t)n * p.Cout + (okc ? co : 0)) * HW + (size_t)(okc ? y : 0) * W;
+      const int xa = (x < W) ? x : 0, xb = (x + 1 < W) ? x + 1 : 0;
+      dg[k][0] = p.dy.x[base + xa]; dg[k][1] = p.dy.x[base + xb];
+      if (dymode == SC_SRC_BNBWD) { dv[k][0] = p.dy.aux[base + xa]; dv[k][1] = p.dy.aux[base + xb]; }
+      else { dv[k][0] = 0.f; dv[k][1] = 0.f; }
+    }
+  };
+  auto dy_store = [&](int y0, int x0) {
+#pragma unroll
+    for (int k = 0; k < NDY; ++k) {
+      const int it = tid + NT * k;
+      const int col_l = (it >> 5) & (COT - 1), row = (it >> 4) & 1, col = 2 * (it & 15);
+      const int y = y0 + row, x = x0 + col;
+      const bool okc = (cot * COT + col_l < p.Cout) && y < H;
+      const float4 c0 = *reinterpret_cast<const float4*>(&s_ca[col_l * SC_CST]);
+      const float c4 = s_ca[col_l * SC_CST + 4];
+      float v0, v1;
+      if (dymode == SC_SRC_BNBWD) {
+        v0 = sc_pro_bnbwd(dg[k][0], dv[k][0], c0.x, c0.y, c0.z, c0.w, c4, dlo, dhi);
+        v1 = sc_pro_bnbwd(dg[k][1], dv[k][1], c0.x, c0.y, c0.z, c0.w, c4, dlo, dhi);
+      } else {
+        v0 = sc_pro_affine(dg[k][0], c0.x, c0.y, dlo, dhi);
+        v1 = sc_pro_affine(dg[k][1], c0.x, c0.y, dlo, dhi);
+      }
+      v0 = (okc && x < W) ? v0 : 0.f;
+      v1 = (okc && x + 1 < W) ? v1 : 0.f;
+      unsigned t0, t1, t2;
+      split3x2(v0, v1, t0, t1, t2);
+      const int d = (col_l * DYP + row * 32 + col) >> 1;
+      if (it < COT * 32) { s_dy[0][d] = t0; s_dy[1][d] = t1; s_dy[2][d] = t2; }
+    }
+  };
+
+  // ---- input rows R, R+1 (R may be -1): item -> (pair of columns pr in 0..16, row, ci) ----
+  float xr[NXI][2];
+  auto x_load = [&](int n, int R, int x0) {
+#pragma unroll
+    for (int k = 0; k < NXI; ++k) {
+      const int it = tid + NT * k;
+      const int rc = it / 17, pr = it - rc * 17;
+      const int rowi = rc & 1, cil = (rc >> 1) & (CIT - 1);
+      const int chr = cit * CIT + cil;
+      const int ch = chr < p.Cin ? chr : 0;
+      const bool second = ch >= C0;
+      const int cs = second ? ch - C0 : ch;
+      const int Cs = second ? p.s1.C : p.s0.C;
+      const int up = second ? p.s1.up : p.s0.up;
+      const int y = R + rowi, x = x0 - 1 + 2 * pr;
+      const bool oky = (y >= 0) && (y < H);
+      const int Ws = W >> up;
+      const float* xp = (second ? p.s1.x : p.s0.x) + ((size_t)n * Cs + cs) * ((size_t)(H >> up) * Ws) + (size_t)((oky ? y : 0) >> up) * Ws;
+      const int xa = (x >= 0 && x < W) ? x : 0, xb = (x + 1 < W) ? x + 1 : 0;
+      xr[k][0] = xp[xa >> up]; xr[k][1] = xp[xb >> up];
+    }
+  };
+  auto x_store = [&](int R, int x0) {
+#pragma unroll
+    for (int k = 0; k < NXI; ++k) {
+      const int it = tid + NT * k;
+      const int rc = it / 17, pr = it - rc * 17;
+      const int rowi = rc & 1, cil = (rc >> 1) & (CIT - 1);
+      const int y = R + rowi, x = x0 - 1 + 2 * pr;
+      const bool okc = (cit * CIT + cil < p.Cin) && (y >= 0) && (y < H);
+      const float4 c = *reinterpret_cast<const float4*>(&s_cb[cil * 4]);
+      float v0 = sc_pro_affine(xr[k][0], c.x, c.y, c.z, c.w);
+      float v1 = sc_pro_affine(xr[k][1], c.x, c.y, c.z, c.w);
+      v0 = (okc && x >= 0 && x < W) ? v0 : 0.f;
+      v1 = (okc && x + 1 < W) ? v1 : 0.f;
+      unsigned t0, t1, t2;
+      split3x2(v0, v1, t0, t1, t2);
+      const int slot = (y + 1) & 3;
+      const int d = ((cil * XCP + slot * XRP) >> 1) + pr;
+      if (it < 2 * 17 * CIT) { s_x[0][d] = t0; s_x[1][d] = t1; s_x[2][d] = t2; }
+    }
+  };
+
+  auto compute = [&](int y0) {
+#pragma unroll
+    for (int rr = 0; rr < (KP == 1 ? 2 : 1); ++rr) {
+      const int r = (KP == 1) ? rr : kp;
+      const int slot = (y0 + r + kh) & 3;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bf16x8 A[3];
+        const int da = ((wm * 32 + l31) * DYP + r * 32 + 16 * j + 8 * lhi) >> 1;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) A[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uintx4*>(&s_dy[t][da]));
+        const int dx = ((wn * 32 + l31) * XCP + slot * XRP + 16 * j + 8 * lhi) >> 1;
+        bf16x8 B[3][3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const uintx4 X0 = *reinterpret_cast<const uintx4*>(&s_x[t][dx]);
+          const unsigned X1 = s_x[t][dx + 4];
+          uintx4 S1, S2;
+          S1[0] = __builtin_amdgcn_alignbit(X0[1], X0[0], 16);
+          S1[1] = __builtin_amdgcn_alignbit(X0[2], X0[1], 16);
+          S1[2] = __builtin_amdgcn_alignbit(X0[3], X0[2], 16);
+          S1[3] = __builtin_amdgcn_alignbit(X1, X0[3], 16);
+          S2[0] = X0[1]; S2[1] = X0[2]; S2[2] = X0[3]; S2[3] = X1;
+          B[0][t] = __builtin_bit_cast(bf16x8, X0);
+          B[1][t] = __builtin_bit_cast(bf16x8, S1);
+          B[2][t] = __builtin_bit_cast(bf16x8, S2);
+        }
+        // the six partial products, taps interleaved so that consecutive MFMAs hit different accumulators
+#define SC_BX3_STEP(TA, TB)                                                                                         \
+  _Pragma("unroll") for (int kw = 0; kw < 3; ++kw)                                                                  \
+      acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[TA], B[kw][TB], acc[kw], 0, 0, 0);
+        SC_BX3_STEP(1, 1) SC_BX3_STEP(2, 0) SC_BX3_STEP(0, 2) SC_BX3_STEP(1, 0) SC_BX3_STEP(0, 1) SC_BX3_STEP(0, 0)
+#undef SC_BX3_STEP
+      }
+    }
+  };
+
+  __syncthreads();          // constants in LDS
+  if (t_begin < t_end) {
+    int n, y0, x0;
+    decode(t_begin, n, y0, x0);
+    x_load(n, y0 - 1, x0);
+    dy_load(n, y0, x0);
+    x_store(y0 - 1, x0);
+    x_load(n, y0 + 1, x0);
+    dy_store(y0, x0);
+    x_store(y0 + 1, x0);
+    __syncthreads();
+  }
+  for (long t = t_begin; t < t_end; ++t) {
+    int n, y0, x0, n1 = 0, y1 = 0, x1 = 0;
+    decode(t, n, y0, x0);
+    const bool more = (t + 1) < t_end;
+    if (more) {
+      decode(t + 1, n1, y1, x1);
+      dy_load(n1, y1, x1);
+      x_load(n1, y1 + 1, x1);
+    }
+    compute(y0);
+    __syncthreads();
+    if (more) {
+      dy_store(y1, x1);
+      x_store(y1 + 1, x1);
+      if (y1 == 0) {            // new strip: the two rows above are not in the ring
+        x_load(n1, y1 - 1, x1);
+        x_store(y1 - 1, x1);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- partial store: part[((slice*KP + kp)*9 + tap)*CoP*CiP + co*CiP + ci] ----
+  const int ci = cit * CIT + wn * 32 + l31;
+  const size_t plane = (size_t)p.CoP * p.CiP;
+  float* pb = p.part + ((size_t)blockIdx.x * KP + kp) * 9 * plane;
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cot * COT + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (co < p.CoP && ci < p.CiP) pb[(kh * 3 + kw) * plane + (size_t)co * p.CiP + ci] = acc[kw][r];
+    }
+  }
+}
+
+struct WgradXPlan { int wm, kp, nsl, CoP, CiP, co_tiles, ci_tiles; };
+WgradXPlan plan_wgrad_bx3(int N, int H, int W, int Cout, int Cin) {
+  WgradXPlan pl;
+  pl.wm = Cout > 32 ? 2 : 1;
+  pl.kp = 4 / (2 * pl.wm);
+  pl.CoP = (Cout + 31) / 32 * 32;
+  pl.CiP = (Cin + 31) / 32 * 32;
+  pl.co_tiles = (Cout + 32 * pl.wm - 1) / (32 * pl.wm);
+  pl.ci_tiles = (Cin + 63) / 64;
+  const long T = (long)N * ((W + 31) / 32) * ((H + 1) / 2);
+  long want = 512 / ((long)pl.co_tiles * pl.ci_tiles);
+  if (want > T / 4) want = T / 4;
+  if (want > 512) want = 512;
+  if (want < 1) want = 1;
+  pl.nsl = (int)want;
+  return pl;
+}
+
 }  // namespace
 
 extern "C" size_t sc_packed_weight_floats_bx3(int Cout, int Cin, int co_t, int transpose_flip) {
@@ -384,4 +655,40 @@ extern "C" int sc_conv3x3_bx3(const sc_conv_args* a, sc_stream stream) {
   else hipLaunchKernelGGL((k_conv3_bx3<1>), grid, dim3(256), 0, st, p);
   SC_LAUNCH_OK("sc_conv3x3_bx3");
   return SC_OK;
+}
+
+extern "C" size_t sc_wgrad_bx3_workspace_floats(int N, int H, int W, int Cout, int Cin) {
+  const WgradXPlan pl = plan_wgrad_bx3(N, H, W, Cout, Cin);
+  const size_t E = (size_t)9 * pl.CoP * pl.CiP;
+  const int nparts = pl.nsl * pl.kp;
+  return (size_t)nparts * E + sc_reduce_scratch_floats(nparts, E);
+}
+
+extern "C" int sc_conv3x3_wgrad_bx3(const sc_wgrad_args* a, sc_stream stream) {
+  SC_REQUIRE(a != nullptr, "sc_conv3x3_wgrad_bx3: null args");
+  SC_REQUIRE(a->ks == 3, "sc_conv3x3_wgrad_bx3: ks must be 3");
+  SC_REQUIRE(a->nsrc == 1 || a->nsrc == 2, "sc_conv3x3_wgrad_bx3: nsrc must be 1 or 2");
+  const int C0 = a->src[0].C, C1 = a->nsrc == 2 ? a->src[1].C : 0;
+  SC_REQUIRE(C0 + C1 == a->Cin, "sc_conv3x3_wgrad_bx3: source channels (%d+%d) != Cin %d", C0, C1, a->Cin);
+  SC_REQUIRE(a->dy.C == a->Cout, "sc_conv3x3_wgrad_bx3: dy channels %d != Cout %d", a->dy.C, a->Cout);
+  SC_REQUIRE(a->dy.up == 0 && a->dy.mode != SC_SRC_NORM, "sc_conv3x3_wgrad_bx3: unsupported dy source");
+  SC_REQUIRE(a->dy.mode != SC_SRC_BNBWD || a->dy.aux != nullptr, "sc_conv3x3_wgrad_bx3: BNBWD dy needs aux");
+  SC_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->Cout > 0 && a->Cin > 0, "sc_conv3x3_wgrad_bx3: bad shape");
+  for (int s = 0; s < a->nsrc; ++s) {
+    SC_REQUIRE(a->src[s].mode == SC_SRC_RAW || a->src[s].mode == SC_SRC_AFFINE, "sc_conv3x3_wgrad_bx3: input sources must be RAW or AFFINE");
+    SC_REQUIRE(a->src[s].up == 0 || (a->src[s].up == 1 && a->H % 2 == 0 && a->W % 2 == 0), "sc_conv3x3_wgrad_bx3: upsampled source needs even H,W");
+  }
+  const WgradXPlan pl = plan_wgrad_bx3(a->N, a->H, a->W, a->Cout, a->Cin);
+  const size_t need = sc_wgrad_bx3_workspace_floats(a->N, a->H, a->W, a->Cout, a->Cin);
+  SC_REQUIRE(a->part_floats >= need, "sc_conv3x3_wgrad_bx3: workspace too small (%zu < %zu floats)", a->part_floats, need);
+  WgradXP p;
+  p.dy = to_srcd(a->dy); p.s0 = to_srcd(a->src[0]); p.s1 = a->nsrc == 2 ? to_srcd(a->src[1]) : empty_srcd();
+  p.N = a->N; p.H = a->H; p.W = a->W; p.Cout = a->Cout; p.Cin = a->Cin; p.part = a->part;
+  p.nsl = pl.nsl; p.CoP = pl.CoP; p.CiP = pl.CiP;
+  dim3 grid(pl.nsl, pl.ci_tiles, pl.co_tiles);
+  hipStream_t st = (hipStream_t)stream;
+  if (pl.wm == 2) hipLaunchKernelGGL((k_wgrad3_bx3<2>), grid, dim3(768), 0, st, p);
+  else hipLaunchKernelGGL((k_wgrad3_bx3<1>), grid, dim3(768), 0, st, p);
+  SC_LAUNCH_OK("sc_conv3x3_wgrad_bx3");
+  return sc_wgrad_finish(a->part, pl.nsl * pl.kp, 9, a->Cout, a->Cin, pl.CoP, pl.CiP, a->dw, st);
 }

@@ -1019,16 +1019,19 @@ extern "C" int sc_conv2d_wgrad_mfma(const sc_wgrad_args* a, sc_stream stream) {
   }
 #undef SC_WG
   SC_LAUNCH_OK("sc_conv2d_wgrad_mfma");
-  // two-level reduction of the K-slice partials, then the layout change to OIHW
-  const size_t E = (size_t)a->ks * a->ks * pl.CoP * pl.CiP;
-  const int nparts = pl.nsl * pl.wk;
+  return sc_wgrad_finish(a->part, pl.nsl * pl.wk, a->ks * a->ks, a->Cout, a->Cin, pl.CoP, pl.CiP, a->dw, st);
+}
+
+// two-level reduction of the K-slice partials part[nparts][taps][CoP][CiP] (scratch follows them), then the layout
+// change to OIHW
+int sc_wgrad_finish(float* part, int nparts, int taps, int Cout, int Cin, int CoP, int CiP, float* dw, hipStream_t st) {
+  const size_t E = (size_t)taps * CoP * CiP;
   const float* rows; int nrows;
-  int rc = sc_reduce_rows_partial(a->part, nparts, E, a->part + (size_t)nparts * E, &rows, &nrows, st);
+  int rc = sc_reduce_rows_partial(part, nparts, E, part + (size_t)nparts * E, &rows, &nrows, st);
   if (rc != SC_OK) return rc;
-  const size_t total = (size_t)a->ks * a->ks * a->Cout * a->Cin;
+  const size_t total = (size_t)taps * Cout * Cin;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(256), 0, st, rows, a->dw, nrows, a->ks * a->ks, a->Cout,
-                     a->Cin, pl.CoP, pl.CiP);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(256), 0, st, rows, dw, nrows, taps, Cout, Cin, CoP, CiP);
   SC_LAUNCH_OK("sc_wgrad_reduce");
   return SC_OK;
 }

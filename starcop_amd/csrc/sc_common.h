@@ -116,6 +116,10 @@ int sc_reduce_rows(const float* part, int nparts, size_t E, float* scratch, floa
 int sc_reduce_rows_partial(const float* part, int nparts, size_t E, float* scratch, const float** rows_out,
                            int* nrows_out, hipStream_t st);
 
+// weight-gradient epilogue shared by the MFMA wgrad kernels (conv_mfma.hip): sums part[nparts][taps][CoP][CiP]
+// (reduction scratch of sc_reduce_scratch_floats(nparts, taps*CoP*CiP) floats follows the partials) into dw (OIHW)
+int sc_wgrad_finish(float* part, int nparts, int taps, int Cout, int Cin, int CoP, int CiP, float* dw, hipStream_t st);
+
 // row of this work-group in a [rows][C][2] partial-statistics buffer (grid = (tiles, channel-tiles, N))
 // depthwise tile shape (outputs per block) by plane width; shared by the launchers and sc_stat_rows
 inline int sc_dw_tile_w(int W) { return W > 32 ? 64 : (W > 16 ? 32 : 16); }

@@ -316,6 +316,8 @@ class HyperStarcopUNet(nn.Module):
                 if op["type"] in ("pw", "conv3"):
                     ws = max(ws, lib.sc_wgrad_workspace_floats(N, Ho, Wo, conv.out_channels, conv.in_channels,
                                                                conv.kernel_size[0]))
+                    if conv.kernel_size[0] == 3:
+                        ws = max(ws, lib.sc_wgrad_bx3_workspace_floats(N, Ho, Wo, conv.out_channels, conv.in_channels))
                     if op.get("up"):
                         up = max(up, N * op["ins"][0].C * Ho * Wo)
                 elif op["type"] == "stem":
@@ -589,7 +591,9 @@ class HyperStarcopUNet(nn.Module):
             wa.dw = gv(conv.weight).data_ptr()
             flop = 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * ks * ks
             tok = self._pb(f"k_wgrad_mfma<{ks}> (+reduce)", flop)
-            wgrad_launch(lambda sx: check(lib.sc_conv2d_wgrad_mfma(C.byref(wa), sx)))
+            wfn = (lib.sc_conv3x3_wgrad_bx3 if (self.split_bf16 and ks == 3 and conv.out_channels >= 32 and conv.in_channels > 32)
+                   else lib.sc_conv2d_wgrad_mfma)     # its cin tile is 64 wide: 32 -> 32 layers stay on the fp32 MFMA
+            wgrad_launch(lambda sx, wfn=wfn, wa=wa: check(wfn(C.byref(wa), sx)))
             self._pe(tok)
             # data gradient
             if ins[0].kind == "input":

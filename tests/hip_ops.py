@@ -68,7 +68,7 @@ def conv_mfma(srcs, wpk, N, H, W, Cout, ks, co_t, want_stats=False, csplit=None,
     return outs, stats
 
 
-def wgrad_mfma(dy, srcs, N, H, W, Cout, Cin, ks):
+def wgrad_mfma(dy, srcs, N, H, W, Cout, Cin, ks, bx3=False):
     lib = _lib.load()
     a = sc_wgrad_args()
     a.dy = dy
@@ -76,12 +76,12 @@ def wgrad_mfma(dy, srcs, N, H, W, Cout, Cin, ks):
     for i, s in enumerate(srcs):
         a.src[i] = s
     a.N, a.H, a.W, a.Cout, a.Cin, a.ks = N, H, W, Cout, Cin, ks
-    n = lib.sc_wgrad_workspace_floats(N, H, W, Cout, Cin, ks)
+    n = lib.sc_wgrad_bx3_workspace_floats(N, H, W, Cout, Cin) if bx3 else lib.sc_wgrad_workspace_floats(N, H, W, Cout, Cin, ks)
     ws = torch.empty(n, device=DEV)
     a.part, a.part_floats = ws.data_ptr(), n
     dw = torch.empty(Cout, Cin, ks, ks, device=DEV)
     a.dw = dw.data_ptr()
-    check(lib.sc_conv2d_wgrad_mfma(C.byref(a), stream()))
+    check((lib.sc_conv3x3_wgrad_bx3 if bx3 else lib.sc_conv2d_wgrad_mfma)(C.byref(a), stream()))
     return dw
 
 

@@ -183,6 +183,35 @@ def test_conv_wgrad(hip, ks, cin, cout, H, W, two):
     assert relerr(dw, w.grad) < TOL
 
 
+@pytest.mark.parametrize("cin,cout,H,W,two", [(16, 64, 32, 32, False), (32, 16, 36, 70, True), (48, 40, 21, 32, False), (32, 64, 16, 32, True),
+                                               (80, 32, 20, 36, True), (152, 64, 8, 64, True), (256, 256, 4, 6, False), (72, 136, 10, 33, False)])
+def test_conv_bx3_wgrad(hip, cin, cout, H, W, two):
+    """3x3 weight gradient with split-bf16 operands: vs fp64, and no worse than the fp32 MFMA kernel."""
+    N = 3
+    g, y = rnd(N, cout, H, W, seed=1), rnd(N, cout, H, W, seed=2)
+    a, b = rnd(cout, seed=4) * 0.2 + 1, rnd(cout, seed=5) * 0.2
+    A, B, D = rnd(cout, seed=6), rnd(cout, seed=7) * 0.1, rnd(cout, seed=8) * 0.1
+    yh = y * a[None, :, None, None] + b[None, :, None, None]
+    dy = torch.where((yh > 0) & (yh < 6), g, torch.zeros(())) * A[None, :, None, None] + B[None, :, None, None] * y + D[None, :, None, None]
+    cst = torch.zeros(cout, SC_CST); cst[:, 0], cst[:, 1], cst[:, 2], cst[:, 3], cst[:, 4] = a, b, A, B, D
+    dys = make_src(dev(g), cout, SRC_BNBWD, act=ACT_RELU6, cst=dev(cst), aux=dev(y))
+    if two:
+        c0 = cin - 8
+        prev, skip = rnd(N, c0, H // 2, W // 2, seed=11), rnd(N, 8, H, W, seed=12)
+        sc0, sh0 = rnd(c0, seed=13) * 0.3 + 1, rnd(c0, seed=14) * 0.2
+        xin = torch.cat([F.interpolate(F.relu(prev * sc0[None, :, None, None] + sh0[None, :, None, None]), scale_factor=2), skip], 1)
+        srcs = [make_src(dev(prev), c0, SRC_AFFINE, act=ACT_RELU, up=1, cst=cst_affine(sc0, sh0)), make_src(dev(skip), 8, SRC_RAW)]
+    else:
+        xin = rnd(N, cin, H, W, seed=11)
+        srcs = [make_src(dev(xin), cin, SRC_RAW)]
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xin.double(), w, padding=1).backward(dy.double())
+    dw = wgrad_mfma(dys, srcs, N, H, W, cout, cin, 3, bx3=True)
+    dw32 = wgrad_mfma(dys, srcs, N, H, W, cout, cin, 3)
+    e, e32 = relerr(dw, w.grad), relerr(dw32, w.grad)
+    assert e < 1e-5 and e < 3 * e32 + 2e-7, (e, e32)
+
+
 @pytest.mark.parametrize("C_,H,W,stride", [(32, 32, 32, 1), (24, 20, 28, 2), (96, 16, 16, 2), (40, 7, 9, 1), (960, 2, 3, 1), (576, 4, 6, 2)])
 def test_depthwise(hip, C_, H, W, stride):
     N = 2

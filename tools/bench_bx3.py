@@ -41,3 +41,22 @@ for name, cin, cout, H in SHAPES:
     tbx = timeit(lambda: conv_mfma([src], wb, N, H, W, cout, 3, co_t, want_stats=not bwd, outs=outs, bx3=True))
     err = float((outs[0] - o32).abs().max() / o32.abs().max())
     print(f"{name:10s} {cin:5d}->{cout:4d} {H:3d}^2  f32 {t32:7.3f} ms {flop/t32/1e9:6.1f} TF | bx3 {tbx:7.3f} ms {flop/tbx/1e9:6.1f} TF | x{t32/tbx:4.2f}  diff {err:.1e}")
+
+from hip_ops import wgrad_mfma
+print("--- weight gradient ---")
+for name, cin, cout, H in [("d0a", 1376, 256, 32), ("d0b", 256, 256, 32), ("d1a", 288, 128, 64), ("d1b", 128, 128, 64), ("d2a", 152, 64, 128),
+                           ("d2b", 64, 64, 128), ("d3a", 80, 32, 256), ("d3b", 32, 32, 256)]:
+    W = H
+    x = torch.randn(N, cin, H, W, device=DEV)
+    g = torch.randn(N, cout, H, W, device=DEV)
+    y = torch.randn(N, cout, H, W, device=DEV)
+    cst = torch.rand(cout, SC_CST, device=DEV)
+    cstx = torch.rand(cin, SC_CST, device=DEV)
+    dys = make_src(g, cout, SRC_BNBWD, act=ACT_RELU, cst=cst, aux=y)
+    src = make_src(x, cin, SRC_AFFINE, act=ACT_RELU, cst=cstx)
+    flop = 2.0 * N * H * W * cin * cout * 9
+    t32 = timeit(lambda: wgrad_mfma(dys, [src], N, H, W, cout, cin, 3))
+    tbx = timeit(lambda: wgrad_mfma(dys, [src], N, H, W, cout, cin, 3, bx3=True))
+    a, b = wgrad_mfma(dys, [src], N, H, W, cout, cin, 3), wgrad_mfma(dys, [src], N, H, W, cout, cin, 3, bx3=True)
+    err = float((a - b).abs().max() / a.abs().max())
+    print(f"{name:10s} {cin:5d}->{cout:4d} {H:3d}^2  f32 {t32:7.3f} ms {flop/t32/1e9:6.1f} TF | bx3 {tbx:7.3f} ms {flop/tbx/1e9:6.1f} TF | x{t32/tbx:4.2f}  diff {err:.1e}")
