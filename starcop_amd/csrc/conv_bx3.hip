@@ -22,6 +22,7 @@
 // LDS: patch [3 terms][2 channel halves][10 x 34 pixels] x 16 B (single buffer, next chunk prefetched in registers),
 // filters per filter row kh [3 terms][3 kw][2 halves][32Q couts] x 16 B, double buffered.  ~72 KB -> 2 work-groups / CU.
 #include "sc_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -53,16 +54,20 @@ __device__ __forceinline__ void split3x2(float a, float b, unsigned& t0, unsigne
   t2 = __builtin_bit_cast(unsigned, h2);
 }
 
-template <int Q>
-__global__ __launch_bounds__(256, 2) void k_conv3_bx3(const ConvXP p) {
+// BNB: the (single) source is a BatchNorm/activation-backward source (dgrad); otherwise affine/raw sources (forward)
+template <int Q, bool BNB>
+__global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP p) {
   constexpr int PR = 10, PC = 34, NPX = PR * PC;     // 8 output rows + halo
+  constexpr bool PAD = (Q == 2);                     // Q = 1 keeps LDS under 53 KB (3 work-groups per CU) with guarded stores
+  constexpr int NPXP = PAD ? 384 : NPX;              // padded: 3 staging rounds x 128 threads store unconditionally
   constexpr int CO_T = 32 * Q;
   constexpr int WENT = 18 * CO_T;                    // 16-byte filter entries per (chunk, kh) stage
   constexpr int NWV = (WENT + 255) / 256;
-  constexpr int NR = 3;                              // staging rounds: 128 threads per channel half, 3 x 128 >= 340
+  constexpr int WENTP = PAD ? NWV * 256 : WENT;      // padded likewise
+  constexpr int NR = 3;
 
-  __shared__ uintx4 s_p[3][2][NPX];
-  __shared__ uintx4 s_w[2][WENT];
+  __shared__ uintx4 s_p[3][2][NPXP];
+  __shared__ uintx4 s_w[2][WENTP];
   __shared__ float s_red[4][CO_T][2];
 
   const int tid = threadIdx.x;
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3_bx3(const ConvXP p) {
   // ---- staging state ----
   const int hw = __builtin_amdgcn_readfirstlane(wave >> 1);     // channel half staged by this wave (uniform)
   const int sidx = tid & 127;
-  int off0[NR], off1[NR];             // clamped pixel offsets in source 0 / source 1 (they may differ in `up`)
+  unsigned off0[NR], off1[NR];        // clamped pixel offsets in source 0 / source 1 (they may differ in `up`)
   unsigned inb = 0;
   {
     const int up0 = p.s0.up, up1 = p.s1.up;
@@ -100,73 +105,74 @@ __global__ __launch_bounds__(256, 2) void k_conv3_bx3(const ConvXP p) {
       const int pr = e / PC, pc = e - pr * PC;
       const int y = y0 - 1 + pr, x = x0 - 1 + pc;
       const bool ok = (e < NPX) && (y >= 0) && (y < H) && (x >= 0) && (x < W);
-      off0[r] = ok ? (y >> up0) * Ws0 + (x >> up0) : 0;
-      off1[r] = ok ? (y >> up1) * Ws1 + (x >> up1) : 0;
+      off0[r] = ok ? (unsigned)((y >> up0) * Ws0 + (x >> up0)) : 0u;
+      off1[r] = ok ? (unsigned)((y >> up1) * Ws1 + (x >> up1)) : 0u;
       inb |= ok ? (1u << r) : 0u;
     }
   }
-  float xv[NR][8], av[NR][8];
+  float xv[NR][8], av[BNB ? NR : 1][8];
   uintx4 wv[NWV];
   // per-chunk source description (uniform)
-  const float* xp = nullptr; const float* ap = nullptr; const float* cp = nullptr;
-  int Cs = 0, smode = 0, cbase = 0; size_t plane = 0; bool second = false;
+  const float* xb = nullptr; const float* ab = nullptr; const float* cb = nullptr;
+  size_t plane = 0; int nch = 0; bool second = false;
   float slo = 0.f, shi = 0.f;
 
   auto select_chunk = [&](int kc) {
     second = kc * 16 >= C0;
-    xp = second ? p.s1.x : p.s0.x;
-    ap = second ? p.s1.aux : p.s0.aux;
-    cp = second ? p.s1.cst : p.s0.cst;
-    Cs = second ? p.s1.C : p.s0.C;
-    const int up = second ? p.s1.up : p.s0.up;
-    smode = second ? p.s1.mode : p.s0.mode;
-    const int sact = second ? p.s1.act : p.s0.act;
-    slo = sc_act_lo(sact); shi = sc_act_hi(sact);
-    plane = (size_t)(H >> up) * (W >> up);
-    cbase = kc * 16 + hw * 8 - (second ? C0 : 0);            // first channel (source space) staged by this wave
+    const SrcD& s = second ? p.s1 : p.s0;
+    slo = sc_act_lo(s.act); shi = sc_act_hi(s.act);
+    plane = (size_t)(H >> s.up) * (W >> s.up);
+    const int cbase = kc * 16 + hw * 8 - (second ? C0 : 0);       // first channel (source space) staged by this wave
+    nch = s.C - cbase;                                            // channels j < nch exist
+    const size_t o = ((size_t)n * s.C + (nch > 0 ? cbase : 0)) * plane;
+    xb = s.x + o;
+    ab = BNB ? s.aux + o : nullptr;
+    cb = (s.mode != SC_SRC_RAW) ? s.cst + (size_t)(nch > 0 ? cbase : 0) * SC_CST : nullptr;
   };
   auto load_round = [&](int r) {
-    const int o = second ? off1[r] : off0[r];
+    const unsigned o = second ? off1[r] : off0[r];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int cs = (cbase + j < Cs) ? cbase + j : 0;
-      const size_t b = ((size_t)n * Cs + cs) * plane + o;
-      xv[r][j] = xp[b];
-      av[r][j] = (smode == SC_SRC_BNBWD) ? ap[b] : 0.f;
+      const size_t cj = (j < nch) ? (size_t)j * plane : 0;
+      xv[r][j] = xb[cj + o];
+      if (BNB) av[r][j] = ab[cj + o];
     }
   };
-  auto store_patch = [&]() {
-    float4 c0[8]; float c4[8]; bool chok[8];
+  // prologue + three-term split of two channels (2jp, 2jp+1) of staging round r -> one dword of each term vector.
+  // The twelve units of a chunk ride along with the MFMA steps of filter rows 1 and 2 (interleaved with them by
+  // sched_group_barrier), so that only the LDS writes remain between the two barriers at the end of a chunk.
+  uintx4 pt[NR][3];
+  float cs0[8], cs1[8], cs2[8], cs3[8], cs4[8];         // per-channel constants of the chunk being staged
+  auto load_consts = [&]() {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      chok[j] = cbase + j < Cs;
-      const int cs = chok[j] ? cbase + j : 0;
-      if (smode != SC_SRC_RAW) {
-        c0[j] = *reinterpret_cast<const float4*>(cp + (size_t)cs * SC_CST);
-        c4[j] = cp[(size_t)cs * SC_CST + 4];
-      } else {
-        c0[j] = make_float4(1.f, 0.f, 0.f, 0.f); c4[j] = 0.f;
+      const int cj = (j < nch) ? j : 0;
+      cs0[j] = 1.f; cs1[j] = 0.f; cs2[j] = 0.f; cs3[j] = 0.f; cs4[j] = 0.f;
+      if (cb) {
+        const float4 c = *reinterpret_cast<const float4*>(cb + (size_t)cj * SC_CST);
+        cs0[j] = c.x; cs1[j] = c.y;
+        if (BNB) { cs2[j] = c.z; cs3[j] = c.w; cs4[j] = cb[(size_t)cj * SC_CST + 4]; }
       }
     }
+  };
+  auto convert_unit = [&](int r, int jp) {
+    float v[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = 2 * jp + h;
+      const float t = BNB ? sc_pro_bnbwd(xv[r][j], av[BNB ? r : 0][j], cs0[j], cs1[j], cs2[j], cs3[j], cs4[j], slo, shi)
+                          : sc_pro_affine(xv[r][j], cs0[j], cs1[j], slo, shi);
+      v[h] = (((inb >> r) & 1u) && j < nch) ? t : 0.f;
+    }
+    unsigned a, b, c;
+    split3x2(v[0], v[1], a, b, c);
+    pt[r][0][jp] = a; pt[r][1][jp] = b; pt[r][2][jp] = c;
+  };
+  auto store_patch = [&]() {
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int e = sidx + 128 * r;
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float t = (smode == SC_SRC_BNBWD)
-                            ? sc_pro_bnbwd(xv[r][j], av[r][j], c0[j].x, c0[j].y, c0[j].z, c0[j].w, c4[j], slo, shi)
-                            : sc_pro_affine(xv[r][j], c0[j].x, c0[j].y, slo, shi);
-        v[j] = (((inb >> r) & 1u) && chok[j]) ? t : 0.f;
-      }
-      uintx4 t0, t1, t2;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        unsigned a, b, c;
-        split3x2(v[2 * j], v[2 * j + 1], a, b, c);
-        t0[j] = a; t1[j] = b; t2[j] = c;
-      }
-      if (e < NPX) { s_p[0][hw][e] = t0; s_p[1][hw][e] = t1; s_p[2][hw][e] = t2; }
+      if (PAD || e < NPX) { s_p[0][hw][e] = pt[r][0]; s_p[1][hw][e] = pt[r][1]; s_p[2][hw][e] = pt[r][2]; }
     }
   };
   auto load_w = [&](int s) {
@@ -179,66 +185,143 @@ __global__ __launch_bounds__(256, 2) void k_conv3_bx3(const ConvXP p) {
   };
   auto store_w = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < NWV; ++j) {
-      const int i = tid + 256 * j;
-      if (i < WENT) s_w[buf][i] = wv[j];
-    }
+    for (int j = 0; j < NWV; ++j)
+      if (PAD || tid + 256 * j < WENT) s_w[buf][tid + 256 * j] = wv[j];
   };
-  auto compute = [&](int kh, int buf) {
+  // operand fetches of one step are issued before the 6*Q MFMAs of the previous step (explicit software pipeline: the
+  // scheduler barrier keeps the LDS reads ~6*Q*32 cycles ahead of their use)
+  auto load_A = [&](bf16x8 (&A)[Q][3], int buf, int kw) {
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      bf16x8 A[Q][3];
+    for (int q = 0; q < Q; ++q)
 #pragma unroll
-      for (int q = 0; q < Q; ++q)
+      for (int c = 0; c < 3; ++c)
+        A[q][c] = __builtin_bit_cast(bf16x8, s_w[buf][((c * 3 + kw) * 2 + lhi) * CO_T + q * 32 + l31]);
+  };
+  auto load_B = [&](bf16x8 (&B)[3], int kh, int kw, int pp) {
+    const int e = (2 * wave + pp + kh) * PC + l31 + kw;
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-          A[q][c] = __builtin_bit_cast(bf16x8, s_w[buf][((c * 3 + kw) * 2 + lhi) * CO_T + q * 32 + l31]);
+    for (int c = 0; c < 3; ++c) B[c] = __builtin_bit_cast(bf16x8, s_p[c][lhi][e]);
+  };
+  // six partial products, cout blocks interleaved (independent accumulators back to back)
+#define SC_BX3_STEP(A, B, PP, TA, TB)                                                                              \
+  _Pragma("unroll") for (int q = 0; q < Q; ++q)                                                                    \
+      acc[PP][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[q][TA], B[TB], acc[PP][q], 0, 0, 0);
+#define SC_BX3_MFMAS(A, B, PP)                                                                                     \
+  SC_BX3_STEP(A, B, PP, 1, 1) SC_BX3_STEP(A, B, PP, 2, 0) SC_BX3_STEP(A, B, PP, 0, 2) SC_BX3_STEP(A, B, PP, 1, 0)  \
+  SC_BX3_STEP(A, B, PP, 0, 1) SC_BX3_STEP(A, B, PP, 0, 0)
+  // One step = the 6*Q MFMAs of (A, B) into acc[PP][*] with, when CV, one conversion unit (r, jp) cut into five slices
+  // that are pinned between the MFMAs by scheduler barriers: each slice (<= 7 VALU) issues in the shadow of one MFMA.
+  auto step = [&](const bf16x8 (&A)[Q][3], const bf16x8 (&B)[3], auto ppc, auto cvt, int unit) {
+    constexpr int PP = decltype(ppc)::value;
+    constexpr bool CV = decltype(cvt)::value;
+    constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
+    constexpr int NM = 6 * Q;
+    constexpr int G = NM / 6;                       // MFMAs between slices
+    const int r = unit >> 2, jp = unit & 3;
+    float v0 = 0.f, v1 = 0.f;
+    floatx2 vv = {0.f, 0.f};
+    bf16x2 h0 = {}, h1 = {}, h2 = {};
+    auto mf = [&](int i) {
+      const int pr = i / Q, q = i - pr * Q;
+      acc[PP][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[q][TA[pr]], B[TB[pr]], acc[PP][q], 0, 0, 0);
+    };
+    auto pro = [&](int j) {
+      const float t = BNB ? sc_pro_bnbwd(xv[r][j], av[BNB ? r : 0][j], cs0[j], cs1[j], cs2[j], cs3[j], cs4[j], slo, shi)
+                          : sc_pro_affine(xv[r][j], cs0[j], cs1[j], slo, shi);
+      return (((inb >> r) & 1u) && j < nch) ? t : 0.f;
+    };
 #pragma unroll
-      for (int pp = 0; pp < 2; ++pp) {
-        bf16x8 B[3];
-        const int e = (2 * wave + pp + kh) * PC + l31 + kw;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) B[c] = __builtin_bit_cast(bf16x8, s_p[c][lhi][e]);
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-          floatx16 d = acc[pp][q];
-          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[q][1], B[1], d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[q][2], B[0], d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[q][0], B[2], d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[q][1], B[0], d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[q][0], B[1], d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[q][0], B[0], d, 0, 0, 0);
-          acc[pp][q] = d;
+    for (int i = 0; i < NM; ++i) {
+      mf(i);
+      if (CV && (i + 1) % G == 0 && i + 1 < NM) {
+        const int sl = (i + 1) / G - 1;             // 0..4
+        __builtin_amdgcn_sched_barrier(0);
+        if (sl == 0) v0 = pro(2 * jp);
+        if (sl == 1) v1 = pro(2 * jp + 1);
+        if (sl == 2) { vv = (floatx2){v0, v1}; h0 = __builtin_convertvector(vv, bf16x2); vv -= __builtin_convertvector(h0, floatx2); }
+        if (sl == 3) { h1 = __builtin_convertvector(vv, bf16x2); vv -= __builtin_convertvector(h1, floatx2); }
+        if (sl == 4) {
+          h2 = __builtin_convertvector(vv, bf16x2);
+          pt[r][0][jp] = __builtin_bit_cast(unsigned, h0);
+          pt[r][1][jp] = __builtin_bit_cast(unsigned, h1);
+          pt[r][2][jp] = __builtin_bit_cast(unsigned, h2);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
+  // conversion units 6*cv .. 6*cv+5 ride along with the six steps of a filter row
+  auto compute = [&](int kh, int buf, auto cvt, int cv) {
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    bf16x8 A0[Q][3], A1[Q][3], B0[3], B1[3];
+    load_A(A0, buf, 0); load_B(B0, kh, 0, 0);
+    load_B(B1, kh, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    step(A0, B0, P0{}, cvt, 6 * cv + 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_A(A1, buf, 1); load_B(B0, kh, 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    step(A0, B1, P1{}, cvt, 6 * cv + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_B(B1, kh, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    step(A1, B0, P0{}, cvt, 6 * cv + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    load_A(A0, buf, 2); load_B(B0, kh, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    step(A1, B1, P1{}, cvt, 6 * cv + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    load_B(B1, kh, 2, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    step(A0, B0, P0{}, cvt, 6 * cv + 4);
+    __builtin_amdgcn_sched_barrier(0);
+    step(A0, B1, P1{}, cvt, 6 * cv + 5);
+  };
+#undef SC_BX3_MFMAS
+#undef SC_BX3_STEP
 
-  // ---- pipeline ----
+  // ---- pipeline: filters double-buffered per filter row, patch single-buffered with register prefetch ----
   select_chunk(0);
 #pragma unroll
   for (int r = 0; r < NR; ++r) load_round(r);
   load_w(0);
+  load_consts();
+#pragma unroll
+  for (int u = 0; u < 12; ++u) convert_unit(u >> 2, u & 3);
   store_patch();
   store_w(0);
   __syncthreads();
   const int nst = 3 * nk;
+  auto stage = [&](int s, int kh, auto cvt, int cv) {
+    load_w(s + 1 < nst ? s + 1 : s);          // the last stage reloads itself (unused)
+    compute(kh, s & 1, cvt, cv);
+    store_w((s + 1) & 1);
+    __syncthreads();
+  };
   for (int kc = 0; kc < nk; ++kc) {
-    const bool more = (kc + 1) < nk;
-    if (more) select_chunk(kc + 1);
+    const int s = 3 * kc;
+    if (kc + 1 < nk) {
+      select_chunk(kc + 1);
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int s = 3 * kc + kh;
-      const bool next = (s + 1) < nst;
-      if (next) load_w(s + 1);
-      if (more) load_round(kh);
-      compute(kh, s & 1);
-      if (next) store_w((s + 1) & 1);
-      __syncthreads();
-    }
-    if (more) {
+      for (int r = 0; r < NR; ++r) load_round(r);        // the whole next patch: a chunk of MFMAs hides the HBM latency
+      load_consts();
+      stage(s, 0, std::false_type{}, 0);
+      if (BNB) {        // the longer BatchNorm-backward prologue does not fit the MFMA shadows (and the registers): convert after
+        stage(s + 1, 1, std::false_type{}, 0);
+        stage(s + 2, 2, std::false_type{}, 0);
+#pragma unroll
+        for (int u = 0; u < 12; ++u) convert_unit(u >> 2, u & 3);
+      } else {
+        stage(s + 1, 1, std::true_type{}, 0);
+        stage(s + 2, 2, std::true_type{}, 1);
+      }
       store_patch();
       __syncthreads();
+    } else {
+      stage(s, 0, std::false_type{}, 0);
+      stage(s + 1, 1, std::false_type{}, 0);
+      stage(s + 2, 2, std::false_type{}, 0);
     }
   }
 
@@ -641,6 +724,7 @@ extern "C" int sc_conv3x3_bx3(const sc_conv_args* a, sc_stream stream) {
     SC_REQUIRE(a->src[s].mode == SC_SRC_RAW || a->src[s].cst != nullptr, "sc_conv3x3_bx3: source %d needs constants", s);
     SC_REQUIRE(a->src[s].mode != SC_SRC_NORM, "sc_conv3x3_bx3: NORM sources are the stem's");
     SC_REQUIRE(a->src[s].mode != SC_SRC_BNBWD || a->src[s].aux != nullptr, "sc_conv3x3_bx3: BNBWD source needs aux");
+    SC_REQUIRE(a->src[s].mode != SC_SRC_BNBWD || a->nsrc == 1, "sc_conv3x3_bx3: a BNBWD source cannot be part of a concat");
   }
   ConvXP p;
   p.s0 = to_srcd(a->src[0]);
@@ -651,8 +735,11 @@ extern "C" int sc_conv3x3_bx3(const sc_conv_args* a, sc_stream stream) {
   const int co_tiles = (a->Cout + a->co_t - 1) / a->co_t;
   dim3 grid(((a->W + 31) / 32) * ((a->H + 7) / 8), co_tiles, a->N);
   hipStream_t st = (hipStream_t)stream;
-  if (a->co_t == 64) hipLaunchKernelGGL((k_conv3_bx3<2>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((k_conv3_bx3<1>), grid, dim3(256), 0, st, p);
+  const bool bnb = a->src[0].mode == SC_SRC_BNBWD;
+  if (a->co_t == 64 && bnb) hipLaunchKernelGGL((k_conv3_bx3<2, true>), grid, dim3(256), 0, st, p);
+  else if (a->co_t == 64) hipLaunchKernelGGL((k_conv3_bx3<2, false>), grid, dim3(256), 0, st, p);
+  else if (bnb) hipLaunchKernelGGL((k_conv3_bx3<1, true>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((k_conv3_bx3<1, false>), grid, dim3(256), 0, st, p);
   SC_LAUNCH_OK("sc_conv3x3_bx3");
   return SC_OK;
 }
