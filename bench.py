@@ -21,6 +21,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense, MI355X_MICROARCH.md
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
@@ -161,14 +162,22 @@ def main():
         d = prof[fam]
         ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
         traffic, traffic_note = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_conv3.json")
-        if fam.startswith("k_conv_mfma<3>") and os.path.exists(pmc):
+        bx3 = "bx3" in fam
+        # k_conv3_bx3 / k_wgrad3_bx3 compute fp32-accurate products as 6 bf16 MFMAs: the ceiling for ALGORITHMIC flops is the
+        # dense bf16 MFMA peak / 6; the fp32-MFMA kernels are priced against the fp32 matrix peak.
+        peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if bx3 else FP32_MFMA_PEAK_TFLOPS
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_conv3_bx3.json" if bx3 else "r01_pmc_traffic_conv3.json")
+        if ("conv3" in fam or fam.startswith("k_conv_mfma<3>")) and os.path.exists(pmc):
             t = json.load(open(pmc))
             traffic = round(t["hbm_bytes_per_launch_raw"])
-            traffic_note = ("HBM bytes per launch of k_conv_mfma<3,*> from committed rocprofv3 PMC passes (FETCH_SIZE raw + WRITE_SIZE, "
+            traffic_note = (f"HBM bytes per launch of {t['kernel_pattern']}* from committed rocprofv3 PMC passes (FETCH_SIZE raw + WRITE_SIZE, "
                             "KiB->bytes; 4 B/lane loads: the gfx950 2x FETCH correction for 16 B/lane streams is not applied)")
-        roof = {"kernel": fam, "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+        roof = {"kernel": fam, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
+                "peak_note": ("fp32-equivalent ceiling of the three-term split: dense bf16 MFMA peak 2500 TFLOP/s / 6 products; "
+                              f"the kernel executes {round(6 * ach, 1)} bf16 TFLOP/s on the matrix cores; "
+                              f"{round(ach / FP32_MFMA_PEAK_TFLOPS, 3)} x the fp32 MFMA peak of {FP32_MFMA_PEAK_TFLOPS}") if bx3 else
+                             "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
                 "algorithmic_bytes_per_launch": round(d["bytes"] / d["n"]) if d.get("bytes") else None,
                 "algorithmic_flop_per_launch": round(d["flop"] / d["n"]),
                 "launches_per_step": d["n"] // 3, "avg_launch_ms": round(d["ms"] / d["n"], 4),
@@ -181,7 +190,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "configs[1]: HyperSTARCOP U-Net (smp.Unet mobilenet_v2, 4ch mag1c+RGB) train step "
-                                      "fwd+loss+bwd+Adam, 512x512 tiles, fp32 HIP kernels",
+                                      "fwd+loss+bwd+Adam, 512x512 tiles, fp32 HIP kernels (3x3 convs: fp32 via exact 3-term bf16 split on the bf16 MFMA)",
                           "batch_per_gpu": B, "global_batch": B * world, "tile": [4, T, T],
                           "parallelism": f"dp{world}", "hipgraph": graph is not None, "final_loss": round(loss, 6)},
                "roofline": roof}

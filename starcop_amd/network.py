@@ -417,7 +417,7 @@ class HyperStarcopUNet(nn.Module):
             if self.profile is not None:
                 if ty in ("pw", "conv3"):
                     src_elems = sum(t.C * (H >> t.shift) * (W >> t.shift) for t in op["ins"])
-                    tok = self._pb(f"k_conv_mfma<{conv.kernel_size[0]}> (fwd+dgrad)",
+                    tok = self._pb("k_conv3_bx3 (fwd+dgrad)" if self._wpk[i]["bx3_f"] else f"k_conv_mfma<{conv.kernel_size[0]}> (fwd+dgrad)",
                                    2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * conv.kernel_size[0] ** 2,
                                    4.0 * (N * src_elems + N * o.C * Ho * Wo + conv.weight.numel()))
                 else:
@@ -590,9 +590,9 @@ class HyperStarcopUNet(nn.Module):
             wa.part = plan.ws.data_ptr(); wa.part_floats = plan.ws_floats
             wa.dw = gv(conv.weight).data_ptr()
             flop = 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * ks * ks
-            tok = self._pb(f"k_wgrad_mfma<{ks}> (+reduce)", flop)
             wfn = (lib.sc_conv3x3_wgrad_bx3 if (self.split_bf16 and ks == 3 and conv.out_channels >= 32 and conv.in_channels > 32)
                    else lib.sc_conv2d_wgrad_mfma)     # its cin tile is 64 wide: 32 -> 32 layers stay on the fp32 MFMA
+            tok = self._pb("k_wgrad3_bx3 (+reduce)" if wfn is lib.sc_conv3x3_wgrad_bx3 else f"k_wgrad_mfma<{ks}> (+reduce)", flop)
             wgrad_launch(lambda sx, wfn=wfn, wa=wa: check(wfn(C.byref(wa), sx)))
             self._pe(tok)
             # data gradient
@@ -609,7 +609,7 @@ class HyperStarcopUNet(nn.Module):
             a.add0 = None; a.add1 = None; a.stats = None
             a.accum0 = a.accum1 = 0
             # algorithmic bytes of the data gradient: g and y of the output once each, the input gradient once, the filter
-            tok = self._pb(f"k_conv_mfma<{ks}> (fwd+dgrad)", flop,
+            tok = self._pb("k_conv3_bx3 (fwd+dgrad)" if ent["bx3_b"] else f"k_conv_mfma<{ks}> (fwd+dgrad)", flop,
                            4.0 * (2 * N * o.C * Ho * Wo + N * conv.in_channels * Ho * Wo + conv.weight.numel()))
             if op.get("up"):
                 t_up = ins[0]
