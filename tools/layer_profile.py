@@ -26,6 +26,6 @@ rows = sorted(prof.items(), key=lambda kv: -kv[1]["ms"])
 tot = sum(v["ms"] for v in prof.values()) / R
 print(f"total instrumented GPU time per step: {tot:.2f} ms (B={B}, {T}x{T})")
 print(f"{'op|family':60s} {'ms/step':>9s} {'TFLOP/s':>9s}")
-for k, v in rows[:70]:
+for k, v in rows:
     tf = v["flop"] / (v["ms"] * 1e-3) / 1e12 if v["flop"] else 0.0
     print(f"{k:60s} {v['ms']/R:9.3f} {tf:9.1f}")
