@@ -49,7 +49,8 @@ enum sc_act { SC_ACT_NONE = 0, SC_ACT_RELU = 1, SC_ACT_RELU6 = 2 };
 #define SC_CST 8          /* floats of per-channel constants per channel            */
 /* BatchNorm statistics are written as per-work-group partial rows [rows][C][2] (plain stores, no atomics,
  * deterministic) and summed in fp64 by sc_bn_finalize / sc_bn_bwd_finalize.  rows = sc_stat_rows(kind, ...) */
-enum sc_stat_kind { SC_STAT_CONV3 = 0, SC_STAT_CONV1 = 1, SC_STAT_DW = 2, SC_STAT_STEM = 3, SC_STAT_BNBWD = 4 };
+enum sc_stat_kind { SC_STAT_CONV3 = 0, SC_STAT_CONV1 = 1, SC_STAT_DW = 2, SC_STAT_STEM = 3, SC_STAT_BNBWD = 4,
+                    SC_STAT_CONV1K = 5 /* sc_conv1x1_ksplit: one row per 32 pixels */ };
 
 typedef struct sc_src {
   const float* x;    /* primary tensor  [N, C, H>>up, W>>up]                          */
@@ -104,6 +105,11 @@ typedef struct sc_conv_args {
   float* stats;          /* [rows][Cout][2] partial sums or NULL                 */
 } sc_conv_args;
 int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream);
+/* 1x1 convolution for few-pixel / long-K layers (the <= 64^2 inverted-residual projections and the data gradients of the
+ * expansions): 32-pixel tiles, the four waves of a work-group split K, operands go global -> registers -> MFMA (no LDS
+ * staging).  Same arguments as sc_conv2d_mfma with ks = 1, nsrc = 1 and sc_pack_weights(ks=1) filters; co_t in {32, 64};
+ * statistics rows = sc_stat_rows(SC_STAT_CONV1K, N, H, W). */
+int sc_conv1x1_ksplit(const sc_conv_args* a, sc_stream stream);
 
 /* The same 3x3 convolution (forward, or backward-data with transpose_flip-packed filters) with fp32 accuracy on the
  * bf16 matrix cores: every fp32 operand is split exactly into three bf16 terms while it is staged and the six partial

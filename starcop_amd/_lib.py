@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libstarcop_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 SC_CST = 8
-STAT_CONV3, STAT_CONV1, STAT_DW, STAT_STEM, STAT_BNBWD = 0, 1, 2, 3, 4
+STAT_CONV3, STAT_CONV1, STAT_DW, STAT_STEM, STAT_BNBWD, STAT_CONV1K = 0, 1, 2, 3, 4, 5
 
 SRC_RAW, SRC_AFFINE, SRC_BNBWD, SRC_NORM = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
@@ -68,6 +68,7 @@ SIGNATURES = {
     "sc_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sc_packed_weight_floats": (_sz, [_i, _i, _i, _i, _i]),
     "sc_conv2d_mfma": (_i, [C.POINTER(sc_conv_args), _vp]),
+    "sc_conv1x1_ksplit": (_i, [C.POINTER(sc_conv_args), _vp]),
     "sc_wgrad_bx3_workspace_floats": (_sz, [_i, _i, _i, _i, _i]),
     "sc_conv3x3_wgrad_bx3": (_i, [C.POINTER(sc_wgrad_args), _vp]),
     "sc_pack_weights_bx3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -418,6 +418,120 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma16(const ConvP p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Pointwise (1x1) convolution for the low-resolution layers: few pixels, long K (Cin up to 1280).  The 128-pixel tiles of
+// k_conv_mfma<1> leave most CUs idle there (N*H*W/128 x Cout/64 work-groups, each walking all of K serially).  Here a
+// work-group owns 32 pixels x (32*RM) couts and its four waves split K (chunk kc -> wave kc & 3).  Nothing is shared
+// between the waves, so there is no LDS staging and no barrier in the K loop: the MFMA operand layouts ARE coalesced global
+// reads (B: 32 consecutive pixels of channel 2cp+(l>>5); A: 32 consecutive couts of the packed filter row), prologue in
+// registers, next chunk prefetched.  The four partial accumulators are summed through LDS, then the usual epilogue;
+// statistics rows are per 32-pixel tile (SC_STAT_CONV1K).
+template <int RM, bool BNB>
+__global__ __launch_bounds__(256, 2) void k_conv1_ksplit(const ConvP p) {
+  constexpr int CO_T = 32 * RM, KC = 16, PS = 33;
+  __shared__ float s_acc[4][CO_T * PS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int n = blockIdx.z, cot = blockIdx.y;
+  const int HW = p.H * p.W;
+  const int p0 = blockIdx.x * 32;
+  const int Cin = p.s0.C;
+  const int nk = (Cin + KC - 1) / KC;
+  const float* wbase = p.wpk + (size_t)cot * nk * KC * CO_T;
+  const int pix = p0 + l31;
+  const bool pok = pix < HW;
+  const float* xb = p.s0.x + (size_t)n * Cin * HW + (pok ? pix : 0);
+  const float* ab = BNB ? p.s0.aux + (size_t)n * Cin * HW + (pok ? pix : 0) : nullptr;
+  const float* cst = (p.s0.mode != SC_SRC_RAW) ? p.s0.cst : nullptr;
+  const float lo = sc_act_lo(p.s0.act), hi = sc_act_hi(p.s0.act);
+
+  floatx16 acc[RM];
+#pragma unroll
+  for (int m = 0; m < RM; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+  float bx[8], by[BNB ? 8 : 1], wa[8][RM];
+  float4 c0[8]; float c4[BNB ? 8 : 1];
+  auto load_chunk = [&](int kc) {
+#pragma unroll
+    for (int cp = 0; cp < 8; ++cp) {
+      const int ci = kc * KC + 2 * cp + lhi;
+      const int cc = ci < Cin ? ci : 0;
+      bx[cp] = xb[(size_t)cc * HW];
+      if (BNB) by[cp] = ab[(size_t)cc * HW];
+      if (cst) {
+        if (BNB) { c0[cp] = *reinterpret_cast<const float4*>(cst + (size_t)cc * SC_CST); c4[cp] = cst[(size_t)cc * SC_CST + 4]; }
+        else { const float2 t = *reinterpret_cast<const float2*>(cst + (size_t)cc * SC_CST); c0[cp] = make_float4(t.x, t.y, 0.f, 0.f); }
+      } else {
+        c0[cp] = make_float4(1.f, 0.f, 0.f, 0.f);
+        if (BNB) c4[cp] = 0.f;
+      }
+#pragma unroll
+      for (int m = 0; m < RM; ++m) wa[cp][m] = wbase[(size_t)ci * CO_T + m * 32 + l31];     // filters are zero-padded to nk*16
+    }
+  };
+  int kc = wave;
+  if (kc < nk) load_chunk(kc);
+  while (kc < nk) {
+    float b[8], a[8][RM];
+#pragma unroll
+    for (int cp = 0; cp < 8; ++cp) {
+      const int ci = kc * KC + 2 * cp + lhi;
+      const float t = BNB ? sc_pro_bnbwd(bx[cp], by[BNB ? cp : 0], c0[cp].x, c0[cp].y, c0[cp].z, c0[cp].w, c4[BNB ? cp : 0], lo, hi)
+                          : sc_pro_affine(bx[cp], c0[cp].x, c0[cp].y, lo, hi);
+      b[cp] = (pok && ci < Cin) ? t : 0.f;
+#pragma unroll
+      for (int m = 0; m < RM; ++m) a[cp][m] = wa[cp][m];
+    }
+    const int kn = kc + 4;
+    if (kn < nk) load_chunk(kn);
+#pragma unroll
+    for (int cp = 0; cp < 8; ++cp)
+#pragma unroll
+      for (int m = 0; m < RM; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp][m], b[cp], acc[m], 0, 0, 0);
+    kc = kn;
+  }
+  // ---- sum the four K parts ----
+#pragma unroll
+  for (int m = 0; m < RM; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_acc[wave][(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * PS + l31] = acc[m][r];
+  __syncthreads();
+  const int px = tid & 31, cg = tid >> 5;
+  const int opix = p0 + px;
+  const bool ok_px = opix < HW;
+  const size_t HWs = (size_t)HW;
+  const size_t srow = (size_t)n * gridDim.x + blockIdx.x;
+#pragma unroll
+  for (int i = 0; i < CO_T / 8; ++i) {
+    const int col = cg + 8 * i;
+    const int co = cot * CO_T + col;
+    float v = s_acc[0][col * PS + px] + s_acc[1][col * PS + px] + s_acc[2][col * PS + px] + s_acc[3][col * PS + px];
+    const bool ok = ok_px && (co < p.Cout);
+    if (!ok) v = 0.f;
+    if (p.stats) {
+      const float s = half_sum32(v), ss = half_sum32(v * v);
+      if ((lane & 31) == SC_HALF_SUM_LANE && co < p.Cout) {
+        p.stats[(srow * p.Cout + co) * 2] = s;
+        p.stats[(srow * p.Cout + co) * 2 + 1] = ss;
+      }
+    }
+    if (ok) {
+      float* o; size_t idx; int accum;
+      if (co < p.csplit) {
+        idx = ((size_t)n * p.csplit + co) * HWs + opix; o = p.out0; accum = p.accum0;
+      } else {
+        idx = ((size_t)n * (p.Cout - p.csplit) + (co - p.csplit)) * HWs + opix; o = p.out1; accum = p.accum1;
+      }
+      if (p.add0) v += p.add0[idx];
+      if (p.add1) v += p.add1[idx];
+      if (accum) v += o[idx];
+      o[idx] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // weight packing
 __global__ void k_pack_weights(const float* __restrict__ w, float* __restrict__ wpk, int Cout, int Cin,
                                int taps, int co_t, int tflip, int Kpad, size_t total) {
@@ -970,6 +1084,33 @@ extern "C" int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream) {
   else if (a->co_t == 64) hipLaunchKernelGGL((k_conv_mfma<1, 2>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((k_conv_mfma<1, 1>), grid, dim3(256), 0, st, p);
   SC_LAUNCH_OK("sc_conv2d_mfma");
+  return SC_OK;
+}
+
+extern "C" int sc_conv1x1_ksplit(const sc_conv_args* a, sc_stream stream) {
+  SC_REQUIRE(a != nullptr, "sc_conv1x1_ksplit: null args");
+  SC_REQUIRE(a->ks == 1 && a->nsrc == 1, "sc_conv1x1_ksplit: ks must be 1 with a single source");
+  SC_REQUIRE(a->co_t == 32 || a->co_t == 64, "sc_conv1x1_ksplit: co_t must be 32 or 64 (got %d)", a->co_t);
+  SC_REQUIRE(a->src[0].C > 0 && a->src[0].up == 0, "sc_conv1x1_ksplit: bad source");
+  SC_REQUIRE(a->src[0].mode != SC_SRC_NORM, "sc_conv1x1_ksplit: NORM sources are the stem's");
+  SC_REQUIRE(a->src[0].mode == SC_SRC_RAW || a->src[0].cst != nullptr, "sc_conv1x1_ksplit: source needs constants");
+  SC_REQUIRE(a->src[0].mode != SC_SRC_BNBWD || a->src[0].aux != nullptr, "sc_conv1x1_ksplit: BNBWD source needs aux");
+  SC_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->Cout > 0, "sc_conv1x1_ksplit: bad shape");
+  SC_REQUIRE(a->csplit > 0 && a->csplit <= a->Cout, "sc_conv1x1_ksplit: bad csplit");
+  SC_REQUIRE(a->csplit == a->Cout || (a->add0 == nullptr && a->add1 == nullptr), "sc_conv1x1_ksplit: add tensors need a single output");
+  ConvP p;
+  p.s0 = to_srcd(a->src[0]); p.s1 = empty_srcd();
+  p.wpk = a->wpk; p.N = a->N; p.H = a->H; p.W = a->W; p.Cout = a->Cout;
+  p.out0 = a->out0; p.out1 = a->out1; p.csplit = a->csplit; p.accum0 = a->accum0; p.accum1 = a->accum1;
+  p.add0 = a->add0; p.add1 = a->add1; p.stats = a->stats;
+  dim3 grid((a->H * a->W + 31) / 32, (a->Cout + a->co_t - 1) / a->co_t, a->N);
+  hipStream_t st = (hipStream_t)stream;
+  const bool bnb = a->src[0].mode == SC_SRC_BNBWD;
+  if (a->co_t == 64 && bnb) hipLaunchKernelGGL((k_conv1_ksplit<2, true>), grid, dim3(256), 0, st, p);
+  else if (a->co_t == 64) hipLaunchKernelGGL((k_conv1_ksplit<2, false>), grid, dim3(256), 0, st, p);
+  else if (bnb) hipLaunchKernelGGL((k_conv1_ksplit<1, true>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((k_conv1_ksplit<1, false>), grid, dim3(256), 0, st, p);
+  SC_LAUNCH_OK("sc_conv1x1_ksplit");
   return SC_OK;
 }
 

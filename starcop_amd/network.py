@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD,
-                   STAT_CONV1, STAT_CONV3, STAT_DW, STAT_STEM, check, make_src, ptr, sc_conv_args, sc_wgrad_args, stream)
+                   STAT_CONV1, STAT_CONV1K, STAT_CONV3, STAT_DW, STAT_STEM, check, make_src, ptr, sc_conv_args, sc_wgrad_args, stream)
 
 MBV2_SETTINGS = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2),
                  (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1))
@@ -105,6 +105,15 @@ def _pick_cot(M, ks=1):
         return 32
     p32, p64 = -(-M // 32) * 32, -(-M // 64) * 64
     return 64 if p64 <= p32 * 1.15 else 32
+
+
+def _use_ksplit(N, HW, K, M, ks=1):
+    """1x1 layers with few pixels and long K: the split-K kernel (sc_conv1x1_ksplit) beats the 128-pixel tiles when
+    those leave most CUs idle (measured crossover, tools/bench_pw.py)."""
+    if ks != 1:
+        return False
+    wgs = N * (-(-HW // 128)) * (-(-M // _pick_cot(M, 1)))
+    return wgs <= 512 and (K >= 384 or (K >= 192 and wgs <= 256))
 
 
 class HyperStarcopUNet(nn.Module):
@@ -293,7 +302,10 @@ class HyperStarcopUNet(nn.Module):
                 if t.bn is not None:
                     Ho, Wo = H >> t.shift, W >> t.shift
                     # per-work-group partial rows [rows][C][2] (plain stores; summed in fp64 by the finalize kernels)
-                    plan.srows[t.name] = lib.sc_stat_rows(kind_of[op["type"]], N, Ho, Wo)
+                    kind = kind_of[op["type"]]
+                    if op["type"] == "pw" and _use_ksplit(N, Ho * Wo, op["conv"].in_channels, op["conv"].out_channels):
+                        kind = STAT_CONV1K
+                    plan.srows[t.name] = lib.sc_stat_rows(kind, N, Ho, Wo)
                     plan.brows[t.name] = lib.sc_stat_rows(STAT_BNBWD, N, Ho, Wo)
                     plan.stats_v[t.name] = torch.empty(plan.srows[t.name] * t.C * 2, **f32)
                     plan.cst[t.name] = torch.zeros((t.C, SC_CST), **f32)
@@ -446,7 +458,13 @@ class HyperStarcopUNet(nn.Module):
                 a.csplit, a.accum0, a.accum1 = o.C, 0, 0
                 a.add0 = None; a.add1 = None
                 a.stats = plan.stats_v[o.name].data_ptr() if stats is not None else None
-                check((lib.sc_conv3x3_bx3 if ent["bx3_f"] else lib.sc_conv2d_mfma)(C.byref(a), st))
+                if ent["bx3_f"]:
+                    fconv = lib.sc_conv3x3_bx3
+                elif _use_ksplit(N, Ho * Wo, conv.in_channels, conv.out_channels, a.ks):
+                    fconv = lib.sc_conv1x1_ksplit
+                else:
+                    fconv = lib.sc_conv2d_mfma
+                check(fconv(C.byref(a), st))
             elif ty == "add":
                 sa = self._src_of(plan, op["ins"][0])
                 sb = self._src_of(plan, op["ins"][1])
@@ -605,7 +623,12 @@ class HyperStarcopUNet(nn.Module):
             a.wpk = ent["b"].data_ptr()
             a.N, a.H, a.W, a.Cout = N, Ho, Wo, conv.in_channels
             a.ks, a.co_t = ks, ent["cot_b"]
-            conv_dgrad = lib.sc_conv3x3_bx3 if ent["bx3_b"] else lib.sc_conv2d_mfma
+            if ent["bx3_b"]:
+                conv_dgrad = lib.sc_conv3x3_bx3
+            elif _use_ksplit(N, Ho * Wo, conv.out_channels, conv.in_channels, ks):
+                conv_dgrad = lib.sc_conv1x1_ksplit
+            else:
+                conv_dgrad = lib.sc_conv2d_mfma
             a.add0 = None; a.add1 = None; a.stats = None
             a.accum0 = a.accum1 = 0
             # algorithmic bytes of the data gradient: g and y of the output once each, the input gradient once, the filter

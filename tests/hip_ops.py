@@ -4,7 +4,7 @@ import ctypes as C
 import torch
 
 from starcop_amd import _lib
-from starcop_amd._lib import (ACT_NONE, SC_CST, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_CONV1, STAT_CONV3, check,
+from starcop_amd._lib import (ACT_NONE, SC_CST, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_CONV1, STAT_CONV1K, STAT_CONV3, check,
                               make_src, ptr, sc_conv_args, sc_wgrad_args, stream)
 
 DEV = "cuda"
@@ -42,7 +42,7 @@ def pack_bx3(w, co_t, tflip):
 
 
 def conv_mfma(srcs, wpk, N, H, W, Cout, ks, co_t, want_stats=False, csplit=None, add0=None, add1=None,
-              accum=None, outs=None, bx3=False):
+              accum=None, outs=None, bx3=False, ksplit=False):
     lib = _lib.load()
     a = sc_conv_args()
     a.nsrc = len(srcs)
@@ -61,10 +61,11 @@ def conv_mfma(srcs, wpk, N, H, W, Cout, ks, co_t, want_stats=False, csplit=None,
     a.accum0, a.accum1 = (accum or (0, 0))
     a.add0 = add0.data_ptr() if add0 is not None else None
     a.add1 = add1.data_ptr() if add1 is not None else None
-    rows = lib.sc_stat_rows(STAT_CONV3 if ks == 3 else STAT_CONV1, N, H, W)
+    rows = lib.sc_stat_rows(STAT_CONV3 if ks == 3 else (STAT_CONV1K if ksplit else STAT_CONV1), N, H, W)
     stats = torch.full((rows, Cout, 2), float("nan"), device=DEV) if want_stats else None      # every entry must be written
     a.stats = stats.data_ptr() if want_stats else None
-    check((lib.sc_conv3x3_bx3 if bx3 else lib.sc_conv2d_mfma)(C.byref(a), stream()))
+    fn = lib.sc_conv3x3_bx3 if bx3 else (lib.sc_conv1x1_ksplit if ksplit else lib.sc_conv2d_mfma)
+    check(fn(C.byref(a), stream()))
     return outs, stats
 
 

@@ -90,6 +90,43 @@ def test_conv_dgrad_bnbwd_split_add(hip, ks, cin, cout, H, W):
     assert relerr(outs[0], ref[:, :cs]) < TOL and relerr(outs[1], ref[:, cs:]) < TOL
 
 
+@pytest.mark.parametrize("cin,cout,co_t,H,W", [(384, 64, 64, 8, 8), (960, 160, 64, 4, 4), (576, 96, 32, 8, 6), (24, 144, 32, 10, 13), (1280, 320, 64, 2, 3), (40, 8, 32, 5, 7)])
+def test_conv1x1_ksplit(hip, cin, cout, co_t, H, W):
+    """low-resolution pointwise layers: 32-pixel tiles, K split over the four waves; forward (affine + stats) and dgrad epilogues"""
+    N = 2
+    x, w = rnd(N, cin, H, W, seed=1), rnd(cout, cin, 1, 1, seed=2, scale=0.2)
+    sc, sh = rnd(cin, seed=3) * 0.5 + 1.0, rnd(cin, seed=4) * 0.3
+    ref = F.conv2d(F.relu6(x * sc[None, :, None, None] + sh[None, :, None, None]), w)
+    src = make_src(dev(x), cin, SRC_AFFINE, act=ACT_RELU6, cst=cst_affine(sc, sh))
+    wpk = pack(dev(w), co_t, 0)
+    (out,), stats = conv_mfma([src], wpk, N, H, W, cout, 1, co_t, want_stats=True, ksplit=True)
+    assert relerr(out, ref) < TOL
+    st = stats.double().sum(0).cpu()
+    assert relerr(st[:, 0], ref.double().sum((0, 2, 3))) < 1e-4
+    assert relerr(st[:, 1], (ref.double() ** 2).sum((0, 2, 3))) < 1e-4
+    # raw source
+    (out,), _ = conv_mfma([make_src(dev(x), cin, SRC_RAW)], wpk, N, H, W, cout, 1, co_t, ksplit=True)
+    assert relerr(out, F.conv2d(x, w)) < TOL
+    # backward-data form: BNBWD source, transposed filter, residual add + accumulate, channel split
+    g, y = rnd(N, cout, H, W, seed=5), rnd(N, cout, H, W, seed=6)
+    a, b = rnd(cout, seed=7) * 0.2 + 1, rnd(cout, seed=8) * 0.2
+    A, B, D = rnd(cout, seed=9), rnd(cout, seed=10) * 0.1, rnd(cout, seed=11) * 0.1
+    yh = y * a[None, :, None, None] + b[None, :, None, None]
+    dy = torch.where((yh > 0) & (yh < 6), g, torch.zeros(())) * A[None, :, None, None] + B[None, :, None, None] * y + D[None, :, None, None]
+    refb = F.conv_transpose2d(dy, w)
+    cst = torch.zeros(cout, SC_CST); cst[:, 0], cst[:, 1], cst[:, 2], cst[:, 3], cst[:, 4] = a, b, A, B, D
+    srcb = make_src(dev(g), cout, SRC_BNBWD, act=ACT_RELU6, cst=dev(cst), aux=dev(y))
+    cb = 32 if cin <= 32 else 64
+    wb = pack(dev(w), cb, 1)
+    add0, old = rnd(N, cin, H, W, seed=12), rnd(N, cin, H, W, seed=13)
+    o = dev(old).clone()
+    conv_mfma([srcb], wb, N, H, W, cin, 1, cb, add0=dev(add0), accum=(1, 0), outs=[o], ksplit=True)
+    assert relerr(o, refb + add0 + old) < TOL
+    cs = 8
+    outs, _ = conv_mfma([srcb], wb, N, H, W, cin, 1, cb, csplit=cs, ksplit=True)
+    assert relerr(outs[0], refb[:, :cs]) < TOL and relerr(outs[1], refb[:, cs:]) < TOL
+
+
 # ---- split-bf16 (three-term) 3x3 convolution: fp32 accuracy on the bf16 matrix cores -------------------------------
 BX3_TOL = 1e-5      # vs an fp64 reference; each case is also required to be no worse than 3x the fp32 MFMA kernel's error
 
