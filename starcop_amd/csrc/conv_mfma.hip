@@ -1168,7 +1168,7 @@ extern "C" int sc_conv2d_wgrad_mfma(const sc_wgrad_args* a, sc_stream stream) {
 int sc_wgrad_finish(float* part, int nparts, int taps, int Cout, int Cin, int CoP, int CiP, float* dw, hipStream_t st) {
   const size_t E = (size_t)taps * CoP * CiP;
   const float* rows; int nrows;
-  int rc = sc_reduce_rows_partial(part, nparts, E, part + (size_t)nparts * E, &rows, &nrows, st);
+  int rc = sc_reduce_rows_partial(part, nparts, E, part + (size_t)nparts * E, &rows, &nrows, 64, st);
   if (rc != SC_OK) return rc;
   const size_t total = (size_t)taps * Cout * Cin;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);

@@ -292,10 +292,10 @@ size_t sc_reduce_scratch_floats(int nparts, size_t E) {
 }
 
 int sc_reduce_rows_partial(const float* part, int nparts, size_t E, float* scratch, const float** rows_out, int* nrows_out,
-                           hipStream_t st) {
+                           int max_rows, hipStream_t st) {
   const float* cur = part;
   int np = nparts;
-  while (np > 16) {
+  while (np > max_rows) {    // the caller's final kernel sums up to max_rows rows itself
     const int nn = (np + 15) / 16;
     hipLaunchKernelGGL(k_reduce16, dim3((unsigned)((E + 255) / 256), nn), dim3(256), 0, st, cur, np, E, scratch);
     SC_LAUNCH_OK("sc_reduce16");
@@ -307,7 +307,7 @@ int sc_reduce_rows_partial(const float* part, int nparts, size_t E, float* scrat
 
 int sc_reduce_rows(const float* part, int nparts, size_t E, float* scratch, float* out, hipStream_t st) {
   const float* cur; int np;
-  int rc = sc_reduce_rows_partial(part, nparts, E, scratch, &cur, &np, st);
+  int rc = sc_reduce_rows_partial(part, nparts, E, scratch, &cur, &np, 16, st);
   if (rc != SC_OK) return rc;
   hipLaunchKernelGGL(k_reduce16, dim3((unsigned)((E + 255) / 256), 1), dim3(256), 0, st, cur, np, E, out);
   SC_LAUNCH_OK("sc_reduce16(final)");

@@ -112,9 +112,9 @@ constexpr int SC_HALF_SUM_LANE = 16;
 // for the intermediate levels.  Defined in elementwise.hip.
 size_t sc_reduce_scratch_floats(int nparts, size_t E);
 int sc_reduce_rows(const float* part, int nparts, size_t E, float* scratch, float* out, hipStream_t st);
-// like sc_reduce_rows but leaves <= 16 rows for a caller-side final kernel: returns the pointer/row count
+// like sc_reduce_rows but leaves <= max_rows rows for a caller-side final kernel: returns the pointer/row count
 int sc_reduce_rows_partial(const float* part, int nparts, size_t E, float* scratch, const float** rows_out,
-                           int* nrows_out, hipStream_t st);
+                           int* nrows_out, int max_rows, hipStream_t st);
 
 // weight-gradient epilogue shared by the MFMA wgrad kernels (conv_mfma.hip): sums part[nparts][taps][CoP][CiP]
 // (reduction scratch of sc_reduce_scratch_floats(nparts, taps*CoP*CiP) floats follows the partials) into dw (OIHW)
