@@ -88,10 +88,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("STARCOP_BENCH_BACKEND", "nccl")       # "gloo": functional check of the N>1 path on a 1-GPU box
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)            # nccl == RCCL over xGMI on ROCm
+        else:
+            dist.init_process_group(backend)
 
     from starcop_amd import model_module as mm
     from starcop_amd.parallel import GradSync
@@ -142,7 +147,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = float(net._plans[(B, T, T)].loss_acc.item()) / (B * T * T)
@@ -153,7 +158,7 @@ def main():
         net.profile = {}
         overlap, net.overlap_wgrad = net.overlap_wgrad, False     # serial launches: a kernel's events bracket only itself
         for _ in range(3):
-            step()
+            model.fused_train_step(batch, opt, grad_sync=None)     # rank-local: the other ranks are past the timed region
         torch.cuda.synchronize()
         prof = net.collect_profile()
         net.profile, net.overlap_wgrad = None, overlap
@@ -194,7 +199,7 @@ def main():
                           "batch_per_gpu": B, "global_batch": B * world, "tile": [4, T, T],
                           "parallelism": f"dp{world}", "hipgraph": graph is not None, "final_loss": round(loss, 6)},
                "roofline": roof}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # reported at N=1 only (other ranks would idle at the exit barrier)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:

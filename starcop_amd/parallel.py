@@ -20,7 +20,13 @@ class GradSync:
     def __call__(self, flat_grads: torch.Tensor) -> float:
         """Sum ``flat_grads`` over ranks in place; returns the scale (1/world) the optimiser must apply."""
         if self.world > 1:
-            dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=self.group)
+            if flat_grads.is_cuda and dist.get_backend(self.group) == "gloo":
+                # functional path only (gloo has no device transport on ROCm): stage through the host
+                host = flat_grads.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                flat_grads.copy_(host)
+            else:
+                dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=self.group)      # RCCL, in place, compute stream
         return 1.0 / self.world
 
 
