@@ -78,6 +78,18 @@ int sc_pack_weights(const float* w_oihw, float* wpk, int Cout, int Cin, int ks,
                     int co_t, int transpose_flip, sc_stream stream);
 size_t sc_packed_weight_floats(int Cout, int Cin, int ks, int co_t, int transpose_flip);
 
+/* every filter pack of a network in one launch.  `descs` and `block_starts` (n entries: first 256-thread block of each
+ * descriptor, blocks = ceil(sc_pack_work_items / 256)) live in DEVICE memory and are built once by the caller;
+ * bx3 = 1 selects the sc_pack_weights_bx3 layout (ks must be 3). */
+typedef struct sc_pack_desc {
+  const float* w; float* wpk;
+  int32_t Cout, Cin, ks, co_t, transpose_flip, bx3;
+  uint64_t total;        /* = sc_pack_work_items(...) */
+} sc_pack_desc;
+size_t sc_pack_work_items(int Cout, int Cin, int ks, int co_t, int transpose_flip, int bx3);
+int sc_pack_weights_batch(const sc_pack_desc* descs_dev, const uint32_t* block_starts_dev, int n, uint32_t total_blocks,
+                          sc_stream stream);
+
 /* ------------------------------------------------------------------------- */
 /* dense conv (groups=1, stride 1, pad ks/2, ks in {1,3}) as implicit GEMM on fp32 MFMA.
  * Replaces torch.nn.functional.conv2d (+ cat + interpolate(nearest) + batch_norm + relu/relu6

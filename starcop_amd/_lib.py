@@ -67,6 +67,8 @@ SIGNATURES = {
     "sc_device_check": (_i, []),
     "sc_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sc_packed_weight_floats": (_sz, [_i, _i, _i, _i, _i]),
+    "sc_pack_work_items": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "sc_pack_weights_batch": (_i, [_vp, _vp, _i, C.c_uint32, _vp]),
     "sc_conv2d_mfma": (_i, [C.POINTER(sc_conv_args), _vp]),
     "sc_conv1x1_ksplit": (_i, [C.POINTER(sc_conv_args), _vp]),
     "sc_wgrad_bx3_workspace_floats": (_sz, [_i, _i, _i, _i, _i]),

@@ -683,6 +683,65 @@ WgradXPlan plan_wgrad_bx3(int N, int H, int W, int Cout, int Cin) {
   return pl;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// all filter packs of the network in ONE launch (88 tiny launches per step otherwise): block -> descriptor by binary search
+// over the block offsets, then the same index arithmetic as k_pack_weights (conv_mfma.hip) / k_pack_weights_bx3
+struct PackDesc {
+  const float* w; float* wpk;
+  int Cout, Cin, ks, co_t, tflip, bx3;
+  unsigned long long total;      // work items (fp32 layout: destination floats; bx3: destination bf16 per term)
+};
+static_assert(sizeof(PackDesc) == sizeof(sc_pack_desc), "sc_pack_desc layout");
+
+__global__ __launch_bounds__(256) void k_pack_batch(const PackDesc* __restrict__ descs, const unsigned* __restrict__ starts, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {                      // last descriptor whose first block <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (starts[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackDesc d = descs[lo];
+  const size_t i = (size_t)(blockIdx.x - starts[lo]) * 256 + threadIdx.x;
+  if (i >= d.total) return;
+  const int M = d.tflip ? d.Cin : d.Cout, K = d.tflip ? d.Cout : d.Cin;
+  const int taps = d.ks * d.ks;
+  if (!d.bx3) {
+    const int kc = d.ks == 3 ? 8 : 16;
+    const int Kpad = (K + kc - 1) / kc * kc;
+    const int col = (int)(i % d.co_t);
+    size_t r = i / d.co_t;
+    const int tap = (int)(r % taps); r /= taps;
+    const int k = (int)(r % Kpad);
+    const int m = (int)(r / Kpad) * d.co_t + col;
+    float v = 0.f;
+    if (m < M && k < K) v = d.tflip ? d.w[((size_t)k * M + m) * taps + (taps - 1 - tap)] : d.w[((size_t)m * K + k) * taps + tap];
+    d.wpk[i] = v;
+    return;
+  }
+  const int nchunk = (K + 15) / 16;
+  size_t r = i;
+  const int j = (int)(r % 8); r /= 8;
+  const int col = (int)(r % d.co_t); r /= d.co_t;
+  const int half = (int)(r % 2); r /= 2;
+  const int kw = (int)(r % 3); r /= 3;
+  const int kh = (int)(r % 3); r /= 3;
+  const int chunk = (int)(r % nchunk);
+  const int mt = (int)(r / nchunk);
+  const int m = mt * d.co_t + col, k = chunk * 16 + half * 8 + j, tap = kh * 3 + kw;
+  float v = 0.f;
+  if (m < M && k < K) v = d.tflip ? d.w[((size_t)k * M + m) * 9 + (8 - tap)] : d.w[((size_t)m * K + k) * 9 + tap];
+  const __bf16 t0 = (__bf16)v;
+  float rr = v - (float)t0;
+  const __bf16 t1 = (__bf16)rr;
+  rr -= (float)t1;
+  const __bf16 t2 = (__bf16)rr;
+  const size_t stage = ((size_t)mt * nchunk + chunk) * 3 + kh;
+  const __bf16 t[3] = {t0, t1, t2};
+  unsigned short* out = reinterpret_cast<unsigned short*>(d.wpk);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[((((stage * 3 + c) * 3 + kw) * 2 + half) * d.co_t + col) * 8 + j] = __builtin_bit_cast(unsigned short, t[c]);
+}
+
 }  // namespace
 
 extern "C" size_t sc_packed_weight_floats_bx3(int Cout, int Cin, int co_t, int transpose_flip) {
@@ -778,4 +837,21 @@ extern "C" int sc_conv3x3_wgrad_bx3(const sc_wgrad_args* a, sc_stream stream) {
   else hipLaunchKernelGGL((k_wgrad3_bx3<1>), grid, dim3(768), 0, st, p);
   SC_LAUNCH_OK("sc_conv3x3_wgrad_bx3");
   return sc_wgrad_finish(a->part, pl.nsl * pl.kp, 9, a->Cout, a->Cin, pl.CoP, pl.CiP, a->dw, st);
+}
+
+extern "C" size_t sc_pack_work_items(int Cout, int Cin, int ks, int co_t, int transpose_flip, int bx3) {
+  if (bx3) {
+    const int M = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
+    return (size_t)((M + co_t - 1) / co_t) * ((K + 15) / 16) * 9 * 2 * co_t * 8;
+  }
+  return sc_packed_weight_floats(Cout, Cin, ks, co_t, transpose_flip);
+}
+
+extern "C" int sc_pack_weights_batch(const sc_pack_desc* descs_dev, const uint32_t* block_starts_dev, int n, uint32_t total_blocks,
+                                     sc_stream stream) {
+  SC_REQUIRE(descs_dev && block_starts_dev && n > 0 && total_blocks > 0, "sc_pack_weights_batch: bad argument");
+  hipLaunchKernelGGL(k_pack_batch, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const PackDesc*>(descs_dev), block_starts_dev, n);
+  SC_LAUNCH_OK("sc_pack_weights_batch");
+  return SC_OK;
 }

@@ -379,14 +379,33 @@ class HyperStarcopUNet(nn.Module):
                            f=torch.empty(nf, dtype=torch.float32, device=dev),
                            b=torch.empty(nb, dtype=torch.float32, device=dev))
                 self._wpk[i] = ent
-            if ent["bx3_f"]:
-                check(lib.sc_pack_weights_bx3(ptr(conv.weight), ptr(ent["f"]), co, ci, ent["cot_f"], 0, st))
-            else:
-                check(lib.sc_pack_weights(ptr(conv.weight), ptr(ent["f"]), co, ci, ks, ent["cot_f"], 0, st))
-            if need_bwd and ent["bx3_b"]:
-                check(lib.sc_pack_weights_bx3(ptr(conv.weight), ptr(ent["b"]), co, ci, ent["cot_b"], 1, st))
-            elif need_bwd:
-                check(lib.sc_pack_weights(ptr(conv.weight), ptr(ent["b"]), co, ci, ks, ent["cot_b"], 1, st))
+                self._pack_tables = {}
+        # one launch for all packs: device-side descriptor table, built once per (need_bwd, parameter storage)
+        key = (bool(need_bwd), self._pflat.data_ptr())
+        tab = self._pack_tables.get(key) if hasattr(self, "_pack_tables") else None
+        if tab is None:
+            import numpy as np
+            dt = np.dtype([("w", "<u8"), ("wpk", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"), ("ks", "<i4"), ("co_t", "<i4"),
+                           ("tflip", "<i4"), ("bx3", "<i4"), ("total", "<u8")])
+            rows, starts, nblk = [], [], 0
+            for i, op in enumerate(self._ops):
+                if op["type"] not in ("pw", "conv3"):
+                    continue
+                conv, ent = op["conv"], self._wpk[i]
+                co, ci, ks = conv.out_channels, conv.in_channels, conv.kernel_size[0]
+                for tflip, buf, cot, bx in ((0, ent["f"], ent["cot_f"], ent["bx3_f"]), (1, ent["b"], ent["cot_b"], ent["bx3_b"])):
+                    if tflip and not need_bwd:
+                        continue
+                    total = lib.sc_pack_work_items(co, ci, ks, cot, tflip, int(bx))
+                    rows.append((conv.weight.data_ptr(), buf.data_ptr(), co, ci, ks, cot, tflip, int(bx), total))
+                    starts.append(nblk)
+                    nblk += -(-total // 256)
+            descs = torch.from_numpy(np.array(rows, dtype=dt).view(np.uint8).copy()).to(dev)
+            tab = (descs, torch.tensor(starts, dtype=torch.int32).to(dev), len(rows), nblk)
+            if not hasattr(self, "_pack_tables"):
+                self._pack_tables = {}
+            self._pack_tables[key] = tab
+        check(lib.sc_pack_weights_batch(ptr(tab[0]), ptr(tab[1]), tab[2], tab[3], st))
         self._pack_version = (ver, bool(need_bwd))
 
     # ------------------------------------------------------------------------------------------

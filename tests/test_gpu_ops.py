@@ -127,6 +127,28 @@ def test_conv1x1_ksplit(hip, cin, cout, co_t, H, W):
     assert relerr(outs[0], refb[:, :cs]) < TOL and relerr(outs[1], refb[:, cs:]) < TOL
 
 
+def test_pack_weights_batch(hip):
+    """one launch packs every layer: identical bytes to the per-layer entry points (fp32 and split-bf16 layouts, fwd and dgrad)"""
+    import numpy as np
+    lib = hip
+    cases = [(96, 16, 1, 32, 0, 0), (96, 16, 1, 32, 1, 0), (24, 40, 3, 32, 0, 0), (16, 32, 3, 16, 0, 0), (64, 152, 3, 64, 0, 1), (64, 152, 3, 64, 1, 1), (32, 80, 3, 32, 1, 1)]
+    dt = np.dtype([("w", "<u8"), ("wpk", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"), ("ks", "<i4"), ("co_t", "<i4"), ("tflip", "<i4"), ("bx3", "<i4"), ("total", "<u8")])
+    rows, starts, nblk, want, got = [], [], 0, [], []
+    for k, (co, ci, ks, cot, tf, bx) in enumerate(cases):
+        w = dev(rnd(co, ci, ks, ks, seed=k))
+        ref = pack_bx3(w, cot, tf) if bx else pack(w, cot, tf)
+        out = torch.full_like(ref, float("nan")); _ = dev  # noqa
+        want.append(ref); got.append(out)
+        total = lib.sc_pack_work_items(co, ci, ks, cot, tf, bx)
+        rows.append((w.data_ptr(), out.data_ptr(), co, ci, ks, cot, tf, bx, total)); starts.append(nblk); nblk += -(-total // 256)
+    descs = torch.from_numpy(np.array(rows, dtype=dt).view(np.uint8).copy()).to(DEV)
+    st_t = torch.tensor(starts, dtype=torch.int32).to(DEV)
+    check(lib.sc_pack_weights_batch(ptr(descs), ptr(st_t), len(rows), nblk, stream()))
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
 # ---- split-bf16 (three-term) 3x3 convolution: fp32 accuracy on the bf16 matrix cores -------------------------------
 BX3_TOL = 1e-5      # vs an fp64 reference; each case is also required to be no worse than 3x the fp32 MFMA kernel's error
 
