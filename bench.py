@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", type=int, default=1, help="1: weight gradients on a second HIP stream (default); 0: serial "
                     "launches (use for rocprofv3 per-kernel durations that match the roofline pass)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 (default, BASELINE configs[1], parity mode) | bf16: bf16 matrix math in the 3x3 convolutions (configs[3]-style)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step from a captured hipGraph (default: eager two-stream launches, measured faster)")
     args = ap.parse_args()
 
@@ -101,7 +103,7 @@ def main():
     from starcop_amd import model_module as mm
     from starcop_amd.parallel import GradSync
     torch.manual_seed(1234)                               # identical init on every rank
-    model = mm.ModelModule(mm.default_settings(pos_weight=1)).to(dev).train()
+    model = mm.ModelModule(mm.default_settings(pos_weight=1, precision=args.precision)).to(dev).train()
     opt = model.configure_optimizers()["optimizer"]
     B, T = args.batch, args.tile
     batch = synth_batch(B, T, T, 1234 + rank, dev)
@@ -170,7 +172,8 @@ def main():
         bx3 = "bx3" in fam
         # k_conv3_bx3 / k_wgrad3_bx3 compute fp32-accurate products as 6 bf16 MFMAs: the ceiling for ALGORITHMIC flops is the
         # dense bf16 MFMA peak / 6; the fp32-MFMA kernels are priced against the fp32 matrix peak.
-        peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if bx3 else FP32_MFMA_PEAK_TFLOPS
+        nprod = 1.0 if args.precision == "bf16" else 6.0
+        peak = BF16_MFMA_PEAK_TFLOPS / nprod if bx3 else FP32_MFMA_PEAK_TFLOPS
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_conv3_bx3.json" if bx3 else "r01_pmc_traffic_conv3.json")
         if ("conv3" in fam or fam.startswith("k_conv_mfma<3>")) and os.path.exists(pmc):
             t = json.load(open(pmc))
@@ -180,7 +183,7 @@ def main():
         roof = {"kernel": fam, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
                 "peak_note": ("fp32-equivalent ceiling of the three-term split: dense bf16 MFMA peak 2500 TFLOP/s / 6 products; "
-                              f"the kernel executes {round(6 * ach, 1)} bf16 TFLOP/s on the matrix cores; "
+                              f"the kernel executes {round(nprod * ach, 1)} bf16 TFLOP/s on the matrix cores; "
                               f"{round(ach / FP32_MFMA_PEAK_TFLOPS, 3)} x the fp32 MFMA peak of {FP32_MFMA_PEAK_TFLOPS}") if bx3 else
                              "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
                 "algorithmic_bytes_per_launch": round(d["bytes"] / d["n"]) if d.get("bytes") else None,
@@ -193,11 +196,12 @@ def main():
         tiles = world * B * args.steps
         out = {"metric": "512x512 hyperspectral tiles/sec (train fwd+bwd)", "value": round(tiles / elapsed, 2), "unit": "tiles/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
                "config": {"workload": "configs[1]: HyperSTARCOP U-Net (smp.Unet mobilenet_v2, 4ch mag1c+RGB) train step "
                                       "fwd+loss+bwd+Adam, 512x512 tiles, fp32 HIP kernels (3x3 convs: fp32 via exact 3-term bf16 split on the bf16 MFMA)",
                           "batch_per_gpu": B, "global_batch": B * world, "tile": [4, T, T],
-                          "parallelism": f"dp{world}", "hipgraph": graph is not None, "final_loss": round(loss, 6)},
+                          "parallelism": f"dp{world}", "hipgraph": graph is not None, "final_loss": round(loss, 6),
+                          "precision": args.precision},
                "roofline": roof}
         if not args.no_cpu_baseline and world == 1:       # reported at N=1 only (other ranks would idle at the exit barrier)
             out["cpu_baseline"] = cpu_baseline()

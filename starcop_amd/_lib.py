@@ -36,14 +36,14 @@ class sc_conv_args(C.Structure):
                 ("ks", C.c_int32), ("co_t", C.c_int32),
                 ("out0", C.c_void_p), ("out1", C.c_void_p),
                 ("csplit", C.c_int32), ("accum0", C.c_int32), ("accum1", C.c_int32),
-                ("add0", C.c_void_p), ("add1", C.c_void_p), ("stats", C.c_void_p)]
+                ("add0", C.c_void_p), ("add1", C.c_void_p), ("stats", C.c_void_p), ("terms", C.c_int32)]
 
 
 class sc_wgrad_args(C.Structure):
     _fields_ = [("dy", sc_src), ("src", sc_src * 2), ("nsrc", C.c_int32),
                 ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("Cout", C.c_int32), ("Cin", C.c_int32), ("ks", C.c_int32),
-                ("part", C.c_void_p), ("part_floats", C.c_size_t), ("dw", C.c_void_p)]
+                ("part", C.c_void_p), ("part_floats", C.c_size_t), ("dw", C.c_void_p), ("terms", C.c_int32)]
 
 
 class sc_mag1c_args(C.Structure):
@@ -73,8 +73,8 @@ SIGNATURES = {
     "sc_conv1x1_ksplit": (_i, [C.POINTER(sc_conv_args), _vp]),
     "sc_wgrad_bx3_workspace_floats": (_sz, [_i, _i, _i, _i, _i]),
     "sc_conv3x3_wgrad_bx3": (_i, [C.POINTER(sc_wgrad_args), _vp]),
-    "sc_pack_weights_bx3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "sc_packed_weight_floats_bx3": (_sz, [_i, _i, _i, _i]),
+    "sc_pack_weights_bx3": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sc_packed_weight_floats_bx3": (_sz, [_i, _i, _i, _i, _i]),
     "sc_conv3x3_bx3": (_i, [C.POINTER(sc_conv_args), _vp]),
     "sc_wgrad_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "sc_conv2d_wgrad_mfma": (_i, [C.POINTER(sc_wgrad_args), _vp]),

@@ -55,18 +55,20 @@ __device__ __forceinline__ void split3x2(float a, float b, unsigned& t0, unsigne
 }
 
 // BNB: the (single) source is a BatchNorm/activation-backward source (dgrad); otherwise affine/raw sources (forward)
-template <int Q, bool BNB>
+// NT : number of bf16 terms per operand: 3 = fp32-accurate (six products), 1 = plain bf16 operands (one product; the
+//      "bf16" precision mode of the network: bf16 matrix math, fp32 accumulation and fp32 tensors in HBM)
+template <int Q, bool BNB, int NT>
 __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP p) {
   constexpr int PR = 10, PC = 34, NPX = PR * PC;     // 8 output rows + halo
   constexpr bool PAD = (Q == 2);                     // Q = 1 keeps LDS under 53 KB (3 work-groups per CU) with guarded stores
   constexpr int NPXP = PAD ? 384 : NPX;              // padded: 3 staging rounds x 128 threads store unconditionally
   constexpr int CO_T = 32 * Q;
-  constexpr int WENT = 18 * CO_T;                    // 16-byte filter entries per (chunk, kh) stage
+  constexpr int WENT = 6 * NT * CO_T;                // 16-byte filter entries per (chunk, kh) stage
   constexpr int NWV = (WENT + 255) / 256;
   constexpr int WENTP = PAD ? NWV * 256 : WENT;      // padded likewise
   constexpr int NR = 3;
 
-  __shared__ uintx4 s_p[3][2][NPXP];
+  __shared__ uintx4 s_p[NT][2][NPXP];
   __shared__ uintx4 s_w[2][WENTP];
   __shared__ float s_red[4][CO_T][2];
 
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
   // prologue + three-term split of two channels (2jp, 2jp+1) of staging round r -> one dword of each term vector.
   // The twelve units of a chunk ride along with the MFMA steps of filter rows 1 and 2 (interleaved with them by
   // sched_group_barrier), so that only the LDS writes remain between the two barriers at the end of a chunk.
-  uintx4 pt[NR][3];
+  uintx4 pt[NR][NT];
   float cs0[8], cs1[8], cs2[8], cs3[8], cs4[8];         // per-channel constants of the chunk being staged
   auto load_consts = [&]() {
 #pragma unroll
@@ -164,15 +166,19 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
                           : sc_pro_affine(xv[r][j], cs0[j], cs1[j], slo, shi);
       v[h] = (((inb >> r) & 1u) && j < nch) ? t : 0.f;
     }
-    unsigned a, b, c;
-    split3x2(v[0], v[1], a, b, c);
-    pt[r][0][jp] = a; pt[r][1][jp] = b; pt[r][2][jp] = c;
+    unsigned t[3];
+    split3x2(v[0], v[1], t[0], t[1], t[2]);
+#pragma unroll
+    for (int c = 0; c < NT; ++c) pt[r][c][jp] = t[c];
   };
   auto store_patch = [&]() {
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int e = sidx + 128 * r;
-      if (PAD || e < NPX) { s_p[0][hw][e] = pt[r][0]; s_p[1][hw][e] = pt[r][1]; s_p[2][hw][e] = pt[r][2]; }
+      if (PAD || e < NPX) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c) s_p[c][hw][e] = pt[r][c];
+      }
     }
   };
   auto load_w = [&](int s) {
@@ -190,17 +196,17 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
   };
   // operand fetches of one step are issued before the 6*Q MFMAs of the previous step (explicit software pipeline: the
   // scheduler barrier keeps the LDS reads ~6*Q*32 cycles ahead of their use)
-  auto load_A = [&](bf16x8 (&A)[Q][3], int buf, int kw) {
+  auto load_A = [&](bf16x8 (&A)[Q][NT], int buf, int kw) {
 #pragma unroll
     for (int q = 0; q < Q; ++q)
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
+      for (int c = 0; c < NT; ++c)
         A[q][c] = __builtin_bit_cast(bf16x8, s_w[buf][((c * 3 + kw) * 2 + lhi) * CO_T + q * 32 + l31]);
   };
-  auto load_B = [&](bf16x8 (&B)[3], int kh, int kw, int pp) {
+  auto load_B = [&](bf16x8 (&B)[NT], int kh, int kw, int pp) {
     const int e = (2 * wave + pp + kh) * PC + l31 + kw;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) B[c] = __builtin_bit_cast(bf16x8, s_p[c][lhi][e]);
+    for (int c = 0; c < NT; ++c) B[c] = __builtin_bit_cast(bf16x8, s_p[c][lhi][e]);
   };
   // six partial products, cout blocks interleaved (independent accumulators back to back)
 #define SC_BX3_STEP(A, B, PP, TA, TB)                                                                              \
@@ -211,12 +217,12 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
   SC_BX3_STEP(A, B, PP, 0, 1) SC_BX3_STEP(A, B, PP, 0, 0)
   // One step = the 6*Q MFMAs of (A, B) into acc[PP][*] with, when CV, one conversion unit (r, jp) cut into five slices
   // that are pinned between the MFMAs by scheduler barriers: each slice (<= 7 VALU) issues in the shadow of one MFMA.
-  auto step = [&](const bf16x8 (&A)[Q][3], const bf16x8 (&B)[3], auto ppc, auto cvt, int unit) {
+  auto step = [&](const bf16x8 (&A)[Q][NT], const bf16x8 (&B)[NT], auto ppc, auto cvt, int unit) {
     constexpr int PP = decltype(ppc)::value;
-    constexpr bool CV = decltype(cvt)::value;
-    constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
-    constexpr int NM = 6 * Q;
-    constexpr int G = NM / 6;                       // MFMAs between slices
+    constexpr bool CV = decltype(cvt)::value && NT == 3;
+    constexpr int TA[6] = {NT == 3 ? 1 : 0, 2, 0, 1, 0, 0}, TB[6] = {NT == 3 ? 1 : 0, 0, 2, 0, 1, 0};
+    constexpr int NM = (NT == 3 ? 6 : 1) * Q;
+    constexpr int G = NM >= 6 ? NM / 6 : 1;         // MFMAs between slices
     const int r = unit >> 2, jp = unit & 3;
     float v0 = 0.f, v1 = 0.f;
     floatx2 vv = {0.f, 0.f};
@@ -243,8 +249,8 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
         if (sl == 4) {
           h2 = __builtin_convertvector(vv, bf16x2);
           pt[r][0][jp] = __builtin_bit_cast(unsigned, h0);
-          pt[r][1][jp] = __builtin_bit_cast(unsigned, h1);
-          pt[r][2][jp] = __builtin_bit_cast(unsigned, h2);
+          pt[r][NT > 1 ? 1 : 0][jp] = __builtin_bit_cast(unsigned, NT > 1 ? h1 : h0);
+          pt[r][NT > 2 ? 2 : 0][jp] = __builtin_bit_cast(unsigned, NT > 2 ? h2 : h0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
   auto compute = [&](int kh, int buf, auto cvt, int cv) {
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
-    bf16x8 A0[Q][3], A1[Q][3], B0[3], B1[3];
+    bf16x8 A0[Q][NT], A1[Q][NT], B0[NT], B1[NT];
     load_A(A0, buf, 0); load_B(B0, kh, 0, 0);
     load_B(B1, kh, 0, 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
       for (int r = 0; r < NR; ++r) load_round(r);        // the whole next patch: a chunk of MFMAs hides the HBM latency
       load_consts();
       stage(s, 0, std::false_type{}, 0);
-      if (BNB) {        // the longer BatchNorm-backward prologue does not fit the MFMA shadows (and the registers): convert after
+      if (BNB || NT == 1) {   // the longer BatchNorm-backward prologue does not fit the MFMA shadows (and the registers): convert after
         stage(s + 1, 1, std::false_type{}, 0);
         stage(s + 2, 2, std::false_type{}, 0);
 #pragma unroll
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
 
 // filters -> [co tile][chunk of 16 ci][kh][term][kw][ci half][co][8 ci] bf16; forward or transposed+flipped (dgrad)
 __global__ void k_pack_weights_bx3(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout, int Cin,
-                                   int co_t, int tflip, int nchunk, size_t total) {
+                                   int co_t, int tflip, int nchunk, int nt, size_t total) {
   const int M = tflip ? Cin : Cout, K = tflip ? Cout : Cin;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     size_t r = i;
@@ -404,9 +410,8 @@ __global__ void k_pack_weights_bx3(const float* __restrict__ w, unsigned short* 
     const __bf16 t2 = (__bf16)rr;
     const size_t stage = ((size_t)mt * nchunk + chunk) * 3 + kh;
     const __bf16 t[3] = {t0, t1, t2};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const size_t d = ((((stage * 3 + c) * 3 + kw) * 2 + half) * co_t + col) * 8 + j;
+    for (int c = 0; c < nt; ++c) {
+      const size_t d = ((((stage * nt + c) * 3 + kw) * 2 + half) * co_t + col) * 8 + j;
       wpk[d] = __builtin_bit_cast(unsigned short, t[c]);
     }
   }
@@ -432,18 +437,18 @@ struct WgradXP {
   int CoP, CiP;     // padded dims of the partial buffer
 };
 
-template <int WM>
+template <int WM, int NT>
 __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
-  constexpr int NT = 768;
+  constexpr int NTH = 768;
   constexpr int COT = 32 * WM, CIT = 64, NPAIR = 2 * WM, KP = 4 / NPAIR;
   constexpr int DYP = 72;              // dy pitch per cout in pixels (144 B: conflict-free 16-byte reads)
   constexpr int XRP = 40;              // input row pitch in pixels (34 used)
   constexpr int XCP = 4 * XRP + 8;     // input pitch per cin: 4 ring rows + pad (336 B: conflict-free)
-  constexpr int NDY = (COT * 32 + NT - 1) / NT;     // dy pixel pairs per thread per stage
-  constexpr int NXI = (2 * 17 * CIT + NT - 1) / NT; // input pixel pairs per thread per two rows
+  constexpr int NDY = (COT * 32 + NTH - 1) / NTH;     // dy pixel pairs per thread per stage
+  constexpr int NXI = (2 * 17 * CIT + NTH - 1) / NTH; // input pixel pairs per thread per two rows
 
-  __shared__ __attribute__((aligned(16))) unsigned s_dy[3][COT * DYP / 2];
-  __shared__ __attribute__((aligned(16))) unsigned s_x[3][CIT * XCP / 2];
+  __shared__ __attribute__((aligned(16))) unsigned s_dy[NT][COT * DYP / 2];
+  __shared__ __attribute__((aligned(16))) unsigned s_x[NT][CIT * XCP / 2];
   __shared__ __attribute__((aligned(16))) float s_ca[COT * SC_CST];
   __shared__ __attribute__((aligned(16))) float s_cb[CIT * 4];      // scale, shift, lo, hi per cin
 
@@ -456,11 +461,11 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
   const int H = p.H, W = p.W;
   const int C0 = p.s0.C;
 
-  for (int i = tid; i < COT * SC_CST; i += NT) {
+  for (int i = tid; i < COT * SC_CST; i += NTH) {
     const int ch = cot * COT + i / SC_CST;
     s_ca[i] = (p.dy.cst && p.dy.mode != SC_SRC_RAW && ch < p.Cout) ? p.dy.cst[(size_t)ch * SC_CST + (i % SC_CST)] : ((i % SC_CST) == 0 ? 1.f : 0.f);
   }
-  for (int i = tid; i < CIT; i += NT) {
+  for (int i = tid; i < CIT; i += NTH) {
     const int ch = cit * CIT + i;
     float sc = 1.f, sh = 0.f, lo = -__builtin_inff(), hi = __builtin_inff();
     if (ch < p.Cin) {
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
   auto dy_load = [&](int n, int y0, int x0) {
 #pragma unroll
     for (int k = 0; k < NDY; ++k) {
-      const int it = tid + NT * k;
+      const int it = tid + NTH * k;
       const int co = cot * COT + ((it >> 5) & (COT - 1)), row = (it >> 4) & 1, col = 2 * (it & 15);
       const int y = y0 + row, x = x0 + col;
       const bool okc = co < p.Cout && y < H;
@@ -515,7 +520,7 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
   auto dy_store = [&](int y0, int x0) {
 #pragma unroll
     for (int k = 0; k < NDY; ++k) {
-      const int it = tid + NT * k;
+      const int it = tid + NTH * k;
       const int col_l = (it >> 5) & (COT - 1), row = (it >> 4) & 1, col = 2 * (it & 15);
       const int y = y0 + row, x = x0 + col;
       const bool okc = (cot * COT + col_l < p.Cout) && y < H;
@@ -531,10 +536,13 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
       }
       v0 = (okc && x < W) ? v0 : 0.f;
       v1 = (okc && x + 1 < W) ? v1 : 0.f;
-      unsigned t0, t1, t2;
-      split3x2(v0, v1, t0, t1, t2);
+      unsigned t[3];
+      split3x2(v0, v1, t[0], t[1], t[2]);
       const int d = (col_l * DYP + row * 32 + col) >> 1;
-      if (it < COT * 32) { s_dy[0][d] = t0; s_dy[1][d] = t1; s_dy[2][d] = t2; }
+      if (it < COT * 32) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c) s_dy[c][d] = t[c];
+      }
     }
   };
 
@@ -543,7 +551,7 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
   auto x_load = [&](int n, int R, int x0) {
 #pragma unroll
     for (int k = 0; k < NXI; ++k) {
-      const int it = tid + NT * k;
+      const int it = tid + NTH * k;
       const int rc = it / 17, pr = it - rc * 17;
       const int rowi = rc & 1, cil = (rc >> 1) & (CIT - 1);
       const int chr = cit * CIT + cil;
@@ -563,7 +571,7 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
   auto x_store = [&](int R, int x0) {
 #pragma unroll
     for (int k = 0; k < NXI; ++k) {
-      const int it = tid + NT * k;
+      const int it = tid + NTH * k;
       const int rc = it / 17, pr = it - rc * 17;
       const int rowi = rc & 1, cil = (rc >> 1) & (CIT - 1);
       const int y = R + rowi, x = x0 - 1 + 2 * pr;
@@ -573,11 +581,14 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
       float v1 = sc_pro_affine(xr[k][1], c.x, c.y, c.z, c.w);
       v0 = (okc && x >= 0 && x < W) ? v0 : 0.f;
       v1 = (okc && x + 1 < W) ? v1 : 0.f;
-      unsigned t0, t1, t2;
-      split3x2(v0, v1, t0, t1, t2);
+      unsigned t[3];
+      split3x2(v0, v1, t[0], t[1], t[2]);
       const int slot = (y + 1) & 3;
       const int d = ((cil * XCP + slot * XRP) >> 1) + pr;
-      if (it < 2 * 17 * CIT) { s_x[0][d] = t0; s_x[1][d] = t1; s_x[2][d] = t2; }
+      if (it < 2 * 17 * CIT) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c) s_x[c][d] = t[c];
+      }
     }
   };
 
@@ -588,14 +599,14 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
       const int slot = (y0 + r + kh) & 3;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        bf16x8 A[3];
+        bf16x8 A[NT];
         const int da = ((wm * 32 + l31) * DYP + r * 32 + 16 * j + 8 * lhi) >> 1;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) A[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uintx4*>(&s_dy[t][da]));
+        for (int t = 0; t < NT; ++t) A[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uintx4*>(&s_dy[t][da]));
         const int dx = ((wn * 32 + l31) * XCP + slot * XRP + 16 * j + 8 * lhi) >> 1;
-        bf16x8 B[3][3];
+        bf16x8 B[3][NT];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < NT; ++t) {
           const uintx4 X0 = *reinterpret_cast<const uintx4*>(&s_x[t][dx]);
           const unsigned X1 = s_x[t][dx + 4];
           uintx4 S1, S2;
@@ -612,7 +623,8 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
 #define SC_BX3_STEP(TA, TB)                                                                                         \
   _Pragma("unroll") for (int kw = 0; kw < 3; ++kw)                                                                  \
       acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[TA], B[kw][TB], acc[kw], 0, 0, 0);
-        SC_BX3_STEP(1, 1) SC_BX3_STEP(2, 0) SC_BX3_STEP(0, 2) SC_BX3_STEP(1, 0) SC_BX3_STEP(0, 1) SC_BX3_STEP(0, 0)
+        if constexpr (NT == 3) { SC_BX3_STEP(1, 1) SC_BX3_STEP(2, 0) SC_BX3_STEP(0, 2) SC_BX3_STEP(1, 0) SC_BX3_STEP(0, 1) }
+        SC_BX3_STEP(0, 0)
 #undef SC_BX3_STEP
       }
     }
@@ -738,20 +750,20 @@ __global__ __launch_bounds__(256) void k_pack_batch(const PackDesc* __restrict__
   const size_t stage = ((size_t)mt * nchunk + chunk) * 3 + kh;
   const __bf16 t[3] = {t0, t1, t2};
   unsigned short* out = reinterpret_cast<unsigned short*>(d.wpk);
-#pragma unroll
-  for (int c = 0; c < 3; ++c) out[((((stage * 3 + c) * 3 + kw) * 2 + half) * d.co_t + col) * 8 + j] = __builtin_bit_cast(unsigned short, t[c]);
+  for (int c = 0; c < d.bx3; ++c) out[((((stage * d.bx3 + c) * 3 + kw) * 2 + half) * d.co_t + col) * 8 + j] = __builtin_bit_cast(unsigned short, t[c]);
 }
 
 }  // namespace
 
-extern "C" size_t sc_packed_weight_floats_bx3(int Cout, int Cin, int co_t, int transpose_flip) {
+extern "C" size_t sc_packed_weight_floats_bx3(int Cout, int Cin, int co_t, int transpose_flip, int terms) {
   const int M = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
   const size_t mt = (M + co_t - 1) / co_t, nchunk = (K + 15) / 16;
-  return mt * nchunk * 3 * 18 * (size_t)co_t * 4;     // 16-byte entries -> floats
+  return mt * nchunk * 3 * 6 * (size_t)(terms == 1 ? 1 : 3) * co_t * 4;     // 16-byte entries -> floats
 }
 
 extern "C" int sc_pack_weights_bx3(const float* w, float* wpk, int Cout, int Cin, int co_t, int transpose_flip,
-                                   sc_stream stream) {
+                                   int terms, sc_stream stream) {
+  SC_REQUIRE(terms == 1 || terms == 3, "sc_pack_weights_bx3: terms must be 1 or 3 (got %d)", terms);
   SC_REQUIRE(w && wpk && Cout > 0 && Cin > 0, "sc_pack_weights_bx3: bad argument");
   SC_REQUIRE(co_t == 32 || co_t == 64, "sc_pack_weights_bx3: co_t must be 32 or 64 (got %d)", co_t);
   SC_REQUIRE(((uintptr_t)wpk & 15) == 0, "sc_pack_weights_bx3: destination must be 16-byte aligned");
@@ -760,7 +772,7 @@ extern "C" int sc_pack_weights_bx3(const float* w, float* wpk, int Cout, int Cin
   const size_t total = (size_t)((M + co_t - 1) / co_t) * nchunk * 9 * 2 * co_t * 8;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(k_pack_weights_bx3, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
-                     reinterpret_cast<unsigned short*>(wpk), Cout, Cin, co_t, transpose_flip, nchunk, total);
+                     reinterpret_cast<unsigned short*>(wpk), Cout, Cin, co_t, transpose_flip, nchunk, terms, total);
   SC_LAUNCH_OK("sc_pack_weights_bx3");
   return SC_OK;
 }
@@ -795,10 +807,16 @@ extern "C" int sc_conv3x3_bx3(const sc_conv_args* a, sc_stream stream) {
   dim3 grid(((a->W + 31) / 32) * ((a->H + 7) / 8), co_tiles, a->N);
   hipStream_t st = (hipStream_t)stream;
   const bool bnb = a->src[0].mode == SC_SRC_BNBWD;
-  if (a->co_t == 64 && bnb) hipLaunchKernelGGL((k_conv3_bx3<2, true>), grid, dim3(256), 0, st, p);
-  else if (a->co_t == 64) hipLaunchKernelGGL((k_conv3_bx3<2, false>), grid, dim3(256), 0, st, p);
-  else if (bnb) hipLaunchKernelGGL((k_conv3_bx3<1, true>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((k_conv3_bx3<1, false>), grid, dim3(256), 0, st, p);
+  SC_REQUIRE(a->terms == 0 || a->terms == 1 || a->terms == 3, "sc_conv3x3_bx3: terms must be 0 (= 3), 1 or 3 (got %d)", a->terms);
+#define SC_LAUNCH_BX3(NT)                                                                                  \
+  do {                                                                                                     \
+    if (a->co_t == 64 && bnb) hipLaunchKernelGGL((k_conv3_bx3<2, true, NT>), grid, dim3(256), 0, st, p);   \
+    else if (a->co_t == 64) hipLaunchKernelGGL((k_conv3_bx3<2, false, NT>), grid, dim3(256), 0, st, p);    \
+    else if (bnb) hipLaunchKernelGGL((k_conv3_bx3<1, true, NT>), grid, dim3(256), 0, st, p);               \
+    else hipLaunchKernelGGL((k_conv3_bx3<1, false, NT>), grid, dim3(256), 0, st, p);                       \
+  } while (0)
+  if (a->terms == 1) SC_LAUNCH_BX3(1); else SC_LAUNCH_BX3(3);
+#undef SC_LAUNCH_BX3
   SC_LAUNCH_OK("sc_conv3x3_bx3");
   return SC_OK;
 }
@@ -833,8 +851,14 @@ extern "C" int sc_conv3x3_wgrad_bx3(const sc_wgrad_args* a, sc_stream stream) {
   p.nsl = pl.nsl; p.CoP = pl.CoP; p.CiP = pl.CiP;
   dim3 grid(pl.nsl, pl.ci_tiles, pl.co_tiles);
   hipStream_t st = (hipStream_t)stream;
-  if (pl.wm == 2) hipLaunchKernelGGL((k_wgrad3_bx3<2>), grid, dim3(768), 0, st, p);
-  else hipLaunchKernelGGL((k_wgrad3_bx3<1>), grid, dim3(768), 0, st, p);
+  SC_REQUIRE(a->terms == 0 || a->terms == 1 || a->terms == 3, "sc_conv3x3_wgrad_bx3: terms must be 0 (= 3), 1 or 3 (got %d)", a->terms);
+  if (a->terms == 1) {
+    if (pl.wm == 2) hipLaunchKernelGGL((k_wgrad3_bx3<2, 1>), grid, dim3(768), 0, st, p);
+    else hipLaunchKernelGGL((k_wgrad3_bx3<1, 1>), grid, dim3(768), 0, st, p);
+  } else {
+    if (pl.wm == 2) hipLaunchKernelGGL((k_wgrad3_bx3<2, 3>), grid, dim3(768), 0, st, p);
+    else hipLaunchKernelGGL((k_wgrad3_bx3<1, 3>), grid, dim3(768), 0, st, p);
+  }
   SC_LAUNCH_OK("sc_conv3x3_wgrad_bx3");
   return sc_wgrad_finish(a->part, pl.nsl * pl.kp, 9, a->Cout, a->Cin, pl.CoP, pl.CiP, a->dw, st);
 }

@@ -180,7 +180,16 @@ def configure_architecture(architecture, num_channels, num_classes, extra_settin
         backbone = extra_settings_model.semseg_backbone
         if backbone != "mobilenet_v2":
             raise Exception(f"No HIP model implemented for semseg_backbone: {backbone}")
-        return HyperStarcopUNet(in_channels=num_channels, classes=num_classes)
+        net = HyperStarcopUNet(in_channels=num_channels, classes=num_classes)
+        # extension (not in the reference's config.yaml): settings.model.precision = "fp32" (default, parity mode) | "bf16"
+        # (bf16 matrix math for the 3x3 convolutions, BASELINE configs[3]); absent key -> fp32
+        try:
+            prec = extra_settings_model["precision"] if "precision" in extra_settings_model else "fp32"
+        except TypeError:
+            prec = getattr(extra_settings_model, "precision", "fp32")
+        net.precision = prec
+        _ = net._terms           # validates
+        return net
     raise Exception(f"No model implemented for model_type: {architecture}")
 
 

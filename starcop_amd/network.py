@@ -367,21 +367,22 @@ class HyperStarcopUNet(nn.Module):
             conv = op["conv"]
             co, ci, ks = conv.out_channels, conv.in_channels, conv.kernel_size[0]
             ent = self._wpk.get(i)
-            if ent is None or ent["f"].device != dev or ent["split"] != self.split_bf16:
+            if ent is None or ent["f"].device != dev or ent["split"] != (self.split_bf16, self._terms):
                 cf, cb = _pick_cot(co, ks), _pick_cot(ci, ks)
                 # 3x3 layers with >= 32 output channels run on the bf16 matrix cores with three-term split operands
                 # (fp32 accuracy, conv_bx3.hip); thin ones stay on the fp32 MFMA kernels
                 xf = self.split_bf16 and ks == 3 and cf >= 32
                 xb = self.split_bf16 and ks == 3 and cb >= 32
-                nf = lib.sc_packed_weight_floats_bx3(co, ci, cf, 0) if xf else lib.sc_packed_weight_floats(co, ci, ks, cf, 0)
-                nb = lib.sc_packed_weight_floats_bx3(co, ci, cb, 1) if xb else lib.sc_packed_weight_floats(co, ci, ks, cb, 1)
-                ent = dict(cot_f=cf, cot_b=cb, bx3_f=xf, bx3_b=xb, split=self.split_bf16,
+                nt = self._terms
+                nf = lib.sc_packed_weight_floats_bx3(co, ci, cf, 0, nt) if xf else lib.sc_packed_weight_floats(co, ci, ks, cf, 0)
+                nb = lib.sc_packed_weight_floats_bx3(co, ci, cb, 1, nt) if xb else lib.sc_packed_weight_floats(co, ci, ks, cb, 1)
+                ent = dict(cot_f=cf, cot_b=cb, bx3_f=xf, bx3_b=xb, split=(self.split_bf16, nt), terms=nt,
                            f=torch.empty(nf, dtype=torch.float32, device=dev),
                            b=torch.empty(nb, dtype=torch.float32, device=dev))
                 self._wpk[i] = ent
                 self._pack_tables = {}
         # one launch for all packs: device-side descriptor table, built once per (need_bwd, parameter storage)
-        key = (bool(need_bwd), self._pflat.data_ptr())
+        key = (bool(need_bwd), self._pflat.data_ptr(), self._terms)
         tab = self._pack_tables.get(key) if hasattr(self, "_pack_tables") else None
         if tab is None:
             import numpy as np
@@ -397,7 +398,7 @@ class HyperStarcopUNet(nn.Module):
                     if tflip and not need_bwd:
                         continue
                     total = lib.sc_pack_work_items(co, ci, ks, cot, tflip, int(bx))
-                    rows.append((conv.weight.data_ptr(), buf.data_ptr(), co, ci, ks, cot, tflip, int(bx), total))
+                    rows.append((conv.weight.data_ptr(), buf.data_ptr(), co, ci, ks, cot, tflip, ent["terms"] if bx else 0, total))
                     starts.append(nblk)
                     nblk += -(-total // 256)
             descs = torch.from_numpy(np.array(rows, dtype=dt).view(np.uint8).copy()).to(dev)
@@ -477,6 +478,7 @@ class HyperStarcopUNet(nn.Module):
                 a.csplit, a.accum0, a.accum1 = o.C, 0, 0
                 a.add0 = None; a.add1 = None
                 a.stats = plan.stats_v[o.name].data_ptr() if stats is not None else None
+                a.terms = ent["terms"]
                 if ent["bx3_f"]:
                     fconv = lib.sc_conv3x3_bx3
                 elif _use_ksplit(N, Ho * Wo, conv.in_channels, conv.out_channels, a.ks):
@@ -515,6 +517,13 @@ class HyperStarcopUNet(nn.Module):
     # the CUs the small dgrad / reduce kernels of the dependency chain leave idle.
     overlap_wgrad = True
     split_bf16 = True        # 3x3 convs with >= 32 output channels on the bf16 matrix cores (three-term split, fp32 accuracy)
+    precision = "fp32"       # "bf16": the same kernels with ONE bf16 term per operand (bf16 matrix math, fp32 accumulate/storage)
+
+    @property
+    def _terms(self):
+        if self.precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16' (got {self.precision!r})")
+        return 1 if self.precision == "bf16" else 3
     _side_stream = None
 
     def _backward_impl(self, plan, dlogits):
@@ -626,6 +635,7 @@ class HyperStarcopUNet(nn.Module):
             wa.N, wa.H, wa.W, wa.Cout, wa.Cin, wa.ks = N, Ho, Wo, o.C, conv.in_channels, ks
             wa.part = plan.ws.data_ptr(); wa.part_floats = plan.ws_floats
             wa.dw = gv(conv.weight).data_ptr()
+            wa.terms = self._terms
             flop = 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * ks * ks
             wfn = (lib.sc_conv3x3_wgrad_bx3 if (self.split_bf16 and ks == 3 and conv.out_channels >= 32 and conv.in_channels > 32)
                    else lib.sc_conv2d_wgrad_mfma)     # its cin tile is 64 wide: 32 -> 32 layers stay on the fp32 MFMA
@@ -642,6 +652,7 @@ class HyperStarcopUNet(nn.Module):
             a.wpk = ent["b"].data_ptr()
             a.N, a.H, a.W, a.Cout = N, Ho, Wo, conv.in_channels
             a.ks, a.co_t = ks, ent["cot_b"]
+            a.terms = ent["terms"]
             if ent["bx3_b"]:
                 conv_dgrad = lib.sc_conv3x3_bx3
             elif _use_ksplit(N, Ho * Wo, conv.out_channels, conv.in_channels, ks):

@@ -33,16 +33,16 @@ def pack(w, co_t, tflip):
     return out
 
 
-def pack_bx3(w, co_t, tflip):
+def pack_bx3(w, co_t, tflip, terms=3):
     lib = _lib.load()
     co, ci = w.shape[0], w.shape[1]
-    out = torch.empty(lib.sc_packed_weight_floats_bx3(co, ci, co_t, tflip), device=DEV)
-    check(lib.sc_pack_weights_bx3(ptr(w), ptr(out), co, ci, co_t, tflip, stream()))
+    out = torch.empty(lib.sc_packed_weight_floats_bx3(co, ci, co_t, tflip, terms), device=DEV)
+    check(lib.sc_pack_weights_bx3(ptr(w), ptr(out), co, ci, co_t, tflip, terms, stream()))
     return out
 
 
 def conv_mfma(srcs, wpk, N, H, W, Cout, ks, co_t, want_stats=False, csplit=None, add0=None, add1=None,
-              accum=None, outs=None, bx3=False, ksplit=False):
+              accum=None, outs=None, bx3=False, ksplit=False, terms=0):
     lib = _lib.load()
     a = sc_conv_args()
     a.nsrc = len(srcs)
@@ -58,6 +58,7 @@ def conv_mfma(srcs, wpk, N, H, W, Cout, ks, co_t, want_stats=False, csplit=None,
     a.out0 = outs[0].data_ptr()
     a.out1 = outs[1].data_ptr() if len(outs) > 1 else None
     a.csplit = csplit
+    a.terms = terms
     a.accum0, a.accum1 = (accum or (0, 0))
     a.add0 = add0.data_ptr() if add0 is not None else None
     a.add1 = add1.data_ptr() if add1 is not None else None
@@ -69,7 +70,7 @@ def conv_mfma(srcs, wpk, N, H, W, Cout, ks, co_t, want_stats=False, csplit=None,
     return outs, stats
 
 
-def wgrad_mfma(dy, srcs, N, H, W, Cout, Cin, ks, bx3=False):
+def wgrad_mfma(dy, srcs, N, H, W, Cout, Cin, ks, bx3=False, terms=0):
     lib = _lib.load()
     a = sc_wgrad_args()
     a.dy = dy
@@ -77,6 +78,7 @@ def wgrad_mfma(dy, srcs, N, H, W, Cout, Cin, ks, bx3=False):
     for i, s in enumerate(srcs):
         a.src[i] = s
     a.N, a.H, a.W, a.Cout, a.Cin, a.ks = N, H, W, Cout, Cin, ks
+    a.terms = terms
     n = lib.sc_wgrad_bx3_workspace_floats(N, H, W, Cout, Cin) if bx3 else lib.sc_wgrad_workspace_floats(N, H, W, Cout, Cin, ks)
     ws = torch.empty(n, device=DEV)
     a.part, a.part_floats = ws.data_ptr(), n

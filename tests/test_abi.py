@@ -46,7 +46,27 @@ def test_pure_host_entry_points(lib):
 def test_struct_layouts_match_header():
     from starcop_amd import _lib
     assert ctypes.sizeof(_lib.sc_src) == 40
-    assert ctypes.sizeof(_lib.sc_conv_args) == 2 * 40 + 8 + 8 + 6 * 4 + 2 * 8 + 3 * 4 + 4 + 3 * 8
+    assert ctypes.sizeof(_lib.sc_conv_args) == 2 * 40 + 8 + 8 + 6 * 4 + 2 * 8 + 3 * 4 + 4 + 3 * 8 + 8     # ..., stats, terms (+ tail padding)
+
+
+def test_struct_sizes_match_the_c_compiler(tmp_path):
+    """sizeof / offsetof of every struct in include/starcop_hip.h as gcc lays them out == the ctypes mirrors in _lib.py"""
+    import shutil
+    import subprocess
+    from starcop_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "starcop_hip.h"\nint main(void){'
+                   'printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(sc_src), sizeof(sc_conv_args), offsetof(sc_conv_args, terms), '
+                   'sizeof(sc_wgrad_args), offsetof(sc_wgrad_args, terms), sizeof(sc_pack_desc), offsetof(sc_pack_desc, total));return 0;}\n')
+    exe = tmp_path / "sz"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run(["gcc", "-I", inc, str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = [ctypes.sizeof(_lib.sc_src), ctypes.sizeof(_lib.sc_conv_args), _lib.sc_conv_args.terms.offset,
+            ctypes.sizeof(_lib.sc_wgrad_args), _lib.sc_wgrad_args.terms.offset, 48, 40]
+    assert got == want
 
 
 def test_no_cpu_fallback():

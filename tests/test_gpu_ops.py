@@ -131,16 +131,17 @@ def test_pack_weights_batch(hip):
     """one launch packs every layer: identical bytes to the per-layer entry points (fp32 and split-bf16 layouts, fwd and dgrad)"""
     import numpy as np
     lib = hip
-    cases = [(96, 16, 1, 32, 0, 0), (96, 16, 1, 32, 1, 0), (24, 40, 3, 32, 0, 0), (16, 32, 3, 16, 0, 0), (64, 152, 3, 64, 0, 1), (64, 152, 3, 64, 1, 1), (32, 80, 3, 32, 1, 1)]
+    cases = [(96, 16, 1, 32, 0, 0), (96, 16, 1, 32, 1, 0), (24, 40, 3, 32, 0, 0), (16, 32, 3, 16, 0, 0), (64, 152, 3, 64, 0, 3), (64, 152, 3, 64, 1, 3), (32, 80, 3, 32, 1, 3), (64, 152, 3, 64, 0, 1)]
     dt = np.dtype([("w", "<u8"), ("wpk", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"), ("ks", "<i4"), ("co_t", "<i4"), ("tflip", "<i4"), ("bx3", "<i4"), ("total", "<u8")])
     rows, starts, nblk, want, got = [], [], 0, [], []
     for k, (co, ci, ks, cot, tf, bx) in enumerate(cases):
         w = dev(rnd(co, ci, ks, ks, seed=k))
-        ref = pack_bx3(w, cot, tf) if bx else pack(w, cot, tf)
+        ref = pack_bx3(w, cot, tf, bx) if bx else pack(w, cot, tf)
         out = torch.full_like(ref, float("nan")); _ = dev  # noqa
         want.append(ref); got.append(out)
         total = lib.sc_pack_work_items(co, ci, ks, cot, tf, bx)
-        rows.append((w.data_ptr(), out.data_ptr(), co, ci, ks, cot, tf, bx, total)); starts.append(nblk); nblk += -(-total // 256)
+        rows.append((w.data_ptr(), out.data_ptr(), co, ci, ks, cot, tf, bx, total))       # bx = number of bf16 terms (0: fp32 layout)
+        starts.append(nblk); nblk += -(-total // 256)
     descs = torch.from_numpy(np.array(rows, dtype=dt).view(np.uint8).copy()).to(DEV)
     st_t = torch.tensor(starts, dtype=torch.int32).to(DEV)
     check(lib.sc_pack_weights_batch(ptr(descs), ptr(st_t), len(rows), nblk, stream()))
@@ -240,6 +241,29 @@ def test_conv_wgrad(hip, ks, cin, cout, H, W, two):
     F.conv2d(xin, w, padding=ks // 2).backward(dy)
     dw = wgrad_mfma(dys, srcs, N, H, W, cout, cin, ks)
     assert relerr(dw, w.grad) < TOL
+
+
+@pytest.mark.parametrize("cin,cout,co_t,H,W", [(32, 64, 64, 36, 70), (24, 96, 32, 20, 40), (288, 128, 64, 8, 12)])
+def test_conv_bf16_single_term(hip, cin, cout, co_t, H, W):
+    """terms = 1 ("bf16" precision mode): equals an fp64 convolution of the bf16-rounded operands to fp32-accumulation accuracy,
+    and is within bf16 rounding of the unrounded result; forward, dgrad and wgrad."""
+    N = 2
+    x, w = rnd(N, cin, H, W, seed=1), rnd(cout, cin, 3, 3, seed=2, scale=0.2)
+    rb = lambda t: t.bfloat16().double()
+    ref_r = F.conv2d(rb(x), rb(w), padding=1)
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    src = make_src(dev(x), cin, SRC_RAW)
+    (out,), _ = conv_mfma([src], pack_bx3(dev(w), co_t, 0, 1), N, H, W, cout, 3, co_t, bx3=True, terms=1)
+    assert relerr(out, ref_r) < 5e-6 and relerr(out, ref) < 2e-2
+    g = rnd(N, cout, H, W, seed=3)
+    cb = 32 if cin <= 32 else 64
+    (dx,), _ = conv_mfma([make_src(dev(g), cout, SRC_RAW)], pack_bx3(dev(w), cb, 1, 1), N, H, W, cin, 3, cb, bx3=True, terms=1)
+    assert relerr(dx, F.conv_transpose2d(rb(g), rb(w), padding=1)) < 5e-6
+    if cin > 32:
+        wz = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(rb(x), wz, padding=1).backward(rb(g))
+        dw = wgrad_mfma(make_src(dev(g), cout, SRC_RAW), [src], N, H, W, cout, cin, 3, bx3=True, terms=1)
+        assert relerr(dw, wz.grad) < 5e-6
 
 
 @pytest.mark.parametrize("cin,cout,H,W,two", [(16, 64, 32, 32, False), (32, 16, 36, 70, True), (48, 40, 21, 32, False), (32, 64, 16, 32, True),

@@ -159,3 +159,33 @@ def test_predict_odd_size(hip):
         want = torch.sigmoid(ref(ref_normalize(torch.from_numpy(pad)[None])))[0, 0, 13:-13, 3:-3]
     assert got.shape == (70, 90)
     assert relerr(torch.from_numpy(got), want) < 1e-4
+
+
+def test_bf16_precision_mode_trains_like_fp32(hip):
+    """settings.model.precision = "bf16" (BASELINE configs[3]: bf16 matrix math in the 3x3 convolutions, fp32 accumulate and
+    storage).  Parity gate of SURVEY 8d for bf16: the mask quality after training matches the fp32 run (F1 within 0.005 on the
+    synthetic validation batch), and the loss curves stay within bf16 noise of each other."""
+    from starcop_amd.metrics import f1score
+    B, H, W, steps = 4, 128, 128, 60
+    train = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in synth_batch(B, H, W, seed=5).items()}
+    val = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in synth_batch(B, H, W, seed=6).items()}
+    res = {}
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(0)
+        model = mm.ModelModule(mm.default_settings(pos_weight=1, lr=1e-3, precision=prec)).to(DEV).train()
+        assert model.network.precision == prec
+        opt = model.configure_optimizers()["optimizer"]
+        losses = []
+        for _ in range(steps):
+            losses.append(float(model.fused_train_step(train, opt).item()) / (B * H * W))
+        model.eval()
+        with torch.no_grad():
+            pred = (model(val["input"]) >= 0).long()
+        y = val["output"].long()
+        tp = int(((pred == 1) & (y == 1)).sum()); fp = int(((pred == 1) & (y == 0)).sum()); fn = int(((pred == 0) & (y == 1)).sum())
+        res[prec] = (losses, 2 * tp / max(2 * tp + fp + fn, 1))
+    (l32, f32), (l16, f16) = res["fp32"], res["bf16"]
+    assert l32[-1] < 0.6 * l32[0] and l16[-1] < 0.6 * l16[0]                       # both learn
+    assert abs(l16[0] - l32[0]) < 2e-2 * l32[0]                                    # same start, bf16 rounding only
+    assert abs(l16[-1] - l32[-1]) < 0.15 * l32[-1]
+    assert abs(f16 - f32) <= 0.005 + 0.02 * (1 - f32), (f16, f32)
