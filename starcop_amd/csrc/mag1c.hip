@@ -294,8 +294,23 @@ __global__ __launch_bounds__(256) void k_mag1c(const Mag1cP p) {
 //   B0 = C_0^{-1} = W/N (W = (C_0/N)^{-1}, formed once: Cholesky -> triangular inverse -> X^T X),  U = [v tau],
 //   M = [[0,-1],[-1,q]]:  (C_0 + U M U^T)^{-1} b = B0 b - B0 U (M^{-1} + U^T B0 U)^{-1} U^T B0 b
 // Per iteration: two mat-vecs (W v, W t_new; W tau is last iteration's W t_new), a 2x2 solve, two streaming passes.
-template <typename T>
-__global__ __launch_bounds__(256) void k_mag1c_fast(const Mag1cP p) {
+// NT threads per group (1024: the 125 KB matrix in LDS allows one work-group per CU, so the work-group itself has to fill it)
+template <int NW>
+__device__ __forceinline__ double block_sum_n(double v, double* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = wave_sum_d(v);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) t += red[w];
+  return t;
+}
+
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void k_mag1c_fast(const Mag1cP p) {
+  constexpr int NW = NT / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int g = blockIdx.x;
   const int S = p.S, LDC = S | 1;                           // odd pitch: conflict-free row-per-lane ds_read_b64
@@ -305,8 +320,8 @@ __global__ __launch_bounds__(256) void k_mag1c_fast(const Mag1cP p) {
   double* xbar = vec, *tmpl = vec + VEC, *tau = vec + 2 * VEC, *mu = vec + 3 * VEC, *tnew = vec + 4 * VEC;
   double* cit = vec + 5 * VEC, *vv = vec + 6 * VEC, *col = vec + 7 * VEC;
   double* p1 = vec + 8 * VEC, *p2 = vec + 9 * VEC, *p3 = vec + 10 * VEC;
-  double* red = vec + 11 * VEC;      // [16]
-  double* stg = red + 16;            // [S16][17]
+  double* red = vec + 11 * VEC;      // [64]: [0,32) block sums, [32,64) broadcast scalars
+  double* stg = red + 64;            // [S16][17]; after phase B reused as scratch (4 x 128 partial mat-vec sums)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int P = p.P[g], pitch = p.Ppad[g];
@@ -321,10 +336,10 @@ __global__ __launch_bounds__(256) void k_mag1c_fast(const Mag1cP p) {
   double nstat;
   {
     double c = 0.0;
-    for (int q = tid; q < P; q += 256) c += (mk == nullptr || mk[q]) ? 1.0 : 0.0;
-    nstat = block_sum1(c, red);
+    for (int q = tid; q < P; q += NT) c += (mk == nullptr || mk[q]) ? 1.0 : 0.0;
+    nstat = block_sum_n<NW>(c, red);
   }
-  for (int s = wave; s < S; s += 4) {
+  for (int s = wave; s < S; s += NW) {
     double a = 0.0;
     for (int q = lane; q < P; q += 64 * 8) {
       T xr[8];
@@ -336,19 +351,20 @@ __global__ __launch_bounds__(256) void k_mag1c_fast(const Mag1cP p) {
     a = wave_sum_d(a);
     if (lane == 0) xbar[s] = a / nstat;
   }
-  for (int s = tid; s < S; s += 256) tmpl[s] = p.templ[s];
+  for (int s = tid; s < S; s += NT) tmpl[s] = p.templ[s];
   __syncthreads();
 
   // ---------------- phase B: C_0 on the fp64 MFMA, written as A = C_0/N straight into LDS (both triangles)
   {
     const int nb = S16 >> 4;
     const int nblk = nb * (nb + 1) / 2;
-    doublex4 acc[9];
+    constexpr int NB = (36 + NW - 1) / NW;       // 16x16 blocks of the upper triangle (<= 36 for S <= 128) per wave
+    doublex4 acc[NB];
 #pragma unroll
-    for (int b = 0; b < 9; ++b) acc[b] = (doublex4){0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < NB; ++b) acc[b] = (doublex4){0.0, 0.0, 0.0, 0.0};
     for (int c0 = 0; c0 < P; c0 += 16) {
       __syncthreads();
-      for (int i = tid; i < S16 * 16; i += 256) {
+      for (int i = tid; i < S16 * 16; i += NT) {
         const int s = i >> 4, k = i & 15, q = c0 + k;
         double v = 0.0;
         if (s < S && q < P && (mk == nullptr || mk[q])) v = (double)X[(size_t)s * pitch + q] - xbar[s];
@@ -356,8 +372,8 @@ __global__ __launch_bounds__(256) void k_mag1c_fast(const Mag1cP p) {
       }
       __syncthreads();
 #pragma unroll
-      for (int b = 0; b < 9; ++b) {
-        const int blk = wave + 4 * b;
+      for (int b = 0; b < NB; ++b) {
+        const int blk = wave + NW * b;
         if (blk < nblk) {
           int bi = 0, rem = blk;
           while (rem >= nb - bi) { rem -= nb - bi; ++bi; }
@@ -373,8 +389,8 @@ __global__ __launch_bounds__(256) void k_mag1c_fast(const Mag1cP p) {
     }
     __syncthreads();
 #pragma unroll
-    for (int b = 0; b < 9; ++b) {
-      const int blk = wave + 4 * b;
+    for (int b = 0; b < NB; ++b) {
+      const int blk = wave + NW * b;
       if (blk < nblk) {
         int bi = 0, rem = blk;
         while (rem >= nb - bi) { rem -= nb - bi; ++bi; }
@@ -394,30 +410,38 @@ __global__ __launch_bounds__(256) void k_mag1c_fast(const Mag1cP p) {
     const double djj = Cm[j * LDC + j];
     if (!(djj > 0.0)) notpd = true;
     const double d = sqrt(djj);
-    for (int i = j + tid; i < S; i += 256) col[i] = (i == j) ? d : Cm[i * LDC + j] / d;
+    for (int i = j + tid; i < S; i += NT) col[i] = (i == j) ? d : Cm[i * LDC + j] / d;
     __syncthreads();
     const int ti = tid >> 4, tk = tid & 15;
-    for (int i = j + 1 + ti; i < S; i += 16) {
+    for (int i = j + 1 + ti; i < S; i += NT / 16) {
       const double ci = col[i];
       for (int k = j + 1 + tk; k <= i; k += 16) Cm[i * LDC + k] -= ci * col[k];
     }
-    for (int i = j + tid; i < S; i += 256) Cm[i * LDC + j] = col[i];
+    for (int i = j + tid; i < S; i += NT) Cm[i * LDC + j] = col[i];
     __syncthreads();
   }
   // ---------------- X = L^{-1}: thread j builds column j; X[i][j] (i > j) lives at Cm[j][i] (upper triangle), 1/L[j][j] in col[]
   if (tid < S) col[tid] = 1.0 / Cm[tid * LDC + tid];
   __syncthreads();
-  if (tid < S) {
-    const int j = tid;
-    for (int i = j + 1; i < S; ++i) {
-      double a = Cm[i * LDC + j] * col[j];                   // L[i][j] * X[j][j]
-      for (int k = j + 1; k < i; ++k) a = fma(Cm[i * LDC + k], Cm[j * LDC + k], a);
-      Cm[j * LDC + i] = -a * col[i];
+  {
+    // column j is built by the TPC lanes tid = j*TPC .. j*TPC+TPC-1 (adjacent lanes of one wave): they split the inner
+    // product over k and combine with DPP-free xor shuffles; rows i are sequential (forward substitution)
+    constexpr int TPC = NT / 128;                            // 8 at NT = 1024, 2 at NT = 256
+    const int j = tid / TPC, part = tid % TPC;
+    if (j < S) {
+      for (int i = j + 1; i < S; ++i) {
+        double a = (part == 0) ? Cm[i * LDC + j] * col[j] : 0.0;            // L[i][j] * X[j][j]
+        for (int k = j + 1 + part; k < i; k += TPC) a = fma(Cm[i * LDC + k], Cm[j * LDC + k], a);
+#pragma unroll
+        for (int o = TPC >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (part == 0) Cm[j * LDC + i] = -a * col[i];
+        __builtin_amdgcn_wave_barrier();
+      }
     }
   }
   __syncthreads();
   // ---------------- W = X^T X -> global scratch (the C_0 slot), then back into LDS as a full symmetric matrix
-  for (int e = tid; e < S * S; e += 256) {
+  for (int e = tid; e < S * S; e += NT) {
     const int a = e / S, b = e - a * S;
     if (b > a) continue;
     // sum_{i >= a} X[i][a] X[i][b]   (a >= b);  X[i][c] = (i == c) ? col[c] : Cm[c][i]
@@ -427,8 +451,8 @@ __global__ __launch_bounds__(256) void k_mag1c_fast(const Mag1cP p) {
   }
   __threadfence_block();
   __syncthreads();
-  for (int e = tid; e < S * S; e += 256) { const int a = e / S, b = e - a * S; Cm[a * LDC + b] = C0[e]; }
-  for (int s = tid; s < S; s += 256) { p2[s] = 0.0; vv[s] = 0.0; tau[s] = 0.0; }
+  for (int e = tid; e < S * S; e += NT) { const int a = e / S, b = e - a * S; Cm[a * LDC + b] = C0[e]; }
+  for (int s = tid; s < S; s += NT) { p2[s] = 0.0; vv[s] = 0.0; tau[s] = 0.0; }
   __syncthreads();
 
   // ---------------- rmf (it == 0) then the reweighted-L1 iterations
@@ -437,25 +461,34 @@ __global__ __launch_bounds__(256) void k_mag1c_fast(const Mag1cP p) {
   for (int it = 0; it <= last; ++it) {
     double wbar = 0.0, q = 0.0;
     if (it > 0) { wbar = sw / nstat; q = sww - nstat * wbar * wbar; }
-    for (int s = tid; s < S; s += 256) {
+    for (int s = tid; s < S; s += NT) {
       const double m = (it > 0) ? xbar[s] - wbar * tau[s] : xbar[s];
       mu[s] = m;
       tnew[s] = tmpl[s] * m;
     }
     __syncthreads();
-    // p1 = W v (threads 0..127), p3 = W t_new (threads 128..255): one row per thread, 4 partial sums
+    // p1 = W v, p3 = W t_new: row r = tid & 127, vector = (tid >> 7) & 1, the NT/256 column parts of a row are summed via LDS
     {
-      const int r = tid & 127;
-      const double* u = (tid < 128) ? vv : tnew;
+      constexpr int NP = NT / 256;
+      const int r = tid & 127, which = (tid >> 7) & 1, part = tid >> 8;
+      const double* u = which ? tnew : vv;
+      double a0 = 0.0, a1 = 0.0;
       if (r < S) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int c = 0;
-        for (; c + 3 < S; c += 4) {
-          a0 = fma(Cm[r * LDC + c], u[c], a0); a1 = fma(Cm[r * LDC + c + 1], u[c + 1], a1);
-          a2 = fma(Cm[r * LDC + c + 2], u[c + 2], a2); a3 = fma(Cm[r * LDC + c + 3], u[c + 3], a3);
+        int c = 2 * part;
+        for (; c + 1 < S; c += 2 * NP) { a0 = fma(Cm[r * LDC + c], u[c], a0); a1 = fma(Cm[r * LDC + c + 1], u[c + 1], a1); }
+        if (c < S) a0 = fma(Cm[r * LDC + c], u[c], a0);
+      }
+      if (NP == 1) {
+        if (r < S) (which ? p3 : p1)[r] = a0 + a1;
+      } else {
+        stg[(part * 2 + which) * 128 + r] = a0 + a1;
+        __syncthreads();
+        if (tid < 256 && r < S) {
+          double t = 0.0;
+#pragma unroll
+          for (int q2 = 0; q2 < NP; ++q2) t += stg[(q2 * 2 + which) * 128 + r];
+          (which ? p3 : p1)[r] = t;
         }
-        for (; c < S; ++c) a0 = fma(Cm[r * LDC + c], u[c], a0);
-        ((tid < 128) ? p1 : p3)[r] = (a0 + a1) + (a2 + a3);
       }
     }
     __syncthreads();
@@ -481,23 +514,23 @@ __global__ __launch_bounds__(256) void k_mag1c_fast(const Mag1cP p) {
         y2 = (g11 * z2 - g12 * z1) / det;
       }
       if (lane == 0) {
-        red[8] = d[5] - y1 * d[3] - y2 * d[4];            // normaliser  t . C^{-1} t
-        red[9] = d[8] - y1 * d[6] - y2 * d[7];            // mu . C^{-1} t
-        red[10] = mm; red[11] = y1; red[12] = y2;
+        red[32] = d[5] - y1 * d[3] - y2 * d[4];           // normaliser  t . C^{-1} t
+        red[33] = d[8] - y1 * d[6] - y2 * d[7];           // mu . C^{-1} t
+        red[34] = mm; red[35] = y1; red[36] = y2;
       }
     }
     __syncthreads();
     {
-      const double y1 = red[11], y2 = red[12];
-      for (int s = tid; s < S; s += 256) cit[s] = p3[s] - y1 * p1[s] - y2 * p2[s];
+      const double y1 = red[35], y2 = red[36];
+      for (int s = tid; s < S; s += NT) cit[s] = p3[s] - y1 * p1[s] - y2 * p2[s];
     }
     __syncthreads();
-    double norm = red[8];
-    const double mucit = red[9], mumu = red[10];
+    double norm = red[32];
+    const double mucit = red[33], mumu = red[34];
     if (!(norm == norm)) notpd = true;
     if (it > 0 && norm < 1.0) norm = 1.0;
     double lsw = 0.0, lsww = 0.0;
-    for (int q0 = tid; q0 < P; q0 += 256) {
+    for (int q0 = tid; q0 < P; q0 += NT) {
       double dot = 0.0, dmu = 0.0;
       const bool need_mu = (it == 0) && !p.albedo_override;
       for (int s0 = 0; s0 < S; s0 += 16) {            // 16 independent loads in flight per pixel, then the FMAs
@@ -530,11 +563,11 @@ __global__ __launch_bounds__(256) void k_mag1c_fast(const Mag1cP p) {
       lsw += w; lsww += w * w;
     }
     if (it == last) break;
-    sw = block_sum1(lsw, red);
-    sww = block_sum1(lsww, red + 4);
+    sw = block_sum_n<NW>(lsw, red);
+    sww = block_sum_n<NW>(lsww, red + 16);
     __threadfence_block();
     __syncthreads();
-    for (int s = wave; s < S; s += 4) {
+    for (int s = wave; s < S; s += NW) {
       double a = 0.0;
       for (int q0 = lane; q0 < P; q0 += 64 * 8) {    // 16 independent loads in flight per lane
         T xr[8]; double wr[8];
@@ -551,7 +584,7 @@ __global__ __launch_bounds__(256) void k_mag1c_fast(const Mag1cP p) {
   const double scale = (p.num_iter >= 0 || p.apply_scaling) ? 1e5 : 1.0;
   T* mo = reinterpret_cast<T*>(p.mf_out) + po;
   T* ao = reinterpret_cast<T*>(p.alb_out) + po;
-  for (int q0 = tid; q0 < P; q0 += 256) {
+  for (int q0 = tid; q0 < P; q0 += NT) {
     mo[q0] = (T)(mfw[q0] * scale);
     ao[q0] = (T)Rw[q0];
   }
@@ -605,7 +638,8 @@ __global__ void k_scatter(const TI* __restrict__ val, const long long* __restric
 
 size_t mag1c_lds_bytes(int S) {
   const int S16 = (S + 15) & ~15;
-  return ((size_t)S * (S + 1) + 11 * VEC + 16 + (size_t)S16 * 17) * sizeof(double);
+  const size_t stg = (size_t)S16 * 17 > 8 * 128 ? (size_t)S16 * 17 : 8 * 128;
+  return ((size_t)S * (S + 1) + 11 * VEC + 64 + stg) * sizeof(double);
 }
 
 }  // namespace
@@ -635,11 +669,11 @@ extern "C" int sc_mag1c_groups(const sc_mag1c_args* a, sc_stream stream) {
   hipError_t e;
   const bool fast = a->alpha == 0.0;     // no shrinkage: one factorisation per group + Woodbury updates
   if (fast && a->x_is_f64) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c_fast<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) hipLaunchKernelGGL(k_mag1c_fast<double>, dim3(a->G), dim3(256), lds, st, p);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c_fast<double, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) hipLaunchKernelGGL((k_mag1c_fast<double, 1024>), dim3(a->G), dim3(1024), lds, st, p);
   } else if (fast) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c_fast<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) hipLaunchKernelGGL(k_mag1c_fast<float>, dim3(a->G), dim3(256), lds, st, p);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c_fast<float, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) hipLaunchKernelGGL((k_mag1c_fast<float, 1024>), dim3(a->G), dim3(1024), lds, st, p);
   } else if (a->x_is_f64) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess) hipLaunchKernelGGL(k_mag1c<double>, dim3(a->G), dim3(256), lds, st, p);
