@@ -471,6 +471,96 @@ __device__ __forceinline__ void head_stage_patch(const SrcD& in, float* s_in, in
 }
 
 // CIN > 0: compile-time channel count -> the 9*CIN filter taps are scalar (SGPR) operands; CIN == 0: generic, taps in LDS
+// Register-blocked head forward for Cin = 16: tile 16 rows x 64 cols, a thread owns 4 horizontally adjacent outputs, so
+// one (ci, kh) needs 6 consecutive inputs = one 16-byte + one 8-byte LDS read for 12 FMAs (the one-output-per-thread
+// form does 144 4-byte LDS reads per output and is LDS-issue bound at 4x the HBM time).  Channels in two passes of 8
+// (39 KB of LDS -> 4 work-groups per CU).
+__global__ __launch_bounds__(256, 4) void k_head_fwd16(const SrcD in, const float* __restrict__ w, const float* __restrict__ bias,
+                                                     float* __restrict__ out, int H, int W) {
+  constexpr int CIN = 16, CP = 8, TR = 16, TC = 64, PR = TR + 2, PW = TC + 2, PC = 68;
+  __shared__ __attribute__((aligned(16))) float s_in[CP * PR * PC];
+  __shared__ __attribute__((aligned(16))) float s_w[CIN * 12];           // 9 taps per channel, padded to 12
+  const int n = blockIdx.z;
+  const int tiles_x = (W + TC - 1) / TC;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int y0 = ty * TR, x0 = tx * TC;
+  if (threadIdx.x < CIN * 12) { const int c = threadIdx.x / 12, t = threadIdx.x - 12 * c; s_w[threadIdx.x] = t < 9 ? w[c * 9 + t] : 0.f; }
+  const float lo = sc_act_lo(in.act), hi = sc_act_hi(in.act);
+  const bool raw = in.mode == SC_SRC_RAW;
+  const int py = threadIdx.x >> 4, pxg = threadIdx.x & 15;
+  float acc[4];
+  const float b0 = bias ? bias[0] : 0.f;
+#pragma unroll
+  for (int o = 0; o < 4; ++o) acc[o] = b0;
+#pragma unroll
+  for (int pass = 0; pass < CIN / CP; ++pass) {
+    if (pass) __syncthreads();
+    // staging: a wave takes whole patch rows (uniform channel / row -> scalar constants and row addresses), lane = column;
+    // lanes 0,1 also fetch the two right-halo columns; 6 rows (12 loads) in flight
+    {
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      constexpr int NROW = CP * PR, RB = 6;
+      const int xa = x0 - 1 + lane, xb = x0 + 63 + lane;                 // xb only for lane < 2
+      const bool oka = (xa >= 0) && (xa < W), okb = (lane < 2) && (xb < W);
+#pragma unroll 1
+      for (int rr0 = wave; rr0 < NROW; rr0 += 4 * RB) {
+        float va[RB], vb[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          const int rr = rr0 + 4 * u;
+          const int rc = rr < NROW ? rr : 0;
+          const int ci = rc / PR, r = rc - ci * PR;
+          const int y = y0 - 1 + r;
+          const bool oky = (y >= 0) && (y < H);
+          const float* row = in.x + ((size_t)n * CIN + pass * CP + ci) * H * W + (size_t)(oky ? y : 0) * W;
+          va[u] = row[oka ? xa : 0];
+          vb[u] = row[okb ? xb : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          const int rr = rr0 + 4 * u;
+          if (rr < NROW) {
+            const int ci = rr / PR, r = rr - ci * PR;
+            const int y = y0 - 1 + r;
+            const bool oky = (y >= 0) && (y < H);
+            const int cg = pass * CP + ci;
+            const float sc = raw ? 1.f : in.cst[(size_t)cg * SC_CST], sh = raw ? 0.f : in.cst[(size_t)cg * SC_CST + 1];
+            s_in[(ci * PR + r) * PC + lane] = (oky && oka) ? sc_pro_affine(va[u], sc, sh, lo, hi) : 0.f;
+            if (lane < 2) s_in[(ci * PR + r) * PC + 64 + lane] = (oky && okb) ? sc_pro_affine(vb[u], sc, sh, lo, hi) : 0.f;
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int ci = 0; ci < CP; ++ci) {
+      const float4* wp = reinterpret_cast<const float4*>(&s_w[(pass * CP + ci) * 12]);     // broadcast reads
+      const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+      const float wk[9] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x};
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const float* rp = &s_in[(ci * PR + py + kh) * PC + 4 * pxg];
+        const float4 a = *reinterpret_cast<const float4*>(rp);
+        const float2 b = *reinterpret_cast<const float2*>(rp + 4);
+        const float v[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int o = 0; o < 4; ++o) acc[o] = fmaf(wk[kh * 3 + kw], v[o + kw], acc[o]);
+      }
+    }
+  }
+  const int y = y0 + py, x = x0 + 4 * pxg;
+  if (y >= H) return;
+  float* op = out + (size_t)n * H * W + (size_t)y * W + x;
+  if (x + 3 < W && ((W & 3) == 0)) {
+    *reinterpret_cast<float4*>(op) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  } else {
+#pragma unroll
+    for (int o = 0; o < 4; ++o) if (x + o < W) op[o] = acc[o];
+  }
+}
+
 template <int CIN>
 __global__ __launch_bounds__(256) void k_head_fwd(const SrcD in, const float* __restrict__ w, const float* __restrict__ bias,
                                                   float* __restrict__ out, int Cin_rt, int H, int W) {
@@ -666,8 +756,12 @@ extern "C" int sc_head_conv_fwd(const sc_src* in, const float* w, const float* b
   SC_REQUIRE(Cin >= 1 && Cin <= HEAD_MAXCI, "sc_head_conv_fwd: Cin must be in [1,%d]", HEAD_MAXCI);
   SC_REQUIRE((in->mode == SC_SRC_RAW || in->mode == SC_SRC_AFFINE) && in->up == 0, "sc_head_conv_fwd: unsupported source mode");
   dim3 grid(((W + HT_C - 1) / HT_C) * ((H + HT_R - 1) / HT_R), 1, N);
-  if (Cin == 16) hipLaunchKernelGGL((k_head_fwd<16>), grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), w, bias, out, Cin, H, W);
-  else hipLaunchKernelGGL((k_head_fwd<0>), grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), w, bias, out, Cin, H, W);
+  if (Cin == 16) {
+    dim3 g16(((W + 63) / 64) * ((H + 15) / 16), 1, N);
+    hipLaunchKernelGGL(k_head_fwd16, g16, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), w, bias, out, H, W);
+  } else {
+    hipLaunchKernelGGL((k_head_fwd<0>), grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), w, bias, out, Cin, H, W);
+  }
   SC_LAUNCH_OK("sc_head_conv_fwd");
   return SC_OK;
 }
