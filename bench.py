@@ -22,6 +22,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
@@ -180,9 +181,15 @@ def main():
             traffic = round(t["hbm_bytes_per_launch_raw"])
             traffic_note = (f"HBM bytes per launch of {t['kernel_pattern']}* from committed rocprofv3 PMC passes (FETCH_SIZE raw + WRITE_SIZE, "
                             "KiB->bytes; 4 B/lane loads: the gfx950 2x FETCH correction for 16 B/lane streams is not applied)")
-        roof = {"kernel": fam, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+        hbm = ("<1>" in fam or "k_dw" in fam or "elementwise" in fam) and d.get("bytes")     # streaming families: HBM roofline
+        if hbm:
+            ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            peak = HBM_PEAK_GBS
+        roof = {"kernel": fam, "bound": "hbm" if hbm else "mfma", "achieved": round(ach, 2), "peak": round(peak, 1),
+                "unit": "GB/s" if hbm else "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
-                "peak_note": ("fp32-equivalent ceiling of the three-term split: dense bf16 MFMA peak 2500 TFLOP/s / 6 products; "
+                "peak_note": "HBM3E peak (MI355X_MICROARCH.md); achieved = algorithmic bytes of these launches / their time" if hbm else
+                             ("fp32-equivalent ceiling of the three-term split: dense bf16 MFMA peak 2500 TFLOP/s / 6 products; "
                               f"the kernel executes {round(nprod * ach, 1)} bf16 TFLOP/s on the matrix cores; "
                               f"{round(ach / FP32_MFMA_PEAK_TFLOPS, 3)} x the fp32 MFMA peak of {FP32_MFMA_PEAK_TFLOPS}") if bx3 else
                              "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",

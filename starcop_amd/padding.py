@@ -23,7 +23,7 @@ def padded_predict(tensor, model, divisor=32, device=torch.device("cpu")):
         raise AssertionError(f"Expected 3D tensor, found {len(tensor.shape)}D tensor")
     rows, cols = tensor.shape[-2], tensor.shape[-1]
     (top, bottom), (left, right) = find_padding(rows, divisor), find_padding(cols, divisor)
-    x = torch.as_tensor(np.asarray(tensor)).to(device)[None]
+    x = torch.as_tensor(np.ascontiguousarray(tensor)).to(device)[None]      # a strided host view makes the H2D copy 10x slower
     with torch.no_grad():
         if top or bottom or left or right:
             if max(top, bottom) >= rows or max(left, right) >= cols:
