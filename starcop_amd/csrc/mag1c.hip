@@ -47,18 +47,32 @@ __device__ __forceinline__ double block_sum1(double v, double* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_mag1c(const Mag1cP p) {
+template <int NW>
+__device__ __forceinline__ double block_sum_n(double v, double* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = wave_sum_d(v);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) t += red[w];
+  return t;
+}
+
+template <typename T, int NT>
+__global__ __launch_bounds__(NT, NT == 512 ? 6 : 4) void k_mag1c(const Mag1cP p) {      // 512 threads: 3 groups per CU
+  constexpr int NW = NT / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int g = blockIdx.x;
-  const int S = p.S, LDC = S + 1;
+  const int S = p.S, LDC = S | 1;                         // odd pitch: conflict-free row-per-lane ds_read_b64
   const int S16 = (S + 15) & ~15;
   double* Cm = reinterpret_cast<double*>(smem);           // [S][LDC] working covariance / Cholesky factor
   double* vec = Cm + (size_t)S * LDC;
   double* xbar = vec, *tmpl = vec + VEC, *tau = vec + 2 * VEC, *mu = vec + 3 * VEC, *tnew = vec + 4 * VEC;
   double* cit = vec + 5 * VEC, *vv = vec + 6 * VEC, *col = vec + 7 * VEC;
-  double* red = vec + 8 * VEC;       // [16]
-  double* stg = red + 16;            // [S16][17] staging for the scatter matrix
+  double* red = vec + 8 * VEC;       // [64]: [0,32) block sums, [32,64) broadcast scalars
+  double* stg = red + 64;            // [S16][17] staging for the scatter matrix
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int P = p.P[g], pitch = p.Ppad[g];
@@ -73,10 +87,10 @@ __global__ __launch_bounds__(256) void k_mag1c(const Mag1cP p) {
   double nstat;
   {
     double c = 0.0;
-    for (int q = tid; q < P; q += 256) c += (mk == nullptr || mk[q]) ? 1.0 : 0.0;
-    nstat = block_sum1(c, red);
+    for (int q = tid; q < P; q += NT) c += (mk == nullptr || mk[q]) ? 1.0 : 0.0;
+    nstat = block_sum_n<NW>(c, red);
   }
-  for (int s = wave; s < S; s += 4) {
+  for (int s = wave; s < S; s += NW) {
     double a = 0.0;
     for (int q = lane; q < P; q += 64 * 8) {
       T xr[8];
@@ -88,19 +102,20 @@ __global__ __launch_bounds__(256) void k_mag1c(const Mag1cP p) {
     a = wave_sum_d(a);
     if (lane == 0) xbar[s] = a / nstat;
   }
-  for (int s = tid; s < S; s += 256) tmpl[s] = p.templ[s];
+  for (int s = tid; s < S; s += NT) tmpl[s] = p.templ[s];
   __syncthreads();
 
   // ---------------- phase B: C_0 = sum_p (x_p - xbar)(x_p - xbar)^T  on v_mfma_f64_16x16x4_f64
   {
     const int nb = S16 >> 4;
     const int nblk = nb * (nb + 1) / 2;
-    doublex4 acc[9];
+    constexpr int NB = (36 + NW - 1) / NW;
+    doublex4 acc[NB];
 #pragma unroll
-    for (int b = 0; b < 9; ++b) acc[b] = (doublex4){0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < NB; ++b) acc[b] = (doublex4){0.0, 0.0, 0.0, 0.0};
     for (int c0 = 0; c0 < P; c0 += 16) {
       __syncthreads();
-      for (int i = tid; i < S16 * 16; i += 256) {
+      for (int i = tid; i < S16 * 16; i += NT) {
         const int s = i >> 4, k = i & 15, q = c0 + k;
         double v = 0.0;
         if (s < S && q < P && (mk == nullptr || mk[q])) v = (double)X[(size_t)s * pitch + q] - xbar[s];
@@ -108,8 +123,8 @@ __global__ __launch_bounds__(256) void k_mag1c(const Mag1cP p) {
       }
       __syncthreads();
 #pragma unroll
-      for (int b = 0; b < 9; ++b) {
-        const int blk = wave + 4 * b;
+      for (int b = 0; b < NB; ++b) {
+        const int blk = wave + NW * b;
         if (blk < nblk) {
           // upper-triangular block index -> (bi <= bj)
           int bi = 0, rem = blk;
@@ -125,8 +140,8 @@ __global__ __launch_bounds__(256) void k_mag1c(const Mag1cP p) {
       }
     }
 #pragma unroll
-    for (int b = 0; b < 9; ++b) {
-      const int blk = wave + 4 * b;
+    for (int b = 0; b < NB; ++b) {
+      const int blk = wave + NW * b;
       if (blk < nblk) {
         int bi = 0, rem = blk;
         while (rem >= nb - bi) { rem -= nb - bi; ++bi; }
@@ -150,20 +165,20 @@ __global__ __launch_bounds__(256) void k_mag1c(const Mag1cP p) {
     // (1) mean / target / covariance of the target-removed data
     double wbar = 0.0, q = 0.0;
     if (it > 0) { wbar = sw / nstat; q = sww - nstat * wbar * wbar; }
-    for (int s = tid; s < S; s += 256) {
+    for (int s = tid; s < S; s += NT) {
       const double m = (it > 0) ? xbar[s] - wbar * tau[s] : xbar[s];
       mu[s] = m;
       tnew[s] = tmpl[s] * m;
     }
     __syncthreads();
     const double oma = 1.0 - p.alpha;
-    for (int i0 = tid; i0 < S * S; i0 += 256 * 8) {
+    for (int i0 = tid; i0 < S * S; i0 += NT * 8) {
       double c0v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) c0v[u] = C0[min(i0 + 256 * u, S * S - 1)];
+      for (int u = 0; u < 8; ++u) c0v[u] = C0[min(i0 + NT * u, S * S - 1)];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int i = i0 + 256 * u;
+        const int i = i0 + NT * u;
         if (i < S * S) {
           const int r = i / S, c = i - r * S;
           if (c <= r) {
@@ -177,20 +192,37 @@ __global__ __launch_bounds__(256) void k_mag1c(const Mag1cP p) {
       }
     }
     __syncthreads();
-    // (2) Cholesky, lower, in place (right-looking; two barriers per column)
-    for (int j = 0; j < S; ++j) {
-      const double djj = Cm[j * LDC + j];
-      if (!(djj > 0.0)) notpd = true;
-      const double d = sqrt(djj);
-      for (int i = j + tid; i < S; i += 256) col[i] = (i == j) ? d : Cm[i * LDC + j] / d;
-      __syncthreads();
-      const int ti = tid >> 4, tk = tid & 15;
-      for (int i = j + 1 + ti; i < S; i += 16) {
-        const double ci = col[i];
-        for (int k = j + 1 + tk; k <= i; k += 16) Cm[i * LDC + k] -= ci * col[k];
+    // (2) Cholesky, lower, in place.  S <= 64: left-looking inside wave 0 (lane = row; no block barriers -- with 31
+    //     factorisations per group the 2*S barriers of the block version were the largest item of an EMIT iteration);
+    //     larger S: right-looking over the whole block, two barriers per column.
+    if (S <= 64) {
+      if (wave == 0) {
+        const int i = lane < S ? lane : S - 1;
+        for (int j = 0; j < S; ++j) {
+          double sacc = Cm[i * LDC + j];
+          for (int kx = 0; kx < j; ++kx) sacc = fma(-Cm[i * LDC + kx], Cm[j * LDC + kx], sacc);
+          const double djj = __shfl(sacc, j, 64);
+          if (!(djj > 0.0)) notpd = true;
+          const double d = sqrt(djj);
+          if (lane >= j && lane < S) Cm[lane * LDC + j] = (lane == j) ? d : sacc / d;
+        }
       }
-      for (int i = j + tid; i < S; i += 256) Cm[i * LDC + j] = col[i];
       __syncthreads();
+    } else {
+      for (int j = 0; j < S; ++j) {
+        const double djj = Cm[j * LDC + j];
+        if (!(djj > 0.0)) notpd = true;
+        const double d = sqrt(djj);
+        for (int i = j + tid; i < S; i += NT) col[i] = (i == j) ? d : Cm[i * LDC + j] / d;
+        __syncthreads();
+        const int ti = tid >> 4, tk = tid & 15;
+        for (int i = j + 1 + ti; i < S; i += NT / 16) {
+          const double ci = col[i];
+          for (int kx = j + 1 + tk; kx <= i; kx += 16) Cm[i * LDC + kx] -= ci * col[kx];
+        }
+        for (int i = j + tid; i < S; i += NT) Cm[i * LDC + j] = col[i];
+        __syncthreads();
+      }
     }
     // (3) cit = C^{-1} tnew : forward and backward substitution by wave 0 (each lane owns rows lane, lane+64)
     if (wave == 0) {
@@ -217,15 +249,15 @@ __global__ __launch_bounds__(256) void k_mag1c(const Mag1cP p) {
       if (lane < S) { a0 += tnew[lane] * b0; a1 += mu[lane] * b0; a2 += mu[lane] * mu[lane]; }
       if (lane + 64 < S) { a0 += tnew[lane + 64] * b1; a1 += mu[lane + 64] * b1; a2 += mu[lane + 64] * mu[lane + 64]; }
       a0 = wave_sum_d(a0); a1 = wave_sum_d(a1); a2 = wave_sum_d(a2);
-      if (lane == 0) { red[8] = a0; red[9] = a1; red[10] = a2; }
+      if (lane == 0) { red[32] = a0; red[33] = a1; red[34] = a2; }
     }
     __syncthreads();
-    double norm = red[8];
-    const double mucit = red[9], mumu = red[10];
+    double norm = red[32];
+    const double mucit = red[33], mumu = red[34];
     if (it > 0 && norm < 1.0) norm = 1.0;               // normalizer.clamp_(min=1) (mag1c.py:264-266)
     // (5) per-pixel filter
     double lsw = 0.0, lsww = 0.0;
-    for (int q0 = tid; q0 < P; q0 += 256) {
+    for (int q0 = tid; q0 < P; q0 += NT) {
       double dot = 0.0, dmu = 0.0;
       const bool need_mu = (it == 0) && !p.albedo_override;
       for (int s0 = 0; s0 < S; s0 += 16) {            // 16 independent loads in flight per pixel, then the FMAs
@@ -258,12 +290,12 @@ __global__ __launch_bounds__(256) void k_mag1c(const Mag1cP p) {
       lsw += w; lsww += w * w;
     }
     if (it == last) break;
-    sw = block_sum1(lsw, red);
-    sww = block_sum1(lsww, red + 4);
+    sw = block_sum_n<NW>(lsw, red);
+    sww = block_sum_n<NW>(lsww, red + 16);
     __threadfence_block();
     __syncthreads();
     // (6) v = X w - xbar * sum(w);  tau <- current target
-    for (int s = wave; s < S; s += 4) {
+    for (int s = wave; s < S; s += NW) {
       double a = 0.0;
       for (int q0 = lane; q0 < P; q0 += 64 * 8) {    // 16 independent loads in flight per lane
         T xr[8]; double wr[8];
@@ -281,7 +313,7 @@ __global__ __launch_bounds__(256) void k_mag1c(const Mag1cP p) {
   const double scale = (p.num_iter >= 0 || p.apply_scaling) ? 1e5 : 1.0;
   T* mo = reinterpret_cast<T*>(p.mf_out) + po;
   T* ao = reinterpret_cast<T*>(p.alb_out) + po;
-  for (int q0 = tid; q0 < P; q0 += 256) {
+  for (int q0 = tid; q0 < P; q0 += NT) {
     mo[q0] = (T)(mfw[q0] * scale);
     ao[q0] = (T)Rw[q0];
   }
@@ -295,19 +327,6 @@ __global__ __launch_bounds__(256) void k_mag1c(const Mag1cP p) {
 //   M = [[0,-1],[-1,q]]:  (C_0 + U M U^T)^{-1} b = B0 b - B0 U (M^{-1} + U^T B0 U)^{-1} U^T B0 b
 // Per iteration: two mat-vecs (W v, W t_new; W tau is last iteration's W t_new), a 2x2 solve, two streaming passes.
 // NT threads per group (1024: the 125 KB matrix in LDS allows one work-group per CU, so the work-group itself has to fill it)
-template <int NW>
-__device__ __forceinline__ double block_sum_n(double v, double* red) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  v = wave_sum_d(v);
-  __syncthreads();
-  if (lane == 0) red[wave] = v;
-  __syncthreads();
-  double t = 0.0;
-#pragma unroll
-  for (int w = 0; w < NW; ++w) t += red[w];
-  return t;
-}
-
 template <typename T, int NT>
 __global__ __launch_bounds__(NT) void k_mag1c_fast(const Mag1cP p) {
   constexpr int NW = NT / 64;
@@ -674,12 +693,17 @@ extern "C" int sc_mag1c_groups(const sc_mag1c_args* a, sc_stream stream) {
   } else if (fast) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c_fast<float, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess) hipLaunchKernelGGL((k_mag1c_fast<float, 1024>), dim3(a->G), dim3(1024), lds, st, p);
-  } else if (a->x_is_f64) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) hipLaunchKernelGGL(k_mag1c<double>, dim3(a->G), dim3(256), lds, st, p);
   } else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) hipLaunchKernelGGL(k_mag1c<float>, dim3(a->G), dim3(256), lds, st, p);
+    // general path (alpha != 0: refactorisation every iteration).  Few bands: 512 threads (4 groups per CU);
+    // many bands: the matrix fills the LDS, one group of 1024 threads per CU
+#define SC_MAG1C_GO(T_, NT_)                                                                                                   \
+    do {                                                                                                                       \
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c<T_, NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e == hipSuccess) hipLaunchKernelGGL((k_mag1c<T_, NT_>), dim3(a->G), dim3(NT_), lds, st, p);                          \
+    } while (0)
+    if (a->S <= 64) { if (a->x_is_f64) SC_MAG1C_GO(double, 512); else SC_MAG1C_GO(float, 512); }
+    else { if (a->x_is_f64) SC_MAG1C_GO(double, 1024); else SC_MAG1C_GO(float, 1024); }
+#undef SC_MAG1C_GO
   }
   if (e != hipSuccess) { sc_set_error("sc_mag1c_groups: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return SC_ERR_LAUNCH; }
   SC_LAUNCH_OK("sc_mag1c_groups");
