@@ -281,6 +281,10 @@ int sc_mag1c_pack(const void* cube, int cube_is_f64, int S_total, int band0, int
                   const int64_t* poff, const int32_t* P, int G, void* xpacked, int out_is_f64,
                   sc_stream stream);
 /* out[pix_index[i]] = val[i]  (results back to image order; fill the rest before calling) */
+/* valid[p] = all(cube[p][band0 .. band0+S) > nodata): the default pixel mask of func_by_groups
+ * (starcop/models/mag1c.py:140-142, torch.all(x > NODATA, dim=-1)) in one pass over the pixel-major cube */
+int sc_valid_mask(const void* cube, int cube_is_f64, int S_total, int band0, int S, double nodata, int64_t npix,
+                  unsigned char* valid, sc_stream stream);
 int sc_scatter(const void* val, int val_is_f64, const int64_t* pix_index, size_t n, void* out,
                int out_is_f64, sc_stream stream);
 

@@ -105,6 +105,7 @@ SIGNATURES = {
     "sc_mag1c_workspace_doubles": (_sz, [_i, _i, C.c_int64]),
     "sc_mag1c_groups": (_i, [C.POINTER(sc_mag1c_args), _vp]),
     "sc_mag1c_pack": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "sc_valid_mask": (_i, [_vp, _i, _i, _i, _i, _d, C.c_int64, _vp, _vp]),
     "sc_scatter": (_i, [_vp, _i, _vp, _sz, _vp, _i, _vp]),
     "sc_trimmed_sum_workspace_bytes": (_sz, [_i]),
     "sc_trimmed_sums": (_i, [_vp, _i, _sz, _d, _vp, _vp, _sz, _vp]),

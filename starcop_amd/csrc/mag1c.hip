@@ -655,6 +655,26 @@ __global__ void k_scatter(const TI* __restrict__ val, const long long* __restric
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[pix[i]] = (TO)val[i];
 }
 
+// valid[p] = all(cube[p][band0 .. band0+S) > nodata)  (func_by_groups' default mask, mag1c.py:140-142) in one pass:
+// a block owns 256 consecutive pixels = one contiguous run of the pixel-major cube, read with coalesced loads
+template <typename T>
+__global__ __launch_bounds__(256) void k_valid_mask(const T* __restrict__ cube, int S_total, int band0, int S, double nodata,
+                                                    long long npix, unsigned char* __restrict__ valid) {
+  __shared__ int s_ok[256];
+  const long long p0 = (long long)blockIdx.x * 256;
+  const int np = (int)((npix - p0) < 256 ? (npix - p0) : 256);
+  s_ok[threadIdx.x] = 1;
+  __syncthreads();
+  const T* base = cube + p0 * S_total;
+  const long long n = (long long)np * S_total;
+  for (long long e = threadIdx.x; e < n; e += 256) {
+    const int q = (int)(e / S_total), b = (int)(e - (long long)q * S_total);
+    if (b >= band0 && b < band0 + S && !((double)base[e] > nodata)) s_ok[q] = 0;      // benign race: every writer stores 0
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < np) valid[p0 + threadIdx.x] = (unsigned char)s_ok[threadIdx.x];
+}
+
 size_t mag1c_lds_bytes(int S) {
   const int S16 = (S + 15) & ~15;
   const size_t stg = (size_t)S16 * 17 > 8 * 128 ? (size_t)S16 * 17 : 8 * 128;
@@ -743,5 +763,16 @@ extern "C" int sc_scatter(const void* val, int val_is_f64, const int64_t* pix_in
   else if (out_is_f64) hipLaunchKernelGGL((k_scatter<float, double>), dim3(blocks), dim3(256), 0, st, (const float*)val, px, n, (double*)out);
   else hipLaunchKernelGGL((k_scatter<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)val, px, n, (float*)out);
   SC_LAUNCH_OK("sc_scatter");
+  return SC_OK;
+}
+
+extern "C" int sc_valid_mask(const void* cube, int cube_is_f64, int S_total, int band0, int S, double nodata, int64_t npix,
+                             unsigned char* valid, sc_stream stream) {
+  SC_REQUIRE(cube && valid && S_total > 0 && band0 >= 0 && S > 0 && band0 + S <= S_total && npix >= 0, "sc_valid_mask: bad argument");
+  if (npix == 0) return SC_OK;
+  const unsigned blocks = (unsigned)((npix + 255) / 256);
+  if (cube_is_f64) hipLaunchKernelGGL(k_valid_mask<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)cube, S_total, band0, S, nodata, (long long)npix, valid);
+  else hipLaunchKernelGGL(k_valid_mask<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)cube, S_total, band0, S, nodata, (long long)npix, valid);
+  SC_LAUNCH_OK("sc_valid_mask");
   return SC_OK;
 }

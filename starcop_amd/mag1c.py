@@ -143,11 +143,15 @@ def func_by_groups(func, x, groups, mask=None, disable_pbar=True, samples_read=5
         x = x.float()
     H, W, S_total = x.shape
     b0, b1 = (0, S_total) if band_slice is None else (band_slice.start or 0, band_slice.stop or S_total)
-    groups_t = torch.as_tensor(np.asarray(groups)).to(dev).reshape(-1).long()
+    groups_t = (groups if torch.is_tensor(groups) else torch.as_tensor(np.asarray(groups))).to(dev).reshape(-1).long()
     if mask is None:
-        mask_t = torch.all(x[..., b0:b1] > NODATA, dim=-1).reshape(-1)
+        xc = x.contiguous()
+        mask_u8 = torch.empty(H * W, dtype=torch.uint8, device=dev)
+        check(_lib.load().sc_valid_mask(ptr(xc), 1 if xc.dtype == torch.float64 else 0, S_total, b0, b1 - b0, float(NODATA),
+                                        H * W, ptr(mask_u8), stream()))
+        mask_t = mask_u8.bool()
     else:
-        mask_t = torch.as_tensor(np.asarray(mask)).to(dev).reshape(-1).bool()
+        mask_t = (mask if torch.is_tensor(mask) else torch.as_tensor(np.asarray(mask))).to(dev).reshape(-1).bool()
     mf_out = torch.full((H * W,), NODATA, dtype=x.dtype, device=dev)
     alb_out = torch.full((H * W,), NODATA, dtype=x.dtype, device=dev)
     valid_idx = torch.nonzero(mask_t).reshape(-1)
