@@ -205,6 +205,9 @@ int sc_bn_bwd_reduce(const float* g, const float* y, const float* cst_fwd, int a
 /* dgamma, dbeta and the SC_SRC_BNBWD constants {scale, shift, A, B, D} */
 int sc_bn_bwd_finalize(const double* sums, int nrows, double count, const float* cst_fwd,
                        float* dgamma, float* dbeta, float* cst_bwd, int C, sc_stream stream);
+/* both steps in one launch for few-pixel layers (one block per channel over all N*HW elements); same outputs */
+int sc_bn_bwd_small(const float* g, const float* y, const float* cst_fwd, int act, int N, int C, int HW,
+                    float* dgamma, float* dbeta, float* cst_bwd, sc_stream stream);
 /* out = v(a) + v(b)   (residual add of an inverted-residual block; b may be NULL) */
 int sc_add_srcs(const sc_src* a, const sc_src* b, float* out, int N, int C, int HW, sc_stream stream);
 /* out[n,c,y,x] (+)= sum of the 2x2 block of in (backward of nearest x2 upsample) */

@@ -118,6 +118,59 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
   if (threadIdx.x < 2) sums[(stat_row() * C + c) * 2 + threadIdx.x] = v[threadIdx.x];
 }
 
+// Low-resolution layers: one block per channel walks all N*HW elements of its channel and finalises in the same launch
+// (no partial rows, no second kernel: the two-kernel form costs two ~7 us dependent launches per BatchNorm and, at 16x16 or
+// 32x32, 10^4 work-groups of a few hundred elements each).
+__global__ __launch_bounds__(256) void k_bn_bwd_small(const float* __restrict__ g, const float* __restrict__ y,
+                                                      const float* __restrict__ cst, int act, int N, int C, int HW, double count,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ cst_bwd) {
+  __shared__ double s_tmp[8];
+  const int c = blockIdx.x;
+  const float scale = cst[(size_t)c * SC_CST], shift = cst[(size_t)c * SC_CST + 1];
+  const float mean = cst[(size_t)c * SC_CST + 2], invstd = cst[(size_t)c * SC_CST + 3];
+  const float lo = sc_act_lo(act), hi = sc_act_hi(act);
+  double v[2] = {0.0, 0.0};
+  for (int n = 0; n < N; ++n) {
+    const size_t base = ((size_t)n * C + c) * HW;
+    float s1 = 0.f, s2 = 0.f;
+    if ((HW & 3) == 0) {
+      for (int i = threadIdx.x * 4; i < HW; i += 1024) {
+        const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
+        const float4 gv = *reinterpret_cast<const float4*>(g + base + i);
+        const float ya[4] = {yv.x, yv.y, yv.z, yv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float yh = fmaf(ya[k], scale, shift);
+          const float gb = (yh > lo && yh < hi) ? ga[k] : 0.f;
+          s1 += gb;
+          s2 = fmaf(gb, (ya[k] - mean) * invstd, s2);
+        }
+      }
+    } else {
+      for (int i = threadIdx.x; i < HW; i += 256) {
+        const float yv = y[base + i], gv = g[base + i];
+        const float yh = fmaf(yv, scale, shift);
+        const float gb = (yh > lo && yh < hi) ? gv : 0.f;
+        s1 += gb;
+        s2 = fmaf(gb, (yv - mean) * invstd, s2);
+      }
+    }
+    v[0] += (double)s1; v[1] += (double)s2;
+  }
+  block_sum_d<2>(v, s_tmp);
+  if (threadIdx.x != 0) return;
+  const double t1 = v[0], t2 = v[1];
+  if (dbeta) dbeta[c] = (float)t1;
+  if (dgamma) dgamma[c] = (float)t2;
+  const double c1 = t1 / count, c2 = t2 / count;
+  float* o = cst_bwd + (size_t)c * SC_CST;
+  o[0] = scale; o[1] = shift;
+  o[2] = scale;
+  o[3] = (float)(-(double)scale * c2 * (double)invstd);
+  o[4] = (float)(-(double)scale * c1 + (double)scale * c2 * (double)invstd * (double)mean);
+  o[5] = 0.f; o[6] = 0.f; o[7] = 0.f;
+}
+
 __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const double* __restrict__ sums, int nrows, double count,
                                                          const float* __restrict__ cst_fwd, float* __restrict__ dgamma,
                                                          float* __restrict__ dbeta, float* __restrict__ cst_bwd, int C) {
@@ -343,6 +396,15 @@ extern "C" int sc_bn_bwd_reduce(const float* g, const float* y, const float* cst
   dim3 grid((HW + 4095) / 4096, C, N);
   hipLaunchKernelGGL(k_bn_bwd_reduce, grid, dim3(256), 0, (hipStream_t)stream, g, y, cst_fwd, act, sums, C, HW);
   SC_LAUNCH_OK("sc_bn_bwd_reduce");
+  return SC_OK;
+}
+
+extern "C" int sc_bn_bwd_small(const float* g, const float* y, const float* cst_fwd, int act, int N, int C, int HW,
+                               float* dgamma, float* dbeta, float* cst_bwd, sc_stream stream) {
+  SC_REQUIRE(g && y && cst_fwd && cst_bwd && N > 0 && C > 0 && HW > 0, "sc_bn_bwd_small: bad argument");
+  hipLaunchKernelGGL(k_bn_bwd_small, dim3(C), dim3(256), 0, (hipStream_t)stream, g, y, cst_fwd, act, N, C, HW,
+                     (double)N * HW, dgamma, dbeta, cst_bwd);
+  SC_LAUNCH_OK("sc_bn_bwd_small");
   return SC_OK;
 }
 

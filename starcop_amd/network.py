@@ -517,6 +517,7 @@ class HyperStarcopUNet(nn.Module):
     # the CUs the small dgrad / reduce kernels of the dependency chain leave idle.
     overlap_wgrad = True
     split_bf16 = True        # 3x3 convs with >= 32 output channels on the bf16 matrix cores (three-term split, fp32 accuracy)
+    bn_small_max = 16384     # BatchNorm backward in one launch (block per channel) when a channel has at most this many elements
     precision = "fp32"       # "bf16": the same kernels with ONE bf16 term per operand (bf16 matrix math, fp32 accumulate/storage)
 
     @property
@@ -567,6 +568,10 @@ class HyperStarcopUNet(nn.Module):
 
         def bn_backward(t):
             Ho, Wo = H >> t.shift, W >> t.shift
+            if N * Ho * Wo <= self.bn_small_max and t.C >= 64:        # low-resolution layers: one launch, one block per channel
+                check(lib.sc_bn_bwd_small(ptr(plan.grad[t.name]), ptr(plan.buf[t.name]), ptr(plan.cst[t.name]), t.act, N, t.C,
+                                          Ho * Wo, ptr(gv(t.bn.weight)), ptr(gv(t.bn.bias)), ptr(plan.cstb[t.name]), st))
+                return
             check(lib.sc_bn_bwd_reduce(ptr(plan.grad[t.name]), ptr(plan.buf[t.name]), ptr(plan.cst[t.name]), t.act,
                                        ptr(plan.bsums_v[t.name]), N, t.C, Ho * Wo, st))
             check(lib.sc_bn_bwd_finalize(ptr(plan.bsums_v[t.name]), plan.brows[t.name], float(N * Ho * Wo), ptr(plan.cst[t.name]),

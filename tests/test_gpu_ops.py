@@ -403,6 +403,10 @@ def test_batchnorm_bookkeeping(hip):
     dgm, dbt, cstb = torch.empty(C_, device=DEV), torch.empty(C_, device=DEV), torch.zeros(C_, SC_CST, device=DEV)
     check(hip.sc_bn_bwd_finalize(ptr(sums), nrows, cnt, ptr(cst), ptr(dgm), ptr(dbt), ptr(cstb), C_, stream()))
     assert relerr(dgm, gamma.grad) < TOL and relerr(dbt, beta.grad) < TOL
+    # one-launch form for few-pixel layers
+    dg2, db2, cb2 = torch.empty(C_, device=DEV), torch.empty(C_, device=DEV), torch.full((C_, SC_CST), float("nan"), device=DEV)
+    check(hip.sc_bn_bwd_small(ptr(gd), ptr(yd), ptr(cst), ACT_RELU6, N, C_, H * W, ptr(dg2), ptr(db2), ptr(cb2), stream()))
+    assert relerr(dg2, gamma.grad) < TOL and relerr(db2, beta.grad) < TOL and relerr(cb2, cstb) < 1e-5
     dsrc = make_src(gd, C_, SRC_BNBWD, act=ACT_RELU6, cst=cstb, aux=yd)
     dyd = torch.empty_like(yd)
     check(hip.sc_apply_src(C.byref(dsrc), ptr(dyd), N, C_, H * W, stream()))
