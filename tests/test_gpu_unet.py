@@ -189,3 +189,39 @@ def test_bf16_precision_mode_trains_like_fp32(hip):
     assert abs(l16[0] - l32[0]) < 2e-2 * l32[0]                                    # same start, bf16 rounding only
     assert abs(l16[-1] - l32[-1]) < 0.15 * l32[-1]
     assert abs(f16 - f32) <= 0.005 + 0.02 * (1 - f32), (f16, f32)
+
+
+def test_training_trajectory_follows_the_oracle(hip):
+    """Three optimiser steps of the HIP path (fused_train_step: forward + weighted BCE + backward + fused Adam) next to the
+    CPU oracle doing ModelModule.training_step + torch.optim.Adam on the same tiles from the same weights.  Adam's first
+    steps are sign-like (m/sqrt(v) ~ +-1), so fp32 rounding differences in near-zero gradients become O(lr) parameter
+    differences and trajectories of ANY two fp32 implementations drift apart: the oracle is therefore run in fp64 as truth
+    and in fp32 as the reference path, and the HIP losses must stay as close to the truth as the fp32 oracle does
+    (<= max(5e-3, 10x its deviation) at every step, the bar of the gradient test)."""
+    B, H, W, steps = 2, 64, 64, 3
+    model, ref = make_pair(seed=11, pos_weight=1.0)
+    model.train(); ref.train()
+    ref64 = copy.deepcopy(ref).double()
+    batch = synth_batch(B, H, W, seed=12)
+    dbatch = to_dev(batch)
+    opt = model.configure_optimizers()["optimizer"]
+    xn = ref_normalize(batch["input"])
+
+    def oracle_run(net, dt):
+        o = torch.optim.Adam(net.parameters(), lr=1e-4)
+        out = []
+        for _ in range(steps):
+            logits = net(xn.to(dt))
+            loss = (F.binary_cross_entropy_with_logits(logits, batch["output"].to(dt), reduction="none") * batch["weight_loss"].to(dt)).mean()
+            o.zero_grad(); loss.backward(); o.step()
+            out.append(float(loss))
+        return out
+
+    l32 = oracle_run(ref, torch.float32)
+    l64 = oracle_run(ref64, torch.float64)
+    l_hip = [float(model.fused_train_step(dbatch, opt).item()) / (B * H * W) for _ in range(steps)]
+    for i in range(steps):
+        dev_ref = abs(l32[i] - l64[i]) / abs(l64[i])
+        dev_hip = abs(l_hip[i] - l64[i]) / abs(l64[i])
+        assert dev_hip <= max(5e-3, 10 * dev_ref), (i, l_hip[i], l32[i], l64[i])
+    assert l_hip[-1] < l_hip[0]
