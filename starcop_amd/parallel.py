@@ -45,3 +45,31 @@ def shard_range(n_items: int, rank: int, world: int):
     base, rem = divmod(n_items, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def sharded_map(fn, items: torch.Tensor, group=None, gather=True):
+    """Independent work items (inference tiles, scenes, mag1c column blocks) partitioned over the ranks -- the
+    "tile-sharded" multi-GPU mode of BASELINE configs[4].  ``items`` is a tensor whose first dimension indexes the work
+    items (identical on every rank); ``fn(items[lo:hi])`` must return a tensor whose first dimension is ``hi - lo``.
+    No collective on the data path; with ``gather`` the per-rank results are concatenated on every rank by one
+    ``all_gather`` of equally padded slabs (RCCL on GPU tensors; gloo results are staged through the host)."""
+    n = int(items.shape[0])
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_range(n, rank, world)
+    out = fn(items[lo:hi])
+    if world == 1 or not gather:
+        return out
+    slab = -(-n // world)
+    pad = torch.zeros((slab,) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
+    pad[:hi - lo] = out
+    via_host = pad.is_cuda and dist.get_backend(group) == "gloo"
+    send = pad.cpu() if via_host else pad
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send, group=group)
+    parts = []
+    for r in range(world):
+        a, b = shard_range(n, r, world)
+        parts.append(recv[r][:b - a])
+    res = torch.cat(parts, 0)
+    return res.to(out.device) if via_host else res

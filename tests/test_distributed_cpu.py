@@ -29,6 +29,12 @@ def _worker(rank, world, port, q):
         cm.update(torch.tensor([1, 0, 1, rank]), torch.tensor([1, 0, 0, 1]))
         cm.sync()
         lo, hi = shard_range(621, rank, world)
+        # tile-sharded map: 7 "tiles" over 2 ranks (4 + 3), results gathered in order on every rank
+        from starcop_amd.parallel import sharded_map
+        tiles = torch.arange(7 * 3, dtype=torch.float32).reshape(7, 3)
+        calls = []
+        got = sharded_map(lambda t: (calls.append(int(t.shape[0])) or t * 2 + 1), tiles)
+        assert torch.equal(got, tiles * 2 + 1) and calls == [4 - rank]
         q.put((rank, avg.tolist(), scale, cm.compute().tolist(), (lo, hi)))
     finally:
         dist.destroy_process_group()
