@@ -266,7 +266,7 @@ constexpr int STEM_MAXCI = 8;
 __global__ __launch_bounds__(256) void k_stem_fwd(const SrcD in, const float* __restrict__ w, float* __restrict__ out,
                                                   int Cin, int Hin, int Win, int Hout, int Wout, float* stats) {
   __shared__ float s_w[STEM_CO * STEM_MAXCI * 9];
-  __shared__ float s_red[4][STEM_CO][2];
+  __shared__ float s_red[8][STEM_CO][2];        // per half-wave partial sums (DPP reductions, no LDS crossbar traffic)
   const int n = blockIdx.z;
   for (int i = threadIdx.x; i < STEM_CO * Cin * 9; i += 256) s_w[i] = w[i];
   const int tiles_x = (Wout + 15) >> 4;
@@ -308,15 +308,17 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const SrcD in, const float* __
     if (ok) out[((size_t)n * STEM_CO + co) * HWo + (size_t)oy * Wout + ox] = acc;
     if (stats) {
       const float a = ok ? acc : 0.f;
-      const float s = wave_sum(a), ss = wave_sum(a * a);
-      if (lane == 0) { s_red[wave][co][0] = s; s_red[wave][co][1] = ss; }
+      const float s = half_sum32(a), ss = half_sum32(a * a);
+      if ((lane & 31) == SC_HALF_SUM_LANE) { s_red[wave * 2 + (lane >> 5)][co][0] = s; s_red[wave * 2 + (lane >> 5)][co][1] = ss; }
     }
   }
   if (stats) {
     __syncthreads();
     if (threadIdx.x < STEM_CO * 2) {
       const int co = threadIdx.x >> 1, k = threadIdx.x & 1;
-      const float t = s_red[0][co][k] + s_red[1][co][k] + s_red[2][co][k] + s_red[3][co][k];
+      float t = 0.f;
+#pragma unroll
+      for (int h = 0; h < 8; ++h) t += s_red[h][co][k];
       stats[(stat_row() * STEM_CO + co) * 2 + k] = t;
     }
   }
