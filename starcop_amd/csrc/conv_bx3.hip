@@ -692,10 +692,18 @@ WgradXPlan plan_wgrad_bx3(int N, int H, int W, int Cout, int Cin) {
   pl.co_tiles = (Cout + 32 * pl.wm - 1) / (32 * pl.wm);
   pl.ci_tiles = (Cin + 32 * pl.nci - 1) / (32 * pl.nci);
   const long T = (long)N * ((W + 31) / 32) * ((H + 1) / 2);
-  long want = 512 / ((long)pl.co_tiles * pl.ci_tiles);
-  if (want > T / 4) want = T / 4;
-  if (want > 512) want = 512;
-  if (want < 1) want = 1;
+  // K slices: one work-group per CU is resident (95 KB of LDS), so the launch runs in rounds of 256 work-groups.  Pick the
+  // slice count that minimises  rounds x (stages per slice + fixed prologue/epilogue), e.g.
+  // 16 tiles -> 16 slices (one full round) rather than 32; 88 tiles -> 5 slices (1.7 rounds) rather than 3 (1.03 rounds).
+  const long tiles = (long)pl.co_tiles * pl.ci_tiles;
+  const long nmax = T / 4 < 512 ? (T / 4 > 1 ? T / 4 : 1) : 512;
+  auto cost = [&](long k) { return (double)((tiles * k + 255) / 256) * ((double)((T + k - 1) / k) + 6.0); };
+  double best_cost = 1e30;
+  for (long k = 1; k <= nmax; ++k) best_cost = cost(k) < best_cost ? cost(k) : best_cost;
+  long best = 1;
+  for (long k = 1; k <= nmax; ++k)
+    if (cost(k) <= 1.03 * best_cost) { best = k; break; }        // fewest slices (least partial-sum traffic) within 3 %
+  long want = best;
   pl.nsl = (int)want;
   return pl;
 }

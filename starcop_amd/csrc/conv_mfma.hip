@@ -1000,7 +1000,7 @@ WgradPlan plan_wgrad(int N, int H, int W, int Cout, int Cin, int ks) {
     pl.CoP = 32; pl.CiP = (Cin + 31) / 32 * 32;
     pl.co_tiles = 1; pl.ci_tiles = (Cin + 16 * pl.wn - 1) / (16 * pl.wn);
     pl.stages = (long)N * ((W + 31) / 32) * ((H + 3) / 4);
-    long want = 2048 / pl.ci_tiles;
+    long want = 512 / pl.ci_tiles;       // x4 K parts per work-group: 2048 partial rows (8192 rows cost 0.6 GB of partial traffic per step)
     if (want < 1) want = 1;
     if (want > pl.stages) want = pl.stages;
     pl.nsl = (int)want;
