@@ -16,6 +16,7 @@
 // global loads for chunk k+1 issued before the MFMAs of chunk k (register staged because of the
 // prologue), one barrier per chunk.
 #include "sc_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -263,14 +264,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
 // Thin layers (Cout <= 16: decoder.blocks.4.*): the same implicit GEMM on v_mfma_f32_16x16x4_f32 so that no MFMA row is
 // wasted.  A: lane -> W[co = l&15][ci = 4*kq + (l>>4)],  B: lane -> patch[ci = 4*kq + (l>>4)][pixel = 16*pb + (l&15)],
 // D (4 regs): col = l&15 (pixel), row = 4*(l>>4) + r (cout).  Tile = 16 couts x (4 rows x 32 px), wave w owns row w.
+// RW: image rows per wave (tile = 4*RW rows x 32 px): RW = 2 halves the filter staging per pixel and the halo overhead
+template <bool BNB, int RW>
 __global__ __launch_bounds__(256, 2) void k_conv_mfma16(const ConvP p) {
   constexpr int TAPS = 9, CO_T = 16, KC = 8;
-  constexpr int PR = 6, PC = 34, PCH = PR * PC, NE = (PCH + 31) / 32;
+  constexpr int PR = 4 * RW + 2, PC = 34, PCH = PR * PC, NE = (PCH + 31) / 32;
+  constexpr int PCHP = NE * 32;                // padded channel pitch: the NE staging rounds store unconditionally
   constexpr int WCH = KC * TAPS * CO_T;        // 1152 floats per chunk
   constexpr int NW = (WCH / 4 + 255) / 256;    // 2
+  constexpr int WCHP = NW * 256 * 4;           // padded likewise
 
-  __shared__ __attribute__((aligned(16))) float s_w[2][WCH];
-  __shared__ float s_p[2][KC * PCH];
+  __shared__ __attribute__((aligned(16))) float s_w[2][WCHP];
+  __shared__ float s_p[2][KC * PCHP];
   __shared__ float s_red[4][CO_T][2];
 
   const int tid = threadIdx.x;
@@ -280,50 +285,57 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma16(const ConvP p) {
   const int H = p.H, W = p.W;
   const int tiles_x = (W + 31) >> 5;
   const int ty = blockIdx.x / tiles_x;
-  const int y0 = ty * 4, x0 = (blockIdx.x - ty * tiles_x) * 32;
+  const int y0 = ty * 4 * RW, x0 = (blockIdx.x - ty * tiles_x) * 32;
   const int C0 = p.s0.C;
   const int Cin = C0 + p.s1.C;
   const int nk = (Cin + KC - 1) / KC;
   const float* wbase = p.wpk;
 
-  floatx4 acc[2];
-  acc[0] = (floatx4){0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
+  floatx4 acc[RW][2];
+#pragma unroll
+  for (int rr = 0; rr < RW; ++rr) { acc[rr][0] = (floatx4){0.f, 0.f, 0.f, 0.f}; acc[rr][1] = acc[rr][0]; }
 
   const int sci = tid >> 5, sq = tid & 31;
-  float xv[NE], av[NE];
+  // pixel offsets of this thread's patch positions: the same for every chunk (per source: `up` may differ)
+  unsigned off0[NE], off1[NE];
   unsigned inb = 0;
-  float4 c0 = make_float4(1.f, 0.f, 0.f, 0.f);
-  float c4 = 0.f, slo = 0.f, shi = 0.f;
-  int smode = 0;
-  floatx4 wv[NW];
-
-  auto load_chunk = [&](int kc) {
-    const int cg = kc * KC + sci;
-    const bool second = cg >= C0;
-    const int cs = second ? cg - C0 : cg;
-    const float* xp = second ? p.s1.x : p.s0.x;
-    const float* ap = second ? p.s1.aux : p.s0.aux;
-    const float* cp = second ? p.s1.cst : p.s0.cst;
-    const int Cs = second ? p.s1.C : p.s0.C;
-    const int up = second ? p.s1.up : p.s0.up;
-    smode = second ? p.s1.mode : p.s0.mode;
-    const int sact = second ? p.s1.act : p.s0.act;
-    slo = sc_act_lo(sact); shi = sc_act_hi(sact);
-    if (smode != SC_SRC_RAW) { c0 = *reinterpret_cast<const float4*>(cp + (size_t)cs * SC_CST); c4 = cp[(size_t)cs * SC_CST + 4]; }
-    else { c0 = make_float4(1.f, 0.f, 0.f, 0.f); c4 = 0.f; }
-    const int Hs = H >> up, Ws = W >> up;
-    const float* xb = xp + ((size_t)n * Cs + cs) * Hs * Ws;
-    const float* ab = (smode == SC_SRC_BNBWD) ? ap + ((size_t)n * Cs + cs) * Hs * Ws : xb;
-    inb = 0;
+  {
+    const int up0 = p.s0.up, up1 = p.s1.up;
+    const int Ws0 = W >> up0, Ws1 = W >> up1;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
       const int e = sq + 32 * i;
       const int pr = e / PC, pc = e - pr * PC;
       const int y = y0 - 1 + pr, x = x0 - 1 + pc;
       const bool ok = (e < PCH) && (y >= 0) && (y < H) && (x >= 0) && (x < W);
-      const int off = ok ? (y >> up) * Ws + (x >> up) : 0;
-      xv[i] = xb[off]; av[i] = ab[off];
+      off0[i] = ok ? (unsigned)((y >> up0) * Ws0 + (x >> up0)) : 0u;
+      off1[i] = ok ? (unsigned)((y >> up1) * Ws1 + (x >> up1)) : 0u;
       inb |= ok ? (1u << i) : 0u;
+    }
+  }
+  float xv[NE], av[BNB ? NE : 1];
+  float4 c0 = make_float4(1.f, 0.f, 0.f, 0.f);
+  float c4 = 0.f, slo = 0.f, shi = 0.f;
+  bool chok = true;
+  floatx4 wv[NW];
+
+  auto load_chunk = [&](int kc) {
+    const int cg = kc * KC + sci;
+    const bool second = cg >= C0;
+    const SrcD& s = second ? p.s1 : p.s0;
+    chok = cg < Cin;
+    const int cs = chok ? (second ? cg - C0 : cg) : 0;
+    slo = sc_act_lo(s.act); shi = sc_act_hi(s.act);
+    if (s.mode != SC_SRC_RAW) { c0 = *reinterpret_cast<const float4*>(s.cst + (size_t)cs * SC_CST); c4 = BNB ? s.cst[(size_t)cs * SC_CST + 4] : 0.f; }
+    else { c0 = make_float4(1.f, 0.f, 0.f, 0.f); c4 = 0.f; }
+    const size_t plane = (size_t)(H >> s.up) * (W >> s.up);
+    const float* xb = s.x + ((size_t)n * s.C + cs) * plane;
+    const float* ab = BNB ? s.aux + ((size_t)n * s.C + cs) * plane : nullptr;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const unsigned o = second ? off1[i] : off0[i];
+      xv[i] = xb[o];
+      if (BNB) av[i] = ab[o];
     }
     const floatx4* wsrc = reinterpret_cast<const floatx4*>(wbase + (size_t)kc * WCH);
 #pragma unroll
@@ -333,24 +345,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma16(const ConvP p) {
     }
   };
   auto store_chunk = [&](int buf) {
-    if (smode == SC_SRC_BNBWD) {
 #pragma unroll
-      for (int i = 0; i < NE; ++i) {
-        const int e = sq + 32 * i;
-        if (e < PCH) s_p[buf][sci * PCH + e] = ((inb >> i) & 1u) ? sc_pro_bnbwd(xv[i], av[i], c0.x, c0.y, c0.z, c0.w, c4, slo, shi) : 0.f;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NE; ++i) {
-        const int e = sq + 32 * i;
-        if (e < PCH) s_p[buf][sci * PCH + e] = ((inb >> i) & 1u) ? sc_pro_affine(xv[i], c0.x, c0.y, slo, shi) : 0.f;
-      }
+    for (int i = 0; i < NE; ++i) {
+      const float t = BNB ? sc_pro_bnbwd(xv[i], av[BNB ? i : 0], c0.x, c0.y, c0.z, c0.w, c4, slo, shi) : sc_pro_affine(xv[i], c0.x, c0.y, slo, shi);
+      s_p[buf][sci * PCHP + sq + 32 * i] = (((inb >> i) & 1u) && chok) ? t : 0.f;
     }
 #pragma unroll
-    for (int j = 0; j < NW; ++j) {
-      const int i4 = tid + 256 * j;
-      if (i4 < WCH / 4) *reinterpret_cast<floatx4*>(&s_w[buf][i4 * 4]) = wv[j];
-    }
+    for (int j = 0; j < NW; ++j) *reinterpret_cast<floatx4*>(&s_w[buf][(tid + 256 * j) * 4]) = wv[j];
   };
   auto compute_chunk = [&](int buf) {
 #pragma unroll
@@ -361,10 +362,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma16(const ConvP p) {
         const int kh = tap / 3, kw = tap - 3 * kh;
         const float a = s_w[buf][(cil * TAPS + tap) * CO_T + l15];
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
-          const float b = s_p[buf][cil * PCH + (wave + kh) * PC + pb * 16 + l15 + kw];
-          acc[pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[pb], 0, 0, 0);
-        }
+        for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) {
+            const float b = s_p[buf][cil * PCHP + (wave * RW + rr + kh) * PC + pb * 16 + l15 + kw];
+            acc[rr][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[rr][pb], 0, 0, 0);
+          }
       }
     }
   };
@@ -380,7 +383,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma16(const ConvP p) {
     __syncthreads();
   }
 
-  const int oy = y0 + wave;
   const size_t HWs = (size_t)H * W;
   const bool want_stats = p.stats != nullptr;
 #pragma unroll
@@ -388,18 +390,22 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma16(const ConvP p) {
     const int co = 4 * lq + r;
     float s = 0.f, ss = 0.f;
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {
-      const int ox = x0 + pb * 16 + l15;
-      float v = acc[pb][r];
-      const bool ok = (oy < H) && (ox < W) && (co < p.Cout);
-      if (!ok) v = 0.f;
-      s += v; ss = fmaf(v, v, ss);
-      if (ok) {
-        const size_t idx = ((size_t)n * p.Cout + co) * HWs + (size_t)oy * W + ox;
-        if (p.add0) v += p.add0[idx];
-        if (p.add1) v += p.add1[idx];
-        if (p.accum0) v += p.out0[idx];
-        p.out0[idx] = v;
+    for (int rr = 0; rr < RW; ++rr) {
+      const int oy = y0 + wave * RW + rr;
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        const int ox = x0 + pb * 16 + l15;
+        float v = acc[rr][pb][r];
+        const bool ok = (oy < H) && (ox < W) && (co < p.Cout);
+        if (!ok) v = 0.f;
+        s += v; ss = fmaf(v, v, ss);
+        if (ok) {
+          const size_t idx = ((size_t)n * p.Cout + co) * HWs + (size_t)oy * W + ox;
+          if (p.add0) v += p.add0[idx];
+          if (p.add1) v += p.add1[idx];
+          if (p.accum0) v += p.out0[idx];
+          p.out0[idx] = v;
+        }
       }
     }
     if (want_stats) {      // 16-lane row sums (each row of 16 lanes = one cout)
@@ -409,10 +415,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma16(const ConvP p) {
     }
   }
   if (want_stats) {
+    // statistics rows keep the 4-image-row granularity of SC_STAT_CONV3: with RW = 2 a work-group writes two of them
     __syncthreads();
-    if (tid < CO_T * 2) {
-      const int co = tid >> 1, k = tid & 1;
-      if (co < p.Cout) p.stats[(stat_row() * p.Cout + co) * 2 + k] = s_red[0][co][k] + s_red[1][co][k] + s_red[2][co][k] + s_red[3][co][k];
+    const int rows4 = (H + 3) >> 2;
+    const int tx = blockIdx.x - ty * tiles_x;
+    for (int i = tid; i < RW * CO_T * 2; i += 256) {
+      const int hh = i / (CO_T * 2), rem = i - hh * (CO_T * 2);
+      const int co = rem >> 1, k2 = rem & 1;
+      const int t4 = RW * ty + hh;
+      if (co < p.Cout && t4 < rows4) {
+        float t = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < 4 / RW; ++w2) t += s_red[hh * (4 / RW) + w2][co][k2];
+        const size_t row = ((size_t)n * rows4 + t4) * tiles_x + tx;
+        p.stats[(row * p.Cout + co) * 2 + k2] = t;
+      }
     }
   }
 }
@@ -1078,7 +1095,18 @@ extern "C" int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream) {
   if (a->ks == 3) grid = dim3(((a->W + 31) / 32) * ((a->H + 3) / 4), co_tiles, a->N);
   else grid = dim3((a->H * a->W + 127) / 128, co_tiles, a->N);
   hipStream_t st = (hipStream_t)stream;
-  if (a->co_t == 16) hipLaunchKernelGGL(k_conv_mfma16, grid, dim3(256), 0, st, p);
+  if (a->co_t == 16) {
+    static const int rw = getenv("SC_THIN_RW") ? atoi(getenv("SC_THIN_RW")) : 2;
+    const bool bnb = a->src[0].mode == SC_SRC_BNBWD;
+    if (rw == 2 && a->H >= 8) {
+      dim3 g2(((a->W + 31) / 32) * ((a->H + 7) / 8), 1, a->N);
+      if (bnb) hipLaunchKernelGGL((k_conv_mfma16<true, 2>), g2, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((k_conv_mfma16<false, 2>), g2, dim3(256), 0, st, p);
+    } else {
+      if (bnb) hipLaunchKernelGGL((k_conv_mfma16<true, 1>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((k_conv_mfma16<false, 1>), grid, dim3(256), 0, st, p);
+    }
+  }
   else if (a->ks == 3 && a->co_t == 64) hipLaunchKernelGGL((k_conv_mfma<3, 2>), grid, dim3(256), 0, st, p);
   else if (a->ks == 3) hipLaunchKernelGGL((k_conv_mfma<3, 1>), grid, dim3(256), 0, st, p);
   else if (a->co_t == 64) hipLaunchKernelGGL((k_conv_mfma<1, 2>), grid, dim3(256), 0, st, p);
