@@ -30,7 +30,8 @@ struct ConvP {
   float* stats;
 };
 
-template <int KS, int RM>
+// BNB: the (single) source is a BatchNorm-backward source (dgrad launches); mixing it with other modes in a concat is not used
+template <int KS, int RM, bool BNB>
 __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
   constexpr int TAPS = KS * KS;
   constexpr int CO_T = 32 * RM;
@@ -75,30 +76,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
   // ---- staging state (registers) ----
   const int sci = tid >> 5;     // channel of the chunk this thread stages
   const int sq = tid & 31;
-  float xv[NC][NE], av[NC][NE];
-  unsigned inb = 0;                 // pixel validity is the same for every channel of the chunk
-  bool chok[NC];
-  float4 c0[NC];
-  float c4[NC];
-  int smode = 0, sact = 0;
-  floatx4 wv[NW];
-
-  float slo = 0.f, shi = 0.f;
-  auto load_chunk = [&](int kc) {
-    // the source (of a concat) is uniform per chunk: KC divides the first source's channel count when nsrc == 2
-    const bool second = kc * KC >= C0;
-    const float* xp = second ? p.s1.x : p.s0.x;
-    const float* ap = second ? p.s1.aux : p.s0.aux;
-    const float* cp = second ? p.s1.cst : p.s0.cst;
-    const int Cs = second ? p.s1.C : p.s0.C;
-    const int up = second ? p.s1.up : p.s0.up;
-    smode = second ? p.s1.mode : p.s0.mode;
-    sact = second ? p.s1.act : p.s0.act;
-    slo = sc_act_lo(sact); shi = sc_act_hi(sact);
-    const int Hs = H >> up, Ws = W >> up;
-    // per-thread pixel offsets of this tile (shared by the NC channels)
-    int off[NE];
-    inb = 0;
+  // pixel offsets of this thread's patch positions: the same for every chunk (per source: `up` may differ)
+  unsigned off0[NE], off1[NE];
+  unsigned inb = 0;
+  {
+    const int up0 = p.s0.up, up1 = p.s1.up;
+    const int Ws0 = W >> up0, Ws1 = W >> up1;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
       bool ok;
@@ -107,31 +90,48 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
         const int pr = e / PC, pc = e - pr * PC;
         const int y = y0 - 1 + pr, x = x0 - 1 + pc;
         ok = (e < PCH) && (y >= 0) && (y < H) && (x >= 0) && (x < W);
-        off[i] = ok ? (y >> up) * Ws + (x >> up) : 0;      // clamped: unconditional loads, no exec-mask branches
+        off0[i] = ok ? (unsigned)((y >> up0) * Ws0 + (x >> up0)) : 0u;      // clamped: unconditional loads, no exec-mask branches
+        off1[i] = ok ? (unsigned)((y >> up1) * Ws1 + (x >> up1)) : 0u;
       } else {
         const int pix = p0 + sq + 32 * i;
         ok = pix < H * W;
-        off[i] = ok ? pix : 0;
+        off0[i] = ok ? (unsigned)pix : 0u;
+        off1[i] = off0[i];
       }
       inb |= ok ? (1u << i) : 0u;
     }
+  }
+  float xv[NC][NE], av[BNB ? NC : 1][NE];
+  bool chok[NC];
+  float4 c0[NC];
+  float c4[NC];
+  floatx4 wv[NW];
+  float slo = 0.f, shi = 0.f;
+
+  auto load_chunk = [&](int kc) {
+    // the source (of a concat) is uniform per chunk: KC divides the first source's channel count when nsrc == 2
+    const bool second = kc * KC >= C0;
+    const SrcD& s = second ? p.s1 : p.s0;
+    slo = sc_act_lo(s.act); shi = sc_act_hi(s.act);
+    const size_t plane = (size_t)(H >> s.up) * (W >> s.up);
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc) {
       const int cg = kc * KC + sci + 8 * cc;          // channel in concat space
       chok[cc] = cg < Cin;
       const int cs = chok[cc] ? (second ? cg - C0 : cg) : 0;
-      if (smode != SC_SRC_RAW) {
-        c0[cc] = *reinterpret_cast<const float4*>(cp + (size_t)cs * SC_CST);
-        c4[cc] = cp[(size_t)cs * SC_CST + 4];
+      if (s.mode != SC_SRC_RAW) {
+        c0[cc] = *reinterpret_cast<const float4*>(s.cst + (size_t)cs * SC_CST);
+        c4[cc] = BNB ? s.cst[(size_t)cs * SC_CST + 4] : 0.f;
       } else {
         c0[cc] = make_float4(1.f, 0.f, 0.f, 0.f); c4[cc] = 0.f;
       }
-      const float* xb = xp + ((size_t)n * Cs + cs) * Hs * Ws;
-      const float* ab = (smode == SC_SRC_BNBWD) ? ap + ((size_t)n * Cs + cs) * Hs * Ws : xb;
+      const float* xb = s.x + ((size_t)n * s.C + cs) * plane;
+      const float* ab = BNB ? s.aux + ((size_t)n * s.C + cs) * plane : nullptr;
 #pragma unroll
       for (int i = 0; i < NE; ++i) {
-        xv[cc][i] = xb[off[i]];
-        av[cc][i] = ab[off[i]];
+        const unsigned o = second ? off1[i] : off0[i];
+        xv[cc][i] = xb[o];
+        if (BNB) av[cc][i] = ab[o];
       }
     }
     const floatx4* wsrc = reinterpret_cast<const floatx4*>(wbase + (size_t)kc * WCH);
@@ -146,23 +146,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc) {
       const int chl = sci + 8 * cc;
-      if (smode == SC_SRC_BNBWD) {
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-          const int e = sq + 32 * i;
-          if (e < PCH) {
-            const float v = sc_pro_bnbwd(xv[cc][i], av[cc][i], c0[cc].x, c0[cc].y, c0[cc].z, c0[cc].w, c4[cc], slo, shi);
-            s_p[buf][chl * PCH + e] = (((inb >> i) & 1u) && chok[cc]) ? v : 0.f;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < NE; ++i) {
-          const int e = sq + 32 * i;
-          if (e < PCH) {
-            const float v = sc_pro_affine(xv[cc][i], c0[cc].x, c0[cc].y, slo, shi);
-            s_p[buf][chl * PCH + e] = (((inb >> i) & 1u) && chok[cc]) ? v : 0.f;
-          }
+      for (int i = 0; i < NE; ++i) {
+        const int e = sq + 32 * i;
+        if (e < PCH) {
+          const float v = BNB ? sc_pro_bnbwd(xv[cc][i], av[BNB ? cc : 0][i], c0[cc].x, c0[cc].y, c0[cc].z, c0[cc].w, c4[cc], slo, shi)
+                              : sc_pro_affine(xv[cc][i], c0[cc].x, c0[cc].y, slo, shi);
+          s_p[buf][chl * PCH + e] = (((inb >> i) & 1u) && chok[cc]) ? v : 0.f;
         }
       }
     }
@@ -1083,6 +1073,7 @@ extern "C" int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream) {
     SC_REQUIRE(a->src[s].up == 0 || (a->ks == 3 && a->H % 2 == 0 && a->W % 2 == 0), "sc_conv2d_mfma: upsampled source needs ks=3 and even H,W");
     SC_REQUIRE(a->src[s].mode == SC_SRC_RAW || a->src[s].cst != nullptr, "sc_conv2d_mfma: source %d needs constants", s);
     SC_REQUIRE(a->src[s].mode != SC_SRC_BNBWD || a->src[s].aux != nullptr, "sc_conv2d_mfma: BNBWD source needs aux");
+    SC_REQUIRE(a->src[s].mode != SC_SRC_BNBWD || a->nsrc == 1, "sc_conv2d_mfma: a BNBWD source cannot be part of a concat");
   }
   ConvP p;
   p.s0 = to_srcd(a->src[0]);
@@ -1107,10 +1098,19 @@ extern "C" int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream) {
       else hipLaunchKernelGGL((k_conv_mfma16<false, 1>), grid, dim3(256), 0, st, p);
     }
   }
-  else if (a->ks == 3 && a->co_t == 64) hipLaunchKernelGGL((k_conv_mfma<3, 2>), grid, dim3(256), 0, st, p);
-  else if (a->ks == 3) hipLaunchKernelGGL((k_conv_mfma<3, 1>), grid, dim3(256), 0, st, p);
-  else if (a->co_t == 64) hipLaunchKernelGGL((k_conv_mfma<1, 2>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((k_conv_mfma<1, 1>), grid, dim3(256), 0, st, p);
+  else {
+    const bool bnb = a->src[0].mode == SC_SRC_BNBWD;
+#define SC_CM(KS_, RM_)                                                                               \
+    do {                                                                                              \
+      if (bnb) hipLaunchKernelGGL((k_conv_mfma<KS_, RM_, true>), grid, dim3(256), 0, st, p);          \
+      else hipLaunchKernelGGL((k_conv_mfma<KS_, RM_, false>), grid, dim3(256), 0, st, p);             \
+    } while (0)
+    if (a->ks == 3 && a->co_t == 64) SC_CM(3, 2);
+    else if (a->ks == 3) SC_CM(3, 1);
+    else if (a->co_t == 64) SC_CM(1, 2);
+    else SC_CM(1, 1);
+#undef SC_CM
+  }
   SC_LAUNCH_OK("sc_conv2d_mfma");
   return SC_OK;
 }
