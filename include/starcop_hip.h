@@ -116,6 +116,9 @@ typedef struct sc_conv_args {
   const float* add1;     /*   (only valid with csplit == Cout)                   */
   float* stats;          /* [rows][Cout][2] partial sums or NULL                 */
   int32_t terms;         /* sc_conv3x3_bx3 only: bf16 terms per operand, 0 or 3 = fp32-accurate split, 1 = plain bf16 */
+  int32_t down0;         /* sc_conv3x3_bx3 only: 1 = channels [0,csplit) are stored 2x2-summed at half resolution into out0
+                          * ([N,csplit,H/2,W/2]): the backward of F.interpolate(scale_factor=2, mode="nearest") in
+                          * smp's DecoderBlock fused into the data-gradient store (no full-resolution temporary) */
 } sc_conv_args;
 int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream);
 /* 1x1 convolution for few-pixel / long-K layers (the <= 64^2 inverted-residual projections and the data gradients of the

@@ -36,7 +36,7 @@ class sc_conv_args(C.Structure):
                 ("ks", C.c_int32), ("co_t", C.c_int32),
                 ("out0", C.c_void_p), ("out1", C.c_void_p),
                 ("csplit", C.c_int32), ("accum0", C.c_int32), ("accum1", C.c_int32),
-                ("add0", C.c_void_p), ("add1", C.c_void_p), ("stats", C.c_void_p), ("terms", C.c_int32)]
+                ("add0", C.c_void_p), ("add1", C.c_void_p), ("stats", C.c_void_p), ("terms", C.c_int32), ("down0", C.c_int32)]
 
 
 class sc_wgrad_args(C.Structure):

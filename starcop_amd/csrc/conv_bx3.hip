@@ -39,6 +39,7 @@ struct ConvXP {
   int csplit, accum0, accum1;
   const float* add0; const float* add1;
   float* stats;
+  int down0;
 };
 
 // exact three-term bf16 split of two floats; returns packed pairs (low half = first value)
@@ -342,6 +343,20 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
       const int col = q * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
       const int co = cot * CO_T + col;
       float sv = 0.f, sq = 0.f;
+      if (p.down0 && co < p.csplit) {
+        // backward of nearest x2 upsampling fused into the store: the wave's two rows are a vertical pixel pair, adjacent
+        // lanes a horizontal one -> sum the 2x2 block and store it at half resolution (no full-resolution temporary)
+        const int oy = y0 + 2 * wave;
+        float v = ((oy < H) && (ox < W)) ? acc[0][q][r] : 0.f;
+        v += ((oy + 1 < H) && (ox < W)) ? acc[1][q][r] : 0.f;
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+        if (!(l31 & 1) && oy < H && ox < W) {
+          const size_t idx = (((size_t)n * p.csplit + co) * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1);
+          if (p.accum0) v += p.out0[idx];
+          p.out0[idx] = v;
+        }
+        continue;
+      }
 #pragma unroll
       for (int pp = 0; pp < 2; ++pp) {
         const int oy = y0 + 2 * wave + pp;
@@ -816,6 +831,9 @@ extern "C" int sc_conv3x3_bx3(const sc_conv_args* a, sc_stream stream) {
   p.wpk = reinterpret_cast<const uintx4*>(a->wpk); p.N = a->N; p.H = a->H; p.W = a->W; p.Cout = a->Cout;
   p.out0 = a->out0; p.out1 = a->out1; p.csplit = a->csplit; p.accum0 = a->accum0; p.accum1 = a->accum1;
   p.add0 = a->add0; p.add1 = a->add1; p.stats = a->stats;
+  p.down0 = a->down0 ? 1 : 0;
+  SC_REQUIRE(!p.down0 || (a->H % 2 == 0 && a->W % 2 == 0 && a->stats == nullptr && a->add0 == nullptr && a->add1 == nullptr),
+             "sc_conv3x3_bx3: down0 (2x2-summed half-resolution out0) needs even H, W and no stats/add tensors");
   const int co_tiles = (a->Cout + a->co_t - 1) / a->co_t;
   dim3 grid(((a->W + 31) / 32) * ((a->H + 7) / 8), co_tiles, a->N);
   hipStream_t st = (hipStream_t)stream;

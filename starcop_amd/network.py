@@ -671,8 +671,14 @@ class HyperStarcopUNet(nn.Module):
                            4.0 * (2 * N * o.C * Ho * Wo + N * conv.in_channels * Ho * Wo + conv.weight.numel()))
             if op.get("up"):
                 t_up = ins[0]
-                a.out0 = plan.up_tmp.data_ptr()
+                fused_down = conv_dgrad is lib.sc_conv3x3_bx3      # the split-bf16 kernel stores the 2x2 sums itself
                 a.csplit = t_up.C
+                if fused_down:
+                    a.out0 = plan.grad[t_up.name].data_ptr()
+                    a.accum0 = 1 if t_up.name in written else 0
+                    a.down0 = 1
+                else:
+                    a.out0 = plan.up_tmp.data_ptr()
                 if len(ins) == 2:
                     t_sk = ins[1]
                     a.out1 = plan.grad[t_sk.name].data_ptr()
@@ -682,8 +688,9 @@ class HyperStarcopUNet(nn.Module):
                     a.out1 = None
                 check(conv_dgrad(C.byref(a), st))
                 self._pe(tok)
-                check(lib.sc_downsum2x2(ptr(plan.up_tmp), ptr(plan.grad[t_up.name]), 1 if t_up.name in written else 0,
-                                        N, t_up.C, Ho // 2, Wo // 2, st))
+                if not fused_down:
+                    check(lib.sc_downsum2x2(ptr(plan.up_tmp), ptr(plan.grad[t_up.name]), 1 if t_up.name in written else 0,
+                                            N, t_up.C, Ho // 2, Wo // 2, st))
                 written.add(t_up.name)
             else:
                 tin = ins[0]

@@ -42,7 +42,7 @@ def pack_bx3(w, co_t, tflip, terms=3):
 
 
 def conv_mfma(srcs, wpk, N, H, W, Cout, ks, co_t, want_stats=False, csplit=None, add0=None, add1=None,
-              accum=None, outs=None, bx3=False, ksplit=False, terms=0):
+              accum=None, outs=None, bx3=False, ksplit=False, terms=0, down0=False):
     lib = _lib.load()
     a = sc_conv_args()
     a.nsrc = len(srcs)
@@ -52,13 +52,14 @@ def conv_mfma(srcs, wpk, N, H, W, Cout, ks, co_t, want_stats=False, csplit=None,
     a.N, a.H, a.W, a.Cout, a.ks, a.co_t = N, H, W, Cout, ks, co_t
     csplit = Cout if csplit is None else csplit
     if outs is None:
-        outs = [torch.empty(N, csplit, H, W, device=DEV)]
+        outs = [torch.empty(N, csplit, H // 2, W // 2, device=DEV) if down0 else torch.empty(N, csplit, H, W, device=DEV)]
         if csplit < Cout:
             outs.append(torch.empty(N, Cout - csplit, H, W, device=DEV))
     a.out0 = outs[0].data_ptr()
     a.out1 = outs[1].data_ptr() if len(outs) > 1 else None
     a.csplit = csplit
     a.terms = terms
+    a.down0 = 1 if down0 else 0
     a.accum0, a.accum1 = (accum or (0, 0))
     a.add0 = add0.data_ptr() if add0 is not None else None
     a.add1 = add1.data_ptr() if add1 is not None else None

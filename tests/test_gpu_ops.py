@@ -266,6 +266,27 @@ def test_conv_bf16_single_term(hip, cin, cout, co_t, H, W):
         assert relerr(dw, wz.grad) < 5e-6
 
 
+@pytest.mark.parametrize("cin,cout,cs,H,W,co_t", [(80, 32, 64, 16, 64, 64), (152, 64, 128, 24, 40, 64), (32, 16, 32, 20, 36, 32), (288, 128, 256, 8, 12, 64)])
+def test_conv_bx3_dgrad_fused_upsample_backward(hip, cin, cout, cs, H, W, co_t):
+    """decoder conv1 data gradient: channels [0, cs) belong to the nearest-x2-upsampled input -> stored as 2x2 sums at half
+    resolution (== F.interpolate backward), the skip channels at full resolution; with and without accumulation."""
+    N = 2
+    g = rnd(N, cout, H, W, seed=1)
+    w = rnd(cout, cin, 3, 3, seed=3, scale=0.2)
+    ref = F.conv_transpose2d(g.double(), w.double(), padding=1)
+    ref_up = F.avg_pool2d(ref[:, :cs], 2) * 4
+    src = make_src(dev(g), cout, SRC_RAW)
+    wpk = pack_bx3(dev(w), co_t, 1)
+    if cs < cin:
+        outs, _ = conv_mfma([src], wpk, N, H, W, cin, 3, co_t, csplit=cs, bx3=True, down0=True)
+        assert relerr(outs[0], ref_up) < 1e-5 and relerr(outs[1], ref[:, cs:]) < 1e-5
+    old = rnd(N, cs, H // 2, W // 2, seed=5)
+    o0 = dev(old).clone()
+    extra = [torch.empty(N, cin - cs, H, W, device=DEV)] if cs < cin else []
+    conv_mfma([src], wpk, N, H, W, cin, 3, co_t, csplit=cs, bx3=True, down0=True, accum=(1, 0), outs=[o0] + extra)
+    assert relerr(o0, ref_up + old.double()) < 1e-5
+
+
 @pytest.mark.parametrize("cin,cout,H,W,two", [(16, 64, 32, 32, False), (32, 16, 36, 70, True), (32, 32, 24, 40, False), (48, 40, 21, 32, False), (32, 64, 16, 32, True),
                                                (80, 32, 20, 36, True), (152, 64, 8, 64, True), (256, 256, 4, 6, False), (72, 136, 10, 33, False)])
 def test_conv_bx3_wgrad(hip, cin, cout, H, W, two):
