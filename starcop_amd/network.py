@@ -667,8 +667,11 @@ class HyperStarcopUNet(nn.Module):
             a.add0 = None; a.add1 = None; a.stats = None
             a.accum0 = a.accum1 = 0
             # algorithmic bytes of the data gradient: g and y of the output once each, the input gradient once, the filter
+            gin_elems = N * conv.in_channels * Ho * Wo
+            if op.get("up") and ent["bx3_b"]:      # the upsampled source's gradient is stored 2x2-summed (quarter size)
+                gin_elems -= N * ins[0].C * Ho * Wo * 3 // 4
             tok = self._pb("k_conv3_bx3 (fwd+dgrad)" if ent["bx3_b"] else f"k_conv_mfma<{ks}> (fwd+dgrad)", flop,
-                           4.0 * (2 * N * o.C * Ho * Wo + N * conv.in_channels * Ho * Wo + conv.weight.numel()))
+                           4.0 * (2 * N * o.C * Ho * Wo + gin_elems + conv.weight.numel()))
             if op.get("up"):
                 t_up = ins[0]
                 fused_down = conv_dgrad is lib.sc_conv3x3_bx3      # the split-bf16 kernel stores the 2x2 sums itself
