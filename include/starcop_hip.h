@@ -310,6 +310,26 @@ int sc_band_ratio(const float* background, const float* signal, float* out, int 
 int sc_clip_scale(const float* x, float* out, size_t n, float div, float lo, float hi, float mult,
                   int nan_to_num, sc_stream stream);
 
+/* ------------------------------------------------------------------------- */
+/* evaluation masks of the baselines and of run_validation.
+ * Thresholded prediction with an optional binary opening by a 3x3 structuring element:
+ *   starcop/baselines.py:25-27 binary_opening = dilation(erosion(x)) ; :53-57 Mag1cBaseline.apply_threshold (pred > thr, cross SE)
+ * kornia.morphology.{erosion,dilation} (third-party, absent from /root/reference: restated from its published algorithm,
+ * border_type='geodesic', engine='unfold'): erosion = min over the SE's set cells, pixels outside the image never lower the
+ * minimum; dilation = max over the cells of the SE flipped in both axes, pixels outside never raise the maximum.
+ * se_bits: bit (3*r + c) set <=> SE[r][c] != 0; 0 = no morphology (plain pred > thr); the cross of the reference is 0xBA.
+ *   sc_binary_opening      : out[n][h][w] (int64) = opening(pred > thr); tile_count[n] += sum(out[n]) if not NULL
+ *   sc_threshold_confusion : for T <= 32 thresholds at once (validation.py:38,121-127: the PR curve; T = 1: the per-tile
+ *                            matrix :106) cm[n][t][2*target + p] += 1, p = the mask above at thresholds[t] (host array),
+ *                            target = (int64)target_f32 in {0, 1} (other values are counted in *invalid and skipped);
+ *                            pixels with ignore[i] != 0 are skipped (validation.py:84-100 mask_from_magic).            */
+#define SC_SE_CROSS 0xBA
+int sc_binary_opening(const float* pred, float threshold, int se_bits, int64_t* out, int64_t* tile_count,
+                      int N, int H, int W, sc_stream stream);
+int sc_threshold_confusion(const float* pred, const float* target, const unsigned char* ignore,
+                           const float* thresholds, int T, int se_bits, int64_t* cm, int64_t* invalid,
+                           int N, int H, int W, sc_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,3 +93,89 @@ def emit_rescale(mf, rgb):
     out[0] = np.clip(mf[:h, :w] / 240., 0., 2.) * 1750.
     out[1:] = np.clip(rgb[:, :h, :w] / 20., 0., 2.) * 60.
     return np.nan_to_num(out)
+
+
+# ---- evaluation masks / run_validation -----------------------------------------------------------
+# starcop/baselines.py:25-57 (binary_opening, Mag1cBaseline.apply_threshold) and starcop/validation.py:26-224.
+# kornia (the reference's morphology backend) and torchmetrics are absent from this image and validation.py does not
+# import without them: PARITY UNPINNED against the reference itself for this block; the opening is cross-checked against
+# scipy.ndimage (tests/test_oracle.py) and the metric formulas are the golden-pinned ones above (g7_metrics).
+def binary_opening(mask, se):
+    """dilation(erosion(mask)) for a (H,W) boolean mask and a 3x3 structuring element, kornia 'geodesic' borders:
+    outside pixels are +inf for the erosion and -inf for the dilation; the dilation uses the SE flipped in both axes."""
+    mask = np.asarray(mask, dtype=bool)
+    se = np.asarray(se) != 0
+    H, W = mask.shape
+    pad = np.ones((H + 2, W + 2), dtype=bool)
+    pad[1:-1, 1:-1] = mask
+    er = np.ones((H, W), dtype=bool)
+    for r in range(3):
+        for c in range(3):
+            if se[r, c]:
+                er &= pad[r:r + H, c:c + W]
+    pad = np.zeros((H + 2, W + 2), dtype=bool)
+    pad[1:-1, 1:-1] = er
+    di = np.zeros((H, W), dtype=bool)
+    sef = se[::-1, ::-1]
+    for r in range(3):
+        for c in range(3):
+            if sef[r, c]:
+                di |= pad[r:r + H, c:c + W]
+    return di
+
+
+def confusion(pred_binary, target, ignore=None):
+    """[[TN, FP], [FN, TP]] int64, cm[target, prediction]."""
+    p = np.asarray(pred_binary).astype(np.int64).reshape(-1)
+    t = np.asarray(target).astype(np.int64).reshape(-1)
+    if ignore is not None:
+        keep = np.asarray(ignore).reshape(-1) == 0
+        p, t = p[keep], t[keep]
+    return np.bincount(t * 2 + p, minlength=4).reshape(2, 2)
+
+
+def apply_threshold(pred, thr, se=None):
+    m = np.asarray(pred, dtype=np.float32) > np.float32(thr)
+    return binary_opening(m, se) if se is not None else m
+
+
+def run_validation(preds, pred_binaries, labels, thresholds=None, se=None, ignores=None):
+    """Per-tile rows and aggregated metrics of validation.py:26-224 from per-tile arrays: ``preds`` float (H,W) scores,
+    ``pred_binaries`` the model's own masks, ``labels`` {0,1}.  Returns (rows: list of dict, metrics: dict)."""
+    if thresholds is None:
+        thresholds = [0, 1e-3, 1e-2] + np.arange(0.5, .96, .05).tolist() + [.99, .995, .999]
+    thresholds = np.sort(thresholds)[::-1]
+    rows, agg = [], np.zeros((2, 2), np.int64)
+    cm_thr = np.zeros((len(thresholds), 2, 2), np.int64)
+    for i, (p, pb, y) in enumerate(zip(preds, pred_binaries, labels)):
+        cm = confusion(pb, y, None if ignores is None else ignores[i])
+        agg += cm
+        row = {k: v for k, v in metrics(cm.astype(np.float64)).items()}
+        row.update(TP=int(cm[1, 1]), TN=int(cm[0, 0]), FP=int(cm[0, 1]), FN=int(cm[1, 0]))
+        npl = int(np.asarray(y).astype(np.int64).sum())
+        H, W = np.asarray(pb).shape
+        row.update(label_pixels_plume=npl, has_plume=npl > 0, difficulty="easy" if npl > 1000 else "hard",
+                   pred_pixels_plume=int(np.asarray(pb).sum()),
+                   pred_classification=int(np.asarray(pb).sum() > 10 * H * W / 64 ** 2))
+        rows.append(row)
+        for k, thr in enumerate(thresholds):
+            cm_thr[k] += confusion(apply_threshold(p, thr, se), y)
+    out = {"confusion_matrix": agg}
+    out.update(metrics(agg.astype(np.float64)))
+
+    def group(has, diff):
+        sel = [r for r in rows if r["has_plume"] == has and r["difficulty"] == diff]
+        return {k: sum(r[k] for r in sel) for k in ("TP", "FP", "TN", "FN")}
+    total = sum(r["TP"] + r["FP"] + r["TN"] + r["FN"] for r in rows)
+    g = group(False, "hard")
+    out["FPR_no_plume"] = g["FP"] / (g["FP"] + g["TN"])
+    for d in ("easy", "hard"):
+        g = group(True, d)
+        m = metrics(np.array([[g["TN"], g["FP"]], [g["FN"], g["TP"]]], np.float64))
+        out.update({f"{k}_{d}": v for k, v in m.items()})
+        out[f"frac_total_{d}"] = sum(g.values()) / total
+    ccm = confusion([r["pred_classification"] for r in rows], [int(r["has_plume"]) for r in rows])
+    out["classification_confusion_matrix"] = ccm
+    out.update({f"classification_{k}": v for k, v in metrics(ccm.astype(np.float64)).items()})
+    out["thresholded"] = [dict(threshold=float(t), confusion_matrix=cm_thr[k]) for k, t in enumerate(thresholds)]
+    return rows, out

@@ -348,6 +348,10 @@ class ModelModule(_Base):
     def apply_threshold(self, pred, threshold):
         return (pred > threshold).long()
 
+    def threshold_spec(self) -> int:
+        """``apply_threshold`` is a plain ``pred > threshold`` (no morphology): see validation.run_validation."""
+        return 0
+
     # ---------------------------------------------------------------------------------------------
     def predict(self, tensor: np.ndarray) -> np.ndarray:
         """np (C,H,W) raw products -> np (H,W) plume probability, any H,W (reflect-padded to x32); the
