@@ -31,3 +31,52 @@ def test_bench_two_ranks_one_gpu(hip):
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["value"] > 0
     assert rec["roofline"]["frac"] > 0 and "cpu_baseline" not in rec
     assert not [l for l in outs[0][0].splitlines() if l.startswith("{")]          # rank 1 prints nothing
+
+
+_RCCL_WORLD1 = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["SC_ROOT"])
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=dev)                       # the call bench.py makes for N > 1
+from bench import synth_batch
+from starcop_amd import model_module as mm
+from starcop_amd.parallel import GradSync, broadcast_parameters
+from starcop_amd import metrics as M
+torch.manual_seed(1234)
+model = mm.ModelModule(mm.default_settings(pos_weight=1)).to(dev).train()
+opt = model.configure_optimizers()["optimizer"]
+broadcast_parameters(model.network)
+batch = synth_batch(2, 128, 128, 1234, dev)
+
+
+class Forced(GradSync):                                              # world 1, but the collective is issued
+    def __call__(self, flat):
+        self.seen = float(flat.abs().sum())
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        self.after = float(flat.abs().sum())
+        return 1.0
+
+
+sync = Forced(1)
+l0 = float(model.fused_train_step(batch, opt, grad_sync=sync))
+assert sync.seen > 0 and sync.seen == sync.after, (sync.seen, sync.after)
+l1 = float(model.fused_train_step(batch, opt, grad_sync=sync))
+dist.barrier()
+t = torch.tensor([1.5], device=dev, dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+cm = M.BinaryConfusionMatrix(); cm.update(torch.tensor([1, 0, 1], device=dev), torch.tensor([1, 0, 0], device=dev)); cm.sync()
+assert int(cm.compute().sum()) == 3 and float(t) == 1.5 and l1 == l1
+dist.destroy_process_group()
+print("RCCL_WORLD1_OK", l0, l1)
+"""
+
+
+def test_rccl_world1_collectives(hip):
+    """RCCL itself on the one GPU of the box: process-group init with device_id, broadcast of the flat parameter buffer,
+    in-place all_reduce of the flat gradient buffer between backward and Adam, barrier, MAX of the timing scalar and the
+    confusion-matrix sum -- every collective call of the N>1 path, executed by the real backend."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               SC_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", _RCCL_WORLD1], env=env, capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert p.returncode == 0 and "RCCL_WORLD1_OK" in p.stdout, (p.stdout[-500:], p.stderr[-1500:])
