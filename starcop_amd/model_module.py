@@ -388,10 +388,19 @@ class ModelModule(_Base):
         plan.loss_acc.zero_()
         check(lib.sc_bce_logits_weighted(ptr(logits), ptr(y), ptr(w), self.loss_function.pos_weight_host(), logits.numel(),
                                          ptr(plan.loss_acc), ptr(plan.dlogits), None, stream()))
-        net._backward_impl(plan, plan.dlogits)
         scale = 1.0
-        if grad_sync is not None:
-            scale = grad_sync(net.flat_grads())
+        if grad_sync is not None and hasattr(grad_sync, "begin"):
+            # two buckets: decoder + head gradients are reduced while the encoder's backward runs, the rest afterwards
+            started = []
+            g = net.flat_grads()
+            net._backward_impl(plan, plan.dlogits,
+                               on_tail_ready=lambda lo, hi: started.append((lo, grad_sync.begin(g[lo:hi]))))
+            lo = started[0][0] if started else g.numel()
+            scale = grad_sync.finish(g[:lo], [h for _, h in started])
+        else:
+            net._backward_impl(plan, plan.dlogits)
+            if grad_sync is not None:
+                scale = grad_sync(net.flat_grads())
         optimizer.step_flat(grad_scale=scale)
         plan.loss_n = logits.numel()
         return plan.loss_acc   # device double: sum of weighted per-pixel losses; divide by plan.loss_n for the mean

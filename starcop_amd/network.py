@@ -527,8 +527,13 @@ class HyperStarcopUNet(nn.Module):
         return 1 if self.precision == "bf16" else 3
     _side_stream = None
 
-    def _backward_impl(self, plan, dlogits):
-        """Fills the flat gradient buffer from dL/dlogits.  Needs the plan of a training-mode forward."""
+    def _backward_impl(self, plan, dlogits, on_tail_ready=None):
+        """Fills the flat gradient buffer from dL/dlogits.  Needs the plan of a training-mode forward.
+
+        ``on_tail_ready(lo, hi)`` is called once, when the walk leaves the decoder: every gradient of the decoder and head
+        parameters (flat range [lo, hi), two thirds of the buffer) has been queued, so a data-parallel caller can start
+        reducing that bucket while the encoder's backward still runs.  It is called with the weight-gradient stream
+        current (ordered after the main stream), i.e. a collective issued inside it waits for both."""
         lib = _lib.load()
         st = stream()
         main = torch.cuda.current_stream()
@@ -577,11 +582,21 @@ class HyperStarcopUNet(nn.Module):
             check(lib.sc_bn_bwd_finalize(ptr(plan.bsums_v[t.name]), plan.brows[t.name], float(N * Ho * Wo), ptr(plan.cst[t.name]),
                                          ptr(gv(t.bn.weight)), ptr(gv(t.bn.bias)), ptr(plan.cstb[t.name]), t.C, st))
 
+        tail_lo = sum(p.numel() for p in self.encoder.parameters())
+        tail_pending = on_tail_ready is not None
         for i in range(len(self._ops) - 1, -1, -1):
             op = self._ops[i]
             ty, o = op["type"], op["out"]
             Ho, Wo = H >> o.shift, W >> o.shift
             conv = op.get("conv")
+            if tail_pending and (conv is None or (conv.weight.data_ptr() - self._pflat.data_ptr()) // 4 < tail_lo):
+                tail_pending = False            # first encoder op: the decoder/head bucket is complete
+                if side is not None:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        on_tail_ready(tail_lo, self._gflat.numel())
+                else:
+                    on_tail_ready(tail_lo, self._gflat.numel())
             self._cur_op = o.name + ":bwd"
             if ty == "head":
                 tin = op["ins"][0]

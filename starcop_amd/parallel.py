@@ -3,10 +3,12 @@
 The reference has no collective of its own; with ``training.devices > 1`` Lightning wraps the module in DDP
 (SURVEY.md section 5): per-step gradient AVERAGE over ranks, BatchNorm statistics stay rank-local (no SyncBN),
 confusion matrices are summed at epoch end.  Here the whole gradient lives in one flat fp32 buffer
-(6 629 233 floats = 26.5 MB), so the exchange is a single in-place ``all_reduce(SUM)`` on the compute stream and
-the 1/world average is folded into the fused Adam kernel (``grad_scale``) -- no bucket copies, no extra pass.
-xGMI is point-to-point (7 links x ~153 GB/s per GPU): one large message lets RCCL use all links at once;
-26.5 MB costs ~0.1-0.3 ms against a >=15 ms step, so it is not overlapped with backward yet.
+(6 629 233 floats = 26.5 MB) laid out [encoder | decoder | head], so the exchange is in-place ``all_reduce(SUM)`` on
+slices of it -- no bucket copies, no extra pass -- and the 1/world average is folded into the fused Adam kernel
+(``grad_scale``).  Two buckets: the decoder + head slice (17.7 MB, complete when the backward walk leaves the decoder)
+is reduced asynchronously on RCCL's stream while the encoder's backward runs; the encoder slice (8.8 MB) follows when
+the walk ends.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): few large messages let RCCL use all links at
+once, which is why there are two buckets and not DDP's 25 MB / per-layer granularity.
 """
 import torch
 import torch.distributed as dist
@@ -17,10 +19,13 @@ class GradSync:
         self.group = group
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
 
+    def _host_staged(self, t):
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+
     def __call__(self, flat_grads: torch.Tensor) -> float:
         """Sum ``flat_grads`` over ranks in place; returns the scale (1/world) the optimiser must apply."""
-        if self.world > 1:
-            if flat_grads.is_cuda and dist.get_backend(self.group) == "gloo":
+        if self.world > 1 and flat_grads.numel():
+            if self._host_staged(flat_grads):
                 # functional path only (gloo has no device transport on ROCm): stage through the host
                 host = flat_grads.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
@@ -28,6 +33,24 @@ class GradSync:
             else:
                 dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=self.group)      # RCCL, in place, compute stream
         return 1.0 / self.world
+
+    def begin(self, bucket: torch.Tensor):
+        """Start summing ``bucket`` (a slice of the flat gradient buffer whose gradients are all queued on the current
+        stream) over ranks, asynchronously; returns a handle for :meth:`finish` (None if nothing is in flight)."""
+        if self.world <= 1 or bucket.numel() == 0:
+            return None
+        if self._host_staged(bucket):
+            self(bucket)
+            return None
+        return dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self, rest: torch.Tensor, handles) -> float:
+        """Sum ``rest`` (the remainder of the buffer), then make the current stream wait for the buckets in flight."""
+        scale = self(rest)
+        for h in handles:
+            if h is not None:
+                h.wait()
+        return scale
 
 
 def broadcast_parameters(network, src=0, group=None):

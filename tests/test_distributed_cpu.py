@@ -25,6 +25,11 @@ def _worker(rank, world, port, q):
         g = torch.arange(10, dtype=torch.float32) * (rank + 1)
         scale = GradSync(world)(g)
         avg = g * scale
+        # two-bucket form used by fused_train_step: tail bucket asynchronously, the rest at the end
+        g2 = torch.arange(10, dtype=torch.float32) * (rank + 1)
+        gs = GradSync(world)
+        h = gs.begin(g2[6:])
+        assert gs.finish(g2[:6], [h]) == scale and torch.equal(g2, g)
         cm = M.BinaryConfusionMatrix()
         cm.update(torch.tensor([1, 0, 1, rank]), torch.tensor([1, 0, 0, 1]))
         cm.sync()

@@ -50,18 +50,34 @@ broadcast_parameters(model.network)
 batch = synth_batch(2, 128, 128, 1234, dev)
 
 
-class Forced(GradSync):                                              # world 1, but the collective is issued
+class Forced(GradSync):                                              # world 1, but every collective is issued
+    def __init__(self):
+        super().__init__(1)
+        self.sizes = []
+
     def __call__(self, flat):
-        self.seen = float(flat.abs().sum())
+        self.sizes.append(("sync", flat.numel()))
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        self.after = float(flat.abs().sum())
         return 1.0
 
+    def begin(self, bucket):
+        self.sizes.append(("async", bucket.numel()))
+        return dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True)
 
-sync = Forced(1)
+
+# reference run without any collective: the sum over one rank is the identity, so parameters must match bit for bit
+ref = mm.ModelModule(mm.default_settings(pos_weight=1)).to(dev).train()
+ref.load_state_dict(model.state_dict())
+ropt = ref.configure_optimizers()["optimizer"]
+for _ in range(2):
+    ref.fused_train_step(batch, ropt)
+sync = Forced()
 l0 = float(model.fused_train_step(batch, opt, grad_sync=sync))
-assert sync.seen > 0 and sync.seen == sync.after, (sync.seen, sync.after)
 l1 = float(model.fused_train_step(batch, opt, grad_sync=sync))
+n_enc = sum(p.numel() for p in model.network.encoder.parameters())
+n_all = sum(p.numel() for p in model.network.parameters())
+assert sync.sizes == [("async", n_all - n_enc), ("sync", n_enc)] * 2, sync.sizes
+assert torch.equal(model.network.flat_parameters(), ref.network.flat_parameters())
 dist.barrier()
 t = torch.tensor([1.5], device=dev, dtype=torch.float64)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
