@@ -71,6 +71,9 @@ def cpu_baseline(budget_s=25.0):
             "sample": f"{n} train steps of batch {B} x 4ch 512x512 fp32 (oracle/unet_ref.py + torch.optim.Adam) after 1 warm-up"}
 
 
+CONV_ROOFLINE_TILES_S = 1718.0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,6 +213,11 @@ def main():
                           "parallelism": f"dp{world}", "hipgraph": graph is not None, "final_loss": round(loss, 6),
                           "precision": args.precision},
                "roofline": roof}
+        if T == 512 and args.precision == "fp32":
+            # sum over the 63 conv layers of max(FLOP / fp32 peak, min bytes / HBM peak) = 0.582 ms per tile fwd+bwd
+            out["conv_roofline"] = {"tiles_per_s_per_gpu": CONV_ROOFLINE_TILES_S,
+                                    "frac": round(tiles / elapsed / world / CONV_ROOFLINE_TILES_S, 4),
+                                    "note": "sum-of-layers fp32 conv roofline (157.3 TFLOP/s fp32 matrix peak, 8 TB/s HBM), 0.582 ms/tile"}
         if not args.no_cpu_baseline and world == 1:       # reported at N=1 only (other ranks would idle at the exit barrier)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
