@@ -330,6 +330,20 @@ int sc_threshold_confusion(const float* pred, const float* target, const unsigne
                            const float* thresholds, int T, int se_bits, int64_t* cm, int64_t* invalid,
                            int N, int H, int W, sc_stream stream);
 
+/* ------------------------------------------------------------------------- */
+/* training-batch assembly from tiles resident in HBM: crop a window of a stored tile and apply the
+ * spatial augmentations of starcop/data/datamodule.py:128-134 (kornia 0.6.7 RandomRotation(degrees=90, p=.5) ->
+ * RandomHorizontalFlip(p=.5) -> RandomVerticalFlip(p=.5), applied in that order by starcop/data/dataset.py:99-102) in one
+ * gather: out[b][c][y][x] = crop_b(ys, xs) with (x, y) un-flipped, then rotated about the crop centre ((w-1)/2, (h-1)/2):
+ *   xs = cx + cos*(x - cx) - sin*(y - cy),  ys = cy + sin*(x - cx) + cos*(y - cy)
+ * sampled bilinearly (mode 0) or at the nearest pixel (mode 1) with zeros outside the crop -- what kornia's rotate() ->
+ * warp_affine -> F.grid_sample(align_corners=True, padding_mode="zeros") computes.  Items without the rotate flag are
+ * exact copies.  Per-item arrays are device pointers: tile index, window offsets, cos/sin, flags (1 rotate, 2 hflip,
+ * 4 vflip).  tiles: [M][C][Hs][Ws] f32, out: [B][C][h][w] f32.                                                       */
+int sc_gather_augment(const float* tiles, int M, int C, int Hs, int Ws, const int32_t* tile, const int32_t* row_off,
+                      const int32_t* col_off, const float* cos_t, const float* sin_t, const int32_t* flags, int B,
+                      int h, int w, int mode, float* out, sc_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -179,3 +179,40 @@ def run_validation(preds, pred_binaries, labels, thresholds=None, se=None, ignor
     out.update({f"classification_{k}": v for k, v in metrics(ccm.astype(np.float64)).items()})
     out["thresholded"] = [dict(threshold=float(t), confusion_matrix=cm_thr[k]) for k, t in enumerate(thresholds)]
     return rows, out
+
+
+# ---- training-batch assembly (starcop/data/datamodule.py:128-134, dataset.py:99-102) --------------------
+# kornia 0.6.7 is absent (PARITY UNPINNED against it); rotate() there is warp_affine -> F.affine_grid/F.grid_sample with
+# align_corners=True and zeros padding, about the centre ((w-1)/2, (h-1)/2).  tests/test_oracle.py checks this restatement
+# against torch.nn.functional.grid_sample itself.
+def rotate_flip(crop, cos_t, sin_t, rotate, hflip, vflip, nearest=False):
+    """(C,h,w) float32 crop -> vflip(hflip(rotate(crop))) with the inverse map of sc_gather_augment, float32 arithmetic."""
+    crop = np.asarray(crop, np.float32)
+    C_, h, w = crop.shape
+    out = crop
+    if rotate:
+        cx, cy = np.float32(0.5 * (w - 1)), np.float32(0.5 * (h - 1))
+        yy, xx = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing="ij")
+        cs, sn = np.float32(cos_t), np.float32(sin_t)
+        dx, dy = xx - cx, yy - cy
+        xs, ys = cx + cs * dx - sn * dy, cy + sn * dx + cs * dy
+        pad = np.zeros((C_, h + 2, w + 2), np.float32)
+        pad[:, 1:-1, 1:-1] = crop
+
+        def at(y, x):
+            ok = (y >= 0) & (y < h) & (x >= 0) & (x < w)
+            return np.where(ok, pad[:, np.clip(y, -1, h) + 1, np.clip(x, -1, w) + 1], np.float32(0))
+        if nearest:
+            out = at(np.rint(ys).astype(np.int64), np.rint(xs).astype(np.int64))
+        else:
+            x0, y0 = np.floor(xs), np.floor(ys)
+            ax, ay = xs - x0, ys - y0
+            x0, y0 = x0.astype(np.int64), y0.astype(np.int64)
+            one = np.float32(1)
+            out = (at(y0, x0) * (one - ax) * (one - ay) + at(y0, x0 + 1) * ax * (one - ay)
+                   + at(y0 + 1, x0) * (one - ax) * ay + at(y0 + 1, x0 + 1) * ax * ay)
+    if hflip:
+        out = out[:, :, ::-1]
+    if vflip:
+        out = out[:, ::-1, :]
+    return np.ascontiguousarray(out, dtype=np.float32)

@@ -7,6 +7,7 @@ Public surface (mirrors the reference):
   starcop_amd.padding.padded_predict / find_padding
   starcop_amd.mag1c.rmf / acrwl1mf / func_by_groups / generate_template_from_bands / get_mask_bad_bands
   starcop_amd.metrics
+  starcop_amd.datamodule.ResidentTileSet / TrainLoader (HBM-resident training batches)
   starcop_amd.validation.run_validation ; starcop_amd.baselines.Mag1cBaseline / SanchezBaseline / VaronBaseline / binary_opening
 All compute runs in starcop_amd/libstarcop_hip.so (include/starcop_hip.h); there is no CPU fallback.
 """

@@ -114,6 +114,7 @@ SIGNATURES = {
     "sc_clip_scale": (_i, [_vp, _vp, _sz, _f, _f, _f, _f, _i, _vp]),
     "sc_binary_opening": (_i, [_vp, _f, _i, _vp, _vp, _i, _i, _i, _vp]),
     "sc_threshold_confusion": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "sc_gather_augment": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
 }
 SE_CROSS = 0xBA        # the 3x3 cross of starcop/baselines.py:39-41 as sc_binary_opening's se_bits
 

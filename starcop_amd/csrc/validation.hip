@@ -189,3 +189,62 @@ extern "C" int sc_threshold_confusion(const float* pred, const float* target, co
   p.cm = reinterpret_cast<long long*>(cm); p.invalid = reinterpret_cast<long long*>(invalid);
   return launch(p, (hipStream_t)stream);
 }
+
+// ---- training-batch assembly: window crop + rotation + flips of HBM-resident tiles in one gather ----
+namespace {
+
+struct GatherP {
+  const float* tiles;
+  const int* tile; const int* row_off; const int* col_off;
+  const float* cs; const float* sn; const int* flags;
+  int M, C, Hs, Ws, B, h, w, mode;
+  float* out;
+};
+
+__global__ __launch_bounds__(256) void k_gather_augment(const GatherP p) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.h * p.w) return;
+  int y = i / p.w, x = i - y * p.w;
+  const int fl = p.flags[b];
+  const int t = p.tile[b], r0 = p.row_off[b], c0 = p.col_off[b];
+  const float* src = p.tiles + ((size_t)t * p.C + c) * ((size_t)p.Hs * p.Ws);
+  float* dst = p.out + ((size_t)b * p.C + c) * ((size_t)p.h * p.w) + i;
+  // the flips were applied last: undo them first
+  if (fl & 4) y = p.h - 1 - y;
+  if (fl & 2) x = p.w - 1 - x;
+  auto at = [&](int yy, int xx) -> float {      // zeros outside the crop window (not outside the stored tile)
+    return (yy >= 0 && yy < p.h && xx >= 0 && xx < p.w) ? src[(size_t)(r0 + yy) * p.Ws + (c0 + xx)] : 0.f;
+  };
+  if (!(fl & 1)) { *dst = at(y, x); return; }
+  const float cx = 0.5f * (p.w - 1), cy = 0.5f * (p.h - 1);
+  const float cs = p.cs[b], sn = p.sn[b];
+  const float dx = (float)x - cx, dy = (float)y - cy;
+  const float xs = cx + cs * dx - sn * dy, ys = cy + sn * dx + cs * dy;
+  if (p.mode == 1) {
+    *dst = at((int)nearbyintf(ys), (int)nearbyintf(xs));
+    return;
+  }
+  const float xf = floorf(xs), yf = floorf(ys);
+  const int x0 = (int)xf, y0 = (int)yf;
+  const float ax = xs - xf, ay = ys - yf;
+  const float v = at(y0, x0) * (1.f - ax) * (1.f - ay) + at(y0, x0 + 1) * ax * (1.f - ay) +
+                  at(y0 + 1, x0) * (1.f - ax) * ay + at(y0 + 1, x0 + 1) * ax * ay;
+  *dst = v;
+}
+
+}  // namespace
+
+extern "C" int sc_gather_augment(const float* tiles, int M, int C, int Hs, int Ws, const int32_t* tile, const int32_t* row_off,
+                                 const int32_t* col_off, const float* cos_t, const float* sin_t, const int32_t* flags, int B,
+                                 int h, int w, int mode, float* out, sc_stream stream) {
+  SC_REQUIRE(tiles && tile && row_off && col_off && cos_t && sin_t && flags && out, "sc_gather_augment: null pointer");
+  SC_REQUIRE(M > 0 && C > 0 && C <= 65535 && B > 0 && B <= 65535, "sc_gather_augment: bad M=%d C=%d B=%d", M, C, B);
+  SC_REQUIRE(h > 0 && w > 0 && h <= Hs && w <= Ws, "sc_gather_augment: window %dx%d does not fit the %dx%d tiles", h, w, Hs, Ws);
+  SC_REQUIRE(mode == 0 || mode == 1, "sc_gather_augment: mode=%d (0 bilinear, 1 nearest)", mode);
+  GatherP p{tiles, tile, row_off, col_off, cos_t, sin_t, flags, M, C, Hs, Ws, B, h, w, mode, out};
+  dim3 grid((h * w + 255) / 256, C, B);
+  hipLaunchKernelGGL(k_gather_augment, grid, dim3(256), 0, (hipStream_t)stream, p);
+  SC_LAUNCH_OK("k_gather_augment");
+  return SC_OK;
+}
