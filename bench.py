@@ -168,7 +168,9 @@ def main():
         torch.cuda.synchronize()
         prof = net.collect_profile()
         net.profile, net.overlap_wgrad = None, overlap
-        fam = max(prof, key=lambda k: prof[k]["ms"])
+        # dominant family among those with a stated algorithmic work (flops or bytes): the roofline needs a numerator
+        priced = [k for k in prof if prof[k]["flop"] or prof[k].get("bytes")] or list(prof)
+        fam = max(priced, key=lambda k: prof[k]["ms"])
         tot_ms = sum(v["ms"] for v in prof.values())
         d = prof[fam]
         ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
