@@ -84,8 +84,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", type=int, default=1, help="1: weight gradients on a second HIP stream (default); 0: serial "
                     "launches (use for rocprofv3 per-kernel durations that match the roofline pass)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
-                    help="fp32 (default, BASELINE configs[1], parity mode) | bf16: bf16 matrix math in the 3x3 convolutions (configs[3]-style)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32-bwd2", "fp32-2", "bf16"],
+                    help="fp32 (default, BASELINE configs[1], parity mode: 3 bf16 terms per operand) | fp32-bwd2 (2 terms in dgrad/wgrad) | fp32-2 (2 terms everywhere) | bf16 (1 term, configs[3]-style)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step from a captured hipGraph (default: eager two-stream launches, measured faster)")
     args = ap.parse_args()
 
@@ -178,7 +178,9 @@ def main():
         bx3 = "bx3" in fam
         # k_conv3_bx3 / k_wgrad3_bx3 compute fp32-accurate products as 6 bf16 MFMAs: the ceiling for ALGORITHMIC flops is the
         # dense bf16 MFMA peak / 6; the fp32-MFMA kernels are priced against the fp32 matrix peak.
-        nprod = 1.0 if args.precision == "bf16" else 6.0
+        tf_, tb_ = net._terms                                # bf16 terms per operand, forward / backward
+        nterms = tb_ if ("dgrad)" in fam and "fwd" not in fam) or "wgrad" in fam else tf_
+        nprod = {1: 1.0, 2: 3.0, 3: 6.0}[nterms]
         peak = BF16_MFMA_PEAK_TFLOPS / nprod if bx3 else FP32_MFMA_PEAK_TFLOPS
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_conv3_bx3.json" if bx3 else "r01_pmc_traffic_conv3.json")
         if ("conv3" in fam or fam.startswith("k_conv_mfma<3>")) and os.path.exists(pmc):
@@ -194,7 +196,7 @@ def main():
                 "unit": "GB/s" if hbm else "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
                 "peak_note": "HBM3E peak (MI355X_MICROARCH.md); achieved = algorithmic bytes of these launches / their time" if hbm else
-                             ("fp32-equivalent ceiling of the three-term split: dense bf16 MFMA peak 2500 TFLOP/s / 6 products; "
+                             (f"fp32-equivalent ceiling of the {nterms}-term split: dense bf16 MFMA peak 2500 TFLOP/s / {int(nprod)} products; "
                               f"the kernel executes {round(nprod * ach, 1)} bf16 TFLOP/s on the matrix cores; "
                               f"{round(ach / FP32_MFMA_PEAK_TFLOPS, 3)} x the fp32 MFMA peak of {FP32_MFMA_PEAK_TFLOPS}") if bx3 else
                              "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
@@ -208,14 +210,14 @@ def main():
         tiles = world * B * args.steps
         out = {"metric": "512x512 hyperspectral tiles/sec (train fwd+bwd)", "value": round(tiles / elapsed, 2), "unit": "tiles/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
                "config": {"workload": "configs[1]: HyperSTARCOP U-Net (smp.Unet mobilenet_v2, 4ch mag1c+RGB) train step "
                                       "fwd+loss+bwd+Adam, 512x512 tiles, fp32 HIP kernels (3x3 convs: fp32 via exact 3-term bf16 split on the bf16 MFMA)",
                           "batch_per_gpu": B, "global_batch": B * world, "tile": [4, T, T],
                           "parallelism": f"dp{world}", "hipgraph": graph is not None, "final_loss": round(loss, 6),
                           "precision": args.precision},
                "roofline": roof}
-        if T == 512 and args.precision == "fp32":
+        if T == 512 and args.precision != "bf16":
             # sum over the 63 conv layers of max(FLOP / fp32 peak, min bytes / HBM peak) = 0.582 ms per tile fwd+bwd
             out["conv_roofline"] = {"tiles_per_s_per_gpu": CONV_ROOFLINE_TILES_S,
                                     "frac": round(tiles / elapsed / world / CONV_ROOFLINE_TILES_S, 4),

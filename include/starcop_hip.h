@@ -80,7 +80,7 @@ size_t sc_packed_weight_floats(int Cout, int Cin, int ks, int co_t, int transpos
 
 /* every filter pack of a network in one launch.  `descs` and `block_starts` (n entries: first 256-thread block of each
  * descriptor, blocks = ceil(sc_pack_work_items / 256)) live in DEVICE memory and are built once by the caller;
- * bx3 = number of bf16 terms (3 or 1) selects the sc_pack_weights_bx3 layout (ks must be 3); 0 = fp32 layout. */
+ * bx3 = number of bf16 terms (3, 2 or 1) selects the sc_pack_weights_bx3 layout (ks must be 3); 0 = fp32 layout. */
 typedef struct sc_pack_desc {
   const float* w; float* wpk;
   int32_t Cout, Cin, ks, co_t, transpose_flip, bx3;
@@ -115,7 +115,7 @@ typedef struct sc_conv_args {
   const float* add0;     /* optional [N,Cout,H,W] tensors added in the epilogue  */
   const float* add1;     /*   (only valid with csplit == Cout)                   */
   float* stats;          /* [rows][Cout][2] partial sums or NULL                 */
-  int32_t terms;         /* sc_conv3x3_bx3 only: bf16 terms per operand, 0 or 3 = fp32-accurate split, 1 = plain bf16 */
+  int32_t terms;         /* sc_conv3x3_bx3 only: bf16 terms per operand, 0 or 3 = fp32-accurate split, 2 = two terms (2^-18), 1 = plain bf16 */
   int32_t down0;         /* sc_conv3x3_bx3 only: 1 = channels [0,csplit) are stored 2x2-summed at half resolution into out0
                           * ([N,csplit,H/2,W/2]): the backward of F.interpolate(scale_factor=2, mode="nearest") in
                           * smp's DecoderBlock fused into the data-gradient store (no full-resolution temporary) */
@@ -135,6 +135,8 @@ int sc_conv1x1_ksplit(const sc_conv_args* a, sc_stream stream);
  * sc_pack_weights_bx3 (16-byte aligned).  A concat needs src[0].C % 16 == 0.
  * `terms` = 1 (args->terms and the pack call) keeps only the leading bf16 term of each operand: one MFMA per block, bf16
  * matrix math with fp32 accumulation -- the network's "bf16" precision mode (BASELINE configs[3]); tensors stay fp32.
+ * `terms` = 2 keeps two terms per operand and the three products a0*b1 + a1*b0 + a0*b0 (operand error 2^-18): the opt-in
+ * "fp32-bwd2" / "fp32-2" modes.
  * Replaces the same torch.nn.functional.conv2d calls as sc_conv2d_mfma (starcop/models/model_module.py:244). */
 int sc_pack_weights_bx3(const float* w_oihw, float* wpk, int Cout, int Cin, int co_t, int transpose_flip, int terms,
                         sc_stream stream);
@@ -154,7 +156,7 @@ typedef struct sc_wgrad_args {
   int32_t N, H, W, Cout, Cin, ks;
   float* part; size_t part_floats;
   float* dw;
-  int32_t terms;         /* sc_conv3x3_wgrad_bx3 only: 0 or 3 = fp32-accurate split, 1 = plain bf16 operands */
+  int32_t terms;         /* sc_conv3x3_wgrad_bx3 only: 0 or 3 = fp32-accurate split, 2 = two terms, 1 = plain bf16 operands */
 } sc_wgrad_args;
 size_t sc_wgrad_workspace_floats(int N, int H, int W, int Cout, int Cin, int ks);
 int sc_conv2d_wgrad_mfma(const sc_wgrad_args* a, sc_stream stream);

@@ -56,8 +56,9 @@ __device__ __forceinline__ void split3x2(float a, float b, unsigned& t0, unsigne
 }
 
 // BNB: the (single) source is a BatchNorm/activation-backward source (dgrad); otherwise affine/raw sources (forward)
-// NT : number of bf16 terms per operand: 3 = fp32-accurate (six products), 1 = plain bf16 operands (one product; the
-//      "bf16" precision mode of the network: bf16 matrix math, fp32 accumulation and fp32 tensors in HBM)
+// NT : number of bf16 terms per operand: 3 = fp32-accurate (six products), 2 = a0*b1 + a1*b0 + a0*b0 (three products, operand
+//      error 2^-18: the opt-in "fp32-bwd2" / "fp32-2" modes), 1 = plain bf16 operands (one product; the "bf16" precision
+//      mode of the network: bf16 matrix math, fp32 accumulation and fp32 tensors in HBM)
 template <int Q, bool BNB, int NT>
 __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP p) {
   constexpr int PR = 10, PC = 34, NPX = PR * PC;     // 8 output rows + halo
@@ -221,8 +222,8 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
   auto step = [&](const bf16x8 (&A)[Q][NT], const bf16x8 (&B)[NT], auto ppc, auto cvt, int unit) {
     constexpr int PP = decltype(ppc)::value;
     constexpr bool CV = decltype(cvt)::value && NT == 3;
-    constexpr int TA[6] = {NT == 3 ? 1 : 0, 2, 0, 1, 0, 0}, TB[6] = {NT == 3 ? 1 : 0, 0, 2, 0, 1, 0};
-    constexpr int NM = (NT == 3 ? 6 : 1) * Q;
+    constexpr int TA[6] = {NT == 3 ? 1 : 0, NT == 3 ? 2 : 1, 0, 1, 0, 0}, TB[6] = {NT == 3 ? 1 : (NT == 2 ? 1 : 0), 0, NT == 3 ? 2 : 0, 0, 1, 0};
+    constexpr int NM = (NT == 3 ? 6 : (NT == 2 ? 3 : 1)) * Q;
     constexpr int G = NM >= 6 ? NM / 6 : 1;         // MFMAs between slices
     const int r = unit >> 2, jp = unit & 3;
     float v0 = 0.f, v1 = 0.f;
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
       for (int r = 0; r < NR; ++r) load_round(r);        // the whole next patch: a chunk of MFMAs hides the HBM latency
       load_consts();
       stage(s, 0, std::false_type{}, 0);
-      if (BNB || NT == 1) {   // the longer BatchNorm-backward prologue does not fit the MFMA shadows (and the registers): convert after
+      if (BNB || NT != 3) {   // the longer BatchNorm-backward prologue does not fit the MFMA shadows (and the registers): convert after
         stage(s + 1, 1, std::false_type{}, 0);
         stage(s + 2, 2, std::false_type{}, 0);
 #pragma unroll
@@ -641,6 +642,7 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
   _Pragma("unroll") for (int kw = 0; kw < 3; ++kw)                                                                  \
       acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[TA], B[kw][TB], acc[kw], 0, 0, 0);
         if constexpr (NT == 3) { SC_BX3_STEP(1, 1) SC_BX3_STEP(2, 0) SC_BX3_STEP(0, 2) SC_BX3_STEP(1, 0) SC_BX3_STEP(0, 1) }
+        if constexpr (NT == 2) { SC_BX3_STEP(0, 1) SC_BX3_STEP(1, 0) }
         SC_BX3_STEP(0, 0)
 #undef SC_BX3_STEP
       }
@@ -786,12 +788,12 @@ __global__ __launch_bounds__(256) void k_pack_batch(const PackDesc* __restrict__
 extern "C" size_t sc_packed_weight_floats_bx3(int Cout, int Cin, int co_t, int transpose_flip, int terms) {
   const int M = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
   const size_t mt = (M + co_t - 1) / co_t, nchunk = (K + 15) / 16;
-  return mt * nchunk * 3 * 6 * (size_t)(terms == 1 ? 1 : 3) * co_t * 4;     // 16-byte entries -> floats
+  return mt * nchunk * 3 * 6 * (size_t)(terms >= 1 && terms <= 3 ? terms : 3) * co_t * 4;     // 16-byte entries -> floats
 }
 
 extern "C" int sc_pack_weights_bx3(const float* w, float* wpk, int Cout, int Cin, int co_t, int transpose_flip,
                                    int terms, sc_stream stream) {
-  SC_REQUIRE(terms == 1 || terms == 3, "sc_pack_weights_bx3: terms must be 1 or 3 (got %d)", terms);
+  SC_REQUIRE(terms >= 1 && terms <= 3, "sc_pack_weights_bx3: terms must be 1, 2 or 3 (got %d)", terms);
   SC_REQUIRE(w && wpk && Cout > 0 && Cin > 0, "sc_pack_weights_bx3: bad argument");
   SC_REQUIRE(co_t == 32 || co_t == 64, "sc_pack_weights_bx3: co_t must be 32 or 64 (got %d)", co_t);
   SC_REQUIRE(((uintptr_t)wpk & 15) == 0, "sc_pack_weights_bx3: destination must be 16-byte aligned");
@@ -838,7 +840,7 @@ extern "C" int sc_conv3x3_bx3(const sc_conv_args* a, sc_stream stream) {
   dim3 grid(((a->W + 31) / 32) * ((a->H + 7) / 8), co_tiles, a->N);
   hipStream_t st = (hipStream_t)stream;
   const bool bnb = a->src[0].mode == SC_SRC_BNBWD;
-  SC_REQUIRE(a->terms == 0 || a->terms == 1 || a->terms == 3, "sc_conv3x3_bx3: terms must be 0 (= 3), 1 or 3 (got %d)", a->terms);
+  SC_REQUIRE(a->terms >= 0 && a->terms <= 3, "sc_conv3x3_bx3: terms must be 0 (= 3), 1, 2 or 3 (got %d)", a->terms);
 #define SC_LAUNCH_BX3(NT)                                                                                  \
   do {                                                                                                     \
     if (a->co_t == 64 && bnb) hipLaunchKernelGGL((k_conv3_bx3<2, true, NT>), grid, dim3(256), 0, st, p);   \
@@ -846,7 +848,7 @@ extern "C" int sc_conv3x3_bx3(const sc_conv_args* a, sc_stream stream) {
     else if (bnb) hipLaunchKernelGGL((k_conv3_bx3<1, true, NT>), grid, dim3(256), 0, st, p);               \
     else hipLaunchKernelGGL((k_conv3_bx3<1, false, NT>), grid, dim3(256), 0, st, p);                       \
   } while (0)
-  if (a->terms == 1) SC_LAUNCH_BX3(1); else SC_LAUNCH_BX3(3);
+  if (a->terms == 1) SC_LAUNCH_BX3(1); else if (a->terms == 2) SC_LAUNCH_BX3(2); else SC_LAUNCH_BX3(3);
 #undef SC_LAUNCH_BX3
   SC_LAUNCH_OK("sc_conv3x3_bx3");
   return SC_OK;
@@ -882,7 +884,7 @@ extern "C" int sc_conv3x3_wgrad_bx3(const sc_wgrad_args* a, sc_stream stream) {
   p.nsl = pl.nsl; p.CoP = pl.CoP; p.CiP = pl.CiP;
   dim3 grid(pl.nsl, pl.ci_tiles, pl.co_tiles);
   hipStream_t st = (hipStream_t)stream;
-  SC_REQUIRE(a->terms == 0 || a->terms == 1 || a->terms == 3, "sc_conv3x3_wgrad_bx3: terms must be 0 (= 3), 1 or 3 (got %d)", a->terms);
+  SC_REQUIRE(a->terms >= 0 && a->terms <= 3, "sc_conv3x3_wgrad_bx3: terms must be 0 (= 3), 1, 2 or 3 (got %d)", a->terms);
 #define SC_WGX(WM_, NT_, NCI_) hipLaunchKernelGGL((k_wgrad3_bx3<WM_, NT_, NCI_>), grid, dim3(768), 0, st, p)
 #define SC_WGX_NT(NT_)                                   \
   do {                                                   \
@@ -891,7 +893,7 @@ extern "C" int sc_conv3x3_wgrad_bx3(const sc_wgrad_args* a, sc_stream stream) {
     else if (pl.nci == 2) SC_WGX(1, NT_, 2);             \
     else SC_WGX(1, NT_, 1);                              \
   } while (0)
-  if (a->terms == 1) SC_WGX_NT(1); else SC_WGX_NT(3);
+  if (a->terms == 1) SC_WGX_NT(1); else if (a->terms == 2) SC_WGX_NT(2); else SC_WGX_NT(3);
 #undef SC_WGX_NT
 #undef SC_WGX
   SC_LAUNCH_OK("sc_conv3x3_wgrad_bx3");

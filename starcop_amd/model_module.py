@@ -181,7 +181,7 @@ def configure_architecture(architecture, num_channels, num_classes, extra_settin
         if backbone != "mobilenet_v2":
             raise Exception(f"No HIP model implemented for semseg_backbone: {backbone}")
         net = HyperStarcopUNet(in_channels=num_channels, classes=num_classes)
-        # extension (not in the reference's config.yaml): settings.model.precision = "fp32" (default, parity mode) | "bf16"
+        # extension (not in the reference's config.yaml): settings.model.precision = "fp32" (default, parity mode) | "fp32-bwd2" | "fp32-2" | "bf16"
         # (bf16 matrix math for the 3x3 convolutions, BASELINE configs[3]); absent key -> fp32
         try:
             prec = extra_settings_model["precision"] if "precision" in extra_settings_model else "fp32"

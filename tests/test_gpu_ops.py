@@ -266,6 +266,33 @@ def test_conv_bf16_single_term(hip, cin, cout, co_t, H, W):
         assert relerr(dw, wz.grad) < 5e-6
 
 
+@pytest.mark.parametrize("cin,cout,co_t,H,W", [(32, 64, 64, 36, 70), (80, 32, 32, 20, 40), (288, 128, 64, 8, 12)])
+def test_conv_two_term_split(hip, cin, cout, co_t, H, W):
+    """terms = 2 (the "fp32-bwd2" / "fp32-2" modes): a0*b0 + a0*b1 + a1*b0 of the exact two-term bf16 splits -- equals an
+    fp64 convolution of the 16-bit-significand operands (minus the a1*b1 term, 2^-18) and is within 2e-5 of the unrounded
+    fp64 result (operand error 2^-18, random sign, averaged over K >= 288 terms); forward, dgrad and wgrad with the
+    network's prologues."""
+    N = 2
+    x, w = rnd(N, cin, H, W, seed=1), rnd(cout, cin, 3, 3, seed=2, scale=0.2)
+    cst = torch.rand(cin, SC_CST) + 0.5
+    src = make_src(dev(x), cin, SRC_AFFINE, act=ACT_RELU, cst=dev(cst))
+    xin = torch.relu(x.double() * cst[:, 0].double()[None, :, None, None] + cst[:, 1].double()[None, :, None, None])
+    ref = F.conv2d(xin, w.double(), padding=1)
+    (out,), _ = conv_mfma([src], pack_bx3(dev(w), co_t, 0, 2), N, H, W, cout, 3, co_t, bx3=True, terms=2)
+    (out3,), _ = conv_mfma([src], pack_bx3(dev(w), co_t, 0, 3), N, H, W, cout, 3, co_t, bx3=True, terms=3)
+    e2, e3 = relerr(out, ref), relerr(out3, ref)
+    assert e2 < 2e-5 and e3 < 2e-6, (e2, e3)
+    g = rnd(N, cout, H, W, seed=3)
+    cb = 32 if cin <= 32 else 64
+    (dx,), _ = conv_mfma([make_src(dev(g), cout, SRC_RAW)], pack_bx3(dev(w), cb, 1, 2), N, H, W, cin, 3, cb, bx3=True, terms=2)
+    assert relerr(dx, F.conv_transpose2d(g.double(), w.double(), padding=1)) < 2e-5
+    if cin >= 32 and cout >= 32:
+        wz = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xin, wz, padding=1).backward(g.double())
+        dw = wgrad_mfma(make_src(dev(g), cout, SRC_RAW), [src], N, H, W, cout, cin, 3, bx3=True, terms=2)
+        assert relerr(dw, wz.grad) < 2e-5
+
+
 @pytest.mark.parametrize("cin,cout,cs,H,W,co_t", [(80, 32, 64, 16, 64, 64), (152, 64, 128, 24, 40, 64), (32, 16, 32, 20, 36, 32), (288, 128, 256, 8, 12, 64)])
 def test_conv_bx3_dgrad_fused_upsample_backward(hip, cin, cout, cs, H, W, co_t):
     """decoder conv1 data gradient: channels [0, cs) belong to the nearest-x2-upsampled input -> stored as 2x2 sums at half

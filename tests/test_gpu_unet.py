@@ -225,3 +225,47 @@ def test_training_trajectory_follows_the_oracle(hip):
         dev_hip = abs(l_hip[i] - l64[i]) / abs(l64[i])
         assert dev_hip <= max(5e-3, 10 * dev_ref), (i, l_hip[i], l32[i], l64[i])
     assert l_hip[-1] < l_hip[0]
+
+
+@pytest.mark.parametrize("precision", ["fp32-bwd2", "fp32-2"])
+def test_two_term_precision_modes(hip, precision):
+    """"fp32-bwd2": forward identical to "fp32" bit for bit, gradients (two bf16 terms per operand in dgrad/wgrad) as close to
+    the fp64 oracle as the contract asks (<= max(1e-3, 10x the fp32 oracle's own deviation)).  "fp32-2": logits within the
+    1e-4 contract as well."""
+    B, H, W = 4, 128, 128
+    model, ref = make_pair(seed=3, pos_weight=1.0)
+    strict = copy.deepcopy(model)
+    model.network.precision = precision
+    model.train(); strict.train(); ref.train()
+    ref64 = copy.deepcopy(ref).double()
+    batch = synth_batch(B, H, W, seed=5)
+
+    def oracle_step(net, dt):
+        logits = net(ref_normalize(batch["input"]).to(dt))
+        loss = (F.binary_cross_entropy_with_logits(logits, batch["output"].to(dt), pos_weight=torch.tensor(1.0, dtype=dt),
+                                                   reduction="none") * batch["weight_loss"].to(dt)).mean()
+        net.zero_grad(); loss.backward()
+        return logits.detach(), {k: p.grad.clone() for k, p in net.named_parameters()}
+
+    _, g32 = oracle_step(ref, torch.float32)
+    logits64, g64 = oracle_step(ref64, torch.float64)
+    loss = model.training_step(to_dev(batch), 0)
+    logits = model.network._plans[(B, H, W)].buf["logits"].clone()
+    loss.backward()
+    strict.training_step(to_dev(batch), 0)
+    logits_strict = strict.network._plans[(B, H, W)].buf["logits"]
+    if precision == "fp32-bwd2":
+        assert torch.equal(logits, logits_strict)
+    assert relerr(logits, logits64) < 1e-4
+    bad = []
+    for k, p in model.network.named_parameters():
+        e_hip, e_ref = relerr(p.grad, g64[k]), relerr(g32[k], g64[k])
+        if not e_hip <= max(1e-3, 10 * e_ref):
+            bad.append((k, e_hip, e_ref))
+    assert not bad, bad[:10]
+    # eval-mode logits of the two-term forward against the oracle (contract: 1e-4)
+    model.eval(); ref.eval()
+    with torch.no_grad():
+        want = ref(ref_normalize(batch["input"]))
+        got = model(to_dev(batch)["input"])
+    assert relerr(got, want) < (1e-4 if precision == "fp32-2" else 1e-5)
