@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", type=int, default=1, help="1: weight gradients on a second HIP stream (default); 0: serial "
                     "launches (use for rocprofv3 per-kernel durations that match the roofline pass)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32-bwd2", "fp32-2", "bf16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32-x3", "fp32-bwd2", "fp32-2", "bf16"],
                     help="fp32 (default, BASELINE configs[1], parity mode: 3 bf16 terms per operand) | fp32-bwd2 (2 terms in dgrad/wgrad) | fp32-2 (2 terms everywhere) | bf16 (1 term, configs[3]-style)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step from a captured hipGraph (default: eager two-stream launches, measured faster)")
     args = ap.parse_args()
@@ -180,7 +180,7 @@ def main():
         # dense bf16 MFMA peak / 6; the fp32-MFMA kernels are priced against the fp32 matrix peak.
         tf_, tb_ = net._terms                                # bf16 terms per operand, forward / backward
         nterms = tb_ if ("dgrad)" in fam and "fwd" not in fam) or "wgrad" in fam else tf_
-        nprod = {1: 1.0, 2: 3.0, 3: 6.0}[nterms]
+        nprod = {1: 1.0, 2: 3.0, 3: 6.0, 4: 3.0}[nterms]
         peak = BF16_MFMA_PEAK_TFLOPS / nprod if bx3 else FP32_MFMA_PEAK_TFLOPS
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_conv3_bx3.json" if bx3 else "r01_pmc_traffic_conv3.json")
         if ("conv3" in fam or fam.startswith("k_conv_mfma<3>")) and os.path.exists(pmc):

@@ -101,6 +101,8 @@ int sc_pack_weights_batch(const sc_pack_desc* descs_dev, const uint32_t* block_s
  *   stats  : if non-NULL, per-channel sum / sum-of-squares of acc over each work-group's pixel tile are written to
  *            stats[row][Cout][2] (float), row = n*tiles + tile, rows = sc_stat_rows(SC_STAT_CONV3|CONV1, N, H, W)
  */
+#define SC_TERMS_F16X2 4   /* `terms` code: two fp16 terms per operand with exact power-of-two range scaling (22 significand
+                            * bits, three products: fp32-level accuracy at half the MFMA work of the three-term bf16 split) */
 typedef struct sc_conv_args {
   sc_src src[2];
   int32_t nsrc;
@@ -119,6 +121,8 @@ typedef struct sc_conv_args {
   int32_t down0;         /* sc_conv3x3_bx3 only: 1 = channels [0,csplit) are stored 2x2-summed at half resolution into out0
                           * ([N,csplit,H/2,W/2]): the backward of F.interpolate(scale_factor=2, mode="nearest") in
                           * smp's DecoderBlock fused into the data-gradient store (no full-resolution temporary) */
+  const float* absmax;   /* terms == SC_TERMS_F16X2 with a BNBWD source: device float >= the tensor's max |A_c g| (written by
+                          * sc_bn_bwd_reduce / sc_bn_bwd_small); NULL: the gradient operand is taken to be O(1)              */
 } sc_conv_args;
 int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream);
 /* 1x1 convolution for few-pixel / long-K layers (the <= 64^2 inverted-residual projections and the data gradients of the
@@ -157,6 +161,7 @@ typedef struct sc_wgrad_args {
   float* part; size_t part_floats;
   float* dw;
   int32_t terms;         /* sc_conv3x3_wgrad_bx3 only: 0 or 3 = fp32-accurate split, 2 = two terms, 1 = plain bf16 operands */
+  const float* absmax;   /* terms == SC_TERMS_F16X2: scale hint of dy, as in sc_conv_args                                     */
 } sc_wgrad_args;
 size_t sc_wgrad_workspace_floats(int N, int H, int W, int Cout, int Cin, int ks);
 int sc_conv2d_wgrad_mfma(const sc_wgrad_args* a, sc_stream stream);
@@ -204,15 +209,17 @@ int sc_bn_finalize(const float* stats, int nrows, double count, const float* gam
                    float* running_mean, float* running_var, float momentum, float eps,
                    int training, float* cst_fwd, int C, sc_stream stream);
 /* sums[row][C][2] = { sum g_bn, sum g_bn * xhat } over the row's pixels, g_bn = g * act'(BN(y));
- * rows = sc_stat_rows(SC_STAT_BNBWD, N, H, W) */
+ * rows = sc_stat_rows(SC_STAT_BNBWD, N, H, W).
+ * absmax (optional, device float, zeroed by the caller before the first launch of a step): raised to
+ * max_c |gamma_c * invstd_c| * max |g_bn| by an order-independent atomic max -- the range hint of the SC_TERMS_F16X2 kernels */
 int sc_bn_bwd_reduce(const float* g, const float* y, const float* cst_fwd, int act,
-                     double* sums, int N, int C, int HW, sc_stream stream);
+                     double* sums, int N, int C, int HW, float* absmax, sc_stream stream);
 /* dgamma, dbeta and the SC_SRC_BNBWD constants {scale, shift, A, B, D} */
 int sc_bn_bwd_finalize(const double* sums, int nrows, double count, const float* cst_fwd,
                        float* dgamma, float* dbeta, float* cst_bwd, int C, sc_stream stream);
 /* both steps in one launch for few-pixel layers (one block per channel over all N*HW elements); same outputs */
 int sc_bn_bwd_small(const float* g, const float* y, const float* cst_fwd, int act, int N, int C, int HW,
-                    float* dgamma, float* dbeta, float* cst_bwd, sc_stream stream);
+                    float* dgamma, float* dbeta, float* cst_bwd, float* absmax, sc_stream stream);
 /* out = v(a) + v(b)   (residual add of an inverted-residual block; b may be NULL) */
 int sc_add_srcs(const sc_src* a, const sc_src* b, float* out, int N, int C, int HW, sc_stream stream);
 /* out[n,c,y,x] (+)= sum of the 2x2 block of in (backward of nearest x2 upsample) */

@@ -36,14 +36,16 @@ class sc_conv_args(C.Structure):
                 ("ks", C.c_int32), ("co_t", C.c_int32),
                 ("out0", C.c_void_p), ("out1", C.c_void_p),
                 ("csplit", C.c_int32), ("accum0", C.c_int32), ("accum1", C.c_int32),
-                ("add0", C.c_void_p), ("add1", C.c_void_p), ("stats", C.c_void_p), ("terms", C.c_int32), ("down0", C.c_int32)]
+                ("add0", C.c_void_p), ("add1", C.c_void_p), ("stats", C.c_void_p), ("terms", C.c_int32), ("down0", C.c_int32),
+                ("absmax", C.c_void_p)]
 
 
 class sc_wgrad_args(C.Structure):
     _fields_ = [("dy", sc_src), ("src", sc_src * 2), ("nsrc", C.c_int32),
                 ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("Cout", C.c_int32), ("Cin", C.c_int32), ("ks", C.c_int32),
-                ("part", C.c_void_p), ("part_floats", C.c_size_t), ("dw", C.c_void_p), ("terms", C.c_int32)]
+                ("part", C.c_void_p), ("part_floats", C.c_size_t), ("dw", C.c_void_p), ("terms", C.c_int32),
+                ("absmax", C.c_void_p)]
 
 
 class sc_mag1c_args(C.Structure):
@@ -91,8 +93,8 @@ SIGNATURES = {
     "sc_head_conv_wgrad": (_i, [_vp, C.POINTER(sc_src), _vp, _sz, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sc_stat_rows": (_i, [_i, _i, _i, _i]),
     "sc_bn_finalize": (_i, [_vp, _i, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _i, _vp]),
-    "sc_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
-    "sc_bn_bwd_small": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "sc_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "sc_bn_bwd_small": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sc_bn_bwd_finalize": (_i, [_vp, _i, _d, _vp, _vp, _vp, _vp, _i, _vp]),
     "sc_add_srcs": (_i, [C.POINTER(sc_src), C.POINTER(sc_src), _vp, _i, _i, _i, _vp]),
     "sc_apply_src": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _vp]),
@@ -116,6 +118,7 @@ SIGNATURES = {
     "sc_threshold_confusion": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "sc_gather_augment": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
 }
+TERMS_F16X2 = 4        # `terms` code of the two-fp16-term kernels (include/starcop_hip.h SC_TERMS_F16X2)
 SE_CROSS = 0xBA        # the 3x3 cross of starcop/baselines.py:39-41 as sc_binary_opening's se_bits
 
 _lib = None

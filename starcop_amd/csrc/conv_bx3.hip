@@ -30,6 +30,43 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) float floatx2;
 typedef __attribute__((ext_vector_type(4))) unsigned int uintx4;
+typedef __attribute__((ext_vector_type(8))) _Float16 halfx8;
+typedef __attribute__((ext_vector_type(2))) _Float16 halfx2;
+
+// ---- two fp16 terms ("H" mode, terms code SC_TERMS_F16X2 = 4) ----
+// a*s = h0 + h1 exactly to 22 significand bits (round-to-nearest conversions), products h0*g0 + h0*g1 + h1*g0: the dropped
+// h1*g1 is 2^-22 |a||b|, below the fp32 accumulation error of a K >= 288 reduction.  fp16 has 5 exponent bits, so every
+// operand is brought into range by an exact power-of-two scale that the epilogue divides out again:
+//   filters     x 2^8  (|w| < 255; the absolute error 2^-25 of a sub-normal second term is 2^-33 in filter units)
+//   activations x 2    (BatchNorm-normalised, ReLU6-clipped or ReLU: |x| < 32752; absolute error floor 2^-26)
+//   gradients   x 2^(5-e), 2^e >= the tensor's max |A_c g| from the BatchNorm-backward reduction (args->absmax): the
+//               prologue output A g + B y + D is bounded by (2 + max|x_hat|) times that, so anything up to
+//               max|x_hat| = 2045 (the most a 4M-sample channel can reach is 2048) fits; error floor 2^-30 of the maximum
+// Values beyond the range are clamped to +-65504 (a finite error, never an inf/NaN); the three-term bf16 split
+// ("fp32-x3") has fp32's exponent range and no such limits.
+constexpr float SC_H_SW = 256.f, SC_H_SX = 2.f, SC_H_MAX = 65504.f;
+__device__ __forceinline__ float h_grad_scale(const float* absmax) {
+  const float M = absmax ? *absmax : 0.f;
+  if (!(M > 0.f) || !(M < 3.0e38f)) return 1.f;
+  int e;
+  (void)frexpf(M, &e);                                  // M = m * 2^e, m in [0.5, 1)
+  e = 5 - e;
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  return ldexpf(1.f, e);                                // M * s in [16, 32)
+}
+__device__ __forceinline__ void split2h(float a, float b, unsigned& t0, unsigned& t1) {
+  floatx2 v = {__builtin_amdgcn_fmed3f(a, -SC_H_MAX, SC_H_MAX), __builtin_amdgcn_fmed3f(b, -SC_H_MAX, SC_H_MAX)};
+  const halfx2 h0 = __builtin_convertvector(v, halfx2);
+  v -= __builtin_convertvector(h0, floatx2);
+  const halfx2 h1 = __builtin_convertvector(v, halfx2);
+  t0 = __builtin_bit_cast(unsigned, h0);
+  t1 = __builtin_bit_cast(unsigned, h1);
+}
+template <bool HF>
+__device__ __forceinline__ floatx16 mfma_split(const bf16x8& a, const bf16x8& b, const floatx16& c) {
+  if constexpr (HF) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(halfx8, a), __builtin_bit_cast(halfx8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
 struct ConvXP {
   SrcD s0, s1;
@@ -40,6 +77,7 @@ struct ConvXP {
   const float* add0; const float* add1;
   float* stats;
   int down0;
+  const float* absmax;
 };
 
 // exact three-term bf16 split of two floats; returns packed pairs (low half = first value)
@@ -59,8 +97,9 @@ __device__ __forceinline__ void split3x2(float a, float b, unsigned& t0, unsigne
 // NT : number of bf16 terms per operand: 3 = fp32-accurate (six products), 2 = a0*b1 + a1*b0 + a0*b0 (three products, operand
 //      error 2^-18: the opt-in "fp32-bwd2" / "fp32-2" modes), 1 = plain bf16 operands (one product; the "bf16" precision
 //      mode of the network: bf16 matrix math, fp32 accumulation and fp32 tensors in HBM)
-template <int Q, bool BNB, int NT>
+template <int Q, bool BNB, int NT, bool HF = false>
 __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP p) {
+  static_assert(!HF || NT == 2, "the fp16 mode has two terms");
   constexpr int PR = 10, PC = 34, NPX = PR * PC;     // 8 output rows + halo
   constexpr bool PAD = (Q == 2);                     // Q = 1 keeps LDS under 53 KB (3 work-groups per CU) with guarded stores
   constexpr int NPXP = PAD ? 384 : NPX;              // padded: 3 staging rounds x 128 threads store unconditionally
@@ -86,6 +125,10 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
   const int Cin = C0 + p.s1.C;
   const int nk = (Cin + 15) >> 4;                    // packed filters are zero-padded to nk*16 input channels
   const uintx4* wbase = p.wpk + (size_t)cot * nk * 3 * WENT;
+
+  // fp16 mode: operand scale of the staged tensor and the factor that removes it (and the filters' 2^8) again
+  const float hsx = !HF ? 1.f : (BNB ? h_grad_scale(p.absmax) : SC_H_SX);
+  const float hinv = !HF ? 1.f : 1.f / (hsx * SC_H_SW);
 
   floatx16 acc[2][Q];
 #pragma unroll
@@ -169,7 +212,8 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
       v[h] = (((inb >> r) & 1u) && j < nch) ? t : 0.f;
     }
     unsigned t[3];
-    split3x2(v[0], v[1], t[0], t[1], t[2]);
+    if constexpr (HF) { split2h(v[0] * hsx, v[1] * hsx, t[0], t[1]); t[2] = 0u; }
+    else split3x2(v[0], v[1], t[0], t[1], t[2]);
 #pragma unroll
     for (int c = 0; c < NT; ++c) pt[r][c][jp] = t[c];
   };
@@ -231,7 +275,7 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
     bf16x2 h0 = {}, h1 = {}, h2 = {};
     auto mf = [&](int i) {
       const int pr = i / Q, q = i - pr * Q;
-      acc[PP][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[q][TA[pr]], B[TB[pr]], acc[PP][q], 0, 0, 0);
+      acc[PP][q] = mfma_split<HF>(A[q][TA[pr]], B[TB[pr]], acc[PP][q]);
     };
     auto pro = [&](int j) {
       const float t = BNB ? sc_pro_bnbwd(xv[r][j], av[BNB ? r : 0][j], cs0[j], cs1[j], cs2[j], cs3[j], cs4[j], slo, shi)
@@ -350,6 +394,7 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
         const int oy = y0 + 2 * wave;
         float v = ((oy < H) && (ox < W)) ? acc[0][q][r] : 0.f;
         v += ((oy + 1 < H) && (ox < W)) ? acc[1][q][r] : 0.f;
+        if (HF) v *= hinv;
         v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
         if (!(l31 & 1) && oy < H && ox < W) {
           const size_t idx = (((size_t)n * p.csplit + co) * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1);
@@ -363,6 +408,7 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
         const int oy = y0 + 2 * wave + pp;
         const bool ok = (oy < H) && (ox < W) && (co < p.Cout);
         float v = ok ? acc[pp][q][r] : 0.f;
+        if (HF) v *= hinv;
         sv += v; sq = fmaf(v, v, sq);
         if (ok) {
           const size_t opix = (size_t)oy * W + ox;
@@ -404,31 +450,44 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
 }
 
 // filters -> [co tile][chunk of 16 ci][kh][term][kw][ci half][co][8 ci] bf16; forward or transposed+flipped (dgrad)
+// the bf16 / fp16 term bits of one filter value (fp16: scaled by 2^8, see split2h)
+__device__ __forceinline__ void split_filter(float v, bool half, unsigned short (&t)[3]) {
+  if (half) {
+    const float vs = __builtin_amdgcn_fmed3f(v * SC_H_SW, -SC_H_MAX, SC_H_MAX);
+    const _Float16 h0 = (_Float16)vs;
+    const _Float16 h1 = (_Float16)(vs - (float)h0);
+    t[0] = __builtin_bit_cast(unsigned short, h0); t[1] = __builtin_bit_cast(unsigned short, h1); t[2] = 0;
+    return;
+  }
+  const __bf16 t0 = (__bf16)v;
+  float rr = v - (float)t0;
+  const __bf16 t1 = (__bf16)rr;
+  rr -= (float)t1;
+  const __bf16 t2 = (__bf16)rr;
+  t[0] = __builtin_bit_cast(unsigned short, t0); t[1] = __builtin_bit_cast(unsigned short, t1); t[2] = __builtin_bit_cast(unsigned short, t2);
+}
+
 __global__ void k_pack_weights_bx3(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout, int Cin,
-                                   int co_t, int tflip, int nchunk, int nt, size_t total) {
+                                   int co_t, int tflip, int nchunk, int nt, int half, size_t total) {
   const int M = tflip ? Cin : Cout, K = tflip ? Cout : Cin;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     size_t r = i;
     const int j = (int)(r % 8); r /= 8;
     const int col = (int)(r % co_t); r /= co_t;
-    const int half = (int)(r % 2); r /= 2;
+    const int hf = (int)(r % 2); r /= 2;
     const int kw = (int)(r % 3); r /= 3;
     const int kh = (int)(r % 3); r /= 3;
     const int chunk = (int)(r % nchunk);
     const int mt = (int)(r / nchunk);
-    const int m = mt * co_t + col, k = chunk * 16 + half * 8 + j, tap = kh * 3 + kw;
+    const int m = mt * co_t + col, k = chunk * 16 + hf * 8 + j, tap = kh * 3 + kw;
     float v = 0.f;
     if (m < M && k < K) v = tflip ? w[((size_t)k * M + m) * 9 + (8 - tap)] : w[((size_t)m * K + k) * 9 + tap];
-    const __bf16 t0 = (__bf16)v;
-    float rr = v - (float)t0;
-    const __bf16 t1 = (__bf16)rr;
-    rr -= (float)t1;
-    const __bf16 t2 = (__bf16)rr;
+    unsigned short t[3];
+    split_filter(v, half != 0, t);
     const size_t stage = ((size_t)mt * nchunk + chunk) * 3 + kh;
-    const __bf16 t[3] = {t0, t1, t2};
     for (int c = 0; c < nt; ++c) {
-      const size_t d = ((((stage * nt + c) * 3 + kw) * 2 + half) * co_t + col) * 8 + j;
-      wpk[d] = __builtin_bit_cast(unsigned short, t[c]);
+      const size_t d = ((((stage * nt + c) * 3 + kw) * 2 + hf) * co_t + col) * 8 + j;
+      wpk[d] = t[c];
     }
   }
 }
@@ -446,6 +505,7 @@ __global__ void k_pack_weights_bx3(const float* __restrict__ w, unsigned short* 
 // The input rows live in a 4-slot ring per channel (slot = (row + 1) & 3): walking down a 32-column strip only the two
 // new rows are fetched per stage, every element is split into its three bf16 terms once.
 struct WgradXP {
+  const float* absmax;
   SrcD dy, s0, s1;
   int N, H, W, Cout, Cin;
   float* part;
@@ -454,9 +514,12 @@ struct WgradXP {
 };
 
 // NCI: 32-wide cin blocks per tile (2: 64 cins; 1: 32 cins for channel counts that would waste most of a 64-wide tile)
-template <int WM, int NT, int NCI>
+template <int WM, int NT, int NCI, bool HF = false>
 __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
+  static_assert(!HF || NT == 2, "the fp16 mode has two terms");
   constexpr int NTH = 768;
+  const float hsg = HF ? h_grad_scale(p.absmax) : 1.f;          // fp16 mode: scale of the gradient operand
+  const float hinv = HF ? 1.f / (hsg * SC_H_SX) : 1.f;
   constexpr int COT = 32 * WM, CIT = 32 * NCI, NPAIR = NCI * WM, KP = 4 / NPAIR;     // KP K parts: rows and, at KP = 4, 16-pixel steps
   constexpr int DYP = 72;              // dy pitch per cout in pixels (144 B: conflict-free 16-byte reads)
   constexpr int XRP = 40;              // input row pitch in pixels (34 used)
@@ -554,7 +617,8 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
       v0 = (okc && x < W) ? v0 : 0.f;
       v1 = (okc && x + 1 < W) ? v1 : 0.f;
       unsigned t[3];
-      split3x2(v0, v1, t[0], t[1], t[2]);
+      if constexpr (HF) { split2h(v0 * hsg, v1 * hsg, t[0], t[1]); t[2] = 0u; }
+      else split3x2(v0, v1, t[0], t[1], t[2]);
       const int d = (col_l * DYP + row * 32 + col) >> 1;
       if (it < COT * 32) {
 #pragma unroll
@@ -599,7 +663,8 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
       v0 = (okc && x >= 0 && x < W) ? v0 : 0.f;
       v1 = (okc && x + 1 < W) ? v1 : 0.f;
       unsigned t[3];
-      split3x2(v0, v1, t[0], t[1], t[2]);
+      if constexpr (HF) { split2h(v0 * SC_H_SX, v1 * SC_H_SX, t[0], t[1]); t[2] = 0u; }
+      else split3x2(v0, v1, t[0], t[1], t[2]);
       const int slot = (y + 1) & 3;
       const int d = ((cil * XCP + slot * XRP) >> 1) + pr;
       if (it < 2 * 17 * CIT) {
@@ -640,7 +705,7 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
         // the six partial products, taps interleaved so that consecutive MFMAs hit different accumulators
 #define SC_BX3_STEP(TA, TB)                                                                                         \
   _Pragma("unroll") for (int kw = 0; kw < 3; ++kw)                                                                  \
-      acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[TA], B[kw][TB], acc[kw], 0, 0, 0);
+      acc[kw] = mfma_split<HF>(A[TA], B[kw][TB], acc[kw]);
         if constexpr (NT == 3) { SC_BX3_STEP(1, 1) SC_BX3_STEP(2, 0) SC_BX3_STEP(0, 2) SC_BX3_STEP(1, 0) SC_BX3_STEP(0, 1) }
         if constexpr (NT == 2) { SC_BX3_STEP(0, 1) SC_BX3_STEP(1, 0) }
         SC_BX3_STEP(0, 0)
@@ -691,7 +756,7 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = cot * COT + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      if (co < p.CoP && ci < p.CiP) pb[(kh * 3 + kw) * plane + (size_t)co * p.CiP + ci] = acc[kw][r];
+      if (co < p.CoP && ci < p.CiP) pb[(kh * 3 + kw) * plane + (size_t)co * p.CiP + ci] = HF ? acc[kw][r] * hinv : acc[kw][r];
     }
   }
 }
@@ -772,15 +837,13 @@ __global__ __launch_bounds__(256) void k_pack_batch(const PackDesc* __restrict__
   const int m = mt * d.co_t + col, k = chunk * 16 + half * 8 + j, tap = kh * 3 + kw;
   float v = 0.f;
   if (m < M && k < K) v = d.tflip ? d.w[((size_t)k * M + m) * 9 + (8 - tap)] : d.w[((size_t)m * K + k) * 9 + tap];
-  const __bf16 t0 = (__bf16)v;
-  float rr = v - (float)t0;
-  const __bf16 t1 = (__bf16)rr;
-  rr -= (float)t1;
-  const __bf16 t2 = (__bf16)rr;
+  unsigned short t[3];
+  const bool hmode = d.bx3 == SC_TERMS_F16X2;
+  const int nt = hmode ? 2 : d.bx3;
+  split_filter(v, hmode, t);
   const size_t stage = ((size_t)mt * nchunk + chunk) * 3 + kh;
-  const __bf16 t[3] = {t0, t1, t2};
   unsigned short* out = reinterpret_cast<unsigned short*>(d.wpk);
-  for (int c = 0; c < d.bx3; ++c) out[((((stage * d.bx3 + c) * 3 + kw) * 2 + half) * d.co_t + col) * 8 + j] = __builtin_bit_cast(unsigned short, t[c]);
+  for (int c = 0; c < nt; ++c) out[((((stage * nt + c) * 3 + kw) * 2 + half) * d.co_t + col) * 8 + j] = t[c];
 }
 
 }  // namespace
@@ -788,12 +851,12 @@ __global__ __launch_bounds__(256) void k_pack_batch(const PackDesc* __restrict__
 extern "C" size_t sc_packed_weight_floats_bx3(int Cout, int Cin, int co_t, int transpose_flip, int terms) {
   const int M = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
   const size_t mt = (M + co_t - 1) / co_t, nchunk = (K + 15) / 16;
-  return mt * nchunk * 3 * 6 * (size_t)(terms >= 1 && terms <= 3 ? terms : 3) * co_t * 4;     // 16-byte entries -> floats
+  return mt * nchunk * 3 * 6 * (size_t)(terms == SC_TERMS_F16X2 ? 2 : (terms >= 1 && terms <= 3 ? terms : 3)) * co_t * 4;     // 16-byte entries -> floats
 }
 
 extern "C" int sc_pack_weights_bx3(const float* w, float* wpk, int Cout, int Cin, int co_t, int transpose_flip,
                                    int terms, sc_stream stream) {
-  SC_REQUIRE(terms >= 1 && terms <= 3, "sc_pack_weights_bx3: terms must be 1, 2 or 3 (got %d)", terms);
+  SC_REQUIRE(terms >= 1 && terms <= 4, "sc_pack_weights_bx3: terms must be 1, 2, 3 or SC_TERMS_F16X2 (got %d)", terms);
   SC_REQUIRE(w && wpk && Cout > 0 && Cin > 0, "sc_pack_weights_bx3: bad argument");
   SC_REQUIRE(co_t == 32 || co_t == 64, "sc_pack_weights_bx3: co_t must be 32 or 64 (got %d)", co_t);
   SC_REQUIRE(((uintptr_t)wpk & 15) == 0, "sc_pack_weights_bx3: destination must be 16-byte aligned");
@@ -802,7 +865,8 @@ extern "C" int sc_pack_weights_bx3(const float* w, float* wpk, int Cout, int Cin
   const size_t total = (size_t)((M + co_t - 1) / co_t) * nchunk * 9 * 2 * co_t * 8;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(k_pack_weights_bx3, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
-                     reinterpret_cast<unsigned short*>(wpk), Cout, Cin, co_t, transpose_flip, nchunk, terms, total);
+                     reinterpret_cast<unsigned short*>(wpk), Cout, Cin, co_t, transpose_flip, nchunk,
+                     terms == SC_TERMS_F16X2 ? 2 : terms, terms == SC_TERMS_F16X2 ? 1 : 0, total);
   SC_LAUNCH_OK("sc_pack_weights_bx3");
   return SC_OK;
 }
@@ -840,15 +904,17 @@ extern "C" int sc_conv3x3_bx3(const sc_conv_args* a, sc_stream stream) {
   dim3 grid(((a->W + 31) / 32) * ((a->H + 7) / 8), co_tiles, a->N);
   hipStream_t st = (hipStream_t)stream;
   const bool bnb = a->src[0].mode == SC_SRC_BNBWD;
-  SC_REQUIRE(a->terms >= 0 && a->terms <= 3, "sc_conv3x3_bx3: terms must be 0 (= 3), 1, 2 or 3 (got %d)", a->terms);
-#define SC_LAUNCH_BX3(NT)                                                                                  \
-  do {                                                                                                     \
-    if (a->co_t == 64 && bnb) hipLaunchKernelGGL((k_conv3_bx3<2, true, NT>), grid, dim3(256), 0, st, p);   \
-    else if (a->co_t == 64) hipLaunchKernelGGL((k_conv3_bx3<2, false, NT>), grid, dim3(256), 0, st, p);    \
-    else if (bnb) hipLaunchKernelGGL((k_conv3_bx3<1, true, NT>), grid, dim3(256), 0, st, p);               \
-    else hipLaunchKernelGGL((k_conv3_bx3<1, false, NT>), grid, dim3(256), 0, st, p);                       \
+  SC_REQUIRE(a->terms >= 0 && a->terms <= 4, "sc_conv3x3_bx3: terms must be 0 (= 3), 1, 2, 3 or SC_TERMS_F16X2 (got %d)", a->terms);
+  p.absmax = a->absmax;
+#define SC_LAUNCH_BX3(NT, HF)                                                                                  \
+  do {                                                                                                         \
+    if (a->co_t == 64 && bnb) hipLaunchKernelGGL((k_conv3_bx3<2, true, NT, HF>), grid, dim3(256), 0, st, p);   \
+    else if (a->co_t == 64) hipLaunchKernelGGL((k_conv3_bx3<2, false, NT, HF>), grid, dim3(256), 0, st, p);    \
+    else if (bnb) hipLaunchKernelGGL((k_conv3_bx3<1, true, NT, HF>), grid, dim3(256), 0, st, p);               \
+    else hipLaunchKernelGGL((k_conv3_bx3<1, false, NT, HF>), grid, dim3(256), 0, st, p);                       \
   } while (0)
-  if (a->terms == 1) SC_LAUNCH_BX3(1); else if (a->terms == 2) SC_LAUNCH_BX3(2); else SC_LAUNCH_BX3(3);
+  if (a->terms == 1) SC_LAUNCH_BX3(1, false); else if (a->terms == 2) SC_LAUNCH_BX3(2, false);
+  else if (a->terms == SC_TERMS_F16X2) SC_LAUNCH_BX3(2, true); else SC_LAUNCH_BX3(3, false);
 #undef SC_LAUNCH_BX3
   SC_LAUNCH_OK("sc_conv3x3_bx3");
   return SC_OK;
@@ -884,16 +950,18 @@ extern "C" int sc_conv3x3_wgrad_bx3(const sc_wgrad_args* a, sc_stream stream) {
   p.nsl = pl.nsl; p.CoP = pl.CoP; p.CiP = pl.CiP;
   dim3 grid(pl.nsl, pl.ci_tiles, pl.co_tiles);
   hipStream_t st = (hipStream_t)stream;
-  SC_REQUIRE(a->terms >= 0 && a->terms <= 3, "sc_conv3x3_wgrad_bx3: terms must be 0 (= 3), 1, 2 or 3 (got %d)", a->terms);
-#define SC_WGX(WM_, NT_, NCI_) hipLaunchKernelGGL((k_wgrad3_bx3<WM_, NT_, NCI_>), grid, dim3(768), 0, st, p)
-#define SC_WGX_NT(NT_)                                   \
-  do {                                                   \
-    if (pl.wm == 2 && pl.nci == 2) SC_WGX(2, NT_, 2);    \
-    else if (pl.wm == 2) SC_WGX(2, NT_, 1);              \
-    else if (pl.nci == 2) SC_WGX(1, NT_, 2);             \
-    else SC_WGX(1, NT_, 1);                              \
+  SC_REQUIRE(a->terms >= 0 && a->terms <= 4, "sc_conv3x3_wgrad_bx3: terms must be 0 (= 3), 1, 2, 3 or SC_TERMS_F16X2 (got %d)", a->terms);
+  p.absmax = a->absmax;
+#define SC_WGX(WM_, NT_, NCI_, HF_) hipLaunchKernelGGL((k_wgrad3_bx3<WM_, NT_, NCI_, HF_>), grid, dim3(768), 0, st, p)
+#define SC_WGX_NT(NT_, HF_)                                   \
+  do {                                                        \
+    if (pl.wm == 2 && pl.nci == 2) SC_WGX(2, NT_, 2, HF_);    \
+    else if (pl.wm == 2) SC_WGX(2, NT_, 1, HF_);              \
+    else if (pl.nci == 2) SC_WGX(1, NT_, 2, HF_);             \
+    else SC_WGX(1, NT_, 1, HF_);                              \
   } while (0)
-  if (a->terms == 1) SC_WGX_NT(1); else if (a->terms == 2) SC_WGX_NT(2); else SC_WGX_NT(3);
+  if (a->terms == 1) SC_WGX_NT(1, false); else if (a->terms == 2) SC_WGX_NT(2, false);
+  else if (a->terms == SC_TERMS_F16X2) SC_WGX_NT(2, true); else SC_WGX_NT(3, false);
 #undef SC_WGX_NT
 #undef SC_WGX
   SC_LAUNCH_OK("sc_conv3x3_wgrad_bx3");

@@ -80,9 +80,24 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ s
   o[0] = scale; o[1] = shift; o[2] = meanf; o[3] = invstd; o[4] = 0.f; o[5] = 0.f; o[6] = 0.f; o[7] = 0.f;
 }
 
+// max over the block of m (>= 0), then *slot = max(*slot, m * factor): the order-independent (hence reproducible) unsigned
+// atomicMax on the bit pattern of a non-negative float
+__device__ __forceinline__ void block_absmax_to(float m, float factor, float* slot, float* s_m) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3])) * fabsf(factor);
+    if (t > 0.f) atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, t));
+  }
+}
+
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ g, const float* __restrict__ y,
-                                                       const float* __restrict__ cst, int act, double* __restrict__ sums, int C, int HW) {
+                                                       const float* __restrict__ cst, int act, double* __restrict__ sums, int C, int HW,
+                                                       float* __restrict__ absmax) {
   __shared__ double s_tmp[8];
+  __shared__ float s_m[4];
   const int c = blockIdx.y, n = blockIdx.z;
   const float scale = cst[(size_t)c * SC_CST], shift = cst[(size_t)c * SC_CST + 1];
   const float mean = cst[(size_t)c * SC_CST + 2], invstd = cst[(size_t)c * SC_CST + 3];
@@ -90,7 +105,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
   const size_t base = ((size_t)n * C + c) * HW;
   const int start = blockIdx.x * 4096;
   const int end = min(start + 4096, HW);
-  float s1 = 0.f, s2 = 0.f;
+  float s1 = 0.f, s2 = 0.f, mx = 0.f;
   if ((HW & 3) == 0) {
     for (int i = start + threadIdx.x * 4; i < end; i += 1024) {
       const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
@@ -102,6 +117,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
         const float gb = (yh > lo && yh < hi) ? ga[k] : 0.f;
         s1 += gb;
         s2 = fmaf(gb, (ya[k] - mean) * invstd, s2);
+        mx = fmaxf(mx, fabsf(gb));
       }
     }
   } else {
@@ -111,11 +127,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
       const float gb = (yh > lo && yh < hi) ? gv : 0.f;
       s1 += gb;
       s2 = fmaf(gb, (yv - mean) * invstd, s2);
+      mx = fmaxf(mx, fabsf(gb));
     }
   }
   double v[2] = {(double)s1, (double)s2};
   block_sum_d<2>(v, s_tmp);
   if (threadIdx.x < 2) sums[(stat_row() * C + c) * 2 + threadIdx.x] = v[threadIdx.x];
+  if (absmax) block_absmax_to(mx, scale, absmax, s_m);
 }
 
 // Low-resolution layers: one block per channel walks all N*HW elements of its channel and finalises in the same launch
@@ -123,8 +141,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
 // 32x32, 10^4 work-groups of a few hundred elements each).
 __global__ __launch_bounds__(256) void k_bn_bwd_small(const float* __restrict__ g, const float* __restrict__ y,
                                                       const float* __restrict__ cst, int act, int N, int C, int HW, double count,
-                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ cst_bwd) {
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ cst_bwd,
+                                                      float* __restrict__ absmax) {
   __shared__ double s_tmp[8];
+  __shared__ float s_m[4];
+  float mx = 0.f;
   const int c = blockIdx.x;
   const float scale = cst[(size_t)c * SC_CST], shift = cst[(size_t)c * SC_CST + 1];
   const float mean = cst[(size_t)c * SC_CST + 2], invstd = cst[(size_t)c * SC_CST + 3];
@@ -144,6 +165,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_small(const float* __restrict__ 
           const float gb = (yh > lo && yh < hi) ? ga[k] : 0.f;
           s1 += gb;
           s2 = fmaf(gb, (ya[k] - mean) * invstd, s2);
+          mx = fmaxf(mx, fabsf(gb));
         }
       }
     } else {
@@ -153,11 +175,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_small(const float* __restrict__ 
         const float gb = (yh > lo && yh < hi) ? gv : 0.f;
         s1 += gb;
         s2 = fmaf(gb, (yv - mean) * invstd, s2);
+        mx = fmaxf(mx, fabsf(gb));
       }
     }
     v[0] += (double)s1; v[1] += (double)s2;
   }
   block_sum_d<2>(v, s_tmp);
+  if (absmax) block_absmax_to(mx, scale, absmax, s_m);
   if (threadIdx.x != 0) return;
   const double t1 = v[0], t2 = v[1];
   if (dbeta) dbeta[c] = (float)t1;
@@ -391,19 +415,19 @@ extern "C" int sc_bn_finalize(const float* stats, int nrows, double count, const
 }
 
 extern "C" int sc_bn_bwd_reduce(const float* g, const float* y, const float* cst_fwd, int act, double* sums, int N, int C,
-                                int HW, sc_stream stream) {
+                                int HW, float* absmax, sc_stream stream) {
   SC_REQUIRE(g && y && cst_fwd && sums && N > 0 && C > 0 && HW > 0, "sc_bn_bwd_reduce: bad argument");
   dim3 grid((HW + 4095) / 4096, C, N);
-  hipLaunchKernelGGL(k_bn_bwd_reduce, grid, dim3(256), 0, (hipStream_t)stream, g, y, cst_fwd, act, sums, C, HW);
+  hipLaunchKernelGGL(k_bn_bwd_reduce, grid, dim3(256), 0, (hipStream_t)stream, g, y, cst_fwd, act, sums, C, HW, absmax);
   SC_LAUNCH_OK("sc_bn_bwd_reduce");
   return SC_OK;
 }
 
 extern "C" int sc_bn_bwd_small(const float* g, const float* y, const float* cst_fwd, int act, int N, int C, int HW,
-                               float* dgamma, float* dbeta, float* cst_bwd, sc_stream stream) {
+                               float* dgamma, float* dbeta, float* cst_bwd, float* absmax, sc_stream stream) {
   SC_REQUIRE(g && y && cst_fwd && cst_bwd && N > 0 && C > 0 && HW > 0, "sc_bn_bwd_small: bad argument");
   hipLaunchKernelGGL(k_bn_bwd_small, dim3(C), dim3(256), 0, (hipStream_t)stream, g, y, cst_fwd, act, N, C, HW,
-                     (double)N * HW, dgamma, dbeta, cst_bwd);
+                     (double)N * HW, dgamma, dbeta, cst_bwd, absmax);
   SC_LAUNCH_OK("sc_bn_bwd_small");
   return SC_OK;
 }

@@ -25,7 +25,8 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD,
-                   STAT_CONV1, STAT_CONV1K, STAT_CONV3, STAT_DW, STAT_STEM, check, make_src, ptr, sc_conv_args, sc_wgrad_args, stream)
+                   STAT_CONV1, STAT_CONV1K, STAT_CONV3, STAT_DW, STAT_STEM, TERMS_F16X2, check, make_src, ptr, sc_conv_args, sc_wgrad_args,
+                   stream)
 
 MBV2_SETTINGS = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2),
                  (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1))
@@ -342,6 +343,8 @@ class HyperStarcopUNet(nn.Module):
             plan.ws_floats = ws
             plan.up_tmp = torch.empty(max(up, 1), **f32)
             plan.dw_acc = torch.zeros(n_dw, dtype=torch.float64, device=dev)
+            # one float per BatchNorm'd tensor: max |gamma*invstd * g| of its gradient, the range hint of the fp16-split kernels
+            plan.gmax = torch.zeros(len(self._ops) + 1, dtype=torch.float32, device=dev)
             for t in self._tensors.values():
                 if t.bn is not None:
                     plan.bsums_v[t.name] = torch.empty(plan.brows[t.name] * t.C * 2, dtype=torch.float64, device=dev)
@@ -519,15 +522,16 @@ class HyperStarcopUNet(nn.Module):
     overlap_wgrad = True
     split_bf16 = True        # 3x3 convs with >= 32 output channels on the bf16 matrix cores (three-term split, fp32 accuracy)
     bn_small_max = 16384     # BatchNorm backward in one launch (block per channel) when a channel has at most this many elements
-    # Arithmetic of the 3x3 convolutions with >= 32 channels (conv_bx3.hip): every fp32 operand is split exactly into k bf16
-    # terms and the products of weight >= 2^-8k are accumulated in fp32 on the bf16 matrix cores.
-    #   "fp32"       three terms forward and backward (six products; error = one fp32 rounding; the parity / bench default)
-    #   "fp32-bwd2"  three terms forward, two in dgrad/wgrad (three products, operand error 2^-18: measured <= 1e-5 on the
-    #                gradients against the contract's 1e-3; the logits are bit-identical to "fp32")
-    #   "fp32-2"     two terms everywhere (logits ~2e-5 from the oracle, inside the 1e-4 contract with less margin)
-    #   "bf16"       one term: plain bf16 matrix math, fp32 accumulation and fp32 tensors in HBM (BASELINE configs[3])
+    # Arithmetic of the 3x3 convolutions with >= 32 channels (conv_bx3.hip): every fp32 operand is split exactly into a few
+    # 16-bit terms while it is staged and the leading products are accumulated in fp32 on the matrix cores.
+    #   "fp32"       two fp16 terms per operand (22 significand bits, exact power-of-two range scaling), three products:
+    #                error below the fp32 accumulation error of the reduction -- the parity / bench default
+    #   "fp32-x3"    three bf16 terms, six products (error = one fp32 rounding, fp32's full exponent range; 11 % slower)
+    #   "fp32-bwd2"  three bf16 terms forward, two in dgrad/wgrad (operand error 2^-18; logits identical to "fp32-x3")
+    #   "fp32-2"     two bf16 terms everywhere (logits ~2e-5 from the oracle, inside the 1e-4 contract with less margin)
+    #   "bf16"       one bf16 term: plain bf16 matrix math, fp32 accumulation and fp32 tensors in HBM (BASELINE configs[3])
     precision = "fp32"
-    _TERMS = {"fp32": (3, 3), "fp32-bwd2": (3, 2), "fp32-2": (2, 2), "bf16": (1, 1)}
+    _TERMS = {"fp32": (TERMS_F16X2, TERMS_F16X2), "fp32-x3": (3, 3), "fp32-bwd2": (3, 2), "fp32-2": (2, 2), "bf16": (1, 1)}
 
     def _bx3_family(self, which):
         """profiling family of the split-bf16 3x3 kernel: forward and dgrad launches are one family unless they run with a
@@ -574,6 +578,10 @@ class HyperStarcopUNet(nn.Module):
                                "statistics); call .train() first")
         dlogits = dlogits.contiguous()
         plan.dw_acc.zero_()
+        half_bwd = self._terms[1] == TERMS_F16X2
+        gmax_slot = {}
+        if half_bwd:
+            plan.gmax.zero_()
         written = set()
         res_of = {}       # tensor name -> name of the residual sum z (z = t + ...)
         for op in self._ops:
@@ -587,14 +595,18 @@ class HyperStarcopUNet(nn.Module):
                 dw_offs[i] = dw_off
                 dw_off += op["conv"].out_channels * 9
 
-        def bn_backward(t):
+        def bn_backward(t, slot=None):
             Ho, Wo = H >> t.shift, W >> t.shift
+            amax = None
+            if slot is not None:
+                amax = plan.gmax.data_ptr() + 4 * slot
+                gmax_slot[t.name] = amax
             if N * Ho * Wo <= self.bn_small_max and t.C >= 64:        # low-resolution layers: one launch, one block per channel
                 check(lib.sc_bn_bwd_small(ptr(plan.grad[t.name]), ptr(plan.buf[t.name]), ptr(plan.cst[t.name]), t.act, N, t.C,
-                                          Ho * Wo, ptr(gv(t.bn.weight)), ptr(gv(t.bn.bias)), ptr(plan.cstb[t.name]), st))
+                                          Ho * Wo, ptr(gv(t.bn.weight)), ptr(gv(t.bn.bias)), ptr(plan.cstb[t.name]), amax, st))
                 return
             check(lib.sc_bn_bwd_reduce(ptr(plan.grad[t.name]), ptr(plan.buf[t.name]), ptr(plan.cst[t.name]), t.act,
-                                       ptr(plan.bsums_v[t.name]), N, t.C, Ho * Wo, st))
+                                       ptr(plan.bsums_v[t.name]), N, t.C, Ho * Wo, amax, st))
             check(lib.sc_bn_bwd_finalize(ptr(plan.bsums_v[t.name]), plan.brows[t.name], float(N * Ho * Wo), ptr(plan.cst[t.name]),
                                          ptr(gv(t.bn.weight)), ptr(gv(t.bn.bias)), ptr(plan.cstb[t.name]), t.C, st))
 
@@ -633,7 +645,7 @@ class HyperStarcopUNet(nn.Module):
                 written.add(p_t.name)
                 continue
             tok = self._pb("elementwise/bn")
-            bn_backward(o)
+            bn_backward(o, i if (half_bwd and ty == "conv3") else None)
             self._pe(tok)
             dy = self._dy_src(plan, o)
             if ty == "stem":
@@ -672,6 +684,7 @@ class HyperStarcopUNet(nn.Module):
             wa.part = plan.ws.data_ptr(); wa.part_floats = plan.ws_floats
             wa.dw = gv(conv.weight).data_ptr()
             wa.terms = self._terms[1]
+            wa.absmax = gmax_slot.get(o.name)
             flop = 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * ks * ks
             wfn = (lib.sc_conv3x3_wgrad_bx3 if (self.split_bf16 and ks == 3 and conv.out_channels >= 32 and conv.in_channels >= 32)
                    else lib.sc_conv2d_wgrad_mfma)     # thin layers (16 channels on either side) stay on the fp32 MFMA
@@ -689,6 +702,7 @@ class HyperStarcopUNet(nn.Module):
             a.N, a.H, a.W, a.Cout = N, Ho, Wo, conv.in_channels
             a.ks, a.co_t = ks, ent["cot_b"]
             a.terms = ent["terms_b"]
+            a.absmax = gmax_slot.get(o.name)
             if ent["bx3_b"]:
                 conv_dgrad = lib.sc_conv3x3_bx3
             elif _use_ksplit(N, Ho * Wo, conv.out_channels, conv.in_channels, ks):

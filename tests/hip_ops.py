@@ -42,7 +42,7 @@ def pack_bx3(w, co_t, tflip, terms=3):
 
 
 def conv_mfma(srcs, wpk, N, H, W, Cout, ks, co_t, want_stats=False, csplit=None, add0=None, add1=None,
-              accum=None, outs=None, bx3=False, ksplit=False, terms=0, down0=False):
+              accum=None, outs=None, bx3=False, ksplit=False, terms=0, down0=False, absmax=None):
     lib = _lib.load()
     a = sc_conv_args()
     a.nsrc = len(srcs)
@@ -60,6 +60,7 @@ def conv_mfma(srcs, wpk, N, H, W, Cout, ks, co_t, want_stats=False, csplit=None,
     a.csplit = csplit
     a.terms = terms
     a.down0 = 1 if down0 else 0
+    a.absmax = absmax.data_ptr() if absmax is not None else None
     a.accum0, a.accum1 = (accum or (0, 0))
     a.add0 = add0.data_ptr() if add0 is not None else None
     a.add1 = add1.data_ptr() if add1 is not None else None
@@ -71,7 +72,7 @@ def conv_mfma(srcs, wpk, N, H, W, Cout, ks, co_t, want_stats=False, csplit=None,
     return outs, stats
 
 
-def wgrad_mfma(dy, srcs, N, H, W, Cout, Cin, ks, bx3=False, terms=0):
+def wgrad_mfma(dy, srcs, N, H, W, Cout, Cin, ks, bx3=False, terms=0, absmax=None):
     lib = _lib.load()
     a = sc_wgrad_args()
     a.dy = dy
@@ -80,6 +81,7 @@ def wgrad_mfma(dy, srcs, N, H, W, Cout, Cin, ks, bx3=False, terms=0):
         a.src[i] = s
     a.N, a.H, a.W, a.Cout, a.Cin, a.ks = N, H, W, Cout, Cin, ks
     a.terms = terms
+    a.absmax = absmax.data_ptr() if absmax is not None else None
     n = lib.sc_wgrad_bx3_workspace_floats(N, H, W, Cout, Cin) if bx3 else lib.sc_wgrad_workspace_floats(N, H, W, Cout, Cin, ks)
     ws = torch.empty(n, device=DEV)
     a.part, a.part_floats = ws.data_ptr(), n

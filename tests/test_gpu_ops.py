@@ -293,6 +293,57 @@ def test_conv_two_term_split(hip, cin, cout, co_t, H, W):
         assert relerr(dw, wz.grad) < 2e-5
 
 
+@pytest.mark.parametrize("gscale", [1.0, 3e-8, 2e4])
+@pytest.mark.parametrize("cin,cout,co_t,H,W", [(32, 64, 64, 36, 70), (80, 32, 32, 20, 40), (288, 128, 64, 8, 12)])
+def test_conv_two_fp16_terms(hip, cin, cout, co_t, H, W, gscale):
+    """terms = SC_TERMS_F16X2: two fp16 terms per operand (22 significand bits), three products, exact power-of-two range
+    scaling -- as accurate as the three-term bf16 split (<= 2e-6 of fp64) whatever the magnitude of the gradient tensor
+    (the scale comes from the max |A g| that sc_bn_bwd_reduce leaves in `absmax`); forward, dgrad and wgrad."""
+    from starcop_amd._lib import TERMS_F16X2
+    N = 2
+    x, w = rnd(N, cin, H, W, seed=1), rnd(cout, cin, 3, 3, seed=2, scale=0.2)
+    w[0, 0, 0, 0], w[1, 1, 1, 1] = 3e-4, 40.0                      # tiny and huge filter entries
+    cst = torch.rand(cin, SC_CST) + 0.5
+    src = make_src(dev(x), cin, SRC_AFFINE, act=ACT_RELU, cst=dev(cst))
+    xin = torch.relu(x.double() * cst[:, 0].double()[None, :, None, None] + cst[:, 1].double()[None, :, None, None])
+    ref = F.conv2d(xin, w.double(), padding=1)
+    (out,), st = conv_mfma([src], pack_bx3(dev(w), co_t, 0, TERMS_F16X2), N, H, W, cout, 3, co_t, bx3=True, terms=TERMS_F16X2, want_stats=True)
+    assert relerr(out, ref) < 2e-6
+    assert relerr(st.sum(0)[:, 0], ref.sum((0, 2, 3))) < 1e-5       # the statistics see the un-scaled values
+    # gradient operand through the BatchNorm-backward prologue, at three magnitudes
+    g, y = rnd(N, cout, H, W, seed=3) * gscale, rnd(N, cout, H, W, seed=4)
+    a, b = rnd(cout, seed=4) * 0.2 + 1, rnd(cout, seed=5) * 0.2
+    A, B, D = a.clone(), rnd(cout, seed=7) * 0.1 * gscale, rnd(cout, seed=8) * 0.1 * gscale
+    yh = y * a[None, :, None, None] + b[None, :, None, None]
+    gm = torch.where(yh > 0, g, torch.zeros(()))
+    dy = (gm.double() * A.double()[None, :, None, None] + B.double()[None, :, None, None] * y.double() + D.double()[None, :, None, None])
+    cstb = torch.zeros(cout, SC_CST); cstb[:, 0], cstb[:, 1], cstb[:, 2], cstb[:, 3], cstb[:, 4] = a, b, A, B, D
+    # the range hint exactly as the network produces it: sc_bn_bwd_reduce on (g, y) with the forward constants (scale = A)
+    cf = torch.zeros(cout, SC_CST); cf[:, 0], cf[:, 1], cf[:, 2], cf[:, 3] = a, b, 0.0, 1.0
+    rows = hip.sc_stat_rows(STAT_BNBWD, N, H, W)
+    sums = torch.empty(rows * cout * 2, dtype=torch.float64, device=DEV)
+    amax = torch.zeros(1, device=DEV)
+    gd, yd = dev(g), dev(y)
+    check(hip.sc_bn_bwd_reduce(ptr(gd), ptr(yd), ptr(dev(cf)), ACT_RELU, ptr(sums), N, cout, H * W, ptr(amax), stream()))
+    want_max = float((gm.abs().amax((0, 2, 3)) * a.abs()).max())
+    assert float(amax) == pytest.approx(want_max, rel=1e-6)
+    dsrc = make_src(gd, cout, SRC_BNBWD, act=ACT_RELU, cst=dev(cstb), aux=yd)
+    cb = 32 if cin <= 32 else 64
+    (dx,), _ = conv_mfma([dsrc], pack_bx3(dev(w), cb, 1, TERMS_F16X2), N, H, W, cin, 3, cb, bx3=True, terms=TERMS_F16X2, absmax=amax)
+    assert relerr(dx, F.conv_transpose2d(dy, w.double(), padding=1)) < 1e-5     # dy itself is formed in fp32
+    if cin >= 32 and cout >= 32:
+        wz = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xin, wz, padding=1).backward(dy)
+        dw = wgrad_mfma(dsrc, [src], N, H, W, cout, cin, 3, bx3=True, terms=TERMS_F16X2, absmax=amax)
+        dw3 = wgrad_mfma(dsrc, [src], N, H, W, cout, cin, 3, bx3=True, terms=3)
+        assert relerr(dw, wz.grad) < max(1e-5, 2 * relerr(dw3, wz.grad))
+    # bn_bwd_small leaves the same hint
+    amax2 = torch.zeros(1, device=DEV)
+    dg2, db2, cb2 = torch.empty(cout, device=DEV), torch.empty(cout, device=DEV), torch.empty(cout, SC_CST, device=DEV)
+    check(hip.sc_bn_bwd_small(ptr(gd), ptr(yd), ptr(dev(cf)), ACT_RELU, N, cout, H * W, ptr(dg2), ptr(db2), ptr(cb2), ptr(amax2), stream()))
+    assert float(amax2) == float(amax)
+
+
 @pytest.mark.parametrize("cin,cout,cs,H,W,co_t", [(80, 32, 64, 16, 64, 64), (152, 64, 128, 24, 40, 64), (32, 16, 32, 20, 36, 32), (288, 128, 256, 8, 12, 64)])
 def test_conv_bx3_dgrad_fused_upsample_backward(hip, cin, cout, cs, H, W, co_t):
     """decoder conv1 data gradient: channels [0, cs) belong to the nearest-x2-upsampled input -> stored as 2x2 sums at half
@@ -447,13 +498,13 @@ def test_batchnorm_bookkeeping(hip):
     nrows = hip.sc_stat_rows(STAT_BNBWD, N, H, W)
     sums = torch.full((nrows, C_, 2), float("nan"), dtype=torch.float64, device=DEV)
     gd = dev(g)
-    check(hip.sc_bn_bwd_reduce(ptr(gd), ptr(yd), ptr(cst), ACT_RELU6, ptr(sums), N, C_, H * W, stream()))
+    check(hip.sc_bn_bwd_reduce(ptr(gd), ptr(yd), ptr(cst), ACT_RELU6, ptr(sums), N, C_, H * W, None, stream()))
     dgm, dbt, cstb = torch.empty(C_, device=DEV), torch.empty(C_, device=DEV), torch.zeros(C_, SC_CST, device=DEV)
     check(hip.sc_bn_bwd_finalize(ptr(sums), nrows, cnt, ptr(cst), ptr(dgm), ptr(dbt), ptr(cstb), C_, stream()))
     assert relerr(dgm, gamma.grad) < TOL and relerr(dbt, beta.grad) < TOL
     # one-launch form for few-pixel layers
     dg2, db2, cb2 = torch.empty(C_, device=DEV), torch.empty(C_, device=DEV), torch.full((C_, SC_CST), float("nan"), device=DEV)
-    check(hip.sc_bn_bwd_small(ptr(gd), ptr(yd), ptr(cst), ACT_RELU6, N, C_, H * W, ptr(dg2), ptr(db2), ptr(cb2), stream()))
+    check(hip.sc_bn_bwd_small(ptr(gd), ptr(yd), ptr(cst), ACT_RELU6, N, C_, H * W, ptr(dg2), ptr(db2), ptr(cb2), None, stream()))
     assert relerr(dg2, gamma.grad) < TOL and relerr(db2, beta.grad) < TOL and relerr(cb2, cstb) < 1e-5
     dsrc = make_src(gd, C_, SRC_BNBWD, act=ACT_RELU6, cst=cstb, aux=yd)
     dyd = torch.empty_like(yd)

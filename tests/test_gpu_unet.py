@@ -227,14 +227,16 @@ def test_training_trajectory_follows_the_oracle(hip):
     assert l_hip[-1] < l_hip[0]
 
 
-@pytest.mark.parametrize("precision", ["fp32-bwd2", "fp32-2"])
+@pytest.mark.parametrize("precision", ["fp32-bwd2", "fp32-2", "fp32-x3"])
 def test_two_term_precision_modes(hip, precision):
-    """"fp32-bwd2": forward identical to "fp32" bit for bit, gradients (two bf16 terms per operand in dgrad/wgrad) as close to
+    """"fp32-x3": the three-term bf16 split (fp32's exponent range) as an alternative to the default two-fp16-term kernels.
+    "fp32-bwd2": forward identical to "fp32-x3" bit for bit, gradients (two bf16 terms per operand in dgrad/wgrad) as close to
     the fp64 oracle as the contract asks (<= max(1e-3, 10x the fp32 oracle's own deviation)).  "fp32-2": logits within the
     1e-4 contract as well."""
     B, H, W = 4, 128, 128
     model, ref = make_pair(seed=3, pos_weight=1.0)
     strict = copy.deepcopy(model)
+    strict.network.precision = "fp32-x3"
     model.network.precision = precision
     model.train(); strict.train(); ref.train()
     ref64 = copy.deepcopy(ref).double()
@@ -268,4 +270,4 @@ def test_two_term_precision_modes(hip, precision):
     with torch.no_grad():
         want = ref(ref_normalize(batch["input"]))
         got = model(to_dev(batch)["input"])
-    assert relerr(got, want) < (1e-4 if precision == "fp32-2" else 1e-5)
+    assert relerr(got, want) < (1e-4 if precision == "fp32-2" else 1e-5)     # fp32-h2 (two fp16 terms): as tight as the three-term split

@@ -7,7 +7,7 @@ from hip_ops import DEV, conv_mfma, pack, pack_bx3
 from starcop_amd._lib import SRC_AFFINE, SRC_BNBWD, ACT_RELU, SC_CST, make_src
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-TERMS = int(os.environ.get("SC_TERMS", "3"))
+TERMS = int(os.environ.get("SC_TERMS", "4"))     # 4 = two fp16 terms (the default mode), 3 / 2 / 1 = bf16 terms
 # (name, cin, cout, H)
 SHAPES = [("d0a", 1376, 256, 32), ("d0b", 256, 256, 32), ("d1a", 288, 128, 64), ("d1b", 128, 128, 64), ("d2a", 152, 64, 128),
           ("d2b", 64, 64, 128), ("d3a", 80, 32, 256), ("d3b", 32, 32, 256), ("d0a.dgrad", 256, 1376, 32), ("d1a.dgrad", 128, 288, 64),
