@@ -196,8 +196,8 @@ def main():
                 "unit": "GB/s" if hbm else "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
                 "peak_note": "HBM3E peak (MI355X_MICROARCH.md); achieved = algorithmic bytes of these launches / their time" if hbm else
-                             (f"fp32-equivalent ceiling of the {nterms}-term split: dense bf16 MFMA peak 2500 TFLOP/s / {int(nprod)} products; "
-                              f"the kernel executes {round(nprod * ach, 1)} bf16 TFLOP/s on the matrix cores; "
+                             (f"fp32-equivalent ceiling of the {'two-fp16-term' if nterms == 4 else str(nterms) + '-bf16-term'} split: dense 16-bit MFMA peak "
+                              f"2500 TFLOP/s / {int(nprod)} products; the kernel executes {round(nprod * ach, 1)} 16-bit TFLOP/s on the matrix cores; "
                               f"{round(ach / FP32_MFMA_PEAK_TFLOPS, 3)} x the fp32 MFMA peak of {FP32_MFMA_PEAK_TFLOPS}") if bx3 else
                              "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
                 "algorithmic_bytes_per_launch": round(d["bytes"] / d["n"]) if d.get("bytes") else None,
@@ -212,7 +212,8 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
                "config": {"workload": "configs[1]: HyperSTARCOP U-Net (smp.Unet mobilenet_v2, 4ch mag1c+RGB) train step "
-                                      "fwd+loss+bwd+Adam, 512x512 tiles, fp32 HIP kernels (3x3 convs: fp32 via exact 3-term bf16 split on the bf16 MFMA)",
+                                      "fwd+loss+bwd+Adam, 512x512 tiles, fp32 HIP kernels (3x3 convs: fp32 operands split exactly into 16-bit terms on the "
+                                      "matrix cores, fp32 accumulation; see config.precision and DESIGN.md section 2)",
                           "batch_per_gpu": B, "global_batch": B * world, "tile": [4, T, T],
                           "parallelism": f"dp{world}", "hipgraph": graph is not None, "final_loss": round(loss, 6),
                           "precision": args.precision},

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
   // that are pinned between the MFMAs by scheduler barriers: each slice (<= 7 VALU) issues in the shadow of one MFMA.
   auto step = [&](const bf16x8 (&A)[Q][NT], const bf16x8 (&B)[NT], auto ppc, auto cvt, int unit) {
     constexpr int PP = decltype(ppc)::value;
-    constexpr bool CV = decltype(cvt)::value && NT == 3;
+    constexpr bool CV = decltype(cvt)::value && NT == 3;     // (measured: no gain from interleaving the two-term conversions)
     constexpr int TA[6] = {NT == 3 ? 1 : 0, NT == 3 ? 2 : 1, 0, 1, 0, 0}, TB[6] = {NT == 3 ? 1 : (NT == 2 ? 1 : 0), 0, NT == 3 ? 2 : 0, 0, 1, 0};
     constexpr int NM = (NT == 3 ? 6 : (NT == 2 ? 3 : 1)) * Q;
     constexpr int G = NM >= 6 ? NM / 6 : 1;         // MFMAs between slices
@@ -290,13 +290,15 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
         __builtin_amdgcn_sched_barrier(0);
         if (sl == 0) v0 = pro(2 * jp);
         if (sl == 1) v1 = pro(2 * jp + 1);
-        if (sl == 2) { vv = (floatx2){v0, v1}; h0 = __builtin_convertvector(vv, bf16x2); vv -= __builtin_convertvector(h0, floatx2); }
-        if (sl == 3) { h1 = __builtin_convertvector(vv, bf16x2); vv -= __builtin_convertvector(h1, floatx2); }
-        if (sl == 4) {
-          h2 = __builtin_convertvector(vv, bf16x2);
-          pt[r][0][jp] = __builtin_bit_cast(unsigned, h0);
-          pt[r][NT > 1 ? 1 : 0][jp] = __builtin_bit_cast(unsigned, NT > 1 ? h1 : h0);
-          pt[r][NT > 2 ? 2 : 0][jp] = __builtin_bit_cast(unsigned, NT > 2 ? h2 : h0);
+        {
+          if (sl == 2) { vv = (floatx2){v0, v1}; h0 = __builtin_convertvector(vv, bf16x2); vv -= __builtin_convertvector(h0, floatx2); }
+          if (sl == 3) { h1 = __builtin_convertvector(vv, bf16x2); vv -= __builtin_convertvector(h1, floatx2); }
+          if (sl == 4) {
+            h2 = __builtin_convertvector(vv, bf16x2);
+            pt[r][0][jp] = __builtin_bit_cast(unsigned, h0);
+            pt[r][NT > 1 ? 1 : 0][jp] = __builtin_bit_cast(unsigned, NT > 1 ? h1 : h0);
+            pt[r][NT > 2 ? 2 : 0][jp] = __builtin_bit_cast(unsigned, NT > 2 ? h2 : h0);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }

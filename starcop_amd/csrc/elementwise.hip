@@ -89,7 +89,9 @@ __device__ __forceinline__ void block_absmax_to(float m, float factor, float* sl
   __syncthreads();
   if (threadIdx.x == 0) {
     const float t = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3])) * fabsf(factor);
-    if (t > 0.f) atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, t));
+    // thousands of blocks share the slot: only those that would raise it pay for the atomic (a stale read just means
+    // one atomic more; the result is the maximum either way)
+    if (t > __builtin_nontemporal_load(slot)) atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, t));
   }
 }
 

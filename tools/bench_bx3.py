@@ -34,7 +34,7 @@ for name, cin, cout, H in SHAPES:
     bwd = name.endswith("dgrad")
     src = make_src(x, cin, SRC_BNBWD, act=ACT_RELU, cst=cst, aux=y) if bwd else make_src(x, cin, SRC_AFFINE, act=ACT_RELU, cst=cst)
     flop = 2.0 * N * H * W * cin * cout * 9
-    co_t = 64 if cout > 32 else 32
+    co_t = int(os.environ.get("SC_COT", "0")) or (64 if cout > 32 else 32)
     wf, wb = pack(w, co_t, 0), pack_bx3(w, co_t, 0, TERMS)
     outs = [torch.empty(N, cout, H, W, device=DEV)]
     t32 = timeit(lambda: conv_mfma([src], wf, N, H, W, cout, 3, co_t, want_stats=not bwd, outs=outs))
