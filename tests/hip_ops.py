@@ -33,7 +33,13 @@ def pack(w, co_t, tflip):
     return out
 
 
-def pack_bx3(w, co_t, tflip, terms=3):
+# the split the un-parametrised bx3 tests run with: 3 = three bf16 terms, 4 = two fp16 terms (SC_TERMS_F16X2, the network default);
+# tests/test_gpu_ops.py and tests/test_gpu_fuzz.py run their split-kernel cases under both (fixture `split_mode`)
+DEFAULT_BX3_TERMS = 3
+
+
+def pack_bx3(w, co_t, tflip, terms=None):
+    terms = DEFAULT_BX3_TERMS if terms is None else terms
     lib = _lib.load()
     co, ci = w.shape[0], w.shape[1]
     out = torch.empty(lib.sc_packed_weight_floats_bx3(co, ci, co_t, tflip, terms), device=DEV)
@@ -58,7 +64,7 @@ def conv_mfma(srcs, wpk, N, H, W, Cout, ks, co_t, want_stats=False, csplit=None,
     a.out0 = outs[0].data_ptr()
     a.out1 = outs[1].data_ptr() if len(outs) > 1 else None
     a.csplit = csplit
-    a.terms = terms
+    a.terms = terms if (terms or not bx3) else DEFAULT_BX3_TERMS
     a.down0 = 1 if down0 else 0
     a.absmax = absmax.data_ptr() if absmax is not None else None
     a.accum0, a.accum1 = (accum or (0, 0))
@@ -80,7 +86,7 @@ def wgrad_mfma(dy, srcs, N, H, W, Cout, Cin, ks, bx3=False, terms=0, absmax=None
     for i, s in enumerate(srcs):
         a.src[i] = s
     a.N, a.H, a.W, a.Cout, a.Cin, a.ks = N, H, W, Cout, Cin, ks
-    a.terms = terms
+    a.terms = terms if (terms or not bx3) else DEFAULT_BX3_TERMS
     a.absmax = absmax.data_ptr() if absmax is not None else None
     n = lib.sc_wgrad_bx3_workspace_floats(N, H, W, Cout, Cin) if bx3 else lib.sc_wgrad_workspace_floats(N, H, W, Cout, Cin, ks)
     ws = torch.empty(n, device=DEV)

@@ -16,8 +16,18 @@ def _rnd(rng, *shape, scale=1.0):
     return torch.from_numpy(rng.standard_normal(shape).astype(np.float32) * scale)
 
 
+@pytest.fixture(params=[3, 4], ids=["bf16x3", "fp16x2"])
+def split_mode(request):
+    """run a split-kernel test under both operand splits (three bf16 terms / two fp16 terms)"""
+    import hip_ops
+    old, hip_ops.DEFAULT_BX3_TERMS = hip_ops.DEFAULT_BX3_TERMS, request.param
+    yield request.param
+    hip_ops.DEFAULT_BX3_TERMS = old
+
+
+
 @pytest.mark.parametrize("seed", range(12))
-def test_fuzz_conv3(hip, seed):
+def test_fuzz_conv3(hip, split_mode, seed):
     rng = np.random.default_rng(1000 + seed)
     N = int(rng.integers(1, 4))
     H, W = int(rng.integers(3, 45)), int(rng.integers(3, 75))
@@ -83,7 +93,7 @@ def test_fuzz_conv1(hip, seed):
 
 
 @pytest.mark.parametrize("seed", range(4))
-def test_fuzz_concat_upsample(hip, seed):
+def test_fuzz_concat_upsample(hip, split_mode, seed):
     rng = np.random.default_rng(3000 + seed)
     N = int(rng.integers(1, 3))
     H, W = 2 * int(rng.integers(2, 14)), 2 * int(rng.integers(2, 30))

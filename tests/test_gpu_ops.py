@@ -13,6 +13,15 @@ from starcop_amd import _lib  # noqa: E402
 from starcop_amd._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD,
                               STAT_DW, STAT_STEM, check, make_src, ptr, stream)  # noqa: E402
 
+@pytest.fixture(params=[3, 4], ids=["bf16x3", "fp16x2"])
+def split_mode(request):
+    """run a split-kernel test under both operand splits (three bf16 terms / two fp16 terms)"""
+    import hip_ops
+    old, hip_ops.DEFAULT_BX3_TERMS = hip_ops.DEFAULT_BX3_TERMS, request.param
+    yield request.param
+    hip_ops.DEFAULT_BX3_TERMS = old
+
+
 TOL = 1e-4
 
 
@@ -156,7 +165,7 @@ BX3_TOL = 1e-5      # vs an fp64 reference; each case is also required to be no 
 
 @pytest.mark.parametrize("cin,cout,co_t,H,W", [(16, 64, 64, 32, 32), (40, 16, 32, 12, 40), (32, 64, 64, 36, 70), (24, 96, 32, 20, 40),
                                                 (64, 40, 64, 37, 33), (1376, 256, 64, 4, 6), (8, 8, 32, 8, 8)])
-def test_conv_bx3_fwd_affine_stats(hip, cin, cout, co_t, H, W):
+def test_conv_bx3_fwd_affine_stats(hip, split_mode, cin, cout, co_t, H, W):
     N = 2
     x, w = rnd(N, cin, H, W, seed=1), rnd(cout, cin, 3, 3, seed=2, scale=0.2)
     sc, sh = rnd(cin, seed=3) * 0.5 + 1.0, rnd(cin, seed=4) * 0.3
@@ -175,7 +184,7 @@ def test_conv_bx3_fwd_affine_stats(hip, cin, cout, co_t, H, W):
     assert relerr(st[:, 1], (ref ** 2).sum((0, 2, 3))) < 1e-5
 
 
-def test_conv_bx3_upsample_concat(hip):
+def test_conv_bx3_upsample_concat(hip, split_mode):
     N, c0, c1, cout, H, W = 2, 32, 24, 48, 16, 64
     prev, skip = rnd(N, c0, H // 2, W // 2, seed=1), rnd(N, c1, H, W, seed=2)
     w = rnd(cout, c0 + c1, 3, 3, seed=3, scale=0.1)
@@ -191,7 +200,7 @@ def test_conv_bx3_upsample_concat(hip):
 
 
 @pytest.mark.parametrize("cin,cout,H,W", [(32, 16, 32, 32), (16, 32, 20, 40), (80, 32, 16, 32), (256, 128, 4, 6), (152, 64, 24, 32)])
-def test_conv_bx3_dgrad_bnbwd_split_add(hip, cin, cout, H, W):
+def test_conv_bx3_dgrad_bnbwd_split_add(hip, split_mode, cin, cout, H, W):
     N = 2
     g, y = rnd(N, cout, H, W, seed=1), rnd(N, cout, H, W, seed=2)
     w = rnd(cout, cin, 3, 3, seed=3, scale=0.2)
@@ -345,7 +354,7 @@ def test_conv_two_fp16_terms(hip, cin, cout, co_t, H, W, gscale):
 
 
 @pytest.mark.parametrize("cin,cout,cs,H,W,co_t", [(80, 32, 64, 16, 64, 64), (152, 64, 128, 24, 40, 64), (32, 16, 32, 20, 36, 32), (288, 128, 256, 8, 12, 64)])
-def test_conv_bx3_dgrad_fused_upsample_backward(hip, cin, cout, cs, H, W, co_t):
+def test_conv_bx3_dgrad_fused_upsample_backward(hip, split_mode, cin, cout, cs, H, W, co_t):
     """decoder conv1 data gradient: channels [0, cs) belong to the nearest-x2-upsampled input -> stored as 2x2 sums at half
     resolution (== F.interpolate backward), the skip channels at full resolution; with and without accumulation."""
     N = 2
@@ -367,7 +376,7 @@ def test_conv_bx3_dgrad_fused_upsample_backward(hip, cin, cout, cs, H, W, co_t):
 
 @pytest.mark.parametrize("cin,cout,H,W,two", [(16, 64, 32, 32, False), (32, 16, 36, 70, True), (32, 32, 24, 40, False), (48, 40, 21, 32, False), (32, 64, 16, 32, True),
                                                (80, 32, 20, 36, True), (152, 64, 8, 64, True), (256, 256, 4, 6, False), (72, 136, 10, 33, False)])
-def test_conv_bx3_wgrad(hip, cin, cout, H, W, two):
+def test_conv_bx3_wgrad(hip, split_mode, cin, cout, H, W, two):
     """3x3 weight gradient with split-bf16 operands: vs fp64, and no worse than the fp32 MFMA kernel."""
     N = 3
     g, y = rnd(N, cout, H, W, seed=1), rnd(N, cout, H, W, seed=2)
