@@ -178,9 +178,13 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
   };
   auto load_round = [&](int r) {
     const unsigned o = second ? off1[r] : off0[r];
+    // channels beyond the source's last one re-read its LAST channel (masked to zero at conversion): clamping to channel 0
+    // instead makes the address equal to j = 0's, which the compiler turns into "load channel 0, wait for it, copy, branch
+    // around the other loads" -- a memory round trip at issue time in every staging round
+    const int jmax = nch > 0 ? nch - 1 : 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const size_t cj = (j < nch) ? (size_t)j * plane : 0;
+      const size_t cj = (size_t)(j < jmax ? j : jmax) * plane;
       xv[r][j] = xb[cj + o];
       if (BNB) av[r][j] = ab[cj + o];
     }
@@ -191,9 +195,10 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
   uintx4 pt[NR][NT];
   float cs0[8], cs1[8], cs2[8], cs3[8], cs4[8];         // per-channel constants of the chunk being staged
   auto load_consts = [&]() {
+    const int jmax = nch > 0 ? nch - 1 : 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int cj = (j < nch) ? j : 0;
+      const int cj = j < jmax ? j : jmax;
       cs0[j] = 1.f; cs1[j] = 0.f; cs2[j] = 0.f; cs3[j] = 0.f; cs4[j] = 0.f;
       if (cb) {
         const float4 c = *reinterpret_cast<const float4*>(cb + (size_t)cj * SC_CST);
