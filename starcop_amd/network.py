@@ -136,6 +136,43 @@ class HyperStarcopUNet(nn.Module):
         self._plans = {}
         self._pflat = self._gflat = None
         self._pack_version = None
+        self.register_load_state_dict_post_hook(HyperStarcopUNet._after_load)
+
+    @staticmethod
+    def _after_load(module, incompatible_keys):
+        module.check_split_range()          # (a post hook must return None)
+
+    # -- range of the default (two-fp16-term) split: filters are scaled by 2^8 and activations by 2 before the fp16 conversion
+    FP16_MAX_WEIGHT, FP16_MAX_ACT = 255.0, 32752.0
+
+    def split_range_report(self):
+        """Largest |filter| of the split 3x3 convolutions and a bound on their input activations, max_c(64 |gamma_c| + |beta_c|)
+        over the BatchNorms that feed them (|x_hat| <= 64 covers every realistic tile), against the limits of the two-fp16-term
+        kernels.  Synchronises the device; called once after a checkpoint is loaded."""
+        wmax = amax = 0.0
+        for op in self._ops:
+            if op["type"] != "conv3" or _pick_cot(op["conv"].out_channels, 3) < 32:
+                continue
+            wmax = max(wmax, float(op["conv"].weight.detach().abs().max()))
+            for t in op["ins"]:
+                bn = getattr(t, "bn", None)
+                if bn is not None:
+                    amax = max(amax, float((64.0 * bn.weight.detach().abs() + bn.bias.detach().abs()).max()))
+        return dict(max_abs_filter=wmax, filter_limit=self.FP16_MAX_WEIGHT, activation_bound=amax, activation_limit=self.FP16_MAX_ACT,
+                    ok=bool(wmax < self.FP16_MAX_WEIGHT and amax < self.FP16_MAX_ACT))
+
+    def check_split_range(self):
+        """A checkpoint whose filters or BatchNorm gains leave the fp16 range of the default split is run with the
+        three-term bf16 split (fp32's exponent range) instead -- never with silently clamped operands."""
+        if self.precision != "fp32":
+            return True
+        rep = self.split_range_report()
+        if not rep["ok"]:
+            import warnings
+            warnings.warn(f"HyperStarcopUNet: parameters outside the range of the two-fp16-term kernels ({rep}); "
+                          f"switching to precision='fp32-x3' (three bf16 terms, no range limits)")
+            self.precision = "fp32-x3"
+        return rep["ok"]
 
     # -- init conventions of torchvision MobileNetV2 / smp initialize_decoder / initialize_head
     def reset_parameters(self):

@@ -271,3 +271,31 @@ def test_two_term_precision_modes(hip, precision):
         want = ref(ref_normalize(batch["input"]))
         got = model(to_dev(batch)["input"])
     assert relerr(got, want) < (1e-4 if precision == "fp32-2" else 1e-5)     # fp32-h2 (two fp16 terms): as tight as the three-term split
+
+
+def test_checkpoint_outside_fp16_range_falls_back_to_three_term_split(hip):
+    """the default split scales filters by 2^8 and activations by 2 into fp16: a checkpoint beyond that range must run with the
+    three-term bf16 split (fp32's exponent range) instead of clamped operands -- and still match the oracle."""
+    model, ref = make_pair(seed=1, pos_weight=1.0)
+    net = model.network
+    assert net.precision == "fp32" and net.split_range_report()["ok"]
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    k = "decoder.blocks.1.conv1.0.weight"
+    sd[k][3, 5, 1, 1] = 300.0                                   # > 255: not representable after the 2^8 filter scale
+    with pytest.warns(UserWarning, match="fp32-x3"):
+        net.load_state_dict(sd)
+    assert net.precision == "fp32-x3" and not net.split_range_report()["ok"]
+    ref.load_state_dict({k: v.cpu() for k, v in sd.items()})
+    model.eval(); ref.eval()
+    batch = synth_batch(2, 64, 64, seed=2)
+    with torch.no_grad():
+        want = ref(ref_normalize(batch["input"]))
+        got = model(to_dev(batch)["input"])
+    assert relerr(got, want) < 1e-4
+    # a huge BatchNorm gain in front of a split convolution does the same
+    model2, _ = make_pair(seed=1, pos_weight=1.0)
+    sd = {k: v.clone() for k, v in model2.network.state_dict().items()}
+    sd["decoder.blocks.0.conv1.1.weight"][7] = 600.0
+    with pytest.warns(UserWarning):
+        model2.network.load_state_dict(sd)
+    assert model2.network.precision == "fp32-x3"
