@@ -410,6 +410,9 @@ class HyperStarcopUNet(nn.Module):
             tf_, tb_ = self._terms
             if ent is None or ent["f"].device != dev or ent["split"] != (self.split_bf16, tf_, tb_):
                 cf, cb = _pick_cot(co, ks), _pick_cot(ci, ks)
+                if ks == 3 and co <= 16 and ci >= 32 and self.split_bf16:
+                    cf = 32       # decoder.blocks.4.conv1 (32 -> 16): the split kernel with half-empty cout blocks still beats
+                                  # the fp32-MFMA thin kernel (0.36 vs 0.50 ms); 16 -> 16 layers do not (tools/bench_thin_bx3.py)
                 # 3x3 layers with >= 32 output channels run on the bf16 matrix cores with three-term split operands
                 # (fp32 accuracy, conv_bx3.hip); thin ones stay on the fp32 MFMA kernels
                 xf = self.split_bf16 and ks == 3 and cf >= 32
