@@ -54,7 +54,16 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ s
   double mean, var;
   if (training) {
     double v[2] = {0.0, 0.0};
-    for (int r = threadIdx.x; r < nrows; r += 256) {
+    // up to 32768 rows (512x512 layers): eight independent loads in flight per thread, summed in the same order as a plain loop
+    int r = threadIdx.x;
+    for (; r + 7 * 256 < nrows; r += 8 * 256) {
+      float2 t[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const float2*>(stats + ((size_t)(r + 256 * k) * C + c) * 2);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { v[0] += (double)t[k].x; v[1] += (double)t[k].y; }
+    }
+    for (; r < nrows; r += 256) {
       const float2 t = *reinterpret_cast<const float2*>(stats + ((size_t)r * C + c) * 2);
       v[0] += (double)t.x; v[1] += (double)t.y;
     }

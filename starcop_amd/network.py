@@ -413,8 +413,8 @@ class HyperStarcopUNet(nn.Module):
                 if ks == 3 and co <= 16 and ci >= 32 and self.split_bf16:
                     cf = 32       # decoder.blocks.4.conv1 (32 -> 16): the split kernel with half-empty cout blocks still beats
                                   # the fp32-MFMA thin kernel (0.36 vs 0.50 ms); 16 -> 16 layers do not (tools/bench_thin_bx3.py)
-                # 3x3 layers with >= 32 output channels run on the bf16 matrix cores with three-term split operands
-                # (fp32 accuracy, conv_bx3.hip); thin ones stay on the fp32 MFMA kernels
+                # 3x3 layers with >= 32 output channels run on the 16-bit matrix cores with exactly-split operands
+                # (fp32-level accuracy, conv_bx3.hip; `precision` picks the split); thin ones stay on the fp32 MFMA kernels
                 xf = self.split_bf16 and ks == 3 and cf >= 32
                 xb = self.split_bf16 and ks == 3 and cb >= 32
                 nf = lib.sc_packed_weight_floats_bx3(co, ci, cf, 0, tf_) if xf else lib.sc_packed_weight_floats(co, ci, ks, cf, 0)
@@ -560,7 +560,7 @@ class HyperStarcopUNet(nn.Module):
     # HIP stream, forked after each layer's BatchNorm-backward constants and joined before the optimiser, so they fill
     # the CUs the small dgrad / reduce kernels of the dependency chain leave idle.
     overlap_wgrad = True
-    split_bf16 = True        # 3x3 convs with >= 32 output channels on the bf16 matrix cores (three-term split, fp32 accuracy)
+    split_bf16 = True        # 3x3 convs with >= 32 output channels on the 16-bit matrix cores (False: everything on the fp32 MFMA)
     bn_small_max = 16384     # BatchNorm backward in one launch (block per channel) when a channel has at most this many elements
     # Arithmetic of the 3x3 convolutions with >= 32 channels (conv_bx3.hip): every fp32 operand is split exactly into a few
     # 16-bit terms while it is staged and the leading products are accumulated in fp32 on the matrix cores.
