@@ -175,7 +175,7 @@ def main():
         d = prof[fam]
         ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
         traffic, traffic_note = None, None
-        bx3 = "bx3" in fam
+        bx3 = "bx3" in fam or "thin_h" in fam
         # k_conv3_bx3 / k_wgrad3_bx3 compute fp32-accurate products as 6 bf16 MFMAs: the ceiling for ALGORITHMIC flops is the
         # dense bf16 MFMA peak / 6; the fp32-MFMA kernels are priced against the fp32 matrix peak.
         tf_, tb_ = net._terms                                # bf16 terms per operand, forward / backward

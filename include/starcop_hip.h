@@ -165,6 +165,16 @@ typedef struct sc_wgrad_args {
 } sc_wgrad_args;
 size_t sc_wgrad_workspace_floats(int N, int H, int W, int Cout, int Cin, int ks);
 int sc_conv2d_wgrad_mfma(const sc_wgrad_args* a, sc_stream stream);
+/* Thin 3x3 layers (Cout <= 16, Cin = 16 or 32: smp's decoder.blocks.4 at full resolution) with two fp16 terms on
+ * v_mfma_f32_16x16x32_f16: the filter bank stays in registers, all input channels are staged in one pass.  Same arguments as
+ * sc_conv3x3_bx3 with terms = SC_TERMS_F16X2, nsrc = 1, a single plain output (csplit = Cout, no add / accumulate / down0);
+ * `wpk` from sc_pack_weights_thin16 (or a sc_pack_desc with bx3 = SC_PACK_THIN16); statistics rows SC_STAT_CONV3.
+ * Forward, or backward-data with transpose_flip-packed filters (then "Cout" is the layer's input channel count). */
+#define SC_PACK_THIN16 5
+size_t sc_packed_weight_floats_thin16(int Cout, int Cin, int transpose_flip);
+int sc_pack_weights_thin16(const float* w_oihw, float* wpk, int Cout, int Cin, int transpose_flip, sc_stream stream);
+int sc_conv3x3_thin16(const sc_conv_args* a, sc_stream stream);
+
 /* the 3x3 weight gradient with split-bf16 operands on the bf16 matrix cores (see sc_conv3x3_bx3); same arguments,
  * ks must be 3; workspace from sc_wgrad_bx3_workspace_floats */
 size_t sc_wgrad_bx3_workspace_floats(int N, int H, int W, int Cout, int Cin);

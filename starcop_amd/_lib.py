@@ -114,10 +114,14 @@ SIGNATURES = {
     "sc_trimmed_sums": (_i, [_vp, _i, _sz, _d, _vp, _vp, _sz, _vp]),
     "sc_band_ratio": (_i, [_vp, _vp, _vp, _i, _sz, _vp, _vp, _f, _f, _vp]),
     "sc_clip_scale": (_i, [_vp, _vp, _sz, _f, _f, _f, _f, _i, _vp]),
+    "sc_packed_weight_floats_thin16": (_sz, [_i, _i, _i]),
+    "sc_pack_weights_thin16": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "sc_conv3x3_thin16": (_i, [C.POINTER(sc_conv_args), _vp]),
     "sc_binary_opening": (_i, [_vp, _f, _i, _vp, _vp, _i, _i, _i, _vp]),
     "sc_threshold_confusion": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "sc_gather_augment": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
 }
+PACK_THIN16 = 5        # sc_pack_desc.bx3 code of the register layout of sc_conv3x3_thin16
 TERMS_F16X2 = 4        # `terms` code of the two-fp16-term kernels (include/starcop_hip.h SC_TERMS_F16X2)
 SE_CROSS = 0xBA        # the 3x3 cross of starcop/baselines.py:39-41 as sc_binary_opening's se_bits
 

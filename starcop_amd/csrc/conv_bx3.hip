@@ -474,6 +474,178 @@ __device__ __forceinline__ void split_filter(float v, bool half, unsigned short 
   t[0] = __builtin_bit_cast(unsigned short, t0); t[1] = __builtin_bit_cast(unsigned short, t1); t[2] = __builtin_bit_cast(unsigned short, t2);
 }
 
+// ------------------------------------------------------------------------------------------
+// Thin 3x3 layers (<= 16 output channels, 16 or 32 input channels: decoder.blocks.4, 512x512) with two fp16 terms on
+// v_mfma_f32_16x16x32_f16.  The whole filter bank (<= 16 x 32 x 9) lives in REGISTERS in MFMA-operand form (A: lane -> cout l&15,
+// k = 8*(l>>4)..+7; 5 or 9 K steps x 2 terms x 4 VGPRs), all input channels of the 10x34 patch are staged in ONE pass (no K loop,
+// one barrier), and a K step covers 32 = (taps x channels): with 16 input channels two taps per MFMA.
+//   B: lane -> pixel l&15 of a 16-pixel block, k group l>>4 -> (tap, channel half): one 16-byte LDS read
+//   D: lane -> pixel l&15, couts 4*(l>>4) .. +3
+// Work-group = 4 waves, tile 8 rows x 32 px; wave = 2 rows = four 16-pixel blocks.  Single source (may be upsampled), single
+// output, optional statistics rows (SC_STAT_CONV3 layout); anything else stays on the other kernels.
+template <int CIN, bool BNB>
+__global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
+  constexpr int PR = 10, PC = 34, NPX = PR * PC;
+  constexpr int NH = CIN / 8;                 // 8-channel groups
+  constexpr int NG = 9 * NH, NS = (NG + 3) / 4;
+  constexpr int NE = (NPX * NH + 255) / 256;  // staging entries (pixel x channel group) per thread
+  __shared__ uintx4 s_p[2][NH][NPX];
+  __shared__ float s_red[4][16][2];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int n = blockIdx.z;
+  const int H = p.H, W = p.W;
+  const int tiles_x = (W + 31) >> 5;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int y0 = ty * 8, x0 = tx * 32;
+  const float hsx = BNB ? h_grad_scale(p.absmax) : SC_H_SX;
+  const float hinv = 1.f / (hsx * SC_H_SW);
+
+  uintx4 A[NS][2];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) A[s][t] = p.wpk[(s * 2 + t) * 64 + lane];
+
+  // ---- stage the patch: entry q -> (channel group, patch pixel); consecutive lanes = consecutive pixels
+  const SrcD& src = p.s0;
+  const int up = src.up;
+  const int Ws = W >> up;
+  const size_t plane = (size_t)(H >> up) * Ws;
+  const float slo = sc_act_lo(src.act), shi = sc_act_hi(src.act);
+  float xv[NE][8], av[BNB ? NE : 1][8];
+  bool okv[NE];
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    const int q = tid + 256 * k;
+    const int grp = q / NPX, e = q - grp * NPX;
+    const int pr = e / PC, pc = e - pr * PC;
+    const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+    const bool ok = (q < NPX * NH) && y >= 0 && y < H && x >= 0 && x < W;
+    okv[k] = ok;
+    const unsigned off = ok ? (unsigned)((y >> up) * Ws + (x >> up)) : 0u;
+    const int g8 = (q < NPX * NH ? grp : 0) * 8;
+    const float* xb = src.x + ((size_t)n * CIN + g8) * plane + off;
+    const float* ab = BNB ? src.aux + ((size_t)n * CIN + g8) * plane + off : nullptr;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      xv[k][j] = xb[(size_t)j * plane];
+      if (BNB) av[k][j] = ab[(size_t)j * plane];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    const int q = tid + 256 * k;
+    const int grp = q / NPX, e = q - grp * NPX;
+    const int g8 = (q < NPX * NH ? grp : 0) * 8;
+    uintx4 t0, t1;
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+      float v[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = 2 * jp + h;
+        float4 c = make_float4(1.f, 0.f, 0.f, 0.f);
+        float c4 = 0.f;
+        if (src.mode != SC_SRC_RAW) {
+          c = *reinterpret_cast<const float4*>(src.cst + (size_t)(g8 + j) * SC_CST);
+          if (BNB) c4 = src.cst[(size_t)(g8 + j) * SC_CST + 4];
+        }
+        const float t = BNB ? sc_pro_bnbwd(xv[k][j], av[BNB ? k : 0][j], c.x, c.y, c.z, c.w, c4, slo, shi)
+                            : sc_pro_affine(xv[k][j], c.x, c.y, slo, shi);
+        v[h] = okv[k] ? t * hsx : 0.f;
+      }
+      unsigned a0, a1;
+      split2h(v[0], v[1], a0, a1);
+      t0[jp] = a0; t1[jp] = a1;
+    }
+    if (q < NPX * NH) { s_p[0][grp][e] = t0; s_p[1][grp][e] = t1; }
+  }
+  __syncthreads();
+
+  // ---- MFMAs: four 16-pixel blocks per wave, all K steps from LDS, filters from registers
+  floatx4 acc[4];
+#pragma unroll
+  for (int pb = 0; pb < 4; ++pb) acc[pb] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int gi = 4 * s + lg;
+    const int gic = gi < NG ? gi : 0;            // padded K groups: zero filters, any finite patch entry
+    const int tap = gic / NH, half = gic - tap * NH;
+    const int kh = tap / 3, kw = tap - 3 * kh;
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+      const int e = (2 * wave + (pb >> 1) + kh) * PC + 16 * (pb & 1) + l15 + kw;
+      const halfx8 b0 = __builtin_bit_cast(halfx8, s_p[0][half][e]);
+      const halfx8 b1 = __builtin_bit_cast(halfx8, s_p[1][half][e]);
+      const halfx8 a0 = __builtin_bit_cast(halfx8, A[s][0]);
+      const halfx8 a1 = __builtin_bit_cast(halfx8, A[s][1]);
+      acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, acc[pb], 0, 0, 0);
+      acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, acc[pb], 0, 0, 0);
+      acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc[pb], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: store, per-cout sums of the wave's 2 x 32 pixels
+  const size_t HWs = (size_t)H * W;
+  const bool want_stats = p.stats != nullptr;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co = 4 * lg + r;
+    float sv = 0.f, sq = 0.f;
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+      const int oy = y0 + 2 * wave + (pb >> 1), ox = x0 + 16 * (pb & 1) + l15;
+      const bool ok = oy < H && ox < W && co < p.Cout;
+      const float v = ok ? acc[pb][r] * hinv : 0.f;
+      sv += v; sq = fmaf(v, v, sq);
+      if (ok) p.out0[((size_t)n * p.Cout + co) * HWs + (size_t)oy * W + ox] = v;
+    }
+    if (want_stats) {
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { sv += __shfl_xor(sv, o, 64); sq += __shfl_xor(sq, o, 64); }
+      if (l15 == 0) { s_red[wave][co][0] = sv; s_red[wave][co][1] = sq; }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    const int rows4 = (H + 3) >> 2;
+    if (tid < 2 * 16 * 2) {
+      const int hh = tid >> 5, col = (tid >> 1) & 15, k = tid & 1;
+      const int t4 = 2 * ty + hh;
+      if (col < p.Cout && t4 < rows4) {
+        const size_t row = ((size_t)n * rows4 + t4) * tiles_x + tx;
+        p.stats[(row * p.Cout + col) * 2 + k] = s_red[2 * hh][col][k] + s_red[2 * hh + 1][col][k];
+      }
+    }
+  }
+}
+
+// filters of a thin layer in the register layout of k_conv3_thin_h: entry ((s*2 + term)*64 + lane) of 8 halves
+__device__ __forceinline__ void pack_thin_item(const float* __restrict__ w, unsigned short* __restrict__ out, size_t i, int Cout, int Cin,
+                                               int tflip) {
+  const int M = tflip ? Cin : Cout, K = tflip ? Cout : Cin;      // rows (<= 16), reduction channels (16 | 32)
+  const int NH = K / 8, NG = 9 * NH;
+  const int j = (int)(i & 7);
+  const int lane = (int)((i >> 3) & 63);
+  const int s = (int)(i >> 9);
+  const int m = lane & 15, gi = 4 * s + (lane >> 4);
+  float v = 0.f;
+  if (gi < NG && m < M) {
+    const int tap = gi / NH, k = (gi - tap * NH) * 8 + j;
+    v = tflip ? w[((size_t)k * M + m) * 9 + (8 - tap)] : w[((size_t)m * K + k) * 9 + tap];
+  }
+  unsigned short t[3];
+  split_filter(v, true, t);
+  out[((size_t)(s * 2 + 0) * 64 + lane) * 8 + j] = t[0];
+  out[((size_t)(s * 2 + 1) * 64 + lane) * 8 + j] = t[1];
+}
+__global__ void k_pack_weights_thin(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout, int Cin, int tflip, size_t total) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < total) pack_thin_item(w, wpk, i, Cout, Cin, tflip);
+}
+
 __global__ void k_pack_weights_bx3(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout, int Cin,
                                    int co_t, int tflip, int nchunk, int nt, int half, size_t total) {
   const int M = tflip ? Cin : Cout, K = tflip ? Cout : Cin;
@@ -817,6 +989,7 @@ __global__ __launch_bounds__(256) void k_pack_batch(const PackDesc* __restrict__
   const PackDesc d = descs[lo];
   const size_t i = (size_t)(blockIdx.x - starts[lo]) * 256 + threadIdx.x;
   if (i >= d.total) return;
+  if (d.bx3 == SC_PACK_THIN16) { pack_thin_item(d.w, reinterpret_cast<unsigned short*>(d.wpk), i, d.Cout, d.Cin, d.tflip); return; }
   const int M = d.tflip ? d.Cin : d.Cout, K = d.tflip ? d.Cout : d.Cin;
   const int taps = d.ks * d.ks;
   if (!d.bx3) {
@@ -975,7 +1148,57 @@ extern "C" int sc_conv3x3_wgrad_bx3(const sc_wgrad_args* a, sc_stream stream) {
   return sc_wgrad_finish(a->part, pl.nsl * pl.kp, 9, a->Cout, a->Cin, pl.CoP, pl.CiP, a->dw, st);
 }
 
+static int thin_steps(int Cout, int Cin, int transpose_flip) { return (9 * ((transpose_flip ? Cout : Cin) / 8) + 3) / 4; }
+
+extern "C" size_t sc_packed_weight_floats_thin16(int Cout, int Cin, int transpose_flip) {
+  return (size_t)thin_steps(Cout, Cin, transpose_flip) * 2 * 64 * 4;       // 16-byte entries -> floats
+}
+
+static bool thin16_shape_ok(int Cout, int Cin, int transpose_flip) {
+  const int M = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
+  return M >= 1 && M <= 16 && (K == 16 || K == 32);
+}
+
+extern "C" int sc_pack_weights_thin16(const float* w, float* wpk, int Cout, int Cin, int transpose_flip, sc_stream stream) {
+  SC_REQUIRE(w && wpk && ((uintptr_t)wpk & 15) == 0, "sc_pack_weights_thin16: bad pointer");
+  SC_REQUIRE(thin16_shape_ok(Cout, Cin, transpose_flip), "sc_pack_weights_thin16: needs <= 16 output and 16 or 32 input channels (got %d, %d, flip %d)",
+             Cout, Cin, transpose_flip);
+  const size_t total = (size_t)thin_steps(Cout, Cin, transpose_flip) * 512;
+  hipLaunchKernelGGL(k_pack_weights_thin, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     reinterpret_cast<unsigned short*>(wpk), Cout, Cin, transpose_flip, total);
+  SC_LAUNCH_OK("sc_pack_weights_thin16");
+  return SC_OK;
+}
+
+extern "C" int sc_conv3x3_thin16(const sc_conv_args* a, sc_stream stream) {
+  SC_REQUIRE(a != nullptr && a->ks == 3 && a->nsrc == 1, "sc_conv3x3_thin16: one source, ks = 3");
+  const int Cin = a->src[0].C;
+  SC_REQUIRE(a->Cout >= 1 && a->Cout <= 16 && (Cin == 16 || Cin == 32), "sc_conv3x3_thin16: needs <= 16 output and 16 or 32 input channels (got %d, %d)",
+             a->Cout, Cin);
+  SC_REQUIRE(a->N > 0 && a->N <= 65535 && a->H > 0 && a->W > 0, "sc_conv3x3_thin16: bad shape");
+  SC_REQUIRE(a->csplit == a->Cout && !a->accum0 && !a->add0 && !a->add1 && !a->down0 && a->out0,
+             "sc_conv3x3_thin16: a single plain output only (no split / add / accumulate / down-sum epilogue)");
+  SC_REQUIRE(a->terms == SC_TERMS_F16X2, "sc_conv3x3_thin16: terms must be SC_TERMS_F16X2");
+  SC_REQUIRE(((uintptr_t)a->wpk & 15) == 0, "sc_conv3x3_thin16: packed filters must be 16-byte aligned");
+  const sc_src& s = a->src[0];
+  SC_REQUIRE(s.up == 0 || (s.up == 1 && a->H % 2 == 0 && a->W % 2 == 0), "sc_conv3x3_thin16: upsampled source needs even H, W");
+  SC_REQUIRE(s.mode == SC_SRC_RAW || s.cst != nullptr, "sc_conv3x3_thin16: source needs constants");
+  SC_REQUIRE(s.mode != SC_SRC_NORM && (s.mode != SC_SRC_BNBWD || s.aux != nullptr), "sc_conv3x3_thin16: unsupported source");
+  ConvXP p{};
+  p.s0 = to_srcd(s); p.s1 = empty_srcd();
+  p.wpk = reinterpret_cast<const uintx4*>(a->wpk); p.N = a->N; p.H = a->H; p.W = a->W; p.Cout = a->Cout;
+  p.out0 = a->out0; p.csplit = a->Cout; p.stats = a->stats; p.absmax = a->absmax;
+  dim3 grid(((a->W + 31) / 32) * ((a->H + 7) / 8), 1, a->N);
+  hipStream_t st = (hipStream_t)stream;
+  const bool bnb = s.mode == SC_SRC_BNBWD;
+  if (Cin == 16) { if (bnb) hipLaunchKernelGGL((k_conv3_thin_h<16, true>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((k_conv3_thin_h<16, false>), grid, dim3(256), 0, st, p); }
+  else           { if (bnb) hipLaunchKernelGGL((k_conv3_thin_h<32, true>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((k_conv3_thin_h<32, false>), grid, dim3(256), 0, st, p); }
+  SC_LAUNCH_OK("sc_conv3x3_thin16");
+  return SC_OK;
+}
+
 extern "C" size_t sc_pack_work_items(int Cout, int Cin, int ks, int co_t, int transpose_flip, int bx3) {
+  if (bx3 == SC_PACK_THIN16) return (size_t)thin_steps(Cout, Cin, transpose_flip) * 512;
   if (bx3) {
     const int M = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
     return (size_t)((M + co_t - 1) / co_t) * ((K + 15) / 16) * 9 * 2 * co_t * 8;

@@ -19,14 +19,15 @@ activation backward the same way (g, y -> dy on load).
 """
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn as nn
 
 from . import _lib
 from ._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD,
-                   STAT_CONV1, STAT_CONV1K, STAT_CONV3, STAT_DW, STAT_STEM, TERMS_F16X2, check, make_src, ptr, sc_conv_args, sc_wgrad_args,
-                   stream)
+                   PACK_THIN16, STAT_CONV1, STAT_CONV1K, STAT_CONV3, STAT_DW, STAT_STEM, TERMS_F16X2, check, make_src, ptr,
+                   sc_conv_args, sc_wgrad_args, stream)
 
 MBV2_SETTINGS = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2),
                  (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1))
@@ -421,7 +422,15 @@ class HyperStarcopUNet(nn.Module):
                 nb = lib.sc_packed_weight_floats_bx3(co, ci, cb, 1, tb_) if xb else lib.sc_packed_weight_floats(co, ci, ks, cb, 1)
                 ent = dict(cot_f=cf, cot_b=cb, bx3_f=xf, bx3_b=xb, split=(self.split_bf16, tf_, tb_), terms_f=tf_, terms_b=tb_,
                            f=torch.empty(nf, dtype=torch.float32, device=dev),
-                           b=torch.empty(nb, dtype=torch.float32, device=dev))
+                           b=torch.empty(nb, dtype=torch.float32, device=dev), tf=None, tb=None)
+                # decoder.blocks.4 (<= 16 output channels at full resolution) under the two-fp16-term split: filters in registers
+                # (sc_conv3x3_thin16; 0.20-0.28 vs 0.31-0.51 ms per launch).  The backward-data kernel only takes the plain
+                # epilogue, so the regular pack is kept beside it.
+                if self.split_bf16 and self.thin16 and ks == 3 and len(op["ins"]) == 1:
+                    if tf_ == TERMS_F16X2 and co <= 16 and ci in (16, 32):
+                        ent["tf"] = torch.empty(lib.sc_packed_weight_floats_thin16(co, ci, 0), dtype=torch.float32, device=dev)
+                    if tb_ == TERMS_F16X2 and ci <= 16 and co in (16, 32):
+                        ent["tb"] = torch.empty(lib.sc_packed_weight_floats_thin16(co, ci, 1), dtype=torch.float32, device=dev)
                 self._wpk[i] = ent
                 self._pack_tables = {}
         # one launch for all packs: device-side descriptor table, built once per (need_bwd, parameter storage)
@@ -443,6 +452,13 @@ class HyperStarcopUNet(nn.Module):
                     total = lib.sc_pack_work_items(co, ci, ks, cot, tflip, int(bx))
                     rows.append((conv.weight.data_ptr(), buf.data_ptr(), co, ci, ks, cot, tflip,
                                  (ent["terms_b"] if tflip else ent["terms_f"]) if bx else 0, total))
+                    starts.append(nblk)
+                    nblk += -(-total // 256)
+                for tflip, buf in ((0, ent["tf"]), (1, ent["tb"])):
+                    if buf is None or (tflip and not need_bwd):
+                        continue
+                    total = lib.sc_pack_work_items(co, ci, ks, 16, tflip, PACK_THIN16)
+                    rows.append((conv.weight.data_ptr(), buf.data_ptr(), co, ci, ks, 16, tflip, PACK_THIN16, total))
                     starts.append(nblk)
                     nblk += -(-total // 256)
             descs = torch.from_numpy(np.array(rows, dtype=dt).view(np.uint8).copy()).to(dev)
@@ -493,7 +509,8 @@ class HyperStarcopUNet(nn.Module):
             if self.profile is not None:
                 if ty in ("pw", "conv3"):
                     src_elems = sum(t.C * (H >> t.shift) * (W >> t.shift) for t in op["ins"])
-                    tok = self._pb(self._bx3_family("fwd") if self._wpk[i]["bx3_f"] else f"k_conv_mfma<{conv.kernel_size[0]}> (fwd+dgrad)",
+                    tok = self._pb("k_conv3_thin_h (fwd+dgrad)" if self._wpk[i]["tf"] is not None else
+                                   self._bx3_family("fwd") if self._wpk[i]["bx3_f"] else f"k_conv_mfma<{conv.kernel_size[0]}> (fwd+dgrad)",
                                    2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * conv.kernel_size[0] ** 2,
                                    4.0 * (N * src_elems + N * o.C * Ho * Wo + conv.weight.numel()))
                 else:
@@ -523,7 +540,10 @@ class HyperStarcopUNet(nn.Module):
                 a.add0 = None; a.add1 = None
                 a.stats = plan.stats_v[o.name].data_ptr() if stats is not None else None
                 a.terms = ent["terms_f"]
-                if ent["bx3_f"]:
+                if ent["tf"] is not None:
+                    fconv = lib.sc_conv3x3_thin16
+                    a.wpk = ent["tf"].data_ptr()
+                elif ent["bx3_f"]:
                     fconv = lib.sc_conv3x3_bx3
                 elif _use_ksplit(N, Ho * Wo, conv.in_channels, conv.out_channels, a.ks):
                     fconv = lib.sc_conv1x1_ksplit
@@ -560,6 +580,7 @@ class HyperStarcopUNet(nn.Module):
     # HIP stream, forked after each layer's BatchNorm-backward constants and joined before the optimiser, so they fill
     # the CUs the small dgrad / reduce kernels of the dependency chain leave idle.
     overlap_wgrad = True
+    thin16 = os.environ.get("STARCOP_THIN16", "1") != "0"     # decoder.blocks.4 on sc_conv3x3_thin16 (0: the fp32-MFMA thin kernels)
     split_bf16 = True        # 3x3 convs with >= 32 output channels on the 16-bit matrix cores (False: everything on the fp32 MFMA)
     bn_small_max = 16384     # BatchNorm backward in one launch (block per channel) when a channel has at most this many elements
     # Arithmetic of the 3x3 convolutions with >= 32 channels (conv_bx3.hip): every fp32 operand is split exactly into a few
@@ -755,7 +776,9 @@ class HyperStarcopUNet(nn.Module):
             gin_elems = N * conv.in_channels * Ho * Wo
             if op.get("up") and ent["bx3_b"]:      # the upsampled source's gradient is stored 2x2-summed (quarter size)
                 gin_elems -= N * ins[0].C * Ho * Wo * 3 // 4
-            tok = self._pb(self._bx3_family("dgrad") if ent["bx3_b"] else f"k_conv_mfma<{ks}> (fwd+dgrad)", flop,
+            thin_b = (ent["tb"] is not None and not op.get("up") and ins[0].name not in written and res_of.get(ins[0].name) is None)
+            tok = self._pb("k_conv3_thin_h (fwd+dgrad)" if thin_b else
+                           self._bx3_family("dgrad") if ent["bx3_b"] else f"k_conv_mfma<{ks}> (fwd+dgrad)", flop,
                            4.0 * (2 * N * o.C * Ho * Wo + gin_elems + conv.weight.numel()))
             if op.get("up"):
                 t_up = ins[0]
@@ -788,6 +811,9 @@ class HyperStarcopUNet(nn.Module):
                 z = res_of.get(tin.name)
                 if z is not None:
                     a.add0 = plan.grad[z].data_ptr()
+                if thin_b:
+                    conv_dgrad = lib.sc_conv3x3_thin16
+                    a.wpk = ent["tb"].data_ptr()
                 check(conv_dgrad(C.byref(a), st))
                 self._pe(tok)
                 written.add(tin.name)

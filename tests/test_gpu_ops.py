@@ -290,7 +290,7 @@ def test_conv_two_term_split(hip, cin, cout, co_t, H, W):
     (out,), _ = conv_mfma([src], pack_bx3(dev(w), co_t, 0, 2), N, H, W, cout, 3, co_t, bx3=True, terms=2)
     (out3,), _ = conv_mfma([src], pack_bx3(dev(w), co_t, 0, 3), N, H, W, cout, 3, co_t, bx3=True, terms=3)
     e2, e3 = relerr(out, ref), relerr(out3, ref)
-    assert e2 < 2e-5 and e3 < 2e-6, (e2, e3)
+    assert e2 < 2e-5 and e3 < 4e-6, (e2, e3)        # e3: the fp32 accumulation noise of the K = 2592 reduction
     g = rnd(N, cout, H, W, seed=3)
     cb = 32 if cin <= 32 else 64
     (dx,), _ = conv_mfma([make_src(dev(g), cout, SRC_RAW)], pack_bx3(dev(w), cb, 1, 2), N, H, W, cin, 3, cb, bx3=True, terms=2)
@@ -589,3 +589,64 @@ def test_masks_bit_exact(hip):
         assert torch.equal(cls.cpu(), (rb.sum((-1, -2)) > 10 * H * W / 64 ** 2).long().reshape(-1))
         assert relerr(pred, torch.sigmoid(z)) < 1e-6
     assert cls.cpu().tolist()[:2] == [0, 1]
+
+
+@pytest.mark.parametrize("gscale", [1.0, 1e-6])
+@pytest.mark.parametrize("cin,cout,H,W,up", [(16, 16, 36, 70, 0), (32, 16, 24, 40, 1), (16, 9, 8, 33, 0), (32, 16, 64, 64, 0)])
+def test_conv_thin16_two_fp16_terms(hip, cin, cout, H, W, up, gscale):
+    """sc_conv3x3_thin16 (decoder.blocks.4: filters in registers, one staging pass, v_mfma_f32_16x16x32_f16): forward with
+    BatchNorm/ReLU prologue (+ nearest x2 upsampling) and statistics rows, and backward-data from transposed filters with the
+    BatchNorm-backward prologue, against fp64."""
+    from starcop_amd._lib import TERMS_F16X2, sc_conv_args
+    import ctypes as C
+    N = 2
+    lib = hip
+
+    def pack_thin(w, tflip):
+        co, ci = w.shape[:2]
+        out = torch.empty(lib.sc_packed_weight_floats_thin16(co, ci, tflip), device=DEV)
+        check(lib.sc_pack_weights_thin16(ptr(w), ptr(out), co, ci, tflip, stream()))
+        return out
+
+    def run(src, wpk, Cout_, want_stats=False, absmax=None):
+        a = sc_conv_args()
+        a.nsrc = 1; a.src[0] = src
+        a.wpk = wpk.data_ptr()
+        a.N, a.H, a.W, a.Cout, a.ks, a.co_t = N, H, W, Cout_, 3, 16
+        out = torch.full((N, Cout_, H, W), float("nan"), device=DEV)
+        a.out0 = out.data_ptr(); a.csplit = Cout_; a.terms = TERMS_F16X2
+        rows = lib.sc_stat_rows(_lib.STAT_CONV3, N, H, W)
+        st = torch.full((rows, Cout_, 2), float("nan"), device=DEV) if want_stats else None
+        a.stats = st.data_ptr() if want_stats else None
+        a.absmax = absmax.data_ptr() if absmax is not None else None
+        check(lib.sc_conv3x3_thin16(C.byref(a), stream()))
+        return out, st
+
+    x = rnd(N, cin, H >> up, W >> up, seed=1)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=0.2)
+    sc, sh = rnd(cin, seed=3) * 0.3 + 1.0, rnd(cin, seed=4) * 0.2
+    xin = torch.relu(x.double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+    if up:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin, w.double(), padding=1)
+    src = make_src(dev(x), cin, SRC_AFFINE, act=ACT_RELU, up=up, cst=cst_affine(sc, sh))
+    out, st = run(src, pack_thin(dev(w), 0), cout, want_stats=True)
+    assert relerr(out, ref) < 2e-6
+    assert relerr(st.sum(0)[:, 0], ref.sum((0, 2, 3))) < 1e-5 and relerr(st.sum(0)[:, 1], (ref * ref).sum((0, 2, 3))) < 1e-5
+    if up or cout != 16:
+        return
+    # backward-data: gradient of the cin-channel input from (g, y) of the cout-channel output; here cout == 16 so that the
+    # transposed problem (rows = cin <= 16 or reduction = 16) is a thin one when cin == 16
+    if cin != 16:
+        return
+    g, y = rnd(N, cout, H, W, seed=5) * gscale, rnd(N, cout, H, W, seed=6)
+    a_, b_ = rnd(cout, seed=7) * 0.2 + 1, rnd(cout, seed=8) * 0.2
+    A, B, D = a_.clone(), rnd(cout, seed=9) * 0.1 * gscale, rnd(cout, seed=10) * 0.1 * gscale
+    yh = y * a_[None, :, None, None] + b_[None, :, None, None]
+    gm = torch.where(yh > 0, g, torch.zeros(()))
+    dy = gm.double() * A.double()[None, :, None, None] + B.double()[None, :, None, None] * y.double() + D.double()[None, :, None, None]
+    cstb = torch.zeros(cout, SC_CST); cstb[:, 0], cstb[:, 1], cstb[:, 2], cstb[:, 3], cstb[:, 4] = a_, b_, A, B, D
+    amax = torch.tensor([float((gm.abs().amax((0, 2, 3)) * a_.abs()).max())], device=DEV)
+    dsrc = make_src(dev(g), cout, SRC_BNBWD, act=ACT_RELU, cst=dev(cstb), aux=dev(y))
+    dx, _ = run(dsrc, pack_thin(dev(w), 1), cin, absmax=amax)
+    assert relerr(dx, F.conv_transpose2d(dy, w.double(), padding=1)) < 1e-5

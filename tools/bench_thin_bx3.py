@@ -25,7 +25,20 @@ for name, cin, cout, H, up in [("d4a", 32, 16, 512, 1), ("d4b", 16, 16, 512, 0),
     o16 = outs[0].clone()
     tbx = timeit(lambda: conv_mfma([src], pack_bx3(w, 32, 0, 4), N, H, W, cout, 3, 32, want_stats=not bwd, outs=outs, bx3=True, terms=4))
     err = float((outs[0] - o16).abs().max() / o16.abs().max())
-    print(f"{name:10s} {cin:3d}->{cout:3d} {H}^2  thin-fp32 {t16:.3f} ms | split(co_t=32) {tbx:.3f} ms  diff {err:.1e}")
+    import ctypes as C
+    from starcop_amd import _lib
+    from starcop_amd._lib import sc_conv_args, check, ptr, stream, STAT_CONV3
+    lib = _lib.load()
+    wt = torch.empty(lib.sc_packed_weight_floats_thin16(cout, cin, 0), device=DEV)
+    check(lib.sc_pack_weights_thin16(ptr(w), ptr(wt), cout, cin, 0, stream()))
+    a = sc_conv_args(); a.nsrc = 1; a.src[0] = src; a.wpk = wt.data_ptr()
+    a.N, a.H, a.W, a.Cout, a.ks, a.co_t = N, H, W, cout, 3, 16
+    a.out0 = outs[0].data_ptr(); a.csplit = cout; a.terms = 4
+    st_ = torch.empty(lib.sc_stat_rows(STAT_CONV3, N, H, W), cout, 2, device=DEV)
+    a.stats = None if bwd else st_.data_ptr()
+    tth = timeit(lambda: check(lib.sc_conv3x3_thin16(C.byref(a), stream())))
+    err2 = float((outs[0] - o16).abs().max() / o16.abs().max())
+    print(f"{name:10s} {cin:3d}->{cout:3d} {H}^2  thin-fp32 {t16:.3f} ms | split(co_t=32) {tbx:.3f} ms  diff {err:.1e} | thin16-fp16x2 {tth:.3f} ms diff {err2:.1e}")
 print("--- weight gradient ---")
 for name, cin, cout, H, up in [("d4a", 32, 16, 512, 1), ("d4b", 16, 16, 512, 0), ("d3b", 32, 32, 256, 0)]:
     W = H
