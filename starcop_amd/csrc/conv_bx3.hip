@@ -388,6 +388,84 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
   const size_t HWs = (size_t)H * W;
   const bool want_stats = p.stats != nullptr;
   const int ox = x0 + l31;
+  if (p.csplit == p.Cout || p.csplit % CO_T == 0) {
+    // The cout tile lies entirely in one output (always, in this network: a split falls on a tile boundary): one uniform base
+    // pointer per work-group and a 32-bit lane offset (< 64 channels x H x W), so a store is one add + one saddr global_store
+    // instead of the 64-bit multiply chain per element of the general path below -- which costs as much as two K chunks on the
+    // 32- and 64-channel layers.
+    const bool first = cot * CO_T < p.csplit;
+    const int Cs = first ? p.csplit : p.Cout - p.csplit;                 // channels of the output this tile goes to
+    const int c0 = first ? cot * CO_T : cot * CO_T - p.csplit;            // first channel of the tile in it
+    const bool accum = first ? p.accum0 != 0 : p.accum1 != 0;
+    const int Climit = first ? p.csplit : p.Cout;
+    if (first && p.down0) {
+      // backward of nearest x2 upsampling fused into the store: the wave's two rows are a vertical pixel pair, adjacent lanes a
+      // horizontal one -> sum the 2x2 block and store it at half resolution (no full-resolution temporary)
+      const unsigned hq32 = (unsigned)((H >> 1) * (W >> 1));
+      float* const ob = p.out0 + ((size_t)n * Cs + c0) * hq32;
+      const int oy = y0 + 2 * wave;
+      const bool st = !(l31 & 1) && oy < H && ox < W;
+      const unsigned loff = (unsigned)(4 * lhi) * hq32 + (unsigned)(st ? (oy >> 1) * (W >> 1) + (ox >> 1) : 0);
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cu = q * 32 + (r & 3) + 8 * (r >> 2);
+          float v = ((oy < H) && (ox < W)) ? acc[0][q][r] : 0.f;
+          v += ((oy + 1 < H) && (ox < W)) ? acc[1][q][r] : 0.f;
+          if (HF) v *= hinv;
+          v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+          if (st && cot * CO_T + cu + 4 * lhi < Climit) {
+            const unsigned off = loff + (unsigned)cu * hq32;
+            if (accum) v += ob[off];
+            ob[off] = v;
+          }
+        }
+      }
+    } else {
+      const size_t cbase = ((size_t)n * Cs + c0) * HWs;
+      float* const ob = (first ? p.out0 : p.out1) + cbase;
+      const float* const a0 = p.add0 ? p.add0 + cbase : nullptr;
+      const float* const a1 = p.add1 ? p.add1 + cbase : nullptr;
+      const unsigned hw32 = (unsigned)HWs;
+      unsigned loff[2]; bool okp[2];
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp) {
+        const int oy = y0 + 2 * wave + pp;
+        okp[pp] = (oy < H) && (ox < W);
+        loff[pp] = (unsigned)(4 * lhi) * hw32 + (unsigned)(okp[pp] ? oy * W + ox : 0);
+      }
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cu = q * 32 + (r & 3) + 8 * (r >> 2);            // compile-time part of the channel
+          const int col = cu + 4 * lhi;
+          const bool okc = cot * CO_T + col < Climit;
+          float sv = 0.f, sq = 0.f;
+#pragma unroll
+          for (int pp = 0; pp < 2; ++pp) {
+            const bool ok = okp[pp] && okc;
+            float v = ok ? acc[pp][q][r] : 0.f;
+            if (HF) v *= hinv;
+            sv += v; sq = fmaf(v, v, sq);
+            if (ok) {
+              const unsigned off = loff[pp] + (unsigned)cu * hw32;
+              if (a0) v += a0[off];
+              if (a1) v += a1[off];
+              if (accum) v += ob[off];
+              ob[off] = v;
+            }
+          }
+          if (want_stats) {
+            const float s = half_sum32(sv);
+            const float ss = half_sum32(sq);
+            if (l31 == SC_HALF_SUM_LANE) { s_red[wave][col][0] = s; s_red[wave][col][1] = ss; }
+          }
+        }
+      }
+    }
+  } else
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
 #pragma unroll
