@@ -208,6 +208,43 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
   }
   const size_t HWs = (size_t)H * W;
   const bool want_stats = p.stats != nullptr;
+  if (p.csplit == p.Cout || p.csplit % CO_T == 0) {
+    // the cout tile lies entirely in one output: uniform base pointer + 32-bit lane offsets (see k_conv3_bx3's epilogue)
+    const bool first = cot * CO_T < p.csplit;
+    const int Cs = first ? p.csplit : p.Cout - p.csplit;
+    const int c0 = first ? cot * CO_T : cot * CO_T - p.csplit;
+    const bool accum = first ? p.accum0 != 0 : p.accum1 != 0;
+    const int Climit = first ? p.csplit : p.Cout;
+    const size_t cbase = ((size_t)n * Cs + c0) * HWs;
+    float* const ob = (first ? p.out0 : p.out1) + cbase;
+    const float* const a0 = p.add0 ? p.add0 + cbase : nullptr;
+    const float* const a1 = p.add1 ? p.add1 + cbase : nullptr;
+    const unsigned hw32 = (unsigned)HWs;
+    const unsigned loff = (unsigned)(4 * lhi) * hw32 + (unsigned)(pix_ok ? opix : 0);
+#pragma unroll
+    for (int m = 0; m < RM; ++m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cu = m * 32 + (r & 3) + 8 * (r >> 2);
+        const int col = cu + 4 * lhi;
+        float v = acc[m][r];
+        const bool ok = pix_ok && (cot * CO_T + col < Climit);
+        if (!ok) v = 0.f;
+        if (want_stats) {
+          const float s = half_sum32(v);
+          const float ss = half_sum32(v * v);
+          if (l31 == SC_HALF_SUM_LANE) { s_red[wave][col][0] = s; s_red[wave][col][1] = ss; }
+        }
+        if (ok) {
+          const unsigned off = loff + (unsigned)cu * hw32;
+          if (a0) v += a0[off];
+          if (a1) v += a1[off];
+          if (accum) v += ob[off];
+          ob[off] = v;
+        }
+      }
+    }
+  } else
 #pragma unroll
   for (int m = 0; m < RM; ++m) {
 #pragma unroll
@@ -508,6 +545,11 @@ __global__ __launch_bounds__(256, 2) void k_conv1_ksplit(const ConvP p) {
   const bool ok_px = opix < HW;
   const size_t HWs = (size_t)HW;
   const size_t srow = (size_t)n * gridDim.x + blockIdx.x;
+  const bool single = p.csplit == p.Cout;
+  const size_t cbase = ((size_t)n * p.Cout + (size_t)cot * CO_T) * HWs;
+  float* const ob = p.out0 + cbase;
+  const float* const a0 = p.add0 ? p.add0 + cbase : nullptr;
+  const float* const a1 = p.add1 ? p.add1 + cbase : nullptr;
 #pragma unroll
   for (int i = 0; i < CO_T / 8; ++i) {
     const int col = cg + 8 * i;
@@ -523,6 +565,14 @@ __global__ __launch_bounds__(256, 2) void k_conv1_ksplit(const ConvP p) {
       }
     }
     if (ok) {
+      if (single) {         // one output (every launch of the network): uniform base + 32-bit offset
+        const unsigned off = (unsigned)col * (unsigned)HWs + (unsigned)opix;
+        if (a0) v += a0[off];
+        if (a1) v += a1[off];
+        if (p.accum0) v += ob[off];
+        ob[off] = v;
+        continue;
+      }
       float* o; size_t idx; int accum;
       if (co < p.csplit) {
         idx = ((size_t)n * p.csplit + co) * HWs + opix; o = p.out0; accum = p.accum0;
