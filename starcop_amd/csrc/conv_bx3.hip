@@ -1,26 +1,29 @@
-// Dense 3x3 NCHW conv2d (stride 1, pad 1) with fp32 accuracy on the bf16 matrix cores of gfx950.
+// Dense 3x3 NCHW conv2d (stride 1, pad 1) with fp32-level accuracy on the 16-bit matrix cores of gfx950.
 //
-// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate, so the decoder's 3x3 convolutions (88 % of the U-Net's MACs:
-// smp.Unet built at starcop/models/model_module.py:244-251) are MFMA-bound on it.  Here every fp32 operand is split
-// exactly into three bf16 terms  a = a0 + a1 + a2  (a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1); 3 x 8
-// significand bits) and the product is accumulated in fp32 from the six partial products whose weight is >= 2^-24:
-//     a*b ~= a1*b1 + a2*b0 + a0*b2 + a1*b0 + a0*b1 + a0*b0
-// = 6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block (192 cycles) instead of 8 x v_mfma_f32_32x32x2_f32 (512 cycles).
-// The dropped terms are O(2^-24 |a||b|), the same size as one fp32 rounding; measured against fp64 the result is as
-// close as the fp32 MFMA path (tests/test_gpu_ops.py::test_conv_bx3_*).
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the 16-bit MFMA rate, so the decoder's 3x3 convolutions (88 % of the U-Net's MACs:
+// smp.Unet built at starcop/models/model_module.py:244-251) are MFMA-bound on it.  Here every fp32 operand is split exactly
+// into 16-bit terms while it is staged and the leading partial products are accumulated in fp32:
+//   two fp16 terms (default, template HF):  a*s = h0 + h1 (2 x 11 significand bits, power-of-two range scale s divided out in
+//       the epilogue, see split2h below), products h0*g1 + h1*g0 + h0*g0 = 3 x v_mfma_f32_32x32x16_f16 per 32x32x16 block
+//   three bf16 terms (NT = 3):  a = a0 + a1 + a2 (3 x 8 bits, fp32's exponent range), the six products of weight >= 2^-24
+//       a1*b1 + a2*b0 + a0*b2 + a1*b0 + a0*b1 + a0*b0 = 6 x v_mfma_f32_32x32x16_bf16 (192 cycles; the fp32 MFMA needs 512)
+//   NT = 2 / NT = 1 with bf16: the opt-in reduced-accuracy modes of the network ("fp32-bwd2", "fp32-2", "bf16")
+// Measured against fp64 both full-accuracy splits are as close as the fp32 MFMA path (tests/test_gpu_ops.py::test_conv_bx3_*,
+// test_conv_two_fp16_terms).
 //
 // Same "normalise on load" contract as conv_mfma.hip: the producer's BatchNorm+activation (forward), or the
 // BatchNorm/activation backward (dgrad), nearest x2 upsampling and the channel concat are applied while the tile is
-// staged; the bf16 split happens in the same pass.  The same kernel computes dgrad from transposed+flipped filters.
+// staged; the split happens in the same pass.  The same kernel computes dgrad from transposed+flipped filters.
 //
 // GEMM view:  D[co][pixel] = sum_{tap} sum_{ci} Wp[tap][co][ci] * patch[ci][pixel + d(tap)],  K step = 16 channels
 //   A (32 x 16): lane l -> W[co = l&31][ci = 8*(l>>5) .. +7]      (one 16-byte LDS read)
 //   B (16 x 32): lane l -> patch[ci = 8*(l>>5) .. +7][pixel l&31]  (one 16-byte LDS read)
 //   D: col = l&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(l>>5) (cout)
 // Work-group = 4 waves, tile = 8 rows x 32 cols x (32*Q couts); wave w owns rows 2w, 2w+1 and all Q cout blocks
-// (2 x Q accumulators: every A read is used twice, every B read Q times -> 0.5 KB of LDS per MFMA at Q = 2).
-// LDS: patch [3 terms][2 channel halves][10 x 34 pixels] x 16 B (single buffer, next chunk prefetched in registers),
-// filters per filter row kh [3 terms][3 kw][2 halves][32Q couts] x 16 B, double buffered.  ~72 KB -> 2 work-groups / CU.
+// (2 x Q accumulators: every A read is used twice, every B read Q times).
+// LDS: patch [terms][2 channel halves][10 x 34 pixels] x 16 B (single buffer, next chunk prefetched in registers),
+// filters per filter row kh [terms][3 kw][2 halves][32Q couts] x 16 B, double buffered: 51 KB (two terms) / 72 KB (three terms)
+// at Q = 2 -> 2 work-groups per CU (the Q = 2 kernels need 220 VGPRs).
 #include "sc_common.h"
 #include <type_traits>
 
