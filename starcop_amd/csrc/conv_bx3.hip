@@ -975,9 +975,16 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
   };
 
   __syncthreads();          // constants in LDS
+  // stage coordinates of t and t+1, advanced incrementally (decode() is a 64-bit division: ~200 scalar instructions)
+  int n = 0, y0 = 0, x0 = 0;
+  if (t_begin < t_end) decode(t_begin, n, y0, x0);
+  int n1 = n, y1 = y0, x1 = x0;
+  auto advance = [&](int& nn, int& yy, int& xx) {
+    yy += 2;
+    if (yy >= 2 * RS) { yy = 0; xx += 32; if (xx >= 32 * tiles_x) { xx = 0; ++nn; } }
+  };
+  advance(n1, y1, x1);
   if (t_begin < t_end) {
-    int n, y0, x0;
-    decode(t_begin, n, y0, x0);
     x_load(n, y0 - 1, x0);
     dy_load(n, y0, x0);
     x_store(y0 - 1, x0);
@@ -987,11 +994,8 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
     __syncthreads();
   }
   for (long t = t_begin; t < t_end; ++t) {
-    int n, y0, x0, n1 = 0, y1 = 0, x1 = 0;
-    decode(t, n, y0, x0);
     const bool more = (t + 1) < t_end;
     if (more) {
-      decode(t + 1, n1, y1, x1);
       dy_load(n1, y1, x1);
       x_load(n1, y1 + 1, x1);
     }
@@ -1006,6 +1010,8 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
       }
     }
     __syncthreads();
+    n = n1; y0 = y1; x0 = x1;
+    advance(n1, y1, x1);
   }
   // ---- partial store: part[((slice*KP + kp)*9 + tap)*CoP*CiP + co*CiP + ci] ----
   const int ci = cit * CIT + wn * 32 + l31;
