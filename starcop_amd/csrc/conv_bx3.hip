@@ -850,11 +850,15 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
       const int co = cot * COT + ((it >> 5) & (COT - 1)), row = (it >> 4) & 1, col = 2 * (it & 15);
       const int y = y0 + row, x = x0 + col;
       const bool okc = co < p.Cout && y < H;
-      const size_t base = ((size_t)n * p.Cout + (okc ? co : 0)) * HW + (size_t)(okc ? y : 0) * W;
-      const int xa = (x < W) ? x : 0, xb = (x + 1 < W) ? x + 1 : 0;
-      dg[k][0] = p.dy.x[base + xa]; dg[k][1] = p.dy.x[base + xb];
-      if (dymode == SC_SRC_BNBWD) { dv[k][0] = p.dy.aux[base + xa]; dv[k][1] = p.dy.aux[base + xb]; }
-      else { dv[k][0] = 0.f; dv[k][1] = 0.f; }
+      // uniform image base + 32-bit lane offset (< Cout * H * W): saddr loads, no 64-bit lane arithmetic
+      const float* const gx = p.dy.x + (size_t)n * p.Cout * HW;
+      const unsigned base = (unsigned)(okc ? co : 0) * (unsigned)HW + (unsigned)((okc ? y : 0) * W);
+      const unsigned xa = (x < W) ? x : 0, xb = (x + 1 < W) ? x + 1 : 0;
+      dg[k][0] = gx[base + xa]; dg[k][1] = gx[base + xb];
+      if (dymode == SC_SRC_BNBWD) {
+        const float* const ga = p.dy.aux + (size_t)n * p.Cout * HW;
+        dv[k][0] = ga[base + xa]; dv[k][1] = ga[base + xb];
+      } else { dv[k][0] = 0.f; dv[k][1] = 0.f; }
     }
   };
   auto dy_store = [&](int y0, int x0) {
