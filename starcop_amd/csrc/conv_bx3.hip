@@ -955,7 +955,10 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const uintx4 X0 = *reinterpret_cast<const uintx4*>(&s_x[t][dx]);
-          const unsigned X1 = s_x[t][dx + 4];
+          // the dword after the chunk: read as part of the NEXT aligned 16 bytes.  A ds_read_b32 of one dword per cin row
+          // hits only 8 of the 32 banks (rows are 16-byte aligned: 4-way conflict, 8 LDS cycles); a second ds_read_b128 is
+          // conflict-free (4 cycles) -- measured by SQ_LDS_BANK_CONFLICT: 56 % of this kernel's LDS cycles before
+          const unsigned X1 = (*reinterpret_cast<const uintx4*>(&s_x[t][dx + 4]))[0];
           uintx4 S1, S2;
           S1[0] = __builtin_amdgcn_alignbit(X0[1], X0[0], 16);
           S1[1] = __builtin_amdgcn_alignbit(X0[2], X0[1], 16);
