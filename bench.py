@@ -74,6 +74,26 @@ def cpu_baseline(budget_s=25.0):
 CONV_ROOFLINE_TILES_S = 1718.0
 
 
+def self_launch(n, backend):
+    """Re-executes this command line under torch.distributed.run with n ranks on this node (rendezvous on 127.0.0.1:free port)
+    and returns its exit code.  The driver may call `python bench.py --gpus N` directly; every rank then runs main() with
+    RANK / LOCAL_RANK / WORLD_SIZE set, exactly as under an external torchrun."""
+    import socket
+    import subprocess
+    if backend == "nccl" and torch.cuda.device_count() < n:
+        raise SystemExit(f"bench.py: --gpus {n} needs {n} visible GPUs, found {torch.cuda.device_count()} "
+                         "(STARCOP_BENCH_BACKEND=gloo runs the N-rank path on fewer devices as a functional check only)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: required for RCCL between processes on this stack
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,16 +105,23 @@ def main():
     ap.add_argument("--overlap", type=int, default=1, help="1: weight gradients on a second HIP stream (default); 0: serial "
                     "launches (use for rocprofv3 per-kernel durations that match the roofline pass)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32-x3", "fp32-bwd2", "fp32-2", "bf16"],
-                    help="fp32 (default, BASELINE configs[1], parity mode: 3 bf16 terms per operand) | fp32-bwd2 (2 terms in dgrad/wgrad) | fp32-2 (2 terms everywhere) | bf16 (1 term, configs[3]-style)")
+                    help="arithmetic of the >=32-channel 3x3 convolutions: fp32 (default, BASELINE configs[1], the parity mode: every fp32 operand split exactly "
+                    "into two fp16 terms, three MFMA products) | fp32-x3 (three bf16 terms, six products: bit-faithful fp32 range) | fp32-bwd2 "
+                    "(two bf16 terms in dgrad/wgrad) | fp32-2 (two bf16 terms everywhere) | bf16 (one term, configs[3]-style)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step from a captured hipGraph (default: eager two-stream launches, measured faster)")
     args = ap.parse_args()
 
+    backend = os.environ.get("STARCOP_BENCH_BACKEND", "nccl")       # "gloo": functional check of the N>1 path on a 1-GPU box
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no rank environment: launch the N ranks ourselves (one process per GPU, RCCL)
+        sys.exit(self_launch(args.gpus, backend))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    backend = os.environ.get("STARCOP_BENCH_BACKEND", "nccl")       # "gloo": functional check of the N>1 path on a 1-GPU box
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} needs {world} visible GPUs, found {torch.cuda.device_count()}")
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -103,6 +130,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)            # nccl == RCCL over xGMI on ROCm
         else:
             dist.init_process_group(backend)
+        world = dist.get_world_size()                                  # n_gpus / tile counts below come from the live process group
 
     from starcop_amd import model_module as mm
     from starcop_amd.parallel import GradSync
@@ -209,7 +237,7 @@ def main():
     if rank == 0:
         tiles = world * B * args.steps
         out = {"metric": "512x512 hyperspectral tiles/sec (train fwd+bwd)", "value": round(tiles / elapsed, 2), "unit": "tiles/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+               "n_gpus": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
                "config": {"workload": "configs[1]: HyperSTARCOP U-Net (smp.Unet mobilenet_v2, 4ch mag1c+RGB) train step "
                                       "fwd+loss+bwd+Adam, 512x512 tiles, fp32 HIP kernels (3x3 convs: fp32 operands split exactly into 16-bit terms on the "

@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE -- not product code (see oracle/__init__.py).  PINNED: checked against outputs of the
 reference itself (tests/golden/g1_filters.npz, g2_groups_*.npz, g3_templates.npz, written by
-tests/golden/make_golden.py importing /root/reference/starcop/models/mag1c.py) in tests/test_oracle_mag1c.py.
+tests/golden/make_golden.py importing /root/reference/starcop/models/mag1c.py) in tests/test_oracle.py.
 
 Follows /root/reference/starcop/models/mag1c.py:
   rmf :284-348, acrwl1mf :177-280, func_by_groups :116-174, get_mask_bad_bands :98-113,

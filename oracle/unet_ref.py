@@ -16,7 +16,7 @@ bytes; structure is pinned by
 
   * the parameter count the reference logged: 6 629 233 trainable for C=4
     (notebooks/(bonus)_training_demo.ipynb cell 19) -- asserted in
-    tests/test_oracle_unet.py,
+    tests/test_oracle.py,
   * ``state_dict`` key names (``encoder.features.N...``, ``decoder.blocks.N.convK.M``,
     ``segmentation_head.0``) so that reference checkpoints would load with
     ``strict=True``.
@@ -196,3 +196,17 @@ def layer_table(in_channels=4, hw=512):
         rows.append((f"decoder.blocks.{b}.conv2.0", co, co, 3, 1, 1, h, h))
     rows.append(("segmentation_head.0", 16, 1, 3, 1, 1, h, h))
     return rows
+
+
+def conv_stack_ref(params, x, relu_last=True):
+    """A bias-carrying stack ``conv(k, pad k//2) -> ReLU -> conv -> ReLU`` evaluated with the same stock CPU ops the
+    restatement above uses (``F.conv2d`` / ``F.relu`` / autograd).  Restates the reference's in-repo blocks
+    ``layer_factory.double_conv`` (/root/reference/starcop/models/architectures/layer_factory.py:4-9) and ``UNet.conv_last``
+    (architectures/unet.py:21): the only convolution arithmetic the reference itself holds, and therefore what pins the
+    convolution / ReLU forward and backward of this oracle to reference-executed numbers (golden G9,
+    tests/golden/make_golden.py::g9_convblocks, checked in tests/test_oracle.py::test_g9_conv_blocks)."""
+    for i, (w, b) in enumerate(params):
+        x = F.conv2d(x, w, b, padding=w.shape[-1] // 2)
+        if i + 1 < len(params) or relu_last:
+            x = F.relu(x)
+    return x

@@ -497,6 +497,7 @@ class HyperStarcopUNet(nn.Module):
         plan = self._get_plan(N, H, W, need_grad)
         plan.buf["x"] = x
         plan.x_cst = x_cst
+        plan.generation = getattr(plan, "generation", 0) + 1     # activations of an earlier forward of this shape are gone
         self._pack_all(need_grad)
         st = stream()
         for i, op in enumerate(self._ops):
@@ -837,17 +838,28 @@ class _UNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, x, x_cst, *params):
         plan = net._forward_impl(x, x_cst, True, True)
-        ctx.net, ctx.plan = net, plan
+        ctx.net, ctx.plan, ctx.generation = net, plan, plan.generation
         return plan.buf["logits"].clone()
 
     @staticmethod
     def backward(ctx, g):
         net, plan = ctx.net, ctx.plan
+        if plan.generation != ctx.generation:
+            raise RuntimeError("HyperStarcopUNet.backward: another forward of the same input shape ran after this one; the "
+                               "network keeps ONE set of activation buffers per (N, H, W), so call backward() before the next "
+                               "train-mode forward of that shape (or use a different batch shape)")
+        params = list(net.parameters())
+        # Gradient accumulation (accumulate_grad_batches > 1, zero_grad(set_to_none=False)): a p.grad left over from the last
+        # backward IS a view of the flat gradient buffer, which _backward_impl overwrites.  Move those accumulators onto a
+        # snapshot first and hand autograd fresh copies, so AccumulateGrad computes old + new (never new + new).
+        aliased = [p.grad is not None and p.grad.data_ptr() == net._grad_view(p).data_ptr() for p in params]
+        if any(aliased):
+            snap = net._gflat.clone()
+            base = net._gflat.data_ptr()
+            for p, al in zip(params, aliased):
+                if al:
+                    off = (p.grad.data_ptr() - base) // 4
+                    p.grad = snap[off:off + p.numel()].view(p.shape)
         net._backward_impl(plan, g.float())
-        grads = []
-        for p in net.parameters():
-            gv = net._grad_view(p)
-            if p.grad is not None and p.grad.data_ptr() == gv.data_ptr():
-                gv = gv.clone()     # caller is accumulating gradients across steps
-            grads.append(gv)
+        grads = [net._grad_view(p).clone() if al else net._grad_view(p) for p, al in zip(params, aliased)]
         return (None, None, None) + tuple(grads)

@@ -91,7 +91,10 @@ class DataNormalizer(torch.nn.Module):
     # ---- constants for the fused stem prologue: [C][8] = {offset, factor, clip_min, clip_max, 0...}
     def consts(self, device):
         c = self._consts
-        if c is None or c.device != torch.device(device):
+        # keyed on the parameters' identity and version: load_state_dict / in-place edits of the table invalidate the cache
+        key = tuple((t.data_ptr(), t._version) for t in (self.offsets_input, self.factors_input, self.clip_min_input, self.clip_max_input))
+        if c is None or c.device != torch.device(device) or getattr(self, "_consts_key", None) != key:
+            self._consts_key = key
             n = self.offsets_input.shape[0]
             c = torch.zeros((n, SC_CST), dtype=torch.float32)
             c[:, 0] = self.offsets_input.reshape(-1).float().cpu()

@@ -26,13 +26,39 @@ class FusedAdam(torch.optim.Adam):
         self._hp_dev = torch.zeros(4, dtype=torch.float32, device=flat.device)
         self._lr_host = None
         self._flat_ptr = flat.data_ptr()
-        off = 0
-        for p in params:
+        self._bind_state_views()
+
+    def _bind_state_views(self):
+        """(re)point the per-parameter state entries at the flat moment buffers; tensors found there that are NOT those views
+        (what torch.optim.Optimizer.load_state_dict leaves: copies of a checkpoint's exp_avg / exp_avg_sq / step) are first
+        copied into the flat buffers, so a resumed run continues with the checkpoint's moments and bias corrections"""
+        off, step = 0, None
+        for p in self.network.parameters():
             n = p.numel()
+            mv, vv = self._m[off:off + n].view(p.shape), self._v[off:off + n].view(p.shape)
+            st = self.state.get(p)
+            if st is not None and "exp_avg" in st and st["exp_avg"].data_ptr() != mv.data_ptr():
+                mv.copy_(st["exp_avg"].to(mv.device, torch.float32).reshape(p.shape))
+                vv.copy_(st["exp_avg_sq"].to(vv.device, torch.float32).reshape(p.shape))
+                s = int(round(float(st.get("step", 0))))
+                step = s if step is None else max(step, s)
             self.state[p] = {"step": self._step_dev.view(()),   # shared scalar step (tensor, like capturable Adam)
-                             "exp_avg": self._m[off:off + n].view(p.shape),
-                             "exp_avg_sq": self._v[off:off + n].view(p.shape)}
+                             "exp_avg": mv, "exp_avg_sq": vv}
             off += n
+        if step is not None:
+            self._step_dev.fill_(step)
+        self._lr_host = None                                     # param_groups may carry a different lr now
+
+    def load_state_dict(self, state_dict):
+        """Checkpoint resume (Lightning restores the optimiser this way; reference train.py:137).  Accepts this class's own
+        state and a plain torch.optim.Adam state of the same parameter list."""
+        super().load_state_dict(state_dict)
+        self._bind_state_views()
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        if hasattr(self, "_m"):
+            self._bind_state_views()
 
     def _sync_lr(self):
         lr = float(self.param_groups[0]["lr"])

@@ -1,0 +1,62 @@
+"""G9 golden vectors: the reference's own convolution blocks (layer_factory.double_conv, architectures/unet.py UNet
+sub-blocks; /root/reference/starcop/models/architectures/layer_factory.py:4-9, unet.py:7-51), run by the reference in the
+build container (tests/golden/make_golden.py::g9_convblocks).  Inputs, filters, biases and the upstream gradient are
+regenerated here from the same numpy PCG64 uniform streams; only the reference's outputs are stored in g9_convblocks.npz.
+"""
+import os
+
+import numpy as np
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g9_convblocks.npz")
+
+# name -> (conv list [(cout, cin, k)], input shape, seed); activation after every conv of a double_conv is ReLU, conv_last has none
+CASES = {
+    "dc_4_8": ([(8, 4, 3), (8, 8, 3)], (1, 4, 64, 64), 901),
+    "unet_down1": ([(64, 4, 3), (64, 64, 3)], (1, 4, 64, 64), 902),
+    "unet_down2": ([(128, 64, 3), (128, 128, 3)], (1, 64, 32, 32), 903),
+    "unet_up1": ([(64, 192, 3), (64, 64, 3)], (1, 192, 64, 64), 904),
+    "unet_last": ([(1, 64, 1)], (1, 64, 64, 64), 905),
+}
+
+
+def _fill(rng, shape, bound):
+    return ((rng.random(shape) * 2.0 - 1.0) * bound).astype(np.float32)
+
+
+def case_tensors(name):
+    """-> (params [(w, b)], x, r): r is dL/d(output)"""
+    convs, xshape, seed = CASES[name]
+    rng = np.random.default_rng(seed)
+    params = [(torch.from_numpy(_fill(rng, (co, ci, k, k), 1.0 / np.sqrt(ci * k * k))), torch.from_numpy(_fill(rng, (co,), 0.1)))
+              for co, ci, k in convs]
+    rng = np.random.default_rng(seed + 1000)
+    x = torch.from_numpy(_fill(rng, xshape, 1.5))
+    yshape = (xshape[0], convs[-1][0]) + tuple(xshape[2:])
+    r = torch.from_numpy(_fill(rng, yshape, 1.0))
+    return params, x, r
+
+
+def load():
+    return np.load(GOLD)
+
+
+def golden_err(z, name, key, got):
+    """max |got - golden| / max(max|golden|, 1e-3) over what the fixture stores for <name>.<key> (full tensor, or lattice crop
+    + fp64 checksums over the thinned axes)"""
+    got = got.detach().double().cpu().numpy()
+    errs = []
+    pre = f"{name}.{key}."
+
+    def rel(a, b):
+        return float(np.abs(a - b).max() / max(float(np.abs(b).max()), 1e-3))
+    if pre + "full" in z.files:
+        errs.append(rel(got, z[pre + "full"].astype(np.float64)))
+    if pre + "crop3" in z.files:
+        errs.append(rel(got[..., ::3, ::3], z[pre + "crop3"].astype(np.float64)))
+        errs.append(rel(got.sum(axis=(-2, -1)), z[pre + "chsum"]))
+    if pre + "crop2" in z.files:
+        errs.append(rel(got[::2, ::2], z[pre + "crop2"].astype(np.float64)))
+        errs.append(rel(got.sum(axis=1), z[pre + "cisum"]))
+    assert errs, f"no golden entry for {pre}*"
+    return max(errs)

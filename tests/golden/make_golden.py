@@ -243,6 +243,67 @@ def g8_ratio():
     np.savez_compressed(os.path.join(OUT, "g8_ratio.npz"), **out)
 
 
+# ---- G9: the reference's own convolution blocks (the only conv arithmetic the reference itself holds) -------------------------
+# Weights, biases, inputs and the upstream gradient are drawn from numpy PCG64 *uniform* streams (bit-stable across numpy
+# versions), so tests/g9_util.py regenerates them from the seeds below and only the reference's OUTPUTS are stored
+# (strided crops + fp64 per-channel checksums for the big tensors).
+G9_CASES = (  # name, how the block is obtained from the reference, input shape, seed
+    ("dc_4_8", ("double_conv", 4, 8), (1, 4, 64, 64), 901),
+    ("unet_down1", ("UNet", "dconv_down1"), (1, 4, 64, 64), 902),        # 4 -> 64 -> 64
+    ("unet_down2", ("UNet", "dconv_down2"), (1, 64, 32, 32), 903),       # 64 -> 128 -> 128
+    ("unet_up1", ("UNet", "dconv_up1"), (1, 192, 64, 64), 904),          # cat(128, 64) -> 64 -> 64
+    ("unet_last", ("UNet", "conv_last"), (1, 64, 64, 64), 905),          # 1x1, 64 -> 1, bias
+)
+
+
+def g9_fill(rng, shape, bound):
+    return ((rng.random(shape) * 2.0 - 1.0) * bound).astype(np.float32)
+
+
+def g9_params(seed, convs):
+    """convs: [(cout, cin, k)] -> [(weight, bias)] drawn in order from PCG64(seed): U(-1/sqrt(fan_in), ..) and U(-0.1, 0.1)"""
+    rng = np.random.default_rng(seed)
+    return [(g9_fill(rng, (co, ci, k, k), 1.0 / np.sqrt(ci * k * k)), g9_fill(rng, (co,), 0.1)) for co, ci, k in convs]
+
+
+def g9_crop(a):
+    """what is stored of a tensor: everything if small; else a stride-3 lattice over the image axes (filters: every second
+    output and input channel, all taps) + fp64 checksums over the axes that were thinned"""
+    a = np.asarray(a)
+    if a.size <= 40000:
+        return {"full": a}
+    if a.shape[-1] <= 3:
+        return {"crop2": a[::2, ::2].copy(), "cisum": a.astype(np.float64).sum(axis=1)}
+    return {"crop3": a[..., ::3, ::3].copy(), "chsum": a.astype(np.float64).sum(axis=(-2, -1))}
+
+
+def g9_convblocks():
+    from starcop.models.architectures import layer_factory as ref_lf, unet as ref_unet
+    torch.manual_seed(0)
+    net = ref_unet.UNet(4, 1)
+    out = {}
+    for name, how, xshape, seed in G9_CASES:
+        block = ref_lf.double_conv(how[1], how[2]) if how[0] == "double_conv" else getattr(net, how[1])
+        convs = [m for m in ([block] if isinstance(block, torch.nn.Conv2d) else block) if isinstance(m, torch.nn.Conv2d)]
+        params = g9_params(seed, [(c.out_channels, c.in_channels, c.kernel_size[0]) for c in convs])
+        with torch.no_grad():
+            for c, (w, b) in zip(convs, params):
+                c.weight.copy_(torch.from_numpy(w)); c.bias.copy_(torch.from_numpy(b))
+        rng = np.random.default_rng(seed + 1000)
+        x = torch.from_numpy(g9_fill(rng, xshape, 1.5)).requires_grad_(True)
+        y = block(x)
+        r = torch.from_numpy(g9_fill(rng, tuple(y.shape), 1.0))
+        (y * r).sum().backward()
+        rec = {"y": y.detach().numpy(), "gx": x.grad.numpy()}
+        for i, c in enumerate(convs):
+            rec[f"gw{i}"], rec[f"gb{i}"] = c.weight.grad.numpy(), c.bias.grad.numpy()
+        for k, v in rec.items():
+            for kk, vv in g9_crop(v).items():
+                out[f"{name}.{k}.{kk}"] = vv
+        out[f"{name}.meta"] = np.array([seed] + list(xshape) + [c.out_channels for c in convs], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "g9_convblocks.npz"), **out)
+
+
 if __name__ == "__main__":
     tpl = g3_templates()
     g1_filters(tpl)
@@ -252,6 +313,7 @@ if __name__ == "__main__":
     g7_metrics()
     g8_ratio()
     g5_masks()
+    g9_convblocks()
     print("golden vectors written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f))} bytes")

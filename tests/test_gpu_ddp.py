@@ -96,3 +96,22 @@ def test_rccl_world1_collectives(hip):
                SC_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, "-c", _RCCL_WORLD1], env=env, capture_output=True, text=True, cwd=ROOT, timeout=300)
     assert p.returncode == 0 and "RCCL_WORLD1_OK" in p.stdout, (p.stdout[-500:], p.stderr[-1500:])
+
+
+def test_bench_self_launches_n_ranks(hip):
+    """the driver's own command line, `python bench.py --gpus N ...` with NO rank environment: bench.py must start the N ranks
+    itself (torch.distributed.run on 127.0.0.1) and report n_gpus from the live process group.  gloo on the one GPU of this box;
+    with the default backend the same command demands N visible GPUs and refuses loudly otherwise."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--tile", "128"]
+    p = subprocess.run(cmd, env=dict(env, STARCOP_BENCH_BACKEND="gloo"), capture_output=True, text=True, cwd=ROOT, timeout=400)
+    assert p.returncode == 0, (p.stdout[-500:], p.stderr[-1500:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2" and rec["value"] > 0
+    import torch
+    if torch.cuda.device_count() < 2:          # RCCL path: fewer devices than ranks is an error, never a silent 1-rank run
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=120)
+        assert p.returncode != 0 and "needs 2 visible GPUs" in (p.stderr + p.stdout)
+        assert not [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -46,6 +46,9 @@ def make_pair(seed=0, pos_weight=1.0, warm=True):
     return model.to(DEV), ref
 
 
+GRAD_RATIO_GATE = 3.0      # a gradient tensor may be at most this many times further from the fp64 oracle than the fp32 CPU path is
+
+
 def ref_normalize(x):
     fac = torch.tensor([1750., 60., 60., 60.])[None, :, None, None]
     return torch.clamp(x / fac, 0, 2)
@@ -77,8 +80,8 @@ def test_eval_logits_and_masks(hip, B, H, W):
 def test_train_forward_backward_and_adam(hip):
     """Gradients through 62 train-mode BatchNorms + ReLU(6) masks are ill-conditioned in fp32 (a mask flip is a
     discrete change, the deviations are chaotic draws), so "truth" is the oracle evaluated in fp64 and the bar is: the
-    HIP path is as close to it as the reference's own fp32 CPU path is (every parameter <= max(1e-3, 10x the fp32
-    oracle's deviation), median ratio < 2).  The kernels themselves are held to 1e-4 in tests/test_gpu_ops.py."""
+    HIP path is as close to it as the reference's own fp32 CPU path is (every parameter <= max(1e-3, 3x the fp32
+    oracle's deviation), median ratio < 2; the worst ratio is printed).  The kernels themselves are held to 1e-4 in tests/test_gpu_ops.py."""
     B, H, W = 4, 128, 128
     model, ref = make_pair(seed=3, pos_weight=1.0)
     model.train(); ref.train()
@@ -104,13 +107,17 @@ def test_train_forward_backward_and_adam(hip):
     assert relerr(logits, logits_ref) < 1e-4
     assert relerr(logits, logits64) < 1e-4
     opt.zero_grad(); loss.backward()
-    bad, worst, ratios = [], 0.0, []
+    bad, worst, ratios, worst_ratio = [], 0.0, [], 0.0
     for k, p in model.network.named_parameters():
         e_hip, e_ref = relerr(p.grad, g64[k]), relerr(g32[k], g64[k])
         worst = max(worst, e_hip)
         ratios.append(e_hip / max(e_ref, 1e-7))
-        if not e_hip <= max(1e-3, 10 * e_ref):          # per parameter: same order as the fp32 CPU path's own deviation
+        if e_hip > 1e-3:
+            worst_ratio = max(worst_ratio, ratios[-1])
+        if not e_hip <= max(1e-3, GRAD_RATIO_GATE * e_ref):     # per parameter: same order as the fp32 CPU path's own deviation
             bad.append((k, e_hip, e_ref))
+    print(f"worst ratio (HIP error / fp32-CPU-path error vs the fp64 oracle) among gradients over 1e-3: {worst_ratio:.2f}; "
+          f"median ratio {float(np.median(ratios)):.2f}")
     assert not bad, f"{len(bad)} gradients further from the fp64 oracle than the fp32 reference path: {bad[:10]}"
     assert float(np.median(ratios)) < 2.0, np.median(ratios)   # and typically no worse than it
     # running statistics after one train-mode forward
@@ -299,3 +306,76 @@ def test_checkpoint_outside_fp16_range_falls_back_to_three_term_split(hip):
     with pytest.warns(UserWarning):
         model2.network.load_state_dict(sd)
     assert model2.network.precision == "fp32-x3"
+
+
+def test_optimizer_checkpoint_resume(hip):
+    """FusedAdam.load_state_dict: a resumed run (Lightning restores optimiser state through load_state_dict; reference
+    train.py:137 resume_from_checkpoint) continues with the checkpoint's moments and step count -- parameters after the next
+    step equal the uninterrupted run's bit for bit, and a plain torch.optim.Adam state of the same parameters loads too."""
+    import io
+    B, H, W = 2, 64, 64
+    model_a, _ = make_pair(seed=31)
+    batch = to_dev(synth_batch(B, H, W, seed=32))
+    model_a.train()
+    opt_a = model_a.configure_optimizers()["optimizer"]
+    for _ in range(3):
+        model_a.fused_train_step(batch, opt_a)
+    buf = io.BytesIO()
+    torch.save({"model": model_a.state_dict(), "opt": opt_a.state_dict()}, buf)
+    buf.seek(0)
+    ck = torch.load(buf, map_location="cpu", weights_only=False)
+    torch.manual_seed(99)
+    model_b = mm.ModelModule(mm.default_settings(pos_weight=1.0)).to(DEV).train()
+    model_b.load_state_dict(ck["model"])
+    opt_b = model_b.configure_optimizers()["optimizer"]
+    opt_b.load_state_dict(ck["opt"])
+    assert int(opt_b._step_dev) == 3
+    assert torch.equal(opt_b._m, opt_a._m) and torch.equal(opt_b._v, opt_a._v)
+    p0 = next(model_b.network.parameters())
+    assert opt_b.state[p0]["exp_avg"].data_ptr() == opt_b._m.data_ptr()           # state entries are views of the flat buffers again
+    model_a.fused_train_step(batch, opt_a)
+    model_b.fused_train_step(batch, opt_b)
+    assert torch.equal(model_a.network.flat_parameters(), model_b.network.flat_parameters())
+    # a torch.optim.Adam checkpoint (what the reference writes) resumes as well
+    ref_opt = torch.optim.Adam([torch.nn.Parameter(p.detach().cpu().clone()) for p in model_b.network.parameters()], lr=1e-4)
+    for p in ref_opt.param_groups[0]["params"]:
+        p.grad = torch.full_like(p, 0.25)
+    ref_opt.step(); ref_opt.step()
+    opt_b.load_state_dict(ref_opt.state_dict())
+    assert int(opt_b._step_dev) == 2 and float(opt_b._m.min()) > 0
+
+
+def test_gradient_accumulation_and_stale_plan(hip):
+    """accumulate_grad_batches > 1: two training_step + backward calls without zero_grad must leave g1 + g2 in p.grad (the
+    flat gradient buffer is overwritten by every backward, so accumulators are moved off it first); and a backward whose
+    activations were overwritten by a later forward of the same shape raises instead of returning wrong gradients."""
+    B, H, W = 2, 64, 64
+    model, _ = make_pair(seed=41)
+    model.train()
+    b1, b2 = to_dev(synth_batch(B, H, W, seed=42)), to_dev(synth_batch(B, H, W, seed=43))
+    sd = copy.deepcopy(model.state_dict())
+    singles = []
+    for b in (b1, b2):
+        model.load_state_dict(sd)            # identical BatchNorm running statistics for both orders of evaluation
+        model.zero_grad(set_to_none=True)
+        model.training_step(b, 1).backward()
+        singles.append([p.grad.detach().clone() for p in model.network.parameters()])
+    for set_to_none in (True, False):
+        model.load_state_dict(sd)
+        model.zero_grad(set_to_none=set_to_none)
+        model.training_step(b1, 1).backward()
+        model.training_step(b2, 1).backward()
+        for p, g1, g2 in zip(model.network.parameters(), *singles):
+            assert torch.equal(p.grad, g1 + g2)
+    # the optimiser consumes the accumulated gradients (copied back into the flat buffer by FusedAdam.step)
+    opt = model.configure_optimizers()["optimizer"]
+    opt.step()
+    flat_g = model.network.flat_grads()
+    assert torch.equal(flat_g, torch.cat([(g1 + g2).reshape(-1) for g1, g2 in zip(*singles)]))
+    # stale activations
+    model.zero_grad(set_to_none=True)
+    l1 = model.training_step(b1, 1)
+    l2 = model.training_step(b2, 1)
+    with pytest.raises(RuntimeError, match="another forward of the same input shape"):
+        l1.backward()
+    l2.backward()

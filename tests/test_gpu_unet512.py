@@ -1,0 +1,102 @@
+"""Whole-network parity AT THE BENCHED SHAPE (BASELINE.json configs[1]: 4 x 512 x 512 tiles, batch up to 16): at this size
+different code runs than in the 64^2..128^2 tests of test_gpu_unet.py -- the full-resolution thin kernels, 32-bit lane
+offsets in the epilogues, the weight-gradient slice planner, the BatchNorm-backward switch-over and the split-K thresholds.
+Oracle: oracle/unet_ref.py (torch CPU fp32; fp64 as the truth for gradients), same seeded tiles and weights.
+Gates: logits 1e-4 relative (north_star), loss 1e-4, running statistics 1e-4, gradients as close to the fp64 oracle as the
+fp32 CPU path is (<= max(1e-3, 3x its own deviation))."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from hip_ops import DEV, relerr  # noqa: E402
+from test_gpu_unet import make_pair, ref_normalize, synth_batch, to_dev  # noqa: E402
+
+T = 512
+
+
+def test_eval_logits_and_masks_512(hip):
+    B = 2
+    model, ref = make_pair(seed=21)
+    model.eval(); ref.eval()
+    batch = synth_batch(B, T, T, seed=22)
+    with torch.no_grad():
+        want = ref(ref_normalize(batch["input"]))
+        got = model(batch["input"].to(DEV))
+    e = relerr(got, want)
+    print(f"eval logits 2x4x512x512: rel err {e:.2e}")
+    assert e < 1e-4
+    out = model.batch_with_preds(to_dev(batch))
+    near = want.abs() < 1e-3
+    pb_ref = (torch.sigmoid(want) > .5).long()
+    assert torch.equal(out["pred_binary"].cpu()[~near], pb_ref[~near])
+    assert int(near.sum()) < 1e-3 * near.numel()
+
+
+def test_train_step_512(hip):
+    """one training step at 2 x 4 x 512 x 512: train-mode logits, loss, running statistics and gradient tensors"""
+    B = 2
+    model, ref = make_pair(seed=23, pos_weight=1.0)
+    model.train(); ref.train()
+    ref64 = copy.deepcopy(ref).double()
+    batch = synth_batch(B, T, T, seed=24)
+
+    def oracle_step(net, dt):
+        logits = net(ref_normalize(batch["input"]).to(dt))
+        loss = (F.binary_cross_entropy_with_logits(logits, batch["output"].to(dt), reduction="none") * batch["weight_loss"].to(dt)).mean()
+        net.zero_grad(); loss.backward()
+        return logits.detach(), float(loss), {k: p.grad.clone() for k, p in net.named_parameters()}
+
+    logits32, loss32, g32 = oracle_step(ref, torch.float32)
+    logits64, loss64, g64 = oracle_step(ref64, torch.float64)
+    loss = model.training_step(to_dev(batch), 0)
+    logits = model.network._plans[(B, T, T)].buf["logits"]
+    e32, e64 = relerr(logits, logits32), relerr(logits, logits64)
+    print(f"train logits 2x4x512x512: rel err {e32:.2e} vs fp32 oracle, {e64:.2e} vs fp64 oracle (fp32 oracle vs fp64: {relerr(logits32, logits64):.2e})")
+    assert e32 < 1e-4 and e64 < 1e-4
+    assert abs(float(loss.detach()) - loss64) < 1e-4 * max(1.0, abs(loss64))
+    model.zero_grad(); loss.backward()
+    sd, sdr = model.network.state_dict(), ref.state_dict()
+    for k in sd:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert relerr(sd[k], sdr[k]) < 1e-4, k
+    named = dict(model.network.named_parameters())
+    worst_ratio, worst_abs, bad = 0.0, 0.0, []
+    for k in g64:
+        e_hip, e_ref = relerr(named[k].grad, g64[k]), relerr(g32[k], g64[k])
+        worst_abs = max(worst_abs, e_hip)
+        if e_hip > 1e-3:
+            worst_ratio = max(worst_ratio, e_hip / max(e_ref, 1e-7))
+        if not e_hip <= max(1e-3, 3 * e_ref):
+            bad.append((k, e_hip, e_ref))
+    print(f"gradients at 512^2: worst rel err vs fp64 oracle {worst_abs:.2e}; worst ratio to the fp32 CPU path's own error among tensors over 1e-3: {worst_ratio:.2f}")
+    for k in ("decoder.blocks.4.conv1.0.weight", "decoder.blocks.4.conv2.0.weight", "decoder.blocks.4.conv2.1.weight", "encoder.features.0.0.weight",
+              "segmentation_head.0.weight", "segmentation_head.0.bias", "decoder.blocks.0.conv1.0.weight", "encoder.features.18.0.weight"):
+        print(f"   {k}: hip {relerr(named[k].grad, g64[k]):.2e}   fp32 oracle {relerr(g32[k], g64[k]):.2e}")
+    assert not bad, bad[:10]
+
+
+def test_train_forward_loss_b16_512(hip):
+    """the bench's exact shape (16 x 4 x 512 x 512, bench.synth_batch tiles): train-mode logits and loss vs the CPU oracle"""
+    import bench
+    B = 16
+    torch.manual_seed(1234)
+    model, ref = make_pair(seed=25, warm=False)
+    model.train(); ref.train()
+    batch = bench.synth_batch(B, T, T, 1234, "cpu")
+    with torch.no_grad():
+        want = ref(ref_normalize(batch["input"]))
+        loss_ref = float((F.binary_cross_entropy_with_logits(want, batch["output"], reduction="none") * batch["weight_loss"]).mean())
+    opt = model.configure_optimizers()["optimizer"]
+    acc = model.fused_train_step(to_dev(batch), opt)
+    loss = float(acc.item()) / (B * T * T)
+    got = model.network._plans[(B, T, T)].buf["logits"]
+    e = relerr(got, want)
+    print(f"train logits 16x4x512x512: rel err {e:.2e}; loss {loss:.6f} vs oracle {loss_ref:.6f}")
+    assert e < 1e-4
+    assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
+    assert all(bool(torch.isfinite(p).all()) for p in model.network.parameters())
