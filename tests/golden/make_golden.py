@@ -277,21 +277,44 @@ def g9_crop(a):
     return {"crop3": a[..., ::3, ::3].copy(), "chsum": a.astype(np.float64).sum(axis=(-2, -1))}
 
 
+G9_RELU_MARGIN = 1e-5
+G9_SEED_TRIES = 4000
+
+
 def g9_convblocks():
+    """A ReLU is a discrete switch: a pre-activation within fp32 rounding of zero may legitimately fall on either side in two
+    correct implementations and then moves a whole bias/filter gradient by O(|dL/dy|).  The seed of every case is therefore
+    advanced until no pre-activation of the block lies within G9_RELU_MARGIN of zero (10x the rounding noise of a K <= 1728
+    fp32 reduction of O(1) terms); the chosen seed is stored in <name>.meta[0]."""
     from starcop.models.architectures import layer_factory as ref_lf, unet as ref_unet
     torch.manual_seed(0)
     net = ref_unet.UNet(4, 1)
     out = {}
-    for name, how, xshape, seed in G9_CASES:
+    for name, how, xshape, seed0 in G9_CASES:
         block = ref_lf.double_conv(how[1], how[2]) if how[0] == "double_conv" else getattr(net, how[1])
         convs = [m for m in ([block] if isinstance(block, torch.nn.Conv2d) else block) if isinstance(m, torch.nn.Conv2d)]
-        params = g9_params(seed, [(c.out_channels, c.in_channels, c.kernel_size[0]) for c in convs])
-        with torch.no_grad():
-            for c, (w, b) in zip(convs, params):
-                c.weight.copy_(torch.from_numpy(w)); c.bias.copy_(torch.from_numpy(b))
-        rng = np.random.default_rng(seed + 1000)
-        x = torch.from_numpy(g9_fill(rng, xshape, 1.5)).requires_grad_(True)
-        y = block(x)
+        pre = []
+        hooks = [c.register_forward_hook(lambda m, i, o: pre.append(float(o.detach().abs().min()))) for c in convs]
+        best = (-1.0, -1)
+        for seed in list(range(seed0, seed0 + 7 * G9_SEED_TRIES, 7)) + [None]:
+            if seed is None:                       # no seed reached the margin: take the best one seen
+                seed = best[1]
+            params = g9_params(seed, [(c.out_channels, c.in_channels, c.kernel_size[0]) for c in convs])
+            with torch.no_grad():
+                for c, (w, b) in zip(convs, params):
+                    c.weight.copy_(torch.from_numpy(w)); c.bias.copy_(torch.from_numpy(b))
+            rng = np.random.default_rng(seed + 1000)
+            x = torch.from_numpy(g9_fill(rng, xshape, 1.5)).requires_grad_(True)
+            del pre[:]
+            for c in convs:
+                c.zero_grad()
+            y = block(x)
+            if how[1] == "conv_last" or min(pre) > G9_RELU_MARGIN or seed == best[1]:
+                break
+            best = max(best, (min(pre), seed))
+        for h in hooks:
+            h.remove()
+        print(f"G9 {name}: seed {seed}, min |pre-activation| {min(pre):.2e}")
         r = torch.from_numpy(g9_fill(rng, tuple(y.shape), 1.0))
         (y * r).sum().backward()
         rec = {"y": y.detach().numpy(), "gx": x.grad.numpy()}
