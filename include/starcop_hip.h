@@ -232,6 +232,9 @@ int sc_bn_bwd_small(const float* g, const float* y, const float* cst_fwd, int ac
                     float* dgamma, float* dbeta, float* cst_bwd, float* absmax, sc_stream stream);
 /* out = v(a) + v(b)   (residual add of an inverted-residual block; b may be NULL) */
 int sc_add_srcs(const sc_src* a, const sc_src* b, float* out, int N, int C, int HW, sc_stream stream);
+/* same, and *absmax (device float, never lowered) is raised to max |out|: the range evidence for residual sums that feed a
+ * two-fp16-term convolution without a BatchNorm in between (smp skip connections taken after an inverted-residual add) */
+int sc_add_srcs_absmax(const sc_src* a, const sc_src* b, float* out, int N, int C, int HW, float* absmax, sc_stream stream);
 /* out[n,c,y,x] (+)= sum of the 2x2 block of in (backward of nearest x2 upsample) */
 int sc_downsum2x2(const float* in, float* out, int accum, int N, int C, int Hout, int Wout,
                   sc_stream stream);
@@ -312,6 +315,24 @@ int sc_valid_mask(const void* cube, int cube_is_f64, int S_total, int band0, int
                   unsigned char* valid, sc_stream stream);
 int sc_scatter(const void* val, int val_is_f64, const int64_t* pix_index, size_t n, void* out,
                int out_is_f64, sc_stream stream);
+/* same with the element count in device memory (n_dev[0] <= n_max): no host synchronisation between layout and scatter */
+int sc_scatter_n(const void* val, int val_is_f64, const int64_t* pix_index, const int64_t* n_dev, size_t n_max, void* out,
+                 int out_is_f64, sc_stream stream);
+/* valid[p] = all(cube[p][band0 .. band0+S) != fill): the EMIT driver's pixel mask (starcop/models/mag1c_emit.py:60-66,
+ * torch.any(raw == fill_value, dim=-1) inverted) in one pass over the pixel-major cube */
+int sc_valid_mask_ne(const void* cube, int cube_is_f64, int S_total, int band0, int S, double fill, int64_t npix,
+                     unsigned char* valid, sc_stream stream);
+/* Packed layout of COLUMN-STRUCTURED groups, built on the device with no sort and no host round trip.  Both drivers of the
+ * reference group by detector columns: one column per group in starcop/process_aviris.py:209-219 (un-orthorectified cubes),
+ * blocks of column_step columns in starcop/models/mag1c_emit.py:58-84.  Group g = columns [gcol[g], gcol[g+1]) of a
+ * (rows, cols) image; its pixels are the valid ones (valid[r*cols + c] != 0) in row-major order -- the order of the
+ * reference's boolean indexing; a group with <= min_keep valid pixels gets P[g] = 0 and is skipped by sc_mag1c_groups
+ * (starcop/models/mag1c.py:166: groups of <= 10 pixels are not filtered).
+ * Outputs (device): P[G], Ppad[G] (P rounded up to 64), poff[G] / xoff[G] (exclusive scans of P and of Ppad*S),
+ * pix_index[rows*cols] (the first sum(P) entries are written), totals[2] = {sum P, sum Ppad*S}. */
+int sc_mag1c_layout_columns(const unsigned char* valid, int rows, int cols, const int32_t* gcol /*[G+1]*/, int G, int S,
+                            int min_keep, int32_t* P, int32_t* Ppad, int64_t* poff, int64_t* xoff, int64_t* pix_index,
+                            int64_t* totals, sc_stream stream);
 
 /* band-ratio feature (starcop/data/feature_extration.py:37-56).  For B tiles of n pixels:
  *   sc_trimmed_sums : sums[b] = sum of x[b][i] with lower <= x <= upper, lower/upper = numpy.percentile(x[b], p / 100-p)

@@ -97,6 +97,7 @@ SIGNATURES = {
     "sc_bn_bwd_small": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sc_bn_bwd_finalize": (_i, [_vp, _i, _d, _vp, _vp, _vp, _vp, _i, _vp]),
     "sc_add_srcs": (_i, [C.POINTER(sc_src), C.POINTER(sc_src), _vp, _i, _i, _i, _vp]),
+    "sc_add_srcs_absmax": (_i, [C.POINTER(sc_src), C.POINTER(sc_src), _vp, _i, _i, _i, _vp, _vp]),
     "sc_apply_src": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _vp]),
     "sc_downsum2x2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sc_fill_f64": (_i, [_vp, _d, _sz, _vp]),
@@ -110,6 +111,9 @@ SIGNATURES = {
     "sc_mag1c_pack": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "sc_valid_mask": (_i, [_vp, _i, _i, _i, _i, _d, C.c_int64, _vp, _vp]),
     "sc_scatter": (_i, [_vp, _i, _vp, _sz, _vp, _i, _vp]),
+    "sc_scatter_n": (_i, [_vp, _i, _vp, _vp, _sz, _vp, _i, _vp]),
+    "sc_valid_mask_ne": (_i, [_vp, _i, _i, _i, _i, _d, C.c_int64, _vp, _vp]),
+    "sc_mag1c_layout_columns": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sc_trimmed_sum_workspace_bytes": (_sz, [_i]),
     "sc_trimmed_sums": (_i, [_vp, _i, _sz, _d, _vp, _vp, _sz, _vp]),
     "sc_band_ratio": (_i, [_vp, _vp, _vp, _i, _sz, _vp, _vp, _f, _f, _vp]),

@@ -240,7 +240,10 @@ __device__ __forceinline__ float ld_src(const SrcD& s, size_t idx, float4 c0, fl
   return sc_prologue(s.mode, s.act, x, au, c0, c4);
 }
 
-__global__ __launch_bounds__(256) void k_add_srcs(const SrcD a, const SrcD b, int has_b, float* __restrict__ out, int C, int HW) {
+__global__ __launch_bounds__(256) void k_add_srcs(const SrcD a, const SrcD b, int has_b, float* __restrict__ out, int C, int HW,
+                                                  float* __restrict__ absmax) {
+  __shared__ float s_m[4];
+  float mx = 0.f;
   const int c = blockIdx.y, n = blockIdx.z;
   float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), b0 = a0; float a4 = 0.f, b4 = 0.f;
   if (a.mode != SC_SRC_RAW) { a0 = *reinterpret_cast<const float4*>(a.cst + (size_t)c * SC_CST); a4 = a.cst[(size_t)c * SC_CST + 4]; }
@@ -251,7 +254,9 @@ __global__ __launch_bounds__(256) void k_add_srcs(const SrcD a, const SrcD b, in
     float v = ld_src(a, base + i, a0, a4);
     if (has_b) v += ld_src(b, base + i, b0, b4);
     out[base + i] = v;
+    mx = fmaxf(mx, fabsf(v));
   }
+  if (absmax) block_absmax_to(mx, 1.f, absmax, s_m);
 }
 
 __global__ __launch_bounds__(256) void k_downsum2x2(const float* __restrict__ in, float* __restrict__ out, int accum,
@@ -452,14 +457,19 @@ extern "C" int sc_bn_bwd_finalize(const double* sums, int nrows, double count, c
   return SC_OK;
 }
 
-extern "C" int sc_add_srcs(const sc_src* a, const sc_src* b, float* out, int N, int C, int HW, sc_stream stream) {
+extern "C" int sc_add_srcs_absmax(const sc_src* a, const sc_src* b, float* out, int N, int C, int HW, float* absmax,
+                                  sc_stream stream) {
   SC_REQUIRE(a && a->C == C && (!b || b->C == C), "sc_add_srcs: channel mismatch");
   SC_REQUIRE(a->up == 0 && (!b || b->up == 0), "sc_add_srcs: upsampled sources unsupported");
   dim3 grid((HW + 2047) / 2048, C, N);
   hipLaunchKernelGGL(k_add_srcs, grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*a), b ? to_srcd(*b) : empty_srcd(),
-                     b ? 1 : 0, out, C, HW);
+                     b ? 1 : 0, out, C, HW, absmax);
   SC_LAUNCH_OK("sc_add_srcs");
   return SC_OK;
+}
+
+extern "C" int sc_add_srcs(const sc_src* a, const sc_src* b, float* out, int N, int C, int HW, sc_stream stream) {
+  return sc_add_srcs_absmax(a, b, out, N, C, HW, nullptr, stream);
 }
 
 extern "C" int sc_apply_src(const sc_src* a, float* out, int N, int C, int HW, sc_stream stream) {

@@ -76,6 +76,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 4) void k_mag1c(const Mag1cP p)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int P = p.P[g], pitch = p.Ppad[g];
+  if (P <= 0) return;                                     // skipped group (sc_mag1c_layout_columns: too few valid pixels)
   const T* X = reinterpret_cast<const T*>(p.x) + p.xoff[g];
   const long long po = p.poff[g];
   const unsigned char* mk = p.statmask ? p.statmask + po : nullptr;
@@ -344,6 +345,7 @@ __global__ __launch_bounds__(NT) void k_mag1c_fast(const Mag1cP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int P = p.P[g], pitch = p.Ppad[g];
+  if (P <= 0) return;                                     // skipped group (sc_mag1c_layout_columns: too few valid pixels)
   const T* X = reinterpret_cast<const T*>(p.x) + p.xoff[g];
   const long long po = p.poff[g];
   const unsigned char* mk = p.statmask ? p.statmask + po : nullptr;
@@ -675,6 +677,103 @@ __global__ __launch_bounds__(256) void k_valid_mask(const T* __restrict__ cube, 
   if ((int)threadIdx.x < np) valid[p0 + threadIdx.x] = (unsigned char)s_ok[threadIdx.x];
 }
 
+// valid[p] = all(cube[p][band0 .. band0+S) != fill)   (mag1c_emit.py:60-66: pixels with any band equal to the fill value are left out)
+template <typename T>
+__global__ __launch_bounds__(256) void k_valid_mask_ne(const T* __restrict__ cube, int S_total, int band0, int S, double fill,
+                                                       long long npix, unsigned char* __restrict__ valid) {
+  __shared__ int s_ok[256];
+  const long long p0 = (long long)blockIdx.x * 256;
+  const int np = (int)((npix - p0) < 256 ? (npix - p0) : 256);
+  s_ok[threadIdx.x] = 1;
+  __syncthreads();
+  const T* base = cube + p0 * S_total;
+  const long long n = (long long)np * S_total;
+  for (long long e = threadIdx.x; e < n; e += 256) {
+    const int q = (int)(e / S_total), b = (int)(e - (long long)q * S_total);
+    if (b >= band0 && b < band0 + S && (double)base[e] == fill) s_ok[q] = 0;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < np) valid[p0 + threadIdx.x] = (unsigned char)s_ok[threadIdx.x];
+}
+
+// ---- packed layout of column-structured groups, built on the device without a sort -----------------------------------------
+// group g = image columns [gcol[g], gcol[g+1]); its pixels are the valid ones in row-major order.
+__device__ __forceinline__ int lc_row_count(const unsigned char* __restrict__ valid, int r, int cols, int c0, int c1) {
+  int n = 0;
+  for (int c = c0; c < c1; ++c) n += valid[(size_t)r * cols + c] ? 1 : 0;
+  return n;
+}
+// inclusive scan of one int per thread over a 256-thread block; returns the block total through `total`
+__device__ __forceinline__ int lc_block_scan(int v, int* s_w, int& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+  if (lane == 63) s_w[wave] = v;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += s_w[w];
+  total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  __syncthreads();
+  return v + base;
+}
+__global__ __launch_bounds__(256) void k_lc_count(const unsigned char* __restrict__ valid, int rows, int cols,
+                                                  const int* __restrict__ gcol, int min_keep, int* __restrict__ P) {
+  __shared__ int s_w[4];
+  const int g = blockIdx.x, c0 = gcol[g], c1 = gcol[g + 1];
+  int n = 0;
+  for (int r = threadIdx.x; r < rows; r += 256) n += lc_row_count(valid, r, cols, c0, c1);
+  int total;
+  (void)lc_block_scan(n, s_w, total);
+  if (threadIdx.x == 0) P[g] = total > min_keep ? total : 0;
+}
+__global__ __launch_bounds__(256) void k_lc_scan(const int* __restrict__ P, int G, int S, int* __restrict__ Ppad,
+                                                 long long* __restrict__ poff, long long* __restrict__ xoff,
+                                                 long long* __restrict__ totals) {
+  __shared__ int s_w[4];
+  long long carry_p = 0, carry_x = 0;
+  for (int g0 = 0; g0 < G; g0 += 256) {
+    const int g = g0 + threadIdx.x;
+    const int pv = g < G ? P[g] : 0;
+    const int pp = (pv + 63) & ~63;
+    int tp, tq;
+    const int ip = lc_block_scan(pv, s_w, tp);
+    const int iq = lc_block_scan(pp, s_w, tq);
+    if (g < G) {
+      Ppad[g] = pp;
+      poff[g] = carry_p + (ip - pv);
+      xoff[g] = (carry_x + (iq - pp)) * (long long)S;
+    }
+    carry_p += tp; carry_x += tq;
+  }
+  if (threadIdx.x == 0) { totals[0] = carry_p; totals[1] = carry_x * (long long)S; }
+}
+__global__ __launch_bounds__(256) void k_lc_index(const unsigned char* __restrict__ valid, int rows, int cols,
+                                                  const int* __restrict__ gcol, const int* __restrict__ P,
+                                                  const long long* __restrict__ poff, long long* __restrict__ pix) {
+  __shared__ int s_w[4];
+  const int g = blockIdx.x;
+  if (P[g] <= 0) return;
+  const int c0 = gcol[g], c1 = gcol[g + 1];
+  long long* out = pix + poff[g];
+  int carry = 0;
+  for (int r0 = 0; r0 < rows; r0 += 256) {
+    const int r = r0 + threadIdx.x;
+    const int n = r < rows ? lc_row_count(valid, r, cols, c0, c1) : 0;
+    int total;
+    int pos = carry + lc_block_scan(n, s_w, total) - n;
+    if (r < rows)
+      for (int c = c0; c < c1; ++c)
+        if (valid[(size_t)r * cols + c]) out[pos++] = (long long)r * cols + c;
+    carry += total;
+  }
+}
+template <typename TI, typename TO>
+__global__ void k_scatter_n(const TI* __restrict__ val, const long long* __restrict__ pix, const long long* __restrict__ n_dev,
+                            TO* __restrict__ out) {
+  const size_t n = (size_t)*n_dev;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[pix[i]] = (TO)val[i];
+}
+
 size_t mag1c_lds_bytes(int S) {
   const int S16 = (S + 15) & ~15;
   const size_t stg = (size_t)S16 * 17 > 8 * 128 ? (size_t)S16 * 17 : 8 * 128;
@@ -774,5 +873,45 @@ extern "C" int sc_valid_mask(const void* cube, int cube_is_f64, int S_total, int
   if (cube_is_f64) hipLaunchKernelGGL(k_valid_mask<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)cube, S_total, band0, S, nodata, (long long)npix, valid);
   else hipLaunchKernelGGL(k_valid_mask<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)cube, S_total, band0, S, nodata, (long long)npix, valid);
   SC_LAUNCH_OK("sc_valid_mask");
+  return SC_OK;
+}
+
+extern "C" int sc_valid_mask_ne(const void* cube, int cube_is_f64, int S_total, int band0, int S, double fill, int64_t npix,
+                                unsigned char* valid, sc_stream stream) {
+  SC_REQUIRE(cube && valid && S_total > 0 && band0 >= 0 && S > 0 && band0 + S <= S_total && npix >= 0, "sc_valid_mask_ne: bad argument");
+  if (npix == 0) return SC_OK;
+  const unsigned blocks = (unsigned)((npix + 255) / 256);
+  if (cube_is_f64) hipLaunchKernelGGL(k_valid_mask_ne<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)cube, S_total, band0, S, fill, (long long)npix, valid);
+  else hipLaunchKernelGGL(k_valid_mask_ne<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)cube, S_total, band0, S, fill, (long long)npix, valid);
+  SC_LAUNCH_OK("sc_valid_mask_ne");
+  return SC_OK;
+}
+
+extern "C" int sc_mag1c_layout_columns(const unsigned char* valid, int rows, int cols, const int32_t* gcol, int G, int S,
+                                       int min_keep, int32_t* P, int32_t* Ppad, int64_t* poff, int64_t* xoff,
+                                       int64_t* pix_index, int64_t* totals, sc_stream stream) {
+  SC_REQUIRE(valid && gcol && P && Ppad && poff && xoff && pix_index && totals, "sc_mag1c_layout_columns: null pointer argument");
+  SC_REQUIRE(rows > 0 && cols > 0 && G >= 0 && S >= 1 && S <= MAXS, "sc_mag1c_layout_columns: bad shape");
+  if (G == 0) return SC_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_lc_count, dim3(G), dim3(256), 0, st, valid, rows, cols, gcol, min_keep, P);
+  hipLaunchKernelGGL(k_lc_scan, dim3(1), dim3(256), 0, st, (const int*)P, G, S, Ppad, (long long*)poff, (long long*)xoff, (long long*)totals);
+  hipLaunchKernelGGL(k_lc_index, dim3(G), dim3(256), 0, st, valid, rows, cols, gcol, (const int*)P, (const long long*)poff, (long long*)pix_index);
+  SC_LAUNCH_OK("sc_mag1c_layout_columns");
+  return SC_OK;
+}
+
+extern "C" int sc_scatter_n(const void* val, int val_is_f64, const int64_t* pix_index, const int64_t* n_dev, size_t n_max,
+                            void* out, int out_is_f64, sc_stream stream) {
+  SC_REQUIRE(val && pix_index && out && n_dev, "sc_scatter_n: null pointer argument");
+  if (n_max == 0) return SC_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (int)((n_max + 255) / 256 > 2048 ? 2048 : (n_max + 255) / 256);
+  const long long* px = (const long long*)pix_index; const long long* nd = (const long long*)n_dev;
+  if (val_is_f64 && out_is_f64) hipLaunchKernelGGL((k_scatter_n<double, double>), dim3(blocks), dim3(256), 0, st, (const double*)val, px, nd, (double*)out);
+  else if (val_is_f64) hipLaunchKernelGGL((k_scatter_n<double, float>), dim3(blocks), dim3(256), 0, st, (const double*)val, px, nd, (float*)out);
+  else if (out_is_f64) hipLaunchKernelGGL((k_scatter_n<float, double>), dim3(blocks), dim3(256), 0, st, (const float*)val, px, nd, (double*)out);
+  else hipLaunchKernelGGL((k_scatter_n<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)val, px, nd, (float*)out);
+  SC_LAUNCH_OK("sc_scatter_n");
   return SC_OK;
 }

@@ -76,6 +76,82 @@ def _run_groups(cube2d, S_total, band0, S, pix_index, counts, template, num_iter
     return mf, alb
 
 
+def _column_runs(ids):
+    """ids: 1-D host int array (group id of every image column).  -> (gcol int32 [G+1], sorted-by-column) if every id
+    occupies ONE contiguous run of columns, else None."""
+    ids = np.asarray(ids)
+    cuts = np.flatnonzero(np.diff(ids) != 0) + 1
+    starts = np.concatenate([[0], cuts])
+    if np.unique(ids[starts]).size != starts.size:
+        return None
+    return np.concatenate([starts, [ids.size]]).astype(np.int32)
+
+
+_LAYOUT_CACHE = {}
+COLUMN_FAST_PATH = True      # False: always take the general (device sort) layout path; tests compare the two bit for bit
+
+
+def _run_column_groups(cube3, b0, S, valid_u8, gcol, min_keep, template, num_iter, alpha, k, flags, fill, out_dtype):
+    """Column-structured groups (both drivers of the reference): layout, pack, filter and scatter entirely on the device --
+    ``sc_mag1c_layout_columns`` -> ``sc_mag1c_pack`` -> ``sc_mag1c_groups`` -> ``sc_scatter_n`` with every per-group array and
+    the pixel count in device memory; the only host synchronisation is the status check after the filter."""
+    lib = _lib.load()
+    dev = cube3.device
+    rows, cols, S_total = cube3.shape
+    HW = rows * cols
+    G = int(gcol.size - 1)
+    is64 = cube3.dtype == torch.float64
+    dt = cube3.dtype
+    mf_out = torch.full((HW,), fill, dtype=out_dtype, device=dev)
+    alb_out = torch.full((HW,), fill, dtype=out_dtype, device=dev)
+    if G == 0:
+        return mf_out.reshape(rows, cols), alb_out.reshape(rows, cols)
+    if S > MAX_BANDS:
+        raise ValueError(f"mag1c: at most {MAX_BANDS} bands per filter (got {S})")
+    key = (dev, gcol.tobytes())
+    gcol_d = _LAYOUT_CACHE.get(key)
+    if gcol_d is None:
+        if len(_LAYOUT_CACHE) > 16:
+            _LAYOUT_CACHE.clear()
+        gcol_d = _LAYOUT_CACHE[key] = torch.from_numpy(gcol).to(dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    i64 = dict(dtype=torch.int64, device=dev)
+    P_d, ppad_d = torch.empty(G, **i32), torch.empty(G, **i32)
+    poff_d, xoff_d, totals = torch.empty(G, **i64), torch.empty(G, **i64), torch.empty(2, **i64)
+    pix = torch.empty(HW, **i64)
+    st = stream()
+    check(lib.sc_mag1c_layout_columns(ptr(valid_u8), rows, cols, ptr(gcol_d), G, S, int(min_keep), ptr(P_d), ptr(ppad_d),
+                                      ptr(poff_d), ptr(xoff_d), ptr(pix), ptr(totals), st))
+    xp = torch.zeros((HW + 64 * G) * S, dtype=dt, device=dev)            # upper bound of sum(Ppad) * S: no size read-back
+    check(lib.sc_mag1c_pack(ptr(cube3), 1 if is64 else 0, S_total, b0, S, ptr(pix), ptr(xoff_d), ptr(ppad_d),
+                            ptr(poff_d), ptr(P_d), G, ptr(xp), 1 if is64 else 0, st))
+    a = sc_mag1c_args()
+    a.x = xp.data_ptr(); a.x_is_f64 = 1 if is64 else 0
+    a.xoff = xoff_d.data_ptr(); a.P = P_d.data_ptr(); a.Ppad = ppad_d.data_ptr(); a.poff = poff_d.data_ptr()
+    a.statmask = None
+    a.G, a.S, a.npix = G, S, HW
+    templ = torch.as_tensor(template, dtype=torch.float64).to(dev).contiguous()
+    if templ.numel() != S:
+        raise ValueError(f"mag1c: template has {templ.numel()} bands, data has {S}")
+    a.templ = templ.data_ptr()
+    a.num_iter, a.alpha, a.cov_update_scaling = int(num_iter), float(alpha), float(k)
+    a.albedo_override, a.zero_override, a.sparse_override, a.apply_scaling = (int(bool(f)) for f in flags)
+    work = torch.empty(lib.sc_mag1c_workspace_doubles(G, S, HW), dtype=torch.float64, device=dev)
+    status = torch.zeros(G, dtype=torch.int32, device=dev)
+    mf, alb = torch.empty(HW, dtype=dt, device=dev), torch.empty(HW, dtype=dt, device=dev)
+    a.work, a.mf_out, a.albedo_out, a.status = work.data_ptr(), mf.data_ptr(), alb.data_ptr(), status.data_ptr()
+    check(lib.sc_mag1c_groups(C.byref(a), st))
+    o64 = 1 if out_dtype == torch.float64 else 0
+    check(lib.sc_scatter_n(ptr(mf), 1 if is64 else 0, ptr(pix), ptr(totals), HW, ptr(mf_out), o64, st))
+    check(lib.sc_scatter_n(ptr(alb), 1 if is64 else 0, ptr(pix), ptr(totals), HW, ptr(alb_out), o64, st))
+    if int(status.max()):          # the reference's torch.linalg.cholesky raises (mag1c.py:251,323)
+        bad = torch.nonzero(status).reshape(-1)
+        raise torch.linalg.LinAlgError(
+            f"linalg.cholesky: (Batch element {int(bad[0])}): The factorization could not be completed because the "
+            "input is not positive-definite")
+    return mf_out.reshape(rows, cols), alb_out.reshape(rows, cols)
+
+
 def _batched(x, template, num_iter, alpha, k, flags, mask):
     _lib.require_device(x)
     if x.dim() != 3:
@@ -152,6 +228,16 @@ def func_by_groups(func, x, groups, mask=None, disable_pbar=True, samples_read=5
         mask_t = mask_u8.bool()
     else:
         mask_t = (mask if torch.is_tensor(mask) else torch.as_tensor(np.asarray(mask))).to(dev).reshape(-1).bool()
+    if isinstance(func, Filter) and COLUMN_FAST_PATH:
+        # both drivers of the reference group by detector column(s): when every row of `groups` is the same and each id is one
+        # run of columns, the layout is built on the device without the sort below (results are the same pixels in the same order)
+        g_host = groups.cpu().numpy() if torch.is_tensor(groups) else np.asarray(groups)
+        g_host = g_host.reshape(H, W)
+        gcol = _column_runs(g_host[0]) if bool((g_host == g_host[:1]).all()) else None
+        if gcol is not None:
+            xc = x.contiguous()
+            return _run_column_groups(xc, b0, b1 - b0, mask_t.to(torch.uint8).contiguous() if mask is not None else mask_u8, gcol, 10,
+                                      func.template, func.num_iter, func.alpha, func.k, func.flags, NODATA, x.dtype)
     mf_out = torch.full((H * W,), NODATA, dtype=x.dtype, device=dev)
     alb_out = torch.full((H * W,), NODATA, dtype=x.dtype, device=dev)
     valid_idx = torch.nonzero(mask_t).reshape(-1)
@@ -202,35 +288,27 @@ def mag1c_columns(raw, template, fill_value=-9999.0, column_step=None, num_iter=
     _lib.require_device()
     raw = raw.to(dev).float().contiguous()
     rows, cols, S = raw.shape
-    step = column_step or cols
-    invalid = torch.any(raw == fill_value, dim=-1)
-    colgroup = (torch.arange(cols, device=dev) // step)[None, :].expand(rows, cols)
-    valid = ~invalid
+    step = int(column_step or cols)
+    lib = _lib.load()
+    # pixels with any band equal to the fill value are left out (mag1c_emit.py:60-66): one pass over the cube
+    valid = torch.empty(rows * cols, dtype=torch.uint8, device=dev)
+    check(lib.sc_valid_mask_ne(ptr(raw), 0, S, 0, S, float(fill_value), rows * cols, ptr(valid), stream()))
     if column_range is not None:
-        cr = torch.zeros(cols, dtype=torch.bool, device=dev)
-        cr[column_range[0]:column_range[1]] = True
-        valid = valid & cr[None, :]
-    mf_out = torch.full((rows * cols,), float(fill_value), dtype=torch.float32, device=dev)
-    alb_out = torch.full((rows * cols,), float(fill_value), dtype=torch.float32, device=dev)
-    vidx = torch.nonzero(valid.reshape(-1)).reshape(-1)
-    if vidx.numel() == 0:
-        return mf_out.reshape(rows, cols), alb_out.reshape(rows, cols)
-    gv = colgroup.reshape(-1)[vidx]
-    # pixel order inside a block follows the reference's boolean indexing raw[:, c0:c1][valid] (row-major)
-    order = torch.argsort(gv, stable=True)
-    pix = vidx[order].contiguous()
-    _, counts = torch.unique_consecutive(gv[order], return_counts=True)
+        c0, c1 = int(column_range[0]), int(column_range[1])
+        if c0 % step or (c1 % step and c1 != cols):
+            raise ValueError(f"mag1c_columns: column_range {column_range} must fall on column_step={step} boundaries: a "
+                             "truncated block would be filtered with different statistics than in the whole scene")
+        edges = np.arange(c0, c1, step)
+        gcol = np.concatenate([edges, [c1]]).astype(np.int32)
+    else:
+        gcol = np.concatenate([np.arange(0, cols, step), [cols]]).astype(np.int32)
     # The reference converts the float32 radiances to float64 before filtering (:74-75).  The kernels evaluate every
     # statistic, factorisation and per-pixel product in fp64 whatever the storage type, and double(float32) is exact, so
     # the float32 cube is filtered as it is: the same arithmetic on the same values at half the HBM traffic (the EMIT
     # path streams X 62 times and is bandwidth-bound); the results are rounded to float32 once, as the reference does (:90).
-    x32 = raw.reshape(rows * cols, S)
-    mf, alb = _run_groups(x32, S, 0, S, pix, counts.cpu(), template, num_iter, covariance_lerp_alpha, 1.0,
-                          (False, False, False, True))
-    lib = _lib.load()
-    check(lib.sc_scatter(ptr(mf), 0, ptr(pix), pix.numel(), ptr(mf_out), 0, stream()))
-    check(lib.sc_scatter(ptr(alb), 0, ptr(pix), pix.numel(), ptr(alb_out), 0, stream()))
-    return mf_out.reshape(rows, cols), alb_out.reshape(rows, cols)
+    # Pixel order inside a block follows the reference's boolean indexing raw[:, c0:c1][valid] (row-major).
+    return _run_column_groups(raw, 0, S, valid, gcol, 0, template, num_iter, covariance_lerp_alpha, 1.0,
+                              (False, False, False, True), float(fill_value), torch.float32)
 
 
 # ------------------------------------------------------------------------------------------------

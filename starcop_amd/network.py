@@ -145,12 +145,21 @@ class HyperStarcopUNet(nn.Module):
 
     # -- range of the default (two-fp16-term) split: filters are scaled by 2^8 and activations by 2 before the fp16 conversion
     FP16_MAX_WEIGHT, FP16_MAX_ACT = 255.0, 32752.0
+    range_check_every = 200     # optimiser steps between two check_split_range() calls during training (0: never)
 
     def split_range_report(self):
-        """Largest |filter| of the split 3x3 convolutions and a bound on their input activations, max_c(64 |gamma_c| + |beta_c|)
-        over the BatchNorms that feed them (|x_hat| <= 64 covers every realistic tile), against the limits of the two-fp16-term
-        kernels.  Synchronises the device; called once after a checkpoint is loaded."""
-        wmax = amax = 0.0
+        """Largest |filter| of the split 3x3 convolutions, a bound on their BatchNorm-fed input activations, max_c(64 |gamma_c| +
+        |beta_c|) (|x_hat| <= 64 covers every realistic tile), and the largest |value| observed so far in the residual sums that
+        feed them with no BatchNorm in between (recorded by sc_add_srcs_absmax in every forward), against the limits of the
+        two-fp16-term kernels.  Synchronises the device; called after a checkpoint is loaded and every `range_check_every`
+        optimiser steps (FusedAdam), so filters / gains that grow during training are caught too."""
+        wmax = amax = rmax = 0.0
+        fin_feeds_split = {t.name for op in self._ops if op["type"] == "conv3" and _pick_cot(op["conv"].out_channels, 3) >= 32
+                           for t in op["ins"] if t.kind == "fin"}
+        for plan in self._plans.values():          # observed: residual sums have no BatchNorm to bound them
+            for n, i in plan.fin_slot.items():
+                if n in fin_feeds_split:
+                    rmax = max(rmax, float(plan.fin_amax[i]))
         for op in self._ops:
             if op["type"] != "conv3" or _pick_cot(op["conv"].out_channels, 3) < 32:
                 continue
@@ -160,7 +169,7 @@ class HyperStarcopUNet(nn.Module):
                 if bn is not None:
                     amax = max(amax, float((64.0 * bn.weight.detach().abs() + bn.bias.detach().abs()).max()))
         return dict(max_abs_filter=wmax, filter_limit=self.FP16_MAX_WEIGHT, activation_bound=amax, activation_limit=self.FP16_MAX_ACT,
-                    ok=bool(wmax < self.FP16_MAX_WEIGHT and amax < self.FP16_MAX_ACT))
+                    residual_absmax=rmax, ok=bool(wmax < self.FP16_MAX_WEIGHT and amax < self.FP16_MAX_ACT and rmax < self.FP16_MAX_ACT))
 
     def check_split_range(self):
         """A checkpoint whose filters or BatchNorm gains leave the fp16 range of the default split is run with the
@@ -349,6 +358,9 @@ class HyperStarcopUNet(nn.Module):
                     plan.stats_v[t.name] = torch.empty(plan.srows[t.name] * t.C * 2, **f32)
                     plan.cst[t.name] = torch.zeros((t.C, SC_CST), **f32)
                     plan.cstb[t.name] = torch.zeros((t.C, SC_CST), **f32)
+            fins = [t.name for t in self._tensors.values() if t.kind == "fin" and t.name != "logits"]
+            plan.fin_slot = {n: i for i, n in enumerate(fins)}
+            plan.fin_amax = torch.zeros(len(fins), **f32)        # running max |value| of each residual sum (never lowered)
             plan.has_grad = False
             self._plans[key] = plan
         if need_grad and not plan.has_grad:
@@ -554,7 +566,10 @@ class HyperStarcopUNet(nn.Module):
             elif ty == "add":
                 sa = self._src_of(plan, op["ins"][0])
                 sb = self._src_of(plan, op["ins"][1])
-                check(lib.sc_add_srcs(C.byref(sa), C.byref(sb), ptr(plan.buf[o.name]), N, o.C, Ho * Wo, st))
+                # the residual sums are the only inputs of a split convolution that no BatchNorm bounds (the skips taken after
+                # features.3/6/13): their max |value| is recorded for split_range_report
+                check(lib.sc_add_srcs_absmax(C.byref(sa), C.byref(sb), ptr(plan.buf[o.name]), N, o.C, Ho * Wo,
+                                             plan.fin_amax.data_ptr() + 4 * plan.fin_slot[o.name], st))
             elif ty == "head":
                 s = self._src_of(plan, op["ins"][0])
                 check(lib.sc_head_conv_fwd(C.byref(s), ptr(conv.weight), ptr(conv.bias), ptr(plan.buf[o.name]),

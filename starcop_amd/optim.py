@@ -85,6 +85,10 @@ class FusedAdam(torch.optim.Adam):
                                float(grp["eps"]), float(grp["weight_decay"]), 1.0, 1.0, float(grad_scale),
                                ptr(self._hp_dev), st))
         net.mark_parameters_changed()
+        self._steps_since_check = getattr(self, "_steps_since_check", 0) + 1
+        if net.range_check_every and self._steps_since_check >= net.range_check_every and not torch.cuda.is_current_stream_capturing():
+            self._steps_since_check = 0
+            net.check_split_range()          # trained filters / BatchNorm gains / residual sums still inside the fp16-split range?
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -121,6 +121,62 @@ def test_column_driver_emit_semantics(hip):
     assert np.array_equal(merged, mf)
 
 
+def test_template_generated_on_the_box_drives_the_filter(hip):
+    """a13 end to end on the GPU box: generate_template_from_bands reads the CH4 look-up table that ships with the package
+    (starcop_amd/data/ch4.lut, no reference checkout needed), reproduces the reference's template (golden G3) and bad-band mask,
+    and the template it made drives the EMIT column driver to the oracle's result."""
+    g3 = np.load(os.path.join(G, "g3_templates.npz"))
+    assert np.array_equal(hip_mag1c.get_mask_bad_bands(g3["badband_wave"]), g3["badband_keep"])
+    full = hip_mag1c.generate_template_from_bands(g3["emit_centers"], g3["emit_fwhm"])
+    t = full[g3["emit_keep"]]
+    assert np.abs(t - g3["emit_template_kept"]).max() < 1e-9 * np.abs(g3["emit_template_kept"]).max()
+    ta = hip_mag1c.generate_template_from_bands(g3["aviris_centers"], g3["aviris_fwhm"])[g3["aviris_keep"]]
+    assert np.abs(ta - g3["aviris_template_kept"]).max() < 1e-9 * np.abs(g3["aviris_template_kept"]).max()
+    rng = np.random.default_rng(14)
+    S, rows, cols = t.shape[0], 64, 8
+    raw = (rng.uniform(1, 6, size=S) * (1 + 0.05 * rng.standard_normal((rows, cols, S)))).astype(np.float32)
+    k = np.zeros((rows, cols)); k[10:30, 2:5] = 3e-5
+    raw = (raw * (1 + k[..., None] * t[:, 1])).astype(np.float32)
+    want_mf, _ = mag1c_ref.mag1c_columns(raw, t[:, 1], -9999.0, column_step=2, num_iter=30, alpha=1e-4)
+    mf, _ = hip_mag1c.mag1c_columns(torch.from_numpy(raw).to(DEV), t[:, 1], -9999.0, column_step=2, num_iter=30)
+    assert rel(mf.cpu().numpy(), want_mf).max() < 1e-5
+
+
+def test_column_layout_equals_sorted_layout(hip):
+    """column-structured groups take the sort-free device layout (sc_mag1c_layout_columns); it must give exactly the packed
+    order of the general path (stable sort by group id): same pixels, same order, same kernel -> bit-identical results, incl.
+    NODATA pixels, a user mask, multi-column groups, a group of <= 10 valid pixels (skipped) and an all-invalid column"""
+    rng = np.random.default_rng(31)
+    t = np.load(os.path.join(G, "g3_templates.npz"))["aviris_template_kept"][:, 1][:24]
+    H, W, S = 80, 37, 24
+    cube = (rng.uniform(1, 6, size=S) * (1 + 0.05 * rng.standard_normal((H, W, S)))).astype(np.float32)
+    cube[5:9, 3, 2] = hip_mag1c.NODATA                      # invalid pixels inside a group
+    cube[:, 11, :] = hip_mag1c.NODATA                       # a whole column invalid
+    cube[: H - 7, 15, 0] = hip_mag1c.NODATA                 # a single-column group with 7 valid pixels: skipped (<= 10)
+    ids = np.concatenate([np.arange(1, 21), np.repeat(np.arange(30, 36), 3)])[:W]      # single columns, then 3-column blocks
+    groups = np.repeat(ids[None, :], H, 0)
+    x = torch.from_numpy(cube).to(DEV)
+    mask = (rng.random((H, W)) > 0.1) & np.all(cube > hip_mag1c.NODATA, axis=-1)
+    for m in (None, mask):
+        hip_mag1c.COLUMN_FAST_PATH = True
+        a_mf, a_alb = hip_mag1c.acrwl1mf_by_groups(x, t, groups, mask=m)
+        try:
+            hip_mag1c.COLUMN_FAST_PATH = False
+            b_mf, b_alb = hip_mag1c.acrwl1mf_by_groups(x, t, groups, mask=m)
+        finally:
+            hip_mag1c.COLUMN_FAST_PATH = True
+        assert torch.equal(a_mf, b_mf) and torch.equal(a_alb, b_alb)
+        assert bool((a_mf[:, 11] == hip_mag1c.NODATA).all()) and bool((a_mf[:, 15] == hip_mag1c.NODATA).all())
+        assert bool((a_mf[:, 0] != hip_mag1c.NODATA).all()) if m is None else True
+    # and against the oracle
+    want_mf, _ = mag1c_ref.func_by_groups(lambda xg: mag1c_ref.acrwl1mf(xg, t, num_iter=30, alpha=0.0), cube, groups)
+    got = a_mf if m is None else hip_mag1c.acrwl1mf_by_groups(x, t, groups)[0]
+    got = got.cpu().numpy()
+    assert np.array_equal(got == hip_mag1c.NODATA, want_mf == hip_mag1c.NODATA)
+    ok = want_mf != hip_mag1c.NODATA
+    assert np.mean(rel(got[ok], want_mf[ok]) > 1e-3) < 2e-3
+
+
 def test_cfg3_size_properties(hip):
     """BASELINE config 3 shape (512 column groups x 512 px x 125 bands, fp32): size-independent properties --
     pixels without plume stay near zero, planted enhancement is recovered in order of magnitude, groups are

@@ -308,6 +308,36 @@ def test_checkpoint_outside_fp16_range_falls_back_to_three_term_split(hip):
     assert model2.network.precision == "fp32-x3"
 
 
+def test_residual_sums_are_range_checked(hip):
+    """the residual sums (encoder.features.3/6/13 outputs) reach decoder conv1 layers with no BatchNorm in between, so no static
+    bound exists for them: every forward records their max |value| (sc_add_srcs_absmax) and split_range_report / the periodic
+    re-check during training compare it with the two-fp16-term limit, falling back to the three-term split beyond it"""
+    model, ref = make_pair(seed=5)
+    net = model.network
+    model.eval(); ref.eval()
+    batch = synth_batch(2, 64, 64, seed=6)
+    feats = {}
+    hooks = [ref.encoder.features[i].register_forward_hook(lambda m, i_, o, k=i: feats.__setitem__(k, o)) for i in (3, 6, 13)]
+    with torch.no_grad():
+        ref(ref_normalize(batch["input"]))
+        model(to_dev(batch)["input"])
+    for h in hooks:
+        h.remove()
+    rep = net.split_range_report()
+    want = max(float(v.abs().max()) for v in feats.values())
+    assert rep["ok"] and abs(rep["residual_absmax"] - want) < 1e-4 * want
+    # a checkpoint whose residual stream explodes: the projection BatchNorm of features.3 gets a huge gain
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    sd["encoder.features.3.conv.3.weight"][:] = 4.0e4
+    net.load_state_dict(sd)                     # static limits still fine (this BatchNorm feeds no split convolution directly)
+    assert net.precision == "fp32"
+    with torch.no_grad():
+        model(to_dev(batch)["input"])
+    with pytest.warns(UserWarning, match="fp32-x3"):
+        assert not net.check_split_range()
+    assert net.precision == "fp32-x3" and net.split_range_report()["residual_absmax"] > net.FP16_MAX_ACT
+
+
 def test_optimizer_checkpoint_resume(hip):
     """FusedAdam.load_state_dict: a resumed run (Lightning restores optimiser state through load_state_dict; reference
     train.py:137 resume_from_checkpoint) continues with the checkpoint's moments and step count -- parameters after the next

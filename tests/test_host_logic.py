@@ -102,14 +102,16 @@ def test_differences_and_band_mask():
     assert np.array_equal(mm.differences(torch.from_numpy(g5["pb_64"]), torch.from_numpy(g5["gt_64"])).numpy(), g5["diff_64"])
     g3 = np.load(os.path.join(G, "g3_templates.npz"))
     assert np.array_equal(get_mask_bad_bands(g3["badband_wave"]), g3["badband_keep"])
-    lut_dir = "/root/reference/starcop/models"
-    if os.path.exists(os.path.join(lut_dir, "ch4.lut")):
-        t = generate_template_from_bands(g3["aviris_centers"], g3["aviris_fwhm"], lut_dir=lut_dir)
-        assert np.abs(t[g3["aviris_keep"]] - g3["aviris_template_kept"]).max() < 1e-9 * np.abs(g3["aviris_template_kept"]).max()
+    # the CH4 look-up table ships with the package (starcop_amd/data/, BSD-3 data file of mag1c upstream): no lut_dir needed
+    t = generate_template_from_bands(g3["aviris_centers"], g3["aviris_fwhm"])
+    assert np.abs(t[g3["aviris_keep"]] - g3["aviris_template_kept"]).max() < 1e-9 * np.abs(g3["aviris_template_kept"]).max()
+    te = generate_template_from_bands(g3["emit_centers"], g3["emit_fwhm"])
+    assert np.abs(te[g3["emit_keep"]] - g3["emit_template_kept"]).max() < 1e-9 * np.abs(g3["emit_template_kept"]).max()
     with pytest.raises(RuntimeError):
-        generate_template_from_bands([2300.0, np.nan], [5.0, 5.0], lut_dir=lut_dir)
+        generate_template_from_bands([2300.0, np.nan], [5.0, 5.0])
     with pytest.raises(RuntimeError):
-        generate_template_from_bands([2300.0, 2310.0], [5.0], lut_dir=lut_dir)
+        generate_template_from_bands([2300.0, 2310.0], [5.0])
+
 
 
 def test_shard_range_is_a_partition():
