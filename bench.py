@@ -74,6 +74,74 @@ def cpu_baseline(budget_s=25.0):
 CONV_ROOFLINE_TILES_S = 1718.0
 
 
+def _timeit(fn, reps):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def bench_extras(model, dev, precision):
+    """The other BASELINE.json configurations, measured after the timed region (rank 0, N=1) so the driver sees them too:
+    configs[2] mag1c on a 125-band AVIRIS-like tile, the EMIT-like granule of configs[4] (mag1c + scene inference), and the
+    eval forward of the 4-channel U-Net.  Whole-call wall times with inputs resident in HBM; synthetic seeded data."""
+    import numpy as np
+    from starcop_amd import mag1c
+    from starcop_amd import model_module as mm
+    out = {}
+    g3 = np.load(os.path.join(ROOT, "tests", "golden", "g3_templates.npz"))     # templates the reference generated (fixture: data)
+    gen = torch.Generator(device=dev).manual_seed(7)
+
+    def cube(H, W, templ):
+        S = templ.size
+        base = torch.rand(S, generator=gen, device=dev) * 5 + 1
+        c = base * (1 + 0.05 * torch.randn(H, W, S, generator=gen, device=dev))
+        conc = torch.zeros(H, W, device=dev); conc[H // 3:H // 3 + 60, W // 4:W // 4 + 40] = 2000.0
+        return (c * (1 + conc[..., None] * 1e-5 * torch.as_tensor(templ, device=dev, dtype=torch.float32))).float().contiguous()
+
+    # ---- configs[2]: AVIRIS-NG 125-band tile, one detector column per group (process_aviris.py:209-219), alpha = 0, 30 iterations
+    S = 125
+    t125 = np.interp(np.linspace(0, 72, S), np.arange(73), g3["aviris_template_kept"][:, 1])
+    x = cube(512, 512, t125)
+    groups = np.arange(1, 513)[None, :].repeat(512, 0)
+    dt = _timeit(lambda: mag1c.acrwl1mf_by_groups(x, t125, groups), 5)
+    dt0 = _timeit(lambda: mag1c.acrwl1mf_by_groups(x, t125, groups, num_iter=0), 5)
+    it_bytes = 31 * 2 * 512 * 512 * S * 4          # X streamed twice per iteration (DESIGN.md section 3), 31 rounds
+    out["mag1c_cfg3"] = {"workload": "configs[2]: 512x512 px x 125 bands fp32, 512 column groups, acrwl1mf num_iter=30 alpha=0",
+                         "ms_per_tile": round(dt * 1e3, 3), "tiles_s": round(1 / dt, 1), "setup_ms": round(dt0 * 1e3, 3),
+                         "roofline": {"bound": "cache (a group's 256 KB of radiances stay in L2/MALL between its 62 sweeps; HBM sees the cube once)",
+                                      "streamed_bytes_per_tile": it_bytes, "streamed_GBs": round(it_bytes / max(dt - dt0, 1e-9) / 1e9, 1),
+                                      "hbm_min_bytes_per_tile": 512 * 512 * S * 4 + 8 * 512 * 512,
+                                      "note": "iteration time = ms_per_tile - setup_ms (setup: validity mask, layout, pack, means, scatter matrix, Cholesky)"}}
+    # ---- EMIT-like granule (configs[4] preprocessing): 1280 x 1242 px, 49 bands in [2122, 2488] nm, fp64 arithmetic, alpha = 1e-4
+    te = g3["emit_template_kept"][:, 1]
+    raw = cube(1280, 1242, te)
+    dt = _timeit(lambda: mag1c.mag1c_columns(raw, te, -9999.0, column_step=2), 3)
+    sw = 62 * 1280 * 1242 * te.size * 4
+    out["mag1c_emit"] = {"workload": "EMIT-like 1280x1242 px x 49 bands fp32 storage / fp64 arithmetic, column_step=2 (621 groups), alpha=1e-4",
+                         "ms_per_granule": round(dt * 1e3, 3), "Mpx_s": round(1280 * 1242 / dt / 1e6, 1),
+                         "tile_equivalents_s": round(1280 * 1242 / 262144 / dt, 1),
+                         "roofline": {"bound": "hbm", "streamed_bytes_per_granule": sw, "achieved_GBs": round(sw / dt / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
+                                      "frac": round(sw / dt / 1e9 / HBM_PEAK_GBS, 3),
+                                      "note": "X (float32) is streamed 62 times (refactorisation every iteration); whole-call time incl. mask/layout/pack/scatter"}}
+    # ---- U-Net inference
+    model.eval()
+    b16 = synth_batch(16, 512, 512, 77, dev)
+    with torch.no_grad():
+        dt = _timeit(lambda: model(b16["input"]), 10)
+        dtp = _timeit(lambda: model.batch_with_preds(b16), 10)
+    out["infer_b16"] = {"workload": "eval forward, 16 x 4ch 512x512, precision " + precision, "tiles_s": round(16 / dt, 1), "ms": round(dt * 1e3, 3),
+                        "batch_with_preds_tiles_s": round(16 / dtp, 1)}
+    scene = np.random.default_rng(5).uniform(0, 100, size=(4, 1280, 1242)).astype(np.float32)
+    dt = _timeit(lambda: model.predict(scene), 5)
+    out["predict_scene"] = {"workload": "ModelModule.predict on a host (4, 1280, 1242) float32 scene: reflect-pad to x32, forward, sigmoid, crop, back to host",
+                            "ms": round(dt * 1e3, 3), "Mpx_s": round(1280 * 1242 / dt / 1e6, 1)}
+    model.train()
+    return out
+
+
 def self_launch(n, backend):
     """Re-executes this command line under torch.distributed.run with n ranks on this node (rendezvous on 127.0.0.1:free port)
     and returns its exit code.  The driver may call `python bench.py --gpus N` directly; every rank then runs main() with
@@ -102,6 +170,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="tiles per GPU (weak scaling)")
     ap.add_argument("--tile", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the mag1c / inference measurements reported under `extra`")
     ap.add_argument("--overlap", type=int, default=1, help="1: weight gradients on a second HIP stream (default); 0: serial "
                     "launches (use for rocprofv3 per-kernel durations that match the roofline pass)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32-x3", "fp32-bwd2", "fp32-2", "bf16"],
@@ -251,6 +320,20 @@ def main():
             out["conv_roofline"] = {"tiles_per_s_per_gpu": CONV_ROOFLINE_TILES_S,
                                     "frac": round(tiles / elapsed / world / CONV_ROOFLINE_TILES_S, 4),
                                     "note": "sum-of-layers fp32 conv roofline (157.3 TFLOP/s fp32 matrix peak, 8 TB/s HBM), 0.582 ms/tile"}
+        if world == 1 and not args.no_extras:
+            # the bit-faithful split (three bf16 terms, six products, fp32's exponent range) timed by the same loop
+            if args.precision == "fp32" and T == 512:
+                net.precision = "fp32-x3"
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    step()
+                torch.cuda.synchronize()
+                out["config"]["precision_exact_tiles_s"] = round(B * 10 / (time.perf_counter() - t1), 2)
+                net.precision = "fp32"
+            out["extra"] = bench_extras(model, dev, args.precision)
         if not args.no_cpu_baseline and world == 1:       # reported at N=1 only (other ranks would idle at the exit barrier)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

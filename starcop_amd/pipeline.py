@@ -26,14 +26,96 @@ def nearest_bands(wavelengths, targets=RGB_NM):
     return [int(np.argmin(np.abs(w - t))) for t in targets]
 
 
+# Receptive field of smp.Unet('mobilenet_v2'): encoder 3x3 convolutions at strides 1..32 reach 490 px, the decoder
+# adds 126 -> a logit depends on inputs at most 308 px away.  Halo >= 320 (a multiple of 32, the network's stride) therefore makes a
+# tile's core logits IDENTICAL to the whole-scene forward in eval mode (BatchNorm is affine there); smaller halos are an approximation.
+RECEPTIVE_HALO = 320
+
+
+def scene_tiles(H, W, tile=512, halo=RECEPTIVE_HALO):
+    """Partition an (H, W) scene into ``tile`` x ``tile`` cores and their halo-extended windows, clipped to the scene (so the
+    convolutions' zero padding falls on the true border, as in the whole-scene forward).  Returns an int64 tensor (n, 8):
+    core y0, y1, x0, x1 and window y0, y1, x0, x1.  H, W, tile and halo must be multiples of 32 (encoder stride): only shifts by
+    multiples of 32 commute with the network."""
+    for v, name in ((H, "H"), (W, "W"), (tile, "tile"), (halo, "halo")):
+        if v % 32 or (v <= 0 and name != "halo"):
+            raise ValueError(f"scene_tiles: {name}={v} must be a positive multiple of 32")
+    rows = []
+    for y0 in range(0, H, tile):
+        for x0 in range(0, W, tile):
+            y1, x1 = min(y0 + tile, H), min(x0 + tile, W)
+            rows.append((y0, y1, x0, x1, max(0, y0 - halo), min(H, y1 + halo), max(0, x0 - halo), min(W, x1 + halo)))
+    return torch.tensor(rows, dtype=torch.int64)
+
+
+def stitch(cores, rects, H, W):
+    """cores: (n, tile, tile) per-tile core values (zero-padded at the right / bottom scene edge) -> (H, W)"""
+    out = torch.empty((H, W), dtype=cores.dtype, device=cores.device)
+    for c, (y0, y1, x0, x1) in zip(cores, rects[:, :4].tolist()):
+        out[y0:y1, x0:x1] = c[:y1 - y0, :x1 - x0]
+    return out
+
+
+@torch.no_grad()
+def tiled_logits(model, x, tile=512, halo=RECEPTIVE_HALO, batch=8, group=None):
+    """Sliding-window inference of a (C, H, W) device scene (H, W multiples of 32): the tiles are independent work items, so with
+    ``torch.distributed`` initialised they are partitioned over the ranks (``parallel.sharded_map``: no collective on the data
+    path, one all_gather of the core logits at the end) -- the tile-sharded mode of BASELINE configs[4].  Windows of equal
+    shape are stacked into batches of up to ``batch``.  Returns (H, W) logits on every rank."""
+    from .parallel import sharded_map
+    C_, H, W = x.shape
+    rects = scene_tiles(H, W, tile, halo)
+
+    def run(my):
+        cores = torch.zeros((my.shape[0], tile, tile), dtype=torch.float32, device=x.device)
+        by_shape = {}
+        for i, r in enumerate(my.tolist()):
+            by_shape.setdefault((r[5] - r[4], r[7] - r[6]), []).append((i, r))
+        for items in by_shape.values():
+            for k in range(0, len(items), batch):
+                chunk = items[k:k + batch]
+                xb = torch.stack([x[:, r[4]:r[5], r[6]:r[7]] for _, r in chunk]).contiguous()
+                lg = model(xb)
+                for j, (i, r) in enumerate(chunk):
+                    cores[i, :r[1] - r[0], :r[3] - r[2]] = lg[j, 0, r[0] - r[4]:r[1] - r[4], r[2] - r[6]:r[3] - r[6]]
+        return cores
+
+    cores = sharded_map(run, rects, group=group)
+    return stitch(cores, rects, H, W)
+
+
+def _merge_column_shards(t, fill, group=None):
+    """every rank filtered a disjoint set of column blocks and left ``fill`` elsewhere: merged = max over ranks (mf >= 0 and
+    albedo > 0 are above the fill value -9999)"""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t
+
+
 @torch.no_grad()
 def emit_scene_predict(model, raw, wavelengths, template, fill_value=-9999.0, column_step=2, num_iter=30,
-                       covariance_lerp_alpha=1e-4, column_range=None):
+                       covariance_lerp_alpha=1e-4, column_range=None, tile=None, halo=RECEPTIVE_HALO, ratio_bands=None,
+                       distributed=None, group=None):
     """``raw``: (rows, cols, S) float32 EMIT L1B radiance (device or host), ``wavelengths``: (S,) nm, ``template``: unit CH4
     absorption for the bands inside [2122, 2488] nm (``mag1c.generate_template_from_bands``; (K,) or (K, 2)).
     Returns a dict of device tensors: ``mf`` (rows, cols) ppm*m, ``albedo``, ``input`` (4, H', W') in the AVIRIS value range,
     ``prediction`` (H', W') plume probability and ``pred_binary`` (int64) -- H', W' = rows, cols cropped to multiples of 32
-    (emit_dataset.py:80-93)."""
+    (emit_dataset.py:80-93).
+
+    ``tile``: None = one whole-scene forward (the reference's only mode); an int = sliding-window inference on ``tile`` x
+    ``tile`` cores with ``halo`` (:func:`tiled_logits`).  ``ratio_bands=(2350, 2310)`` additionally returns ``ratio``, the
+    on-the-fly two-band ratio of feature_extration.py:42-56 on the nearest bands (absorbing, reference).
+    With ``torch.distributed`` initialised (``distributed=None`` -> automatic) the column blocks of the matched filter and the
+    inference tiles are partitioned over the ranks; the per-rank mf / albedo columns are merged (one all_reduce) before the
+    network input is built, so every rank returns the full-scene result.  ``column_range=(c0, c1)`` (explicit manual shard,
+    c0 / c1 on column_step boundaries) returns ONLY ``mf`` and ``albedo`` of that shard: a network input built from a partial
+    mf would be wrong for the whole scene."""
+    import torch.distributed as dist
     raw = torch.as_tensor(raw)
     dev = raw.device if raw.is_cuda else model.device
     raw = raw.to(dev).float()
@@ -45,14 +127,37 @@ def emit_scene_predict(model, raw, wavelengths, template, fill_value=-9999.0, co
     if t.size != keep.size:
         raise ValueError(f"template has {t.size} bands, the cube has {keep.size} inside {EMIT_MAG1C_RANGE_NM} nm")
     sub = raw[..., int(keep[0]):int(keep[-1]) + 1].contiguous()
-    mf, alb = mag1c.mag1c_columns(sub, t, fill_value, column_step=column_step, num_iter=num_iter,
-                                  covariance_lerp_alpha=covariance_lerp_alpha, column_range=column_range)
+    if distributed is None:
+        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    cols = raw.shape[1]
+    step = int(column_step or cols)
+    if column_range is not None:
+        mf, alb = mag1c.mag1c_columns(sub, t, fill_value, column_step=column_step, num_iter=num_iter,
+                                      covariance_lerp_alpha=covariance_lerp_alpha, column_range=column_range)
+        return {"mf": mf, "albedo": alb}
+    if distributed:
+        from .parallel import shard_range
+        nblk = -(-cols // step)
+        lo, hi = shard_range(nblk, dist.get_rank(group), dist.get_world_size(group))
+        mf, alb = mag1c.mag1c_columns(sub, t, fill_value, column_step=column_step, num_iter=num_iter,
+                                      covariance_lerp_alpha=covariance_lerp_alpha, column_range=(lo * step, min(hi * step, cols)))
+        mf, alb = _merge_column_shards(mf, fill_value, group), _merge_column_shards(alb, fill_value, group)
+    else:
+        mf, alb = mag1c.mag1c_columns(sub, t, fill_value, column_step=column_step, num_iter=num_iter,
+                                      covariance_lerp_alpha=covariance_lerp_alpha)
     rgb = raw[..., nearest_bands(w)].permute(2, 0, 1).contiguous()
     x = emit_to_aviris_input(mf, rgb)
+    out = {"mf": mf, "albedo": alb, "input": x}
+    if ratio_bands is not None:
+        from .features import ratio_2c_match_c_from_sums_outlier
+        ia, ir = nearest_bands(w, ratio_bands)
+        out["ratio"] = ratio_2c_match_c_from_sums_outlier(raw[..., ia].contiguous(), raw[..., ir].contiguous())
     was = model.training
     model.eval()
     try:
-        masks = masks_from_logits(model(x[None]))
+        logits = model(x[None]) if tile is None else tiled_logits(model, x, tile, halo, group=group if distributed else None)[None, None]
+        masks = masks_from_logits(logits.contiguous())
     finally:
         model.train(was)
-    return {"mf": mf, "albedo": alb, "input": x, "prediction": masks["prediction"][0, 0], "pred_binary": masks["pred_binary"][0, 0]}
+    out["prediction"], out["pred_binary"] = masks["prediction"][0, 0], masks["pred_binary"][0, 0]
+    return out

@@ -115,3 +115,41 @@ def test_bench_self_launches_n_ranks(hip):
         p = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=120)
         assert p.returncode != 0 and "needs 2 visible GPUs" in (p.stderr + p.stdout)
         assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+_SCENE_WORLD2 = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["SC_ROOT"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+from starcop_amd import model_module as mm, pipeline
+rng = np.random.default_rng(1)
+rows, cols = 200, 170
+wl = np.linspace(381.0, 2493.0, 285)
+keep = np.nonzero((wl >= 2122.0) & (wl <= 2488.0))[0]
+templ = -np.abs(rng.standard_normal(keep.size)) * 0.3 - 0.05
+raw = (rng.uniform(1, 6, size=285) * (1 + 0.05 * rng.standard_normal((rows, cols, 285)))).astype(np.float32)
+torch.manual_seed(0)
+model = mm.ModelModule(mm.default_settings(pos_weight=1)).to("cuda:0").eval()
+single = pipeline.emit_scene_predict(model, raw, wl, templ, column_step=2, tile=64, halo=320, distributed=False)
+both = pipeline.emit_scene_predict(model, raw, wl, templ, column_step=2, tile=64, halo=320)          # shards columns and tiles
+assert torch.equal(single["mf"], both["mf"]) and torch.equal(single["albedo"], both["albedo"])
+assert torch.equal(single["prediction"], both["prediction"]) and torch.equal(single["pred_binary"], both["pred_binary"])
+dist.barrier()
+if dist.get_rank() == 0:
+    print("SCENE_WORLD2_OK")
+dist.destroy_process_group()
+"""
+
+
+def test_scene_pipeline_two_ranks(hip, tmp_path):
+    """configs[4] tile-sharded mode with two ranks (gloo, one GPU): the column blocks of the matched filter and the inference
+    tiles are partitioned over the ranks, merged by one all_reduce / all_gather, and every rank ends with exactly the
+    single-process result"""
+    script = tmp_path / "scene2.py"
+    script.write_text(_SCENE_WORLD2)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(SC_ROOT=ROOT)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29553", str(script)], env=env, capture_output=True, text=True, cwd=ROOT, timeout=400)
+    assert p.returncode == 0 and "SCENE_WORLD2_OK" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])

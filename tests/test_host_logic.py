@@ -121,3 +121,25 @@ def test_shard_range_is_a_partition():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+
+
+def test_scene_tiles_partition_and_stitch():
+    """sliding-window tiler of BASELINE configs[4]: the cores partition the scene, the windows are the cores grown by the halo and
+    clipped to the scene, everything stays on the 32-px grid of the encoder stride; stitch() inverts the cut"""
+    from starcop_amd.pipeline import scene_tiles, stitch
+    for H, W, tile, halo in ((1280, 1216, 512, 320), (512, 512, 512, 64), (96, 160, 64, 32), (1024, 1024, 256, 0)):
+        r = scene_tiles(H, W, tile, halo)
+        cover = torch.zeros(H, W, dtype=torch.int32)
+        for y0, y1, x0, x1, wy0, wy1, wx0, wx1 in r.tolist():
+            cover[y0:y1, x0:x1] += 1
+            assert wy0 == max(0, y0 - halo) and wy1 == min(H, y1 + halo) and wx0 == max(0, x0 - halo) and wx1 == min(W, x1 + halo)
+            assert all(v % 32 == 0 for v in (y0, y1, x0, x1, wy0, wy1, wx0, wx1))
+            assert 0 < y1 - y0 <= tile and 0 < x1 - x0 <= tile
+        assert int(cover.min()) == int(cover.max()) == 1
+        scene = torch.arange(H * W, dtype=torch.float32).reshape(H, W)
+        cores = torch.zeros(r.shape[0], tile, tile)
+        for i, (y0, y1, x0, x1, *_) in enumerate(r.tolist()):
+            cores[i, :y1 - y0, :x1 - x0] = scene[y0:y1, x0:x1]
+        assert torch.equal(stitch(cores, r, H, W), scene)
+    with pytest.raises(ValueError):
+        scene_tiles(1000, 1024, 512, 64)

@@ -8,10 +8,10 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/p_eager /tmp/p_serial /tmp/p_fetch /tmp/p_write
-rocprofv3 --kernel-trace -d /tmp/p_eager -o run -- python $ROOT/bench.py --steps 16 --warmup 4 --no-cpu-baseline > $OUT/bench_eager.log 2>&1
-rocprofv3 --kernel-trace -d /tmp/p_serial -o run -- python $ROOT/bench.py --steps 16 --warmup 4 --no-cpu-baseline --overlap 0 > $OUT/bench_serial.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_fetch -o run -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --graph 0 > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_write -o run -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --graph 0 > $OUT/pmc_write.log 2>&1
+rocprofv3 --kernel-trace -d /tmp/p_eager -o run -- python $ROOT/bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-extras > $OUT/bench_eager.log 2>&1
+rocprofv3 --kernel-trace -d /tmp/p_serial -o run -- python $ROOT/bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-extras --overlap 0 > $OUT/bench_serial.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_fetch -o run -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --graph 0 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_write -o run -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --graph 0 > $OUT/pmc_write.log 2>&1
 cd $ROOT
 python tools/prof_summary.py $(find /tmp/p_eager -name "*.db" | head -1) > $OUT/kernel_trace_stats_bench_b16.txt
 python tools/prof_summary.py $(find /tmp/p_serial -name "*.db" | head -1) > $OUT/kernel_trace_stats_bench_b16_serial.txt
