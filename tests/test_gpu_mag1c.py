@@ -169,7 +169,7 @@ def test_column_layout_equals_sorted_layout(hip):
         assert bool((a_mf[:, 11] == hip_mag1c.NODATA).all()) and bool((a_mf[:, 15] == hip_mag1c.NODATA).all())
         assert bool((a_mf[:, 0] != hip_mag1c.NODATA).all()) if m is None else True
     # and against the oracle
-    want_mf, _ = mag1c_ref.func_by_groups(lambda xg: mag1c_ref.acrwl1mf(xg, t, num_iter=30, alpha=0.0), cube, groups)
+    want_mf, _ = mag1c_ref.func_by_groups(lambda xg: mag1c_ref.acrwl1mf_group(xg, t, num_iter=30, alpha=0.0), cube, groups)
     got = a_mf if m is None else hip_mag1c.acrwl1mf_by_groups(x, t, groups)[0]
     got = got.cpu().numpy()
     assert np.array_equal(got == hip_mag1c.NODATA, want_mf == hip_mag1c.NODATA)
