@@ -384,6 +384,16 @@ int sc_gather_augment(const float* tiles, int M, int C, int Hs, int Ws, const in
                       const int32_t* col_off, const float* cos_t, const float* sin_t, const int32_t* flags, int B,
                       int h, int w, int mode, float* out, sc_stream stream);
 
+/* ------------------------------------------------------------------------- */
+/* HOST functions (no device involved): decoders of the on-disk sample format -- one tiled GeoTIFF per product per sample,
+ * read by rasterio in the reference (starcop/data/dataset.py:66-76, written by save_cog at sampling_dataset.py:332-355).
+ *   sc_tiff_lzw_decode : TIFF 6.0 LZW (GDAL's default COG compression); *written = bytes produced (<= n_out)
+ *   sc_tiff_unpredict  : undo TIFF predictor 2 (integer samples) or 3 (floating point) of one decoded block of
+ *                        rows x cols x spp samples of bps bytes; `out` receives little-endian samples               */
+int sc_tiff_lzw_decode(const uint8_t* in_host, size_t n_in, uint8_t* out_host, size_t n_out, size_t* written_host);
+int sc_tiff_unpredict(const uint8_t* in_host, int predictor, int rows, int cols, int spp, int bps, int big_endian,
+                      uint8_t* out_host);
+
 #ifdef __cplusplus
 }
 #endif

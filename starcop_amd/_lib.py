@@ -124,6 +124,8 @@ SIGNATURES = {
     "sc_binary_opening": (_i, [_vp, _f, _i, _vp, _vp, _i, _i, _i, _vp]),
     "sc_threshold_confusion": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "sc_gather_augment": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "sc_tiff_lzw_decode": (_i, [_vp, _sz, _vp, _sz, C.POINTER(C.c_size_t)]),
+    "sc_tiff_unpredict": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp]),
 }
 PACK_THIN16 = 5        # sc_pack_desc.bx3 code of the register layout of sc_conv3x3_thin16
 TERMS_F16X2 = 4        # `terms` code of the two-fp16-term kernels (include/starcop_hip.h SC_TERMS_F16X2)
@@ -183,6 +185,27 @@ def require_device(t=None):
     if dev not in _device_ok:
         check(load().sc_device_check())
         _device_ok[dev] = True
+
+
+def tiff_lzw_decode(buf: bytes, n_out: int) -> bytes:
+    """host: TIFF LZW stream -> at most n_out bytes (sc_tiff_lzw_decode)"""
+    out = C.create_string_buffer(n_out)
+    written = C.c_size_t(0)
+    src = (C.c_char * len(buf)).from_buffer_copy(buf)
+    if load().sc_tiff_lzw_decode(C.cast(src, C.c_void_p), len(buf), C.cast(out, C.c_void_p), n_out, C.byref(written)) != 0:
+        raise ValueError("corrupt TIFF LZW stream")
+    return out.raw[:written.value]
+
+
+def tiff_unpredict(a, predictor, rows, cols, spp, bps, big_endian):
+    """host: undo TIFF predictor 2 / 3 on a decoded block (uint8 numpy array) -> uint8 array of little-endian samples"""
+    import numpy as np
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    out = np.empty_like(a)
+    if load().sc_tiff_unpredict(a.ctypes.data_as(C.c_void_p), predictor, rows, cols, spp, bps, int(bool(big_endian)),
+                                out.ctypes.data_as(C.c_void_p)) != 0:
+        raise ValueError(f"TIFF predictor {predictor} with {bps}-byte samples is not supported")
+    return out
 
 
 def stream():

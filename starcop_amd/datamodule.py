@@ -16,7 +16,8 @@ What is different underneath: the reference decodes one GeoTIFF window per produ
 augments on the CPU; 1 GPU consumes ~940 tiles/s = 23 GB/s of decoded fp32 samples, which no host pipeline sustains.  The
 whole STARCOP training set (~3 400 tiles x 6 products x 1 MB = 20 GB) fits 14 times into one MI355X's 288 GB, so the tiles
 are uploaded once and every batch is cut, rotated and flipped by ONE gather kernel per tensor (``sc_gather_augment``)
-straight out of HBM.  Reading the GeoTIFF/COG files themselves stays outside this build (OUT).
+straight out of HBM.  The sample folders on disk (one tiled GeoTIFF per product) are decoded by ``io_formats.load_tileset``
+(own TIFF reader, thread pool, pinned staging buffers, asynchronous upload) into the ``ResidentTileSet`` below.
 kornia is absent from the build image: the rotation follows kornia 0.6.7's ``rotate`` -> ``warp_affine`` ->
 ``F.grid_sample(align_corners=True, padding_mode="zeros")`` chain and is tested against ``F.grid_sample`` itself.
 """

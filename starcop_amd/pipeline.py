@@ -161,3 +161,36 @@ def emit_scene_predict(model, raw, wavelengths, template, fill_value=-9999.0, co
         model.train(was)
     out["prediction"], out["pred_binary"] = masks["prediction"][0, 0], masks["pred_binary"][0, 0]
     return out
+
+
+@torch.no_grad()
+def aviris_scene_mag1c(aviris_img_folder, mf_filename, albedo_filename=None, use_wavelength_range=mag1c.DEFAULT_WAVELENGTH_RANGE,
+                       device="cuda", extra_tags=None):
+    """``run_mag1c`` of the reference (starcop/process_aviris.py:146-232) on the MI355X: opens ``<name>_img`` (radiance, ENVI)
+    and ``<name>_glt`` (sample / line look-up, ENVI) of an AVIRIS-NG flight line as BIP memmaps, keeps the bands that are not
+    affected by water vapour inside ``use_wavelength_range`` (they must form a slice), builds the CH4 target from the header's
+    band centres and widths, runs acrwl1mf(num_iter=30) per detector sample (groups = |GLT sample index|, pixels with index 0
+    are not data) and writes the result as tiled GeoTIFFs (BLOCKSIZE 128).  Returns (mf, albedo) device tensors.
+    The radiance slice is uploaded once from the memmap through pinned memory; everything after that stays on the device."""
+    import os
+    from . import io_formats as io
+    folder = aviris_img_folder.rstrip("/")
+    name = os.path.basename(folder)
+    rdn, meta = io.open_envi(os.path.join(folder, f"{name}_img"))
+    glt, _ = io.open_envi(os.path.join(folder, f"{name}_glt"))
+    wl = meta["wavelengths"]
+    keep = mag1c.get_mask_bad_bands(wl) & (wl >= use_wavelength_range[0]) & (wl <= use_wavelength_range[1])
+    idx = np.flatnonzero(keep)
+    assert idx[-1] - idx[0] + 1 == idx.shape[0], "Not all indexes included. Can't be a slice!"
+    target = mag1c.generate_template_from_bands(centers=wl, fwhm=meta["fwhm"])
+    spec = target[keep, 1]
+    host = torch.from_numpy(np.ascontiguousarray(rdn[..., idx[0]:idx[-1] + 1], dtype=np.float32))
+    x = (host.pin_memory() if torch.cuda.is_available() else host).to(device, non_blocking=True)
+    groups = np.abs(np.asarray(glt[..., 0])).astype(np.int64)
+    mf, alb = mag1c.func_by_groups(mag1c.Filter(spec, num_iter=30), x, groups, mask=groups != 0)
+    tags = dict(extra_tags or {})
+    tags.setdefault(42113, (2, (str(mag1c.NODATA),)))                     # GDAL_NODATA, as fill_value_default=NODATA
+    io.write_tiff(mf_filename, mf.cpu().numpy(), blocksize=128, extra_tags=tags)
+    if albedo_filename is not None:
+        io.write_tiff(albedo_filename, alb.cpu().numpy(), blocksize=128, extra_tags=tags)
+    return mf, alb

@@ -1,6 +1,7 @@
 """HBM-resident training data path: crop + rotation + flips gather kernel against the oracle (exact for
 copies and flips, 1e-5 for the bilinear rotation), the tiled sample table, the weighted sampler and a short training run."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -141,3 +142,40 @@ def test_end_to_end_train_then_validate(hip):
     assert hist[-1] < hist[0] and all(np.isfinite(hist))
     assert 0.0 <= met["iou"] <= 1.0 and int(met["confusion_matrix"].sum()) == 12 * 256 * 256
     assert met_b["f1score"] > 0.8                       # the label is the planted plume above ~450: mag1c > 500 nearly recovers it
+
+
+def test_disk_samples_to_resident_tiles_to_train_step(hip, tmp_path):
+    """f2 end to end: sample folders on disk in the reference's layout (one tiled GeoTIFF per product, dataset.py:59-102) ->
+    io_formats.load_tileset (pinned staging, async upload) -> ResidentTileSet -> TrainLoader crops -> fused train steps; and the
+    un-augmented batch equals what the reference's Dataset.__getitem__ assembles from the same files (read back with read_tiff)."""
+    from starcop_amd import io_formats as io, model_module as mm
+    rng = np.random.default_rng(0)
+    prods = ["mag1c", "TOA_AVIRIS_640nm", "TOA_AVIRIS_550nm", "TOA_AVIRIS_460nm"]
+    folders = []
+    for i in range(3):
+        d = tmp_path / f"ang2019_{i:03d}"
+        d.mkdir()
+        mag = np.clip(rng.normal(0, 400, (512, 512)), 0, None).astype(np.float32)
+        mag[100:160, 200 + 20 * i:260 + 20 * i] += 1500
+        io.write_tiff(str(d / "mag1c.tif"), mag)
+        for p in prods[1:]:
+            io.write_tiff(str(d / f"{p}.tif"), rng.uniform(5, 110, (512, 512)).astype(np.float32), compress=None)
+        io.write_tiff(str(d / "labelbinary.tif"), (mag > 900).astype(np.uint8))
+        io.write_tiff(str(d / "weight_mag1c.tif"), np.clip(mag / 400, 0.1, 1).astype(np.float32))
+        folders.append(str(d))
+    ts = io.load_tileset(folders, prods, ("labelbinary",), "weight_mag1c", device=DEV)
+    assert len(ts) == 3 and ts.inputs.shape == (3, 4, 512, 512) and ts.ids[1] == "ang2019_001"
+    for i, f in enumerate(folders):
+        assert np.array_equal(ts.inputs[i].cpu().numpy(), io.load_sample(f, prods))
+        assert np.array_equal(ts.outputs[i, 0].cpu().numpy(), io.read_tiff(os.path.join(f, "labelbinary.tif"))[0].astype(np.float32))
+    loader = dm.TrainLoader(ts, batch_size=8, training_size=(128, 128), augment=False, weight_sampling=False, seed=1)
+    batch = next(iter(loader))
+    row = loader.table.loc[batch["id"][0]]
+    win = (int(row.window_row_off), int(row.window_col_off), 128, 128)
+    assert np.array_equal(batch["input"][0].cpu().numpy(), io.load_sample(folders[int(row.tile)], prods, win))
+    torch.manual_seed(0)
+    model = mm.ModelModule(mm.default_settings(pos_weight=1)).to(DEV).train()
+    opt = model.configure_optimizers()["optimizer"]
+    aug = dm.TrainLoader(ts, batch_size=8, training_size=(128, 128), seed=2)
+    losses = [float(model.fused_train_step(b, opt).item()) / (8 * 128 * 128) for b, _ in zip(aug, range(4))]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] * 1.5

@@ -88,3 +88,48 @@ def test_emit_scene_predict_tiled_and_ratio(hip):
     assert set(part) == {"mf", "albedo"} and torch.equal(part["mf"][:, :80], a["mf"][:, :80])
     with pytest.raises(ValueError):
         pipeline.emit_scene_predict(model, raw, wl, templ, column_step=2, column_range=(1, 80))
+
+
+def test_aviris_scene_mag1c_from_envi_files(hip, tmp_path):
+    """process_aviris.run_mag1c (:146-232) end to end from ENVI files on disk: BIP radiance + GLT memmaps -> band selection ->
+    CH4 target from the shipped LUT -> acrwl1mf per detector sample (|GLT sample index|, 0 = no data) -> tiled GeoTIFF output;
+    against the oracle's func_by_groups on the same arrays, and the written file read back"""
+    import os
+    from oracle import mag1c_ref
+    from starcop_amd import io_formats as io, mag1c
+    rng = np.random.default_rng(5)
+    nl, ns = 96, 40
+    wl = np.linspace(2000.0, 2500.0, 101)                     # 5 nm grid: 74 bands inside [2122, 2488] and outside the bad-band windows
+    fwhm = np.full_like(wl, 5.6)
+    target = mag1c.generate_template_from_bands(wl, fwhm)[:, 1]
+    cube = (rng.uniform(1, 6, size=wl.size) * (1 + 0.05 * rng.standard_normal((nl, ns, wl.size)))).astype(np.float32)
+    k = np.zeros((nl, ns)); k[30:50, 10:20] = 2e-5
+    cube = (cube * (1 + k[..., None] * np.nan_to_num(target))).astype(np.float32)
+    glt = np.zeros((nl, ns, 2), dtype=np.int32)
+    glt[..., 0] = (np.arange(ns)[None, :] + (np.arange(nl)[:, None] // 8)) % 23 + 1      # orthorectified: detector sample varies along a row AND down
+    glt[:5, :, 0] = 0                                                                    # no-data border
+    glt[..., 0] *= np.where(rng.random((nl, ns)) < 0.5, 1, -1)                           # interpolated pixels carry a negative index
+    glt[..., 1] = np.arange(nl)[:, None]
+    folder = tmp_path / "ang20190101t000000_rdn"
+    folder.mkdir()
+    name = folder.name
+    for suffix, arr, dt, extra in (("img", cube, 4, f"wavelength = {{ {', '.join(f'{v:.4f}' for v in wl)} }}\nfwhm = {{ {', '.join(f'{v:.2f}' for v in fwhm)} }}\n"),
+                                   ("glt", glt, 3, "")):
+        arr.tofile(str(folder / f"{name}_{suffix}"))
+        (folder / f"{name}_{suffix}.hdr").write_text(f"ENVI\nsamples = {ns}\nlines = {nl}\nbands = {arr.shape[2]}\nheader offset = 0\n"
+                                                     f"data type = {dt}\ninterleave = bip\nbyte order = 0\n{extra}")
+    out_mf, out_alb = str(tmp_path / "mag1c.tif"), str(tmp_path / "albedo.tif")
+    mf, alb = pipeline.aviris_scene_mag1c(str(folder), out_mf, out_alb)
+    keep = mag1c.get_mask_bad_bands(wl) & (wl >= 2122) & (wl <= 2488)
+    groups = np.abs(glt[..., 0])
+    want_mf, want_alb = mag1c_ref.func_by_groups(lambda xg: mag1c_ref.acrwl1mf_group(xg, target[keep], num_iter=30, alpha=0.0),
+                                                 cube[..., keep], groups, mask=groups != 0)
+    got = mf.cpu().numpy()
+    assert np.array_equal(got == mag1c.NODATA, want_mf == mag1c.NODATA) and (got[:5] == mag1c.NODATA).all()
+    ok = want_mf != mag1c.NODATA
+    d = np.abs(got[ok] - want_mf[ok]) / max(float(np.abs(want_mf[ok]).max()), 1.0)
+    assert np.mean(d > 1e-3) < 2e-3
+    back = io.read_tiff(out_mf)
+    info = io.tiff_info(out_mf)
+    assert np.array_equal(back[0], got) and info.block == (128, 128) and info.tags[42113][1][0] == str(mag1c.NODATA)
+    assert np.array_equal(io.read_tiff(out_alb)[0], alb.cpu().numpy())
