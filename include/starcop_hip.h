@@ -238,6 +238,12 @@ int sc_add_srcs_absmax(const sc_src* a, const sc_src* b, float* out, int N, int 
 /* out[n,c,y,x] (+)= sum of the 2x2 block of in (backward of nearest x2 upsample) */
 int sc_downsum2x2(const float* in, float* out, int accum, int N, int C, int Hout, int Wout,
                   sc_stream stream);
+/* the two resampling ops of the reference's in-repo UNet (starcop/models/architectures/unet.py:15,35-43), each reading its input
+ * through the source's prologue (bias + ReLU of the producing convolution):
+ *   sc_maxpool2x2          : nn.MaxPool2d(2)            in [N,C,2*Hout,2*Wout] -> out [N,C,Hout,Wout]
+ *   sc_upsample_bilinear2x : F.interpolate(scale_factor=2, mode='bilinear', align_corners=True)   in [N,C,Hin,Win] -> out [N,C,2Hin,2Win] */
+int sc_maxpool2x2(const sc_src* in, float* out, int N, int C, int Hout, int Wout, sc_stream stream);
+int sc_upsample_bilinear2x(const sc_src* in, float* out, int N, int C, int Hin, int Win, sc_stream stream);
 int sc_fill_f64(double* p, double v, size_t n, sc_stream stream);
 int sc_apply_src(const sc_src* a, float* out, int N, int C, int HW, sc_stream stream);
 

@@ -210,3 +210,19 @@ def conv_stack_ref(params, x, relu_last=True):
         if i + 1 < len(params) or relu_last:
             x = F.relu(x)
     return x
+
+
+def simple_unet_ref(sd, x):
+    """The reference's in-repo ``UNet`` (/root/reference/starcop/models/architectures/unet.py:7-51) as a function of its
+    ``state_dict``: four double_conv stages with MaxPool2d(2) in between, three [bilinear x2 (align_corners=True) -> cat(skip) ->
+    double_conv] stages, 1x1 head -- stock CPU ops.  Pinned by the reference's own forward of the full network (golden G9
+    ``unet_full.*``, tests/test_oracle.py::test_g9_full_unet)."""
+    def dc(name, t):
+        return conv_stack_ref([(sd[f"{name}.0.weight"], sd[f"{name}.0.bias"]), (sd[f"{name}.2.weight"], sd[f"{name}.2.bias"])], t)
+    c1 = dc("dconv_down1", x)
+    c2 = dc("dconv_down2", F.max_pool2d(c1, 2))
+    c3 = dc("dconv_down3", F.max_pool2d(c2, 2))
+    t = dc("dconv_down4", F.max_pool2d(c3, 2))
+    for name, skip in (("dconv_up3", c3), ("dconv_up2", c2), ("dconv_up1", c1)):
+        t = dc(name, torch.cat([F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=True), skip], dim=1))
+    return F.conv2d(t, sd["conv_last.weight"], sd["conv_last.bias"])

@@ -259,6 +259,43 @@ __global__ __launch_bounds__(256) void k_add_srcs(const SrcD a, const SrcD b, in
   if (absmax) block_absmax_to(mx, 1.f, absmax, s_m);
 }
 
+// nn.MaxPool2d(2) of the in-repo UNet (architectures/unet.py:15): out[n,c,y,x] = max of the 2x2 block of v(in) (v = the source's prologue)
+__global__ __launch_bounds__(256) void k_maxpool2x2(const SrcD a, float* __restrict__ out, int C, int Hout, int Wout) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f); float a4 = 0.f;
+  if (a.mode != SC_SRC_RAW) { a0 = *reinterpret_cast<const float4*>(a.cst + (size_t)c * SC_CST); a4 = a.cst[(size_t)c * SC_CST + 4]; }
+  const size_t ibase = ((size_t)n * C + c) * (size_t)(4 * Hout * Wout), obase = ((size_t)n * C + c) * (size_t)(Hout * Wout);
+  const int Win = 2 * Wout;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < Hout * Wout; i += gridDim.x * 256) {
+    const int y = i / Wout, x = i - y * Wout;
+    const size_t p = ibase + (size_t)(2 * y) * Win + 2 * x;
+    const float v = fmaxf(fmaxf(ld_src(a, p, a0, a4), ld_src(a, p + 1, a0, a4)), fmaxf(ld_src(a, p + Win, a0, a4), ld_src(a, p + Win + 1, a0, a4)));
+    out[obase + i] = v;
+  }
+}
+
+// F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) (architectures/unet.py:35,39,43): output pixel (Y, X) of a
+// (2H, 2W) grid samples the input at Y*(H-1)/(2H-1), X*(W-1)/(2W-1); weights and the two-step lerp as torch's CPU kernel
+// (area_pixel_compute_source_index + compute_scales_value: scale = (in-1)/(out-1) in float)
+__global__ __launch_bounds__(256) void k_upsample_bilinear2x(const SrcD a, float* __restrict__ out, int C, int Hin, int Win) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f); float a4 = 0.f;
+  if (a.mode != SC_SRC_RAW) { a0 = *reinterpret_cast<const float4*>(a.cst + (size_t)c * SC_CST); a4 = a.cst[(size_t)c * SC_CST + 4]; }
+  const int Ho = 2 * Hin, Wo = 2 * Win;
+  const float sh = Ho > 1 ? (float)(Hin - 1) / (float)(Ho - 1) : 0.f, sw = Wo > 1 ? (float)(Win - 1) / (float)(Wo - 1) : 0.f;
+  const size_t ibase = ((size_t)n * C + c) * (size_t)(Hin * Win), obase = ((size_t)n * C + c) * (size_t)(Ho * Wo);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < Ho * Wo; i += gridDim.x * 256) {
+    const int Y = i / Wo, X = i - Y * Wo;
+    const float fy = sh * (float)Y, fx = sw * (float)X;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hin - 1 ? 1 : 0), x1 = x0 + (x0 < Win - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float v00 = ld_src(a, ibase + (size_t)y0 * Win + x0, a0, a4), v01 = ld_src(a, ibase + (size_t)y0 * Win + x1, a0, a4);
+    const float v10 = ld_src(a, ibase + (size_t)y1 * Win + x0, a0, a4), v11 = ld_src(a, ibase + (size_t)y1 * Win + x1, a0, a4);
+    out[obase + i] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_downsum2x2(const float* __restrict__ in, float* __restrict__ out, int accum,
                                                     int Hout, int Wout, size_t total) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -474,6 +511,24 @@ extern "C" int sc_add_srcs(const sc_src* a, const sc_src* b, float* out, int N, 
 
 extern "C" int sc_apply_src(const sc_src* a, float* out, int N, int C, int HW, sc_stream stream) {
   return sc_add_srcs(a, nullptr, out, N, C, HW, stream);
+}
+
+extern "C" int sc_maxpool2x2(const sc_src* in, float* out, int N, int C, int Hout, int Wout, sc_stream stream) {
+  SC_REQUIRE(in && in->x && out && N > 0 && C > 0 && Hout > 0 && Wout > 0 && in->up == 0, "sc_maxpool2x2: bad argument");
+  SC_REQUIRE(in->mode != SC_SRC_BNBWD, "sc_maxpool2x2: forward sources only");
+  dim3 grid((Hout * Wout + 1023) / 1024, C, N);
+  hipLaunchKernelGGL(k_maxpool2x2, grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), out, C, Hout, Wout);
+  SC_LAUNCH_OK("sc_maxpool2x2");
+  return SC_OK;
+}
+
+extern "C" int sc_upsample_bilinear2x(const sc_src* in, float* out, int N, int C, int Hin, int Win, sc_stream stream) {
+  SC_REQUIRE(in && in->x && out && N > 0 && C > 0 && Hin > 0 && Win > 0 && in->up == 0, "sc_upsample_bilinear2x: bad argument");
+  SC_REQUIRE(in->mode != SC_SRC_BNBWD, "sc_upsample_bilinear2x: forward sources only");
+  dim3 grid((4 * Hin * Win + 1023) / 1024, C, N);
+  hipLaunchKernelGGL(k_upsample_bilinear2x, grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), out, C, Hin, Win);
+  SC_LAUNCH_OK("sc_upsample_bilinear2x");
+  return SC_OK;
 }
 
 extern "C" int sc_downsum2x2(const float* in, float* out, int accum, int N, int C, int Hout, int Wout, sc_stream stream) {

@@ -63,3 +63,45 @@ def golden_err(z, name, key, got):
         errs.append(rel(got.sum(axis=1), z[pre + "cisum"]))
     assert errs, f"no golden entry for {pre}*"
     return max(errs)
+
+
+def emit_cube(seed, rows, cols, centers):
+    """the cube of golden G10 (tests/golden/make_golden.py::g10_emit_cube), regenerated from the same PCG64 uniform streams"""
+    rng = np.random.default_rng(seed)
+    S = centers.size
+    base = 1.0 + 5.0 * rng.random(S)
+    raw = (base * (1.0 + 0.1 * (rng.random((rows, cols, S)) - 0.5))).astype(np.float32)
+    dip = np.exp(-0.5 * ((centers - 2300.0) / 60.0) ** 2)
+    raw[20:40, 3:6, :] *= (1.0 - 0.03 * dip).astype(np.float32)
+    raw[:7, :3, :] = -9999.0
+    raw[50, 7, 250] = -9999.0
+    return raw
+
+
+FULL_SEED = 4242
+FULL_KEYS = [f"{blk}.{i}.{wb}" for blk in ("dconv_down1", "dconv_down2", "dconv_down3", "dconv_down4", "dconv_up3", "dconv_up2", "dconv_up1")
+             for i in (0, 2) for wb in ("weight", "bias")] + ["conv_last.weight", "conv_last.bias"]
+FULL_CH = {"dconv_down1": (4, 64), "dconv_down2": (64, 128), "dconv_down3": (128, 256), "dconv_down4": (256, 512),
+           "dconv_up3": (768, 256), "dconv_up2": (384, 128), "dconv_up1": (192, 64)}
+
+
+def full_unet_state():
+    """state_dict of the reference's UNet(4, 1) as make_golden filled it: one PCG64 stream in state_dict order"""
+    rng = np.random.default_rng(FULL_SEED)
+    sd = {}
+    for k in FULL_KEYS:
+        blk, *rest = k.split(".")
+        if blk == "conv_last":
+            shape = (1, 64, 1, 1) if rest[0] == "weight" else (1,)
+        else:
+            ci, co = FULL_CH[blk]
+            cin = ci if rest[0] == "0" else co
+            shape = (co, cin, 3, 3) if rest[1] == "weight" else (co,)
+        bound = np.sqrt(6.0 / (shape[1] * shape[2] * shape[3])) if len(shape) == 4 else 0.1
+        sd[k] = torch.from_numpy(_fill(rng, shape, bound))
+    return sd
+
+
+def full_unet_input(tag):
+    shape = tuple(int(v) for v in load()[f"unet_full.{tag}.shape"])
+    return torch.from_numpy(_fill(np.random.default_rng(FULL_SEED + 1 + len(tag) + shape[0]), shape, 1.5))

@@ -278,6 +278,7 @@ def g9_crop(a):
 
 
 G9_RELU_MARGIN = 1e-5
+G9_FULL_SEED = 4242
 G9_SEED_TRIES = 4000
 
 
@@ -324,7 +325,64 @@ def g9_convblocks():
             for kk, vv in g9_crop(v).items():
                 out[f"{name}.{k}.{kk}"] = vv
         out[f"{name}.meta"] = np.array([seed] + list(xshape) + [c.out_channels for c in convs], dtype=np.int64)
+    # ---- the whole in-repo UNet(4, 1): 7.78 M parameters drawn from one PCG64 stream in state_dict order (weights U(+-sqrt(3/fan_in)),
+    # i.e. variance-preserving under ReLU would need 6/fan_in; 3/fan_in keeps activations O(1) through 15 layers; biases U(+-0.1))
+    torch.manual_seed(0)
+    full = ref_unet.UNet(4, 1).eval()
+    rng = np.random.default_rng(G9_FULL_SEED)
+    with torch.no_grad():
+        for k, v in full.state_dict().items():
+            if k.endswith("weight"):
+                fan_in = v.shape[1] * v.shape[2] * v.shape[3]
+                v.copy_(torch.from_numpy(g9_fill(rng, tuple(v.shape), np.sqrt(6.0 / fan_in))))
+            else:
+                v.copy_(torch.from_numpy(g9_fill(rng, tuple(v.shape), 0.1)))
+        for tag, shape in (("a", (1, 4, 64, 64)), ("b", (2, 4, 96, 64))):
+            x = torch.from_numpy(g9_fill(np.random.default_rng(G9_FULL_SEED + 1 + len(tag) + shape[0]), shape, 1.5))
+            out[f"unet_full.{tag}.y"] = full(x).numpy()
+            out[f"unet_full.{tag}.shape"] = np.array(shape, dtype=np.int64)
     np.savez_compressed(os.path.join(OUT, "g9_convblocks.npz"), **out)
+
+
+# ---- G10: the EMIT driver itself (starcop/models/mag1c_emit.py:16-90) on a duck-typed raster ---------------------------------
+def g10_emit_cube(seed, rows, cols, centers):
+    """(rows, cols, S) float32 radiance-like cube from PCG64 uniform streams (regenerated by tests/g9_util.py::emit_cube)"""
+    rng = np.random.default_rng(seed)
+    S = centers.size
+    base = 1.0 + 5.0 * rng.random(S)
+    raw = (base * (1.0 + 0.1 * (rng.random((rows, cols, S)) - 0.5))).astype(np.float32)
+    dip = np.exp(-0.5 * ((centers - 2300.0) / 60.0) ** 2)                # a plume-like absorption around 2300 nm
+    raw[20:40, 3:6, :] *= (1.0 - 0.03 * dip).astype(np.float32)
+    raw[:7, :3, :] = -9999.0                                             # fill wedge
+    raw[50, 7, 250] = -9999.0                                            # a single fill sample inside the mag1c band range
+    return raw
+
+
+def g10_emit_driver():
+    geo = _stub("georeader"); rd = _stub("georeader.readers"); em = _stub("georeader.readers.emit", EMITImage=object)
+    gt = _stub("georeader.geotensor", GeoTensor=object)
+    geo.readers, rd.emit, geo.geotensor = rd, em, gt
+    from starcop.models import mag1c_emit as ref_emit
+    g3 = np.load(os.path.join(OUT, "g3_templates.npz"))
+
+    class EI:                                      # what mag1c_emit touches of georeader's EMITImage
+        fill_value_default = -9999.0
+
+        def __init__(self, raw, wavelengths, fwhm):
+            self.raw, self.wavelengths, self.fwhm = raw, wavelengths, fwhm
+
+        def read_from_bands(self, sel):
+            return EI(self.raw[..., sel], self.wavelengths[sel], self.fwhm[sel])
+
+        def load_raw(self, transpose=False):
+            return self.raw
+    seed, rows, cols = 77, 96, 10
+    raw = g10_emit_cube(seed, rows, cols, g3["emit_centers"])
+    out = {"meta": np.array([seed, rows, cols], dtype=np.int64)}
+    for step in (2, 4, None):
+        mf, alb = ref_emit.mag1c_emit(EI(raw, g3["emit_centers"], g3["emit_fwhm"]), column_step=step, georreferenced=False, display_pbar=False)
+        out[f"mf_step{step}"], out[f"albedo_step{step}"] = mf, alb
+    np.savez_compressed(os.path.join(OUT, "g10_emit_driver.npz"), **out)
 
 
 if __name__ == "__main__":
@@ -337,6 +395,7 @@ if __name__ == "__main__":
     g8_ratio()
     g5_masks()
     g9_convblocks()
+    g10_emit_driver()
     print("golden vectors written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f))} bytes")

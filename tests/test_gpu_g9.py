@@ -126,3 +126,40 @@ def test_g9_blocks_hip(hip, name, terms):
     print(f"G9 {name} terms={terms}: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
     bad = {k: v for k, v in errs.items() if not v < TOL}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g9_full_unet_hip(hip, tag):
+    """the reference's whole in-repo UNet(4, 1) on the HIP kernels (starcop_amd/unet_simple.py: split-MFMA 3x3
+    convolutions, bias + ReLU prologues, sc_maxpool2x2, sc_upsample_bilinear2x, two-source concat convolutions, 1x1 head) against
+    the logits the REFERENCE computed for the same weights and input -- a 15-convolution-deep pin of the kernels"""
+    from starcop_amd.unet_simple import SimpleUNet
+    net = SimpleUNet(4, 1)
+    sd = g9_util.full_unet_state()
+    assert list(net.state_dict().keys()) == list(sd.keys())            # the reference module's key names and order
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    x = g9_util.full_unet_input(tag)
+    got = net(x.to(DEV))
+    want = torch.from_numpy(g9_util.load()[f"unet_full.{tag}.y"])
+    e = float((got.cpu() - want).abs().max() / want.abs().max())
+    print(f"in-repo UNet(4,1) {tuple(x.shape)}: logits rel err vs the reference's own forward {e:.2e}")
+    assert got.shape == want.shape and e < TOL
+
+
+def test_simple_unet_other_shapes_and_contract(hip):
+    from oracle.unet_ref import simple_unet_ref
+    from starcop_amd.unet_simple import SimpleUNet
+    net = SimpleUNet(4, 1)
+    net.load_state_dict(g9_util.full_unet_state())
+    net = net.to(DEV).eval()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 4, 128, 200, generator=g)
+    with torch.no_grad():
+        want = simple_unet_ref(g9_util.full_unet_state(), x)
+    got = net(x.to(DEV)).cpu()
+    assert float((got - want).abs().max() / want.abs().max()) < TOL
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 4, 60, 64, device=DEV))
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 3, 64, 64, device=DEV))

@@ -177,6 +177,24 @@ def test_column_layout_equals_sorted_layout(hip):
     assert np.mean(rel(got[ok], want_mf[ok]) > 1e-3) < 2e-3
 
 
+@pytest.mark.parametrize("step", [2, 4, None])
+def test_emit_driver_vs_reference_golden(hip, step):
+    """a14 pinned: the HIP EMIT driver (band selection, template from the shipped LUT, fill mask, column blocks, fp64 filter,
+    float32 outputs) against what the reference's own mag1c_emit() returned for the same cube (golden G10)"""
+    import g9_util
+    g3, g10 = np.load(os.path.join(G, "g3_templates.npz")), np.load(os.path.join(G, "g10_emit_driver.npz"))
+    seed, rows, cols = (int(v) for v in g10["meta"])
+    raw = g9_util.emit_cube(seed, rows, cols, g3["emit_centers"])
+    sel = (g3["emit_centers"] >= 2122) & (g3["emit_centers"] <= 2488)
+    templ = hip_mag1c.generate_template_from_bands(g3["emit_centers"][sel], g3["emit_fwhm"][sel])[:, 1]
+    mf, alb = hip_mag1c.mag1c_columns(torch.from_numpy(np.ascontiguousarray(raw[..., sel])).to(DEV), templ, -9999.0, column_step=step, num_iter=30)
+    mf, alb = mf.cpu().numpy(), alb.cpu().numpy()
+    want_mf, want_alb = g10[f"mf_step{step}"], g10[f"albedo_step{step}"]
+    assert mf.dtype == np.float32 and np.array_equal(mf == -9999.0, want_mf == -9999.0)
+    ok = want_mf != -9999.0
+    assert rel(mf[ok], want_mf[ok]).max() < 1e-5 and rel(alb[ok], want_alb[ok]).max() < 1e-6
+
+
 def test_cfg3_size_properties(hip):
     """BASELINE config 3 shape (512 column groups x 512 px x 125 bands, fp32): size-independent properties --
     pixels without plume stay near zero, planted enhancement is recovered in order of magnitude, groups are
