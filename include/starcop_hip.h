@@ -189,6 +189,14 @@ int sc_dwconv3x3_dgrad(const sc_src* dy, const float* w, float* dx, int accum,
                        int N, int C, int Hin, int Win, int stride, sc_stream stream);
 int sc_dwconv3x3_wgrad(const sc_src* dy, const sc_src* in, double* dw_acc /*[C][9] zeroed*/,
                        int N, int C, int Hin, int Win, int stride, sc_stream stream);
+/* the three of them in one pass: dx (overwritten), dw_acc (+=, fp64 atomics) and, if in_sums != NULL, the BatchNorm-backward
+ * partial sums of the INPUT tensor, in_sums[row][C][2] = {sum g_bn, sum g_bn * xhat}, g_bn = dx * act'(BN(y_in)), rows =
+ * sc_stat_rows(SC_STAT_DW, N, Hin, Win) -- what sc_bn_bwd_reduce(dx, y_in) would compute by streaming both tensors again
+ * (`in` must then be the SC_SRC_AFFINE source of that BatchNorm'd tensor with its cst_fwd constants).  In a MobileNetV2
+ * inverted-residual block both sides of the depthwise conv are the 6x-expanded tensors: this kernel reads (g, y) of the
+ * output once instead of twice and saves the (dx, y_in) pass of the expansion's BatchNorm backward. */
+int sc_dwconv3x3_bwd_fused(const sc_src* dy, const sc_src* in, const float* w, float* dx, double* dw_acc, double* in_sums,
+                           int N, int C, int Hin, int Win, int stride, sc_stream stream);
 int sc_cast_f64_f32(const double* in, float* out, size_t n, sc_stream stream);
 
 /* stem: conv 3x3 stride 2 pad 1, Cin<=8 -> 32, input read through its prologue

@@ -124,6 +124,7 @@ SIGNATURES = {
     "sc_binary_opening": (_i, [_vp, _f, _i, _vp, _vp, _i, _i, _i, _vp]),
     "sc_threshold_confusion": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "sc_gather_augment": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "sc_dwconv3x3_bwd_fused": (_i, [C.POINTER(sc_src), C.POINTER(sc_src), _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sc_maxpool2x2": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _i, _vp]),
     "sc_upsample_bilinear2x": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _i, _vp]),
     "sc_tiff_lzw_decode": (_i, [_vp, _sz, _vp, _sz, C.POINTER(C.c_size_t)]),

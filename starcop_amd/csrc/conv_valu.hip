@@ -259,6 +259,304 @@ __global__ __launch_bounds__(256) void k_dw_wgrad(const SrcD dy, const SrcD in, 
   if (threadIdx.x < 9) atomicAdd(&dw_acc[c * 9 + threadIdx.x], (double)prod[threadIdx.x]);
 }
 
+// Depthwise backward in ONE pass over its three big tensors: dx (backward-data), dW (backward-weight, fp64 atomics) and -- when the
+// input is a BatchNorm'd tensor -- the BatchNorm-backward partial sums of that INPUT (sum g_bn, sum g_bn * xhat over the tile,
+// g_bn = dx * act'(BN(y_in))), which sc_bn_bwd_reduce would otherwise re-stream dx and y_in for.  In an inverted-residual block
+// the tensors on either side of the depthwise conv are the 6x-expanded ones, i.e. the HBM traffic of the block's backward: the
+// separate kernels read (g_d, y_d) twice and (dx, y_in) once more than this one.
+// Tile = TW x TH INPUT pixels; a thread owns R CONSECUTIVE rows of one column and slides a 3x3 register window down them (three
+// LDS reads per patch per row instead of nine).  The input patch is kept RAW in LDS (its centre is the y of xhat; BatchNorm +
+// ReLU6 are two instructions on the three values a row step reads), the dy patch is stored after its BatchNorm-backward prologue.
+// Patches are staged row-wise: lane = column, no per-element index division.
+template <int PH, int TW, int PWP, typename F>
+__device__ __forceinline__ void dw_stage_rows(float* s, const float* __restrict__ xb, int y0, int x0, int H, int W, F&& pro) {
+  // interior columns 1..TW of the (TW + 2)-wide patch
+  constexpr int NI = (PH * TW + 255) / 256;
+#pragma unroll
+  for (int i0 = 0; i0 < NI; i0 += SC_DW_LB) {
+    float v[SC_DW_LB];
+#pragma unroll
+    for (int j = 0; j < SC_DW_LB; ++j)
+      if (i0 + j < NI) {
+        const int e = threadIdx.x + (i0 + j) * 256;
+        const int r = e / TW, cc = e % TW + 1;
+        const int iy = y0 + r, ix = x0 + cc;
+        const bool ok = (r < PH) && (iy >= 0) && (iy < H) && (ix < W);
+        v[j] = xb[ok ? iy * W + ix : 0];
+      }
+#pragma unroll
+    for (int j = 0; j < SC_DW_LB; ++j)
+      if (i0 + j < NI) {
+        const int e = threadIdx.x + (i0 + j) * 256;
+        const int r = e / TW, cc = e % TW + 1;
+        const int iy = y0 + r, ix = x0 + cc;
+        const bool ok = (iy >= 0) && (iy < H) && (ix < W);
+        if (r < PH) s[r * PWP + cc] = ok ? pro(v[j]) : 0.f;
+      }
+  }
+  // the two halo columns
+  for (int e = threadIdx.x; e < 2 * PH; e += 256) {
+    const int r = e >> 1, cc = (e & 1) ? TW + 1 : 0;
+    const int iy = y0 + r, ix = x0 + cc;
+    const bool ok = (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);
+    s[r * PWP + cc] = ok ? pro(xb[iy * W + ix]) : 0.f;
+  }
+}
+template <int PH, int TW, int PWP, typename F>
+__device__ __forceinline__ void dw_stage_rows2(float* s, const float* __restrict__ gb, const float* __restrict__ yb, int y0, int x0,
+                                               int H, int W, F&& pro) {
+  constexpr int NI = (PH * TW + 255) / 256, LB = SC_DW_LB / 2;
+#pragma unroll
+  for (int i0 = 0; i0 < NI; i0 += LB) {
+    float g[LB], yv[LB];
+#pragma unroll
+    for (int j = 0; j < LB; ++j)
+      if (i0 + j < NI) {
+        const int e = threadIdx.x + (i0 + j) * 256;
+        const int r = e / TW, cc = e % TW + 1;
+        const int iy = y0 + r, ix = x0 + cc;
+        const bool ok = (r < PH) && (iy >= 0) && (iy < H) && (ix < W);
+        const int o = ok ? iy * W + ix : 0;
+        g[j] = gb[o]; yv[j] = yb[o];
+      }
+#pragma unroll
+    for (int j = 0; j < LB; ++j)
+      if (i0 + j < NI) {
+        const int e = threadIdx.x + (i0 + j) * 256;
+        const int r = e / TW, cc = e % TW + 1;
+        const int iy = y0 + r, ix = x0 + cc;
+        const bool ok = (iy >= 0) && (iy < H) && (ix < W);
+        if (r < PH) s[r * PWP + cc] = ok ? pro(g[j], yv[j]) : 0.f;
+      }
+  }
+  for (int e = threadIdx.x; e < 2 * PH; e += 256) {
+    const int r = e >> 1, cc = (e & 1) ? TW + 1 : 0;
+    const int iy = y0 + r, ix = x0 + cc;
+    const bool ok = (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);
+    s[r * PWP + cc] = ok ? pro(gb[iy * W + ix], yb[iy * W + ix]) : 0.f;
+  }
+}
+
+template <int S, int TW, int R>
+__global__ __launch_bounds__(256) void k_dw_bwd(const SrcD dy, const SrcD in, const float* __restrict__ w, float* __restrict__ dx,
+                                                double* __restrict__ dw_acc, double* __restrict__ in_sums, int NC, int C, int Hin,
+                                                int Win, int Hout, int Wout) {
+  constexpr int TB = 256 / TW, TH = TB * R;
+  constexpr int PHD = (S == 1) ? TH + 2 : TH / 2 + 1, PWD = (S == 1) ? TW + 2 : TW / 2 + 1, PWDP = PWD | 1;
+  constexpr int PHX = TH + 2, PWX = TW + 2, PWXP = PWX | 1;
+  static_assert(S == 1 || (TH % 2 == 0 && TW % 2 == 0), "stride-2 tiles must be even");
+  __shared__ float s_d[PHD * PWDP];
+  __shared__ float s_x[PHX * PWXP];      // RAW input values (zero outside the image)
+  __shared__ float s_tmp[44];
+  // XCD-aware numbering: work-groups are handed to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  The tiles
+  // of one (n, c) plane share halo rows / columns, so they are numbered 8 apart: a plane's tiles all run on ONE XCD, close in time.
+  const int tiles_x = (Win + TW - 1) / TW;
+  const int tiles = tiles_x * ((Hin + TH - 1) / TH);
+  const int planes = NC;                           // = N * C (the launcher pads the grid to whole groups of 8 planes)
+  const int grp = blockIdx.x / (8 * tiles), within = blockIdx.x - grp * 8 * tiles;
+  const int plane = grp * 8 + (within & 7), tile = within >> 3;
+  if (plane >= planes) return;
+  const int n = plane / C, c = plane - n * C;
+  const int iy0 = (tile / tiles_x) * TH, ix0 = (tile % tiles_x) * TW;
+  const int oyb = (S == 1) ? iy0 - 1 : iy0 / 2, oxb = (S == 1) ? ix0 - 1 : ix0 / 2;
+  float4 c0 = make_float4(1.f, 0.f, 0.f, 0.f); float c4 = 0.f;
+  if (dy.mode != SC_SRC_RAW) { c0 = *reinterpret_cast<const float4*>(dy.cst + (size_t)c * SC_CST); c4 = dy.cst[(size_t)c * SC_CST + 4]; }
+  const float dlo = sc_act_lo(dy.act), dhi = sc_act_hi(dy.act);
+  float xs = 1.f, xh = 0.f, xmean = 0.f, xinv = 1.f;
+  if (in.mode != SC_SRC_RAW) {
+    const float4 ci = *reinterpret_cast<const float4*>(in.cst + (size_t)c * SC_CST);
+    xs = ci.x; xh = ci.y; xmean = ci.z; xinv = ci.w;
+  }
+  const float xlo = sc_act_lo(in.act), xhi = sc_act_hi(in.act);
+  const size_t obase = ((size_t)n * C + c) * Hout * Wout, ibase = ((size_t)n * C + c) * Hin * Win;
+  // ---- staging: EVERY global load of the tile (dy patch as g and y, raw input patch, halo columns) is issued before the first
+  // one is consumed -- one memory round trip per work-group instead of one per batch (these kernels are latency-bound: ~30 KB per
+  // work-group, a few hundred instructions per thread)
+  const bool bnb = dy.mode == SC_SRC_BNBWD;
+  const float* gbp = dy.x + obase;
+  const float* ybp = bnb ? dy.aux + obase : dy.x + obase;
+  const float* xbp = in.x + ibase;
+  auto dpro = [&](float g, float yv) {
+    return bnb ? sc_pro_bnbwd(g, yv, c0.x, c0.y, c0.z, c0.w, c4, dlo, dhi) : sc_pro_affine(g, c0.x, c0.y, dlo, dhi);
+  };
+  constexpr int DCOLS = (S == 1) ? TW : PWD;                 // S == 1: interior columns row-wise (+ 2 halo columns); S == 2: whole patch
+  constexpr int DOFF = (S == 1) ? 1 : 0;
+  constexpr int NID = (PHD * DCOLS + 255) / 256, NIX = (PHX * TW + 255) / 256;
+  float vg[NID], vy[NID], vx[NIX], hg = 0.f, hy = 0.f, hx = 0.f, hg2 = 0.f, hy2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NID; ++i) {
+    const int e = threadIdx.x + i * 256;
+    const int r = e / DCOLS, cc = e % DCOLS + DOFF;
+    const int oy = oyb + r, ox = oxb + cc;
+    const bool ok = (r < PHD) && (oy >= 0) && (oy < Hout) && (ox >= 0) && (ox < Wout);
+    const int o = ok ? oy * Wout + ox : 0;
+    vg[i] = gbp[o]; vy[i] = ybp[o];
+  }
+#pragma unroll
+  for (int i = 0; i < NIX; ++i) {
+    const int e = threadIdx.x + i * 256;
+    const int r = e / TW, cc = e % TW + 1;
+    const int iy = iy0 - 1 + r, ixx = ix0 - 1 + cc;
+    const bool ok = (r < PHX) && (iy >= 0) && (iy < Hin) && (ixx < Win);
+    vx[i] = xbp[ok ? iy * Win + ixx : 0];
+  }
+  static_assert(2 * PHX <= 256 && 2 * PHD <= 512, "halo columns: at most one (input) / two (dy) elements per thread");
+  {
+    const int e = threadIdx.x;
+    const int r = e >> 1, cc = (e & 1) ? TW + 1 : 0;
+    const int iy = iy0 - 1 + r, ixx = ix0 - 1 + cc;
+    const bool ok = (e < 2 * PHX) && (iy >= 0) && (iy < Hin) && (ixx >= 0) && (ixx < Win);
+    hx = xbp[ok ? iy * Win + ixx : 0];
+    if (S == 1) {
+      const int oy = oyb + r, ox = oxb + cc;
+      const bool okd = (e < 2 * PHD) && (oy >= 0) && (oy < Hout) && (ox >= 0) && (ox < Wout);
+      const int o = okd ? oy * Wout + ox : 0;
+      hg = gbp[o]; hy = ybp[o];
+      (void)hg2; (void)hy2;
+    }
+  }
+  // ---- all loads are in flight: consume
+#pragma unroll
+  for (int i = 0; i < NID; ++i) {
+    const int e = threadIdx.x + i * 256;
+    const int r = e / DCOLS, cc = e % DCOLS + DOFF;
+    const int oy = oyb + r, ox = oxb + cc;
+    const bool ok = (oy >= 0) && (oy < Hout) && (ox >= 0) && (ox < Wout);
+    if (r < PHD) s_d[r * PWDP + cc] = ok ? dpro(vg[i], vy[i]) : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < NIX; ++i) {
+    const int e = threadIdx.x + i * 256;
+    const int r = e / TW, cc = e % TW + 1;
+    const int iy = iy0 - 1 + r, ixx = ix0 - 1 + cc;
+    const bool ok = (iy >= 0) && (iy < Hin) && (ixx < Win);
+    if (r < PHX) s_x[r * PWXP + cc] = ok ? vx[i] : 0.f;
+  }
+  {
+    const int e = threadIdx.x;
+    const int r = e >> 1, cc = (e & 1) ? TW + 1 : 0;
+    const int iy = iy0 - 1 + r, ixx = ix0 - 1 + cc;
+    if (e < 2 * PHX) s_x[r * PWXP + cc] = ((iy >= 0) && (iy < Hin) && (ixx >= 0) && (ixx < Win)) ? hx : 0.f;
+    if (S == 1 && e < 2 * PHD) {
+      const int oy = oyb + r, ox = oxb + cc;
+      s_d[r * PWDP + cc] = ((oy >= 0) && (oy < Hout) && (ox >= 0) && (ox < Wout)) ? dpro(hg, hy) : 0.f;
+    }
+  }
+  float wk[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wk[t] = w[c * 9 + t];
+  __syncthreads();
+  const int ty = threadIdx.x / TW, tx = threadIdx.x % TW;
+  const int ix = ix0 + tx;
+  const int row0 = ty * R;                         // this thread's rows of the tile: row0 .. row0 + R - 1, consecutive
+  // zero padding applies to the ACTIVATED input: columns / rows outside the image contribute 0 whatever BN(0) is
+  const bool cok[3] = {ix - 1 >= 0 && ix - 1 < Win, ix < Win, ix + 1 < Win};
+  auto xact = [&](float raw, bool ok) { return ok ? sc_pro_affine(raw, xs, xh, xlo, xhi) : 0.f; };
+  float* db = dx + ibase;
+  float red[2] = {0.f, 0.f};
+  float prod[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) prod[t] = 0.f;
+  if (S == 1) {
+    float xr[3][3], xa[3][3], dd[3][3];            // raw input, activated input, dy: rows (k, k+1, k+2) of the patches, columns tx..tx+2
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool rok = (iy0 - 1 + row0 + j >= 0) && (iy0 - 1 + row0 + j < Hin);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        xr[j][q] = s_x[(row0 + j) * PWXP + tx + q];
+        xa[j][q] = xact(xr[j][q], rok && cok[q]);
+        dd[j][q] = s_d[(row0 + j) * PWDP + tx + q];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int row = row0 + k, iy = iy0 + row;
+      const bool rok = iy + 1 < Hin;               // patch row (row + 2) is image row iy + 1 >= 0
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        xr[2][q] = s_x[(row + 2) * PWXP + tx + q];
+        xa[2][q] = xact(xr[2][q], rok && cok[q]);
+        dd[2][q] = s_d[(row + 2) * PWDP + tx + q];
+      }
+      float acc = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kh * 3 + kw], dd[2 - kh][2 - kw], acc);
+      const bool ok = iy < Hin && ix < Win;
+      const float dyv = ok ? dd[1][1] : 0.f;       // S == 1: Hout == Hin, Wout == Win
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) prod[kh * 3 + kw] = fmaf(dyv, xa[kh][kw], prod[kh * 3 + kw]);
+      if (ok) {
+        db[(size_t)iy * Win + ix] = acc;
+        const float yraw = xr[1][1];
+        const float yh = fmaf(yraw, xs, xh);
+        const float gb = (yh > xlo && yh < xhi) ? acc : 0.f;
+        red[0] += gb;
+        red[1] = fmaf(gb, (yraw - xmean) * xinv, red[1]);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        xr[0][q] = xr[1][q]; xr[1][q] = xr[2][q];
+        xa[0][q] = xa[1][q]; xa[1][q] = xa[2][q];
+        dd[0][q] = dd[1][q]; dd[1][q] = dd[2][q];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int row = row0 + k, iy = iy0 + row;
+      float acc = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int t = iy + 1 - kh;                 // = 2 * oy
+        if ((t & 1) || t < 0) continue;
+        const int r = t / 2 - oyb;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int u = ix + 1 - kw;
+          if ((u & 1) || u < 0) continue;
+          acc = fmaf(wk[kh * 3 + kw], s_d[r * PWDP + u / 2 - oxb], acc);
+        }
+      }
+      if (iy < Hin && ix < Win) {
+        db[(size_t)iy * Win + ix] = acc;
+        const float yraw = s_x[(row + 1) * PWXP + tx + 1];
+        const float yh = fmaf(yraw, xs, xh);
+        const float gb = (yh > xlo && yh < xhi) ? acc : 0.f;
+        red[0] += gb;
+        red[1] = fmaf(gb, (yraw - xmean) * xinv, red[1]);
+      }
+    }
+    constexpr int OW = TW / 2, NO = (TH / 2) * OW;
+    for (int o = threadIdx.x; o < NO; o += 256) {
+      const int orow = o / OW, ocol = o - orow * OW;
+      const int oy = iy0 / 2 + orow, ox = ix0 / 2 + ocol;
+      const float dyv = (oy < Hout && ox < Wout) ? s_d[orow * PWDP + ocol] : 0.f;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int yy = iy0 - 1 + 2 * orow + kh;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int xx = ix0 - 1 + 2 * ocol + kw;
+          const bool ok = yy >= 0 && yy < Hin && xx >= 0 && xx < Win;
+          prod[kh * 3 + kw] = fmaf(dyv, xact(s_x[(2 * orow + kh) * PWXP + 2 * ocol + kw], ok), prod[kh * 3 + kw]);
+        }
+      }
+    }
+  }
+  float all[11];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) all[t] = prod[t];
+  all[9] = red[0]; all[10] = red[1];
+  block_sum<11>(all, s_tmp);
+  if (threadIdx.x < 9) atomicAdd(&dw_acc[c * 9 + threadIdx.x], (double)all[threadIdx.x]);
+  if (in_sums && threadIdx.x < 2) in_sums[(((size_t)n * tiles + tile) * C + c) * 2 + threadIdx.x] = (double)all[9 + threadIdx.x];
+}
+
 // ---------------------------------------------------------------- stem (3x3 s2, Cin<=8 -> 32)
 constexpr int STEM_CO = 32;
 constexpr int STEM_MAXCI = 8;
@@ -706,6 +1004,25 @@ extern "C" int sc_dwconv3x3_wgrad(const sc_src* dy, const sc_src* in, double* dw
   dim3 grid((unsigned)(T < want ? T : want), C);
   SC_DW_DISPATCH(k_dw_wgrad, Wout, grid, to_srcd(*dy), to_srcd(*in), dw_acc, N, C, Hin, Win, Hout, Wout, 0);
   SC_LAUNCH_OK("sc_dwconv3x3_wgrad");
+  return SC_OK;
+}
+
+extern "C" int sc_dwconv3x3_bwd_fused(const sc_src* dy, const sc_src* in, const float* w, float* dx, double* dw_acc,
+                                      double* in_sums, int N, int C, int Hin, int Win, int stride, sc_stream stream) {
+  SC_REQUIRE(dy && in && w && dx && dw_acc && dy->C == C && in->C == C, "sc_dwconv3x3_bwd_fused: bad argument");
+  SC_REQUIRE(stride == 1 || stride == 2, "sc_dwconv3x3_bwd_fused: stride must be 1 or 2");
+  SC_REQUIRE((in->mode == SC_SRC_RAW || in->mode == SC_SRC_AFFINE) && in->up == 0 && dy->mode != SC_SRC_NORM && dy->up == 0,
+             "sc_dwconv3x3_bwd_fused: unsupported source mode");
+  SC_REQUIRE(dy->mode != SC_SRC_BNBWD || dy->aux != nullptr, "sc_dwconv3x3_bwd_fused: BNBWD source needs aux");
+  SC_REQUIRE(!in_sums || in->mode == SC_SRC_AFFINE, "sc_dwconv3x3_bwd_fused: BatchNorm-backward sums need an affine (BatchNorm'd) input");
+  SC_REQUIRE(stride == 1 || (Hin % 2 == 0 && Win % 2 == 0), "sc_dwconv3x3_bwd_fused: stride 2 needs even input sizes");
+  const int Hout = (Hin - 1) / stride + 1, Wout = (Win - 1) / stride + 1;
+  hipStream_t st = (hipStream_t)stream;
+  const long planes8 = ((long)N * C + 7) / 8 * 8;
+  SC_REQUIRE(planes8 * dw_tiles(Hin, Win) < (1L << 31), "sc_dwconv3x3_bwd_fused: grid too large");
+  dim3 grid((unsigned)(planes8 * dw_tiles(Hin, Win)));
+  SC_DW_DISPATCH(k_dw_bwd, Win, grid, to_srcd(*dy), to_srcd(*in), w, dx, dw_acc, in_sums, N * C, C, Hin, Win, Hout, Wout);
+  SC_LAUNCH_OK("sc_dwconv3x3_bwd_fused");
   return SC_OK;
 }
 

@@ -398,6 +398,13 @@ class HyperStarcopUNet(nn.Module):
             for t in self._tensors.values():
                 if t.bn is not None:
                     plan.bsums_v[t.name] = torch.empty(plan.brows[t.name] * t.C * 2, dtype=torch.float64, device=dev)
+            # inputs of the depthwise convolutions: their BatchNorm-backward sums come out of the fused depthwise backward
+            plan.dwrows, plan.dwsums = {}, {}
+            for op in self._ops:
+                if op["type"] == "dw" and op["ins"][0].bn is not None:
+                    ti = op["ins"][0]
+                    plan.dwrows[ti.name] = lib.sc_stat_rows(STAT_DW, N, H >> ti.shift, W >> ti.shift)
+                    plan.dwsums[ti.name] = torch.empty(plan.dwrows[ti.name] * ti.C * 2, dtype=torch.float64, device=dev)
             plan.dlogits = torch.empty((N, 1, H, W), **f32)
             plan.has_grad = True
         return plan
@@ -596,6 +603,7 @@ class HyperStarcopUNet(nn.Module):
     # HIP stream, forked after each layer's BatchNorm-backward constants and joined before the optimiser, so they fill
     # the CUs the small dgrad / reduce kernels of the dependency chain leave idle.
     overlap_wgrad = True
+    fuse_dw_bwd = os.environ.get("STARCOP_FUSE_DW", "1") != "0"     # depthwise dgrad + wgrad + the input's BatchNorm-backward sums in one kernel
     thin16 = os.environ.get("STARCOP_THIN16", "1") != "0"     # decoder.blocks.4 on sc_conv3x3_thin16 (0: the fp32-MFMA thin kernels)
     split_bf16 = True        # 3x3 convs with >= 32 output channels on the 16-bit matrix cores (False: everything on the fp32 MFMA)
     bn_small_max = 16384     # BatchNorm backward in one launch (block per channel) when a channel has at most this many elements
@@ -672,8 +680,14 @@ class HyperStarcopUNet(nn.Module):
                 dw_offs[i] = dw_off
                 dw_off += op["conv"].out_channels * 9
 
+        reduced = set()      # tensors whose BatchNorm-backward sums were produced by the fused depthwise backward
+
         def bn_backward(t, slot=None):
             Ho, Wo = H >> t.shift, W >> t.shift
+            if t.name in reduced:
+                check(lib.sc_bn_bwd_finalize(ptr(plan.dwsums[t.name]), plan.dwrows[t.name], float(N * Ho * Wo), ptr(plan.cst[t.name]),
+                                             ptr(gv(t.bn.weight)), ptr(gv(t.bn.bias)), ptr(plan.cstb[t.name]), t.C, st))
+                return
             amax = None
             if slot is not None:
                 amax = plan.gmax.data_ptr() + 4 * slot
@@ -738,6 +752,15 @@ class HyperStarcopUNet(nn.Module):
                 s = self._src_of(plan, tin)
                 acc = plan.dw_acc[dw_offs[i]:dw_offs[i] + o.C * 9]
                 tok = self._pb("k_dw_*")
+                if self.fuse_dw_bwd and tin.name not in written and tin.bn is not None and tin.name in plan.dwsums:
+                    # one pass: dx, dW and the BatchNorm-backward sums of the (6x expanded) input tensor
+                    check(lib.sc_dwconv3x3_bwd_fused(C.byref(dy), C.byref(s), ptr(conv.weight), ptr(plan.grad[tin.name]), ptr(acc),
+                                                     ptr(plan.dwsums[tin.name]), N, o.C, Hi, Wi, op["stride"], st))
+                    wgrad_launch(lambda sx, acc=acc, conv=conv, o=o: check(lib.sc_cast_f64_f32(ptr(acc), ptr(gv(conv.weight)), o.C * 9, sx)))
+                    self._pe(tok)
+                    written.add(tin.name)
+                    reduced.add(tin.name)
+                    continue
 
                 def dw_wgrad(sx, dy=dy, s=s, acc=acc, conv=conv, o=o, Hi=Hi, Wi=Wi, stride=op["stride"]):
                     check(lib.sc_dwconv3x3_wgrad(C.byref(dy), C.byref(s), ptr(acc), N, o.C, Hi, Wi, stride, sx))

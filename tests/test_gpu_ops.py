@@ -650,3 +650,55 @@ def test_conv_thin16_two_fp16_terms(hip, cin, cout, H, W, up, gscale):
     dsrc = make_src(dev(g), cout, SRC_BNBWD, act=ACT_RELU, cst=dev(cstb), aux=dev(y))
     dx, _ = run(dsrc, pack_thin(dev(w), 1), cin, absmax=amax)
     assert relerr(dx, F.conv_transpose2d(dy, w.double(), padding=1)) < 1e-5
+
+
+@pytest.mark.parametrize("stride,C_,H,W", [(1, 8, 64, 96), (2, 8, 64, 96), (1, 24, 32, 32), (2, 24, 32, 64), (1, 40, 16, 16), (2, 40, 16, 16),
+                                           (1, 5, 70, 50), (2, 6, 36, 20)])
+def test_dw_bwd_fused(hip, stride, C_, H, W):
+    """depthwise backward in one pass (sc_dwconv3x3_bwd_fused): dx, dW and the BatchNorm-backward sums of the input, against
+    autograd on the same graph  x -> BN affine + ReLU6 -> depthwise conv -> y ; dy = BNBWD(g, y)"""
+    lib = _lib.load()
+    N = 2
+    x = rnd(N, C_, H, W, seed=1, scale=2.0)
+    w = rnd(C_, 1, 3, 3, seed=2, scale=0.4)
+    sc, sh = rnd(C_, seed=3) * 0.3 + 1.0, rnd(C_, seed=4) * 0.5 + 1.0
+    mean, invstd = rnd(C_, seed=5) * 0.2, rnd(C_, seed=6).abs() + 0.5
+    xa = x.clone().requires_grad_(True)
+    pre = xa * sc[None, :, None, None] + sh[None, :, None, None]
+    act = F.relu6(pre)
+    wq = w.clone().requires_grad_(True)
+    y = F.conv2d(act, wq, stride=stride, padding=1, groups=C_)
+    Ho, Wo = y.shape[-2:]
+    g = rnd(N, C_, Ho, Wo, seed=7)
+    a, b = rnd(C_, seed=8) * 0.2 + 1, rnd(C_, seed=9) * 0.2
+    A, B, D = rnd(C_, seed=10), rnd(C_, seed=11) * 0.1, rnd(C_, seed=12) * 0.1
+    yd = y.detach()
+    yh = yd * a[None, :, None, None] + b[None, :, None, None]
+    dy = torch.where((yh > 0) & (yh < 6), g, torch.zeros(())) * A[None, :, None, None] + B[None, :, None, None] * yd + D[None, :, None, None]
+    y.backward(dy)
+    dact = torch.autograd.grad(F.conv2d(act.detach().requires_grad_(True), w, stride=stride, padding=1, groups=C_), [], allow_unused=True) if False else None
+    # dx of the kernel = gradient w.r.t. the ACTIVATED input (the consumer-side prologue backward is applied later through BNBWD)
+    act2 = act.detach().clone().requires_grad_(True)
+    F.conv2d(act2, w, stride=stride, padding=1, groups=C_).backward(dy)
+    dx_ref = act2.grad
+    pre_d = pre.detach()
+    gbn = torch.where((pre_d > 0) & (pre_d < 6), dx_ref, torch.zeros(()))
+    s1_ref = gbn.double().sum((0, 2, 3))
+    s2_ref = (gbn.double() * ((x.double() - mean.double()[None, :, None, None]) * invstd.double()[None, :, None, None])).sum((0, 2, 3))
+    cst_d = torch.zeros(C_, SC_CST); cst_d[:, 0], cst_d[:, 1], cst_d[:, 2], cst_d[:, 3], cst_d[:, 4] = a, b, A, B, D
+    cst_x = torch.zeros(C_, SC_CST); cst_x[:, 0], cst_x[:, 1], cst_x[:, 2], cst_x[:, 3] = sc, sh, mean, invstd
+    dsrc = make_src(dev(g), C_, SRC_BNBWD, act=ACT_RELU6, cst=dev(cst_d), aux=dev(yd))
+    xsrc = make_src(dev(x), C_, SRC_AFFINE, act=ACT_RELU6, cst=dev(cst_x))
+    dx = torch.full((N, C_, H, W), float("nan"), device=DEV)
+    acc = torch.zeros(C_ * 9, dtype=torch.float64, device=DEV)
+    rows = lib.sc_stat_rows(STAT_DW, N, H, W)
+    sums = torch.full((rows, C_, 2), float("nan"), dtype=torch.float64, device=DEV)
+    check(lib.sc_dwconv3x3_bwd_fused(C.byref(dsrc), C.byref(xsrc), ptr(dev(w)), ptr(dx), ptr(acc), ptr(sums), N, C_, H, W, stride, stream()))
+    assert relerr(dx, dx_ref) < TOL
+    assert relerr(acc.reshape(C_, 1, 3, 3), wq.grad) < TOL
+    tot = sums.sum(0).cpu()
+    assert relerr(tot[:, 0], s1_ref) < TOL and relerr(tot[:, 1], s2_ref) < TOL
+    # and it equals the three separate kernels it replaces
+    dx2 = torch.empty_like(dx)
+    check(lib.sc_dwconv3x3_dgrad(C.byref(dsrc), ptr(dev(w)), ptr(dx2), 0, N, C_, H, W, stride, stream()))
+    assert torch.equal(dx, dx2)
