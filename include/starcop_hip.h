@@ -165,6 +165,19 @@ typedef struct sc_wgrad_args {
 } sc_wgrad_args;
 size_t sc_wgrad_workspace_floats(int N, int H, int W, int Cout, int Cin, int ks);
 int sc_conv2d_wgrad_mfma(const sc_wgrad_args* a, sc_stream stream);
+/* The same kernel without its trailing reduction launches: the K-slice partials stay in a->part (which must then be a buffer
+ * of this layer's own, alive until the batch reduction) and `pending` (HOST struct) receives what sc_wgrad_reduce_batch needs.
+ * A network's ~35 pointwise layers each end in 2-3 few-microsecond dependent launches otherwise; the batch sums all of them in
+ * ONE launch at the end of the backward pass.  descs_dev / block_starts_dev: DEVICE arrays built once by the caller (the
+ * descriptors do not change between steps), block_starts[i] = first 256-thread block of descriptor i, blocks_i = ceil(total_i/256). */
+typedef struct sc_wgrad_pending {
+  const float* part; float* dw;
+  int32_t nparts, taps, Cout, Cin, CoP, CiP;
+  uint64_t total;        /* taps * Cout * Cin */
+} sc_wgrad_pending;
+int sc_conv2d_wgrad_mfma_deferred(const sc_wgrad_args* a, sc_wgrad_pending* pending_host, sc_stream stream);
+int sc_wgrad_reduce_batch(const sc_wgrad_pending* descs_dev, const uint32_t* block_starts_dev, int n, uint32_t total_blocks,
+                          sc_stream stream);
 /* Thin 3x3 layers (Cout <= 16, Cin = 16 or 32: smp's decoder.blocks.4 at full resolution) with two fp16 terms on
  * v_mfma_f32_16x16x32_f16: the filter bank stays in registers, all input channels are staged in one pass.  Same arguments as
  * sc_conv3x3_bx3 with terms = SC_TERMS_F16X2, nsrc = 1, a single plain output (csplit = Cout, no add / accumulate / down0);

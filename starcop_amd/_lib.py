@@ -48,6 +48,11 @@ class sc_wgrad_args(C.Structure):
                 ("absmax", C.c_void_p)]
 
 
+class sc_wgrad_pending(C.Structure):
+    _fields_ = [("part", C.c_void_p), ("dw", C.c_void_p), ("nparts", C.c_int32), ("taps", C.c_int32), ("Cout", C.c_int32),
+                ("Cin", C.c_int32), ("CoP", C.c_int32), ("CiP", C.c_int32), ("total", C.c_uint64)]
+
+
 class sc_mag1c_args(C.Structure):
     _fields_ = [("x", C.c_void_p), ("x_is_f64", C.c_int32), ("xoff", C.c_void_p),
                 ("P", C.c_void_p), ("Ppad", C.c_void_p), ("poff", C.c_void_p), ("statmask", C.c_void_p),
@@ -125,6 +130,8 @@ SIGNATURES = {
     "sc_threshold_confusion": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "sc_gather_augment": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sc_dwconv3x3_bwd_fused": (_i, [C.POINTER(sc_src), C.POINTER(sc_src), _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sc_conv2d_wgrad_mfma_deferred": (_i, [C.POINTER(sc_wgrad_args), C.POINTER(sc_wgrad_pending), _vp]),
+    "sc_wgrad_reduce_batch": (_i, [_vp, _vp, _i, C.c_uint32, _vp]),
     "sc_maxpool2x2": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _i, _vp]),
     "sc_upsample_bilinear2x": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _i, _vp]),
     "sc_tiff_lzw_decode": (_i, [_vp, _sz, _vp, _sz, C.POINTER(C.c_size_t)]),

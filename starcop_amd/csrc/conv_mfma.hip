@@ -1197,7 +1197,16 @@ extern "C" size_t sc_wgrad_workspace_floats(int N, int H, int W, int Cout, int C
   return (size_t)nparts * E + sc_reduce_scratch_floats(nparts, E);
 }
 
-extern "C" int sc_conv2d_wgrad_mfma(const sc_wgrad_args* a, sc_stream stream) {
+static int wgrad_mfma_launch(const sc_wgrad_args* a, sc_stream stream, sc_wgrad_pending* pending);
+
+extern "C" int sc_conv2d_wgrad_mfma(const sc_wgrad_args* a, sc_stream stream) { return wgrad_mfma_launch(a, stream, nullptr); }
+
+extern "C" int sc_conv2d_wgrad_mfma_deferred(const sc_wgrad_args* a, sc_wgrad_pending* pending, sc_stream stream) {
+  SC_REQUIRE(pending != nullptr, "sc_conv2d_wgrad_mfma_deferred: null descriptor");
+  return wgrad_mfma_launch(a, stream, pending);
+}
+
+static int wgrad_mfma_launch(const sc_wgrad_args* a, sc_stream stream, sc_wgrad_pending* pending) {
   SC_REQUIRE(a != nullptr, "sc_conv2d_wgrad_mfma: null args");
   SC_REQUIRE(a->ks == 1 || a->ks == 3, "sc_conv2d_wgrad_mfma: ks must be 1 or 3");
   SC_REQUIRE(a->nsrc == 1 || a->nsrc == 2, "sc_conv2d_wgrad_mfma: nsrc must be 1 or 2");
@@ -1236,7 +1245,55 @@ extern "C" int sc_conv2d_wgrad_mfma(const sc_wgrad_args* a, sc_stream stream) {
   }
 #undef SC_WG
   SC_LAUNCH_OK("sc_conv2d_wgrad_mfma");
+  if (pending) {          // the caller sums the K-slice partials of many layers in one launch (sc_wgrad_reduce_batch)
+    pending->part = a->part; pending->dw = a->dw;
+    pending->nparts = pl.nsl * pl.wk; pending->taps = a->ks * a->ks;
+    pending->Cout = a->Cout; pending->Cin = a->Cin; pending->CoP = pl.CoP; pending->CiP = pl.CiP;
+    pending->total = (uint64_t)pending->taps * a->Cout * a->Cin;
+    return SC_OK;
+  }
   return sc_wgrad_finish(a->part, pl.nsl * pl.wk, a->ks * a->ks, a->Cout, a->Cin, pl.CoP, pl.CiP, a->dw, st);
+}
+
+namespace {
+// dw[co][ci][tap] = sum_k part[k][tap][co][ci] for every pending layer: one thread per weight, partial rows summed in a fixed
+// order (bit-reproducible), 8 loads in flight
+__global__ __launch_bounds__(256) void k_wgrad_reduce_batch(const sc_wgrad_pending* __restrict__ descs, const unsigned* __restrict__ starts, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (starts[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const sc_wgrad_pending d = descs[lo];
+  const size_t i = (size_t)(blockIdx.x - starts[lo]) * 256 + threadIdx.x;
+  if (i >= d.total) return;
+  const int ci = (int)(i % d.Cin);
+  size_t r = i / d.Cin;
+  const int co = (int)(r % d.Cout);
+  const int tap = (int)(r / d.Cout);
+  const size_t plane = (size_t)d.CoP * d.CiP, stride = (size_t)d.taps * plane;
+  const float* src = d.part + (size_t)tap * plane + (size_t)co * d.CiP + ci;
+  float s = 0.f;
+  int k = 0;
+  for (; k + 8 <= d.nparts; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; k < d.nparts; ++k) s += src[(size_t)k * stride];
+  d.dw[((size_t)co * d.Cin + ci) * d.taps + tap] = s;
+}
+}  // namespace
+
+extern "C" int sc_wgrad_reduce_batch(const sc_wgrad_pending* descs_dev, const uint32_t* block_starts_dev, int n, uint32_t total_blocks,
+                                     sc_stream stream) {
+  SC_REQUIRE(descs_dev && block_starts_dev && n >= 0, "sc_wgrad_reduce_batch: bad argument");
+  if (n == 0 || total_blocks == 0) return SC_OK;
+  hipLaunchKernelGGL(k_wgrad_reduce_batch, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, block_starts_dev, n);
+  SC_LAUNCH_OK("sc_wgrad_reduce_batch");
+  return SC_OK;
 }
 
 // two-level reduction of the K-slice partials part[nparts][taps][CoP][CiP] (scratch follows them), then the layout

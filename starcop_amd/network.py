@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD,
+from ._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD, sc_wgrad_pending,
                    PACK_THIN16, STAT_CONV1, STAT_CONV1K, STAT_CONV3, STAT_DW, STAT_STEM, TERMS_F16X2, check, make_src, ptr,
                    sc_conv_args, sc_wgrad_args, stream)
 
@@ -391,6 +391,15 @@ class HyperStarcopUNet(nn.Module):
                     n_dw += conv.out_channels * 9
             plan.ws = torch.empty(ws, **f32)
             plan.ws_floats = ws
+            # pointwise weight gradients keep their K-slice partials in buffers of their own until ONE batched reduction at the
+            # end of the backward pass (sc_wgrad_reduce_batch) instead of 2-3 dependent few-microsecond launches per layer
+            plan.pw_part, plan.pw_table = {}, None
+            if self.batch_pw_reduce:
+                for i, op in enumerate(self._ops):
+                    if op["type"] == "pw":
+                        conv, o = op["conv"], op["out"]
+                        nfl = lib.sc_wgrad_workspace_floats(N, H >> o.shift, W >> o.shift, conv.out_channels, conv.in_channels, 1)
+                        plan.pw_part[i] = torch.empty(nfl, **f32)
             plan.up_tmp = torch.empty(max(up, 1), **f32)
             plan.dw_acc = torch.zeros(n_dw, dtype=torch.float64, device=dev)
             # one float per BatchNorm'd tensor: max |gamma*invstd * g| of its gradient, the range hint of the fp16-split kernels
@@ -603,6 +612,7 @@ class HyperStarcopUNet(nn.Module):
     # HIP stream, forked after each layer's BatchNorm-backward constants and joined before the optimiser, so they fill
     # the CUs the small dgrad / reduce kernels of the dependency chain leave idle.
     overlap_wgrad = True
+    batch_pw_reduce = os.environ.get("STARCOP_BATCH_PW_REDUCE", "1") != "0"     # one reduction launch for all pointwise weight gradients
     fuse_dw_bwd = os.environ.get("STARCOP_FUSE_DW", "1") != "0"     # depthwise dgrad + wgrad + the input's BatchNorm-backward sums in one kernel
     thin16 = os.environ.get("STARCOP_THIN16", "1") != "0"     # decoder.blocks.4 on sc_conv3x3_thin16 (0: the fp32-MFMA thin kernels)
     split_bf16 = True        # 3x3 convs with >= 32 output channels on the 16-bit matrix cores (False: everything on the fp32 MFMA)
@@ -681,6 +691,7 @@ class HyperStarcopUNet(nn.Module):
                 dw_off += op["conv"].out_channels * 9
 
         reduced = set()      # tensors whose BatchNorm-backward sums were produced by the fused depthwise backward
+        pw_pending = []      # pointwise weight gradients whose K-slice partials await the batched reduction
 
         def bn_backward(t, slot=None):
             Ho, Wo = H >> t.shift, W >> t.shift
@@ -789,7 +800,13 @@ class HyperStarcopUNet(nn.Module):
             wfn = (lib.sc_conv3x3_wgrad_bx3 if (self.split_bf16 and ks == 3 and conv.out_channels >= 32 and conv.in_channels >= 32)
                    else lib.sc_conv2d_wgrad_mfma)     # thin layers (16 channels on either side) stay on the fp32 MFMA
             tok = self._pb("k_wgrad3_bx3 (+reduce)" if wfn is lib.sc_conv3x3_wgrad_bx3 else f"k_wgrad_mfma<{ks}> (+reduce)", flop)
-            wgrad_launch(lambda sx, wfn=wfn, wa=wa: check(wfn(C.byref(wa), sx)))
+            if ty == "pw" and i in plan.pw_part:
+                wa.part = plan.pw_part[i].data_ptr(); wa.part_floats = plan.pw_part[i].numel()
+                pend = sc_wgrad_pending()
+                wgrad_launch(lambda sx, wa=wa, pend=pend: check(lib.sc_conv2d_wgrad_mfma_deferred(C.byref(wa), C.byref(pend), sx)))
+                pw_pending.append(pend)
+            else:
+                wgrad_launch(lambda sx, wfn=wfn, wa=wa: check(wfn(C.byref(wa), sx)))
             self._pe(tok)
             # data gradient
             if ins[0].kind == "input":
@@ -856,6 +873,22 @@ class HyperStarcopUNet(nn.Module):
                 check(conv_dgrad(C.byref(a), st))
                 self._pe(tok)
                 written.add(tin.name)
+        if pw_pending:
+            if plan.pw_table is None:       # descriptors are static for a plan: device table built once
+                import numpy as np
+                raw = b"".join(bytes(p_) for p_ in pw_pending)
+                starts, nblk = [], 0
+                for p_ in pw_pending:
+                    starts.append(nblk)
+                    nblk += -(-int(p_.total) // 256)
+                plan.pw_table = (torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(self._pflat.device),
+                                 torch.tensor(starts, dtype=torch.int32).to(self._pflat.device), len(pw_pending), nblk, raw)
+            elif plan.pw_table[4] != b"".join(bytes(p_) for p_ in pw_pending):
+                raise RuntimeError("HyperStarcopUNet: weight-gradient reduction table changed between steps")
+            tab = plan.pw_table
+            tok = self._pb("k_wgrad_mfma<1> (+reduce)")
+            wgrad_launch(lambda sx: check(lib.sc_wgrad_reduce_batch(ptr(tab[0]), ptr(tab[1]), tab[2], tab[3], sx)))
+            self._pe(tok)
         if side is not None:
             main.wait_stream(side)          # join: every weight gradient is in the flat buffer before Adam / all-reduce
 

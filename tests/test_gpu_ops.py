@@ -702,3 +702,38 @@ def test_dw_bwd_fused(hip, stride, C_, H, W):
     dx2 = torch.empty_like(dx)
     check(lib.sc_dwconv3x3_dgrad(C.byref(dsrc), ptr(dev(w)), ptr(dx2), 0, N, C_, H, W, stride, stream()))
     assert torch.equal(dx, dx2)
+
+
+def test_wgrad_deferred_batch_reduce(hip):
+    """pointwise weight gradients with the reduction of their K-slice partials deferred into ONE batched launch
+    (sc_conv2d_wgrad_mfma_deferred + sc_wgrad_reduce_batch) == autograd, for several layers of different shape at once"""
+    import numpy as np
+    from starcop_amd._lib import sc_wgrad_args, sc_wgrad_pending
+    lib = _lib.load()
+    N = 2
+    cases = [(96, 16, 32, 32), (24, 144, 16, 24), (160, 960, 4, 4), (1280, 320, 2, 3), (8, 40, 9, 7)]
+    pend, wants, outs, keep = [], [], [], []
+    for k, (co, ci, H, W) in enumerate(cases):
+        x, g = rnd(N, ci, H, W, seed=10 + k), rnd(N, co, H, W, seed=20 + k)
+        wants.append(torch.einsum("nohw,nihw->oi", g, x).reshape(co, ci, 1, 1))
+        a = sc_wgrad_args()
+        xd, gd = dev(x), dev(g)
+        a.dy = make_src(gd, co, SRC_RAW)
+        a.nsrc = 1
+        a.src[0] = make_src(xd, ci, SRC_RAW)
+        a.N, a.H, a.W, a.Cout, a.Cin, a.ks = N, H, W, co, ci, 1
+        nfl = lib.sc_wgrad_workspace_floats(N, H, W, co, ci, 1)
+        part = torch.empty(nfl, device=DEV); dw = torch.full((co, ci, 1, 1), float("nan"), device=DEV)
+        a.part, a.part_floats, a.dw = part.data_ptr(), nfl, dw.data_ptr()
+        p = sc_wgrad_pending()
+        check(lib.sc_conv2d_wgrad_mfma_deferred(C.byref(a), C.byref(p), stream()))
+        assert p.total == co * ci and p.nparts >= 1
+        pend.append(p); outs.append(dw); keep += [part, xd, gd]
+    starts, nblk = [], 0
+    for p in pend:
+        starts.append(nblk); nblk += -(-int(p.total) // 256)
+    descs = torch.from_numpy(np.frombuffer(b"".join(bytes(p) for p in pend), dtype=np.uint8).copy()).to(DEV)
+    st_d = torch.tensor(starts, dtype=torch.int32, device=DEV)
+    check(lib.sc_wgrad_reduce_batch(ptr(descs), ptr(st_d), len(pend), nblk, stream()))
+    for dw, want in zip(outs, wants):
+        assert relerr(dw, want) < TOL
