@@ -101,43 +101,99 @@ __device__ __forceinline__ void dw_stage2(float* s, const float* __restrict__ gb
 
 template <int S, int TW, int R>
 __global__ __launch_bounds__(256) void k_dw_fwd(const SrcD in, const float* __restrict__ w, float* __restrict__ out,
-                                                int C, int Hin, int Win, int Hout, int Wout, float* stats) {
+                                                int NC, int C, int Hin, int Win, int Hout, int Wout, float* stats) {
   constexpr int TB = 256 / TW, TH = TB * R;
   constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PWP = PW | 1;
   __shared__ float s_x[PH * PWP];
   __shared__ float s_tmp[8];
-  const int c = blockIdx.y, n = blockIdx.z;
+  // XCD-aware numbering (see k_dw_bwd): the tiles of one (n, c) plane are 8 apart in the linear work-group id -> one XCD, one L2
   const int tiles_x = (Wout + TW - 1) / TW;
-  const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+  const int tiles = tiles_x * ((Hout + TH - 1) / TH);
+  const int grp = blockIdx.x / (8 * tiles), within = blockIdx.x - grp * 8 * tiles;
+  const int plane = grp * 8 + (within & 7), tile = within >> 3;
+  if (plane >= NC) return;
+  const int n = plane / C, c = plane - n * C;
+  const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
   float sc = 1.f, sh = 0.f;
   if (in.mode != SC_SRC_RAW) { sc = in.cst[(size_t)c * SC_CST]; sh = in.cst[(size_t)c * SC_CST + 1]; }
   const float lo = sc_act_lo(in.act), hi = sc_act_hi(in.act);
   const float* xb = in.x + ((size_t)n * C + c) * Hin * Win;
-  dw_stage<PH, PW, PWP>(s_x, xb, ty0 * S - 1, tx0 * S - 1, Hin, Win, [&](float v) { return sc_pro_affine(v, sc, sh, lo, hi); });
+  // stride 1: every load of the patch is in flight before the first use (one memory round trip per work-group)
+  constexpr int NE = PH * PW, NIT = (NE + 255) / 256, LB = (S == 1) ? NIT : SC_DW_LB;   // measured: stride-2 patches (33 loads per thread) are faster in batches of 8
+  const int y0 = ty0 * S - 1, x0 = tx0 * S - 1;
   float wk[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wk[t] = w[c * 9 + t];
+#pragma unroll
+  for (int i0 = 0; i0 < NIT; i0 += LB) {
+    float v[LB];
+#pragma unroll
+    for (int j = 0; j < LB; ++j)
+      if (i0 + j < NIT) {
+        const int e = threadIdx.x + (i0 + j) * 256;
+        const int r = e / PW, cc = e - r * PW;
+        const int iy = y0 + r, ix = x0 + cc;
+        const bool ok = (e < NE) && (iy >= 0) && (iy < Hin) && (ix >= 0) && (ix < Win);
+        v[j] = xb[ok ? iy * Win + ix : 0];
+      }
+#pragma unroll
+    for (int j = 0; j < LB; ++j)
+      if (i0 + j < NIT) {
+        const int e = threadIdx.x + (i0 + j) * 256;
+        const int r = e / PW, cc = e - r * PW;
+        const int iy = y0 + r, ix = x0 + cc;
+        const bool ok = (iy >= 0) && (iy < Hin) && (ix >= 0) && (ix < Win);
+        if (e < NE) s_x[r * PWP + cc] = ok ? sc_pro_affine(v[j], sc, sh, lo, hi) : 0.f;
+      }
+  }
   __syncthreads();
   const int ty = threadIdx.x / TW, tx = threadIdx.x % TW;
   const int ox = tx0 + tx;
   float* ob = out + ((size_t)n * C + c) * Hout * Wout;
-  float v[2] = {0.f, 0.f};
+  float sv[2] = {0.f, 0.f};
+  if (S == 1) {
+    // a thread owns R consecutive rows of one column: 3x3 register window, three LDS reads per output row
+    const int row0 = ty * R;
+    float a[3][3];
 #pragma unroll
-  for (int k = 0; k < R; ++k) {
-    const int row = ty + k * TB, oy = ty0 + row;
-    float acc = 0.f;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+      for (int q = 0; q < 3; ++q) a[j][q] = s_x[(row0 + j) * PWP + tx + q];
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kh * 3 + kw], s_x[(row * S + kh) * PWP + tx * S + kw], acc);
-    if ((oy < Hout) && (ox < Wout)) {
-      ob[(size_t)oy * Wout + ox] = acc;
-      v[0] += acc; v[1] = fmaf(acc, acc, v[1]);
+    for (int k = 0; k < R; ++k) {
+      const int row = row0 + k, oy = ty0 + row;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a[2][q] = s_x[(row + 2) * PWP + tx + q];
+      float acc = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kh * 3 + kw], a[kh][kw], acc);
+      if ((oy < Hout) && (ox < Wout)) {
+        ob[(size_t)oy * Wout + ox] = acc;
+        sv[0] += acc; sv[1] = fmaf(acc, acc, sv[1]);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { a[0][q] = a[1][q]; a[1][q] = a[2][q]; }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int row = ty + k * TB, oy = ty0 + row;
+      float acc = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kh * 3 + kw], s_x[(row * S + kh) * PWP + tx * S + kw], acc);
+      if ((oy < Hout) && (ox < Wout)) {
+        ob[(size_t)oy * Wout + ox] = acc;
+        sv[0] += acc; sv[1] = fmaf(acc, acc, sv[1]);
+      }
     }
   }
   if (stats) {
-    block_sum<2>(v, s_tmp);
-    if (threadIdx.x < 2) stats[(stat_row() * C + c) * 2 + threadIdx.x] = v[threadIdx.x];
+    block_sum<2>(sv, s_tmp);
+    if (threadIdx.x < 2) stats[(((size_t)n * tiles + tile) * C + c) * 2 + threadIdx.x] = sv[threadIdx.x];
   }
 }
 
@@ -971,8 +1027,10 @@ extern "C" int sc_dwconv3x3_fwd(const sc_src* in, const float* w, float* out, in
   SC_REQUIRE((in->mode == SC_SRC_RAW || in->mode == SC_SRC_AFFINE) && in->up == 0, "sc_dwconv3x3_fwd: unsupported source mode");
   const int Hout = (Hin - 1) / stride + 1, Wout = (Win - 1) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((unsigned)dw_tiles(Hout, Wout), C, N);
-  SC_DW_DISPATCH(k_dw_fwd, Wout, grid, to_srcd(*in), w, out, C, Hin, Win, Hout, Wout, stats);
+  const long planes8 = ((long)N * C + 7) / 8 * 8;
+  SC_REQUIRE(planes8 * dw_tiles(Hout, Wout) < (1L << 31), "sc_dwconv3x3_fwd: grid too large");
+  dim3 grid((unsigned)(planes8 * dw_tiles(Hout, Wout)));
+  SC_DW_DISPATCH(k_dw_fwd, Wout, grid, to_srcd(*in), w, out, N * C, C, Hin, Win, Hout, Wout, stats);
   SC_LAUNCH_OK("sc_dwconv3x3_fwd");
   return SC_OK;
 }
