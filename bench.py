@@ -279,12 +279,18 @@ def main():
         nterms = tb_ if ("dgrad)" in fam and "fwd" not in fam) or "wgrad" in fam else tf_
         nprod = {1: 1.0, 2: 3.0, 3: 6.0, 4: 3.0}[nterms]
         peak = BF16_MFMA_PEAK_TFLOPS / nprod if bx3 else FP32_MFMA_PEAK_TFLOPS
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_conv3_bx3.json" if bx3 else "r01_pmc_traffic_conv3.json")
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic_conv3_bx3.json" if bx3 else "r01_pmc_traffic_conv3.json")
         if ("conv3" in fam or fam.startswith("k_conv_mfma<3>")) and os.path.exists(pmc):
             t = json.load(open(pmc))
-            traffic = round(t["hbm_bytes_per_launch_raw"])
-            traffic_note = (f"HBM bytes per launch of {t['kernel_pattern']}* from committed rocprofv3 PMC passes (FETCH_SIZE raw + WRITE_SIZE, "
-                            "KiB->bytes; 4 B/lane loads: the gfx950 2x FETCH correction for 16 B/lane streams is not applied)")
+            if "hbm_bytes_per_launch_corrected" in t:
+                traffic = round(t["hbm_bytes_per_launch_corrected"])
+                traffic_note = (f"memory-side bytes per launch of {t['kernel_pattern']}* from committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs, "
+                                f"KiB -> bytes), FETCH_SIZE divided by {t['fetch_calibration']['FETCH_SIZE_reported_over_known']:.3f} = what the counter reports of a KNOWN "
+                                "1 GiB stream in this kernel's own 4 B/lane access pattern (profiles/r02_pmc_calibration.json; WRITE_SIZE calibrates to 1.000). "
+                                "Infinity-Cache hits are counted (MI355X_MICROARCH.md), so this is L2-miss traffic, an upper bound on HBM bytes")
+            else:
+                traffic = round(t["hbm_bytes_per_launch_raw"])
+                traffic_note = (f"HBM bytes per launch of {t['kernel_pattern']}* from committed rocprofv3 PMC passes (FETCH_SIZE raw + WRITE_SIZE)")
         hbm = ("<1>" in fam or "k_dw" in fam or "elementwise" in fam) and d.get("bytes")     # streaming families: HBM roofline
         if hbm:
             ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
