@@ -25,6 +25,7 @@
 // filters per filter row kh [terms][3 kw][2 halves][32Q couts] x 16 B, double buffered: 51 KB (two terms) / 72 KB (three terms)
 // at Q = 2 -> 2 work-groups per CU (the Q = 2 kernels need 220 VGPRs).
 #include "sc_common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -81,6 +82,7 @@ struct ConvXP {
   float* stats;
   int down0;
   const float* absmax;
+  int xcdmap;          // 1: 1-D grid, the cout tiles of a pixel tile numbered 8 apart (same XCD, back to back: its L2 serves the patch re-reads)
 };
 
 // exact three-term bf16 split of two floats; returns packed pairs (low half = first value)
@@ -119,10 +121,34 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int n = blockIdx.z, cot = blockIdx.y;
   const int H = p.H, W = p.W;
   const int tiles_x = (W + 31) >> 5;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  int n, cot, tile;
+  if (p.xcdmap) {
+    // work-groups go to the 8 XCDs round-robin by linear id and each XCD has its own L2: number the cout tiles of one pixel tile 8
+    // apart so that they run on ONE XCD back to back and the patch they all stage is fetched from memory once, not once per cout tile
+    const int ncot = (p.Cout + CO_T - 1) / CO_T;
+    const int per_img = tiles_x * ((H + 7) >> 3);
+    const int slot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    int pt;
+    if (p.xcdmap == 2) {
+      // each XCD walks a CONTIGUOUS eighth of the pixel tiles in order: x- and y-neighbouring tiles (which share halo columns /
+      // rows and the 128-byte lines their misaligned 34-pixel row segments straddle) run on one XCD within its ~64 resident
+      // work-groups, so those lines are L2 hits instead of separate memory requests
+      const int total = per_img * p.N, per_xcd = (total + 7) >> 3;
+      const int j = slot / ncot;
+      pt = xcd * per_xcd + j;
+      if (j >= per_xcd || pt >= total) return;
+    } else {
+      pt = (slot / ncot) * 8 + xcd;
+      if (pt >= per_img * p.N) return;
+    }
+    cot = slot % ncot;
+    n = pt / per_img; tile = pt - n * per_img;
+  } else {
+    n = blockIdx.z; cot = blockIdx.y; tile = blockIdx.x;
+  }
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * 8, x0 = tx * 32;
   const int C0 = p.s0.C;
   const int Cin = C0 + p.s1.C;
@@ -575,10 +601,18 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
-  const int n = blockIdx.z;
   const int H = p.H, W = p.W;
   const int tiles_x = (W + 31) >> 5;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  int n, tile;
+  if (p.xcdmap) {      // each XCD walks a contiguous eighth of the pixel tiles (see k_conv3_bx3): halo lines shared in its L2
+    const int per_img = tiles_x * ((H + 7) >> 3), total = per_img * p.N, per_xcd = (total + 7) >> 3;
+    const int j = blockIdx.x >> 3, pt = (blockIdx.x & 7) * per_xcd + j;
+    if (j >= per_xcd || pt >= total) return;
+    n = pt / per_img; tile = pt - n * per_img;
+  } else {
+    n = blockIdx.z; tile = blockIdx.x;
+  }
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * 8, x0 = tx * 32;
   const float hsx = BNB ? h_grad_scale(p.absmax) : SC_H_SX;
   const float hinv = 1.f / (hsx * SC_H_SW);
@@ -1176,6 +1210,13 @@ extern "C" int sc_conv3x3_bx3(const sc_conv_args* a, sc_stream stream) {
              "sc_conv3x3_bx3: down0 (2x2-summed half-resolution out0) needs even H, W and no stats/add tensors");
   const int co_tiles = (a->Cout + a->co_t - 1) / a->co_t;
   dim3 grid(((a->W + 31) / 32) * ((a->H + 7) / 8), co_tiles, a->N);
+  static const int xcdmap_env = [] { const char* e = getenv("STARCOP_BX3_XCDMAP"); return e ? atoi(e) : 2; }();   // 0: plain 3-D grid
+  p.xcdmap = xcdmap_env == 2 ? 2 : ((xcdmap_env && co_tiles > 1) ? 1 : 0);
+  if (p.xcdmap) {
+    const long pt8 = ((long)grid.x * a->N + 7) / 8 * 8;
+    SC_REQUIRE(pt8 * co_tiles < (1L << 31), "sc_conv3x3_bx3: grid too large");
+    grid = dim3((unsigned)(pt8 * co_tiles));
+  }
   hipStream_t st = (hipStream_t)stream;
   const bool bnb = a->src[0].mode == SC_SRC_BNBWD;
   SC_REQUIRE(a->terms >= 0 && a->terms <= 4, "sc_conv3x3_bx3: terms must be 0 (= 3), 1, 2, 3 or SC_TERMS_F16X2 (got %d)", a->terms);
@@ -1283,6 +1324,12 @@ extern "C" int sc_conv3x3_thin16(const sc_conv_args* a, sc_stream stream) {
   p.wpk = reinterpret_cast<const uintx4*>(a->wpk); p.N = a->N; p.H = a->H; p.W = a->W; p.Cout = a->Cout;
   p.out0 = a->out0; p.csplit = a->Cout; p.stats = a->stats; p.absmax = a->absmax;
   dim3 grid(((a->W + 31) / 32) * ((a->H + 7) / 8), 1, a->N);
+  static const int xcdmap_env = [] { const char* e = getenv("STARCOP_BX3_XCDMAP"); return e ? atoi(e) : 2; }();
+  p.xcdmap = xcdmap_env ? 2 : 0;
+  if (p.xcdmap) {
+    const long total = (long)grid.x * a->N, per_xcd = (total + 7) / 8;
+    grid = dim3((unsigned)(per_xcd * 8));
+  }
   hipStream_t st = (hipStream_t)stream;
   const bool bnb = s.mode == SC_SRC_BNBWD;
   if (Cin == 16) { if (bnb) hipLaunchKernelGGL((k_conv3_thin_h<16, true>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((k_conv3_thin_h<16, false>), grid, dim3(256), 0, st, p); }
