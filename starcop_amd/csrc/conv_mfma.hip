@@ -16,6 +16,7 @@
 // global loads for chunk k+1 issued before the MFMAs of chunk k (register staged because of the
 // prologue), one barrier per chunk.
 #include "sc_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -27,6 +28,7 @@ struct ConvP {
   int csplit, accum0, accum1;
   const float* add0; const float* add1;
   float* stats;
+  int xcdmap;     // 1: 1-D grid; each XCD walks a contiguous eighth of the pixel tiles, the cout tiles of a pixel tile back to back
 };
 
 // BNB: the (single) source is a BatchNorm-backward source (dgrad launches); mixing it with other modes in a concat is not used
@@ -50,16 +52,31 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int n = blockIdx.z, cot = blockIdx.y;
   const int H = p.H, W = p.W;
+  const int per_img = (KS == 3) ? ((W + 31) >> 5) * ((H + 3) >> 2) : (H * W + 127) >> 7;
+  int n, cot, tile;
+  if (p.xcdmap) {
+    // work-groups go to the 8 XCDs round-robin by linear id; each XCD has its own L2.  XCD k walks the k-th contiguous eighth of
+    // the pixel tiles, all cout tiles of a pixel tile back to back: the input tile they share (and, for 3x3, the halo lines of
+    // neighbouring tiles) is fetched from memory once and then hits in that L2 -- lower latency for these latency-bound kernels
+    const int ncot = (p.Cout + CO_T - 1) / CO_T;
+    const int total = per_img * p.N, per_xcd = (total + 7) >> 3;
+    const int slot = blockIdx.x >> 3, j = slot / ncot;
+    const int pt = (blockIdx.x & 7) * per_xcd + j;
+    if (j >= per_xcd || pt >= total) return;
+    cot = slot - j * ncot;
+    n = pt / per_img; tile = pt - n * per_img;
+  } else {
+    n = blockIdx.z; cot = blockIdx.y; tile = blockIdx.x;
+  }
   int y0 = 0, x0 = 0, p0 = 0;
   if (KS == 3) {
     const int tiles_x = (W + 31) >> 5;
-    const int ty = blockIdx.x / tiles_x;
+    const int ty = tile / tiles_x;
     y0 = ty * 4;
-    x0 = (blockIdx.x - ty * tiles_x) * 32;
+    x0 = (tile - ty * tiles_x) * 32;
   } else {
-    p0 = blockIdx.x * 128;
+    p0 = tile * 128;
   }
   const int C0 = p.s0.C;
   const int Cin = C0 + p.s1.C;
@@ -280,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
       const int co = cot * CO_T + col;
       if (co < p.Cout) {
         const float t = s_red[0][col][k] + s_red[1][col][k] + s_red[2][col][k] + s_red[3][col][k];
-        p.stats[(stat_row() * p.Cout + co) * 2 + k] = t;
+        p.stats[(((size_t)n * per_img + tile) * p.Cout + co) * 2 + k] = t;
       }
     }
   }
@@ -1135,6 +1152,14 @@ extern "C" int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream) {
   if (a->ks == 3) grid = dim3(((a->W + 31) / 32) * ((a->H + 3) / 4), co_tiles, a->N);
   else grid = dim3((a->H * a->W + 127) / 128, co_tiles, a->N);
   hipStream_t st = (hipStream_t)stream;
+  p.xcdmap = 0;
+  static const int xcdmap_env = [] { const char* e = getenv("STARCOP_MFMA_XCDMAP"); return e ? atoi(e) : 0; }();   // measured: no gain for the 1x1 layers (2.82 vs 2.89 ms per step): off
+  if (a->co_t != 16 && xcdmap_env) {
+    const long total = (long)grid.x * a->N, per_xcd = (total + 7) / 8;
+    SC_REQUIRE(per_xcd * 8 * co_tiles < (1L << 31), "sc_conv2d_mfma: grid too large");
+    grid = dim3((unsigned)(per_xcd * 8 * co_tiles));
+    p.xcdmap = 1;
+  }
   if (a->co_t == 16) {
     const bool bnb = a->src[0].mode == SC_SRC_BNBWD;
     if (a->H >= 8) {          // 8-row tiles (two rows per wave): measured 0.58 -> 0.49 ms on 32->16 channels at 512^2
@@ -1175,6 +1200,7 @@ extern "C" int sc_conv1x1_ksplit(const sc_conv_args* a, sc_stream stream) {
   SC_REQUIRE(a->csplit > 0 && a->csplit <= a->Cout, "sc_conv1x1_ksplit: bad csplit");
   SC_REQUIRE(a->csplit == a->Cout || (a->add0 == nullptr && a->add1 == nullptr), "sc_conv1x1_ksplit: add tensors need a single output");
   ConvP p;
+  p.xcdmap = 0;
   p.s0 = to_srcd(a->src[0]); p.s1 = empty_srcd();
   p.wpk = a->wpk; p.N = a->N; p.H = a->H; p.W = a->W; p.Cout = a->Cout;
   p.out0 = a->out0; p.out1 = a->out1; p.csplit = a->csplit; p.accum0 = a->accum0; p.accum1 = a->accum1;
