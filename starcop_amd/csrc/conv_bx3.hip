@@ -590,7 +590,6 @@ __device__ __forceinline__ void split_filter(float v, bool half, unsigned short 
 //   D: lane -> pixel l&15, couts 4*(l>>4) .. +3
 // Work-group = 4 waves, tile 8 rows x 32 px; wave = 2 rows = four 16-pixel blocks.  Single source (may be upsampled), single
 // output, optional statistics rows (SC_STAT_CONV3 layout); anything else stays on the other kernels.
-constexpr int SC_THIN_TPW = 1;          // pixel tiles per work-group of k_conv3_thin_h (measured: 4 tiles with the filters loaded once = 0.81 vs 0.73 ms per step: the serial load -> split -> MFMA -> store chain per tile needs the extra work-groups to hide its latency)
 template <int CIN, bool BNB>
 __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
   constexpr int PR = 10, PC = 34, NPX = PR * PC;
@@ -604,6 +603,17 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
   const int l15 = lane & 15, lg = lane >> 4;
   const int H = p.H, W = p.W;
   const int tiles_x = (W + 31) >> 5;
+  int n, tile;
+  if (p.xcdmap) {      // each XCD walks a contiguous eighth of the pixel tiles (see k_conv3_bx3): halo lines shared in its L2
+    const int per_img = tiles_x * ((H + 7) >> 3), total = per_img * p.N, per_xcd = (total + 7) >> 3;
+    const int j = blockIdx.x >> 3, pt = (blockIdx.x & 7) * per_xcd + j;
+    if (j >= per_xcd || pt >= total) return;
+    n = pt / per_img; tile = pt - n * per_img;
+  } else {
+    n = blockIdx.z; tile = blockIdx.x;
+  }
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int y0 = ty * 8, x0 = tx * 32;
   const float hsx = BNB ? h_grad_scale(p.absmax) : SC_H_SX;
   const float hinv = 1.f / (hsx * SC_H_SW);
 
@@ -612,25 +622,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
   for (int s = 0; s < NS; ++s)
 #pragma unroll
     for (int t = 0; t < 2; ++t) A[s][t] = p.wpk[(s * 2 + t) * 64 + lane];
-
-  // A work-group's filter registers (10-18 KB per wave, fetched through L2) cost more bytes than the patch of one tile: in the
-  // XCD-mapped numbering a work-group therefore walks SC_THIN_TPW consecutive (x-adjacent) pixel tiles with the filters loaded once.
-  // Each XCD walks a contiguous eighth of the pixel tiles (see k_conv3_bx3): halo lines are shared in its L2.
-  const int per_img = tiles_x * ((H + 7) >> 3), total = per_img * p.N;
-  int pt_begin, pt_end;
-  if (p.xcdmap) {
-    const int per_xcd = (total + 7) >> 3;
-    const int j0 = (int)(blockIdx.x >> 3) * SC_THIN_TPW, base = (int)(blockIdx.x & 7) * per_xcd;
-    pt_begin = base + j0;
-    pt_end = min(min(base + j0 + SC_THIN_TPW, base + per_xcd), total);
-  } else {
-    pt_begin = (int)blockIdx.z * per_img + (int)blockIdx.x; pt_end = pt_begin + 1;
-  }
-  for (int pt = pt_begin; pt < pt_end; ++pt) {
-  if (pt != pt_begin) __syncthreads();          // the previous tile's MFMAs / statistics are done with the LDS buffers
-  const int n = pt / per_img, tile = pt - n * per_img;
-  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-  const int y0 = ty * 8, x0 = tx * 32;
 
   // ---- stage the patch: entry q -> (channel group, patch pixel); consecutive lanes = consecutive pixels
   const SrcD& src = p.s0;
@@ -744,7 +735,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
       }
     }
   }
-  }   // tiles of this work-group
 }
 
 // filters of a thin layer in the register layout of k_conv3_thin_h: entry ((s*2 + term)*64 + lane) of 8 halves
@@ -1338,7 +1328,7 @@ extern "C" int sc_conv3x3_thin16(const sc_conv_args* a, sc_stream stream) {
   p.xcdmap = xcdmap_env ? 2 : 0;
   if (p.xcdmap) {
     const long total = (long)grid.x * a->N, per_xcd = (total + 7) / 8;
-    grid = dim3((unsigned)((per_xcd + SC_THIN_TPW - 1) / SC_THIN_TPW * 8));
+    grid = dim3((unsigned)(per_xcd * 8));
   }
   hipStream_t st = (hipStream_t)stream;
   const bool bnb = s.mode == SC_SRC_BNBWD;

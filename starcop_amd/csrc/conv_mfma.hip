@@ -32,7 +32,7 @@ struct ConvP {
 };
 
 // BNB: the (single) source is a BatchNorm-backward source (dgrad launches); mixing it with other modes in a concat is not used
-template <int KS, int RM, bool BNB>
+template <int KS, int RM, bool BNB, int PF_ = 1>
 __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
   constexpr int TAPS = KS * KS;
   constexpr int CO_T = 32 * RM;
@@ -117,48 +117,55 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
       inb |= ok ? (1u << i) : 0u;
     }
   }
-  float xv[NC][NE], av[BNB ? NC : 1][NE];
-  bool chok[NC];
-  float4 c0[NC];
-  float c4[NC];
-  floatx4 wv[NW];
-  float slo = 0.f, shi = 0.f;
+  // Staging registers of one K chunk.  1x1 layers keep TWO chunks in flight (PF = 2): their work per chunk (16 channels x 128 pixels,
+  // 8-16 MFMAs per wave) is far shorter than a memory round trip, so with one chunk of look-ahead every iteration waits for its loads
+  // (measured: 2.9k cycles per chunk against ~1k of MFMA); 3x3 chunks carry 9x the MFMA work and stay at one.
+  constexpr int PF = (KS == 1) ? PF_ : 1;
+  struct Stg {
+    float xv[NC][NE], av[BNB ? NC : 1][NE];
+    bool chok[NC];
+    float4 c0[NC];
+    float c4[NC];
+    floatx4 wv[NW];
+    float slo, shi;
+  };
+  Stg stg[PF];
 
-  auto load_chunk = [&](int kc) {
+  auto load_chunk = [&](int kc, Stg& g) {
     // the source (of a concat) is uniform per chunk: KC divides the first source's channel count when nsrc == 2
     const bool second = kc * KC >= C0;
     const SrcD& s = second ? p.s1 : p.s0;
-    slo = sc_act_lo(s.act); shi = sc_act_hi(s.act);
+    g.slo = sc_act_lo(s.act); g.shi = sc_act_hi(s.act);
     const size_t plane = (size_t)(H >> s.up) * (W >> s.up);
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc) {
       const int cg = kc * KC + sci + 8 * cc;          // channel in concat space
-      chok[cc] = cg < Cin;
-      const int cs = chok[cc] ? (second ? cg - C0 : cg) : 0;
+      g.chok[cc] = cg < Cin;
+      const int cs = g.chok[cc] ? (second ? cg - C0 : cg) : 0;
       if (s.mode != SC_SRC_RAW) {
-        c0[cc] = *reinterpret_cast<const float4*>(s.cst + (size_t)cs * SC_CST);
-        c4[cc] = BNB ? s.cst[(size_t)cs * SC_CST + 4] : 0.f;
+        g.c0[cc] = *reinterpret_cast<const float4*>(s.cst + (size_t)cs * SC_CST);
+        g.c4[cc] = BNB ? s.cst[(size_t)cs * SC_CST + 4] : 0.f;
       } else {
-        c0[cc] = make_float4(1.f, 0.f, 0.f, 0.f); c4[cc] = 0.f;
+        g.c0[cc] = make_float4(1.f, 0.f, 0.f, 0.f); g.c4[cc] = 0.f;
       }
       const float* xb = s.x + ((size_t)n * s.C + cs) * plane;
       const float* ab = BNB ? s.aux + ((size_t)n * s.C + cs) * plane : nullptr;
 #pragma unroll
       for (int i = 0; i < NE; ++i) {
         const unsigned o = second ? off1[i] : off0[i];
-        xv[cc][i] = xb[o];
-        if (BNB) av[cc][i] = ab[o];
+        g.xv[cc][i] = xb[o];
+        if (BNB) g.av[cc][i] = ab[o];
       }
     }
     const floatx4* wsrc = reinterpret_cast<const floatx4*>(wbase + (size_t)kc * WCH);
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int i4 = tid + 256 * j;
-      wv[j] = wsrc[i4 < WCH / 4 ? i4 : WCH / 4 - 1];   // clamped: unconditional load keeps wv in registers
+      g.wv[j] = wsrc[i4 < WCH / 4 ? i4 : WCH / 4 - 1];   // clamped: unconditional load keeps wv in registers
     }
   };
 
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, const Stg& g) {
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc) {
       const int chl = sci + 8 * cc;
@@ -166,16 +173,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
       for (int i = 0; i < NE; ++i) {
         const int e = sq + 32 * i;
         if (e < PCH) {
-          const float v = BNB ? sc_pro_bnbwd(xv[cc][i], av[BNB ? cc : 0][i], c0[cc].x, c0[cc].y, c0[cc].z, c0[cc].w, c4[cc], slo, shi)
-                              : sc_pro_affine(xv[cc][i], c0[cc].x, c0[cc].y, slo, shi);
-          s_p[buf][chl * PCH + e] = (((inb >> i) & 1u) && chok[cc]) ? v : 0.f;
+          const float v = BNB ? sc_pro_bnbwd(g.xv[cc][i], g.av[BNB ? cc : 0][i], g.c0[cc].x, g.c0[cc].y, g.c0[cc].z, g.c0[cc].w, g.c4[cc], g.slo, g.shi)
+                              : sc_pro_affine(g.xv[cc][i], g.c0[cc].x, g.c0[cc].y, g.slo, g.shi);
+          s_p[buf][chl * PCH + e] = (((inb >> i) & 1u) && g.chok[cc]) ? v : 0.f;
         }
       }
     }
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int i4 = tid + 256 * j;
-      if (i4 < WCH / 4) *reinterpret_cast<floatx4*>(&s_w[buf][i4 * 4]) = wv[j];
+      if (i4 < WCH / 4) *reinterpret_cast<floatx4*>(&s_w[buf][i4 * 4]) = g.wv[j];
     }
   };
 
@@ -195,21 +202,45 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
 #pragma unroll
         for (int m = 0; m < RM; ++m) {
           const float a = s_w[buf][(cil * TAPS + tap) * CO_T + m * 32 + l31];
+#ifdef SC_EXPERIMENT_SKIP_MFMA
+          acc[m][0] = fmaf(a, b, acc[m][0]);      // timing experiment only: operand traffic without the matrix work
+#else
           acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m], 0, 0, 0);
+#endif
         }
       }
     }
   };
 
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-  for (int kc = 0; kc < nk; ++kc) {
-    const bool more = (kc + 1) < nk;
-    if (more) load_chunk(kc + 1);
-    compute_chunk(kc & 1);
-    if (more) store_chunk((kc + 1) & 1);
+  if (PF == 1) {
+    load_chunk(0, stg[0]);
+    store_chunk(0, stg[0]);
     __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+      const bool more = (kc + 1) < nk;
+      if (more) load_chunk(kc + 1, stg[0]);
+      compute_chunk(kc & 1);
+      if (more) store_chunk((kc + 1) & 1, stg[0]);
+      __syncthreads();
+    }
+  } else {
+    // chunk kc + 1 was loaded one iteration ago into stg[(kc + 1) & 1]; chunk kc + 2 is requested now into the other set
+    load_chunk(0, stg[0]);
+    if (nk > 1) load_chunk(1, stg[PF - 1]);
+    store_chunk(0, stg[0]);
+    __syncthreads();
+    for (int kc = 0; kc < nk; kc += 2) {
+      if (kc + 2 < nk) load_chunk(kc + 2, stg[0]);
+      compute_chunk(0);
+      if (kc + 1 < nk) store_chunk(1, stg[PF - 1]);
+      __syncthreads();
+      if (kc + 1 < nk) {
+        if (kc + 3 < nk) load_chunk(kc + 3, stg[PF - 1]);
+        compute_chunk(1);
+        if (kc + 2 < nk) store_chunk(0, stg[0]);
+        __syncthreads();
+      }
+    }
   }
 
   // ---- epilogue ----
@@ -629,6 +660,9 @@ __global__ void k_pack_weights(const float* __restrict__ w, float* __restrict__ 
 // weight gradient.  GEMM view: D[co][ci] (per tap) = sum_pixels dy[co][pix] * in[ci][pix + d(tap)]
 //   A: lane -> dy_lds[co = l&31][pix = 2q + (l>>5)],  B: lane -> in_lds[ci = l&31][pix(+tap)]
 // Work-group tile (32*WM couts) x (32*WN cins), WK = 4/(WM*WN) waves split the pixel rows of a stage.
+#ifndef SC_WG1_OCC
+#define SC_WG1_OCC 1
+#endif
 struct WgradP {
   SrcD dy, s0, s1;
   int N, H, W, Cout, Cin;
@@ -638,7 +672,7 @@ struct WgradP {
 };
 
 template <int KS, int WM, int WN>
-__global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradP p) {
+__global__ __launch_bounds__(256, KS == 1 ? SC_WG1_OCC : 1) void k_wgrad_mfma(const WgradP p) {
   constexpr int TAPS = KS * KS;
   constexpr int WK = 4 / (WM * WN);
   constexpr int SR = (WK == 4) ? 4 : 2;        // pixel rows (of 32) per stage
@@ -1178,10 +1212,17 @@ extern "C" int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream) {
       if (bnb) hipLaunchKernelGGL((k_conv_mfma<KS_, RM_, true>), grid, dim3(256), 0, st, p);          \
       else hipLaunchKernelGGL((k_conv_mfma<KS_, RM_, false>), grid, dim3(256), 0, st, p);             \
     } while (0)
+    static const int pf_env = [] { const char* e = getenv("STARCOP_PW_PF"); return e ? atoi(e) : 1; }();
+#define SC_CM2(RM_)                                                                                  \
+    do {                                                                                              \
+      if (bnb) hipLaunchKernelGGL((k_conv_mfma<1, RM_, true, 2>), grid, dim3(256), 0, st, p);         \
+      else hipLaunchKernelGGL((k_conv_mfma<1, RM_, false, 2>), grid, dim3(256), 0, st, p);            \
+    } while (0)
     if (a->ks == 3 && a->co_t == 64) SC_CM(3, 2);
     else if (a->ks == 3) SC_CM(3, 1);
-    else if (a->co_t == 64) SC_CM(1, 2);
-    else SC_CM(1, 1);
+    else if (a->co_t == 64) { if (pf_env == 2) SC_CM2(2); else SC_CM(1, 2); }
+    else { if (pf_env == 2) SC_CM2(1); else SC_CM(1, 1); }
+#undef SC_CM2
 #undef SC_CM
   }
   SC_LAUNCH_OK("sc_conv2d_mfma");
