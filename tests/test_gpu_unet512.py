@@ -109,3 +109,34 @@ def test_train_forward_loss_b16_512(hip):
     assert e64 < max(1e-4, 1.25 * r64)
     assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
     assert all(bool(torch.isfinite(p).all()) for p in model.network.parameters())
+
+
+def test_bf16_mode_trains_like_fp32_at_512(hip):
+    """BASELINE configs[3] shape family (batch 16 x 4 x 512 x 512; 64 per GPU only changes the batch dimension): the bf16 matrix-math
+    mode (one bf16 term per operand in the 3x3 convolutions, fp32 accumulation / storage / optimiser state) against the fp32 default --
+    SURVEY 8d's bf16 gate: the masks after training agree in F1 within 0.005.  Every precision mode (fp32-x3 included) goes through ONE
+    loss blow-up of this Adam(lr 1e-3) + BatchNorm recipe between steps 350 and 500 and recovers (tools/debug_train512.py); 1000 steps
+    end well after it, on the same plateau (the step is bit-reproducible run to run, so the trajectory is too)"""
+    import bench
+    from starcop_amd import model_module as mm
+    B, steps = 16, 1000
+    train = bench.synth_batch(B, T, T, 4321, DEV)
+    res = {}
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(0)
+        model = mm.ModelModule(mm.default_settings(pos_weight=1, lr=1e-3, precision=prec)).to(DEV).train()
+        opt = model.configure_optimizers()["optimizer"]
+        losses = [float(model.fused_train_step(train, opt).item()) / (B * T * T) for _ in range(steps)]
+        model.eval()
+        with torch.no_grad():
+            pred = (model(train["input"]) >= 0).long()
+        y = train["output"].long()
+        tp = int(((pred == 1) & (y == 1)).sum()); fp = int(((pred == 1) & (y == 0)).sum()); fn = int(((pred == 0) & (y == 1)).sum())
+        res[prec] = (losses, 2 * tp / max(2 * tp + fp + fn, 1))
+    (l32, f32), (l16, f16) = res["fp32"], res["bf16"]
+    m32, m16 = float(np.median(l32[-50:])), float(np.median(l16[-50:]))
+    print(f"bf16 gate 512^2 b16, {steps} steps: loss fp32 {l32[0]:.4f} -> median(last 50) {m32:.5f}, bf16 {l16[0]:.4f} -> {m16:.5f}; "
+          f"F1 fp32 {f32:.4f}, bf16 {f16:.4f}")
+    assert m32 < 0.05 * l32[0] and m16 < 0.05 * l16[0]                            # both fit the tiles
+    assert abs(l16[0] - l32[0]) < 2e-2 * l32[0]                                   # same start: bf16 rounding only
+    assert f32 > 0.98 and f16 > 0.98 and abs(f16 - f32) <= 0.005, (f16, f32)
