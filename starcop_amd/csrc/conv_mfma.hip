@@ -39,9 +39,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
   constexpr int PR = (KS == 3) ? 6 : 4;
   constexpr int PC = (KS == 3) ? 34 : 32;
   constexpr int PCH = PR * PC;                 // patch floats per channel
-  constexpr int NE = (PCH + 31) / 32;          // patch elements per thread (32 threads per channel)
   constexpr int KC = (KS == 3) ? 8 : 16;       // input channels per K chunk (one barrier per chunk)
-  constexpr int NC = KC / 8;                   // channels staged per thread (8 half-waves, one channel each, NC rounds)
+  // staging decomposition.  3x3: a half-wave per channel (8 channels per round), 32 lanes over the 6x34 patch.  1x1: a WAVE per
+  // channel (4 per round, 4 rounds), 64 lanes over the 128 pixels in two slots: the channel is wave-uniform, so its plane pointer
+  // and BatchNorm constants live in SGPRs and a staged element costs one global load + the prologue instead of per-lane 64-bit
+  // address arithmetic and constant broadcasts (these kernels were VALU-issue bound: 940 VALU per 141 MFMA per wave, SQ counters
+  // in profiles/r02_pmc_sq_pointwise.txt)
+  constexpr int NE = (KS == 3) ? (PCH + 31) / 32 : 2;
+  constexpr int NC = (KS == 3) ? KC / 8 : KC / 4;
   constexpr int WCH = KC * TAPS * CO_T;        // weight floats per chunk
   constexpr int NW = (WCH / 4 + 255) / 256;    // float4 per thread
 
@@ -90,8 +95,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
   // ---- staging state (registers) ----
-  const int sci = tid >> 5;     // channel of the chunk this thread stages
-  const int sq = tid & 31;
+  const int sci = (KS == 3) ? tid >> 5 : __builtin_amdgcn_readfirstlane(tid >> 6);     // first channel of the chunk this thread stages
+  const int sq = (KS == 3) ? tid & 31 : tid & 63;
+  constexpr int CSTEP = (KS == 3) ? 8 : 4, ESTEP = (KS == 3) ? 32 : 64;
   // pixel offsets of this thread's patch positions: the same for every chunk (per source: `up` may differ)
   unsigned off0[NE], off1[NE];
   unsigned inb = 0;
@@ -109,9 +115,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
         off0[i] = ok ? (unsigned)((y >> up0) * Ws0 + (x >> up0)) : 0u;      // clamped: unconditional loads, no exec-mask branches
         off1[i] = ok ? (unsigned)((y >> up1) * Ws1 + (x >> up1)) : 0u;
       } else {
-        const int pix = p0 + sq + 32 * i;
+        const int pix = p0 + sq + ESTEP * i;
         ok = pix < H * W;
-        off0[i] = ok ? (unsigned)pix : 0u;
+        off0[i] = ok ? (unsigned)pix : (unsigned)(H * W - 1);      // clamped to a valid pixel: a 1x1 output depends on its own pixel only
         off1[i] = off0[i];
       }
       inb |= ok ? (1u << i) : 0u;
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
     const size_t plane = (size_t)(H >> s.up) * (W >> s.up);
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc) {
-      const int cg = kc * KC + sci + 8 * cc;          // channel in concat space
+      const int cg = kc * KC + sci + CSTEP * cc;      // channel in concat space
       g.chok[cc] = cg < Cin;
       const int cs = g.chok[cc] ? (second ? cg - C0 : cg) : 0;
       if (s.mode != SC_SRC_RAW) {
@@ -168,14 +174,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
   auto store_chunk = [&](int buf, const Stg& g) {
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc) {
-      const int chl = sci + 8 * cc;
+      const int chl = sci + CSTEP * cc;
 #pragma unroll
       for (int i = 0; i < NE; ++i) {
-        const int e = sq + 32 * i;
+        const int e = sq + ESTEP * i;
         if (e < PCH) {
           const float v = BNB ? sc_pro_bnbwd(g.xv[cc][i], g.av[BNB ? cc : 0][i], g.c0[cc].x, g.c0[cc].y, g.c0[cc].z, g.c0[cc].w, g.c4[cc], g.slo, g.shi)
                               : sc_pro_affine(g.xv[cc][i], g.c0[cc].x, g.c0[cc].y, g.slo, g.shi);
-          s_p[buf][chl * PCH + e] = (((inb >> i) & 1u) && g.chok[cc]) ? v : 0.f;
+          // 1x1: out-of-range pixel slots hold a clamped duplicate (their outputs are masked in the epilogue); padded channels are zero
+          if (KS == 3) s_p[buf][chl * PCH + e] = (((inb >> i) & 1u) && g.chok[cc]) ? v : 0.f;
+          else s_p[buf][chl * PCH + e] = g.chok[cc] ? v : 0.f;
         }
       }
     }
