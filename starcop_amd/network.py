@@ -100,13 +100,16 @@ class _T:
         self.res_grad = None        # 'fin' tensor z = self + ...: z.grad must be added to self.grad
 
 
+_COT_RATIO = float(os.environ.get("STARCOP_COT_RATIO", "1.15"))
+
+
 def _pick_cot(M, ks=1):
     if M <= 16 and ks == 3:
         return 16            # thin layers: v_mfma_f32_16x16x4_f32 kernel, no wasted MFMA rows
     if M <= 32:
         return 32
     p32, p64 = -(-M // 32) * 32, -(-M // 64) * 64
-    return 64 if p64 <= p32 * 1.15 else 32
+    return 64 if p64 <= p32 * _COT_RATIO else 32
 
 
 def _use_ksplit(N, HW, K, M, ks=1):
