@@ -265,6 +265,14 @@ int sc_downsum2x2(const float* in, float* out, int accum, int N, int C, int Hout
  *   sc_upsample_bilinear2x : F.interpolate(scale_factor=2, mode='bilinear', align_corners=True)   in [N,C,Hin,Win] -> out [N,C,2Hin,2Win] */
 int sc_maxpool2x2(const sc_src* in, float* out, int N, int C, int Hout, int Wout, sc_stream stream);
 int sc_upsample_bilinear2x(const sc_src* in, float* out, int N, int C, int Hin, int Win, sc_stream stream);
+/* their backward passes (autograd of the same two torch ops):
+ *   sc_maxpool2x2_bwd          : gin[window] (+)= gpool at the FIRST maximum of each 2x2 window of v(in) (row-major order, as
+ *                                max_pool2d_with_indices), 0 elsewhere;  in [N,C,2Hout,2Wout], gpool [N,C,Hout,Wout]
+ *   sc_upsample_bilinear2x_bwd : gin [N,C,Hin,Win] = transpose of the interpolation applied to gout [N,C,2Hin,2Win]; a gather
+ *                                with the forward weights (deterministic, no atomics)                                       */
+int sc_maxpool2x2_bwd(const sc_src* in, const float* gpool, float* gin, int accum, int N, int C, int Hout, int Wout,
+                      sc_stream stream);
+int sc_upsample_bilinear2x_bwd(const float* gout, float* gin, int N, int C, int Hin, int Win, sc_stream stream);
 int sc_fill_f64(double* p, double v, size_t n, sc_stream stream);
 int sc_apply_src(const sc_src* a, float* out, int N, int C, int HW, sc_stream stream);
 

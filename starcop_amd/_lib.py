@@ -134,6 +134,8 @@ SIGNATURES = {
     "sc_wgrad_reduce_batch": (_i, [_vp, _vp, _i, C.c_uint32, _vp]),
     "sc_maxpool2x2": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _i, _vp]),
     "sc_upsample_bilinear2x": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _i, _vp]),
+    "sc_maxpool2x2_bwd": (_i, [C.POINTER(sc_src), _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sc_upsample_bilinear2x_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sc_tiff_lzw_decode": (_i, [_vp, _sz, _vp, _sz, C.POINTER(C.c_size_t)]),
     "sc_tiff_unpredict": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp]),
 }

@@ -296,6 +296,67 @@ __global__ __launch_bounds__(256) void k_upsample_bilinear2x(const SrcD a, float
   }
 }
 
+// backward of nn.MaxPool2d(2): the gradient of a pooled pixel goes to the FIRST maximum of its 2x2 window in row-major order (what
+// torch's max_pool2d_with_indices records); the window values are read through the source's prologue, like the forward
+__global__ __launch_bounds__(256) void k_maxpool2x2_bwd(const SrcD a, const float* __restrict__ gp, float* __restrict__ gin, int accum,
+                                                        int C, int Hout, int Wout) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f); float a4 = 0.f;
+  if (a.mode != SC_SRC_RAW) { a0 = *reinterpret_cast<const float4*>(a.cst + (size_t)c * SC_CST); a4 = a.cst[(size_t)c * SC_CST + 4]; }
+  const size_t ibase = ((size_t)n * C + c) * (size_t)(4 * Hout * Wout), obase = ((size_t)n * C + c) * (size_t)(Hout * Wout);
+  const int Win = 2 * Wout;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < Hout * Wout; i += gridDim.x * 256) {
+    const int y = i / Wout, x = i - y * Wout;
+    const size_t p = ibase + (size_t)(2 * y) * Win + 2 * x;
+    const float v[4] = {ld_src(a, p, a0, a4), ld_src(a, p + 1, a0, a4), ld_src(a, p + Win, a0, a4), ld_src(a, p + Win + 1, a0, a4)};
+    int best = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) if (v[k] > v[best]) best = k;
+    const float g = gp[obase + i];
+    const size_t q[4] = {p, p + 1, p + Win, p + Win + 1};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float t = (k == best) ? g : 0.f;
+      gin[q[k]] = accum ? gin[q[k]] + t : t;
+    }
+  }
+}
+
+// backward of the bilinear x2 upsampling (align_corners=True) as a GATHER (deterministic, no atomics): input pixel (y, x) collects
+// every output pixel whose two source rows / columns include it, with exactly the forward kernel's weights
+__device__ __forceinline__ void bil_src(int Y, int Hin, float sh, int& y0, int& y1, float& ly) {
+  const float fy = sh * (float)Y;
+  y0 = (int)fy; y1 = y0 + (y0 < Hin - 1 ? 1 : 0); ly = fy - (float)y0;
+}
+__global__ __launch_bounds__(256) void k_upsample_bilinear2x_bwd(const float* __restrict__ gout, float* __restrict__ gin, int C, int Hin, int Win) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int Ho = 2 * Hin, Wo = 2 * Win;
+  const float sh = Ho > 1 ? (float)(Hin - 1) / (float)(Ho - 1) : 0.f, sw = Wo > 1 ? (float)(Win - 1) / (float)(Wo - 1) : 0.f;
+  const size_t ibase = ((size_t)n * C + c) * (size_t)(Hin * Win), obase = ((size_t)n * C + c) * (size_t)(Ho * Wo);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < Hin * Win; i += gridDim.x * 256) {
+    const int y = i / Win, x = i - y * Win;
+    // output rows whose source position lies in (y - 1, y + 1): Y in [(y - 1) / sh, (y + 1) / sh]; two spare rows on either side
+    const int Ylo = sh > 0.f ? max(0, (int)((float)(y - 1) / sh) - 1) : 0, Yhi = sh > 0.f ? min(Ho - 1, (int)((float)(y + 1) / sh) + 2) : Ho - 1;
+    const int Xlo = sw > 0.f ? max(0, (int)((float)(x - 1) / sw) - 1) : 0, Xhi = sw > 0.f ? min(Wo - 1, (int)((float)(x + 1) / sw) + 2) : Wo - 1;
+    float acc = 0.f;
+    for (int Y = Ylo; Y <= Yhi; ++Y) {
+      int y0, y1; float ly;
+      bil_src(Y, Hin, sh, y0, y1, ly);
+      const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+      if (wy == 0.f) continue;
+      float row = 0.f;
+      for (int X = Xlo; X <= Xhi; ++X) {
+        int x0, x1; float lx;
+        bil_src(X, Win, sw, x0, x1, lx);
+        const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+        if (wx != 0.f) row = fmaf(wx, gout[obase + (size_t)Y * Wo + X], row);
+      }
+      acc = fmaf(wy, row, acc);
+    }
+    gin[ibase + i] = acc;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_downsum2x2(const float* __restrict__ in, float* __restrict__ out, int accum,
                                                     int Hout, int Wout, size_t total) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -528,6 +589,24 @@ extern "C" int sc_upsample_bilinear2x(const sc_src* in, float* out, int N, int C
   dim3 grid((4 * Hin * Win + 1023) / 1024, C, N);
   hipLaunchKernelGGL(k_upsample_bilinear2x, grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), out, C, Hin, Win);
   SC_LAUNCH_OK("sc_upsample_bilinear2x");
+  return SC_OK;
+}
+
+extern "C" int sc_maxpool2x2_bwd(const sc_src* in, const float* gpool, float* gin, int accum, int N, int C, int Hout, int Wout,
+                                 sc_stream stream) {
+  SC_REQUIRE(in && in->x && gpool && gin && N > 0 && C > 0 && Hout > 0 && Wout > 0 && in->up == 0, "sc_maxpool2x2_bwd: bad argument");
+  SC_REQUIRE(in->mode != SC_SRC_BNBWD, "sc_maxpool2x2_bwd: forward sources only");
+  dim3 grid((Hout * Wout + 1023) / 1024, C, N);
+  hipLaunchKernelGGL(k_maxpool2x2_bwd, grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), gpool, gin, accum, C, Hout, Wout);
+  SC_LAUNCH_OK("sc_maxpool2x2_bwd");
+  return SC_OK;
+}
+
+extern "C" int sc_upsample_bilinear2x_bwd(const float* gout, float* gin, int N, int C, int Hin, int Win, sc_stream stream) {
+  SC_REQUIRE(gout && gin && N > 0 && C > 0 && Hin > 0 && Win > 0, "sc_upsample_bilinear2x_bwd: bad argument");
+  dim3 grid((Hin * Win + 1023) / 1024, C, N);
+  hipLaunchKernelGGL(k_upsample_bilinear2x_bwd, grid, dim3(256), 0, (hipStream_t)stream, gout, gin, C, Hin, Win);
+  SC_LAUNCH_OK("sc_upsample_bilinear2x_bwd");
   return SC_OK;
 }
 

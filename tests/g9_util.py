@@ -105,3 +105,25 @@ def full_unet_state():
 def full_unet_input(tag):
     shape = tuple(int(v) for v in load()[f"unet_full.{tag}.shape"])
     return torch.from_numpy(_fill(np.random.default_rng(FULL_SEED + 1 + len(tag) + shape[0]), shape, 1.5))
+
+
+def full_unet_grad_case():
+    """input and upstream gradient of the golden backward case (unet_full.grad.*): L = sum(y * r) on the 1x4x64x64 input"""
+    x = torch.from_numpy(_fill(np.random.default_rng(FULL_SEED + 3), (1, 4, 64, 64), 1.5))
+    r = torch.from_numpy(_fill(np.random.default_rng(FULL_SEED + 77), (1, 1, 64, 64), 1.0))
+    return x, r
+
+
+def full_unet_grad_errs(z, grads):
+    """{name: rel err} of parameter gradients (dict name -> tensor) against the golden marginal sums / bias gradients"""
+    errs = {}
+    for k in FULL_KEYS:
+        g = grads[k].detach().double().cpu().numpy()
+        if g.ndim == 1:
+            want = z[f"unet_full.grad.{k}"]
+            errs[k] = float(np.abs(g - want).max() / max(float(np.abs(want).max()), 1e-3))
+        else:
+            for tag, ax in (("cisum", 1), ("cosum", 0)):
+                want = z[f"unet_full.grad.{k}.{tag}"]
+                errs[f"{k}.{tag}"] = float(np.abs(g.sum(axis=ax) - want).max() / max(float(np.abs(want).max()), 1e-3))
+    return errs

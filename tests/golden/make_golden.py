@@ -341,6 +341,20 @@ def g9_convblocks():
             x = torch.from_numpy(g9_fill(np.random.default_rng(G9_FULL_SEED + 1 + len(tag) + shape[0]), shape, 1.5))
             out[f"unet_full.{tag}.y"] = full(x).numpy()
             out[f"unet_full.{tag}.shape"] = np.array(shape, dtype=np.int64)
+    # backward of the whole network (conv / ReLU / MaxPool2d / bilinear-upsample autograd, 15 convolutions deep): L = sum(y * r);
+    # stored per parameter: bias gradients in full, filter gradients as their two marginal sums (over cin and over cout, fp64)
+    x = torch.from_numpy(g9_fill(np.random.default_rng(G9_FULL_SEED + 3), (1, 4, 64, 64), 1.5))
+    y = full(x)
+    r = torch.from_numpy(g9_fill(np.random.default_rng(G9_FULL_SEED + 77), tuple(y.shape), 1.0))
+    full.zero_grad()
+    (y * r).sum().backward()
+    for k, p_ in full.named_parameters():
+        gk = p_.grad.numpy().astype(np.float64)
+        if gk.ndim == 1:
+            out[f"unet_full.grad.{k}"] = gk
+        else:
+            out[f"unet_full.grad.{k}.cisum"] = gk.sum(axis=1)
+            out[f"unet_full.grad.{k}.cosum"] = gk.sum(axis=0)
     np.savez_compressed(os.path.join(OUT, "g9_convblocks.npz"), **out)
 
 
