@@ -108,9 +108,12 @@ def full_unet_input(tag):
 
 
 def full_unet_grad_case():
-    """input and upstream gradient of the golden backward case (unet_full.grad.*): L = sum(y * r) on the 1x4x64x64 input"""
-    x = torch.from_numpy(_fill(np.random.default_rng(FULL_SEED + 3), (1, 4, 64, 64), 1.5))
-    r = torch.from_numpy(_fill(np.random.default_rng(FULL_SEED + 77), (1, 1, 64, 64), 1.0))
+    """input and upstream gradient of the golden backward case (unet_full.grad.*): L = sum(y * r); seed and shape from the fixture
+    (make_golden advances the input seed until no ReLU / max-pool switch of the whole network sits within 1e-5 of flipping)"""
+    meta = load()["unet_full.grad.meta"]
+    seed, shape = int(meta[0]), tuple(int(v) for v in meta[1:])
+    x = torch.from_numpy(_fill(np.random.default_rng(seed), shape, 1.5))
+    r = torch.from_numpy(_fill(np.random.default_rng(seed + 77), (shape[0], 1) + shape[2:], 1.0))
     return x, r
 
 

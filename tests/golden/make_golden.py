@@ -341,13 +341,44 @@ def g9_convblocks():
             x = torch.from_numpy(g9_fill(np.random.default_rng(G9_FULL_SEED + 1 + len(tag) + shape[0]), shape, 1.5))
             out[f"unet_full.{tag}.y"] = full(x).numpy()
             out[f"unet_full.{tag}.shape"] = np.array(shape, dtype=np.int64)
-    # backward of the whole network (conv / ReLU / MaxPool2d / bilinear-upsample autograd, 15 convolutions deep): L = sum(y * r);
+    # backward of the whole network (conv / ReLU / MaxPool2d / bilinear-upsample autograd, 15 convolutions deep): L = sum(y * r).
+    # A ReLU input within rounding of zero, or a max-pool window whose two largest values are within rounding of each other, is a
+    # discrete switch that two correct fp32 implementations may set differently -- and ONE flipped pixel moves every upstream
+    # gradient sum by ~1 % (sums of random-sign terms are only sqrt(n) larger than a term).  The case is therefore small
+    # (2 x 4 x 16 x 16: ~0.25 M activations) and its input seed is advanced until every ReLU input is further than
+    # G9_RELU_MARGIN from zero and every positive pooling window has a top-2 gap above it.
     # stored per parameter: bias gradients in full, filter gradients as their two marginal sums (over cin and over cout, fp64)
-    x = torch.from_numpy(g9_fill(np.random.default_rng(G9_FULL_SEED + 3), (1, 4, 64, 64), 1.5))
+    margins = []
+    hooks = [m.register_forward_hook(lambda mod, i, o: margins.append(float(o.detach().abs().min())))
+             for n_, m in full.named_modules() if isinstance(m, torch.nn.Conv2d) and n_ != "conv_last"]
+
+    def pool_gap(mod, i, o):
+        t = torch.nn.functional.unfold(i[0].detach(), 2, stride=2).reshape(i[0].shape[0], i[0].shape[1], 4, -1)
+        top = t.topk(2, dim=2).values
+        pos = top[:, :, 0] > 0
+        if bool(pos.any()):
+            margins.append(float((top[:, :, 0] - top[:, :, 1])[pos].min()))
+    hooks.append(full.maxpool.register_forward_hook(pool_gap))
+    best = (-1.0, -1)
+    gshape = (2, 4, 16, 16)
+    for seed in list(range(G9_FULL_SEED + 100, G9_FULL_SEED + 100 + 3000)) + [None]:
+        if seed is None:
+            seed = best[1]
+        x = torch.from_numpy(g9_fill(np.random.default_rng(seed), gshape, 1.5))
+        del margins[:]
+        with torch.no_grad():
+            full(x)
+        if min(margins) > G9_RELU_MARGIN or seed == best[1]:
+            break
+        best = max(best, (min(margins), seed))
+    print(f"G9 unet_full backward case: input seed {seed}, smallest switch margin {min(margins):.2e}")
+    for h in hooks:
+        h.remove()
     y = full(x)
-    r = torch.from_numpy(g9_fill(np.random.default_rng(G9_FULL_SEED + 77), tuple(y.shape), 1.0))
+    r = torch.from_numpy(g9_fill(np.random.default_rng(seed + 77), tuple(y.shape), 1.0))
     full.zero_grad()
     (y * r).sum().backward()
+    out["unet_full.grad.meta"] = np.array([seed] + list(gshape), dtype=np.int64)
     for k, p_ in full.named_parameters():
         gk = p_.grad.numpy().astype(np.float64)
         if gk.ndim == 1:
