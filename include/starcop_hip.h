@@ -188,6 +188,12 @@ size_t sc_packed_weight_floats_thin16(int Cout, int Cin, int transpose_flip);
 int sc_pack_weights_thin16(const float* w_oihw, float* wpk, int Cout, int Cin, int transpose_flip, sc_stream stream);
 int sc_conv3x3_thin16(const sc_conv_args* a, sc_stream stream);
 
+/* weight gradient of the same thin layers (Cout <= 16, Cin = 16 | 32, one source which may be upsampled) with two fp16 terms on
+ * v_mfma_f32_16x16x32_f16: same sc_wgrad_args as sc_conv2d_wgrad_mfma with terms = SC_TERMS_F16X2 (absmax = the dy range hint),
+ * workspace from sc_wgrad_thin16_workspace_floats.  Replaces the fp32-MFMA thin weight gradient (the step's last MFMA-bound fp32 kernel). */
+size_t sc_wgrad_thin16_workspace_floats(int N, int H, int W, int Cout, int Cin);
+int sc_conv3x3_wgrad_thin16(const sc_wgrad_args* a, sc_stream stream);
+
 /* the 3x3 weight gradient with split-bf16 operands on the bf16 matrix cores (see sc_conv3x3_bx3); same arguments,
  * ks must be 3; workspace from sc_wgrad_bx3_workspace_floats */
 size_t sc_wgrad_bx3_workspace_floats(int N, int H, int W, int Cout, int Cin);

@@ -130,6 +130,8 @@ SIGNATURES = {
     "sc_threshold_confusion": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "sc_gather_augment": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sc_dwconv3x3_bwd_fused": (_i, [C.POINTER(sc_src), C.POINTER(sc_src), _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sc_wgrad_thin16_workspace_floats": (_sz, [_i, _i, _i, _i, _i]),
+    "sc_conv3x3_wgrad_thin16": (_i, [C.POINTER(sc_wgrad_args), _vp]),
     "sc_conv2d_wgrad_mfma_deferred": (_i, [C.POINTER(sc_wgrad_args), C.POINTER(sc_wgrad_pending), _vp]),
     "sc_wgrad_reduce_batch": (_i, [_vp, _vp, _i, C.c_uint32, _vp]),
     "sc_maxpool2x2": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _i, _vp]),

@@ -1068,6 +1068,186 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient of the THIN 3x3 layers (Cout <= 16, Cin = 16 | 32: smp's decoder.blocks.4 at full resolution) with two fp16
+// terms on v_mfma_f32_16x16x32_f16.  These two layers were the last MFMA-bound fp32 kernels of the step (k_wgrad_mfma16: 0.83 ms at
+// 0.4-0.5 of the fp32 matrix peak); the split needs 3 x 16-cycle MFMAs per 16 x 16 x 32 block instead of 8 x 32 cycles.
+// GEMM view (per tap):  D[co][ci] = sum_px dy[co][px] * in[ci][px + d(tap)],  K step = 32 pixels of one image row
+//   A (16 x 32): lane l -> dy[co = l&15][px = 8*(l>>4) .. +7]                  (one 16-byte LDS read per term)
+//   B (32 x 16): lane l -> in[ci = l&15][px + kw + 8*(l>>4) .. +7]: rows are stored from image column x0 - 1, so kw = 0 is an aligned
+//                16-byte read, kw = 1 a 16-bit funnel shift (v_alignbit) with the next dword, kw = 2 a register renaming
+//   D: lane -> ci = l&15, co = 4*(l>>4) + r
+// Work-group = 4 waves; stage = 4 image rows x 32 columns of one image; wave w owns row w (its own K part: four partial rows per
+// work-group, summed by sc_wgrad_finish).  No register prefetch: 39 KB of LDS and <= 168 VGPRs keep three work-groups per CU, which
+// overlap each other's load -> split -> MFMA phases.
+template <int CIN, bool BNB>
+__global__ __launch_bounds__(256, CIN == 32 ? 2 : 3) void k_wgrad_thin_h(const WgradXP p) {
+  constexpr int NCB = CIN / 16, SR = 4, PRW = SR + 2;
+  constexpr int DYP = SR * 32 + 8;          // dy pitch per cout in halves (272 B)
+  constexpr int XP = 40, XCP = PRW * XP + 8; // input pitch per row (34 used) / per channel in halves (80 B / 496 B)
+  constexpr int NDY = (16 * SR * 16) / 256;  // dy pixel pairs per thread per stage
+  constexpr int NXI = (CIN * PRW * 17 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned s_dy[2][16 * DYP / 2];
+  __shared__ __attribute__((aligned(16))) unsigned s_x[2][CIN * XCP / 2];
+  __shared__ __attribute__((aligned(16))) float s_ca[16 * SC_CST];
+  __shared__ __attribute__((aligned(16))) float s_cb[CIN * 4];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int H = p.H, W = p.W;
+  const float hsg = h_grad_scale(p.absmax);
+  const float hinv = 1.f / (hsg * SC_H_SX);
+
+  for (int i = tid; i < 16 * SC_CST; i += 256) {
+    const int ch = i / SC_CST;
+    s_ca[i] = (p.dy.cst && p.dy.mode != SC_SRC_RAW && ch < p.Cout) ? p.dy.cst[(size_t)ch * SC_CST + (i % SC_CST)] : ((i % SC_CST) == 0 ? 1.f : 0.f);
+  }
+  for (int i = tid; i < CIN; i += 256) {
+    float sc = 1.f, sh = 0.f;
+    if (p.s0.cst && p.s0.mode != SC_SRC_RAW) { sc = p.s0.cst[(size_t)i * SC_CST]; sh = p.s0.cst[(size_t)i * SC_CST + 1]; }
+    s_cb[i * 4] = sc; s_cb[i * 4 + 1] = sh; s_cb[i * 4 + 2] = sc_act_lo(p.s0.act); s_cb[i * 4 + 3] = sc_act_hi(p.s0.act);
+  }
+
+  floatx4 acc[9][NCB];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[t][cb] = (floatx4){0.f, 0.f, 0.f, 0.f};
+
+  const int tiles_x = (W + 31) >> 5, RS = (H + SR - 1) / SR;
+  const long T = (long)p.N * tiles_x * RS;
+  const long t_begin = T * blockIdx.x / p.nsl, t_end = T * (blockIdx.x + 1) / p.nsl;
+  const float dlo = sc_act_lo(p.dy.act), dhi = sc_act_hi(p.dy.act);
+  const size_t HW = (size_t)H * W;
+  const int up = p.s0.up, Ws = W >> up;
+  const size_t plane_s = (size_t)(H >> up) * Ws;
+  __syncthreads();
+
+  for (long t = t_begin; t < t_end; ++t) {
+    const int strip = (int)(t / RS), ty = (int)(t - (long)strip * RS);
+    const int n = strip / tiles_x, x0 = (strip - n * tiles_x) * 32, y0 = ty * SR;
+    // ---- global loads of the stage, all in flight before the first use
+    float dg[NDY][2], dv[BNB ? NDY : 1][2], xr[NXI][2];
+#pragma unroll
+    for (int k = 0; k < NDY; ++k) {
+      const int it = tid + 256 * k;
+      const int co = it >> 6, row = (it >> 4) & 3, col = 2 * (it & 15);
+      const int y = y0 + row, x = x0 + col;
+      const bool okc = co < p.Cout && y < H;
+      const float* const gx = p.dy.x + (size_t)n * p.Cout * HW;
+      const unsigned base = (unsigned)(okc ? co : 0) * (unsigned)HW + (unsigned)((okc ? y : 0) * W);
+      const unsigned xa = (x < W) ? x : 0, xb = (x + 1 < W) ? x + 1 : 0;
+      dg[k][0] = gx[base + xa]; dg[k][1] = gx[base + xb];
+      if (BNB) {
+        const float* const ga = p.dy.aux + (size_t)n * p.Cout * HW;
+        dv[k][0] = ga[base + xa]; dv[k][1] = ga[base + xb];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NXI; ++k) {
+      const int it = tid + 256 * k;
+      const int rc = it / 17, pr = it - rc * 17;
+      const int rowi = rc % PRW, cil = (rc / PRW) % CIN;
+      const int y = y0 - 1 + rowi, x = x0 - 1 + 2 * pr;
+      const bool oky = (y >= 0) && (y < H);
+      const float* xp = p.s0.x + ((size_t)n * CIN + cil) * plane_s + (size_t)((oky ? y : 0) >> up) * Ws;
+      const int xa = (x >= 0 && x < W) ? x : 0, xb = (x + 1 < W) ? x + 1 : 0;
+      xr[k][0] = xp[xa >> up]; xr[k][1] = xp[xb >> up];
+    }
+    if (t != t_begin) __syncthreads();          // the previous stage's MFMAs are done with the LDS tiles
+    // ---- prologue + two-fp16-term split -> LDS
+#pragma unroll
+    for (int k = 0; k < NDY; ++k) {
+      const int it = tid + 256 * k;
+      const int co = it >> 6, row = (it >> 4) & 3, col = 2 * (it & 15);
+      const int y = y0 + row, x = x0 + col;
+      const bool okc = (co < p.Cout) && y < H;
+      const float4 c0 = *reinterpret_cast<const float4*>(&s_ca[co * SC_CST]);
+      const float c4 = s_ca[co * SC_CST + 4];
+      float v0, v1;
+      if (BNB) {
+        v0 = sc_pro_bnbwd(dg[k][0], dv[k][0], c0.x, c0.y, c0.z, c0.w, c4, dlo, dhi);
+        v1 = sc_pro_bnbwd(dg[k][1], dv[k][1], c0.x, c0.y, c0.z, c0.w, c4, dlo, dhi);
+      } else {
+        v0 = sc_pro_affine(dg[k][0], c0.x, c0.y, dlo, dhi);
+        v1 = sc_pro_affine(dg[k][1], c0.x, c0.y, dlo, dhi);
+      }
+      v0 = (okc && x < W) ? v0 * hsg : 0.f;
+      v1 = (okc && x + 1 < W) ? v1 * hsg : 0.f;
+      unsigned t0, t1;
+      split2h(v0, v1, t0, t1);
+      const int d = (co * DYP + row * 32 + col) >> 1;
+      s_dy[0][d] = t0; s_dy[1][d] = t1;
+    }
+#pragma unroll
+    for (int k = 0; k < NXI; ++k) {
+      const int it = tid + 256 * k;
+      const int rc = it / 17, pr = it - rc * 17;
+      const int rowi = rc % PRW, cil = (rc / PRW) % CIN;
+      const int y = y0 - 1 + rowi, x = x0 - 1 + 2 * pr;
+      const bool oky = (y >= 0) && (y < H);
+      const float4 c = *reinterpret_cast<const float4*>(&s_cb[cil * 4]);
+      float v0 = sc_pro_affine(xr[k][0], c.x, c.y, c.z, c.w);
+      float v1 = sc_pro_affine(xr[k][1], c.x, c.y, c.z, c.w);
+      v0 = (oky && x >= 0 && x < W) ? v0 * SC_H_SX : 0.f;
+      v1 = (oky && x + 1 < W) ? v1 * SC_H_SX : 0.f;
+      unsigned t0, t1;
+      split2h(v0, v1, t0, t1);
+      const int d = ((cil * XCP + rowi * XP) >> 1) + pr;
+      if (it < CIN * PRW * 17) { s_x[0][d] = t0; s_x[1][d] = t1; }
+    }
+    __syncthreads();
+    // ---- MFMAs: wave w = image row y0 + w of the stage
+    {
+      const int r = wave;
+      halfx8 A[2];
+      const int da = (l15 * DYP + r * 32 + 8 * lg) >> 1;
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) A[tm] = __builtin_bit_cast(halfx8, *reinterpret_cast<const uintx4*>(&s_dy[tm][da]));
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          const int dx = (((cb * 16 + l15) * XCP + (r + kh) * XP) >> 1) + 4 * lg;
+          halfx8 B[3][2];
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm) {
+            const uintx4 X0 = *reinterpret_cast<const uintx4*>(&s_x[tm][dx]);
+            const unsigned X1 = (*reinterpret_cast<const uintx4*>(&s_x[tm][dx + 4]))[0];
+            uintx4 S1, S2;
+            S1[0] = __builtin_amdgcn_alignbit(X0[1], X0[0], 16);
+            S1[1] = __builtin_amdgcn_alignbit(X0[2], X0[1], 16);
+            S1[2] = __builtin_amdgcn_alignbit(X0[3], X0[2], 16);
+            S1[3] = __builtin_amdgcn_alignbit(X1, X0[3], 16);
+            S2[0] = X0[1]; S2[1] = X0[2]; S2[2] = X0[3]; S2[3] = X1;
+            B[0][tm] = __builtin_bit_cast(halfx8, X0);
+            B[1][tm] = __builtin_bit_cast(halfx8, S1);
+            B[2][tm] = __builtin_bit_cast(halfx8, S2);
+          }
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            floatx4 c = acc[kh * 3 + kw][cb];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], B[kw][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[1], B[kw][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], B[kw][0], c, 0, 0, 0);
+            acc[kh * 3 + kw][cb] = c;
+          }
+        }
+      }
+    }
+  }
+  // ---- partial store: part[((slice*4 + wave)*9 + tap)*CoP*CiP + co*CiP + ci]   (CoP = 16, CiP = CIN)
+  const size_t plane = (size_t)16 * CIN;
+  float* pb = p.part + ((size_t)blockIdx.x * 4 + wave) * 9 * plane;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pb[tap * plane + (size_t)(4 * lg + r) * CIN + cb * 16 + l15] = acc[tap][cb][r] * hinv;
+}
+
 struct WgradXPlan { int wm, nci, kp, nsl, CoP, CiP, co_tiles, ci_tiles; };
 WgradXPlan plan_wgrad_bx3(int N, int H, int W, int Cout, int Cin) {
   WgradXPlan pl;
@@ -1281,6 +1461,46 @@ extern "C" int sc_conv3x3_wgrad_bx3(const sc_wgrad_args* a, sc_stream stream) {
 #undef SC_WGX
   SC_LAUNCH_OK("sc_conv3x3_wgrad_bx3");
   return sc_wgrad_finish(a->part, pl.nsl * pl.kp, 9, a->Cout, a->Cin, pl.CoP, pl.CiP, a->dw, st);
+}
+
+static int wgrad_thin16_slices(int N, int H, int W) {
+  const long T = (long)N * ((W + 31) / 32) * ((H + 3) / 4);
+  return (int)(T < 768 ? T : 768);            // three work-groups per CU resident: one round of 768
+}
+
+extern "C" size_t sc_wgrad_thin16_workspace_floats(int N, int H, int W, int Cout, int Cin) {
+  (void)Cout;
+  const size_t E = (size_t)9 * 16 * Cin;
+  const int nparts = 4 * wgrad_thin16_slices(N, H, W);
+  return (size_t)nparts * E + sc_reduce_scratch_floats(nparts, E);
+}
+
+extern "C" int sc_conv3x3_wgrad_thin16(const sc_wgrad_args* a, sc_stream stream) {
+  SC_REQUIRE(a != nullptr && a->ks == 3 && a->nsrc == 1, "sc_conv3x3_wgrad_thin16: one source, ks = 3");
+  SC_REQUIRE(a->Cout >= 1 && a->Cout <= 16 && (a->Cin == 16 || a->Cin == 32) && a->src[0].C == a->Cin && a->dy.C == a->Cout,
+             "sc_conv3x3_wgrad_thin16: needs <= 16 output and 16 or 32 input channels (got %d, %d)", a->Cout, a->Cin);
+  SC_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0, "sc_conv3x3_wgrad_thin16: bad shape");
+  SC_REQUIRE(a->terms == SC_TERMS_F16X2, "sc_conv3x3_wgrad_thin16: terms must be SC_TERMS_F16X2");
+  SC_REQUIRE(a->dy.up == 0 && a->dy.mode != SC_SRC_NORM && (a->dy.mode != SC_SRC_BNBWD || a->dy.aux != nullptr), "sc_conv3x3_wgrad_thin16: unsupported dy source");
+  SC_REQUIRE(a->dy.mode == SC_SRC_RAW || a->dy.cst != nullptr, "sc_conv3x3_wgrad_thin16: dy source needs constants");
+  const sc_src& s = a->src[0];
+  SC_REQUIRE((s.mode == SC_SRC_RAW || (s.mode == SC_SRC_AFFINE && s.cst != nullptr)), "sc_conv3x3_wgrad_thin16: input source must be RAW or AFFINE");
+  SC_REQUIRE(s.up == 0 || (s.up == 1 && a->H % 2 == 0 && a->W % 2 == 0), "sc_conv3x3_wgrad_thin16: upsampled source needs even H, W");
+  SC_REQUIRE((size_t)a->Cout * a->H * a->W < (1ull << 32), "sc_conv3x3_wgrad_thin16: image too large for 32-bit lane offsets");
+  const size_t need = sc_wgrad_thin16_workspace_floats(a->N, a->H, a->W, a->Cout, a->Cin);
+  SC_REQUIRE(a->part_floats >= need, "sc_conv3x3_wgrad_thin16: workspace too small (%zu < %zu floats)", a->part_floats, need);
+  WgradXP p;
+  p.absmax = a->absmax;
+  p.dy = to_srcd(a->dy); p.s0 = to_srcd(s); p.s1 = empty_srcd();
+  p.N = a->N; p.H = a->H; p.W = a->W; p.Cout = a->Cout; p.Cin = a->Cin; p.part = a->part;
+  p.nsl = wgrad_thin16_slices(a->N, a->H, a->W); p.CoP = 16; p.CiP = a->Cin;
+  hipStream_t st = (hipStream_t)stream;
+  const bool bnb = a->dy.mode == SC_SRC_BNBWD;
+  dim3 grid(p.nsl);
+  if (a->Cin == 16) { if (bnb) hipLaunchKernelGGL((k_wgrad_thin_h<16, true>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((k_wgrad_thin_h<16, false>), grid, dim3(256), 0, st, p); }
+  else              { if (bnb) hipLaunchKernelGGL((k_wgrad_thin_h<32, true>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((k_wgrad_thin_h<32, false>), grid, dim3(256), 0, st, p); }
+  SC_LAUNCH_OK("sc_conv3x3_wgrad_thin16");
+  return sc_wgrad_finish(a->part, 4 * p.nsl, 9, a->Cout, a->Cin, 16, a->Cin, a->dw, st);
 }
 
 static int thin_steps(int Cout, int Cin, int transpose_flip) { return (9 * ((transpose_flip ? Cout : Cin) / 8) + 3) / 4; }

@@ -384,6 +384,8 @@ class HyperStarcopUNet(nn.Module):
                                                                conv.kernel_size[0]))
                     if conv.kernel_size[0] == 3:
                         ws = max(ws, lib.sc_wgrad_bx3_workspace_floats(N, Ho, Wo, conv.out_channels, conv.in_channels))
+                        if conv.out_channels <= 16 and conv.in_channels in (16, 32):
+                            ws = max(ws, lib.sc_wgrad_thin16_workspace_floats(N, Ho, Wo, conv.out_channels, conv.in_channels))
                     if op.get("up"):
                         up = max(up, N * op["ins"][0].C * Ho * Wo)
                 elif op["type"] == "stem":
@@ -801,8 +803,12 @@ class HyperStarcopUNet(nn.Module):
             wa.absmax = gmax_slot.get(o.name)
             flop = 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * ks * ks
             wfn = (lib.sc_conv3x3_wgrad_bx3 if (self.split_bf16 and ks == 3 and conv.out_channels >= 32 and conv.in_channels >= 32)
-                   else lib.sc_conv2d_wgrad_mfma)     # thin layers (16 channels on either side) stay on the fp32 MFMA
-            tok = self._pb("k_wgrad3_bx3 (+reduce)" if wfn is lib.sc_conv3x3_wgrad_bx3 else f"k_wgrad_mfma<{ks}> (+reduce)", flop)
+                   else lib.sc_conv2d_wgrad_mfma)     # 16-channel layers outside the cases below stay on the fp32 MFMA
+            if (self.split_bf16 and self.thin16 and ks == 3 and self._terms[1] == TERMS_F16X2 and len(ins) == 1
+                    and conv.out_channels <= 16 and conv.in_channels in (16, 32)):
+                wfn = lib.sc_conv3x3_wgrad_thin16     # decoder.blocks.4: two fp16 terms on the 16x16x32 MFMA (was MFMA-bound in fp32)
+            tok = self._pb("k_wgrad3_bx3 (+reduce)" if wfn is lib.sc_conv3x3_wgrad_bx3 else
+                           "k_wgrad_thin_h (+reduce)" if wfn is lib.sc_conv3x3_wgrad_thin16 else f"k_wgrad_mfma<{ks}> (+reduce)", flop)
             if ty == "pw" and i in plan.pw_part:
                 wa.part = plan.pw_part[i].data_ptr(); wa.part_floats = plan.pw_part[i].numel()
                 pend = sc_wgrad_pending()

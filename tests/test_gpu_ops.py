@@ -737,3 +737,47 @@ def test_wgrad_deferred_batch_reduce(hip):
     check(lib.sc_wgrad_reduce_batch(ptr(descs), ptr(st_d), len(pend), nblk, stream()))
     for dw, want in zip(outs, wants):
         assert relerr(dw, want) < TOL
+
+
+@pytest.mark.parametrize("cin,cout,H,W,up,bnb", [(16, 16, 32, 64, 0, True), (32, 16, 16, 32, 0, True), (32, 16, 24, 40, 1, True), (16, 8, 20, 36, 0, False),
+                                                   (32, 16, 64, 64, 1, True), (16, 16, 9, 33, 0, True)])
+def test_wgrad_thin16_split(hip, cin, cout, H, W, up, bnb):
+    """thin 3x3 weight gradient on the two-fp16-term 16x16x32 MFMA (sc_conv3x3_wgrad_thin16: decoder.blocks.4) against autograd
+    in fp64: BNBWD / affine dy prologues, affine + ReLU input prologue, nearest-x2 upsampled input, ragged edges, range hint"""
+    from starcop_amd._lib import sc_wgrad_args, TERMS_F16X2
+    lib = _lib.load()
+    N = 2
+    if up and (H % 2 or W % 2):
+        pytest.skip("upsampled sources need even sizes")
+    xs = rnd(N, cin, H >> up, W >> up, seed=1, scale=1.5)
+    sc, sh = rnd(cin, seed=2) * 0.3 + 1.0, rnd(cin, seed=3) * 0.4
+    xin = F.relu(xs * sc[None, :, None, None] + sh[None, :, None, None])
+    if up:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    g, y = rnd(N, cout, H, W, seed=4, scale=3e-4), rnd(N, cout, H, W, seed=5)
+    a, b = rnd(cout, seed=6) * 0.2 + 1, rnd(cout, seed=7) * 0.2
+    A, B, D = rnd(cout, seed=8) + 2.0, rnd(cout, seed=9) * 1e-5, rnd(cout, seed=10) * 1e-5
+    if bnb:
+        yh = y * a[None, :, None, None] + b[None, :, None, None]
+        dy = torch.where(yh > 0, g, torch.zeros(())) * A[None, :, None, None] + B[None, :, None, None] * y + D[None, :, None, None]
+        cst = torch.zeros(cout, SC_CST); cst[:, 0], cst[:, 1], cst[:, 2], cst[:, 3], cst[:, 4] = a, b, A, B, D
+        dsrc = make_src(dev(g), cout, SRC_BNBWD, act=ACT_RELU, cst=dev(cst), aux=dev(y))
+        amax = dev(torch.tensor([float((A.abs().max() * g.abs().max()))]))
+    else:
+        dy = g * a[None, :, None, None] + b[None, :, None, None] * 1e-4
+        cst = torch.zeros(cout, SC_CST); cst[:, 0], cst[:, 1] = a, b * 1e-4
+        dsrc = make_src(dev(g), cout, SRC_AFFINE, act=ACT_NONE, cst=dev(cst))
+        amax = dev(torch.tensor([float(dy.abs().max())]))
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xin.double(), w, padding=1).backward(dy.double())
+    args = sc_wgrad_args()
+    args.dy = dsrc
+    args.nsrc = 1
+    args.src[0] = make_src(dev(xs), cin, SRC_AFFINE, act=ACT_RELU, up=up, cst=cst_affine(sc, sh))
+    args.N, args.H, args.W, args.Cout, args.Cin, args.ks = N, H, W, cout, cin, 3
+    n = lib.sc_wgrad_thin16_workspace_floats(N, H, W, cout, cin)
+    ws = torch.empty(n, device=DEV); dw = torch.full((cout, cin, 3, 3), float("nan"), device=DEV)
+    args.part, args.part_floats, args.dw = ws.data_ptr(), n, dw.data_ptr()
+    args.terms, args.absmax = TERMS_F16X2, amax.data_ptr()
+    check(lib.sc_conv3x3_wgrad_thin16(C.byref(args), stream()))
+    assert relerr(dw, w.grad) < 2e-5
