@@ -163,11 +163,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("STARCOP_HIP_LIB", LIB_PATH)        # development knob: an experiment build of the same sources
+    if not os.path.exists(path):
         raise StarcopHipError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C starcop_amd/csrc`).  starcop_amd has no CPU/torch fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)     # AttributeError if the symbol is not exported
         fn.restype = res

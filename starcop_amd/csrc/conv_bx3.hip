@@ -28,6 +28,10 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef SC_EXP
+#define SC_EXP 0      // tools/build_exp.sh: elimination experiments on the weight-gradient kernels (never in the shipped library)
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -808,20 +812,26 @@ struct WgradXP {
 };
 
 // NCI: 32-wide cin blocks per tile (2: 64 cins; 1: 32 cins for channel counts that would waste most of a 64-wide tile)
-template <int WM, int NT, int NCI, bool HF = false>
+// PIPE (fp16 mode): one barrier per stage.  The dy tile is double-buffered and the input ring has 8 slots, so stage t+1 is
+// split and stored while other waves still run the MFMAs of stage t (the matrix pipe and the VALU overlap across the three
+// waves of a SIMD instead of alternating in lock step), and every item's global load for stage t+2 is issued right after
+// its registers were consumed for stage t+1: a whole stage in flight with no extra registers.
+template <int WM, int NT, int NCI, bool HF = false, bool PIPE = false>
 __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
   static_assert(!HF || NT == 2, "the fp16 mode has two terms");
+  static_assert(!PIPE || HF, "the pipelined variant is the fp16 mode's");
   constexpr int NTH = 768;
   const float hsg = HF ? h_grad_scale(p.absmax) : 1.f;          // fp16 mode: scale of the gradient operand
   const float hinv = HF ? 1.f / (hsg * SC_H_SX) : 1.f;
   constexpr int COT = 32 * WM, CIT = 32 * NCI, NPAIR = NCI * WM, KP = 4 / NPAIR;     // KP K parts: rows and, at KP = 4, 16-pixel steps
   constexpr int DYP = 72;              // dy pitch per cout in pixels (144 B: conflict-free 16-byte reads)
   constexpr int XRP = 40;              // input row pitch in pixels (34 used)
-  constexpr int XCP = 4 * XRP + 8;     // input pitch per cin: 4 ring rows + pad (336 B: conflict-free)
+  constexpr int RING = PIPE ? 8 : 4;
+  constexpr int XCP = RING * XRP + 8;  // input pitch per cin: ring rows + pad (336 / 656 B: conflict-free)
   constexpr int NDY = (COT * 32 + NTH - 1) / NTH;     // dy pixel pairs per thread per stage
   constexpr int NXI = (2 * 17 * CIT + NTH - 1) / NTH; // input pixel pairs per thread per two rows
 
-  __shared__ __attribute__((aligned(16))) unsigned s_dy[NT][COT * DYP / 2];
+  __shared__ __attribute__((aligned(16))) unsigned s_dy[PIPE ? 2 : 1][NT][COT * DYP / 2];
   __shared__ __attribute__((aligned(16))) unsigned s_x[NT][CIT * XCP / 2];
   __shared__ __attribute__((aligned(16))) float s_ca[COT * SC_CST];
   __shared__ __attribute__((aligned(16))) float s_cb[CIT * 4];      // scale, shift, lo, hi per cin
@@ -860,48 +870,99 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   // stage enumeration: strips (image, 32-column strip) outer, row pairs inner
-  const int tiles_x = (W + 31) >> 5, RS = (H + 1) >> 1;
-  const long T = (long)p.N * tiles_x * RS;
+  // PIPE: every strip starts with a pre-stage at y0 = -2 that only brings rows -1 (zeros) and 0 into the ring, so that EVERY
+  // stage fetches exactly two new input rows and the loop body has no conditional loads
+  const int tiles_x = (W + 31) >> 5, RS = (H + 1) >> 1, RSS = PIPE ? RS + 1 : RS, YB = PIPE ? -2 : 0;
+  const long T = (long)p.N * tiles_x * RSS;
   const long t_begin = T * blockIdx.x / p.nsl, t_end = T * (blockIdx.x + 1) / p.nsl;
-  const int dymode = p.dy.mode;
+  const int dymode = PIPE ? (int)SC_SRC_BNBWD : p.dy.mode;      // the pipelined variant is launched for BatchNorm-backward gradients only
   const float dlo = sc_act_lo(p.dy.act), dhi = sc_act_hi(p.dy.act);
   const size_t HW = (size_t)H * W;
 
   auto decode = [&](long t, int& n, int& y0, int& x0) {
-    const int strip = (int)(t / RS);
-    const int ty = (int)(t - (long)strip * RS);
+    const int strip = (int)(t / RSS);
+    const int ty = (int)(t - (long)strip * RSS);
     n = strip / tiles_x;
     x0 = (strip - n * tiles_x) * 32;
-    y0 = ty * 2;
+    y0 = ty * 2 + YB;
   };
 
   // ---- dy: thread owns pixel pairs (co = item >> 5, row = (item >> 4) & 1, cols 2*(item & 15), +1) ----
   float dg[NDY][2], dv[NDY][2];
-  auto dy_load = [&](int n, int y0, int x0) {
+  // PIPE: per-item address invariants in registers: the byte offset of the item's gradient channel plane (+ column), the
+  // input item's channel plane pointer and which source it belongs to
+  unsigned dyo[NDY];
+  const char* xch[(2 * 17 * CIT + NTH - 1) / NTH];
+  unsigned xsec = 0;
+  unsigned istr0 = 0, istr1 = 0;
+  if constexpr (PIPE) {
 #pragma unroll
     for (int k = 0; k < NDY; ++k) {
-      const int it = tid + NTH * k;
+      int it = tid + NTH * k;
+      if (it >= COT * 32) it -= COT * 32;
+      const int co = cot * COT + ((it >> 5) & (COT - 1));
+      dyo[k] = (unsigned)(co < p.Cout ? co : 0) * (unsigned)HW * 4u;
+    }
+    istr0 = (unsigned)((size_t)p.s0.C * (H >> p.s0.up) * (W >> p.s0.up) * 4);
+    istr1 = (unsigned)((size_t)p.s1.C * (H >> p.s1.up) * (W >> p.s1.up) * 4);
+#pragma unroll
+    for (int k = 0; k < NXI; ++k) {
+      int it = tid + NTH * k;
+      if (it >= 2 * 17 * CIT) it -= 2 * 17 * CIT;
+      const int cil = ((it / 17) >> 1) & (CIT - 1);
+      const int chr = cit * CIT + cil;
+      const int ch = chr < p.Cin ? chr : 0;
+      const bool second = ch >= C0;
+      const int cs = second ? ch - C0 : ch;
+      const int up = second ? p.s1.up : p.s0.up;
+      xch[k] = reinterpret_cast<const char*>((second ? p.s1.x : p.s0.x) + (size_t)cs * ((size_t)(H >> up) * (W >> up)));
+      xsec |= second ? (1u << k) : 0u;
+    }
+  }
+  // PIPE: no guarded items (the compiler's s_waitcnt counting gives up at every exec-mask branch): threads past the last item
+  // redo one of the first items and store the same values to the same place
+  auto dy_load_item = [&](int k, int n, int y0, int x0) {
+    {
+      int it = tid + NTH * k;
+      if (PIPE && it >= COT * 32) it -= COT * 32;
       const int co = cot * COT + ((it >> 5) & (COT - 1)), row = (it >> 4) & 1, col = 2 * (it & 15);
       const int y = y0 + row, x = x0 + col;
-      const bool okc = co < p.Cout && y < H;
+      const bool okc = co < p.Cout && y < H && y >= 0;
+      if constexpr (PIPE) {
+        // one 8-byte load per tensor: W and col are even (host-checked), the byte offset within the image fits 32 bits
+        const size_t io = (size_t)n * p.Cout * HW * 4;
+        const unsigned off = dyo[k] + (unsigned)(((y >= 0 && y < H) ? y : 0) * W + ((x < W) ? x : 0)) * 4u;
+        const float2 g = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(p.dy.x) + io + off);
+        const float2 a = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(p.dy.aux) + io + off);
+        dg[k][0] = g.x; dg[k][1] = g.y; dv[k][0] = a.x; dv[k][1] = a.y;
+        return;
+      }
       // uniform image base + 32-bit lane offset (< Cout * H * W): saddr loads, no 64-bit lane arithmetic
       const float* const gx = p.dy.x + (size_t)n * p.Cout * HW;
       const unsigned base = (unsigned)(okc ? co : 0) * (unsigned)HW + (unsigned)((okc ? y : 0) * W);
       const unsigned xa = (x < W) ? x : 0, xb = (x + 1 < W) ? x + 1 : 0;
+#if SC_EXP == 2      // experiment: no global loads
+      dg[k][0] = (float)(base + xa); dg[k][1] = (float)(base + xb); dv[k][0] = dg[k][1]; dv[k][1] = dg[k][0]; (void)gx;
+#else
       dg[k][0] = gx[base + xa]; dg[k][1] = gx[base + xb];
       if (dymode == SC_SRC_BNBWD) {
         const float* const ga = p.dy.aux + (size_t)n * p.Cout * HW;
         dv[k][0] = ga[base + xa]; dv[k][1] = ga[base + xb];
       } else { dv[k][0] = 0.f; dv[k][1] = 0.f; }
+#endif
     }
   };
-  auto dy_store = [&](int y0, int x0) {
+  auto dy_load = [&](int n, int y0, int x0) {
 #pragma unroll
-    for (int k = 0; k < NDY; ++k) {
-      const int it = tid + NTH * k;
+    for (int k = 0; k < NDY; ++k) dy_load_item(k, n, y0, x0);
+  };
+  auto dy_store_item = [&](int k, int buf, int y0, int x0) {
+    {
+      int it = tid + NTH * k;
+      if (PIPE && it >= COT * 32) it -= COT * 32;
       const int col_l = (it >> 5) & (COT - 1), row = (it >> 4) & 1, col = 2 * (it & 15);
       const int y = y0 + row, x = x0 + col;
-      const bool okc = (cot * COT + col_l < p.Cout) && y < H;
+      const bool okc = (cot * COT + col_l < p.Cout) && y < H && y >= 0;
       const float4 c0 = *reinterpret_cast<const float4*>(&s_ca[col_l * SC_CST]);
       const float c4 = s_ca[col_l * SC_CST + 4];
       float v0, v1;
@@ -915,24 +976,44 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
       v0 = (okc && x < W) ? v0 : 0.f;
       v1 = (okc && x + 1 < W) ? v1 : 0.f;
       unsigned t[3];
+#if SC_EXP == 3      // experiment: no prologue, no split
+      t[0] = __builtin_bit_cast(unsigned, dg[k][0]) ^ __builtin_bit_cast(unsigned, dv[k][0]); t[1] = __builtin_bit_cast(unsigned, dg[k][1]) ^ __builtin_bit_cast(unsigned, dv[k][1]); t[2] = 0u;
+      (void)v0; (void)v1;
+#else
       if constexpr (HF) { split2h(v0 * hsg, v1 * hsg, t[0], t[1]); t[2] = 0u; }
       else split3x2(v0, v1, t[0], t[1], t[2]);
+#endif
       const int d = (col_l * DYP + row * 32 + col) >> 1;
-      if (it < COT * 32) {
+      if (PIPE || it < COT * 32) {
 #pragma unroll
-        for (int c = 0; c < NT; ++c) s_dy[c][d] = t[c];
+        for (int c = 0; c < NT; ++c) s_dy[buf][c][d] = t[c];
       }
     }
+  };
+  auto dy_store = [&](int buf, int y0, int x0) {
+#pragma unroll
+    for (int k = 0; k < NDY; ++k) dy_store_item(k, buf, y0, x0);
   };
 
   // ---- input rows R, R+1 (R may be -1): item -> (pair of columns pr in 0..16, row, ci) ----
   float xr[NXI][2];
-  auto x_load = [&](int n, int R, int x0) {
-#pragma unroll
-    for (int k = 0; k < NXI; ++k) {
-      const int it = tid + NTH * k;
+  auto x_load_item = [&](float (&xr)[NXI][2], int k, int n, int R, int x0) {
+    {
+      int it = tid + NTH * k;
+      if (PIPE && it >= 2 * 17 * CIT) it -= 2 * 17 * CIT;
       const int rc = it / 17, pr = it - rc * 17;
       const int rowi = rc & 1, cil = (rc >> 1) & (CIT - 1);
+      if constexpr (PIPE) {
+        const bool sec = (xsec >> k) & 1u;
+        const int up = sec ? p.s1.up : p.s0.up;
+        const int y = R + rowi, x = x0 - 1 + 2 * pr;
+        const int yc = (y >= 0 && y < H) ? y : 0;
+        const int xa = (x >= 0 && x < W) ? x : 0, xb = (x + 1 < W) ? x + 1 : 0;
+        const unsigned ro = (unsigned)n * (sec ? istr1 : istr0) + (unsigned)((yc >> up) * (W >> up)) * 4u;
+        xr[k][0] = *reinterpret_cast<const float*>(xch[k] + (ro + (unsigned)(xa >> up) * 4u));
+        xr[k][1] = *reinterpret_cast<const float*>(xch[k] + (ro + (unsigned)(xb >> up) * 4u));
+        return;
+      }
       const int chr = cit * CIT + cil;
       const int ch = chr < p.Cin ? chr : 0;
       const bool second = ch >= C0;
@@ -944,13 +1025,22 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
       const int Ws = W >> up;
       const float* xp = (second ? p.s1.x : p.s0.x) + ((size_t)n * Cs + cs) * ((size_t)(H >> up) * Ws) + (size_t)((oky ? y : 0) >> up) * Ws;
       const int xa = (x >= 0 && x < W) ? x : 0, xb = (x + 1 < W) ? x + 1 : 0;
+#if SC_EXP == 2
+      xr[k][0] = (float)(xa >> up) + (float)(size_t)xp; xr[k][1] = (float)(xb >> up);
+#else
       xr[k][0] = xp[xa >> up]; xr[k][1] = xp[xb >> up];
+#endif
     }
   };
-  auto x_store = [&](int R, int x0) {
+  auto x_load = [&](float (&xr)[NXI][2], int n, int R, int x0) {
 #pragma unroll
-    for (int k = 0; k < NXI; ++k) {
-      const int it = tid + NTH * k;
+    for (int k = 0; k < NXI; ++k) x_load_item(xr, k, n, R, x0);
+  };
+  // sl0: ring slot of row R (PIPE: a running position, see the loop; otherwise (R + 1) & 3)
+  auto x_store_item = [&](const float (&xr)[NXI][2], int k, int R, int x0, int sl0) {
+    {
+      int it = tid + NTH * k;
+      if (PIPE && it >= 2 * 17 * CIT) it -= 2 * 17 * CIT;
       const int rc = it / 17, pr = it - rc * 17;
       const int rowi = rc & 1, cil = (rc >> 1) & (CIT - 1);
       const int y = R + rowi, x = x0 - 1 + 2 * pr;
@@ -961,29 +1051,40 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
       v0 = (okc && x >= 0 && x < W) ? v0 : 0.f;
       v1 = (okc && x + 1 < W) ? v1 : 0.f;
       unsigned t[3];
+#if SC_EXP == 3
+      t[0] = __builtin_bit_cast(unsigned, xr[k][0]); t[1] = __builtin_bit_cast(unsigned, xr[k][1]); t[2] = 0u; (void)v0; (void)v1;
+#else
       if constexpr (HF) { split2h(v0 * SC_H_SX, v1 * SC_H_SX, t[0], t[1]); t[2] = 0u; }
       else split3x2(v0, v1, t[0], t[1], t[2]);
-      const int slot = (y + 1) & 3;
+#endif
+      const int slot = (sl0 + rowi) & (RING - 1);
       const int d = ((cil * XCP + slot * XRP) >> 1) + pr;
-      if (it < 2 * 17 * CIT) {
+      if (PIPE || it < 2 * 17 * CIT) {
 #pragma unroll
         for (int c = 0; c < NT; ++c) s_x[c][d] = t[c];
       }
     }
   };
+  auto x_store = [&](const float (&xr)[NXI][2], int R, int x0, int sl0) {
+#pragma unroll
+    for (int k = 0; k < NXI; ++k) x_store_item(xr, k, R, x0, sl0);
+  };
 
-  auto compute = [&](int y0) {
+  auto compute = [&](int sl0, int buf) {          // sl0: ring slot of image row y0 - 1
+#if SC_EXP == 4
+    return;
+#endif
 #pragma unroll
     for (int rr = 0; rr < (KP == 1 ? 2 : 1); ++rr) {
       const int r = (KP == 1) ? rr : (kp & 1);
-      const int slot = (y0 + r + kh) & 3;
+      const int slot = (sl0 + r + kh) & (RING - 1);
 #pragma unroll
       for (int jj = 0; jj < (KP == 4 ? 1 : 2); ++jj) {
         const int j = (KP == 4) ? (kp >> 1) : jj;
         bf16x8 A[NT];
         const int da = ((wm * 32 + l31) * DYP + r * 32 + 16 * j + 8 * lhi) >> 1;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) A[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uintx4*>(&s_dy[t][da]));
+        for (int t = 0; t < NT; ++t) A[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uintx4*>(&s_dy[buf][t][da]));
         const int dx = ((wn * 32 + l31) * XCP + slot * XRP + 16 * j + 8 * lhi) >> 1;
         bf16x8 B[3][NT];
 #pragma unroll
@@ -1004,9 +1105,15 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
           B[2][t] = __builtin_bit_cast(bf16x8, S2);
         }
         // the six partial products, taps interleaved so that consecutive MFMAs hit different accumulators
+#if SC_EXP == 1     // experiment: no MFMAs (one FMA keeps the operand reads alive)
+#define SC_BX3_STEP(TA, TB)                                                                                         \
+  _Pragma("unroll") for (int kw = 0; kw < 3; ++kw)                                                                  \
+      acc[kw][0] += (float)(__builtin_bit_cast(uintx4, A[TA])[0] & 0xffffu) * (float)(__builtin_bit_cast(uintx4, B[kw][TB])[0] & 0xffffu);
+#else
 #define SC_BX3_STEP(TA, TB)                                                                                         \
   _Pragma("unroll") for (int kw = 0; kw < 3; ++kw)                                                                  \
       acc[kw] = mfma_split<HF>(A[TA], B[kw][TB], acc[kw]);
+#endif
         if constexpr (NT == 3) { SC_BX3_STEP(1, 1) SC_BX3_STEP(2, 0) SC_BX3_STEP(0, 2) SC_BX3_STEP(1, 0) SC_BX3_STEP(0, 1) }
         if constexpr (NT == 2) { SC_BX3_STEP(0, 1) SC_BX3_STEP(1, 0) }
         SC_BX3_STEP(0, 0)
@@ -1022,37 +1129,84 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
   int n1 = n, y1 = y0, x1 = x0;
   auto advance = [&](int& nn, int& yy, int& xx) {
     yy += 2;
-    if (yy >= 2 * RS) { yy = 0; xx += 32; if (xx >= 32 * tiles_x) { xx = 0; ++nn; } }
+    if (yy >= 2 * RS) { yy = YB; xx += 32; if (xx >= 32 * tiles_x) { xx = 0; ++nn; } }
   };
   advance(n1, y1, x1);
-  if (t_begin < t_end) {
-    x_load(n, y0 - 1, x0);
-    dy_load(n, y0, x0);
-    x_store(y0 - 1, x0);
-    x_load(n, y0 + 1, x0);
-    dy_store(y0, x0);
-    x_store(y0 + 1, x0);
-    __syncthreads();
-  }
-  for (long t = t_begin; t < t_end; ++t) {
-    const bool more = (t + 1) < t_end;
-    if (more) {
-      dy_load(n1, y1, x1);
-      x_load(n1, y1 + 1, x1);
+  if constexpr (!PIPE) {
+    if (t_begin < t_end) {
+      x_load(xr, n, y0 - 1, x0);
+      dy_load(n, y0, x0);
+      x_store(xr, y0 - 1, x0, y0 & 3);
+      x_load(xr, n, y0 + 1, x0);
+      dy_store(0, y0, x0);
+      x_store(xr, y0 + 1, x0, (y0 + 2) & 3);
+      __syncthreads();
     }
-    compute(y0);
-    __syncthreads();
-    if (more) {
-      dy_store(y1, x1);
-      x_store(y1 + 1, x1);
-      if (y1 == 0) {            // new strip: the two rows above are not in the ring
-        x_load(n1, y1 - 1, x1);
-        x_store(y1 - 1, x1);
+    for (long t = t_begin; t < t_end; ++t) {
+      const bool more = (t + 1) < t_end;
+      if (more) {
+        dy_load(n1, y1, x1);
+        x_load(xr, n1, y1 + 1, x1);
       }
+      compute(y0 & 3, 0);
+      __syncthreads();
+      if (more) {
+        dy_store(0, y1, x1);
+        x_store(xr, y1 + 1, x1, (y1 + 2) & 3);
+        if (y1 == 0) {            // new strip: the two rows above are not in the ring
+          x_load(xr, n1, y1 - 1, x1);
+          x_store(xr, y1 - 1, x1, y1 & 3);
+        }
+      }
+      __syncthreads();
+      n = n1; y0 = y1; x0 = x1;
+      advance(n1, y1, x1);
     }
-    __syncthreads();
-    n = n1; y0 = y1; x0 = x1;
-    advance(n1, y1, x1);
+  } else {
+    // rp: ring slot of image row y0 - 1 of the current stage, which reads slots rp .. rp+3 while the two new rows of stage t+1
+    // are stored to rp+4, rp+5 and the dy tile to the other buffer: one barrier per stage.  Registers: the values of stage t+1
+    // were requested one whole stage ago; each item's registers are re-used for its stage t+2 request right after the
+    // conversion.  Past the last stage the coordinates stay on the last one (a harmless re-fetch, stored but never read).
+    int rp = 0, buf = 0;
+    const int nlast = p.N - 1;
+    auto advance_sat = [&](int& nn, int& yy, int& xx) {
+      const int pn = nn, py = yy, px = xx;
+      advance(nn, yy, xx);
+      if (nn > nlast) { nn = pn; yy = py; xx = px; }
+    };
+    if (n1 > nlast) { n1 = n; y1 = y0; x1 = x0; }
+    int n2 = n1, y2 = y1, x2 = x1;
+    advance_sat(n2, y2, x2);
+    if (t_begin < t_end) {
+      x_load(xr, n, y0 - 1, x0);
+      dy_load(n, y0, x0);
+      x_store(xr, y0 - 1, x0, rp);
+      x_load(xr, n, y0 + 1, x0);
+      dy_store(0, y0, x0);
+      x_store(xr, y0 + 1, x0, rp + 2);
+      dy_load(n1, y1, x1);
+      x_load(xr, n1, y1 + 1, x1);
+      __syncthreads();
+    }
+    for (long t = t_begin; t < t_end; ++t) {
+      if (y0 >= 0) compute(rp, buf);          // (the pre-stage of a strip has no gradient rows)
+#pragma unroll
+      for (int k = 0; k < NDY; ++k) {
+        dy_store_item(k, buf ^ 1, y1, x1);
+        dy_load_item(k, n2, y2, x2);
+      }
+#pragma unroll
+      for (int k = 0; k < NXI; ++k) {
+        x_store_item(xr, k, y1 + 1, x1, rp + 4);
+        x_load_item(xr, k, n2, y2 + 1, x2);
+      }
+      __syncthreads();
+      rp = (rp + 2) & 7;
+      buf ^= 1;
+      n = n1; y0 = y1; x0 = x1;
+      n1 = n2; y1 = y2; x1 = x2;
+      advance_sat(n2, y2, x2);
+    }
   }
   // ---- partial store: part[((slice*KP + kp)*9 + tap)*CoP*CiP + co*CiP + ci] ----
   const int ci = cit * CIT + wn * 32 + l31;
@@ -1447,16 +1601,24 @@ extern "C" int sc_conv3x3_wgrad_bx3(const sc_wgrad_args* a, sc_stream stream) {
   hipStream_t st = (hipStream_t)stream;
   SC_REQUIRE(a->terms >= 0 && a->terms <= 4, "sc_conv3x3_wgrad_bx3: terms must be 0 (= 3), 1, 2, 3 or SC_TERMS_F16X2 (got %d)", a->terms);
   p.absmax = a->absmax;
-#define SC_WGX(WM_, NT_, NCI_, HF_) hipLaunchKernelGGL((k_wgrad3_bx3<WM_, NT_, NCI_, HF_>), grid, dim3(768), 0, st, p)
-#define SC_WGX_NT(NT_, HF_)                                   \
-  do {                                                        \
-    if (pl.wm == 2 && pl.nci == 2) SC_WGX(2, NT_, 2, HF_);    \
-    else if (pl.wm == 2) SC_WGX(2, NT_, 1, HF_);              \
-    else if (pl.nci == 2) SC_WGX(1, NT_, 2, HF_);             \
-    else SC_WGX(1, NT_, 1, HF_);                              \
+  static const int pipe_env = [] { const char* e = getenv("STARCOP_WG3_PIPE"); return e ? atoi(e) : 1; }();   // 0: two-barrier stages
+#define SC_WGX(WM_, NT_, NCI_, HF_, PIPE_) hipLaunchKernelGGL((k_wgrad3_bx3<WM_, NT_, NCI_, HF_, PIPE_>), grid, dim3(768), 0, st, p)
+#define SC_WGX_NT(NT_, HF_, PIPE_)                                   \
+  do {                                                               \
+    if (pl.wm == 2 && pl.nci == 2) SC_WGX(2, NT_, 2, HF_, PIPE_);    \
+    else if (pl.wm == 2) SC_WGX(2, NT_, 1, HF_, PIPE_);              \
+    else if (pl.nci == 2) SC_WGX(1, NT_, 2, HF_, PIPE_);             \
+    else SC_WGX(1, NT_, 1, HF_, PIPE_);                              \
   } while (0)
-  if (a->terms == 1) SC_WGX_NT(1, false); else if (a->terms == 2) SC_WGX_NT(2, false);
-  else if (a->terms == SC_TERMS_F16X2) SC_WGX_NT(2, true); else SC_WGX_NT(3, false);
+  if (a->terms == 1) SC_WGX_NT(1, false, false); else if (a->terms == 2) SC_WGX_NT(2, false, false);
+  else if (a->terms == SC_TERMS_F16X2) {
+    // the pipelined variant: BatchNorm-backward gradients, 8-byte gradient loads (even W), 32-bit byte offsets within a tensor
+    bool pipe = pipe_env && a->dy.mode == SC_SRC_BNBWD && a->W % 2 == 0 && (((uintptr_t)a->dy.x | (uintptr_t)a->dy.aux) & 7) == 0 &&
+                (size_t)a->Cout * a->H * a->W * 4 < (1ull << 32);
+    for (int s = 0; s < a->nsrc; ++s) pipe = pipe && (size_t)a->N * a->src[s].C * (a->H >> a->src[s].up) * (a->W >> a->src[s].up) * 4 < (1ull << 32);
+    if (pipe) SC_WGX_NT(2, true, true); else SC_WGX_NT(2, true, false);
+  }
+  else SC_WGX_NT(3, false, false);
 #undef SC_WGX_NT
 #undef SC_WGX
   SC_LAUNCH_OK("sc_conv3x3_wgrad_bx3");
