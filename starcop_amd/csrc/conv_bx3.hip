@@ -1225,24 +1225,26 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
 
 // ------------------------------------------------------------------------------------------
 // Weight gradient of the THIN 3x3 layers (Cout <= 16, Cin = 16 | 32: smp's decoder.blocks.4 at full resolution) with two fp16
-// terms on v_mfma_f32_16x16x32_f16.  These two layers were the last MFMA-bound fp32 kernels of the step (k_wgrad_mfma16: 0.83 ms at
-// 0.4-0.5 of the fp32 matrix peak); the split needs 3 x 16-cycle MFMAs per 16 x 16 x 32 block instead of 8 x 32 cycles.
+// terms on v_mfma_f32_16x16x32_f16 (3 x 16-cycle MFMAs per 16 x 16 x 32 block; the fp32 kernel needs 8 x 32 cycles).
 // GEMM view (per tap):  D[co][ci] = sum_px dy[co][px] * in[ci][px + d(tap)],  K step = 32 pixels of one image row
 //   A (16 x 32): lane l -> dy[co = l&15][px = 8*(l>>4) .. +7]                  (one 16-byte LDS read per term)
 //   B (32 x 16): lane l -> in[ci = l&15][px + kw + 8*(l>>4) .. +7]: rows are stored from image column x0 - 1, so kw = 0 is an aligned
 //                16-byte read, kw = 1 a 16-bit funnel shift (v_alignbit) with the next dword, kw = 2 a register renaming
 //   D: lane -> ci = l&15, co = 4*(l>>4) + r
-// Work-group = 4 waves; stage = 4 image rows x 32 columns of one image; wave w owns row w (its own K part: four partial rows per
-// work-group, summed by sc_wgrad_finish).  No register prefetch: 39 KB of LDS and <= 168 VGPRs keep three work-groups per CU, which
-// overlap each other's load -> split -> MFMA phases.
+// Work-group = 4 waves; stage = 4 image rows x 32 columns of one image, wave w owns row w (its own K part; the four are summed
+// through LDS at the end).  Pipeline as in k_wgrad3_bx3<PIPE>: the input rows live in a 12-slot ring per channel (a stage reads
+// six rows and the four new rows of the next stage are stored meanwhile), the dy tile is double-buffered: ONE barrier per stage,
+// straight-line loop body (every strip has a pre-stage at y0 = -4 that only brings rows -3 .. 0 in), and each item's global
+// load for stage t+2 is issued right behind its stage t+1 conversion -- a whole stage in flight with no second register set.
 template <int CIN, bool BNB>
 __global__ __launch_bounds__(256, CIN == 32 ? 2 : 3) void k_wgrad_thin_h(const WgradXP p) {
-  constexpr int NCB = CIN / 16, SR = 4, PRW = SR + 2;
-  constexpr int DYP = SR * 32 + 8;          // dy pitch per cout in halves (272 B)
-  constexpr int XP = 40, XCP = PRW * XP + 8; // input pitch per row (34 used) / per channel in halves (80 B / 496 B)
-  constexpr int NDY = (16 * SR * 16) / 256;  // dy pixel pairs per thread per stage
-  constexpr int NXI = (CIN * PRW * 17 + 255) / 256;
-  __shared__ __attribute__((aligned(16))) unsigned s_dy[2][16 * DYP / 2];
+  constexpr int NCB = CIN / 16, SR = 4, RING = 12;
+  constexpr int DYP = SR * 32 + 8;             // dy pitch per cout in halves (272 B)
+  constexpr int XP = 40, XCP = RING * XP + 8;  // input pitch per row (34 used) / per channel in halves (80 B / 976 B: conflict-free)
+  constexpr int NDY = (16 * SR * 16) / 256;    // dy pixel pairs per thread per stage (exact)
+  constexpr int XCNT = CIN * SR * 17;          // input pixel pairs per stage
+  constexpr int NXI = (XCNT + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned s_dy[2][2][16 * DYP / 2];      // [buffer][term]
   __shared__ __attribute__((aligned(16))) unsigned s_x[2][CIN * XCP / 2];
   __shared__ __attribute__((aligned(16))) float s_ca[16 * SC_CST];
   __shared__ __attribute__((aligned(16))) float s_cb[CIN * 4];
@@ -1269,137 +1271,224 @@ __global__ __launch_bounds__(256, CIN == 32 ? 2 : 3) void k_wgrad_thin_h(const W
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) acc[t][cb] = (floatx4){0.f, 0.f, 0.f, 0.f};
 
-  const int tiles_x = (W + 31) >> 5, RS = (H + SR - 1) / SR;
-  const long T = (long)p.N * tiles_x * RS;
+  const int tiles_x = (W + 31) >> 5, RS = (H + SR - 1) / SR, RSS = RS + 1;
+  const long T = (long)p.N * tiles_x * RSS;
   const long t_begin = T * blockIdx.x / p.nsl, t_end = T * (blockIdx.x + 1) / p.nsl;
   const float dlo = sc_act_lo(p.dy.act), dhi = sc_act_hi(p.dy.act);
   const size_t HW = (size_t)H * W;
   const int up = p.s0.up, Ws = W >> up;
-  const size_t plane_s = (size_t)(H >> up) * Ws;
-  __syncthreads();
+  const unsigned istr = (unsigned)((size_t)CIN * (H >> up) * Ws * 4);      // bytes per image of the input (host-checked < 2^32 / N)
 
-  for (long t = t_begin; t < t_end; ++t) {
-    const int strip = (int)(t / RS), ty = (int)(t - (long)strip * RS);
-    const int n = strip / tiles_x, x0 = (strip - n * tiles_x) * 32, y0 = ty * SR;
-    // ---- global loads of the stage, all in flight before the first use
-    float dg[NDY][2], dv[BNB ? NDY : 1][2], xr[NXI][2];
+  // per-item address invariants (bytes within one image)
+  unsigned dyo[NDY], xo[NXI];
 #pragma unroll
-    for (int k = 0; k < NDY; ++k) {
-      const int it = tid + 256 * k;
-      const int co = it >> 6, row = (it >> 4) & 3, col = 2 * (it & 15);
-      const int y = y0 + row, x = x0 + col;
-      const bool okc = co < p.Cout && y < H;
-      const float* const gx = p.dy.x + (size_t)n * p.Cout * HW;
-      const unsigned base = (unsigned)(okc ? co : 0) * (unsigned)HW + (unsigned)((okc ? y : 0) * W);
-      const unsigned xa = (x < W) ? x : 0, xb = (x + 1 < W) ? x + 1 : 0;
-      dg[k][0] = gx[base + xa]; dg[k][1] = gx[base + xb];
-      if (BNB) {
-        const float* const ga = p.dy.aux + (size_t)n * p.Cout * HW;
-        dv[k][0] = ga[base + xa]; dv[k][1] = ga[base + xb];
-      }
+  for (int k = 0; k < NDY; ++k) {
+    const int co = (tid + 256 * k) >> 6;
+    dyo[k] = (unsigned)(co < p.Cout ? co : 0) * (unsigned)HW * 4u;
+  }
+#pragma unroll
+  for (int k = 0; k < NXI; ++k) {
+    int it = tid + 256 * k;
+    if (it >= XCNT) it -= XCNT;
+    xo[k] = (unsigned)((it / 17) >> 2) * (unsigned)((H >> up) * Ws) * 4u;
+  }
+
+  float dg[NDY][2], dv[BNB ? NDY : 1][2], xr[NXI][2];
+  // dy item: co = it >> 6, row = (it >> 4) & 3, columns 2 * (it & 15), +1: one 8-byte load per tensor (W even, host-checked)
+  auto dy_load_item = [&](int k, int n, int y0, int x0) {
+    const int it = tid + 256 * k;
+    const int row = (it >> 4) & 3, col = 2 * (it & 15);
+    const int y = y0 + row, x = x0 + col;
+    const size_t io = (size_t)n * p.Cout * HW * 4;
+    const unsigned off = dyo[k] + (unsigned)(((y >= 0 && y < H) ? y : 0) * W + ((x < W) ? x : 0)) * 4u;
+    const float2 g = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(p.dy.x) + io + off);
+    dg[k][0] = g.x; dg[k][1] = g.y;
+    if (BNB) {
+      const float2 a = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(p.dy.aux) + io + off);
+      dv[k][0] = a.x; dv[k][1] = a.y;
     }
-#pragma unroll
-    for (int k = 0; k < NXI; ++k) {
-      const int it = tid + 256 * k;
-      const int rc = it / 17, pr = it - rc * 17;
-      const int rowi = rc % PRW, cil = (rc / PRW) % CIN;
-      const int y = y0 - 1 + rowi, x = x0 - 1 + 2 * pr;
-      const bool oky = (y >= 0) && (y < H);
-      const float* xp = p.s0.x + ((size_t)n * CIN + cil) * plane_s + (size_t)((oky ? y : 0) >> up) * Ws;
-      const int xa = (x >= 0 && x < W) ? x : 0, xb = (x + 1 < W) ? x + 1 : 0;
-      xr[k][0] = xp[xa >> up]; xr[k][1] = xp[xb >> up];
+  };
+  auto dy_store_item = [&](int k, int buf, int y0, int x0) {
+    const int it = tid + 256 * k;
+    const int co = it >> 6, row = (it >> 4) & 3, col = 2 * (it & 15);
+    const int y = y0 + row, x = x0 + col;
+    const bool ok = (co < p.Cout) && y >= 0 && y < H && x < W;
+    const float4 c0 = *reinterpret_cast<const float4*>(&s_ca[co * SC_CST]);
+    const float c4 = s_ca[co * SC_CST + 4];
+    float v0, v1;
+    if (BNB) {
+      v0 = sc_pro_bnbwd(dg[k][0], dv[k][0], c0.x, c0.y, c0.z, c0.w, c4, dlo, dhi);
+      v1 = sc_pro_bnbwd(dg[k][1], dv[k][1], c0.x, c0.y, c0.z, c0.w, c4, dlo, dhi);
+    } else {
+      v0 = sc_pro_affine(dg[k][0], c0.x, c0.y, dlo, dhi);
+      v1 = sc_pro_affine(dg[k][1], c0.x, c0.y, dlo, dhi);
     }
-    if (t != t_begin) __syncthreads();          // the previous stage's MFMAs are done with the LDS tiles
-    // ---- prologue + two-fp16-term split -> LDS
+    v0 = ok ? v0 * hsg : 0.f;
+    v1 = ok ? v1 * hsg : 0.f;
+    unsigned t0, t1;
+    split2h(v0, v1, t0, t1);
+    const int d = (co * DYP + row * 32 + col) >> 1;
+    s_dy[buf][0][d] = t0; s_dy[buf][1][d] = t1;
+  };
+  // input item: pair pr in 0..16 (columns x0 - 1 + 2 pr, +1), row R + rowi, channel cil; sl0 = ring slot of row R
+  auto x_load_item = [&](int k, int n, int R, int x0) {
+    int it = tid + 256 * k;
+    if (it >= XCNT) it -= XCNT;
+    const int rc = it / 17, pr = it - rc * 17;
+    const int rowi = rc & 3;
+    const int y = R + rowi, x = x0 - 1 + 2 * pr;
+    const int yc = (y >= 0 && y < H) ? y : 0;
+    const int xa = (x >= 0 && x < W) ? x : 0, xb = (x + 1 < W) ? x + 1 : 0;
+    const char* base = reinterpret_cast<const char*>(p.s0.x) + (size_t)n * istr;
+    const unsigned ro = xo[k] + (unsigned)((yc >> up) * Ws) * 4u;
+    xr[k][0] = *reinterpret_cast<const float*>(base + (ro + (unsigned)(xa >> up) * 4u));
+    xr[k][1] = *reinterpret_cast<const float*>(base + (ro + (unsigned)(xb >> up) * 4u));
+  };
+  auto x_store_item = [&](int k, int R, int x0, int sl0) {
+    int it = tid + 256 * k;
+    if (it >= XCNT) it -= XCNT;
+    const int rc = it / 17, pr = it - rc * 17;
+    const int rowi = rc & 3, cil = rc >> 2;
+    const int y = R + rowi, x = x0 - 1 + 2 * pr;
+    const bool oky = (y >= 0) && (y < H);
+    const float4 c = *reinterpret_cast<const float4*>(&s_cb[cil * 4]);
+    float v0 = sc_pro_affine(xr[k][0], c.x, c.y, c.z, c.w);
+    float v1 = sc_pro_affine(xr[k][1], c.x, c.y, c.z, c.w);
+    v0 = (oky && x >= 0 && x < W) ? v0 * SC_H_SX : 0.f;
+    v1 = (oky && x + 1 < W) ? v1 * SC_H_SX : 0.f;
+    unsigned t0, t1;
+    split2h(v0, v1, t0, t1);
+    int slot = sl0 + rowi;
+    slot = slot >= RING ? slot - RING : slot;
+    const int d = ((cil * XCP + slot * XP) >> 1) + pr;
+    s_x[0][d] = t0; s_x[1][d] = t1;
+  };
+  auto ring = [](int v) { return v >= RING ? v - RING : v; };
+  // MFMAs of one stage: wave w = image row y0 + w; rp = ring slot of row y0 - 1
+  auto compute = [&](int rp, int buf) {
+    const int r = wave;
+    halfx8 A[2];
+    const int da = (l15 * DYP + r * 32 + 8 * lg) >> 1;
 #pragma unroll
-    for (int k = 0; k < NDY; ++k) {
-      const int it = tid + 256 * k;
-      const int co = it >> 6, row = (it >> 4) & 3, col = 2 * (it & 15);
-      const int y = y0 + row, x = x0 + col;
-      const bool okc = (co < p.Cout) && y < H;
-      const float4 c0 = *reinterpret_cast<const float4*>(&s_ca[co * SC_CST]);
-      const float c4 = s_ca[co * SC_CST + 4];
-      float v0, v1;
-      if (BNB) {
-        v0 = sc_pro_bnbwd(dg[k][0], dv[k][0], c0.x, c0.y, c0.z, c0.w, c4, dlo, dhi);
-        v1 = sc_pro_bnbwd(dg[k][1], dv[k][1], c0.x, c0.y, c0.z, c0.w, c4, dlo, dhi);
-      } else {
-        v0 = sc_pro_affine(dg[k][0], c0.x, c0.y, dlo, dhi);
-        v1 = sc_pro_affine(dg[k][1], c0.x, c0.y, dlo, dhi);
-      }
-      v0 = (okc && x < W) ? v0 * hsg : 0.f;
-      v1 = (okc && x + 1 < W) ? v1 * hsg : 0.f;
-      unsigned t0, t1;
-      split2h(v0, v1, t0, t1);
-      const int d = (co * DYP + row * 32 + col) >> 1;
-      s_dy[0][d] = t0; s_dy[1][d] = t1;
-    }
+    for (int tm = 0; tm < 2; ++tm) A[tm] = __builtin_bit_cast(halfx8, *reinterpret_cast<const uintx4*>(&s_dy[buf][tm][da]));
 #pragma unroll
-    for (int k = 0; k < NXI; ++k) {
-      const int it = tid + 256 * k;
-      const int rc = it / 17, pr = it - rc * 17;
-      const int rowi = rc % PRW, cil = (rc / PRW) % CIN;
-      const int y = y0 - 1 + rowi, x = x0 - 1 + 2 * pr;
-      const bool oky = (y >= 0) && (y < H);
-      const float4 c = *reinterpret_cast<const float4*>(&s_cb[cil * 4]);
-      float v0 = sc_pro_affine(xr[k][0], c.x, c.y, c.z, c.w);
-      float v1 = sc_pro_affine(xr[k][1], c.x, c.y, c.z, c.w);
-      v0 = (oky && x >= 0 && x < W) ? v0 * SC_H_SX : 0.f;
-      v1 = (oky && x + 1 < W) ? v1 * SC_H_SX : 0.f;
-      unsigned t0, t1;
-      split2h(v0, v1, t0, t1);
-      const int d = ((cil * XCP + rowi * XP) >> 1) + pr;
-      if (it < CIN * PRW * 17) { s_x[0][d] = t0; s_x[1][d] = t1; }
-    }
-    __syncthreads();
-    // ---- MFMAs: wave w = image row y0 + w of the stage
-    {
-      const int r = wave;
-      halfx8 A[2];
-      const int da = (l15 * DYP + r * 32 + 8 * lg) >> 1;
+    for (int kh = 0; kh < 3; ++kh) {
+      const int slot = ring(rp + r + kh);
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm) A[tm] = __builtin_bit_cast(halfx8, *reinterpret_cast<const uintx4*>(&s_dy[tm][da]));
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int dx = (((cb * 16 + l15) * XCP + slot * XP) >> 1) + 4 * lg;
+        halfx8 B[3][2];
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
+        for (int tm = 0; tm < 2; ++tm) {
+          const uintx4 X0 = *reinterpret_cast<const uintx4*>(&s_x[tm][dx]);
+          const unsigned X1 = (*reinterpret_cast<const uintx4*>(&s_x[tm][dx + 4]))[0];
+          uintx4 S1, S2;
+          S1[0] = __builtin_amdgcn_alignbit(X0[1], X0[0], 16);
+          S1[1] = __builtin_amdgcn_alignbit(X0[2], X0[1], 16);
+          S1[2] = __builtin_amdgcn_alignbit(X0[3], X0[2], 16);
+          S1[3] = __builtin_amdgcn_alignbit(X1, X0[3], 16);
+          S2[0] = X0[1]; S2[1] = X0[2]; S2[2] = X0[3]; S2[3] = X1;
+          B[0][tm] = __builtin_bit_cast(halfx8, X0);
+          B[1][tm] = __builtin_bit_cast(halfx8, S1);
+          B[2][tm] = __builtin_bit_cast(halfx8, S2);
+        }
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) {
-          const int dx = (((cb * 16 + l15) * XCP + (r + kh) * XP) >> 1) + 4 * lg;
-          halfx8 B[3][2];
-#pragma unroll
-          for (int tm = 0; tm < 2; ++tm) {
-            const uintx4 X0 = *reinterpret_cast<const uintx4*>(&s_x[tm][dx]);
-            const unsigned X1 = (*reinterpret_cast<const uintx4*>(&s_x[tm][dx + 4]))[0];
-            uintx4 S1, S2;
-            S1[0] = __builtin_amdgcn_alignbit(X0[1], X0[0], 16);
-            S1[1] = __builtin_amdgcn_alignbit(X0[2], X0[1], 16);
-            S1[2] = __builtin_amdgcn_alignbit(X0[3], X0[2], 16);
-            S1[3] = __builtin_amdgcn_alignbit(X1, X0[3], 16);
-            S2[0] = X0[1]; S2[1] = X0[2]; S2[2] = X0[3]; S2[3] = X1;
-            B[0][tm] = __builtin_bit_cast(halfx8, X0);
-            B[1][tm] = __builtin_bit_cast(halfx8, S1);
-            B[2][tm] = __builtin_bit_cast(halfx8, S2);
-          }
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            floatx4 c = acc[kh * 3 + kw][cb];
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], B[kw][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[1], B[kw][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], B[kw][0], c, 0, 0, 0);
-            acc[kh * 3 + kw][cb] = c;
-          }
+        for (int kw = 0; kw < 3; ++kw) {
+          floatx4 c = acc[kh * 3 + kw][cb];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], B[kw][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[1], B[kw][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], B[kw][0], c, 0, 0, 0);
+          acc[kh * 3 + kw][cb] = c;
         }
       }
     }
+  };
+
+  // stage coordinates (n, y0, x0) of t, t+1, t+2; past the last stage they stay on the last one (harmless re-fetch)
+  const int nlast = p.N - 1;
+  auto advance = [&](int& nn, int& yy, int& xx) {
+    const int pn = nn, py = yy, px = xx;
+    yy += SR;
+    if (yy >= SR * RS) { yy = -SR; xx += 32; if (xx >= 32 * tiles_x) { xx = 0; ++nn; } }
+    if (nn > nlast) { nn = pn; yy = py; xx = px; }
+  };
+  int n = 0, y0 = 0, x0 = 0;
+  if (t_begin < t_end) {
+    const int strip = (int)(t_begin / RSS), ty = (int)(t_begin - (long)strip * RSS);
+    n = strip / tiles_x; x0 = (strip - n * tiles_x) * 32; y0 = (ty - 1) * SR;
   }
-  // ---- partial store: part[((slice*4 + wave)*9 + tap)*CoP*CiP + co*CiP + ci]   (CoP = 16, CiP = CIN)
-  const size_t plane = (size_t)16 * CIN;
-  float* pb = p.part + ((size_t)blockIdx.x * 4 + wave) * 9 * plane;
+  int n1 = n, y1 = y0, x1 = x0;
+  advance(n1, y1, x1);
+  int n2 = n1, y2 = y1, x2 = x1;
+  advance(n2, y2, x2);
+  __syncthreads();          // constants in LDS
+  int rp = 0, buf = 0;
+  if (t_begin < t_end) {
+    // the first stage's six rows (two batches of four: rows y0 - 1 .. y0 + 6, the last two are the next stage's first two) and dy
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
+    for (int k = 0; k < NXI; ++k) x_load_item(k, n, y0 - 1, x0);
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
+    for (int k = 0; k < NDY; ++k) dy_load_item(k, n, y0, x0);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pb[tap * plane + (size_t)(4 * lg + r) * CIN + cb * 16 + l15] = acc[tap][cb][r] * hinv;
+    for (int k = 0; k < NXI; ++k) { x_store_item(k, y0 - 1, x0, rp); x_load_item(k, n, y0 + 3, x0); }
+#pragma unroll
+    for (int k = 0; k < NDY; ++k) { dy_store_item(k, 0, y0, x0); dy_load_item(k, n1, y1, x1); }
+#pragma unroll
+    for (int k = 0; k < NXI; ++k) { x_store_item(k, y0 + 3, x0, rp + 4); x_load_item(k, n1, y1 + 1, x1); }
+    __syncthreads();
+  }
+  for (long t = t_begin; t < t_end; ++t) {
+    if (y0 >= 0) compute(rp, buf);            // (the pre-stage of a strip has no gradient rows)
+#pragma unroll
+    for (int k = 0; k < NDY; ++k) {
+      dy_store_item(k, buf ^ 1, y1, x1);
+      dy_load_item(k, n2, y2, x2);
+    }
+    const int sl1 = ring(rp + 6);             // rows y1 + 1 .. y1 + 4 = y0 + 5 .. y0 + 8
+#pragma unroll
+    for (int k = 0; k < NXI; ++k) {
+      x_store_item(k, y1 + 1, x1, sl1);
+      x_load_item(k, n2, y2 + 1, x2);
+    }
+    __syncthreads();
+    rp = ring(rp + 4);
+    buf ^= 1;
+    n = n1; y0 = y1; x0 = x1;
+    n1 = n2; y1 = y2; x1 = x2;
+    advance(n2, y2, x2);
+  }
+  // ---- the four waves' partial sums through LDS (two rounds), then part[slice][tap][co][ci]   (CoP = 16, CiP = CIN)
+  float* red = reinterpret_cast<float*>(&s_x[0][0]);        // 2 x 9 x NCB x 256 floats = 18 / 36 KB of the 31 / 62 KB ring
+  auto put = [&](int slot) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+        *reinterpret_cast<floatx4*>(&red[(((slot * 9 + tap) * NCB + cb) * 64 + lane) * 4]) = acc[tap][cb];
+  };
+  auto take = [&](int slot) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) acc[tap][cb] += *reinterpret_cast<const floatx4*>(&red[(((slot * 9 + tap) * NCB + cb) * 64 + lane) * 4]);
+  };
+  if (wave >= 2) put(wave - 2);
+  __syncthreads();
+  if (wave < 2) take(wave);
+  __syncthreads();
+  if (wave == 1) put(0);
+  __syncthreads();
+  if (wave == 0) {
+    take(0);
+    const size_t plane = (size_t)16 * CIN;
+    float* pb = p.part + (size_t)blockIdx.x * 9 * plane;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pb[tap * plane + (size_t)(4 * lg + r) * CIN + cb * 16 + l15] = acc[tap][cb][r] * hinv;
+  }
 }
 
 struct WgradXPlan { int wm, nci, kp, nsl, CoP, CiP, co_tiles, ci_tiles; };
@@ -1626,14 +1715,14 @@ extern "C" int sc_conv3x3_wgrad_bx3(const sc_wgrad_args* a, sc_stream stream) {
 }
 
 static int wgrad_thin16_slices(int N, int H, int W) {
-  const long T = (long)N * ((W + 31) / 32) * ((H + 3) / 4);
+  const long T = (long)N * ((W + 31) / 32) * ((H + 3) / 4 + 1);
   return (int)(T < 768 ? T : 768);            // three work-groups per CU resident: one round of 768
 }
 
 extern "C" size_t sc_wgrad_thin16_workspace_floats(int N, int H, int W, int Cout, int Cin) {
   (void)Cout;
   const size_t E = (size_t)9 * 16 * Cin;
-  const int nparts = 4 * wgrad_thin16_slices(N, H, W);
+  const int nparts = wgrad_thin16_slices(N, H, W);
   return (size_t)nparts * E + sc_reduce_scratch_floats(nparts, E);
 }
 
@@ -1648,7 +1737,9 @@ extern "C" int sc_conv3x3_wgrad_thin16(const sc_wgrad_args* a, sc_stream stream)
   const sc_src& s = a->src[0];
   SC_REQUIRE((s.mode == SC_SRC_RAW || (s.mode == SC_SRC_AFFINE && s.cst != nullptr)), "sc_conv3x3_wgrad_thin16: input source must be RAW or AFFINE");
   SC_REQUIRE(s.up == 0 || (s.up == 1 && a->H % 2 == 0 && a->W % 2 == 0), "sc_conv3x3_wgrad_thin16: upsampled source needs even H, W");
-  SC_REQUIRE((size_t)a->Cout * a->H * a->W < (1ull << 32), "sc_conv3x3_wgrad_thin16: image too large for 32-bit lane offsets");
+  SC_REQUIRE((size_t)a->Cout * a->H * a->W * 4 < (1ull << 32) && (size_t)a->N * a->Cin * a->H * a->W * 4 < (1ull << 32),
+             "sc_conv3x3_wgrad_thin16: tensors too large for 32-bit byte offsets");
+  SC_REQUIRE(a->W % 2 == 0 && (((uintptr_t)a->dy.x | (uintptr_t)a->dy.aux) & 7) == 0, "sc_conv3x3_wgrad_thin16: needs an even width and 8-byte aligned gradient tensors");
   const size_t need = sc_wgrad_thin16_workspace_floats(a->N, a->H, a->W, a->Cout, a->Cin);
   SC_REQUIRE(a->part_floats >= need, "sc_conv3x3_wgrad_thin16: workspace too small (%zu < %zu floats)", a->part_floats, need);
   WgradXP p;
@@ -1662,7 +1753,7 @@ extern "C" int sc_conv3x3_wgrad_thin16(const sc_wgrad_args* a, sc_stream stream)
   if (a->Cin == 16) { if (bnb) hipLaunchKernelGGL((k_wgrad_thin_h<16, true>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((k_wgrad_thin_h<16, false>), grid, dim3(256), 0, st, p); }
   else              { if (bnb) hipLaunchKernelGGL((k_wgrad_thin_h<32, true>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((k_wgrad_thin_h<32, false>), grid, dim3(256), 0, st, p); }
   SC_LAUNCH_OK("sc_conv3x3_wgrad_thin16");
-  return sc_wgrad_finish(a->part, 4 * p.nsl, 9, a->Cout, a->Cin, 16, a->Cin, a->dw, st);
+  return sc_wgrad_finish(a->part, p.nsl, 9, a->Cout, a->Cin, 16, a->Cin, a->dw, st);
 }
 
 static int thin_steps(int Cout, int Cin, int transpose_flip) { return (9 * ((transpose_flip ? Cout : Cin) / 8) + 3) / 4; }

@@ -805,7 +805,7 @@ class HyperStarcopUNet(nn.Module):
             wfn = (lib.sc_conv3x3_wgrad_bx3 if (self.split_bf16 and ks == 3 and conv.out_channels >= 32 and conv.in_channels >= 32)
                    else lib.sc_conv2d_wgrad_mfma)     # 16-channel layers outside the cases below stay on the fp32 MFMA
             if (self.split_bf16 and self.thin16 and ks == 3 and self._terms[1] == TERMS_F16X2 and len(ins) == 1
-                    and conv.out_channels <= 16 and conv.in_channels in (16, 32)):
+                    and conv.out_channels <= 16 and conv.in_channels in (16, 32) and Wo % 2 == 0):
                 wfn = lib.sc_conv3x3_wgrad_thin16     # decoder.blocks.4: two fp16 terms on the 16x16x32 MFMA (was MFMA-bound in fp32)
             tok = self._pb("k_wgrad3_bx3 (+reduce)" if wfn is lib.sc_conv3x3_wgrad_bx3 else
                            "k_wgrad_thin_h (+reduce)" if wfn is lib.sc_conv3x3_wgrad_thin16 else f"k_wgrad_mfma<{ks}> (+reduce)", flop)

@@ -740,7 +740,7 @@ def test_wgrad_deferred_batch_reduce(hip):
 
 
 @pytest.mark.parametrize("cin,cout,H,W,up,bnb", [(16, 16, 32, 64, 0, True), (32, 16, 16, 32, 0, True), (32, 16, 24, 40, 1, True), (16, 8, 20, 36, 0, False),
-                                                   (32, 16, 64, 64, 1, True), (16, 16, 9, 33, 0, True)])
+                                                   (32, 16, 64, 64, 1, True), (16, 16, 9, 34, 0, True), (16, 16, 3, 70, 0, True), (32, 12, 5, 32, 0, False)])
 def test_wgrad_thin16_split(hip, cin, cout, H, W, up, bnb):
     """thin 3x3 weight gradient on the two-fp16-term 16x16x32 MFMA (sc_conv3x3_wgrad_thin16: decoder.blocks.4) against autograd
     in fp64: BNBWD / affine dy prologues, affine + ReLU input prologue, nearest-x2 upsampled input, ragged edges, range hint"""
