@@ -117,6 +117,9 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
   constexpr int NWV = (WENT + 255) / 256;
   constexpr int WENTP = PAD ? NWV * 256 : WENT;      // padded likewise
   constexpr int NR = 3;
+  // filters fetched two stages ahead: 12 more registers, so not in the 256-register three-term kernels and not in the
+  // 32-cout BatchNorm-backward kernel (168 registers for three work-groups per CU: it would spill)
+  constexpr bool W2 = (NT != 3) && !(Q == 1 && BNB);
 
   __shared__ uintx4 s_p[NT][2][NPXP];
   __shared__ uintx4 s_w[2][WENTP];
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
     }
   }
   float xv[NR][8], av[BNB ? NR : 1][8];
-  uintx4 wv[NWV];
+  uintx4 wvA[NWV], wvB[W2 ? NWV : 1];    // filter stages s+1 and (W2) s+2, see the pipeline below
   // per-chunk source description (uniform)
   const float* xb = nullptr; const float* ab = nullptr; const float* cb = nullptr;
   size_t plane = 0; int nch = 0; bool second = false;
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
       }
     }
   };
-  auto load_w = [&](int s) {
+  auto load_w = [&](uintx4 (&wv)[NWV], int s) {
     const uintx4* src = wbase + (size_t)s * WENT;
 #pragma unroll
     for (int j = 0; j < NWV; ++j) {
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
       wv[j] = src[i < WENT ? i : WENT - 1];
     }
   };
-  auto store_w = [&](int buf) {
+  auto store_w = [&](const uintx4 (&wv)[NWV], int buf) {
 #pragma unroll
     for (int j = 0; j < NWV; ++j)
       if (PAD || tid + 256 * j < WENT) s_w[buf][tid + 256 * j] = wv[j];
@@ -281,6 +284,10 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
   // operand fetches of one step are issued before the 6*Q MFMAs of the previous step (explicit software pipeline: the
   // scheduler barrier keeps the LDS reads ~6*Q*32 cycles ahead of their use)
   auto load_A = [&](bf16x8 (&A)[Q][NT], int buf, int kw) {
+#if SC_EXP == 8      // experiment: no LDS operand reads
+    for (int q = 0; q < Q; ++q) for (int c = 0; c < NT; ++c) A[q][c] = __builtin_bit_cast(bf16x8, (uintx4){(unsigned)(buf + kw + q), (unsigned)c, 1u, 2u});
+    return;
+#endif
 #pragma unroll
     for (int q = 0; q < Q; ++q)
 #pragma unroll
@@ -288,6 +295,13 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
         A[q][c] = __builtin_bit_cast(bf16x8, s_w[buf][((c * 3 + kw) * 2 + lhi) * CO_T + q * 32 + l31]);
   };
   auto load_B = [&](bf16x8 (&B)[NT], int kh, int kw, int pp) {
+#if SC_EXP == 8
+    for (int c = 0; c < NT; ++c) B[c] = __builtin_bit_cast(bf16x8, (uintx4){(unsigned)(kh + kw + pp), (unsigned)c, 3u, 4u});
+    return;
+#endif
+#if SC_EXP == 11     // experiment: only the kw = 0 patch operands are read (a third of the B reads; wrong results)
+    if (kw != 0) return;
+#endif
     const int e = (2 * wave + pp + kh) * PC + l31 + kw;
 #pragma unroll
     for (int c = 0; c < NT; ++c) B[c] = __builtin_bit_cast(bf16x8, s_p[c][lhi][e]);
@@ -313,7 +327,11 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
     bf16x2 h0 = {}, h1 = {}, h2 = {};
     auto mf = [&](int i) {
       const int pr = i / Q, q = i - pr * Q;
+#if SC_EXP == 7      // experiment: no MFMAs (two integer ops keep the operand reads alive)
+      acc[PP][q][0] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, acc[PP][q][0]) ^ __builtin_bit_cast(uintx4, A[q][TA[pr]])[pr & 3] ^ __builtin_bit_cast(uintx4, B[TB[pr]])[(pr + 1) & 3]);
+#else
       acc[PP][q] = mfma_split<HF>(A[q][TA[pr]], B[TB[pr]], acc[PP][q]);
+#endif
     };
     auto pro = [&](int j) {
       const float t = BNB ? sc_pro_bnbwd(xv[r][j], av[BNB ? r : 0][j], cs0[j], cs1[j], cs2[j], cs3[j], cs4[j], slo, shi)
@@ -372,48 +390,126 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
   };
 #undef SC_BX3_MFMAS
 #undef SC_BX3_STEP
+  // the same six steps with every operand requested TWO steps before its use (three patch-operand buffers, 8 more registers):
+  // one step of 3*Q MFMAs (96 / 192 cycles) does not cover the LDS latency once 8-12 waves per CU are reading
+  auto compute_deep = [&](int kh, int buf) {
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    constexpr std::false_type nocv{};
+    bf16x8 A0[Q][NT], A1[Q][NT], Ba[NT], Bb[NT], Bc[NT];
+    load_A(A0, buf, 0); load_B(Ba, kh, 0, 0); load_B(Bb, kh, 0, 1);
+    load_A(A1, buf, 1); load_B(Bc, kh, 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    step(A0, Ba, P0{}, nocv, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_B(Ba, kh, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    step(A0, Bb, P1{}, nocv, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_A(A0, buf, 2); load_B(Bb, kh, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    step(A1, Bc, P0{}, nocv, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_B(Bc, kh, 2, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    step(A1, Ba, P1{}, nocv, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    step(A0, Bb, P0{}, nocv, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    step(A0, Bc, P1{}, nocv, 0);
+  };
 
   // ---- pipeline: filters double-buffered per filter row, patch single-buffered with register prefetch ----
+  // vmcnt retires in order: waiting for a filter stage that was requested AFTER the next chunk's patch waits for the patch as
+  // well.  W2: the filters of stage s+2 are requested at the top of stage s, BEFORE the patch loads of that stage, so the stage
+  // ends of a chunk only ever wait for requests older than the patch and the patch has the whole chunk (three stages of MFMAs)
+  // to arrive.  Without W2 (three-term kernels, no registers left) it has one stage.
   select_chunk(0);
 #pragma unroll
   for (int r = 0; r < NR; ++r) load_round(r);
-  load_w(0);
+  load_w(wvA, 0);
   load_consts();
 #pragma unroll
   for (int u = 0; u < 12; ++u) convert_unit(u >> 2, u & 3);
   store_patch();
-  store_w(0);
-  __syncthreads();
+  store_w(wvA, 0);
   const int nst = 3 * nk;
-  auto stage = [&](int s, int kh, auto cvt, int cv) {
-    load_w(s + 1 < nst ? s + 1 : s);          // the last stage reloads itself (unused)
-    compute(kh, s & 1, cvt, cv);
-    store_w((s + 1) & 1);
-    __syncthreads();
-  };
-  for (int kc = 0; kc < nk; ++kc) {
-    const int s = 3 * kc;
-    if (kc + 1 < nk) {
-      select_chunk(kc + 1);
+  if constexpr (W2) load_w(wvA, 1);             // nst >= 3
+  __syncthreads();
+  auto next_patch = [&](int kc) {
+    select_chunk(kc + 1);
 #pragma unroll
-      for (int r = 0; r < NR; ++r) load_round(r);        // the whole next patch: a chunk of MFMAs hides the HBM latency
-      load_consts();
-      stage(s, 0, std::false_type{}, 0);
-      if (BNB || NT != 3) {   // the longer BatchNorm-backward prologue does not fit the MFMA shadows (and the registers): convert after
-        stage(s + 1, 1, std::false_type{}, 0);
-        stage(s + 2, 2, std::false_type{}, 0);
+    for (int r = 0; r < NR; ++r) load_round(r);        // the whole next patch: a chunk of MFMAs hides the HBM latency
+    load_consts();
+  };
+  if constexpr (W2) {
+    // stage s: request W(s+2) into WB, [patch], MFMAs from buffer s&1, W(s+1) (in WA since the previous stage) -> buffer (s+1)&1
+    auto stage = [&](int s, int kh, uintx4 (&WA)[NWV], uintx4 (&WB)[NWV], int patch_kc) {
+      load_w(WB, s + 2 < nst ? s + 2 : nst - 1);
+      if (patch_kc >= 0) next_patch(patch_kc);
+#if SC_EXP == 12
+      compute(kh, s & 1, std::false_type{}, 0);
+#else
+      compute_deep(kh, s & 1);
+#endif
+      store_w(WA, (s + 1) & 1);
+#if SC_EXP != 9      // experiment 9: no barriers
+      __syncthreads();
+#endif
+    };
+    auto chunk = [&](int kc, uintx4 (&WA)[NWV], uintx4 (&WB)[NWV]) {
+      const int s = 3 * kc;
+      const bool more = kc + 1 < nk;
+      stage(s, 0, WA, WB, more ? kc : -1);
+      stage(s + 1, 1, WB, WA, -1);
+      stage(s + 2, 2, WA, WB, -1);
+      if (more) {
+#if SC_EXP != 10     // experiment 10: no conversion
 #pragma unroll
         for (int u = 0; u < 12; ++u) convert_unit(u >> 2, u & 3);
-      } else {
-        stage(s + 1, 1, std::true_type{}, 0);
-        stage(s + 2, 2, std::true_type{}, 1);
+#endif
+        store_patch();
+#if SC_EXP != 9
+        __syncthreads();
+#endif
       }
-      store_patch();
+    };
+    for (int kc = 0; kc < nk; kc += 2) {
+      chunk(kc, wvA, wvB);
+      if (kc + 1 < nk) chunk(kc + 1, wvB, wvA);
+    }
+  } else {
+    auto stage = [&](int s, int kh, auto cvt, int cv) {
+      load_w(wvA, s + 1 < nst ? s + 1 : s);          // the last stage reloads itself (unused)
+#if SC_EXP == 12
+      compute(kh, s & 1, cvt, cv);
+#else
+      if constexpr (NT != 3) compute_deep(kh, s & 1); else compute(kh, s & 1, cvt, cv);
+#endif
+      store_w(wvA, (s + 1) & 1);
       __syncthreads();
-    } else {
-      stage(s, 0, std::false_type{}, 0);
-      stage(s + 1, 1, std::false_type{}, 0);
-      stage(s + 2, 2, std::false_type{}, 0);
+    };
+    for (int kc = 0; kc < nk; ++kc) {
+      const int s = 3 * kc;
+      if (kc + 1 < nk) {
+        next_patch(kc);
+        stage(s, 0, std::false_type{}, 0);
+        if (BNB) {   // the longer BatchNorm-backward prologue does not fit the MFMA shadows (and the registers): convert after
+          stage(s + 1, 1, std::false_type{}, 0);
+          stage(s + 2, 2, std::false_type{}, 0);
+#pragma unroll
+          for (int u = 0; u < 12; ++u) convert_unit(u >> 2, u & 3);
+        } else {
+          stage(s + 1, 1, std::true_type{}, 0);
+          stage(s + 2, 2, std::true_type{}, 1);
+        }
+        store_patch();
+        __syncthreads();
+      } else {
+        stage(s, 0, std::false_type{}, 0);
+        stage(s + 1, 1, std::false_type{}, 0);
+        stage(s + 2, 2, std::false_type{}, 0);
+      }
     }
   }
 

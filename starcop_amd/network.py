@@ -101,6 +101,8 @@ class _T:
 
 
 _COT_RATIO = float(os.environ.get("STARCOP_COT_RATIO", "1.15"))
+# development knob: "d0a,d0b;d0a" forces 32-wide cout tiles for the forward (before ';') / backward-data launches of these ops
+_FORCE_COT32 = [set(x.split(",")) for x in (os.environ.get("STARCOP_FORCE_COT32", ";") + ";").split(";")[:2]]
 
 
 def _pick_cot(M, ks=1):
@@ -447,6 +449,10 @@ class HyperStarcopUNet(nn.Module):
                 if ks == 3 and co <= 16 and ci >= 32 and self.split_bf16:
                     cf = 32       # decoder.blocks.4.conv1 (32 -> 16): the split kernel with half-empty cout blocks still beats
                                   # the fp32-MFMA thin kernel (0.36 vs 0.50 ms); 16 -> 16 layers do not (tools/bench_thin_bx3.py)
+                if op["out"].name in _FORCE_COT32[0]:
+                    cf = 32
+                if op["out"].name in _FORCE_COT32[1]:
+                    cb = 32
                 # 3x3 layers with >= 32 output channels run on the 16-bit matrix cores with exactly-split operands
                 # (fp32-level accuracy, conv_bx3.hip; `precision` picks the split); thin ones stay on the fp32 MFMA kernels
                 xf = self.split_bf16 and ks == 3 and cf >= 32
