@@ -70,6 +70,19 @@ __device__ __forceinline__ void split2h(float a, float b, unsigned& t0, unsigned
   t0 = __builtin_bit_cast(unsigned, h0);
   t1 = __builtin_bit_cast(unsigned, h1);
 }
+// The same split with scalar remainders, for the producer waves of k_conv3_ws: beside the MFMAs of the consumer wave on the
+// same SIMD a v_pk_add_f32 costs several issue slots (MI355X_MICROARCH.md: packed f32 VALU is "an anti-lever beside MFMAs";
+// measured -7 % there).  In the single-role kernels, whose staging phases are VALU-bound, the packed form is the faster one
+// (weight gradients +3-6 %, thin forward +2-5 % with the scalar form).
+__device__ __forceinline__ void split2h_scalar(float a, float b, unsigned& t0, unsigned& t1) {
+  a = __builtin_amdgcn_fmed3f(a, -SC_H_MAX, SC_H_MAX);
+  b = __builtin_amdgcn_fmed3f(b, -SC_H_MAX, SC_H_MAX);
+  const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+  const float ra = a - (float)ha, rb = b - (float)hb;
+  const _Float16 la = (_Float16)ra, lb = (_Float16)rb;
+  t0 = (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+  t1 = (unsigned)__builtin_bit_cast(unsigned short, la) | ((unsigned)__builtin_bit_cast(unsigned short, lb) << 16);
+}
 template <bool HF>
 __device__ __forceinline__ floatx16 mfma_split(const bf16x8& a, const bf16x8& b, const floatx16& c) {
   if constexpr (HF) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(halfx8, a), __builtin_bit_cast(halfx8, b), c, 0, 0, 0);
@@ -138,6 +151,26 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
     const int per_img = tiles_x * ((H + 7) >> 3);
     const int slot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
     int pt;
+    if (p.xcdmap == 3) {
+      // cout-major: every XCD owns a few cout tiles (or, with fewer than 8 tiles, 8/ncot XCDs share one and split the pixel
+      // tiles) and walks all pixel tiles for them.  For layers whose packed filters exceed an XCD's 4 MB L2 (decoder.blocks.0:
+      // 12.7 MB) the pixel-major orders re-stream ALL filters from memory for every group of pixel tiles (0.8 GB per launch,
+      // the work-groups then run at the ~9 B/clk/CU of memory-side loads); this way an XCD's filters stay in its L2 and the
+      // (much smaller) patches are what is fetched 8 times
+      const int total = per_img * p.N;
+      if (ncot >= 8) {
+        const int mine = (ncot - xcd + 7) >> 3;             // cout tiles xcd, xcd + 8, ...
+        const int k = slot / total;
+        if (k >= mine) return;
+        cot = xcd + 8 * k; pt = slot - k * total;
+      } else {
+        const int g = 8 / ncot;                             // ncot in {1, 2, 4} (host-checked)
+        const int per = (total + g - 1) / g;
+        cot = xcd / g; pt = (xcd - cot * g) * per + slot;
+        if (slot >= per || pt >= total) return;
+      }
+      n = pt / per_img; tile = pt - n * per_img;
+    } else {
     if (p.xcdmap == 2) {
       // each XCD walks a CONTIGUOUS eighth of the pixel tiles in order: x- and y-neighbouring tiles (which share halo columns /
       // rows and the 128-byte lines their misaligned 34-pixel row segments straddle) run on one XCD within its ~64 resident
@@ -152,6 +185,7 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
     }
     cot = slot % ncot;
     n = pt / per_img; tile = pt - n * per_img;
+    }
   } else {
     n = blockIdx.z; cot = blockIdx.y; tile = blockIdx.x;
   }
@@ -645,6 +679,504 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
       }
     }
   }
+  if (want_stats) {
+    // two partial rows per work-group, laid out exactly like the 4-row tiles of k_conv_mfma<3> (SC_STAT_CONV3)
+    __syncthreads();
+    const int rows4 = (H + 3) >> 2;
+    for (int i = tid; i < 2 * CO_T * 2; i += 256) {
+      const int hh = i / (CO_T * 2), rem = i - hh * (CO_T * 2);
+      const int col = rem >> 1, k = rem & 1;
+      const int co = cot * CO_T + col;
+      const int t4 = 2 * ty + hh;
+      if (co < p.Cout && t4 < rows4) {
+        const float t = s_red[2 * hh][col][k] + s_red[2 * hh + 1][col][k];
+        const size_t row = ((size_t)n * rows4 + t4) * tiles_x + tx;
+        p.stats[(row * p.Cout + co) * 2 + k] = t;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Wave-specialised variant of k_conv3_bx3 for the two-fp16-term mode: 8 waves, waves 0-3 CONSUME (LDS operand reads + MFMAs,
+// the tile mapping of k_conv3_bx3: wave w = output rows 2w, 2w+1, all Q cout blocks), waves 4-7 PRODUCE (global loads,
+// prologue, split, LDS stores of the next chunk's patch and of the next filter row).  The patch is double-buffered, so the
+// two halves only meet at ONE barrier per filter-row stage.  Why: in the single-role kernel a wave's MFMA phases and its
+// staging phases alternate, the other work-group on the CU is mostly in the same phase, and the matrix pipe sits at 23-38 %
+// (SQ_VALU_MFMA_BUSY_CYCLES); removing the MFMAs alone (operand reads kept) left 65-75 % of the time, i.e. the two parts ran
+// back to back.  Here one consumer and one producer wave share each SIMD and overlap by construction.
+// Producer pipeline per stage s = 3 kc + j (all straight-line, so the compiler's vmcnt counting stays exact):
+//   request filters W(s+2)  ->  convert + store round j of patch kc+1 (requested one chunk ago)  ->  [j == 2: constants of
+//   chunk kc+2]  ->  request round j of patch kc+2 into the same registers  ->  store W(s+1)  ->  barrier
+// (filters are requested BEFORE the patch round of the stage: vmcnt retires in order, and this way waiting for a filter row
+// never waits for a younger patch request).
+template <int Q, bool BNB>
+__global__ __launch_bounds__(512, 4) void k_conv3_ws(const ConvXP p) {
+  constexpr int NT = 2;
+  constexpr bool HF = true;
+  constexpr int PR = 10, PC = 34, NPX = PR * PC;     // 8 output rows + halo
+  constexpr int NPXP = NPX;                          // (guarded stores in the third staging round: two work-groups per CU need < 80 KB)
+  constexpr int CO_T = 32 * Q;
+  constexpr int WENT = 6 * NT * CO_T;                // 16-byte filter entries per (chunk, kh) stage
+  constexpr int NWV = (WENT + 255) / 256;
+  constexpr int WENTP = NWV * 256;
+  constexpr int NR = 3;
+
+  __shared__ uintx4 s_p[2][NT][2][NPXP];
+  __shared__ uintx4 s_w[2][WENTP];
+  __shared__ float s_red[4][CO_T][2];
+  constexpr int WS_BNB_MAXC = 256;                   // BatchNorm-backward sources: the constants of all channels live in LDS (host-checked)
+  __shared__ __attribute__((aligned(16))) float s_cst[BNB ? WS_BNB_MAXC * SC_CST : 4];
+
+  const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);      // 0: consumer, 1: producer
+  const int tid = threadIdx.x & 255;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int H = p.H, W = p.W;
+  const int tiles_x = (W + 31) >> 5;
+  int n, cot, tile;
+  if (p.xcdmap) {
+    // work-groups go to the 8 XCDs round-robin by linear id and each XCD has its own L2: number the cout tiles of one pixel tile 8
+    // apart so that they run on ONE XCD back to back and the patch they all stage is fetched from memory once, not once per cout tile
+    const int ncot = (p.Cout + CO_T - 1) / CO_T;
+    const int per_img = tiles_x * ((H + 7) >> 3);
+    const int slot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    int pt;
+    if (p.xcdmap == 3) {
+      // cout-major: every XCD owns a few cout tiles (or, with fewer than 8 tiles, 8/ncot XCDs share one and split the pixel
+      // tiles) and walks all pixel tiles for them.  For layers whose packed filters exceed an XCD's 4 MB L2 (decoder.blocks.0:
+      // 12.7 MB) the pixel-major orders re-stream ALL filters from memory for every group of pixel tiles (0.8 GB per launch,
+      // the work-groups then run at the ~9 B/clk/CU of memory-side loads); this way an XCD's filters stay in its L2 and the
+      // (much smaller) patches are what is fetched 8 times
+      const int total = per_img * p.N;
+      if (ncot >= 8) {
+        const int mine = (ncot - xcd + 7) >> 3;             // cout tiles xcd, xcd + 8, ...
+        const int k = slot / total;
+        if (k >= mine) return;
+        cot = xcd + 8 * k; pt = slot - k * total;
+      } else {
+        const int g = 8 / ncot;                             // ncot in {1, 2, 4} (host-checked)
+        const int per = (total + g - 1) / g;
+        cot = xcd / g; pt = (xcd - cot * g) * per + slot;
+        if (slot >= per || pt >= total) return;
+      }
+      n = pt / per_img; tile = pt - n * per_img;
+    } else {
+    if (p.xcdmap == 2) {
+      // each XCD walks a CONTIGUOUS eighth of the pixel tiles in order: x- and y-neighbouring tiles (which share halo columns /
+      // rows and the 128-byte lines their misaligned 34-pixel row segments straddle) run on one XCD within its ~64 resident
+      // work-groups, so those lines are L2 hits instead of separate memory requests
+      const int total = per_img * p.N, per_xcd = (total + 7) >> 3;
+      const int j = slot / ncot;
+      pt = xcd * per_xcd + j;
+      if (j >= per_xcd || pt >= total) return;
+    } else {
+      pt = (slot / ncot) * 8 + xcd;
+      if (pt >= per_img * p.N) return;
+    }
+    cot = slot % ncot;
+    n = pt / per_img; tile = pt - n * per_img;
+    }
+  } else {
+    n = blockIdx.z; cot = blockIdx.y; tile = blockIdx.x;
+  }
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int y0 = ty * 8, x0 = tx * 32;
+  const int C0 = p.s0.C;
+  const int Cin = C0 + p.s1.C;
+  const int nk = (Cin + 15) >> 4;                    // packed filters are zero-padded to nk*16 input channels
+  const uintx4* wbase = p.wpk + (size_t)cot * nk * 3 * WENT;
+
+  // fp16 mode: operand scale of the staged tensor and the factor that removes it (and the filters' 2^8) again
+  const float hsx = !HF ? 1.f : (BNB ? h_grad_scale(p.absmax) : SC_H_SX);
+  const float hinv = !HF ? 1.f : 1.f / (hsx * SC_H_SW);
+
+  const int nst = 3 * nk;
+  const bool want_stats = p.stats != nullptr;
+  if constexpr (BNB) {
+    for (int i = (int)threadIdx.x; i < p.s0.C * SC_CST; i += 512) s_cst[i] = p.s0.cst[i];
+    __syncthreads();
+  }
+  if (role == 1) {
+    // =========================== producers ===========================
+  // ---- staging state (producers) ----
+  const int hw = __builtin_amdgcn_readfirstlane(wave >> 1);     // channel half staged by this wave (uniform)
+  const int sidx = tid & 127;
+  unsigned off0[NR], off1[NR];        // clamped pixel offsets in source 0 / source 1 (they may differ in `up`)
+  unsigned inb = 0;
+  {
+    const int up0 = p.s0.up, up1 = p.s1.up;
+    const int Ws0 = W >> up0, Ws1 = W >> up1;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int e = sidx + 128 * r;
+      const int pr = e / PC, pc = e - pr * PC;
+      const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+      const bool ok = (e < NPX) && (y >= 0) && (y < H) && (x >= 0) && (x < W);
+      off0[r] = ok ? (unsigned)((y >> up0) * Ws0 + (x >> up0)) : 0u;
+      off1[r] = ok ? (unsigned)((y >> up1) * Ws1 + (x >> up1)) : 0u;
+      inb |= ok ? (1u << r) : 0u;
+    }
+  }
+  float xv[NR][8], av[BNB ? NR : 1][8];
+  uintx4 wr[3][NWV];                                   // filter rows s+1 .. s+3, each requested one chunk before its LDS store
+  struct Chunk { const float* xb; const float* ab; const float* cb; size_t plane; int nch, cbase; bool second, raw; float slo, shi; };
+  auto make_chunk = [&](int kc) {
+    Chunk c;
+    c.second = kc * 16 >= C0;
+    const SrcD& s = c.second ? p.s1 : p.s0;
+    c.slo = sc_act_lo(s.act); c.shi = sc_act_hi(s.act);
+    c.plane = (size_t)(H >> s.up) * (W >> s.up);
+    const int cbase = kc * 16 + hw * 8 - (c.second ? C0 : 0);       // first channel (source space) staged by this wave
+    c.nch = s.C - cbase;                                              // channels j < nch exist
+    c.cbase = c.nch > 0 ? cbase : 0;
+    const size_t o = ((size_t)n * s.C + (c.nch > 0 ? cbase : 0)) * c.plane;
+    c.xb = s.x + o;
+    c.ab = BNB ? s.aux + o : nullptr;
+    // RAW sources load (and ignore) a few of their own values: a load under a branch would make the compiler drain vmcnt at the
+    // merge, and a pointer to a __device__ table of identity constants turns the loads into FLAT ones (vmcnt(0) again)
+    c.raw = s.mode == SC_SRC_RAW;
+    c.cb = c.raw ? s.x : s.cst + (size_t)(c.nch > 0 ? cbase : 0) * SC_CST;
+    return c;
+  };
+  auto load_round = [&](const Chunk& c, int r) {
+    const unsigned o = c.second ? off1[r] : off0[r];
+    const int jmax = c.nch > 0 ? c.nch - 1 : 0;       // channels beyond the last re-read it (masked at conversion), see k_conv3_bx3
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const size_t cj = (size_t)(j < jmax ? j : jmax) * c.plane;
+      xv[r][j] = c.xb[cj + o];
+      if (BNB) av[r][j] = c.ab[cj + o];
+    }
+  };
+  struct Cst { float sc[BNB ? 1 : 8], sh[BNB ? 1 : 8]; };    // forward: scale / shift of a chunk's eight channels (BNB: constants in LDS)
+  Cst csA, csB;
+  auto load_consts = [&](const Chunk& c, Cst& k) {
+    if constexpr (!BNB) {
+      const int jmax = c.nch > 0 ? c.nch - 1 : 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int cj = j < jmax ? j : jmax;
+        const float2 v = *reinterpret_cast<const float2*>(c.cb + (size_t)cj * SC_CST);     // (never a conditional load: see make_chunk)
+        k.sc[j] = c.raw ? 1.f : v.x; k.sh[j] = c.raw ? 0.f : v.y;
+      }
+    }
+  };
+  // prologue + split of the eight channels of round r, stored to patch buffer pb
+  auto convert_store_round = [&](const Chunk& c, const Cst& k, int r, int pb) {
+    uintx4 t0, t1;
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+      float v[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = 2 * jp + h;
+        float t;
+        if constexpr (BNB) {
+          const int ch = c.cbase + (j < c.nch ? j : 0);             // (uniform address: an LDS broadcast)
+          const float4 k4 = *reinterpret_cast<const float4*>(&s_cst[ch * SC_CST]);
+          t = sc_pro_bnbwd(xv[r][j], av[r][j], k4.x, k4.y, k4.z, k4.w, s_cst[ch * SC_CST + 4], c.slo, c.shi);
+        } else {
+          t = sc_pro_affine(xv[r][j], k.sc[BNB ? 0 : j], k.sh[BNB ? 0 : j], c.slo, c.shi);
+        }
+        v[h] = (((inb >> r) & 1u) && j < c.nch) ? t : 0.f;
+      }
+      unsigned a, b;
+      split2h_scalar(v[0] * hsx, v[1] * hsx, a, b);
+      t0[jp] = a; t1[jp] = b;
+    }
+    const int e = sidx + 128 * r;
+    if (e < NPX) { s_p[pb][0][hw][e] = t0; s_p[pb][1][hw][e] = t1; }
+  };
+  auto load_w = [&](uintx4 (&wv)[NWV], int s) {
+    const uintx4* src = wbase + (size_t)s * WENT;
+#pragma unroll
+    for (int j = 0; j < NWV; ++j) {
+      const int i = tid + 256 * j;
+      wv[j] = src[i < WENT ? i : WENT - 1];
+    }
+  };
+  auto store_w = [&](const uintx4 (&wv)[NWV], int buf) {
+#pragma unroll
+    for (int j = 0; j < NWV; ++j) s_w[buf][tid + 256 * j] = wv[j];
+  };
+    auto clampk = [&](int kc) { return kc < nk ? kc : nk - 1; };
+    auto clamps = [&](int st) { return st < nst ? st : nst - 1; };
+    // Every request (patch round, filter row, constants) is consumed exactly one chunk after it was issued and in issue order,
+    // so each wait is "all but the requests of the last chunk" and nothing is ever waited for early (vmcnt retires in order).
+    Chunk cnext = make_chunk(clampk(1));                // the chunk whose raw values sit in xv / av
+    {
+      const Chunk c0 = make_chunk(0);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) load_round(c0, r);
+      load_w(wr[0], 0);
+      load_consts(c0, csA);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) convert_store_round(c0, csA, r, 0);
+      store_w(wr[0], 0);
+      load_consts(cnext, csB);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) { load_round(cnext, r); load_w(wr[r], clamps(1 + r)); }
+    }
+    __syncthreads();
+    int pb = 1;                                         // patch buffer being filled
+    // chunk kc (stages s = 3 kc + j): K1 = constants of chunk kc+1 (in use), K2 receives those of chunk kc+2
+    auto chunk = [&](int kc, Cst& K1, Cst& K2) {
+      const Chunk cn2 = make_chunk(clampk(kc + 2));
+      load_consts(cn2, K2);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int s = 3 * kc + j;
+#if SC_EXP == 13     // experiment 13: idle producers (consumer path alone)
+        (void)s;
+#elif SC_EXP == 14   // experiment 14: no global loads in the loop
+        convert_store_round(cnext, K1, j, pb);
+        store_w(wr[j], (s + 1) & 1);
+#elif SC_EXP == 15   // experiment 15: loads only (no conversion, no LDS stores)
+        load_round(cn2, j);
+        load_w(wr[j], clamps(s + 4));
+        if (xv[j][0] == 1.2345f && wr[j][0][0] == 77u) s_w[0][tid] = wr[j][0];     // keep the loads alive
+#elif SC_EXP == 16   // experiment 16: no filter traffic
+        convert_store_round(cnext, K1, j, pb);
+        load_round(cn2, j);
+#elif SC_EXP == 17   // experiment 17: no patch traffic
+        store_w(wr[j], (s + 1) & 1);
+        load_w(wr[j], clamps(s + 4));
+#else
+        convert_store_round(cnext, K1, j, pb);
+        load_round(cn2, j);
+        store_w(wr[j], (s + 1) & 1);
+        load_w(wr[j], clamps(s + 4));
+#endif
+        __syncthreads();
+      }
+      cnext = cn2;
+      pb ^= 1;
+    };
+    // (always pairs of chunks, the second one past the end is a harmless repeat of the last: a conditional call would make the
+    // compiler merge two request histories at the join and fall back to vmcnt(0))
+    for (int kc = 0; kc < nk; kc += 2) {
+      chunk(kc, csB, csA);
+      chunk(kc + 1, csA, csB);
+    }
+    if (want_stats) __syncthreads();                    // the consumers' statistics barrier
+    return;
+  }
+  // =========================== consumers ===========================
+  floatx16 acc[2][Q];
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[pp][q][r] = 0.f;
+
+  int pbuf = 0;                                         // patch buffer the consumers read
+  auto load_A = [&](bf16x8 (&A)[Q][NT], int buf, int kw) {
+#if SC_EXP == 8      // experiment: no LDS operand reads
+    for (int q = 0; q < Q; ++q) for (int c = 0; c < NT; ++c) A[q][c] = __builtin_bit_cast(bf16x8, (uintx4){(unsigned)(buf + kw + q), (unsigned)c, 1u, 2u});
+    return;
+#endif
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int c = 0; c < NT; ++c)
+        A[q][c] = __builtin_bit_cast(bf16x8, s_w[buf][((c * 3 + kw) * 2 + lhi) * CO_T + q * 32 + l31]);
+  };
+  auto load_B = [&](bf16x8 (&B)[NT], int kh, int kw, int pp) {   // reads patch buffer `pbuf`
+#if SC_EXP == 8
+    for (int c = 0; c < NT; ++c) B[c] = __builtin_bit_cast(bf16x8, (uintx4){(unsigned)(kh + kw + pp), (unsigned)c, 3u, 4u});
+    return;
+#endif
+#if SC_EXP == 11     // experiment: only the kw = 0 patch operands are read (a third of the B reads; wrong results)
+    if (kw != 0) return;
+#endif
+    const int e = (2 * wave + pp + kh) * PC + l31 + kw;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) B[c] = __builtin_bit_cast(bf16x8, s_p[pbuf][c][lhi][e]);
+  };
+  // One step = the 3*Q MFMAs of (A, B) into acc[PP][*]
+  auto step = [&](const bf16x8 (&A)[Q][NT], const bf16x8 (&B)[NT], auto ppc) {
+    constexpr int PP = decltype(ppc)::value;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[PP][q] = mfma_split<true>(A[q][0], B[1], acc[PP][q]);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[PP][q] = mfma_split<true>(A[q][1], B[0], acc[PP][q]);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[PP][q] = mfma_split<true>(A[q][0], B[0], acc[PP][q]);
+  };
+  // the six steps of one filter row; operands are requested one step (3*Q MFMAs) ahead: a third patch-operand buffer
+  // measured no gain in the single-role kernel and would not fit the 128 registers of two work-groups per CU
+  auto compute = [&](int kh, int buf) {
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    bf16x8 A0[Q][NT], A1[Q][NT], B0[NT], B1[NT];
+    load_A(A0, buf, 0); load_B(B0, kh, 0, 0);
+    load_B(B1, kh, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    step(A0, B0, P0{});
+    __builtin_amdgcn_sched_barrier(0);
+    load_A(A1, buf, 1); load_B(B0, kh, 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    step(A0, B1, P1{});
+    __builtin_amdgcn_sched_barrier(0);
+    load_B(B1, kh, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    step(A1, B0, P0{});
+    __builtin_amdgcn_sched_barrier(0);
+    load_A(A0, buf, 2); load_B(B0, kh, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    step(A1, B1, P1{});
+    __builtin_amdgcn_sched_barrier(0);
+    load_B(B1, kh, 2, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    step(A0, B0, P0{});
+    __builtin_amdgcn_sched_barrier(0);
+    step(A0, B1, P1{});
+  };
+
+  __syncthreads();                                      // chunk 0 staged
+  for (int kc = 0; kc < ((nk + 1) & ~1); ++kc) {        // (the producers work in pairs of chunks)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (kc < nk) compute(j, (3 * kc + j) & 1);
+      __syncthreads();
+    }
+    pbuf ^= 1;
+  }
+
+  // ---- epilogue: the four consumer waves hold the tile ----
+  const size_t HWs = (size_t)H * W;
+  const int ox = x0 + l31;
+  if (p.csplit == p.Cout || p.csplit % CO_T == 0) {
+    // The cout tile lies entirely in one output (always, in this network: a split falls on a tile boundary): one uniform base
+    // pointer per work-group and a 32-bit lane offset (< 64 channels x H x W), so a store is one add + one saddr global_store
+    // instead of the 64-bit multiply chain per element of the general path below -- which costs as much as two K chunks on the
+    // 32- and 64-channel layers.
+    const bool first = cot * CO_T < p.csplit;
+    const int Cs = first ? p.csplit : p.Cout - p.csplit;                 // channels of the output this tile goes to
+    const int c0 = first ? cot * CO_T : cot * CO_T - p.csplit;            // first channel of the tile in it
+    const bool accum = first ? p.accum0 != 0 : p.accum1 != 0;
+    const int Climit = first ? p.csplit : p.Cout;
+    if (first && p.down0) {
+      // backward of nearest x2 upsampling fused into the store: the wave's two rows are a vertical pixel pair, adjacent lanes a
+      // horizontal one -> sum the 2x2 block and store it at half resolution (no full-resolution temporary)
+      const unsigned hq32 = (unsigned)((H >> 1) * (W >> 1));
+      float* const ob = p.out0 + ((size_t)n * Cs + c0) * hq32;
+      const int oy = y0 + 2 * wave;
+      const bool st = !(l31 & 1) && oy < H && ox < W;
+      const unsigned loff = (unsigned)(4 * lhi) * hq32 + (unsigned)(st ? (oy >> 1) * (W >> 1) + (ox >> 1) : 0);
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cu = q * 32 + (r & 3) + 8 * (r >> 2);
+          float v = ((oy < H) && (ox < W)) ? acc[0][q][r] : 0.f;
+          v += ((oy + 1 < H) && (ox < W)) ? acc[1][q][r] : 0.f;
+          if (HF) v *= hinv;
+          v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+          if (st && cot * CO_T + cu + 4 * lhi < Climit) {
+            const unsigned off = loff + (unsigned)cu * hq32;
+            if (accum) v += ob[off];
+            ob[off] = v;
+          }
+        }
+      }
+    } else {
+      const size_t cbase = ((size_t)n * Cs + c0) * HWs;
+      float* const ob = (first ? p.out0 : p.out1) + cbase;
+      const float* const a0 = p.add0 ? p.add0 + cbase : nullptr;
+      const float* const a1 = p.add1 ? p.add1 + cbase : nullptr;
+      const unsigned hw32 = (unsigned)HWs;
+      unsigned loff[2]; bool okp[2];
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp) {
+        const int oy = y0 + 2 * wave + pp;
+        okp[pp] = (oy < H) && (ox < W);
+        loff[pp] = (unsigned)(4 * lhi) * hw32 + (unsigned)(okp[pp] ? oy * W + ox : 0);
+      }
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cu = q * 32 + (r & 3) + 8 * (r >> 2);            // compile-time part of the channel
+          const int col = cu + 4 * lhi;
+          const bool okc = cot * CO_T + col < Climit;
+          float sv = 0.f, sq = 0.f;
+#pragma unroll
+          for (int pp = 0; pp < 2; ++pp) {
+            const bool ok = okp[pp] && okc;
+            float v = ok ? acc[pp][q][r] : 0.f;
+            if (HF) v *= hinv;
+            sv += v; sq = fmaf(v, v, sq);
+            if (ok) {
+              const unsigned off = loff[pp] + (unsigned)cu * hw32;
+              if (a0) v += a0[off];
+              if (a1) v += a1[off];
+              if (accum) v += ob[off];
+              ob[off] = v;
+            }
+          }
+          if (want_stats) {
+            const float s = half_sum32(sv);
+            const float ss = half_sum32(sq);
+            if (l31 == SC_HALF_SUM_LANE) { s_red[wave][col][0] = s; s_red[wave][col][1] = ss; }
+          }
+        }
+      }
+    }
+  } else
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int col = q * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const int co = cot * CO_T + col;
+      float sv = 0.f, sq = 0.f;
+      if (p.down0 && co < p.csplit) {
+        // backward of nearest x2 upsampling fused into the store: the wave's two rows are a vertical pixel pair, adjacent
+        // lanes a horizontal one -> sum the 2x2 block and store it at half resolution (no full-resolution temporary)
+        const int oy = y0 + 2 * wave;
+        float v = ((oy < H) && (ox < W)) ? acc[0][q][r] : 0.f;
+        v += ((oy + 1 < H) && (ox < W)) ? acc[1][q][r] : 0.f;
+        if (HF) v *= hinv;
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+        if (!(l31 & 1) && oy < H && ox < W) {
+          const size_t idx = (((size_t)n * p.csplit + co) * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1);
+          if (p.accum0) v += p.out0[idx];
+          p.out0[idx] = v;
+        }
+        continue;
+      }
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp) {
+        const int oy = y0 + 2 * wave + pp;
+        const bool ok = (oy < H) && (ox < W) && (co < p.Cout);
+        float v = ok ? acc[pp][q][r] : 0.f;
+        if (HF) v *= hinv;
+        sv += v; sq = fmaf(v, v, sq);
+        if (ok) {
+          const size_t opix = (size_t)oy * W + ox;
+          float* o; size_t idx; int accum;
+          if (co < p.csplit) {
+            idx = ((size_t)n * p.csplit + co) * HWs + opix; o = p.out0; accum = p.accum0;
+          } else {
+            idx = ((size_t)n * (p.Cout - p.csplit) + (co - p.csplit)) * HWs + opix; o = p.out1; accum = p.accum1;
+          }
+          if (p.add0) v += p.add0[idx];
+          if (p.add1) v += p.add1[idx];
+          if (accum) v += o[idx];
+          o[idx] = v;
+        }
+      }
+      if (want_stats) {
+        const float s = half_sum32(sv);
+        const float ss = half_sum32(sq);
+        if (l31 == SC_HALF_SUM_LANE) { s_red[wave][col][0] = s; s_red[wave][col][1] = ss; }
+      }
+    }
+  }
+
   if (want_stats) {
     // two partial rows per work-group, laid out exactly like the 4-row tiles of k_conv_mfma<3> (SC_STAT_CONV3)
     __syncthreads();
@@ -1730,8 +2262,20 @@ extern "C" int sc_conv3x3_bx3(const sc_conv_args* a, sc_stream stream) {
   const int co_tiles = (a->Cout + a->co_t - 1) / a->co_t;
   dim3 grid(((a->W + 31) / 32) * ((a->H + 7) / 8), co_tiles, a->N);
   static const int xcdmap_env = [] { const char* e = getenv("STARCOP_BX3_XCDMAP"); return e ? atoi(e) : 2; }();   // 0: plain 3-D grid
-  p.xcdmap = xcdmap_env == 2 ? 2 : ((xcdmap_env && co_tiles > 1) ? 1 : 0);
-  if (p.xcdmap) {
+  p.xcdmap = xcdmap_env >= 2 ? 2 : ((xcdmap_env && co_tiles > 1) ? 1 : 0);
+  {
+    // cout-major numbering (3) when the packed filters of the launch do not fit an XCD's L2
+    static const long big_env = [] { const char* e = getenv("STARCOP_BX3_COUTMAJOR_BYTES"); return e ? atol(e) : 3L << 20; }();
+    const long nkc = (C0 + C1 + 15) / 16;
+    const long wbytes = (long)co_tiles * nkc * 3 * 6 * (a->terms == SC_TERMS_F16X2 || a->terms == 2 ? 2 : (a->terms == 1 ? 1 : 3)) * a->co_t * 16;
+    if (xcdmap_env >= 2 && big_env > 0 && wbytes > big_env && (co_tiles >= 8 || co_tiles == 1 || co_tiles == 2 || co_tiles == 4)) p.xcdmap = 3;
+  }
+  if (p.xcdmap == 3) {
+    const long total = (long)grid.x * a->N;
+    const long slots = co_tiles >= 8 ? (long)((co_tiles + 7) / 8) * total : (total + (8 / co_tiles) - 1) / (8 / co_tiles);
+    SC_REQUIRE(slots * 8 < (1L << 31), "sc_conv3x3_bx3: grid too large");
+    grid = dim3((unsigned)(slots * 8));
+  } else if (p.xcdmap) {
     const long pt8 = ((long)grid.x * a->N + 7) / 8 * 8;
     SC_REQUIRE(pt8 * co_tiles < (1L << 31), "sc_conv3x3_bx3: grid too large");
     grid = dim3((unsigned)(pt8 * co_tiles));
@@ -1747,7 +2291,17 @@ extern "C" int sc_conv3x3_bx3(const sc_conv_args* a, sc_stream stream) {
     else if (bnb) hipLaunchKernelGGL((k_conv3_bx3<1, true, NT, HF>), grid, dim3(256), 0, st, p);               \
     else hipLaunchKernelGGL((k_conv3_bx3<1, false, NT, HF>), grid, dim3(256), 0, st, p);                       \
   } while (0)
+  static const int ws_env = [] { const char* e = getenv("STARCOP_BX3_WS"); return e ? atoi(e) : 1; }();   // 0: single-role kernels
+  static const int ws_env_min = [] { const char* e = getenv("STARCOP_BX3_WS_MINCHUNKS"); return e ? atoi(e) : 16; }();
   if (a->terms == 1) SC_LAUNCH_BX3(1, false); else if (a->terms == 2) SC_LAUNCH_BX3(2, false);
+  // the wave-specialised kernel pays for its 8-wave work-groups (prologue / epilogue of only two per CU) on short K loops:
+  // measured faster from 16 chunks of 16 input channels up (decoder.blocks.0), level at 8-10, slower below
+  else if (a->terms == SC_TERMS_F16X2 && ws_env && (C0 + C1 + 15) / 16 >= ws_env_min && (!bnb || a->src[0].C <= 256)) {
+    if (a->co_t == 64 && bnb) hipLaunchKernelGGL((k_conv3_ws<2, true>), grid, dim3(512), 0, st, p);
+    else if (a->co_t == 64) hipLaunchKernelGGL((k_conv3_ws<2, false>), grid, dim3(512), 0, st, p);
+    else if (bnb) hipLaunchKernelGGL((k_conv3_ws<1, true>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((k_conv3_ws<1, false>), grid, dim3(512), 0, st, p);
+  }
   else if (a->terms == SC_TERMS_F16X2) SC_LAUNCH_BX3(2, true); else SC_LAUNCH_BX3(3, false);
 #undef SC_LAUNCH_BX3
   SC_LAUNCH_OK("sc_conv3x3_bx3");
