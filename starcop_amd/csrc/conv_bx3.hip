@@ -2264,8 +2264,10 @@ extern "C" int sc_conv3x3_bx3(const sc_conv_args* a, sc_stream stream) {
   static const int xcdmap_env = [] { const char* e = getenv("STARCOP_BX3_XCDMAP"); return e ? atoi(e) : 2; }();   // 0: plain 3-D grid
   p.xcdmap = xcdmap_env >= 2 ? 2 : ((xcdmap_env && co_tiles > 1) ? 1 : 0);
   {
-    // cout-major numbering (3) when the packed filters of the launch do not fit an XCD's L2
-    static const long big_env = [] { const char* e = getenv("STARCOP_BX3_COUTMAJOR_BYTES"); return e ? atol(e) : 3L << 20; }();
+    // cout-major numbering (3) for launches whose packed filters exceed this many bytes.  Off by default: measured on
+    // decoder.blocks.0 (12.7 MB of filters) it is level on the forward (292 vs 291 us) and slower on the backward-data launch
+    // (392 vs 368 us) -- the Infinity Cache absorbs the filter re-reads, the patches are what an XCD should share
+    static const long big_env = [] { const char* e = getenv("STARCOP_BX3_COUTMAJOR_BYTES"); return e ? atol(e) : 0L; }();
     const long nkc = (C0 + C1 + 15) / 16;
     const long wbytes = (long)co_tiles * nkc * 3 * 6 * (a->terms == SC_TERMS_F16X2 || a->terms == 2 ? 2 : (a->terms == 1 ? 1 : 3)) * a->co_t * 16;
     if (xcdmap_env >= 2 && big_env > 0 && wbytes > big_env && (co_tiles >= 8 || co_tiles == 1 || co_tiles == 2 || co_tiles == 4)) p.xcdmap = 3;
