@@ -1,4 +1,4 @@
-"""Per-kernel PMC counter sums from a rocprofv3 --pmc results.db:  python tools/pmc_summary.py db [kernel-substring]"""
+"""Per-kernel PMC counter sums from a rocprofv3 --pmc results.db:  python tools/pmc_summary.py db [kernel-substring[|substring...]]"""
 import sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
 pat = sys.argv[2] if len(sys.argv) > 2 else ""
@@ -8,7 +8,7 @@ valcol = "value" if "value" in cols else [x for x in cols if "value" in x][0]
 q = f"select kernel_name, {namecol}, count(distinct dispatch_id), sum({valcol}) from counters_collection group by kernel_name, {namecol}"
 agg = {}
 for k, n, d, v in c.execute(q):
-    if pat in k:
+    if any(x in k for x in pat.split('|')):
         agg.setdefault(k, {})[n] = (d, v)
 for k, d in agg.items():
     print(k[:110])

@@ -10,8 +10,10 @@ def per_launch(db, counter):
     c = sqlite3.connect(db)
     cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
     namecol = "counter_name" if "counter_name" in cols else [x for x in cols if "counter" in x and "name" in x][0]
-    rows = c.execute(f"select count(distinct dispatch_id), sum(value) from counters_collection where kernel_name like ? and {namecol} = ?",
-                     (f"%{pat}%", counter)).fetchone()
+    pats = pat.split("|")               # "k_conv3_bx3|k_conv3_ws": launches of either kernel template
+    where = " or ".join(["kernel_name like ?"] * len(pats))
+    rows = c.execute(f"select count(distinct dispatch_id), sum(value) from counters_collection where ({where}) and {namecol} = ?",
+                     (*[f"%{x}%" for x in pats], counter)).fetchone()
     return rows[0], rows[1] * 1024.0 / rows[0]
 
 
