@@ -189,7 +189,10 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
   } else {
     n = blockIdx.z; cot = blockIdx.y; tile = blockIdx.x;
   }
-  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  // (integer division has no scalar form: its uniform results come back in VGPRs and drag every address derived from them into
+  // 64-bit VALU arithmetic; readfirstlane says that they are uniform)
+  n = __builtin_amdgcn_readfirstlane(n); cot = __builtin_amdgcn_readfirstlane(cot); tile = __builtin_amdgcn_readfirstlane(tile);
+  const int ty = __builtin_amdgcn_readfirstlane(tile / tiles_x), tx = tile - ty * tiles_x;
   const int y0 = ty * 8, x0 = tx * 32;
   const int C0 = p.s0.C;
   const int Cin = C0 + p.s1.C;
@@ -780,7 +783,10 @@ __global__ __launch_bounds__(512, 4) void k_conv3_ws(const ConvXP p) {
   } else {
     n = blockIdx.z; cot = blockIdx.y; tile = blockIdx.x;
   }
-  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  // (integer division has no scalar form: its uniform results come back in VGPRs and drag every address derived from them into
+  // 64-bit VALU arithmetic; readfirstlane says that they are uniform)
+  n = __builtin_amdgcn_readfirstlane(n); cot = __builtin_amdgcn_readfirstlane(cot); tile = __builtin_amdgcn_readfirstlane(tile);
+  const int ty = __builtin_amdgcn_readfirstlane(tile / tiles_x), tx = tile - ty * tiles_x;
   const int y0 = ty * 8, x0 = tx * 32;
   const int C0 = p.s0.C;
   const int Cin = C0 + p.s1.C;
@@ -1244,7 +1250,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
   } else {
     n = blockIdx.z; tile = blockIdx.x;
   }
-  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  n = __builtin_amdgcn_readfirstlane(n); tile = __builtin_amdgcn_readfirstlane(tile);      // uniform (see k_conv3_bx3)
+  const int ty = __builtin_amdgcn_readfirstlane(tile / tiles_x), tx = tile - ty * tiles_x;
   const int y0 = ty * 8, x0 = tx * 32;
   const float hsx = BNB ? h_grad_scale(p.absmax) : SC_H_SX;
   const float hinv = 1.f / (hsx * SC_H_SW);
@@ -1754,6 +1761,7 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
   // stage coordinates of t and t+1, advanced incrementally (decode() is a 64-bit division: ~200 scalar instructions)
   int n = 0, y0 = 0, x0 = 0;
   if (t_begin < t_end) decode(t_begin, n, y0, x0);
+  n = __builtin_amdgcn_readfirstlane(n); y0 = __builtin_amdgcn_readfirstlane(y0); x0 = __builtin_amdgcn_readfirstlane(x0);   // uniform: scalar address arithmetic
   int n1 = n, y1 = y0, x1 = x0;
   auto advance = [&](int& nn, int& yy, int& xx) {
     yy += 2;
@@ -2045,6 +2053,7 @@ __global__ __launch_bounds__(256, CIN == 32 ? 2 : 3) void k_wgrad_thin_h(const W
     const int strip = (int)(t_begin / RSS), ty = (int)(t_begin - (long)strip * RSS);
     n = strip / tiles_x; x0 = (strip - n * tiles_x) * 32; y0 = (ty - 1) * SR;
   }
+  n = __builtin_amdgcn_readfirstlane(n); y0 = __builtin_amdgcn_readfirstlane(y0); x0 = __builtin_amdgcn_readfirstlane(x0);   // uniform: scalar address arithmetic
   int n1 = n, y1 = y0, x1 = x0;
   advance(n1, y1, x1);
   int n2 = n1, y2 = y1, x2 = x1;

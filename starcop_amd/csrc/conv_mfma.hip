@@ -16,6 +16,7 @@
 // global loads for chunk k+1 issued before the MFMAs of chunk k (register staged because of the
 // prologue), one barrier per chunk.
 #include "sc_common.h"
+#include <vector>
 #include <cstdlib>
 
 namespace {
@@ -74,6 +75,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
   } else {
     n = blockIdx.z; cot = blockIdx.y; tile = blockIdx.x;
   }
+  // integer division has no scalar form: its (uniform) results come back in VGPRs and drag every address derived from them into
+  // 64-bit VALU arithmetic (11 instructions per channel plane and chunk in the 1x1 kernel).  Say that they are uniform.
+  n = __builtin_amdgcn_readfirstlane(n); cot = __builtin_amdgcn_readfirstlane(cot); tile = __builtin_amdgcn_readfirstlane(tile);
   int y0 = 0, x0 = 0, p0 = 0;
   if (KS == 3) {
     const int tiles_x = (W + 31) >> 5;
@@ -147,8 +151,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
     for (int cc = 0; cc < NC; ++cc) {
       const int cg = kc * KC + sci + CSTEP * cc;      // channel in concat space
       g.chok[cc] = cg < Cin;
-      const int cs = g.chok[cc] ? (second ? cg - C0 : cg) : 0;
-      if (s.mode != SC_SRC_RAW) {
+      // 1x1: the channel is wave-uniform (sci is); saying so keeps the plane pointers in SGPRs (scalar multiplies, saddr loads
+      // with the 32-bit pixel offset) instead of a 64-bit VALU multiply chain per channel and chunk
+      const int cs_v = g.chok[cc] ? (second ? cg - C0 : cg) : 0;
+      const int cs = (KS == 1) ? __builtin_amdgcn_readfirstlane(cs_v) : cs_v;
+      // 1x1: never a load under a branch.  For the wave-uniform channels of the 1x1 kernels these are SCALAR loads, and a
+      // conditional one is waited for (lgkmcnt(0)) inside its branch: four exposed scalar-memory round trips per chunk.  The host
+      // therefore hands RAW sources a table of identity constants (sc_identity_cst) and the kernel always loads.
+      if (KS == 1 || s.mode != SC_SRC_RAW) {
         g.c0[cc] = *reinterpret_cast<const float4*>(s.cst + (size_t)cs * SC_CST);
         g.c4[cc] = BNB ? s.cst[(size_t)cs * SC_CST + 4] : 0.f;
       } else {
@@ -159,8 +169,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
 #pragma unroll
       for (int i = 0; i < NE; ++i) {
         const unsigned o = second ? off1[i] : off0[i];
-        g.xv[cc][i] = xb[o];
-        if (BNB) g.av[cc][i] = ab[o];
+        if (KS == 1) {
+          // uniform plane pointer + 32-bit BYTE offset (host-checked: a plane is < 4 GB): one saddr load, no 64-bit lane arithmetic
+          const unsigned ob = o * 4u;
+          g.xv[cc][i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xb) + ob);
+          if (BNB) g.av[cc][i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ab) + ob);
+        } else {
+          g.xv[cc][i] = xb[o];
+          if (BNB) g.av[cc][i] = ab[o];
+        }
       }
     }
     const floatx4* wsrc = reinterpret_cast<const floatx4*>(wbase + (size_t)kc * WCH);
@@ -774,10 +791,12 @@ __global__ __launch_bounds__(256, KS == 1 ? SC_WG1_OCC : 1) void k_wgrad_mfma(co
 
   const float dlo = sc_act_lo(dyact), dhi = sc_act_hi(dyact);
   auto load_stage = [&](long t) {
-    const int n = (int)(t / per_img);
-    const int rem = (int)(t - (long)n * per_img);
+    // 32-bit division (the host keeps the stage count below 2^31) and readfirstlane: the division runs on the VALU and leaves
+    // its uniform results in VGPRs, which would drag every address of the stage into 64-bit lane arithmetic
+    const int n = __builtin_amdgcn_readfirstlane((int)((unsigned)t / (unsigned)per_img));
+    const int rem = __builtin_amdgcn_readfirstlane((int)((unsigned)t - (unsigned)n * (unsigned)per_img));
     int y0 = 0, x0 = 0, p0 = 0;
-    if (KS == 3) { const int ty = rem / tiles_x; y0 = ty * SR; x0 = (rem - ty * tiles_x) * 32; }
+    if (KS == 3) { const int ty = __builtin_amdgcn_readfirstlane(rem / tiles_x); y0 = ty * SR; x0 = (rem - ty * tiles_x) * 32; }
     else p0 = rem * SR * 32;
     sn = n; sy0 = y0; sx0 = x0; sp0 = p0;
     const size_t HW = (size_t)H * W;
@@ -1164,6 +1183,24 @@ extern "C" int sc_pack_weights(const float* w, float* wpk, int Cout, int Cin, in
   return SC_OK;
 }
 
+// [SC_IDENTITY_MAXC][SC_CST] floats on the current device: scale 1, everything else 0.  Allocated and filled on first use (an eager
+// call: every capture is preceded by warm-up steps), one table per device of the process.
+static const float* sc_identity_cst(int C) {
+  constexpr int SC_IDENTITY_MAXC = 4096, MAXDEV = 16;
+  static float* table[MAXDEV] = {};
+  int dev = 0;
+  if (C > SC_IDENTITY_MAXC || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+  if (!table[dev]) {
+    std::vector<float> h((size_t)SC_IDENTITY_MAXC * SC_CST, 0.f);
+    for (int c = 0; c < SC_IDENTITY_MAXC; ++c) h[(size_t)c * SC_CST] = 1.f;
+    float* d = nullptr;
+    if (hipMalloc(&d, h.size() * sizeof(float)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    table[dev] = d;
+  }
+  return table[dev];
+}
+
 extern "C" int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream) {
   SC_REQUIRE(a != nullptr, "sc_conv2d_mfma: null args");
   SC_REQUIRE(a->ks == 1 || a->ks == 3, "sc_conv2d_mfma: ks must be 1 or 3 (got %d)", a->ks);
@@ -1186,6 +1223,11 @@ extern "C" int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream) {
   ConvP p;
   p.s0 = to_srcd(a->src[0]);
   p.s1 = a->nsrc == 2 ? to_srcd(a->src[1]) : empty_srcd();
+  if (a->ks == 1) {
+    // RAW sources of the 1x1 kernel read identity constants (scale 1, shift 0): see load_chunk
+    if (p.s0.mode == SC_SRC_RAW) { p.s0.cst = sc_identity_cst(p.s0.C); SC_REQUIRE(p.s0.cst != nullptr, "sc_conv2d_mfma: identity constants unavailable (C = %d)", p.s0.C); }
+    if (a->nsrc == 2 && p.s1.mode == SC_SRC_RAW) { p.s1.cst = sc_identity_cst(p.s1.C); SC_REQUIRE(p.s1.cst != nullptr, "sc_conv2d_mfma: identity constants unavailable (C = %d)", p.s1.C); }
+  }
   p.wpk = a->wpk; p.N = a->N; p.H = a->H; p.W = a->W; p.Cout = a->Cout;
   p.out0 = a->out0; p.out1 = a->out1; p.csplit = a->csplit; p.accum0 = a->accum0; p.accum1 = a->accum1;
   p.add0 = a->add0; p.add1 = a->add1; p.stats = a->stats;
@@ -1295,6 +1337,7 @@ static int wgrad_mfma_launch(const sc_wgrad_args* a, sc_stream stream, sc_wgrad_
     SC_REQUIRE(a->src[s].up == 0 || (a->ks == 3 && a->H % 2 == 0 && a->W % 2 == 0), "sc_conv2d_wgrad_mfma: upsampled source needs ks=3, even H,W");
   }
   const WgradPlan pl = plan_wgrad(a->N, a->H, a->W, a->Cout, a->Cin, a->ks);
+  SC_REQUIRE(pl.stages < (1L << 31), "sc_conv2d_wgrad_mfma: too many stages (%ld) for the kernel's 32-bit stage arithmetic", pl.stages);
   const size_t need = sc_wgrad_workspace_floats(a->N, a->H, a->W, a->Cout, a->Cin, a->ks);
   SC_REQUIRE(a->part_floats >= need, "sc_conv2d_wgrad_mfma: workspace too small (%zu < %zu floats)", a->part_floats, need);
   WgradP p;

