@@ -123,6 +123,16 @@ typedef struct sc_conv_args {
                           * smp's DecoderBlock fused into the data-gradient store (no full-resolution temporary) */
   const float* absmax;   /* terms == SC_TERMS_F16X2 with a BNBWD source: device float >= the tensor's max |A_c g| (written by
                           * sc_bn_bwd_reduce / sc_bn_bwd_small); NULL: the gradient operand is taken to be O(1)              */
+  /* Backward-data launches of sc_conv2d_mfma with ks = 1 only (NULL elsewhere).  When the launch writes the COMPLETE gradient g
+   * of a tensor y that is followed by BatchNorm + activation (single output, no accumulate, no add tensors), the epilogue also
+   * produces what sc_bn_bwd_reduce(g, y, bnb_cst, bnb_act, ...) would compute by streaming g and y again: per-channel partial
+   * sums of g*act' and g*act'*x_hat as fp64 rows bnb_sums[sc_stat_rows(SC_STAT_CONV1, N, H, W)][Cout][2] for
+   * sc_bn_bwd_finalize, and (optional) the range hint max |scale_c g act'| into *bnb_absmax (atomic max, zero it first). */
+  const float* bnb_y;    /* the tensor's raw (pre-BatchNorm) values [N,Cout,H,W]                                             */
+  const float* bnb_cst;  /* its forward constants [Cout][SC_CST] (scale, shift, mean, invstd)                                */
+  double* bnb_sums;      /* NULL: no fused reduction                                                                         */
+  float* bnb_absmax;     /* or NULL                                                                                          */
+  int32_t bnb_act;       /* activation after the BatchNorm (sc_act)                                                          */
 } sc_conv_args;
 int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream);
 /* 1x1 convolution for few-pixel / long-K layers (the <= 64^2 inverted-residual projections and the data gradients of the

@@ -37,7 +37,8 @@ class sc_conv_args(C.Structure):
                 ("out0", C.c_void_p), ("out1", C.c_void_p),
                 ("csplit", C.c_int32), ("accum0", C.c_int32), ("accum1", C.c_int32),
                 ("add0", C.c_void_p), ("add1", C.c_void_p), ("stats", C.c_void_p), ("terms", C.c_int32), ("down0", C.c_int32),
-                ("absmax", C.c_void_p)]
+                ("absmax", C.c_void_p),
+                ("bnb_y", C.c_void_p), ("bnb_cst", C.c_void_p), ("bnb_sums", C.c_void_p), ("bnb_absmax", C.c_void_p), ("bnb_act", C.c_int32)]
 
 
 class sc_wgrad_args(C.Structure):

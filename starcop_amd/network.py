@@ -625,6 +625,10 @@ class HyperStarcopUNet(nn.Module):
     overlap_wgrad = True
     batch_pw_reduce = os.environ.get("STARCOP_BATCH_PW_REDUCE", "1") != "0"     # one reduction launch for all pointwise weight gradients
     fuse_dw_bwd = os.environ.get("STARCOP_FUSE_DW", "1") != "0"     # depthwise dgrad + wgrad + the input's BatchNorm-backward sums in one kernel
+    # BatchNorm-backward sums of a depthwise output in the epilogue of the 1x1 backward-data launch that writes its gradient.
+    # OFF: measured 1179 vs 1189 tiles/s -- the reduction pass it saves runs at 6 TB/s (0.24 ms), the extra ~25 VALU per element
+    # in the issue-bound 1x1 epilogue cost 0.37 ms.
+    fuse_bn_bwd = os.environ.get("STARCOP_FUSE_BNBWD", "0") != "0"
     thin16 = os.environ.get("STARCOP_THIN16", "1") != "0"     # decoder.blocks.4 on sc_conv3x3_thin16 (0: the fp32-MFMA thin kernels)
     split_bf16 = True        # 3x3 convs with >= 32 output channels on the 16-bit matrix cores (False: everything on the fp32 MFMA)
     bn_small_max = 16384     # BatchNorm backward in one launch (block per channel) when a channel has at most this many elements
@@ -701,7 +705,11 @@ class HyperStarcopUNet(nn.Module):
                 dw_offs[i] = dw_off
                 dw_off += op["conv"].out_channels * 9
 
-        reduced = set()      # tensors whose BatchNorm-backward sums were produced by the fused depthwise backward
+        reduced = set()      # tensors whose BatchNorm-backward sums were produced by the launch that wrote their gradient
+        n_cons = {}          # consumers per tensor: a gradient is complete after ONE launch only for single-consumer tensors
+        for op in self._ops:
+            for t in op["ins"]:
+                n_cons[t.name] = n_cons.get(t.name, 0) + 1
         pw_pending = []      # pointwise weight gradients whose K-slice partials await the batched reduction
 
         def bn_backward(t, slot=None):
@@ -882,6 +890,17 @@ class HyperStarcopUNet(nn.Module):
                 z = res_of.get(tin.name)
                 if z is not None:
                     a.add0 = plan.grad[z].data_ptr()
+                if (self.fuse_bn_bwd and conv_dgrad is lib.sc_conv2d_mfma and ks == 1 and tin.bn is not None and not a.accum0 and z is None
+                        and n_cons.get(tin.name, 0) == 1 and tin.name not in reduced):
+                    # this launch writes the complete gradient of a BatchNorm'd tensor (the depthwise output in an inverted-residual
+                    # block): its epilogue also leaves the BatchNorm-backward partial sums, instead of sc_bn_bwd_reduce streaming
+                    # the gradient and the tensor again
+                    if tin.name not in plan.dwsums:
+                        plan.dwrows[tin.name] = lib.sc_stat_rows(STAT_CONV1, N, Ho, Wo)
+                        plan.dwsums[tin.name] = torch.empty(plan.dwrows[tin.name] * tin.C * 2, dtype=torch.float64, device=self._pflat.device)
+                    a.bnb_y, a.bnb_cst = plan.buf[tin.name].data_ptr(), plan.cst[tin.name].data_ptr()
+                    a.bnb_sums, a.bnb_absmax, a.bnb_act = plan.dwsums[tin.name].data_ptr(), None, tin.act
+                    reduced.add(tin.name)
                 if thin_b:
                     conv_dgrad = lib.sc_conv3x3_thin16
                     a.wpk = ent["tb"].data_ptr()

@@ -48,7 +48,7 @@ def pack_bx3(w, co_t, tflip, terms=None):
 
 
 def conv_mfma(srcs, wpk, N, H, W, Cout, ks, co_t, want_stats=False, csplit=None, add0=None, add1=None,
-              accum=None, outs=None, bx3=False, ksplit=False, terms=0, down0=False, absmax=None):
+              accum=None, outs=None, bx3=False, ksplit=False, terms=0, down0=False, absmax=None, bnb=None):
     lib = _lib.load()
     a = sc_conv_args()
     a.nsrc = len(srcs)
@@ -73,6 +73,10 @@ def conv_mfma(srcs, wpk, N, H, W, Cout, ks, co_t, want_stats=False, csplit=None,
     rows = lib.sc_stat_rows(STAT_CONV3 if ks == 3 else (STAT_CONV1K if ksplit else STAT_CONV1), N, H, W)
     stats = torch.full((rows, Cout, 2), float("nan"), device=DEV) if want_stats else None      # every entry must be written
     a.stats = stats.data_ptr() if want_stats else None
+    if bnb is not None:          # fused BatchNorm-backward reduction: dict(y=, cst=, act=, sums=, absmax=)
+        a.bnb_y, a.bnb_cst, a.bnb_act = bnb["y"].data_ptr(), bnb["cst"].data_ptr(), bnb["act"]
+        a.bnb_sums = bnb["sums"].data_ptr()
+        a.bnb_absmax = bnb["absmax"].data_ptr() if bnb.get("absmax") is not None else None
     fn = lib.sc_conv3x3_bx3 if bx3 else (lib.sc_conv1x1_ksplit if ksplit else lib.sc_conv2d_mfma)
     check(fn(C.byref(a), stream()))
     return outs, stats

@@ -1,6 +1,7 @@
 """Per-kernel parity: every HIP op, called through the C ABI, against plain torch fp32 CPU ops on the
 same seeded inputs (tolerance 1e-4 relative to the max magnitude unless stated; integer outputs bit-exact)."""
 import ctypes as C
+import os
 
 import pytest
 import torch
@@ -10,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 from hip_ops import (dev, DEV, conv_mfma, cst_affine, pack, pack_bx3, relerr, wgrad_mfma)  # noqa: E402
 from starcop_amd import _lib  # noqa: E402
-from starcop_amd._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD,
+from starcop_amd._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD, STAT_CONV1,
                               STAT_DW, STAT_STEM, check, make_src, ptr, stream)  # noqa: E402
 
 @pytest.fixture(params=[3, 4], ids=["bf16x3", "fp16x2"])
@@ -782,3 +783,48 @@ def test_wgrad_thin16_split(hip, cin, cout, H, W, up, bnb):
     args.terms, args.absmax = TERMS_F16X2, amax.data_ptr()
     check(lib.sc_conv3x3_wgrad_thin16(C.byref(args), stream()))
     assert relerr(dw, w.grad) < 2e-5
+
+
+def test_wave_specialised_kernel_covers_every_feature():
+    """k_conv3_ws normally takes only K loops of >= 16 chunks (decoder.blocks.0).  Re-run the split-kernel op tests in a child process
+    with STARCOP_BX3_WS_MINCHUNKS=1, which routes EVERY two-fp16-term 3x3 launch through it: concat + upsampled sources, the
+    BatchNorm-backward prologue, split outputs with the fused 2x2 down-sum, add tensors, statistics, odd chunk counts, ragged tiles."""
+    import subprocess, sys
+    env = dict(os.environ, STARCOP_BX3_WS_MINCHUNKS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "(bx3 or fp16 or two_term) and not wave_specialised"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("cin,cout,co_t,H,W,act", [(144, 24, 64, 20, 28, ACT_RELU6), (96, 16, 32, 32, 32, ACT_RELU6), (40, 8, 32, 7, 9, ACT_RELU),
+                                                   (576, 96, 64, 8, 8, ACT_RELU6), (32, 16, 32, 64, 64, ACT_NONE)])
+def test_pw_dgrad_fused_bn_backward_sums(hip, cin, cout, co_t, H, W, act):
+    """1x1 backward-data launch with the fused BatchNorm-backward reduction of the tensor whose gradient it writes (the depthwise
+    output of an inverted-residual block): the gradient itself is unchanged bit for bit, and the fp64 partial rows / the range hint
+    equal what sc_bn_bwd_reduce computes from the stored gradient and the tensor (same masks, same x_hat)."""
+    lib = hip
+    N = 3
+    g, yo = rnd(N, cout, H, W, seed=1), rnd(N, cout, H, W, seed=2)
+    w = rnd(cout, cin, 1, 1, seed=3, scale=0.3)
+    cb = torch.zeros(cout, SC_CST); cb[:, 0], cb[:, 1] = rnd(cout, seed=4) * 0.2 + 1, rnd(cout, seed=5) * 0.2
+    cb[:, 2], cb[:, 3], cb[:, 4] = rnd(cout, seed=6) * 0.2 + 1, rnd(cout, seed=7) * 0.1, rnd(cout, seed=8) * 0.1
+    dsrc = make_src(dev(g), cout, SRC_BNBWD, act=ACT_NONE, cst=dev(cb), aux=dev(yo))
+    wpk = pack(dev(w), co_t, 1)
+    yin = dev(rnd(N, cin, H, W, seed=9, scale=2.0))                     # the tensor whose gradient the launch writes
+    cin_c = torch.zeros(cin, SC_CST); cin_c[:, 0], cin_c[:, 1] = rnd(cin, seed=10) * 0.3 + 1, rnd(cin, seed=11) * 0.5
+    cin_c[:, 2], cin_c[:, 3] = rnd(cin, seed=12) * 0.2, rnd(cin, seed=13).abs() + 0.5
+    cin_d = dev(cin_c)
+    (dx0,), _ = conv_mfma([dsrc], wpk, N, H, W, cin, 1, co_t)
+    rows = lib.sc_stat_rows(STAT_CONV1, N, H, W)
+    sums = torch.full((rows, cin, 2), float("nan"), dtype=torch.float64, device=DEV)
+    amax = torch.zeros(1, device=DEV)
+    (dx,), _ = conv_mfma([dsrc], wpk, N, H, W, cin, 1, co_t, bnb=dict(y=yin, cst=cin_d, act=act, sums=sums, absmax=amax))
+    assert torch.equal(dx, dx0)
+    rrows = lib.sc_stat_rows(STAT_BNBWD, N, H, W)
+    ref = torch.empty(rrows * cin * 2, dtype=torch.float64, device=DEV)
+    rmax = torch.zeros(1, device=DEV)
+    check(lib.sc_bn_bwd_reduce(ptr(dx0), ptr(yin), ptr(cin_d), act, ptr(ref), N, cin, H * W, ptr(rmax), stream()))
+    got, want = sums.sum(0), ref.view(rrows, cin, 2).sum(0)
+    assert not torch.isnan(got).any()
+    assert float((got - want).abs().max() / want.abs().max()) < 2e-6
+    assert float(amax) == pytest.approx(float(rmax), rel=1e-6)
