@@ -5,6 +5,9 @@
 // forward / backward-data / backward-weight, all with the "normalise on load" prologues of
 // sc_common.h.  Reference call site of the whole network: starcop/models/model_module.py:244-251.
 #include "sc_common.h"
+#ifndef SC_HEAD_RB
+#define SC_HEAD_RB 18     // patch rows (x2 loads) a wave keeps in flight while staging the head forward tile
+#endif
 
 namespace {
 
@@ -855,7 +858,7 @@ __global__ __launch_bounds__(256, 4) void k_head_fwd16(const SrcD in, const floa
     // lanes 0,1 also fetch the two right-halo columns; 6 rows (12 loads) in flight
     {
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-      constexpr int NROW = CP * PR, RB = 6;
+      constexpr int NROW = CP * PR, RB = SC_HEAD_RB;
       const int xa = x0 - 1 + lane, xb = x0 + 63 + lane;                 // xb only for lane < 2
       const bool oka = (xa >= 0) && (xa < W), okb = (lane < 2) && (xb < W);
 #pragma unroll 1

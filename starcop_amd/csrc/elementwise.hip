@@ -44,30 +44,49 @@ __device__ __forceinline__ void block_sum_d(double (&v)[NV], double* s_tmp /* [4
 }
 
 // ---------------------------------------------------------------- BatchNorm
-// one block per channel: fp64 sum of the per-work-group partial rows, then the per-channel constants
-__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ stats, int nrows, double count,
-                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float* running_mean, float* running_var, float momentum, float eps,
-                                                     int training, float* __restrict__ cst, int C) {
-  __shared__ double s_tmp[8];
+// one block per channel: fp64 sum of the per-work-group partial rows, then the per-channel constants.  NW waves per block: a
+// channel's rows are C*8 bytes apart (one 64-byte sector per 8 useful bytes), so the sum is a latency chain of nrows / (64 NW x 8)
+// round trips -- 16 waves for the full-resolution layers (32768 rows: 38 -> ~12 us), 4 otherwise
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_bn_finalize(const float* __restrict__ stats, int nrows, double count,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* running_mean, float* running_var, float momentum, float eps,
+                                                         int training, float* __restrict__ cst, int C) {
+  constexpr int NT = 64 * NW;
+  __shared__ double s_tmp[2 * NW];
   const int c = blockIdx.x;
   double mean, var;
   if (training) {
     double v[2] = {0.0, 0.0};
-    // up to 32768 rows (512x512 layers): eight independent loads in flight per thread, summed in the same order as a plain loop
+    // eight independent loads in flight per thread
     int r = threadIdx.x;
-    for (; r + 7 * 256 < nrows; r += 8 * 256) {
+    for (; r + 7 * NT < nrows; r += 8 * NT) {
       float2 t[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const float2*>(stats + ((size_t)(r + 256 * k) * C + c) * 2);
+      for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const float2*>(stats + ((size_t)(r + NT * k) * C + c) * 2);
 #pragma unroll
       for (int k = 0; k < 8; ++k) { v[0] += (double)t[k].x; v[1] += (double)t[k].y; }
     }
-    for (; r < nrows; r += 256) {
+    for (; r < nrows; r += NT) {
       const float2 t = *reinterpret_cast<const float2*>(stats + ((size_t)r * C + c) * 2);
       v[0] += (double)t.x; v[1] += (double)t.y;
     }
-    block_sum_d<2>(v, s_tmp);
+    {
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const double sw = wave_sum_d(v[k]);
+        if (lane == 0) s_tmp[wave * 2 + k] = sw;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += s_tmp[w * 2 + k];       // fixed order: reproducible
+        v[k] = t;
+      }
+    }
     mean = v[0] / count;
     var = v[1] / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -522,8 +541,12 @@ extern "C" int sc_bn_finalize(const float* stats, int nrows, double count, const
                               float* cst_fwd, int C, sc_stream stream) {
   SC_REQUIRE(C > 0 && cst_fwd && gamma && beta && running_mean && running_var, "sc_bn_finalize: null argument");
   SC_REQUIRE(!training || (stats && count > 0 && nrows > 0), "sc_bn_finalize: training needs stats rows and count");
-  hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, nrows, count, gamma, beta,
-                     running_mean, running_var, momentum, eps, training, cst_fwd, C);
+  if (training && nrows >= 4096)
+    hipLaunchKernelGGL((k_bn_finalize<16>), dim3(C), dim3(1024), 0, (hipStream_t)stream, stats, nrows, count, gamma, beta,
+                       running_mean, running_var, momentum, eps, training, cst_fwd, C);
+  else
+    hipLaunchKernelGGL((k_bn_finalize<4>), dim3(C), dim3(256), 0, (hipStream_t)stream, stats, nrows, count, gamma, beta,
+                       running_mean, running_var, momentum, eps, training, cst_fwd, C);
   SC_LAUNCH_OK("sc_bn_finalize");
   return SC_OK;
 }
