@@ -252,22 +252,25 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
       __syncthreads();
     }
   } else {
-    // chunk kc + 1 was loaded one iteration ago into stg[(kc + 1) & 1]; chunk kc + 2 is requested now into the other set
-    load_chunk(0, stg[0]);
-    if (nk > 1) load_chunk(1, stg[PF - 1]);
+    // Two chunks of look-ahead, STRAIGHT-LINE: chunk kc + 2 is requested into the register set that the store of chunk kc just
+    // freed, every load is unconditional (past the end: the last chunk again, stored but never multiplied) and only the
+    // LDS-read + MFMA block of an odd tail sits under a (uniform) branch.  The first version of this path had `if (kc + 2 < nk)`
+    // around its loads; hipcc merges the two request histories at such a join into s_waitcnt vmcnt(0), which turned the
+    // look-ahead into "wait for everything" (and measured slower than PF = 1).
+    auto ld = [&](int kc, Stg& g) { load_chunk(kc < nk ? kc : nk - 1, g); };
+    ld(0, stg[0]);
+    ld(1, stg[PF - 1]);
     store_chunk(0, stg[0]);
     __syncthreads();
     for (int kc = 0; kc < nk; kc += 2) {
-      if (kc + 2 < nk) load_chunk(kc + 2, stg[0]);
+      ld(kc + 2, stg[0]);
       compute_chunk(0);
-      if (kc + 1 < nk) store_chunk(1, stg[PF - 1]);
+      store_chunk(1, stg[PF - 1]);
       __syncthreads();
-      if (kc + 1 < nk) {
-        if (kc + 3 < nk) load_chunk(kc + 3, stg[PF - 1]);
-        compute_chunk(1);
-        if (kc + 2 < nk) store_chunk(0, stg[0]);
-        __syncthreads();
-      }
+      ld(kc + 3, stg[PF - 1]);
+      if (kc + 1 < nk) compute_chunk(1);
+      store_chunk(0, stg[0]);
+      __syncthreads();
     }
   }
 
