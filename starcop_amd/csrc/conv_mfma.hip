@@ -971,10 +971,29 @@ __global__ __launch_bounds__(256, KS == 1 ? SC_WG1_OCC : 1) void k_wgrad_mfma(co
     if (more) store_stage();
     __syncthreads();
   }
-  // ---- partial store: part[((slice*WK + wk)*TAPS + tap)*CoP*CiP + co*CiP + ci] ----
+  // 1x1: the WK pixel-row parts of a work-group are summed through LDS (fixed order) before the store: one partial per K slice
+  // instead of WK -- half / a quarter of the 0.5 GB of partials the pointwise layers wrote and the batched reduction re-read per step
+  constexpr int WKP = (KS == 1) ? 1 : WK;      // partials per work-group
+  if constexpr (KS == 1 && WK > 1) {
+    constexpr int NPAIR = WM * WN;
+    static_assert((WK - 1) * NPAIR * 1024 <= COT * PA, "reduction scratch must fit the dy tile");
+    float* red = s_a;                          // (the loop ended with a barrier: the staging tiles are free)
+    const int pairw = wave % NPAIR;
+    if (wk > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wk - 1) * NPAIR + pairw) * 1024 + r * 64 + lane] = acc[0][r];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+#pragma unroll
+    for (int k = 1; k < WK; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][r] += red[((k - 1) * NPAIR + pairw) * 1024 + r * 64 + lane];
+  }
+  // ---- partial store: part[((slice*WKP + wk)*TAPS + tap)*CoP*CiP + co*CiP + ci] ----
   const int ci = cit * CIT + wn * 32 + l31;
   const size_t plane = (size_t)p.CoP * p.CiP;
-  float* pb = p.part + ((size_t)blockIdx.x * WK + wk) * TAPS * plane;
+  float* pb = p.part + ((size_t)blockIdx.x * WKP + (KS == 1 ? 0 : wk)) * TAPS * plane;
 #pragma unroll
   for (int tap = 0; tap < TAPS; ++tap) {
 #pragma unroll
@@ -1209,7 +1228,8 @@ WgradPlan plan_wgrad(int N, int H, int W, int Cout, int Cin, int ks) {
   pl.ci_tiles = (Cin + 32 * pl.wn - 1) / (32 * pl.wn);
   if (ks == 3) pl.stages = (long)N * ((W + 31) / 32) * ((H + pl.sr - 1) / pl.sr);
   else pl.stages = (long)N * (((long)H * W + pl.sr * 32 - 1) / (pl.sr * 32));
-  long want = 1024 / ((long)pl.co_tiles * pl.ci_tiles);
+  static const long wgs_env = [] { const char* e = getenv("STARCOP_WG_TARGET"); return e ? atol(e) : 512L; }();       // work-groups per launch aimed at: 512 = one full round at two per CU (measured 1.65 vs 1.84 ms at 1024, 1.96 at 768, 2.1 at 256 or 2048)
+  long want = wgs_env / ((long)pl.co_tiles * pl.ci_tiles);
   if (want < 1) want = 1;
   if (want > pl.stages) want = pl.stages;
   if (want > 512) want = 512;
@@ -1375,7 +1395,7 @@ extern "C" int sc_conv1x1_ksplit(const sc_conv_args* a, sc_stream stream) {
 extern "C" size_t sc_wgrad_workspace_floats(int N, int H, int W, int Cout, int Cin, int ks) {
   const WgradPlan pl = plan_wgrad(N, H, W, Cout, Cin, ks);
   const size_t E = (size_t)ks * ks * pl.CoP * pl.CiP;
-  const int nparts = pl.nsl * pl.wk;
+  const int nparts = pl.nsl * (ks == 1 ? 1 : pl.wk);      // 1x1: the K parts of a work-group are summed in the kernel
   return (size_t)nparts * E + sc_reduce_scratch_floats(nparts, E);
 }
 
@@ -1430,12 +1450,12 @@ static int wgrad_mfma_launch(const sc_wgrad_args* a, sc_stream stream, sc_wgrad_
   SC_LAUNCH_OK("sc_conv2d_wgrad_mfma");
   if (pending) {          // the caller sums the K-slice partials of many layers in one launch (sc_wgrad_reduce_batch)
     pending->part = a->part; pending->dw = a->dw;
-    pending->nparts = pl.nsl * pl.wk; pending->taps = a->ks * a->ks;
+    pending->nparts = pl.nsl * (a->ks == 1 ? 1 : pl.wk); pending->taps = a->ks * a->ks;
     pending->Cout = a->Cout; pending->Cin = a->Cin; pending->CoP = pl.CoP; pending->CiP = pl.CiP;
     pending->total = (uint64_t)pending->taps * a->Cout * a->Cin;
     return SC_OK;
   }
-  return sc_wgrad_finish(a->part, pl.nsl * pl.wk, a->ks * a->ks, a->Cout, a->Cin, pl.CoP, pl.CiP, a->dw, st);
+  return sc_wgrad_finish(a->part, pl.nsl * (a->ks == 1 ? 1 : pl.wk), a->ks * a->ks, a->Cout, a->Cin, pl.CoP, pl.CiP, a->dw, st);
 }
 
 namespace {
