@@ -1844,10 +1844,36 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
       advance_sat(n2, y2, x2);
     }
   }
-  // ---- partial store: part[((slice*KP + kp)*9 + tap)*CoP*CiP + co*CiP + ci] ----
+  // PIPE: the KP K parts of a work-group are summed through LDS (fixed order, one round per part) before the store: one partial
+  // per K slice instead of KP (the 32-cout layers wrote 1024 x 36 KB of partials per launch)
+  constexpr bool RED = PIPE && (KP == 1 || 3 * NPAIR * 3072 <= NT * CIT * XCP / 2);      // (the scratch is the input ring; host: wgrad3_pipe_reduces)
+  constexpr int KPP = RED ? 1 : KP;            // partials per work-group
+  if constexpr (RED && KP > 1) {
+    float* red = reinterpret_cast<float*>(&s_x[0][0]);       // the loop ended with a barrier: the ring is free
+    const int slot = pair + NPAIR * kh;
+#pragma unroll
+    for (int k = 1; k < KP; ++k) {
+      if (kp == k) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[slot * 3072 + (kw * 16 + r) * 64 + lane] = acc[kw][r];
+      }
+      __syncthreads();
+      if (kp == 0) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[kw][r] += red[slot * 3072 + (kw * 16 + r) * 64 + lane];
+      }
+      if (k + 1 < KP) __syncthreads();
+    }
+    if (kp != 0) return;
+  }
+  // ---- partial store: part[((slice*KPP + kp)*9 + tap)*CoP*CiP + co*CiP + ci] ----
   const int ci = cit * CIT + wn * 32 + l31;
   const size_t plane = (size_t)p.CoP * p.CiP;
-  float* pb = p.part + ((size_t)blockIdx.x * KP + kp) * 9 * plane;
+  float* pb = p.part + ((size_t)blockIdx.x * KPP + (RED ? 0 : kp)) * 9 * plane;
 #pragma unroll
   for (int kw = 0; kw < 3; ++kw) {
 #pragma unroll
@@ -2319,6 +2345,12 @@ extern "C" int sc_conv3x3_bx3(const sc_conv_args* a, sc_stream stream) {
   return SC_OK;
 }
 
+// does the pipelined kernel of this plan sum its K parts itself? (mirrors the kernel's RED: 8-slot ring of two fp16 terms as scratch)
+static bool wgrad3_pipe_reduces(const WgradXPlan& pl) {
+  const int npair = pl.nci * pl.wm, cit = 32 * pl.nci, xcp = 8 * 40 + 8;
+  return pl.kp == 1 || 3 * npair * 3072 <= 2 * cit * xcp / 2;
+}
+
 extern "C" size_t sc_wgrad_bx3_workspace_floats(int N, int H, int W, int Cout, int Cin) {
   const WgradXPlan pl = plan_wgrad_bx3(N, H, W, Cout, Cin);
   const size_t E = (size_t)9 * pl.CoP * pl.CiP;
@@ -2351,6 +2383,7 @@ extern "C" int sc_conv3x3_wgrad_bx3(const sc_wgrad_args* a, sc_stream stream) {
   hipStream_t st = (hipStream_t)stream;
   SC_REQUIRE(a->terms >= 0 && a->terms <= 4, "sc_conv3x3_wgrad_bx3: terms must be 0 (= 3), 1, 2, 3 or SC_TERMS_F16X2 (got %d)", a->terms);
   p.absmax = a->absmax;
+  int nparts = pl.nsl * pl.kp;          // (the pipelined variant sums its K parts in the kernel: pl.nsl)
   static const int pipe_env = [] { const char* e = getenv("STARCOP_WG3_PIPE"); return e ? atoi(e) : 1; }();   // 0: two-barrier stages
 #define SC_WGX(WM_, NT_, NCI_, HF_, PIPE_) hipLaunchKernelGGL((k_wgrad3_bx3<WM_, NT_, NCI_, HF_, PIPE_>), grid, dim3(768), 0, st, p)
 #define SC_WGX_NT(NT_, HF_, PIPE_)                                   \
@@ -2366,13 +2399,13 @@ extern "C" int sc_conv3x3_wgrad_bx3(const sc_wgrad_args* a, sc_stream stream) {
     bool pipe = pipe_env && a->dy.mode == SC_SRC_BNBWD && a->W % 2 == 0 && (((uintptr_t)a->dy.x | (uintptr_t)a->dy.aux) & 7) == 0 &&
                 (size_t)a->Cout * a->H * a->W * 4 < (1ull << 32);
     for (int s = 0; s < a->nsrc; ++s) pipe = pipe && (size_t)a->N * a->src[s].C * (a->H >> a->src[s].up) * (a->W >> a->src[s].up) * 4 < (1ull << 32);
-    if (pipe) SC_WGX_NT(2, true, true); else SC_WGX_NT(2, true, false);
+    if (pipe) { SC_WGX_NT(2, true, true); if (wgrad3_pipe_reduces(pl)) nparts = pl.nsl; } else SC_WGX_NT(2, true, false);
   }
   else SC_WGX_NT(3, false, false);
 #undef SC_WGX_NT
 #undef SC_WGX
   SC_LAUNCH_OK("sc_conv3x3_wgrad_bx3");
-  return sc_wgrad_finish(a->part, pl.nsl * pl.kp, 9, a->Cout, a->Cin, pl.CoP, pl.CiP, a->dw, st);
+  return sc_wgrad_finish(a->part, nparts, 9, a->Cout, a->Cin, pl.CoP, pl.CiP, a->dw, st);
 }
 
 static int wgrad_thin16_slices(int N, int H, int W) {
