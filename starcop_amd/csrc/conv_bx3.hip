@@ -2408,15 +2408,16 @@ extern "C" int sc_conv3x3_wgrad_bx3(const sc_wgrad_args* a, sc_stream stream) {
   return sc_wgrad_finish(a->part, nparts, 9, a->Cout, a->Cin, pl.CoP, pl.CiP, a->dw, st);
 }
 
-static int wgrad_thin16_slices(int N, int H, int W) {
+static int wgrad_thin16_slices(int N, int H, int W, int Cin) {
   const long T = (long)N * ((W + 31) / 32) * ((H + 3) / 4 + 1);
-  return (int)(T < 768 ? T : 768);            // three work-groups per CU resident: one round of 768
+  const long full = Cin > 16 ? 512 : 768;     // ONE full round: three work-groups per CU are resident with 16 input channels, two with 32
+  return (int)(T < full ? T : full);
 }
 
 extern "C" size_t sc_wgrad_thin16_workspace_floats(int N, int H, int W, int Cout, int Cin) {
   (void)Cout;
   const size_t E = (size_t)9 * 16 * Cin;
-  const int nparts = wgrad_thin16_slices(N, H, W);
+  const int nparts = wgrad_thin16_slices(N, H, W, Cin);
   return (size_t)nparts * E + sc_reduce_scratch_floats(nparts, E);
 }
 
@@ -2440,7 +2441,7 @@ extern "C" int sc_conv3x3_wgrad_thin16(const sc_wgrad_args* a, sc_stream stream)
   p.absmax = a->absmax;
   p.dy = to_srcd(a->dy); p.s0 = to_srcd(s); p.s1 = empty_srcd();
   p.N = a->N; p.H = a->H; p.W = a->W; p.Cout = a->Cout; p.Cin = a->Cin; p.part = a->part;
-  p.nsl = wgrad_thin16_slices(a->N, a->H, a->W); p.CoP = 16; p.CiP = a->Cin;
+  p.nsl = wgrad_thin16_slices(a->N, a->H, a->W, a->Cin); p.CoP = 16; p.CiP = a->Cin;
   hipStream_t st = (hipStream_t)stream;
   const bool bnb = a->dy.mode == SC_SRC_BNBWD;
   dim3 grid(p.nsl);
