@@ -302,6 +302,9 @@ def main():
                                   f"2500 TFLOP/s / {int(nprod)} products; the kernel executes {round(nprod * ach, 1)} 16-bit TFLOP/s on the matrix cores; "
                                   f"{round(ach / FP32_MFMA_PEAK_TFLOPS, 3)} x the fp32 MFMA peak of {FP32_MFMA_PEAK_TFLOPS}") if bx3 else
                                  "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
+                    "kernel_templates": ("k_conv3_bx3<Q,BNB,2,true>; launches with K loops of >= 16 chunks (decoder.blocks.0) run the "
+                                         "wave-specialised k_conv3_ws<Q,BNB> of the same contraction (both names appear in the rocprofv3 "
+                                         "kernel traces under profiles/)") if (fam.startswith("k_conv3_bx3") and nterms == 4) else None,
                     "algorithmic_bytes_per_launch": round(d["bytes"] / d["n"]) if d.get("bytes") else None,
                     "algorithmic_flop_per_launch": round(d["flop"] / d["n"]),
                     "launches_per_step": d["n"] // 3, "avg_launch_ms": round(d["ms"] / d["n"], 4),
