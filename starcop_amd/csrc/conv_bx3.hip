@@ -1236,6 +1236,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
   constexpr int NE = (NPX * NH + 255) / 256;  // staging entries (pixel x channel group) per thread
   __shared__ uintx4 s_p[2][NH][NPX];
   __shared__ float s_red[4][16][2];
+  __shared__ __attribute__((aligned(16))) float s_c[CIN * 8];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -1256,6 +1257,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
   const float hsx = BNB ? h_grad_scale(p.absmax) : SC_H_SX;
   const float hinv = 1.f / (hsx * SC_H_SW);
 
+  // per-channel constants through LDS, requested FIRST: read from global memory inside the conversion (under the `mode != RAW`
+  // branch) they were a second, fully exposed memory round trip per work-group behind the patch loads
+  const SrcD& src = p.s0;
+  if (tid < CIN * 2) {
+    const int ch = tid >> 1, h = tid & 1;
+    float4 v = h ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(1.f, 0.f, 0.f, 0.f);
+    if (src.mode != SC_SRC_RAW) v = *reinterpret_cast<const float4*>(src.cst + (size_t)ch * SC_CST + 4 * h);
+    *reinterpret_cast<float4*>(&s_c[ch * 8 + 4 * h]) = v;
+  }
   uintx4 A[NS][2];
 #pragma unroll
   for (int s = 0; s < NS; ++s)
@@ -1263,7 +1273,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
     for (int t = 0; t < 2; ++t) A[s][t] = p.wpk[(s * 2 + t) * 64 + lane];
 
   // ---- stage the patch: entry q -> (channel group, patch pixel); consecutive lanes = consecutive pixels
-  const SrcD& src = p.s0;
   const int up = src.up;
   const int Ws = W >> up;
   const size_t plane = (size_t)(H >> up) * Ws;
@@ -1288,6 +1297,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
       if (BNB) av[k][j] = ab[(size_t)j * plane];
     }
   }
+  __syncthreads();          // constants in LDS (the patch loads stay in flight)
 #pragma unroll
   for (int k = 0; k < NE; ++k) {
     const int q = tid + 256 * k;
@@ -1300,12 +1310,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int j = 2 * jp + h;
-        float4 c = make_float4(1.f, 0.f, 0.f, 0.f);
-        float c4 = 0.f;
-        if (src.mode != SC_SRC_RAW) {
-          c = *reinterpret_cast<const float4*>(src.cst + (size_t)(g8 + j) * SC_CST);
-          if (BNB) c4 = src.cst[(size_t)(g8 + j) * SC_CST + 4];
-        }
+        const float4 c = *reinterpret_cast<const float4*>(&s_c[(g8 + j) * 8]);
+        const float c4 = BNB ? s_c[(g8 + j) * 8 + 4] : 0.f;
         const float t = BNB ? sc_pro_bnbwd(xv[k][j], av[BNB ? k : 0][j], c.x, c.y, c.z, c.w, c4, slo, shi)
                             : sc_pro_affine(xv[k][j], c.x, c.y, slo, shi);
         v[h] = okv[k] ? t * hsx : 0.f;
