@@ -846,6 +846,14 @@ __global__ __launch_bounds__(256, 4) void k_head_fwd16(const SrcD in, const floa
   if (threadIdx.x < CIN * 12) { const int c = threadIdx.x / 12, t = threadIdx.x - 12 * c; s_w[threadIdx.x] = t < 9 ? w[c * 9 + t] : 0.f; }
   const float lo = sc_act_lo(in.act), hi = sc_act_hi(in.act);
   const bool raw = in.mode == SC_SRC_RAW;
+  // scale / shift of the 16 channels through LDS, requested before the patch: read per staged row inside the loop they were a
+  // (scalar) memory round trip per iteration
+  __shared__ float s_sc[CIN * 2];
+  if (threadIdx.x >= 224 && threadIdx.x < 224 + CIN * 2) {
+    const int i = threadIdx.x - 224, c = i >> 1, h = i & 1;
+    s_sc[i] = raw ? (h ? 0.f : 1.f) : in.cst[(size_t)c * SC_CST + h];
+  }
+  __syncthreads();
   const int py = threadIdx.x >> 4, pxg = threadIdx.x & 15;
   float acc[4];
   const float b0 = bias ? bias[0] : 0.f;
@@ -883,7 +891,7 @@ __global__ __launch_bounds__(256, 4) void k_head_fwd16(const SrcD in, const floa
             const int y = y0 - 1 + r;
             const bool oky = (y >= 0) && (y < H);
             const int cg = pass * CP + ci;
-            const float sc = raw ? 1.f : in.cst[(size_t)cg * SC_CST], sh = raw ? 0.f : in.cst[(size_t)cg * SC_CST + 1];
+            const float sc = s_sc[cg * 2], sh = s_sc[cg * 2 + 1];
             s_in[(ci * PR + r) * PC + lane] = (oky && oka) ? sc_pro_affine(va[u], sc, sh, lo, hi) : 0.f;
             if (lane < 2) s_in[(ci * PR + r) * PC + 64 + lane] = (oky && okb) ? sc_pro_affine(vb[u], sc, sh, lo, hi) : 0.f;
           }
