@@ -117,16 +117,13 @@ __global__ __launch_bounds__(256) void k_dw_fwd(const SrcD in, const float* __re
   if (plane >= NC) return;
   const int n = plane / C, c = plane - n * C;
   const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
-  float sc = 1.f, sh = 0.f;
-  if (in.mode != SC_SRC_RAW) { sc = in.cst[(size_t)c * SC_CST]; sh = in.cst[(size_t)c * SC_CST + 1]; }
+  float sc = 1.f, sh = 0.f;          // (requested after the first batch of patch loads, see k_dw_bwd)
   const float lo = sc_act_lo(in.act), hi = sc_act_hi(in.act);
   const float* xb = in.x + ((size_t)n * C + c) * Hin * Win;
   // stride 1: every load of the patch is in flight before the first use (one memory round trip per work-group)
   constexpr int NE = PH * PW, NIT = (NE + 255) / 256, LB = (S == 1) ? NIT : SC_DW_LB;   // measured: stride-2 patches (33 loads per thread) are faster in batches of 8
   const int y0 = ty0 * S - 1, x0 = tx0 * S - 1;
   float wk[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) wk[t] = w[c * 9 + t];
 #pragma unroll
   for (int i0 = 0; i0 < NIT; i0 += LB) {
     float v[LB];
@@ -139,6 +136,12 @@ __global__ __launch_bounds__(256) void k_dw_fwd(const SrcD in, const float* __re
         const bool ok = (e < NE) && (iy >= 0) && (iy < Hin) && (ix >= 0) && (ix < Win);
         v[j] = xb[ok ? iy * Win + ix : 0];
       }
+    if (i0 == 0) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (in.mode != SC_SRC_RAW) { sc = in.cst[(size_t)c * SC_CST]; sh = in.cst[(size_t)c * SC_CST + 1]; }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wk[t] = w[c * 9 + t];
+    }
 #pragma unroll
     for (int j = 0; j < LB; ++j)
       if (i0 + j < NIT) {
@@ -418,14 +421,12 @@ __global__ __launch_bounds__(256) void k_dw_bwd(const SrcD dy, const SrcD in, co
   const int n = plane / C, c = plane - n * C;
   const int iy0 = (tile / tiles_x) * TH, ix0 = (tile % tiles_x) * TW;
   const int oyb = (S == 1) ? iy0 - 1 : iy0 / 2, oxb = (S == 1) ? ix0 - 1 : ix0 / 2;
+  // (the per-channel constants are requested AFTER the patch loads below: scalar loads return out of order, so the wait for
+  // the tensor pointers in front of the first patch load would otherwise also wait for them -- a dependent scalar-memory round
+  // trip per work-group before anything is in flight)
   float4 c0 = make_float4(1.f, 0.f, 0.f, 0.f); float c4 = 0.f;
-  if (dy.mode != SC_SRC_RAW) { c0 = *reinterpret_cast<const float4*>(dy.cst + (size_t)c * SC_CST); c4 = dy.cst[(size_t)c * SC_CST + 4]; }
   const float dlo = sc_act_lo(dy.act), dhi = sc_act_hi(dy.act);
   float xs = 1.f, xh = 0.f, xmean = 0.f, xinv = 1.f;
-  if (in.mode != SC_SRC_RAW) {
-    const float4 ci = *reinterpret_cast<const float4*>(in.cst + (size_t)c * SC_CST);
-    xs = ci.x; xh = ci.y; xmean = ci.z; xinv = ci.w;
-  }
   const float xlo = sc_act_lo(in.act), xhi = sc_act_hi(in.act);
   const size_t obase = ((size_t)n * C + c) * Hout * Wout, ibase = ((size_t)n * C + c) * Hin * Win;
   // ---- staging: EVERY global load of the tile (dy patch as g and y, raw input patch, halo columns) is issued before the first
@@ -474,7 +475,13 @@ __global__ __launch_bounds__(256) void k_dw_bwd(const SrcD dy, const SrcD in, co
       (void)hg2; (void)hy2;
     }
   }
-  // ---- all loads are in flight: consume
+  // ---- all loads are in flight: the channel's constants, then consume
+  __builtin_amdgcn_sched_barrier(0);
+  if (dy.mode != SC_SRC_RAW) { c0 = *reinterpret_cast<const float4*>(dy.cst + (size_t)c * SC_CST); c4 = dy.cst[(size_t)c * SC_CST + 4]; }
+  if (in.mode != SC_SRC_RAW) {
+    const float4 ci = *reinterpret_cast<const float4*>(in.cst + (size_t)c * SC_CST);
+    xs = ci.x; xh = ci.y; xmean = ci.z; xinv = ci.w;
+  }
 #pragma unroll
   for (int i = 0; i < NID; ++i) {
     const int e = threadIdx.x + i * 256;
