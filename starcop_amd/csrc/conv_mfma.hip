@@ -215,6 +215,29 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
   };
 
   auto compute_chunk = [&](int buf) {
+    if constexpr (KS == 1) {
+      // all operand reads of the chunk first, then the MFMAs: the compiler otherwise emits read, wait lgkmcnt(0), MFMA for every
+      // K step, i.e. one exposed LDS round trip per MFMA
+      float b[KC / 2], a[KC / 2][RM];
+#pragma unroll
+      for (int cp = 0; cp < KC / 2; ++cp) {
+        const int cil = 2 * cp + lhi;
+        b[cp] = s_p[buf][cil * PCH + wave * 32 + l31];
+#pragma unroll
+        for (int m = 0; m < RM; ++m) a[cp][m] = s_w[buf][cil * CO_T + m * 32 + l31];
+      }
+#pragma unroll
+      for (int cp = 0; cp < KC / 2; ++cp)
+#pragma unroll
+        for (int m = 0; m < RM; ++m) {
+#ifdef SC_EXPERIMENT_SKIP_MFMA
+          acc[m][0] = fmaf(a[cp][m], b[cp], acc[m][0]);
+#else
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp][m], b[cp], acc[m], 0, 0, 0);
+#endif
+        }
+      return;
+    }
 #pragma unroll
     for (int cp = 0; cp < KC / 2; ++cp) {
       const int cil = 2 * cp + lhi;
