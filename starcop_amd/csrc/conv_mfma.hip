@@ -974,6 +974,18 @@ __global__ __launch_bounds__(256, KS == 1 ? SC_WG1_OCC : 1) void k_wgrad_mfma(co
 #pragma unroll
     for (int rr0 = 0; rr0 < RW; ++rr0) {
       const int rr = wk * RW + rr0;
+      if constexpr (KS == 1) {
+        // all 32 operand reads of the row first, then its 16 MFMAs (otherwise: read, wait lgkmcnt(0), MFMA per K step)
+        float av[16], bv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          av[q] = s_a[(wm * 32 + l31) * PA + rr * 32 + 2 * q + lhi];
+          bv[q] = s_b[(wn * 32 + l31) * PB + rr * 32 + 2 * q + lhi];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc[0], 0, 0, 0);
+        continue;
+      }
 #pragma unroll 4
       for (int q = 0; q < 16; ++q) {
         const float a = s_a[(wm * 32 + l31) * PA + rr * 32 + 2 * q + lhi];
