@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1_ksplit(const ConvP p) {
   const bool pok = pix < HW;
   const float* xb = p.s0.x + (size_t)n * Cin * HW + (pok ? pix : 0);
   const float* ab = BNB ? p.s0.aux + (size_t)n * Cin * HW + (pok ? pix : 0) : nullptr;
-  const float* cst = (p.s0.mode != SC_SRC_RAW) ? p.s0.cst : nullptr;
+  const float* cst = p.s0.cst;          // never NULL: the host hands RAW sources the identity table (no load under a branch)
   const float lo = sc_act_lo(p.s0.act), hi = sc_act_hi(p.s0.act);
 
   floatx16 acc[RM];
@@ -655,13 +655,8 @@ __global__ __launch_bounds__(256, 2) void k_conv1_ksplit(const ConvP p) {
       const int cc = ci < Cin ? ci : 0;
       bx[cp] = xb[(size_t)cc * HW];
       if (BNB) by[cp] = ab[(size_t)cc * HW];
-      if (cst) {
-        if (BNB) { c0[cp] = *reinterpret_cast<const float4*>(cst + (size_t)cc * SC_CST); c4[cp] = cst[(size_t)cc * SC_CST + 4]; }
-        else { const float2 t = *reinterpret_cast<const float2*>(cst + (size_t)cc * SC_CST); c0[cp] = make_float4(t.x, t.y, 0.f, 0.f); }
-      } else {
-        c0[cp] = make_float4(1.f, 0.f, 0.f, 0.f);
-        if (BNB) c4[cp] = 0.f;
-      }
+      if (BNB) { c0[cp] = *reinterpret_cast<const float4*>(cst + (size_t)cc * SC_CST); c4[cp] = cst[(size_t)cc * SC_CST + 4]; }
+      else { const float2 t = *reinterpret_cast<const float2*>(cst + (size_t)cc * SC_CST); c0[cp] = make_float4(t.x, t.y, 0.f, 0.f); }
 #pragma unroll
       for (int m = 0; m < RM; ++m) wa[cp][m] = wbase[(size_t)ci * CO_T + m * 32 + l31];     // filters are zero-padded to nk*16
     }
@@ -680,7 +675,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1_ksplit(const ConvP p) {
       for (int m = 0; m < RM; ++m) a[cp][m] = wa[cp][m];
     }
     const int kn = kc + 4;
-    if (kn < nk) load_chunk(kn);
+    load_chunk(kn < nk ? kn : kc);         // unconditional (past the end: this chunk again, never used): exact vmcnt counting
 #pragma unroll
     for (int cp = 0; cp < 8; ++cp)
 #pragma unroll
@@ -1413,6 +1408,7 @@ extern "C" int sc_conv1x1_ksplit(const sc_conv_args* a, sc_stream stream) {
   p.bnb_y = nullptr; p.bnb_cst = nullptr; p.bnb_sums = nullptr; p.bnb_absmax = nullptr; p.bnb_act = 0;
   p.xcdmap = 0;
   p.s0 = to_srcd(a->src[0]); p.s1 = empty_srcd();
+  if (p.s0.mode == SC_SRC_RAW) { p.s0.cst = sc_identity_cst(p.s0.C); SC_REQUIRE(p.s0.cst != nullptr, "sc_conv1x1_ksplit: identity constants unavailable (C = %d)", p.s0.C); }
   p.wpk = a->wpk; p.N = a->N; p.H = a->H; p.W = a->W; p.Cout = a->Cout;
   p.out0 = a->out0; p.out1 = a->out1; p.csplit = a->csplit; p.accum0 = a->accum0; p.accum1 = a->accum1;
   p.add0 = a->add0; p.add1 = a->add1; p.stats = a->stats;
