@@ -1233,10 +1233,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
   constexpr int PR = 10, PC = 34, NPX = PR * PC;
   constexpr int NH = CIN / 8;                 // 8-channel groups
   constexpr int NG = 9 * NH, NS = (NG + 3) / 4;
-  constexpr int NE = (NPX * NH + 255) / 256;  // staging entries (pixel x channel group) per thread
   __shared__ uintx4 s_p[2][NH][NPX];
   __shared__ float s_red[4][16][2];
-  __shared__ __attribute__((aligned(16))) float s_c[CIN * 8];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -1257,52 +1255,58 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
   const float hsx = BNB ? h_grad_scale(p.absmax) : SC_H_SX;
   const float hinv = 1.f / (hsx * SC_H_SW);
 
-  // per-channel constants through LDS, requested FIRST: read from global memory inside the conversion (under the `mode != RAW`
-  // branch) they were a second, fully exposed memory round trip per work-group behind the patch loads
   const SrcD& src = p.s0;
-  if (tid < CIN * 2) {
-    const int ch = tid >> 1, h = tid & 1;
-    float4 v = h ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(1.f, 0.f, 0.f, 0.f);
-    if (src.mode != SC_SRC_RAW) v = *reinterpret_cast<const float4*>(src.cst + (size_t)ch * SC_CST + 4 * h);
-    *reinterpret_cast<float4*>(&s_c[ch * 8 + 4 * h]) = v;
-  }
   uintx4 A[NS][2];
 #pragma unroll
   for (int s = 0; s < NS; ++s)
 #pragma unroll
     for (int t = 0; t < 2; ++t) A[s][t] = p.wpk[(s * 2 + t) * 64 + lane];
 
-  // ---- stage the patch: entry q -> (channel group, patch pixel); consecutive lanes = consecutive pixels
+  // ---- stage the patch.  A wave stages ONE 8-channel group (4 / NH waves per group), lanes = consecutive patch pixels: the
+  // group -- hence the plane pointers and the per-channel constants -- is wave-uniform, so the constants are SCALAR loads into
+  // SGPRs.  (First version: entry -> (group, pixel) per lane, constants fetched per element from global memory under the
+  // `mode != RAW` branch: a second, fully exposed memory round trip behind the patch loads; through LDS: 48 ds_reads per thread.)
+  constexpr int WPG = 4 / NH, TPG = 64 * WPG, NR = (NPX + TPG - 1) / TPG;
+  const int grp = __builtin_amdgcn_readfirstlane(wave / WPG);
+  const int g8 = grp * 8;
+  const int e0 = tid - grp * TPG;
   const int up = src.up;
   const int Ws = W >> up;
   const size_t plane = (size_t)(H >> up) * Ws;
   const float slo = sc_act_lo(src.act), shi = sc_act_hi(src.act);
-  float xv[NE][8], av[BNB ? NE : 1][8];
-  bool okv[NE];
+  float xv[NR][8], av[BNB ? NR : 1][8];
+  bool okv[NR];
+  const float* const xg = src.x + ((size_t)n * CIN + g8) * plane;
+  const float* const ag = BNB ? src.aux + ((size_t)n * CIN + g8) * plane : nullptr;
 #pragma unroll
-  for (int k = 0; k < NE; ++k) {
-    const int q = tid + 256 * k;
-    const int grp = q / NPX, e = q - grp * NPX;
+  for (int r = 0; r < NR; ++r) {
+    const int e = e0 + TPG * r;
     const int pr = e / PC, pc = e - pr * PC;
     const int y = y0 - 1 + pr, x = x0 - 1 + pc;
-    const bool ok = (q < NPX * NH) && y >= 0 && y < H && x >= 0 && x < W;
-    okv[k] = ok;
+    const bool ok = (e < NPX) && y >= 0 && y < H && x >= 0 && x < W;
+    okv[r] = ok;
     const unsigned off = ok ? (unsigned)((y >> up) * Ws + (x >> up)) : 0u;
-    const int g8 = (q < NPX * NH ? grp : 0) * 8;
-    const float* xb = src.x + ((size_t)n * CIN + g8) * plane + off;
-    const float* ab = BNB ? src.aux + ((size_t)n * CIN + g8) * plane + off : nullptr;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      xv[k][j] = xb[(size_t)j * plane];
-      if (BNB) av[k][j] = ab[(size_t)j * plane];
+      xv[r][j] = xg[(size_t)j * plane + off];
+      if (BNB) av[r][j] = ag[(size_t)j * plane + off];
     }
   }
-  __syncthreads();          // constants in LDS (the patch loads stay in flight)
+  // the group's constants: requested behind the patch (the wait of a scalar load under the RAW branch then overlaps its flight)
+  __builtin_amdgcn_sched_barrier(0);
+  float4 cc[8]; float c4[8];
 #pragma unroll
-  for (int k = 0; k < NE; ++k) {
-    const int q = tid + 256 * k;
-    const int grp = q / NPX, e = q - grp * NPX;
-    const int g8 = (q < NPX * NH ? grp : 0) * 8;
+  for (int j = 0; j < 8; ++j) { cc[j] = make_float4(1.f, 0.f, 0.f, 0.f); c4[j] = 0.f; }
+  if (src.mode != SC_SRC_RAW) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      cc[j] = *reinterpret_cast<const float4*>(src.cst + (size_t)(g8 + j) * SC_CST);
+      if (BNB) c4[j] = src.cst[(size_t)(g8 + j) * SC_CST + 4];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int e = e0 + TPG * r;
     uintx4 t0, t1;
 #pragma unroll
     for (int jp = 0; jp < 4; ++jp) {
@@ -1310,17 +1314,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int j = 2 * jp + h;
-        const float4 c = *reinterpret_cast<const float4*>(&s_c[(g8 + j) * 8]);
-        const float c4 = BNB ? s_c[(g8 + j) * 8 + 4] : 0.f;
-        const float t = BNB ? sc_pro_bnbwd(xv[k][j], av[BNB ? k : 0][j], c.x, c.y, c.z, c.w, c4, slo, shi)
-                            : sc_pro_affine(xv[k][j], c.x, c.y, slo, shi);
-        v[h] = okv[k] ? t * hsx : 0.f;
+        const float t = BNB ? sc_pro_bnbwd(xv[r][j], av[BNB ? r : 0][j], cc[j].x, cc[j].y, cc[j].z, cc[j].w, c4[j], slo, shi)
+                            : sc_pro_affine(xv[r][j], cc[j].x, cc[j].y, slo, shi);
+        v[h] = okv[r] ? t * hsx : 0.f;
       }
       unsigned a0, a1;
       split2h(v[0], v[1], a0, a1);
       t0[jp] = a0; t1[jp] = a1;
     }
-    if (q < NPX * NH) { s_p[0][grp][e] = t0; s_p[1][grp][e] = t1; }
+    if (e < NPX) { s_p[0][grp][e] = t0; s_p[1][grp][e] = t1; }
   }
   __syncthreads();
 
