@@ -62,8 +62,18 @@ __device__ __forceinline__ float h_grad_scale(const float* absmax) {
   e = e < -100 ? -100 : (e > 100 ? 100 : e);
   return ldexpf(1.f, e);                                // M * s in [16, 32)
 }
+// The operand scale s and (forward sources) the clamp are folded into the prologue constants by the callers: s is a power of
+// two, so  clamp(s * min(max(x*sc + sh, lo), hi))  ==  med3(x*(s*sc) + s*sh, max(s*lo, -65504), min(s*hi, 65504))  bit for bit
+// (h_lo / h_hi / sc_pro_affine_h), and  s * (A g + B y + D)  ==  (sA) g + (sB) y + sD  -- 3 resp. 1 VALU less per staged value.
+__device__ __forceinline__ float h_lo(float lo, float s) { return fmaxf(lo * s, -SC_H_MAX); }
+__device__ __forceinline__ float h_hi(float hi, float s) { return fminf(hi * s, SC_H_MAX); }
+__device__ __forceinline__ float sc_pro_affine_h(float x, float sc, float sh, float lo, float hi) {
+  return __builtin_amdgcn_fmed3f(fmaf(x, sc, sh), lo, hi);
+}
+template <bool CLAMP = true>
 __device__ __forceinline__ void split2h(float a, float b, unsigned& t0, unsigned& t1) {
-  floatx2 v = {__builtin_amdgcn_fmed3f(a, -SC_H_MAX, SC_H_MAX), __builtin_amdgcn_fmed3f(b, -SC_H_MAX, SC_H_MAX)};
+  floatx2 v = {a, b};
+  if constexpr (CLAMP) v = floatx2{__builtin_amdgcn_fmed3f(a, -SC_H_MAX, SC_H_MAX), __builtin_amdgcn_fmed3f(b, -SC_H_MAX, SC_H_MAX)};
   const halfx2 h0 = __builtin_convertvector(v, halfx2);
   v -= __builtin_convertvector(h0, floatx2);
   const halfx2 h1 = __builtin_convertvector(v, halfx2);
@@ -74,9 +84,12 @@ __device__ __forceinline__ void split2h(float a, float b, unsigned& t0, unsigned
 // same SIMD a v_pk_add_f32 costs several issue slots (MI355X_MICROARCH.md: packed f32 VALU is "an anti-lever beside MFMAs";
 // measured -7 % there).  In the single-role kernels, whose staging phases are VALU-bound, the packed form is the faster one
 // (weight gradients +3-6 %, thin forward +2-5 % with the scalar form).
+template <bool CLAMP = true>
 __device__ __forceinline__ void split2h_scalar(float a, float b, unsigned& t0, unsigned& t1) {
-  a = __builtin_amdgcn_fmed3f(a, -SC_H_MAX, SC_H_MAX);
-  b = __builtin_amdgcn_fmed3f(b, -SC_H_MAX, SC_H_MAX);
+  if constexpr (CLAMP) {
+    a = __builtin_amdgcn_fmed3f(a, -SC_H_MAX, SC_H_MAX);
+    b = __builtin_amdgcn_fmed3f(b, -SC_H_MAX, SC_H_MAX);
+  }
   const _Float16 ha = (_Float16)a, hb = (_Float16)b;
   const float ra = a - (float)ha, rb = b - (float)hb;
   const _Float16 la = (_Float16)ra, lb = (_Float16)rb;
@@ -241,6 +254,7 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
     second = kc * 16 >= C0;
     const SrcD& s = second ? p.s1 : p.s0;
     slo = sc_act_lo(s.act); shi = sc_act_hi(s.act);
+    if constexpr (HF && !BNB) { slo = h_lo(slo, hsx); shi = h_hi(shi, hsx); }      // (operand scale + clamp folded, see split2h)
     plane = (size_t)(H >> s.up) * (W >> s.up);
     const int cbase = kc * 16 + hw * 8 - (second ? C0 : 0);       // first channel (source space) staged by this wave
     nch = s.C - cbase;                                            // channels j < nch exist
@@ -272,11 +286,11 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int cj = j < jmax ? j : jmax;
-      cs0[j] = 1.f; cs1[j] = 0.f; cs2[j] = 0.f; cs3[j] = 0.f; cs4[j] = 0.f;
+      cs0[j] = BNB ? 1.f : hsx; cs1[j] = 0.f; cs2[j] = 0.f; cs3[j] = 0.f; cs4[j] = 0.f;
       if (cb) {
         const float4 c = *reinterpret_cast<const float4*>(cb + (size_t)cj * SC_CST);
-        cs0[j] = c.x; cs1[j] = c.y;
-        if (BNB) { cs2[j] = c.z; cs3[j] = c.w; cs4[j] = cb[(size_t)cj * SC_CST + 4]; }
+        if (BNB) { cs0[j] = c.x; cs1[j] = c.y; cs2[j] = c.z; cs3[j] = c.w; cs4[j] = cb[(size_t)cj * SC_CST + 4]; }
+        else { cs0[j] = c.x * hsx; cs1[j] = c.y * hsx; }
       }
     }
   };
@@ -286,11 +300,14 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
     for (int h = 0; h < 2; ++h) {
       const int j = 2 * jp + h;
       const float t = BNB ? sc_pro_bnbwd(xv[r][j], av[BNB ? r : 0][j], cs0[j], cs1[j], cs2[j], cs3[j], cs4[j], slo, shi)
-                          : sc_pro_affine(xv[r][j], cs0[j], cs1[j], slo, shi);
+                          : (HF ? sc_pro_affine_h(xv[r][j], cs0[j], cs1[j], slo, shi) : sc_pro_affine(xv[r][j], cs0[j], cs1[j], slo, shi));
       v[h] = (((inb >> r) & 1u) && j < nch) ? t : 0.f;
     }
     unsigned t[3];
-    if constexpr (HF) { split2h(v[0] * hsx, v[1] * hsx, t[0], t[1]); t[2] = 0u; }
+    if constexpr (HF) {      // (BNB: the constants are wave-uniform SGPR values here, scaling them would move them to VGPRs)
+      if constexpr (BNB) split2h(v[0] * hsx, v[1] * hsx, t[0], t[1]); else split2h<false>(v[0], v[1], t[0], t[1]);
+      t[2] = 0u;
+    }
     else split3x2(v[0], v[1], t[0], t[1], t[2]);
 #pragma unroll
     for (int c = 0; c < NT; ++c) pt[r][c][jp] = t[c];
@@ -800,7 +817,10 @@ __global__ __launch_bounds__(512, 4) void k_conv3_ws(const ConvXP p) {
   const int nst = 3 * nk;
   const bool want_stats = p.stats != nullptr;
   if constexpr (BNB) {
-    for (int i = (int)threadIdx.x; i < p.s0.C * SC_CST; i += 512) s_cst[i] = p.s0.cst[i];
+    for (int i = (int)threadIdx.x; i < p.s0.C * SC_CST; i += 512) {
+      const int f = i & (SC_CST - 1);                   // A, B, D (fields 2..4) carry the operand scale, see split2h
+      s_cst[i] = p.s0.cst[i] * ((HF && f >= 2 && f <= 4) ? hsx : 1.f);
+    }
     __syncthreads();
   }
   if (role == 1) {
@@ -832,6 +852,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_ws(const ConvXP p) {
     c.second = kc * 16 >= C0;
     const SrcD& s = c.second ? p.s1 : p.s0;
     c.slo = sc_act_lo(s.act); c.shi = sc_act_hi(s.act);
+    if constexpr (HF && !BNB) { c.slo = h_lo(c.slo, hsx); c.shi = h_hi(c.shi, hsx); }     // (scale + clamp folded, see split2h)
     c.plane = (size_t)(H >> s.up) * (W >> s.up);
     const int cbase = kc * 16 + hw * 8 - (c.second ? C0 : 0);       // first channel (source space) staged by this wave
     c.nch = s.C - cbase;                                              // channels j < nch exist
@@ -864,7 +885,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_ws(const ConvXP p) {
       for (int j = 0; j < 8; ++j) {
         const int cj = j < jmax ? j : jmax;
         const float2 v = *reinterpret_cast<const float2*>(c.cb + (size_t)cj * SC_CST);     // (never a conditional load: see make_chunk)
-        k.sc[j] = c.raw ? 1.f : v.x; k.sh[j] = c.raw ? 0.f : v.y;
+        k.sc[j] = c.raw ? hsx : v.x * hsx; k.sh[j] = c.raw ? 0.f : v.y * hsx;     // (scale folded, see split2h)
       }
     }
   };
@@ -883,12 +904,13 @@ __global__ __launch_bounds__(512, 4) void k_conv3_ws(const ConvXP p) {
           const float4 k4 = *reinterpret_cast<const float4*>(&s_cst[ch * SC_CST]);
           t = sc_pro_bnbwd(xv[r][j], av[r][j], k4.x, k4.y, k4.z, k4.w, s_cst[ch * SC_CST + 4], c.slo, c.shi);
         } else {
-          t = sc_pro_affine(xv[r][j], k.sc[BNB ? 0 : j], k.sh[BNB ? 0 : j], c.slo, c.shi);
+          t = HF ? sc_pro_affine_h(xv[r][j], k.sc[BNB ? 0 : j], k.sh[BNB ? 0 : j], c.slo, c.shi)
+                 : sc_pro_affine(xv[r][j], k.sc[BNB ? 0 : j], k.sh[BNB ? 0 : j], c.slo, c.shi);
         }
         v[h] = (((inb >> r) & 1u) && j < c.nch) ? t : 0.f;
       }
       unsigned a, b;
-      split2h_scalar(v[0] * hsx, v[1] * hsx, a, b);
+      split2h_scalar<BNB>(v[0], v[1], a, b);
       t0[jp] = a; t1[jp] = b;
     }
     const int e = sidx + 128 * r;
@@ -1273,7 +1295,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
   const int up = src.up;
   const int Ws = W >> up;
   const size_t plane = (size_t)(H >> up) * Ws;
-  const float slo = sc_act_lo(src.act), shi = sc_act_hi(src.act);
+  // (operand scale -- and for forward sources the clamp -- folded into the constants, see split2h)
+  const float slo = BNB ? sc_act_lo(src.act) : h_lo(sc_act_lo(src.act), hsx), shi = BNB ? sc_act_hi(src.act) : h_hi(sc_act_hi(src.act), hsx);
   float xv[NR][8], av[BNB ? NR : 1][8];
   bool okv[NR];
   const float* const xg = src.x + ((size_t)n * CIN + g8) * plane;
@@ -1296,12 +1319,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
   __builtin_amdgcn_sched_barrier(0);
   float4 cc[8]; float c4[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { cc[j] = make_float4(1.f, 0.f, 0.f, 0.f); c4[j] = 0.f; }
+  for (int j = 0; j < 8; ++j) { cc[j] = make_float4(BNB ? 1.f : hsx, 0.f, 0.f, 0.f); c4[j] = 0.f; }
   if (src.mode != SC_SRC_RAW) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       cc[j] = *reinterpret_cast<const float4*>(src.cst + (size_t)(g8 + j) * SC_CST);
       if (BNB) c4[j] = src.cst[(size_t)(g8 + j) * SC_CST + 4];
+      else { cc[j].x *= hsx; cc[j].y *= hsx; }
     }
   }
 #pragma unroll
@@ -1315,11 +1339,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
       for (int h = 0; h < 2; ++h) {
         const int j = 2 * jp + h;
         const float t = BNB ? sc_pro_bnbwd(xv[r][j], av[BNB ? r : 0][j], cc[j].x, cc[j].y, cc[j].z, cc[j].w, c4[j], slo, shi)
-                            : sc_pro_affine(xv[r][j], cc[j].x, cc[j].y, slo, shi);
-        v[h] = okv[r] ? t * hsx : 0.f;
+                            : sc_pro_affine_h(xv[r][j], cc[j].x, cc[j].y, slo, shi);
+        v[h] = okv[r] ? (BNB ? t * hsx : t) : 0.f;
       }
       unsigned a0, a1;
-      split2h(v[0], v[1], a0, a1);
+      split2h<BNB>(v[0], v[1], a0, a1);
       t0[jp] = a0; t1[jp] = a1;
     }
     if (e < NPX) { s_p[0][grp][e] = t0; s_p[1][grp][e] = t1; }
@@ -1490,7 +1514,10 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
 
   for (int i = tid; i < COT * SC_CST; i += NTH) {
     const int ch = cot * COT + i / SC_CST;
-    s_ca[i] = (p.dy.cst && p.dy.mode != SC_SRC_RAW && ch < p.Cout) ? p.dy.cst[(size_t)ch * SC_CST + (i % SC_CST)] : ((i % SC_CST) == 0 ? 1.f : 0.f);
+    // (the operand scale rides in the constants, see split2h: A, B, D of the BatchNorm-backward form, scale / shift otherwise)
+    const int f = i % SC_CST;
+    const float fs = (p.dy.mode == SC_SRC_BNBWD ? (f >= 2 && f <= 4) : (f < 2)) ? hsg : 1.f;
+    s_ca[i] = fs * ((p.dy.cst && p.dy.mode != SC_SRC_RAW && ch < p.Cout) ? p.dy.cst[(size_t)ch * SC_CST + f] : (f == 0 ? 1.f : 0.f));
   }
   for (int i = tid; i < CIT; i += NTH) {
     const int ch = cit * CIT + i;
@@ -1503,6 +1530,7 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
       if (cp && md != SC_SRC_RAW) { sc = cp[(size_t)(second ? ch - C0 : ch) * SC_CST]; sh = cp[(size_t)(second ? ch - C0 : ch) * SC_CST + 1]; }
       lo = sc_act_lo(act); hi = sc_act_hi(act);
     }
+    if constexpr (HF) { sc *= SC_H_SX; sh *= SC_H_SX; lo = h_lo(lo, SC_H_SX); hi = h_hi(hi, SC_H_SX); }      // (see split2h)
     s_cb[i * 4] = sc; s_cb[i * 4 + 1] = sh; s_cb[i * 4 + 2] = lo; s_cb[i * 4 + 3] = hi;
   }
 
@@ -1519,7 +1547,8 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
   const long T = (long)p.N * tiles_x * RSS;
   const long t_begin = T * blockIdx.x / p.nsl, t_end = T * (blockIdx.x + 1) / p.nsl;
   const int dymode = PIPE ? (int)SC_SRC_BNBWD : p.dy.mode;      // the pipelined variant is launched for BatchNorm-backward gradients only
-  const float dlo = sc_act_lo(p.dy.act), dhi = sc_act_hi(p.dy.act);
+  const float dls = dymode == SC_SRC_BNBWD ? 1.f : hsg;         // (limits of an affine gradient source scale with its constants)
+  const float dlo = sc_act_lo(p.dy.act) * dls, dhi = sc_act_hi(p.dy.act) * dls;
   const size_t HW = (size_t)H * W;
 
   auto decode = [&](long t, int& n, int& y0, int& x0) {
@@ -1623,7 +1652,7 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
       t[0] = __builtin_bit_cast(unsigned, dg[k][0]) ^ __builtin_bit_cast(unsigned, dv[k][0]); t[1] = __builtin_bit_cast(unsigned, dg[k][1]) ^ __builtin_bit_cast(unsigned, dv[k][1]); t[2] = 0u;
       (void)v0; (void)v1;
 #else
-      if constexpr (HF) { split2h(v0 * hsg, v1 * hsg, t[0], t[1]); t[2] = 0u; }
+      if constexpr (HF) { split2h(v0, v1, t[0], t[1]); t[2] = 0u; }
       else split3x2(v0, v1, t[0], t[1], t[2]);
 #endif
       const int d = (col_l * DYP + row * 32 + col) >> 1;
@@ -1689,15 +1718,15 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
       const int y = R + rowi, x = x0 - 1 + 2 * pr;
       const bool okc = (cit * CIT + cil < p.Cin) && (y >= 0) && (y < H);
       const float4 c = *reinterpret_cast<const float4*>(&s_cb[cil * 4]);
-      float v0 = sc_pro_affine(xr[k][0], c.x, c.y, c.z, c.w);
-      float v1 = sc_pro_affine(xr[k][1], c.x, c.y, c.z, c.w);
+      float v0 = HF ? sc_pro_affine_h(xr[k][0], c.x, c.y, c.z, c.w) : sc_pro_affine(xr[k][0], c.x, c.y, c.z, c.w);
+      float v1 = HF ? sc_pro_affine_h(xr[k][1], c.x, c.y, c.z, c.w) : sc_pro_affine(xr[k][1], c.x, c.y, c.z, c.w);
       v0 = (okc && x >= 0 && x < W) ? v0 : 0.f;
       v1 = (okc && x + 1 < W) ? v1 : 0.f;
       unsigned t[3];
 #if SC_EXP == 3
       t[0] = __builtin_bit_cast(unsigned, xr[k][0]); t[1] = __builtin_bit_cast(unsigned, xr[k][1]); t[2] = 0u; (void)v0; (void)v1;
 #else
-      if constexpr (HF) { split2h(v0 * SC_H_SX, v1 * SC_H_SX, t[0], t[1]); t[2] = 0u; }
+      if constexpr (HF) { split2h<false>(v0, v1, t[0], t[1]); t[2] = 0u; }
       else split3x2(v0, v1, t[0], t[1], t[2]);
 #endif
       const int slot = (sl0 + rowi) & (RING - 1);
@@ -1926,13 +1955,15 @@ __global__ __launch_bounds__(256, CIN == 32 ? 2 : 3) void k_wgrad_thin_h(const W
   const float hinv = 1.f / (hsg * SC_H_SX);
 
   for (int i = tid; i < 16 * SC_CST; i += 256) {
-    const int ch = i / SC_CST;
-    s_ca[i] = (p.dy.cst && p.dy.mode != SC_SRC_RAW && ch < p.Cout) ? p.dy.cst[(size_t)ch * SC_CST + (i % SC_CST)] : ((i % SC_CST) == 0 ? 1.f : 0.f);
+    const int ch = i / SC_CST, f = i % SC_CST;          // (operand scales folded into the constants, see split2h)
+    const float fs = (BNB ? (f >= 2 && f <= 4) : (f < 2)) ? hsg : 1.f;
+    s_ca[i] = fs * ((p.dy.cst && p.dy.mode != SC_SRC_RAW && ch < p.Cout) ? p.dy.cst[(size_t)ch * SC_CST + f] : (f == 0 ? 1.f : 0.f));
   }
   for (int i = tid; i < CIN; i += 256) {
     float sc = 1.f, sh = 0.f;
     if (p.s0.cst && p.s0.mode != SC_SRC_RAW) { sc = p.s0.cst[(size_t)i * SC_CST]; sh = p.s0.cst[(size_t)i * SC_CST + 1]; }
-    s_cb[i * 4] = sc; s_cb[i * 4 + 1] = sh; s_cb[i * 4 + 2] = sc_act_lo(p.s0.act); s_cb[i * 4 + 3] = sc_act_hi(p.s0.act);
+    s_cb[i * 4] = sc * SC_H_SX; s_cb[i * 4 + 1] = sh * SC_H_SX;
+    s_cb[i * 4 + 2] = h_lo(sc_act_lo(p.s0.act), SC_H_SX); s_cb[i * 4 + 3] = h_hi(sc_act_hi(p.s0.act), SC_H_SX);
   }
 
   floatx4 acc[9][NCB];
@@ -1944,7 +1975,7 @@ __global__ __launch_bounds__(256, CIN == 32 ? 2 : 3) void k_wgrad_thin_h(const W
   const int tiles_x = (W + 31) >> 5, RS = (H + SR - 1) / SR, RSS = RS + 1;
   const long T = (long)p.N * tiles_x * RSS;
   const long t_begin = T * blockIdx.x / p.nsl, t_end = T * (blockIdx.x + 1) / p.nsl;
-  const float dlo = sc_act_lo(p.dy.act), dhi = sc_act_hi(p.dy.act);
+  const float dlo = sc_act_lo(p.dy.act) * (BNB ? 1.f : hsg), dhi = sc_act_hi(p.dy.act) * (BNB ? 1.f : hsg);
   const size_t HW = (size_t)H * W;
   const int up = p.s0.up, Ws = W >> up;
   const unsigned istr = (unsigned)((size_t)CIN * (H >> up) * Ws * 4);      // bytes per image of the input (host-checked < 2^32 / N)
@@ -1993,8 +2024,8 @@ __global__ __launch_bounds__(256, CIN == 32 ? 2 : 3) void k_wgrad_thin_h(const W
       v0 = sc_pro_affine(dg[k][0], c0.x, c0.y, dlo, dhi);
       v1 = sc_pro_affine(dg[k][1], c0.x, c0.y, dlo, dhi);
     }
-    v0 = ok ? v0 * hsg : 0.f;
-    v1 = ok ? v1 * hsg : 0.f;
+    v0 = ok ? v0 : 0.f;
+    v1 = ok ? v1 : 0.f;
     unsigned t0, t1;
     split2h(v0, v1, t0, t1);
     const int d = (co * DYP + row * 32 + col) >> 1;
@@ -2022,12 +2053,12 @@ __global__ __launch_bounds__(256, CIN == 32 ? 2 : 3) void k_wgrad_thin_h(const W
     const int y = R + rowi, x = x0 - 1 + 2 * pr;
     const bool oky = (y >= 0) && (y < H);
     const float4 c = *reinterpret_cast<const float4*>(&s_cb[cil * 4]);
-    float v0 = sc_pro_affine(xr[k][0], c.x, c.y, c.z, c.w);
-    float v1 = sc_pro_affine(xr[k][1], c.x, c.y, c.z, c.w);
-    v0 = (oky && x >= 0 && x < W) ? v0 * SC_H_SX : 0.f;
-    v1 = (oky && x + 1 < W) ? v1 * SC_H_SX : 0.f;
+    float v0 = sc_pro_affine_h(xr[k][0], c.x, c.y, c.z, c.w);
+    float v1 = sc_pro_affine_h(xr[k][1], c.x, c.y, c.z, c.w);
+    v0 = (oky && x >= 0 && x < W) ? v0 : 0.f;
+    v1 = (oky && x + 1 < W) ? v1 : 0.f;
     unsigned t0, t1;
-    split2h(v0, v1, t0, t1);
+    split2h<false>(v0, v1, t0, t1);
     int slot = sl0 + rowi;
     slot = slot >= RING ? slot - RING : slot;
     const int d = ((cil * XCP + slot * XP) >> 1) + pr;
