@@ -70,22 +70,38 @@ __device__ __forceinline__ float h_hi(float hi, float s) { return fminf(hi * s, 
 __device__ __forceinline__ float sc_pro_affine_h(float x, float sc, float sh, float lo, float hi) {
   return __builtin_amdgcn_fmed3f(fmaf(x, sc, sh), lo, hi);
 }
+// The remainder a - h0 is ONE v_fma_mix_f32 per value (f16 half of the packed first term x -1 + a, the same single rounding as
+// convert-back-and-subtract): a pair costs cvt_pk, 2 x fma_mix, cvt_pk instead of cvt_pk, 2 x cvt, (pk_)sub, cvt_pk.  The
+// compiler does not form it by itself (it rewrites fma(h, -1, a) into the subtraction), hence the inline assembly.
+#ifndef SC_SPLIT_MIX
+#define SC_SPLIT_MIX 1
+#endif
 template <bool CLAMP = true>
 __device__ __forceinline__ void split2h(float a, float b, unsigned& t0, unsigned& t1) {
   floatx2 v = {a, b};
   if constexpr (CLAMP) v = floatx2{__builtin_amdgcn_fmed3f(a, -SC_H_MAX, SC_H_MAX), __builtin_amdgcn_fmed3f(b, -SC_H_MAX, SC_H_MAX)};
   const halfx2 h0 = __builtin_convertvector(v, halfx2);
-  v -= __builtin_convertvector(h0, floatx2);
-  const halfx2 h1 = __builtin_convertvector(v, halfx2);
   t0 = __builtin_bit_cast(unsigned, h0);
+#if SC_SPLIT_MIX
+  float ra, rb;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(t0), "v"(v[0]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(t0), "v"(v[1]));
+  v = floatx2{ra, rb};
+#else
+  v -= __builtin_convertvector(h0, floatx2);
+#endif
+  const halfx2 h1 = __builtin_convertvector(v, halfx2);
   t1 = __builtin_bit_cast(unsigned, h1);
 }
-// The same split with scalar remainders, for the producer waves of k_conv3_ws: beside the MFMAs of the consumer wave on the
-// same SIMD a v_pk_add_f32 costs several issue slots (MI355X_MICROARCH.md: packed f32 VALU is "an anti-lever beside MFMAs";
-// measured -7 % there).  In the single-role kernels, whose staging phases are VALU-bound, the packed form is the faster one
-// (weight gradients +3-6 %, thin forward +2-5 % with the scalar form).
+// The split for the producer waves of k_conv3_ws.  Without the fma_mix form it keeps its remainders scalar: beside the MFMAs
+// of the consumer wave on the same SIMD a v_pk_add_f32 costs several issue slots (MI355X_MICROARCH.md: packed f32 VALU is "an
+// anti-lever beside MFMAs"; measured -7 % there), while in the single-role kernels, whose staging phases are VALU-bound, the
+// packed subtraction was the faster one (weight gradients +3-6 %, thin forward +2-5 % with the scalar form).
 template <bool CLAMP = true>
 __device__ __forceinline__ void split2h_scalar(float a, float b, unsigned& t0, unsigned& t1) {
+#if SC_SPLIT_MIX
+  split2h<CLAMP>(a, b, t0, t1);
+#else
   if constexpr (CLAMP) {
     a = __builtin_amdgcn_fmed3f(a, -SC_H_MAX, SC_H_MAX);
     b = __builtin_amdgcn_fmed3f(b, -SC_H_MAX, SC_H_MAX);
@@ -95,6 +111,7 @@ __device__ __forceinline__ void split2h_scalar(float a, float b, unsigned& t0, u
   const _Float16 la = (_Float16)ra, lb = (_Float16)rb;
   t0 = (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
   t1 = (unsigned)__builtin_bit_cast(unsigned short, la) | ((unsigned)__builtin_bit_cast(unsigned short, lb) << 16);
+#endif
 }
 template <bool HF>
 __device__ __forceinline__ floatx16 mfma_split(const bf16x8& a, const bf16x8& b, const floatx16& c) {
