@@ -1393,6 +1393,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
   // ---- epilogue: store, per-cout sums of the wave's 2 x 32 pixels
   const size_t HWs = (size_t)H * W;
   const bool want_stats = p.stats != nullptr;
+  // uniform image base + 32-bit lane BYTE offsets (Cout * H * W < 2^30, host-checked): the 64-bit form cost ~60 VALU per thread
+  float* const outn = p.out0 + (size_t)n * p.Cout * HWs;
+  const unsigned HWu = (unsigned)HWs;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int co = 4 * lg + r;
@@ -1403,7 +1406,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
       const bool ok = oy < H && ox < W && co < p.Cout;
       const float v = ok ? acc[pb][r] * hinv : 0.f;
       sv += v; sq = fmaf(v, v, sq);
-      if (ok) p.out0[((size_t)n * p.Cout + co) * HWs + (size_t)oy * W + ox] = v;
+      if (ok) *reinterpret_cast<float*>(reinterpret_cast<char*>(outn) + ((unsigned)co * HWu + (unsigned)(oy * W + ox)) * 4u) = v;
     }
     if (want_stats) {
 #pragma unroll
@@ -2543,6 +2546,7 @@ extern "C" int sc_conv3x3_thin16(const sc_conv_args* a, sc_stream stream) {
   SC_REQUIRE(s.up == 0 || (s.up == 1 && a->H % 2 == 0 && a->W % 2 == 0), "sc_conv3x3_thin16: upsampled source needs even H, W");
   SC_REQUIRE(s.mode == SC_SRC_RAW || s.cst != nullptr, "sc_conv3x3_thin16: source needs constants");
   SC_REQUIRE(s.mode != SC_SRC_NORM && (s.mode != SC_SRC_BNBWD || s.aux != nullptr), "sc_conv3x3_thin16: unsupported source");
+  SC_REQUIRE((size_t)a->Cout * a->H * a->W < ((size_t)1 << 30), "sc_conv3x3_thin16: one image of the output must stay below 2^30 elements");
   ConvXP p{};
   p.s0 = to_srcd(s); p.s1 = empty_srcd();
   p.wpk = reinterpret_cast<const uintx4*>(a->wpk); p.N = a->N; p.H = a->H; p.W = a->W; p.Cout = a->Cout;
