@@ -4,6 +4,7 @@
 //   head 3x3, Cin(16) -> 1, bias       -- segmentation_head.0
 // forward / backward-data / backward-weight, all with the "normalise on load" prologues of
 // sc_common.h.  Reference call site of the whole network: starcop/models/model_module.py:244-251.
+#include <type_traits>
 #include "sc_common.h"
 #ifndef SC_HEAD_RB
 #define SC_HEAD_RB 18     // patch rows (x2 loads) a wave keeps in flight while staging the head forward tile
@@ -399,16 +400,22 @@ __device__ __forceinline__ void dw_stage_rows2(float* s, const float* __restrict
   }
 }
 
-template <int S, int TW, int R>
+// V4 (widths divisible by 4, 16-byte aligned tensors): the interior columns of both patches are staged as float4 -- a quarter of
+// the load instructions, index arithmetic and bounds tests of the element-wise form (these kernels are issue-bound: ~1100 VALU
+// per wave for 8 outputs per thread, 40 % of them staging).  The interior then starts at LDS column 4 (CO = 3 columns of offset)
+// so that the stores are aligned ds_write_b128.
+template <int S, int TW, int R, bool V4>
 __global__ __launch_bounds__(256) void k_dw_bwd(const SrcD dy, const SrcD in, const float* __restrict__ w, float* __restrict__ dx,
                                                 double* __restrict__ dw_acc, double* __restrict__ in_sums, int NC, int C, int Hin,
                                                 int Win, int Hout, int Wout) {
   constexpr int TB = 256 / TW, TH = TB * R;
-  constexpr int PHD = (S == 1) ? TH + 2 : TH / 2 + 1, PWD = (S == 1) ? TW + 2 : TW / 2 + 1, PWDP = PWD | 1;
-  constexpr int PHX = TH + 2, PWX = TW + 2, PWXP = PWX | 1;
+  constexpr int CO = V4 ? 3 : 0, DCO = (S == 1) ? CO : 0;      // LDS column offsets of the input / dy patches
+  constexpr int PHD = (S == 1) ? TH + 2 : TH / 2 + 1, PWD = (S == 1) ? TW + 2 : TW / 2 + 1;
+  constexpr int PWDP = V4 ? ((PWD + DCO + 3) & ~3) : (PWD | 1);
+  constexpr int PHX = TH + 2, PWX = TW + 2, PWXP = V4 ? TW + 8 : (PWX | 1);
   static_assert(S == 1 || (TH % 2 == 0 && TW % 2 == 0), "stride-2 tiles must be even");
-  __shared__ float s_d[PHD * PWDP];
-  __shared__ float s_x[PHX * PWXP];      // RAW input values (zero outside the image)
+  __shared__ __attribute__((aligned(16))) float s_d[PHD * PWDP];
+  __shared__ __attribute__((aligned(16))) float s_x[PHX * PWXP];      // RAW input values (zero outside the image)
   __shared__ float s_tmp[44];
   // XCD-aware numbering: work-groups are handed to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  The tiles
   // of one (n, c) plane share halo rows / columns, so they are numbered 8 apart: a plane's tiles all run on ONE XCD, close in time.
@@ -441,24 +448,48 @@ __global__ __launch_bounds__(256) void k_dw_bwd(const SrcD dy, const SrcD in, co
   };
   constexpr int DCOLS = (S == 1) ? TW : PWD;                 // S == 1: interior columns row-wise (+ 2 halo columns); S == 2: whole patch
   constexpr int DOFF = (S == 1) ? 1 : 0;
-  constexpr int NID = (PHD * DCOLS + 255) / 256, NIX = (PHX * TW + 255) / 256;
-  float vg[NID], vy[NID], vx[NIX], hg = 0.f, hy = 0.f, hx = 0.f, hg2 = 0.f, hy2 = 0.f;
+  // V4: DC4 / XC4 float4 columns per patch row (S == 2: the dy patch is TW/2 aligned columns + one more, staged like a halo column)
+  constexpr int DC4 = ((S == 1) ? TW : TW / 2) / 4, XC4 = TW / 4;
+  constexpr int NID = V4 ? (PHD * DC4 + 255) / 256 : (PHD * DCOLS + 255) / 256, NIX = V4 ? (PHX * XC4 + 255) / 256 : (PHX * TW + 255) / 256;
+  typedef typename std::conditional<V4, float4, float>::type stage_t;
+  stage_t vg[NID], vy[NID], vx[NIX];
+  float hg = 0.f, hy = 0.f, hx = 0.f, hg2 = 0.f, hy2 = 0.f;
+  if constexpr (V4) {
 #pragma unroll
-  for (int i = 0; i < NID; ++i) {
-    const int e = threadIdx.x + i * 256;
-    const int r = e / DCOLS, cc = e % DCOLS + DOFF;
-    const int oy = oyb + r, ox = oxb + cc;
-    const bool ok = (r < PHD) && (oy >= 0) && (oy < Hout) && (ox >= 0) && (ox < Wout);
-    const int o = ok ? oy * Wout + ox : 0;
-    vg[i] = gbp[o]; vy[i] = ybp[o];
-  }
+    for (int i = 0; i < NID; ++i) {
+      const int e = threadIdx.x + i * 256;
+      const int r = e / DC4, c4 = e % DC4;
+      const int oy = oyb + r, ox = oxb + DOFF + 4 * c4;
+      const bool ok = (r < PHD) && (oy >= 0) && (oy < Hout) && (ox < Wout);
+      const int o = ok ? oy * Wout + ox : 0;
+      vg[i] = *reinterpret_cast<const float4*>(gbp + o); vy[i] = *reinterpret_cast<const float4*>(ybp + o);
+    }
 #pragma unroll
-  for (int i = 0; i < NIX; ++i) {
-    const int e = threadIdx.x + i * 256;
-    const int r = e / TW, cc = e % TW + 1;
-    const int iy = iy0 - 1 + r, ixx = ix0 - 1 + cc;
-    const bool ok = (r < PHX) && (iy >= 0) && (iy < Hin) && (ixx < Win);
-    vx[i] = xbp[ok ? iy * Win + ixx : 0];
+    for (int i = 0; i < NIX; ++i) {
+      const int e = threadIdx.x + i * 256;
+      const int r = e / XC4, c4 = e % XC4;
+      const int iy = iy0 - 1 + r, ixx = ix0 + 4 * c4;
+      const bool ok = (r < PHX) && (iy >= 0) && (iy < Hin) && (ixx < Win);
+      vx[i] = *reinterpret_cast<const float4*>(xbp + (ok ? iy * Win + ixx : 0));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NID; ++i) {
+      const int e = threadIdx.x + i * 256;
+      const int r = e / DCOLS, cc = e % DCOLS + DOFF;
+      const int oy = oyb + r, ox = oxb + cc;
+      const bool ok = (r < PHD) && (oy >= 0) && (oy < Hout) && (ox >= 0) && (ox < Wout);
+      const int o = ok ? oy * Wout + ox : 0;
+      vg[i] = gbp[o]; vy[i] = ybp[o];
+    }
+#pragma unroll
+    for (int i = 0; i < NIX; ++i) {
+      const int e = threadIdx.x + i * 256;
+      const int r = e / TW, cc = e % TW + 1;
+      const int iy = iy0 - 1 + r, ixx = ix0 - 1 + cc;
+      const bool ok = (r < PHX) && (iy >= 0) && (iy < Hin) && (ixx < Win);
+      vx[i] = xbp[ok ? iy * Win + ixx : 0];
+    }
   }
   static_assert(2 * PHX <= 256 && 2 * PHD <= 512, "halo columns: at most one (input) / two (dy) elements per thread");
   {
@@ -472,8 +503,13 @@ __global__ __launch_bounds__(256) void k_dw_bwd(const SrcD dy, const SrcD in, co
       const bool okd = (e < 2 * PHD) && (oy >= 0) && (oy < Hout) && (ox >= 0) && (ox < Wout);
       const int o = okd ? oy * Wout + ox : 0;
       hg = gbp[o]; hy = ybp[o];
-      (void)hg2; (void)hy2;
+    } else if (V4) {                     // S == 2: patch column TW/2 (row e)
+      const int oy = oyb + e, ox = oxb + TW / 2;
+      const bool okd = (e < PHD) && (oy >= 0) && (oy < Hout) && (ox < Wout);
+      const int o = okd ? oy * Wout + ox : 0;
+      hg = gbp[o]; hy = ybp[o];
     }
+    (void)hg2; (void)hy2;
   }
   // ---- all loads are in flight: the channel's constants, then consume
   __builtin_amdgcn_sched_barrier(0);
@@ -482,30 +518,56 @@ __global__ __launch_bounds__(256) void k_dw_bwd(const SrcD dy, const SrcD in, co
     const float4 ci = *reinterpret_cast<const float4*>(in.cst + (size_t)c * SC_CST);
     xs = ci.x; xh = ci.y; xmean = ci.z; xinv = ci.w;
   }
+  if constexpr (V4) {
 #pragma unroll
-  for (int i = 0; i < NID; ++i) {
-    const int e = threadIdx.x + i * 256;
-    const int r = e / DCOLS, cc = e % DCOLS + DOFF;
-    const int oy = oyb + r, ox = oxb + cc;
-    const bool ok = (oy >= 0) && (oy < Hout) && (ox >= 0) && (ox < Wout);
-    if (r < PHD) s_d[r * PWDP + cc] = ok ? dpro(vg[i], vy[i]) : 0.f;
-  }
+    for (int i = 0; i < NID; ++i) {
+      const int e = threadIdx.x + i * 256;
+      const int r = e / DC4, c4 = e % DC4;
+      const int oy = oyb + r, ox = oxb + DOFF + 4 * c4;
+      const bool ok = (oy >= 0) && (oy < Hout) && (ox < Wout);
+      float4 t;
+      t.x = ok ? dpro(vg[i].x, vy[i].x) : 0.f; t.y = ok ? dpro(vg[i].y, vy[i].y) : 0.f;
+      t.z = ok ? dpro(vg[i].z, vy[i].z) : 0.f; t.w = ok ? dpro(vg[i].w, vy[i].w) : 0.f;
+      if (r < PHD) *reinterpret_cast<float4*>(&s_d[r * PWDP + DCO + DOFF + 4 * c4]) = t;
+    }
 #pragma unroll
-  for (int i = 0; i < NIX; ++i) {
-    const int e = threadIdx.x + i * 256;
-    const int r = e / TW, cc = e % TW + 1;
-    const int iy = iy0 - 1 + r, ixx = ix0 - 1 + cc;
-    const bool ok = (iy >= 0) && (iy < Hin) && (ixx < Win);
-    if (r < PHX) s_x[r * PWXP + cc] = ok ? vx[i] : 0.f;
+    for (int i = 0; i < NIX; ++i) {
+      const int e = threadIdx.x + i * 256;
+      const int r = e / XC4, c4 = e % XC4;
+      const int iy = iy0 - 1 + r, ixx = ix0 + 4 * c4;
+      const bool ok = (iy >= 0) && (iy < Hin) && (ixx < Win);
+      if (r < PHX) *reinterpret_cast<float4*>(&s_x[r * PWXP + CO + 1 + 4 * c4]) = ok ? vx[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NID; ++i) {
+      const int e = threadIdx.x + i * 256;
+      const int r = e / DCOLS, cc = e % DCOLS + DOFF;
+      const int oy = oyb + r, ox = oxb + cc;
+      const bool ok = (oy >= 0) && (oy < Hout) && (ox >= 0) && (ox < Wout);
+      if (r < PHD) s_d[r * PWDP + cc] = ok ? dpro(vg[i], vy[i]) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NIX; ++i) {
+      const int e = threadIdx.x + i * 256;
+      const int r = e / TW, cc = e % TW + 1;
+      const int iy = iy0 - 1 + r, ixx = ix0 - 1 + cc;
+      const bool ok = (iy >= 0) && (iy < Hin) && (ixx < Win);
+      if (r < PHX) s_x[r * PWXP + cc] = ok ? vx[i] : 0.f;
+    }
   }
   {
     const int e = threadIdx.x;
     const int r = e >> 1, cc = (e & 1) ? TW + 1 : 0;
     const int iy = iy0 - 1 + r, ixx = ix0 - 1 + cc;
-    if (e < 2 * PHX) s_x[r * PWXP + cc] = ((iy >= 0) && (iy < Hin) && (ixx >= 0) && (ixx < Win)) ? hx : 0.f;
+    if (e < 2 * PHX) s_x[r * PWXP + CO + cc] = ((iy >= 0) && (iy < Hin) && (ixx >= 0) && (ixx < Win)) ? hx : 0.f;
     if (S == 1 && e < 2 * PHD) {
       const int oy = oyb + r, ox = oxb + cc;
-      s_d[r * PWDP + cc] = ((oy >= 0) && (oy < Hout) && (ox >= 0) && (ox < Wout)) ? dpro(hg, hy) : 0.f;
+      s_d[r * PWDP + DCO + cc] = ((oy >= 0) && (oy < Hout) && (ox >= 0) && (ox < Wout)) ? dpro(hg, hy) : 0.f;
+    }
+    if (S == 2 && V4 && e < PHD) {
+      const int oy = oyb + e, ox = oxb + TW / 2;
+      s_d[e * PWDP + TW / 2] = ((oy >= 0) && (oy < Hout) && (ox < Wout)) ? dpro(hg, hy) : 0.f;
     }
   }
   float wk[9];
@@ -530,9 +592,9 @@ __global__ __launch_bounds__(256) void k_dw_bwd(const SrcD dy, const SrcD in, co
       const bool rok = (iy0 - 1 + row0 + j >= 0) && (iy0 - 1 + row0 + j < Hin);
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        xr[j][q] = s_x[(row0 + j) * PWXP + tx + q];
+        xr[j][q] = s_x[(row0 + j) * PWXP + CO + tx + q];
         xa[j][q] = xact(xr[j][q], rok && cok[q]);
-        dd[j][q] = s_d[(row0 + j) * PWDP + tx + q];
+        dd[j][q] = s_d[(row0 + j) * PWDP + DCO + tx + q];
       }
     }
 #pragma unroll
@@ -541,9 +603,9 @@ __global__ __launch_bounds__(256) void k_dw_bwd(const SrcD dy, const SrcD in, co
       const bool rok = iy + 1 < Hin;               // patch row (row + 2) is image row iy + 1 >= 0
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        xr[2][q] = s_x[(row + 2) * PWXP + tx + q];
+        xr[2][q] = s_x[(row + 2) * PWXP + CO + tx + q];
         xa[2][q] = xact(xr[2][q], rok && cok[q]);
-        dd[2][q] = s_d[(row + 2) * PWDP + tx + q];
+        dd[2][q] = s_d[(row + 2) * PWDP + DCO + tx + q];
       }
       float acc = 0.f;
 #pragma unroll
@@ -590,7 +652,7 @@ __global__ __launch_bounds__(256) void k_dw_bwd(const SrcD dy, const SrcD in, co
       }
       if (iy < Hin && ix < Win) {
         db[(size_t)iy * Win + ix] = acc;
-        const float yraw = s_x[(row + 1) * PWXP + tx + 1];
+        const float yraw = s_x[(row + 1) * PWXP + CO + tx + 1];
         const float yh = fmaf(yraw, xs, xh);
         const float gb = (yh > xlo && yh < xhi) ? acc : 0.f;
         red[0] += gb;
@@ -609,7 +671,7 @@ __global__ __launch_bounds__(256) void k_dw_bwd(const SrcD dy, const SrcD in, co
         for (int kw = 0; kw < 3; ++kw) {
           const int xx = ix0 - 1 + 2 * ocol + kw;
           const bool ok = yy >= 0 && yy < Hin && xx >= 0 && xx < Win;
-          prod[kh * 3 + kw] = fmaf(dyv, xact(s_x[(2 * orow + kh) * PWXP + 2 * ocol + kw], ok), prod[kh * 3 + kw]);
+          prod[kh * 3 + kw] = fmaf(dyv, xact(s_x[(2 * orow + kh) * PWXP + CO + 2 * ocol + kw], ok), prod[kh * 3 + kw]);
         }
       }
     }
@@ -621,6 +683,102 @@ __global__ __launch_bounds__(256) void k_dw_bwd(const SrcD dy, const SrcD in, co
   block_sum<11>(all, s_tmp);
   if (threadIdx.x < 9) atomicAdd(&dw_acc[c * 9 + threadIdx.x], (double)all[threadIdx.x]);
   if (in_sums && threadIdx.x < 2) in_sums[(((size_t)n * tiles + tile) * C + c) * 2 + threadIdx.x] = (double)all[9 + threadIdx.x];
+}
+
+// The same fused backward for 16x16 planes at stride 1 (features.15-17 at 512^2 input: 960 channels x 16 images = 15360 planes).
+// One plane is one tile there, and a 256-thread work-group per 256 pixels spends its time on launch, barrier and an 11-value block
+// reduction (65 us per layer = 1 TB/s, slower than the three separate kernels).  Here a WAVE owns a plane: one float4 load per
+// lane and tensor, a wave-private LDS patch (zero border), four outputs per lane, DPP wave sums, atomics from lane 0.
+__global__ __launch_bounds__(256) void k_dw_bwd_p16(const SrcD dy, const SrcD in, const float* __restrict__ w, float* __restrict__ dx,
+                                                    double* __restrict__ dw_acc, double* __restrict__ in_sums, int C) {
+  constexpr int P = 24, PR = 18;                 // patch pitch (interior at columns 4..19, halo columns 3 and 20), patch rows
+  __shared__ __attribute__((aligned(16))) float s_d[4][PR * P];
+  __shared__ __attribute__((aligned(16))) float s_x[4][PR * P];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int plane = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);      // (the launcher guarantees N * C % 4 == 0)
+  const int n = plane / C, c = plane - n * C;
+  const bool bnb = dy.mode == SC_SRC_BNBWD;
+  const size_t base = (size_t)plane * 256;
+  const float4 g4 = *reinterpret_cast<const float4*>(dy.x + base + 4 * lane);
+  const float4 y4 = bnb ? *reinterpret_cast<const float4*>(dy.aux + base + 4 * lane) : g4;
+  const float4 x4 = *reinterpret_cast<const float4*>(in.x + base + 4 * lane);
+  float4 c0 = make_float4(1.f, 0.f, 0.f, 0.f); float c4 = 0.f;
+  float xs = 1.f, xh = 0.f, xmean = 0.f, xinv = 1.f;
+  if (dy.mode != SC_SRC_RAW) { c0 = *reinterpret_cast<const float4*>(dy.cst + (size_t)c * SC_CST); c4 = dy.cst[(size_t)c * SC_CST + 4]; }
+  if (in.mode != SC_SRC_RAW) {
+    const float4 ci = *reinterpret_cast<const float4*>(in.cst + (size_t)c * SC_CST);
+    xs = ci.x; xh = ci.y; xmean = ci.z; xinv = ci.w;
+  }
+  float wk[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wk[t] = w[c * 9 + t];
+  const float dlo = sc_act_lo(dy.act), dhi = sc_act_hi(dy.act), xlo = sc_act_lo(in.act), xhi = sc_act_hi(in.act);
+  auto dpro = [&](float g, float yv) {
+    return bnb ? sc_pro_bnbwd(g, yv, c0.x, c0.y, c0.z, c0.w, c4, dlo, dhi) : sc_pro_affine(g, c0.x, c0.y, dlo, dhi);
+  };
+  float* sd = s_d[wave];
+  float* sx = s_x[wave];
+  // zero the patches (the border is what matters), then the interior: LDS operations of one wave execute in order
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = lane; i < PR * P / 4; i += 64) { reinterpret_cast<float4*>(sd)[i] = z4; reinterpret_cast<float4*>(sx)[i] = z4; }
+  const int r = lane >> 2, q4 = lane & 3;        // this lane's image row and its group of four columns
+  {
+    float4 t;
+    t.x = dpro(g4.x, y4.x); t.y = dpro(g4.y, y4.y); t.z = dpro(g4.z, y4.z); t.w = dpro(g4.w, y4.w);
+    *reinterpret_cast<float4*>(&sd[(r + 1) * P + 4 + 4 * q4]) = t;
+    *reinterpret_cast<float4*>(&sx[(r + 1) * P + 4 + 4 * q4]) = x4;
+  }
+  __syncthreads();
+  // rows r-1 .. r+1 (patch rows r .. r+2), image columns 4 q4 - 1 .. 4 q4 + 4 (patch columns 4 q4 + 3 .. 4 q4 + 8)
+  float D[3][6], XA[3][6];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float* dr = &sd[(r + j) * P + 4 * q4 + 3];
+    const float* xr = &sx[(r + j) * P + 4 * q4 + 3];
+    const float4 dm = *reinterpret_cast<const float4*>(dr + 1), xm = *reinterpret_cast<const float4*>(xr + 1);
+    D[j][0] = dr[0]; D[j][1] = dm.x; D[j][2] = dm.y; D[j][3] = dm.z; D[j][4] = dm.w; D[j][5] = dr[5];
+    const float xv[6] = {xr[0], xm.x, xm.y, xm.z, xm.w, xr[5]};
+    const bool rok = (r - 1 + j >= 0) && (r - 1 + j < 16);
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+      const int col = 4 * q4 - 1 + m;
+      // zero padding applies to the ACTIVATED input (see k_dw_bwd)
+      XA[j][m] = (rok && col >= 0 && col < 16) ? sc_pro_affine(xv[m], xs, xh, xlo, xhi) : 0.f;
+    }
+  }
+  float prod[9], red[2] = {0.f, 0.f}, o[4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) prod[t] = 0.f;
+  const float xraw[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float acc = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kh * 3 + kw], D[2 - kh][i + 2 - kw], acc);
+    const float dyv = D[1][i + 1];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) prod[kh * 3 + kw] = fmaf(dyv, XA[kh][i + kw], prod[kh * 3 + kw]);
+    o[i] = acc;
+    const float yh = fmaf(xraw[i], xs, xh);
+    const float gb = (yh > xlo && yh < xhi) ? acc : 0.f;
+    red[0] += gb;
+    red[1] = fmaf(gb, (xraw[i] - xmean) * xinv, red[1]);
+  }
+  *reinterpret_cast<float4*>(dx + base + 4 * lane) = make_float4(o[0], o[1], o[2], o[3]);
+  float all[11];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) all[t] = wave_sum(prod[t]);
+  all[9] = wave_sum(red[0]); all[10] = wave_sum(red[1]);
+  if (lane == 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) atomicAdd(&dw_acc[c * 9 + t], (double)all[t]);
+    if (in_sums) { in_sums[((size_t)n * C + c) * 2] = (double)all[9]; in_sums[((size_t)n * C + c) * 2 + 1] = (double)all[10]; }
+  }
 }
 
 // ---------------------------------------------------------------- stem (3x3 s2, Cin<=8 -> 32)
@@ -1033,6 +1191,17 @@ int head_blocks(int N, int H, int W) {
     else hipLaunchKernelGGL((KERNEL<2, 16, 1>), GRID, dim3(256), 0, st, __VA_ARGS__);                              \
   } while (0)
 
+#define SC_DW_DISPATCH4(KERNEL, V4_, W_, GRID, ...)                                                                     \
+  do {                                                                                                                  \
+    const int tw_ = sc_dw_tile_w(W_);                                                                                   \
+    if (stride == 1 && tw_ == 64) hipLaunchKernelGGL((KERNEL<1, 64, 8, V4_>), GRID, dim3(256), 0, st, __VA_ARGS__);     \
+    else if (stride == 1 && tw_ == 32) hipLaunchKernelGGL((KERNEL<1, 32, 4, V4_>), GRID, dim3(256), 0, st, __VA_ARGS__);\
+    else if (stride == 1) hipLaunchKernelGGL((KERNEL<1, 16, 1, V4_>), GRID, dim3(256), 0, st, __VA_ARGS__);             \
+    else if (tw_ == 64) hipLaunchKernelGGL((KERNEL<2, 64, 8, V4_>), GRID, dim3(256), 0, st, __VA_ARGS__);               \
+    else if (tw_ == 32) hipLaunchKernelGGL((KERNEL<2, 32, 4, V4_>), GRID, dim3(256), 0, st, __VA_ARGS__);               \
+    else hipLaunchKernelGGL((KERNEL<2, 16, 1, V4_>), GRID, dim3(256), 0, st, __VA_ARGS__);                              \
+  } while (0)
+
 static inline long dw_tiles(int H, int W) {
   const int tw = sc_dw_tile_w(W), th = sc_dw_tile_h(W);
   return (long)((W + tw - 1) / tw) * ((H + th - 1) / th);
@@ -1097,7 +1266,18 @@ extern "C" int sc_dwconv3x3_bwd_fused(const sc_src* dy, const sc_src* in, const 
   const long planes8 = ((long)N * C + 7) / 8 * 8;
   SC_REQUIRE(planes8 * dw_tiles(Hin, Win) < (1L << 31), "sc_dwconv3x3_bwd_fused: grid too large");
   dim3 grid((unsigned)(planes8 * dw_tiles(Hin, Win)));
-  SC_DW_DISPATCH(k_dw_bwd, Win, grid, to_srcd(*dy), to_srcd(*in), w, dx, dw_acc, in_sums, N * C, C, Hin, Win, Hout, Wout);
+  // float4 staging where every patch row is 16-byte aligned (SC_DW_V4=0 forces the element-wise form)
+  static const bool v4_env = [] { const char* e = getenv("STARCOP_DW_V4"); return !e || atoi(e) != 0; }();
+  const bool v4 = v4_env && Win % 4 == 0 && Wout % 4 == 0 &&
+                  ((((uintptr_t)dy->x) | ((uintptr_t)dy->aux) | ((uintptr_t)in->x)) & 15) == 0;
+  static const bool p16_env = [] { const char* e = getenv("STARCOP_DW_P16"); return !e || atoi(e) != 0; }();
+  if (p16_env && v4 && stride == 1 && Hin == 16 && Win == 16 && ((long)N * C) % 4 == 0) {      // a wave per 16x16 plane
+    hipLaunchKernelGGL(k_dw_bwd_p16, dim3((unsigned)((long)N * C / 4)), dim3(256), 0, st, to_srcd(*dy), to_srcd(*in), w, dx, dw_acc, in_sums, C);
+    SC_LAUNCH_OK("sc_dwconv3x3_bwd_fused");
+    return SC_OK;
+  }
+  if (v4) SC_DW_DISPATCH4(k_dw_bwd, true, Win, grid, to_srcd(*dy), to_srcd(*in), w, dx, dw_acc, in_sums, N * C, C, Hin, Win, Hout, Wout);
+  else SC_DW_DISPATCH4(k_dw_bwd, false, Win, grid, to_srcd(*dy), to_srcd(*in), w, dx, dw_acc, in_sums, N * C, C, Hin, Win, Hout, Wout);
   SC_LAUNCH_OK("sc_dwconv3x3_bwd_fused");
   return SC_OK;
 }

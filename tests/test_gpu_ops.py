@@ -655,7 +655,7 @@ def test_conv_thin16_two_fp16_terms(hip, cin, cout, H, W, up, gscale):
 
 
 @pytest.mark.parametrize("stride,C_,H,W", [(1, 8, 64, 96), (2, 8, 64, 96), (1, 24, 32, 32), (2, 24, 32, 64), (1, 40, 16, 16), (2, 40, 16, 16),
-                                           (1, 5, 70, 50), (2, 6, 36, 20)])
+                                           (1, 5, 70, 50), (2, 6, 36, 20), (1, 6, 16, 16), (1, 5, 16, 16)])
 def test_dw_bwd_fused(hip, stride, C_, H, W):
     """depthwise backward in one pass (sc_dwconv3x3_bwd_fused): dx, dW and the BatchNorm-backward sums of the input, against
     autograd on the same graph  x -> BN affine + ReLU6 -> depthwise conv -> y ; dy = BNBWD(g, y)"""
