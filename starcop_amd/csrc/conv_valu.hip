@@ -781,6 +781,55 @@ __global__ __launch_bounds__(256) void k_dw_bwd_p16(const SrcD dy, const SrcD in
   }
 }
 
+// forward for 16x16 planes at stride 1, a wave per plane (see k_dw_bwd_p16)
+__global__ __launch_bounds__(256) void k_dw_fwd_p16(const SrcD in, const float* __restrict__ w, float* __restrict__ out, int C,
+                                                    float* __restrict__ stats) {
+  constexpr int P = 24, PR = 18;
+  __shared__ __attribute__((aligned(16))) float s_x[4][PR * P];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int plane = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  const int n = plane / C, c = plane - n * C;
+  const size_t base = (size_t)plane * 256;
+  const float4 x4 = *reinterpret_cast<const float4*>(in.x + base + 4 * lane);
+  float sc = 1.f, sh = 0.f;
+  if (in.mode != SC_SRC_RAW) { sc = in.cst[(size_t)c * SC_CST]; sh = in.cst[(size_t)c * SC_CST + 1]; }
+  float wk[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wk[t] = w[c * 9 + t];
+  const float lo = sc_act_lo(in.act), hi = sc_act_hi(in.act);
+  float* sx = s_x[wave];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = lane; i < PR * P / 4; i += 64) reinterpret_cast<float4*>(sx)[i] = z4;
+  const int r = lane >> 2, q4 = lane & 3;
+  *reinterpret_cast<float4*>(&sx[(r + 1) * P + 4 + 4 * q4]) =
+      make_float4(sc_pro_affine(x4.x, sc, sh, lo, hi), sc_pro_affine(x4.y, sc, sh, lo, hi), sc_pro_affine(x4.z, sc, sh, lo, hi),
+                  sc_pro_affine(x4.w, sc, sh, lo, hi));
+  __syncthreads();
+  float A[3][6];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float* xr = &sx[(r + j) * P + 4 * q4 + 3];
+    const float4 xm = *reinterpret_cast<const float4*>(xr + 1);
+    A[j][0] = xr[0]; A[j][1] = xm.x; A[j][2] = xm.y; A[j][3] = xm.z; A[j][4] = xm.w; A[j][5] = xr[5];
+  }
+  float o[4], sv = 0.f, sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float acc = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kh * 3 + kw], A[kh][i + kw], acc);
+    o[i] = acc; sv += acc; sq = fmaf(acc, acc, sq);
+  }
+  *reinterpret_cast<float4*>(out + base + 4 * lane) = make_float4(o[0], o[1], o[2], o[3]);
+  if (stats) {
+    sv = wave_sum(sv); sq = wave_sum(sq);
+    if (lane == 0) { stats[((size_t)n * C + c) * 2] = sv; stats[((size_t)n * C + c) * 2 + 1] = sq; }
+  }
+}
+
 // ---------------------------------------------------------------- stem (3x3 s2, Cin<=8 -> 32)
 constexpr int STEM_CO = 32;
 constexpr int STEM_MAXCI = 8;
@@ -1217,6 +1266,12 @@ extern "C" int sc_dwconv3x3_fwd(const sc_src* in, const float* w, float* out, in
   const long planes8 = ((long)N * C + 7) / 8 * 8;
   SC_REQUIRE(planes8 * dw_tiles(Hout, Wout) < (1L << 31), "sc_dwconv3x3_fwd: grid too large");
   dim3 grid((unsigned)(planes8 * dw_tiles(Hout, Wout)));
+  static const bool p16_env = [] { const char* e = getenv("STARCOP_DW_P16"); return !e || atoi(e) != 0; }();
+  if (p16_env && stride == 1 && Hin == 16 && Win == 16 && ((long)N * C) % 4 == 0 && (((uintptr_t)in->x | (uintptr_t)out) & 15) == 0) {
+    hipLaunchKernelGGL(k_dw_fwd_p16, dim3((unsigned)((long)N * C / 4)), dim3(256), 0, st, to_srcd(*in), w, out, C, stats);
+    SC_LAUNCH_OK("sc_dwconv3x3_fwd");
+    return SC_OK;
+  }
   SC_DW_DISPATCH(k_dw_fwd, Wout, grid, to_srcd(*in), w, out, N * C, C, Hin, Win, Hout, Wout, stats);
   SC_LAUNCH_OK("sc_dwconv3x3_fwd");
   return SC_OK;
@@ -1271,7 +1326,7 @@ extern "C" int sc_dwconv3x3_bwd_fused(const sc_src* dy, const sc_src* in, const 
   const bool v4 = v4_env && Win % 4 == 0 && Wout % 4 == 0 &&
                   ((((uintptr_t)dy->x) | ((uintptr_t)dy->aux) | ((uintptr_t)in->x)) & 15) == 0;
   static const bool p16_env = [] { const char* e = getenv("STARCOP_DW_P16"); return !e || atoi(e) != 0; }();
-  if (p16_env && v4 && stride == 1 && Hin == 16 && Win == 16 && ((long)N * C) % 4 == 0) {      // a wave per 16x16 plane
+  if (p16_env && v4 && stride == 1 && Hin == 16 && Win == 16 && ((long)N * C) % 4 == 0 && ((uintptr_t)dx & 15) == 0) {      // a wave per 16x16 plane
     hipLaunchKernelGGL(k_dw_bwd_p16, dim3((unsigned)((long)N * C / 4)), dim3(256), 0, st, to_srcd(*dy), to_srcd(*in), w, dx, dw_acc, in_sums, C);
     SC_LAUNCH_OK("sc_dwconv3x3_bwd_fused");
     return SC_OK;

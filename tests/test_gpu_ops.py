@@ -405,7 +405,8 @@ def test_conv_bx3_wgrad(hip, split_mode, cin, cout, H, W, two):
     assert e < 1e-5 and e < 3 * e32 + 2e-7, (e, e32)
 
 
-@pytest.mark.parametrize("C_,H,W,stride", [(32, 32, 32, 1), (24, 20, 28, 2), (96, 16, 16, 2), (40, 7, 9, 1), (960, 2, 3, 1), (576, 4, 6, 2)])
+@pytest.mark.parametrize("C_,H,W,stride", [(32, 32, 32, 1), (24, 20, 28, 2), (96, 16, 16, 2), (40, 7, 9, 1), (960, 2, 3, 1), (576, 4, 6, 2),
+                                           (46, 16, 16, 1), (7, 16, 16, 1)])       # 16x16 stride 1: the wave-per-plane kernel (N*C % 4 == 0) and its fallback
 def test_depthwise(hip, C_, H, W, stride):
     N = 2
     x, w = rnd(N, C_, H, W, seed=1), rnd(C_, 1, 3, 3, seed=2, scale=0.3)
