@@ -634,44 +634,52 @@ __global__ __launch_bounds__(256) void k_dw_bwd(const SrcD dy, const SrcD in, co
       }
     }
   } else {
+    // stride 2: a thread owns 2 x 2 blocks of the input tile -- block (a, b) = input rows 2a, 2a+1 / columns 2b, 2b+1 = output pixel
+    // (a, b).  The taps that reach each of its four pixels are fixed by the pixel's parity (1, 2, 2 and 4 of them), so nothing
+    // diverges: 9 FMAs for the four dx values, 9 for the filter gradient of output (a, b), one 3 x 3 window of the input and a 2 x 2
+    // window of dy from LDS.  (Before: one pixel per thread and row with `if (parity) continue` inside the tap loops -- the column
+    // parity alternates from lane to lane, so every wave walked all nine taps with half its lanes masked, ~110 VALU per pixel.)
+    // The FMA order per pixel is the one of k_dw_dgrad (kh outer, kw inner), so dx stays bit-identical to it.
+    constexpr int BW = TW / 2, NB = (TH / 2) * BW;
+    for (int blk = threadIdx.x; blk < NB; blk += 256) {
+      const int a = blk / BW, b = blk - a * BW;
+      const int oy = iy0 / 2 + a, ox = ix0 / 2 + b;
+      const float d00 = s_d[a * PWDP + b], d01 = s_d[a * PWDP + b + 1];
+      const float d10 = s_d[(a + 1) * PWDP + b], d11 = s_d[(a + 1) * PWDP + b + 1];
+      float xr[3][3];
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-      const int row = row0 + k, iy = iy0 + row;
-      float acc = 0.f;
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) xr[kh][kw] = s_x[(2 * a + kh) * PWXP + CO + 2 * b + kw];
+      const float dyv = (oy < Hout && ox < Wout) ? d00 : 0.f;
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
-        const int t = iy + 1 - kh;                 // = 2 * oy
-        if ((t & 1) || t < 0) continue;
-        const int r = t / 2 - oyb;
+        const int yy = iy0 - 1 + 2 * a + kh;
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-          const int u = ix + 1 - kw;
-          if ((u & 1) || u < 0) continue;
-          acc = fmaf(wk[kh * 3 + kw], s_d[r * PWDP + u / 2 - oxb], acc);
+          const int xx = ix0 - 1 + 2 * b + kw;
+          const bool ok = yy >= 0 && yy < Hin && xx >= 0 && xx < Win;
+          prod[kh * 3 + kw] = fmaf(dyv, xact(xr[kh][kw], ok), prod[kh * 3 + kw]);
         }
       }
-      if (iy < Hin && ix < Win) {
-        db[(size_t)iy * Win + ix] = acc;
-        const float yraw = s_x[(row + 1) * PWXP + CO + tx + 1];
-        const float yh = fmaf(yraw, xs, xh);
-        const float gb = (yh > xlo && yh < xhi) ? acc : 0.f;
-        red[0] += gb;
-        red[1] = fmaf(gb, (yraw - xmean) * xinv, red[1]);
-      }
-    }
-    constexpr int OW = TW / 2, NO = (TH / 2) * OW;
-    for (int o = threadIdx.x; o < NO; o += 256) {
-      const int orow = o / OW, ocol = o - orow * OW;
-      const int oy = iy0 / 2 + orow, ox = ix0 / 2 + ocol;
-      const float dyv = (oy < Hout && ox < Wout) ? s_d[orow * PWDP + ocol] : 0.f;
+      float o[2][2];
+      o[0][0] = fmaf(wk[4], d00, 0.f);
+      o[0][1] = fmaf(wk[5], d00, fmaf(wk[3], d01, 0.f));
+      o[1][0] = fmaf(wk[7], d00, fmaf(wk[1], d10, 0.f));
+      o[1][1] = fmaf(wk[8], d00, fmaf(wk[6], d01, fmaf(wk[2], d10, fmaf(wk[0], d11, 0.f))));
+      const int iy = iy0 + 2 * a, ixx = ix0 + 2 * b;
+      if (iy < Hin && ixx < Win) {                 // (even sizes: a block is inside the image or outside as a whole)
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int yy = iy0 - 1 + 2 * orow + kh;
+        for (int i = 0; i < 2; ++i) {
+          *reinterpret_cast<float2*>(db + (size_t)(iy + i) * Win + ixx) = make_float2(o[i][0], o[i][1]);
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int xx = ix0 - 1 + 2 * ocol + kw;
-          const bool ok = yy >= 0 && yy < Hin && xx >= 0 && xx < Win;
-          prod[kh * 3 + kw] = fmaf(dyv, xact(s_x[(2 * orow + kh) * PWXP + CO + 2 * ocol + kw], ok), prod[kh * 3 + kw]);
+          for (int j = 0; j < 2; ++j) {
+            const float yraw = xr[i + 1][j + 1];
+            const float yh = fmaf(yraw, xs, xh);
+            const float gb = (yh > xlo && yh < xhi) ? o[i][j] : 0.f;
+            red[0] += gb;
+            red[1] = fmaf(gb, (yraw - xmean) * xinv, red[1]);
+          }
         }
       }
     }
