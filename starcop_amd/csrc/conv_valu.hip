@@ -103,12 +103,14 @@ __device__ __forceinline__ void dw_stage2(float* s, const float* __restrict__ gb
   }
 }
 
-template <int S, int TW, int R>
+// V4: float4 staging of the TW * S aligned interior columns (see k_dw_bwd), interior at LDS column 4
+template <int S, int TW, int R, bool V4>
 __global__ __launch_bounds__(256) void k_dw_fwd(const SrcD in, const float* __restrict__ w, float* __restrict__ out,
                                                 int NC, int C, int Hin, int Win, int Hout, int Wout, float* stats) {
   constexpr int TB = 256 / TW, TH = TB * R;
-  constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PWP = PW | 1;
-  __shared__ float s_x[PH * PWP];
+  constexpr int CO = V4 ? 3 : 0, IC = TW * S;
+  constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PWP = V4 ? IC + 8 : (PW | 1);
+  __shared__ __attribute__((aligned(16))) float s_x[PH * PWP];
   __shared__ float s_tmp[8];
   // XCD-aware numbering (see k_dw_bwd): the tiles of one (n, c) plane are 8 apart in the linear work-group id -> one XCD, one L2
   const int tiles_x = (Wout + TW - 1) / TW;
@@ -125,6 +127,49 @@ __global__ __launch_bounds__(256) void k_dw_fwd(const SrcD in, const float* __re
   constexpr int NE = PH * PW, NIT = (NE + 255) / 256, LB = (S == 1) ? NIT : SC_DW_LB;   // measured: stride-2 patches (33 loads per thread) are faster in batches of 8
   const int y0 = ty0 * S - 1, x0 = tx0 * S - 1;
   float wk[9];
+  if constexpr (V4) {
+    constexpr int IC4 = IC / 4, NI4 = (PH * IC4 + 255) / 256, NHC = (S == 1) ? 2 : 1;     // halo columns: left (+ right at stride 1)
+    static_assert(NHC * PH <= 256, "one halo element per thread");
+    float4 v[NI4];
+#pragma unroll
+    for (int i = 0; i < NI4; ++i) {
+      const int e = threadIdx.x + i * 256;
+      const int r = e / IC4, c4 = e % IC4;
+      const int iy = y0 + r, ix = x0 + 1 + 4 * c4;
+      const bool ok = (r < PH) && (iy >= 0) && (iy < Hin) && (ix < Win);
+      v[i] = *reinterpret_cast<const float4*>(xb + (ok ? iy * Win + ix : 0));
+    }
+    float hv;
+    {
+      const int e = threadIdx.x;
+      const int r = (NHC == 2) ? e >> 1 : e, cc = (NHC == 2 && (e & 1)) ? IC + 1 : 0;
+      const int iy = y0 + r, ix = x0 + cc;
+      const bool ok = (e < NHC * PH) && (iy >= 0) && (iy < Hin) && (ix >= 0) && (ix < Win);
+      hv = xb[ok ? iy * Win + ix : 0];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (in.mode != SC_SRC_RAW) { sc = in.cst[(size_t)c * SC_CST]; sh = in.cst[(size_t)c * SC_CST + 1]; }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wk[t] = w[c * 9 + t];
+#pragma unroll
+    for (int i = 0; i < NI4; ++i) {
+      const int e = threadIdx.x + i * 256;
+      const int r = e / IC4, c4 = e % IC4;
+      const int iy = y0 + r, ix = x0 + 1 + 4 * c4;
+      const bool ok = (iy >= 0) && (iy < Hin) && (ix < Win);
+      float4 t;
+      t.x = ok ? sc_pro_affine(v[i].x, sc, sh, lo, hi) : 0.f; t.y = ok ? sc_pro_affine(v[i].y, sc, sh, lo, hi) : 0.f;
+      t.z = ok ? sc_pro_affine(v[i].z, sc, sh, lo, hi) : 0.f; t.w = ok ? sc_pro_affine(v[i].w, sc, sh, lo, hi) : 0.f;
+      if (r < PH) *reinterpret_cast<float4*>(&s_x[r * PWP + 4 + 4 * c4]) = t;
+    }
+    {
+      const int e = threadIdx.x;
+      const int r = (NHC == 2) ? e >> 1 : e, cc = (NHC == 2 && (e & 1)) ? IC + 1 : 0;
+      const int iy = y0 + r, ix = x0 + cc;
+      const bool ok = (iy >= 0) && (iy < Hin) && (ix >= 0) && (ix < Win);
+      if (e < NHC * PH) s_x[r * PWP + CO + cc] = ok ? sc_pro_affine(hv, sc, sh, lo, hi) : 0.f;
+    }
+  } else {
 #pragma unroll
   for (int i0 = 0; i0 < NIT; i0 += LB) {
     float v[LB];
@@ -153,6 +198,7 @@ __global__ __launch_bounds__(256) void k_dw_fwd(const SrcD in, const float* __re
         if (e < NE) s_x[r * PWP + cc] = ok ? sc_pro_affine(v[j], sc, sh, lo, hi) : 0.f;
       }
   }
+  }
   __syncthreads();
   const int ty = threadIdx.x / TW, tx = threadIdx.x % TW;
   const int ox = tx0 + tx;
@@ -165,12 +211,12 @@ __global__ __launch_bounds__(256) void k_dw_fwd(const SrcD in, const float* __re
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) a[j][q] = s_x[(row0 + j) * PWP + tx + q];
+      for (int q = 0; q < 3; ++q) a[j][q] = s_x[(row0 + j) * PWP + CO + tx + q];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       const int row = row0 + k, oy = ty0 + row;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) a[2][q] = s_x[(row + 2) * PWP + tx + q];
+      for (int q = 0; q < 3; ++q) a[2][q] = s_x[(row + 2) * PWP + CO + tx + q];
       float acc = 0.f;
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
@@ -191,7 +237,7 @@ __global__ __launch_bounds__(256) void k_dw_fwd(const SrcD in, const float* __re
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kh * 3 + kw], s_x[(row * S + kh) * PWP + tx * S + kw], acc);
+        for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kh * 3 + kw], s_x[(row * S + kh) * PWP + CO + tx * S + kw], acc);
       if ((oy < Hout) && (ox < Wout)) {
         ob[(size_t)oy * Wout + ox] = acc;
         sv[0] += acc; sv[1] = fmaf(acc, acc, sv[1]);
@@ -1236,6 +1282,17 @@ int head_blocks(int N, int H, int W) {
 
 }  // namespace
 
+#define SC_DW_DISPATCH4(KERNEL, V4_, W_, GRID, ...)                                                                     \
+  do {                                                                                                                  \
+    const int tw_ = sc_dw_tile_w(W_);                                                                                   \
+    if (stride == 1 && tw_ == 64) hipLaunchKernelGGL((KERNEL<1, 64, 8, V4_>), GRID, dim3(256), 0, st, __VA_ARGS__);     \
+    else if (stride == 1 && tw_ == 32) hipLaunchKernelGGL((KERNEL<1, 32, 4, V4_>), GRID, dim3(256), 0, st, __VA_ARGS__);\
+    else if (stride == 1) hipLaunchKernelGGL((KERNEL<1, 16, 1, V4_>), GRID, dim3(256), 0, st, __VA_ARGS__);             \
+    else if (tw_ == 64) hipLaunchKernelGGL((KERNEL<2, 64, 8, V4_>), GRID, dim3(256), 0, st, __VA_ARGS__);               \
+    else if (tw_ == 32) hipLaunchKernelGGL((KERNEL<2, 32, 4, V4_>), GRID, dim3(256), 0, st, __VA_ARGS__);               \
+    else hipLaunchKernelGGL((KERNEL<2, 16, 1, V4_>), GRID, dim3(256), 0, st, __VA_ARGS__);                              \
+  } while (0)
+
 // tile shape by plane width: (TW, R) = (64, 8) -> 64x32, (32, 4) -> 32x32, (16, 1) -> 16x16 outputs per block
 #define SC_DW_DISPATCH(KERNEL, W_, GRID, ...)                                                                      \
   do {                                                                                                             \
@@ -1246,17 +1303,6 @@ int head_blocks(int N, int H, int W) {
     else if (tw_ == 64) hipLaunchKernelGGL((KERNEL<2, 64, 8>), GRID, dim3(256), 0, st, __VA_ARGS__);               \
     else if (tw_ == 32) hipLaunchKernelGGL((KERNEL<2, 32, 4>), GRID, dim3(256), 0, st, __VA_ARGS__);               \
     else hipLaunchKernelGGL((KERNEL<2, 16, 1>), GRID, dim3(256), 0, st, __VA_ARGS__);                              \
-  } while (0)
-
-#define SC_DW_DISPATCH4(KERNEL, V4_, W_, GRID, ...)                                                                     \
-  do {                                                                                                                  \
-    const int tw_ = sc_dw_tile_w(W_);                                                                                   \
-    if (stride == 1 && tw_ == 64) hipLaunchKernelGGL((KERNEL<1, 64, 8, V4_>), GRID, dim3(256), 0, st, __VA_ARGS__);     \
-    else if (stride == 1 && tw_ == 32) hipLaunchKernelGGL((KERNEL<1, 32, 4, V4_>), GRID, dim3(256), 0, st, __VA_ARGS__);\
-    else if (stride == 1) hipLaunchKernelGGL((KERNEL<1, 16, 1, V4_>), GRID, dim3(256), 0, st, __VA_ARGS__);             \
-    else if (tw_ == 64) hipLaunchKernelGGL((KERNEL<2, 64, 8, V4_>), GRID, dim3(256), 0, st, __VA_ARGS__);               \
-    else if (tw_ == 32) hipLaunchKernelGGL((KERNEL<2, 32, 4, V4_>), GRID, dim3(256), 0, st, __VA_ARGS__);               \
-    else hipLaunchKernelGGL((KERNEL<2, 16, 1, V4_>), GRID, dim3(256), 0, st, __VA_ARGS__);                              \
   } while (0)
 
 static inline long dw_tiles(int H, int W) {
@@ -1280,7 +1326,11 @@ extern "C" int sc_dwconv3x3_fwd(const sc_src* in, const float* w, float* out, in
     SC_LAUNCH_OK("sc_dwconv3x3_fwd");
     return SC_OK;
   }
-  SC_DW_DISPATCH(k_dw_fwd, Wout, grid, to_srcd(*in), w, out, N * C, C, Hin, Win, Hout, Wout, stats);
+  static const bool v4_env = [] { const char* e = getenv("STARCOP_DW_V4"); return !e || atoi(e) != 0; }();
+  if (v4_env && Win % 4 == 0 && (((uintptr_t)in->x) & 15) == 0)
+    SC_DW_DISPATCH4(k_dw_fwd, true, Wout, grid, to_srcd(*in), w, out, N * C, C, Hin, Win, Hout, Wout, stats);
+  else
+    SC_DW_DISPATCH4(k_dw_fwd, false, Wout, grid, to_srcd(*in), w, out, N * C, C, Hin, Win, Hout, Wout, stats);
   SC_LAUNCH_OK("sc_dwconv3x3_fwd");
   return SC_OK;
 }
