@@ -245,6 +245,11 @@ int sc_head_conv_dgrad(const float* dlogits, const float* w, float* gin,
 size_t sc_head_wgrad_workspace_floats(int N, int Cin, int H, int W);
 int sc_head_conv_wgrad(const float* dlogits, const sc_src* in, float* part, size_t part_floats,
                        float* dw, float* dbias, int N, int Cin, int H, int W, sc_stream stream);
+/* dgrad + wgrad + dbias of the head in ONE sweep over (dlogits, in) -- Cin = 16 only (model_module.py:244-251: the decoder's last
+ * block has 16 channels); same results as the two calls above, gin = gradient w.r.t. the ACTIVATED input.  Workspace as for
+ * sc_head_conv_wgrad. */
+int sc_head_conv_bwd(const float* dlogits, const sc_src* in, const float* w, float* gin, float* part, size_t part_floats,
+                     float* dw, float* dbias, int N, int Cin, int H, int W, sc_stream stream);
 
 /* ------------------------------------------------------------------------- */
 /* BatchNorm2d bookkeeping (torch.nn.BatchNorm2d inside smp/torchvision blocks)

@@ -1258,6 +1258,117 @@ __global__ __launch_bounds__(256) void k_head_dgrad(const float* __restrict__ dl
   }
 }
 
+// Head backward in one pass (Cin = 16): gin, dW and dbias from ONE sweep over (dlogits, x).
+//   gin[ci](q)   = sum_t w[ci][t] * dl(q + 1 - t)                         (flipped 3x3 window of dlogits around pixel q)
+//   dW[ci][t]    = sum_p dl(p) * xa[ci](p + t - 1) = sum_q xa[ci](q) * dl(q + 1 - t)   -- the SAME window, so the input needs no
+//   halo: a thread reads xa[ci](q) of its own pixel only, and the separate kernels' second pass over x (268 MB at 16 x 512^2)
+//   and their 16 re-reads of the dlogits plane go away.
+// Work-group = 4 waves, each owning 4 input channels; tile = 64 columns x HB_R rows, lanes = columns, rows walked with the next
+// row's loads in flight; persistent over tiles so that the 36 wave sums + atomics per wave are paid once per work-group.
+constexpr int HB_ROW = 16 * 9 + 1, HB_MAXWG = 1024;       // floats per partial row, most work-groups of a launch
+constexpr int HB_R = 32, HB_PF = 4;       // tile rows, rows of load look-ahead (HB_R % HB_PF == 0)
+__global__ __launch_bounds__(256) void k_head_bwd16(const float* __restrict__ dl, const SrcD in, const float* __restrict__ w,
+                                                    float* __restrict__ gin, float* __restrict__ rows, int N, int H, int W) {
+  constexpr int CIN = 16, PR = HB_R + 2, PC = 64 + 2;
+  __shared__ float s_dl[PR * PC];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int c0 = wave * 4;                         // (uniform: the filters and constants below are scalar loads into SGPRs)
+  float wk[4][9], sc[4], sh[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sc[j] = 1.f; sh[j] = 0.f;
+    if (in.mode != SC_SRC_RAW) { sc[j] = in.cst[(size_t)(c0 + j) * SC_CST]; sh[j] = in.cst[(size_t)(c0 + j) * SC_CST + 1]; }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wk[j][t] = w[(c0 + j) * 9 + t];
+  }
+  const float lo = sc_act_lo(in.act), hi = sc_act_hi(in.act);
+  float prod[4][9], bsum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) prod[j][t] = 0.f;
+  const int tiles_x = (W + 63) / 64, tiles_y = (H + HB_R - 1) / HB_R;
+  const int T = N * tiles_x * tiles_y;
+  const size_t HW = (size_t)H * W;
+  for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
+    const int n = tile / (tiles_x * tiles_y), tt = tile - n * tiles_x * tiles_y;
+    const int y0 = (tt / tiles_x) * HB_R, x0 = (tt % tiles_x) * 64;
+    __syncthreads();                               // (the previous tile's window reads are done)
+    for (int i = threadIdx.x; i < PR * PC; i += 256) {
+      const int r = i / PC, cc = i - r * PC;
+      const int y = y0 - 1 + r, x = x0 - 1 + cc;
+      s_dl[i] = (y >= 0 && y < H && x >= 0 && x < W) ? dl[(size_t)n * HW + (size_t)y * W + x] : 0.f;
+    }
+    __syncthreads();
+    const int x = x0 + lane;
+    const bool xok = x < W;
+    const float* xb = in.x + ((size_t)n * CIN + c0) * HW + (xok ? x : 0);
+    float* gb = gin + ((size_t)n * CIN + c0) * HW + x;
+    // rows are requested HB_PF ahead (clamped, unconditional): with one row of look-ahead a wave had 1 KB in flight and the CU 8 KB
+    float xq[HB_PF][4];
+#pragma unroll
+    for (int u = 0; u < HB_PF; ++u) {
+      const int yc = (y0 + u < H) ? y0 + u : H - 1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xq[u][j] = xb[(size_t)j * HW + (size_t)yc * W];
+    }
+    for (int r0 = 0; r0 < HB_R; r0 += HB_PF) {
+#pragma unroll
+      for (int u = 0; u < HB_PF; ++u) {
+        const int r = r0 + u, y = y0 + r;
+        // d[t] = dl(q + 1 - t): patch row (r + 1) + 1 - kh, patch column (lane + 1) + 1 - kw
+        float d[9];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) d[kh * 3 + kw] = s_dl[(r + 2 - kh) * PC + lane + 2 - kw];
+        const bool ok = xok && y < H;
+        if (wave == 0) bsum += ok ? d[4] : 0.f;
+        const int yn = (y + HB_PF < H) ? y + HB_PF : H - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float g = 0.f;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) g = fmaf(wk[j][t], d[t], g);
+          if (ok) gb[(size_t)j * HW + (size_t)y * W] = g;
+          const float xa = ok ? sc_pro_affine(xq[u][j], sc[j], sh[j], lo, hi) : 0.f;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) prod[j][t] = fmaf(xa, d[t], prod[j][t]);
+          xq[u][j] = xb[(size_t)j * HW + (size_t)yn * W];      // refill the slot with row r + HB_PF
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      // one partial row per work-group, summed by k_head_bwd_reduce: a thousand work-groups adding into the same 145 doubles
+      // serialise on the atomics (measured: 231 us with 512 work-groups, 262 us with 1024)
+      const float v = wave_sum(prod[j][t]);
+      if (lane == 0) rows[(size_t)blockIdx.x * HB_ROW + (c0 + j) * 9 + t] = v;
+    }
+  if (wave == 0) {
+    bsum = wave_sum(bsum);
+    if (lane == 0) rows[(size_t)blockIdx.x * HB_ROW + CIN * 9] = bsum;
+  }
+}
+// dW / dbias = column sums (in double) of the partial rows: one work-group per column
+__global__ __launch_bounds__(256) void k_head_bwd_reduce(const float* __restrict__ rows, int nrows, float* __restrict__ dw, float* __restrict__ dbias) {
+  __shared__ double s_tmp[4];
+  const int col = blockIdx.x;
+  double v = 0.0;
+  for (int r = threadIdx.x; r < nrows; r += 256) v += (double)rows[(size_t)r * HB_ROW + col];
+  v = wave_sum_d(v);
+  if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    v = (s_tmp[0] + s_tmp[1]) + (s_tmp[2] + s_tmp[3]);
+    if (col < 16 * 9) dw[col] = (float)v;
+    else if (dbias) dbias[0] = (float)v;
+  }
+}
+
 // sum of a float array into a double accumulator (bias gradient of the head = sum of dlogits)
 __global__ __launch_bounds__(256) void k_sum_f32_to_f64(const float* __restrict__ x, size_t n, double* acc) {
   __shared__ float s_tmp[4];
@@ -1395,6 +1506,23 @@ extern "C" int sc_dwconv3x3_bwd_fused(const sc_src* dy, const sc_src* in, const 
   return SC_OK;
 }
 
+extern "C" int sc_head_conv_bwd(const float* dlogits, const sc_src* in, const float* w, float* gin, float* part, size_t part_floats,
+                                float* dw, float* dbias, int N, int Cin, int H, int W, sc_stream stream) {
+  SC_REQUIRE(dlogits && in && w && gin && part && dw && in->C == Cin, "sc_head_conv_bwd: bad argument");
+  SC_REQUIRE(Cin == 16, "sc_head_conv_bwd: Cin must be 16 (use sc_head_conv_dgrad + sc_head_conv_wgrad otherwise)");
+  SC_REQUIRE((in->mode == SC_SRC_RAW || in->mode == SC_SRC_AFFINE) && in->up == 0, "sc_head_conv_bwd: unsupported source mode");
+  SC_REQUIRE(part_floats >= sc_head_wgrad_workspace_floats(N, Cin, H, W), "sc_head_conv_bwd: workspace too small");
+  SC_REQUIRE(N > 0 && H > 0 && W > 0, "sc_head_conv_bwd: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const long T = (long)N * ((W + 63) / 64) * ((H + HB_R - 1) / HB_R);
+  const int nwg = (int)(T < HB_MAXWG ? T : HB_MAXWG);       // (all resident: 116 registers -> 4 work-groups per CU)
+  hipLaunchKernelGGL(k_head_bwd16, dim3(nwg), dim3(256), 0, st, dlogits, to_srcd(*in), w, gin, part, N, H, W);
+  SC_LAUNCH_OK("sc_head_conv_bwd");
+  hipLaunchKernelGGL(k_head_bwd_reduce, dim3(HB_ROW), dim3(256), 0, st, part, nwg, dw, dbias);
+  SC_LAUNCH_OK("sc_head_conv_bwd(reduce)");
+  return SC_OK;
+}
+
 extern "C" int sc_cast_f64_f32(const double* in, float* out, size_t n, sc_stream stream) {
   if (n == 0) return SC_OK;
   const int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
@@ -1465,7 +1593,9 @@ extern "C" int sc_head_conv_dgrad(const float* dlogits, const float* w, float* g
 
 extern "C" size_t sc_head_wgrad_workspace_floats(int N, int Cin, int H, int W) {
   (void)N; (void)H; (void)W;
-  return 2 * ((size_t)Cin * 9 + 1) + 2;       // Cin*9 + 1 double accumulators
+  // Cin*9 + 1 double accumulators (sc_head_conv_wgrad) or the partial rows of sc_head_conv_bwd
+  const size_t a = 2 * ((size_t)Cin * 9 + 1) + 2, b = (size_t)HB_MAXWG * HB_ROW;
+  return a > b ? a : b;
 }
 
 // dW[0][ci][tap] = sum_px dlogits[px] * act(in)[ci][px + d(tap)]: the depthwise weight-gradient kernel with the single

@@ -103,6 +103,7 @@ class _T:
 _COT_RATIO = float(os.environ.get("STARCOP_COT_RATIO", "1.15"))
 # development knob: "d0a,d0b;d0a" forces 32-wide cout tiles for the forward (before ';') / backward-data launches of these ops
 _FORCE_COT32 = [set(x.split(",")) for x in (os.environ.get("STARCOP_FORCE_COT32", ";") + ";").split(";")[:2]]
+_HEAD_FUSED_BWD = os.environ.get("STARCOP_HEAD_FUSED_BWD", "1") != "0"      # dev knob: 0 = separate head dgrad / wgrad launches
 
 
 def _pick_cot(M, ks=1):
@@ -751,11 +752,16 @@ class HyperStarcopUNet(nn.Module):
                 tin = op["ins"][0]
                 s = self._src_of(plan, tin)
                 tok = self._pb("k_head_*")
-                wgrad_launch(lambda sx: check(lib.sc_head_conv_wgrad(
-                    ptr(dlogits), C.byref(s), ptr(plan.ws), plan.ws_floats, ptr(gv(conv.weight)), ptr(gv(conv.bias)), N,
-                    conv.in_channels, Ho, Wo, sx)))
-                check(lib.sc_head_conv_dgrad(ptr(dlogits), ptr(conv.weight), ptr(plan.grad[tin.name]), N,
-                                             conv.in_channels, Ho, Wo, st))
+                if conv.in_channels == 16 and _HEAD_FUSED_BWD:
+                    # one sweep over (dlogits, x) for gin, dW and dbias (sc_head_conv_bwd)
+                    check(lib.sc_head_conv_bwd(ptr(dlogits), C.byref(s), ptr(conv.weight), ptr(plan.grad[tin.name]), ptr(plan.ws),
+                                               plan.ws_floats, ptr(gv(conv.weight)), ptr(gv(conv.bias)), N, conv.in_channels, Ho, Wo, st))
+                else:
+                    wgrad_launch(lambda sx: check(lib.sc_head_conv_wgrad(
+                        ptr(dlogits), C.byref(s), ptr(plan.ws), plan.ws_floats, ptr(gv(conv.weight)), ptr(gv(conv.bias)), N,
+                        conv.in_channels, Ho, Wo, sx)))
+                    check(lib.sc_head_conv_dgrad(ptr(dlogits), ptr(conv.weight), ptr(plan.grad[tin.name]), N,
+                                                 conv.in_channels, Ho, Wo, st))
                 self._pe(tok)
                 written.add(tin.name)
                 continue

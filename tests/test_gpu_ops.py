@@ -482,6 +482,12 @@ def test_head(hip):
     ws, dw, db = torch.empty(n, device=DEV), torch.empty(1, Cin, 3, 3, device=DEV), torch.empty(1, device=DEV)
     check(hip.sc_head_conv_wgrad(ptr(dld), C.byref(src), ptr(ws), n, ptr(dw), ptr(db), N, Cin, H, W, stream()))
     assert relerr(dw, wr.grad) < TOL and relerr(db, br.grad) < TOL
+    # the one-sweep backward (Cin = 16): same gin bit for bit, same dW / dbias
+    gin2 = torch.full((N, Cin, H, W), float("nan"), device=DEV)
+    dw2, db2 = torch.empty(1, Cin, 3, 3, device=DEV), torch.empty(1, device=DEV)
+    check(hip.sc_head_conv_bwd(ptr(dld), C.byref(src), ptr(wd), ptr(gin2), ptr(ws), n, ptr(dw2), ptr(db2), N, Cin, H, W, stream()))
+    assert torch.equal(gin2, gin)
+    assert relerr(dw2, wr.grad) < TOL and relerr(db2, br.grad) < TOL
 
 
 def test_batchnorm_bookkeeping(hip):
