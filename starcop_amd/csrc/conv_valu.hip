@@ -888,46 +888,76 @@ __global__ __launch_bounds__(256) void k_dw_fwd_p16(const SrcD in, const float* 
 constexpr int STEM_CO = 32;
 constexpr int STEM_MAXCI = 8;
 
+// CINT: compile-time bound of the channel loops (4 for the 4-channel HyperSTARCOP input, STEM_MAXCI otherwise)
+template <int CINT>
 __global__ __launch_bounds__(256) void k_stem_fwd(const SrcD in, const float* __restrict__ w, float* __restrict__ out,
                                                   int Cin, int Hin, int Win, int Hout, int Wout, float* stats) {
-  __shared__ float s_w[STEM_CO * STEM_MAXCI * 9];
+  __shared__ float s_in[CINT][17 * 66];
   __shared__ float s_red[8][STEM_CO][2];        // per half-wave partial sums (DPP reductions, no LDS crossbar traffic)
   const int n = blockIdx.z;
-  for (int i = threadIdx.x; i < STEM_CO * Cin * 9; i += 256) s_w[i] = w[i];
-  const int tiles_x = (Wout + 15) >> 4;
+  // tile = 32 x 8 outputs: a wave stores two 128-byte row segments per channel (16 x 16 tiles: four 64-byte pieces)
+  const int tiles_x = (Wout + 31) >> 5;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int oy = ty * 16 + (threadIdx.x >> 4), ox = tx * 16 + (threadIdx.x & 15);
+  const int oy = ty * 8 + (threadIdx.x >> 5), ox = tx * 32 + (threadIdx.x & 31);
   const bool ok = (oy < Hout) && (ox < Wout);
-  float v[STEM_MAXCI * 9];
+  // The 17 x 65 input patch of the 8 x 32 output tile is staged ONCE per channel through LDS: every element is loaded and run
+  // through the source prologue (the normaliser's division for raw products) once instead of up to nine times, all loads of the
+  // thread are in flight together (clamped, unconditional), and the per-channel constants are uniform.  (Before: 36 loads per
+  // thread, each under its own bounds branch with the constants fetched behind it -- 36 dependent memory round trips.)
+  constexpr int PS = 65, PSP = 66, NE = 17 * PS, NIT = (NE + 255) / 256;
+  {
+    const int iy0 = ty * 16 - 1, ix0 = tx * 64 - 1;
+    float raw[CINT][NIT];
 #pragma unroll
-  for (int i = 0; i < STEM_MAXCI * 9; ++i) v[i] = 0.f;
-  if (ok) {
-#pragma unroll
-    for (int ci = 0; ci < STEM_MAXCI; ++ci) {
+    for (int ci = 0; ci < CINT; ++ci) {
       if (ci < Cin) {
-        const size_t ibase = ((size_t)n * Cin + ci) * Hin * Win;
+        const float* xb = in.x + ((size_t)n * Cin + ci) * Hin * Win;
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          const int iy = oy * 2 + kh - 1;
+        for (int i = 0; i < NIT; ++i) {
+          const int e = threadIdx.x + i * 256;
+          const int r = e / PS, cc = e - r * PS;
+          const int iy = iy0 + r, ix = ix0 + cc;
+          const bool inb = (e < NE) && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+          raw[ci][i] = xb[inb ? (size_t)iy * Win + ix : 0];
+        }
+      }
+    }
 #pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int ix = ox * 2 + kw - 1;
-            if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) v[ci * 9 + kh * 3 + kw] = load_src(in, ibase + (size_t)iy * Win + ix, ci);
-          }
+    for (int ci = 0; ci < CINT; ++ci) {
+      if (ci < Cin) {
+        float4 c0 = make_float4(1.f, 0.f, 0.f, 0.f); float c4 = 0.f;
+        if (in.mode != SC_SRC_RAW) { c0 = *reinterpret_cast<const float4*>(in.cst + (size_t)ci * SC_CST); c4 = in.cst[(size_t)ci * SC_CST + 4]; }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+          const int e = threadIdx.x + i * 256;
+          const int r = e / PS, cc = e - r * PS;
+          const int iy = iy0 + r, ix = ix0 + cc;
+          const bool inb = iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+          const float t = (in.mode == SC_SRC_RAW) ? raw[ci][i] : sc_prologue(in.mode, in.act, raw[ci][i], 0.f, c0, c4);
+          if (e < NE) s_in[ci][r * PSP + cc] = inb ? t : 0.f;
         }
       }
     }
   }
+  __syncthreads();
+  float v[CINT * 9];
+#pragma unroll
+  for (int ci = 0; ci < CINT; ++ci)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+        v[ci * 9 + kh * 3 + kw] = (ci < Cin) ? s_in[ci][(2 * (threadIdx.x >> 5) + kh) * PSP + 2 * (threadIdx.x & 31) + kw] : 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t HWo = (size_t)Hout * Wout;
   for (int co = 0; co < STEM_CO; ++co) {
     float acc = 0.f;
 #pragma unroll
-    for (int ci = 0; ci < STEM_MAXCI; ++ci) {
+    for (int ci = 0; ci < CINT; ++ci) {
       if (ci < Cin) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc = fmaf(s_w[(co * Cin + ci) * 9 + t], v[ci * 9 + t], acc);
+        for (int t = 0; t < 9; ++t) acc = fmaf(w[(co * Cin + ci) * 9 + t], v[ci * 9 + t], acc);      // (uniform index: scalar loads, SGPR operands)
       }
     }
     if (ok) out[((size_t)n * STEM_CO + co) * HWo + (size_t)oy * Wout + ox] = acc;
@@ -1537,8 +1567,9 @@ extern "C" int sc_stem_conv_fwd(const sc_src* in, const float* w, float* out, in
   SC_REQUIRE(Cin >= 1 && Cin <= STEM_MAXCI, "sc_stem_conv_fwd: Cin must be in [1,%d] (got %d)", STEM_MAXCI, Cin);
   SC_REQUIRE(in->mode != SC_SRC_BNBWD && in->up == 0, "sc_stem_conv_fwd: unsupported source mode");
   const int Hout = (Hin - 1) / 2 + 1, Wout = (Win - 1) / 2 + 1;
-  dim3 grid(((Wout + 15) / 16) * ((Hout + 15) / 16), 1, N);
-  hipLaunchKernelGGL(k_stem_fwd, grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), w, out, Cin, Hin, Win, Hout, Wout, stats);
+  dim3 grid(((Wout + 31) / 32) * ((Hout + 7) / 8), 1, N);
+  if (Cin <= 4) hipLaunchKernelGGL(k_stem_fwd<4>, grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), w, out, Cin, Hin, Win, Hout, Wout, stats);
+  else hipLaunchKernelGGL(k_stem_fwd<STEM_MAXCI>, grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), w, out, Cin, Hin, Win, Hout, Wout, stats);
   SC_LAUNCH_OK("sc_stem_conv_fwd");
   return SC_OK;
 }
