@@ -1065,16 +1065,29 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const SrcD dy, const SrcD in
       }
     }
   }
-  float* pr = part + ((size_t)blockIdx.x * 4 + wave) * (STEM_CO * J);
+  // the four waves' accumulators are summed through LDS in a fixed order (((w0 + w1) + w2) + w3): ONE partial row per work-group
+  // (a row per wave left 4096 rows = 19 MB for the reduction kernels: 72 us, more than half of this kernel's own time)
+  __syncthreads();
+  float* s_sum = s_x;                              // 32 * J <= 2304 floats
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb)
+      for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-    for (int jb = 0; jb < NJB; ++jb)
+        for (int jb = 0; jb < NJB; ++jb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = cb * 16 + 4 * lq + r, j = jb * 16 + l15;
-        if (j < J) pr[co * J + j] = acc[cb][jb][r];      // [co][ci][tap] (OIHW order)
-      }
+          for (int r = 0; r < 4; ++r) {
+            const int co = cb * 16 + 4 * lq + r, j = jb * 16 + l15;
+            if (j < J) {
+              const float prev = wv ? s_sum[co * J + j] : 0.f;
+              s_sum[co * J + j] = prev + acc[cb][jb][r];
+            }
+          }
+    }
+    __syncthreads();
+  }
+  float* pr = part + (size_t)blockIdx.x * (STEM_CO * J);      // [co][ci][tap] (OIHW order)
+  for (int i = tid; i < STEM_CO * J; i += 256) pr[i] = s_sum[i];
 }
 
 // ---------------------------------------------------------------- head (3x3, Cin<=32 -> 1, bias)
@@ -1576,7 +1589,7 @@ extern "C" int sc_stem_conv_fwd(const sc_src* in, const float* w, float* out, in
 
 extern "C" size_t sc_stem_wgrad_workspace_floats(int N, int Cin, int Hin, int Win) {
   const int Hout = (Hin - 1) / 2 + 1, Wout = (Win - 1) / 2 + 1;
-  const int nb = 4 * stem_blocks(N, Hout, Wout);      // one partial row per wave
+  const int nb = stem_blocks(N, Hout, Wout);          // one partial row per work-group
   const size_t E = (size_t)STEM_CO * Cin * 9;
   return (size_t)nb * E + sc_reduce_scratch_floats(nb, E);
 }
@@ -1594,7 +1607,7 @@ extern "C" int sc_stem_conv_wgrad(const sc_src* dy, const sc_src* in, float* par
   if (njb <= 3) hipLaunchKernelGGL((k_stem_wgrad<3>), dim3(nb), dim3(256), 0, st, to_srcd(*dy), to_srcd(*in), part, N, Cin, Hin, Win, Hout, Wout);
   else hipLaunchKernelGGL((k_stem_wgrad<5>), dim3(nb), dim3(256), 0, st, to_srcd(*dy), to_srcd(*in), part, N, Cin, Hin, Win, Hout, Wout);
   SC_LAUNCH_OK("sc_stem_conv_wgrad");
-  return sc_reduce_rows(part, 4 * nb, E, part + (size_t)4 * nb * E, dw, st);
+  return sc_reduce_rows(part, nb, E, part + (size_t)nb * E, dw, st);
 }
 
 extern "C" int sc_head_conv_fwd(const sc_src* in, const float* w, const float* bias, float* out, int N, int Cin,
