@@ -114,12 +114,14 @@ def test_train_forward_loss_b16_512(hip):
 def test_bf16_mode_trains_like_fp32_at_512(hip):
     """BASELINE configs[3] shape family (batch 16 x 4 x 512 x 512; 64 per GPU only changes the batch dimension): the bf16 matrix-math
     mode (one bf16 term per operand in the 3x3 convolutions, fp32 accumulation / storage / optimiser state) against the fp32 default --
-    SURVEY 8d's bf16 gate: the masks after training agree in F1 within 0.005.  Every precision mode (fp32-x3 included) goes through ONE
-    loss blow-up of this Adam(lr 1e-3) + BatchNorm recipe between steps 350 and 500 and recovers (tools/debug_train512.py); 1000 steps
-    end well after it, on the same plateau (the step is bit-reproducible run to run, so the trajectory is too)"""
+    SURVEY 8d's bf16 gate: the masks after training agree in F1 within 0.005.  The comparison is made after 300 steps, where every
+    mode has fitted the 16 tiles (loss 0.289 -> 0.003, F1 0.998) and BEFORE the recipe's instabilities start: once the loss is below
+    ~1e-3, Adam(lr 1e-3) on 16 fixed tiles blows up every few hundred steps (0.0004 -> 0.3 within three steps, then a slow
+    recovery) in EVERY precision mode, fp32-x3 included, first at step 373-619 depending on the last bits of the arithmetic
+    (tools/debug_train512.py) -- where a run stands at step 1000 is a lottery, not a property of the bf16 mode."""
     import bench
     from starcop_amd import model_module as mm
-    B, steps = 16, 1000
+    B, steps = 16, 300
     train = bench.synth_batch(B, T, T, 4321, DEV)
     res = {}
     for prec in ("fp32", "bf16"):
@@ -139,4 +141,4 @@ def test_bf16_mode_trains_like_fp32_at_512(hip):
           f"F1 fp32 {f32:.4f}, bf16 {f16:.4f}")
     assert m32 < 0.05 * l32[0] and m16 < 0.05 * l16[0]                            # both fit the tiles
     assert abs(l16[0] - l32[0]) < 2e-2 * l32[0]                                   # same start: bf16 rounding only
-    assert f32 > 0.98 and f16 > 0.98 and abs(f16 - f32) <= 0.005, (f16, f32)
+    assert f32 > 0.99 and f16 > 0.99 and abs(f16 - f32) <= 0.005, (f16, f32)

@@ -7,7 +7,7 @@ DEV = "cuda"; B, T, steps = 16, 512, int(os.environ.get("STEPS", "400"))
 train = bench.synth_batch(B, T, T, 4321, DEV)
 for prec in sys.argv[1:] or ("fp32", "bf16", "fp32-x3"):
     torch.manual_seed(0)
-    model = mm.ModelModule(mm.default_settings(pos_weight=1, lr=1e-3, precision=prec)).to(DEV).train()
+    model = mm.ModelModule(mm.default_settings(pos_weight=1, lr=float(os.environ.get("LR", "1e-3")), precision=prec)).to(DEV).train()
     opt = model.configure_optimizers()["optimizer"]
     losses = []
     for i in range(steps):
