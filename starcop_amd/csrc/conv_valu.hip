@@ -739,23 +739,31 @@ __global__ __launch_bounds__(256) void k_dw_bwd(const SrcD dy, const SrcD in, co
   if (in_sums && threadIdx.x < 2) in_sums[(((size_t)n * tiles + tile) * C + c) * 2 + threadIdx.x] = (double)all[9 + threadIdx.x];
 }
 
-// The same fused backward for 16x16 planes at stride 1 (features.15-17 at 512^2 input: 960 channels x 16 images = 15360 planes).
-// One plane is one tile there, and a 256-thread work-group per 256 pixels spends its time on launch, barrier and an 11-value block
-// reduction (65 us per layer = 1 TB/s, slower than the three separate kernels).  Here a WAVE owns a plane: one float4 load per
-// lane and tensor, a wave-private LDS patch (zero border), four outputs per lane, DPP wave sums, atomics from lane 0.
-__global__ __launch_bounds__(256) void k_dw_bwd_p16(const SrcD dy, const SrcD in, const float* __restrict__ w, float* __restrict__ dx,
-                                                    double* __restrict__ dw_acc, double* __restrict__ in_sums, int C) {
-  constexpr int P = 24, PR = 18;                 // patch pitch (interior at columns 4..19, halo columns 3 and 20), patch rows
+// The same fused backward for whole 16x16 / 32x32 planes at stride 1 (features.8-13 and 15-17 at 512^2 input: up to 15360 planes
+// per layer).  One plane is one tile there, and a 256-thread work-group per plane spends its time on launch, barrier and an
+// 11-value block reduction (16x16: 65 us per layer = 1 TB/s, slower than the three separate kernels).  Here a WAVE owns a plane:
+// G float4 loads per lane and tensor (PS = 16: G = 1, four lanes per row; PS = 32: G = 4, two lanes per row), a wave-private LDS
+// patch with a zero border, 4 G outputs per lane, DPP wave sums, atomics from lane 0.
+template <int PS>
+__global__ __launch_bounds__(256) void k_dw_bwd_plane(const SrcD dy, const SrcD in, const float* __restrict__ w, float* __restrict__ dx,
+                                                      double* __restrict__ dw_acc, double* __restrict__ in_sums, int C) {
+  constexpr int P = PS + 8, PR = PS + 2;         // patch pitch (interior at columns 4..PS+3, halo columns 3 and PS+4), patch rows
+  constexpr int LPR = (PS == 16) ? 4 : 2, G = PS / (4 * LPR), HW = PS * PS;
   __shared__ __attribute__((aligned(16))) float s_d[4][PR * P];
   __shared__ __attribute__((aligned(16))) float s_x[4][PR * P];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int plane = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);      // (the launcher guarantees N * C % 4 == 0)
   const int n = plane / C, c = plane - n * C;
   const bool bnb = dy.mode == SC_SRC_BNBWD;
-  const size_t base = (size_t)plane * 256;
-  const float4 g4 = *reinterpret_cast<const float4*>(dy.x + base + 4 * lane);
-  const float4 y4 = bnb ? *reinterpret_cast<const float4*>(dy.aux + base + 4 * lane) : g4;
-  const float4 x4 = *reinterpret_cast<const float4*>(in.x + base + 4 * lane);
+  const int r = lane / LPR, q = lane % LPR;      // this lane's image row and its run of 4 G columns
+  const size_t base = (size_t)plane * HW + (size_t)r * PS + q * 4 * G;
+  float4 g4[G], y4[G], x4[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    g4[g] = *reinterpret_cast<const float4*>(dy.x + base + 4 * g);
+    y4[g] = bnb ? *reinterpret_cast<const float4*>(dy.aux + base + 4 * g) : g4[g];
+    x4[g] = *reinterpret_cast<const float4*>(in.x + base + 4 * g);
+  }
   float4 c0 = make_float4(1.f, 0.f, 0.f, 0.f); float c4 = 0.f;
   float xs = 1.f, xh = 0.f, xmean = 0.f, xinv = 1.f;
   if (dy.mode != SC_SRC_RAW) { c0 = *reinterpret_cast<const float4*>(dy.cst + (size_t)c * SC_CST); c4 = dy.cst[(size_t)c * SC_CST + 4]; }
@@ -776,54 +784,59 @@ __global__ __launch_bounds__(256) void k_dw_bwd_p16(const SrcD dy, const SrcD in
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int i = lane; i < PR * P / 4; i += 64) { reinterpret_cast<float4*>(sd)[i] = z4; reinterpret_cast<float4*>(sx)[i] = z4; }
-  const int r = lane >> 2, q4 = lane & 3;        // this lane's image row and its group of four columns
-  {
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
     float4 t;
-    t.x = dpro(g4.x, y4.x); t.y = dpro(g4.y, y4.y); t.z = dpro(g4.z, y4.z); t.w = dpro(g4.w, y4.w);
-    *reinterpret_cast<float4*>(&sd[(r + 1) * P + 4 + 4 * q4]) = t;
-    *reinterpret_cast<float4*>(&sx[(r + 1) * P + 4 + 4 * q4]) = x4;
+    t.x = dpro(g4[g].x, y4[g].x); t.y = dpro(g4[g].y, y4[g].y); t.z = dpro(g4[g].z, y4[g].z); t.w = dpro(g4[g].w, y4[g].w);
+    *reinterpret_cast<float4*>(&sd[(r + 1) * P + 4 + 4 * (q * G + g)]) = t;
+    *reinterpret_cast<float4*>(&sx[(r + 1) * P + 4 + 4 * (q * G + g)]) = x4[g];
   }
   __syncthreads();
-  // rows r-1 .. r+1 (patch rows r .. r+2), image columns 4 q4 - 1 .. 4 q4 + 4 (patch columns 4 q4 + 3 .. 4 q4 + 8)
-  float D[3][6], XA[3][6];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const float* dr = &sd[(r + j) * P + 4 * q4 + 3];
-    const float* xr = &sx[(r + j) * P + 4 * q4 + 3];
-    const float4 dm = *reinterpret_cast<const float4*>(dr + 1), xm = *reinterpret_cast<const float4*>(xr + 1);
-    D[j][0] = dr[0]; D[j][1] = dm.x; D[j][2] = dm.y; D[j][3] = dm.z; D[j][4] = dm.w; D[j][5] = dr[5];
-    const float xv[6] = {xr[0], xm.x, xm.y, xm.z, xm.w, xr[5]};
-    const bool rok = (r - 1 + j >= 0) && (r - 1 + j < 16);
-#pragma unroll
-    for (int m = 0; m < 6; ++m) {
-      const int col = 4 * q4 - 1 + m;
-      // zero padding applies to the ACTIVATED input (see k_dw_bwd)
-      XA[j][m] = (rok && col >= 0 && col < 16) ? sc_pro_affine(xv[m], xs, xh, xlo, xhi) : 0.f;
-    }
-  }
-  float prod[9], red[2] = {0.f, 0.f}, o[4];
+  float prod[9], red[2] = {0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < 9; ++t) prod[t] = 0.f;
-  const float xraw[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float acc = 0.f;
+  for (int g = 0; g < G; ++g) {
+    const int cb = 4 * (q * G + g);              // first image column of this group of four
+    // rows r-1 .. r+1 (patch rows r .. r+2), image columns cb - 1 .. cb + 4 (patch columns cb + 3 .. cb + 8)
+    float D[3][6], XA[3][6];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+    for (int j = 0; j < 3; ++j) {
+      const float* dr = &sd[(r + j) * P + cb + 3];
+      const float* xr = &sx[(r + j) * P + cb + 3];
+      const float4 dm = *reinterpret_cast<const float4*>(dr + 1), xm = *reinterpret_cast<const float4*>(xr + 1);
+      D[j][0] = dr[0]; D[j][1] = dm.x; D[j][2] = dm.y; D[j][3] = dm.z; D[j][4] = dm.w; D[j][5] = dr[5];
+      const float xv[6] = {xr[0], xm.x, xm.y, xm.z, xm.w, xr[5]};
+      const bool rok = (r - 1 + j >= 0) && (r - 1 + j < PS);
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kh * 3 + kw], D[2 - kh][i + 2 - kw], acc);
-    const float dyv = D[1][i + 1];
+      for (int m = 0; m < 6; ++m) {
+        const int col = cb - 1 + m;
+        // zero padding applies to the ACTIVATED input (see k_dw_bwd)
+        XA[j][m] = (rok && col >= 0 && col < PS) ? sc_pro_affine(xv[m], xs, xh, xlo, xhi) : 0.f;
+      }
+    }
+    float o[4];
+    const float xraw[4] = {x4[g].x, x4[g].y, x4[g].z, x4[g].w};
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+    for (int i = 0; i < 4; ++i) {
+      float acc = 0.f;
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) prod[kh * 3 + kw] = fmaf(dyv, XA[kh][i + kw], prod[kh * 3 + kw]);
-    o[i] = acc;
-    const float yh = fmaf(xraw[i], xs, xh);
-    const float gb = (yh > xlo && yh < xhi) ? acc : 0.f;
-    red[0] += gb;
-    red[1] = fmaf(gb, (xraw[i] - xmean) * xinv, red[1]);
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kh * 3 + kw], D[2 - kh][i + 2 - kw], acc);
+      const float dyv = D[1][i + 1];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) prod[kh * 3 + kw] = fmaf(dyv, XA[kh][i + kw], prod[kh * 3 + kw]);
+      o[i] = acc;
+      const float yh = fmaf(xraw[i], xs, xh);
+      const float gb = (yh > xlo && yh < xhi) ? acc : 0.f;
+      red[0] += gb;
+      red[1] = fmaf(gb, (xraw[i] - xmean) * xinv, red[1]);
+    }
+    *reinterpret_cast<float4*>(dx + base + 4 * g) = make_float4(o[0], o[1], o[2], o[3]);
   }
-  *reinterpret_cast<float4*>(dx + base + 4 * lane) = make_float4(o[0], o[1], o[2], o[3]);
   float all[11];
 #pragma unroll
   for (int t = 0; t < 9; ++t) all[t] = wave_sum(prod[t]);
@@ -835,16 +848,21 @@ __global__ __launch_bounds__(256) void k_dw_bwd_p16(const SrcD dy, const SrcD in
   }
 }
 
-// forward for 16x16 planes at stride 1, a wave per plane (see k_dw_bwd_p16)
-__global__ __launch_bounds__(256) void k_dw_fwd_p16(const SrcD in, const float* __restrict__ w, float* __restrict__ out, int C,
-                                                    float* __restrict__ stats) {
-  constexpr int P = 24, PR = 18;
+// forward for whole 16x16 / 32x32 planes at stride 1, a wave per plane (see k_dw_bwd_plane)
+template <int PS>
+__global__ __launch_bounds__(256) void k_dw_fwd_plane(const SrcD in, const float* __restrict__ w, float* __restrict__ out, int C,
+                                                      float* __restrict__ stats) {
+  constexpr int P = PS + 8, PR = PS + 2;
+  constexpr int LPR = (PS == 16) ? 4 : 2, G = PS / (4 * LPR), HW = PS * PS;
   __shared__ __attribute__((aligned(16))) float s_x[4][PR * P];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int plane = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
   const int n = plane / C, c = plane - n * C;
-  const size_t base = (size_t)plane * 256;
-  const float4 x4 = *reinterpret_cast<const float4*>(in.x + base + 4 * lane);
+  const int r = lane / LPR, q = lane % LPR;
+  const size_t base = (size_t)plane * HW + (size_t)r * PS + q * 4 * G;
+  float4 x4[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) x4[g] = *reinterpret_cast<const float4*>(in.x + base + 4 * g);
   float sc = 1.f, sh = 0.f;
   if (in.mode != SC_SRC_RAW) { sc = in.cst[(size_t)c * SC_CST]; sh = in.cst[(size_t)c * SC_CST + 1]; }
   float wk[9];
@@ -855,29 +873,35 @@ __global__ __launch_bounds__(256) void k_dw_fwd_p16(const SrcD in, const float* 
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int i = lane; i < PR * P / 4; i += 64) reinterpret_cast<float4*>(sx)[i] = z4;
-  const int r = lane >> 2, q4 = lane & 3;
-  *reinterpret_cast<float4*>(&sx[(r + 1) * P + 4 + 4 * q4]) =
-      make_float4(sc_pro_affine(x4.x, sc, sh, lo, hi), sc_pro_affine(x4.y, sc, sh, lo, hi), sc_pro_affine(x4.z, sc, sh, lo, hi),
-                  sc_pro_affine(x4.w, sc, sh, lo, hi));
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+    *reinterpret_cast<float4*>(&sx[(r + 1) * P + 4 + 4 * (q * G + g)]) =
+        make_float4(sc_pro_affine(x4[g].x, sc, sh, lo, hi), sc_pro_affine(x4[g].y, sc, sh, lo, hi), sc_pro_affine(x4[g].z, sc, sh, lo, hi),
+                    sc_pro_affine(x4[g].w, sc, sh, lo, hi));
   __syncthreads();
-  float A[3][6];
+  float sv = 0.f, sq = 0.f;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const float* xr = &sx[(r + j) * P + 4 * q4 + 3];
-    const float4 xm = *reinterpret_cast<const float4*>(xr + 1);
-    A[j][0] = xr[0]; A[j][1] = xm.x; A[j][2] = xm.y; A[j][3] = xm.z; A[j][4] = xm.w; A[j][5] = xr[5];
+  for (int g = 0; g < G; ++g) {
+    const int cb = 4 * (q * G + g);
+    float A[3][6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float* xr = &sx[(r + j) * P + cb + 3];
+      const float4 xm = *reinterpret_cast<const float4*>(xr + 1);
+      A[j][0] = xr[0]; A[j][1] = xm.x; A[j][2] = xm.y; A[j][3] = xm.z; A[j][4] = xm.w; A[j][5] = xr[5];
+    }
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float acc = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kh * 3 + kw], A[kh][i + kw], acc);
+      o[i] = acc; sv += acc; sq = fmaf(acc, acc, sq);
+    }
+    *reinterpret_cast<float4*>(out + base + 4 * g) = make_float4(o[0], o[1], o[2], o[3]);
   }
-  float o[4], sv = 0.f, sq = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float acc = 0.f;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kh * 3 + kw], A[kh][i + kw], acc);
-    o[i] = acc; sv += acc; sq = fmaf(acc, acc, sq);
-  }
-  *reinterpret_cast<float4*>(out + base + 4 * lane) = make_float4(o[0], o[1], o[2], o[3]);
   if (stats) {
     sv = wave_sum(sv); sq = wave_sum(sq);
     if (lane == 0) { stats[((size_t)n * C + c) * 2] = sv; stats[((size_t)n * C + c) * 2 + 1] = sq; }
@@ -1475,8 +1499,13 @@ extern "C" int sc_dwconv3x3_fwd(const sc_src* in, const float* w, float* out, in
   SC_REQUIRE(planes8 * dw_tiles(Hout, Wout) < (1L << 31), "sc_dwconv3x3_fwd: grid too large");
   dim3 grid((unsigned)(planes8 * dw_tiles(Hout, Wout)));
   static const bool p16_env = [] { const char* e = getenv("STARCOP_DW_P16"); return !e || atoi(e) != 0; }();
-  if (p16_env && stride == 1 && Hin == 16 && Win == 16 && ((long)N * C) % 4 == 0 && (((uintptr_t)in->x | (uintptr_t)out) & 15) == 0) {
-    hipLaunchKernelGGL(k_dw_fwd_p16, dim3((unsigned)((long)N * C / 4)), dim3(256), 0, st, to_srcd(*in), w, out, C, stats);
+  // (32 x 32 planes through the same kernel measured SLOWER than the work-group-per-plane form -- backward 50 -> 63 us, forward
+  // 22 -> 27 us on features.12: 16 pixels per lane, 43 KB of LDS per work-group -- so it is opt-in: STARCOP_DW_P32=1)
+  static const bool p32_env = [] { const char* e = getenv("STARCOP_DW_P32"); return e && atoi(e) != 0; }();
+  const bool plane_ok = stride == 1 && Hin == Win && ((long)N * C) % 4 == 0 && (((uintptr_t)in->x | (uintptr_t)out) & 15) == 0;
+  if (plane_ok && ((p16_env && Hin == 16) || (p16_env && p32_env && Hin == 32))) {      // a wave per plane
+    if (Hin == 16) hipLaunchKernelGGL(k_dw_fwd_plane<16>, dim3((unsigned)((long)N * C / 4)), dim3(256), 0, st, to_srcd(*in), w, out, C, stats);
+    else hipLaunchKernelGGL(k_dw_fwd_plane<32>, dim3((unsigned)((long)N * C / 4)), dim3(256), 0, st, to_srcd(*in), w, out, C, stats);
     SC_LAUNCH_OK("sc_dwconv3x3_fwd");
     return SC_OK;
   }
@@ -1538,8 +1567,13 @@ extern "C" int sc_dwconv3x3_bwd_fused(const sc_src* dy, const sc_src* in, const 
   const bool v4 = v4_env && Win % 4 == 0 && Wout % 4 == 0 &&
                   ((((uintptr_t)dy->x) | ((uintptr_t)dy->aux) | ((uintptr_t)in->x)) & 15) == 0;
   static const bool p16_env = [] { const char* e = getenv("STARCOP_DW_P16"); return !e || atoi(e) != 0; }();
-  if (p16_env && v4 && stride == 1 && Hin == 16 && Win == 16 && ((long)N * C) % 4 == 0 && ((uintptr_t)dx & 15) == 0) {      // a wave per 16x16 plane
-    hipLaunchKernelGGL(k_dw_bwd_p16, dim3((unsigned)((long)N * C / 4)), dim3(256), 0, st, to_srcd(*dy), to_srcd(*in), w, dx, dw_acc, in_sums, C);
+  // (32 x 32 planes through the same kernel measured SLOWER than the work-group-per-plane form -- backward 50 -> 63 us, forward
+  // 22 -> 27 us on features.12: 16 pixels per lane, 43 KB of LDS per work-group -- so it is opt-in: STARCOP_DW_P32=1)
+  static const bool p32_env = [] { const char* e = getenv("STARCOP_DW_P32"); return e && atoi(e) != 0; }();
+  const bool plane_ok = v4 && stride == 1 && Hin == Win && ((long)N * C) % 4 == 0 && ((uintptr_t)dx & 15) == 0;
+  if (plane_ok && ((p16_env && Hin == 16) || (p16_env && p32_env && Hin == 32))) {      // a wave per plane
+    if (Hin == 16) hipLaunchKernelGGL(k_dw_bwd_plane<16>, dim3((unsigned)((long)N * C / 4)), dim3(256), 0, st, to_srcd(*dy), to_srcd(*in), w, dx, dw_acc, in_sums, C);
+    else hipLaunchKernelGGL(k_dw_bwd_plane<32>, dim3((unsigned)((long)N * C / 4)), dim3(256), 0, st, to_srcd(*dy), to_srcd(*in), w, dx, dw_acc, in_sums, C);
     SC_LAUNCH_OK("sc_dwconv3x3_bwd_fused");
     return SC_OK;
   }
