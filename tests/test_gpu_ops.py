@@ -803,6 +803,17 @@ def test_wave_specialised_kernel_covers_every_feature():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_depthwise_plane_kernels_at_32():
+    """The wave-per-plane depthwise kernels also exist for 32 x 32 planes (opt-in: measured slower there than the work-group form).
+    Re-run the depthwise op tests -- they contain 32 x 32 stride-1 cases with N * C % 4 == 0 -- in a child process with
+    STARCOP_DW_P32=1 so that the template stays correct for both sizes."""
+    import subprocess, sys
+    env = dict(os.environ, STARCOP_DW_P32="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "(dw_bwd_fused or test_depthwise) and not plane_kernels"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("cin,cout,co_t,H,W,act", [(144, 24, 64, 20, 28, ACT_RELU6), (96, 16, 32, 32, 32, ACT_RELU6), (40, 8, 32, 7, 9, ACT_RELU),
                                                    (576, 96, 64, 8, 8, ACT_RELU6), (32, 16, 32, 64, 64, ACT_NONE)])
 def test_pw_dgrad_fused_bn_backward_sums(hip, cin, cout, co_t, H, W, act):
