@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
 
   __shared__ __attribute__((aligned(16))) float s_w[2][WCH];
   __shared__ float s_p[2][KC * PCH];
-  __shared__ float s_red[4][CO_T][2];
+  __shared__ float s_red[8][CO_T][2];       // [wave][16-lane row of the half-wave]: two partials per 32-pixel sum, see row_sum16
   __shared__ __attribute__((aligned(16))) float s_bc[CO_T * 4];      // fused BatchNorm-backward reduction: (scale, shift, mean, invstd) of the tile's channels
 
   const int tid = threadIdx.x;
@@ -348,9 +348,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
         const bool ok = pix_ok && (cot * CO_T + col < Climit);
         if (!ok) v = 0.f;
         if (want_stats) {
-          const float s = half_sum32(v);
-          const float ss = half_sum32(v * v);
-          if (l31 == SC_HALF_SUM_LANE) { s_red[wave][col][0] = s; s_red[wave][col][1] = ss; }
+          const float s = row_sum16(v);
+          const float ss = row_sum16(v * v);
+          if ((l31 & 15) == 0) { s_red[2 * wave + (l31 >> 4)][col][0] = s; s_red[2 * wave + (l31 >> 4)][col][1] = ss; }
         }
         if (want_bnb) {
           const float4 c = *reinterpret_cast<const float4*>(&s_bc[col * 4]);       // scale, shift, mean, invstd
@@ -358,9 +358,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
           const float yh = fmaf(yv, c.x, c.y);
           const float gb = (yh > blo && yh < bhi) ? v : 0.f;
           bmx = fmaxf(bmx, fabsf(gb * c.x));
-          const float s = half_sum32(gb);
-          const float ss = half_sum32(gb * ((yv - c.z) * c.w));
-          if (l31 == SC_HALF_SUM_LANE) { s_red[wave][col][0] = s; s_red[wave][col][1] = ss; }
+          const float s = row_sum16(gb);
+          const float ss = row_sum16(gb * ((yv - c.z) * c.w));
+          if ((l31 & 15) == 0) { s_red[2 * wave + (l31 >> 4)][col][0] = s; s_red[2 * wave + (l31 >> 4)][col][1] = ss; }
         }
         if (ok) {
           const unsigned off = loff + (unsigned)cu * hw32;
@@ -387,9 +387,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
       const bool ok = pix_ok && (co < p.Cout);
       if (!ok) v = 0.f;
       if (want_stats) {
-        const float s = half_sum32(v);
-        const float ss = half_sum32(v * v);
-        if (l31 == SC_HALF_SUM_LANE) { s_red[wave][col][0] = s; s_red[wave][col][1] = ss; }
+        const float s = row_sum16(v);
+        const float ss = row_sum16(v * v);
+        if ((l31 & 15) == 0) { s_red[2 * wave + (l31 >> 4)][col][0] = s; s_red[2 * wave + (l31 >> 4)][col][1] = ss; }
       }
       if (ok) {
         float* o; size_t idx; int accum;
@@ -411,7 +411,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
       const int col = tid >> 1, k = tid & 1;
       const int co = cot * CO_T + col;
       if (co < p.Cout) {
-        const float t = s_red[0][col][k] + s_red[1][col][k] + s_red[2][col][k] + s_red[3][col][k];
+        // (the association of the former half-wave sums: bit-identical statistics)
+        const float t = (((s_red[0][col][k] + s_red[1][col][k]) + (s_red[2][col][k] + s_red[3][col][k])) + (s_red[4][col][k] + s_red[5][col][k])) +
+                        (s_red[6][col][k] + s_red[7][col][k]);
         p.stats[(((size_t)n * per_img + tile) * p.Cout + co) * 2 + k] = t;
       }
     }
@@ -423,7 +425,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
       const int col = tid >> 1, k = tid & 1;
       const int co = cot * CO_T + col;
       if (co < p.Cout) {
-        const float t = s_red[0][col][k] + s_red[1][col][k] + s_red[2][col][k] + s_red[3][col][k];
+        // (the association of the former half-wave sums: bit-identical statistics)
+        const float t = (((s_red[0][col][k] + s_red[1][col][k]) + (s_red[2][col][k] + s_red[3][col][k])) + (s_red[4][col][k] + s_red[5][col][k])) +
+                        (s_red[6][col][k] + s_red[7][col][k]);
         p.bnb_sums[(((size_t)n * per_img + tile) * p.Cout + co) * 2 + k] = (double)t;
       }
     }

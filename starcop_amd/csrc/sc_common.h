@@ -107,6 +107,15 @@ __device__ __forceinline__ float half_sum32(float v) {
   return v;
 }
 constexpr int SC_HALF_SUM_LANE = 16;
+// the first four steps only: every lane holds the sum of its 16-lane row.  Callers that keep one partial per ROW (two per
+// half-wave) save the row_bcast step, the one DPP step the compiler cannot fold into its add (row mask => v_mov_b32_dpp + add).
+__device__ __forceinline__ float row_sum16(float v) {
+  SC_DPP_ADD(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
+  SC_DPP_ADD(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
+  SC_DPP_ADD(v, 0x141, 0xF);   // row_half_mirror
+  SC_DPP_ADD(v, 0x140, 0xF);   // row_mirror
+  return v;
+}
 
 // sums nparts rows of E floats (part[k][i]) into out[i]; uses `scratch` (>= sc_reduce_scratch_floats)
 // for the intermediate levels.  Defined in elementwise.hip.

@@ -2,7 +2,7 @@
 import re, subprocess, sys, os, tempfile
 src = sys.argv[1]; pat = sys.argv[2] if len(sys.argv) > 2 else ""
 d = os.path.dirname(os.path.abspath(src)); out = os.path.join(tempfile.gettempdir(), os.path.basename(src) + ".s")
-extra = ["-fno-slp-vectorize"] if "bx3" in src else []
+extra = ["-fno-slp-vectorize"] if ("bx3" in src or "conv_mfma" in src) else []
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{d}/../../include", f"-I{d}", "-Wno-unused-result",
                 *extra, "-S", "--cuda-device-only", src, "-o", out], check=True, stderr=subprocess.DEVNULL)
 s = open(out).read()
