@@ -96,8 +96,10 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // sum over the 32 lanes of each half-wave with DPP adds (one VALU instruction each, no LDS crossbar traffic):
 // quad_perm, quad_perm, row_half_mirror, row_mirror -> 16-lane row sums in every lane; row_bcast15 into rows 1 and 3
 // -> lanes 16..31 hold the sum of lanes 0..31, lanes 48..63 the sum of lanes 32..63.  Read the result at (lane&31)==16.
+// (bound_ctrl for the full-mask permutations: every lane has a valid source there, and with it the compiler folds the DPP move into
+// the add -- v_add_f32_dpp -- for all of them instead of for the quad permutations only)
 #define SC_DPP_ADD(v, ctrl, rmask) \
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xF, false))
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xF, (rmask) == 0xF))
 __device__ __forceinline__ float half_sum32(float v) {
   SC_DPP_ADD(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
   SC_DPP_ADD(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
