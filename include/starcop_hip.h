@@ -263,19 +263,22 @@ int sc_bn_finalize(const float* stats, int nrows, double count, const float* gam
 /* sums[row][C][2] = { sum g_bn, sum g_bn * xhat } over the row's pixels, g_bn = g * act'(BN(y));
  * rows = sc_stat_rows(SC_STAT_BNBWD, N, H, W).
  * absmax (optional, device float, zeroed by the caller before the first launch of a step): raised to
- * max_c |gamma_c * invstd_c| * max |g_bn| by an order-independent atomic max -- the range hint of the SC_TERMS_F16X2 kernels */
+ * max_c |gamma_c * invstd_c| * max |g_bn| by an order-independent atomic max -- the range hint of the SC_TERMS_F16X2 kernels.
+ * act_absmax (optional, device float, NEVER lowered -- a sticky record): raised to max |act(BN(y))|, the largest activation
+ * value a consumer of this tensor stages; the two-fp16-term kernels need it below 32752 (HyperStarcopUNet.split_range_report) */
 int sc_bn_bwd_reduce(const float* g, const float* y, const float* cst_fwd, int act,
-                     double* sums, int N, int C, int HW, float* absmax, sc_stream stream);
+                     double* sums, int N, int C, int HW, float* absmax, float* act_absmax, sc_stream stream);
 /* dgamma, dbeta and the SC_SRC_BNBWD constants {scale, shift, A, B, D} */
 int sc_bn_bwd_finalize(const double* sums, int nrows, double count, const float* cst_fwd,
                        float* dgamma, float* dbeta, float* cst_bwd, int C, sc_stream stream);
 /* both steps in one launch for few-pixel layers (one block per channel over all N*HW elements); same outputs */
 int sc_bn_bwd_small(const float* g, const float* y, const float* cst_fwd, int act, int N, int C, int HW,
-                    float* dgamma, float* dbeta, float* cst_bwd, float* absmax, sc_stream stream);
+                    float* dgamma, float* dbeta, float* cst_bwd, float* absmax, float* act_absmax, sc_stream stream);
 /* out = v(a) + v(b)   (residual add of an inverted-residual block; b may be NULL) */
 int sc_add_srcs(const sc_src* a, const sc_src* b, float* out, int N, int C, int HW, sc_stream stream);
 /* same, and *absmax (device float, never lowered) is raised to max |out|: the range evidence for residual sums that feed a
- * two-fp16-term convolution without a BatchNorm in between (smp skip connections taken after an inverted-residual add) */
+ * two-fp16-term convolution without a BatchNorm in between (smp skip connections taken after an inverted-residual add).
+ * out may be NULL (b too): then the call only records max |v(a)| -- the inference-time range check of a BatchNorm'd tensor */
 int sc_add_srcs_absmax(const sc_src* a, const sc_src* b, float* out, int N, int C, int HW, float* absmax, sc_stream stream);
 /* out[n,c,y,x] (+)= sum of the 2x2 block of in (backward of nearest x2 upsample) */
 int sc_downsum2x2(const float* in, float* out, int accum, int N, int C, int Hout, int Wout,

@@ -125,7 +125,7 @@ __device__ __forceinline__ void block_absmax_to(float m, float factor, float* sl
 
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ g, const float* __restrict__ y,
                                                        const float* __restrict__ cst, int act, double* __restrict__ sums, int C, int HW,
-                                                       float* __restrict__ absmax) {
+                                                       float* __restrict__ absmax, float* __restrict__ act_absmax) {
   __shared__ double s_tmp[8];
   __shared__ float s_m[4];
   const int c = blockIdx.y, n = blockIdx.z;
@@ -135,7 +135,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
   const size_t base = ((size_t)n * C + c) * HW;
   const int start = blockIdx.x * 4096;
   const int end = min(start + 4096, HW);
-  float s1 = 0.f, s2 = 0.f, mx = 0.f;
+  // ax: largest |BatchNorm output| seen (the activation clamps only towards zero, so this bounds |act(BN(y))|): the device-side
+  // range record of the tensors that feed the two-fp16-term kernels -- one v_max per element in a pass that reads y anyway
+  float s1 = 0.f, s2 = 0.f, mx = 0.f, ax = 0.f;
   if ((HW & 3) == 0) {
     for (int i = start + threadIdx.x * 4; i < end; i += 1024) {
       const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
@@ -148,6 +150,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
         s1 += gb;
         s2 = fmaf(gb, (ya[k] - mean) * invstd, s2);
         mx = fmaxf(mx, fabsf(gb));
+        ax = fmaxf(ax, fabsf(yh));
       }
     }
   } else {
@@ -158,12 +161,17 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
       s1 += gb;
       s2 = fmaf(gb, (yv - mean) * invstd, s2);
       mx = fmaxf(mx, fabsf(gb));
+      ax = fmaxf(ax, fabsf(yh));
     }
   }
   double v[2] = {(double)s1, (double)s2};
   block_sum_d<2>(v, s_tmp);
   if (threadIdx.x < 2) sums[(stat_row() * C + c) * 2 + threadIdx.x] = v[threadIdx.x];
   if (absmax) block_absmax_to(mx, scale, absmax, s_m);
+  if (act_absmax) {
+    __syncthreads();
+    block_absmax_to(act == SC_ACT_RELU6 ? fminf(ax, 6.f) : ax, 1.f, act_absmax, s_m);
+  }
 }
 
 // Low-resolution layers: one block per channel walks all N*HW elements of its channel and finalises in the same launch
@@ -172,10 +180,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
 __global__ __launch_bounds__(256) void k_bn_bwd_small(const float* __restrict__ g, const float* __restrict__ y,
                                                       const float* __restrict__ cst, int act, int N, int C, int HW, double count,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ cst_bwd,
-                                                      float* __restrict__ absmax) {
+                                                      float* __restrict__ absmax, float* __restrict__ act_absmax) {
   __shared__ double s_tmp[8];
   __shared__ float s_m[4];
-  float mx = 0.f;
+  float mx = 0.f, ax = 0.f;
   const int c = blockIdx.x;
   const float scale = cst[(size_t)c * SC_CST], shift = cst[(size_t)c * SC_CST + 1];
   const float mean = cst[(size_t)c * SC_CST + 2], invstd = cst[(size_t)c * SC_CST + 3];
@@ -190,6 +198,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_small(const float* __restrict__ 
       s1 += gb;
       s2 = fmaf(gb, (ya[k] - mean) * invstd, s2);
       mx = fmaxf(mx, fabsf(gb));
+      ax = fmaxf(ax, fabsf(yh));
     }
   };
   if ((HW & 3) == 0) {
@@ -229,12 +238,17 @@ __global__ __launch_bounds__(256) void k_bn_bwd_small(const float* __restrict__ 
         s1 += gb;
         s2 = fmaf(gb, (yv - mean) * invstd, s2);
         mx = fmaxf(mx, fabsf(gb));
+        ax = fmaxf(ax, fabsf(yh));
       }
       v[0] += (double)s1; v[1] += (double)s2;
     }
   }
   block_sum_d<2>(v, s_tmp);
   if (absmax) block_absmax_to(mx, scale, absmax, s_m);
+  if (act_absmax) {
+    __syncthreads();
+    block_absmax_to(act == SC_ACT_RELU6 ? fminf(ax, 6.f) : ax, 1.f, act_absmax, s_m);
+  }
   if (threadIdx.x != 0) return;
   const double t1 = v[0], t2 = v[1];
   if (dbeta) dbeta[c] = (float)t1;
@@ -295,7 +309,7 @@ __global__ __launch_bounds__(256) void k_add_srcs(const SrcD a, const SrcD b, in
   for (int i = start + threadIdx.x; i < end; i += 256) {
     float v = ld_src(a, base + i, a0, a4);
     if (has_b) v += ld_src(b, base + i, b0, b4);
-    out[base + i] = v;
+    if (out) out[base + i] = v;
     mx = fmaxf(mx, fabsf(v));
   }
   if (absmax) block_absmax_to(mx, 1.f, absmax, s_m);
@@ -575,19 +589,19 @@ extern "C" int sc_bn_finalize(const float* stats, int nrows, double count, const
 }
 
 extern "C" int sc_bn_bwd_reduce(const float* g, const float* y, const float* cst_fwd, int act, double* sums, int N, int C,
-                                int HW, float* absmax, sc_stream stream) {
+                                int HW, float* absmax, float* act_absmax, sc_stream stream) {
   SC_REQUIRE(g && y && cst_fwd && sums && N > 0 && C > 0 && HW > 0, "sc_bn_bwd_reduce: bad argument");
   dim3 grid((HW + 4095) / 4096, C, N);
-  hipLaunchKernelGGL(k_bn_bwd_reduce, grid, dim3(256), 0, (hipStream_t)stream, g, y, cst_fwd, act, sums, C, HW, absmax);
+  hipLaunchKernelGGL(k_bn_bwd_reduce, grid, dim3(256), 0, (hipStream_t)stream, g, y, cst_fwd, act, sums, C, HW, absmax, act_absmax);
   SC_LAUNCH_OK("sc_bn_bwd_reduce");
   return SC_OK;
 }
 
 extern "C" int sc_bn_bwd_small(const float* g, const float* y, const float* cst_fwd, int act, int N, int C, int HW,
-                               float* dgamma, float* dbeta, float* cst_bwd, float* absmax, sc_stream stream) {
+                               float* dgamma, float* dbeta, float* cst_bwd, float* absmax, float* act_absmax, sc_stream stream) {
   SC_REQUIRE(g && y && cst_fwd && cst_bwd && N > 0 && C > 0 && HW > 0, "sc_bn_bwd_small: bad argument");
   hipLaunchKernelGGL(k_bn_bwd_small, dim3(C), dim3(256), 0, (hipStream_t)stream, g, y, cst_fwd, act, N, C, HW,
-                     (double)N * HW, dgamma, dbeta, cst_bwd, absmax);
+                     (double)N * HW, dgamma, dbeta, cst_bwd, absmax, act_absmax);
   SC_LAUNCH_OK("sc_bn_bwd_small");
   return SC_OK;
 }
@@ -605,6 +619,7 @@ extern "C" int sc_add_srcs_absmax(const sc_src* a, const sc_src* b, float* out, 
                                   sc_stream stream) {
   SC_REQUIRE(a && a->C == C && (!b || b->C == C), "sc_add_srcs: channel mismatch");
   SC_REQUIRE(a->up == 0 && (!b || b->up == 0), "sc_add_srcs: upsampled sources unsupported");
+  SC_REQUIRE(out || absmax, "sc_add_srcs: neither an output nor an absmax record");
   dim3 grid((HW + 2047) / 2048, C, N);
   hipLaunchKernelGGL(k_add_srcs, grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*a), b ? to_srcd(*b) : empty_srcd(),
                      b ? 1 : 0, out, C, HW, absmax);

@@ -153,42 +153,82 @@ class HyperStarcopUNet(nn.Module):
     FP16_MAX_WEIGHT, FP16_MAX_ACT = 255.0, 32752.0
     range_check_every = 200     # optimiser steps between two check_split_range() calls during training (0: never)
 
-    def split_range_report(self):
-        """Largest |filter| of the split 3x3 convolutions, a bound on their BatchNorm-fed input activations, max_c(64 |gamma_c| +
-        |beta_c|) (|x_hat| <= 64 covers every realistic tile), and the largest |value| observed so far in the residual sums that
-        feed them with no BatchNorm in between (recorded by sc_add_srcs_absmax in every forward), against the limits of the
-        two-fp16-term kernels.  Synchronises the device; called after a checkpoint is loaded and every `range_check_every`
-        optimiser steps (FusedAdam), so filters / gains that grow during training are caught too."""
-        wmax = amax = rmax = 0.0
-        fin_feeds_split = {t.name for op in self._ops if op["type"] == "conv3" and _pick_cot(op["conv"].out_channels, 3) >= 32
-                           for t in op["ins"] if t.kind == "fin"}
-        for plan in self._plans.values():          # observed: residual sums have no BatchNorm to bound them
-            for n, i in plan.fin_slot.items():
-                if n in fin_feeds_split:
-                    rmax = max(rmax, float(plan.fin_amax[i]))
+    def _split_feeders(self):
+        """inputs of the split 3x3 convolutions: (BatchNorm'd tensors whose activation is not bounded by ReLU6, residual sums)"""
+        raw, fin = [], []
         for op in self._ops:
-            if op["type"] != "conv3" or _pick_cot(op["conv"].out_channels, 3) < 32:
+            if op["type"] == "conv3":        # every decoder convolution stages fp16 terms (k_conv3_bx3 / _ws / k_conv3_thin_h)
+                for t in op["ins"]:
+                    if t.kind == "fin" and t.name not in fin:
+                        fin.append(t.name)
+                    elif t.kind == "raw" and t.act != ACT_RELU6 and t.name not in raw:
+                        raw.append(t.name)
+        return raw, fin
+
+    def split_range_report(self, sync_ranks=False):
+        """The operands of the split 3x3 convolutions against the limits of the two-fp16-term kernels:
+
+        * largest |filter| (limit 255: filters are scaled by 2^8 before the fp16 conversion);
+        * ``activation_observed``: the largest |activation| that has reached one of them so far, from DEVICE-SIDE STICKY RECORDS --
+          for BatchNorm-fed inputs ``sc_bn_bwd_reduce / sc_bn_bwd_small`` leave max |BN(y)| of every training step (they stream y
+          anyway), in inference ``sc_add_srcs_absmax(out=NULL)`` records it at the ``range_check_every`` cadence; residual sums
+          (no BatchNorm bounds them) are recorded by ``sc_add_srcs_absmax`` in every forward.  The records are never lowered, so a
+          check at any later time sees every step since the last one: there is no window in which a clamp goes unnoticed;
+        * ``activation_bound``: the static bound max_c(64 |gamma_c| + |beta_c|) (|x_hat| <= 64 covers every realistic tile) --
+          what can be said about a checkpoint before any data has flowed (``load_state_dict``).
+
+        Synchronises the device.  ``sync_ranks``: MAX over the ranks of an initialised process group, so that every replica of a
+        data-parallel job takes the same decision (FusedAdam passes it; all ranks step together there)."""
+        wmax = amax = rmax = omax = 0.0
+        raw_feed, fin_feed = self._split_feeders()
+        for plan in self._plans.values():
+            for n, i in plan.fin_slot.items():
+                if n in fin_feed:
+                    rmax = max(rmax, float(plan.fin_amax[i]))
+            if plan.act_slot:
+                omax = max(omax, float(plan.act_amax.max()))
+        for op in self._ops:
+            if op["type"] != "conv3":
                 continue
             wmax = max(wmax, float(op["conv"].weight.detach().abs().max()))
             for t in op["ins"]:
                 bn = getattr(t, "bn", None)
-                if bn is not None:
+                if bn is not None and t.act != ACT_RELU6:
                     amax = max(amax, float((64.0 * bn.weight.detach().abs() + bn.bias.detach().abs()).max()))
-        return dict(max_abs_filter=wmax, filter_limit=self.FP16_MAX_WEIGHT, activation_bound=amax, activation_limit=self.FP16_MAX_ACT,
-                    residual_absmax=rmax, ok=bool(wmax < self.FP16_MAX_WEIGHT and amax < self.FP16_MAX_ACT and rmax < self.FP16_MAX_ACT))
+        if sync_ranks and torch.distributed.is_available() and torch.distributed.is_initialized() and self._pflat is not None:
+            v = torch.tensor([wmax, amax, rmax, omax], dtype=torch.float32, device=self._pflat.device)
+            torch.distributed.all_reduce(v, op=torch.distributed.ReduceOp.MAX)
+            wmax, amax, rmax, omax = (float(x) for x in v.tolist())
+        return dict(max_abs_filter=wmax, filter_limit=self.FP16_MAX_WEIGHT, activation_bound=amax, activation_observed=omax,
+                    activation_limit=self.FP16_MAX_ACT, residual_absmax=rmax,
+                    ok=bool(wmax < self.FP16_MAX_WEIGHT and max(amax, omax, rmax) < self.FP16_MAX_ACT))
 
-    def check_split_range(self):
-        """A checkpoint whose filters or BatchNorm gains leave the fp16 range of the default split is run with the
-        three-term bf16 split (fp32's exponent range) instead -- never with silently clamped operands."""
+    def check_split_range(self, sync_ranks=False):
+        """A checkpoint (or a training run) whose filters or activations leave the fp16 range of the default split continues with
+        the three-term bf16 split (fp32's exponent range); the warning says how long operands may have been clamped."""
         if self.precision != "fp32":
             return True
-        rep = self.split_range_report()
+        rep = self.split_range_report(sync_ranks)
         if not rep["ok"]:
             import warnings
-            warnings.warn(f"HyperStarcopUNet: parameters outside the range of the two-fp16-term kernels ({rep}); "
-                          f"switching to precision='fp32-x3' (three bf16 terms, no range limits)")
+            seen = max(rep["activation_observed"], rep["residual_absmax"]) >= self.FP16_MAX_ACT
+            warnings.warn(f"HyperStarcopUNet: operands outside the range of the two-fp16-term kernels ({rep}); "
+                          f"switching to precision='fp32-x3' (three bf16 terms, no range limits)"
+                          + (f"; activations beyond the limit were clamped to +-65504/2 in launches since the previous check "
+                             f"(at most {self.range_check_every} steps)" if seen else ""))
             self.precision = "fp32-x3"
         return rep["ok"]
+
+    def _record_activation_range(self, plan):
+        """inference: one streaming pass per BatchNorm-fed input of a split convolution, raising its sticky record (training steps
+        get the same record for free from the BatchNorm-backward reductions)"""
+        lib = _lib.load()
+        st = stream()
+        for name, slot in plan.act_slot.items():
+            t = self._tensors[name]
+            s = self._src_of(plan, t)
+            check(lib.sc_add_srcs_absmax(C.byref(s), None, None, plan.N, t.C, (plan.H >> t.shift) * (plan.W >> t.shift),
+                                         plan.act_amax.data_ptr() + 4 * slot, st))
 
     # -- init conventions of torchvision MobileNetV2 / smp initialize_decoder / initialize_head
     def reset_parameters(self):
@@ -367,6 +407,10 @@ class HyperStarcopUNet(nn.Module):
             fins = [t.name for t in self._tensors.values() if t.kind == "fin" and t.name != "logits"]
             plan.fin_slot = {n: i for i, n in enumerate(fins)}
             plan.fin_amax = torch.zeros(len(fins), **f32)        # running max |value| of each residual sum (never lowered)
+            raw_feed = self._split_feeders()[0]
+            plan.act_slot = {n: i for i, n in enumerate(raw_feed)}
+            plan.act_amax = torch.zeros(max(len(raw_feed), 1), **f32)   # sticky max |BN output| of the split kernels' BatchNorm-fed inputs
+            plan.n_eval = 0
             plan.has_grad = False
             self._plans[key] = plan
         if need_grad and not plan.has_grad:
@@ -611,6 +655,15 @@ class HyperStarcopUNet(nn.Module):
         if training:      # one multi-tensor launch for the 62 step counters
             torch._foreach_add_(self._nbt_list(), 1)
         plan.training = training
+        if (not training and self.precision == "fp32" and self.range_check_every and plan.act_slot
+                and not torch.cuda.is_current_stream_capturing()):
+            # inference has no backward pass to leave the activation records: stream the handful of tensors at the check cadence
+            # (first forward of a shape included) and, if one is out of range, redo THIS forward with the three-term split
+            plan.n_eval += 1
+            if plan.n_eval % self.range_check_every == 1 or self.range_check_every == 1:
+                self._record_activation_range(plan)
+                if not self.check_split_range():
+                    return self._forward_impl(x, x_cst, training, need_grad)
         return plan
 
     def _nbt_list(self):
@@ -658,8 +711,12 @@ class HyperStarcopUNet(nn.Module):
         return self._TERMS[self.precision]
     _side_stream = None
 
-    def _backward_impl(self, plan, dlogits, on_tail_ready=None):
+    def _backward_impl(self, plan, dlogits, on_tail_ready=None, only_ops=None):
         """Fills the flat gradient buffer from dL/dlogits.  Needs the plan of a training-mode forward.
+
+        ``only_ops`` (a list of indices into ``self._ops``; parity tests): run the backward of just these ops, each from whatever
+        ``plan.grad[out]`` / ``plan.buf`` / ``plan.cst`` hold -- the teacher-forced per-layer gates feed every layer the oracle's
+        activations and upstream gradient through exactly the launches a training step makes for it.
 
         ``on_tail_ready(lo, hi)`` is called once, when the walk leaves the decoder: every gradient of the decoder and head
         parameters (flat range [lo, hi), two thirds of the buffer) has been queued, so a data-parallel caller can start
@@ -723,18 +780,20 @@ class HyperStarcopUNet(nn.Module):
             if slot is not None:
                 amax = plan.gmax.data_ptr() + 4 * slot
                 gmax_slot[t.name] = amax
+            aslot = plan.act_slot.get(t.name)           # BatchNorm-fed input of a split convolution: sticky max |BN(y)| record
+            aact = plan.act_amax.data_ptr() + 4 * aslot if aslot is not None else None
             if N * Ho * Wo <= self.bn_small_max and t.C >= 64:        # low-resolution layers: one launch, one block per channel
                 check(lib.sc_bn_bwd_small(ptr(plan.grad[t.name]), ptr(plan.buf[t.name]), ptr(plan.cst[t.name]), t.act, N, t.C,
-                                          Ho * Wo, ptr(gv(t.bn.weight)), ptr(gv(t.bn.bias)), ptr(plan.cstb[t.name]), amax, st))
+                                          Ho * Wo, ptr(gv(t.bn.weight)), ptr(gv(t.bn.bias)), ptr(plan.cstb[t.name]), amax, aact, st))
                 return
             check(lib.sc_bn_bwd_reduce(ptr(plan.grad[t.name]), ptr(plan.buf[t.name]), ptr(plan.cst[t.name]), t.act,
-                                       ptr(plan.bsums_v[t.name]), N, t.C, Ho * Wo, amax, st))
+                                       ptr(plan.bsums_v[t.name]), N, t.C, Ho * Wo, amax, aact, st))
             check(lib.sc_bn_bwd_finalize(ptr(plan.bsums_v[t.name]), plan.brows[t.name], float(N * Ho * Wo), ptr(plan.cst[t.name]),
                                          ptr(gv(t.bn.weight)), ptr(gv(t.bn.bias)), ptr(plan.cstb[t.name]), t.C, st))
 
         tail_lo = sum(p.numel() for p in self.encoder.parameters())
         tail_pending = on_tail_ready is not None
-        for i in range(len(self._ops) - 1, -1, -1):
+        for i in (range(len(self._ops) - 1, -1, -1) if only_ops is None else only_ops):
             op = self._ops[i]
             ty, o = op["type"], op["out"]
             Ho, Wo = H >> o.shift, W >> o.shift
@@ -788,7 +847,8 @@ class HyperStarcopUNet(nn.Module):
                 s = self._src_of(plan, tin)
                 acc = plan.dw_acc[dw_offs[i]:dw_offs[i] + o.C * 9]
                 tok = self._pb("k_dw_*")
-                if self.fuse_dw_bwd and tin.name not in written and tin.bn is not None and tin.name in plan.dwsums:
+                if (self.fuse_dw_bwd and tin.name not in written and tin.bn is not None and tin.name in plan.dwsums
+                        and n_cons.get(tin.name, 0) == 1):      # the fused sums are complete only for a single-consumer input
                     # one pass: dx, dW and the BatchNorm-backward sums of the (6x expanded) input tensor
                     check(lib.sc_dwconv3x3_bwd_fused(C.byref(dy), C.byref(s), ptr(conv.weight), ptr(plan.grad[tin.name]), ptr(acc),
                                                      ptr(plan.dwsums[tin.name]), N, o.C, Hi, Wi, op["stride"], st))
@@ -914,18 +974,21 @@ class HyperStarcopUNet(nn.Module):
                 self._pe(tok)
                 written.add(tin.name)
         if pw_pending:
-            if plan.pw_table is None:       # descriptors are static for a plan: device table built once
+            raw = b"".join(bytes(p_) for p_ in pw_pending)
+            if plan.pw_table is None:
+                plan.pw_table = {}
+            if raw not in plan.pw_table:
+                # descriptors are static for a plan, so the device table is built once -- and another one when a descriptor changes
+                # (parameters re-flattened / moved, a partial backward of the parity tests); earlier tables stay alive because a
+                # launch on the weight-gradient stream may still be reading them
                 import numpy as np
-                raw = b"".join(bytes(p_) for p_ in pw_pending)
                 starts, nblk = [], 0
                 for p_ in pw_pending:
                     starts.append(nblk)
                     nblk += -(-int(p_.total) // 256)
-                plan.pw_table = (torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(self._pflat.device),
-                                 torch.tensor(starts, dtype=torch.int32).to(self._pflat.device), len(pw_pending), nblk, raw)
-            elif plan.pw_table[4] != b"".join(bytes(p_) for p_ in pw_pending):
-                raise RuntimeError("HyperStarcopUNet: weight-gradient reduction table changed between steps")
-            tab = plan.pw_table
+                plan.pw_table[raw] = (torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(self._pflat.device),
+                                      torch.tensor(starts, dtype=torch.int32).to(self._pflat.device), len(pw_pending), nblk)
+            tab = plan.pw_table[raw]
             tok = self._pb("k_wgrad_mfma<1> (+reduce)")
             wgrad_launch(lambda sx: check(lib.sc_wgrad_reduce_batch(ptr(tab[0]), ptr(tab[1]), tab[2], tab[3], sx)))
             self._pe(tok)

@@ -88,7 +88,9 @@ class FusedAdam(torch.optim.Adam):
         self._steps_since_check = getattr(self, "_steps_since_check", 0) + 1
         if net.range_check_every and self._steps_since_check >= net.range_check_every and not torch.cuda.is_current_stream_capturing():
             self._steps_since_check = 0
-            net.check_split_range()          # trained filters / BatchNorm gains / residual sums still inside the fp16-split range?
+            # filters, BatchNorm gains and the device-side sticky activation records (every step since the last check) still inside
+            # the fp16-split range?  MAX over the ranks of a data-parallel job: all replicas switch together or not at all
+            net.check_split_range(sync_ranks=True)
 
     @torch.no_grad()
     def step(self, closure=None):

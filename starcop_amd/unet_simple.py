@@ -213,7 +213,7 @@ class SimpleUNet(nn.Module):
             co, ci, ks = ent["co"], ent["ci"], ent["ks"]
             rows = lib.sc_stat_rows(STAT_BNBWD, N, h, w)
             sums = torch.zeros(rows, co, 2, dtype=torch.float64, device=dev)
-            check(lib.sc_bn_bwd_reduce(ptr(g), ptr(y), ptr(ent["cst"]), r["act"], ptr(sums), N, co, h * w, None, st))
+            check(lib.sc_bn_bwd_reduce(ptr(g), ptr(y), ptr(ent["cst"]), r["act"], ptr(sums), N, co, h * w, None, None, st))
             grads[name + ".bias"] = sums.sum(0)[:ent["co0"], 0].float()
             dy = make_src(g, co, SRC_BNBWD, act=r["act"], cst=ent["cst"], aux=y)
             dw, ws = self._wgrad(dy, r["srcs"], N, h, w, co, ci, ks)

@@ -58,7 +58,7 @@ def _bias_grad_and_absmax(g, y, cst, act, N, Cc, HW):
     # xhat = (y - c[2]) * c[3] is only used for the second column; cst_fwd layout {scale, shift, mean, invstd}
     cf = cst.clone(); cf[:, 2], cf[:, 3] = 0.0, 1.0
     amax = dev(torch.zeros(1))
-    check(lib.sc_bn_bwd_reduce(ptr(g), ptr(y), ptr(dev(cf)), act, ptr(sums), N, Cc, HW, ptr(amax), stream()))
+    check(lib.sc_bn_bwd_reduce(ptr(g), ptr(y), ptr(dev(cf)), act, ptr(sums), N, Cc, HW, ptr(amax), None, stream()))
     return sums.sum(0)[:, 0].float(), amax
 
 

@@ -217,3 +217,59 @@ def test_cfg3_size_properties(hip):
     assert np.median(outside) < 50
     sub, _ = hip_mag1c.acrwl1mf_by_groups(x[:, 16:32].contiguous(), t, groups[:, 16:32])
     assert np.array_equal(sub.cpu().numpy(), mf[:, 16:32])
+
+
+def test_cfg3_s125_vs_fp64_oracle(hip):
+    """BASELINE configs[2] at its stated size per group: 125 bands, 512-pixel detector-column groups, fp32 radiances, alpha = 0,
+    30 iterations (process_aviris.py:209-219 -> mag1c.py:177-280).  24 columns (24 x 31 Choleskys of 125^2 on the CPU) against
+    oracle/mag1c_ref.acrwl1mf_group evaluated in float64 ON THE SAME float32 radiances (exact arithmetic = the truth): the HIP
+    path computes in fp64, so every pixel must sit within 1e-5; and against the oracle run in the reference's own float32 within
+    its fp32 noise (1e-3 on >= 99.8 % of the pixels).  NODATA pixels inside a group and a skipped group keep the exact pattern."""
+    rng = np.random.default_rng(81)
+    S, H, W = 125, 512, 24
+    t73 = np.load(os.path.join(G, "g3_templates.npz"))["aviris_template_kept"][:, 1]
+    t = np.interp(np.linspace(0, 72, S), np.arange(73), t73)
+    base = rng.uniform(1, 6, size=S)
+    cube = base * (1 + 0.05 * rng.standard_normal((H, W, S)))
+    conc = np.zeros((H, W)); conc[200:260, 4:14] = 1500.0
+    cube = (cube * (1 + conc[..., None] * 1e-5 * t)).astype(np.float32)
+    cube[17:23, 5, 40] = hip_mag1c.NODATA                    # invalid pixels inside a group
+    cube[: H - 9, 20, 0] = hip_mag1c.NODATA                  # 9 valid pixels: group skipped (<= 10)
+    groups = np.arange(1, W + 1)[None, :].repeat(H, 0)
+    mf, alb = hip_mag1c.acrwl1mf_by_groups(torch.from_numpy(cube).to(DEV), t, groups)
+    mf, alb = mf.cpu().numpy(), alb.cpu().numpy()
+    want64, alb64 = mag1c_ref.func_by_groups(lambda xg: mag1c_ref.acrwl1mf_group(xg, t, num_iter=30, alpha=0.0), cube.astype(np.float64), groups)
+    want32, _ = mag1c_ref.func_by_groups(lambda xg: mag1c_ref.acrwl1mf_group(xg, t.astype(np.float32), num_iter=30, alpha=0.0), cube, groups)
+    assert np.array_equal(mf == hip_mag1c.NODATA, want64 == hip_mag1c.NODATA)
+    assert (mf[:, 20] == hip_mag1c.NODATA).all() and (mf[17:23, 5] == hip_mag1c.NODATA).all()
+    ok = want64 != hip_mag1c.NODATA
+    e64, ealb = rel(mf[ok], want64[ok]), rel(alb[ok], alb64[ok])
+    e32 = rel(mf[ok], want32[ok])
+    print(f"configs[2] S=125 P=512 x {W} groups: mf vs fp64 oracle max {e64.max():.2e}, albedo {ealb.max():.2e}; "
+          f"vs fp32 oracle: {np.mean(e32 > 1e-3) * 100:.3f} % of pixels over 1e-3 (max {e32.max():.2e})")
+    assert e64.max() < 1e-5 and ealb.max() < 1e-6
+    assert np.mean(e32 > 1e-3) < 2e-3
+
+
+def test_emit_full_height_block_vs_fp64_oracle(hip):
+    """one full-height EMIT block at the granule's real geometry (1280 rows, 49 bands kept of 2122-2488 nm, column_step 2,
+    alpha 1e-4, fill -9999: mag1c_emit.py:50-90) against oracle/mag1c_ref.mag1c_columns (float64): <= 1e-6 on every pixel --
+    the goldens (G10) hold 96-row cubes only, and at 2560 pixels per group the kernel walks 40 pixel tiles per band."""
+    import g9_util
+    g3 = np.load(os.path.join(G, "g3_templates.npz"))
+    sel = (g3["emit_centers"] >= 2122) & (g3["emit_centers"] <= 2488)
+    raw = g9_util.emit_cube(5150, 1280, 8, g3["emit_centers"])[..., sel]
+    raw = np.ascontiguousarray(raw)
+    raw[100:140, 2, :] = -9999.0                       # fill pixels inside a block
+    raw[:, 5, 3] = -9999.0                             # a column that is all fill in one band -> invalid
+    S = int(sel.sum())
+    assert S >= 40
+    templ = hip_mag1c.generate_template_from_bands(g3["emit_centers"][sel], g3["emit_fwhm"][sel])[:, 1]
+    mf, alb = hip_mag1c.mag1c_columns(torch.from_numpy(raw).to(DEV), templ, -9999.0, column_step=2, num_iter=30)
+    mf, alb = mf.cpu().numpy(), alb.cpu().numpy()
+    want_mf, want_alb = mag1c_ref.mag1c_columns(raw, np.asarray(templ, dtype=np.float64), -9999.0, column_step=2, num_iter=30, alpha=1e-4)
+    assert np.array_equal(mf == -9999.0, want_mf == -9999.0)
+    ok = want_mf != -9999.0
+    e, ea = rel(mf[ok], want_mf[ok]).max(), rel(alb[ok], want_alb[ok]).max()
+    print(f"EMIT block 1280 x 2 x {S}: mf {e:.2e}, albedo {ea:.2e} vs the fp64 oracle")
+    assert e < 1e-6 and ea < 1e-6

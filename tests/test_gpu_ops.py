@@ -334,10 +334,12 @@ def test_conv_two_fp16_terms(hip, cin, cout, co_t, H, W, gscale):
     rows = hip.sc_stat_rows(STAT_BNBWD, N, H, W)
     sums = torch.empty(rows * cout * 2, dtype=torch.float64, device=DEV)
     amax = torch.zeros(1, device=DEV)
+    aact = torch.full((1,), 0.25, device=DEV)            # the activation record is sticky: it is only ever raised
     gd, yd = dev(g), dev(y)
-    check(hip.sc_bn_bwd_reduce(ptr(gd), ptr(yd), ptr(dev(cf)), ACT_RELU, ptr(sums), N, cout, H * W, ptr(amax), stream()))
+    check(hip.sc_bn_bwd_reduce(ptr(gd), ptr(yd), ptr(dev(cf)), ACT_RELU, ptr(sums), N, cout, H * W, ptr(amax), ptr(aact), stream()))
     want_max = float((gm.abs().amax((0, 2, 3)) * a.abs()).max())
     assert float(amax) == pytest.approx(want_max, rel=1e-6)
+    assert float(aact) == pytest.approx(float(yh.abs().max()), rel=1e-6)     # max |BatchNorm output| >= max |relu(.)|
     dsrc = make_src(gd, cout, SRC_BNBWD, act=ACT_RELU, cst=dev(cstb), aux=yd)
     cb = 32 if cin <= 32 else 64
     (dx,), _ = conv_mfma([dsrc], pack_bx3(dev(w), cb, 1, TERMS_F16X2), N, H, W, cin, 3, cb, bx3=True, terms=TERMS_F16X2, absmax=amax)
@@ -349,10 +351,10 @@ def test_conv_two_fp16_terms(hip, cin, cout, co_t, H, W, gscale):
         dw3 = wgrad_mfma(dsrc, [src], N, H, W, cout, cin, 3, bx3=True, terms=3)
         assert relerr(dw, wz.grad) < max(1e-5, 2 * relerr(dw3, wz.grad))
     # bn_bwd_small leaves the same hint
-    amax2 = torch.zeros(1, device=DEV)
+    amax2, aact2 = torch.zeros(1, device=DEV), torch.full((1,), 1e9, device=DEV)
     dg2, db2, cb2 = torch.empty(cout, device=DEV), torch.empty(cout, device=DEV), torch.empty(cout, SC_CST, device=DEV)
-    check(hip.sc_bn_bwd_small(ptr(gd), ptr(yd), ptr(dev(cf)), ACT_RELU, N, cout, H * W, ptr(dg2), ptr(db2), ptr(cb2), ptr(amax2), stream()))
-    assert float(amax2) == float(amax)
+    check(hip.sc_bn_bwd_small(ptr(gd), ptr(yd), ptr(dev(cf)), ACT_RELU, N, cout, H * W, ptr(dg2), ptr(db2), ptr(cb2), ptr(amax2), ptr(aact2), stream()))
+    assert float(amax2) == float(amax) and float(aact2) == 1e9              # a larger record is never lowered
 
 
 @pytest.mark.parametrize("cin,cout,cs,H,W,co_t", [(80, 32, 64, 16, 64, 64), (152, 64, 128, 24, 40, 64), (32, 16, 32, 20, 36, 32), (288, 128, 256, 8, 12, 64)])
@@ -516,13 +518,13 @@ def test_batchnorm_bookkeeping(hip):
     nrows = hip.sc_stat_rows(STAT_BNBWD, N, H, W)
     sums = torch.full((nrows, C_, 2), float("nan"), dtype=torch.float64, device=DEV)
     gd = dev(g)
-    check(hip.sc_bn_bwd_reduce(ptr(gd), ptr(yd), ptr(cst), ACT_RELU6, ptr(sums), N, C_, H * W, None, stream()))
+    check(hip.sc_bn_bwd_reduce(ptr(gd), ptr(yd), ptr(cst), ACT_RELU6, ptr(sums), N, C_, H * W, None, None, stream()))
     dgm, dbt, cstb = torch.empty(C_, device=DEV), torch.empty(C_, device=DEV), torch.zeros(C_, SC_CST, device=DEV)
     check(hip.sc_bn_bwd_finalize(ptr(sums), nrows, cnt, ptr(cst), ptr(dgm), ptr(dbt), ptr(cstb), C_, stream()))
     assert relerr(dgm, gamma.grad) < TOL and relerr(dbt, beta.grad) < TOL
     # one-launch form for few-pixel layers
     dg2, db2, cb2 = torch.empty(C_, device=DEV), torch.empty(C_, device=DEV), torch.full((C_, SC_CST), float("nan"), device=DEV)
-    check(hip.sc_bn_bwd_small(ptr(gd), ptr(yd), ptr(cst), ACT_RELU6, N, C_, H * W, ptr(dg2), ptr(db2), ptr(cb2), None, stream()))
+    check(hip.sc_bn_bwd_small(ptr(gd), ptr(yd), ptr(cst), ACT_RELU6, N, C_, H * W, ptr(dg2), ptr(db2), ptr(cb2), None, None, stream()))
     assert relerr(dg2, gamma.grad) < TOL and relerr(db2, beta.grad) < TOL and relerr(cb2, cstb) < 1e-5
     dsrc = make_src(gd, C_, SRC_BNBWD, act=ACT_RELU6, cst=cstb, aux=yd)
     dyd = torch.empty_like(yd)
@@ -841,7 +843,7 @@ def test_pw_dgrad_fused_bn_backward_sums(hip, cin, cout, co_t, H, W, act):
     rrows = lib.sc_stat_rows(STAT_BNBWD, N, H, W)
     ref = torch.empty(rrows * cin * 2, dtype=torch.float64, device=DEV)
     rmax = torch.zeros(1, device=DEV)
-    check(lib.sc_bn_bwd_reduce(ptr(dx0), ptr(yin), ptr(cin_d), act, ptr(ref), N, cin, H * W, ptr(rmax), stream()))
+    check(lib.sc_bn_bwd_reduce(ptr(dx0), ptr(yin), ptr(cin_d), act, ptr(ref), N, cin, H * W, ptr(rmax), None, stream()))
     got, want = sums.sum(0), ref.view(rrows, cin, 2).sum(0)
     assert not torch.isnan(got).any()
     assert float((got - want).abs().max() / want.abs().max()) < 2e-6

@@ -340,6 +340,46 @@ def test_residual_sums_are_range_checked(hip):
     assert net.precision == "fp32-x3" and net.split_range_report()["residual_absmax"] > net.FP16_MAX_ACT
 
 
+def test_batchnorm_fed_activations_are_range_recorded_on_the_device(hip):
+    """BatchNorm-fed inputs of the fp16-split convolutions (decoder conv outputs, the features.1 skip): their largest |BN(y)| is
+    a device-side sticky record -- left by the BatchNorm-backward reductions of every training step, and by a streaming pass at
+    the check cadence in inference -- so no step runs with silently clamped activations between two checks."""
+    B, H, W = 2, 64, 64
+    model, ref = make_pair(seed=7)
+    net = model.network
+    feeders = ["encoder.features.1.conv.2"] + [f"decoder.blocks.{b}.conv{k}.1" for b in range(5) for k in (1, 2)][:-1]
+    seen = {}
+    hooks = [dict(ref.named_modules())[n].register_forward_hook(lambda m, i_, o, n=n: seen.__setitem__(n, float(o.abs().max()))) for n in feeders]
+    batch = synth_batch(B, H, W, seed=8)
+    model.train(); ref.train()
+    with torch.no_grad():
+        ref(ref_normalize(batch["input"]))
+    opt = model.configure_optimizers()["optimizer"]
+    model.fused_train_step(to_dev(batch), opt)
+    rep = net.split_range_report()
+    want = max(seen.values())
+    assert rep["ok"] and abs(rep["activation_observed"] - want) < 1e-3 * want, (rep, want)
+    # inference: a checkpoint whose running variance makes one decoder BatchNorm output explode -- nothing static can see it
+    # (gamma, beta are ordinary); the first forward records it, warns, and is redone with the three-term split
+    model2, ref2 = make_pair(seed=9)
+    sd = {k: v.clone() for k, v in model2.network.state_dict().items()}
+    sd["decoder.blocks.2.conv1.1.running_var"][:] = 1e-12
+    sd["decoder.blocks.2.conv1.1.running_mean"][:] = 3.0
+    model2.network.load_state_dict(sd)
+    assert model2.network.precision == "fp32"
+    ref2.load_state_dict({k: v.cpu() for k, v in sd.items()})
+    model2.eval(); ref2.eval()
+    with torch.no_grad():
+        want = ref2(ref_normalize(batch["input"]))
+        with pytest.warns(UserWarning, match="fp32-x3"):
+            got = model2(to_dev(batch)["input"])
+    assert model2.network.precision == "fp32-x3"
+    assert model2.network.split_range_report()["activation_observed"] > model2.network.FP16_MAX_ACT
+    assert relerr(got, want) < 1e-4
+    for h in hooks:
+        h.remove()
+
+
 def test_optimizer_checkpoint_resume(hip):
     """FusedAdam.load_state_dict: a resumed run (Lightning restores optimiser state through load_state_dict; reference
     train.py:137 resume_from_checkpoint) continues with the checkpoint's moments and step count -- parameters after the next

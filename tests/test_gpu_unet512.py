@@ -142,3 +142,65 @@ def test_bf16_mode_trains_like_fp32_at_512(hip):
     assert m32 < 0.05 * l32[0] and m16 < 0.05 * l16[0]                            # both fit the tiles
     assert abs(l16[0] - l32[0]) < 2e-2 * l32[0]                                   # same start: bf16 rounding only
     assert f32 > 0.99 and f16 > 0.99 and abs(f16 - f32) <= 0.005, (f16, f32)
+
+
+# BASELINE.json configs[3]: "4ch U-Net bf16, batch=64/GPU".  The per-GPU shape of that configuration, against the oracle.
+B64 = 64
+BF16_EVAL_GATE = 5e-2        # bf16 matrix math (8-bit operands) through 63 convolutions: measured 1-2e-2 of max |logit| (printed)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_eval_logits_b64_512(hip, prec):
+    """eval logits of a 64 x 4 x 512 x 512 batch (eval-mode BatchNorm is per tile, so the CPU oracle runs 4 of the 64 tiles:
+    first, last and two from the middle): fp32 within north_star's 1e-4; configs[3]'s bf16 mode within BF16_EVAL_GATE with
+    >= 99.5 % of the mask pixels equal to the fp32 oracle's."""
+    import bench
+    from starcop_amd import model_module as mm
+    torch.manual_seed(41)
+    model = mm.ModelModule(mm.default_settings(pos_weight=1, precision=prec))
+    from oracle.unet_ref import UnetMobileNetV2
+    ref = UnetMobileNetV2(4, 1)
+    ref.load_state_dict(model.network.state_dict())
+    model = model.to(DEV).eval(); ref.eval()
+    batch = bench.synth_batch(B64, T, T, 77, "cpu")
+    pick = [0, 21, 42, 63]
+    with torch.no_grad():
+        want = ref(ref_normalize(batch["input"][pick]))
+        got = model(batch["input"].to(DEV))
+    assert got.shape == (B64, 1, T, T)
+    e = relerr(got[pick], want)
+    agree = float(((got[pick].cpu() >= 0) == (want >= 0)).float().mean())
+    print(f"eval logits 64x4x512x512 [{prec}]: rel err {e:.2e} on tiles {pick}; mask agreement {agree:.5f}")
+    assert e < (1e-4 if prec == "fp32" else BF16_EVAL_GATE)
+    assert agree >= (0.9999 if prec == "fp32" else 0.995)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_fused_train_step_b64_512(hip, prec):
+    """one fused training step (forward + loss + backward + Adam) at configs[3]'s per-GPU batch: the loss against the fp64 oracle's
+    train-mode forward of the same 64 tiles (fp32: 1e-4, bf16: 1e-2), every parameter finite and moved."""
+    import bench
+    from starcop_amd import model_module as mm
+    torch.manual_seed(43)
+    model = mm.ModelModule(mm.default_settings(pos_weight=1, precision=prec))
+    from oracle.unet_ref import UnetMobileNetV2
+    ref = UnetMobileNetV2(4, 1)
+    ref.load_state_dict(model.network.state_dict())
+    ref = ref.double().train()
+    model = model.to(DEV).train()
+    batch = bench.synth_batch(B64, T, T, 78, "cpu")
+    with torch.no_grad():
+        want = ref(ref_normalize(batch["input"]).double())
+        loss_ref = float((F.binary_cross_entropy_with_logits(want, batch["output"].double(), reduction="none") * batch["weight_loss"].double()).mean())
+    del ref
+    before = model.network.flat_parameters().clone()
+    opt = model.configure_optimizers()["optimizer"]
+    acc = model.fused_train_step(to_dev(batch), opt)
+    loss = float(acc.item()) / (B64 * T * T)
+    got = model.network._plans[(B64, T, T)].buf["logits"]
+    e = relerr(got, want)
+    print(f"fused train step 64x4x512x512 [{prec}]: loss {loss:.6f} vs fp64 oracle {loss_ref:.6f}; train-mode logits rel err {e:.2e}")
+    assert abs(loss - loss_ref) < (1e-4 if prec == "fp32" else 1e-2) * max(1.0, abs(loss_ref))
+    assert e < (3e-4 if prec == "fp32" else 1e-1)
+    after = model.network.flat_parameters()
+    assert bool(torch.isfinite(after).all()) and float((after - before).abs().max()) > 0

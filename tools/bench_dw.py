@@ -31,7 +31,7 @@ for name, Cc, H, s in LAYERS:
     tf = timeit(lambda: check(lib.sc_dwconv3x3_bwd_fused(C.byref(ds), C.byref(xs), ptr(w), ptr(dx), ptr(acc), ptr(sums), N, Cc, H, H, s, st)))
     td = timeit(lambda: check(lib.sc_dwconv3x3_dgrad(C.byref(ds), ptr(w), ptr(dx), 0, N, Cc, H, H, s, st)))
     tw = timeit(lambda: check(lib.sc_dwconv3x3_wgrad(C.byref(ds), C.byref(xs), ptr(acc), N, Cc, H, H, s, st)))
-    tr = timeit(lambda: check(lib.sc_bn_bwd_reduce(ptr(dx), ptr(x), ptr(cx), ACT_RELU6, ptr(bs), N, Cc, H * H, None, st)))
+    tr = timeit(lambda: check(lib.sc_bn_bwd_reduce(ptr(dx), ptr(x), ptr(cx), ACT_RELU6, ptr(bs), N, Cc, H * H, None, None, st)))
     byt = 4.0 * N * Cc * (2 * Ho * Ho + 2 * H * H)
     print(f"{name:5s} C={Cc:4d} {H:3d}^2 s{s}: fused {tf*1e3:7.1f} us ({byt/tf/1e6:7.0f} GB/s)   dgrad {td*1e3:6.1f} + wgrad {tw*1e3:6.1f} + bn-reduce {tr*1e3:6.1f} = {(td+tw+tr)*1e3:7.1f} us")
     tot[0] += tf; tot[1] += td + tw; tot[2] += tr

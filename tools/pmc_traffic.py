@@ -22,5 +22,13 @@ nw, wb = per_launch(write_db, "WRITE_SIZE")
 res = {"kernel_pattern": pat, "launches": nf, "fetch_bytes_per_launch_raw": fb, "fetch_bytes_per_launch_x2": 2 * fb,
        "write_bytes_per_launch": wb, "hbm_bytes_per_launch_raw": fb + wb,
        "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `bench.py --steps 3 --warmup 1 --graph 0`"}
+# calibrated figure (profiles/r02_pmc_calibration.json: what FETCH_SIZE reports of a KNOWN 1 GiB stream in a 4 B/lane access pattern)
+import os
+cal_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "r02_pmc_calibration.json")
+if os.path.exists(cal_path):
+    cal = json.load(open(cal_path))
+    f = [v["fetch_reported_over_known"] for v in cal.values() if isinstance(v, dict) and "fetch_reported_over_known" in v][0]
+    res["fetch_calibration"] = {"FETCH_SIZE_reported_over_known": f, "file": "profiles/r02_pmc_calibration.json"}
+    res["hbm_bytes_per_launch_corrected"] = fb / f + wb
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
