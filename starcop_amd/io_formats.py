@@ -152,8 +152,18 @@ def read_tiff(path, window: Optional[Tuple[int, int, int, int]] = None, info: Op
                 for bx in range(c0 // bw, (c0 + w - 1) // bw + 1):
                     k = pl * nby * nbx + by * nbx + bx
                     rows = bh if info.tiled else min(bh, info.height - by * bh)      # tiles are always full size, strips are not
-                    f.seek(info.offsets[k])
-                    blk = _decode_block(f.read(info.counts[k]), info, rows, bw, spp)
+                    if info.counts[k] == 0:
+                        # GDAL sparse file (SPARSE_OK=TRUE): a block that was never written has offset = byte count = 0 and
+                        # reads as the nodata value (GDAL_NODATA, tag 42113) or zeros
+                        nod = info.tags.get(42113)
+                        try:
+                            fillv = float(nod[1][0].strip().strip("\0")) if nod else 0.0
+                        except (ValueError, AttributeError, IndexError):
+                            fillv = 0.0
+                        blk = np.full((rows, bw, spp), fillv, dtype=out.dtype)
+                    else:
+                        f.seek(info.offsets[k])
+                        blk = _decode_block(f.read(info.counts[k]), info, rows, bw, spp)
                     y0, x0 = by * bh, bx * bw
                     ys, ye = max(r0, y0), min(r0 + h, y0 + rows)
                     xs, xe = max(c0, x0), min(c0 + w, x0 + bw)
@@ -285,6 +295,60 @@ def open_envi(path, writable: bool = False):
     def floats(key):
         return np.array([float(v) for v in h[key]], dtype=np.float64) if key in h else None
     return cube, {"wavelengths": floats("wavelength"), "fwhm": floats("fwhm"), "header": h}
+
+
+def envi_geo_tags(header: Dict[str, object]) -> Dict[int, tuple]:
+    """GeoTIFF georeferencing tags from an ENVI header's ``map info`` (what rasterio's ``src.transform`` / ``src.crs`` carry from
+    the radiance file into the mag1c product, process_aviris.py:179-181,222-226).  ``map info = {UTM, x_ref, y_ref, easting,
+    northing, x_size, y_size, zone, North|South, datum, units=..., rotation=deg}`` becomes the affine transform GDAL's ENVI
+    driver builds (rotation in degrees, counter-clockwise, applied to the pixel axes) stored as ModelTransformationTag (34264) --
+    or ModelPixelScale (33550) + ModelTiepoint (33922) when there is no rotation -- and a GeoKeyDirectory (34735) with
+    ProjectedCSTypeGeoKey = EPSG 326zz / 327zz for WGS-84 UTM or GeographicTypeGeoKey 4326 for ``Geographic Lat/Lon``.
+    Returns {} when the header has no usable map info."""
+    mi = header.get("map info")
+    if not isinstance(mi, list) or len(mi) < 7:
+        return {}
+    proj = mi[0].strip().lower()
+    try:
+        xr, yr, e0, n0, px, py = (float(v) for v in mi[1:7])
+    except ValueError:
+        return {}
+    rot = 0.0
+    for v in mi[7:]:
+        if v.lower().replace(" ", "").startswith("rotation="):
+            rot = float(v.split("=")[1])
+    import math
+    r = -math.radians(rot)
+    gt = (e0 - (xr - 1.0) * px, math.cos(r) * px, -math.sin(r) * px, n0 + (yr - 1.0) * py, -math.sin(r) * py, -math.cos(r) * py)
+    tags: Dict[int, tuple] = {}
+    if rot == 0.0:
+        tags[33550] = (12, (px, py, 0.0))
+        tags[33922] = (12, (0.0, 0.0, 0.0, gt[0], gt[3], 0.0))
+    else:
+        tags[34264] = (12, (gt[1], gt[2], 0.0, gt[0], gt[4], gt[5], 0.0, gt[3], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0))
+    if proj == "utm" and len(mi) >= 9:
+        zone = int(float(mi[7]))
+        epsg = (32700 if mi[8].strip().lower().startswith("s") else 32600) + zone
+        # header (version 1, revision 1.0, 3 keys), GTModelType = projected, GTRasterType = PixelIsArea, ProjectedCSType
+        tags[34735] = (3, (1, 1, 0, 3, 1024, 0, 1, 1, 1025, 0, 1, 1, 3072, 0, 1, epsg))
+    elif proj.startswith("geographic"):
+        tags[34735] = (3, (1, 1, 0, 3, 1024, 0, 1, 2, 1025, 0, 1, 1, 2048, 0, 1, 4326))
+    return tags
+
+
+def gdal_metadata_tag(tags: Dict[str, object], descriptions: Sequence[str] = ()) -> Dict[int, tuple]:
+    """GDAL_METADATA (42112): the XML in which GDAL / rasterio keep dataset tags and band descriptions -- what
+    ``save_cog(..., descriptions=[...], tags={...})`` leaves in the reference's products (process_aviris.py:222-232)."""
+    def esc(v):
+        return str(v).replace("&", "&amp;").replace("<", "&lt;").replace(">", "&gt;")
+    items = []
+    for k, v in tags.items():
+        if isinstance(v, (list, tuple, np.ndarray)):
+            v = "[" + " ".join(repr(float(x)) for x in np.asarray(v).ravel()) + "]"
+        items.append(f'  <Item name="{esc(k)}">{esc(v)}</Item>')
+    for i, d in enumerate(descriptions):
+        items.append(f'  <Item name="DESCRIPTION" sample="{i}" role="description">{esc(d)}</Item>')
+    return {42112: (2, ("<GDALMetadata>\n" + "\n".join(items) + "\n</GDALMetadata>",))}
 
 
 # ------------------------------------------------------------------------------------------------ sample folders

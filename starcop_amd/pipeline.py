@@ -57,11 +57,13 @@ def stitch(cores, rects, H, W):
 
 
 @torch.no_grad()
-def tiled_logits(model, x, tile=512, halo=RECEPTIVE_HALO, batch=8, group=None):
+def tiled_logits(model, x, tile=512, halo=RECEPTIVE_HALO, batch=8, group=None, shard=None):
     """Sliding-window inference of a (C, H, W) device scene (H, W multiples of 32): the tiles are independent work items, so with
     ``torch.distributed`` initialised they are partitioned over the ranks (``parallel.sharded_map``: no collective on the data
     path, one all_gather of the core logits at the end) -- the tile-sharded mode of BASELINE configs[4].  Windows of equal
-    shape are stacked into batches of up to ``batch``.  Returns (H, W) logits on every rank."""
+    shape are stacked into batches of up to ``batch``.  Returns (H, W) logits on every rank.
+    ``shard``: None = shard whenever a process group is initialised; False = this rank infers ALL tiles of ITS scene and no
+    collective is entered (one scene per rank: ranks may hold different scenes with different tile counts)."""
     from .parallel import sharded_map
     C_, H, W = x.shape
     rects = scene_tiles(H, W, tile, halo)
@@ -80,20 +82,23 @@ def tiled_logits(model, x, tile=512, halo=RECEPTIVE_HALO, batch=8, group=None):
                     cores[i, :r[1] - r[0], :r[3] - r[2]] = lg[j, 0, r[0] - r[4]:r[1] - r[4], r[2] - r[6]:r[3] - r[6]]
         return cores
 
-    cores = sharded_map(run, rects, group=group)
+    cores = run(rects) if shard is False else sharded_map(run, rects, group=group)
     return stitch(cores, rects, H, W)
 
 
-def _merge_column_shards(t, fill, group=None):
-    """every rank filtered a disjoint set of column blocks and left ``fill`` elsewhere: merged = max over ranks (mf >= 0 and
-    albedo > 0 are above the fill value -9999)"""
+def _merge_column_shards(t, c0, c1, group=None):
+    """every rank filtered the column blocks [c0, c1) it owns: merged by OWNERSHIP -- a rank zeroes the columns it does not own
+    and the ranks SUM, so the result does not depend on how the values compare with the fill value (x + 0 + ... + 0 == x
+    exactly, fill pixels inside an owned block stay fill)"""
     import torch.distributed as dist
+    t[:, :c0] = 0
+    t[:, c1:] = 0
     if dist.get_backend(group) == "gloo" and t.is_cuda:
         h = t.cpu()
-        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
         t.copy_(h)
     else:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 
@@ -139,9 +144,10 @@ def emit_scene_predict(model, raw, wavelengths, template, fill_value=-9999.0, co
         from .parallel import shard_range
         nblk = -(-cols // step)
         lo, hi = shard_range(nblk, dist.get_rank(group), dist.get_world_size(group))
+        c0, c1 = lo * step, min(hi * step, cols)
         mf, alb = mag1c.mag1c_columns(sub, t, fill_value, column_step=column_step, num_iter=num_iter,
-                                      covariance_lerp_alpha=covariance_lerp_alpha, column_range=(lo * step, min(hi * step, cols)))
-        mf, alb = _merge_column_shards(mf, fill_value, group), _merge_column_shards(alb, fill_value, group)
+                                      covariance_lerp_alpha=covariance_lerp_alpha, column_range=(c0, c1))
+        mf, alb = _merge_column_shards(mf, c0, c1, group), _merge_column_shards(alb, c0, c1, group)
     else:
         mf, alb = mag1c.mag1c_columns(sub, t, fill_value, column_step=column_step, num_iter=num_iter,
                                       covariance_lerp_alpha=covariance_lerp_alpha)
@@ -155,7 +161,7 @@ def emit_scene_predict(model, raw, wavelengths, template, fill_value=-9999.0, co
     was = model.training
     model.eval()
     try:
-        logits = model(x[None]) if tile is None else tiled_logits(model, x, tile, halo, group=group if distributed else None)[None, None]
+        logits = model(x[None]) if tile is None else tiled_logits(model, x, tile, halo, group=group, shard=bool(distributed))[None, None]
         masks = masks_from_logits(logits.contiguous())
     finally:
         model.train(was)
@@ -170,7 +176,10 @@ def aviris_scene_mag1c(aviris_img_folder, mf_filename, albedo_filename=None, use
     and ``<name>_glt`` (sample / line look-up, ENVI) of an AVIRIS-NG flight line as BIP memmaps, keeps the bands that are not
     affected by water vapour inside ``use_wavelength_range`` (they must form a slice), builds the CH4 target from the header's
     band centres and widths, runs acrwl1mf(num_iter=30) per detector sample (groups = |GLT sample index|, pixels with index 0
-    are not data) and writes the result as tiled GeoTIFFs (BLOCKSIZE 128).  Returns (mf, albedo) device tensors.
+    are not data) and writes the result as tiled GeoTIFFs (BLOCKSIZE 128) that carry what the reference's ``save_cog`` call leaves
+    in them (process_aviris.py:179-181,219-232): the radiance file's georeferencing (ENVI ``map info`` -> GeoTIFF transform + CRS
+    keys), GDAL_NODATA, the band description and the dataset tags ``wavelengths`` (the kept band centres) and ``mag1c=acfwl1mf``.
+    The target spectrum is cast to the radiance dtype as the reference does (:199).  Returns (mf, albedo) device tensors.
     The radiance slice is uploaded once from the memmap through pinned memory; everything after that stays on the device."""
     import os
     from . import io_formats as io
@@ -183,14 +192,17 @@ def aviris_scene_mag1c(aviris_img_folder, mf_filename, albedo_filename=None, use
     idx = np.flatnonzero(keep)
     assert idx[-1] - idx[0] + 1 == idx.shape[0], "Not all indexes included. Can't be a slice!"
     target = mag1c.generate_template_from_bands(centers=wl, fwhm=meta["fwhm"])
-    spec = target[keep, 1]
+    spec = target.astype(rdn.dtype)[keep, 1]           # process_aviris.py:199: the template in the cube's dtype
     host = torch.from_numpy(np.ascontiguousarray(rdn[..., idx[0]:idx[-1] + 1], dtype=np.float32))
     x = (host.pin_memory() if torch.cuda.is_available() else host).to(device, non_blocking=True)
     groups = np.abs(np.asarray(glt[..., 0])).astype(np.int64)
     mf, alb = mag1c.func_by_groups(mag1c.Filter(spec, num_iter=30), x, groups, mask=groups != 0)
-    tags = dict(extra_tags or {})
-    tags.setdefault(42113, (2, (str(mag1c.NODATA),)))                     # GDAL_NODATA, as fill_value_default=NODATA
-    io.write_tiff(mf_filename, mf.cpu().numpy(), blocksize=128, extra_tags=tags)
+    tags = io.envi_geo_tags(meta["header"])                               # transform + crs of the radiance file
+    tags[42113] = (2, (str(mag1c.NODATA),))                               # GDAL_NODATA, as fill_value_default=NODATA
+    tags.update(extra_tags or {})
+    md = {"wavelengths": wl[keep], "mag1c": "acfwl1mf"}
+    io.write_tiff(mf_filename, mf.cpu().numpy(), blocksize=128,
+                  extra_tags={**tags, **io.gdal_metadata_tag(md, ["CH4 Absorption (ppm x m)"])})
     if albedo_filename is not None:
-        io.write_tiff(albedo_filename, alb.cpu().numpy(), blocksize=128, extra_tags=tags)
+        io.write_tiff(albedo_filename, alb.cpu().numpy(), blocksize=128, extra_tags={**tags, **io.gdal_metadata_tag(md, ["Albedo"])})
     return mf, alb

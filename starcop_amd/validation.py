@@ -181,11 +181,8 @@ def run_validation(model, dataloader, products_plot: Optional[List[str]] = None,
         with open(os.path.join(path_save_results, "results_agg.json"), "w") as fh:
             json.dump(metrics, fh, cls=CustomJSONEncoder)
         if path_save_results_remote is not None:
-            import fsspec
-            fs = fsspec.filesystem("gs")
-            if not path_save_results_remote.endswith("/"):
-                path_save_results_remote = path_save_results_remote + "/"
-            fs.put(path_save_results, path_save_results_remote, recursive=True)
+            raise NotImplementedError("run_validation: uploading the result folder to a bucket (validation.py:213-219) is outside the "
+                                      "hot path; copy path_save_results yourself")
     return out_data, metrics
 
 

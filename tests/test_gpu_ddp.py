@@ -129,12 +129,24 @@ wl = np.linspace(381.0, 2493.0, 285)
 keep = np.nonzero((wl >= 2122.0) & (wl <= 2488.0))[0]
 templ = -np.abs(rng.standard_normal(keep.size)) * 0.3 - 0.05
 raw = (rng.uniform(1, 6, size=285) * (1 + 0.05 * rng.standard_normal((rows, cols, 285)))).astype(np.float32)
+raw[:9, 3:8, :] = -9999.0            # fill pixels inside owned column blocks: the ownership merge must keep them fill
 torch.manual_seed(0)
 model = mm.ModelModule(mm.default_settings(pos_weight=1)).to("cuda:0").eval()
 single = pipeline.emit_scene_predict(model, raw, wl, templ, column_step=2, tile=64, halo=320, distributed=False)
 both = pipeline.emit_scene_predict(model, raw, wl, templ, column_step=2, tile=64, halo=320)          # shards columns and tiles
 assert torch.equal(single["mf"], both["mf"]) and torch.equal(single["albedo"], both["albedo"])
 assert torch.equal(single["prediction"], both["prediction"]) and torch.equal(single["pred_binary"], both["pred_binary"])
+assert bool((both["mf"][:9, 3:8] == -9999.0).all()) and bool((both["mf"][20:, :] != -9999.0).all())
+# one scene PER RANK with sharding switched off: different scenes, different tile counts -- no collective may be entered, and each
+# rank's tiled result must be its own whole-scene result (halo 320: bit-identical)
+r = dist.get_rank()
+rng2 = np.random.default_rng(10 + r)
+rows2, cols2 = 130 + 70 * r, 100 + 40 * r
+raw2 = (rng2.uniform(1, 6, size=285) * (1 + 0.05 * rng2.standard_normal((rows2, cols2, 285)))).astype(np.float32)
+mine = pipeline.emit_scene_predict(model, raw2, wl, templ, column_step=2, tile=64, halo=320, distributed=False)
+whole = pipeline.emit_scene_predict(model, raw2, wl, templ, column_step=2, tile=None, distributed=False)
+assert mine["prediction"].shape == whole["prediction"].shape and torch.equal(mine["prediction"], whole["prediction"])
+assert torch.equal(mine["mf"], whole["mf"])
 dist.barrier()
 if dist.get_rank() == 0:
     print("SCENE_WORLD2_OK")

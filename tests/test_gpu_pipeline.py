@@ -113,7 +113,8 @@ def test_aviris_scene_mag1c_from_envi_files(hip, tmp_path):
     folder = tmp_path / "ang20190101t000000_rdn"
     folder.mkdir()
     name = folder.name
-    for suffix, arr, dt, extra in (("img", cube, 4, f"wavelength = {{ {', '.join(f'{v:.4f}' for v in wl)} }}\nfwhm = {{ {', '.join(f'{v:.2f}' for v in fwhm)} }}\n"),
+    for suffix, arr, dt, extra in (("img", cube, 4, f"wavelength = {{ {', '.join(f'{v:.4f}' for v in wl)} }}\nfwhm = {{ {', '.join(f'{v:.2f}' for v in fwhm)} }}\n"
+                                    "map info = {UTM, 1, 1, 500000.0, 4100000.0, 5.0, 5.0, 11, North, WGS-84, units=Meters, rotation=-12.0}\n"),
                                    ("glt", glt, 3, "")):
         arr.tofile(str(folder / f"{name}_{suffix}"))
         (folder / f"{name}_{suffix}.hdr").write_text(f"ENVI\nsamples = {ns}\nlines = {nl}\nbands = {arr.shape[2]}\nheader offset = 0\n"
@@ -133,3 +134,8 @@ def test_aviris_scene_mag1c_from_envi_files(hip, tmp_path):
     info = io.tiff_info(out_mf)
     assert np.array_equal(back[0], got) and info.block == (128, 128) and info.tags[42113][1][0] == str(mag1c.NODATA)
     assert np.array_equal(io.read_tiff(out_alb)[0], alb.cpu().numpy())
+    # what the reference's save_cog call leaves in the product: transform + crs of the radiance file, description, tags
+    assert info.tags[34735][1][-1] == 32611 and abs(info.tags[34264][1][3] - 500000.0) < 1e-9
+    xml = info.tags[42112][1][0]
+    assert '<Item name="mag1c">acfwl1mf</Item>' in xml and "CH4 Absorption (ppm x m)" in xml and f"{wl[keep][0]!r}" in xml
+    assert "Albedo" in io.tiff_info(out_alb).tags[42112][1][0]

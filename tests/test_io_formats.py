@@ -241,3 +241,48 @@ def test_load_sample_matches_dataset_semantics(tmp_path):
     win = (200, 64, 128, 128)
     y = io.load_sample(str(folder), ["labelbinary"], win)
     assert y.dtype == np.float32 and np.array_equal(y[0], prods["labelbinary"][200:328, 64:192].astype(np.float32))
+
+
+def test_sparse_tiles_read_as_nodata(tmp_path):
+    """GDAL SPARSE_OK files: a tile that was never written has offset = byte count = 0 and reads as GDAL_NODATA (or zeros)"""
+    import struct
+    a = np.arange(256 * 256, dtype=np.float32).reshape(256, 256)
+    p = str(tmp_path / "sparse.tif")
+    io.write_tiff(p, a, blocksize=128, compress="deflate", extra_tags={42113: (2, ("-9999.0",))})
+    info = io.tiff_info(p)
+    raw = bytearray(open(p, "rb").read())
+    # zero the offset and byte count of tile 2 (second row, first column) inside the out-of-line TileOffsets / TileByteCounts arrays
+    n = struct.unpack_from("<H", raw, 8)[0]
+    for k in range(n):
+        tag, typ, cnt, val = struct.unpack_from("<HHII", raw, 10 + 12 * k)
+        if tag in (324, 325):
+            struct.pack_into("<I", raw, val + 4 * 2, 0)
+    open(p, "wb").write(bytes(raw))
+    back = io.read_tiff(p)[0]
+    assert (back[128:, :128] == -9999.0).all()
+    assert np.array_equal(back[:128], a[:128]) and np.array_equal(back[128:, 128:], a[128:, 128:])
+    assert (io.read_tiff(p, window=(100, 100, 60, 60))[0][28:, :28] == -9999.0).all()
+
+
+def test_envi_map_info_to_geotiff_tags(tmp_path):
+    """the georeferencing run_mag1c copies from the radiance file (process_aviris.py:179-181): ENVI map info -> GeoTIFF tags"""
+    hdr = {"map info": ["UTM", "1", "1", "500000.0", "4100000.0", "5.0", "5.0", "11", "North", "WGS-84", "units=Meters"]}
+    t = io.envi_geo_tags(hdr)
+    assert t[33550] == (12, (5.0, 5.0, 0.0)) and t[33922] == (12, (0.0, 0.0, 0.0, 500000.0, 4100000.0, 0.0))
+    assert t[34735][1][-1] == 32611 and t[34735][1][3] == 3
+    hdr["map info"] = hdr["map info"] + ["rotation=30.0"]
+    hdr["map info"][8] = "South"
+    t = io.envi_geo_tags(hdr)
+    m = t[34264][1]
+    assert 33550 not in t and t[34735][1][-1] == 32711
+    c, s_ = np.cos(np.radians(30.0)), np.sin(np.radians(30.0))
+    assert np.allclose([m[0], m[1], m[3], m[4], m[5], m[7]], [5 * c, 5 * s_, 500000.0, 5 * s_, -5 * c, 4100000.0])
+    assert io.envi_geo_tags({}) == {} and io.envi_geo_tags({"map info": ["UTM", "x"]}) == {}
+    # tags survive a write / read cycle together with the GDAL metadata the reference's save_cog leaves
+    p = str(tmp_path / "g.tif")
+    md = io.gdal_metadata_tag({"wavelengths": np.array([2122.5, 2127.5]), "mag1c": "acfwl1mf"}, ["CH4 Absorption (ppm x m)"])
+    io.write_tiff(p, np.zeros((32, 32), np.float32), blocksize=16, extra_tags={**t, **md})
+    info = io.tiff_info(p)
+    assert info.tags[34264][1] == m and info.tags[34735][1][-1] == 32711
+    xml = info.tags[42112][1][0]
+    assert '<Item name="mag1c">acfwl1mf</Item>' in xml and 'role="description">CH4 Absorption (ppm x m)</Item>' in xml and "2122.5" in xml
