@@ -137,5 +137,5 @@ def test_aviris_scene_mag1c_from_envi_files(hip, tmp_path):
     # what the reference's save_cog call leaves in the product: transform + crs of the radiance file, description, tags
     assert info.tags[34735][1][-1] == 32611 and abs(info.tags[34264][1][3] - 500000.0) < 1e-9
     xml = info.tags[42112][1][0]
-    assert '<Item name="mag1c">acfwl1mf</Item>' in xml and "CH4 Absorption (ppm x m)" in xml and f"{wl[keep][0]!r}" in xml
+    assert '<Item name="mag1c">acfwl1mf</Item>' in xml and "CH4 Absorption (ppm x m)" in xml and repr(float(wl[keep][0])) in xml
     assert "Albedo" in io.tiff_info(out_alb).tags[42112][1][0]

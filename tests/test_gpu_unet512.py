@@ -107,6 +107,9 @@ def test_train_forward_loss_b16_512(hip):
     print(f"train logits 16x4x512x512: HIP vs fp32 oracle {e32:.2e}, HIP vs fp64 oracle {e64:.2e}, fp32 oracle vs fp64 oracle {r64:.2e}; "
           f"loss {loss:.6f} vs fp64 oracle {loss_ref:.6f}")
     assert e64 < max(1e-4, 1.25 * r64)
+    # against the reference's own (fp32 CPU) path: no further from it than 1.5 x that path's own distance from the truth
+    # (measured 1.66e-4 vs 1.50e-4; 2 x 512^2 and 64 x 512^2 eval, where the fp32 path is itself inside 1e-4, are gated at 1e-4)
+    assert e32 < max(1e-4, 1.5 * r64)
     assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
     assert all(bool(torch.isfinite(p).all()) for p in model.network.parameters())
 
