@@ -50,7 +50,8 @@ enum sc_act { SC_ACT_NONE = 0, SC_ACT_RELU = 1, SC_ACT_RELU6 = 2 };
 /* BatchNorm statistics are written as per-work-group partial rows [rows][C][2] (plain stores, no atomics,
  * deterministic) and summed in fp64 by sc_bn_finalize / sc_bn_bwd_finalize.  rows = sc_stat_rows(kind, ...) */
 enum sc_stat_kind { SC_STAT_CONV3 = 0, SC_STAT_CONV1 = 1, SC_STAT_DW = 2, SC_STAT_STEM = 3, SC_STAT_BNBWD = 4,
-                    SC_STAT_CONV1K = 5 /* sc_conv1x1_ksplit: one row per 32 pixels */ };
+                    SC_STAT_CONV1K = 5 /* sc_conv1x1_ksplit: one row per 32 pixels */,
+                    SC_STAT_PW3 = 6 /* sc_conv1x1_pw3: one row per 32 flat pixels of the whole batch */ };
 
 typedef struct sc_src {
   const float* x;    /* primary tensor  [N, C, H>>up, W>>up]                          */
@@ -194,6 +195,7 @@ int sc_wgrad_reduce_batch(const sc_wgrad_pending* descs_dev, const uint32_t* blo
  * `wpk` from sc_pack_weights_thin16 (or a sc_pack_desc with bx3 = SC_PACK_THIN16); statistics rows SC_STAT_CONV3.
  * Forward, or backward-data with transpose_flip-packed filters (then "Cout" is the layer's input channel count). */
 #define SC_PACK_THIN16 5
+#define SC_PACK_PW3 6      /* sc_pack_desc.bx3 code of the pointwise layout of sc_conv1x1_pw3 (ks = 1; co_t ignored) */
 size_t sc_packed_weight_floats_thin16(int Cout, int Cin, int transpose_flip);
 int sc_pack_weights_thin16(const float* w_oihw, float* wpk, int Cout, int Cin, int transpose_flip, sc_stream stream);
 int sc_conv3x3_thin16(const sc_conv_args* a, sc_stream stream);
@@ -203,6 +205,21 @@ int sc_conv3x3_thin16(const sc_conv_args* a, sc_stream stream);
  * workspace from sc_wgrad_thin16_workspace_floats.  Replaces the fp32-MFMA thin weight gradient (the step's last MFMA-bound fp32 kernel). */
 size_t sc_wgrad_thin16_workspace_floats(int N, int H, int W, int Cout, int Cin);
 int sc_conv3x3_wgrad_thin16(const sc_wgrad_args* a, sc_stream stream);
+
+/* Pointwise (1x1) convolutions on the 16-bit matrix cores with fp32 accuracy (every fp32 operand split exactly into three bf16
+ * terms, six products, fp32 accumulation: the arithmetic of sc_conv3x3_bx3 with terms = 3), without LDS staging: the MobileNetV2
+ * encoder's expansion / projection convolutions (torchvision InvertedResidual.conv, smp.Unet's encoder at
+ * starcop/models/model_module.py:244-251), forward or backward-data (transpose_flip-packed filters, SC_SRC_BNBWD source).
+ * Same sc_conv_args as sc_conv2d_mfma with ks = 1, nsrc = 1, a single output (csplit = Cout; add0 / accum0 allowed; no add1,
+ * out1, down0, bnb_*); `wpk` from a sc_pack_desc with bx3 = SC_PACK_PW3 (sc_packed_weight_floats_pw3 floats); co_t / terms are
+ * ignored; statistics rows = sc_stat_rows(SC_STAT_PW3, N, H, W) = one row per 32 flat pixels of the batch. */
+size_t sc_packed_weight_floats_pw3(int Cout, int Cin, int transpose_flip);
+int sc_conv1x1_pw3(const sc_conv_args* a, sc_stream stream);
+/* its weight gradient (K = pixels; H*W must be a multiple of 8): same sc_wgrad_args as sc_conv2d_wgrad_mfma with ks = 1, nsrc = 1;
+ * workspace from sc_wgrad_pw3_workspace_floats; pending != NULL defers the sum over the K-slice partials to
+ * sc_wgrad_reduce_batch (as sc_conv2d_wgrad_mfma_deferred), NULL finishes it here. */
+size_t sc_wgrad_pw3_workspace_floats(int N, int H, int W, int Cout, int Cin);
+int sc_conv1x1_wgrad_pw3(const sc_wgrad_args* a, sc_wgrad_pending* pending_host, sc_stream stream);
 
 /* the 3x3 weight gradient with split-bf16 operands on the bf16 matrix cores (see sc_conv3x3_bx3); same arguments,
  * ks must be 3; workspace from sc_wgrad_bx3_workspace_floats */

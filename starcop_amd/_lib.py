@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libstarcop_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 SC_CST = 8
-STAT_CONV3, STAT_CONV1, STAT_DW, STAT_STEM, STAT_BNBWD, STAT_CONV1K = 0, 1, 2, 3, 4, 5
+STAT_CONV3, STAT_CONV1, STAT_DW, STAT_STEM, STAT_BNBWD, STAT_CONV1K, STAT_PW3 = 0, 1, 2, 3, 4, 5, 6
 
 SRC_RAW, SRC_AFFINE, SRC_BNBWD, SRC_NORM = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
@@ -136,6 +136,10 @@ SIGNATURES = {
     "sc_conv3x3_wgrad_thin16": (_i, [C.POINTER(sc_wgrad_args), _vp]),
     "sc_conv2d_wgrad_mfma_deferred": (_i, [C.POINTER(sc_wgrad_args), C.POINTER(sc_wgrad_pending), _vp]),
     "sc_wgrad_reduce_batch": (_i, [_vp, _vp, _i, C.c_uint32, _vp]),
+    "sc_packed_weight_floats_pw3": (_sz, [_i, _i, _i]),
+    "sc_conv1x1_pw3": (_i, [C.POINTER(sc_conv_args), _vp]),
+    "sc_wgrad_pw3_workspace_floats": (_sz, [_i, _i, _i, _i, _i]),
+    "sc_conv1x1_wgrad_pw3": (_i, [C.POINTER(sc_wgrad_args), C.POINTER(sc_wgrad_pending), _vp]),
     "sc_maxpool2x2": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _i, _vp]),
     "sc_upsample_bilinear2x": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _i, _vp]),
     "sc_maxpool2x2_bwd": (_i, [C.POINTER(sc_src), _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -143,6 +147,7 @@ SIGNATURES = {
     "sc_tiff_lzw_decode": (_i, [_vp, _sz, _vp, _sz, C.POINTER(C.c_size_t)]),
     "sc_tiff_unpredict": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp]),
 }
+PACK_PW3 = 6           # sc_pack_desc.bx3 code of the pointwise layout of sc_conv1x1_pw3
 PACK_THIN16 = 5        # sc_pack_desc.bx3 code of the register layout of sc_conv3x3_thin16
 TERMS_F16X2 = 4        # `terms` code of the two-fp16-term kernels (include/starcop_hip.h SC_TERMS_F16X2)
 SE_CROSS = 0xBA        # the 3x3 cross of starcop/baselines.py:39-41 as sc_binary_opening's se_bits

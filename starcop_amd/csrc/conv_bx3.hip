@@ -2264,6 +2264,21 @@ __global__ __launch_bounds__(256) void k_pack_batch(const PackDesc* __restrict__
   if (i >= d.total) return;
   if (d.bx3 == SC_PACK_THIN16) { pack_thin_item(d.w, reinterpret_cast<unsigned short*>(d.wpk), i, d.Cout, d.Cin, d.tflip); return; }
   const int M = d.tflip ? d.Cin : d.Cout, K = d.tflip ? d.Cout : d.Cin;
+  if (d.bx3 == SC_PACK_PW3) {
+    // pointwise filters for k_pw3 (conv_pw3.hip): [cout block][k step][term][lane][8] bf16, lane -> cout l&31, k = 16*step + 8*(l>>5) + j;
+    // three exact bf16 terms; cout blocks zero-padded to a multiple of 4
+    const int nks = (K + 15) / 16;
+    const int j = (int)(i % 8), lane = (int)((i / 8) % 64);
+    const int ks = (int)((i / 512) % nks), cb = (int)(i / ((size_t)512 * nks));
+    const int m = cb * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5) + j;
+    float v = 0.f;
+    if (m < M && k < K) v = d.tflip ? d.w[(size_t)k * M + m] : d.w[(size_t)m * K + k];
+    unsigned short t[3];
+    split_filter(v, false, t);
+    unsigned short* out = reinterpret_cast<unsigned short*>(d.wpk);
+    for (int c = 0; c < 3; ++c) out[((((size_t)cb * nks + ks) * 3 + c) * 64 + lane) * 8 + j] = t[c];
+    return;
+  }
   const int taps = d.ks * d.ks;
   if (!d.bx3) {
     const int kc = d.ks == 3 ? 8 : 16;
@@ -2568,6 +2583,10 @@ extern "C" int sc_conv3x3_thin16(const sc_conv_args* a, sc_stream stream) {
 
 extern "C" size_t sc_pack_work_items(int Cout, int Cin, int ks, int co_t, int transpose_flip, int bx3) {
   if (bx3 == SC_PACK_THIN16) return (size_t)thin_steps(Cout, Cin, transpose_flip) * 512;
+  if (bx3 == SC_PACK_PW3) {
+    const int M = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
+    return (size_t)(((M + 31) / 32 + 3) / 4 * 4) * ((K + 15) / 16) * 512;
+  }
   if (bx3) {
     const int M = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
     return (size_t)((M + co_t - 1) / co_t) * ((K + 15) / 16) * 9 * 2 * co_t * 8;

@@ -1312,6 +1312,8 @@ static const float* sc_identity_cst(int C) {
   return table[dev];
 }
 
+const float* sc_identity_cst_table(int C) { return sc_identity_cst(C); }
+
 extern "C" int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream) {
   SC_REQUIRE(a != nullptr, "sc_conv2d_mfma: null args");
   SC_REQUIRE(a->ks == 1 || a->ks == 3, "sc_conv2d_mfma: ks must be 1 or 3 (got %d)", a->ks);

@@ -569,6 +569,7 @@ extern "C" int sc_stat_rows(int kind, int N, int H, int W) {
     case SC_STAT_DW: return N * ((W + sc_dw_tile_w(W) - 1) / sc_dw_tile_w(W)) * ((H + sc_dw_tile_h(W) - 1) / sc_dw_tile_h(W));
     case SC_STAT_STEM: return N * ((W + 31) / 32) * ((H + 7) / 8);
     case SC_STAT_BNBWD: return N * ((H * W + 4095) / 4096);
+    case SC_STAT_PW3: return (int)(((long)N * H * W + 31) / 32);
     default: return -1;
   }
 }

@@ -131,6 +131,9 @@ int sc_reduce_rows_partial(const float* part, int nparts, size_t E, float* scrat
 // (reduction scratch of sc_reduce_scratch_floats(nparts, taps*CoP*CiP) floats follows the partials) into dw (OIHW)
 int sc_wgrad_finish(float* part, int nparts, int taps, int Cout, int Cin, int CoP, int CiP, float* dw, hipStream_t st);
 
+// device table [C][SC_CST] of identity constants (scale 1, rest 0) for RAW sources; NULL if unavailable (conv_mfma.hip)
+const float* sc_identity_cst_table(int C);
+
 // row of this work-group in a [rows][C][2] partial-statistics buffer (grid = (tiles, channel-tiles, N))
 // depthwise tile shape (outputs per block) by plane width; shared by the launchers and sc_stat_rows
 inline int sc_dw_tile_w(int W) { return W > 32 ? 64 : (W > 16 ? 32 : 16); }

@@ -26,7 +26,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD, sc_wgrad_pending,
-                   PACK_THIN16, STAT_CONV1, STAT_CONV1K, STAT_CONV3, STAT_DW, STAT_STEM, TERMS_F16X2, check, make_src, ptr,
+                   PACK_PW3, PACK_THIN16, STAT_PW3, STAT_CONV1, STAT_CONV1K, STAT_CONV3, STAT_DW, STAT_STEM, TERMS_F16X2, check, make_src, ptr,
                    sc_conv_args, sc_wgrad_args, stream)
 
 MBV2_SETTINGS = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2),
@@ -113,6 +113,28 @@ def _pick_cot(M, ks=1):
         return 32
     p32, p64 = -(-M // 32) * 32, -(-M // 64) * 64
     return 64 if p64 <= p32 * _COT_RATIO else 32
+
+
+# Pointwise convolutions on sc_conv1x1_pw3 / sc_conv1x1_wgrad_pw3 (conv_pw3.hip: split-bf16 MFMA, register-only, no LDS staging).
+# Measured per layer against k_conv_mfma<1> / k_conv1_ksplit / k_wgrad_mfma<1> at batch 16 (tools/bench_layers.py):
+# it wins where the K loop is short and the plane small (the projections' data gradients 22 -> 18 us, the 16^2 expansions 29 -> 22,
+# features.18 58 -> 38) and loses on long K loops (its waves do not split K) and on the 128^2 / 256^2 planes.  "1" = the measured
+# rule below, "all" = every pointwise launch (the tests run both), "0" = off.
+_PW3 = os.environ.get("STARCOP_PW3", "1")
+
+
+def _use_pw3(which, HW, K=0, M=0):
+    """which: 0 forward, 1 backward-data (K = the layer's output channels), 2 backward-weight (K, M = Cin, Cout; it reads 8-pixel
+    groups: H*W % 8 == 0).  K = contraction length of the launch."""
+    if _PW3 == "0" or (which == 2 and HW % 8):
+        return False
+    if _PW3 == "all":
+        return True
+    if which == 0:
+        return HW <= 4096 and (K <= 320 or (K <= 576 and HW >= 1024))
+    if which == 1:
+        return HW <= 4096 and K <= 192
+    return HW <= 1024 and K * M <= 300000 and (HW <= 256 or K * M <= 32768)
 
 
 def _use_ksplit(N, HW, K, M, ks=1):
@@ -397,13 +419,29 @@ class HyperStarcopUNet(nn.Module):
                     Ho, Wo = H >> t.shift, W >> t.shift
                     # per-work-group partial rows [rows][C][2] (plain stores; summed in fp64 by the finalize kernels)
                     kind = kind_of[op["type"]]
-                    if op["type"] == "pw" and _use_ksplit(N, Ho * Wo, op["conv"].in_channels, op["conv"].out_channels):
+                    if op["type"] == "pw" and _use_pw3(0, Ho * Wo, op["conv"].in_channels):
+                        kind = STAT_PW3
+                    elif op["type"] == "pw" and _use_ksplit(N, Ho * Wo, op["conv"].in_channels, op["conv"].out_channels):
                         kind = STAT_CONV1K
                     plan.srows[t.name] = lib.sc_stat_rows(kind, N, Ho, Wo)
                     plan.brows[t.name] = lib.sc_stat_rows(STAT_BNBWD, N, Ho, Wo)
                     plan.stats_v[t.name] = torch.empty(plan.srows[t.name] * t.C * 2, **f32)
                     plan.cst[t.name] = torch.zeros((t.C, SC_CST), **f32)
                     plan.cstb[t.name] = torch.zeros((t.C, SC_CST), **f32)
+            # which filter layouts the pointwise layers need at this resolution (sticky over all plans of the network)
+            need = getattr(self, "_pw_need", None)
+            if need is None:
+                need = self._pw_need = {}
+            for i, op in enumerate(self._ops):
+                if op["type"] == "pw":
+                    hw = (H >> op["out"].shift) * (W >> op["out"].shift)
+                    for tflip in (0, 1):
+                        cv = op["conv"]
+                        lay = "pw3" if _use_pw3(tflip, hw, cv.out_channels if tflip else cv.in_channels) else "mfma"
+                        if lay not in need.setdefault((i, tflip), set()):
+                            need[(i, tflip)].add(lay)
+                            self._pack_version = None
+                            self._pack_tables = {}
             fins = [t.name for t in self._tensors.values() if t.kind == "fin" and t.name != "logits"]
             plan.fin_slot = {n: i for i, n in enumerate(fins)}
             plan.fin_amax = torch.zeros(len(fins), **f32)        # running max |value| of each residual sum (never lowered)
@@ -450,7 +488,10 @@ class HyperStarcopUNet(nn.Module):
                 for i, op in enumerate(self._ops):
                     if op["type"] == "pw":
                         conv, o = op["conv"], op["out"]
-                        nfl = lib.sc_wgrad_workspace_floats(N, H >> o.shift, W >> o.shift, conv.out_channels, conv.in_channels, 1)
+                        Hq, Wq = H >> o.shift, W >> o.shift
+                        nfl = (lib.sc_wgrad_pw3_workspace_floats(N, Hq, Wq, conv.out_channels, conv.in_channels)
+                               if _use_pw3(2, Hq * Wq, conv.in_channels, conv.out_channels)
+                               else lib.sc_wgrad_workspace_floats(N, Hq, Wq, conv.out_channels, conv.in_channels, 1))
                         plan.pw_part[i] = torch.empty(nfl, **f32)
             plan.up_tmp = torch.empty(max(up, 1), **f32)
             plan.dw_acc = torch.zeros(n_dw, dtype=torch.float64, device=dev)
@@ -517,6 +558,12 @@ class HyperStarcopUNet(nn.Module):
                         ent["tb"] = torch.empty(lib.sc_packed_weight_floats_thin16(co, ci, 1), dtype=torch.float32, device=dev)
                 self._wpk[i] = ent
                 self._pack_tables = {}
+            if op["type"] == "pw":       # the split-bf16 layout of sc_conv1x1_pw3, where a plan runs this layer on it
+                need = getattr(self, "_pw_need", {})
+                for tflip, key in ((0, "pf"), (1, "pb")):
+                    if "pw3" in need.get((i, tflip), ()) and (ent.get(key) is None or ent[key].device != dev):
+                        ent[key] = torch.empty(lib.sc_packed_weight_floats_pw3(co, ci, tflip), dtype=torch.float32, device=dev)
+                        self._pack_tables = {}
         # one launch for all packs: device-side descriptor table, built once per (need_bwd, parameter storage)
         key = (bool(need_bwd), self._pflat.data_ptr(), self._terms)
         tab = self._pack_tables.get(key) if hasattr(self, "_pack_tables") else None
@@ -533,6 +580,8 @@ class HyperStarcopUNet(nn.Module):
                 for tflip, buf, cot, bx in ((0, ent["f"], ent["cot_f"], ent["bx3_f"]), (1, ent["b"], ent["cot_b"], ent["bx3_b"])):
                     if tflip and not need_bwd:
                         continue
+                    if op["type"] == "pw" and "mfma" not in getattr(self, "_pw_need", {}).get((i, tflip), ("mfma",)):
+                        continue        # every plan runs this layer on sc_conv1x1_pw3: the fp32-MFMA layout is not needed
                     total = lib.sc_pack_work_items(co, ci, ks, cot, tflip, int(bx))
                     rows.append((conv.weight.data_ptr(), buf.data_ptr(), co, ci, ks, cot, tflip,
                                  (ent["terms_b"] if tflip else ent["terms_f"]) if bx else 0, total))
@@ -543,6 +592,13 @@ class HyperStarcopUNet(nn.Module):
                         continue
                     total = lib.sc_pack_work_items(co, ci, ks, 16, tflip, PACK_THIN16)
                     rows.append((conv.weight.data_ptr(), buf.data_ptr(), co, ci, ks, 16, tflip, PACK_THIN16, total))
+                    starts.append(nblk)
+                    nblk += -(-total // 256)
+                for tflip, buf in ((0, ent.get("pf")), (1, ent.get("pb"))):
+                    if buf is None or (tflip and not need_bwd):
+                        continue
+                    total = lib.sc_pack_work_items(co, ci, 1, 0, tflip, PACK_PW3)
+                    rows.append((conv.weight.data_ptr(), buf.data_ptr(), co, ci, 1, 0, tflip, PACK_PW3, total))
                     starts.append(nblk)
                     nblk += -(-total // 256)
             descs = torch.from_numpy(np.array(rows, dtype=dt).view(np.uint8).copy()).to(dev)
@@ -625,7 +681,10 @@ class HyperStarcopUNet(nn.Module):
                 a.add0 = None; a.add1 = None
                 a.stats = plan.stats_v[o.name].data_ptr() if stats is not None else None
                 a.terms = ent["terms_f"]
-                if ent["tf"] is not None:
+                if ty == "pw" and _use_pw3(0, Ho * Wo, conv.in_channels):
+                    fconv = lib.sc_conv1x1_pw3
+                    a.wpk = ent["pf"].data_ptr()
+                elif ent["tf"] is not None:
                     fconv = lib.sc_conv3x3_thin16
                     a.wpk = ent["tf"].data_ptr()
                 elif ent["bx3_f"]:
@@ -892,7 +951,9 @@ class HyperStarcopUNet(nn.Module):
             if ty == "pw" and i in plan.pw_part:
                 wa.part = plan.pw_part[i].data_ptr(); wa.part_floats = plan.pw_part[i].numel()
                 pend = sc_wgrad_pending()
-                wgrad_launch(lambda sx, wa=wa, pend=pend: check(lib.sc_conv2d_wgrad_mfma_deferred(C.byref(wa), C.byref(pend), sx)))
+                wdef = (lib.sc_conv1x1_wgrad_pw3 if _use_pw3(2, Ho * Wo, conv.in_channels, conv.out_channels)
+                        else lib.sc_conv2d_wgrad_mfma_deferred)
+                wgrad_launch(lambda sx, wa=wa, pend=pend, wdef=wdef: check(wdef(C.byref(wa), C.byref(pend), sx)))
                 pw_pending.append(pend)
             else:
                 wgrad_launch(lambda sx, wfn=wfn, wa=wa: check(wfn(C.byref(wa), sx)))
@@ -911,6 +972,9 @@ class HyperStarcopUNet(nn.Module):
             a.absmax = gmax_slot.get(o.name)
             if ent["bx3_b"]:
                 conv_dgrad = lib.sc_conv3x3_bx3
+            elif ty == "pw" and _use_pw3(1, Ho * Wo, conv.out_channels):
+                conv_dgrad = lib.sc_conv1x1_pw3
+                a.wpk = ent["pb"].data_ptr()
             elif _use_ksplit(N, Ho * Wo, conv.out_channels, conv.in_channels, ks):
                 conv_dgrad = lib.sc_conv1x1_ksplit
             else:

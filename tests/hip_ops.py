@@ -104,3 +104,65 @@ def wgrad_mfma(dy, srcs, N, H, W, Cout, Cin, ks, bx3=False, terms=0, absmax=None
 def relerr(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).abs().max() / max(float(b.abs().max()), 1e-3))
+
+
+def pack_pw3(w, tflip):
+    """pointwise filter (Cout, Cin, 1, 1) -> the sc_conv1x1_pw3 layout through the batched pack launch (the network's path)"""
+    import numpy as np
+    from starcop_amd._lib import PACK_PW3
+    lib = _lib.load()
+    co, ci = w.shape[0], w.shape[1]
+    out = torch.zeros(lib.sc_packed_weight_floats_pw3(co, ci, tflip), device=DEV)
+    total = lib.sc_pack_work_items(co, ci, 1, 0, tflip, PACK_PW3)
+    dt = np.dtype([("w", "<u8"), ("wpk", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"), ("ks", "<i4"), ("co_t", "<i4"),
+                   ("tflip", "<i4"), ("bx3", "<i4"), ("total", "<u8")])
+    descs = torch.from_numpy(np.array([(w.data_ptr(), out.data_ptr(), co, ci, 1, 0, tflip, PACK_PW3, total)], dtype=dt).view(np.uint8).copy()).to(DEV)
+    starts = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _KEEP.extend([descs, starts])
+    check(lib.sc_pack_weights_batch(ptr(descs), ptr(starts), 1, -(-total // 256), stream()))
+    return out
+
+
+def conv_pw3(src, wpk, N, H, W, Cout, want_stats=False, add0=None, accum_into=None):
+    from starcop_amd._lib import STAT_PW3
+    lib = _lib.load()
+    a = sc_conv_args()
+    a.nsrc = 1
+    a.src[0] = src
+    a.wpk = wpk.data_ptr()
+    a.N, a.H, a.W, a.Cout, a.ks, a.co_t = N, H, W, Cout, 1, 32
+    out = accum_into if accum_into is not None else torch.full((N, Cout, H, W), float("nan"), device=DEV)
+    a.out0, a.out1, a.csplit = out.data_ptr(), None, Cout
+    a.accum0 = 1 if accum_into is not None else 0
+    a.add0 = add0.data_ptr() if add0 is not None else None
+    rows = lib.sc_stat_rows(STAT_PW3, N, H, W)
+    stats = torch.full((rows, Cout, 2), float("nan"), device=DEV) if want_stats else None
+    a.stats = stats.data_ptr() if want_stats else None
+    check(lib.sc_conv1x1_pw3(C.byref(a), stream()))
+    return out, stats
+
+
+def wgrad_pw3(dy, src, N, H, W, Cout, Cin, deferred=False):
+    from starcop_amd._lib import sc_wgrad_pending
+    lib = _lib.load()
+    a = sc_wgrad_args()
+    a.dy, a.nsrc = dy, 1
+    a.src[0] = src
+    a.N, a.H, a.W, a.Cout, a.Cin, a.ks = N, H, W, Cout, Cin, 1
+    n = lib.sc_wgrad_pw3_workspace_floats(N, H, W, Cout, Cin)
+    ws = torch.empty(n, device=DEV)
+    a.part, a.part_floats = ws.data_ptr(), n
+    dw = torch.full((Cout, Cin, 1, 1), float("nan"), device=DEV)
+    a.dw = dw.data_ptr()
+    _KEEP.append(ws)
+    if not deferred:
+        check(lib.sc_conv1x1_wgrad_pw3(C.byref(a), None, stream()))
+        return dw
+    pend = sc_wgrad_pending()
+    check(lib.sc_conv1x1_wgrad_pw3(C.byref(a), C.byref(pend), stream()))
+    import numpy as np
+    descs = torch.from_numpy(np.frombuffer(bytes(pend), dtype=np.uint8).copy()).to(DEV)
+    starts = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _KEEP.extend([descs, starts])
+    check(lib.sc_wgrad_reduce_batch(ptr(descs), ptr(starts), 1, -(-int(pend.total) // 256), stream()))
+    return dw

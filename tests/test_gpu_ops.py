@@ -848,3 +848,73 @@ def test_pw_dgrad_fused_bn_backward_sums(hip, cin, cout, co_t, H, W, act):
     assert not torch.isnan(got).any()
     assert float((got - want).abs().max() / want.abs().max()) < 2e-6
     assert float(amax) == pytest.approx(float(rmax), rel=1e-6)
+
+
+# ---- pointwise convolutions on the split-bf16 MFMA without LDS staging (conv_pw3.hip)
+PW3_SHAPES = [(16, 96, 2, 64, 64), (64, 384, 3, 32, 32), (384, 64, 2, 32, 32), (160, 960, 2, 16, 16), (960, 320, 2, 16, 16), (24, 144, 2, 24, 40),
+              (144, 24, 1, 20, 12), (320, 1280, 2, 4, 6), (32, 16, 1, 2, 2), (96, 576, 5, 2, 3), (40, 8, 2, 1, 1)]
+
+
+@pytest.mark.parametrize("cin,cout,N,H,W", PW3_SHAPES)
+def test_conv_pw3_forward_affine_stats(hip, cin, cout, N, H, W):
+    """sc_conv1x1_pw3 forward: ReLU6(BatchNorm) prologue, fp32-accurate three-bf16-term contraction, per-32-pixel statistics rows;
+    against F.conv2d in float64: <= 2e-6 of the largest output (one fp32 rounding per product + fp32 accumulation)"""
+    from hip_ops import conv_pw3, pack_pw3
+    x, w = rnd(N, cin, H, W, seed=1, scale=3.0), rnd(cout, cin, 1, 1, seed=2, scale=0.3)
+    cst = torch.rand(cin, SC_CST, generator=torch.Generator().manual_seed(3)) + 0.5
+    for mode, act in ((SRC_AFFINE, ACT_RELU6), (SRC_RAW, ACT_NONE)):
+        src = make_src(dev(x), cin, mode, act=act, cst=dev(cst) if mode == SRC_AFFINE else None)
+        xin = x.double() if mode == SRC_RAW else act_ref(x.double() * cst[:, 0].double()[None, :, None, None] + cst[:, 1].double()[None, :, None, None], act)
+        ref = F.conv2d(xin, w.double())
+        out, st = conv_pw3(src, pack_pw3(dev(w), 0), N, H, W, cout, want_stats=True)
+        assert relerr(out, ref) < 2e-6, mode
+        assert not torch.isnan(st).any()
+        assert relerr(st.sum(0)[:, 0], ref.sum((0, 2, 3))) < 1e-5 and relerr(st.sum(0)[:, 1], (ref * ref).sum((0, 2, 3))) < 1e-5
+
+
+@pytest.mark.parametrize("cin,cout,N,H,W", PW3_SHAPES)
+def test_conv_pw3_dgrad_bnbwd_add_accum(hip, cin, cout, N, H, W):
+    """backward-data: the BatchNorm / activation backward applied on load (g, y -> dy), transposed filter, the residual gradient
+    added in the epilogue and accumulation into an existing gradient; against conv_transpose2d in float64"""
+    from hip_ops import conv_pw3, pack_pw3
+    w = rnd(cout, cin, 1, 1, seed=2, scale=0.3)
+    g, y = rnd(N, cout, H, W, seed=3) * 1e-3, rnd(N, cout, H, W, seed=4)
+    a, b = rnd(cout, seed=4) * 0.2 + 1, rnd(cout, seed=5) * 0.2
+    A, B, D = rnd(cout, seed=6) * 0.3 + 1, rnd(cout, seed=7) * 1e-4, rnd(cout, seed=8) * 1e-4
+    yh = y * a[None, :, None, None] + b[None, :, None, None]
+    gm = torch.where((yh > 0) & (yh < 6), g, torch.zeros(()))
+    dy = gm.double() * A.double()[None, :, None, None] + B.double()[None, :, None, None] * y.double() + D.double()[None, :, None, None]
+    cstb = torch.zeros(cout, SC_CST); cstb[:, 0], cstb[:, 1], cstb[:, 2], cstb[:, 3], cstb[:, 4] = a, b, A, B, D
+    dsrc = make_src(dev(g), cout, SRC_BNBWD, act=ACT_RELU6, cst=dev(cstb), aux=dev(y))
+    ref = F.conv_transpose2d(dy, w.double())
+    wpk = pack_pw3(dev(w), 1)
+    dx, _ = conv_pw3(dsrc, wpk, N, H, W, cin)
+    assert relerr(dx, ref) < 1e-5            # dy itself is formed in fp32
+    res = rnd(N, cin, H, W, seed=9) * 1e-3
+    old = rnd(N, cin, H, W, seed=10) * 1e-3
+    acc = dev(old.clone())
+    dx2, _ = conv_pw3(dsrc, wpk, N, H, W, cin, add0=dev(res), accum_into=acc)
+    assert relerr(dx2, ref + res.double() + old.double()) < 1e-5
+
+
+@pytest.mark.parametrize("cin,cout,N,H,W", [s for s in PW3_SHAPES if (s[3] * s[4]) % 8 == 0])
+@pytest.mark.parametrize("deferred", [False, True])
+def test_conv_pw3_wgrad(hip, cin, cout, N, H, W, deferred):
+    """weight gradient with K = pixels: BNBWD dy and AFFINE input split in registers; against autograd in float64; both the
+    in-place finish and the deferred batch reduction"""
+    from hip_ops import wgrad_pw3
+    x = rnd(N, cin, H, W, seed=1, scale=3.0)
+    cst = torch.rand(cin, SC_CST, generator=torch.Generator().manual_seed(3)) + 0.5
+    xin = act_ref(x.double() * cst[:, 0].double()[None, :, None, None] + cst[:, 1].double()[None, :, None, None], ACT_RELU6)
+    g, y = rnd(N, cout, H, W, seed=3) * 1e-3, rnd(N, cout, H, W, seed=4)
+    a, b = rnd(cout, seed=4) * 0.2 + 1, rnd(cout, seed=5) * 0.2
+    A, B, D = rnd(cout, seed=6) * 0.3 + 1, rnd(cout, seed=7) * 1e-4, rnd(cout, seed=8) * 1e-4
+    yh = y * a[None, :, None, None] + b[None, :, None, None]
+    gm = torch.where(yh > 0, g, torch.zeros(()))
+    dy = gm.double() * A.double()[None, :, None, None] + B.double()[None, :, None, None] * y.double() + D.double()[None, :, None, None]
+    cstb = torch.zeros(cout, SC_CST); cstb[:, 0], cstb[:, 1], cstb[:, 2], cstb[:, 3], cstb[:, 4] = a, b, A, B, D
+    dsrc = make_src(dev(g), cout, SRC_BNBWD, act=ACT_RELU, cst=dev(cstb), aux=dev(y))
+    src = make_src(dev(x), cin, SRC_AFFINE, act=ACT_RELU6, cst=dev(cst))
+    ref = torch.einsum("nohw,nihw->oi", dy, xin)[:, :, None, None]
+    dw = wgrad_pw3(dsrc, src, N, H, W, cout, cin, deferred=deferred)
+    assert relerr(dw, ref) < 1e-5
