@@ -1,0 +1,683 @@
+"""Minimal HDF5 / NetCDF-4 reader for EMIT L1B radiance granules (pure Python + numpy + zlib; no h5py / netCDF4 / HDF5 library).
+
+The reference opens an EMIT ``*_RAD_*.nc`` file with ``georeader.readers.emit.EMITImage`` (netCDF4 underneath) and hands it to
+``mag1c_emit`` (/root/reference/starcop/models/mag1c_emit.py:5,16-48; notebooks/inference_on_raw_EMIT_nc_file.ipynb cells 8-11):
+what that path reads is the ``radiance`` variable (downtrack, crosstrack, bands) float32, ``sensor_band_parameters/wavelengths``
+and ``/fwhm``, the ``_FillValue`` and, for orthorectification, ``location/glt_x`` / ``glt_y``.  A NetCDF-4 file is an HDF5 file, so
+this module implements the part of the HDF5 file format those variables use, from the published format specification
+(HDF5 File Format Specification 3.0):
+
+  * superblock versions 0-3; object headers version 1 and 2 with continuation blocks;
+  * groups as symbol tables (B-tree v1 + local heap) and as link messages -- compact, or dense in a fractal heap;
+  * datatypes: fixed-point and IEEE floating point, either byte order (+ fixed-length strings in attributes);
+  * data layouts: compact, contiguous, chunked with a version-1 B-tree (layout v3, what netCDF-C writes) and the version-4
+    single-chunk / implicit / fixed-array indexes (libver "latest");
+  * filters: deflate, shuffle, fletcher32;  attributes stored in the object header (versions 1-3) with numeric / string values.
+
+Not implemented (raises NotImplementedError with the feature's name): extensible-array and v2-B-tree chunk indexes, compound data, external / virtual storage, dense attribute storage (such attributes are skipped).
+Chunks are inflated by a thread pool (zlib releases the GIL); a hyperslab read touches only the chunks it intersects.
+"""
+import os
+import struct
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_SIG = b"\x89HDF\r\n\x1a\n"
+_UNDEF = 0xFFFFFFFFFFFFFFFF
+
+
+class H5Error(ValueError):
+    pass
+
+
+class _Buf:
+    """file bytes with offset/length-size aware readers"""
+
+    def __init__(self, data, so=8, sl=8, base=0):
+        self.d, self.so, self.sl, self.base = data, so, sl, base
+
+    def u(self, pos, n):
+        return int.from_bytes(self.d[pos:pos + n], "little")
+
+    def off(self, pos):
+        v = self.u(pos, self.so)
+        return None if v == (1 << (8 * self.so)) - 1 else v + self.base
+
+    def len_(self, pos):
+        return self.u(pos, self.sl)
+
+
+class H5Dataset:
+    def __init__(self, f, name, msgs):
+        self._f, self.name = f, name
+        self.attrs: Dict[str, object] = {}
+        self.shape: Tuple[int, ...] = ()
+        self.dtype = None
+        self.fillvalue = None
+        self._layout = None
+        self._filters: List[Tuple[int, Tuple[int, ...]]] = []
+        for typ, body in msgs:
+            if typ == 0x0001:
+                self.shape = f._dataspace(body)
+            elif typ == 0x0003:
+                self.dtype = f._datatype(body)[0]
+            elif typ == 0x0008:
+                self._layout = body
+            elif typ == 0x000B:
+                self._filters = f._filters(body)
+            elif typ in (0x0004, 0x0005):
+                self._fill_raw = (typ, body)
+            elif typ == 0x000C:
+                try:
+                    k, v = f._attribute(body)
+                    self.attrs[k] = v
+                except NotImplementedError:
+                    pass
+        if self.dtype is not None and getattr(self, "_fill_raw", None) is not None:
+            self.fillvalue = f._fill(self._fill_raw, self.dtype)
+
+    # ------------------------------------------------------------------ data access
+    def _chunk_table(self):
+        """-> (chunk_shape, {chunk origin tuple: (address, nbytes, filter_mask)}) or (None, ...) for contiguous / compact"""
+        f, b, body = self._f, self._f._b, self._layout
+        d = b.d
+        ver = d[body]
+        rank = len(self.shape)
+        if ver == 3:
+            cls = d[body + 1]
+            if cls == 0:
+                n = b.u(body + 2, 2)
+                return None, ("compact", body + 4, n)
+            if cls == 1:
+                return None, ("contiguous", b.off(body + 2), b.len_(body + 2 + b.so))
+            if cls != 2:
+                raise NotImplementedError(f"HDF5 data layout class {cls}")
+            nd = d[body + 2]
+            bt = b.off(body + 3)
+            dims = [b.u(body + 3 + b.so + 4 * i, 4) for i in range(nd)]
+            chunk = tuple(dims[:rank])
+            table = {}
+            if bt is not None:
+                f._btree1_chunks(bt, rank, table)
+            return chunk, table
+        if ver == 4:
+            cls = d[body + 1]
+            if cls == 0:
+                n = b.u(body + 2, 2)
+                return None, ("compact", body + 4, n)
+            if cls == 1:
+                return None, ("contiguous", b.off(body + 2), b.len_(body + 2 + b.so))
+            if cls != 2:
+                raise NotImplementedError(f"HDF5 data layout class {cls} (virtual / external storage)")
+            flags, nd, enc = d[body + 2], d[body + 3], d[body + 4]
+            p = body + 5
+            dims = [b.u(p + enc * i, enc) for i in range(nd)]
+            p += enc * nd
+            chunk = tuple(dims[:rank])
+            itype = d[p]; p += 1
+            filtered = bool(self._filters)
+            esize = int(np.dtype(self.dtype).itemsize) * int(np.prod(chunk))
+            nchunks = [-(-s // c) for s, c in zip(self.shape, chunk)]
+            table = {}
+            if itype == 1:                              # single chunk
+                if flags & 2:
+                    size, mask = b.len_(p), b.u(p + b.sl, 4); p += b.sl + 4
+                else:
+                    size, mask = esize, 0
+                addr = b.off(p)
+                if addr is not None:
+                    table[(0,) * rank] = (addr, size, mask)
+            elif itype == 2:                            # implicit: all chunks contiguous, unfiltered
+                addr = b.off(p)
+                for i, idx in enumerate(np.ndindex(*nchunks)):
+                    table[tuple(k * c for k, c in zip(idx, chunk))] = (addr + i * esize, esize, 0)
+            elif itype == 3:                            # fixed array
+                page_bits = d[p]; p += 1
+                hdr = b.off(p)
+                if hdr is not None:                     # undefined address: no chunk was ever written
+                    f._fixed_array(hdr, nchunks, chunk, filtered, esize, table)
+            else:
+                raise NotImplementedError({4: "extensible-array", 5: "version-2 B-tree"}.get(itype, f"type {itype}") + " chunk index")
+            return chunk, table
+        raise NotImplementedError(f"HDF5 data layout message version {ver}")
+
+    def _decode(self, raw, mask):
+        for k, (fid, cd) in reversed(list(enumerate(self._filters))):
+            if mask & (1 << k):
+                continue
+            if fid == 1:
+                raw = zlib.decompress(raw)
+            elif fid == 2:
+                n = cd[0] if cd else np.dtype(self.dtype).itemsize
+                a = np.frombuffer(raw, dtype=np.uint8)
+                m = a.size // n
+                raw = np.ascontiguousarray(a[:m * n].reshape(n, m).T).tobytes() + a[m * n:].tobytes()
+            elif fid == 3:
+                raw = raw[:-4]
+            else:
+                raise NotImplementedError(f"HDF5 filter id {fid}")
+        return raw
+
+    def read(self, sel: Optional[Sequence[slice]] = None, threads: int = 8) -> np.ndarray:
+        """the whole dataset, or the hyperslab ``sel`` (a tuple of unit-step slices, one per dimension)"""
+        rank = len(self.shape)
+        dt = np.dtype(self.dtype)
+        if sel is None:
+            sel = (slice(None),) * rank
+        sel = tuple(sel) + (slice(None),) * (rank - len(sel))
+        lo, hi = [], []
+        for s, n in zip(sel, self.shape):
+            a, b_, st = s.indices(n)
+            if st != 1:
+                raise ValueError("H5Dataset.read: unit-step slices only")
+            lo.append(a); hi.append(max(a, b_))
+        out_shape = tuple(h - l for l, h in zip(lo, hi))
+        chunk, table = self._chunk_table()
+        d = self._f._b.d
+        if chunk is None:
+            kind, addr, n = table
+            if addr is None:
+                full = np.full(self.shape, self.fillvalue if self.fillvalue is not None else 0, dtype=dt)
+            else:
+                full = np.frombuffer(d, dtype=dt, count=int(np.prod(self.shape, dtype=np.int64)), offset=addr).reshape(self.shape)
+            return np.array(full[tuple(slice(l, h) for l, h in zip(lo, hi))], dtype=dt.newbyteorder("="))
+        out = np.full(out_shape, self.fillvalue if self.fillvalue is not None else 0, dtype=dt.newbyteorder("="))
+        if rank == 0 or 0 in out_shape:
+            return out
+        ranges = [range(l // c * c, h, c) for l, h, c in zip(lo, hi, chunk)]
+        origins = [o for o in np.array(np.meshgrid(*ranges, indexing="ij")).reshape(rank, -1).T.tolist()]
+
+        def one(o):
+            ent = table.get(tuple(o))
+            if ent is None:
+                return
+            addr, n, mask = ent
+            raw = self._decode(bytes(d[addr:addr + n]), mask)
+            blk = np.frombuffer(raw, dtype=dt, count=int(np.prod(chunk))).reshape(chunk)
+            src = tuple(slice(max(l, oo) - oo, min(h, oo + c) - oo) for l, h, oo, c in zip(lo, hi, o, chunk))
+            dst = tuple(slice(max(l, oo) - l, min(h, oo + c) - l) for l, h, oo, c in zip(lo, hi, o, chunk))
+            out[dst] = blk[src]
+        if threads > 1 and len(origins) > 1:
+            with ThreadPoolExecutor(threads) as ex:
+                list(ex.map(one, origins))
+        else:
+            for o in origins:
+                one(o)
+        return out
+
+    def __getitem__(self, key):
+        if key is Ellipsis or key == slice(None):
+            return self.read()
+        key = key if isinstance(key, tuple) else (key,)
+        return self.read(key)
+
+
+class H5File:
+    """``f = H5File(path); f["radiance"].read(); f["sensor_band_parameters/wavelengths"][...]; f.keys("location")``"""
+
+    def __init__(self, path):
+        self.path = path
+        self._mm = np.memmap(path, dtype=np.uint8, mode="r")
+        data = memoryview(self._mm)
+        pos = 0
+        while bytes(data[pos:pos + 8]) != _SIG:
+            pos = 512 if pos == 0 else pos * 2
+            if pos + 8 > len(data):
+                raise H5Error(f"{path}: not an HDF5 / NetCDF-4 file")
+        ver = data[pos + 8]
+        self.superblock_version = ver
+        if ver in (0, 1):
+            so, sl = data[pos + 13], data[pos + 14]
+            p = pos + 24 + (4 if ver == 1 else 0)
+            self._b = _Buf(data, so, sl)
+            base = self._b.u(p, so)
+            self._b.base = base
+            p += 4 * so                       # base, free-space, end-of-file, driver-info addresses
+            self._root = self._b.off(p + so)  # root symbol-table entry: link name offset, object header address
+        elif ver in (2, 3):
+            so, sl = data[pos + 9], data[pos + 10]
+            self._b = _Buf(data, so, sl)
+            self._b.base = self._b.u(pos + 12, so)
+            self._root = self._b.off(pos + 12 + 3 * so)
+        else:
+            raise NotImplementedError(f"HDF5 superblock version {ver}")
+        self._cache: Dict[int, object] = {}
+
+    def close(self):
+        self._b = None
+        self._mm = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ------------------------------------------------------------------ object headers
+    def _messages(self, addr) -> List[Tuple[int, int]]:
+        """-> [(message type, body position)] of the object header at ``addr``; message bodies stay in the file buffer"""
+        b, d = self._b, self._b.d
+        out = []
+        if bytes(d[addr:addr + 4]) == b"OHDR":
+            flags = d[addr + 5]
+            p = addr + 6
+            if flags & 0x20:
+                p += 16
+            if flags & 0x10:
+                p += 4
+            szb = 1 << (flags & 3)
+            size0 = b.u(p, szb); p += szb
+            blocks = [(p, p + size0)]
+            co = 2 if flags & 0x04 else 0
+            while blocks:
+                p, end = blocks.pop(0)
+                while p + 4 + co <= end:
+                    typ, size = d[p], b.u(p + 1, 2)
+                    body = p + 4 + co
+                    if typ == 0x10:
+                        ca, cl = b.off(body), b.len_(body + b.so)
+                        if bytes(d[ca:ca + 4]) != b"OCHK":
+                            raise H5Error("object header continuation block without OCHK signature")
+                        blocks.append((ca + 4, ca + cl - 4))
+                    elif typ != 0:
+                        out.append((typ, body))
+                    p = body + size
+            return out
+        if d[addr] != 1:
+            raise H5Error(f"object header at {addr}: unknown version {d[addr]}")
+        nmsg = b.u(addr + 2, 2)
+        size0 = b.u(addr + 8, 4)
+        blocks = [(addr + 16, addr + 16 + size0)]
+        while blocks and nmsg > 0:
+            p, end = blocks.pop(0)
+            while p + 8 <= end and nmsg > 0:
+                typ, size = b.u(p, 2), b.u(p + 2, 2)
+                body = p + 8
+                nmsg -= 1
+                if typ == 0x10:
+                    blocks.append((b.off(body), b.off(body) + b.len_(body + b.so)))
+                elif typ != 0:
+                    out.append((typ, body))
+                p = body + size
+        return out
+
+    # ------------------------------------------------------------------ groups
+    def _links(self, addr) -> Dict[str, int]:
+        b, d = self._b, self._b.d
+        links: Dict[str, int] = {}
+        for typ, body in self._messages(addr):
+            if typ == 0x0011:                                    # symbol table: B-tree v1 + local heap
+                bt, heap = b.off(body), b.off(body + b.so)
+                if bytes(d[heap:heap + 4]) != b"HEAP":
+                    raise H5Error("local heap signature")
+                seg = b.off(heap + 8 + 2 * b.sl)
+                self._btree1_group(bt, seg, links)
+            elif typ == 0x0006:
+                self._link_message(body, links)
+            elif typ == 0x0002:                                  # link info: dense storage in a fractal heap
+                flags = d[body + 1]
+                p = body + 2 + (8 if flags & 1 else 0)
+                fh = b.off(p)
+                if fh is not None:
+                    self._fractal_heap_links(fh, links)
+        return links
+
+    def _link_message(self, body, links) -> int:
+        """parses one link message at ``body``; returns the position after it"""
+        b, d = self._b, self._b.d
+        if d[body] != 1:
+            raise H5Error("link message version")
+        flags = d[body + 1]
+        p = body + 2
+        ltype = 0
+        if flags & 0x08:
+            ltype = d[p]; p += 1
+        if flags & 0x04:
+            p += 8
+        if flags & 0x10:
+            p += 1
+        nb = 1 << (flags & 3)
+        n = b.u(p, nb); p += nb
+        name = bytes(d[p:p + n]).decode("utf-8", "replace"); p += n
+        if ltype == 0:
+            links[name] = b.off(p); p += b.so
+        elif ltype == 1:                                         # soft link: length + path (not followed)
+            p += 2 + b.u(p, 2)
+        else:
+            p += 2 + b.u(p, 2)
+        return p
+
+    def _btree1_group(self, addr, heap_seg, links):
+        b, d = self._b, self._b.d
+        if bytes(d[addr:addr + 4]) != b"TREE" or d[addr + 4] != 0:
+            raise H5Error("group B-tree node")
+        level, n = d[addr + 5], b.u(addr + 6, 2)
+        p = addr + 8 + 2 * b.so
+        for i in range(n):
+            child = b.off(p + b.sl + i * (b.sl + b.so))
+            if level > 0:
+                self._btree1_group(child, heap_seg, links)
+                continue
+            if bytes(d[child:child + 4]) != b"SNOD":
+                raise H5Error("symbol table node")
+            ns = b.u(child + 6, 2)
+            q = child + 8
+            for _ in range(ns):
+                noff, oh = b.u(q, b.so), b.off(q + b.so)
+                e = heap_seg + noff
+                end = e
+                while d[end] != 0:
+                    end += 1
+                links[bytes(d[e:end]).decode("utf-8", "replace")] = oh
+                q += 2 * b.so + 24
+
+    def _fractal_heap_links(self, addr, links):
+        """dense link storage: the link messages stored back to back in the heap's direct blocks"""
+        self._fractal_heap_walk(addr, lambda q: self._link_message(q, links) if self._b.d[q] == 1 else None)
+
+    def _fractal_heap_walk(self, addr, parse):
+        """calls ``parse(position) -> next position | None`` on the managed objects of a fractal heap, direct block by direct block
+        (objects are stored back to back from the start of a block; parse returns None at the first byte that is not an object)"""
+        b, d = self._b, self._b.d
+        if bytes(d[addr:addr + 4]) != b"FRHP":
+            raise H5Error("fractal heap header")
+        p = addr + 5
+        p += 2                          # heap ID length
+        io_filter_len = b.u(p, 2); p += 2
+        flags = d[p]; p += 1
+        p += 4                          # max size of managed objects
+        p += b.sl + b.so                # next huge id, huge B-tree address
+        p += b.sl + b.so                # free space, free-space manager address
+        p += 4 * b.sl                   # managed space, allocated, iterator offset, number of managed objects
+        p += 4 * b.sl                   # huge size / count, tiny size / count
+        table_width = b.u(p, 2); p += 2
+        start_size = b.len_(p); p += b.sl
+        max_direct = b.len_(p); p += b.sl
+        max_heap_bits = b.u(p, 2); p += 2
+        p += 2                          # starting rows of the root indirect block
+        root = b.off(p); p += b.so
+        root_rows = b.u(p, 2); p += 2
+        if io_filter_len:
+            raise NotImplementedError("filtered fractal heap (dense link storage)")
+        off_bytes = (max_heap_bits + 7) // 8
+        checksum = 4 if flags & 2 else 0
+
+        def direct(blk, size):
+            if blk is None or bytes(d[blk:blk + 4]) != b"FHDB":
+                return
+            q = blk + 5 + b.so + off_bytes + checksum
+            end = blk + size
+            while q is not None and q < end:
+                q = parse(q)
+
+        def indirect(blk, nrows):
+            if blk is None or bytes(d[blk:blk + 4]) != b"FHIB":
+                return
+            q = blk + 5 + b.so + off_bytes
+            max_direct_rows = 2 + (max_direct // start_size).bit_length() - 1
+            for r in range(nrows):
+                size = start_size * (1 if r < 2 else 1 << (r - 1))
+                for _ in range(table_width):
+                    child = b.off(q); q += b.so
+                    if r < max_direct_rows:
+                        direct(child, size)
+                    else:
+                        rows = (size // start_size // table_width).bit_length() - 1 + 1
+                        indirect(child, rows)
+        if root is None:
+            return
+        if root_rows == 0:
+            direct(root, start_size)
+        else:
+            indirect(root, root_rows)
+
+    # ------------------------------------------------------------------ messages
+    def _dataspace(self, body):
+        b, d = self._b, self._b.d
+        ver, rank = d[body], d[body + 1]
+        if ver == 1:
+            p = body + 8
+        elif ver == 2:
+            if d[body + 3] == 2:
+                return ()
+            p = body + 4
+        else:
+            raise NotImplementedError(f"dataspace version {ver}")
+        return tuple(b.len_(p + i * b.sl) for i in range(rank))
+
+    def _datatype(self, body):
+        """-> (numpy dtype, message size)"""
+        b, d = self._b, self._b.d
+        cls, bits0 = d[body] & 0x0F, d[body + 1]
+        size = b.u(body + 4, 4)
+        bo = ">" if bits0 & 1 else "<"
+        if cls == 0:
+            return np.dtype(f"{bo}{'i' if bits0 & 8 else 'u'}{size}"), 12
+        if cls == 1:
+            if size not in (2, 4, 8):
+                raise NotImplementedError(f"{size}-byte floating-point type")
+            return np.dtype(f"{bo}f{size}"), 20
+        if cls == 3:
+            return np.dtype(f"S{size}"), 8
+        if cls == 9 and (bits0 & 0x0F) == 1:           # variable-length string: (length, global heap collection, object index)
+            return np.dtype([("len", "<u4"), ("heap", f"<u{b.so}"), ("idx", "<u4")]), 8
+        raise NotImplementedError({2: "time", 4: "bitfield", 5: "opaque", 6: "compound", 7: "reference", 8: "enumerated", 9: "variable-length",
+                                   10: "array"}.get(cls, f"class {cls}") + " datatype")
+
+    def _filters(self, body):
+        b, d = self._b, self._b.d
+        ver, n = d[body], d[body + 1]
+        p = body + (8 if ver == 1 else 2)
+        out = []
+        for _ in range(n):
+            fid = b.u(p, 2); p += 2
+            nlen = 0
+            if ver == 1 or fid >= 256:
+                nlen = b.u(p, 2); p += 2
+            p += 2
+            ncd = b.u(p, 2); p += 2
+            p += (nlen + 7) // 8 * 8 if ver == 1 else nlen
+            cd = tuple(b.u(p + 4 * i, 4) for i in range(ncd)); p += 4 * ncd
+            if ver == 1 and ncd % 2:
+                p += 4
+            out.append((fid, cd))
+        return out
+
+    def _fill(self, raw, dtype):
+        typ, body = raw
+        b, d = self._b, self._b.d
+        if typ == 0x0004:
+            n, p = b.u(body, 4), body + 4
+        else:
+            ver = d[body]
+            if ver in (1, 2):
+                if ver == 2 and not d[body + 3]:
+                    return None
+                n, p = b.u(body + 4, 4), body + 8
+            else:
+                if not d[body + 1] & 0x20:
+                    return None
+                n, p = b.u(body + 2, 4), body + 6
+        if n != np.dtype(dtype).itemsize:
+            return None
+        return np.frombuffer(bytes(d[p:p + n]), dtype=dtype)[0].astype(np.dtype(dtype).newbyteorder("="))
+
+    def _attribute(self, body, want_end=False):
+        b, d = self._b, self._b.d
+        ver = d[body]
+        if ver not in (1, 2, 3):
+            raise H5Error("attribute message version")
+        nsz, tsz, ssz = b.u(body + 2, 2), b.u(body + 4, 2), b.u(body + 6, 2)
+        p = body + 8 + (1 if ver == 3 else 0)
+        pad = (lambda n: (n + 7) // 8 * 8) if ver == 1 else (lambda n: n)
+        name = bytes(d[p:p + nsz]).split(b"\0")[0].decode("utf-8", "replace"); p += pad(nsz)
+        dt, _ = self._datatype(p); tp = p; p += pad(tsz)
+        shape = self._dataspace(p); p += pad(ssz)
+        n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        a = np.frombuffer(bytes(d[p:p + n * dt.itemsize]), dtype=dt)
+        if want_end:
+            self._attr_end = p + n * dt.itemsize
+        if dt.names:                                     # variable-length strings live in global heap collections
+            vals = [self._global_heap_object(int(x["heap"]) + b.base, int(x["idx"]))[:int(x["len"])].decode("utf-8", "replace") for x in a]
+            return name, (vals[0] if not shape else vals)
+        if dt.kind == "S":
+            vals = [x.split(b"\0")[0].decode("utf-8", "replace") for x in a]
+            return name, (vals[0] if not shape else vals)
+        a = a.astype(dt.newbyteorder("="))
+        return name, (a[0] if not shape else a.reshape(shape))
+
+    def _global_heap_object(self, addr, index) -> bytes:
+        b, d = self._b, self._b.d
+        if bytes(d[addr:addr + 4]) != b"GCOL":
+            raise H5Error("global heap collection signature")
+        end = addr + b.len_(addr + 8)
+        p = addr + 8 + b.sl
+        while p + 8 + b.sl <= end:
+            idx, size = b.u(p, 2), b.len_(p + 8)
+            if idx == 0:
+                break
+            if idx == index:
+                return bytes(d[p + 8 + b.sl:p + 8 + b.sl + size])
+            p += 8 + b.sl + (size + 7) // 8 * 8
+        raise H5Error(f"global heap object {index} not found")
+
+    def _btree1_chunks(self, addr, rank, table):
+        b, d = self._b, self._b.d
+        if bytes(d[addr:addr + 4]) != b"TREE" or d[addr + 4] != 1:
+            raise H5Error("chunk B-tree node")
+        level, n = d[addr + 5], b.u(addr + 6, 2)
+        p = addr + 8 + 2 * b.so
+        ksz = 8 + 8 * (rank + 1)
+        for i in range(n):
+            k = p + i * (ksz + b.so)
+            size, mask = b.u(k, 4), b.u(k + 4, 4)
+            origin = tuple(b.u(k + 8 + 8 * j, 8) for j in range(rank))
+            child = b.off(k + ksz)
+            if level > 0:
+                self._btree1_chunks(child, rank, table)
+            else:
+                table[origin] = (child, size, mask)
+
+    def _fixed_array(self, hdr, nchunks, chunk, filtered, esize, table):
+        b, d = self._b, self._b.d
+        if bytes(d[hdr:hdr + 4]) != b"FAHD":
+            raise H5Error("fixed array header")
+        entry, page_bits = d[hdr + 6], d[hdr + 7]
+        nent = b.len_(hdr + 8)
+        db = b.off(hdr + 8 + b.sl)
+        if db is None:
+            return
+        if bytes(d[db:db + 4]) != b"FADB":
+            raise H5Error("fixed array data block")
+        p = db + 6 + b.so
+        per_page = 1 << page_bits
+        paged = nent > per_page
+        if paged:
+            npages = -(-nent // per_page)
+            p += (npages + 7) // 8
+        idx = list(np.ndindex(*nchunks))
+        for i in range(nent):
+            if paged:
+                pg, k = divmod(i, per_page)
+                q = p + pg * (per_page * entry + 4) + k * entry
+            else:
+                q = p + i * entry
+            addr = b.off(q)
+            if addr is None:
+                continue
+            if filtered:
+                csz = b.u(q + b.so, entry - b.so - 4)
+                mask = b.u(q + entry - 4, 4)
+            else:
+                csz, mask = esize, 0
+            table[tuple(k_ * c for k_, c in zip(idx[i], chunk))] = (addr, csz, mask)
+
+    # ------------------------------------------------------------------ public
+    def _resolve(self, path) -> int:
+        addr = self._root
+        for part in [p for p in path.split("/") if p]:
+            links = self._cache.get(("links", addr))
+            if links is None:
+                links = self._cache[("links", addr)] = self._links(addr)
+            if part not in links:
+                raise KeyError(f"{self.path}: no object '{part}' in '{path}' (have {sorted(links)})")
+            addr = links[part]
+        return addr
+
+    def keys(self, group="/"):
+        return sorted(self._links(self._resolve(group)))
+
+    def __contains__(self, path):
+        try:
+            self._resolve(path)
+            return True
+        except KeyError:
+            return False
+
+    def __getitem__(self, path) -> H5Dataset:
+        addr = self._resolve(path)
+        msgs = self._messages(addr)
+        if not any(t == 0x0008 for t, _ in msgs):
+            raise KeyError(f"{self.path}: '{path}' is a group (members: {sorted(self._links(addr))})")
+        return H5Dataset(self, path, msgs)
+
+    def attrs(self, path="/") -> Dict[str, object]:
+        """attributes of a group or dataset: those in the object header and those in dense storage (more than 8: netCDF global
+        attributes); values of unsupported types are skipped"""
+        out = {}
+        b, d = self._b, self._b.d
+        for typ, body in self._messages(self._resolve(path)):
+            if typ == 0x000C:
+                try:
+                    k, v = self._attribute(body)
+                    out[k] = v
+                except NotImplementedError:
+                    pass
+            elif typ == 0x0015:                                   # attribute info: fractal heap of attribute messages
+                flags = d[body + 1]
+                fh = b.off(body + 2 + (2 if flags & 1 else 0))
+                if fh is None:
+                    continue
+
+                def parse(q):
+                    if d[q] not in (1, 2, 3):
+                        return None
+                    try:
+                        k, v = self._attribute(q, want_end=True)
+                        out[k] = v
+                        return self._attr_end
+                    except NotImplementedError:
+                        return None                               # a value type this reader cannot size: stop at it
+                self._fractal_heap_walk(fh, parse)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------ EMIT L1B
+def read_emit_l1b(path, wavelength_range: Optional[Tuple[float, float]] = None, rows: Optional[slice] = None, threads: int = 8):
+    """The part of an EMIT L1B radiance granule the hot path consumes (what ``EMITImage(path)`` + ``read_from_bands`` +
+    ``load_raw(transpose=False)`` give ``mag1c_emit``, mag1c_emit.py:40-48): ``radiance`` (rows, cols, bands) float32 restricted to
+    the bands inside ``wavelength_range`` (a contiguous band slice is read chunk-wise; None = all bands), band centres and widths,
+    the fill value, and the geometry look-up table when the file carries one.
+    -> dict(radiance, wavelengths, fwhm, band_slice, fill_value, glt_x, glt_y)"""
+    with H5File(path) as f:
+        wl = np.asarray(f["sensor_band_parameters/wavelengths"].read(), dtype=np.float64)
+        fw = np.asarray(f["sensor_band_parameters/fwhm"].read(), dtype=np.float64)
+        rad = f["radiance"]
+        if len(rad.shape) != 3 or rad.shape[2] != wl.size:
+            raise H5Error(f"{path}: radiance shape {rad.shape} does not end in the {wl.size} bands of sensor_band_parameters")
+        b0, b1 = 0, wl.size
+        if wavelength_range is not None:
+            keep = np.flatnonzero((wl >= wavelength_range[0]) & (wl <= wavelength_range[1]))
+            if keep.size == 0:
+                raise ValueError("There are no bands in the selected wavelength range")
+            b0, b1 = int(keep[0]), int(keep[-1]) + 1
+        fill = rad.attrs.get("_FillValue", rad.fillvalue)
+        x = rad.read((rows or slice(None), slice(None), slice(b0, b1)), threads=threads)
+        out = {"radiance": np.ascontiguousarray(x, dtype=np.float32), "wavelengths": wl[b0:b1], "fwhm": fw[b0:b1], "band_slice": (b0, b1),
+               "fill_value": float(fill) if fill is not None else -9999.0, "glt_x": None, "glt_y": None}
+        if "location/glt_x" in f and "location/glt_y" in f:
+            out["glt_x"], out["glt_y"] = f["location/glt_x"].read(), f["location/glt_y"].read()
+        return out

@@ -120,21 +120,34 @@ def emit_scene_predict(model, raw, wavelengths, template, fill_value=-9999.0, co
     network input is built, so every rank returns the full-scene result.  ``column_range=(c0, c1)`` (explicit manual shard,
     c0 / c1 on column_step boundaries) returns ONLY ``mf`` and ``albedo`` of that shard: a network input built from a partial
     mf would be wrong for the whole scene."""
-    import torch.distributed as dist
     raw = torch.as_tensor(raw)
     dev = raw.device if raw.is_cuda else model.device
     raw = raw.to(dev).float()
     w = np.asarray(wavelengths, dtype=np.float64)
     keep = np.nonzero((w >= EMIT_MAG1C_RANGE_NM[0]) & (w <= EMIT_MAG1C_RANGE_NM[1]))[0]
     assert keep.size and np.all(np.diff(keep) == 1), "the mag1c bands must be contiguous"
+    sub = raw[..., int(keep[0]):int(keep[-1]) + 1].contiguous()
+    rgb = raw[..., nearest_bands(w)].permute(2, 0, 1).contiguous()
+    ratio = None
+    if ratio_bands is not None:
+        ia, ir = nearest_bands(w, ratio_bands)
+        ratio = (raw[..., ia].contiguous(), raw[..., ir].contiguous())
+    return _emit_predict_parts(model, sub, rgb, ratio, template, fill_value, column_step, num_iter, covariance_lerp_alpha, column_range,
+                               tile, halo, distributed, group)
+
+
+def _emit_predict_parts(model, sub, rgb, ratio, template, fill_value, column_step, num_iter, covariance_lerp_alpha, column_range, tile, halo,
+                        distributed, group):
+    """``sub``: (rows, cols, K) device float32 radiance of the mag1c bands, ``rgb``: (3, rows, cols), ``ratio``: None or the
+    (absorbing, reference) band planes -- the pieces of the cube the scene pipeline touches"""
+    import torch.distributed as dist
     t = np.asarray(template, dtype=np.float64)
     t = t[:, 1] if t.ndim == 2 else t
-    if t.size != keep.size:
-        raise ValueError(f"template has {t.size} bands, the cube has {keep.size} inside {EMIT_MAG1C_RANGE_NM} nm")
-    sub = raw[..., int(keep[0]):int(keep[-1]) + 1].contiguous()
+    if t.size != sub.shape[-1]:
+        raise ValueError(f"template has {t.size} bands, the cube has {sub.shape[-1]} inside {EMIT_MAG1C_RANGE_NM} nm")
     if distributed is None:
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-    cols = raw.shape[1]
+    cols = sub.shape[1]
     step = int(column_step or cols)
     if column_range is not None:
         mf, alb = mag1c.mag1c_columns(sub, t, fill_value, column_step=column_step, num_iter=num_iter,
@@ -151,13 +164,11 @@ def emit_scene_predict(model, raw, wavelengths, template, fill_value=-9999.0, co
     else:
         mf, alb = mag1c.mag1c_columns(sub, t, fill_value, column_step=column_step, num_iter=num_iter,
                                       covariance_lerp_alpha=covariance_lerp_alpha)
-    rgb = raw[..., nearest_bands(w)].permute(2, 0, 1).contiguous()
     x = emit_to_aviris_input(mf, rgb)
     out = {"mf": mf, "albedo": alb, "input": x}
-    if ratio_bands is not None:
+    if ratio is not None:
         from .features import ratio_2c_match_c_from_sums_outlier
-        ia, ir = nearest_bands(w, ratio_bands)
-        out["ratio"] = ratio_2c_match_c_from_sums_outlier(raw[..., ia].contiguous(), raw[..., ir].contiguous())
+        out["ratio"] = ratio_2c_match_c_from_sums_outlier(ratio[0], ratio[1])
     was = model.training
     model.eval()
     try:
@@ -166,6 +177,46 @@ def emit_scene_predict(model, raw, wavelengths, template, fill_value=-9999.0, co
     finally:
         model.train(was)
     out["prediction"], out["pred_binary"] = masks["prediction"][0, 0], masks["pred_binary"][0, 0]
+    return out
+
+
+@torch.no_grad()
+def emit_granule_predict(model, nc_path, column_step=2, num_iter=30, covariance_lerp_alpha=1e-4, tile=None, halo=RECEPTIVE_HALO,
+                         ratio_bands=None, distributed=None, group=None, rows=None, threads=8):
+    """The notebook path of the reference end to end FROM THE FILE (notebooks/inference_on_raw_EMIT_nc_file.ipynb cells 8-19:
+    ``EMITImage(path)`` -> ``mag1c_emit`` -> RGB bands -> rescale -> ``model`` -> threshold): opens the EMIT L1B radiance granule
+    (NetCDF-4) with :mod:`starcop_amd.hdf5_reader`, reads ONLY what the pipeline touches -- the contiguous band slice inside
+    [2122, 2488] nm chunk-wise, the three RGB band planes, the two ratio bands if asked for: ~0.35 GB of the 1.8 GB cube -- builds the
+    CH4 target from the file's band centres / widths (shipped look-up table) and runs :func:`emit_scene_predict`'s device pipeline.
+    ``rows``: optional slice of downtrack lines.  Returns its dict plus ``wavelengths``, ``fwhm`` (the mag1c bands) and ``glt_x`` /
+    ``glt_y`` (host arrays, or None) for orthorectification by the caller."""
+    from .hdf5_reader import H5File
+    dev = model.device
+    rs = rows or slice(None)
+    with H5File(nc_path) as f:
+        wl = np.asarray(f["sensor_band_parameters/wavelengths"].read(), dtype=np.float64)
+        fwhm = np.asarray(f["sensor_band_parameters/fwhm"].read(), dtype=np.float64)
+        rad = f["radiance"]
+        keep = np.nonzero((wl >= EMIT_MAG1C_RANGE_NM[0]) & (wl <= EMIT_MAG1C_RANGE_NM[1]))[0]
+        assert keep.size, "There are no bands in the selected wavelength range"
+        b0, b1 = int(keep[0]), int(keep[-1]) + 1
+        fill = rad.attrs.get("_FillValue", rad.fillvalue)
+        fill = float(fill) if fill is not None else -9999.0
+
+        def plane(i):
+            return np.ascontiguousarray(rad.read((rs, slice(None), slice(i, i + 1)), threads=threads)[..., 0], dtype=np.float32)
+        sub_h = np.ascontiguousarray(rad.read((rs, slice(None), slice(b0, b1)), threads=threads), dtype=np.float32)
+        rgb_h = np.stack([plane(i) for i in nearest_bands(wl)])
+        ratio_h = [plane(i) for i in nearest_bands(wl, ratio_bands)] if ratio_bands is not None else None
+        glt = (f["location/glt_x"].read(), f["location/glt_y"].read()) if ("location/glt_x" in f and "location/glt_y" in f) else (None, None)
+
+    def up(a):
+        h = torch.from_numpy(a)
+        return (h.pin_memory() if torch.cuda.is_available() else h).to(dev, non_blocking=True)
+    template = mag1c.generate_template_from_bands(wl[b0:b1], fwhm[b0:b1])
+    out = _emit_predict_parts(model, up(sub_h), up(rgb_h), tuple(up(a) for a in ratio_h) if ratio_h else None, template, fill, column_step,
+                              num_iter, covariance_lerp_alpha, None, tile, halo, distributed, group)
+    out.update(wavelengths=wl[b0:b1], fwhm=fwhm[b0:b1], glt_x=glt[0], glt_y=glt[1], fill_value=fill)
     return out
 
 

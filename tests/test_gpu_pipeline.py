@@ -139,3 +139,29 @@ def test_aviris_scene_mag1c_from_envi_files(hip, tmp_path):
     xml = info.tags[42112][1][0]
     assert '<Item name="mag1c">acfwl1mf</Item>' in xml and "CH4 Absorption (ppm x m)" in xml and repr(float(wl[keep][0])) in xml
     assert "Albedo" in io.tiff_info(out_alb).tags[42112][1][0]
+
+
+def test_emit_granule_predict_from_netcdf_file(hip):
+    """the notebook path from the FILE.  An EMIT-L1B-like NetCDF-4 granule written by libhdf5 (tests/golden/io,
+    make_io_fixtures.py) -> own HDF5 reader (only the mag1c band slice and the RGB planes are read) -> template from the file's
+    band centres / widths -> mag1c -> rescale -> U-Net -> mask; equal to emit_scene_predict on the array a full read returns,
+    and mf against the fp64 oracle"""
+    import os
+    from starcop_amd import hdf5_reader, mag1c
+    path = os.path.join(os.path.dirname(__file__), "golden", "io", "emit_l1b_like_sb0.nc")
+    torch.manual_seed(0)
+    model = mm.ModelModule(mm.default_settings(pos_weight=1)).to(DEV).eval()
+    out = pipeline.emit_granule_predict(model, path, column_step=4, ratio_bands=(2350, 2310))
+    full = hdf5_reader.read_emit_l1b(path)                              # all 285 bands
+    wl = full["wavelengths"]
+    keep = (wl >= 2122) & (wl <= 2488)
+    templ = mag1c.generate_template_from_bands(wl[keep], full["fwhm"][keep])
+    want = pipeline.emit_scene_predict(model, full["radiance"], wl, templ, fill_value=full["fill_value"], column_step=4, ratio_bands=(2350, 2310))
+    for k in ("mf", "albedo", "input", "prediction", "pred_binary", "ratio"):
+        assert torch.equal(out[k], want[k]), k
+    assert np.allclose(out["wavelengths"], wl[keep]) and out["glt_x"].shape == (60, 70) and out["fill_value"] == -9999.0
+    sub = full["radiance"][..., keep]
+    mf_ref, _ = mag1c_ref.mag1c_columns(sub, templ[:, 1], -9999.0, column_step=4)
+    assert np.array_equal(out["mf"].cpu().numpy() == -9999.0, mf_ref == -9999.0) and bool((out["mf"][:5, :3] == -9999.0).all())
+    ok = mf_ref != -9999.0
+    assert np.abs(out["mf"].cpu().numpy()[ok] - mf_ref[ok]).max() < 1e-4 * max(1.0, float(np.abs(mf_ref[ok]).max()))
