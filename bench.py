@@ -134,6 +134,13 @@ def bench_extras(model, dev, precision):
                                       "streamed_bytes_per_tile": it_bytes, "streamed_GBs": round(it_bytes / max(dt - dt0, 1e-9) / 1e9, 1),
                                       "hbm_min_bytes_per_tile": 512 * 512 * S * 4 + 8 * 512 * 512,
                                       "note": "iteration time = ms_per_tile - setup_ms (setup: validity mask, layout, pack, means, scatter matrix, Cholesky)"}}
+    # ---- the same tile with ORTHORECTIFIED groups (process_aviris.py:211-217: |GLT sample index| varies along a row and down; 598
+    # detector samples): the layout is a device counting sort (sc_mag1c_layout_ids) instead of torch sort / unique
+    gl = ((np.arange(512)[None, :] + np.arange(512)[:, None] // 3) % 598 + 1).astype(np.int64)
+    gl_d = torch.from_numpy(gl).to(dev)
+    dtg = _timeit(lambda: mag1c.acrwl1mf_by_groups(x, t125, gl_d, max_group=598), 5)
+    out["mag1c_glt"] = {"workload": "configs[2] tile with orthorectified (scattered) groups: 598 ids, ~438 px each, layout by device counting sort",
+                        "ms_per_tile": round(dtg * 1e3, 3), "tiles_s": round(1 / dtg, 1)}
     # ---- EMIT-like granule (configs[4] preprocessing): 1280 x 1242 px, 49 bands in [2122, 2488] nm, fp64 arithmetic, alpha = 1e-4
     te = g3["emit_template_kept"][:, 1]
     raw = cube(1280, 1242, te)

@@ -410,6 +410,18 @@ int sc_mag1c_layout_columns(const unsigned char* valid, int rows, int cols, cons
                             int min_keep, int32_t* P, int32_t* Ppad, int64_t* poff, int64_t* xoff, int64_t* pix_index,
                             int64_t* totals, sc_stream stream);
 
+/* The same packed layout for ARBITRARY integer groups -- the orthorectified AVIRIS-NG cube, where the group of a pixel is
+ * |GLT sample index| (starcop/process_aviris.py:211-217: samples_glt_file = abs(glt[..., 0]), 0 = no data), ids bounded by the
+ * detector width: a stable counting sort on the device (per-1024-pixel-block histograms, a scan over the blocks per id, ranked
+ * scatter) instead of torch.nonzero / argsort / unique_consecutive / repeat_interleave and their host round trip.
+ * Group g = id value g in [0, nids): its pixels are the valid ones (valid[p] != 0, ids[p] == g) in ascending pixel index (the
+ * order of the reference's boolean indexing x[groups == g]); ids outside [0, nids) are ignored; a group with <= min_keep valid
+ * pixels gets P[g] = 0.  Outputs as sc_mag1c_layout_columns with G = nids; work: sc_mag1c_layout_ids_workspace_ints ints. */
+size_t sc_mag1c_layout_ids_workspace_ints(int64_t npix, int nids);
+int sc_mag1c_layout_ids(const unsigned char* valid, const int32_t* ids, int64_t npix, int nids, int S, int min_keep,
+                        int32_t* P, int32_t* Ppad, int64_t* poff, int64_t* xoff, int64_t* pix_index, int64_t* totals,
+                        int32_t* work, sc_stream stream);
+
 /* band-ratio feature (starcop/data/feature_extration.py:37-56).  For B tiles of n pixels:
  *   sc_trimmed_sums : sums[b] = sum of x[b][i] with lower <= x <= upper, lower/upper = numpy.percentile(x[b], p / 100-p)
  *                     (exact order statistics by radix select + numpy's linear interpolation)   == np.sum(no_outliers(x, p))

@@ -121,6 +121,8 @@ SIGNATURES = {
     "sc_scatter_n": (_i, [_vp, _i, _vp, _vp, _sz, _vp, _i, _vp]),
     "sc_valid_mask_ne": (_i, [_vp, _i, _i, _i, _i, _d, C.c_int64, _vp, _vp]),
     "sc_mag1c_layout_columns": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sc_mag1c_layout_ids_workspace_ints": (_sz, [C.c_int64, _i]),
+    "sc_mag1c_layout_ids": (_i, [_vp, _vp, C.c_int64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sc_trimmed_sum_workspace_bytes": (_sz, [_i]),
     "sc_trimmed_sums": (_i, [_vp, _i, _sz, _d, _vp, _vp, _sz, _vp]),
     "sc_band_ratio": (_i, [_vp, _vp, _vp, _i, _sz, _vp, _vp, _f, _f, _vp]),

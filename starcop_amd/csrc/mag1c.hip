@@ -617,22 +617,40 @@ __global__ __launch_bounds__(256) void k_mag1c_pack(const TI* __restrict__ cube,
                                                     const long long* __restrict__ pix, const long long* __restrict__ xoff,
                                                     const int* __restrict__ Ppad, const long long* __restrict__ poff,
                                                     const int* __restrict__ P, TO* __restrict__ xp) {
-  // tile transpose through LDS: 64 pixels x up to 128 bands per step
+  // tile transpose through LDS: 64 pixels x up to 128 bands per step.  Read side: a WAVE per pixel (its index is one scalar load,
+  // its S bands one or two coalesced row reads of the pixel-major cube; no per-element index load or division); write side: 64
+  // consecutive pixels of a band per wave.  The padding [P, Ppad) of every band row is written as zeros, so the packed buffer
+  // needs no memset.
   __shared__ float s_t[64][MAXS + 1];
   const int g = blockIdx.x;
   const int np = P[g], pitch = Ppad[g];
   TO* out = xp + xoff[g];
   const long long* pg = pix + poff[g];
-  for (int q0 = blockIdx.y * 64; q0 < np; q0 += gridDim.y * 64) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int q0 = blockIdx.y * 64; q0 < pitch; q0 += gridDim.y * 64) {
     __syncthreads();
-    for (int i = threadIdx.x; i < 64 * S; i += 256) {
-      const int k = i / S, s = i - k * S;
-      if (q0 + k < np) s_t[k][s] = (float)cube[(size_t)pg[q0 + k] * S_total + band0 + s];
+    // the wave's 16 pixel indices in one load (lane j -> pixel wave + 4j), then all 32 row reads in flight before the first LDS store:
+    // two memory round trips per tile instead of 32 dependent ones
+    const int kq = q0 + wave + 4 * (lane & 15);
+    const long long myidx = (lane < 16 && kq < np) ? pg[kq] : -1;
+    float v[16][2];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const long long idx = __shfl(myidx, j, 64);
+      const TI* row = cube + (size_t)(idx < 0 ? 0 : idx) * S_total + band0;
+      v[j][0] = (idx >= 0 && lane < S) ? (float)row[lane] : 0.f;
+      v[j][1] = (idx >= 0 && lane + 64 < S) ? (float)row[lane + 64] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int k = wave + 4 * j;
+      if (lane < S) s_t[k][lane] = v[j][0];
+      if (lane + 64 < S) s_t[k][lane + 64] = v[j][1];
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * S; i += 256) {
       const int s = i >> 6, k = i & 63;
-      if (q0 + k < np) out[(size_t)s * pitch + q0 + k] = (TO)s_t[k][s];
+      out[(size_t)s * pitch + q0 + k] = (q0 + k < np) ? (TO)s_t[k][s] : (TO)0;
     }
   }
 }
@@ -646,9 +664,9 @@ __global__ __launch_bounds__(256) void k_mag1c_pack_f64(const double* __restrict
   const int np = P[g], pitch = Ppad[g];
   double* out = xp + xoff[g];
   const long long* pg = pix + poff[g];
-  for (int i = blockIdx.y * 256 + threadIdx.x; i < np * S; i += gridDim.y * 256) {
-    const int s = i / np, k = i - s * np;
-    out[(size_t)s * pitch + k] = cube[(size_t)pg[k] * S_total + band0 + s];
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < pitch * S; i += gridDim.y * 256) {
+    const int s = i / pitch, k = i - s * pitch;
+    out[(size_t)s * pitch + k] = k < np ? cube[(size_t)pg[k] * S_total + band0 + s] : 0.0;      // padding written: no memset of the buffer
   }
 }
 
@@ -765,6 +783,59 @@ __global__ __launch_bounds__(256) void k_lc_index(const unsigned char* __restric
       for (int c = c0; c < c1; ++c)
         if (valid[(size_t)r * cols + c]) out[pos++] = (long long)r * cols + c;
     carry += total;
+  }
+}
+// ---- layout of ARBITRARY integer groups by a stable counting sort (the orthorectified AVIRIS-NG case: groups = |GLT sample index|,
+// process_aviris.py:211-217, bounded by the detector width).  Group g = id value g; pixels of a group in ascending pixel index
+// (the order of the reference's boolean indexing and of a stable sort).  Blocks of LI_BLK consecutive pixels, one wave each.
+constexpr int LI_BLK = 1024;
+// cnt[b][id] = valid pixels with that id in block b (a block is one wave walking its pixels in order: plain increments)
+__global__ __launch_bounds__(64) void k_li_count(const unsigned char* __restrict__ valid, const int* __restrict__ ids, long long npix,
+                                                 int nids, int* __restrict__ cnt) {
+  const long long p0 = (long long)blockIdx.x * LI_BLK;
+  int* row = cnt + (size_t)blockIdx.x * nids;
+  for (int c = 0; c < LI_BLK; c += 64) {
+    const long long p = p0 + c + threadIdx.x;
+    const bool ok = p < npix && valid[p];
+    const int id = ok ? ids[p] : -1;
+    if (id >= 0 && id < nids) atomicAdd(row + id, 1);         // one wave owns the row: order-independent integer sums
+  }
+}
+// per id: exclusive scan of cnt over the blocks (in place) and the group's total
+__global__ __launch_bounds__(256) void k_li_colscan(int* __restrict__ cnt, int nblk, int nids, int min_keep, int* __restrict__ P) {
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  if (id >= nids) return;
+  int run = 0;
+  for (int b = 0; b < nblk; ++b) {
+    const int v = cnt[(size_t)b * nids + id];
+    cnt[(size_t)b * nids + id] = run;
+    run += v;
+  }
+  P[id] = run > min_keep ? run : 0;
+}
+// pix[poff[id] + (pixels of id in earlier blocks) + (rank inside the block)] = pixel
+__global__ __launch_bounds__(64) void k_li_index(const unsigned char* __restrict__ valid, const int* __restrict__ ids, long long npix,
+                                                 int nids, int* __restrict__ cnt, const int* __restrict__ P,
+                                                 const long long* __restrict__ poff, long long* __restrict__ pix) {
+  const long long p0 = (long long)blockIdx.x * LI_BLK;
+  int* row = cnt + (size_t)blockIdx.x * nids;                  // running position of every id inside this block's range
+  const int lane = threadIdx.x;
+  for (int c = 0; c < LI_BLK; c += 64) {
+    const long long p = p0 + c + lane;
+    const bool ok = p < npix && valid[p];
+    int id = ok ? ids[p] : -1;
+    if (id >= nids) id = -1;
+    // rank among the lower lanes of this chunk with the same id, and how many lanes of the chunk share it
+    int rank = 0, same = 0;
+    for (int j = 0; j < 64; ++j) {
+      const int idj = __shfl(id, j, 64);
+      if (idj == id) { same++; if (j < lane) rank++; }
+    }
+    if (id >= 0) {
+      const int base = row[id];
+      if (P[id] > 0) pix[poff[id] + base + rank] = p;
+      if (rank == same - 1) row[id] = base + same;             // the last lane of the id advances the running position
+    }
   }
 }
 template <typename TI, typename TO>
@@ -898,6 +969,27 @@ extern "C" int sc_mag1c_layout_columns(const unsigned char* valid, int rows, int
   hipLaunchKernelGGL(k_lc_scan, dim3(1), dim3(256), 0, st, (const int*)P, G, S, Ppad, (long long*)poff, (long long*)xoff, (long long*)totals);
   hipLaunchKernelGGL(k_lc_index, dim3(G), dim3(256), 0, st, valid, rows, cols, gcol, (const int*)P, (const long long*)poff, (long long*)pix_index);
   SC_LAUNCH_OK("sc_mag1c_layout_columns");
+  return SC_OK;
+}
+
+extern "C" size_t sc_mag1c_layout_ids_workspace_ints(int64_t npix, int nids) {
+  return (size_t)((npix + LI_BLK - 1) / LI_BLK) * (size_t)nids;
+}
+
+extern "C" int sc_mag1c_layout_ids(const unsigned char* valid, const int32_t* ids, int64_t npix, int nids, int S, int min_keep,
+                                   int32_t* P, int32_t* Ppad, int64_t* poff, int64_t* xoff, int64_t* pix_index, int64_t* totals,
+                                   int32_t* work, sc_stream stream) {
+  SC_REQUIRE(valid && ids && P && Ppad && poff && xoff && pix_index && totals && work, "sc_mag1c_layout_ids: null pointer argument");
+  SC_REQUIRE(npix > 0 && nids > 0 && S > 0, "sc_mag1c_layout_ids: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)((npix + LI_BLK - 1) / LI_BLK);
+  if (hipMemsetAsync(work, 0, (size_t)nblk * nids * sizeof(int), st) != hipSuccess) { sc_set_error("sc_mag1c_layout_ids: memset failed"); return SC_ERR_LAUNCH; }
+  hipLaunchKernelGGL(k_li_count, dim3(nblk), dim3(64), 0, st, valid, ids, (long long)npix, nids, work);
+  hipLaunchKernelGGL(k_li_colscan, dim3((nids + 255) / 256), dim3(256), 0, st, work, nblk, nids, min_keep, P);
+  hipLaunchKernelGGL(k_lc_scan, dim3(1), dim3(256), 0, st, (const int*)P, nids, S, Ppad, (long long*)poff, (long long*)xoff, (long long*)totals);
+  hipLaunchKernelGGL(k_li_index, dim3(nblk), dim3(64), 0, st, valid, ids, (long long)npix, nids, work, (const int*)P,
+                     (const long long*)poff, (long long*)pix_index);
+  SC_LAUNCH_OK("sc_mag1c_layout_ids");
   return SC_OK;
 }
 

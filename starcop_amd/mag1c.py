@@ -46,7 +46,7 @@ def _run_groups(cube2d, S_total, band0, S, pix_index, counts, template, num_iter
     poff = torch.cumsum(counts_t, 0) - counts_t
     xoff = torch.cumsum(ppad * S, 0) - ppad * S
     total = int((ppad * S).sum())
-    xp = torch.zeros(total, dtype=dt, device=dev)
+    xp = torch.empty(total, dtype=dt, device=dev)                # sc_mag1c_pack writes the padding of every band row too
     P_d = counts_t.to(torch.int32).to(dev)
     ppad_d = ppad.to(torch.int32).to(dev)
     poff_d, xoff_d = poff.to(dev), xoff.to(dev)
@@ -88,18 +88,22 @@ def _column_runs(ids):
 
 
 _LAYOUT_CACHE = {}
+MAX_GROUP_IDS = 1 << 16      # group ids up to this take the device counting sort (detector widths are ~600-1300); larger / negative ids
+                             # fall back to the general sort
 COLUMN_FAST_PATH = True      # False: always take the general (device sort) layout path; tests compare the two bit for bit
 
 
-def _run_column_groups(cube3, b0, S, valid_u8, gcol, min_keep, template, num_iter, alpha, k, flags, fill, out_dtype):
-    """Column-structured groups (both drivers of the reference): layout, pack, filter and scatter entirely on the device --
-    ``sc_mag1c_layout_columns`` -> ``sc_mag1c_pack`` -> ``sc_mag1c_groups`` -> ``sc_scatter_n`` with every per-group array and
-    the pixel count in device memory; the only host synchronisation is the status check after the filter."""
+def _run_column_groups(cube3, b0, S, valid_u8, gcol, min_keep, template, num_iter, alpha, k, flags, fill, out_dtype, ids=None, nids=0):
+    """Layout, pack, filter and scatter entirely on the device -- ``sc_mag1c_layout_columns`` (column-structured groups: both
+    drivers of the reference on un-orthorectified cubes) or ``sc_mag1c_layout_ids`` (``ids``: int32 device tensor of a group id
+    per pixel in [0, nids): the orthorectified |GLT sample| case) -> ``sc_mag1c_pack`` -> ``sc_mag1c_groups`` -> ``sc_scatter_n``
+    with every per-group array and the pixel count in device memory; the only host synchronisation is the status check after
+    the filter."""
     lib = _lib.load()
     dev = cube3.device
     rows, cols, S_total = cube3.shape
     HW = rows * cols
-    G = int(gcol.size - 1)
+    G = int(gcol.size - 1) if ids is None else int(nids)
     is64 = cube3.dtype == torch.float64
     dt = cube3.dtype
     mf_out = torch.full((HW,), fill, dtype=out_dtype, device=dev)
@@ -108,21 +112,28 @@ def _run_column_groups(cube3, b0, S, valid_u8, gcol, min_keep, template, num_ite
         return mf_out.reshape(rows, cols), alb_out.reshape(rows, cols)
     if S > MAX_BANDS:
         raise ValueError(f"mag1c: at most {MAX_BANDS} bands per filter (got {S})")
-    key = (dev, gcol.tobytes())
-    gcol_d = _LAYOUT_CACHE.get(key)
-    if gcol_d is None:
-        if len(_LAYOUT_CACHE) > 16:
-            _LAYOUT_CACHE.clear()
-        gcol_d = _LAYOUT_CACHE[key] = torch.from_numpy(gcol).to(dev)
+    gcol_d = None
+    if ids is None:
+        key = (dev, gcol.tobytes())
+        gcol_d = _LAYOUT_CACHE.get(key)
+        if gcol_d is None:
+            if len(_LAYOUT_CACHE) > 16:
+                _LAYOUT_CACHE.clear()
+            gcol_d = _LAYOUT_CACHE[key] = torch.from_numpy(gcol).to(dev)
     i32 = dict(dtype=torch.int32, device=dev)
     i64 = dict(dtype=torch.int64, device=dev)
     P_d, ppad_d = torch.empty(G, **i32), torch.empty(G, **i32)
     poff_d, xoff_d, totals = torch.empty(G, **i64), torch.empty(G, **i64), torch.empty(2, **i64)
     pix = torch.empty(HW, **i64)
     st = stream()
-    check(lib.sc_mag1c_layout_columns(ptr(valid_u8), rows, cols, ptr(gcol_d), G, S, int(min_keep), ptr(P_d), ptr(ppad_d),
-                                      ptr(poff_d), ptr(xoff_d), ptr(pix), ptr(totals), st))
-    xp = torch.zeros((HW + 64 * G) * S, dtype=dt, device=dev)            # upper bound of sum(Ppad) * S: no size read-back
+    if ids is None:
+        check(lib.sc_mag1c_layout_columns(ptr(valid_u8), rows, cols, ptr(gcol_d), G, S, int(min_keep), ptr(P_d), ptr(ppad_d),
+                                          ptr(poff_d), ptr(xoff_d), ptr(pix), ptr(totals), st))
+    else:           # arbitrary integer groups (orthorectified cube): stable counting sort on the device
+        work = torch.empty(lib.sc_mag1c_layout_ids_workspace_ints(HW, G), **i32)
+        check(lib.sc_mag1c_layout_ids(ptr(valid_u8), ptr(ids), HW, G, S, int(min_keep), ptr(P_d), ptr(ppad_d), ptr(poff_d), ptr(xoff_d),
+                                      ptr(pix), ptr(totals), ptr(work), st))
+    xp = torch.empty((HW + 64 * G) * S, dtype=dt, device=dev)            # upper bound of sum(Ppad) * S: no size read-back, no memset
     check(lib.sc_mag1c_pack(ptr(cube3), 1 if is64 else 0, S_total, b0, S, ptr(pix), ptr(xoff_d), ptr(ppad_d),
                             ptr(poff_d), ptr(P_d), G, ptr(xp), 1 if is64 else 0, st))
     a = sc_mag1c_args()
@@ -205,7 +216,7 @@ class Filter:
 
 
 @torch.no_grad()
-def func_by_groups(func, x, groups, mask=None, disable_pbar=True, samples_read=50, band_slice=None):
+def func_by_groups(func, x, groups, mask=None, disable_pbar=True, samples_read=50, band_slice=None, max_group=None):
     """(H, W, S) radiance + (H, W) integer groups -> (mf, albedo) (H, W) tensors, NODATA where not computed.
 
     Every group id present under ``mask`` is filtered on its own valid pixels; groups with <= 10 valid pixels are
@@ -238,6 +249,15 @@ def func_by_groups(func, x, groups, mask=None, disable_pbar=True, samples_read=5
             xc = x.contiguous()
             return _run_column_groups(xc, b0, b1 - b0, mask_t.to(torch.uint8).contiguous() if mask is not None else mask_u8, gcol, 10,
                                       func.template, func.num_iter, func.alpha, func.k, func.flags, NODATA, x.dtype)
+    if isinstance(func, Filter) and COLUMN_FAST_PATH:
+        # any other integer group map (the orthorectified GLT grid of process_aviris.py:211-217): counting sort on the device.
+        # The ids are bounded by the detector width; max_group (or one .max() read-back) sizes the histogram.
+        gmin, gmax = (0, int(max_group)) if max_group is not None else (int(groups_t.min()), int(groups_t.max()))
+        if gmin >= 0 and gmax < MAX_GROUP_IDS:
+            xc = x.contiguous()
+            return _run_column_groups(xc, b0, b1 - b0, mask_t.to(torch.uint8).contiguous() if mask is not None else mask_u8, None, 10,
+                                      func.template, func.num_iter, func.alpha, func.k, func.flags, NODATA, x.dtype,
+                                      ids=groups_t.to(torch.int32).contiguous(), nids=gmax + 1)
     mf_out = torch.full((H * W,), NODATA, dtype=x.dtype, device=dev)
     alb_out = torch.full((H * W,), NODATA, dtype=x.dtype, device=dev)
     valid_idx = torch.nonzero(mask_t).reshape(-1)
@@ -271,9 +291,11 @@ def func_by_groups(func, x, groups, mask=None, disable_pbar=True, samples_read=5
 
 
 @torch.no_grad()
-def acrwl1mf_by_groups(x, template, groups, mask=None, num_iter=30, alpha=0., band_slice=None):
-    """AVIRIS-NG driver core (process_aviris.py:209-219): acrwl1mf(num_iter=30, alpha=0) per detector column."""
-    return func_by_groups(Filter(template, num_iter=num_iter, alpha=alpha), x, groups, mask, band_slice=band_slice)
+def acrwl1mf_by_groups(x, template, groups, mask=None, num_iter=30, alpha=0., band_slice=None, max_group=None):
+    """AVIRIS-NG driver core (process_aviris.py:209-219): acrwl1mf(num_iter=30, alpha=0) per detector column.  ``max_group``: an
+    upper bound of the group ids if the caller knows it (the detector width): saves the one device read-back that sizes the
+    counting sort of a non-column-structured (orthorectified) group map."""
+    return func_by_groups(Filter(template, num_iter=num_iter, alpha=alpha), x, groups, mask, band_slice=band_slice, max_group=max_group)
 
 
 @torch.no_grad()

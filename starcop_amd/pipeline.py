@@ -247,7 +247,7 @@ def aviris_scene_mag1c(aviris_img_folder, mf_filename, albedo_filename=None, use
     host = torch.from_numpy(np.ascontiguousarray(rdn[..., idx[0]:idx[-1] + 1], dtype=np.float32))
     x = (host.pin_memory() if torch.cuda.is_available() else host).to(device, non_blocking=True)
     groups = np.abs(np.asarray(glt[..., 0])).astype(np.int64)
-    mf, alb = mag1c.func_by_groups(mag1c.Filter(spec, num_iter=30), x, groups, mask=groups != 0)
+    mf, alb = mag1c.func_by_groups(mag1c.Filter(spec, num_iter=30), x, groups, mask=groups != 0, max_group=int(groups.max()))
     tags = io.envi_geo_tags(meta["header"])                               # transform + crs of the radiance file
     tags[42113] = (2, (str(mag1c.NODATA),))                               # GDAL_NODATA, as fill_value_default=NODATA
     tags.update(extra_tags or {})

@@ -14,7 +14,7 @@ import sys
 import numpy as np
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "io")
-ROWS, COLS, BANDS = 32, 24, 285
+ROWS, COLS, BANDS = 40, 32, 285
 
 
 def emit_arrays():
@@ -26,7 +26,7 @@ def emit_arrays():
     dip = np.exp(-0.5 * ((wl - 2300.0) / 60.0) ** 2).astype(np.float32)
     rad[10:26, 8:20, :] *= (1.0 - 0.03 * dip)
     rad[:5, :3, :] = -9999.0
-    rad[30, 7, 250] = -9999.0
+    rad[38, 7, 250] = -9999.0
     glt_x = rng.integers(0, COLS + 1, (60, 70)).astype(np.int32)
     glt_y = rng.integers(0, ROWS + 1, (60, 70)).astype(np.int32)
     lon = (10.0 + 0.001 * np.arange(COLS)[None, :] + 0.0 * np.arange(ROWS)[:, None]).astype(np.float64)
@@ -49,7 +49,7 @@ def write_emit(path, libver):
             dims[name] = d
         for name in ("flat_field_update", "build_dcid", "orbit_number"):      # scalar variables: 11 root members, past the compact-link limit
             f.create_dataset(name, data=np.float32(len(name)))
-        r = f.create_dataset("radiance", data=rad, chunks=(16, 24, 32), compression="gzip", compression_opts=6, shuffle=True, fillvalue=np.float32(-9999.0))
+        r = f.create_dataset("radiance", data=rad, chunks=(16, 32, 32), compression="gzip", compression_opts=6, shuffle=True, fillvalue=np.float32(-9999.0))
         r.attrs["_FillValue"] = np.float32(-9999.0)
         r.attrs["long_name"] = "Radiance Data"
         r.attrs["units"] = "uW/cm^2/SR/nm"
@@ -61,11 +61,11 @@ def write_emit(path, libver):
         for ds in (g["wavelengths"], g["fwhm"]):
             ds.dims[0].attach_scale(dims["bands"])
         loc = f.create_group("location", track_order=True)
-        loc.create_dataset("lon", data=lon, chunks=(16, 24), compression="gzip", fletcher32=True)
-        loc.create_dataset("lat", data=lat, chunks=(16, 24), compression="gzip")
+        loc.create_dataset("lon", data=lon, chunks=(16, 32), compression="gzip", fletcher32=True)
+        loc.create_dataset("lat", data=lat, chunks=(16, 32), compression="gzip")
         loc.create_dataset("glt_x", data=glt_x, chunks=(30, 70), compression="gzip", shuffle=True, fillvalue=np.int32(0))
         loc.create_dataset("glt_y", data=glt_y, chunks=(30, 70), compression="gzip", shuffle=True, fillvalue=np.int32(0))
-        loc.create_dataset("elev", shape=(ROWS, COLS), dtype="f4", chunks=(16, 24), fillvalue=np.float32(-9999.0))   # never written: all fill
+        loc.create_dataset("elev", shape=(ROWS, COLS), dtype="f4", chunks=(16, 32), fillvalue=np.float32(-9999.0))   # never written: all fill
 
 
 def tiff_arrays():

@@ -273,3 +273,33 @@ def test_emit_full_height_block_vs_fp64_oracle(hip):
     e, ea = rel(mf[ok], want_mf[ok]).max(), rel(alb[ok], want_alb[ok]).max()
     print(f"EMIT block 1280 x 2 x {S}: mf {e:.2e}, albedo {ea:.2e} vs the fp64 oracle")
     assert e < 1e-6 and ea < 1e-6
+
+
+def test_id_layout_equals_sorted_layout(hip):
+    """orthorectified group maps (|GLT sample index|, process_aviris.py:211-217) are laid out by a stable counting sort on the
+    device (sc_mag1c_layout_ids); bit-identical to the general torch sort path: scattered ids with gaps, groups of <= 10 pixels
+    (skipped), masked pixels, NODATA pixels; ids the counting sort does not take (negative) fall back to the sort"""
+    rng = np.random.default_rng(12)
+    t = np.load(os.path.join(G, "g3_templates.npz"))["aviris_template_kept"][:, 1][:24]
+    H, W, S = 90, 70, 24
+    cube = (rng.uniform(1, 6, size=S) * (1 + 0.05 * rng.standard_normal((H, W, S)))).astype(np.float32)
+    cube[5:9, 3, 2] = hip_mag1c.NODATA
+    ids = ((np.arange(W)[None, :] * 3 + np.arange(H)[:, None] // 4) % 37) * 5 + 2          # ids 2, 7, ..., 182 (gaps), scattered
+    ids[40:42, 10:13] = 400                                                                # a group of 6 pixels: skipped
+    ids[:3, :] = 0
+    mask = (rng.random((H, W)) > 0.1) & (ids != 0)
+    x = torch.from_numpy(cube).to(DEV)
+    for m, mg in ((mask, None), (mask, 400), (None, None)):
+        a_mf, a_alb = hip_mag1c.acrwl1mf_by_groups(x, t, ids, mask=m, max_group=mg)
+        try:
+            hip_mag1c.COLUMN_FAST_PATH = False
+            b_mf, b_alb = hip_mag1c.acrwl1mf_by_groups(x, t, ids, mask=m)
+        finally:
+            hip_mag1c.COLUMN_FAST_PATH = True
+        assert torch.equal(a_mf, b_mf) and torch.equal(a_alb, b_alb)
+        assert bool((a_mf[40:42, 10:13] == hip_mag1c.NODATA).all())
+        if m is not None:
+            assert bool((a_mf[:3] == hip_mag1c.NODATA).all()) and bool((a_mf[~torch.from_numpy(m).to(DEV)] == hip_mag1c.NODATA).all())
+    neg = ids.copy(); neg[ids == 7] = -7
+    c_mf, _ = hip_mag1c.acrwl1mf_by_groups(x, t, neg, mask=mask)
+    assert torch.equal(c_mf, a_mf if False else hip_mag1c.acrwl1mf_by_groups(x, t, ids, mask=mask)[0])

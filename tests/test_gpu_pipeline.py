@@ -160,6 +160,7 @@ def test_emit_granule_predict_from_netcdf_file(hip):
     for k in ("mf", "albedo", "input", "prediction", "pred_binary", "ratio"):
         assert torch.equal(out[k], want[k]), k
     assert np.allclose(out["wavelengths"], wl[keep]) and out["glt_x"].shape == (60, 70) and out["fill_value"] == -9999.0
+    assert out["prediction"].shape == (32, 32) and out["mf"].shape == (40, 32)
     sub = full["radiance"][..., keep]
     mf_ref, _ = mag1c_ref.mag1c_columns(sub, templ[:, 1], -9999.0, column_step=4)
     assert np.array_equal(out["mf"].cpu().numpy() == -9999.0, mf_ref == -9999.0) and bool((out["mf"][:5, :3] == -9999.0).all())

@@ -10,7 +10,7 @@ from starcop_amd import hdf5_reader as h5
 from starcop_amd import io_formats as io
 
 G = os.path.join(os.path.dirname(__file__), "golden", "io")
-ROWS, COLS, BANDS = 32, 24, 285
+ROWS, COLS, BANDS = 40, 32, 285
 
 
 def emit_arrays():
@@ -22,7 +22,7 @@ def emit_arrays():
     dip = np.exp(-0.5 * ((wl - 2300.0) / 60.0) ** 2).astype(np.float32)
     rad[10:26, 8:20, :] *= (1.0 - 0.03 * dip)
     rad[:5, :3, :] = -9999.0
-    rad[30, 7, 250] = -9999.0
+    rad[38, 7, 250] = -9999.0
     glt_x = rng.integers(0, COLS + 1, (60, 70)).astype(np.int32)
     glt_y = rng.integers(0, ROWS + 1, (60, 70)).astype(np.int32)
     lon = (10.0 + 0.001 * np.arange(COLS)[None, :] + 0.0 * np.arange(ROWS)[:, None]).astype(np.float64)
@@ -45,7 +45,7 @@ def test_hdf5_reader_on_libhdf5_written_emit_like_granules(name, sb):
         assert r.shape == (ROWS, COLS, BANDS) and r.dtype == np.dtype("<f4")
         assert float(r.attrs["_FillValue"]) == -9999.0 and float(r.fillvalue) == -9999.0 and r.attrs["units"] == "uW/cm^2/SR/nm"
         assert np.array_equal(r.read(), rad)
-        assert np.array_equal(r.read((slice(3, 29), slice(5, 20), slice(240, 283))), rad[3:29, 5:20, 240:283])
+        assert np.array_equal(r.read((slice(3, 37), slice(5, 30), slice(240, 283))), rad[3:37, 5:30, 240:283])
         assert np.array_equal(r[7:9, :, 31:33], rad[7:9, :, 31:33])                      # a slab that straddles chunk borders
         assert np.array_equal(f["sensor_band_parameters/wavelengths"].read(), wl) and np.array_equal(f["sensor_band_parameters/fwhm"][...], fwhm)
         assert np.array_equal(f["location/glt_x"].read(), glt_x) and np.array_equal(f["location/glt_y"].read(), glt_y)
