@@ -165,3 +165,118 @@ def test_scene_pipeline_two_ranks(hip, tmp_path):
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29553", str(script)], env=env, capture_output=True, text=True, cwd=ROOT, timeout=400)
     assert p.returncode == 0 and "SCENE_WORLD2_OK" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+
+
+_WORLD2_EQUIV = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["SC_ROOT"])
+backend = os.environ["SC_BACKEND"]
+rank, local = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"])
+dev_index = local if backend == "nccl" else 0
+torch.cuda.set_device(dev_index)
+dev = torch.device("cuda", dev_index)
+if backend == "nccl":
+    dist.init_process_group("nccl", device_id=dev)                   # RCCL over xGMI between the two GPUs
+else:
+    dist.init_process_group("gloo")
+from bench import synth_batch
+from starcop_amd import model_module as mm
+from starcop_amd.parallel import GradSync, broadcast_parameters
+B, T, STEPS = 2, 128, 2
+torch.manual_seed(1234 + 17 * rank)                                  # DIFFERENT init per rank: broadcast_parameters must fix it
+model = mm.ModelModule(mm.default_settings(pos_weight=1)).to(dev).train()
+broadcast_parameters(model.network)
+start = {k: v.clone() for k, v in model.state_dict().items()}
+opt = model.configure_optimizers()["optimizer"]
+halves = [synth_batch(B, T, T, 100 + r, dev) for r in range(2)]
+sync = GradSync(2)
+for _ in range(STEPS):
+    model.fused_train_step(halves[rank], opt, grad_sync=sync)
+got = model.network.flat_parameters().clone()
+# single-process emulation of the same job (DDP semantics: rank-local BatchNorm statistics, gradient AVERAGE over ranks):
+# two replicas take their own half, their flat gradients are summed, both apply Adam with grad_scale 1/2
+reps = []
+for r in range(2):
+    m = mm.ModelModule(mm.default_settings(pos_weight=1)).to(dev).train()
+    m.load_state_dict(start)
+    reps.append((m, m.configure_optimizers()["optimizer"]))
+
+
+class Emul(GradSync):
+    def __init__(self):
+        super().__init__(1)
+        self.world = 2
+    def __call__(self, flat):
+        return 0.5
+    def begin(self, bucket):
+        return None
+
+
+for _ in range(STEPS):
+    grads = []
+    for r, (m, o) in enumerate(reps):
+        net = m.network
+        net._ensure_flat()
+        # forward + loss + backward of this replica's half (no optimiser step yet): the pieces fused_train_step is made of
+        loss = m.training_step(halves[r], 0)
+        m.zero_grad(); loss.backward()
+        grads.append(net.flat_grads().clone())
+    total = grads[0] + grads[1]
+    for m, o in reps:
+        m.network.flat_grads().copy_(total)
+        o.step_flat(grad_scale=0.5)
+want = reps[rank][0].network.flat_parameters()
+d = float((got - want).abs().max())
+scale = float(want.abs().max())
+assert d <= 1e-6 * scale, (rank, d, scale)                           # the sum of two fp32 values is the same in either order
+sd_mine, sd_ref = model.state_dict(), reps[rank][0].state_dict()
+for k in sd_mine:
+    if "running_" in k:
+        assert torch.allclose(sd_mine[k], sd_ref[k], rtol=1e-5, atol=1e-7), (rank, k)      # rank-local statistics, as under DDP
+# both ranks hold the same parameters
+other = got.clone()
+if backend == "nccl":
+    dist.broadcast(other, src=0)
+else:
+    h = other.cpu(); dist.broadcast(h, src=0); other = h.to(dev)
+assert torch.equal(other, got) or rank == 0
+dist.barrier()
+if rank == 0:
+    print("WORLD2_EQUIV_OK", backend, d)
+dist.destroy_process_group()
+"""
+
+
+def _run_world2(backend, port, tmp_path):
+    script = tmp_path / "world2.py"
+    script.write_text(_WORLD2_EQUIV)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SC_ROOT=ROOT, SC_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script)], env=env, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert p.returncode == 0 and "WORLD2_EQUIV_OK" in p.stdout, (p.stdout[-500:], p.stderr[-2500:])
+    return p.stdout
+
+
+def test_two_ranks_equal_the_single_process_emulation(hip, tmp_path):
+    """two data-parallel ranks (different initial seeds: broadcast_parameters aligns them; different halves of the global batch;
+    two-bucket gradient exchange overlapped with the encoder backward) end with the parameters of a single-process emulation of
+    the same job -- two replicas with rank-local BatchNorm statistics whose flat gradients are summed and averaged into Adam.
+    gloo on the one GPU of the box (the functional path)."""
+    _run_world2("gloo", 29561, tmp_path)
+
+
+def test_two_ranks_over_rccl_when_two_gpus(hip, tmp_path):
+    """the same job over REAL RCCL (one process per GPU, xGMI) -- runs only where the box exposes two GPUs: the round's 1-GPU boxes
+    skip it, an 8-GPU node executes the async decoder bucket, the side-stream ordering and the dmabuf IPC setting for real; and
+    `python bench.py --gpus 2` must then report a 2-rank line"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs (RCCL between devices)")
+    _run_world2("nccl", 29563, tmp_path)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-extras"], env=env,
+                       capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert p.returncode == 0, (p.stdout[-500:], p.stderr[-1500:])
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["value"] > 0

@@ -64,6 +64,14 @@ def test_tiled_inference_equals_whole_scene(hip):
     inner[:, 1024 - 384:1024 + 384] = False
     print(f"halo 64: max rel err {float(d.max()):.2e} overall, {float(d[inner].max()):.2e} further than 384 px from any seam")
     assert float(d[inner].max()) < 1e-4
+    # throughput mode: full-width row strips (vertical halo only) -- the same exactness at (512 + 640) / 512 = 2.25x the scene's work
+    # instead of 5x for square cores
+    rs = pipeline.scene_tiles(H, W, 512, 320, strips=True)
+    assert rs.shape[0] == 2 and rs[:, 2].tolist() == [0, 0] and rs[:, 3].tolist() == [W, W] and rs[1, 4:6].tolist() == [192, 1024]
+    strips = pipeline.tiled_logits(model, x, tile=512, halo=pipeline.RECEPTIVE_HALO, strips=True)
+    es = relerr(strips, whole)
+    print(f"strips (512 rows + halo 320) vs whole-scene logits: rel err {es:.2e}")
+    assert es < 1e-4 and torch.equal((strips >= 0)[far], (whole >= 0)[far])
 
 
 def test_emit_scene_predict_tiled_and_ratio(hip):
