@@ -28,9 +28,6 @@
 #include <cstdlib>
 #include <type_traits>
 
-#ifndef SC_EXP
-#define SC_EXP 0      // tools/build_exp.sh: elimination experiments on the weight-gradient kernels (never in the shipped library)
-#endif
 
 namespace {
 
@@ -355,10 +352,6 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
   // operand fetches of one step are issued before the 6*Q MFMAs of the previous step (explicit software pipeline: the
   // scheduler barrier keeps the LDS reads ~6*Q*32 cycles ahead of their use)
   auto load_A = [&](bf16x8 (&A)[Q][NT], int buf, int kw) {
-#if SC_EXP == 8      // experiment: no LDS operand reads
-    for (int q = 0; q < Q; ++q) for (int c = 0; c < NT; ++c) A[q][c] = __builtin_bit_cast(bf16x8, (uintx4){(unsigned)(buf + kw + q), (unsigned)c, 1u, 2u});
-    return;
-#endif
 #pragma unroll
     for (int q = 0; q < Q; ++q)
 #pragma unroll
@@ -366,13 +359,6 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
         A[q][c] = __builtin_bit_cast(bf16x8, s_w[buf][((c * 3 + kw) * 2 + lhi) * CO_T + q * 32 + l31]);
   };
   auto load_B = [&](bf16x8 (&B)[NT], int kh, int kw, int pp) {
-#if SC_EXP == 8
-    for (int c = 0; c < NT; ++c) B[c] = __builtin_bit_cast(bf16x8, (uintx4){(unsigned)(kh + kw + pp), (unsigned)c, 3u, 4u});
-    return;
-#endif
-#if SC_EXP == 11     // experiment: only the kw = 0 patch operands are read (a third of the B reads; wrong results)
-    if (kw != 0) return;
-#endif
     const int e = (2 * wave + pp + kh) * PC + l31 + kw;
 #pragma unroll
     for (int c = 0; c < NT; ++c) B[c] = __builtin_bit_cast(bf16x8, s_p[c][lhi][e]);
@@ -398,11 +384,7 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
     bf16x2 h0 = {}, h1 = {}, h2 = {};
     auto mf = [&](int i) {
       const int pr = i / Q, q = i - pr * Q;
-#if SC_EXP == 7      // experiment: no MFMAs (two integer ops keep the operand reads alive)
-      acc[PP][q][0] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, acc[PP][q][0]) ^ __builtin_bit_cast(uintx4, A[q][TA[pr]])[pr & 3] ^ __builtin_bit_cast(uintx4, B[TB[pr]])[(pr + 1) & 3]);
-#else
       acc[PP][q] = mfma_split<HF>(A[q][TA[pr]], B[TB[pr]], acc[PP][q]);
-#endif
     };
     auto pro = [&](int j) {
       const float t = BNB ? sc_pro_bnbwd(xv[r][j], av[BNB ? r : 0][j], cs0[j], cs1[j], cs2[j], cs3[j], cs4[j], slo, shi)
@@ -518,15 +500,9 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
     auto stage = [&](int s, int kh, uintx4 (&WA)[NWV], uintx4 (&WB)[NWV], int patch_kc) {
       load_w(WB, s + 2 < nst ? s + 2 : nst - 1);
       if (patch_kc >= 0) next_patch(patch_kc);
-#if SC_EXP == 12
-      compute(kh, s & 1, std::false_type{}, 0);
-#else
       compute_deep(kh, s & 1);
-#endif
       store_w(WA, (s + 1) & 1);
-#if SC_EXP != 9      // experiment 9: no barriers
       __syncthreads();
-#endif
     };
     auto chunk = [&](int kc, uintx4 (&WA)[NWV], uintx4 (&WB)[NWV]) {
       const int s = 3 * kc;
@@ -535,14 +511,10 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
       stage(s + 1, 1, WB, WA, -1);
       stage(s + 2, 2, WA, WB, -1);
       if (more) {
-#if SC_EXP != 10     // experiment 10: no conversion
 #pragma unroll
         for (int u = 0; u < 12; ++u) convert_unit(u >> 2, u & 3);
-#endif
         store_patch();
-#if SC_EXP != 9
         __syncthreads();
-#endif
       }
     };
     for (int kc = 0; kc < nk; kc += 2) {
@@ -552,11 +524,7 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
   } else {
     auto stage = [&](int s, int kh, auto cvt, int cv) {
       load_w(wvA, s + 1 < nst ? s + 1 : s);          // the last stage reloads itself (unused)
-#if SC_EXP == 12
-      compute(kh, s & 1, cvt, cv);
-#else
       if constexpr (NT != 3) compute_deep(kh, s & 1); else compute(kh, s & 1, cvt, cv);
-#endif
       store_w(wvA, (s + 1) & 1);
       __syncthreads();
     };
@@ -972,27 +940,10 @@ __global__ __launch_bounds__(512, 4) void k_conv3_ws(const ConvXP p) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int s = 3 * kc + j;
-#if SC_EXP == 13     // experiment 13: idle producers (consumer path alone)
-        (void)s;
-#elif SC_EXP == 14   // experiment 14: no global loads in the loop
-        convert_store_round(cnext, K1, j, pb);
-        store_w(wr[j], (s + 1) & 1);
-#elif SC_EXP == 15   // experiment 15: loads only (no conversion, no LDS stores)
-        load_round(cn2, j);
-        load_w(wr[j], clamps(s + 4));
-        if (xv[j][0] == 1.2345f && wr[j][0][0] == 77u) s_w[0][tid] = wr[j][0];     // keep the loads alive
-#elif SC_EXP == 16   // experiment 16: no filter traffic
-        convert_store_round(cnext, K1, j, pb);
-        load_round(cn2, j);
-#elif SC_EXP == 17   // experiment 17: no patch traffic
-        store_w(wr[j], (s + 1) & 1);
-        load_w(wr[j], clamps(s + 4));
-#else
         convert_store_round(cnext, K1, j, pb);
         load_round(cn2, j);
         store_w(wr[j], (s + 1) & 1);
         load_w(wr[j], clamps(s + 4));
-#endif
         __syncthreads();
       }
       cnext = cn2;
@@ -1018,10 +969,6 @@ __global__ __launch_bounds__(512, 4) void k_conv3_ws(const ConvXP p) {
 
   int pbuf = 0;                                         // patch buffer the consumers read
   auto load_A = [&](bf16x8 (&A)[Q][NT], int buf, int kw) {
-#if SC_EXP == 8      // experiment: no LDS operand reads
-    for (int q = 0; q < Q; ++q) for (int c = 0; c < NT; ++c) A[q][c] = __builtin_bit_cast(bf16x8, (uintx4){(unsigned)(buf + kw + q), (unsigned)c, 1u, 2u});
-    return;
-#endif
 #pragma unroll
     for (int q = 0; q < Q; ++q)
 #pragma unroll
@@ -1029,13 +976,6 @@ __global__ __launch_bounds__(512, 4) void k_conv3_ws(const ConvXP p) {
         A[q][c] = __builtin_bit_cast(bf16x8, s_w[buf][((c * 3 + kw) * 2 + lhi) * CO_T + q * 32 + l31]);
   };
   auto load_B = [&](bf16x8 (&B)[NT], int kh, int kw, int pp) {   // reads patch buffer `pbuf`
-#if SC_EXP == 8
-    for (int c = 0; c < NT; ++c) B[c] = __builtin_bit_cast(bf16x8, (uintx4){(unsigned)(kh + kw + pp), (unsigned)c, 3u, 4u});
-    return;
-#endif
-#if SC_EXP == 11     // experiment: only the kw = 0 patch operands are read (a third of the B reads; wrong results)
-    if (kw != 0) return;
-#endif
     const int e = (2 * wave + pp + kh) * PC + l31 + kw;
 #pragma unroll
     for (int c = 0; c < NT; ++c) B[c] = __builtin_bit_cast(bf16x8, s_p[pbuf][c][lhi][e]);
@@ -1633,15 +1573,11 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
       const float* const gx = p.dy.x + (size_t)n * p.Cout * HW;
       const unsigned base = (unsigned)(okc ? co : 0) * (unsigned)HW + (unsigned)((okc ? y : 0) * W);
       const unsigned xa = (x < W) ? x : 0, xb = (x + 1 < W) ? x + 1 : 0;
-#if SC_EXP == 2      // experiment: no global loads
-      dg[k][0] = (float)(base + xa); dg[k][1] = (float)(base + xb); dv[k][0] = dg[k][1]; dv[k][1] = dg[k][0]; (void)gx;
-#else
       dg[k][0] = gx[base + xa]; dg[k][1] = gx[base + xb];
       if (dymode == SC_SRC_BNBWD) {
         const float* const ga = p.dy.aux + (size_t)n * p.Cout * HW;
         dv[k][0] = ga[base + xa]; dv[k][1] = ga[base + xb];
       } else { dv[k][0] = 0.f; dv[k][1] = 0.f; }
-#endif
     }
   };
   auto dy_load = [&](int n, int y0, int x0) {
@@ -1668,13 +1604,8 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
       v0 = (okc && x < W) ? v0 : 0.f;
       v1 = (okc && x + 1 < W) ? v1 : 0.f;
       unsigned t[3];
-#if SC_EXP == 3      // experiment: no prologue, no split
-      t[0] = __builtin_bit_cast(unsigned, dg[k][0]) ^ __builtin_bit_cast(unsigned, dv[k][0]); t[1] = __builtin_bit_cast(unsigned, dg[k][1]) ^ __builtin_bit_cast(unsigned, dv[k][1]); t[2] = 0u;
-      (void)v0; (void)v1;
-#else
       if constexpr (HF) { split2h(v0, v1, t[0], t[1]); t[2] = 0u; }
       else split3x2(v0, v1, t[0], t[1], t[2]);
-#endif
       const int d = (col_l * DYP + row * 32 + col) >> 1;
       if (PIPE || it < COT * 32) {
 #pragma unroll
@@ -1717,11 +1648,7 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
       const int Ws = W >> up;
       const float* xp = (second ? p.s1.x : p.s0.x) + ((size_t)n * Cs + cs) * ((size_t)(H >> up) * Ws) + (size_t)((oky ? y : 0) >> up) * Ws;
       const int xa = (x >= 0 && x < W) ? x : 0, xb = (x + 1 < W) ? x + 1 : 0;
-#if SC_EXP == 2
-      xr[k][0] = (float)(xa >> up) + (float)(size_t)xp; xr[k][1] = (float)(xb >> up);
-#else
       xr[k][0] = xp[xa >> up]; xr[k][1] = xp[xb >> up];
-#endif
     }
   };
   auto x_load = [&](float (&xr)[NXI][2], int n, int R, int x0) {
@@ -1743,12 +1670,8 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
       v0 = (okc && x >= 0 && x < W) ? v0 : 0.f;
       v1 = (okc && x + 1 < W) ? v1 : 0.f;
       unsigned t[3];
-#if SC_EXP == 3
-      t[0] = __builtin_bit_cast(unsigned, xr[k][0]); t[1] = __builtin_bit_cast(unsigned, xr[k][1]); t[2] = 0u; (void)v0; (void)v1;
-#else
       if constexpr (HF) { split2h<false>(v0, v1, t[0], t[1]); t[2] = 0u; }
       else split3x2(v0, v1, t[0], t[1], t[2]);
-#endif
       const int slot = (sl0 + rowi) & (RING - 1);
       const int d = ((cil * XCP + slot * XRP) >> 1) + pr;
       if (PIPE || it < 2 * 17 * CIT) {
@@ -1763,9 +1686,6 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
   };
 
   auto compute = [&](int sl0, int buf) {          // sl0: ring slot of image row y0 - 1
-#if SC_EXP == 4
-    return;
-#endif
 #pragma unroll
     for (int rr = 0; rr < (KP == 1 ? 2 : 1); ++rr) {
       const int r = (KP == 1) ? rr : (kp & 1);
@@ -1797,15 +1717,9 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
           B[2][t] = __builtin_bit_cast(bf16x8, S2);
         }
         // the six partial products, taps interleaved so that consecutive MFMAs hit different accumulators
-#if SC_EXP == 1     // experiment: no MFMAs (one FMA keeps the operand reads alive)
-#define SC_BX3_STEP(TA, TB)                                                                                         \
-  _Pragma("unroll") for (int kw = 0; kw < 3; ++kw)                                                                  \
-      acc[kw][0] += (float)(__builtin_bit_cast(uintx4, A[TA])[0] & 0xffffu) * (float)(__builtin_bit_cast(uintx4, B[kw][TB])[0] & 0xffffu);
-#else
 #define SC_BX3_STEP(TA, TB)                                                                                         \
   _Pragma("unroll") for (int kw = 0; kw < 3; ++kw)                                                                  \
       acc[kw] = mfma_split<HF>(A[TA], B[kw][TB], acc[kw]);
-#endif
         if constexpr (NT == 3) { SC_BX3_STEP(1, 1) SC_BX3_STEP(2, 0) SC_BX3_STEP(0, 2) SC_BX3_STEP(1, 0) SC_BX3_STEP(0, 1) }
         if constexpr (NT == 2) { SC_BX3_STEP(0, 1) SC_BX3_STEP(1, 0) }
         SC_BX3_STEP(0, 0)
