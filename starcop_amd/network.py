@@ -515,7 +515,7 @@ class HyperStarcopUNet(nn.Module):
     def _pack_all(self, need_bwd):
         """(Re)pack conv filters into the MFMA kernels' layouts when the parameters changed."""
         lib = _lib.load()
-        ver = tuple(p._version for p in self.parameters())
+        ver = (tuple(p._version for p in self.parameters()), self._terms, self.split_bf16, self.thin16)    # a precision switch repacks too
         pv = self._pack_version
         if pv is not None and pv[0] == ver and (pv[1] or not need_bwd):
             return
