@@ -265,8 +265,14 @@ int sc_head_conv_wgrad(const float* dlogits, const sc_src* in, float* part, size
 /* dgrad + wgrad + dbias of the head in ONE sweep over (dlogits, in) -- Cin = 16 only (model_module.py:244-251: the decoder's last
  * block has 16 channels); same results as the two calls above, gin = gradient w.r.t. the ACTIVATED input.  Workspace as for
  * sc_head_conv_wgrad. */
+/* bn_sums != NULL (then `in` must be the SC_SRC_AFFINE source of a BatchNorm'd tensor): the launch also leaves what
+ * sc_bn_bwd_reduce(gin, in->x, in->cst, in->act, ...) would compute in a pass of its own over both tensors -- rows
+ * bn_sums[sc_head_bwd_bn_rows(N, H, W)][Cin][2] = {sum g', sum g' x_hat} for sc_bn_bwd_finalize, and (bn_absmax != NULL, zeroed by
+ * the caller) the range hint max |scale_c g'| -- because gin is that tensor's complete gradient and its values stream through
+ * this kernel anyway. */
+int sc_head_bwd_bn_rows(int N, int H, int W);
 int sc_head_conv_bwd(const float* dlogits, const sc_src* in, const float* w, float* gin, float* part, size_t part_floats,
-                     float* dw, float* dbias, int N, int Cin, int H, int W, sc_stream stream);
+                     float* dw, float* dbias, int N, int Cin, int H, int W, double* bn_sums, float* bn_absmax, sc_stream stream);
 
 /* ------------------------------------------------------------------------- */
 /* BatchNorm2d bookkeeping (torch.nn.BatchNorm2d inside smp/torchvision blocks)

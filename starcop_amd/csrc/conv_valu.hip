@@ -1334,17 +1334,25 @@ __global__ __launch_bounds__(256) void k_head_dgrad(const float* __restrict__ dl
 // row's loads in flight; persistent over tiles so that the 36 wave sums + atomics per wave are paid once per work-group.
 constexpr int HB_ROW = 16 * 9 + 1, HB_MAXWG = 1024;       // floats per partial row, most work-groups of a launch
 constexpr int HB_R = 32, HB_PF = 4;       // tile rows, rows of load look-ahead (HB_R % HB_PF == 0)
+// BNS: the launch also leaves the BatchNorm-backward sums of the INPUT tensor (the gradient it writes is that tensor's complete
+// gradient, and its raw values pass through this kernel anyway): per work-group rows bn_sums[wg][16][2] = {sum g', sum g' x_hat},
+// g' = gin * act'(BN(y)), and the range hint max |scale g'| -- what sc_bn_bwd_reduce(gin, y) computes in a pass of its own
+// (536 MB at 16 x 512^2).
+template <bool BNS>
 __global__ __launch_bounds__(256) void k_head_bwd16(const float* __restrict__ dl, const SrcD in, const float* __restrict__ w,
-                                                    float* __restrict__ gin, float* __restrict__ rows, int N, int H, int W) {
+                                                    float* __restrict__ gin, float* __restrict__ rows, int N, int H, int W,
+                                                    double* __restrict__ bn_sums, float* __restrict__ bn_absmax) {
   constexpr int CIN = 16, PR = HB_R + 2, PC = 64 + 2;
   __shared__ float s_dl[PR * PC];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int c0 = wave * 4;                         // (uniform: the filters and constants below are scalar loads into SGPRs)
-  float wk[4][9], sc[4], sh[4];
+  float wk[4][9], sc[4], sh[4], mu[4], is[4];
+  float b1[4] = {0.f, 0.f, 0.f, 0.f}, b2[4] = {0.f, 0.f, 0.f, 0.f}, bmx = 0.f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    sc[j] = 1.f; sh[j] = 0.f;
+    sc[j] = 1.f; sh[j] = 0.f; mu[j] = 0.f; is[j] = 1.f;
     if (in.mode != SC_SRC_RAW) { sc[j] = in.cst[(size_t)(c0 + j) * SC_CST]; sh[j] = in.cst[(size_t)(c0 + j) * SC_CST + 1]; }
+    if (BNS) { mu[j] = in.cst[(size_t)(c0 + j) * SC_CST + 2]; is[j] = in.cst[(size_t)(c0 + j) * SC_CST + 3]; }
 #pragma unroll
     for (int t = 0; t < 9; ++t) wk[j][t] = w[(c0 + j) * 9 + t];
   }
@@ -1398,6 +1406,13 @@ __global__ __launch_bounds__(256) void k_head_bwd16(const float* __restrict__ dl
 #pragma unroll
           for (int t = 0; t < 9; ++t) g = fmaf(wk[j][t], d[t], g);
           if (ok) gb[(size_t)j * HW + (size_t)y * W] = g;
+          if (BNS) {
+            const float yh = fmaf(xq[u][j], sc[j], sh[j]);
+            const float gq = (ok && yh > lo && yh < hi) ? g : 0.f;
+            b1[j] += gq;
+            b2[j] = fmaf(gq, (xq[u][j] - mu[j]) * is[j], b2[j]);
+            bmx = fmaxf(bmx, fabsf(gq * sc[j]));
+          }
           const float xa = ok ? sc_pro_affine(xq[u][j], sc[j], sh[j], lo, hi) : 0.f;
 #pragma unroll
           for (int t = 0; t < 9; ++t) prod[j][t] = fmaf(xa, d[t], prod[j][t]);
@@ -1418,6 +1433,21 @@ __global__ __launch_bounds__(256) void k_head_bwd16(const float* __restrict__ dl
   if (wave == 0) {
     bsum = wave_sum(bsum);
     if (lane == 0) rows[(size_t)blockIdx.x * HB_ROW + CIN * 9] = bsum;
+  }
+  if (BNS) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float s1 = wave_sum(b1[j]), s2 = wave_sum(b2[j]);
+      if (lane == 0) {
+        bn_sums[((size_t)blockIdx.x * CIN + c0 + j) * 2] = (double)s1;
+        bn_sums[((size_t)blockIdx.x * CIN + c0 + j) * 2 + 1] = (double)s2;
+      }
+    }
+    if (bn_absmax) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) bmx = fmaxf(bmx, __shfl_xor(bmx, o, 64));
+      if (lane == 0 && bmx > __builtin_nontemporal_load(bn_absmax)) atomicMax(reinterpret_cast<unsigned*>(bn_absmax), __builtin_bit_cast(unsigned, bmx));
+    }
   }
 }
 // dW / dbias = column sums (in double) of the partial rows: one work-group per column
@@ -1583,8 +1613,14 @@ extern "C" int sc_dwconv3x3_bwd_fused(const sc_src* dy, const sc_src* in, const 
   return SC_OK;
 }
 
+extern "C" int sc_head_bwd_bn_rows(int N, int H, int W) {
+  const long T = (long)N * ((W + 63) / 64) * ((H + HB_R - 1) / HB_R);
+  return (int)(T < HB_MAXWG ? T : HB_MAXWG);
+}
+
 extern "C" int sc_head_conv_bwd(const float* dlogits, const sc_src* in, const float* w, float* gin, float* part, size_t part_floats,
-                                float* dw, float* dbias, int N, int Cin, int H, int W, sc_stream stream) {
+                                float* dw, float* dbias, int N, int Cin, int H, int W, double* bn_sums, float* bn_absmax,
+                                sc_stream stream) {
   SC_REQUIRE(dlogits && in && w && gin && part && dw && in->C == Cin, "sc_head_conv_bwd: bad argument");
   SC_REQUIRE(Cin == 16, "sc_head_conv_bwd: Cin must be 16 (use sc_head_conv_dgrad + sc_head_conv_wgrad otherwise)");
   SC_REQUIRE((in->mode == SC_SRC_RAW || in->mode == SC_SRC_AFFINE) && in->up == 0, "sc_head_conv_bwd: unsupported source mode");
@@ -1593,7 +1629,9 @@ extern "C" int sc_head_conv_bwd(const float* dlogits, const sc_src* in, const fl
   hipStream_t st = (hipStream_t)stream;
   const long T = (long)N * ((W + 63) / 64) * ((H + HB_R - 1) / HB_R);
   const int nwg = (int)(T < HB_MAXWG ? T : HB_MAXWG);       // (all resident: 116 registers -> 4 work-groups per CU)
-  hipLaunchKernelGGL(k_head_bwd16, dim3(nwg), dim3(256), 0, st, dlogits, to_srcd(*in), w, gin, part, N, H, W);
+  SC_REQUIRE(!bn_sums || in->mode == SC_SRC_AFFINE, "sc_head_conv_bwd: the fused BatchNorm-backward sums need the AFFINE source of that BatchNorm");
+  if (bn_sums) hipLaunchKernelGGL(k_head_bwd16<true>, dim3(nwg), dim3(256), 0, st, dlogits, to_srcd(*in), w, gin, part, N, H, W, bn_sums, bn_absmax);
+  else hipLaunchKernelGGL(k_head_bwd16<false>, dim3(nwg), dim3(256), 0, st, dlogits, to_srcd(*in), w, gin, part, N, H, W, (double*)nullptr, (float*)nullptr);
   SC_LAUNCH_OK("sc_head_conv_bwd");
   hipLaunchKernelGGL(k_head_bwd_reduce, dim3(HB_ROW), dim3(256), 0, st, part, nwg, dw, dbias);
   SC_LAUNCH_OK("sc_head_conv_bwd(reduce)");

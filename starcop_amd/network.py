@@ -101,6 +101,7 @@ class _T:
 
 
 _COT_RATIO = float(os.environ.get("STARCOP_COT_RATIO", "1.15"))
+_COT_RATIO3 = float(os.environ.get("STARCOP_COT_RATIO3", "1.15"))     # the same choice for the 3x3 layers (64-wide tiles stage a patch fewer times)
 # development knob: "d0a,d0b;d0a" forces 32-wide cout tiles for the forward (before ';') / backward-data launches of these ops
 _FORCE_COT32 = [set(x.split(",")) for x in (os.environ.get("STARCOP_FORCE_COT32", ";") + ";").split(";")[:2]]
 _HEAD_FUSED_BWD = os.environ.get("STARCOP_HEAD_FUSED_BWD", "1") != "0"      # dev knob: 0 = separate head dgrad / wgrad launches
@@ -112,7 +113,7 @@ def _pick_cot(M, ks=1):
     if M <= 32:
         return 32
     p32, p64 = -(-M // 32) * 32, -(-M // 64) * 64
-    return 64 if p64 <= p32 * _COT_RATIO else 32
+    return 64 if p64 <= p32 * (_COT_RATIO3 if ks == 3 else _COT_RATIO) else 32
 
 
 # Pointwise convolutions on sc_conv1x1_pw3 / sc_conv1x1_wgrad_pw3 (conv_pw3.hip: split-bf16 MFMA, register-only, no LDS staging).
@@ -742,6 +743,7 @@ class HyperStarcopUNet(nn.Module):
     # OFF: measured 1179 vs 1189 tiles/s -- the reduction pass it saves runs at 6 TB/s (0.24 ms), the extra ~25 VALU per element
     # in the issue-bound 1x1 epilogue cost 0.37 ms.
     fuse_bn_bwd = os.environ.get("STARCOP_FUSE_BNBWD", "0") != "0"
+    fuse_head_bn = os.environ.get("STARCOP_FUSE_HEAD_BN", "1") != "0"      # BatchNorm-backward sums of the decoder's last tensor in the head backward
     thin16 = os.environ.get("STARCOP_THIN16", "1") != "0"     # decoder.blocks.4 on sc_conv3x3_thin16 (0: the fp32-MFMA thin kernels)
     split_bf16 = True        # 3x3 convs with >= 32 output channels on the 16-bit matrix cores (False: everything on the fp32 MFMA)
     bn_small_max = 16384     # BatchNorm backward in one launch (block per channel) when a channel has at most this many elements
@@ -827,18 +829,19 @@ class HyperStarcopUNet(nn.Module):
         for op in self._ops:
             for t in op["ins"]:
                 n_cons[t.name] = n_cons.get(t.name, 0) + 1
+        prod_idx = {op["out"].name: k for k, op in enumerate(self._ops)}      # producer op of every tensor (its range-hint slot)
         pw_pending = []      # pointwise weight gradients whose K-slice partials await the batched reduction
 
         def bn_backward(t, slot=None):
             Ho, Wo = H >> t.shift, W >> t.shift
-            if t.name in reduced:
-                check(lib.sc_bn_bwd_finalize(ptr(plan.dwsums[t.name]), plan.dwrows[t.name], float(N * Ho * Wo), ptr(plan.cst[t.name]),
-                                             ptr(gv(t.bn.weight)), ptr(gv(t.bn.bias)), ptr(plan.cstb[t.name]), t.C, st))
-                return
             amax = None
             if slot is not None:
                 amax = plan.gmax.data_ptr() + 4 * slot
                 gmax_slot[t.name] = amax
+            if t.name in reduced:          # the launch that wrote this gradient left the sums (and raised the range-hint slot)
+                check(lib.sc_bn_bwd_finalize(ptr(plan.dwsums[t.name]), plan.dwrows[t.name], float(N * Ho * Wo), ptr(plan.cst[t.name]),
+                                             ptr(gv(t.bn.weight)), ptr(gv(t.bn.bias)), ptr(plan.cstb[t.name]), t.C, st))
+                return
             aslot = plan.act_slot.get(t.name)           # BatchNorm-fed input of a split convolution: sticky max |BN(y)| record
             aact = plan.act_amax.data_ptr() + 4 * aslot if aslot is not None else None
             if N * Ho * Wo <= self.bn_small_max and t.C >= 64:        # low-resolution layers: one launch, one block per channel
@@ -871,9 +874,21 @@ class HyperStarcopUNet(nn.Module):
                 s = self._src_of(plan, tin)
                 tok = self._pb("k_head_*")
                 if conv.in_channels == 16 and _HEAD_FUSED_BWD:
-                    # one sweep over (dlogits, x) for gin, dW and dbias (sc_head_conv_bwd)
+                    # one sweep over (dlogits, x) for gin, dW and dbias (sc_head_conv_bwd) -- and, the head being the only consumer
+                    # of the decoder's last tensor, that tensor's BatchNorm-backward sums and range hint (its raw values stream
+                    # through the kernel anyway): saves sc_bn_bwd_reduce's pass over 2 x 268 MB at 16 x 512^2
+                    bns = bna = None
+                    if self.fuse_head_bn and tin.bn is not None and tin.kind == "raw" and n_cons.get(tin.name, 0) == 1:
+                        if tin.name not in plan.dwsums:
+                            plan.dwrows[tin.name] = lib.sc_head_bwd_bn_rows(N, Ho, Wo)
+                            plan.dwsums[tin.name] = torch.empty(plan.dwrows[tin.name] * tin.C * 2, dtype=torch.float64, device=self._pflat.device)
+                        bns = ptr(plan.dwsums[tin.name])
+                        if half_bwd:
+                            bna = plan.gmax.data_ptr() + 4 * prod_idx[tin.name]
+                        reduced.add(tin.name)
                     check(lib.sc_head_conv_bwd(ptr(dlogits), C.byref(s), ptr(conv.weight), ptr(plan.grad[tin.name]), ptr(plan.ws),
-                                               plan.ws_floats, ptr(gv(conv.weight)), ptr(gv(conv.bias)), N, conv.in_channels, Ho, Wo, st))
+                                               plan.ws_floats, ptr(gv(conv.weight)), ptr(gv(conv.bias)), N, conv.in_channels, Ho, Wo,
+                                               bns, bna, st))
                 else:
                     wgrad_launch(lambda sx: check(lib.sc_head_conv_wgrad(
                         ptr(dlogits), C.byref(s), ptr(plan.ws), plan.ws_floats, ptr(gv(conv.weight)), ptr(gv(conv.bias)), N,

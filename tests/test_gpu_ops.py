@@ -487,9 +487,26 @@ def test_head(hip):
     # the one-sweep backward (Cin = 16): same gin bit for bit, same dW / dbias
     gin2 = torch.full((N, Cin, H, W), float("nan"), device=DEV)
     dw2, db2 = torch.empty(1, Cin, 3, 3, device=DEV), torch.empty(1, device=DEV)
-    check(hip.sc_head_conv_bwd(ptr(dld), C.byref(src), ptr(wd), ptr(gin2), ptr(ws), n, ptr(dw2), ptr(db2), N, Cin, H, W, stream()))
+    check(hip.sc_head_conv_bwd(ptr(dld), C.byref(src), ptr(wd), ptr(gin2), ptr(ws), n, ptr(dw2), ptr(db2), N, Cin, H, W, None, None, stream()))
     assert torch.equal(gin2, gin)
     assert relerr(dw2, wr.grad) < TOL and relerr(db2, br.grad) < TOL
+    # ... and the BatchNorm-backward sums of its input in the same sweep == what sc_bn_bwd_reduce computes from (gin, x)
+    cf = torch.zeros(Cin, SC_CST); cf[:, 0], cf[:, 1], cf[:, 2], cf[:, 3] = sc, sh, rnd(Cin, seed=6) * 0.1, rnd(Cin, seed=7).abs() + 0.5
+    cfd = dev(cf)
+    src2 = make_src(dev(x), Cin, SRC_AFFINE, act=ACT_RELU, cst=cfd)
+    rows = hip.sc_head_bwd_bn_rows(N, H, W)
+    sums = torch.full((rows, Cin, 2), float("nan"), dtype=torch.float64, device=DEV)
+    amax = torch.zeros(1, device=DEV)
+    gin3 = torch.empty(N, Cin, H, W, device=DEV)
+    check(hip.sc_head_conv_bwd(ptr(dld), C.byref(src2), ptr(wd), ptr(gin3), ptr(ws), n, ptr(dw2), ptr(db2), N, Cin, H, W, ptr(sums), ptr(amax), stream()))
+    assert torch.equal(gin3, gin) and not torch.isnan(sums).any()
+    rrows = hip.sc_stat_rows(STAT_BNBWD, N, H, W)
+    rsums = torch.empty(rrows * Cin * 2, dtype=torch.float64, device=DEV)
+    ramax = torch.zeros(1, device=DEV)
+    check(hip.sc_bn_bwd_reduce(ptr(gin), ptr(dev(x)), ptr(cfd), ACT_RELU, ptr(rsums), N, Cin, H * W, ptr(ramax), None, stream()))
+    want = rsums.view(rrows, Cin, 2).sum(0)
+    assert relerr(sums.sum(0)[:, 0], want[:, 0]) < 1e-6 and relerr(sums.sum(0)[:, 1], want[:, 1]) < 1e-6
+    assert float(amax) == pytest.approx(float(ramax), rel=1e-6)
 
 
 def test_batchnorm_bookkeeping(hip):
