@@ -280,9 +280,12 @@ int sc_head_conv_bwd(const float* dlogits, const sc_src* in, const float* w, flo
  *             `momentum` (unbiased variance), cst_fwd = {scale, shift, mean, invstd,...}
  * training=0: cst_fwd from running stats */
 int sc_stat_rows(int kind, int N, int H, int W);
+/* scratch (optional, SC_BN_FINALIZE_SCRATCH_DOUBLES(C) doubles): with >= 4096 rows the rows of all channels are first summed as
+ * one coalesced stream into 64 fp64 partial rows there (the per-channel walk reads a 64-byte sector per 8 useful bytes) */
+#define SC_BN_FINALIZE_SCRATCH_DOUBLES(C) (64 * 2 * (size_t)(C))
 int sc_bn_finalize(const float* stats, int nrows, double count, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps,
-                   int training, float* cst_fwd, int C, sc_stream stream);
+                   int training, float* cst_fwd, int C, double* scratch, sc_stream stream);
 /* sums[row][C][2] = { sum g_bn, sum g_bn * xhat } over the row's pixels, g_bn = g * act'(BN(y));
  * rows = sc_stat_rows(SC_STAT_BNBWD, N, H, W).
  * absmax (optional, device float, zeroed by the caller before the first launch of a step): raised to

@@ -100,7 +100,7 @@ SIGNATURES = {
     "sc_head_conv_bwd": (_i, [_vp, C.POINTER(sc_src), _vp, _vp, _vp, _sz, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sc_head_bwd_bn_rows": (_i, [_i, _i, _i]),
     "sc_stat_rows": (_i, [_i, _i, _i, _i]),
-    "sc_bn_finalize": (_i, [_vp, _i, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _i, _vp]),
+    "sc_bn_finalize": (_i, [_vp, _i, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _i, _vp, _vp]),
     "sc_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "sc_bn_bwd_small": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sc_bn_bwd_finalize": (_i, [_vp, _i, _d, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -47,8 +47,39 @@ __device__ __forceinline__ void block_sum_d(double (&v)[NV], double* s_tmp /* [4
 // one block per channel: fp64 sum of the per-work-group partial rows, then the per-channel constants.  NW waves per block: a
 // channel's rows are C*8 bytes apart (one 64-byte sector per 8 useful bytes), so the sum is a latency chain of nrows / (64 NW x 8)
 // round trips -- 16 waves for the full-resolution layers (32768 rows: 38 -> ~12 us), 4 otherwise
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_bn_finalize(const float* __restrict__ stats, int nrows, double count,
+// Pre-reduction for the many-row layers (full resolution: 8192-32768 rows): the rows of ALL channels are read as one contiguous
+// stream (consecutive threads = consecutive floats of a row: coalesced, every byte used -- the per-channel walk above touches a
+// 64-byte sector per 8 useful bytes, and C blocks each pull the whole buffer), BN_PRE_S work-groups x 1024 threads, fp64 sums, a
+// fixed-order LDS reduction -> part[BN_PRE_S][C][2] doubles for k_bn_finalize<4, double>.
+constexpr int BN_PRE_S = 64;
+__global__ __launch_bounds__(1024) void k_bn_rows_prereduce(const float* __restrict__ stats, int nrows, int C, double* __restrict__ part) {
+  __shared__ double s_d[1024];
+  const int E = 2 * C;                       // floats per row
+  const int rpp = 1024 / E;                  // rows per pass of the block
+  const int e = threadIdx.x % E, rs = threadIdx.x / E;
+  const int per = (nrows + BN_PRE_S - 1) / BN_PRE_S;
+  const int r0 = blockIdx.x * per, r1 = min(r0 + per, nrows);
+  double v = 0.0;
+  if (rs < rpp) {
+    int r = r0 + rs;
+    for (; r + 3 * rpp < r1; r += 4 * rpp) {
+      const float a = stats[(size_t)r * E + e], b = stats[(size_t)(r + rpp) * E + e], c = stats[(size_t)(r + 2 * rpp) * E + e],
+                  d = stats[(size_t)(r + 3 * rpp) * E + e];
+      v += (double)a; v += (double)b; v += (double)c; v += (double)d;
+    }
+    for (; r < r1; r += rpp) v += (double)stats[(size_t)r * E + e];
+  }
+  s_d[threadIdx.x] = v;
+  __syncthreads();
+  if (threadIdx.x < E) {
+    double t = 0.0;
+    for (int k = 0; k < rpp; ++k) t += s_d[k * E + threadIdx.x];
+    part[(size_t)blockIdx.x * E + threadIdx.x] = t;
+  }
+}
+
+template <int NW, typename TS = float>
+__global__ __launch_bounds__(64 * NW) void k_bn_finalize(const TS* __restrict__ stats, int nrows, double count,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* running_mean, float* running_var, float momentum, float eps,
                                                          int training, float* __restrict__ cst, int C) {
@@ -61,15 +92,14 @@ __global__ __launch_bounds__(64 * NW) void k_bn_finalize(const float* __restrict
     // eight independent loads in flight per thread
     int r = threadIdx.x;
     for (; r + 7 * NT < nrows; r += 8 * NT) {
-      float2 t[8];
+      TS t[8][2];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const float2*>(stats + ((size_t)(r + NT * k) * C + c) * 2);
+      for (int k = 0; k < 8; ++k) { t[k][0] = stats[((size_t)(r + NT * k) * C + c) * 2]; t[k][1] = stats[((size_t)(r + NT * k) * C + c) * 2 + 1]; }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { v[0] += (double)t[k].x; v[1] += (double)t[k].y; }
+      for (int k = 0; k < 8; ++k) { v[0] += (double)t[k][0]; v[1] += (double)t[k][1]; }
     }
     for (; r < nrows; r += NT) {
-      const float2 t = *reinterpret_cast<const float2*>(stats + ((size_t)r * C + c) * 2);
-      v[0] += (double)t.x; v[1] += (double)t.y;
+      v[0] += (double)stats[((size_t)r * C + c) * 2]; v[1] += (double)stats[((size_t)r * C + c) * 2 + 1];
     }
     {
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -576,10 +606,14 @@ extern "C" int sc_stat_rows(int kind, int N, int H, int W) {
 
 extern "C" int sc_bn_finalize(const float* stats, int nrows, double count, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, int training,
-                              float* cst_fwd, int C, sc_stream stream) {
+                              float* cst_fwd, int C, double* scratch, sc_stream stream) {
   SC_REQUIRE(C > 0 && cst_fwd && gamma && beta && running_mean && running_var, "sc_bn_finalize: null argument");
   SC_REQUIRE(!training || (stats && count > 0 && nrows > 0), "sc_bn_finalize: training needs stats rows and count");
-  if (training && nrows >= 4096)
+  if (training && nrows >= 4096 && scratch && 2 * C <= 1024) {
+    hipLaunchKernelGGL(k_bn_rows_prereduce, dim3(BN_PRE_S), dim3(1024), 0, (hipStream_t)stream, stats, nrows, C, scratch);
+    hipLaunchKernelGGL((k_bn_finalize<4, double>), dim3(C), dim3(256), 0, (hipStream_t)stream, (const double*)scratch, BN_PRE_S, count, gamma,
+                       beta, running_mean, running_var, momentum, eps, training, cst_fwd, C);
+  } else if (training && nrows >= 4096)
     hipLaunchKernelGGL((k_bn_finalize<16>), dim3(C), dim3(1024), 0, (hipStream_t)stream, stats, nrows, count, gamma, beta,
                        running_mean, running_var, momentum, eps, training, cst_fwd, C);
   else

@@ -100,6 +100,7 @@ class _T:
         self.res_grad = None        # 'fin' tensor z = self + ...: z.grad must be added to self.grad
 
 
+_BN_PRE = os.environ.get("STARCOP_BN_PRE", "1") != "0"      # coalesced pre-reduction of many-row BatchNorm statistics (sc_bn_finalize scratch)
 _COT_RATIO = float(os.environ.get("STARCOP_COT_RATIO", "1.15"))
 _COT_RATIO3 = float(os.environ.get("STARCOP_COT_RATIO3", "1.15"))     # the same choice for the 3x3 layers (64-wide tiles stage a patch fewer times)
 # development knob: "d0a,d0b;d0a" forces 32-wide cout tiles for the forward (before ';') / backward-data launches of these ops
@@ -444,6 +445,7 @@ class HyperStarcopUNet(nn.Module):
                             self._pack_version = None
                             self._pack_tables = {}
             fins = [t.name for t in self._tensors.values() if t.kind == "fin" and t.name != "logits"]
+            plan.bn_scratch = torch.empty(64 * 2 * max(t.C for t in self._tensors.values()), dtype=torch.float64, device=dev)   # sc_bn_finalize
             plan.fin_slot = {n: i for i, n in enumerate(fins)}
             plan.fin_amax = torch.zeros(len(fins), **f32)        # running max |value| of each residual sum (never lowered)
             raw_feed = self._split_feeders()[0]
@@ -711,7 +713,7 @@ class HyperStarcopUNet(nn.Module):
                 bn = o.bn
                 check(lib.sc_bn_finalize(stats, plan.srows[o.name], float(N * Ho * Wo), ptr(bn.weight), ptr(bn.bias),
                                          ptr(bn.running_mean), ptr(bn.running_var), float(bn.momentum), float(bn.eps),
-                                         1 if training else 0, ptr(plan.cst[o.name]), o.C, st))
+                                         1 if training else 0, ptr(plan.cst[o.name]), o.C, ptr(plan.bn_scratch) if _BN_PRE else None, st))
         if training:      # one multi-tensor launch for the 62 step counters
             torch._foreach_add_(self._nbt_list(), 1)
         plan.training = training

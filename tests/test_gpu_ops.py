@@ -526,8 +526,21 @@ def test_batchnorm_bookkeeping(hip):
     cst = torch.zeros(C_, SC_CST, device=DEV)
     cnt = float(N * H * W)
     check(hip.sc_bn_finalize(ptr(stats), 300, cnt, ptr(dev(gamma)), ptr(dev(beta)), ptr(rmd), ptr(rvd),
-                             0.1, 1e-5, 1, ptr(cst), C_, stream()))
+                             0.1, 1e-5, 1, ptr(cst), C_, None, stream()))
     assert relerr(rmd, rm) < 1e-5 and relerr(rvd, rv) < 1e-5
+    # many rows (full-resolution layers): the coalesced pre-reduction into 64 fp64 partial rows gives the same constants
+    nr = 5000
+    big = torch.zeros(nr, C_, 2, device=DEV)
+    big[:, :, 0] = (yd.double().sum((0, 2, 3)) / nr).float()[None, :] + torch.randn(nr, C_, device=DEV) * 1e-3
+    big[:, :, 1] = ((yd.double() ** 2).sum((0, 2, 3)) / nr).float()[None, :]
+    outs = []
+    for scr in (None, torch.empty(64 * 2 * C_, dtype=torch.float64, device=DEV)):
+        rm2, rv2, c2 = torch.zeros(C_, device=DEV), torch.ones(C_, device=DEV), torch.zeros(C_, SC_CST, device=DEV)
+        check(hip.sc_bn_finalize(ptr(big), nr, cnt, ptr(dev(gamma)), ptr(dev(beta)), ptr(rm2), ptr(rv2), 0.1, 1e-5, 1, ptr(c2), C_, ptr(scr), stream()))
+        outs.append((rm2, rv2, c2))
+    assert all(relerr(a, b) < 1e-6 for a, b in zip(outs[0], outs[1]))
+    m_want = big[:, :, 0].double().sum(0) / cnt
+    assert relerr(outs[1][2][:, 2], m_want) < 1e-6
     src = make_src(yd, C_, SRC_AFFINE, act=ACT_RELU6, cst=cst)
     zz = torch.empty_like(yd)
     check(hip.sc_apply_src(C.byref(src), ptr(zz), N, C_, H * W, stream()))
