@@ -328,7 +328,7 @@ def main():
                                     "Infinity-Cache hits are counted (MI355X_MICROARCH.md), so this is L2-miss traffic, an upper bound on HBM bytes. "
                                     "Not measured inside this run")
                     break
-            hbm = ("<1>" in fam or "k_dw" in fam or "elementwise" in fam) and d.get("bytes")     # streaming families: HBM roofline
+            hbm = ("<1>" in fam or "k_dw" in fam or "elementwise" in fam or "k_pw3_ebwd" in fam) and d.get("bytes")     # streaming families: HBM roofline
             if hbm:
                 ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
                 peak = HBM_PEAK_GBS
@@ -354,7 +354,7 @@ def main():
         # largest HBM-priced (streaming) family by time is reported beside it.
         priced = [k for k in prof if prof[k]["flop"] or prof[k].get("bytes")] or list(prof)
         roof = roof_of(max(priced, key=lambda k: prof[k]["flop"]))
-        streaming = [k for k in priced if ("<1>" in k or "k_dw" in k) and prof[k].get("bytes")]
+        streaming = [k for k in priced if ("<1>" in k or "k_dw" in k or "k_pw3_ebwd" in k) and prof[k].get("bytes")]
         roof_streaming = roof_of(max(streaming, key=lambda k: prof[k]["ms"])) if streaming else None
         if roof_streaming is not None:
             roof_streaming.pop("families_ms_per_step", None)

@@ -218,6 +218,13 @@ int sc_conv1x1_pw3(const sc_conv_args* a, sc_stream stream);
 /* its weight gradient (K = pixels; H*W must be a multiple of 8): same sc_wgrad_args as sc_conv2d_wgrad_mfma with ks = 1, nsrc = 1;
  * workspace from sc_wgrad_pw3_workspace_floats; pending != NULL defers the sum over the K-slice partials to
  * sc_wgrad_reduce_batch (as sc_conv2d_wgrad_mfma_deferred), NULL finishes it here. */
+/* Fused backward of an EXPANSION convolution (torchvision InvertedResidual.conv[0]: Cin <= 32 -> hidden = 6 Cin <= 192 channels) at
+ * the high resolutions: the data gradient (as sc_conv1x1_pw3 with `a`: BNBWD source of the expanded tensor, transpose_flip filters,
+ * a->Cout = Cin, optional add0 / accum0) AND the weight gradient (as sc_conv1x1_wgrad_pw3 with `wa`: the same dy, the block input
+ * as source) from ONE pass over (g, y) of the 6x tensor -- both launches are HBM-bound on that tensor, and in one kernel its second
+ * use hits the cache.  H*W % 8 == 0; workspace (wa->part) from sc_pw3_ebwd_workspace_floats; pending as sc_conv1x1_wgrad_pw3. */
+size_t sc_pw3_ebwd_workspace_floats(int N, int H, int W, int hidden, int Cin);
+int sc_conv1x1_expand_bwd_pw3(const sc_conv_args* a, const sc_wgrad_args* wa, sc_wgrad_pending* pending_host, sc_stream stream);
 size_t sc_wgrad_pw3_workspace_floats(int N, int H, int W, int Cout, int Cin);
 int sc_conv1x1_wgrad_pw3(const sc_wgrad_args* a, sc_wgrad_pending* pending_host, sc_stream stream);
 

@@ -142,6 +142,8 @@ SIGNATURES = {
     "sc_packed_weight_floats_pw3": (_sz, [_i, _i, _i]),
     "sc_conv1x1_pw3": (_i, [C.POINTER(sc_conv_args), _vp]),
     "sc_wgrad_pw3_workspace_floats": (_sz, [_i, _i, _i, _i, _i]),
+    "sc_pw3_ebwd_workspace_floats": (_sz, [_i, _i, _i, _i, _i]),
+    "sc_conv1x1_expand_bwd_pw3": (_i, [C.POINTER(sc_conv_args), C.POINTER(sc_wgrad_args), C.POINTER(sc_wgrad_pending), _vp]),
     "sc_conv1x1_wgrad_pw3": (_i, [C.POINTER(sc_wgrad_args), C.POINTER(sc_wgrad_pending), _vp]),
     "sc_maxpool2x2": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _i, _vp]),
     "sc_upsample_bilinear2x": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _i, _vp]),

@@ -139,6 +139,19 @@ def _use_pw3(which, HW, K=0, M=0):
     return HW <= 1024 and K * M <= 300000 and (HW <= 256 or K * M <= 32768)
 
 
+# OFF by default: measured 1324-1326 vs 1329-1336 tiles/s (same box).  The fused launch takes 308 us on features.2 against 178 + 208 for
+# the two separate ones, but it sits on the main stream, where the separate weight gradient overlapped the dependency chain on the
+# second stream: the serial sum falls by 0.08 ms, the critical path grows.
+_PW3_EBWD = os.environ.get("STARCOP_PW3_EBWD", "0") != "0"
+_PW3_EBWD_MINHW = int(os.environ.get("STARCOP_PW3_EBWD_MINHW", "4096"))
+
+
+def _use_ebwd(HW, Cin, Cout):
+    """expansion convolutions (Cin <= 32 -> 6 Cin <= 192 channels) at the high resolutions: data and weight gradient from one pass
+    over (g, y) of the 6x tensor (sc_conv1x1_expand_bwd_pw3) -- both are HBM-bound on it"""
+    return _PW3_EBWD and _PW3 != "0" and HW % 8 == 0 and HW >= _PW3_EBWD_MINHW and Cin <= 32 and 2 * Cin <= Cout <= 192
+
+
 def _use_ksplit(N, HW, K, M, ks=1):
     """1x1 layers with few pixels and long K: the split-K kernel (sc_conv1x1_ksplit) beats the 128-pixel tiles when
     those leave most CUs idle (measured crossover, tools/bench_pw.py)."""
@@ -440,6 +453,8 @@ class HyperStarcopUNet(nn.Module):
                     for tflip in (0, 1):
                         cv = op["conv"]
                         lay = "pw3" if _use_pw3(tflip, hw, cv.out_channels if tflip else cv.in_channels) else "mfma"
+                        if tflip and op["ins"][0].kind != "input" and _use_ebwd(hw, cv.in_channels, cv.out_channels):
+                            lay = "pw3"        # the fused expansion backward reads the k_pw3 layout
                         if lay not in need.setdefault((i, tflip), set()):
                             need[(i, tflip)].add(lay)
                             self._pack_version = None
@@ -492,7 +507,9 @@ class HyperStarcopUNet(nn.Module):
                     if op["type"] == "pw":
                         conv, o = op["conv"], op["out"]
                         Hq, Wq = H >> o.shift, W >> o.shift
-                        nfl = (lib.sc_wgrad_pw3_workspace_floats(N, Hq, Wq, conv.out_channels, conv.in_channels)
+                        nfl = (lib.sc_pw3_ebwd_workspace_floats(N, Hq, Wq, conv.out_channels, conv.in_channels)
+                               if (op["ins"][0].kind != "input" and _use_ebwd(Hq * Wq, conv.in_channels, conv.out_channels))
+                               else lib.sc_wgrad_pw3_workspace_floats(N, Hq, Wq, conv.out_channels, conv.in_channels)
                                if _use_pw3(2, Hq * Wq, conv.in_channels, conv.out_channels)
                                else lib.sc_wgrad_workspace_floats(N, Hq, Wq, conv.out_channels, conv.in_channels, 1))
                         plan.pw_part[i] = torch.empty(nfl, **f32)
@@ -958,6 +975,30 @@ class HyperStarcopUNet(nn.Module):
             wa.terms = self._terms[1]
             wa.absmax = gmax_slot.get(o.name)
             flop = 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * ks * ks
+            if (ty == "pw" and i in plan.pw_part and ins[0].kind != "input" and _use_ebwd(Ho * Wo, conv.in_channels, conv.out_channels)):
+                # expansion convolution at a high resolution: data gradient + weight gradient from ONE pass over (g, y) of the 6x
+                # tensor, on the main stream (the data gradient is on the critical path, the weight gradient rides along)
+                tin = ins[0]
+                wa.part = plan.pw_part[i].data_ptr(); wa.part_floats = plan.pw_part[i].numel()
+                a = sc_conv_args()
+                a.nsrc = 1
+                a.src[0] = dy
+                a.wpk = self._wpk[i]["pb"].data_ptr()
+                a.N, a.H, a.W, a.Cout, a.ks, a.co_t = N, Ho, Wo, conv.in_channels, 1, 32
+                a.out0 = plan.grad[tin.name].data_ptr(); a.out1 = None
+                a.csplit = conv.in_channels
+                a.accum0 = 1 if tin.name in written else 0
+                a.accum1 = 0
+                z = res_of.get(tin.name)
+                a.add0 = plan.grad[z].data_ptr() if z is not None else None
+                a.add1 = None; a.stats = None
+                pend = sc_wgrad_pending()
+                tok = self._pb("k_pw3_ebwd (dgrad+wgrad)", 2 * flop, 4.0 * (2 * N * o.C * Ho * Wo + 2 * N * conv.in_channels * Ho * Wo + conv.weight.numel()))
+                check(lib.sc_conv1x1_expand_bwd_pw3(C.byref(a), C.byref(wa), C.byref(pend), st))
+                self._pe(tok)
+                pw_pending.append(pend)
+                written.add(tin.name)
+                continue
             wfn = (lib.sc_conv3x3_wgrad_bx3 if (self.split_bf16 and ks == 3 and conv.out_channels >= 32 and conv.in_channels >= 32)
                    else lib.sc_conv2d_wgrad_mfma)     # 16-channel layers outside the cases below stay on the fp32 MFMA
             if (self.split_bf16 and self.thin16 and ks == 3 and self._terms[1] == TERMS_F16X2 and len(ins) == 1

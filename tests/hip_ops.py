@@ -166,3 +166,30 @@ def wgrad_pw3(dy, src, N, H, W, Cout, Cin, deferred=False):
     _KEEP.extend([descs, starts])
     check(lib.sc_wgrad_reduce_batch(ptr(descs), ptr(starts), 1, -(-int(pend.total) // 256), stream()))
     return dw
+
+
+def expand_bwd_pw3(dsrc, src, wpk_t, N, H, W, hidden, Cin, add0=None, accum_into=None):
+    """fused expansion backward (sc_conv1x1_expand_bwd_pw3): -> (dx, dw)"""
+    from starcop_amd._lib import sc_wgrad_pending
+    lib = _lib.load()
+    a = sc_conv_args()
+    a.nsrc = 1
+    a.src[0] = dsrc
+    a.wpk = wpk_t.data_ptr()
+    a.N, a.H, a.W, a.Cout, a.ks, a.co_t = N, H, W, Cin, 1, 32
+    dx = accum_into if accum_into is not None else torch.full((N, Cin, H, W), float("nan"), device=DEV)
+    a.out0, a.out1, a.csplit = dx.data_ptr(), None, Cin
+    a.accum0 = 1 if accum_into is not None else 0
+    a.add0 = add0.data_ptr() if add0 is not None else None
+    wa = sc_wgrad_args()
+    wa.dy, wa.nsrc = dsrc, 1
+    wa.src[0] = src
+    wa.N, wa.H, wa.W, wa.Cout, wa.Cin, wa.ks = N, H, W, hidden, Cin, 1
+    n = lib.sc_pw3_ebwd_workspace_floats(N, H, W, hidden, Cin)
+    ws = torch.empty(n, device=DEV)
+    wa.part, wa.part_floats = ws.data_ptr(), n
+    dw = torch.full((hidden, Cin, 1, 1), float("nan"), device=DEV)
+    wa.dw = dw.data_ptr()
+    _KEEP.append(ws)
+    check(lib.sc_conv1x1_expand_bwd_pw3(C.byref(a), C.byref(wa), None, stream()))
+    return dx, dw

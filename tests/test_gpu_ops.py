@@ -948,3 +948,33 @@ def test_conv_pw3_wgrad(hip, cin, cout, N, H, W, deferred):
     ref = torch.einsum("nohw,nihw->oi", dy, xin)[:, :, None, None]
     dw = wgrad_pw3(dsrc, src, N, H, W, cout, cin, deferred=deferred)
     assert relerr(dw, ref) < 1e-5
+
+
+@pytest.mark.parametrize("cin,hid,N,H,W", [(16, 96, 2, 64, 64), (24, 144, 3, 32, 40), (32, 192, 2, 16, 24), (8, 48, 1, 4, 6), (24, 144, 1, 2, 4), (16, 96, 5, 8, 9)])
+def test_expand_bwd_fused_pw3(hip, cin, hid, N, H, W):
+    """sc_conv1x1_expand_bwd_pw3: data gradient and weight gradient of an expansion convolution from one pass over (g, y) of the
+    expanded tensor -- dx bit-identical to sc_conv1x1_pw3's backward-data launch (with the residual add and accumulation), dW
+    against autograd in float64"""
+    from hip_ops import conv_pw3, expand_bwd_pw3, pack_pw3
+    x = rnd(N, cin, H, W, seed=1, scale=2.0)
+    cst = torch.rand(cin, SC_CST, generator=torch.Generator().manual_seed(3)) + 0.5
+    xin = x.double() * cst[:, 0].double()[None, :, None, None] + cst[:, 1].double()[None, :, None, None]
+    w = rnd(hid, cin, 1, 1, seed=2, scale=0.3)
+    g, y = rnd(N, hid, H, W, seed=3) * 1e-3, rnd(N, hid, H, W, seed=4)
+    a, b = rnd(hid, seed=4) * 0.2 + 1, rnd(hid, seed=5) * 0.2 + 2.5
+    A, B, D = rnd(hid, seed=6) * 0.3 + 1, rnd(hid, seed=7) * 1e-4, rnd(hid, seed=8) * 1e-4
+    yh = y * a[None, :, None, None] + b[None, :, None, None]
+    gm = torch.where((yh > 0) & (yh < 6), g, torch.zeros(()))
+    dy = gm.double() * A.double()[None, :, None, None] + B.double()[None, :, None, None] * y.double() + D.double()[None, :, None, None]
+    cstb = torch.zeros(hid, SC_CST); cstb[:, 0], cstb[:, 1], cstb[:, 2], cstb[:, 3], cstb[:, 4] = a, b, A, B, D
+    dsrc = make_src(dev(g), hid, SRC_BNBWD, act=ACT_RELU6, cst=dev(cstb), aux=dev(y))
+    src = make_src(dev(x), cin, SRC_AFFINE, act=ACT_NONE, cst=dev(cst))
+    wt = pack_pw3(dev(w), 1)
+    res, old = rnd(N, cin, H, W, seed=9) * 1e-3, rnd(N, cin, H, W, seed=10) * 1e-3
+    dx_sep, _ = conv_pw3(dsrc, wt, N, H, W, cin, add0=dev(res), accum_into=dev(old.clone()))
+    dx, dw = expand_bwd_pw3(dsrc, src, wt, N, H, W, hid, cin, add0=dev(res), accum_into=dev(old.clone()))
+    assert torch.equal(dx, dx_sep)
+    assert relerr(dx, F.conv_transpose2d(dy, w.double()) + res.double() + old.double()) < 1e-5
+    assert relerr(dw, torch.einsum("nohw,nihw->oi", dy, xin)[:, :, None, None]) < 1e-5
+    dx2, dw2 = expand_bwd_pw3(dsrc, src, wt, N, H, W, hid, cin)
+    assert relerr(dx2, F.conv_transpose2d(dy, w.double())) < 1e-5 and torch.equal(dw2, dw)
