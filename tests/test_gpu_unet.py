@@ -385,6 +385,41 @@ def test_batchnorm_fed_activations_are_range_recorded_on_the_device(hip):
         h.remove()
 
 
+def test_inference_constants_are_cached_and_invalidated(hip):
+    """eval-mode BatchNorm constants are computed once per plan and reused while parameters and running statistics are unchanged
+    (62 launches fewer per forward); a torch-side change of a buffer or parameter, a training step (raw-pointer updates) and
+    load_state_dict all invalidate them -- checked against the oracle after each"""
+    model, ref = make_pair(seed=11)
+    net = model.network
+    batch = synth_batch(2, 64, 64, seed=12)
+    xin = to_dev(batch)["input"]
+
+    def check_eval():
+        model.eval(); ref.eval()
+        with torch.no_grad():
+            want = ref(ref_normalize(batch["input"]))
+            got = model(xin)
+            again = model(xin)
+        assert relerr(got, want) < 1e-4 and torch.equal(got, again)
+    check_eval()
+    key0 = net._plans[(2, 64, 64)].eval_cst_key
+    assert key0 is not None
+    with torch.no_grad():                                      # torch-side buffer / parameter edits
+        net.decoder.blocks[1].conv1[1].running_mean.add_(0.5); ref.decoder.blocks[1].conv1[1].running_mean.add_(0.5)
+        net.encoder.features[3].conv[0][1].weight.mul_(1.5); ref.encoder.features[3].conv[0][1].weight.mul_(1.5)
+    check_eval()
+    assert net._plans[(2, 64, 64)].eval_cst_key != key0
+    model.train(); ref.train()                                 # a training step changes running statistics through raw pointers
+    opt = model.configure_optimizers()["optimizer"]
+    model.fused_train_step(to_dev(batch), opt)
+    ref.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    check_eval()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    sd["decoder.blocks.3.conv2.1.running_var"] *= 2.0
+    net.load_state_dict(sd); ref.load_state_dict({k: v.cpu() for k, v in sd.items()})
+    check_eval()
+
+
 def test_optimizer_checkpoint_resume(hip):
     """FusedAdam.load_state_dict: a resumed run (Lightning restores optimiser state through load_state_dict; reference
     train.py:137 resume_from_checkpoint) continues with the checkpoint's moments and step count -- parameters after the next
