@@ -164,6 +164,22 @@ def bench_extras(model, dev, precision):
     dt = _timeit(lambda: model.predict(scene), 5)
     out["predict_scene"] = {"workload": "ModelModule.predict on a host (4, 1280, 1242) float32 scene: reflect-pad to x32, forward, sigmoid, crop, back to host",
                             "ms": round(dt * 1e3, 3), "Mpx_s": round(1280 * 1242 / dt / 1e6, 1)}
+    # ---- configs[4] end to end on one GPU: EMIT-like cube -> mag1c (49 bands, fp64) -> RGB + rescale -> band ratio -> U-Net -> mask,
+    # whole-scene forward and the tile-sharded form (512-row full-width strips + halo 320: what each rank of an N-GPU job runs on its share)
+    from starcop_amd import pipeline
+    wl = np.linspace(381.0, 2493.0, 285)
+    keep = (wl >= 2122.0) & (wl <= 2488.0)
+    te285 = np.interp(wl[keep], np.linspace(2122.0, 2488.0, te.size), te)
+    gen2 = torch.Generator(device=dev).manual_seed(11)
+    cube285 = (torch.rand(285, generator=gen2, device=dev) * 5 + 1) * (1 + 0.05 * torch.randn(1280, 1242, 285, generator=gen2, device=dev))
+    cube285 = cube285.float().contiguous()
+    dt_w = _timeit(lambda: pipeline.emit_scene_predict(model, cube285, wl, te285, column_step=2, ratio_bands=(2350, 2310)), 3)
+    dt_t = _timeit(lambda: pipeline.emit_scene_predict(model, cube285, wl, te285, column_step=2, ratio_bands=(2350, 2310), tile=512), 3)
+    out["emit_scene"] = {"workload": "configs[4]: EMIT-like 1280x1242x285 fp32 cube resident in HBM -> mag1c on the 49 bands in [2122, 2488] nm (fp64, column_step 2) "
+                                     "-> RGB bands + range rescale -> two-band ratio -> U-Net eval forward -> probability + binary mask",
+                         "ms_whole_scene_forward": round(dt_w * 1e3, 3), "ms_row_strips_512_halo_320": round(dt_t * 1e3, 3),
+                         "scenes_s": round(1 / dt_w, 2), "tile_equivalents_s": round(1280 * 1242 / 262144 / dt_w, 1)}
+    del cube285
     model.train()
     return out
 

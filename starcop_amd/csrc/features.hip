@@ -56,6 +56,63 @@ __global__ __launch_bounds__(RS_THREADS) void k_order_stat(const float* __restri
   if (threadIdx.x == 0) out[(size_t)tile * nranks + r] = key2f(prefix);
 }
 
+// ---- large tiles (a whole scene as one tile: 1.6 M pixels of an EMIT granule): the single-work-group select above walks the tile four
+// times with 1024 threads (3 ms per plane).  Here a pass is one launch of many work-groups: every block counts its chunk for all four
+// ranks at once in LDS (the ranks have their own prefixes) and flushes to global histograms with integer atomics (exact, order-
+// independent); a one-block kernel per pass picks the digit of every rank and clears the histograms.  8 launches, ~60 us per plane.
+struct RsState { unsigned prefix[4]; unsigned mask; unsigned pad; unsigned long long k[4]; };
+
+__global__ __launch_bounds__(256) void k_rs_hist(const float* __restrict__ x, size_t n, const RsState* __restrict__ st, int shift,
+                                                 unsigned* __restrict__ hist /*[B][4][256]*/) {
+  __shared__ unsigned h[4][256];
+  const int tile = blockIdx.y;
+  const RsState s = st[tile];
+  for (int i = threadIdx.x; i < 1024; i += 256) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const float* xt = x + (size_t)tile * n;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const unsigned key = f2key(xt[i]);
+    const unsigned km = key & s.mask, bin = (key >> shift) & 255u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (km == s.prefix[r]) atomicAdd(&h[r][bin], 1u);
+  }
+  __syncthreads();
+  unsigned* g = hist + (size_t)tile * 1024;
+  for (int i = threadIdx.x; i < 1024; i += 256) {
+    const unsigned v = (&h[0][0])[i];
+    if (v) atomicAdd(g + i, v);
+  }
+}
+__global__ __launch_bounds__(256) void k_rs_pick(RsState* __restrict__ st, unsigned* __restrict__ hist, int shift, int last, float* __restrict__ out) {
+  const int tile = blockIdx.x;
+  unsigned* g = hist + (size_t)tile * 1024;
+  if (threadIdx.x < 4) {
+    const int r = threadIdx.x;
+    unsigned long long k = st[tile].k[r], cum = 0;
+    int b = 0;
+    for (; b < 256; ++b) {
+      const unsigned c = g[r * 256 + b];
+      if (cum + c > k) break;
+      cum += c;
+    }
+    st[tile].prefix[r] |= (unsigned)b << shift;
+    st[tile].k[r] = k - cum;
+    if (last) out[(size_t)tile * 4 + r] = key2f(st[tile].prefix[r]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) st[tile].mask |= 255u << shift;
+  for (int i = threadIdx.x; i < 1024; i += 256) g[i] = 0;
+}
+__global__ void k_rs_init(RsState* __restrict__ st, unsigned* __restrict__ hist, const long long* __restrict__ ranks, int B) {
+  const int tile = blockIdx.x;
+  if (threadIdx.x < 4) { st[tile].prefix[threadIdx.x] = 0; st[tile].k[threadIdx.x] = (unsigned long long)ranks[threadIdx.x]; }
+  if (threadIdx.x == 0) { st[tile].mask = 0; st[tile].pad = 0; }
+  for (int i = threadIdx.x; i < 1024; i += blockDim.x) hist[(size_t)tile * 1024 + i] = 0;
+  (void)B;
+}
+constexpr size_t RS_LARGE_N = 1u << 17;
+
 // bounds[tile] = {lower, upper} percentiles from the 4 order statistics {lo_k, lo_k+1, hi_k, hi_k+1} (numpy 'linear')
 __global__ void k_percentile_bounds(const float* __restrict__ os, double t_lo, double t_hi, float* __restrict__ bounds, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -113,7 +170,10 @@ __global__ __launch_bounds__(256) void k_clip_scale(const float* __restrict__ x,
 
 }  // namespace
 
-extern "C" size_t sc_trimmed_sum_workspace_bytes(int B) { return (size_t)B * (4 * sizeof(float) + 2 * sizeof(float)) + 64; }
+extern "C" size_t sc_trimmed_sum_workspace_bytes(int B) {
+  // order statistics [B][4] + bounds [B][2] floats, the four ranks, then (large tiles) the select state and histograms
+  return (size_t)B * 6 * sizeof(float) + 64 + 64 + (size_t)B * (sizeof(RsState) + 1024 * sizeof(unsigned));
+}
 
 extern "C" int sc_trimmed_sums(const float* x, int B, size_t n, double p, double* sums, void* work, size_t work_bytes,
                                sc_stream stream) {
@@ -132,7 +192,20 @@ extern "C" int sc_trimmed_sums(const float* x, int B, size_t n, double p, double
   if (hipMemcpyAsync(ranks_d, ranks_h, sizeof(ranks_h), hipMemcpyHostToDevice, st) != hipSuccess) {
     sc_set_error("sc_trimmed_sums: rank upload failed"); return SC_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(k_order_stat, dim3(4, B), dim3(RS_THREADS), 0, st, x, n, ranks_d, 4, os);
+  if (n >= RS_LARGE_N) {
+    char* base = reinterpret_cast<char*>(ranks_d) + 64;
+    RsState* rs = reinterpret_cast<RsState*>(base);
+    unsigned* hist = reinterpret_cast<unsigned*>(base + (size_t)B * sizeof(RsState));
+    hipLaunchKernelGGL(k_rs_init, dim3(B), dim3(256), 0, st, rs, hist, ranks_d, B);
+    const unsigned gx = (unsigned)((n + 8191) / 8192 > 512 ? 512 : (n + 8191) / 8192);
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      hipLaunchKernelGGL(k_rs_hist, dim3(gx, B), dim3(256), 0, st, x, n, (const RsState*)rs, shift, hist);
+      hipLaunchKernelGGL(k_rs_pick, dim3(B), dim3(256), 0, st, rs, hist, shift, pass == 3 ? 1 : 0, os);
+    }
+  } else {
+    hipLaunchKernelGGL(k_order_stat, dim3(4, B), dim3(RS_THREADS), 0, st, x, n, ranks_d, 4, os);
+  }
   SC_LAUNCH_OK("sc_trimmed_sums(order statistics)");
   hipLaunchKernelGGL(k_percentile_bounds, dim3((B + 63) / 64), dim3(64), 0, st, os, t_lo, t_hi, bounds, B);
   if (hipMemsetAsync(sums, 0, (size_t)B * sizeof(double), st) != hipSuccess) { sc_set_error("sc_trimmed_sums: memset failed"); return SC_ERR_LAUNCH; }

@@ -17,8 +17,6 @@ this module implements the part of the HDF5 file format those variables use, fro
 Not implemented (raises NotImplementedError with the feature's name): extensible-array and v2-B-tree chunk indexes, compound data, external / virtual storage, dense attribute storage (such attributes are skipped).
 Chunks are inflated by a thread pool (zlib releases the GIL); a hyperslab read touches only the chunks it intersects.
 """
-import os
-import struct
 import zlib
 from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -26,7 +24,6 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 _SIG = b"\x89HDF\r\n\x1a\n"
-_UNDEF = 0xFFFFFFFFFFFFFFFF
 
 
 class H5Error(ValueError):

@@ -48,3 +48,16 @@ def test_emit_rescale(hip):
     want = host_ref.emit_rescale(mf, rgb)
     assert got.shape == (4, 64, 96)
     assert np.abs(got - want).max() < 1e-3 and np.isfinite(got).all()
+
+
+def test_trimmed_sums_scene_sized_tile(hip):
+    """a whole EMIT scene as ONE tile (1280 x 1242 = 1.6 M pixels): the multi-work-group radix select (global histograms per pass)
+    gives the same exact order statistics as numpy; just below its size threshold the single-work-group select runs -- same answer"""
+    rng = np.random.default_rng(9)
+    for shape in ((1, 1280, 1242), (2, 361, 363), (3, 300, 436)):          # 1.6 M (large path), 131 043 (small path), 130 800
+        x = rng.normal(1.0, 2.0, size=shape).astype(np.float32)
+        x[0, :5] = -7.5                                                     # ties
+        x[0, 7, :9] = [3e4, -2e4, 0.0, 1e-30, -1e-30, 5.0, 5.0, 5.0, 1e9]
+        got = features.trimmed_sums(torch.from_numpy(x).to(DEV)).cpu().numpy()
+        want = np.array([host_ref.trimmed(t.ravel(), 5).astype(np.float64).sum() for t in x])
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-9, shape
