@@ -228,6 +228,17 @@ int sc_conv1x1_expand_bwd_pw3(const sc_conv_args* a, const sc_wgrad_args* wa, sc
 size_t sc_wgrad_pw3_workspace_floats(int N, int H, int W, int Cout, int Cin);
 int sc_conv1x1_wgrad_pw3(const sc_wgrad_args* a, sc_wgrad_pending* pending_host, sc_stream stream);
 
+/* A whole MobileNetV2 inverted-residual block in one launch, INFERENCE only (eval-mode BatchNorm: the constants are known before the
+ * launch): expand 1x1 -> BN + ReLU6 -> depthwise 3x3 (stride 1 | 2) -> BN + ReLU6 -> project 1x1, the 6x-expanded tensors never leave
+ * LDS (torchvision InvertedResidual.conv under torch.no_grad(): starcop/models/model_module.py:90-98,244-251).  x: the block input
+ * (RAW or AFFINE source); wpk_expand / wpk_project: SC_PACK_PW3 packs of the two 1x1 filters (transpose_flip = 0); w_dw [hidden][9];
+ * cst_expand / cst_dw [hidden][SC_CST]: eval-mode constants (scale, shift) from sc_bn_finalize(training = 0); out: the RAW projection
+ * output [N][Cout][Hout][Wout] (its BatchNorm is applied by the consumer).  fp32 accuracy (three exact bf16 terms, six products). */
+int sc_ir_block_eval_supported(int Cin, int hidden, int Cout, int stride);
+int sc_ir_block_eval(const sc_src* x, const float* wpk_expand, const float* wpk_project, const float* w_dw,
+                     const float* cst_expand, const float* cst_dw, float* out, int N, int Cin, int hidden, int Cout,
+                     int H, int W, int stride, sc_stream stream);
+
 /* the 3x3 weight gradient with split-bf16 operands on the bf16 matrix cores (see sc_conv3x3_bx3); same arguments,
  * ks must be 3; workspace from sc_wgrad_bx3_workspace_floats */
 size_t sc_wgrad_bx3_workspace_floats(int N, int H, int W, int Cout, int Cin);

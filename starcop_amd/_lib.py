@@ -145,6 +145,8 @@ SIGNATURES = {
     "sc_pw3_ebwd_workspace_floats": (_sz, [_i, _i, _i, _i, _i]),
     "sc_conv1x1_expand_bwd_pw3": (_i, [C.POINTER(sc_conv_args), C.POINTER(sc_wgrad_args), C.POINTER(sc_wgrad_pending), _vp]),
     "sc_conv1x1_wgrad_pw3": (_i, [C.POINTER(sc_wgrad_args), C.POINTER(sc_wgrad_pending), _vp]),
+    "sc_ir_block_eval_supported": (_i, [_i, _i, _i, _i]),
+    "sc_ir_block_eval": (_i, [C.POINTER(sc_src), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sc_maxpool2x2": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _i, _vp]),
     "sc_upsample_bilinear2x": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _i, _vp]),
     "sc_maxpool2x2_bwd": (_i, [C.POINTER(sc_src), _vp, _vp, _i, _i, _i, _i, _i, _vp]),

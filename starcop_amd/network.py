@@ -287,6 +287,7 @@ class HyperStarcopUNet(nn.Module):
     # ------------------------------------------------------------------------------------------
     def _build_ops(self):
         ops, tensors = [], {}
+        ir_blocks = self._ir_blocks = {}
 
         def T(name, Cn, shift, kind, bn=None, act=ACT_NONE):
             t = _T(name, Cn, shift, kind, bn, act)
@@ -313,6 +314,8 @@ class HyperStarcopUNet(nn.Module):
             ops.append(dict(type="dw", conv=seq[j][0], stride=blk.stride, ins=[h], out=d))
             p = T(f"f{idx}p", seq[j + 1].out_channels, sh, "raw", seq[j + 2], ACT_NONE)
             ops.append(dict(type="pw", conv=seq[j + 1], ins=[d], out=p))
+            if blk.expand:
+                ir_blocks[len(ops) - 3] = (len(ops) - 2, len(ops) - 1, blk.stride)      # expand op -> (depthwise op, project op, stride)
             if blk.use_res_connect:
                 z = T(f"f{idx}", p.C, sh, "fin")
                 ops.append(dict(type="add", ins=[cin_t, p], out=z))
@@ -661,6 +664,14 @@ class HyperStarcopUNet(nn.Module):
         plan.buf["x"] = x
         plan.x_cst = x_cst
         plan.generation = getattr(plan, "generation", 0) + 1     # activations of an earlier forward of this shape are gone
+        if (not training) and self.fuse_ir_eval:      # the fused inference blocks read the k_pw3 layout of both 1x1 filters
+            need = self._pw_need
+            for i_e, (i_dw, i_pr, _) in self._ir_blocks.items():
+                for k in (i_e, i_pr):
+                    if "pw3" not in need.setdefault((k, 0), set()):
+                        need[(k, 0)].add("pw3")
+                        self._pack_version = None
+                        self._pack_tables = {}
         self._pack_all(need_grad)
         st = stream()
         # inference: the BatchNorm constants depend only on parameters and running statistics -- 62 five-microsecond launches of the
@@ -672,9 +683,36 @@ class HyperStarcopUNet(nn.Module):
         if training:
             self._stat_epoch += 1            # running statistics are about to be updated through raw pointers
             plan.eval_cst_key = None
+        fuse_ir = (not training) and self.fuse_ir_eval
+        if not training and not eval_cst_ok:
+            # inference: every BatchNorm's constants up front (they do not depend on the data), so that a fused block can use the
+            # constants of tensors it never materialises
+            for t in self._tensors.values():
+                if t.bn is not None:
+                    bn = t.bn
+                    check(lib.sc_bn_finalize(None, 0, 1.0, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
+                                             float(bn.momentum), float(bn.eps), 0, ptr(plan.cst[t.name]), t.C, None, st))
+        skip = set()
         for i, op in enumerate(self._ops):
+            if i in skip:
+                continue
             ty, o = op["type"], op["out"]
             Ho, Wo = H >> o.shift, W >> o.shift
+            if fuse_ir and i in self._ir_blocks:
+                i_dw, i_pr, stride = self._ir_blocks[i]
+                cv_e, cv_d, cv_p = op["conv"], self._ops[i_dw]["conv"], self._ops[i_pr]["conv"]
+                if lib.sc_ir_block_eval_supported(cv_e.in_channels, cv_e.out_channels, cv_p.out_channels, stride):
+                    # expand -> BN+ReLU6 -> depthwise -> BN+ReLU6 -> project in ONE launch; the 6x tensors never leave LDS
+                    tin, te, td, tp = op["ins"][0], o, self._ops[i_dw]["out"], self._ops[i_pr]["out"]
+                    s = self._src_of(plan, tin)
+                    self._cur_op = tp.name + ":fwd"
+                    tok = self._pb("k_ir_eval")
+                    check(lib.sc_ir_block_eval(C.byref(s), ptr(self._wpk[i]["pf"]), ptr(self._wpk[i_pr]["pf"]), ptr(cv_d.weight),
+                                               ptr(plan.cst[te.name]), ptr(plan.cst[td.name]), ptr(plan.buf[tp.name]), N, cv_e.in_channels,
+                                               cv_e.out_channels, cv_p.out_channels, H >> tin.shift, W >> tin.shift, stride, st))
+                    self._pe(tok)
+                    skip.update((i_dw, i_pr))
+                    continue
             stats = ptr(plan.stats_v[o.name]) if (training and o.bn is not None) else None
             conv = op.get("conv")
             tok = None
@@ -738,7 +776,7 @@ class HyperStarcopUNet(nn.Module):
                 check(lib.sc_head_conv_fwd(C.byref(s), ptr(conv.weight), ptr(conv.bias), ptr(plan.buf[o.name]),
                                            N, conv.in_channels, Ho, Wo, st))
             self._pe(tok)
-            if o.bn is not None and (training or not eval_cst_ok):
+            if o.bn is not None and training:
                 bn = o.bn
                 check(lib.sc_bn_finalize(stats, plan.srows[o.name], float(N * Ho * Wo), ptr(bn.weight), ptr(bn.bias),
                                          ptr(bn.running_mean), ptr(bn.running_var), float(bn.momentum), float(bn.eps),
@@ -776,6 +814,11 @@ class HyperStarcopUNet(nn.Module):
     # OFF: measured 1179 vs 1189 tiles/s -- the reduction pass it saves runs at 6 TB/s (0.24 ms), the extra ~25 VALU per element
     # in the issue-bound 1x1 epilogue cost 0.37 ms.
     fuse_bn_bwd = os.environ.get("STARCOP_FUSE_BNBWD", "0") != "0"
+    # inference: a whole inverted-residual block (expand -> depthwise -> project) in one launch (conv_ir.hip).  Correct (5e-6 of fp64,
+    # whole-network eval tests green with it on) but its first version is SLOWER than the three launches it replaces -- eval forward at
+    # batch 16: 4.74 vs 3.07 ms; only features.7 wins (48 vs 54 us); at 16^2 a launch has 64 work-groups walking 30 hidden chunks with
+    # two barriers each (features.15: 371 vs 68 us) -- so it is opt-in (DESIGN.md 13.1 has what the next version needs)
+    fuse_ir_eval = os.environ.get("STARCOP_IR_EVAL", "0") != "0"
     fuse_head_bn = os.environ.get("STARCOP_FUSE_HEAD_BN", "1") != "0"      # BatchNorm-backward sums of the decoder's last tensor in the head backward
     thin16 = os.environ.get("STARCOP_THIN16", "1") != "0"     # decoder.blocks.4 on sc_conv3x3_thin16 (0: the fp32-MFMA thin kernels)
     split_bf16 = True        # 3x3 convs with >= 32 output channels on the 16-bit matrix cores (False: everything on the fp32 MFMA)

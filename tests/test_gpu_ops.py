@@ -978,3 +978,38 @@ def test_expand_bwd_fused_pw3(hip, cin, hid, N, H, W):
     assert relerr(dw, torch.einsum("nohw,nihw->oi", dy, xin)[:, :, None, None]) < 1e-5
     dx2, dw2 = expand_bwd_pw3(dsrc, src, wt, N, H, W, hid, cin)
     assert relerr(dx2, F.conv_transpose2d(dy, w.double())) < 1e-5 and torch.equal(dw2, dw)
+
+
+@pytest.mark.parametrize("cin,hid,cout,stride,N,H,W,xmode", [(16, 96, 24, 2, 2, 32, 48, "affine"), (24, 144, 24, 1, 2, 24, 40, "raw"), (64, 384, 64, 1, 3, 16, 16, "raw"),
+                                                             (96, 576, 160, 2, 2, 16, 32, "affine"), (160, 960, 320, 1, 2, 8, 8, "raw"), (32, 192, 64, 2, 1, 10, 6, "affine"),
+                                                             (24, 144, 32, 2, 1, 7, 9, "raw"), (16, 96, 24, 1, 1, 5, 3, "affine")])
+def test_inverted_residual_block_eval_fused(hip, cin, hid, cout, stride, N, H, W, xmode):
+    """sc_ir_block_eval: expand -> BN+ReLU6 -> depthwise (stride 1 | 2) -> BN+ReLU6 -> project in one launch, against the three
+    torch ops in float64 (eval-mode BatchNorm = per-channel affine); odd sizes exercise the tile borders and the zero padding of
+    the depthwise conv's activated input"""
+    from hip_ops import pack_pw3
+    lib = _lib.load()
+    assert lib.sc_ir_block_eval_supported(cin, hid, cout, stride) == 1
+    x = rnd(N, cin, H, W, seed=1, scale=2.0)
+    we, wd, wp = rnd(hid, cin, 1, 1, seed=2, scale=0.3), rnd(hid, 1, 3, 3, seed=3, scale=0.4), rnd(cout, hid, 1, 1, seed=4, scale=0.1)
+    g = torch.Generator().manual_seed(5)
+    ce, cd = torch.zeros(hid, SC_CST), torch.zeros(hid, SC_CST)
+    ce[:, 0], ce[:, 1] = torch.rand(hid, generator=g) + 0.5, torch.randn(hid, generator=g) * 0.5 + 1.0
+    cd[:, 0], cd[:, 1] = torch.rand(hid, generator=g) + 0.5, torch.randn(hid, generator=g) * 0.5 + 1.0
+    xin = x.double()
+    if xmode == "affine":
+        cx = torch.rand(cin, SC_CST, generator=g) + 0.5
+        src = make_src(dev(x), cin, SRC_AFFINE, act=ACT_NONE, cst=dev(cx))
+        xin = xin * cx[:, 0].double()[None, :, None, None] + cx[:, 1].double()[None, :, None, None]
+    else:
+        src = make_src(dev(x), cin, SRC_RAW)
+    e = torch.clamp(F.conv2d(xin, we.double()) * ce[:, 0].double()[None, :, None, None] + ce[:, 1].double()[None, :, None, None], 0, 6)
+    d = torch.clamp(F.conv2d(e, wd.double(), stride=stride, padding=1, groups=hid) * cd[:, 0].double()[None, :, None, None] + cd[:, 1].double()[None, :, None, None], 0, 6)
+    ref = F.conv2d(d, wp.double())
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.full((N, cout, Ho, Wo), float("nan"), device=DEV)
+    pe, pp = pack_pw3(dev(we), 0), pack_pw3(dev(wp), 0)          # (kept alive: the launch reads them through raw pointers)
+    check(lib.sc_ir_block_eval(C.byref(src), ptr(pe), ptr(pp), ptr(dev(wd)), ptr(dev(ce)), ptr(dev(cd)), ptr(out),
+                               N, cin, hid, cout, H, W, stride, stream()))
+    assert out.shape == ref.shape and not torch.isnan(out).any()
+    assert relerr(out, ref) < 5e-6
