@@ -143,3 +143,37 @@ def test_scene_tiles_partition_and_stitch():
         assert torch.equal(stitch(cores, r, H, W), scene)
     with pytest.raises(ValueError):
         scene_tiles(1000, 1024, 512, 64)
+
+
+def test_scene_tiles_square_and_strips():
+    """tile table of the sliding-window inference (pipeline.scene_tiles): cores partition the scene, windows = cores + halo clipped to
+    the scene, everything on the 32-pixel stride grid; strips = full-width rows with a vertical halo only"""
+    from starcop_amd import pipeline
+    H, W = 1280, 1248
+    for strips in (False, True):
+        r = pipeline.scene_tiles(H, W, 512, 320, strips=strips).tolist()
+        cover = np.zeros((H, W), dtype=np.int32)
+        for y0, y1, x0, x1, wy0, wy1, wx0, wx1 in r:
+            cover[y0:y1, x0:x1] += 1
+            assert wy0 == max(0, y0 - 320) and wy1 == min(H, y1 + 320) and wx0 == max(0, x0 - 320) and wx1 == min(W, x1 + 320)
+            assert all(v % 32 == 0 for v in (y0, x0, wy0, wx0)) and (wy1 % 32 == 0 and wx1 % 32 == 0)
+            if strips:
+                assert (x0, x1, wx0, wx1) == (0, W, 0, W)
+        assert (cover == 1).all()
+        assert len(r) == (3 if strips else 9)
+    work = lambda rows: sum((wy1 - wy0) * (wx1 - wx0) for _, _, _, _, wy0, wy1, wx0, wx1 in rows) / (H * W)
+    assert work(pipeline.scene_tiles(H, W, 512, 320, strips=True).tolist()) < 0.55 * work(pipeline.scene_tiles(H, W, 512, 320).tolist())      # 1.95x vs 3.8x the scene (clipped at the borders)
+    with pytest.raises(ValueError):
+        pipeline.scene_tiles(1000, W, 512, 320)
+
+
+def test_pointwise_kernel_choice_rules():
+    """which pointwise family a launch takes (network._use_pw3 / _use_ebwd): pure host logic, measured per layer"""
+    from starcop_amd import network as nw
+    if nw._PW3 != "1":
+        pytest.skip("STARCOP_PW3 overridden")
+    assert nw._use_pw3(0, 1024, 64) and nw._use_pw3(0, 256, 160) and nw._use_pw3(0, 256, 320)       # 32^2 / 16^2 expansions, features.18
+    assert not nw._use_pw3(0, 256, 960) and not nw._use_pw3(0, 65536, 16)                           # long K at 16^2; the 256^2 planes
+    assert nw._use_pw3(1, 1024, 64) and not nw._use_pw3(1, 1024, 384)                               # projection vs expansion data gradients
+    assert nw._use_pw3(2, 1024, 64, 384) and not nw._use_pw3(2, 1024, 96, 576) and not nw._use_pw3(2, 4, 64, 384)   # H*W % 8
+    assert not nw._use_ebwd(65536, 16, 96) or nw._PW3_EBWD                                          # opt-in

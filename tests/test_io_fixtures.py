@@ -109,3 +109,18 @@ def test_tiff_reader_on_tifffile_and_libtiff_written_files():
         assert np.array_equal(io.read_tiff(p, window=win).view(want.dtype), want[:, win[0]:win[0] + win[2], win[1]:win[1] + win[3]]), name
     assert io.tiff_info(os.path.join(G, "tiled_f32_deflate_pred3.tif")).block == (128, 128)
     assert io.tiff_info(os.path.join(G, "tiled_f32_deflate_pred3.tif")).predictor == 3
+
+
+def test_hdf5_reader_rejects_damaged_files(tmp_path):
+    """a truncated granule or a file that is not HDF5 raises an exception (never a crash or a silent empty read)"""
+    src = os.path.join(G, "emit_l1b_like_sb0.nc")
+    raw = open(src, "rb").read()
+    cut = tmp_path / "cut.nc"
+    cut.write_bytes(raw[:len(raw) // 3])
+    with pytest.raises(Exception):
+        with h5.H5File(str(cut)) as f:
+            f["radiance"].read()
+    junk = tmp_path / "junk.nc"
+    junk.write_bytes(b"CDF\x01" + b"\0" * 4096)                   # a NetCDF-3 classic header: not HDF5
+    with pytest.raises(h5.H5Error):
+        h5.H5File(str(junk))
