@@ -219,6 +219,9 @@ def main():
                     help="arithmetic of the >=32-channel 3x3 convolutions: fp32 (default, BASELINE configs[1], the parity mode: every fp32 operand split exactly "
                     "into two fp16 terms, three MFMA products) | fp32-x3 (three bf16 terms, six products: bit-faithful fp32 range) | fp32-bwd2 "
                     "(two bf16 terms in dgrad/wgrad) | fp32-2 (two bf16 terms everywhere) | bf16 (one term, configs[3]-style)")
+    ap.add_argument("--gradsync", default=None, choices=["allreduce", "rs_ag"],
+                    help="N > 1: gradient exchange of each bucket -- one all-reduce (default) or direct reduce-scatter + all-gather "
+                         "on the same memory (SURVEY.md section 5; also STARCOP_GRADSYNC)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step from a captured hipGraph (default: eager two-stream launches, measured faster)")
     args = ap.parse_args()
 
@@ -250,7 +253,7 @@ def main():
     opt = model.configure_optimizers()["optimizer"]
     B, T = args.batch, args.tile
     batch = synth_batch(B, T, T, 1234 + rank, dev)
-    sync = GradSync(world) if world > 1 else None
+    sync = GradSync(world, mode=args.gradsync) if world > 1 else None
     net = model.network
     net.overlap_wgrad = bool(args.overlap)
 
@@ -291,10 +294,30 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
-        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        cdev = dev if backend == "nccl" else "cpu"
+        own_ms = 1e3 * elapsed / args.steps
+        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # ---- diagnostics of the exchange, OUTSIDE the timed region (every rank takes part): each rank's own step time and, from
+        # device events around the two buckets of a few more steps, how much of the gradient exchange was NOT hidden behind the
+        # encoder's backward -- what a first multi-GPU run needs to tell a slow rank from an exposed collective
+        sync.timing = True
+        acc, nd = [0.0, 0.0, 0.0], 5
+        for _ in range(nd):
+            step()
+            tm = sync.collect_timing() or {}
+            for i, k in enumerate(("overlap_window", "bucket_rest", "bucket_tail_wait")):
+                acc[i] += tm.get(k, 0.0) / nd
+        sync.timing = False
+        mine = torch.tensor([own_ms] + acc, device=cdev, dtype=torch.float64)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "ms_per_step": round(float(v[0]), 3), "overlap_window_ms": round(float(v[1]), 3),
+                     "exposed_ms_bucket_encoder": round(float(v[2]), 3), "exposed_ms_bucket_decoder_wait": round(float(v[3]), 3)}
+                    for r, v in enumerate(allr)]
     loss = float(net._plans[(B, T, T)].loss_acc.item()) / (B * T * T)
 
     # ---- roofline of the dominant kernel family, measured live with events on the launch stream (eager, instrumented)
@@ -392,6 +415,9 @@ def main():
                           "parallelism": f"dp{world}", "hipgraph": graph is not None, "final_loss": round(loss, 6),
                           "precision": args.precision},
                "roofline": roof}
+        if per_rank is not None:
+            out["config"]["gradsync"] = sync.mode
+            out["per_rank"] = per_rank          # own (not max-over-ranks) step time; exposed = stream time the step waited for a bucket
         if roof_streaming is not None:
             out["roofline_streaming"] = roof_streaming
         if roof_lowest is not None:

@@ -572,13 +572,21 @@ class H5File:
         p = db + 6 + b.so
         per_page = 1 << page_bits
         paged = nent > per_page
+        page_init = None
         if paged:
+            # paged data block (HDF5 spec III.H "Fixed Array Data Block"): prefix | page-initialisation bitmap | 4-byte checksum of
+            # the prefix, THEN the pages; each page = per_page entries (the last one fewer) + its own 4-byte checksum.  A page whose
+            # bitmap bit is 0 was never written: its chunks do not exist (the fill value applies) and its bytes must not be read.
             npages = -(-nent // per_page)
-            p += (npages + 7) // 8
+            nbm = (npages + 7) // 8
+            page_init = [bool(d[p + (g >> 3)] & (0x80 >> (g & 7))) for g in range(npages)]      # most significant bit first
+            p += nbm + 4
         idx = list(np.ndindex(*nchunks))
         for i in range(nent):
             if paged:
                 pg, k = divmod(i, per_page)
+                if not page_init[pg]:
+                    continue
                 q = p + pg * (per_page * entry + 4) + k * entry
             else:
                 q = p + i * entry

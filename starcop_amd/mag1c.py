@@ -88,6 +88,7 @@ def _column_runs(ids):
 
 
 _LAYOUT_CACHE = {}
+MAX_SORT_WORK_INTS = 64 << 20        # histogram ints of the device counting sort (256 MB); beyond: the general sort path
 MAX_GROUP_IDS = 1 << 16      # group ids up to this take the device counting sort (detector widths are ~600-1300); larger / negative ids
                              # fall back to the general sort
 COLUMN_FAST_PATH = True      # False: always take the general (device sort) layout path; tests compare the two bit for bit
@@ -252,8 +253,17 @@ def func_by_groups(func, x, groups, mask=None, disable_pbar=True, samples_read=5
     if isinstance(func, Filter) and COLUMN_FAST_PATH:
         # any other integer group map (the orthorectified GLT grid of process_aviris.py:211-217): counting sort on the device.
         # The ids are bounded by the detector width; max_group (or one .max() read-back) sizes the histogram.
-        gmin, gmax = (0, int(max_group)) if max_group is not None else (int(groups_t.min()), int(groups_t.max()))
-        if gmin >= 0 and gmax < MAX_GROUP_IDS:
+        # max_group is a caller's promise: ids above it (or negative ones) would be dropped to NODATA without a word, so the data
+        # are checked against it (one read-back either way)
+        gmin, gmax = int(groups_t.min()), int(groups_t.max())
+        if max_group is not None:
+            if gmax > int(max_group) or gmin < 0:
+                raise ValueError(f"func_by_groups: group ids span [{gmin}, {gmax}] but max_group={max_group} was given")
+            gmax = int(max_group)
+        # the counting sort keeps ceil(HW/1024) * nids ints of histograms and pads every id's pixels to 64: fine for ids bounded by
+        # a detector width, ruinous for sparse label ids (60 000 ids on a 30 Mpx flight line = 7.6 GB): those take the general path
+        nblk = -(-(H * W) // 1024)
+        if gmin >= 0 and gmax < MAX_GROUP_IDS and nblk * (gmax + 1) <= MAX_SORT_WORK_INTS:
             xc = x.contiguous()
             return _run_column_groups(xc, b0, b1 - b0, mask_t.to(torch.uint8).contiguous() if mask is not None else mask_u8, None, 10,
                                       func.template, func.num_iter, func.alpha, func.k, func.flags, NODATA, x.dtype,

@@ -215,7 +215,10 @@ class HyperStarcopUNet(nn.Module):
           what can be said about a checkpoint before any data has flowed (``load_state_dict``).
 
         Synchronises the device.  ``sync_ranks``: MAX over the ranks of an initialised process group, so that every replica of a
-        data-parallel job takes the same decision (FusedAdam passes it; all ranks step together there)."""
+        data-parallel job takes the same decision (FusedAdam passes it; all ranks step together there).  The all-reduce also
+        carries ``switched`` -- 1 if ANY rank has already left the two-fp16-term mode on its own (an inference forward on
+        rank-local data may do that, ``_forward_impl``) -- and is issued by every rank whatever its own precision, so the
+        collective sequence of the replicas never diverges."""
         wmax = amax = rmax = omax = 0.0
         raw_feed, fin_feed = self._split_feeders()
         for plan in self._plans.values():
@@ -232,28 +235,38 @@ class HyperStarcopUNet(nn.Module):
                 bn = getattr(t, "bn", None)
                 if bn is not None and t.act != ACT_RELU6:
                     amax = max(amax, float((64.0 * bn.weight.detach().abs() + bn.bias.detach().abs()).max()))
+        switched = float(self._range_switched)
         if sync_ranks and torch.distributed.is_available() and torch.distributed.is_initialized() and self._pflat is not None:
-            v = torch.tensor([wmax, amax, rmax, omax], dtype=torch.float32, device=self._pflat.device)
+            v = torch.tensor([wmax, amax, rmax, omax, switched], dtype=torch.float32, device=self._pflat.device)
             torch.distributed.all_reduce(v, op=torch.distributed.ReduceOp.MAX)
-            wmax, amax, rmax, omax = (float(x) for x in v.tolist())
+            wmax, amax, rmax, omax, switched = (float(x) for x in v.tolist())
         return dict(max_abs_filter=wmax, filter_limit=self.FP16_MAX_WEIGHT, activation_bound=amax, activation_observed=omax,
-                    activation_limit=self.FP16_MAX_ACT, residual_absmax=rmax,
-                    ok=bool(wmax < self.FP16_MAX_WEIGHT and max(amax, omax, rmax) < self.FP16_MAX_ACT))
+                    activation_limit=self.FP16_MAX_ACT, residual_absmax=rmax, switched=bool(switched),
+                    ok=bool(wmax < self.FP16_MAX_WEIGHT and max(amax, omax, rmax) < self.FP16_MAX_ACT and not switched))
+
+    _range_switched = False      # this replica left precision "fp32" because of a range check (reported to the other ranks)
 
     def check_split_range(self, sync_ranks=False):
         """A checkpoint (or a training run) whose filters or activations leave the fp16 range of the default split continues with
-        the three-term bf16 split (fp32's exponent range); the warning says how long operands may have been clamped."""
-        if self.precision != "fp32":
+        the three-term bf16 split (fp32's exponent range); the warning says how long operands may have been clamped.
+
+        With ``sync_ranks`` the report's all-reduce runs on EVERY rank, also on one that has already switched (or was configured
+        with another precision): a rank that skipped it would leave the others waiting in the collective."""
+        if self.precision != "fp32" and not sync_ranks:
             return True
         rep = self.split_range_report(sync_ranks)
+        if self.precision != "fp32":
+            return True
         if not rep["ok"]:
             import warnings
             seen = max(rep["activation_observed"], rep["residual_absmax"]) >= self.FP16_MAX_ACT
             warnings.warn(f"HyperStarcopUNet: operands outside the range of the two-fp16-term kernels ({rep}); "
                           f"switching to precision='fp32-x3' (three bf16 terms, no range limits)"
+                          + ("; another rank of the process group had already switched" if rep["switched"] else "")
                           + (f"; activations beyond the limit were clamped to +-65504/2 in launches since the previous check "
                              f"(at most {self.range_check_every} steps)" if seen else ""))
             self.precision = "fp32-x3"
+            self._range_switched = True
         return rep["ok"]
 
     def _record_activation_range(self, plan):
@@ -679,7 +692,11 @@ class HyperStarcopUNet(nn.Module):
         eval_key = None
         if not training:
             eval_key = (tuple(p._version for p in self.parameters()), tuple(b._version for b in self.buffers()), self._stat_epoch)
-        eval_cst_ok = eval_key is not None and getattr(plan, "eval_cst_key", None) == eval_key
+        # (never while a hipGraph is being captured: the graph must contain the finalize launches, or its replays would keep the
+        # constants of capture time whatever happens to the parameters afterwards.  Writers that bypass torch's version counters --
+        # a broadcast into the flat buffer, raw-pointer updates -- must call mark_parameters_changed().)
+        eval_cst_ok = (eval_key is not None and getattr(plan, "eval_cst_key", None) == eval_key
+                       and not torch.cuda.is_current_stream_capturing())
         if training:
             self._stat_epoch += 1            # running statistics are about to be updated through raw pointers
             plan.eval_cst_key = None

@@ -15,12 +15,50 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, world_size=None, group=None):
+    """Sum of the flat gradient buffer over the ranks, in place.
+
+    ``mode``:
+      * ``"allreduce"`` (default): one ``all_reduce(SUM)`` per bucket (RCCL picks ring / tree);
+      * ``"rs_ag"``: ``reduce_scatter_tensor`` + ``all_gather_into_tensor`` on the same memory (rank r reduces the r-th
+        1/world chunk of the bucket, then the chunks are gathered back; both in place: the chunk IS a slice of the bucket).
+        On 8 fully connected xGMI peers this is the direct algorithm of SURVEY.md section 5 -- every GPU exchanges 1/8 of the
+        buffer with each peer on all 7 links at once instead of pushing the whole buffer round a ring.  The < world trailing
+        elements that do not fill a chunk go through a (tiny) all-reduce.  ``STARCOP_GRADSYNC=rs_ag`` selects it globally.
+    ``timing=True`` records, per step, the host-blocking time of each phase with device events (``last_timing``): how long the
+    asynchronous tail bucket had been running when the backward walk ended, and how long the step then still waited for it and
+    for the second bucket -- the EXPOSED (non-overlapped) communication time ``bench.py --gpus N`` prints per rank."""
+
+    def __init__(self, world_size=None, group=None, mode=None, timing=False):
+        import os
         self.group = group
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.mode = mode or os.environ.get("STARCOP_GRADSYNC", "allreduce")
+        if self.mode not in ("allreduce", "rs_ag"):
+            raise ValueError(f"GradSync: mode must be 'allreduce' or 'rs_ag' (got {self.mode!r})")
+        self.timing = timing
+        self.last_timing = None
+        self._ev = []
 
     def _host_staged(self, t):
         return t.is_cuda and dist.get_backend(self.group) == "gloo"
+
+    def _reduce(self, t, async_op=False):
+        """in-place SUM of ``t`` over the ranks; returns the list of work handles when ``async_op``"""
+        handles = []
+        if self.mode == "rs_ag" and t.numel() >= self.world:
+            rank = dist.get_rank(self.group)
+            chunk = t.numel() // self.world
+            main = t[:chunk * self.world]
+            mine = main[rank * chunk:(rank + 1) * chunk]
+            h1 = dist.reduce_scatter_tensor(mine, main, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            h2 = dist.all_gather_into_tensor(main, mine, group=self.group, async_op=async_op)     # same stream: ordered after h1
+            handles += [h1, h2]
+            rest = t[chunk * self.world:]
+            if rest.numel():
+                handles.append(dist.all_reduce(rest, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op))
+        else:
+            handles.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op))
+        return handles if async_op else None
 
     def __call__(self, flat_grads: torch.Tensor) -> float:
         """Sum ``flat_grads`` over ranks in place; returns the scale (1/world) the optimiser must apply."""
@@ -28,29 +66,57 @@ class GradSync:
             if self._host_staged(flat_grads):
                 # functional path only (gloo has no device transport on ROCm): stage through the host
                 host = flat_grads.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                self._reduce(host)
                 flat_grads.copy_(host)
             else:
-                dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=self.group)      # RCCL, in place, compute stream
+                self._reduce(flat_grads)      # RCCL, in place, compute stream
         return 1.0 / self.world
+
+    def _mark(self, t):
+        if self.timing and t.is_cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._ev.append(e)
 
     def begin(self, bucket: torch.Tensor):
         """Start summing ``bucket`` (a slice of the flat gradient buffer whose gradients are all queued on the current
         stream) over ranks, asynchronously; returns a handle for :meth:`finish` (None if nothing is in flight)."""
+        self._ev = []
         if self.world <= 1 or bucket.numel() == 0:
             return None
+        self._mark(bucket)                      # event 0: tail bucket handed to the collective
         if self._host_staged(bucket):
             self(bucket)
             return None
-        return dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self.mode == "rs_ag" and dist.get_backend(self.group) != "nccl":
+            # only RCCL orders a process group's collectives on one stream; gloo's asynchronous ops run on independent threads,
+            # so the all-gather could read the chunk before the reduce-scatter has written it
+            self._reduce(bucket)
+            return None
+        return self._reduce(bucket, async_op=True)
 
     def finish(self, rest: torch.Tensor, handles) -> float:
         """Sum ``rest`` (the remainder of the buffer), then make the current stream wait for the buckets in flight."""
+        self._mark(rest)                        # event 1: the backward walk has ended on this stream
         scale = self(rest)
+        self._mark(rest)                        # event 2: second bucket reduced
         for h in handles:
-            if h is not None:
-                h.wait()
+            for w in (h if isinstance(h, (list, tuple)) else [h]):
+                if w is not None:
+                    w.wait()
+        self._mark(rest)                        # event 3: first (asynchronous) bucket joined
         return scale
+
+    def collect_timing(self):
+        """ms of the last step: {'overlap_window': tail bucket start -> end of backward, 'bucket_rest': exposed time of the
+        second bucket, 'bucket_tail_wait': exposed remainder of the asynchronous bucket}.  Synchronises the device."""
+        if not self.timing or len(self._ev) < 4:
+            return None
+        torch.cuda.synchronize()
+        e = self._ev
+        self.last_timing = dict(overlap_window=e[0].elapsed_time(e[1]), bucket_rest=e[1].elapsed_time(e[2]),
+                                bucket_tail_wait=e[2].elapsed_time(e[3]))
+        return self.last_timing
 
 
 def broadcast_parameters(network, src=0, group=None):

@@ -80,10 +80,11 @@ def run_validation(model, dataloader, products_plot: Optional[List[str]] = None,
     model.eval()
     device = model.device
 
-    path_save_results_remote = None
-    if path_save_results is not None and path_save_results.startswith("gs://"):
-        path_save_results_remote = path_save_results
-        path_save_results = tempfile.mkdtemp(prefix="starcop")
+    if path_save_results is not None and "://" in str(path_save_results):
+        # validation.py:213-219 writes to a temporary folder and uploads it with fsspec.  Cloud-bucket I/O is outside this build
+        # (DESIGN.md scope table): refuse BEFORE the run, not after it when the results would be lost with the exception
+        raise NotImplementedError(f"run_validation: remote result folder {path_save_results!r} (validation.py:213-219) is outside "
+                                  "the hot path; pass a local path_save_results and copy it yourself")
 
     # how the model turns a prediction into a mask at a threshold: a known (threshold, opening) spec runs all
     # thresholds in one kernel; an opaque apply_threshold is called per threshold like the reference does
@@ -180,9 +181,6 @@ def run_validation(model, dataloader, products_plot: Optional[List[str]] = None,
         out_data.to_csv(os.path.join(path_save_results, "results.csv"))
         with open(os.path.join(path_save_results, "results_agg.json"), "w") as fh:
             json.dump(metrics, fh, cls=CustomJSONEncoder)
-        if path_save_results_remote is not None:
-            raise NotImplementedError("run_validation: uploading the result folder to a bucket (validation.py:213-219) is outside the "
-                                      "hot path; copy path_save_results yourself")
     return out_data, metrics
 
 

@@ -68,6 +68,24 @@ def write_emit(path, libver):
         loc.create_dataset("elev", shape=(ROWS, COLS), dtype="f4", chunks=(16, 32), fillvalue=np.float32(-9999.0))   # never written: all fill
 
 
+def paged_arrays():
+    rng = np.random.default_rng(4242)
+    return rng.integers(-30000, 30000, 2600 * 3).astype(np.int16), (rng.random(2500 * 2, dtype=np.float32) * 8).astype(np.float32)
+
+
+def write_paged(path):
+    """libver='latest' datasets whose fixed-array chunk index is PAGED (more than 2^10 chunks): one plain, completely written; one
+    filtered and written only in its first 700 and last 300 chunks, so that the middle page of the index is never initialised"""
+    import h5py
+    a, b = paged_arrays()
+    with h5py.File(path, "w", libver="latest") as f:
+        f.create_dataset("plain", data=a, chunks=(3,))                                     # 2600 chunks -> 3 pages
+        d = f.create_dataset("sparse", shape=b.shape, dtype="f4", chunks=(2,), compression="gzip", compression_opts=1,
+                             fillvalue=np.float32(-1.0))                                   # 2500 chunks -> 3 pages
+        d[:1400] = b[:1400]
+        d[4400:] = b[4400:]
+
+
 def tiff_arrays():
     rng = np.random.default_rng(77)
     f32 = np.round(rng.random((1, 200, 150), dtype=np.float32) * 100, 2).astype(np.float32)
@@ -99,6 +117,7 @@ if __name__ == "__main__":
     write_emit(os.path.join(OUT, "emit_l1b_like_sb0.nc"), "earliest")
     write_emit(os.path.join(OUT, "emit_l1b_like_sb2.nc"), ("v108", "v108"))
     write_emit(os.path.join(OUT, "emit_l1b_like_sb3.nc"), "latest")
+    write_paged(os.path.join(OUT, "fixed_array_paged_sb3.h5"))
     write_tiffs()
     for n in sorted(os.listdir(OUT)):
         print(n, os.path.getsize(os.path.join(OUT, n)))

@@ -30,6 +30,28 @@ def _worker(rank, world, port, q):
         gs = GradSync(world)
         h = gs.begin(g2[6:])
         assert gs.finish(g2[:6], [h]) == scale and torch.equal(g2, g)
+        # direct reduce-scatter + all-gather on the same memory, sizes that do / do not divide by world,
+        # a bucket shorter than world, and the asynchronous two-bucket form
+        for n in (10, 11, 1):
+            g3 = torch.arange(n, dtype=torch.float32) * (rank + 1)
+            assert GradSync(world, mode="rs_ag")(g3) == scale and torch.equal(g3, torch.arange(n, dtype=torch.float32) * 3)
+        g4 = torch.arange(11, dtype=torch.float32) * (rank + 1)
+        gs = GradSync(world, mode="rs_ag")
+        h = gs.begin(g4[5:])
+        assert gs.finish(g4[:5], [h]) == scale and torch.equal(g4, torch.arange(11, dtype=torch.float32) * 3)
+        # a rank that left the two-fp16-term mode on its own (inference on rank-local data) must not desynchronise the
+        # collectives of the periodic range check: every rank issues the all-reduce, and the others follow the switch
+        import warnings
+        from starcop_amd.network import HyperStarcopUNet
+        torch.manual_seed(0)
+        net = HyperStarcopUNet(4, 1)
+        net._ensure_flat()
+        if rank == 1:
+            net.precision, net._range_switched = "fp32-x3", True
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            net.check_split_range(sync_ranks=True)
+        assert net.precision == "fp32-x3", net.precision
         cm = M.BinaryConfusionMatrix()
         cm.update(torch.tensor([1, 0, 1, rank]), torch.tensor([1, 0, 0, 1]))
         cm.sync()

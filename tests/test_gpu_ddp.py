@@ -110,6 +110,14 @@ def test_bench_self_launches_n_ranks(hip):
     assert len(lines) == 1, lines
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2" and rec["value"] > 0
+    # diagnostics of a first multi-GPU run: every rank's own step time and the exposed time of both gradient buckets
+    assert [r["rank"] for r in rec["per_rank"]] == [0, 1] and rec["config"]["gradsync"] == "allreduce"
+    assert all(r["ms_per_step"] > 0 and r["exposed_ms_bucket_encoder"] >= 0 and r["exposed_ms_bucket_decoder_wait"] >= 0 for r in rec["per_rank"])
+    # the direct reduce-scatter + all-gather exchange through the same command line
+    p = subprocess.run(cmd + ["--gradsync", "rs_ag"], env=dict(env, STARCOP_BENCH_BACKEND="gloo"), capture_output=True, text=True, cwd=ROOT, timeout=400)
+    assert p.returncode == 0, (p.stdout[-500:], p.stderr[-1500:])
+    rec2 = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert rec2["config"]["gradsync"] == "rs_ag" and abs(rec2["config"]["final_loss"] - rec["config"]["final_loss"]) < 1e-5
     import torch
     if torch.cuda.device_count() < 2:          # RCCL path: fewer devices than ranks is an error, never a silent 1-rank run
         p = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=120)

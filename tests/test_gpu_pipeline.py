@@ -174,3 +174,62 @@ def test_emit_granule_predict_from_netcdf_file(hip):
     assert np.array_equal(out["mf"].cpu().numpy() == -9999.0, mf_ref == -9999.0) and bool((out["mf"][:5, :3] == -9999.0).all())
     ok = mf_ref != -9999.0
     assert np.abs(out["mf"].cpu().numpy()[ok] - mf_ref[ok]).max() < 1e-4 * max(1.0, float(np.abs(mf_ref[ok]).max()))
+
+
+def test_cfg5_full_size_scene(hip):
+    """BASELINE configs[4] at ITS size -- the 1280 x 1242 x 285 EMIT-like cube bench.py's `extra.emit_scene` times (notebook
+    inference_on_raw_EMIT_nc_file.ipynb cells 8-19) -- checked stage by stage, not only timed:
+      * mf / albedo of 8 column blocks spread over the scene (incl. the ragged last one and one with fill pixels) against
+        oracle/mag1c_ref.mag1c_columns (fp64 numpy, 1280-pixel x 2-column groups, 31 covariance rounds each);
+      * the two-band ratio on the full 1280 x 1242 planes against oracle/host_ref.band_ratio (exact percentiles of 1.6 M values);
+      * the network input against host_ref.emit_rescale;
+      * logits of the throughput mode (512-row full-width strips + 320-px halo, what each rank of a tile-sharded job runs)
+        against the whole-scene forward: <= 1e-5 of the logit range; masks equal away from logit 0."""
+    dev = DEV
+    wl = np.linspace(381.0, 2493.0, 285)
+    keep = np.nonzero((wl >= 2122.0) & (wl <= 2488.0))[0]
+    rng = np.random.default_rng(5)
+    templ = -np.abs(rng.standard_normal(keep.size)) * 0.3 - 0.05
+    gen = torch.Generator(device=dev).manual_seed(11)
+    rows, cols = 1280, 1242
+    cube = ((torch.rand(285, generator=gen, device=dev) * 5 + 1) * (1 + 0.05 * torch.randn(rows, cols, 285, generator=gen, device=dev))).float()
+    cube[100:140, 600:602, :] = -9999.0                       # fill pixels inside one of the checked column blocks
+    cube[:30, :7, :] = -9999.0
+    cube = cube.contiguous()
+    torch.manual_seed(0)
+    model = mm.ModelModule(mm.default_settings(pos_weight=1)).to(dev).eval()
+    whole = pipeline.emit_scene_predict(model, cube, wl, templ, column_step=2, ratio_bands=(2350, 2310))
+    strips = pipeline.emit_scene_predict(model, cube, wl, templ, column_step=2, ratio_bands=(2350, 2310), tile=512)
+    assert whole["prediction"].shape == (1280, 1216) and whole["mf"].shape == (rows, cols)
+    # -- matched filter: 8 column blocks against the fp64 oracle
+    sub = cube[..., int(keep[0]):int(keep[-1]) + 1]
+    worst = 0.0
+    for c0 in (0, 2, 310, 600, 620, 900, 1238, 1240):
+        blk = sub[:, c0:c0 + 2].cpu().numpy()
+        mf_ref, alb_ref = mag1c_ref.mag1c_columns(blk, templ, -9999.0, column_step=2)
+        for got, want in ((whole["mf"][:, c0:c0 + 2], mf_ref), (whole["albedo"][:, c0:c0 + 2], alb_ref)):
+            want = torch.as_tensor(want)
+            assert torch.equal(got.cpu() == -9999.0, want == -9999.0), c0         # exact fill pattern
+            worst = max(worst, relerr(got, want))
+    print(f"configs[4] full size: mf / albedo of 8 column blocks vs the fp64 oracle: worst rel err {worst:.2e}")
+    assert worst < 1e-4
+    assert torch.equal(whole["mf"], strips["mf"])
+    # -- band ratio on the scene-sized planes
+    ia, ir = pipeline.nearest_bands(wl, (2350, 2310))
+    r_ref = host_ref.band_ratio(cube[..., ia].cpu().numpy(), cube[..., ir].cpu().numpy())
+    e_r = relerr(whole["ratio"], torch.as_tensor(r_ref))
+    print(f"configs[4] full size: band ratio vs host_ref.band_ratio: rel err {e_r:.2e}")
+    assert e_r < 1e-4
+    # -- network input
+    rgb = cube[..., pipeline.nearest_bands(wl)].permute(2, 0, 1).cpu().numpy()
+    x_ref = host_ref.emit_rescale(whole["mf"].cpu().numpy(), rgb)
+    assert relerr(whole["input"], torch.as_tensor(x_ref)) < 1e-6
+    # -- strips vs whole-scene logits (from the probabilities' logits: recompute both with the model for the raw logits)
+    with torch.no_grad():
+        lw = model(whole["input"][None])[0, 0]
+    ls = pipeline.tiled_logits(model, whole["input"], tile=512, halo=pipeline.RECEPTIVE_HALO, strips=True)
+    e = relerr(ls, lw)
+    print(f"configs[4] full size: 512-row strips + halo 320 vs whole-scene logits: rel err {e:.2e}")
+    assert e < 1e-5
+    far = lw.abs() > 1e-3
+    assert torch.equal(strips["pred_binary"][far], whole["pred_binary"][far])

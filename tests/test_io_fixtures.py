@@ -59,6 +59,21 @@ def test_hdf5_reader_on_libhdf5_written_emit_like_granules(name, sb):
         assert f.attrs("/")["title"].startswith("EMIT L1B")
 
 
+def test_hdf5_paged_fixed_array_index():
+    """libver='latest' datasets with more than 2^10 chunks: the fixed-array chunk index is PAGED (data block = prefix, page bitmap,
+    checksum, then pages with a checksum each); `sparse` leaves its middle page uninitialised (fill value there)  [ADVICE r3]"""
+    rng = np.random.default_rng(4242)
+    a = rng.integers(-30000, 30000, 2600 * 3).astype(np.int16)
+    b = (rng.random(2500 * 2, dtype=np.float32) * 8).astype(np.float32)
+    want = np.full(b.shape, -1.0, np.float32)
+    want[:1400] = b[:1400]
+    want[4400:] = b[4400:]
+    with h5.H5File(os.path.join(G, "fixed_array_paged_sb3.h5")) as f:
+        assert f.superblock_version == 3
+        assert np.array_equal(f["plain"].read(), a) and np.array_equal(f["plain"][3070:3080], a[3070:3080])     # across the page seam
+        assert np.array_equal(f["sparse"].read(), want)
+
+
 def test_read_emit_l1b_band_window():
     """read_emit_l1b: what EMITImage + read_from_bands + load_raw hand mag1c_emit (mag1c_emit.py:40-48) -- the bands inside
     [2122, 2488] nm as a contiguous slice read chunk-wise, band centres / widths, the fill value, the GLT"""
