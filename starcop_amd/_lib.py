@@ -49,6 +49,11 @@ class sc_wgrad_args(C.Structure):
                 ("absmax", C.c_void_p)]
 
 
+class sc_irt_args(C.Structure):
+    _fields_ = [("x", sc_src), ("w_expand", C.c_void_p), ("w_dw", C.c_void_p), ("cst_expand", C.c_void_p),
+                ("N", C.c_int32), ("Cin", C.c_int32), ("hidden", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("stride", C.c_int32)]
+
+
 class sc_wgrad_pending(C.Structure):
     _fields_ = [("part", C.c_void_p), ("dw", C.c_void_p), ("nparts", C.c_int32), ("taps", C.c_int32), ("Cout", C.c_int32),
                 ("Cin", C.c_int32), ("CoP", C.c_int32), ("CiP", C.c_int32), ("total", C.c_uint64)]
@@ -147,6 +152,15 @@ SIGNATURES = {
     "sc_conv1x1_wgrad_pw3": (_i, [C.POINTER(sc_wgrad_args), C.POINTER(sc_wgrad_pending), _vp]),
     "sc_ir_block_eval_supported": (_i, [_i, _i, _i, _i]),
     "sc_ir_block_eval": (_i, [C.POINTER(sc_src), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "sc_irt_supported": (_i, [_i, _i, _i, _i, _i]),
+    "sc_irt_rows": (_i, [_i, _i, _i, _i, _i]),
+    "sc_irt_bwd_rows": (_i, [_i, _i, _i, _i]),
+    "sc_irt_bwd_workspace_floats": (_sz, [_i, _i, _i, _i]),
+    "sc_irt_expand_stats": (_i, [C.POINTER(sc_irt_args), _vp, _vp]),
+    "sc_irt_fwd": (_i, [C.POINTER(sc_irt_args), _vp, _vp, _vp]),
+    "sc_irt_bwd_sums": (_i, [C.POINTER(sc_irt_args), C.POINTER(sc_src), _vp, _vp, _vp, _vp]),
+    "sc_irt_bwd_data": (_i, [C.POINTER(sc_irt_args), C.POINTER(sc_src), _vp, _vp, _vp, _i, _vp]),
+    "sc_irt_wgrad_finalize": (_i, [C.POINTER(sc_irt_args), _vp, _vp, _vp, _vp]),
     "sc_maxpool2x2": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _i, _vp]),
     "sc_upsample_bilinear2x": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _i, _vp]),
     "sc_maxpool2x2_bwd": (_i, [C.POINTER(sc_src), _vp, _vp, _i, _i, _i, _i, _i, _vp]),
