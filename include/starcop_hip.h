@@ -239,22 +239,25 @@ int sc_ir_block_eval(const sc_src* x, const float* wpk_expand, const float* wpk_
                      const float* cst_expand, const float* cst_dw, float* out, int N, int Cin, int hidden, int Cout,
                      int H, int W, int stride, sc_stream stream);
 
-/* Fused TRAINING execution of the expansion + depthwise pair of a MobileNetV2 inverted-residual block (torchvision
+/* Fused TRAINING execution of the expansion + depthwise pair of a STRIDE-2 MobileNetV2 inverted-residual block (torchvision
  * InvertedResidual.conv[0..1] inside smp.Unet('mobilenet_v2'): starcop/models/model_module.py:244-251; train-mode BatchNorm):
- *     e = conv1x1(x, w_expand) -> BN_e + ReLU6 -> depthwise 3x3 (stride 1 | 2, pad 1) -> d (raw; BN_d is the consumers' business)
- * The 6x-expanded tensor e and its gradient are NEVER stored: every sweep recomputes e from the block input x on the matrix cores
- * (fp32 accuracy: three exact bf16 terms per operand, six products).  Replaces, per block and step, the launches
+ *     e = conv1x1(x, w_expand) -> BN_e + ReLU6 -> depthwise 3x3 (stride 2, pad 1) -> d (raw; BN_d is the consumers' business)
+ * The 6x-expanded tensor e (four times the size of d) and its gradient are NEVER stored: every sweep recomputes e from the block
+ * input x on the matrix cores (fp32 accuracy: three exact bf16 terms per operand, six products).  Replaces, per block and step,
  *   sc_conv1x1_* (expand, +stats) | sc_dwconv3x3_fwd | sc_dwconv3x3_bwd_fused | expand data gradient | expand weight gradient.
- * Cin in {8, 16, 24, 32}, hidden <= 192, H % 4 == 0, W % 8 == 0 (sc_irt_supported).
+ * Cin in {8, 16, 24, 32}, hidden <= 192, H % 4 == 0, W % 8 == 0, stride 2 (sc_irt_supported).
  *   forward :  sc_irt_expand_stats -> sc_bn_finalize(BN_e, rows = sc_irt_rows(0,..)) -> sc_irt_fwd -> sc_bn_finalize(BN_d, rows =
  *              sc_irt_rows(1,..)) -> the projection convolution reads d as an SC_SRC_AFFINE source, as before
- *   backward:  (dy_d = the SC_SRC_BNBWD source of d, from sc_bn_bwd_* on d)
- *              sc_irt_bwd_sums   -> e_sums rows for sc_bn_bwd_finalize(BN_e) (rows = sc_irt_bwd_rows), the depthwise filter gradient
- *                                   (dw_acc[hidden][9] += , fp64 atomics, as sc_dwconv3x3_bwd_fused) and partial rows in `work`
- *              sc_bn_bwd_finalize(BN_e) -> cst_bwd_expand
- *              sc_irt_bwd_data   -> dx = gradient w.r.t. the block input as the source delivers it (optional residual add0 / accumulate)
- *              sc_irt_wgrad_finalize -> dw_expand[hidden][Cin] = A (.) G + B (.) (W_e M) + D (x) s from the partial rows: exact,
- *                                   dy_e being affine in (g'_e, e) per channel and e linear in x (off the critical path).     */
+ *   backward:  (dy_d = the SC_SRC_BNBWD source of d, from sc_bn_bwd_* on d;  `work`: sc_irt_bwd_workspace_floats floats, 16-byte aligned)
+ *              sc_irt_bwd        ONE sweep over (dy_d, x): e_sums rows for sc_bn_bwd_finalize(BN_e) (rows = sc_irt_bwd_rows), the
+ *                                depthwise filter gradient (dw_acc[hidden][9] +=, fp64 atomics, as sc_dwconv3x3_bwd_fused), partial
+ *                                rows of G = sum_px g'_e x^T and the part of dx that does not depend on the batch sums,
+ *                                W_e^T (scale (.) g'_e), into `work`
+ *              sc_bn_bwd_finalize(BN_e) -> cst_bwd_expand (.., .., A, B, D)
+ *              sc_irt_bwd_fix    dx = that part + Q x + r (+ add0) (+ dx),  Q = W_e^T diag(B) W_e, r = W_e^T D: exact, because
+ *                                dy_e = A g'_e + B e + D is affine per channel and e = W_e x
+ *              sc_irt_xmoments   M = sum_px x x^T, s = sum_px x into `work` (any time after x exists; off the critical path)
+ *              sc_irt_wgrad_finalize  dw_expand[hidden][Cin] = A (.) G + B (.) (W_e M) + D (x) s                              */
 typedef struct sc_irt_args {
   sc_src x;                 /* block input [N,Cin,H,W]: SC_SRC_RAW or SC_SRC_AFFINE                                   */
   const float* w_expand;    /* [hidden][Cin]   (the 1x1 filter, OIHW)                                                 */
@@ -265,13 +268,14 @@ typedef struct sc_irt_args {
 int sc_irt_supported(int Cin, int hidden, int H, int W, int stride);
 int sc_irt_rows(int stage, int N, int H, int W, int stride);        /* stage 0: sc_irt_expand_stats, 1: sc_irt_fwd */
 int sc_irt_bwd_rows(int N, int hidden, int H, int W);
-size_t sc_irt_bwd_workspace_floats(int N, int hidden, int H, int W);
+size_t sc_irt_bwd_workspace_floats(int N, int Cin, int hidden, int H, int W);
 int sc_irt_expand_stats(const sc_irt_args* a, float* stats /*[rows][hidden][2]*/, sc_stream stream);
 int sc_irt_fwd(const sc_irt_args* a, float* d_out /*[N,hidden,Ho,Wo] raw*/, float* stats_d /*[rows][hidden][2]*/, sc_stream stream);
-int sc_irt_bwd_sums(const sc_irt_args* a, const sc_src* dy_d, double* e_sums /*[rows][hidden][2]*/, double* dw_acc /*[hidden][9]*/,
-                    float* work, sc_stream stream);
-int sc_irt_bwd_data(const sc_irt_args* a, const sc_src* dy_d, const float* cst_bwd_expand, float* dx, const float* add0, int accum,
-                    sc_stream stream);
+int sc_irt_bwd(const sc_irt_args* a, const sc_src* dy_d, double* e_sums /*[rows][hidden][2]*/, double* dw_acc /*[hidden][9]*/,
+               float* work, sc_stream stream);
+int sc_irt_xmoments(const sc_irt_args* a, float* work, sc_stream stream);
+int sc_irt_bwd_fix(const sc_irt_args* a, const float* cst_bwd_expand, float* work, float* dx, const float* add0, int accum,
+                   sc_stream stream);
 int sc_irt_wgrad_finalize(const sc_irt_args* a, const float* cst_bwd_expand, float* work, float* dw_expand, sc_stream stream);
 
 /* the 3x3 weight gradient with split-bf16 operands on the bf16 matrix cores (see sc_conv3x3_bx3); same arguments,

@@ -155,11 +155,12 @@ SIGNATURES = {
     "sc_irt_supported": (_i, [_i, _i, _i, _i, _i]),
     "sc_irt_rows": (_i, [_i, _i, _i, _i, _i]),
     "sc_irt_bwd_rows": (_i, [_i, _i, _i, _i]),
-    "sc_irt_bwd_workspace_floats": (_sz, [_i, _i, _i, _i]),
+    "sc_irt_bwd_workspace_floats": (_sz, [_i, _i, _i, _i, _i]),
     "sc_irt_expand_stats": (_i, [C.POINTER(sc_irt_args), _vp, _vp]),
     "sc_irt_fwd": (_i, [C.POINTER(sc_irt_args), _vp, _vp, _vp]),
-    "sc_irt_bwd_sums": (_i, [C.POINTER(sc_irt_args), C.POINTER(sc_src), _vp, _vp, _vp, _vp]),
-    "sc_irt_bwd_data": (_i, [C.POINTER(sc_irt_args), C.POINTER(sc_src), _vp, _vp, _vp, _i, _vp]),
+    "sc_irt_bwd": (_i, [C.POINTER(sc_irt_args), C.POINTER(sc_src), _vp, _vp, _vp, _vp]),
+    "sc_irt_xmoments": (_i, [C.POINTER(sc_irt_args), _vp, _vp]),
+    "sc_irt_bwd_fix": (_i, [C.POINTER(sc_irt_args), _vp, _vp, _vp, _vp, _i, _vp]),
     "sc_irt_wgrad_finalize": (_i, [C.POINTER(sc_irt_args), _vp, _vp, _vp, _vp]),
     "sc_maxpool2x2": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _i, _vp]),
     "sc_upsample_bilinear2x": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _i, _vp]),

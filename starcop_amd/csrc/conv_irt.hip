@@ -24,6 +24,7 @@
 //   (2) rows = hidden channels, columns = pixels: a lane owns ONE pixel and 16 channels -> the registers are the B operand of a
 //       contraction over HIDDEN channels (dx) with the filter rows permuted to the accumulator's channel order.
 #include "sc_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -64,6 +65,17 @@ __device__ __forceinline__ floatx16 mfma6(const uintx4 (&a)[3], const uintx4 (&b
   c = mfma_bf16(a[0], b[0], c);
   return c;
 }
+// two independent six-product blocks issued alternately: a chain of dependent MFMAs on ONE accumulator runs at the instruction's
+// latency (16 passes), two interleaved chains at its issue rate
+__device__ __forceinline__ void mfma6x2(const uintx4 (&a)[3], const uintx4 (&b)[3], floatx16& c, const uintx4 (&d)[3], const uintx4 (&e)[3],
+                                        floatx16& f) {
+  c = mfma_bf16(a[1], b[1], c); f = mfma_bf16(d[1], e[1], f);
+  c = mfma_bf16(a[2], b[0], c); f = mfma_bf16(d[2], e[0], f);
+  c = mfma_bf16(a[0], b[2], c); f = mfma_bf16(d[0], e[2], f);
+  c = mfma_bf16(a[1], b[0], c); f = mfma_bf16(d[1], e[0], f);
+  c = mfma_bf16(a[0], b[1], c); f = mfma_bf16(d[0], e[1], f);
+  c = mfma_bf16(a[0], b[0], c); f = mfma_bf16(d[0], e[0], f);
+}
 __device__ __forceinline__ floatx16 zero16() {
   floatx16 z;
 #pragma unroll
@@ -91,7 +103,8 @@ struct IrtP {
   double* dwacc;           // [Hd][9] depthwise filter gradient, fp64 atomics                            (k_irt_bsums)
   float* gpart;            // [rows][nch*32][32]                                                         (k_irt_bsums)
   float* mpart;            // [rows][33][32]: rows 0..31 = M[ci][ci'], row 32 = s[ci']                    (k_irt_bsums)
-  float* dx; const float* add0; int accum;                                                            // (k_irt_bdata)
+  float* dx; const float* add0; int accum;                                                            // (k_irt_bwd: partials; k_irt_fix)
+  const uintx4* wpk;       // packed split filter operands (k_irt_pack)                                  (k_irt_bwd)
   int N, Cin, Hd, H, W, S, Ho, Wo, nch;
   int tiles_x, tiles_y, ntiles, tiles_per_wg, npb;
 };
@@ -355,407 +368,458 @@ __global__ __launch_bounds__(256) void k_irt_fwd(const IrtP p) {
 }
 
 // =================================================================================================================================
-// staging of the depthwise output's gradient for a tile of 8 x 32 e pixels: region of d that the tile's e pixels feed
-//   stride 1: rows r0-1 .. r0+8, columns c0-1 .. c0+32 (10 x 34);  stride 2: rows r0/2 .. r0/2+4, columns c0/2 .. c0/2+16 (5 x 17)
-// s_dy[channel][PITCH]; zeros outside the image and for channels past Hd.  Wave w stages channels w, w+4, ...
-template <int S> struct IrtBwdGeo {
-  static constexpr int RH = S == 1 ? 10 : 5, RW = S == 1 ? 34 : 17, RSZ = RH * RW;
-  static constexpr int PITCH = (RSZ | 1);                    // odd: lanes = channels read conflict-free
+// (C) backward, stride 2, ONE heavy sweep.  dy_e = scale (g' - c1 - c2 xn) is affine in (g', e) per channel, and its coefficient
+// of g' -- the BatchNorm scale -- is known BEFORE the batch sums c1, c2 are, so
+//     dx = W_e^T dy_e = W_e^T (scale (.) g')  +  Q x + r,      Q = W_e^T diag(B) W_e  (Cin x Cin),  r = W_e^T D
+// and the sweep that forms g' can emit the first term at once; the remainder is a Cin -> Cin pointwise fix-up of the small tensor
+// (k_irt_fix) once sc_bn_bwd_finalize has produced B, D.  e, g_e and dy_e never exist in memory, and (dy_d, d) are read ONCE.
+//
+// Work-group = 512 threads = 8 waves on a tile of 8 x 32 e pixels; wave w owns the 4 x 8 pixel block (w / 4, w % 4) -- orientation
+// 1: lane = hidden channel, registers = a 4 x 4 pixel patch, so BN / ReLU6 switch / the stride-2 stencil (9 LDS reads per patch, tap
+// sets fixed by pixel parity at compile time) / all per-channel sums are in-lane.  A work-group walks its tiles and up to 3 chunks
+// of 32 hidden channels (grid.y = chunk groups; a second group writes its own dx partial, the fix-up adds them):
+//   per tile:   stage (dy_d of all its chunks: 5 x 17 per channel, every load issued before the first is used) | barrier
+//   per chunk:  e = x W_e (MFMA) -> g' -> sums, depthwise filter gradient, G += g' x^T (MFMA, K = pixels)
+//               scale (.) g' -> wave-private LDS transpose -> B operand (K = hidden) -> dx += W_e^T (.) (MFMA)
+constexpr int IRT_CG = 3;                  // chunks per work-group
+constexpr int IRT_RW = 17, IRT_RSZ = 51;   // staged region of d per channel for a tile of 4 x 32 e pixels: 3 x 17 (odd pitch: lanes = channels read conflict-free)
+
+struct IrtBwdLds {                         // byte offsets into dynamic LDS
+  int k, dc, xc, dy, T, acc, total;
 };
-template <int S>
-__device__ __forceinline__ void irt_stage_dy(const IrtP& p, float* __restrict__ s_dy, const float* __restrict__ s_dc, int n, int chunk,
-                                             int r0, int c0, int lane, int wave) {
-  using B = IrtBwdGeo<S>;
-  const int ry0 = S == 1 ? r0 - 1 : r0 / 2, rx0 = S == 1 ? c0 - 1 : c0 / 2;
-  const size_t HWo = (size_t)p.Ho * p.Wo;
-  const float lo = sc_act_lo(p.dy.act), hi = sc_act_hi(p.dy.act);
-  const bool bnb = p.dy.mode == SC_SRC_BNBWD;
-  for (int c = wave; c < 32; c += 4) {
-    const int h = chunk * 32 + c;
-    const bool hok = h < p.Hd;
-    const size_t cb = ((size_t)n * p.Hd + (hok ? h : 0)) * HWo;
-    const float k0 = s_dc[c * 8], k1 = s_dc[c * 8 + 1], kA = s_dc[c * 8 + 2], kB = s_dc[c * 8 + 3], kD = s_dc[c * 8 + 4];
-    for (int r = lane; r < B::RSZ; r += 64) {
-      const int ry = r / B::RW, rx = r - ry * B::RW;
-      const int oy = ry0 + ry, ox = rx0 + rx;
-      const bool inb = hok && oy >= 0 && oy < p.Ho && ox >= 0 && ox < p.Wo;
-      const size_t o = cb + (inb ? (size_t)oy * p.Wo + ox : 0);
-      const float g = p.dy.x[o];
-      float v = g;
-      if (bnb) v = sc_pro_bnbwd(g, p.dy.aux[o], k0, k1, kA, kB, kD, lo, hi);
-      s_dy[c * B::PITCH + r] = inb ? v : 0.f;
-    }
-  }
-}
-// constants of the gradient source for the 32 channels of a chunk -> s_dc[32][8] (identity for a RAW source)
-__device__ __forceinline__ void irt_dy_consts(const IrtP& p, float* s_dc, int chunk) {
-  if (threadIdx.x < 32) {
-    const int h = chunk * 32 + threadIdx.x;
-    const int hc = h < p.Hd ? h : p.Hd - 1;
-    float4 c0 = make_float4(1.f, 0.f, 1.f, 0.f); float c4 = 0.f;
-    if (p.dy.mode == SC_SRC_BNBWD) { c0 = *reinterpret_cast<const float4*>(p.dy.cst + (size_t)hc * SC_CST); c4 = p.dy.cst[(size_t)hc * SC_CST + 4]; }
-    *reinterpret_cast<float4*>(s_dc + threadIdx.x * 8) = c0;
-    *reinterpret_cast<float4*>(s_dc + threadIdx.x * 8 + 4) = make_float4(c4, 0.f, 0.f, 0.f);
-  }
+__host__ __device__ inline IrtBwdLds irt_bwd_lds() {
+  // 65.7 KB: two work-groups per CU.  The split filter operands (27-36 KB per group) are read from a packed copy in global memory
+  // instead (k_irt_pack: 16 bytes per lane and operand, L1 / L2 resident).  Measured on features.2: every table in LDS, one
+  // work-group per CU: 412-452 us; this layout: 347 us; the dx operands back in LDS + e operands requested a chunk ahead (79.7 KB,
+  // 20 spilled registers): 432 us.
+  IrtBwdLds l;
+  l.k = 0;                                        // [CG][32][16] float: scale, shift, mean, invstd, wd[9], pad
+  l.dc = l.k + IRT_CG * 32 * 16 * 4;              // [CG][32][8] float
+  l.xc = l.dc + IRT_CG * 32 * 8 * 4;              // [32][2] float
+  l.dy = l.xc + 64 * 4;                           // [CG][32][51] float
+  l.T = l.dy + IRT_CG * 32 * IRT_RSZ * 4;         // [4][32][36] float (also the epilogue's reduction scratch: [3][16][64])
+  l.acc = l.T + 4 * 32 * 36 * 4;                  // [4][CG*32][12] float: per-wave accumulators of sum g', sum g' xn, dW_dw[9]
+  l.total = l.acc + 4 * IRT_CG * 32 * 12 * 4;
+  return l;
 }
 
-// =================================================================================================================================
-// (Bi) backward sums.  grid = (tile sets, chunks): a work-group owns ONE chunk of 32 hidden channels and walks its tiles of
-// 8 x 32 e pixels; a wave owns two 4 x 8 pixel blocks per tile (orientation 1: lane = channel, registers = a 4 x 4 pixel patch).
-template <int NKS, int S>
-__global__ __launch_bounds__(256) void k_irt_bsums(const IrtP p) {
-  using B = IrtBwdGeo<S>;
-  constexpr int RW = B::RW, PITCH = B::PITCH;
-  constexpr int LP = S == 1 ? 6 : 3;                         // rows / columns of dy_d a 4 x 4 patch touches
+template <int NKS>
+__global__ __launch_bounds__(256, 2) void k_irt_bwd(const IrtP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* s_dy = reinterpret_cast<float*>(smem);              // [32][PITCH]
-  float* s_dc = s_dy + 32 * PITCH;                           // [32][8]
-  float* s_xc = s_dc + 256;                                  // [32][2]
-  float* s_red = s_xc + 64;                                  // reduction scratch: [3][16][64] floats (>= [4][32][12])
+  const IrtBwdLds L_ = irt_bwd_lds();
+  float* s_k = reinterpret_cast<float*>(smem + L_.k);
+  float* s_dc = reinterpret_cast<float*>(smem + L_.dc);
+  float* s_xc = reinterpret_cast<float*>(smem + L_.xc);
+  float* s_dy = reinterpret_cast<float*>(smem + L_.dy);
+  float* s_T = reinterpret_cast<float*>(smem + L_.T);
+  float* s_acc = reinterpret_cast<float*>(smem + L_.acc);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int chunk = blockIdx.y;
   const int H = p.H, W = p.W, Hd = p.Hd, Cin = p.Cin;
-  const size_t HW = (size_t)H * W;
-  irt_xconsts(p, s_xc);
-  irt_dy_consts(p, s_dc, chunk);
-  // this lane's hidden channel
-  const int h = chunk * 32 + l31;
-  const bool hok = h < Hd;
-  const int hc = hok ? h : Hd - 1;
-  const float4 ce = *reinterpret_cast<const float4*>(p.cst_e + (size_t)hc * SC_CST);      // scale, shift, mean, invstd
-  float wk[9];
+  const size_t HW = (size_t)H * W, HWo = (size_t)p.Ho * p.Wo;
+  const int ch0 = blockIdx.y * IRT_CG;
+  const int ncg = min(IRT_CG, p.nch - ch0);
+  // ---------------- once per work-group: filter operands and per-channel constants of its chunks
+  const uintx4* g_w = p.wpk + (size_t)ch0 * NKS * 3 * 64 + lane;                      // [nch][NKS][3][64]
+  const uintx4* g_wT = p.wpk + (size_t)p.nch * NKS * 3 * 64 + (size_t)ch0 * 2 * 3 * 64 + lane;   // [nch][2][3][64]
+  for (int i = tid; i < IRT_CG * 32; i += 256) {
+    const int hh = ch0 * 32 + i;
+    const bool ok = hh < Hd && i < ncg * 32;
+    const int hc = hh < Hd ? hh : Hd - 1;
+    float* k = s_k + i * 16;
+    const float4 ce = *reinterpret_cast<const float4*>(p.cst_e + (size_t)hc * SC_CST);
+    k[0] = ce.x; k[1] = ce.y; k[2] = ce.z; k[3] = ce.w;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) wk[k] = hok ? p.wd[(size_t)hc * 9 + k] : 0.f;
-  uintx4 wop[NKS][3];
-  irt_wop<NKS>(p, h, lhi, wop);
+    for (int t = 0; t < 9; ++t) k[4 + t] = ok ? p.wd[(size_t)hc * 9 + t] : 0.f;
+    k[13] = 0.f; k[14] = 0.f; k[15] = 0.f;
+    float4 c0 = make_float4(1.f, 0.f, 1.f, 0.f); float c4 = 0.f;
+    if (p.dy.mode == SC_SRC_BNBWD) { c0 = *reinterpret_cast<const float4*>(p.dy.cst + (size_t)hc * SC_CST); c4 = p.dy.cst[(size_t)hc * SC_CST + 4]; }
+    *reinterpret_cast<float4*>(s_dc + i * 8) = c0;
+    *reinterpret_cast<float4*>(s_dc + i * 8 + 4) = make_float4(c4, 0.f, 0.f, 0.f);
+  }
+  for (int i = tid; i < 4 * IRT_CG * 32 * 12; i += 256) s_acc[i] = 0.f;
+  irt_xconsts(p, s_xc);
   const float lo = sc_act_lo(p.x.act), hi = sc_act_hi(p.x.act);
-  // x^T operand constants: this lane's input channel l31
+  const float dlo = sc_act_lo(p.dy.act), dhi = sc_act_hi(p.dy.act);
+  const bool bnb = p.dy.mode == SC_SRC_BNBWD;
   const bool ciok = l31 < Cin;
   const int cic = ciok ? l31 : Cin - 1;
   const float xsc = p.x.cst[(size_t)cic * SC_CST], xsh = p.x.cst[(size_t)cic * SC_CST + 1];
+  const int bc = wave;                                       // this wave's 4 x 8 pixel block of the 4 x 32 tile
+  float* myT = s_T + wave * (32 * 36);
+  float* myacc = s_acc + wave * (IRT_CG * 32 * 12);
+  // staging: a lane owns ONE position (ry, rx) of the 3 x 17 region, a wave walks channels wave, wave + 4, ... of the group
+  const int sry = lane / IRT_RW, srx = lane - sry * IRT_RW;
+  const bool slane = lane < IRT_RSZ;
+  const int nst = ncg * 8;                                   // channels per wave
 
-  float s1 = 0.f, s2 = 0.f, sx = 0.f, dwd[9];
+  floatx16 accG[IRT_CG];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) dwd[k] = 0.f;
-  floatx16 accG = zero16(), accM = zero16();
+  for (int cq = 0; cq < IRT_CG; ++cq) accG[cq] = zero16();
   const int t_begin = blockIdx.x * p.tiles_per_wg;
   const int t_end = min(t_begin + p.tiles_per_wg, p.ntiles);
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int n = tile / (p.tiles_x * p.tiles_y), tt = tile - n * p.tiles_x * p.tiles_y;
-    const int r0 = (tt / p.tiles_x) * 8, c0 = (tt % p.tiles_x) * 32;
-    __syncthreads();                                           // the previous tile's stencil reads are done (and the constants are in LDS)
-    irt_stage_dy<S>(p, s_dy, s_dc, n, chunk, r0, c0, lane, wave);
-    // operands of this wave's two pixel blocks (global loads: in flight across the barrier)
-    uintx4 xop[2][NKS][3], xT[2][2][3];
-    bool bok[2];
-    float sxl = 0.f;
+    const int r0 = (tt / p.tiles_x) * 4, c0 = (tt % p.tiles_x) * 32;
+    __syncthreads();                                          // the previous tile's reads of s_dy are done (first pass: the tables are written)
+    // ---------------- stage dy_d of every chunk of the group (8 loads per batch in flight, then the prologue and the LDS stores)
+    {
+      const int oy = (r0 >> 1) + sry, ox = (c0 >> 1) + srx;
+      const bool inb = slane && oy < p.Ho && ox < p.Wo;
+      const size_t pos = inb ? (size_t)oy * p.Wo + ox : 0;
+      const float* gsrc = p.dy.x + ((size_t)n * Hd + ch0 * 32) * HWo + pos;
+      const float* ysrc = bnb ? p.dy.aux + ((size_t)n * Hd + ch0 * 32) * HWo + pos : gsrc;
+      const int hrem = Hd - ch0 * 32;                         // channels of the group that exist
+      // every load of the tile in flight before the first is used (one memory round trip; 3 batches of 8 measured 14 us per tile)
+      float gv[IRT_CG * 8], yv[IRT_CG * 8];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int b = wave * 2 + t;
-      const int pr = r0 + 4 * (b >> 2), pc0 = c0 + 8 * (b & 3);
-      bok[t] = pr < H && pc0 < W;                              // H % 4 == 0, W % 8 == 0: a block is inside or outside as a whole
+      for (int k = 0; k < IRT_CG * 8; ++k) {
+        const int cl = wave + 4 * k;
+        const size_t o = (size_t)((k < nst && cl < hrem) ? cl : 0) * HWo;
+        gv[k] = gsrc[o];
+        yv[k] = ysrc[o];
+      }
+#pragma unroll
+      for (int k = 0; k < IRT_CG * 8; ++k) {
+        const int cl = wave + 4 * k;
+        float v = gv[k];
+        if (bnb) {
+          const float4 dc = *reinterpret_cast<const float4*>(s_dc + cl * 8);
+          v = sc_pro_bnbwd(gv[k], yv[k], dc.x, dc.y, dc.z, dc.w, s_dc[cl * 8 + 4], dlo, dhi);
+        }
+        if (slane && k < nst) s_dy[cl * IRT_RSZ + lane] = (inb && cl < hrem) ? v : 0.f;
+      }
+    }
+    // ---------------- operands of this wave's pixel block
+    const int pr = r0, pc0 = c0 + 8 * bc;
+    const bool bok = pr < H && pc0 < W;                       // H % 4 == 0, W % 8 == 0: inside or outside as a whole
+    uintx4 xop[NKS][3], xT[2][3];
+    {
       const int y = pr + (l31 >> 3), x = pc0 + (l31 & 7);
-      irt_xop<NKS>(p, s_xc, p.x.x + (size_t)n * Cin * HW + (bok[t] ? (size_t)y * W + x : 0), bok[t], lhi, lo, hi, HW, xop[t]);
-      // x^T: lane -> input channel l31, k-slots (step s) = pixels (row 2s + j/4, column 4*lhi + j%4) of the block
+      irt_xop<NKS>(p, s_xc, p.x.x + (size_t)n * Cin * HW + (bok ? (size_t)y * W + x : 0), bok, lhi, lo, hi, HW, xop);
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int sstep = 0; sstep < 2; ++sstep) {
         float v[8];
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
-          const size_t o = ((size_t)n * Cin + cic) * HW + (bok[t] ? (size_t)(pr + 2 * s + rr) * W + pc0 + 4 * lhi : 0);
+          const float4 q4 = *reinterpret_cast<const float4*>(p.x.x + ((size_t)n * Cin + cic) * HW +
+                                                             (bok ? (size_t)(pr + 2 * sstep + rr) * W + pc0 + 4 * lhi : 0));
+          const float qv[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float tv = sc_pro_affine(p.x.x[o + q], xsc, xsh, lo, hi);
-            v[4 * rr + q] = (bok[t] && ciok) ? tv : 0.f;
+            const float tv = sc_pro_affine(qv[q], xsc, xsh, lo, hi);
+            v[4 * rr + q] = (bok && ciok) ? tv : 0.f;
           }
         }
-        if (chunk == 0) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) sxl += v[j];
-        }
-        split8(v, xT[t][s]);
+        split8(v, xT[sstep]);
       }
     }
-    sx += sxl;
     __syncthreads();
+    floatx16 accdx = zero16();
+    if (bok) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      if (!bok[t]) continue;                                   // wave-uniform
-      const int b = wave * 2 + t;
-      floatx16 acc = zero16();
+      for (int cq = 0; cq < IRT_CG; ++cq) {
+        if (cq < ncg) {
+          // an opaque zero in every table index: these LDS reads are invariant over the tile loop, and hoisted out of it they pin
+          // ~50 registers per chunk for the whole kernel -- they must be re-read where they are used
+          int z = 0;
+          asm volatile("" : "+v"(z));
+          floatx16 acc = zero16();
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) acc = mfma6(xop[t][ks], wop[ks], acc);        // e[pixel (i/4, 4*lhi + i%4) of the block][channel l31]
-      // dy_d values the patch touches
-      float L[LP][LP];
-      {
-        const float* base = s_dy + l31 * PITCH + (S == 1 ? (4 * (b >> 2)) * RW + 8 * (b & 3) + 4 * lhi
-                                                          : (2 * (b >> 2)) * RW + 4 * (b & 3) + 2 * lhi);
+          for (int ks = 0; ks < NKS; ++ks) {
+            uintx4 w[3];
 #pragma unroll
-        for (int a = 0; a < LP; ++a)
+            for (int t = 0; t < 3; ++t) w[t] = g_w[((cq * NKS + ks) * 3 + t) * 64 + z];
+            acc = mfma6(xop[ks], w, acc);                     // e[pixel (i/4, 4 lhi + i%4) of the block][channel l31]
+          }
+          const float4* kq = reinterpret_cast<const float4*>(s_k + (cq * 32 + l31) * 16 + z);
+          const float4 ce = kq[0];                            // scale, shift, mean, invstd
+          float wk[9];
+          {
+            const float4 a = kq[1], b = kq[2]; const float c = s_k[(cq * 32 + l31) * 16 + 12 + z];
+            wk[0] = a.x; wk[1] = a.y; wk[2] = a.z; wk[3] = a.w; wk[4] = b.x; wk[5] = b.y; wk[6] = b.z; wk[7] = b.w; wk[8] = c;
+          }
+          float Lr[3][3];
+          {
+            const float* base = s_dy + (cq * 32 + l31) * IRT_RSZ + 4 * bc + 2 * lhi + z;
 #pragma unroll
-          for (int q = 0; q < LP; ++q) L[a][q] = base[a * RW + q];
-      }
-      float gq[16];
+            for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+              for (int q = 0; q < 3; ++q) Lr[a][q] = base[a * IRT_RW + q];
+          }
+          float gq[16], dwd[9];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const float e = acc[4 * u + v];
-          const float yh = fmaf(e, ce.x, ce.y);
-          const bool pass = yh > 0.f && yh < 6.f;
-          const float eh = fminf(fmaxf(yh, 0.f), 6.f);
-          const float xn = (e - ce.z) * ce.w;
-          float g = 0.f;
+          for (int k = 0; k < 9; ++k) dwd[k] = 0.f;
+          float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-          for (int ky = 0; ky < 3; ++ky)
+          for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-              // output pixel o = (i + 1 - k) / S  (stride 2: only taps with i + 1 - k even); patch-local index into L
-              if (S == 1) {
-                const float d = L[u + 2 - ky][v + 2 - kx];
-                g = fmaf(wk[ky * 3 + kx], d, g);
-                dwd[ky * 3 + kx] = fmaf(eh, d, dwd[ky * 3 + kx]);
-              } else if (((u + 1 - ky) & 1) == 0 && ((v + 1 - kx) & 1) == 0) {
-                const float d = L[(u + 1 - ky) / 2][(v + 1 - kx) / 2];
-                g = fmaf(wk[ky * 3 + kx], d, g);
-                dwd[ky * 3 + kx] = fmaf(eh, d, dwd[ky * 3 + kx]);
-              }
+            for (int v = 0; v < 4; ++v) {
+              const float e = acc[4 * u + v];
+              const float yh = fmaf(e, ce.x, ce.y);
+              const bool pass = yh > 0.f && yh < 6.f;
+              const float eh = fminf(fmaxf(yh, 0.f), 6.f);
+              const float xn = (e - ce.z) * ce.w;
+              float g = 0.f;
+#pragma unroll
+              for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                  if (((u + 1 - ky) & 1) == 0 && ((v + 1 - kx) & 1) == 0) {      // output pixel (i + 1 - k) / 2 exists for this tap
+                    const float d = Lr[(u + 1 - ky) / 2][(v + 1 - kx) / 2];
+                    g = fmaf(wk[ky * 3 + kx], d, g);
+                    dwd[ky * 3 + kx] = fmaf(eh, d, dwd[ky * 3 + kx]);
+                  }
+              const float gm = pass ? g : 0.f;
+              t1 += gm;
+              t2 = fmaf(gm, xn, t2);
+              gq[4 * u + v] = gm;
+              myT[(8 * u + 4 * lhi + v) * 36 + l31] = gm * ce.x;          // scale (.) g'  ->  T[pixel][channel]
             }
-          const float gm = pass ? g : 0.f;
-          s1 += gm;
-          s2 = fmaf(gm, xn, s2);
-          gq[4 * u + v] = gm;
+          // per-channel scalars of this block: both half-waves hold the same channel -> add the halves, lane < 32 accumulates into
+          // the wave's own LDS row (no other wave touches it: deterministic order)
+          {
+            float* arow = myacc + (cq * 32 + l31) * 12;
+            t1 += __shfl_xor(t1, 32, 64);
+            t2 += __shfl_xor(t2, 32, 64);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) dwd[k] += __shfl_xor(dwd[k], 32, 64);
+            if (lhi == 0) {
+              float4 a0 = *reinterpret_cast<float4*>(arow), a1 = *reinterpret_cast<float4*>(arow + 4), a2 = *reinterpret_cast<float4*>(arow + 8);
+              a0.x += t1; a0.y += t2; a0.z += dwd[0]; a0.w += dwd[1];
+              a1.x += dwd[2]; a1.y += dwd[3]; a1.z += dwd[4]; a1.w += dwd[5];
+              a2.x += dwd[6]; a2.y += dwd[7]; a2.z += dwd[8];
+              *reinterpret_cast<float4*>(arow) = a0; *reinterpret_cast<float4*>(arow + 4) = a1; *reinterpret_cast<float4*>(arow + 8) = a2;
+            }
+          }
+          // G[h][ci] += sum over the block's pixels of g'[h][px] x[ci][px]   (A = g': rows = channels, k = pixels), and
+          // dx[ci][px] += sum_h W_e[h][ci] (scale g')[h][px]: the transposed tile as the B operand (lane = pixel, k = channels);
+          // the two contractions accumulate into different registers and are issued alternately
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int sstep = 0; sstep < 2; ++sstep) {
+            float v8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v8[j] = gq[8 * sstep + j];
+            uintx4 ga[3];
+            split8(v8, ga);
+            const float4 a = *reinterpret_cast<const float4*>(myT + l31 * 36 + 16 * sstep + 8 * lhi);
+            const float4 b = *reinterpret_cast<const float4*>(myT + l31 * 36 + 16 * sstep + 8 * lhi + 4);
+            const float t8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            uintx4 gb[3], wt[3];
+            split8(t8, gb);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) wt[t] = g_wT[((cq * 2 + sstep) * 3 + t) * 64 + z];
+            mfma6x2(ga, xT[sstep], accG[cq], wt, gb, accdx);   // dx[ci 8 (i/4) + 4 lhi + i%4][pixel l31 of the block]
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
         }
-      // G[h][ci] += sum over the block's 32 pixels of g'_e[h][px] x[ci][px]   (A = g'_e: rows = channels, k = pixels)
+      }
+      // ---------------- this group's dx partial of the block: lane = pixel (row l31 / 8, column l31 % 8)
+      float* dst = p.dx + (size_t)blockIdx.y * p.N * Cin * HW + (size_t)n * Cin * HW + (size_t)(pr + (l31 >> 3)) * W + pc0 + (l31 & 7);
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        float v8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v8[j] = gq[8 * s + j];
-        uintx4 ga[3];
-        split8(v8, ga);
-        accG = mfma6(ga, xT[t][s], accG);
-        if (chunk == 0) accM = mfma6(xT[t][s], xT[t][s], accM);
+      for (int i = 0; i < 16; ++i) {
+        const int ci = 8 * (i >> 2) + 4 * lhi + (i & 3);
+        if (ci < Cin) dst[(size_t)ci * HW] = accdx[i];
       }
     }
   }
-  // ---------------- epilogue: the work-group's partial row
+  // ---------------- epilogue: the work-group's partial rows
   __syncthreads();
-  {
-    // per-channel scalars: halves, then waves (fixed order)
-    float v[12];
-    v[0] = s1; v[1] = s2;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) v[2 + k] = dwd[k];
-    v[11] = 0.f;
-#pragma unroll
-    for (int k = 0; k < 11; ++k) v[k] += __shfl_xor(v[k], 32, 64);
-    if (lhi == 0) {
-#pragma unroll
-      for (int k = 0; k < 11; ++k) s_red[(wave * 32 + l31) * 12 + k] = v[k];
-    }
-  }
-  __syncthreads();
-  if (tid < 32 && chunk * 32 + tid < Hd) {
+  if (tid < ncg * 32 && ch0 * 32 + tid < Hd) {
     float v[11];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) v[k] = ((s_red[tid * 12 + k] + s_red[(32 + tid) * 12 + k]) + s_red[(64 + tid) * 12 + k]) + s_red[(96 + tid) * 12 + k];
-    const int hh = chunk * 32 + tid;
+    for (int k = 0; k < 11; ++k)
+      v[k] = ((s_acc[tid * 12 + k] + s_acc[(IRT_CG * 32 + tid) * 12 + k]) + s_acc[(2 * IRT_CG * 32 + tid) * 12 + k]) + s_acc[(3 * IRT_CG * 32 + tid) * 12 + k];
+    const int hh = ch0 * 32 + tid;
     p.esums[((size_t)blockIdx.x * Hd + hh) * 2] = (double)v[0];
     p.esums[((size_t)blockIdx.x * Hd + hh) * 2 + 1] = (double)v[1];
 #pragma unroll
     for (int k = 0; k < 9; ++k) atomicAdd(p.dwacc + (size_t)hh * 9 + k, (double)v[2 + k]);
   }
-  __syncthreads();
-  // G: waves 1..3 -> LDS, wave 0 adds them in order
-  if (wave > 0) {
+  float* s_red = s_T;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s_red[((wave - 1) * 16 + r) * 64 + lane] = accG[r];
-  }
-  __syncthreads();
-  if (wave == 0) {
-    float* part = p.gpart + ((size_t)blockIdx.x * p.nch + chunk) * 32 * 32;
+  for (int cq = 0; cq < IRT_CG; ++cq) {
+    if (cq < ncg) {
+      __syncthreads();
+      if (wave > 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float v = ((accG[r] + s_red[r * 64 + lane]) + s_red[(16 + r) * 64 + lane]) + s_red[(32 + r) * 64 + lane];
-      part[(8 * (r >> 2) + 4 * lhi + (r & 3)) * 32 + l31] = v;
-    }
-  }
-  if (chunk == 0) {
-    __syncthreads();
-    if (wave > 0) {
+        for (int r = 0; r < 16; ++r) s_red[((wave - 1) * 16 + r) * 64 + lane] = accG[cq][r];
+      }
+      __syncthreads();
+      if (wave == 0) {
+        float* part = p.gpart + ((size_t)blockIdx.x * p.nch + ch0 + cq) * 32 * 32;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s_red[((wave - 1) * 16 + r) * 64 + lane] = accM[r];
-    }
-    __syncthreads();
-    float* mp = p.mpart + (size_t)blockIdx.x * 33 * 32;
-    if (wave == 0) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = ((accM[r] + s_red[r * 64 + lane]) + s_red[(16 + r) * 64 + lane]) + s_red[(32 + r) * 64 + lane];
-        mp[(8 * (r >> 2) + 4 * lhi + (r & 3)) * 32 + l31] = v;
+        for (int r = 0; r < 16; ++r) {
+          const float v = ((accG[cq][r] + s_red[r * 64 + lane]) + s_red[(16 + r) * 64 + lane]) + s_red[(32 + r) * 64 + lane];
+          part[(8 * (r >> 2) + 4 * lhi + (r & 3)) * 32 + l31] = v;
+        }
       }
     }
-    __syncthreads();
-    const float sh2 = sx + __shfl_xor(sx, 32, 64);
-    if (lhi == 0) s_red[wave * 32 + l31] = sh2;
-    __syncthreads();
-    if (tid < 32) mp[32 * 32 + tid] = ((s_red[tid] + s_red[32 + tid]) + s_red[64 + tid]) + s_red[96 + tid];
   }
 }
 
 // =================================================================================================================================
-// (Bii) backward data.  One work-group = one tile of 8 x 32 e pixels; a wave owns two image rows of 32 pixels (orientation 2:
-// lane = pixel, registers = 16 hidden channels); dx accumulates over the chunks in registers.
-template <int NKS, int S>
-__global__ __launch_bounds__(256) void k_irt_bdata(const IrtP p) {
-  using B = IrtBwdGeo<S>;
-  constexpr int RW = B::RW, PITCH = B::PITCH;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* s_dy = reinterpret_cast<float*>(smem);              // [32][PITCH]
-  float* s_dc = s_dy + 32 * PITCH;                           // [32][8]
-  float* s_xc = s_dc + 256;                                  // [32][2]
-  float* s_k = s_xc + 64;                                    // [2][5][16]: scale, shift, A, B, D by (lhi, accumulator register)
-  float* s_wd = s_k + 160;                                   // [2][9][16]
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// the split filter operands of k_irt_bwd, once per launch: block = chunk; waves 0..NKS-1: e operands (lane -> hidden channel, k =
+// input channels), waves NKS..NKS+1: dx operands (lane -> input channel, k-slots of step s = hidden channels 16 s + 8 lhi + j)
+template <int NKS>
+__global__ __launch_bounds__(256) void k_irt_pack(const IrtP p, uintx4* __restrict__ wpk) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int chunk = blockIdx.x;
+  if (wave == 0) {
+    uintx4 op[NKS][3];
+    irt_wop<NKS>(p, chunk * 32 + l31, lhi, op);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) wpk[((size_t)(chunk * NKS + ks) * 3 + t) * 64 + lane] = op[ks][t];
+  } else if (wave <= 2) {
+    const int sstep = wave - 1;
+    const bool ciok = l31 < p.Cin;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int hh = chunk * 32 + 16 * sstep + 8 * lhi + j;
+      const float t = p.we[(size_t)(hh < p.Hd ? hh : p.Hd - 1) * p.Cin + (ciok ? l31 : 0)];
+      v[j] = (hh < p.Hd && ciok) ? t : 0.f;
+    }
+    uintx4 op[3];
+    split8(v, op);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) wpk[(size_t)p.nch * NKS * 3 * 64 + ((size_t)(chunk * 2 + sstep) * 3 + t) * 64 + lane] = op[t];
+  }
+}
+
+// =================================================================================================================================
+// second moments of the block input: M[ci][ci'] = sum_px x[ci][px] x[ci'][px], s[ci] = sum_px x[ci][px]  (for dW_e, off the critical
+// path).  K = pixels: lane -> channel l31, k-slots = 8 consecutive pixels (H*W % 8 == 0); wave-strided 16-pixel steps.
+__global__ __launch_bounds__(256) void k_irt_xmom(const IrtP p) {
+  extern __shared__ __attribute__((aligned(16))) float s_mr[];      // [3][16][64] + [4][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int H = p.H, W = p.W, Hd = p.Hd, Cin = p.Cin;
-  const size_t HW = (size_t)H * W;
-  const int tile = blockIdx.x;
-  const int n = tile / (p.tiles_x * p.tiles_y), tt = tile - n * p.tiles_x * p.tiles_y;
-  const int r0 = (tt / p.tiles_x) * 8, c0 = (tt % p.tiles_x) * 32;
+  const int Cin = p.Cin;
+  const size_t HW = (size_t)p.H * p.W;
+  const long NP = (long)p.N * (long)HW;
+  const long ksteps = (NP + 15) / 16;
+  const bool ciok = l31 < Cin;
+  const int cic = ciok ? l31 : Cin - 1;
+  const float xsc = p.x.cst[(size_t)cic * SC_CST], xsh = p.x.cst[(size_t)cic * SC_CST + 1];
+  const float lo = sc_act_lo(p.x.act), hi = sc_act_hi(p.x.act);
+  floatx16 accM = zero16();
+  float sx = 0.f;
+  const long per = (ksteps + gridDim.x - 1) / gridDim.x;
+  const long k_begin = (long)blockIdx.x * per, k_end = min(k_begin + per, ksteps);
+  for (long kq = k_begin + wave; kq < k_end; kq += 4) {
+    const long g0 = (kq * 2 + lhi) * 8;
+    const bool ok = g0 < NP;
+    const long gc = ok ? g0 : 0;
+    const int n = (int)(gc / (long)HW);
+    const size_t px = (size_t)(gc - (long)n * (long)HW);
+    const float* src = p.x.x + ((size_t)n * Cin + cic) * HW + px;
+    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+    const float x8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float t = sc_pro_affine(x8[j], xsc, xsh, lo, hi); v[j] = (ok && ciok) ? t : 0.f; sx += v[j]; }
+    uintx4 op[3];
+    split8(v, op);
+    accM = mfma6(op, op, accM);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_mr[((wave - 1) * 16 + r) * 64 + lane] = accM[r];
+  }
+  const float sh2 = sx + __shfl_xor(sx, 32, 64);
+  if (lhi == 0) s_mr[3 * 16 * 64 + wave * 32 + l31] = sh2;
+  __syncthreads();
+  float* mp = p.mpart + (size_t)blockIdx.x * 33 * 32;
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = ((accM[r] + s_mr[r * 64 + lane]) + s_mr[(16 + r) * 64 + lane]) + s_mr[(32 + r) * 64 + lane];
+      mp[(8 * (r >> 2) + 4 * lhi + (r & 3)) * 32 + l31] = v;
+    }
+  }
+  if (tid < 32) {
+    const float* q = s_mr + 3 * 16 * 64;
+    mp[32 * 32 + tid] = ((q[tid] + q[32 + tid]) + q[64 + tid]) + q[96 + tid];
+  }
+}
+
+// Q = W_e^T diag(B) W_e (row-major [ci'][ci], 32 x Cin), r = W_e^T D: block = ci', thread = (ci, slice of the hidden channels)
+__global__ __launch_bounds__(256) void k_irt_qr(const float* __restrict__ we, const float* __restrict__ cstb, int Hd, int Cin, float* __restrict__ qr) {
+  __shared__ double s_q[256], s_r[8];
+  const int a = blockIdx.x, b = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  double q = 0.0, r = 0.0;
+  if (b < Cin) {
+    for (int h = sl; h < Hd; h += 8) {
+      const double wa = we[(size_t)h * Cin + a];
+      q += wa * (double)cstb[(size_t)h * SC_CST + 3] * (double)we[(size_t)h * Cin + b];
+      if (b == 0) r += wa * (double)cstb[(size_t)h * SC_CST + 4];
+    }
+  }
+  s_q[threadIdx.x] = q;
+  if (b == 0) s_r[sl] = r;
+  __syncthreads();
+  if (threadIdx.x < 32 && b < Cin) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += s_q[k * 32 + b];
+    qr[a * Cin + b] = (float)t;                                // laid out as a [Cin][Cin] filter for irt_wop
+    if (b == 0) {
+      double u = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) u += s_r[k];
+      qr[32 * 32 + a] = (float)u;
+    }
+  }
+}
+
+// fix-up: dx = sum of the chunk groups' partials + Q x + r (+ add0) (+ dx): flat 32-pixel blocks, pixels on the accumulator rows
+template <int NKS>
+__global__ __launch_bounds__(256) void k_irt_fix(const IrtP p, const float* __restrict__ dxp, int ngroups, const float* __restrict__ qr) {
+  __shared__ float s_xc[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int Cin = p.Cin;
+  const size_t HW = (size_t)p.H * p.W;
+  const long NP = (long)p.N * (long)HW;
   irt_xconsts(p, s_xc);
   __syncthreads();
   const float lo = sc_act_lo(p.x.act), hi = sc_act_hi(p.x.act);
-  const int ix = c0 + l31;
-  uintx4 xop[2][NKS][3];
-  bool pok[2];
+  IrtP q = p;
+  q.we = qr; q.Hd = Cin;                                     // the Q matrix as a Cin -> Cin pointwise filter
+  uintx4 qop[NKS][3];
+  irt_wop<NKS>(q, l31, lhi, qop);
+  const float rr = l31 < Cin ? qr[32 * 32 + l31] : 0.f;
+  const size_t gstride = (size_t)p.N * Cin * HW;
+  for (int pb = blockIdx.x * 4 + wave; pb < p.npb; pb += gridDim.x * 4) {
+    const long gp = (long)pb * 32 + l31;
+    const bool ok = gp < NP;
+    const long gpc = ok ? gp : 0;
+    const int n = (int)(gpc / (long)HW);
+    uintx4 xop[NKS][3];
+    irt_xop<NKS>(p, s_xc, p.x.x + (size_t)n * Cin * HW + (size_t)(gpc - (long)n * (long)HW), ok, lhi, lo, hi, HW, xop);
+    floatx16 acc = zero16();
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int iy = r0 + 2 * wave + t;
-    pok[t] = iy < H && ix < W;
-    irt_xop<NKS>(p, s_xc, p.x.x + (size_t)n * Cin * HW + (pok[t] ? (size_t)iy * W + ix : 0), pok[t], lhi, lo, hi, HW, xop[t]);
-  }
-  floatx16 accdx[2] = {zero16(), zero16()};
-  const bool ciok = l31 < Cin;
-
-  for (int chunk = 0; chunk < p.nch; ++chunk) {
-    __syncthreads();                                           // the previous chunk's reads of s_dy / s_k / s_wd are done
-    irt_dy_consts(p, s_dc, chunk);
-    if (tid < 32) {
-      // constants / depthwise taps by (lhi, register): hidden = chunk*32 + 8*(i/4) + 4*lhi + (i%4)
-      const int lh = tid >> 4, i = tid & 15;
-      const int hh = chunk * 32 + 8 * (i >> 2) + 4 * lh + (i & 3);
-      const bool ok = hh < Hd;
-      const int hc = ok ? hh : Hd - 1;
-      s_k[(lh * 5 + 0) * 16 + i] = ok ? p.cst_e[(size_t)hc * SC_CST] : 0.f;
-      s_k[(lh * 5 + 1) * 16 + i] = ok ? p.cst_e[(size_t)hc * SC_CST + 1] : 0.f;
-      s_k[(lh * 5 + 2) * 16 + i] = ok ? p.cstb_e[(size_t)hc * SC_CST + 2] : 0.f;
-      s_k[(lh * 5 + 3) * 16 + i] = ok ? p.cstb_e[(size_t)hc * SC_CST + 3] : 0.f;
-      s_k[(lh * 5 + 4) * 16 + i] = ok ? p.cstb_e[(size_t)hc * SC_CST + 4] : 0.f;
+    for (int ks = 0; ks < NKS; ++ks) acc = mfma6(xop[ks], qop[ks], acc);      // (Q x)[pixel 8 (i/4) + 4 lhi + i%4][ci' = l31]
+    if (l31 < Cin) {
 #pragma unroll
-      for (int k = 0; k < 9; ++k) s_wd[(lh * 9 + k) * 16 + i] = ok ? p.wd[(size_t)hc * 9 + k] : 0.f;
-    }
-    __syncthreads();                                           // s_dc ready for the staging
-    irt_stage_dy<S>(p, s_dy, s_dc, n, chunk, r0, c0, lane, wave);
-    // filter operands of this chunk: rows of W_e (for e) and the permuted rows of W_e^T (for dx)
-    uintx4 wop[NKS][3], wT[2][3];
-    irt_wop<NKS>(p, chunk * 32 + l31, lhi, wop);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int hh = chunk * 32 + 16 * s + 8 * (j >> 2) + 4 * lhi + (j & 3);
-        const float t = p.we[(size_t)(hh < Hd ? hh : Hd - 1) * Cin + (ciok ? l31 : 0)];
-        v[j] = (hh < Hd && ciok) ? t : 0.f;
-      }
-      split8(v, wT[s]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int iyl = 2 * wave + t;                            // row of the tile (wave-uniform)
-      floatx16 acc = zero16();
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) acc = mfma6(wop[ks], xop[t][ks], acc);        // e[channel 8*(i/4) + 4*lhi + (i%4)][pixel l31]
-      float g[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) g[i] = 0.f;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        int rowl;                                              // row of the staged region
-        if (S == 1) rowl = iyl + 2 - ky;
-        else {
-          if (((iyl + 1 - ky) & 1) != 0) continue;             // wave-uniform
-          rowl = (iyl + 1 - ky) >> 1;
+      for (int j = 0; j < 4; ++j) {
+        const long g = (long)pb * 32 + 8 * j + 4 * lhi;       // H*W % 4 == 0: four consecutive pixels of one image
+        if (g >= NP) continue;
+        const int n_ = (int)(g / (long)HW);
+        const size_t idx = ((size_t)n_ * Cin + l31) * HW + (size_t)(g - (long)n_ * (long)HW);
+        float4 o = make_float4(acc[4 * j] + rr, acc[4 * j + 1] + rr, acc[4 * j + 2] + rr, acc[4 * j + 3] + rr);
+        for (int gr = 0; gr < ngroups; ++gr) {
+          const float4 t = *reinterpret_cast<const float4*>(dxp + (size_t)gr * gstride + idx);
+          o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
         }
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          int coll; bool cv = true;
-          if (S == 1) coll = l31 + 2 - kx;
-          else { const int q = l31 + 1 - kx; cv = (q & 1) == 0 && q >= 0; coll = cv ? (q >> 1) : 0; }
-          const float* src = s_dy + rowl * RW + coll;
-          const float4* wq = reinterpret_cast<const float4*>(s_wd + (lhi * 9 + ky * 3 + kx) * 16);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float4 w4 = wq[j];
-            const float* ww = reinterpret_cast<const float*>(&w4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int i = 4 * j + q;
-              const float d = src[(8 * (i >> 2) + 4 * lhi + (i & 3)) * PITCH];
-              g[i] = fmaf(ww[q], (S == 1 || cv) ? d : 0.f, g[i]);
-            }
-          }
-        }
-      }
-      // dy_e = A g' + B e + D, straight into the B operand of dx = W_e^T dy_e
-      float dye[16];
-      {
-        const float4* kq = reinterpret_cast<const float4*>(s_k + lhi * 5 * 16);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 ksc = kq[j], ksh = kq[4 + j], kA = kq[8 + j], kB = kq[12 + j], kD = kq[16 + j];
-          const float* a0 = reinterpret_cast<const float*>(&ksc); const float* a1 = reinterpret_cast<const float*>(&ksh);
-          const float* a2 = reinterpret_cast<const float*>(&kA); const float* a3 = reinterpret_cast<const float*>(&kB);
-          const float* a4 = reinterpret_cast<const float*>(&kD);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int i = 4 * j + q;
-            const float e = acc[i];
-            const float yh = fmaf(e, a0[q], a1[q]);
-            const float gm = (yh > 0.f && yh < 6.f) ? g[i] : 0.f;
-            dye[i] = fmaf(gm, a2[q], fmaf(e, a3[q], a4[q]));
-          }
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        float v8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v8[j] = dye[8 * s + j];
-        uintx4 db[3];
-        split8(v8, db);
-        accdx[t] = mfma6(wT[s], db, accdx[t]);                  // dx[ci 8*(i/4) + 4*lhi + (i%4)][pixel l31]
-      }
-    }
-  }
-  // ---------------- store
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    if (!pok[t]) continue;
-    const int iy = r0 + 2 * wave + t;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int ci = 8 * (i >> 2) + 4 * lhi + (i & 3);
-      if (ci < Cin) {
-        const size_t idx = ((size_t)n * Cin + ci) * HW + (size_t)iy * W + ix;
-        float o = accdx[t][i];
-        if (p.add0) o += p.add0[idx];
-        if (p.accum) o += p.dx[idx];
-        p.dx[idx] = o;
+        if (p.add0) { const float4 t = *reinterpret_cast<const float4*>(p.add0 + idx); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+        if (p.accum) { const float4 t = *reinterpret_cast<const float4*>(p.dx + idx); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+        *reinterpret_cast<float4*>(p.dx + idx) = o;
       }
     }
   }
@@ -799,8 +863,9 @@ __global__ __launch_bounds__(256) void k_irt_dwe(const float* __restrict__ gpart
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------
 bool irt_ok(int Cin, int Hd, int H, int W, int S) {
-  return (S == 1 || S == 2) && Cin >= 8 && Cin <= 32 && Cin % 8 == 0 && Hd >= 8 && Hd <= 32 * IRT_MAXCH && H >= 4 && W >= 8 && H % 4 == 0 &&
-         W % 8 == 0 && (S == 1 || (H % 2 == 0 && W % 2 == 0));
+  // stride 2 only: there the expanded tensor is four times the depthwise output and its eight passes dominate the block; at stride 1
+  // the recomputation (tile halos, staging of an equally large d) measured slower than the separate kernels
+  return S == 2 && Cin >= 8 && Cin <= 32 && Cin % 8 == 0 && Hd >= 8 && Hd <= 32 * IRT_MAXCH && H >= 4 && W >= 8 && H % 4 == 0 && W % 8 == 0;
 }
 int irt_stat_wgs(long npb) { const long w = (npb + 3) / 4; return (int)(w < 512 ? w : 512); }
 int irt_fwd_tiles(int N, int H, int W, int S, int* tx, int* ty) {
@@ -809,15 +874,41 @@ int irt_fwd_tiles(int N, int H, int W, int S, int* tx, int* ty) {
   *tx = (Wo + TW - 1) / TW; *ty = (Ho + TH - 1) / TH;
   return N * *tx * *ty;
 }
-int irt_bwd_tiles(int N, int H, int W, int* tx, int* ty) {
-  *tx = (W + 31) / 32; *ty = (H + 7) / 8;
+int irt_bwd_tiles(int N, int H, int W, int* tx, int* ty) {        // tiles of 4 x 32 e pixels
+  *tx = (W + 31) / 32; *ty = (H + 3) / 4;
   return N * *tx * *ty;
 }
-int irt_bsum_per_wg(int ntiles, int nch) {
-  // about two work-groups per CU over both grid dimensions, at least 2 tiles each
-  int want = (512 + nch - 1) / nch;
-  int per = (ntiles + want - 1) / want;
-  return per < 2 ? 2 : per;
+// rows (= work-groups along x) of the backward sweep: two 256-thread work-groups per CU over both grid dimensions
+int irt_bwd_rows(int N, int hidden, int H, int W, int* per_out) {
+  int tx, ty;
+  const int nt = irt_bwd_tiles(N, H, W, &tx, &ty);
+  const int ngroups = ((hidden + 31) / 32 + IRT_CG - 1) / IRT_CG;
+  int want = 512 / ngroups;
+  if (want < 1) want = 1;
+  int per = (nt + want - 1) / want;
+  if (per < 1) per = 1;
+  if (per_out) *per_out = per;
+  return (nt + per - 1) / per;
+}
+int irt_mom_wgs(long NP) { const long k = (NP + 15) / 16; const long w = (k + 15) / 16; return (int)(w < 256 ? (w < 1 ? 1 : w) : 256); }
+
+struct IrtWork { float* gpart; float* mpart; double* mfin; float* qr; float* wpk; float* dxp; size_t total; };
+IrtWork irt_work(float* work, int N, int Cin, int hidden, int H, int W) {
+  IrtWork w;
+  const size_t rows = (size_t)irt_bwd_rows(N, hidden, H, W, nullptr), nch = (size_t)(hidden + 31) / 32;
+  const size_t ngroups = (nch + IRT_CG - 1) / IRT_CG;
+  const size_t mrows = (size_t)irt_mom_wgs((long)N * H * W);
+  size_t o = 0;
+  w.gpart = work + o; o += rows * nch * 32 * 32;
+  w.mpart = work + o; o += mrows * 33 * 32;
+  o = (o + 1) & ~(size_t)1;                                    // fp64 scratch: 8-byte aligned (work itself is 16-byte aligned)
+  w.mfin = reinterpret_cast<double*>(work + o); o += 2 * 33 * 32;
+  w.qr = work + o; o += 33 * 32;
+  o = (o + 3) & ~(size_t)3;
+  w.wpk = work + o; o += nch * 4 * 3 * 64 * 4;                 // [nch][NKS <= 2][3][64] + [nch][2][3][64] 16-byte entries
+  w.dxp = work + o; o += ngroups * (size_t)N * Cin * H * W;
+  w.total = o;
+  return w;
 }
 
 int irt_fill(IrtP& p, const sc_irt_args* a, const char* who) {
@@ -835,7 +926,7 @@ int irt_fill(IrtP& p, const sc_irt_args* a, const char* who) {
   p.we = a->w_expand; p.wd = a->w_dw; p.cst_e = a->cst_expand; p.cstb_e = nullptr;
   p.dy = empty_srcd();
   p.stats = nullptr; p.dout = nullptr; p.esums = nullptr; p.dwacc = nullptr; p.gpart = nullptr; p.mpart = nullptr;
-  p.dx = nullptr; p.add0 = nullptr; p.accum = 0;
+  p.dx = nullptr; p.add0 = nullptr; p.accum = 0; p.wpk = nullptr;
   p.N = a->N; p.Cin = a->Cin; p.Hd = a->hidden; p.H = a->H; p.W = a->W; p.S = a->stride;
   p.Ho = (a->H - 1) / a->stride + 1; p.Wo = (a->W - 1) / a->stride + 1;
   p.nch = (a->hidden + 31) / 32;
@@ -843,12 +934,6 @@ int irt_fill(IrtP& p, const sc_irt_args* a, const char* who) {
   const long NP = (long)a->N * a->H * a->W;
   SC_REQUIRE(NP * a->hidden < (1L << 31), "%s: tensor too large for 32-bit element counts", who);
   p.npb = (int)((NP + 31) / 32);
-  return SC_OK;
-}
-int irt_dy(IrtP& p, const sc_src* dy, const char* who) {
-  SC_REQUIRE(dy && dy->x && dy->C == p.Hd && dy->up == 0, "%s: dy must be a source of `hidden` channels at the depthwise output's size", who);
-  SC_REQUIRE(dy->mode == SC_SRC_RAW || (dy->mode == SC_SRC_BNBWD && dy->aux && dy->cst), "%s: dy must be a RAW or BNBWD source", who);
-  p.dy = to_srcd(*dy);
   return SC_OK;
 }
 template <typename K>
@@ -867,20 +952,10 @@ extern "C" int sc_irt_rows(int stage, int N, int H, int W, int stride) {
   if (stage == 1) return irt_fwd_tiles(N, H, W, stride, &tx, &ty);
   return -1;
 }
-// rows of stage 2 depend on the chunk count (the grid is tile sets x chunks)
-static int irt_bsum_rows(int N, int H, int W, int hidden, int* per_out) {
-  int tx, ty;
-  const int nt = irt_bwd_tiles(N, H, W, &tx, &ty);
-  const int per = irt_bsum_per_wg(nt, (hidden + 31) / 32);
-  if (per_out) *per_out = per;
-  return (nt + per - 1) / per;
-}
-extern "C" int sc_irt_bwd_rows(int N, int hidden, int H, int W) { return irt_bsum_rows(N, H, W, hidden, nullptr); }
+extern "C" int sc_irt_bwd_rows(int N, int hidden, int H, int W) { return irt_bwd_rows(N, hidden, H, W, nullptr); }
 
-extern "C" size_t sc_irt_bwd_workspace_floats(int N, int hidden, int H, int W) {
-  const size_t rows = (size_t)irt_bsum_rows(N, H, W, hidden, nullptr);
-  const size_t HdP = (size_t)((hidden + 31) / 32) * 32;
-  return rows * HdP * 32 + rows * 33 * 32 + 2 * 33 * 32 + 64;
+extern "C" size_t sc_irt_bwd_workspace_floats(int N, int Cin, int hidden, int H, int W) {
+  return irt_work(nullptr, N, Cin, hidden, H, W).total + 16;
 }
 
 extern "C" int sc_irt_expand_stats(const sc_irt_args* a, float* stats, sc_stream stream) {
@@ -906,70 +981,83 @@ extern "C" int sc_irt_fwd(const sc_irt_args* a, float* d_out, float* stats_d, sc
   p.ntiles = irt_fwd_tiles(p.N, p.H, p.W, p.S, &p.tiles_x, &p.tiles_y);
   const int nks = (p.Cin + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = (size_t)(32 * (p.S == 1 ? IrtFwdGeo<1>::EPAD : IrtFwdGeo<2>::EPAD) + 64) * 4;
-#define SC_IRT_F(NK, SS) { irt_lds_attr(&k_irt_fwd<NK, SS>, lds); hipLaunchKernelGGL((k_irt_fwd<NK, SS>), dim3(p.ntiles), dim3(256), lds, st, p); }
-  if (nks == 1) { if (p.S == 1) SC_IRT_F(1, 1) else SC_IRT_F(1, 2) }
-  else { if (p.S == 1) SC_IRT_F(2, 1) else SC_IRT_F(2, 2) }
-#undef SC_IRT_F
+  const size_t lds = (size_t)(32 * IrtFwdGeo<2>::EPAD + 64) * 4;
+  if (nks == 1) { irt_lds_attr(&k_irt_fwd<1, 2>, lds); hipLaunchKernelGGL((k_irt_fwd<1, 2>), dim3(p.ntiles), dim3(256), lds, st, p); }
+  else { irt_lds_attr(&k_irt_fwd<2, 2>, lds); hipLaunchKernelGGL((k_irt_fwd<2, 2>), dim3(p.ntiles), dim3(256), lds, st, p); }
   SC_LAUNCH_OK("sc_irt_fwd");
   return SC_OK;
 }
 
-extern "C" int sc_irt_bwd_sums(const sc_irt_args* a, const sc_src* dy_d, double* e_sums, double* dw_acc, float* work, sc_stream stream) {
+extern "C" int sc_irt_bwd(const sc_irt_args* a, const sc_src* dy_d, double* e_sums, double* dw_acc, float* work, sc_stream stream) {
   IrtP p;
-  if (int rc = irt_fill(p, a, "sc_irt_bwd_sums")) return rc;
-  if (int rc = irt_dy(p, dy_d, "sc_irt_bwd_sums")) return rc;
-  SC_REQUIRE(e_sums && dw_acc && work, "sc_irt_bwd_sums: null output");
+  if (int rc = irt_fill(p, a, "sc_irt_bwd")) return rc;
+  SC_REQUIRE(dy_d && dy_d->x && dy_d->C == p.Hd && dy_d->up == 0, "sc_irt_bwd: dy must be a source of `hidden` channels at the depthwise output's size");
+  SC_REQUIRE(dy_d->mode == SC_SRC_RAW || (dy_d->mode == SC_SRC_BNBWD && dy_d->aux && dy_d->cst), "sc_irt_bwd: dy must be a RAW or BNBWD source");
+  SC_REQUIRE(e_sums && dw_acc && work && ((uintptr_t)work & 15) == 0, "sc_irt_bwd: null / misaligned output");
+  p.dy = to_srcd(*dy_d);
   p.ntiles = irt_bwd_tiles(p.N, p.H, p.W, &p.tiles_x, &p.tiles_y);
-  const int rows = irt_bsum_rows(p.N, p.H, p.W, p.Hd, &p.tiles_per_wg);
-  p.esums = e_sums; p.dwacc = dw_acc;
-  p.gpart = work;
-  p.mpart = work + (size_t)rows * p.nch * 32 * 32;
+  const int rows = irt_bwd_rows(p.N, p.Hd, p.H, p.W, &p.tiles_per_wg);
+  const IrtWork w = irt_work(work, p.N, p.Cin, p.Hd, p.H, p.W);
+  p.esums = e_sums; p.dwacc = dw_acc; p.gpart = w.gpart; p.dx = w.dxp;
   const int nks = (p.Cin + 15) / 16;
+  const int ngroups = (p.nch + IRT_CG - 1) / IRT_CG;
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = (size_t)(32 * (p.S == 1 ? IrtBwdGeo<1>::PITCH : IrtBwdGeo<2>::PITCH) + 256 + 64 + 3 * 16 * 64) * 4;
-  const dim3 grid(rows, p.nch);
-#define SC_IRT_S(NK, SS) { irt_lds_attr(&k_irt_bsums<NK, SS>, lds); hipLaunchKernelGGL((k_irt_bsums<NK, SS>), grid, dim3(256), lds, st, p); }
-  if (nks == 1) { if (p.S == 1) SC_IRT_S(1, 1) else SC_IRT_S(1, 2) }
-  else { if (p.S == 1) SC_IRT_S(2, 1) else SC_IRT_S(2, 2) }
-#undef SC_IRT_S
-  SC_LAUNCH_OK("sc_irt_bwd_sums");
+  size_t lds = (size_t)irt_bwd_lds().total;
+  if (const char* e_ = getenv("STARCOP_IRT_LDS_PAD")) lds += (size_t)atoi(e_);      // experiment: where the second work-group per CU is lost
+  const dim3 grid(rows, ngroups);
+  uintx4* wpk = reinterpret_cast<uintx4*>(w.wpk);
+  p.wpk = wpk;
+  if (nks == 1) {
+    hipLaunchKernelGGL((k_irt_pack<1>), dim3(p.nch), dim3(256), 0, st, p, wpk);
+    irt_lds_attr(&k_irt_bwd<1>, lds); hipLaunchKernelGGL((k_irt_bwd<1>), grid, dim3(256), lds, st, p);
+  } else {
+    hipLaunchKernelGGL((k_irt_pack<2>), dim3(p.nch), dim3(256), 0, st, p, wpk);
+    irt_lds_attr(&k_irt_bwd<2>, lds); hipLaunchKernelGGL((k_irt_bwd<2>), grid, dim3(256), lds, st, p);
+  }
+  SC_LAUNCH_OK("sc_irt_bwd");
   return SC_OK;
 }
 
-extern "C" int sc_irt_bwd_data(const sc_irt_args* a, const sc_src* dy_d, const float* cst_bwd_expand, float* dx, const float* add0, int accum,
-                               sc_stream stream) {
+extern "C" int sc_irt_xmoments(const sc_irt_args* a, float* work, sc_stream stream) {
   IrtP p;
-  if (int rc = irt_fill(p, a, "sc_irt_bwd_data")) return rc;
-  if (int rc = irt_dy(p, dy_d, "sc_irt_bwd_data")) return rc;
-  SC_REQUIRE(cst_bwd_expand && dx, "sc_irt_bwd_data: null argument");
-  p.cstb_e = cst_bwd_expand; p.dx = dx; p.add0 = add0; p.accum = accum;
-  p.ntiles = irt_bwd_tiles(p.N, p.H, p.W, &p.tiles_x, &p.tiles_y);
-  const int nks = (p.Cin + 15) / 16;
+  if (int rc = irt_fill(p, a, "sc_irt_xmoments")) return rc;
+  SC_REQUIRE(work && ((uintptr_t)work & 15) == 0, "sc_irt_xmoments: null / misaligned workspace");
+  const IrtWork w = irt_work(work, p.N, p.Cin, p.Hd, p.H, p.W);
+  p.mpart = w.mpart;
+  const int wgs = irt_mom_wgs((long)p.N * p.H * p.W);
+  hipLaunchKernelGGL(k_irt_xmom, dim3(wgs), dim3(256), (3 * 16 * 64 + 4 * 32) * sizeof(float), (hipStream_t)stream, p);
+  SC_LAUNCH_OK("sc_irt_xmoments");
+  return SC_OK;
+}
+
+extern "C" int sc_irt_bwd_fix(const sc_irt_args* a, const float* cst_bwd_expand, float* work, float* dx, const float* add0, int accum,
+                              sc_stream stream) {
+  IrtP p;
+  if (int rc = irt_fill(p, a, "sc_irt_bwd_fix")) return rc;
+  SC_REQUIRE(cst_bwd_expand && work && dx && ((uintptr_t)work & 15) == 0, "sc_irt_bwd_fix: null / misaligned argument");
+  const IrtWork w = irt_work(work, p.N, p.Cin, p.Hd, p.H, p.W);
+  p.dx = dx; p.add0 = add0; p.accum = accum;
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = (size_t)(32 * (p.S == 1 ? IrtBwdGeo<1>::PITCH : IrtBwdGeo<2>::PITCH) + 256 + 64 + 160 + 288) * 4;
-#define SC_IRT_D(NK, SS) { irt_lds_attr(&k_irt_bdata<NK, SS>, lds); hipLaunchKernelGGL((k_irt_bdata<NK, SS>), dim3(p.ntiles), dim3(256), lds, st, p); }
-  if (nks == 1) { if (p.S == 1) SC_IRT_D(1, 1) else SC_IRT_D(1, 2) }
-  else { if (p.S == 1) SC_IRT_D(2, 1) else SC_IRT_D(2, 2) }
-#undef SC_IRT_D
-  SC_LAUNCH_OK("sc_irt_bwd_data");
+  hipLaunchKernelGGL(k_irt_qr, dim3(p.Cin), dim3(256), 0, st, p.we, cst_bwd_expand, p.Hd, p.Cin, w.qr);
+  const int nks = (p.Cin + 15) / 16;
+  const int ngroups = (p.nch + IRT_CG - 1) / IRT_CG;
+  const int wgs = irt_stat_wgs(p.npb) * 2 > (p.npb + 3) / 4 ? (p.npb + 3) / 4 : irt_stat_wgs(p.npb) * 2;
+  if (nks == 1) hipLaunchKernelGGL((k_irt_fix<1>), dim3(wgs), dim3(256), 0, st, p, w.dxp, ngroups, w.qr);
+  else hipLaunchKernelGGL((k_irt_fix<2>), dim3(wgs), dim3(256), 0, st, p, w.dxp, ngroups, w.qr);
+  SC_LAUNCH_OK("sc_irt_bwd_fix");
   return SC_OK;
 }
 
 extern "C" int sc_irt_wgrad_finalize(const sc_irt_args* a, const float* cst_bwd_expand, float* work, float* dw_expand, sc_stream stream) {
   SC_REQUIRE(a && cst_bwd_expand && work && dw_expand && a->w_expand, "sc_irt_wgrad_finalize: null argument");
   SC_REQUIRE(irt_ok(a->Cin, a->hidden, a->H, a->W, a->stride), "sc_irt_wgrad_finalize: unsupported block");
-  const int rows = irt_bsum_rows(a->N, a->H, a->W, a->hidden, nullptr);
+  const IrtWork w = irt_work(work, a->N, a->Cin, a->hidden, a->H, a->W);
+  const int rows = irt_bwd_rows(a->N, a->hidden, a->H, a->W, nullptr);
+  const int mrows = irt_mom_wgs((long)a->N * a->H * a->W);
   const int nch = (a->hidden + 31) / 32;
-  const float* gpart = work;
-  const float* mpart = work + (size_t)rows * nch * 32 * 32;
-  // 8-byte aligned fp64 scratch behind the partial rows
-  uintptr_t mf = reinterpret_cast<uintptr_t>(mpart + (size_t)rows * 33 * 32);
-  mf = (mf + 7) & ~(uintptr_t)7;
-  double* mfin = reinterpret_cast<double*>(mf);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_irt_msum, dim3(33), dim3(256), 0, st, mpart, rows, mfin);
-  hipLaunchKernelGGL(k_irt_dwe, dim3(a->hidden), dim3(256), 0, st, gpart, rows, nch * 32, mfin, a->w_expand, cst_bwd_expand, dw_expand, a->hidden,
+  hipLaunchKernelGGL(k_irt_msum, dim3(33), dim3(256), 0, st, w.mpart, mrows, w.mfin);
+  hipLaunchKernelGGL(k_irt_dwe, dim3(a->hidden), dim3(256), 0, st, w.gpart, rows, nch * 32, w.mfin, a->w_expand, cst_bwd_expand, dw_expand, a->hidden,
                      a->Cin);
   SC_LAUNCH_OK("sc_irt_wgrad_finalize");
   return SC_OK;

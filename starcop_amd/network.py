@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD, sc_wgrad_pending,
+from ._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, sc_irt_args, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD, sc_wgrad_pending,
                    PACK_PW3, PACK_THIN16, STAT_PW3, STAT_CONV1, STAT_CONV1K, STAT_CONV3, STAT_DW, STAT_STEM, TERMS_F16X2, check, make_src, ptr,
                    sc_conv_args, sc_wgrad_args, stream)
 
@@ -150,6 +150,20 @@ def _use_ebwd(HW, Cin, Cout):
     """expansion convolutions (Cin <= 32 -> 6 Cin <= 192 channels) at the high resolutions: data and weight gradient from one pass
     over (g, y) of the 6x tensor (sc_conv1x1_expand_bwd_pw3) -- both are HBM-bound on it"""
     return _PW3_EBWD and _PW3 != "0" and HW % 8 == 0 and HW >= _PW3_EBWD_MINHW and Cin <= 32 and 2 * Cin <= Cout <= 192
+
+
+# Fused TRAINING execution of the expansion + depthwise pair of a stride-2 inverted-residual block (conv_irt.hip: the 6x-expanded
+# tensor and its gradient are never stored, every sweep recomputes it from the block input).  Measured per block at batch 16
+# (tools/bench_irt.py against the launches it replaces, tools/bench_layers.py): features.2 (16 -> 96 channels at 256^2, the expanded
+# tensor is 403 MB) 632 vs 835 us; features.4 (128^2) 406 vs 341, features.7 (64^2) 245 vs 143 -- the recomputation pays where the
+# expanded tensor is much larger than everything else the block touches.  "1" = that rule, "all" = every supported block (tests), "0" = off.
+_IRT = os.environ.get("STARCOP_IRT", "1")
+
+
+def _use_irt(Cin, Hd, Hin, Win, stride):
+    if _IRT == "0" or not _lib.load().sc_irt_supported(Cin, Hd, Hin, Win, stride):
+        return False
+    return _IRT == "all" or Hin * Win >= 65536
 
 
 def _use_ksplit(N, HW, K, M, ks=1):
@@ -445,10 +459,21 @@ class HyperStarcopUNet(nn.Module):
             lib = _lib.load()
             plan.cst, plan.cstb, plan.stats_v, plan.bsums_v, plan.srows, plan.brows = {}, {}, {}, {}, {}, {}
             kind_of = {"stem": STAT_STEM, "dw": STAT_DW, "conv3": STAT_CONV3, "pw": STAT_CONV1}
+            # inverted-residual blocks whose expansion + depthwise pair runs fused in TRAINING at this resolution: expand op -> depthwise op
+            plan.irt, plan.irt_of_dw, plan.irt_rows = {}, {}, {}
+            if self.fuse_irt:
+                for i_e, (i_dw, i_pr, stride) in self._ir_blocks.items():
+                    cv, tin = self._ops[i_e]["conv"], self._ops[i_e]["ins"][0]
+                    if tin.kind != "input" and _use_irt(cv.in_channels, cv.out_channels, H >> tin.shift, W >> tin.shift, stride):
+                        plan.irt[i_e], plan.irt_of_dw[i_dw] = i_dw, i_e
+                        te, td = self._ops[i_e]["out"], self._ops[i_dw]["out"]
+                        plan.irt_rows[te.name] = lib.sc_irt_rows(0, N, H >> tin.shift, W >> tin.shift, stride)
+                        plan.irt_rows[td.name] = lib.sc_irt_rows(1, N, H >> tin.shift, W >> tin.shift, stride)
+            irt_e = {self._ops[i]["out"].name for i in plan.irt}
             for op in self._ops:
                 t = op["out"]
-                if t.kind != "input" and t.name not in plan.buf:
-                    plan.buf[t.name] = torch.empty((N, t.C, H >> t.shift, W >> t.shift), **f32)
+                if t.kind != "input" and t.name not in plan.buf and t.name not in irt_e:      # (a fused block's expanded tensor exists
+                    plan.buf[t.name] = torch.empty((N, t.C, H >> t.shift, W >> t.shift), **f32)     #  only in inference: _forward_impl)
                 if t.bn is not None:
                     Ho, Wo = H >> t.shift, W >> t.shift
                     # per-work-group partial rows [rows][C][2] (plain stores; summed in fp64 by the finalize kernels)
@@ -457,7 +482,7 @@ class HyperStarcopUNet(nn.Module):
                         kind = STAT_PW3
                     elif op["type"] == "pw" and _use_ksplit(N, Ho * Wo, op["conv"].in_channels, op["conv"].out_channels):
                         kind = STAT_CONV1K
-                    plan.srows[t.name] = lib.sc_stat_rows(kind, N, Ho, Wo)
+                    plan.srows[t.name] = max(lib.sc_stat_rows(kind, N, Ho, Wo), plan.irt_rows.get(t.name, 0))
                     plan.brows[t.name] = lib.sc_stat_rows(STAT_BNBWD, N, Ho, Wo)
                     plan.stats_v[t.name] = torch.empty(plan.srows[t.name] * t.C * 2, **f32)
                     plan.cst[t.name] = torch.zeros((t.C, SC_CST), **f32)
@@ -493,10 +518,17 @@ class HyperStarcopUNet(nn.Module):
             f32 = dict(dtype=torch.float32, device=dev)
             ws, up = 0, 0
             n_dw = 0
+            irt_e = {self._ops[i]["out"].name for i in plan.irt}
+            plan.irt_esums, plan.irt_work = {}, {}
+            for i_e in plan.irt:
+                cv, tin, te = self._ops[i_e]["conv"], self._ops[i_e]["ins"][0], self._ops[i_e]["out"]
+                Hi, Wi = H >> tin.shift, W >> tin.shift
+                plan.irt_esums[te.name] = torch.empty(lib.sc_irt_bwd_rows(N, cv.out_channels, Hi, Wi) * cv.out_channels * 2, dtype=torch.float64, device=dev)
+                plan.irt_work[te.name] = torch.empty(lib.sc_irt_bwd_workspace_floats(N, cv.in_channels, cv.out_channels, Hi, Wi), **f32)
             for op in self._ops:
                 o = op["out"]
                 Ho, Wo = H >> o.shift, W >> o.shift
-                if op["type"] != "head" and o.kind != "fin":
+                if op["type"] != "head" and o.kind != "fin" and o.name not in irt_e:
                     plan.grad[o.name] = torch.empty((N, o.C, Ho, Wo), **f32)
                 if op["type"] == "add":
                     plan.grad[o.name] = torch.empty((N, o.C, Ho, Wo), **f32)
@@ -523,7 +555,7 @@ class HyperStarcopUNet(nn.Module):
             plan.pw_part, plan.pw_table = {}, None
             if self.batch_pw_reduce:
                 for i, op in enumerate(self._ops):
-                    if op["type"] == "pw":
+                    if op["type"] == "pw" and i not in plan.irt:
                         conv, o = op["conv"], op["out"]
                         Hq, Wq = H >> o.shift, W >> o.shift
                         nfl = (lib.sc_pw3_ebwd_workspace_floats(N, Hq, Wq, conv.out_channels, conv.in_channels)
@@ -542,7 +574,7 @@ class HyperStarcopUNet(nn.Module):
             # inputs of the depthwise convolutions: their BatchNorm-backward sums come out of the fused depthwise backward
             plan.dwrows, plan.dwsums = {}, {}
             for op in self._ops:
-                if op["type"] == "dw" and op["ins"][0].bn is not None:
+                if op["type"] == "dw" and op["ins"][0].bn is not None and op["ins"][0].name not in irt_e:
                     ti = op["ins"][0]
                     plan.dwrows[ti.name] = lib.sc_stat_rows(STAT_DW, N, H >> ti.shift, W >> ti.shift)
                     plan.dwsums[ti.name] = torch.empty(plan.dwrows[ti.name] * ti.C * 2, dtype=torch.float64, device=dev)
@@ -730,6 +762,13 @@ class HyperStarcopUNet(nn.Module):
                     self._pe(tok)
                     skip.update((i_dw, i_pr))
                     continue
+            if i in plan.irt:
+                if training:
+                    self._irt_forward(plan, i, st)
+                    skip.add(plan.irt[i])
+                    continue
+                if o.name not in plan.buf:            # inference on a plan that trains fused: the expanded tensor is needed after all
+                    plan.buf[o.name] = torch.empty((N, o.C, Ho, Wo), dtype=torch.float32, device=self._pflat.device)
             stats = ptr(plan.stats_v[o.name]) if (training and o.bn is not None) else None
             conv = op.get("conv")
             tok = None
@@ -814,6 +853,43 @@ class HyperStarcopUNet(nn.Module):
                     return self._forward_impl(x, x_cst, training, need_grad)
         return plan
 
+    def _irt_args(self, plan, i_e):
+        i_dw = plan.irt[i_e]
+        op, cv_d = self._ops[i_e], self._ops[i_dw]["conv"]
+        cv, tin, te = op["conv"], op["ins"][0], op["out"]
+        a = sc_irt_args()
+        a.x = self._src_of(plan, tin)
+        a.w_expand, a.w_dw, a.cst_expand = cv.weight.data_ptr(), cv_d.weight.data_ptr(), plan.cst[te.name].data_ptr()
+        a.N, a.Cin, a.hidden = plan.N, cv.in_channels, cv.out_channels
+        a.H, a.W, a.stride = plan.H >> tin.shift, plan.W >> tin.shift, self._ops[i_dw]["stride"]
+        return a
+
+    def _irt_forward(self, plan, i_e, st):
+        """training forward of a fused block: statistics of the (never stored) expanded tensor -> its BatchNorm constants -> raw
+        depthwise output + statistics -> the depthwise BatchNorm's constants (conv_irt.hip)"""
+        lib = _lib.load()
+        i_dw = plan.irt[i_e]
+        te, td = self._ops[i_e]["out"], self._ops[i_dw]["out"]
+        a = self._irt_args(plan, i_e)
+        cnt_e = float(plan.N * a.H * a.W)
+        Hd_, Wd_ = plan.H >> td.shift, plan.W >> td.shift
+        self._cur_op = te.name + ":fwd"
+        tok = self._pb("k_irt_* (fused expand+dw)")
+        check(lib.sc_irt_expand_stats(C.byref(a), ptr(plan.stats_v[te.name]), st))
+        self._pe(tok)
+        bn = te.bn
+        check(lib.sc_bn_finalize(ptr(plan.stats_v[te.name]), plan.irt_rows[te.name], cnt_e, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+                                 ptr(bn.running_var), float(bn.momentum), float(bn.eps), 1, ptr(plan.cst[te.name]), te.C,
+                                 ptr(plan.bn_scratch) if _BN_PRE else None, st))
+        self._cur_op = td.name + ":fwd"
+        tok = self._pb("k_irt_* (fused expand+dw)")
+        check(lib.sc_irt_fwd(C.byref(a), ptr(plan.buf[td.name]), ptr(plan.stats_v[td.name]), st))
+        self._pe(tok)
+        bn = td.bn
+        check(lib.sc_bn_finalize(ptr(plan.stats_v[td.name]), plan.irt_rows[td.name], float(plan.N * Hd_ * Wd_), ptr(bn.weight), ptr(bn.bias),
+                                 ptr(bn.running_mean), ptr(bn.running_var), float(bn.momentum), float(bn.eps), 1, ptr(plan.cst[td.name]), td.C,
+                                 ptr(plan.bn_scratch) if _BN_PRE else None, st))
+
     def _nbt_list(self):
         nbt = getattr(self, "_nbt", None)
         if nbt is None or nbt[0].device != self._pflat.device:
@@ -836,6 +912,7 @@ class HyperStarcopUNet(nn.Module):
     # batch 16: 4.74 vs 3.07 ms; only features.7 wins (48 vs 54 us); at 16^2 a launch has 64 work-groups walking 30 hidden chunks with
     # two barriers each (features.15: 371 vs 68 us) -- so it is opt-in (DESIGN.md 13.1 has what the next version needs)
     fuse_ir_eval = os.environ.get("STARCOP_IR_EVAL", "0") != "0"
+    fuse_irt = _IRT != "0"      # training: expansion + depthwise of the stride-2 blocks the rule picks without the 6x tensor (conv_irt.hip)
     fuse_head_bn = os.environ.get("STARCOP_FUSE_HEAD_BN", "1") != "0"      # BatchNorm-backward sums of the decoder's last tensor in the head backward
     thin16 = os.environ.get("STARCOP_THIN16", "1") != "0"     # decoder.blocks.4 on sc_conv3x3_thin16 (0: the fp32-MFMA thin kernels)
     split_bf16 = True        # 3x3 convs with >= 32 output channels on the 16-bit matrix cores (False: everything on the fp32 MFMA)
@@ -948,7 +1025,10 @@ class HyperStarcopUNet(nn.Module):
 
         tail_lo = sum(p.numel() for p in self.encoder.parameters())
         tail_pending = on_tail_ready is not None
+        irt_done = set()
         for i in (range(len(self._ops) - 1, -1, -1) if only_ops is None else only_ops):
+            if i in irt_done:
+                continue
             op = self._ops[i]
             ty, o = op["type"], op["out"]
             Ho, Wo = H >> o.shift, W >> o.shift
@@ -1007,6 +1087,31 @@ class HyperStarcopUNet(nn.Module):
                 wgrad_launch(lambda sx: check(lib.sc_stem_conv_wgrad(C.byref(dy), C.byref(s), ptr(plan.ws), plan.ws_floats,
                                                                      ptr(gv(conv.weight)), N, conv.in_channels, H, W, sx)))
                 self._pe(tok)
+                continue
+            if ty == "dw" and i in plan.irt_of_dw:
+                # fused block: ONE sweep over (dy_d, x) for the depthwise filter gradient, the BatchNorm-backward sums of the
+                # expanded tensor and the part of dx that does not depend on them; the constants; the Cin -> Cin fix-up of dx; the
+                # expansion filter's gradient from the partial rows on the weight-gradient stream.  Covers the expand op too.
+                i_e = plan.irt_of_dw[i]
+                irt_done.add(i_e)
+                op_e = self._ops[i_e]
+                te, tin, cv_e = op_e["out"], op_e["ins"][0], op_e["conv"]
+                a_irt = self._irt_args(plan, i_e)
+                acc = plan.dw_acc[dw_offs[i]:dw_offs[i] + o.C * 9]
+                work, esums = plan.irt_work[te.name], plan.irt_esums[te.name]
+                tok = self._pb("k_irt_* (fused expand+dw)")
+                wgrad_launch(lambda sx, a_irt=a_irt, work=work: check(lib.sc_irt_xmoments(C.byref(a_irt), ptr(work), sx)))
+                check(lib.sc_irt_bwd(C.byref(a_irt), C.byref(dy), ptr(esums), ptr(acc), ptr(work), st))
+                wgrad_launch(lambda sx, acc=acc, conv=conv, o=o: check(lib.sc_cast_f64_f32(ptr(acc), ptr(gv(conv.weight)), o.C * 9, sx)))
+                check(lib.sc_bn_bwd_finalize(ptr(esums), lib.sc_irt_bwd_rows(N, te.C, a_irt.H, a_irt.W), float(N * a_irt.H * a_irt.W),
+                                             ptr(plan.cst[te.name]), ptr(gv(te.bn.weight)), ptr(gv(te.bn.bias)), ptr(plan.cstb[te.name]), te.C, st))
+                z = res_of.get(tin.name)
+                check(lib.sc_irt_bwd_fix(C.byref(a_irt), ptr(plan.cstb[te.name]), ptr(work), ptr(plan.grad[tin.name]),
+                                         ptr(plan.grad[z]) if z is not None else None, 1 if tin.name in written else 0, st))
+                wgrad_launch(lambda sx, a_irt=a_irt, work=work, te=te, cv_e=cv_e: check(lib.sc_irt_wgrad_finalize(
+                    C.byref(a_irt), ptr(plan.cstb[te.name]), ptr(work), ptr(gv(cv_e.weight)), sx)))
+                self._pe(tok)
+                written.add(tin.name)
                 continue
             if ty == "dw":
                 tin = op["ins"][0]

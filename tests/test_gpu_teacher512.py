@@ -64,6 +64,8 @@ def test_teacher_forced_backward_every_layer_512(hip):
     conv_in, grads = _capture_oracle(ref, batch)
     # a HIP training forward builds the plan (buffers, packed filters, normaliser constants); its activations are then replaced
     net = model.network
+    net.fuse_irt = False          # per-op launches need every tensor of a block; the fused expansion + depthwise pair is gated at the
+                                  # same shape by tests/test_gpu_irt.py::test_teacher_forced_fused_block_512
     loss = model.training_step(to_dev(batch), 0)
     plan = net._plans[(B, T, T)]
     name_of = {m: n for n, m in net.named_modules()}

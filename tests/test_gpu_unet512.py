@@ -144,15 +144,23 @@ def test_bf16_mode_trains_like_fp32_at_512(hip):
     # fixed late step is a lottery (see the docstring; in round 3 a changed summation order moved the bf16 run's first blow-up from
     # step 489 to step 266), the state just before the first blow-up of either run is not.
     S = max(k for k in res["fp32"][2] if k <= min(res["fp32"][3], res["bf16"][3]) - 5)
-    f1 = {}
+    # F1 of a single snapshot still jitters by ~0.005 from step to step in either mode (Adam at lr 1e-3 on 16 tiles; a changed
+    # summation order in round 4 moved one snapshot's pair to 0.9926 / 0.9859): the gate is on the MEAN over the last five common
+    # snapshots up to S (steps S-40 .. S), the single pair at S is printed beside it
+    Sset = sorted(k for k in res["fp32"][2] if k <= S)[-5:]
+    f1, f1_S = {}, {}
     for prec, (model, losses, snaps, horizon) in res.items():
-        model.load_state_dict(snaps[S])
-        model.eval()
-        with torch.no_grad():
-            pred = (model(train["input"]) >= 0).long()
-        y = train["output"].long()
-        tp = int(((pred == 1) & (y == 1)).sum()); fp = int(((pred == 1) & (y == 0)).sum()); fn = int(((pred == 0) & (y == 1)).sum())
-        f1[prec] = 2 * tp / max(2 * tp + fp + fn, 1)
+        vals = []
+        for k in Sset:
+            model.load_state_dict(snaps[k])
+            model.eval()
+            with torch.no_grad():
+                pred = (model(train["input"]) >= 0).long()
+            y = train["output"].long()
+            tp = int(((pred == 1) & (y == 1)).sum()); fp = int(((pred == 1) & (y == 0)).sum()); fn = int(((pred == 0) & (y == 1)).sum())
+            vals.append(2 * tp / max(2 * tp + fp + fn, 1))
+        f1[prec], f1_S[prec] = sum(vals) / len(vals), vals[-1]
+    print(f"bf16 gate: F1 at step {S}: fp32 {f1_S['fp32']:.4f}, bf16 {f1_S['bf16']:.4f}; mean over steps {Sset}: fp32 {f1['fp32']:.4f}, bf16 {f1['bf16']:.4f}")
     l32, l16 = res["fp32"][1], res["bf16"][1]
     print(f"bf16 gate 512^2 b16: compared at step {S} (first blow-up: fp32 {res['fp32'][3] + 1}, bf16 {res['bf16'][3] + 1} of {steps}); "
           f"loss fp32 {l32[0]:.4f} -> {l32[S]:.5f}, bf16 {l16[0]:.4f} -> {l16[S]:.5f}; F1 fp32 {f1['fp32']:.4f}, bf16 {f1['bf16']:.4f}")

@@ -10,8 +10,7 @@ a_ = ap.parse_args()
 lib = _lib.load(); _lib.require_device()
 dev = "cuda"
 # name, Cin, hidden, H (= W) of the block input, stride
-BLOCKS = [("features.2", 16, 96, 256, 2), ("features.3", 24, 144, 128, 1), ("features.4", 24, 144, 128, 2), ("features.5", 32, 192, 64, 1),
-          ("features.7", 32, 192, 64, 2)]
+BLOCKS = [("features.2", 16, 96, 256, 2), ("features.4", 24, 144, 128, 2), ("features.7", 32, 192, 64, 2)]
 N = a_.batch
 def timeit(fn, reps):
     for _ in range(2): fn()
@@ -39,16 +38,17 @@ for name, Cin, Hd, H, S in BLOCKS:
     st0 = torch.empty(r0, Hd, 2, device=dev); st1 = torch.empty(r1, Hd, 2, device=dev)
     d = torch.empty(N, Hd, Ho, Wo, device=dev); gd = torch.randn(N, Hd, Ho, Wo, device=dev, generator=g)
     es = torch.empty(r2, Hd, 2, dtype=torch.float64, device=dev); dwa = torch.zeros(Hd, 9, dtype=torch.float64, device=dev)
-    work = torch.empty(lib.sc_irt_bwd_workspace_floats(N, Hd, H, W), device=dev)
+    work = torch.empty(lib.sc_irt_bwd_workspace_floats(N, Cin, Hd, H, W), device=dev)
     dx = torch.empty(N, Cin, H, W, device=dev); dWe = torch.empty(Hd, Cin, device=dev)
     st = stream()
     check(lib.sc_irt_fwd(C.byref(a), ptr(d), ptr(st1), st))
     dy = make_src(gd, Hd, SRC_BNBWD, act=ACT_RELU6, cst=cdb, aux=d)
     t = [timeit(lambda: check(lib.sc_irt_expand_stats(C.byref(a), ptr(st0), st)), a_.reps),
          timeit(lambda: check(lib.sc_irt_fwd(C.byref(a), ptr(d), ptr(st1), st)), a_.reps),
-         timeit(lambda: check(lib.sc_irt_bwd_sums(C.byref(a), C.byref(dy), ptr(es), ptr(dwa), ptr(work), st)), a_.reps),
-         timeit(lambda: check(lib.sc_irt_bwd_data(C.byref(a), C.byref(dy), ptr(cb), ptr(dx), None, 0, st)), a_.reps),
+         timeit(lambda: check(lib.sc_irt_bwd(C.byref(a), C.byref(dy), ptr(es), ptr(dwa), ptr(work), st)), a_.reps),
+         timeit(lambda: check(lib.sc_irt_bwd_fix(C.byref(a), ptr(cb), ptr(work), ptr(dx), None, 0, st)), a_.reps),
+         timeit(lambda: check(lib.sc_irt_xmoments(C.byref(a), ptr(work), st)), a_.reps),
          timeit(lambda: check(lib.sc_irt_wgrad_finalize(C.byref(a), ptr(cb), ptr(work), ptr(dWe), st)), a_.reps)]
     eb = N * Hd * H * W * 4 / 1e6
-    print(f"{name:11s} Cin {Cin:3d} hid {Hd:3d} {H:3d}^2 s{S}  e = {eb:6.0f} MB | stats {t[0]:7.1f}  fwd {t[1]:7.1f}  bsums {t[2]:7.1f}  bdata {t[3]:7.1f}  "
-          f"dwe {t[4]:6.1f} us | sum {sum(t):7.1f} us   rows {r0} {r1} {r2}")
+    print(f"{name:11s} Cin {Cin:3d} hid {Hd:3d} {H:3d}^2 s{S}  e = {eb:6.0f} MB | stats {t[0]:7.1f}  fwd {t[1]:7.1f}  bwd {t[2]:7.1f}  fix {t[3]:7.1f}  "
+          f"xmom {t[4]:6.1f}  dwe {t[5]:6.1f} us | sum {sum(t):7.1f} us   rows {r0} {r1} {r2}")
