@@ -124,16 +124,6 @@ typedef struct sc_conv_args {
                           * smp's DecoderBlock fused into the data-gradient store (no full-resolution temporary) */
   const float* absmax;   /* terms == SC_TERMS_F16X2 with a BNBWD source: device float >= the tensor's max |A_c g| (written by
                           * sc_bn_bwd_reduce / sc_bn_bwd_small); NULL: the gradient operand is taken to be O(1)              */
-  /* Backward-data launches of sc_conv2d_mfma with ks = 1 only (NULL elsewhere).  When the launch writes the COMPLETE gradient g
-   * of a tensor y that is followed by BatchNorm + activation (single output, no accumulate, no add tensors), the epilogue also
-   * produces what sc_bn_bwd_reduce(g, y, bnb_cst, bnb_act, ...) would compute by streaming g and y again: per-channel partial
-   * sums of g*act' and g*act'*x_hat as fp64 rows bnb_sums[sc_stat_rows(SC_STAT_CONV1, N, H, W)][Cout][2] for
-   * sc_bn_bwd_finalize, and (optional) the range hint max |scale_c g act'| into *bnb_absmax (atomic max, zero it first). */
-  const float* bnb_y;    /* the tensor's raw (pre-BatchNorm) values [N,Cout,H,W]                                             */
-  const float* bnb_cst;  /* its forward constants [Cout][SC_CST] (scale, shift, mean, invstd)                                */
-  double* bnb_sums;      /* NULL: no fused reduction                                                                         */
-  float* bnb_absmax;     /* or NULL                                                                                          */
-  int32_t bnb_act;       /* activation after the BatchNorm (sc_act)                                                          */
 } sc_conv_args;
 int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream);
 /* 1x1 convolution for few-pixel / long-K layers (the <= 64^2 inverted-residual projections and the data gradients of the
@@ -218,26 +208,8 @@ int sc_conv1x1_pw3(const sc_conv_args* a, sc_stream stream);
 /* its weight gradient (K = pixels; H*W must be a multiple of 8): same sc_wgrad_args as sc_conv2d_wgrad_mfma with ks = 1, nsrc = 1;
  * workspace from sc_wgrad_pw3_workspace_floats; pending != NULL defers the sum over the K-slice partials to
  * sc_wgrad_reduce_batch (as sc_conv2d_wgrad_mfma_deferred), NULL finishes it here. */
-/* Fused backward of an EXPANSION convolution (torchvision InvertedResidual.conv[0]: Cin <= 32 -> hidden = 6 Cin <= 192 channels) at
- * the high resolutions: the data gradient (as sc_conv1x1_pw3 with `a`: BNBWD source of the expanded tensor, transpose_flip filters,
- * a->Cout = Cin, optional add0 / accum0) AND the weight gradient (as sc_conv1x1_wgrad_pw3 with `wa`: the same dy, the block input
- * as source) from ONE pass over (g, y) of the 6x tensor -- both launches are HBM-bound on that tensor, and in one kernel its second
- * use hits the cache.  H*W % 8 == 0; workspace (wa->part) from sc_pw3_ebwd_workspace_floats; pending as sc_conv1x1_wgrad_pw3. */
-size_t sc_pw3_ebwd_workspace_floats(int N, int H, int W, int hidden, int Cin);
-int sc_conv1x1_expand_bwd_pw3(const sc_conv_args* a, const sc_wgrad_args* wa, sc_wgrad_pending* pending_host, sc_stream stream);
 size_t sc_wgrad_pw3_workspace_floats(int N, int H, int W, int Cout, int Cin);
 int sc_conv1x1_wgrad_pw3(const sc_wgrad_args* a, sc_wgrad_pending* pending_host, sc_stream stream);
-
-/* A whole MobileNetV2 inverted-residual block in one launch, INFERENCE only (eval-mode BatchNorm: the constants are known before the
- * launch): expand 1x1 -> BN + ReLU6 -> depthwise 3x3 (stride 1 | 2) -> BN + ReLU6 -> project 1x1, the 6x-expanded tensors never leave
- * LDS (torchvision InvertedResidual.conv under torch.no_grad(): starcop/models/model_module.py:90-98,244-251).  x: the block input
- * (RAW or AFFINE source); wpk_expand / wpk_project: SC_PACK_PW3 packs of the two 1x1 filters (transpose_flip = 0); w_dw [hidden][9];
- * cst_expand / cst_dw [hidden][SC_CST]: eval-mode constants (scale, shift) from sc_bn_finalize(training = 0); out: the RAW projection
- * output [N][Cout][Hout][Wout] (its BatchNorm is applied by the consumer).  fp32 accuracy (three exact bf16 terms, six products). */
-int sc_ir_block_eval_supported(int Cin, int hidden, int Cout, int stride);
-int sc_ir_block_eval(const sc_src* x, const float* wpk_expand, const float* wpk_project, const float* w_dw,
-                     const float* cst_expand, const float* cst_dw, float* out, int N, int Cin, int hidden, int Cout,
-                     int H, int W, int stride, sc_stream stream);
 
 /* Fused TRAINING execution of the expansion + depthwise pair of a STRIDE-2 MobileNetV2 inverted-residual block (torchvision
  * InvertedResidual.conv[0..1] inside smp.Unet('mobilenet_v2'): starcop/models/model_module.py:244-251; train-mode BatchNorm):
@@ -270,7 +242,7 @@ int sc_irt_rows(int stage, int N, int H, int W, int stride);        /* stage 0: 
 int sc_irt_bwd_rows(int N, int hidden, int H, int W);
 size_t sc_irt_bwd_workspace_floats(int N, int Cin, int hidden, int H, int W);
 int sc_irt_expand_stats(const sc_irt_args* a, float* stats /*[rows][hidden][2]*/, sc_stream stream);
-int sc_irt_fwd(const sc_irt_args* a, float* d_out /*[N,hidden,Ho,Wo] raw*/, float* stats_d /*[rows][hidden][2]*/, sc_stream stream);
+int sc_irt_fwd(const sc_irt_args* a, float* d_out /*[N,hidden,Ho,Wo] raw*/, float* stats_d /*[rows][hidden][2] or NULL (inference)*/, sc_stream stream);
 int sc_irt_bwd(const sc_irt_args* a, const sc_src* dy_d, double* e_sums /*[rows][hidden][2]*/, double* dw_acc /*[hidden][9]*/,
                float* work, sc_stream stream);
 int sc_irt_xmoments(const sc_irt_args* a, float* work, sc_stream stream);

@@ -37,8 +37,7 @@ class sc_conv_args(C.Structure):
                 ("out0", C.c_void_p), ("out1", C.c_void_p),
                 ("csplit", C.c_int32), ("accum0", C.c_int32), ("accum1", C.c_int32),
                 ("add0", C.c_void_p), ("add1", C.c_void_p), ("stats", C.c_void_p), ("terms", C.c_int32), ("down0", C.c_int32),
-                ("absmax", C.c_void_p),
-                ("bnb_y", C.c_void_p), ("bnb_cst", C.c_void_p), ("bnb_sums", C.c_void_p), ("bnb_absmax", C.c_void_p), ("bnb_act", C.c_int32)]
+                ("absmax", C.c_void_p)]
 
 
 class sc_wgrad_args(C.Structure):
@@ -147,11 +146,7 @@ SIGNATURES = {
     "sc_packed_weight_floats_pw3": (_sz, [_i, _i, _i]),
     "sc_conv1x1_pw3": (_i, [C.POINTER(sc_conv_args), _vp]),
     "sc_wgrad_pw3_workspace_floats": (_sz, [_i, _i, _i, _i, _i]),
-    "sc_pw3_ebwd_workspace_floats": (_sz, [_i, _i, _i, _i, _i]),
-    "sc_conv1x1_expand_bwd_pw3": (_i, [C.POINTER(sc_conv_args), C.POINTER(sc_wgrad_args), C.POINTER(sc_wgrad_pending), _vp]),
     "sc_conv1x1_wgrad_pw3": (_i, [C.POINTER(sc_wgrad_args), C.POINTER(sc_wgrad_pending), _vp]),
-    "sc_ir_block_eval_supported": (_i, [_i, _i, _i, _i]),
-    "sc_ir_block_eval": (_i, [C.POINTER(sc_src), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sc_irt_supported": (_i, [_i, _i, _i, _i, _i]),
     "sc_irt_rows": (_i, [_i, _i, _i, _i, _i]),
     "sc_irt_bwd_rows": (_i, [_i, _i, _i, _i]),

@@ -2284,13 +2284,13 @@ extern "C" int sc_conv3x3_bx3(const sc_conv_args* a, sc_stream stream) {
              "sc_conv3x3_bx3: down0 (2x2-summed half-resolution out0) needs even H, W and no stats/add tensors");
   const int co_tiles = (a->Cout + a->co_t - 1) / a->co_t;
   dim3 grid(((a->W + 31) / 32) * ((a->H + 7) / 8), co_tiles, a->N);
-  static const int xcdmap_env = [] { const char* e = getenv("STARCOP_BX3_XCDMAP"); return e ? atoi(e) : 2; }();   // 0: plain 3-D grid
+  constexpr int xcdmap_env = 2;   // XCD-aware 1-D numbering (0 = plain 3-D grid: 2.7x instead of 1.24x the algorithmic bytes)
   p.xcdmap = xcdmap_env >= 2 ? 2 : ((xcdmap_env && co_tiles > 1) ? 1 : 0);
   {
     // cout-major numbering (3) for launches whose packed filters exceed this many bytes.  Off by default: measured on
     // decoder.blocks.0 (12.7 MB of filters) it is level on the forward (292 vs 291 us) and slower on the backward-data launch
     // (392 vs 368 us) -- the Infinity Cache absorbs the filter re-reads, the patches are what an XCD should share
-    static const long big_env = [] { const char* e = getenv("STARCOP_BX3_COUTMAJOR_BYTES"); return e ? atol(e) : 0L; }();
+    constexpr long big_env = 0L;      // cout-major numbering above this filter size: measured +6 % slower backward-data -> off
     const long nkc = (C0 + C1 + 15) / 16;
     const long wbytes = (long)co_tiles * nkc * 3 * 6 * (a->terms == SC_TERMS_F16X2 || a->terms == 2 ? 2 : (a->terms == 1 ? 1 : 3)) * a->co_t * 16;
     if (xcdmap_env >= 2 && big_env > 0 && wbytes > big_env && (co_tiles >= 8 || co_tiles == 1 || co_tiles == 2 || co_tiles == 4)) p.xcdmap = 3;
@@ -2316,7 +2316,7 @@ extern "C" int sc_conv3x3_bx3(const sc_conv_args* a, sc_stream stream) {
     else if (bnb) hipLaunchKernelGGL((k_conv3_bx3<1, true, NT, HF>), grid, dim3(256), 0, st, p);               \
     else hipLaunchKernelGGL((k_conv3_bx3<1, false, NT, HF>), grid, dim3(256), 0, st, p);                       \
   } while (0)
-  static const int ws_env = [] { const char* e = getenv("STARCOP_BX3_WS"); return e ? atoi(e) : 1; }();   // 0: single-role kernels
+  constexpr int ws_env = 1;
   static const int ws_env_min = [] { const char* e = getenv("STARCOP_BX3_WS_MINCHUNKS"); return e ? atoi(e) : 16; }();
   if (a->terms == 1) SC_LAUNCH_BX3(1, false); else if (a->terms == 2) SC_LAUNCH_BX3(2, false);
   // the wave-specialised kernel pays for its 8-wave work-groups (prologue / epilogue of only two per CU) on short K loops:
@@ -2372,7 +2372,7 @@ extern "C" int sc_conv3x3_wgrad_bx3(const sc_wgrad_args* a, sc_stream stream) {
   SC_REQUIRE(a->terms >= 0 && a->terms <= 4, "sc_conv3x3_wgrad_bx3: terms must be 0 (= 3), 1, 2, 3 or SC_TERMS_F16X2 (got %d)", a->terms);
   p.absmax = a->absmax;
   int nparts = pl.nsl * pl.kp;          // (the pipelined variant sums its K parts in the kernel: pl.nsl)
-  static const int pipe_env = [] { const char* e = getenv("STARCOP_WG3_PIPE"); return e ? atoi(e) : 1; }();   // 0: two-barrier stages
+  constexpr int pipe_env = 1;      // one-barrier refill pipeline (0 = the two-barrier stages it replaced: 1.89 vs 1.63 ms per step)
 #define SC_WGX(WM_, NT_, NCI_, HF_, PIPE_) hipLaunchKernelGGL((k_wgrad3_bx3<WM_, NT_, NCI_, HF_, PIPE_>), grid, dim3(768), 0, st, p)
 #define SC_WGX_NT(NT_, HF_, PIPE_)                                   \
   do {                                                               \
@@ -2481,7 +2481,7 @@ extern "C" int sc_conv3x3_thin16(const sc_conv_args* a, sc_stream stream) {
   p.wpk = reinterpret_cast<const uintx4*>(a->wpk); p.N = a->N; p.H = a->H; p.W = a->W; p.Cout = a->Cout;
   p.out0 = a->out0; p.csplit = a->Cout; p.stats = a->stats; p.absmax = a->absmax;
   dim3 grid(((a->W + 31) / 32) * ((a->H + 7) / 8), 1, a->N);
-  static const int xcdmap_env = [] { const char* e = getenv("STARCOP_BX3_XCDMAP"); return e ? atoi(e) : 2; }();
+  constexpr int xcdmap_env = 2;
   p.xcdmap = xcdmap_env ? 2 : 0;
   if (p.xcdmap) {
     const long total = (long)grid.x * a->N, per_xcd = (total + 7) / 8;

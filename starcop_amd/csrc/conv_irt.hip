@@ -272,11 +272,16 @@ __global__ __launch_bounds__(256) void k_irt_fwd(const IrtP p) {
     irt_xop<NKS>(p, s_xc, p.x.x + (size_t)n * p.Cin * HW + (ok ? (size_t)y * W + x : 0), ok, lhi, lo, hi, HW, xop[b]);
     unsigned bits = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int fi = blk * 32 + 8 * (i >> 2) + 4 * lhi + (i & 3);
-      const int eyi = fi / EW, exi = fi - eyi * EW;
-      const int yi = ey0 + eyi, xi = ex0 + exi;
-      if (fi < EPX && yi >= 0 && yi < H && xi >= 0 && xi < W) bits |= 1u << i;
+    for (int j = 0; j < 4; ++j) {
+      // accumulator registers 4 j .. 4 j + 3 = four consecutive flattened pixels: one division, then a walk along the row
+      const int f0 = blk * 32 + 8 * j + 4 * lhi;
+      int eyi = f0 / EW, exi = f0 - eyi * EW;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int yi = ey0 + eyi, xi = ex0 + exi;
+        if (f0 + q < EPX && yi >= 0 && yi < H && xi >= 0 && xi < W) bits |= 1u << (4 * j + q);
+        if (++exi == EW) { exi = 0; ++eyi; }
+      }
     }
     inside[b] = bits;
   }
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(256) void k_irt_fwd(const IrtP p) {
           s1 = am; s2 = am * am;
         }
         const float t1 = wave_total(s1), t2 = wave_total(s2);
-        if (lane == 0) *reinterpret_cast<float2*>(p.stats + ((size_t)tile * Hd + h) * 2) = make_float2(t1, t2);
+        if (p.stats && lane == 0) *reinterpret_cast<float2*>(p.stats + ((size_t)tile * Hd + h) * 2) = make_float2(t1, t2);
       }
     }
     __syncthreads();
@@ -976,7 +981,7 @@ extern "C" int sc_irt_expand_stats(const sc_irt_args* a, float* stats, sc_stream
 extern "C" int sc_irt_fwd(const sc_irt_args* a, float* d_out, float* stats_d, sc_stream stream) {
   IrtP p;
   if (int rc = irt_fill(p, a, "sc_irt_fwd")) return rc;
-  SC_REQUIRE(d_out && stats_d, "sc_irt_fwd: null output");
+  SC_REQUIRE(d_out, "sc_irt_fwd: null output");            // stats_d == NULL: inference (eval-mode constants in cst_expand)
   p.dout = d_out; p.stats = stats_d;
   p.ntiles = irt_fwd_tiles(p.N, p.H, p.W, p.S, &p.tiles_x, &p.tiles_y);
   const int nks = (p.Cin + 15) / 16;
@@ -1002,8 +1007,7 @@ extern "C" int sc_irt_bwd(const sc_irt_args* a, const sc_src* dy_d, double* e_su
   const int nks = (p.Cin + 15) / 16;
   const int ngroups = (p.nch + IRT_CG - 1) / IRT_CG;
   hipStream_t st = (hipStream_t)stream;
-  size_t lds = (size_t)irt_bwd_lds().total;
-  if (const char* e_ = getenv("STARCOP_IRT_LDS_PAD")) lds += (size_t)atoi(e_);      // experiment: where the second work-group per CU is lost
+  const size_t lds = (size_t)irt_bwd_lds().total;      // (measured with a padded request: the second work-group per CU is lost between 80.0 and 82 KB)
   const dim3 grid(rows, ngroups);
   uintx4* wpk = reinterpret_cast<uintx4*>(w.wpk);
   p.wpk = wpk;

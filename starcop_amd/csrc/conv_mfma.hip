@@ -30,8 +30,6 @@ struct ConvP {
   const float* add0; const float* add1;
   float* stats;
   int xcdmap;     // 1: 1-D grid; each XCD walks a contiguous eighth of the pixel tiles, the cout tiles of a pixel tile back to back
-  // fused BatchNorm-backward reduction of the tensor whose gradient a 1x1 backward-data launch writes (sc_conv_args.bnb_*)
-  const float* bnb_y; const float* bnb_cst; double* bnb_sums; float* bnb_absmax; int bnb_act;
 };
 
 // BNB: the (single) source is a BatchNorm-backward source (dgrad launches); mixing it with other modes in a concat is not used
@@ -56,7 +54,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
   __shared__ __attribute__((aligned(16))) float s_w[2][WCH];
   __shared__ float s_p[2][KC * PCH];
   __shared__ float s_red[8][CO_T][2];       // [wave][16-lane row of the half-wave]: two partials per 32-pixel sum, see row_sum16
-  __shared__ __attribute__((aligned(16))) float s_bc[CO_T * 4];      // fused BatchNorm-backward reduction: (scale, shift, mean, invstd) of the tile's channels
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -310,7 +307,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
   }
   const size_t HWs = (size_t)H * W;
   const bool want_stats = p.stats != nullptr;
-  float bnb_wave_max = 0.f;
   if (p.csplit == p.Cout || p.csplit % CO_T == 0) {
     // the cout tile lies entirely in one output: uniform base pointer + 32-bit lane offsets (see k_conv3_bx3's epilogue)
     const bool first = cot * CO_T < p.csplit;
@@ -324,20 +320,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
     const float* const a1 = p.add1 ? p.add1 + cbase : nullptr;
     const unsigned hw32 = (unsigned)HWs;
     const unsigned loff = (unsigned)(4 * lhi) * hw32 + (unsigned)(pix_ok ? opix : 0);
-    // fused BatchNorm-backward reduction (host: ks = 1, one output, no accumulate / add tensors): the y of the tensor whose
-    // gradient this is, is read at the element's own offset; per-channel constants of the tile through LDS
-    const bool want_bnb = (KS == 1) && BNB && p.bnb_sums != nullptr;
-    const float* const yb = want_bnb ? p.bnb_y + cbase : nullptr;
-    float blo = 0.f, bhi = 0.f, bmx = 0.f;
-    if (want_bnb) {
-      for (int i = tid; i < CO_T; i += 256) {
-        const int co = cot * CO_T + i;
-        const float4 c = (co < p.Cout) ? *reinterpret_cast<const float4*>(p.bnb_cst + (size_t)co * SC_CST) : make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(&s_bc[i * 4]) = c;
-      }
-      blo = sc_act_lo(p.bnb_act); bhi = sc_act_hi(p.bnb_act);
-      __syncthreads();
-    }
 #pragma unroll
     for (int m = 0; m < RM; ++m) {
 #pragma unroll
@@ -352,16 +334,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
           const float ss = row_sum16(v * v);
           if ((l31 & 15) == 0) { s_red[2 * wave + (l31 >> 4)][col][0] = s; s_red[2 * wave + (l31 >> 4)][col][1] = ss; }
         }
-        if (want_bnb) {
-          const float4 c = *reinterpret_cast<const float4*>(&s_bc[col * 4]);       // scale, shift, mean, invstd
-          const float yv = ok ? yb[loff + (unsigned)cu * hw32] : 0.f;
-          const float yh = fmaf(yv, c.x, c.y);
-          const float gb = (yh > blo && yh < bhi) ? v : 0.f;
-          bmx = fmaxf(bmx, fabsf(gb * c.x));
-          const float s = row_sum16(gb);
-          const float ss = row_sum16(gb * ((yv - c.z) * c.w));
-          if ((l31 & 15) == 0) { s_red[2 * wave + (l31 >> 4)][col][0] = s; s_red[2 * wave + (l31 >> 4)][col][1] = ss; }
-        }
         if (ok) {
           const unsigned off = loff + (unsigned)cu * hw32;
           if (a0) v += a0[off];
@@ -370,11 +342,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
           ob[off] = v;
         }
       }
-    }
-    if (want_bnb) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) bmx = fmaxf(bmx, __shfl_xor(bmx, o, 64));
-      bnb_wave_max = bmx;
     }
   } else
 #pragma unroll
@@ -415,29 +382,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvP p) {
         const float t = (((s_red[0][col][k] + s_red[1][col][k]) + (s_red[2][col][k] + s_red[3][col][k])) + (s_red[4][col][k] + s_red[5][col][k])) +
                         (s_red[6][col][k] + s_red[7][col][k]);
         p.stats[(((size_t)n * per_img + tile) * p.Cout + co) * 2 + k] = t;
-      }
-    }
-  }
-  if ((KS == 1) && BNB && p.bnb_sums != nullptr) {
-    // one fp64 partial row per work-group (the four waves' 32-pixel sums added in a fixed order: reproducible), rows as SC_STAT_CONV1
-    __syncthreads();
-    if (tid < CO_T * 2) {
-      const int col = tid >> 1, k = tid & 1;
-      const int co = cot * CO_T + col;
-      if (co < p.Cout) {
-        // (the association of the former half-wave sums: bit-identical statistics)
-        const float t = (((s_red[0][col][k] + s_red[1][col][k]) + (s_red[2][col][k] + s_red[3][col][k])) + (s_red[4][col][k] + s_red[5][col][k])) +
-                        (s_red[6][col][k] + s_red[7][col][k]);
-        p.bnb_sums[(((size_t)n * per_img + tile) * p.Cout + co) * 2 + k] = (double)t;
-      }
-    }
-    if (p.bnb_absmax) {
-      float m = bnb_wave_max;
-      if ((tid & 63) == 0) s_bc[wave] = m;
-      __syncthreads();
-      if (tid == 0) {
-        const float t = fmaxf(fmaxf(s_bc[0], s_bc[1]), fmaxf(s_bc[2], s_bc[3]));
-        if (t > __builtin_nontemporal_load(p.bnb_absmax)) atomicMax(reinterpret_cast<unsigned*>(p.bnb_absmax), __builtin_bit_cast(unsigned, t));
       }
     }
   }
@@ -1262,7 +1206,7 @@ WgradPlan plan_wgrad(int N, int H, int W, int Cout, int Cin, int ks) {
   pl.ci_tiles = (Cin + 32 * pl.wn - 1) / (32 * pl.wn);
   if (ks == 3) pl.stages = (long)N * ((W + 31) / 32) * ((H + pl.sr - 1) / pl.sr);
   else pl.stages = (long)N * (((long)H * W + pl.sr * 32 - 1) / (pl.sr * 32));
-  static const long wgs_env = [] { const char* e = getenv("STARCOP_WG_TARGET"); return e ? atol(e) : 512L; }();       // work-groups per launch aimed at: 512 = one full round at two per CU (measured 1.65 vs 1.84 ms at 1024, 1.96 at 768, 2.1 at 256 or 2048)
+  constexpr long wgs_env = 512L;       // work-groups per launch aimed at: 512 = one full round at two per CU (measured 1.65 vs 1.84 ms at 1024, 1.96 at 768, 2.1 at 256 or 2048)
   long want = wgs_env / ((long)pl.co_tiles * pl.ci_tiles);
   if (want < 1) want = 1;
   if (want > pl.stages) want = pl.stages;
@@ -1336,13 +1280,6 @@ extern "C" int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream) {
   ConvP p;
   p.s0 = to_srcd(a->src[0]);
   p.s1 = a->nsrc == 2 ? to_srcd(a->src[1]) : empty_srcd();
-  p.bnb_y = a->bnb_y; p.bnb_cst = a->bnb_cst; p.bnb_sums = a->bnb_sums; p.bnb_absmax = a->bnb_absmax; p.bnb_act = a->bnb_act;
-  if (a->bnb_sums) {
-    SC_REQUIRE(a->ks == 1 && a->src[0].mode == SC_SRC_BNBWD && a->bnb_y && a->bnb_cst,
-               "sc_conv2d_mfma: the fused BatchNorm-backward reduction belongs to 1x1 backward-data launches (BNBWD source) and needs bnb_y, bnb_cst");
-    SC_REQUIRE(a->csplit == a->Cout && !a->accum0 && !a->add0 && !a->add1 && !a->stats,
-               "sc_conv2d_mfma: the fused BatchNorm-backward reduction needs the complete gradient in one output (no split, accumulate, add tensors or statistics)");
-  }
   if (a->ks == 1) {
     // RAW sources of the 1x1 kernel read identity constants (scale 1, shift 0): see load_chunk
     if (p.s0.mode == SC_SRC_RAW) { p.s0.cst = sc_identity_cst(p.s0.C); SC_REQUIRE(p.s0.cst != nullptr, "sc_conv2d_mfma: identity constants unavailable (C = %d)", p.s0.C); }
@@ -1357,7 +1294,7 @@ extern "C" int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream) {
   else grid = dim3((a->H * a->W + 127) / 128, co_tiles, a->N);
   hipStream_t st = (hipStream_t)stream;
   p.xcdmap = 0;
-  static const int xcdmap_env = [] { const char* e = getenv("STARCOP_MFMA_XCDMAP"); return e ? atoi(e) : 0; }();   // measured: no gain for the 1x1 layers (2.82 vs 2.89 ms per step): off
+  constexpr int xcdmap_env = 0;   // measured: no gain for the 1x1 layers (2.82 vs 2.89 ms per step): off
   if (a->co_t != 16 && xcdmap_env) {
     const long total = (long)grid.x * a->N, per_xcd = (total + 7) / 8;
     SC_REQUIRE(per_xcd * 8 * co_tiles < (1L << 31), "sc_conv2d_mfma: grid too large");
@@ -1382,7 +1319,7 @@ extern "C" int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream) {
       if (bnb) hipLaunchKernelGGL((k_conv_mfma<KS_, RM_, true>), grid, dim3(256), 0, st, p);          \
       else hipLaunchKernelGGL((k_conv_mfma<KS_, RM_, false>), grid, dim3(256), 0, st, p);             \
     } while (0)
-    static const int pf_env = [] { const char* e = getenv("STARCOP_PW_PF"); return e ? atoi(e) : 1; }();
+    constexpr int pf_env = 1;          // K chunks of look-ahead (2 measured slower twice: 2.93 vs 2.78 ms)
 #define SC_CM2(RM_)                                                                                  \
     do {                                                                                              \
       if (bnb) hipLaunchKernelGGL((k_conv_mfma<1, RM_, true, 2>), grid, dim3(256), 0, st, p);         \
@@ -1411,7 +1348,6 @@ extern "C" int sc_conv1x1_ksplit(const sc_conv_args* a, sc_stream stream) {
   SC_REQUIRE(a->csplit > 0 && a->csplit <= a->Cout, "sc_conv1x1_ksplit: bad csplit");
   SC_REQUIRE(a->csplit == a->Cout || (a->add0 == nullptr && a->add1 == nullptr), "sc_conv1x1_ksplit: add tensors need a single output");
   ConvP p;
-  p.bnb_y = nullptr; p.bnb_cst = nullptr; p.bnb_sums = nullptr; p.bnb_absmax = nullptr; p.bnb_act = 0;
   p.xcdmap = 0;
   p.s0 = to_srcd(a->src[0]); p.s1 = empty_srcd();
   if (p.s0.mode == SC_SRC_RAW) { p.s0.cst = sc_identity_cst(p.s0.C); SC_REQUIRE(p.s0.cst != nullptr, "sc_conv1x1_ksplit: identity constants unavailable (C = %d)", p.s0.C); }

@@ -367,188 +367,6 @@ __global__ __launch_bounds__(256) void k_pw3_wgrad(const PwWP p) {
 }
 
 
-// ------------------------------------------------------------------------------------------
-// Fused backward of an EXPANSION convolution (Cin <= 32 -> hidden = 6 Cin channels) at the high resolutions: data gradient AND weight
-// gradient from ONE pass over (g, y) of the expanded tensor.  Both stream the 6x tensor's gradient and raw values (806 MB for
-// features.2 at 16 x 256^2) and run at 4.2-4.9 TB/s on their own, i.e. HBM-bound: in one kernel the second use of a 32-pixel block
-// hits L1 / L2.   Per wave and block of 32 flat pixels:
-//   part 1 (weight gradient, K = pixels):  accW[mb] (hidden block x cin) += dy[hid][px] x[cin][px]; operands = 32-byte reads of 8
-//           consecutive pixels of the lane's channel, as k_pw3_wgrad; the accumulators persist over all blocks of the wave;
-//   part 2 (data gradient, K = hidden):   D[px][cin] = sum_hid dy[px][hid] Wt[hid][cin]; the k_pw3 loop (ring of PD K steps), its
-//           dy reads are the lines part 1 just touched; epilogue = k_pw3's (optional residual add / accumulate).
-// A work-group = 4 waves walking pixel blocks wg*4 + wave, + 4*gridDim.x, ...; at the end the four accW are summed through LDS and
-// written as one partial row [hidP][32] for sc_wgrad_reduce_batch.
-struct PwEP {
-  SrcD dy, s;             // dy: BNBWD source of the expanded tensor (hidden channels); s: AFFINE / RAW source of the block input
-  const uintx4* wpk;      // transposed filters in the k_pw3 layout (K = hidden, M = Cin)
-  int NP, HW, Hd, Cin, nks, npb;
-  float* dx; const float* add0; int accum;
-  float* part;            // [gridDim.x][MBH*32][32]
-};
-
-// MBH: 32-channel blocks of the hidden tensor.  (A deeper software pipeline -- the next block's part-1 operands in flight during
-// part 2, the whole body straight-line -- needs 430+ registers, one wave per SIMD, and measured SLOWER: 406 vs 308 us on features.2.)
-template <int MBH>
-__global__ __launch_bounds__(256) void k_pw3_ebwd(const PwEP p) {
-  constexpr int PD = 2;
-  extern __shared__ __attribute__((aligned(16))) float s_mem[];      // [nks*16][8] dy constants, then the reduction scratch
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, lhi = lane >> 5;
-  const int HW = p.HW, Hd = p.Hd, Cin = p.Cin, nks = p.nks;
-  float* s_cst = s_mem;
-  for (int c = tid; c < nks * 16; c += 256) {
-    float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f); float c4 = 0.f;
-    if (c < Hd) { c0 = *reinterpret_cast<const float4*>(p.dy.cst + (size_t)c * SC_CST); c4 = p.dy.cst[(size_t)c * SC_CST + 4]; }
-    *reinterpret_cast<float4*>(s_cst + c * 8) = c0;
-    *reinterpret_cast<float4*>(s_cst + c * 8 + 4) = make_float4(c4, 0.f, 0.f, 0.f);
-  }
-  __syncthreads();
-  const float dlo = sc_act_lo(p.dy.act), dhi = sc_act_hi(p.dy.act);
-  const float xlo = sc_act_lo(p.s.act), xhi = sc_act_hi(p.s.act);
-  const bool x_ok = l31 < Cin;
-  const unsigned x_c = x_ok ? l31 : 0;
-  const float2 xc = *reinterpret_cast<const float2*>(p.s.cst + (size_t)x_c * SC_CST);
-  floatx16 accW[MBH];
-#pragma unroll
-  for (int m = 0; m < MBH; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accW[m][r] = 0.f;
-  const uintx4* wb = p.wpk + lane;
-
-  for (int pb = blockIdx.x * 4 + wave; pb < p.npb; pb += 4 * gridDim.x) {
-    // ---------------- part 1: weight-gradient contributions of this pixel block (two K steps of 16 pixels)
-    uintx4 bx[2][3];
-    size_t poff[2]; bool pok[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int g0 = pb * 32 + ks * 16 + lhi * 8;
-      pok[ks] = g0 < p.NP;
-      const int gc = pok[ks] ? g0 : 0;
-      const int n_ = gc / HW;
-      const size_t pxo = (size_t)(gc - n_ * HW);
-      const size_t ox = ((size_t)n_ * Cin + x_c) * HW + pxo;
-      const float4 x0 = *reinterpret_cast<const float4*>(p.s.x + ox), x1 = *reinterpret_cast<const float4*>(p.s.x + ox + 4);
-      const float x8[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { const float t = sc_pro_affine(x8[j], xc.x, xc.y, xlo, xhi); v[j] = (pok[ks] && x_ok) ? t : 0.f; }
-      split8(v, bx[ks]);
-      poff[ks] = (size_t)n_ * Hd * HW + pxo;                             // image base of the hidden tensor + pixel offset
-    }
-#pragma unroll
-    for (int m = 0; m < MBH; ++m) {
-      const int hid = m * 32 + l31;
-      const bool h_ok = hid < Hd;
-      const unsigned hc = h_ok ? hid : 0;
-      const float4 c0 = *reinterpret_cast<const float4*>(s_cst + hc * 8);
-      const float c4 = s_cst[hc * 8 + 4];
-      float4 gq[2][2], yq[2][2];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const size_t o = poff[ks] + (size_t)hc * HW;
-        gq[ks][0] = *reinterpret_cast<const float4*>(p.dy.x + o); gq[ks][1] = *reinterpret_cast<const float4*>(p.dy.x + o + 4);
-        yq[ks][0] = *reinterpret_cast<const float4*>(p.dy.aux + o); yq[ks][1] = *reinterpret_cast<const float4*>(p.dy.aux + o + 4);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const float g8[8] = {gq[ks][0].x, gq[ks][0].y, gq[ks][0].z, gq[ks][0].w, gq[ks][1].x, gq[ks][1].y, gq[ks][1].z, gq[ks][1].w};
-        const float y8[8] = {yq[ks][0].x, yq[ks][0].y, yq[ks][0].z, yq[ks][0].w, yq[ks][1].x, yq[ks][1].y, yq[ks][1].z, yq[ks][1].w};
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float t = sc_pro_bnbwd(g8[j], y8[j], c0.x, c0.y, c0.z, c0.w, c4, dlo, dhi);
-          v[j] = (pok[ks] && h_ok) ? t : 0.f;
-        }
-        uintx4 a[3];
-        split8(v, a);
-        accW[m] = mfma6(a, bx[ks], accW[m]);
-      }
-    }
-    // ---------------- part 2: data gradient of the same 32 pixels (K = hidden channels; the k_pw3 loop with NCB = 1)
-    const int gp = pb * 32 + l31;
-    const bool qok = gp < p.NP;
-    const int gpc = qok ? gp : 0;
-    const int n = gpc / HW, px = gpc - n * HW;
-    const float* gb = p.dy.x + ((size_t)n * Hd) * HW + px;
-    const float* yb = p.dy.aux + ((size_t)n * Hd) * HW + px;
-    float xr[PD][8], yr[PD][8];
-    uintx4 br[PD][3];
-    floatx16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#define PW3E_ISSUE(slot, ks_)                                                       \
-    {                                                                               \
-      const int kk_ = (ks_) < nks ? (ks_) : nks - 1;                                 \
-      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                               \
-        const int c_ = kk_ * 16 + lhi * 8 + j;                                      \
-        const unsigned o_ = (unsigned)(c_ < Hd ? c_ : Hd - 1) * (unsigned)HW;       \
-        xr[slot][j] = gb[o_];                                                       \
-        yr[slot][j] = yb[o_];                                                       \
-      }                                                                             \
-      _Pragma("unroll") for (int t = 0; t < 3; ++t) br[slot][t] = wb[((size_t)kk_ * 3 + t) * 64]; \
-    }
-#pragma unroll
-    for (int s = 0; s < PD; ++s) PW3E_ISSUE(s, s)
-    for (int ks0 = 0; ks0 < nks; ks0 += PD) {
-#pragma unroll
-      for (int s = 0; s < PD; ++s) {
-        const int ks = ks0 + s;
-        const int kc = ks < nks ? ks : nks - 1;
-        const bool live = qok && ks < nks;
-        const float4* q = reinterpret_cast<const float4*>(s_cst + (kc * 16 + lhi * 8) * 8);
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float4 c0 = q[2 * j]; const float c4 = q[2 * j + 1].x;
-          const float t = sc_pro_bnbwd(xr[s][j], yr[s][j], c0.x, c0.y, c0.z, c0.w, c4, dlo, dhi);
-          v[j] = live ? t : 0.f;
-        }
-        uintx4 a[3];
-        split8(v, a);
-        acc = mfma6(a, br[s], acc);
-        PW3E_ISSUE(s, ks + PD)
-      }
-    }
-#undef PW3E_ISSUE
-    if (l31 < Cin) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int g = pb * 32 + 8 * j + 4 * lhi;
-        if (g >= p.NP) continue;
-        const int n_ = g / HW;
-        const size_t idx = ((size_t)n_ * Cin + l31) * HW + (size_t)(g - n_ * HW);
-        float4 o = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
-        if (p.add0) { const float4 t = *reinterpret_cast<const float4*>(p.add0 + idx); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
-        if (p.accum) { const float4 t = *reinterpret_cast<const float4*>(p.dx + idx); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
-        *reinterpret_cast<float4*>(p.dx + idx) = o;
-      }
-    }
-  }
-  // ---------------- the four waves' weight-gradient accumulators -> one partial row (fixed order)
-  __syncthreads();                                   // every wave is past its last read of s_cst
-  float* s_red = s_mem;
-  constexpr int NR = MBH * 16;
-  if (wave > 0) {
-#pragma unroll
-    for (int m = 0; m < MBH; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s_red[((size_t)(wave - 1) * NR + m * 16 + r) * 64 + lane] = accW[m][r];
-  }
-  __syncthreads();
-  if (wave == 0) {
-    float* part = p.part + (size_t)blockIdx.x * (MBH * 32) * 32;
-#pragma unroll
-    for (int m = 0; m < MBH; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = (m * 16 + r) * 64 + lane;
-        const float v = ((accW[m][r] + s_red[o]) + s_red[NR * 64 + o]) + s_red[2 * NR * 64 + o];
-        const int hid = m * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
-        part[(size_t)hid * 32 + l31] = v;
-      }
-  }
-}
-
 struct PwWPlan { int tm, tn, pd, per_wg, nparts, CoP, CiP, ksteps; };
 
 PwWPlan plan_pw3_wgrad(int N, int H, int W, int Cout, int Cin) {
@@ -586,7 +404,7 @@ extern "C" int sc_conv1x1_pw3(const sc_conv_args* a, sc_stream stream) {
   SC_REQUIRE(a != nullptr, "sc_conv1x1_pw3: null args");
   SC_REQUIRE(a->ks == 1 && a->nsrc == 1, "sc_conv1x1_pw3: ks must be 1 with a single source");
   SC_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->Cout > 0 && a->src[0].C > 0, "sc_conv1x1_pw3: bad shape");
-  SC_REQUIRE(a->csplit == a->Cout && a->out0 && !a->out1 && !a->add1 && !a->accum1 && !a->down0 && !a->bnb_sums,
+  SC_REQUIRE(a->csplit == a->Cout && a->out0 && !a->out1 && !a->add1 && !a->accum1 && !a->down0,
              "sc_conv1x1_pw3: a single plain output (optional add0 / accum0)");
   SC_REQUIRE(a->src[0].up == 0 && a->src[0].x, "sc_conv1x1_pw3: source cannot be upsampled");
   SC_REQUIRE(a->src[0].mode != SC_SRC_NORM, "sc_conv1x1_pw3: NORM sources belong to the stem");
@@ -662,63 +480,4 @@ extern "C" int sc_conv1x1_wgrad_pw3(const sc_wgrad_args* a, sc_wgrad_pending* pe
     return SC_OK;
   }
   return sc_wgrad_finish(a->part, pl.nparts, 1, a->Cout, a->Cin, pl.CoP, pl.CiP, a->dw, st);
-}
-
-// ------------------------------------------------------------------------------------------
-static int pw3_ebwd_wgs(long npb) { const long w = (npb + 3) / 4; return (int)(w < 512 ? w : 512); }
-
-extern "C" size_t sc_pw3_ebwd_workspace_floats(int N, int H, int W, int hidden, int Cin) {
-  const long npb = ((long)N * H * W + 31) / 32;
-  const int mbh = (hidden + 31) / 32;
-  const size_t E = (size_t)mbh * 32 * 32;
-  const int nparts = pw3_ebwd_wgs(npb);
-  (void)Cin;
-  return (size_t)nparts * E + sc_reduce_scratch_floats(nparts, E);
-}
-
-extern "C" int sc_conv1x1_expand_bwd_pw3(const sc_conv_args* a, const sc_wgrad_args* wa, sc_wgrad_pending* pending, sc_stream stream) {
-  SC_REQUIRE(a && wa, "sc_conv1x1_expand_bwd_pw3: null args");
-  SC_REQUIRE(a->ks == 1 && a->nsrc == 1 && wa->ks == 1 && wa->nsrc == 1, "sc_conv1x1_expand_bwd_pw3: 1x1, single sources");
-  const int Hd = a->src[0].C, Cin = a->Cout;
-  SC_REQUIRE(wa->Cout == Hd && wa->Cin == Cin && wa->dy.C == Hd && wa->src[0].C == Cin, "sc_conv1x1_expand_bwd_pw3: channel mismatch");
-  SC_REQUIRE(a->N == wa->N && a->H == wa->H && a->W == wa->W && a->N > 0 && a->H > 0 && a->W > 0, "sc_conv1x1_expand_bwd_pw3: shape mismatch");
-  SC_REQUIRE(Cin >= 1 && Cin <= 32 && Hd >= 16 && Hd <= 192, "sc_conv1x1_expand_bwd_pw3: Cin <= 32 and 16 <= hidden <= 192 (got %d, %d)", Cin, Hd);
-  SC_REQUIRE((a->H * a->W) % 8 == 0, "sc_conv1x1_expand_bwd_pw3: H*W must be a multiple of 8");
-  SC_REQUIRE(a->src[0].mode == SC_SRC_BNBWD && a->src[0].aux && a->src[0].cst && a->src[0].up == 0, "sc_conv1x1_expand_bwd_pw3: dy must be a BNBWD source");
-  SC_REQUIRE(wa->dy.x == a->src[0].x && wa->dy.aux == a->src[0].aux && wa->dy.cst == a->src[0].cst, "sc_conv1x1_expand_bwd_pw3: both argument sets must name the same dy");
-  SC_REQUIRE((wa->src[0].mode == SC_SRC_RAW || wa->src[0].mode == SC_SRC_AFFINE) && wa->src[0].up == 0, "sc_conv1x1_expand_bwd_pw3: input must be RAW or AFFINE");
-  SC_REQUIRE(a->csplit == a->Cout && a->out0 && !a->out1 && !a->add1 && !a->accum1 && !a->down0 && !a->bnb_sums && !a->stats,
-             "sc_conv1x1_expand_bwd_pw3: a single plain data-gradient output (optional add0 / accum0)");
-  SC_REQUIRE(((uintptr_t)a->wpk & 15) == 0, "sc_conv1x1_expand_bwd_pw3: packed filters must be 16-byte aligned");
-  const long NP = (long)a->N * a->H * a->W;
-  SC_REQUIRE(NP * Hd < (1L << 32), "sc_conv1x1_expand_bwd_pw3: tensor too large for 32-bit element offsets");
-  const size_t need = sc_pw3_ebwd_workspace_floats(a->N, a->H, a->W, Hd, Cin);
-  SC_REQUIRE(wa->part_floats >= need, "sc_conv1x1_expand_bwd_pw3: workspace too small (%zu < %zu floats)", wa->part_floats, need);
-  PwEP p;
-  p.dy = to_srcd(a->src[0]); p.s = to_srcd(wa->src[0]);
-  if (p.s.mode == SC_SRC_RAW) { p.s.cst = sc_identity_cst_table(p.s.C); p.s.act = SC_ACT_NONE; SC_REQUIRE(p.s.cst, "sc_conv1x1_expand_bwd_pw3: identity constants unavailable"); }
-  p.wpk = reinterpret_cast<const uintx4*>(a->wpk);
-  p.NP = (int)NP; p.HW = a->H * a->W; p.Hd = Hd; p.Cin = Cin; p.nks = (Hd + 15) / 16; p.npb = (int)((NP + 31) / 32);
-  p.dx = a->out0; p.add0 = a->add0; p.accum = a->accum0; p.part = wa->part;
-  const int mbh = (Hd + 31) / 32;
-  const int nwg = pw3_ebwd_wgs(p.npb);
-  const size_t lds_c = (size_t)p.nks * 16 * 8 * sizeof(float), lds_r = (size_t)3 * mbh * 16 * 64 * sizeof(float);
-  const size_t lds = lds_c > lds_r ? lds_c : lds_r;
-  hipStream_t st = (hipStream_t)stream;
-  switch (mbh) {
-    case 1: hipLaunchKernelGGL((k_pw3_ebwd<1>), dim3(nwg), dim3(256), lds, st, p); break;
-    case 2: hipLaunchKernelGGL((k_pw3_ebwd<2>), dim3(nwg), dim3(256), lds, st, p); break;
-    case 3: hipLaunchKernelGGL((k_pw3_ebwd<3>), dim3(nwg), dim3(256), lds, st, p); break;
-    case 4: hipLaunchKernelGGL((k_pw3_ebwd<4>), dim3(nwg), dim3(256), lds, st, p); break;
-    case 5: hipLaunchKernelGGL((k_pw3_ebwd<5>), dim3(nwg), dim3(256), lds, st, p); break;
-    default: hipLaunchKernelGGL((k_pw3_ebwd<6>), dim3(nwg), dim3(256), lds, st, p); break;
-  }
-  SC_LAUNCH_OK("sc_conv1x1_expand_bwd_pw3");
-  if (pending) {
-    pending->part = wa->part; pending->dw = wa->dw; pending->nparts = nwg; pending->taps = 1;
-    pending->Cout = Hd; pending->Cin = Cin; pending->CoP = mbh * 32; pending->CiP = 32;
-    pending->total = (uint64_t)Hd * Cin;
-    return SC_OK;
-  }
-  return sc_wgrad_finish(wa->part, nwg, 1, Hd, Cin, mbh * 32, 32, wa->dw, st);
 }

@@ -1528,7 +1528,7 @@ extern "C" int sc_dwconv3x3_fwd(const sc_src* in, const float* w, float* out, in
   const long planes8 = ((long)N * C + 7) / 8 * 8;
   SC_REQUIRE(planes8 * dw_tiles(Hout, Wout) < (1L << 31), "sc_dwconv3x3_fwd: grid too large");
   dim3 grid((unsigned)(planes8 * dw_tiles(Hout, Wout)));
-  static const bool p16_env = [] { const char* e = getenv("STARCOP_DW_P16"); return !e || atoi(e) != 0; }();
+  constexpr bool p16_env = true;
   // (32 x 32 planes through the same kernel measured SLOWER than the work-group-per-plane form -- backward 50 -> 63 us, forward
   // 22 -> 27 us on features.12: 16 pixels per lane, 43 KB of LDS per work-group -- so it is opt-in: STARCOP_DW_P32=1)
   static const bool p32_env = [] { const char* e = getenv("STARCOP_DW_P32"); return e && atoi(e) != 0; }();
@@ -1539,7 +1539,7 @@ extern "C" int sc_dwconv3x3_fwd(const sc_src* in, const float* w, float* out, in
     SC_LAUNCH_OK("sc_dwconv3x3_fwd");
     return SC_OK;
   }
-  static const bool v4_env = [] { const char* e = getenv("STARCOP_DW_V4"); return !e || atoi(e) != 0; }();
+  constexpr bool v4_env = true;
   if (v4_env && Win % 4 == 0 && (((uintptr_t)in->x) & 15) == 0)
     SC_DW_DISPATCH4(k_dw_fwd, true, Wout, grid, to_srcd(*in), w, out, N * C, C, Hin, Win, Hout, Wout, stats);
   else
@@ -1593,10 +1593,10 @@ extern "C" int sc_dwconv3x3_bwd_fused(const sc_src* dy, const sc_src* in, const 
   SC_REQUIRE(planes8 * dw_tiles(Hin, Win) < (1L << 31), "sc_dwconv3x3_bwd_fused: grid too large");
   dim3 grid((unsigned)(planes8 * dw_tiles(Hin, Win)));
   // float4 staging where every patch row is 16-byte aligned (SC_DW_V4=0 forces the element-wise form)
-  static const bool v4_env = [] { const char* e = getenv("STARCOP_DW_V4"); return !e || atoi(e) != 0; }();
+  constexpr bool v4_env = true;
   const bool v4 = v4_env && Win % 4 == 0 && Wout % 4 == 0 &&
                   ((((uintptr_t)dy->x) | ((uintptr_t)dy->aux) | ((uintptr_t)in->x)) & 15) == 0;
-  static const bool p16_env = [] { const char* e = getenv("STARCOP_DW_P16"); return !e || atoi(e) != 0; }();
+  constexpr bool p16_env = true;
   // (32 x 32 planes through the same kernel measured SLOWER than the work-group-per-plane form -- backward 50 -> 63 us, forward
   // 22 -> 27 us on features.12: 16 pixels per lane, 43 KB of LDS per work-group -- so it is opt-in: STARCOP_DW_P32=1)
   static const bool p32_env = [] { const char* e = getenv("STARCOP_DW_P32"); return e && atoi(e) != 0; }();

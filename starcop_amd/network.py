@@ -100,12 +100,10 @@ class _T:
         self.res_grad = None        # 'fin' tensor z = self + ...: z.grad must be added to self.grad
 
 
-_BN_PRE = os.environ.get("STARCOP_BN_PRE", "1") != "0"      # coalesced pre-reduction of many-row BatchNorm statistics (sc_bn_finalize scratch)
-_COT_RATIO = float(os.environ.get("STARCOP_COT_RATIO", "1.15"))
-_COT_RATIO3 = float(os.environ.get("STARCOP_COT_RATIO3", "1.15"))     # the same choice for the 3x3 layers (64-wide tiles stage a patch fewer times)
-# development knob: "d0a,d0b;d0a" forces 32-wide cout tiles for the forward (before ';') / backward-data launches of these ops
-_FORCE_COT32 = [set(x.split(",")) for x in (os.environ.get("STARCOP_FORCE_COT32", ";") + ";").split(";")[:2]]
-_HEAD_FUSED_BWD = os.environ.get("STARCOP_HEAD_FUSED_BWD", "1") != "0"      # dev knob: 0 = separate head dgrad / wgrad launches
+_BN_PRE = True      # coalesced pre-reduction of many-row BatchNorm statistics (sc_bn_finalize scratch)
+_COT_RATIO = 1.15      # 64-wide cout tiles when they pad the channel count by less than this factor (measured per layer)
+_COT_RATIO3 = 1.15     # the same choice for the 3x3 layers
+_HEAD_FUSED_BWD = True     # gin, dW and dbias of the head in one sweep (False: the separate data / weight gradient launches)
 
 
 def _pick_cot(M, ks=1):
@@ -137,19 +135,6 @@ def _use_pw3(which, HW, K=0, M=0):
     if which == 1:
         return HW <= 4096 and K <= 192
     return HW <= 1024 and K * M <= 300000 and (HW <= 256 or K * M <= 32768)
-
-
-# OFF by default: measured 1324-1326 vs 1329-1336 tiles/s (same box).  The fused launch takes 308 us on features.2 against 178 + 208 for
-# the two separate ones, but it sits on the main stream, where the separate weight gradient overlapped the dependency chain on the
-# second stream: the serial sum falls by 0.08 ms, the critical path grows.
-_PW3_EBWD = os.environ.get("STARCOP_PW3_EBWD", "0") != "0"
-_PW3_EBWD_MINHW = int(os.environ.get("STARCOP_PW3_EBWD_MINHW", "4096"))
-
-
-def _use_ebwd(HW, Cin, Cout):
-    """expansion convolutions (Cin <= 32 -> 6 Cin <= 192 channels) at the high resolutions: data and weight gradient from one pass
-    over (g, y) of the 6x tensor (sc_conv1x1_expand_bwd_pw3) -- both are HBM-bound on it"""
-    return _PW3_EBWD and _PW3 != "0" and HW % 8 == 0 and HW >= _PW3_EBWD_MINHW and Cin <= 32 and 2 * Cin <= Cout <= 192
 
 
 # Fused TRAINING execution of the expansion + depthwise pair of a stride-2 inverted-residual block (conv_irt.hip: the 6x-expanded
@@ -497,8 +482,6 @@ class HyperStarcopUNet(nn.Module):
                     for tflip in (0, 1):
                         cv = op["conv"]
                         lay = "pw3" if _use_pw3(tflip, hw, cv.out_channels if tflip else cv.in_channels) else "mfma"
-                        if tflip and op["ins"][0].kind != "input" and _use_ebwd(hw, cv.in_channels, cv.out_channels):
-                            lay = "pw3"        # the fused expansion backward reads the k_pw3 layout
                         if lay not in need.setdefault((i, tflip), set()):
                             need[(i, tflip)].add(lay)
                             self._pack_version = None
@@ -558,9 +541,7 @@ class HyperStarcopUNet(nn.Module):
                     if op["type"] == "pw" and i not in plan.irt:
                         conv, o = op["conv"], op["out"]
                         Hq, Wq = H >> o.shift, W >> o.shift
-                        nfl = (lib.sc_pw3_ebwd_workspace_floats(N, Hq, Wq, conv.out_channels, conv.in_channels)
-                               if (op["ins"][0].kind != "input" and _use_ebwd(Hq * Wq, conv.in_channels, conv.out_channels))
-                               else lib.sc_wgrad_pw3_workspace_floats(N, Hq, Wq, conv.out_channels, conv.in_channels)
+                        nfl = (lib.sc_wgrad_pw3_workspace_floats(N, Hq, Wq, conv.out_channels, conv.in_channels)
                                if _use_pw3(2, Hq * Wq, conv.in_channels, conv.out_channels)
                                else lib.sc_wgrad_workspace_floats(N, Hq, Wq, conv.out_channels, conv.in_channels, 1))
                         plan.pw_part[i] = torch.empty(nfl, **f32)
@@ -606,10 +587,6 @@ class HyperStarcopUNet(nn.Module):
                 if ks == 3 and co <= 16 and ci >= 32 and self.split_bf16:
                     cf = 32       # decoder.blocks.4.conv1 (32 -> 16): the split kernel with half-empty cout blocks still beats
                                   # the fp32-MFMA thin kernel (0.36 vs 0.50 ms); 16 -> 16 layers do not (tools/bench_thin_bx3.py)
-                if op["out"].name in _FORCE_COT32[0]:
-                    cf = 32
-                if op["out"].name in _FORCE_COT32[1]:
-                    cb = 32
                 # 3x3 layers with >= 32 output channels run on the 16-bit matrix cores with exactly-split operands
                 # (fp32-level accuracy, conv_bx3.hip; `precision` picks the split); thin ones stay on the fp32 MFMA kernels
                 xf = self.split_bf16 and ks == 3 and cf >= 32
@@ -709,14 +686,6 @@ class HyperStarcopUNet(nn.Module):
         plan.buf["x"] = x
         plan.x_cst = x_cst
         plan.generation = getattr(plan, "generation", 0) + 1     # activations of an earlier forward of this shape are gone
-        if (not training) and self.fuse_ir_eval:      # the fused inference blocks read the k_pw3 layout of both 1x1 filters
-            need = self._pw_need
-            for i_e, (i_dw, i_pr, _) in self._ir_blocks.items():
-                for k in (i_e, i_pr):
-                    if "pw3" not in need.setdefault((k, 0), set()):
-                        need[(k, 0)].add("pw3")
-                        self._pack_version = None
-                        self._pack_tables = {}
         self._pack_all(need_grad)
         st = stream()
         # inference: the BatchNorm constants depend only on parameters and running statistics -- 62 five-microsecond launches of the
@@ -732,7 +701,6 @@ class HyperStarcopUNet(nn.Module):
         if training:
             self._stat_epoch += 1            # running statistics are about to be updated through raw pointers
             plan.eval_cst_key = None
-        fuse_ir = (not training) and self.fuse_ir_eval
         if not training and not eval_cst_ok:
             # inference: every BatchNorm's constants up front (they do not depend on the data), so that a fused block can use the
             # constants of tensors it never materialises
@@ -747,28 +715,20 @@ class HyperStarcopUNet(nn.Module):
                 continue
             ty, o = op["type"], op["out"]
             Ho, Wo = H >> o.shift, W >> o.shift
-            if fuse_ir and i in self._ir_blocks:
-                i_dw, i_pr, stride = self._ir_blocks[i]
-                cv_e, cv_d, cv_p = op["conv"], self._ops[i_dw]["conv"], self._ops[i_pr]["conv"]
-                if lib.sc_ir_block_eval_supported(cv_e.in_channels, cv_e.out_channels, cv_p.out_channels, stride):
-                    # expand -> BN+ReLU6 -> depthwise -> BN+ReLU6 -> project in ONE launch; the 6x tensors never leave LDS
-                    tin, te, td, tp = op["ins"][0], o, self._ops[i_dw]["out"], self._ops[i_pr]["out"]
-                    s = self._src_of(plan, tin)
-                    self._cur_op = tp.name + ":fwd"
-                    tok = self._pb("k_ir_eval")
-                    check(lib.sc_ir_block_eval(C.byref(s), ptr(self._wpk[i]["pf"]), ptr(self._wpk[i_pr]["pf"]), ptr(cv_d.weight),
-                                               ptr(plan.cst[te.name]), ptr(plan.cst[td.name]), ptr(plan.buf[tp.name]), N, cv_e.in_channels,
-                                               cv_e.out_channels, cv_p.out_channels, H >> tin.shift, W >> tin.shift, stride, st))
-                    self._pe(tok)
-                    skip.update((i_dw, i_pr))
-                    continue
             if i in plan.irt:
                 if training:
                     self._irt_forward(plan, i, st)
                     skip.add(plan.irt[i])
                     continue
-                if o.name not in plan.buf:            # inference on a plan that trains fused: the expanded tensor is needed after all
-                    plan.buf[o.name] = torch.empty((N, o.C, Ho, Wo), dtype=torch.float32, device=self._pflat.device)
+                # inference: the same fused forward with the running-statistics constants (computed up front above), no statistics
+                a_irt = self._irt_args(plan, i)
+                td = self._ops[plan.irt[i]]["out"]
+                self._cur_op = td.name + ":fwd"
+                tok = self._pb("k_irt_* (fused expand+dw)")
+                check(lib.sc_irt_fwd(C.byref(a_irt), ptr(plan.buf[td.name]), None, st))
+                self._pe(tok)
+                skip.add(plan.irt[i])
+                continue
             stats = ptr(plan.stats_v[o.name]) if (training and o.bn is not None) else None
             conv = op.get("conv")
             tok = None
@@ -901,20 +861,11 @@ class HyperStarcopUNet(nn.Module):
     # HIP stream, forked after each layer's BatchNorm-backward constants and joined before the optimiser, so they fill
     # the CUs the small dgrad / reduce kernels of the dependency chain leave idle.
     overlap_wgrad = True
-    batch_pw_reduce = os.environ.get("STARCOP_BATCH_PW_REDUCE", "1") != "0"     # one reduction launch for all pointwise weight gradients
-    fuse_dw_bwd = os.environ.get("STARCOP_FUSE_DW", "1") != "0"     # depthwise dgrad + wgrad + the input's BatchNorm-backward sums in one kernel
-    # BatchNorm-backward sums of a depthwise output in the epilogue of the 1x1 backward-data launch that writes its gradient.
-    # OFF: measured 1179 vs 1189 tiles/s -- the reduction pass it saves runs at 6 TB/s (0.24 ms), the extra ~25 VALU per element
-    # in the issue-bound 1x1 epilogue cost 0.37 ms.
-    fuse_bn_bwd = os.environ.get("STARCOP_FUSE_BNBWD", "0") != "0"
-    # inference: a whole inverted-residual block (expand -> depthwise -> project) in one launch (conv_ir.hip).  Correct (5e-6 of fp64,
-    # whole-network eval tests green with it on) but its first version is SLOWER than the three launches it replaces -- eval forward at
-    # batch 16: 4.74 vs 3.07 ms; only features.7 wins (48 vs 54 us); at 16^2 a launch has 64 work-groups walking 30 hidden chunks with
-    # two barriers each (features.15: 371 vs 68 us) -- so it is opt-in (DESIGN.md 13.1 has what the next version needs)
-    fuse_ir_eval = os.environ.get("STARCOP_IR_EVAL", "0") != "0"
+    batch_pw_reduce = True      # one reduction launch for all pointwise weight gradients (False: per-layer reductions; test switch)
+    fuse_dw_bwd = True          # depthwise dgrad + wgrad + the input's BatchNorm-backward sums in one kernel (False: the three separate kernels)
     fuse_irt = _IRT != "0"      # training: expansion + depthwise of the stride-2 blocks the rule picks without the 6x tensor (conv_irt.hip)
-    fuse_head_bn = os.environ.get("STARCOP_FUSE_HEAD_BN", "1") != "0"      # BatchNorm-backward sums of the decoder's last tensor in the head backward
-    thin16 = os.environ.get("STARCOP_THIN16", "1") != "0"     # decoder.blocks.4 on sc_conv3x3_thin16 (0: the fp32-MFMA thin kernels)
+    fuse_head_bn = True         # BatchNorm-backward sums of the decoder's last tensor in the head backward
+    thin16 = True               # decoder.blocks.4 on sc_conv3x3_thin16 (0: the fp32-MFMA thin kernels)
     split_bf16 = True        # 3x3 convs with >= 32 output channels on the 16-bit matrix cores (False: everything on the fp32 MFMA)
     bn_small_max = 16384     # BatchNorm backward in one launch (block per channel) when a channel has at most this many elements
     # Arithmetic of the 3x3 convolutions with >= 32 channels (conv_bx3.hip): every fp32 operand is split exactly into a few
@@ -1154,30 +1105,6 @@ class HyperStarcopUNet(nn.Module):
             wa.terms = self._terms[1]
             wa.absmax = gmax_slot.get(o.name)
             flop = 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * ks * ks
-            if (ty == "pw" and i in plan.pw_part and ins[0].kind != "input" and _use_ebwd(Ho * Wo, conv.in_channels, conv.out_channels)):
-                # expansion convolution at a high resolution: data gradient + weight gradient from ONE pass over (g, y) of the 6x
-                # tensor, on the main stream (the data gradient is on the critical path, the weight gradient rides along)
-                tin = ins[0]
-                wa.part = plan.pw_part[i].data_ptr(); wa.part_floats = plan.pw_part[i].numel()
-                a = sc_conv_args()
-                a.nsrc = 1
-                a.src[0] = dy
-                a.wpk = self._wpk[i]["pb"].data_ptr()
-                a.N, a.H, a.W, a.Cout, a.ks, a.co_t = N, Ho, Wo, conv.in_channels, 1, 32
-                a.out0 = plan.grad[tin.name].data_ptr(); a.out1 = None
-                a.csplit = conv.in_channels
-                a.accum0 = 1 if tin.name in written else 0
-                a.accum1 = 0
-                z = res_of.get(tin.name)
-                a.add0 = plan.grad[z].data_ptr() if z is not None else None
-                a.add1 = None; a.stats = None
-                pend = sc_wgrad_pending()
-                tok = self._pb("k_pw3_ebwd (dgrad+wgrad)", 2 * flop, 4.0 * (2 * N * o.C * Ho * Wo + 2 * N * conv.in_channels * Ho * Wo + conv.weight.numel()))
-                check(lib.sc_conv1x1_expand_bwd_pw3(C.byref(a), C.byref(wa), C.byref(pend), st))
-                self._pe(tok)
-                pw_pending.append(pend)
-                written.add(tin.name)
-                continue
             wfn = (lib.sc_conv3x3_wgrad_bx3 if (self.split_bf16 and ks == 3 and conv.out_channels >= 32 and conv.in_channels >= 32)
                    else lib.sc_conv2d_wgrad_mfma)     # 16-channel layers outside the cases below stay on the fp32 MFMA
             if (self.split_bf16 and self.thin16 and ks == 3 and self._terms[1] == TERMS_F16X2 and len(ins) == 1
@@ -1257,17 +1184,6 @@ class HyperStarcopUNet(nn.Module):
                 z = res_of.get(tin.name)
                 if z is not None:
                     a.add0 = plan.grad[z].data_ptr()
-                if (self.fuse_bn_bwd and conv_dgrad is lib.sc_conv2d_mfma and ks == 1 and tin.bn is not None and not a.accum0 and z is None
-                        and n_cons.get(tin.name, 0) == 1 and tin.name not in reduced):
-                    # this launch writes the complete gradient of a BatchNorm'd tensor (the depthwise output in an inverted-residual
-                    # block): its epilogue also leaves the BatchNorm-backward partial sums, instead of sc_bn_bwd_reduce streaming
-                    # the gradient and the tensor again
-                    if tin.name not in plan.dwsums:
-                        plan.dwrows[tin.name] = lib.sc_stat_rows(STAT_CONV1, N, Ho, Wo)
-                        plan.dwsums[tin.name] = torch.empty(plan.dwrows[tin.name] * tin.C * 2, dtype=torch.float64, device=self._pflat.device)
-                    a.bnb_y, a.bnb_cst = plan.buf[tin.name].data_ptr(), plan.cst[tin.name].data_ptr()
-                    a.bnb_sums, a.bnb_absmax, a.bnb_act = plan.dwsums[tin.name].data_ptr(), None, tin.act
-                    reduced.add(tin.name)
                 if thin_b:
                     conv_dgrad = lib.sc_conv3x3_thin16
                     a.wpk = ent["tb"].data_ptr()

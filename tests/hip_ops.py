@@ -48,7 +48,7 @@ def pack_bx3(w, co_t, tflip, terms=None):
 
 
 def conv_mfma(srcs, wpk, N, H, W, Cout, ks, co_t, want_stats=False, csplit=None, add0=None, add1=None,
-              accum=None, outs=None, bx3=False, ksplit=False, terms=0, down0=False, absmax=None, bnb=None):
+              accum=None, outs=None, bx3=False, ksplit=False, terms=0, down0=False, absmax=None):
     lib = _lib.load()
     a = sc_conv_args()
     a.nsrc = len(srcs)
@@ -73,10 +73,6 @@ def conv_mfma(srcs, wpk, N, H, W, Cout, ks, co_t, want_stats=False, csplit=None,
     rows = lib.sc_stat_rows(STAT_CONV3 if ks == 3 else (STAT_CONV1K if ksplit else STAT_CONV1), N, H, W)
     stats = torch.full((rows, Cout, 2), float("nan"), device=DEV) if want_stats else None      # every entry must be written
     a.stats = stats.data_ptr() if want_stats else None
-    if bnb is not None:          # fused BatchNorm-backward reduction: dict(y=, cst=, act=, sums=, absmax=)
-        a.bnb_y, a.bnb_cst, a.bnb_act = bnb["y"].data_ptr(), bnb["cst"].data_ptr(), bnb["act"]
-        a.bnb_sums = bnb["sums"].data_ptr()
-        a.bnb_absmax = bnb["absmax"].data_ptr() if bnb.get("absmax") is not None else None
     fn = lib.sc_conv3x3_bx3 if bx3 else (lib.sc_conv1x1_ksplit if ksplit else lib.sc_conv2d_mfma)
     check(fn(C.byref(a), stream()))
     return outs, stats
@@ -166,30 +162,3 @@ def wgrad_pw3(dy, src, N, H, W, Cout, Cin, deferred=False):
     _KEEP.extend([descs, starts])
     check(lib.sc_wgrad_reduce_batch(ptr(descs), ptr(starts), 1, -(-int(pend.total) // 256), stream()))
     return dw
-
-
-def expand_bwd_pw3(dsrc, src, wpk_t, N, H, W, hidden, Cin, add0=None, accum_into=None):
-    """fused expansion backward (sc_conv1x1_expand_bwd_pw3): -> (dx, dw)"""
-    from starcop_amd._lib import sc_wgrad_pending
-    lib = _lib.load()
-    a = sc_conv_args()
-    a.nsrc = 1
-    a.src[0] = dsrc
-    a.wpk = wpk_t.data_ptr()
-    a.N, a.H, a.W, a.Cout, a.ks, a.co_t = N, H, W, Cin, 1, 32
-    dx = accum_into if accum_into is not None else torch.full((N, Cin, H, W), float("nan"), device=DEV)
-    a.out0, a.out1, a.csplit = dx.data_ptr(), None, Cin
-    a.accum0 = 1 if accum_into is not None else 0
-    a.add0 = add0.data_ptr() if add0 is not None else None
-    wa = sc_wgrad_args()
-    wa.dy, wa.nsrc = dsrc, 1
-    wa.src[0] = src
-    wa.N, wa.H, wa.W, wa.Cout, wa.Cin, wa.ks = N, H, W, hidden, Cin, 1
-    n = lib.sc_pw3_ebwd_workspace_floats(N, H, W, hidden, Cin)
-    ws = torch.empty(n, device=DEV)
-    wa.part, wa.part_floats = ws.data_ptr(), n
-    dw = torch.full((hidden, Cin, 1, 1), float("nan"), device=DEV)
-    wa.dw = dw.data_ptr()
-    _KEEP.append(ws)
-    check(lib.sc_conv1x1_expand_bwd_pw3(C.byref(a), C.byref(wa), None, stream()))
-    return dx, dw

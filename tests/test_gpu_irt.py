@@ -214,7 +214,7 @@ def test_network_trains_the_same_with_fused_blocks(hip):
     path (features.2 / .4 / .7 / .14 where supported) against the same step on the separate kernels: logits, loss, every parameter
     gradient and the running statistics of the fused BatchNorms (features.N.conv.0.1 / .1.1) -- two HIP paths with different
     summation orders, so the comparison has the fp32 noise floor of 62 train-mode BatchNorms, not bit equality; both are held to the
-    oracle by tests/test_gpu_unet.py / test_gpu_teacher512.py.  Inference on the fused plan re-creates the expanded tensor."""
+    oracle by tests/test_gpu_unet.py / test_gpu_teacher512.py.  Inference takes the fused forward too (no statistics rows)."""
     from test_gpu_unet import make_pair, synth_batch, to_dev
     model, ref = make_pair(seed=11)
     batch = to_dev(synth_batch(2, 128, 128, seed=12))
@@ -259,7 +259,7 @@ def test_network_trains_the_same_with_fused_blocks(hip):
         nw._IRT = "0"
         with torch.no_grad():
             got0 = model(batch["input"])
-        assert relerr(got, got0) < 1e-6
+        assert relerr(got, got0) < 1e-5          # inference runs the same fused forward (running-statistics constants, no statistics rows)
     finally:
         nw._IRT = old
 

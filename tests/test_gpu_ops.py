@@ -846,40 +846,6 @@ def test_depthwise_plane_kernels_at_32():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("cin,cout,co_t,H,W,act", [(144, 24, 64, 20, 28, ACT_RELU6), (96, 16, 32, 32, 32, ACT_RELU6), (40, 8, 32, 7, 9, ACT_RELU),
-                                                   (576, 96, 64, 8, 8, ACT_RELU6), (32, 16, 32, 64, 64, ACT_NONE)])
-def test_pw_dgrad_fused_bn_backward_sums(hip, cin, cout, co_t, H, W, act):
-    """1x1 backward-data launch with the fused BatchNorm-backward reduction of the tensor whose gradient it writes (the depthwise
-    output of an inverted-residual block): the gradient itself is unchanged bit for bit, and the fp64 partial rows / the range hint
-    equal what sc_bn_bwd_reduce computes from the stored gradient and the tensor (same masks, same x_hat)."""
-    lib = hip
-    N = 3
-    g, yo = rnd(N, cout, H, W, seed=1), rnd(N, cout, H, W, seed=2)
-    w = rnd(cout, cin, 1, 1, seed=3, scale=0.3)
-    cb = torch.zeros(cout, SC_CST); cb[:, 0], cb[:, 1] = rnd(cout, seed=4) * 0.2 + 1, rnd(cout, seed=5) * 0.2
-    cb[:, 2], cb[:, 3], cb[:, 4] = rnd(cout, seed=6) * 0.2 + 1, rnd(cout, seed=7) * 0.1, rnd(cout, seed=8) * 0.1
-    dsrc = make_src(dev(g), cout, SRC_BNBWD, act=ACT_NONE, cst=dev(cb), aux=dev(yo))
-    wpk = pack(dev(w), co_t, 1)
-    yin = dev(rnd(N, cin, H, W, seed=9, scale=2.0))                     # the tensor whose gradient the launch writes
-    cin_c = torch.zeros(cin, SC_CST); cin_c[:, 0], cin_c[:, 1] = rnd(cin, seed=10) * 0.3 + 1, rnd(cin, seed=11) * 0.5
-    cin_c[:, 2], cin_c[:, 3] = rnd(cin, seed=12) * 0.2, rnd(cin, seed=13).abs() + 0.5
-    cin_d = dev(cin_c)
-    (dx0,), _ = conv_mfma([dsrc], wpk, N, H, W, cin, 1, co_t)
-    rows = lib.sc_stat_rows(STAT_CONV1, N, H, W)
-    sums = torch.full((rows, cin, 2), float("nan"), dtype=torch.float64, device=DEV)
-    amax = torch.zeros(1, device=DEV)
-    (dx,), _ = conv_mfma([dsrc], wpk, N, H, W, cin, 1, co_t, bnb=dict(y=yin, cst=cin_d, act=act, sums=sums, absmax=amax))
-    assert torch.equal(dx, dx0)
-    rrows = lib.sc_stat_rows(STAT_BNBWD, N, H, W)
-    ref = torch.empty(rrows * cin * 2, dtype=torch.float64, device=DEV)
-    rmax = torch.zeros(1, device=DEV)
-    check(lib.sc_bn_bwd_reduce(ptr(dx0), ptr(yin), ptr(cin_d), act, ptr(ref), N, cin, H * W, ptr(rmax), None, stream()))
-    got, want = sums.sum(0), ref.view(rrows, cin, 2).sum(0)
-    assert not torch.isnan(got).any()
-    assert float((got - want).abs().max() / want.abs().max()) < 2e-6
-    assert float(amax) == pytest.approx(float(rmax), rel=1e-6)
-
-
 # ---- pointwise convolutions on the split-bf16 MFMA without LDS staging (conv_pw3.hip)
 PW3_SHAPES = [(16, 96, 2, 64, 64), (64, 384, 3, 32, 32), (384, 64, 2, 32, 32), (160, 960, 2, 16, 16), (960, 320, 2, 16, 16), (24, 144, 2, 24, 40),
               (144, 24, 1, 20, 12), (320, 1280, 2, 4, 6), (32, 16, 1, 2, 2), (96, 576, 5, 2, 3), (40, 8, 2, 1, 1)]
@@ -950,66 +916,3 @@ def test_conv_pw3_wgrad(hip, cin, cout, N, H, W, deferred):
     assert relerr(dw, ref) < 1e-5
 
 
-@pytest.mark.parametrize("cin,hid,N,H,W", [(16, 96, 2, 64, 64), (24, 144, 3, 32, 40), (32, 192, 2, 16, 24), (8, 48, 1, 4, 6), (24, 144, 1, 2, 4), (16, 96, 5, 8, 9)])
-def test_expand_bwd_fused_pw3(hip, cin, hid, N, H, W):
-    """sc_conv1x1_expand_bwd_pw3: data gradient and weight gradient of an expansion convolution from one pass over (g, y) of the
-    expanded tensor -- dx bit-identical to sc_conv1x1_pw3's backward-data launch (with the residual add and accumulation), dW
-    against autograd in float64"""
-    from hip_ops import conv_pw3, expand_bwd_pw3, pack_pw3
-    x = rnd(N, cin, H, W, seed=1, scale=2.0)
-    cst = torch.rand(cin, SC_CST, generator=torch.Generator().manual_seed(3)) + 0.5
-    xin = x.double() * cst[:, 0].double()[None, :, None, None] + cst[:, 1].double()[None, :, None, None]
-    w = rnd(hid, cin, 1, 1, seed=2, scale=0.3)
-    g, y = rnd(N, hid, H, W, seed=3) * 1e-3, rnd(N, hid, H, W, seed=4)
-    a, b = rnd(hid, seed=4) * 0.2 + 1, rnd(hid, seed=5) * 0.2 + 2.5
-    A, B, D = rnd(hid, seed=6) * 0.3 + 1, rnd(hid, seed=7) * 1e-4, rnd(hid, seed=8) * 1e-4
-    yh = y * a[None, :, None, None] + b[None, :, None, None]
-    gm = torch.where((yh > 0) & (yh < 6), g, torch.zeros(()))
-    dy = gm.double() * A.double()[None, :, None, None] + B.double()[None, :, None, None] * y.double() + D.double()[None, :, None, None]
-    cstb = torch.zeros(hid, SC_CST); cstb[:, 0], cstb[:, 1], cstb[:, 2], cstb[:, 3], cstb[:, 4] = a, b, A, B, D
-    dsrc = make_src(dev(g), hid, SRC_BNBWD, act=ACT_RELU6, cst=dev(cstb), aux=dev(y))
-    src = make_src(dev(x), cin, SRC_AFFINE, act=ACT_NONE, cst=dev(cst))
-    wt = pack_pw3(dev(w), 1)
-    res, old = rnd(N, cin, H, W, seed=9) * 1e-3, rnd(N, cin, H, W, seed=10) * 1e-3
-    dx_sep, _ = conv_pw3(dsrc, wt, N, H, W, cin, add0=dev(res), accum_into=dev(old.clone()))
-    dx, dw = expand_bwd_pw3(dsrc, src, wt, N, H, W, hid, cin, add0=dev(res), accum_into=dev(old.clone()))
-    assert torch.equal(dx, dx_sep)
-    assert relerr(dx, F.conv_transpose2d(dy, w.double()) + res.double() + old.double()) < 1e-5
-    assert relerr(dw, torch.einsum("nohw,nihw->oi", dy, xin)[:, :, None, None]) < 1e-5
-    dx2, dw2 = expand_bwd_pw3(dsrc, src, wt, N, H, W, hid, cin)
-    assert relerr(dx2, F.conv_transpose2d(dy, w.double())) < 1e-5 and torch.equal(dw2, dw)
-
-
-@pytest.mark.parametrize("cin,hid,cout,stride,N,H,W,xmode", [(16, 96, 24, 2, 2, 32, 48, "affine"), (24, 144, 24, 1, 2, 24, 40, "raw"), (64, 384, 64, 1, 3, 16, 16, "raw"),
-                                                             (96, 576, 160, 2, 2, 16, 32, "affine"), (160, 960, 320, 1, 2, 8, 8, "raw"), (32, 192, 64, 2, 1, 10, 6, "affine"),
-                                                             (24, 144, 32, 2, 1, 7, 9, "raw"), (16, 96, 24, 1, 1, 5, 3, "affine")])
-def test_inverted_residual_block_eval_fused(hip, cin, hid, cout, stride, N, H, W, xmode):
-    """sc_ir_block_eval: expand -> BN+ReLU6 -> depthwise (stride 1 | 2) -> BN+ReLU6 -> project in one launch, against the three
-    torch ops in float64 (eval-mode BatchNorm = per-channel affine); odd sizes exercise the tile borders and the zero padding of
-    the depthwise conv's activated input"""
-    from hip_ops import pack_pw3
-    lib = _lib.load()
-    assert lib.sc_ir_block_eval_supported(cin, hid, cout, stride) == 1
-    x = rnd(N, cin, H, W, seed=1, scale=2.0)
-    we, wd, wp = rnd(hid, cin, 1, 1, seed=2, scale=0.3), rnd(hid, 1, 3, 3, seed=3, scale=0.4), rnd(cout, hid, 1, 1, seed=4, scale=0.1)
-    g = torch.Generator().manual_seed(5)
-    ce, cd = torch.zeros(hid, SC_CST), torch.zeros(hid, SC_CST)
-    ce[:, 0], ce[:, 1] = torch.rand(hid, generator=g) + 0.5, torch.randn(hid, generator=g) * 0.5 + 1.0
-    cd[:, 0], cd[:, 1] = torch.rand(hid, generator=g) + 0.5, torch.randn(hid, generator=g) * 0.5 + 1.0
-    xin = x.double()
-    if xmode == "affine":
-        cx = torch.rand(cin, SC_CST, generator=g) + 0.5
-        src = make_src(dev(x), cin, SRC_AFFINE, act=ACT_NONE, cst=dev(cx))
-        xin = xin * cx[:, 0].double()[None, :, None, None] + cx[:, 1].double()[None, :, None, None]
-    else:
-        src = make_src(dev(x), cin, SRC_RAW)
-    e = torch.clamp(F.conv2d(xin, we.double()) * ce[:, 0].double()[None, :, None, None] + ce[:, 1].double()[None, :, None, None], 0, 6)
-    d = torch.clamp(F.conv2d(e, wd.double(), stride=stride, padding=1, groups=hid) * cd[:, 0].double()[None, :, None, None] + cd[:, 1].double()[None, :, None, None], 0, 6)
-    ref = F.conv2d(d, wp.double())
-    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    out = torch.full((N, cout, Ho, Wo), float("nan"), device=DEV)
-    pe, pp = pack_pw3(dev(we), 0), pack_pw3(dev(wp), 0)          # (kept alive: the launch reads them through raw pointers)
-    check(lib.sc_ir_block_eval(C.byref(src), ptr(pe), ptr(pp), ptr(dev(wd)), ptr(dev(ce)), ptr(dev(cd)), ptr(out),
-                               N, cin, hid, cout, H, W, stride, stream()))
-    assert out.shape == ref.shape and not torch.isnan(out).any()
-    assert relerr(out, ref) < 5e-6

@@ -168,7 +168,7 @@ def test_scene_tiles_square_and_strips():
 
 
 def test_pointwise_kernel_choice_rules():
-    """which pointwise family a launch takes (network._use_pw3 / _use_ebwd): pure host logic, measured per layer"""
+    """which pointwise family a launch takes (network._use_pw3): pure host logic, measured per layer"""
     from starcop_amd import network as nw
     if nw._PW3 != "1":
         pytest.skip("STARCOP_PW3 overridden")
@@ -176,4 +176,3 @@ def test_pointwise_kernel_choice_rules():
     assert not nw._use_pw3(0, 256, 960) and not nw._use_pw3(0, 65536, 16)                           # long K at 16^2; the 256^2 planes
     assert nw._use_pw3(1, 1024, 64) and not nw._use_pw3(1, 1024, 384)                               # projection vs expansion data gradients
     assert nw._use_pw3(2, 1024, 64, 384) and not nw._use_pw3(2, 1024, 96, 576) and not nw._use_pw3(2, 4, 64, 384)   # H*W % 8
-    assert not nw._use_ebwd(65536, 16, 96) or nw._PW3_EBWD                                          # opt-in
