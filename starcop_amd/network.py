@@ -115,26 +115,39 @@ def _pick_cot(M, ks=1):
     return 64 if p64 <= p32 * (_COT_RATIO3 if ks == 3 else _COT_RATIO) else 32
 
 
-# Pointwise convolutions on sc_conv1x1_pw3 / sc_conv1x1_wgrad_pw3 (conv_pw3.hip: split-bf16 MFMA, register-only, no LDS staging).
-# Measured per layer against k_conv_mfma<1> / k_conv1_ksplit / k_wgrad_mfma<1> at batch 16 (tools/bench_layers.py):
-# it wins where the K loop is short and the plane small (the projections' data gradients 22 -> 18 us, the 16^2 expansions 29 -> 22,
-# features.18 58 -> 38) and loses on long K loops (its waves do not split K) and on the 128^2 / 256^2 planes.  "1" = the measured
-# rule below, "all" = every pointwise launch (the tests run both), "0" = off.
+# Pointwise convolutions on sc_conv1x1_pw3 / sc_conv1x1_wgrad_pw3 (conv_pw3.hip: split-bf16 MFMA, register-only, no LDS staging)
+# or on k_conv_mfma<1> / k_conv1_ksplit / k_wgrad_mfma<1> (fp32 MFMA, LDS staging, K split over the waves of a work-group).
+# Measured per layer and pass at batch 4, 16 and 64 (tools/bench_layers.py with STARCOP_PW3=all against =0: profiles/r03a/b_layers_*,
+# profiles/r04_layers_b{4,64}_pw3_{all,0}.txt).  What decides is the plane (H*W), the contraction length K and -- new in round 4 --
+# how many waves the launch has: the register-only family does not split K, so a long contraction only pays once
+# (32-pixel blocks of the batch) x (32-channel output blocks) fills the machine:
+#   forward        planes up to 64^2; K <= 320 always, longer K from 1024 (pixel block, output block) pairs
+#                  (batch 4: the 32^2 / 16^2 projections stay on the K-splitting kernel, 15-21 vs 23-43 us; batch 64: every one moves
+#                  over, 72 vs 103 us on features.15-17)
+#   backward-data  K <= 192 (the projections' gradients) on planes up to 64^2 while the batch has <= 131072 pixels of that plane size;
+#                  longer K (the expansions' gradients) at <= 32^2 from 2048 pairs (batch 64: 48 vs 73, 83 vs 130, 148 vs 222 us;
+#                  batch 16 and 4: the other family, 27 vs 32, 38 vs 68)
+#   backward-weight  planes up to 32^2 of at most 32768 batch pixels, small filters (K*M bounds as measured at batch 16)
+# "1" = these rules, "all" = every pointwise launch (the tests run both), "0" = off.
 _PW3 = os.environ.get("STARCOP_PW3", "1")
 
 
-def _use_pw3(which, HW, K=0, M=0):
-    """which: 0 forward, 1 backward-data (K = the layer's output channels), 2 backward-weight (K, M = Cin, Cout; it reads 8-pixel
-    groups: H*W % 8 == 0).  K = contraction length of the launch."""
+def _use_pw3(which, N, HW, Cin, Cout):
+    """which: 0 forward, 1 backward-data, 2 backward-weight (reads 8-pixel groups: H*W % 8 == 0) of a Cin -> Cout pointwise layer on
+    N planes of HW pixels"""
     if _PW3 == "0" or (which == 2 and HW % 8):
         return False
     if _PW3 == "all":
         return True
+    NP = N * HW
+    npb = -(-NP // 32)
     if which == 0:
-        return HW <= 4096 and (K <= 320 or (K <= 576 and HW >= 1024))
+        return HW <= 4096 and (Cin <= 320 or npb * (-(-Cout // 32)) >= 1024)
     if which == 1:
-        return HW <= 4096 and K <= 192
-    return HW <= 1024 and K * M <= 300000 and (HW <= 256 or K * M <= 32768)
+        K, MB = Cout, -(-Cin // 32)
+        return (K <= 192 and HW <= 4096 and NP <= 131072) or (K > 192 and HW <= 1024 and npb * MB >= 2048)
+    KM = Cin * Cout
+    return HW <= 1024 and NP <= 32768 and KM <= 300000 and (HW <= 256 or KM <= 32768)
 
 
 # Fused TRAINING execution of the expansion + depthwise pair of a stride-2 inverted-residual block (conv_irt.hip: the 6x-expanded
@@ -463,7 +476,7 @@ class HyperStarcopUNet(nn.Module):
                     Ho, Wo = H >> t.shift, W >> t.shift
                     # per-work-group partial rows [rows][C][2] (plain stores; summed in fp64 by the finalize kernels)
                     kind = kind_of[op["type"]]
-                    if op["type"] == "pw" and _use_pw3(0, Ho * Wo, op["conv"].in_channels):
+                    if op["type"] == "pw" and _use_pw3(0, N, Ho * Wo, op["conv"].in_channels, op["conv"].out_channels):
                         kind = STAT_PW3
                     elif op["type"] == "pw" and _use_ksplit(N, Ho * Wo, op["conv"].in_channels, op["conv"].out_channels):
                         kind = STAT_CONV1K
@@ -481,7 +494,7 @@ class HyperStarcopUNet(nn.Module):
                     hw = (H >> op["out"].shift) * (W >> op["out"].shift)
                     for tflip in (0, 1):
                         cv = op["conv"]
-                        lay = "pw3" if _use_pw3(tflip, hw, cv.out_channels if tflip else cv.in_channels) else "mfma"
+                        lay = "pw3" if _use_pw3(tflip, N, hw, cv.in_channels, cv.out_channels) else "mfma"
                         if lay not in need.setdefault((i, tflip), set()):
                             need[(i, tflip)].add(lay)
                             self._pack_version = None
@@ -542,7 +555,7 @@ class HyperStarcopUNet(nn.Module):
                         conv, o = op["conv"], op["out"]
                         Hq, Wq = H >> o.shift, W >> o.shift
                         nfl = (lib.sc_wgrad_pw3_workspace_floats(N, Hq, Wq, conv.out_channels, conv.in_channels)
-                               if _use_pw3(2, Hq * Wq, conv.in_channels, conv.out_channels)
+                               if _use_pw3(2, N, Hq * Wq, conv.in_channels, conv.out_channels)
                                else lib.sc_wgrad_workspace_floats(N, Hq, Wq, conv.out_channels, conv.in_channels, 1))
                         plan.pw_part[i] = torch.empty(nfl, **f32)
             plan.up_tmp = torch.empty(max(up, 1), **f32)
@@ -767,7 +780,7 @@ class HyperStarcopUNet(nn.Module):
                 a.add0 = None; a.add1 = None
                 a.stats = plan.stats_v[o.name].data_ptr() if stats is not None else None
                 a.terms = ent["terms_f"]
-                if ty == "pw" and _use_pw3(0, Ho * Wo, conv.in_channels):
+                if ty == "pw" and _use_pw3(0, N, Ho * Wo, conv.in_channels, conv.out_channels):
                     fconv = lib.sc_conv1x1_pw3
                     a.wpk = ent["pf"].data_ptr()
                 elif ent["tf"] is not None:
@@ -1115,7 +1128,7 @@ class HyperStarcopUNet(nn.Module):
             if ty == "pw" and i in plan.pw_part:
                 wa.part = plan.pw_part[i].data_ptr(); wa.part_floats = plan.pw_part[i].numel()
                 pend = sc_wgrad_pending()
-                wdef = (lib.sc_conv1x1_wgrad_pw3 if _use_pw3(2, Ho * Wo, conv.in_channels, conv.out_channels)
+                wdef = (lib.sc_conv1x1_wgrad_pw3 if _use_pw3(2, N, Ho * Wo, conv.in_channels, conv.out_channels)
                         else lib.sc_conv2d_wgrad_mfma_deferred)
                 wgrad_launch(lambda sx, wa=wa, pend=pend, wdef=wdef: check(wdef(C.byref(wa), C.byref(pend), sx)))
                 pw_pending.append(pend)
@@ -1136,7 +1149,7 @@ class HyperStarcopUNet(nn.Module):
             a.absmax = gmax_slot.get(o.name)
             if ent["bx3_b"]:
                 conv_dgrad = lib.sc_conv3x3_bx3
-            elif ty == "pw" and _use_pw3(1, Ho * Wo, conv.out_channels):
+            elif ty == "pw" and _use_pw3(1, N, Ho * Wo, conv.in_channels, conv.out_channels):
                 conv_dgrad = lib.sc_conv1x1_pw3
                 a.wpk = ent["pb"].data_ptr()
             elif _use_ksplit(N, Ho * Wo, conv.out_channels, conv.in_channels, ks):

@@ -168,11 +168,22 @@ def test_scene_tiles_square_and_strips():
 
 
 def test_pointwise_kernel_choice_rules():
-    """which pointwise family a launch takes (network._use_pw3): pure host logic, measured per layer"""
+    """which pointwise family a launch takes (network._use_pw3): pure host logic, measured per layer and pass at batch 4 / 16 / 64
+    (profiles/r03a-b_layers_*, profiles/r04_layers_b*_pw3_*.txt)"""
     from starcop_amd import network as nw
     if nw._PW3 != "1":
         pytest.skip("STARCOP_PW3 overridden")
-    assert nw._use_pw3(0, 1024, 64) and nw._use_pw3(0, 256, 160) and nw._use_pw3(0, 256, 320)       # 32^2 / 16^2 expansions, features.18
-    assert not nw._use_pw3(0, 256, 960) and not nw._use_pw3(0, 65536, 16)                           # long K at 16^2; the 256^2 planes
-    assert nw._use_pw3(1, 1024, 64) and not nw._use_pw3(1, 1024, 384)                               # projection vs expansion data gradients
-    assert nw._use_pw3(2, 1024, 64, 384) and not nw._use_pw3(2, 1024, 96, 576) and not nw._use_pw3(2, 4, 64, 384)   # H*W % 8
+    u = nw._use_pw3
+    # batch 16 (the benched configuration): 32^2 / 16^2 expansions and features.18 forward on the register-only family, the long
+    # contractions at 16^2 and the 256^2 planes not; the projections' data gradients yes, the expansions' no
+    assert u(0, 16, 1024, 64, 384) and u(0, 16, 256, 160, 960) and u(0, 16, 256, 320, 1280) and u(0, 16, 1024, 576, 96)
+    assert not u(0, 16, 256, 960, 160) and not u(0, 16, 65536, 16, 96) and not u(0, 16, 256, 576, 160)
+    assert u(1, 16, 1024, 384, 64) and not u(1, 16, 1024, 64, 384) and not u(1, 16, 256, 160, 960)
+    assert u(2, 16, 1024, 64, 384) and not u(2, 16, 1024, 96, 576) and not u(2, 16, 4, 64, 384)          # H*W % 8
+    # batch 4: a long contraction has too few (pixel block, output block) pairs: the K-splitting kernel keeps the 32^2 / 16^2 projections
+    assert not u(0, 4, 1024, 576, 96) and not u(0, 4, 256, 960, 160) and not u(0, 4, 1024, 384, 96) and u(0, 4, 1024, 64, 384)
+    assert u(1, 4, 1024, 384, 64) and not u(1, 4, 256, 160, 960)
+    # batch 64: every 32^2 / 16^2 layer moves over, forward and backward-data (72 vs 103, 83 vs 130 us on features.15-17); the 64^2
+    # projections' data gradients and the large-batch weight gradients go back to the LDS-staged kernels
+    assert u(0, 64, 256, 960, 160) and u(0, 64, 1024, 576, 96) and u(1, 64, 256, 160, 960) and u(1, 64, 1024, 64, 384)
+    assert not u(1, 64, 4096, 192, 32) and u(1, 64, 1024, 384, 64) and not u(2, 64, 1024, 64, 384) and u(2, 64, 256, 160, 960)
