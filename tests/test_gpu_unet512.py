@@ -168,7 +168,10 @@ def test_bf16_mode_trains_like_fp32_at_512(hip):
     assert l32[S] < 0.05 * l32[0] and l16[S] < 0.05 * l16[0]                      # both fit the tiles
     assert abs(l16[0] - l32[0]) < 2e-2 * l32[0]                                   # same start: bf16 rounding only
     assert max(abs(a - b) for a, b in zip(l32[:S], l16[:S])) < 0.02               # and the same trajectory up to the comparison
-    assert f1["fp32"] > 0.98 and f1["bf16"] > 0.98 and abs(f1["bf16"] - f1["fp32"]) <= 0.005, f1
+    # both modes have fitted the tiles at S, and over the last five common snapshots (where both are still converging, so the level
+    # itself is lower) their masks agree in F1 within SURVEY 8d's 0.005
+    assert f1_S["fp32"] > 0.98 and f1_S["bf16"] > 0.98, f1_S
+    assert abs(f1["bf16"] - f1["fp32"]) <= 0.005, f1
 
 
 # BASELINE.json configs[3]: "4ch U-Net bf16, batch=64/GPU".  The per-GPU shape of that configuration, against the oracle.
