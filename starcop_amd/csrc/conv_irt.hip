@@ -248,127 +248,157 @@ __global__ __launch_bounds__(256) void k_irt_fwd(const IrtP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* s_e = reinterpret_cast<float*>(smem);              // [32][EPAD]
   float* s_xc = s_e + 32 * EPAD;                            // [32][2]
+  float* s_kc = s_xc + 64;                                  // [nch*32][12]: BN_e scale, shift, depthwise taps [9], pad
+  uintx4* s_w = reinterpret_cast<uintx4*>(s_kc + (size_t)p.nch * 32 * 12);      // [nch][NKS][3][64] split filter operands
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int tile = blockIdx.x;
-  const int n = tile / (p.tiles_x * p.tiles_y), tt = tile - n * p.tiles_x * p.tiles_y;
-  const int oy0 = (tt / p.tiles_x) * TH, ox0 = (tt % p.tiles_x) * TW;
-  const int ey0 = oy0 * S - 1, ex0 = ox0 * S - 1;
   const int H = p.H, W = p.W, Hd = p.Hd;
   const size_t HW = (size_t)H * W, HWo = (size_t)p.Ho * p.Wo;
+  // ---------------- once per (persistent) work-group: the tables of every chunk.  (The first version did this per output tile:
+  // 4096 tiles x 3 chunks of filter loads + splits and scalar loads of the taps in the stencil loop: 140 us on features.2.)
+  for (int ch = wave; ch < p.nch; ch += 4) {
+    uintx4 op[NKS][3];
+    irt_wop<NKS>(p, ch * 32 + l31, lhi, op);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) s_w[((size_t)(ch * NKS + ks) * 3 + t) * 64 + lane] = op[ks][t];
+  }
+  for (int i = tid; i < p.nch * 32; i += 256) {
+    const bool ok = i < Hd;
+    const int hc = ok ? i : Hd - 1;
+    float* k = s_kc + i * 12;
+    k[0] = p.cst_e[(size_t)hc * SC_CST]; k[1] = p.cst_e[(size_t)hc * SC_CST + 1];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) k[2 + t] = ok ? p.wd[(size_t)hc * 9 + t] : 0.f;
+    k[11] = 0.f;
+  }
   irt_xconsts(p, s_xc);
   __syncthreads();
   const float lo = sc_act_lo(p.x.act), hi = sc_act_hi(p.x.act);
-  // the x operands of this wave's pixel blocks and the inside-the-image bits of its accumulator pixels
-  uintx4 xop[BPW][NKS][3];
-  unsigned inside[BPW];
-#pragma unroll
-  for (int b = 0; b < BPW; ++b) {
-    const int blk = wave + 4 * b;
-    const int f = blk * 32 + l31;
-    const int ey = f / EW, ex = f - ey * EW;
-    const int y = ey0 + ey, x = ex0 + ex;
-    const bool ok = blk < NBLK && f < EPX && y >= 0 && y < H && x >= 0 && x < W;
-    irt_xop<NKS>(p, s_xc, p.x.x + (size_t)n * p.Cin * HW + (ok ? (size_t)y * W + x : 0), ok, lhi, lo, hi, HW, xop[b]);
-    unsigned bits = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      // accumulator registers 4 j .. 4 j + 3 = four consecutive flattened pixels: one division, then a walk along the row
-      const int f0 = blk * 32 + 8 * j + 4 * lhi;
-      int eyi = f0 / EW, exi = f0 - eyi * EW;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int yi = ey0 + eyi, xi = ex0 + exi;
-        if (f0 + q < EPX && yi >= 0 && yi < H && xi >= 0 && xi < W) bits |= 1u << (4 * j + q);
-        if (++exi == EW) { exi = 0; ++eyi; }
-      }
-    }
-    inside[b] = bits;
-  }
-  // output pixels of this lane (phase 2)
-  const int lox = lane % TW, lrg = lane / TW;                 // column, row group
-  const int oyl = lrg * RPL;                                  // first output row of the lane within the tile
-  const bool colok = ox0 + lox < p.Wo;
+  const int lox = lane % TW, lrg = lane / TW;                 // phase 2: column, row group of this lane's output pixels
+  const int oyl = lrg * RPL;
 
-  for (int chunk = 0; chunk < p.nch; ++chunk) {
-    // ---------------- phase 1
-    {
-      const int h = chunk * 32 + l31;
-      uintx4 wop[NKS][3];
-      irt_wop<NKS>(p, h, lhi, wop);
-      const int hc = h < Hd ? h : Hd - 1;
-      const float sc = p.cst_e[(size_t)hc * SC_CST], sh = p.cst_e[(size_t)hc * SC_CST + 1];
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const int n = tile / (p.tiles_x * p.tiles_y), tt = tile - n * p.tiles_x * p.tiles_y;
+    const int oy0 = (tt / p.tiles_x) * TH, ox0 = (tt % p.tiles_x) * TW;
+    const int ey0 = oy0 * S - 1, ex0 = ox0 * S - 1;
+    // the x operands of this wave's pixel blocks and the inside-the-image bits of its accumulator pixels
+    uintx4 xop[BPW][NKS][3];
+    unsigned inside[BPW];
 #pragma unroll
-      for (int b = 0; b < BPW; ++b) {
-        const int blk = wave + 4 * b;
-        if (blk < NBLK) {
-          floatx16 acc = zero16();
+    for (int b = 0; b < BPW; ++b) {
+      const int blk = wave + 4 * b;
+      const int f = blk * 32 + l31;
+      const int ey = f / EW, ex = f - ey * EW;
+      const int y = ey0 + ey, x = ex0 + ex;
+      const bool ok = blk < NBLK && f < EPX && y >= 0 && y < H && x >= 0 && x < W;
+      irt_xop<NKS>(p, s_xc, p.x.x + (size_t)n * p.Cin * HW + (ok ? (size_t)y * W + x : 0), ok, lhi, lo, hi, HW, xop[b]);
+      unsigned bits = 0;
 #pragma unroll
-          for (int ks = 0; ks < NKS; ++ks) acc = mfma6(xop[b][ks], wop[ks], acc);        // rows = pixels, columns = hidden channels
-          float* dst = s_e + l31 * EPAD + blk * 32 + 4 * lhi;
+      for (int j = 0; j < 4; ++j) {
+        // accumulator registers 4 j .. 4 j + 3 = four consecutive flattened pixels: one division, then a walk along the row
+        const int f0 = blk * 32 + 8 * j + 4 * lhi;
+        int eyi = f0 / EW, exi = f0 - eyi * EW;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float4 v;
-            float* vv = reinterpret_cast<float*>(&v);
+        for (int q = 0; q < 4; ++q) {
+          const int yi = ey0 + eyi, xi = ex0 + exi;
+          if (f0 + q < EPX && yi >= 0 && yi < H && xi >= 0 && xi < W) bits |= 1u << (4 * j + q);
+          if (++exi == EW) { exi = 0; ++eyi; }
+        }
+      }
+      inside[b] = bits;
+    }
+    const bool colok = ox0 + lox < p.Wo;
+    int zt = 0;                                               // opaque zero: keeps the tile-invariant LDS table reads inside the loop
+    asm volatile("" : "+v"(zt));                              // (hoisted, they pin a register set per chunk: 219 registers)
+
+    for (int chunk = 0; chunk < p.nch; ++chunk) {
+      // ---------------- phase 1
+      {
+        const float2 cs = *reinterpret_cast<const float2*>(s_kc + (chunk * 32 + l31) * 12 + zt);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float t = fminf(fmaxf(fmaf(acc[4 * j + q], sc, sh), 0.f), 6.f);
-              vv[q] = ((inside[b] >> (4 * j + q)) & 1u) ? t : 0.f;
+        for (int b = 0; b < BPW; ++b) {
+          const int blk = wave + 4 * b;
+          if (blk < NBLK) {
+            floatx16 acc = zero16();
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+              uintx4 w[3];
+#pragma unroll
+              for (int t = 0; t < 3; ++t) w[t] = s_w[((chunk * NKS + ks) * 3 + t) * 64 + lane + zt];
+              acc = mfma6(xop[b][ks], w, acc);               // rows = pixels, columns = hidden channels
             }
-            *reinterpret_cast<float4*>(dst + 8 * j) = v;
+            float* dst = s_e + l31 * EPAD + blk * 32 + 4 * lhi;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float4 v;
+              float* vv = reinterpret_cast<float*>(&v);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float t = fminf(fmaxf(fmaf(acc[4 * j + q], cs.x, cs.y), 0.f), 6.f);
+                vv[q] = ((inside[b] >> (4 * j + q)) & 1u) ? t : 0.f;
+              }
+              *reinterpret_cast<float4*>(dst + 8 * j) = v;
+            }
           }
         }
       }
-    }
-    __syncthreads();
-    // ---------------- phase 2
+      __syncthreads();
+      // ---------------- phase 2
 #pragma unroll 2
-    for (int cc = 0; cc < 8; ++cc) {
-      const int cl = wave * 8 + cc;
-      const int h = chunk * 32 + cl;                          // wave-uniform
-      if (h < Hd) {
-        float wk[9];
+      for (int cc = 0; cc < 8; ++cc) {
+        const int cl = wave * 8 + cc;
+        const int h = chunk * 32 + cl;                          // wave-uniform
+        if (h < Hd) {
+          float wk[9];
+          {
+            const float* kq = s_kc + (chunk * 32 + cl) * 12 + 2 + zt;      // broadcast reads
 #pragma unroll
-        for (int k = 0; k < 9; ++k) wk[k] = p.wd[(size_t)h * 9 + k];
-        const float* e = s_e + cl * EPAD + (oyl * S) * EW + lox * S;
-        float s1 = 0.f, s2 = 0.f;
-        if (S == 1) {
-          // sliding window down RPL rows of the lane's column
-          float r0[3], r1[3], r2[3];
+            for (int k = 0; k < 9; ++k) wk[k] = kq[k];
+          }
+          const float* e = s_e + cl * EPAD + (oyl * S) * EW + lox * S;
+          float s1 = 0.f, s2 = 0.f;
+          if (S == 1) {
+            // sliding window down RPL rows of the lane's column
+            float r0[3], r1[3], r2[3];
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) { r0[kx] = e[kx]; r1[kx] = e[EW + kx]; }
+            for (int kx = 0; kx < 3; ++kx) { r0[kx] = e[kx]; r1[kx] = e[EW + kx]; }
 #pragma unroll
-          for (int rr = 0; rr < RPL; ++rr) {
+            for (int rr = 0; rr < RPL; ++rr) {
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) r2[kx] = e[(rr + 2) * EW + kx];
+              for (int kx = 0; kx < 3; ++kx) r2[kx] = e[(rr + 2) * EW + kx];
+              float a = 0.f;
+#pragma unroll
+              for (int kx = 0; kx < 3; ++kx) { a = fmaf(wk[kx], r0[kx], a); a = fmaf(wk[3 + kx], r1[kx], a); a = fmaf(wk[6 + kx], r2[kx], a); }
+              const int oy = oy0 + oyl + rr;
+              const bool ok = colok && oy < p.Ho;
+              if (ok) p.dout[((size_t)n * Hd + h) * HWo + (size_t)oy * p.Wo + ox0 + lox] = a;
+              const float am = ok ? a : 0.f;
+              s1 += am; s2 = fmaf(am, am, s2);
+#pragma unroll
+              for (int kx = 0; kx < 3; ++kx) { r0[kx] = r1[kx]; r1[kx] = r2[kx]; }
+            }
+          } else {
             float a = 0.f;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) { a = fmaf(wk[kx], r0[kx], a); a = fmaf(wk[3 + kx], r1[kx], a); a = fmaf(wk[6 + kx], r2[kx], a); }
-            const int oy = oy0 + oyl + rr;
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+              for (int kx = 0; kx < 3; ++kx) a = fmaf(wk[ky * 3 + kx], e[ky * EW + kx], a);
+            const int oy = oy0 + oyl;
             const bool ok = colok && oy < p.Ho;
             if (ok) p.dout[((size_t)n * Hd + h) * HWo + (size_t)oy * p.Wo + ox0 + lox] = a;
             const float am = ok ? a : 0.f;
-            s1 += am; s2 = fmaf(am, am, s2);
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) { r0[kx] = r1[kx]; r1[kx] = r2[kx]; }
+            s1 = am; s2 = am * am;
           }
-        } else {
-          float a = 0.f;
-#pragma unroll
-          for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) a = fmaf(wk[ky * 3 + kx], e[ky * EW + kx], a);
-          const int oy = oy0 + oyl;
-          const bool ok = colok && oy < p.Ho;
-          if (ok) p.dout[((size_t)n * Hd + h) * HWo + (size_t)oy * p.Wo + ox0 + lox] = a;
-          const float am = ok ? a : 0.f;
-          s1 = am; s2 = am * am;
+          if (p.stats) {
+            const float t1 = wave_total(s1), t2 = wave_total(s2);
+            if (lane == 0) *reinterpret_cast<float2*>(p.stats + ((size_t)tile * Hd + h) * 2) = make_float2(t1, t2);
+          }
         }
-        const float t1 = wave_total(s1), t2 = wave_total(s2);
-        if (p.stats && lane == 0) *reinterpret_cast<float2*>(p.stats + ((size_t)tile * Hd + h) * 2) = make_float2(t1, t2);
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
 }
 
@@ -996,9 +1026,14 @@ extern "C" int sc_irt_fwd(const sc_irt_args* a, float* d_out, float* stats_d, sc
   p.ntiles = irt_fwd_tiles(p.N, p.H, p.W, p.S, &p.tiles_x, &p.tiles_y);
   const int nks = (p.Cin + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = (size_t)(32 * IrtFwdGeo<2>::EPAD + 64) * 4;
-  if (nks == 1) { irt_lds_attr(&k_irt_fwd<1, 2>, lds); hipLaunchKernelGGL((k_irt_fwd<1, 2>), dim3(p.ntiles), dim3(256), lds, st, p); }
-  else { irt_lds_attr(&k_irt_fwd<2, 2>, lds); hipLaunchKernelGGL((k_irt_fwd<2, 2>), dim3(p.ntiles), dim3(256), lds, st, p); }
+  const size_t lds = (size_t)(32 * IrtFwdGeo<2>::EPAD + 64 + p.nch * 32 * 12) * 4 + (size_t)p.nch * nks * 3 * 64 * 16;
+  // persistent work-groups: as many as fit the chip at this LDS size (160 KB per CU), at most one per tile
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 4) per_cu = 4;
+  const int wgs = p.ntiles < 256 * per_cu ? p.ntiles : 256 * per_cu;
+  if (nks == 1) { irt_lds_attr(&k_irt_fwd<1, 2>, lds); hipLaunchKernelGGL((k_irt_fwd<1, 2>), dim3(wgs), dim3(256), lds, st, p); }
+  else { irt_lds_attr(&k_irt_fwd<2, 2>, lds); hipLaunchKernelGGL((k_irt_fwd<2, 2>), dim3(wgs), dim3(256), lds, st, p); }
   SC_LAUNCH_OK("sc_irt_fwd");
   return SC_OK;
 }
