@@ -983,7 +983,14 @@ int irt_fill(IrtP& p, const sc_irt_args* a, const char* who) {
 }
 template <typename K>
 void irt_lds_attr(K kern, size_t lds) {
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  // once per kernel (the pointer identifies the instantiation); not a stream operation, so it is safe under graph capture too
+  static const void* done[16];
+  static int ndone = 0;
+  if (lds <= 64 * 1024) return;
+  const void* f = reinterpret_cast<const void*>(kern);
+  for (int i = 0; i < ndone; ++i) if (done[i] == f) return;
+  (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (ndone < 16) done[ndone++] = f;
 }
 
 }  // namespace
