@@ -187,3 +187,23 @@ def test_pointwise_kernel_choice_rules():
     # projections' data gradients and the large-batch weight gradients go back to the LDS-staged kernels
     assert u(0, 64, 256, 960, 160) and u(0, 64, 1024, 576, 96) and u(1, 64, 256, 160, 960) and u(1, 64, 1024, 64, 384)
     assert not u(1, 64, 4096, 192, 32) and u(1, 64, 1024, 384, 64) and not u(2, 64, 1024, 64, 384) and u(2, 64, 256, 160, 960)
+
+
+def test_fused_block_rule():
+    """where the expansion + depthwise pair of an inverted-residual block trains without its 6x tensor (network._use_irt, measured per
+    block: DESIGN.md 14): the stride-2 blocks on planes of at least 256^2 -- features.2 at 512^2 tiles -- and nothing the kernels do not
+    take (stride 1, Cin not a multiple of 8 or > 32, hidden > 192); pure host logic + the library's host-side sc_irt_supported"""
+    from starcop_amd import network as nw
+    if nw._IRT != "1":
+        pytest.skip("STARCOP_IRT overridden")
+    assert nw._use_irt(16, 96, 256, 256, 2)                        # features.2 at 512^2 tiles
+    assert not nw._use_irt(24, 144, 128, 128, 2)                   # features.4: measured slower (414 vs 341 us)
+    assert not nw._use_irt(16, 96, 64, 64, 2)                      # features.2 at 128^2 crops
+    assert not nw._use_irt(24, 144, 256, 256, 1)                   # stride 1 is not built
+    from starcop_amd import _lib
+    lib = _lib.load()
+    assert lib.sc_irt_supported(32, 192, 64, 64, 2) == 1 and lib.sc_irt_supported(32, 192, 64, 64, 1) == 0
+    assert lib.sc_irt_supported(64, 384, 32, 32, 2) == 0 and lib.sc_irt_supported(20, 120, 32, 32, 2) == 0 and lib.sc_irt_supported(32, 224, 32, 32, 2) == 0
+    # rows / workspace are pure functions of the shape
+    assert lib.sc_irt_rows(1, 16, 256, 256, 2) == 16 * 32 * 8 and lib.sc_irt_bwd_rows(16, 96, 256, 256) == 512
+    assert lib.sc_irt_bwd_workspace_floats(16, 16, 96, 256, 256) > 16 * 16 * 256 * 256
