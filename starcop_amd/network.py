@@ -151,17 +151,22 @@ def _use_pw3(which, N, HW, Cin, Cout):
 
 
 # Fused TRAINING execution of the expansion + depthwise pair of a stride-2 inverted-residual block (conv_irt.hip: the 6x-expanded
-# tensor and its gradient are never stored, every sweep recomputes it from the block input).  Measured per block at batch 16
-# (tools/bench_irt.py against the launches it replaces, tools/bench_layers.py): features.2 (16 -> 96 channels at 256^2, the expanded
-# tensor is 403 MB) 632 vs 835 us; features.4 (128^2) 406 vs 341, features.7 (64^2) 245 vs 143 -- the recomputation pays where the
-# expanded tensor is much larger than everything else the block touches.  "1" = that rule, "all" = every supported block (tests), "0" = off.
+# tensor and its gradient are never stored, every sweep recomputes it from the block input).  Measured per block (tools/bench_irt.py
+# against the launches it replaces, tools/bench_layers.py) and on the whole step (bench.py with STARCOP_IRT=1 / 0, same box):
+#   batch 16: features.2 (16 -> 96 channels at 256^2: e = 403 MB) 610 vs 835 us, step +1.3-1.5 %; features.4 (128^2, 151 MB) 414 vs
+#             341, features.7 (64^2) 244 vs 143
+#   batch 64: features.2 (1.6 GB) step +2.5 % (1555 vs 1517 tiles/s); features.4 (604 MB) 1292 vs 1278: a tie; features.7 loses
+#   batch  4: features.2 (101 MB -- the tensor lives in the 256 MB Infinity Cache, the separate kernels' passes over it are cache
+#             hits) step -4..6 % (641 vs 674 tiles/s)
+# so the recomputation pays where the expanded tensor is large against the cache AND the plane is large: planes >= 256^2 whose e is
+# >= 256 MB.  "1" = that rule, "all" = every supported block (tests), "0" = off.
 _IRT = os.environ.get("STARCOP_IRT", "1")
 
 
-def _use_irt(Cin, Hd, Hin, Win, stride):
+def _use_irt(N, Cin, Hd, Hin, Win, stride):
     if _IRT == "0" or not _lib.load().sc_irt_supported(Cin, Hd, Hin, Win, stride):
         return False
-    return _IRT == "all" or Hin * Win >= 65536
+    return _IRT == "all" or (Hin * Win >= 65536 and 4 * N * Hd * Hin * Win >= (256 << 20))
 
 
 def _use_ksplit(N, HW, K, M, ks=1):
@@ -462,7 +467,7 @@ class HyperStarcopUNet(nn.Module):
             if self.fuse_irt:
                 for i_e, (i_dw, i_pr, stride) in self._ir_blocks.items():
                     cv, tin = self._ops[i_e]["conv"], self._ops[i_e]["ins"][0]
-                    if tin.kind != "input" and _use_irt(cv.in_channels, cv.out_channels, H >> tin.shift, W >> tin.shift, stride):
+                    if tin.kind != "input" and _use_irt(N, cv.in_channels, cv.out_channels, H >> tin.shift, W >> tin.shift, stride):
                         plan.irt[i_e], plan.irt_of_dw[i_dw] = i_dw, i_e
                         te, td = self._ops[i_e]["out"], self._ops[i_dw]["out"]
                         plan.irt_rows[te.name] = lib.sc_irt_rows(0, N, H >> tin.shift, W >> tin.shift, stride)

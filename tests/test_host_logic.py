@@ -191,15 +191,18 @@ def test_pointwise_kernel_choice_rules():
 
 def test_fused_block_rule():
     """where the expansion + depthwise pair of an inverted-residual block trains without its 6x tensor (network._use_irt, measured per
-    block: DESIGN.md 14): the stride-2 blocks on planes of at least 256^2 -- features.2 at 512^2 tiles -- and nothing the kernels do not
+    block and batch: DESIGN.md 14): stride-2 blocks on planes of at least 256^2 whose expanded tensor is at least 256 MB -- features.2
+    at 512^2 tiles from batch 11 -- and nothing the kernels do not
     take (stride 1, Cin not a multiple of 8 or > 32, hidden > 192); pure host logic + the library's host-side sc_irt_supported"""
     from starcop_amd import network as nw
     if nw._IRT != "1":
         pytest.skip("STARCOP_IRT overridden")
-    assert nw._use_irt(16, 96, 256, 256, 2)                        # features.2 at 512^2 tiles
-    assert not nw._use_irt(24, 144, 128, 128, 2)                   # features.4: measured slower (414 vs 341 us)
-    assert not nw._use_irt(16, 96, 64, 64, 2)                      # features.2 at 128^2 crops
-    assert not nw._use_irt(24, 144, 256, 256, 1)                   # stride 1 is not built
+    assert nw._use_irt(16, 16, 96, 256, 256, 2) and nw._use_irt(64, 16, 96, 256, 256, 2)      # features.2 at 512^2 tiles, batch 16 / 64
+    assert not nw._use_irt(4, 16, 96, 256, 256, 2)                 # batch 4: e = 101 MB sits in the Infinity Cache (step -5 %)
+    assert not nw._use_irt(16, 24, 144, 128, 128, 2)               # features.4: measured slower (414 vs 341 us)
+    assert not nw._use_irt(64, 24, 144, 128, 128, 2)               # ... and a tie at batch 64
+    assert not nw._use_irt(16, 16, 96, 64, 64, 2)                  # features.2 at 128^2 crops
+    assert not nw._use_irt(16, 24, 144, 256, 256, 1)               # stride 1 is not built
     from starcop_amd import _lib
     lib = _lib.load()
     assert lib.sc_irt_supported(32, 192, 64, 64, 2) == 1 and lib.sc_irt_supported(32, 192, 64, 64, 1) == 0
