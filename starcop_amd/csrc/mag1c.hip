@@ -328,7 +328,8 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 4) void k_mag1c(const Mag1cP p)
 //   M = [[0,-1],[-1,q]]:  (C_0 + U M U^T)^{-1} b = B0 b - B0 U (M^{-1} + U^T B0 U)^{-1} U^T B0 b
 // Per iteration: two mat-vecs (W v, W t_new; W tau is last iteration's W t_new), a 2x2 solve, two streaming passes.
 // NT threads per group (1024: the 125 KB matrix in LDS allows one work-group per CU, so the work-group itself has to fill it)
-template <typename T, int NT>
+// SPLIT: launched as a pair with k_mag1c_res (below); this kernel then leaves the groups that one takes
+template <typename T, int NT, bool SPLIT = false>
 __global__ __launch_bounds__(NT) void k_mag1c_fast(const Mag1cP p) {
   constexpr int NW = NT / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(NT) void k_mag1c_fast(const Mag1cP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int P = p.P[g], pitch = p.Ppad[g];
   if (P <= 0) return;                                     // skipped group (sc_mag1c_layout_columns: too few valid pixels)
+  if (SPLIT && P <= 512 && p.S <= 128) return;           // (res_takes) the register-resident kernel of the pair has this group
   const T* X = reinterpret_cast<const T*>(p.x) + p.xoff[g];
   const long long po = p.poff[g];
   const unsigned char* mk = p.statmask ? p.statmask + po : nullptr;
@@ -611,6 +613,524 @@ __global__ __launch_bounds__(NT) void k_mag1c_fast(const Mag1cP p) {
   }
   if (tid == 0) p.status[g] = notpd ? 1 : 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// k_mag1c_res: the alpha == 0 path (Woodbury form, see k_mag1c_fast) for fp32 radiances and groups of P <= 512 pixels: the
+// group's radiances stay ON CHIP for the whole kernel.  P x S x 4 B (256 KB at 512 pixels x 125 bands) do not fit the LDS
+// beside the S x S matrix, but they fit the REGISTERS of a 512-thread work-group (256 registers each): thread (pixel group
+// pg = wave*4 + lane/16, band lane bg = lane%16) keeps the 16 x 8 tile  x[pg*16 + i][bg + 16*j].  From it:
+//   * band means: in-lane sums, lane permutes over the wave's 4 pixel groups, the 8 waves through LDS;
+//   * C_0 on the fp64 MFMA with BOTH operands straight from registers: lane (bg, pg%4) of the tile is exactly lane (row bg, k) of a
+//     16x16x4 operand of band block j, so  C_0[bi][bj] += x(i, bi) x(i, bj)^T  for i = 0..15 needs no staging, no barrier and no
+//     memory traffic; every wave accumulates its 64 pixels, four blocks per pass, and the eight partial blocks meet in LDS in a
+//     fixed order (deterministic);
+//   * per iteration: the per-pixel dots are 8 in-lane products + one 16-lane DPP row reduction, v = X^T w is 16 x 8 in-lane products
+//     + the same cross-lane / cross-wave reduction as the means -- instead of streaming the 256 KB twice per iteration (62 passes).
+// The streaming kernel did the iterations in 28 us per iteration and group (of which the two passes ~18); this one in the time
+// of its barriers and the fp64 arithmetic.  Launched as a pair with k_mag1c_fast<float, 1024, true>: each group is taken by
+// exactly one of the two, decided on the device from P[g] (no host round trip).
+constexpr int RNT = 512, RNW = 8;
+constexpr int RES_STAGE = 2 * RNW * 4 * 256;                 // doubles: two buffers x 8 waves x 4 blocks x (16 x 16)
+__device__ __forceinline__ bool res_takes(int P, int S) { return P <= 512 && S <= 128; }
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_d(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_sum16_d(double v) {      // every lane of a 16-lane row gets the row's sum
+  v += dpp_mov_d<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_mov_d<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_mov_d<0x141>(v);     // row_half_mirror
+  v += dpp_mov_d<0x140>(v);     // row_mirror
+  return v;
+}
+// the 36 block pairs (bi <= bj) of the upper triangle of an 8 x 8 block matrix, row-major
+constexpr int res_pair_bi(int k) { int bi = 0; while (k >= 8 - bi) { k -= 8 - bi; ++bi; } return bi; }
+constexpr int res_pair_bj(int k) { int bi = 0; while (k >= 8 - bi) { k -= 8 - bi; ++bi; } return bi + k; }
+
+// one row of the register tile through an empty volatile asm: its float -> double conversions stay where the row is used (the asm
+// statements keep their order, and the sums a row feeds pass through one as well) instead of 128 conversions hoisted into 256
+// registers -- the difference between no spill and 40-odd, each of which is a memory round trip inside the iteration
+#define ROWBAR(i) asm volatile("" : "+v"(xt[i][0]), "+v"(xt[i][1]), "+v"(xt[i][2]), "+v"(xt[i][3]), "+v"(xt[i][4]), "+v"(xt[i][5]), "+v"(xt[i][6]), "+v"(xt[i][7]))
+#define ACC8BAR(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
+
+#ifdef STARCOP_MAG1C_PROF
+__device__ long long g_prof[32];
+#define PROF(k) do { if (tid == 0 && g == 0) { const long long t_ = wall_clock64(); g_prof[k] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define PROF(k) do { } while (0)
+#endif
+
+// per-band totals of per-lane partial sums aj[j] (band bg + 16*j): over the wave's four pixel groups by lane permutes, over the eight
+// waves through LDS (stg: 8 x 128).  Thread tz < 128 returns the total of band tz.  Contains one barrier.
+__device__ __forceinline__ double res_band_total(double (&aj)[8], double* stg, int tz) {
+  const int lz = tz & 63;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { aj[j] += __shfl_xor(aj[j], 16, 64); aj[j] += __shfl_xor(aj[j], 32, 64); }
+  if (lz < 16) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) stg[(tz >> 6) * 128 + lz + 16 * j] = aj[j];
+  }
+  __syncthreads();
+  double t = 0.0;
+  if (tz < 128) {
+#pragma unroll
+    for (int w = 0; w < RNW; ++w) t += stg[w * 128 + tz];
+  }
+  return t;
+}
+
+// ---- 16 x 16 block algebra on the fp64 MFMA (v_mfma_f64_16x16x4: lane l holds A[l & 15][l >> 4], B[l >> 4][l & 15];
+// D[(l >> 4) + 4*r][l & 15] in register r).  Blocks live in LDS with arbitrary row / column strides, so a transposed operand is a
+// swap of two arguments.
+template <bool NEG = false>
+__device__ __forceinline__ void blk_mma(doublex4& acc, const double* a, int ar, int ak, const double* b, int bk, int bc, int lane) {
+  const int r = lane & 15, kq = lane >> 4;
+  double av[4], bv[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) { av[kk] = a[r * ar + (4 * kk + kq) * ak]; bv[kk] = b[(4 * kk + kq) * bk + r * bc]; }
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(NEG ? -av[kk] : av[kk], bv[kk], acc, 0, 0, 0);
+}
+template <bool NEG = false>
+__device__ __forceinline__ void blk_store(double* d, int dr, int dc, const doublex4& acc, int lane) {
+  const int c = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) d[(kq + 4 * r) * dr + c * dc] = NEG ? -acc[r] : acc[r];
+}
+__device__ __forceinline__ doublex4 blk_load(const double* d, int dr, int dc, int lane) {
+  const int c = lane & 15, kq = lane >> 4;
+  doublex4 acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = d[(kq + 4 * r) * dr + c * dc];
+  return acc;
+}
+__device__ __forceinline__ double readlane_d(double v, int l) {           // l uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+// Cholesky factor L of one 16 x 16 diagonal block AND X = L^{-1} in one sweep, by one wave: lane r < 16 keeps row r of the block and of
+// X in registers; step j takes the pivot and the column of L from the lanes that own them (v_readlane), no LDS, no barrier.
+// Only X is stored (Dk [16][17], zero above the diagonal): the panel solve, the inverse and W all use X_kk, nothing uses L_kk again.
+__device__ __forceinline__ bool res_diag_factor(const double* blk, int LD, double* Dk, int lane) {
+  const int r = lane & 15;
+  double a[16], x[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) { a[c] = blk[r * LD + c]; x[c] = (c == r) ? 1.0 : 0.0; }
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const double d = readlane_d(a[j], j);
+    if (!(d > 0.0)) bad = true;
+    const double rd = 1.0 / sqrt(d);
+    const double lr = a[j] * rd;                        // L[r][j] (r >= j)
+#pragma unroll
+    for (int c = j + 1; c < 16; ++c) a[c] = fma(-lr, readlane_d(lr, c), a[c]);
+#pragma unroll
+    for (int c = 0; c <= j; ++c) {                      // [L | I] -> [I | X]: row j scaled, then taken out of the rows below
+      const double xj = readlane_d(x[c], j) * rd;
+      x[c] = (r == j) ? xj : (r > j ? fma(-lr, xj, x[c]) : x[c]);
+    }
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) Dk[r * 17 + c] = (c <= r) ? x[c] : 0.0;
+  }
+  return bad;
+}
+
+#define RES_COV1(A)                                                                                                   \
+  {                                                                                                                   \
+    constexpr int bi_ = res_pair_bi(PASS * 4 + A), bj_ = res_pair_bj(PASS * 4 + A);                                   \
+    const double xa_ = bit ? (double)xt[i][bi_] - xb[bi_] : 0.0;                                                      \
+    const double xc_ = bit ? (double)xt[i][bj_] - xb[bj_] : 0.0;                                                      \
+    acc[A] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa_, xc_, acc[A], 0, 0, 0);                                        \
+  }
+
+// four blocks of C_0 (pairs 4*PASS .. 4*PASS+3): every wave's 64 pixels from registers, the eight partial blocks through LDS
+template <int PASS>
+__device__ __forceinline__ void res_cov_pass(float (&xt)[16][8], const double (&xb)[8], unsigned mbits, int nb, double* stage,
+                                             double* __restrict__ C0, int S, double N, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  // (a pass is skipped as a whole when S needs none of its blocks; blocks beyond S inside a pass multiply zeros: no branch per MFMA)
+  if (res_pair_bi(PASS * 4) >= nb || (res_pair_bi(PASS * 4) == res_pair_bi(PASS * 4 + 3) && res_pair_bj(PASS * 4) >= nb)) return;
+  doublex4 acc[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) acc[a] = (doublex4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    ROWBAR(i);
+    const bool bit = (mbits >> i) & 1u;
+    RES_COV1(0) RES_COV1(1) RES_COV1(2) RES_COV1(3)
+  }
+  double* mine = stage + (size_t)(((PASS & 1) * RNW + wave) * 4) * 256;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mine[a * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[a][r];
+  __syncthreads();
+  const double* buf = stage + (size_t)((PASS & 1) * RNW * 4) * 256;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int e = tid + h * RNT, a = e >> 8, idx = e & 255;
+    int k = PASS * 4 + a, bi = 0;
+    while (k >= 8 - bi) { k -= 8 - bi; ++bi; }
+    const int gi = bi * 16 + (idx >> 4), gj = (bi + k) * 16 + (idx & 15);
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < RNW; ++w) t += buf[(w * 4 + a) * 256 + idx];
+    if (gi < S && gj < S) { C0[(size_t)gi * S + gj] = t / N; C0[(size_t)gj * S + gi] = t / N; }
+  }
+}
+
+__global__ __launch_bounds__(RNT) void k_mag1c_res(const Mag1cP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int g = blockIdx.x;
+  const int S = p.S, S16 = (S + 15) & ~15, LD = S16 | 1;    // the matrix padded to whole 16 x 16 blocks (identity beyond S), odd pitch
+  double* vec = reinterpret_cast<double*>(smem);
+  double* xbar = vec, *tmpl = vec + VEC, *tau = vec + 2 * VEC, *mu = vec + 3 * VEC, *tnew = vec + 4 * VEC;
+  double* vv = vec + 6 * VEC, *col = vec + 7 * VEC;
+  double* p1 = vec + 8 * VEC, *p2 = vec + 9 * VEC, *p3 = vec + 10 * VEC;
+  double* red = vec + 11 * VEC;      // [64]: [0,32) wave sums, [40,50) the ten dot products of an iteration
+  double* Cm = red + 64;             // [S16][LD]: A -> L (lower) + L^{-1} blocks (upper, transposed) -> W;  during the covariance: staging
+  double* stg = Cm + (size_t)S16 * LD; // [2176]: mat-vec partials | per-band sums of the 8 waves | the inverses of the diagonal blocks of L
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int P = p.P[g], pitch = p.Ppad[g];
+  if (P <= 0) return;                                     // skipped group (sc_mag1c_layout_columns: too few valid pixels)
+  if (!res_takes(P, S)) return;                           // the streaming kernel of the pair takes this group
+  const float* X = reinterpret_cast<const float*>(p.x) + p.xoff[g];
+  const long long po = p.poff[g];
+  const unsigned char* mk = p.statmask ? p.statmask + po : nullptr;
+  double* C0 = p.workC + (size_t)g * S * S;
+  const double N = (double)P;
+#ifdef STARCOP_MAG1C_PROF
+  long long tprev = wall_clock64();
+#endif
+
+  // ---------------- the tile: 32 float4 loads per thread, all in flight at once (the only trip to memory for the radiances)
+  const int bg = lane & 15, pg = wave * 4 + (lane >> 4), q0 = pg * 16;
+  float xt[16][8];                                          // [pixel q0 + i][band bg + 16*j]
+  {
+    const bool pgok = q0 < pitch;                           // (the pack kernel wrote zeros into [P, pitch), pitch % 64 == 0)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int sj = bg + 16 * j;
+      float4 a[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pgok && sj < S) {
+        const float* src = X + (size_t)sj * pitch + q0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(src + 4 * u);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { xt[4 * u][j] = a[u].x; xt[4 * u + 1][j] = a[u].y; xt[4 * u + 2][j] = a[u].z; xt[4 * u + 3][j] = a[u].w; }
+    }
+  }
+  unsigned mbits = 0;                                       // bit i: pixel q0 + i exists and counts for the statistics
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { const int q = q0 + i; if (q < P && (mk == nullptr || mk[q])) mbits |= 1u << i; }
+  for (int s = tid; s < S; s += RNT) tmpl[s] = p.templ[s];
+  PROF(7);
+
+  // ---------------- band means
+  const double nstat = block_sum_n<RNW>(bg == 0 ? (double)__popc(mbits) : 0.0, red);
+  {
+    double aj[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) aj[j] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      ROWBAR(i);
+      const double m = ((mbits >> i) & 1u) ? 1.0 : 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) aj[j] = fma((double)xt[i][j], m, aj[j]);
+      ACC8BAR(aj);
+    }
+    const double t = res_band_total(aj, stg, tid);
+    if (tid < S) xbar[tid] = t / nstat;
+  }
+  __syncthreads();
+  PROF(8);
+
+  // ---------------- C_0 / N -> global scratch (the LDS matrix region is the staging area meanwhile) -> LDS
+  {
+    double xb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xb[j] = (bg + 16 * j < S) ? xbar[bg + 16 * j] : 0.0;
+    const int nb = S16 >> 4;
+    res_cov_pass<0>(xt, xb, mbits, nb, Cm, C0, S, N, tid);
+    res_cov_pass<1>(xt, xb, mbits, nb, Cm, C0, S, N, tid);
+    res_cov_pass<2>(xt, xb, mbits, nb, Cm, C0, S, N, tid);
+    res_cov_pass<3>(xt, xb, mbits, nb, Cm, C0, S, N, tid);
+    res_cov_pass<4>(xt, xb, mbits, nb, Cm, C0, S, N, tid);
+    res_cov_pass<5>(xt, xb, mbits, nb, Cm, C0, S, N, tid);
+    res_cov_pass<6>(xt, xb, mbits, nb, Cm, C0, S, N, tid);
+    res_cov_pass<7>(xt, xb, mbits, nb, Cm, C0, S, N, tid);
+    res_cov_pass<8>(xt, xb, mbits, nb, Cm, C0, S, N, tid);
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int e = tid; e < S16 * S16; e += RNT) {
+    const int a = e / S16, b = e - a * S16;
+    Cm[a * LD + b] = (a < S && b < S) ? C0[(size_t)a * S + b] : (a == b ? 1.0 : 0.0);
+  }
+  if (tid == 0) red[60] = 0.0;                            // "not positive definite" flag
+  __syncthreads();
+  PROF(9);
+
+  // ---------------- W = A^{-1}, all of it in 16 x 16 blocks on the fp64 MFMA (the unblocked forms: 125 steps of two barriers for the
+  // factor, 124 dependent dot products for the inverse, 62 LDS reads per element of W -- 0.3 of the 0.67 ms of a group)
+  const int nb = S16 >> 4;
+  double* Dx = stg;                                       // X_kk = L_kk^{-1}, [nb][16][17]
+  {
+    // (1) right-looking Cholesky.  Per block column k: panel L_ik = A_ik X_kk^T, trailing A_ij -= L_ik L_jk^T; wave 0 takes the next
+    // diagonal block first and factors it while the others finish the update: two barriers per block column.
+    if (wave == 0 && res_diag_factor(Cm, LD, Dx, lane) && lane == 0) red[60] = 1.0;
+    __syncthreads();
+    for (int k = 0; k < nb; ++k) {
+      for (int i = k + 1 + wave; i < nb; i += RNW) {
+        double* blk = Cm + (size_t)(16 * i) * LD + 16 * k;
+        doublex4 acc = (doublex4){0.0, 0.0, 0.0, 0.0};
+        blk_mma(acc, blk, LD, 1, Dx + k * 272, 1, 17, lane);
+        blk_store(blk, LD, 1, acc, lane);
+      }
+      __syncthreads();
+      if (k + 1 == nb) break;
+      const int n = nb - k - 1, cnt = n * (n + 1) / 2;
+      for (int t0 = (wave == 0) ? 0 : wave; t0 < ((wave == 0) ? 1 : cnt); t0 += RNW - 1) {
+        int t = t0, ii = 0;
+        while (t >= ii + 1) { t -= ii + 1; ++ii; }
+        const int i = k + 1 + ii, j = k + 1 + t;
+        double* blk = Cm + (size_t)(16 * i) * LD + 16 * j;
+        doublex4 acc = blk_load(blk, LD, 1, lane);
+        blk_mma<true>(acc, Cm + (size_t)(16 * i) * LD + 16 * k, LD, 1, Cm + (size_t)(16 * j) * LD + 16 * k, 1, LD, lane);
+        blk_store(blk, LD, 1, acc, lane);
+      }
+      if (wave == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (res_diag_factor(Cm + (size_t)(16 * (k + 1)) * LD + 16 * (k + 1), LD, Dx + (k + 1) * 272, lane) && lane == 0) red[60] = 1.0;
+      }
+      __syncthreads();
+    }
+    PROF(10);
+    // (2) X = L^{-1}.  First Y_im = X_ii L_im in place (all blocks at once), then block column j by wave j alone:
+    //   X_ij = -sum_{m = j .. i-1} Y_im X_mj   (i > j),  stored TRANSPOSED in the free upper block (j, i) -- the form W reads.
+    {
+      const int cnt = nb * (nb - 1) / 2;
+      for (int t0 = wave; t0 < cnt; t0 += RNW) {
+        int t = t0, ii = 0;
+        while (t >= ii + 1) { t -= ii + 1; ++ii; }
+        const int i = ii + 1, m = t;
+        double* blk = Cm + (size_t)(16 * i) * LD + 16 * m;
+        doublex4 acc = (doublex4){0.0, 0.0, 0.0, 0.0};
+        blk_mma(acc, Dx + i * 272, 17, 1, blk, LD, 1, lane);
+        blk_store(blk, LD, 1, acc, lane);
+      }
+    }
+    __syncthreads();
+    for (int j = wave; j < nb; j += RNW) {
+      for (int i = j + 1; i < nb; ++i) {
+        doublex4 acc = (doublex4){0.0, 0.0, 0.0, 0.0};
+        blk_mma(acc, Cm + (size_t)(16 * i) * LD + 16 * j, LD, 1, Dx + j * 272, 17, 1, lane);
+        for (int m = j + 1; m < i; ++m)
+          blk_mma(acc, Cm + (size_t)(16 * i) * LD + 16 * m, LD, 1, Cm + (size_t)(16 * j) * LD + 16 * m, 1, LD, lane);
+        blk_store<true>(Cm + (size_t)(16 * j) * LD + 16 * i, 1, LD, acc, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+    PROF(11);
+    // (3) W_ab = sum_{i >= a} X_ia^T X_ib  (a >= b) into the lower blocks (L is dead), then mirrored
+    {
+      const int cnt = nb * (nb + 1) / 2;
+      for (int t0 = wave; t0 < cnt; t0 += RNW) {
+        int t = t0, a = 0;
+        while (t >= a + 1) { t -= a + 1; ++a; }
+        const int b = t;
+        doublex4 acc = (doublex4){0.0, 0.0, 0.0, 0.0};
+        if (a == b) blk_mma(acc, Dx + a * 272, 1, 17, Dx + a * 272, 17, 1, lane);
+        else blk_mma(acc, Dx + a * 272, 1, 17, Cm + (size_t)(16 * b) * LD + 16 * a, 1, LD, lane);
+        for (int i = a + 1; i < nb; ++i)
+          blk_mma(acc, Cm + (size_t)(16 * a) * LD + 16 * i, LD, 1, Cm + (size_t)(16 * b) * LD + 16 * i, 1, LD, lane);
+        blk_store(Cm + (size_t)(16 * a) * LD + 16 * b, LD, 1, acc, lane);
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < S16 * S16; e += RNT) {
+      const int a = e / S16, b = e - a * S16;
+      if (b > a && (b >> 4) != (a >> 4)) Cm[a * LD + b] = Cm[b * LD + a];
+    }
+  }
+  bool notpd = red[60] != 0.0;
+  for (int s = tid; s < S; s += RNT) { p2[s] = 0.0; vv[s] = 0.0; tau[s] = 0.0; }
+  __syncthreads();
+  PROF(12);
+
+  // ---------------- rmf (it == 0) then the reweighted-L1 iterations; lane (pg, bg) keeps the state of pixel q0 + bg
+  double R_sel = 1.0, mf_sel = 0.0;
+  double sw = 0.0, sww = 0.0;
+  const int last = p.num_iter < 0 ? 0 : p.num_iter;
+  for (int it = 0; it <= last; ++it) {
+    // the lane-dependent addresses of the loop body are rebuilt every iteration from an opaque copy of the thread index: hoisted
+    // out of the loop they would be held in registers (or spilled) beside the 128 of the tile
+    int tz = tid;
+    asm volatile("" : "+v"(tz));
+    const int lz = tz & 63, bz = tz & 15;
+    double wbar = 0.0, q = 0.0;
+    if (it > 0) { wbar = sw / nstat; q = sww - nstat * wbar * wbar; }
+    if (tz < S) {
+      const double m = (it > 0) ? xbar[tz] - wbar * tau[tz] : xbar[tz];
+      mu[tz] = m;
+      tnew[tz] = tmpl[tz] * m;
+    }
+    __syncthreads();
+    PROF(0);
+    // p1 = W v and p3 = W t_new in one pass over W: row r = tz & 127, the columns c = part, part + 4, ..
+    {
+      const int r = tz & 127, part = tz >> 7;
+      double a0 = 0.0, a1 = 0.0;
+      if (r < S) {
+        const double* wr = Cm + r * LD;
+        for (int c = part; c < S; c += RNT / 128) { const double w = wr[c]; a0 = fma(w, vv[c], a0); a1 = fma(w, tnew[c], a1); }
+      }
+      stg[(part * 2) * 128 + r] = a0;
+      stg[(part * 2 + 1) * 128 + r] = a1;
+      __syncthreads();
+      if (tz < 256) {
+        const int which = tz >> 7;
+        if (r < S) (which ? p3 : p1)[r] = (stg[which * 128 + r] + stg[(2 + which) * 128 + r]) + (stg[(4 + which) * 128 + r] + stg[(6 + which) * 128 + r]);
+      }
+    }
+    __syncthreads();
+    PROF(1);
+    // the ten dot products of the 2 x 2 Woodbury solve, two per wave:
+    //   v.p1  v.p2  tau.p2  p1.t  p2.t  t.p3  mu.p1  mu.p2  mu.p3  mu.mu      (vec slots: tau 2, mu 3, t 4, v 6, p1 8, p2 9, p3 10)
+    for (int k = wave; k < 10; k += RNW) {
+      const double* A = vec + ((0x3333498266ull >> (4 * k)) & 15) * VEC;
+      const double* B = vec + ((0x3A98A44998ull >> (4 * k)) & 15) * VEC;
+      double d = 0.0;
+      for (int s = lz; s < S; s += 64) d = fma(A[s], B[s], d);
+      d = wave_sum_d(d);
+      if (lz == 0) red[40 + k] = d;
+    }
+    __syncthreads();
+    PROF(2);
+    double y1 = 0.0, y2 = 0.0;
+    if (it > 0) {
+      // G = M^{-1} + U^T B0 U,  M^{-1} = [[-q,-1],[-1,0]],  B0 = W/N ;  G y = U^T B0 b
+      const double g11 = -q + red[40] / N, g12 = -1.0 + red[41] / N, g22 = red[42] / N;
+      const double z1 = red[43] / N, z2 = red[44] / N;
+      const double det = g11 * g22 - g12 * g12;
+      y1 = (z1 * g22 - z2 * g12) / det;
+      y2 = (g11 * z2 - g12 * z1) / det;
+    }
+    double norm = red[45] - y1 * red[43] - y2 * red[44];           // normaliser  t . C^{-1} t
+    const double mucit = red[48] - y1 * red[46] - y2 * red[47];    // mu . C^{-1} t
+    const double mumu = red[49];
+    if (!(norm == norm)) notpd = true;
+    if (it > 0 && norm < 1.0) norm = 1.0;
+    // per-pixel filter: C^{-1} t for the lane's eight bands, 16 x 8 products, a 16-lane row sum per pixel
+    double w_sel = 0.0;
+    {
+      const bool need_mu = (it == 0) && !p.albedo_override;
+      double cj[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const int sj = bz + 16 * j; cj[j] = sj < S ? p3[sj] - y1 * p1[sj] - y2 * p2[sj] : 0.0; }
+      double dsel = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        double d = 0.0;
+        ROWBAR(i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d = fma((double)xt[i][j], cj[j], d);
+        asm volatile("" : "+v"(d));
+        d = row_sum16_d(d);
+        dsel = (bz == i) ? d : dsel;
+      }
+      double dmu = 0.0;
+      if (need_mu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int sj = bz + 16 * j; cj[j] = sj < S ? mu[sj] : 0.0; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          double d = 0.0;
+          ROWBAR(i);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) d = fma((double)xt[i][j], cj[j], d);
+          asm volatile("" : "+v"(d));
+          d = row_sum16_d(d);
+          dmu = (bz == i) ? d : dmu;
+        }
+      }
+      const int r_q = (tz >> 4) * 16 + bz;
+      if (r_q < P) {
+        const double score = dsel - mucit;
+        double mf;
+        if (it == 0) {
+          R_sel = p.albedo_override ? 1.0 : dmu / mumu;
+          mf = score / (R_sel * norm);
+          if (!p.zero_override) mf = fmax(mf, 0.0);
+        } else {
+          const double reg = p.sparse_override ? 0.0 : 1.0 / (R_sel * (mf_sel + 1e-9));
+          mf = fmax((score - reg) / (R_sel * norm), 0.0);
+        }
+        mf_sel = mf;
+        w_sel = (mk == nullptr || mk[r_q]) ? p.kscale * R_sel * mf : 0.0;
+      }
+    }
+    PROF(3);
+    if (it == last) break;
+    // v = X^T w - xbar * sum(w);  tau <- current target;  W tau <- W t_new.  The sums of w and w^2 ride on the same barrier.
+    {
+      const double s1 = wave_sum_d(w_sel), s2 = wave_sum_d(w_sel * w_sel);
+      if (lz == 0) { red[tz >> 6] = s1; red[16 + (tz >> 6)] = s2; }
+      double aj[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) aj[j] = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const double wi = __shfl(w_sel, (lz & 48) | i, 64);
+        ROWBAR(i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) aj[j] = fma((double)xt[i][j], wi, aj[j]);
+        ACC8BAR(aj);
+      }
+      const double t = res_band_total(aj, stg, tz);
+      sw = 0.0; sww = 0.0;
+#pragma unroll
+      for (int w = 0; w < RNW; ++w) { sw += red[w]; sww += red[16 + w]; }
+      if (tz < S) { vv[tz] = t - xbar[tz] * sw; tau[tz] = tnew[tz]; p2[tz] = p3[tz]; }
+    }
+    __syncthreads();
+    PROF(4);
+  }
+  const double scale = (p.num_iter >= 0 || p.apply_scaling) ? 1e5 : 1.0;
+  {
+    const int r_q = q0 + bg;
+    if (r_q < P) {
+      reinterpret_cast<float*>(p.mf_out)[po + r_q] = (float)(mf_sel * scale);
+      reinterpret_cast<float*>(p.alb_out)[po + r_q] = (float)R_sel;
+    }
+  }
+  if (tid == 0) p.status[g] = notpd ? 1 : 0;
+}
+
+size_t mag1c_res_lds_bytes(int S) {
+  const size_t S16 = (size_t)((S + 15) & ~15), mat = S16 * (S16 | 1);
+  return (11 * VEC + 64 + (mat > (size_t)RES_STAGE ? mat : (size_t)RES_STAGE) + 8 * 272) * sizeof(double);
+}
+
+#ifdef STARCOP_MAG1C_PROF
+}  // namespace
+extern "C" int sc_debug_mag1c_prof(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(long long) * 32); }
+namespace {
+#endif
 
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void k_mag1c_pack(const TI* __restrict__ cube, int S_total, int band0, int S,
@@ -881,8 +1401,14 @@ extern "C" int sc_mag1c_groups(const sc_mag1c_args* a, sc_stream stream) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c_fast<double, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess) hipLaunchKernelGGL((k_mag1c_fast<double, 1024>), dim3(a->G), dim3(1024), lds, st, p);
   } else if (fast) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c_fast<float, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) hipLaunchKernelGGL((k_mag1c_fast<float, 1024>), dim3(a->G), dim3(1024), lds, st, p);
+    // fp32 radiances: a pair of launches; every group is taken by exactly one of them (k_mag1c_res: P <= 512, from registers)
+    const size_t rlds = mag1c_res_lds_bytes(a->S);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c_res), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c_fast<float, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_mag1c_res, dim3(a->G), dim3(RNT), rlds, st, p);
+      hipLaunchKernelGGL((k_mag1c_fast<float, 1024, true>), dim3(a->G), dim3(1024), lds, st, p);
+    }
   } else {
     // general path (alpha != 0: refactorisation every iteration).  Few bands: 512 threads (4 groups per CU);
     // many bands: the matrix fills the LDS, one group of 1024 threads per CU
