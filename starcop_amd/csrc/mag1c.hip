@@ -830,9 +830,9 @@ __global__ __launch_bounds__(RNT) void k_mag1c_res(const Mag1cP p) {
       for (int u = 0; u < 4; ++u) { xt[4 * u][j] = a[u].x; xt[4 * u + 1][j] = a[u].y; xt[4 * u + 2][j] = a[u].z; xt[4 * u + 3][j] = a[u].w; }
     }
   }
-  unsigned mbits = 0;                                       // bit i: pixel q0 + i exists and counts for the statistics
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { const int q = q0 + i; if (q < P && (mk == nullptr || mk[q])) mbits |= 1u << i; }
+  // bit i: pixel q0 + i exists and counts for the statistics -- every lane looks at ITS pixel q0 + bg, the 16-lane row votes
+  const bool mine_ok = q0 + bg < P && (mk == nullptr || mk[q0 + bg]);
+  const unsigned mbits = (unsigned)(__ballot(mine_ok) >> (lane & 48)) & 0xffffu;
   for (int s = tid; s < S; s += RNT) tmpl[s] = p.templ[s];
   PROF(7);
 
@@ -968,71 +968,94 @@ __global__ __launch_bounds__(RNT) void k_mag1c_res(const Mag1cP p) {
     }
   }
   bool notpd = red[60] != 0.0;
-  for (int s = tid; s < S; s += RNT) { p2[s] = 0.0; vv[s] = 0.0; tau[s] = 0.0; }
+
+  // ---------------- rmf (it == 0) then the reweighted-L1 iterations; lane (pg, bg) keeps the state of pixel q0 + bg.
+  // Four barriers per iteration: W [v t] partials | their sums + the ten dot products | the band sums of X^T w | end.
+  double R_sel = 1.0, mf_sel = 0.0;
+  double wbar = 0.0, q = 0.0;
+  const int last = p.num_iter < 0 ? 0 : p.num_iter;
+  if (tid == 0) red[61] = nstat;
+  if (tid < S) { const double m = xbar[tid]; p2[tid] = 0.0; vv[tid] = 0.0; tau[tid] = 0.0; mu[tid] = m; tnew[tid] = tmpl[tid] * m; }
   __syncthreads();
   PROF(12);
-
-  // ---------------- rmf (it == 0) then the reweighted-L1 iterations; lane (pg, bg) keeps the state of pixel q0 + bg
-  double R_sel = 1.0, mf_sel = 0.0;
-  double sw = 0.0, sww = 0.0;
-  const int last = p.num_iter < 0 ? 0 : p.num_iter;
   for (int it = 0; it <= last; ++it) {
     // the lane-dependent addresses of the loop body are rebuilt every iteration from an opaque copy of the thread index: hoisted
     // out of the loop they would be held in registers (or spilled) beside the 128 of the tile
     int tz = tid;
     asm volatile("" : "+v"(tz));
     const int lz = tz & 63, bz = tz & 15;
-    double wbar = 0.0, q = 0.0;
-    if (it > 0) { wbar = sw / nstat; q = sww - nstat * wbar * wbar; }
-    if (tz < S) {
-      const double m = (it > 0) ? xbar[tz] - wbar * tau[tz] : xbar[tz];
-      mu[tz] = m;
-      tnew[tz] = tmpl[tz] * m;
+    // p1 = W v and p3 = W t_new in one pass over W: wave w takes the columns 16w .. 16w+15 for ALL rows (lane l: rows l and l + 64),
+    // so its 16 + 16 vector elements are wave-uniform: one LDS read, then scalar operands from v_readlane -- the pass reads W once
+    // and nothing else (125 KB per iteration; rows beyond S read padding or stale LDS, their sums are never used)
+    {
+      const int c0 = wave * 16;
+      double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+      if (c0 < S16) {
+        double uv = 0.0, ut = 0.0;
+        if (lz < 16 && c0 + lz < S) { uv = vv[c0 + lz]; ut = tnew[c0 + lz]; }
+        const double* w0 = Cm + lz * LD + c0;
+        const double* w1 = w0 + 64 * LD;
+#pragma unroll
+        for (int h = 0; h < 16; h += 8) {                  // (8 + 8 reads in flight: 16 + 16 would not fit beside the tile)
+          double m0[8], m1[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { m0[i] = w0[h + i]; m1[i] = w1[h + i]; }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const double sv = readlane_d(uv, h + i), st = readlane_d(ut, h + i);
+            a0 = fma(m0[i], sv, a0); a1 = fma(m0[i], st, a1);
+            b0 = fma(m1[i], sv, b0); b1 = fma(m1[i], st, b1);
+          }
+        }
+      }
+      double* mine = stg + (tz >> 6) * 256;
+      mine[lz] = a0; mine[lz + 64] = b0; mine[128 + lz] = a1; mine[128 + lz + 64] = b1;
     }
     __syncthreads();
     PROF(0);
-    // p1 = W v and p3 = W t_new in one pass over W: row r = tz & 127, the columns c = part, part + 4, ..
-    {
-      const int r = tz & 127, part = tz >> 7;
-      double a0 = 0.0, a1 = 0.0;
+    // waves 0-3: the sums over the 8 column blocks -> p1 (waves 0, 1), p3 (waves 2, 3) and, while the element is in a register, its
+    // terms of the dot products with v, t, mu;  waves 4-7: the dot products that do not involve p1 / p3
+    //   red[32 + 3*wave ..]: (v.p1, p1.t, mu.p1) x 2 waves, (t.p3, mu.p3, -) x 2 waves;  red[44..48]: v.p2  tau.p2  p2.t  mu.p2  mu.mu
+    if (wave < 4) {
+      const int which = tz >> 7, r = tz & 127;
+      double pv = 0.0;
+#pragma unroll
+      for (int w = 0; w < RNW; ++w) pv += stg[w * 256 + which * 128 + r];
+      double e0 = 0.0, e1 = 0.0, e2 = 0.0;
       if (r < S) {
-        const double* wr = Cm + r * LD;
-        for (int c = part; c < S; c += RNT / 128) { const double w = wr[c]; a0 = fma(w, vv[c], a0); a1 = fma(w, tnew[c], a1); }
+        (which ? p3 : p1)[r] = pv;
+        const double tv = tnew[r], mv = mu[r];
+        if (which) { e0 = tv * pv; e1 = mv * pv; } else { e0 = vv[r] * pv; e1 = tv * pv; e2 = mv * pv; }
       }
-      stg[(part * 2) * 128 + r] = a0;
-      stg[(part * 2 + 1) * 128 + r] = a1;
-      __syncthreads();
-      if (tz < 256) {
-        const int which = tz >> 7;
-        if (r < S) (which ? p3 : p1)[r] = (stg[which * 128 + r] + stg[(2 + which) * 128 + r]) + (stg[(4 + which) * 128 + r] + stg[(6 + which) * 128 + r]);
-      }
+      e0 = wave_sum_d(e0); e1 = wave_sum_d(e1); e2 = wave_sum_d(e2);
+      if (lz == 0) { red[32 + 3 * wave] = e0; red[33 + 3 * wave] = e1; red[34 + 3 * wave] = e2; }
+    } else {
+      // vec slots: tau 2, mu 3, t 4, v 6, p2 9
+      const int sa = wave == 4 ? 6 : wave == 5 ? 2 : wave == 6 ? 9 : 3, sb = wave == 6 ? 4 : 9;
+      const double* A = vec + sa * VEC, *B = vec + sb * VEC;
+      double d = 0.0, d2 = 0.0;
+      for (int s = lz; s < S; s += 64) { d = fma(A[s], B[s], d); if (wave == 7) d2 = fma(A[s], A[s], d2); }
+      d = wave_sum_d(d);
+      if (wave == 7) d2 = wave_sum_d(d2);
+      if (lz == 0) { red[40 + wave] = d; if (wave == 7) red[48] = d2; }
     }
     __syncthreads();
     PROF(1);
-    // the ten dot products of the 2 x 2 Woodbury solve, two per wave:
-    //   v.p1  v.p2  tau.p2  p1.t  p2.t  t.p3  mu.p1  mu.p2  mu.p3  mu.mu      (vec slots: tau 2, mu 3, t 4, v 6, p1 8, p2 9, p3 10)
-    for (int k = wave; k < 10; k += RNW) {
-      const double* A = vec + ((0x3333498266ull >> (4 * k)) & 15) * VEC;
-      const double* B = vec + ((0x3A98A44998ull >> (4 * k)) & 15) * VEC;
-      double d = 0.0;
-      for (int s = lz; s < S; s += 64) d = fma(A[s], B[s], d);
-      d = wave_sum_d(d);
-      if (lz == 0) red[40 + k] = d;
-    }
-    __syncthreads();
-    PROF(2);
+    const double dvp1 = red[32] + red[35], dp1t = red[33] + red[36], dmup1 = red[34] + red[37];
+    const double dtp3 = red[38] + red[41], dmup3 = red[39] + red[42];
+    const double dvp2 = red[44], dtaup2 = red[45], dp2t = red[46], dmup2 = red[47];
     double y1 = 0.0, y2 = 0.0;
     if (it > 0) {
       // G = M^{-1} + U^T B0 U,  M^{-1} = [[-q,-1],[-1,0]],  B0 = W/N ;  G y = U^T B0 b
-      const double g11 = -q + red[40] / N, g12 = -1.0 + red[41] / N, g22 = red[42] / N;
-      const double z1 = red[43] / N, z2 = red[44] / N;
+      const double g11 = -q + dvp1 / N, g12 = -1.0 + dvp2 / N, g22 = dtaup2 / N;
+      const double z1 = dp1t / N, z2 = dp2t / N;
       const double det = g11 * g22 - g12 * g12;
       y1 = (z1 * g22 - z2 * g12) / det;
       y2 = (g11 * z2 - g12 * z1) / det;
     }
-    double norm = red[45] - y1 * red[43] - y2 * red[44];           // normaliser  t . C^{-1} t
-    const double mucit = red[48] - y1 * red[46] - y2 * red[47];    // mu . C^{-1} t
-    const double mumu = red[49];
+    double norm = dtp3 - y1 * dp1t - y2 * dp2t;                     // normaliser  t . C^{-1} t
+    const double mucit = dmup3 - y1 * dmup1 - y2 * dmup2;           // mu . C^{-1} t
+    const double mumu = red[48];
     if (!(norm == norm)) notpd = true;
     if (it > 0 && norm < 1.0) norm = 1.0;
     // per-pixel filter: C^{-1} t for the lane's eight bands, 16 x 8 products, a 16-lane row sum per pixel
@@ -1084,7 +1107,7 @@ __global__ __launch_bounds__(RNT) void k_mag1c_res(const Mag1cP p) {
         w_sel = (mk == nullptr || mk[r_q]) ? p.kscale * R_sel * mf : 0.0;
       }
     }
-    PROF(3);
+    PROF(2);
     if (it == last) break;
     // v = X^T w - xbar * sum(w);  tau <- current target;  W tau <- W t_new.  The sums of w and w^2 ride on the same barrier.
     {
@@ -1102,13 +1125,19 @@ __global__ __launch_bounds__(RNT) void k_mag1c_res(const Mag1cP p) {
         ACC8BAR(aj);
       }
       const double t = res_band_total(aj, stg, tz);
-      sw = 0.0; sww = 0.0;
+      double sw = 0.0, sww = 0.0;
 #pragma unroll
       for (int w = 0; w < RNW; ++w) { sw += red[w]; sww += red[16 + w]; }
-      if (tz < S) { vv[tz] = t - xbar[tz] * sw; tau[tz] = tnew[tz]; p2[tz] = p3[tz]; }
+      const double nst = red[61];                        // (kept in LDS: one register pair less across the whole kernel)
+      wbar = sw / nst; q = sww - nst * wbar * wbar;
+      if (tz < S) {
+        // v, and the next iteration's tau <- t, W tau <- W t, mu = xbar - wbar tau, t = template * mu
+        const double tn = tnew[tz], m = xbar[tz] - wbar * tn;
+        vv[tz] = t - xbar[tz] * sw; tau[tz] = tn; p2[tz] = p3[tz]; mu[tz] = m; tnew[tz] = tmpl[tz] * m;
+      }
     }
     __syncthreads();
-    PROF(4);
+    PROF(3);
   }
   const double scale = (p.num_iter >= 0 || p.apply_scaling) ? 1e5 : 1.0;
   {

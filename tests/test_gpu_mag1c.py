@@ -303,3 +303,38 @@ def test_id_layout_equals_sorted_layout(hip):
     neg = ids.copy(); neg[ids == 7] = -7
     c_mf, _ = hip_mag1c.acrwl1mf_by_groups(x, t, neg, mask=mask)
     assert torch.equal(c_mf, a_mf if False else hip_mag1c.acrwl1mf_by_groups(x, t, ids, mask=mask)[0])
+
+
+@pytest.mark.parametrize("S", [20, 77, 125])
+def test_paired_launch_mixed_group_sizes(hip, S):
+    """alpha = 0, fp32: sc_mag1c_groups launches the register-resident kernel (groups of <= 512 pixels) and the streaming kernel
+    (larger groups) side by side, and each group is taken by exactly one of them, decided on the device.  One call with group sizes
+    on both sides of the boundary (600, 513 | 512, 511, S + 100, S + 30) and a skipped one (5 <= 10 pixels), an arbitrary (non-column)
+    group map, NODATA pixels inside groups; band counts that fill 2, 5 and 8 of the 16 x 16 blocks of the factorisation.  Every
+    pixel within 1e-5 of oracle/mag1c_ref in float64 on the same float32 radiances."""
+    rng = np.random.default_rng(100 + S)
+    sizes = [600, 513, 512, 511, S + 100, S + 30, 5]             # (a group needs more valid pixels than bands: else C is singular)
+    n = sum(sizes)
+    H, W = 1, n
+    t = -np.abs(rng.standard_normal(S)) * 0.3
+    base = rng.uniform(1, 6, size=S)
+    cube = base * (1 + 0.05 * rng.standard_normal((H, W, S))) + 0.2 * rng.standard_normal((H, W, 1)) * base
+    conc = np.zeros((H, W)); conc[0, ::7] = 1500.0
+    cube = (cube * (1 + conc[..., None] * 1e-5 * t)).astype(np.float32)
+    ids = np.repeat(np.arange(1, len(sizes) + 1), sizes)
+    perm = rng.permutation(n)                                   # groups interleaved over the pixels: the counting-sort layout
+    groups = ids[perm][None, :]
+    cube[0, np.flatnonzero(groups[0] == 3)[:4], 1] = hip_mag1c.NODATA      # 512 -> 508 valid pixels
+    cube[0, np.flatnonzero(groups[0] == 2)[:2], 0] = hip_mag1c.NODATA      # 513 -> 511: crosses to the resident kernel
+    mf, alb = hip_mag1c.acrwl1mf_by_groups(torch.from_numpy(cube).to(DEV), t, groups)
+    mf, alb = mf.cpu().numpy(), alb.cpu().numpy()
+    want, walb = mag1c_ref.func_by_groups(lambda xg: mag1c_ref.acrwl1mf_group(xg, t, num_iter=30, alpha=0.0), cube.astype(np.float64), groups)
+    assert np.array_equal(mf == hip_mag1c.NODATA, want == hip_mag1c.NODATA)
+    assert (mf[groups == 7] == hip_mag1c.NODATA).all()
+    ok = want != hip_mag1c.NODATA
+    worst = {}
+    for gid, sz in enumerate(sizes[:-1], 1):
+        sel = ok & (groups == gid)
+        worst[sz] = float(rel(mf[sel], want[sel]).max())
+        assert worst[sz] < 1e-5 and rel(alb[sel], walb[sel]).max() < 1e-6, (sz, worst)
+    print(f"S={S}: worst relative error per group size {worst}")

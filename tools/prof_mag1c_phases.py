@@ -53,8 +53,8 @@ mag1c.acrwl1mf_by_groups(x, t, groups)
 b0 = snap()
 mag1c.acrwl1mf_by_groups(x, t, groups)
 d = (snap() - b0) / 100.0          # us
-names = {7: "tile load", 8: "band means", 9: "covariance", 10: "Cholesky", 11: "L^-1", 12: "W = X^T X", 0: "it: mu, t", 1: "it: W v, W t",
-         2: "it: ten dots", 3: "it: 2x2 + pixel sweep", 4: "it: v = X^T w"}
-for k in (7, 8, 9, 10, 11, 12, 0, 1, 2, 3, 4):
+names = {7: "tile load", 8: "band means", 9: "covariance", 10: "Cholesky", 11: "L^-1", 12: "W = X^T X", 0: "it: W [v t] partials", 1: "it: sums + ten dots",
+         2: "it: 2x2 + pixel sweep", 3: "it: v = X^T w"}
+for k in (7, 8, 9, 10, 11, 12, 0, 1, 2, 3):
     print(f"{names[k]:24s} {d[k]:8.1f} us" + (f"   ({d[k] / 31:.2f} us per iteration)" if k < 7 else ""))
 print(f"{'setup':24s} {d[7:13].sum():8.1f} us\n{'iterations':24s} {d[:7].sum():8.1f} us\n{'group total':24s} {d.sum():8.1f} us")
