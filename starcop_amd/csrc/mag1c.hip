@@ -35,6 +35,13 @@ struct Mag1cP {
   int* status;
 };
 
+#ifdef STARCOP_MAG1C_PROF
+__device__ long long g_prof[32];
+#define PROF(k) do { if (tid == 0 && g == 0) { const long long t_ = wall_clock64(); g_prof[k] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define PROF(k) do { } while (0)
+#endif
+
 constexpr int MAXS = 128;
 constexpr int VEC = 128;
 
@@ -84,6 +91,9 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 4) void k_mag1c(const Mag1cP p)
   double* C0 = p.workC + (size_t)g * S * S;
   const double N = (double)P;
 
+#ifdef STARCOP_MAG1C_PROF
+  long long tprev = wall_clock64();
+#endif
   // ---------------- phase A: band means over the statistics pixels
   double nstat;
   {
@@ -106,6 +116,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 4) void k_mag1c(const Mag1cP p)
   for (int s = tid; s < S; s += NT) tmpl[s] = p.templ[s];
   __syncthreads();
 
+  PROF(16);
   // ---------------- phase B: C_0 = sum_p (x_p - xbar)(x_p - xbar)^T  on v_mfma_f64_16x16x4_f64
   {
     const int nb = S16 >> 4;
@@ -158,6 +169,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 4) void k_mag1c(const Mag1cP p)
   __threadfence_block();
   __syncthreads();
 
+  PROF(17);
   // ---------------- phase C: rmf (it == 0) then the reweighted-L1 iterations
   double sw = 0.0, sww = 0.0;
   bool notpd = false;
@@ -193,6 +205,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 4) void k_mag1c(const Mag1cP p)
       }
     }
     __syncthreads();
+    PROF(18);
     // (2) Cholesky, lower, in place.  S <= 64: left-looking inside wave 0 (lane = row; no block barriers -- with 31
     //     factorisations per group the 2*S barriers of the block version were the largest item of an EMIT iteration);
     //     larger S: right-looking over the whole block, two barriers per column.
@@ -225,6 +238,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 4) void k_mag1c(const Mag1cP p)
         __syncthreads();
       }
     }
+    PROF(19);
     // (3) cit = C^{-1} tnew : forward and backward substitution by wave 0 (each lane owns rows lane, lane+64)
     if (wave == 0) {
       double b0 = lane < S ? tnew[lane] : 0.0;
@@ -253,6 +267,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 4) void k_mag1c(const Mag1cP p)
       if (lane == 0) { red[32] = a0; red[33] = a1; red[34] = a2; }
     }
     __syncthreads();
+    PROF(20);
     double norm = red[32];
     const double mucit = red[33], mumu = red[34];
     if (it > 0 && norm < 1.0) norm = 1.0;               // normalizer.clamp_(min=1) (mag1c.py:264-266)
@@ -290,11 +305,13 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 4) void k_mag1c(const Mag1cP p)
       wv[q0] = w;
       lsw += w; lsww += w * w;
     }
+    PROF(21);
     if (it == last) break;
     sw = block_sum_n<NW>(lsw, red);
     sww = block_sum_n<NW>(lsww, red + 16);
     __threadfence_block();
     __syncthreads();
+    PROF(22);
     // (6) v = X w - xbar * sum(w);  tau <- current target
     for (int s = wave; s < S; s += NW) {
       double a = 0.0;
@@ -309,6 +326,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 4) void k_mag1c(const Mag1cP p)
       if (lane == 0) { vv[s] = a - xbar[s] * sw; tau[s] = tnew[s]; }
     }
     __syncthreads();
+    PROF(23);
   }
   // ---------------- outputs
   const double scale = (p.num_iter >= 0 || p.apply_scaling) ? 1e5 : 1.0;
@@ -656,12 +674,40 @@ constexpr int res_pair_bj(int k) { int bi = 0; while (k >= 8 - bi) { k -= 8 - bi
 #define ROWBAR(i) asm volatile("" : "+v"(xt[i][0]), "+v"(xt[i][1]), "+v"(xt[i][2]), "+v"(xt[i][3]), "+v"(xt[i][4]), "+v"(xt[i][5]), "+v"(xt[i][6]), "+v"(xt[i][7]))
 #define ACC8BAR(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
 
-#ifdef STARCOP_MAG1C_PROF
-__device__ long long g_prof[32];
-#define PROF(k) do { if (tid == 0 && g == 0) { const long long t_ = wall_clock64(); g_prof[k] += t_ - tprev; tprev = t_; } } while (0)
-#else
-#define PROF(k) do { } while (0)
-#endif
+// per-pixel dot products of the register tile with the lane's eight coefficients, reduced over the 16 band lanes of a row so that lane
+// bz ends up with the sum of ITS pixel q0 + bz ("reduce-scatter": at each of the four steps a lane keeps the half of the pixels whose
+// index bit matches its own lane bit and hands the other half to its partner -- row_mirror, row_half_mirror, quad xor 2, quad xor 1
+// flip exactly bit 3, 2, 1, 0 -- 15 exchanges of 7 instructions instead of 16 full row sums of 12 + 16 selects)
+template <int CTRL>
+__device__ __forceinline__ double res_comb(bool sel, double lo, double hi) {
+  return (sel ? hi : lo) + dpp_mov_d<CTRL>(sel ? lo : hi);
+}
+__device__ __forceinline__ double res_pixel_dots(float (&xt)[16][8], const double (&cj)[8], int bz) {
+  const bool b3 = bz & 8, b2 = bz & 4, b1 = bz & 2, b0 = bz & 1;
+  double r4[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    double r8[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      double d[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = a + 4 * h + 8 * u;
+        double t = 0.0;
+        ROWBAR(i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t = fma((double)xt[i][j], cj[j], t);
+        asm volatile("" : "+v"(t));
+        d[u] = t;
+      }
+      r8[h] = res_comb<0x140>(b3, d[0], d[1]);
+    }
+    r4[a] = res_comb<0x141>(b2, r8[0], r8[1]);
+  }
+  return res_comb<0xB1>(b0, res_comb<0x4E>(b1, r4[0], r4[2]), res_comb<0x4E>(b1, r4[1], r4[3]));
+}
+
 
 // per-band totals of per-lane partial sums aj[j] (band bg + 16*j): over the wave's four pixel groups by lane permutes, over the eight
 // waves through LDS (stg: 8 x 128).  Thread tz < 128 returns the total of band tz.  Contains one barrier.
@@ -724,7 +770,9 @@ __device__ __forceinline__ bool res_diag_factor(const double* blk, int LD, doubl
   for (int j = 0; j < 16; ++j) {
     const double d = readlane_d(a[j], j);
     if (!(d > 0.0)) bad = true;
-    const double rd = 1.0 / sqrt(d);
+    double rd = __builtin_amdgcn_rsq(d);                 // v_rsq_f64 + two Newton steps (the sqrt / divide pair is a ~250-cycle chain per pivot)
+    rd = rd * fma(-0.5 * d * rd, rd, 1.5);
+    rd = rd * fma(-0.5 * d * rd, rd, 1.5);
     const double lr = a[j] * rd;                        // L[r][j] (r >= j)
 #pragma unroll
     for (int c = j + 1; c < 16; ++c) a[c] = fma(-lr, readlane_d(lr, c), a[c]);
@@ -752,7 +800,7 @@ __device__ __forceinline__ bool res_diag_factor(const double* blk, int LD, doubl
 // four blocks of C_0 (pairs 4*PASS .. 4*PASS+3): every wave's 64 pixels from registers, the eight partial blocks through LDS
 template <int PASS>
 __device__ __forceinline__ void res_cov_pass(float (&xt)[16][8], const double (&xb)[8], unsigned mbits, int nb, double* stage,
-                                             double* __restrict__ C0, int S, double N, int tid) {
+                                             double* __restrict__ C0, int S, double invN, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
   // (a pass is skipped as a whole when S needs none of its blocks; blocks beyond S inside a pass multiply zeros: no branch per MFMA)
   if (res_pair_bi(PASS * 4) >= nb || (res_pair_bi(PASS * 4) == res_pair_bi(PASS * 4 + 3) && res_pair_bj(PASS * 4) >= nb)) return;
@@ -781,7 +829,7 @@ __device__ __forceinline__ void res_cov_pass(float (&xt)[16][8], const double (&
     double t = 0.0;
 #pragma unroll
     for (int w = 0; w < RNW; ++w) t += buf[(w * 4 + a) * 256 + idx];
-    if (gi < S && gj < S) { C0[(size_t)gi * S + gj] = t / N; C0[(size_t)gj * S + gi] = t / N; }
+    if (gi < S && gj < S) { C0[(size_t)gi * S + gj] = t * invN; C0[(size_t)gj * S + gi] = t * invN; }
   }
 }
 
@@ -862,15 +910,16 @@ __global__ __launch_bounds__(RNT) void k_mag1c_res(const Mag1cP p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) xb[j] = (bg + 16 * j < S) ? xbar[bg + 16 * j] : 0.0;
     const int nb = S16 >> 4;
-    res_cov_pass<0>(xt, xb, mbits, nb, Cm, C0, S, N, tid);
-    res_cov_pass<1>(xt, xb, mbits, nb, Cm, C0, S, N, tid);
-    res_cov_pass<2>(xt, xb, mbits, nb, Cm, C0, S, N, tid);
-    res_cov_pass<3>(xt, xb, mbits, nb, Cm, C0, S, N, tid);
-    res_cov_pass<4>(xt, xb, mbits, nb, Cm, C0, S, N, tid);
-    res_cov_pass<5>(xt, xb, mbits, nb, Cm, C0, S, N, tid);
-    res_cov_pass<6>(xt, xb, mbits, nb, Cm, C0, S, N, tid);
-    res_cov_pass<7>(xt, xb, mbits, nb, Cm, C0, S, N, tid);
-    res_cov_pass<8>(xt, xb, mbits, nb, Cm, C0, S, N, tid);
+    const double invN = 1.0 / N;
+    res_cov_pass<0>(xt, xb, mbits, nb, Cm, C0, S, invN, tid);
+    res_cov_pass<1>(xt, xb, mbits, nb, Cm, C0, S, invN, tid);
+    res_cov_pass<2>(xt, xb, mbits, nb, Cm, C0, S, invN, tid);
+    res_cov_pass<3>(xt, xb, mbits, nb, Cm, C0, S, invN, tid);
+    res_cov_pass<4>(xt, xb, mbits, nb, Cm, C0, S, invN, tid);
+    res_cov_pass<5>(xt, xb, mbits, nb, Cm, C0, S, invN, tid);
+    res_cov_pass<6>(xt, xb, mbits, nb, Cm, C0, S, invN, tid);
+    res_cov_pass<7>(xt, xb, mbits, nb, Cm, C0, S, invN, tid);
+    res_cov_pass<8>(xt, xb, mbits, nb, Cm, C0, S, invN, tid);
   }
   __threadfence_block();
   __syncthreads();
@@ -971,10 +1020,10 @@ __global__ __launch_bounds__(RNT) void k_mag1c_res(const Mag1cP p) {
 
   // ---------------- rmf (it == 0) then the reweighted-L1 iterations; lane (pg, bg) keeps the state of pixel q0 + bg.
   // Four barriers per iteration: W [v t] partials | their sums + the ten dot products | the band sums of X^T w | end.
-  double R_sel = 1.0, mf_sel = 0.0;
+  double R_sel = 1.0, Rinv_sel = 1.0, mf_sel = 0.0;
   double wbar = 0.0, q = 0.0;
   const int last = p.num_iter < 0 ? 0 : p.num_iter;
-  if (tid == 0) red[61] = nstat;
+  if (tid == 0) { red[61] = nstat; red[62] = 1.0 / N; }
   if (tid < S) { const double m = xbar[tid]; p2[tid] = 0.0; vv[tid] = 0.0; tau[tid] = 0.0; mu[tid] = m; tnew[tid] = tmpl[tid] * m; }
   __syncthreads();
   PROF(12);
@@ -1047,17 +1096,19 @@ __global__ __launch_bounds__(RNT) void k_mag1c_res(const Mag1cP p) {
     double y1 = 0.0, y2 = 0.0;
     if (it > 0) {
       // G = M^{-1} + U^T B0 U,  M^{-1} = [[-q,-1],[-1,0]],  B0 = W/N ;  G y = U^T B0 b
-      const double g11 = -q + dvp1 / N, g12 = -1.0 + dvp2 / N, g22 = dtaup2 / N;
-      const double z1 = dp1t / N, z2 = dp2t / N;
-      const double det = g11 * g22 - g12 * g12;
-      y1 = (z1 * g22 - z2 * g12) / det;
-      y2 = (g11 * z2 - g12 * z1) / det;
+      const double invN = red[62];
+      const double g11 = -q + dvp1 * invN, g12 = -1.0 + dvp2 * invN, g22 = dtaup2 * invN;
+      const double z1 = dp1t * invN, z2 = dp2t * invN;
+      const double idet = 1.0 / (g11 * g22 - g12 * g12);
+      y1 = (z1 * g22 - z2 * g12) * idet;
+      y2 = (g11 * z2 - g12 * z1) * idet;
     }
     double norm = dtp3 - y1 * dp1t - y2 * dp2t;                     // normaliser  t . C^{-1} t
     const double mucit = dmup3 - y1 * dmup1 - y2 * dmup2;           // mu . C^{-1} t
     const double mumu = red[48];
     if (!(norm == norm)) notpd = true;
     if (it > 0 && norm < 1.0) norm = 1.0;
+    const double inorm = 1.0 / norm;
     // per-pixel filter: C^{-1} t for the lane's eight bands, 16 x 8 products, a 16-lane row sum per pixel
     double w_sel = 0.0;
     {
@@ -1065,31 +1116,12 @@ __global__ __launch_bounds__(RNT) void k_mag1c_res(const Mag1cP p) {
       double cj[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) { const int sj = bz + 16 * j; cj[j] = sj < S ? p3[sj] - y1 * p1[sj] - y2 * p2[sj] : 0.0; }
-      double dsel = 0.0;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        double d = 0.0;
-        ROWBAR(i);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) d = fma((double)xt[i][j], cj[j], d);
-        asm volatile("" : "+v"(d));
-        d = row_sum16_d(d);
-        dsel = (bz == i) ? d : dsel;
-      }
+      const double dsel = res_pixel_dots(xt, cj, bz);
       double dmu = 0.0;
       if (need_mu) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const int sj = bz + 16 * j; cj[j] = sj < S ? mu[sj] : 0.0; }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          double d = 0.0;
-          ROWBAR(i);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) d = fma((double)xt[i][j], cj[j], d);
-          asm volatile("" : "+v"(d));
-          d = row_sum16_d(d);
-          dmu = (bz == i) ? d : dmu;
-        }
+        dmu = res_pixel_dots(xt, cj, bz);
       }
       const int r_q = (tz >> 4) * 16 + bz;
       if (r_q < P) {
@@ -1097,11 +1129,12 @@ __global__ __launch_bounds__(RNT) void k_mag1c_res(const Mag1cP p) {
         double mf;
         if (it == 0) {
           R_sel = p.albedo_override ? 1.0 : dmu / mumu;
-          mf = score / (R_sel * norm);
+          Rinv_sel = 1.0 / R_sel;
+          mf = score * Rinv_sel * inorm;
           if (!p.zero_override) mf = fmax(mf, 0.0);
         } else {
-          const double reg = p.sparse_override ? 0.0 : 1.0 / (R_sel * (mf_sel + 1e-9));
-          mf = fmax((score - reg) / (R_sel * norm), 0.0);
+          const double reg = p.sparse_override ? 0.0 : Rinv_sel / (mf_sel + 1e-9);
+          mf = fmax((score - reg) * Rinv_sel * inorm, 0.0);
         }
         mf_sel = mf;
         w_sel = (mk == nullptr || mk[r_q]) ? p.kscale * R_sel * mf : 0.0;

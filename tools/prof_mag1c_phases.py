@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tools", "_build")
-LIB = os.path.join(OUT, "libstarcop_hip_prof.so")
+LIB = os.path.join(OUT, os.environ.get("PROF_LIB", "libstarcop_hip_prof.so"))
 CSRC = os.path.join(ROOT, "starcop_amd", "csrc")
 
 if "--build" in sys.argv:
@@ -21,7 +21,7 @@ if "--build" in sys.argv:
     subprocess.run(["make", "-C", CSRC, "-j", "4"], check=True, stdout=subprocess.DEVNULL)
     obj = os.path.join(OUT, "mag1c_prof.o")
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-                    "-I" + CSRC, "-Wno-unused-result", "-DSTARCOP_MAG1C_PROF", "-c", os.path.join(CSRC, "mag1c.hip"), "-o", obj], check=True)
+                    "-I" + CSRC, "-Wno-unused-result", "-DSTARCOP_MAG1C_PROF"] + os.environ.get("EXTRA_DEFS", "").split() + ["-c", os.path.join(CSRC, "mag1c.hip"), "-o", obj], check=True)
     others = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".o") and f != "mag1c.o"]
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", obj] + others + ["-o", LIB], check=True)
     print("built", LIB)
