@@ -346,8 +346,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 4) void k_mag1c(const Mag1cP p)
 //   M = [[0,-1],[-1,q]]:  (C_0 + U M U^T)^{-1} b = B0 b - B0 U (M^{-1} + U^T B0 U)^{-1} U^T B0 b
 // Per iteration: two mat-vecs (W v, W t_new; W tau is last iteration's W t_new), a 2x2 solve, two streaming passes.
 // NT threads per group (1024: the 125 KB matrix in LDS allows one work-group per CU, so the work-group itself has to fill it)
-// SPLIT: launched as a pair with k_mag1c_res (below); this kernel then leaves the groups that one takes
-template <typename T, int NT, bool SPLIT = false>
+template <typename T, int NT>
 __global__ __launch_bounds__(NT) void k_mag1c_fast(const Mag1cP p) {
   constexpr int NW = NT / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -365,7 +364,6 @@ __global__ __launch_bounds__(NT) void k_mag1c_fast(const Mag1cP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int P = p.P[g], pitch = p.Ppad[g];
   if (P <= 0) return;                                     // skipped group (sc_mag1c_layout_columns: too few valid pixels)
-  if (SPLIT && P <= 512 && p.S <= 128) return;           // (res_takes) the register-resident kernel of the pair has this group
   const T* X = reinterpret_cast<const T*>(p.x) + p.xoff[g];
   const long long po = p.poff[g];
   const unsigned char* mk = p.statmask ? p.statmask + po : nullptr;
@@ -633,23 +631,24 @@ __global__ __launch_bounds__(NT) void k_mag1c_fast(const Mag1cP p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// k_mag1c_res: the alpha == 0 path (Woodbury form, see k_mag1c_fast) for fp32 radiances and groups of P <= 512 pixels: the
-// group's radiances stay ON CHIP for the whole kernel.  P x S x 4 B (256 KB at 512 pixels x 125 bands) do not fit the LDS
-// beside the S x S matrix, but they fit the REGISTERS of a 512-thread work-group (256 registers each): thread (pixel group
-// pg = wave*4 + lane/16, band lane bg = lane%16) keeps the 16 x 8 tile  x[pg*16 + i][bg + 16*j].  From it:
+// k_mag1c_tile<JB>: every fp32 group (any P, S <= 16*JB, alpha = 0 or not) with the radiances held in a REGISTER TILE.
+// 512 threads; thread (pixel group pg = wave*4 + lane/16, band lane bg = lane%16) keeps the 16 x JB tile
+//   x[chunk*512 + pg*16 + i][bg + 16*j],   i < 16, j < JB          (JB = 8: 128 registers, S <= 128;  JB = 4: 64 registers, S <= 64)
+// of one 512-pixel chunk of the group.  A group of P <= 512 pixels (JB = 8) is loaded ONCE and stays on chip for the whole kernel
+// (P x S x 4 B = 256 KB at 512 x 125 does not fit the LDS beside the S x S matrix, but it fits the registers of the work-group);
+// larger groups stream their chunks through the same tile -- once per iteration, not twice: the weight of a pixel needs only that
+// pixel's own filter output, so v = X^T w accumulates in the pass that computes the outputs.  From the tile:
 //   * band means: in-lane sums, lane permutes over the wave's 4 pixel groups, the 8 waves through LDS;
 //   * C_0 on the fp64 MFMA with BOTH operands straight from registers: lane (bg, pg%4) of the tile is exactly lane (row bg, k) of a
 //     16x16x4 operand of band block j, so  C_0[bi][bj] += x(i, bi) x(i, bj)^T  for i = 0..15 needs no staging, no barrier and no
-//     memory traffic; every wave accumulates its 64 pixels, four blocks per pass, and the eight partial blocks meet in LDS in a
+//     memory traffic; every wave accumulates its pixels, NACC blocks per pass, and the eight partial blocks meet in LDS in a
 //     fixed order (deterministic);
-//   * per iteration: the per-pixel dots are 8 in-lane products + one 16-lane DPP row reduction, v = X^T w is 16 x 8 in-lane products
-//     + the same cross-lane / cross-wave reduction as the means -- instead of streaming the 256 KB twice per iteration (62 passes).
-// The streaming kernel did the iterations in 28 us per iteration and group (of which the two passes ~18); this one in the time
-// of its barriers and the fp64 arithmetic.  Launched as a pair with k_mag1c_fast<float, 1024, true>: each group is taken by
-// exactly one of the two, decided on the device from P[g] (no host round trip).
+//   * per iteration: the per-pixel dots are JB in-lane products per pixel + a reduce-scatter over the 16 band lanes, v = X^T w is
+//     16 x JB in-lane products + the same cross-lane / cross-wave reduction as the means.
+// The S x S system is solved in 16 x 16 blocks on the fp64 MFMA (spd_inverse_blocked): alpha = 0 inverts C_0/N once and follows
+// the rank-2 changes by the Woodbury identity (see k_mag1c_fast); alpha != 0 (the EMIT driver: the shrinkage is not low rank)
+// rebuilds and inverts C_k every iteration -- 18 us instead of the 88 us of a factorisation + two solves by a single wave.
 constexpr int RNT = 512, RNW = 8;
-constexpr int RES_STAGE = 2 * RNW * 4 * 256;                 // doubles: two buffers x 8 waves x 4 blocks x (16 x 16)
-__device__ __forceinline__ bool res_takes(int P, int S) { return P <= 512 && S <= 128; }
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov_d(double v) {
@@ -664,25 +663,40 @@ __device__ __forceinline__ double row_sum16_d(double v) {      // every lane of 
   v += dpp_mov_d<0x140>(v);     // row_mirror
   return v;
 }
-// the 36 block pairs (bi <= bj) of the upper triangle of an 8 x 8 block matrix, row-major
-constexpr int res_pair_bi(int k) { int bi = 0; while (k >= 8 - bi) { k -= 8 - bi; ++bi; } return bi; }
-constexpr int res_pair_bj(int k) { int bi = 0; while (k >= 8 - bi) { k -= 8 - bi; ++bi; } return bi + k; }
+
+// the block pairs (bi <= bj) of the upper triangle of an n x n block matrix, row-major
+constexpr int tri_pair_bi(int k, int n) { int bi = 0; while (k >= n - bi) { k -= n - bi; ++bi; } return bi; }
+constexpr int tri_pair_bj(int k, int n) { int bi = 0; while (k >= n - bi) { k -= n - bi; ++bi; } return bi + k; }
 
 // one row of the register tile through an empty volatile asm: its float -> double conversions stay where the row is used (the asm
 // statements keep their order, and the sums a row feeds pass through one as well) instead of 128 conversions hoisted into 256
 // registers -- the difference between no spill and 40-odd, each of which is a memory round trip inside the iteration
-#define ROWBAR(i) asm volatile("" : "+v"(xt[i][0]), "+v"(xt[i][1]), "+v"(xt[i][2]), "+v"(xt[i][3]), "+v"(xt[i][4]), "+v"(xt[i][5]), "+v"(xt[i][6]), "+v"(xt[i][7]))
-#define ACC8BAR(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
+template <int JB>
+__device__ __forceinline__ void rowbar(float (&r)[JB]) {
+  if constexpr (JB == 8) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
+  else asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
+}
+template <int JB>
+__device__ __forceinline__ void accbar(double (&a)[JB]) {
+  if constexpr (JB == 8) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+  else asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+}
 
-// per-pixel dot products of the register tile with the lane's eight coefficients, reduced over the 16 band lanes of a row so that lane
-// bz ends up with the sum of ITS pixel q0 + bz ("reduce-scatter": at each of the four steps a lane keeps the half of the pixels whose
-// index bit matches its own lane bit and hands the other half to its partner -- row_mirror, row_half_mirror, quad xor 2, quad xor 1
-// flip exactly bit 3, 2, 1, 0 -- 15 exchanges of 7 instructions instead of 16 full row sums of 12 + 16 selects)
 template <int CTRL>
 __device__ __forceinline__ double res_comb(bool sel, double lo, double hi) {
   return (sel ? hi : lo) + dpp_mov_d<CTRL>(sel ? lo : hi);
 }
-__device__ __forceinline__ double res_pixel_dots(float (&xt)[16][8], const double (&cj)[8], int bz) {
+template <int JB>
+__device__ __forceinline__ double tile_row_dot(float (&xt)[16][JB], const double (&cj)[JB], int i) {
+  double t = 0.0;
+  rowbar<JB>(xt[i]);
+#pragma unroll
+  for (int j = 0; j < JB; ++j) t = fma((double)xt[i][j], cj[j], t);
+  asm volatile("" : "+v"(t));
+  return t;
+}
+template <int JB>
+__device__ __forceinline__ double tile_pixel_dots(float (&xt)[16][JB], const double (&cj)[JB], int bz) {
   const bool b3 = bz & 8, b2 = bz & 4, b1 = bz & 2, b0 = bz & 1;
   double r4[4];
 #pragma unroll
@@ -690,42 +704,56 @@ __device__ __forceinline__ double res_pixel_dots(float (&xt)[16][8], const doubl
     double r8[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      double d[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int i = a + 4 * h + 8 * u;
-        double t = 0.0;
-        ROWBAR(i);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) t = fma((double)xt[i][j], cj[j], t);
-        asm volatile("" : "+v"(t));
-        d[u] = t;
-      }
-      r8[h] = res_comb<0x140>(b3, d[0], d[1]);
+      const double d0 = tile_row_dot<JB>(xt, cj, a + 4 * h), d1 = tile_row_dot<JB>(xt, cj, a + 4 * h + 8);
+      r8[h] = res_comb<0x140>(b3, d0, d1);
     }
     r4[a] = res_comb<0x141>(b2, r8[0], r8[1]);
   }
   return res_comb<0xB1>(b0, res_comb<0x4E>(b1, r4[0], r4[2]), res_comb<0x4E>(b1, r4[1], r4[3]));
 }
 
-
 // per-band totals of per-lane partial sums aj[j] (band bg + 16*j): over the wave's four pixel groups by lane permutes, over the eight
 // waves through LDS (stg: 8 x 128).  Thread tz < 128 returns the total of band tz.  Contains one barrier.
-__device__ __forceinline__ double res_band_total(double (&aj)[8], double* stg, int tz) {
+template <int JB>
+__device__ __forceinline__ double tile_band_total(double (&aj)[JB], double* stg, int tz) {
   const int lz = tz & 63;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { aj[j] += __shfl_xor(aj[j], 16, 64); aj[j] += __shfl_xor(aj[j], 32, 64); }
+  for (int j = 0; j < JB; ++j) { aj[j] += __shfl_xor(aj[j], 16, 64); aj[j] += __shfl_xor(aj[j], 32, 64); }
   if (lz < 16) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) stg[(tz >> 6) * 128 + lz + 16 * j] = aj[j];
+    for (int j = 0; j < JB; ++j) stg[(tz >> 6) * 128 + lz + 16 * j] = aj[j];
   }
   __syncthreads();
   double t = 0.0;
-  if (tz < 128) {
+  if (tz < 16 * JB) {
 #pragma unroll
     for (int w = 0; w < RNW; ++w) t += stg[w * 128 + tz];
   }
   return t;
+}
+
+// one 512-pixel chunk into the tile: 4*JB float4 loads per thread, all in flight at once.  Returns the statistics mask of the lane's
+// 16 pixels (bit i: pixel q0 + i exists and counts): every lane looks at ITS pixel q0 + bg, the 16-lane row votes.
+template <int JB>
+__device__ __forceinline__ unsigned tile_load(float (&xt)[16][JB], const float* X, int pitch, int S, int P, const unsigned char* mk,
+                                              int q0, int bg, int lane) {
+  const bool pgok = q0 < pitch;                             // (the pack kernel wrote zeros into [P, pitch), pitch % 64 == 0)
+#pragma unroll
+  for (int j = 0; j < JB; ++j) {
+    const int sj = bg + 16 * j;
+    float4 a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pgok && sj < S) {
+      const float* src = X + (size_t)sj * pitch + q0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(src + 4 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { xt[4 * u][j] = a[u].x; xt[4 * u + 1][j] = a[u].y; xt[4 * u + 2][j] = a[u].z; xt[4 * u + 3][j] = a[u].w; }
+  }
+  const bool mine_ok = q0 + bg < P && (mk == nullptr || mk[q0 + bg]);
+  return (unsigned)(__ballot(mine_ok) >> (lane & 48)) & 0xffffu;
 }
 
 // ---- 16 x 16 block algebra on the fp64 MFMA (v_mfma_f64_16x16x4: lane l holds A[l & 15][l >> 4], B[l >> 4][l & 15];
@@ -789,152 +817,15 @@ __device__ __forceinline__ bool res_diag_factor(const double* blk, int LD, doubl
   return bad;
 }
 
-#define RES_COV1(A)                                                                                                   \
-  {                                                                                                                   \
-    constexpr int bi_ = res_pair_bi(PASS * 4 + A), bj_ = res_pair_bj(PASS * 4 + A);                                   \
-    const double xa_ = bit ? (double)xt[i][bi_] - xb[bi_] : 0.0;                                                      \
-    const double xc_ = bit ? (double)xt[i][bj_] - xb[bj_] : 0.0;                                                      \
-    acc[A] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa_, xc_, acc[A], 0, 0, 0);                                        \
-  }
 
-// four blocks of C_0 (pairs 4*PASS .. 4*PASS+3): every wave's 64 pixels from registers, the eight partial blocks through LDS
-template <int PASS>
-__device__ __forceinline__ void res_cov_pass(float (&xt)[16][8], const double (&xb)[8], unsigned mbits, int nb, double* stage,
-                                             double* __restrict__ C0, int S, double invN, int tid) {
-  const int lane = tid & 63, wave = tid >> 6;
-  // (a pass is skipped as a whole when S needs none of its blocks; blocks beyond S inside a pass multiply zeros: no branch per MFMA)
-  if (res_pair_bi(PASS * 4) >= nb || (res_pair_bi(PASS * 4) == res_pair_bi(PASS * 4 + 3) && res_pair_bj(PASS * 4) >= nb)) return;
-  doublex4 acc[4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a) acc[a] = (doublex4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    ROWBAR(i);
-    const bool bit = (mbits >> i) & 1u;
-    RES_COV1(0) RES_COV1(1) RES_COV1(2) RES_COV1(3)
-  }
-  double* mine = stage + (size_t)(((PASS & 1) * RNW + wave) * 4) * 256;
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) mine[a * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[a][r];
-  __syncthreads();
-  const double* buf = stage + (size_t)((PASS & 1) * RNW * 4) * 256;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int e = tid + h * RNT, a = e >> 8, idx = e & 255;
-    int k = PASS * 4 + a, bi = 0;
-    while (k >= 8 - bi) { k -= 8 - bi; ++bi; }
-    const int gi = bi * 16 + (idx >> 4), gj = (bi + k) * 16 + (idx & 15);
-    double t = 0.0;
-#pragma unroll
-    for (int w = 0; w < RNW; ++w) t += buf[(w * 4 + a) * 256 + idx];
-    if (gi < S && gj < S) { C0[(size_t)gi * S + gj] = t * invN; C0[(size_t)gj * S + gi] = t * invN; }
-  }
-}
-
-__global__ __launch_bounds__(RNT) void k_mag1c_res(const Mag1cP p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int g = blockIdx.x;
-  const int S = p.S, S16 = (S + 15) & ~15, LD = S16 | 1;    // the matrix padded to whole 16 x 16 blocks (identity beyond S), odd pitch
-  double* vec = reinterpret_cast<double*>(smem);
-  double* xbar = vec, *tmpl = vec + VEC, *tau = vec + 2 * VEC, *mu = vec + 3 * VEC, *tnew = vec + 4 * VEC;
-  double* vv = vec + 6 * VEC, *col = vec + 7 * VEC;
-  double* p1 = vec + 8 * VEC, *p2 = vec + 9 * VEC, *p3 = vec + 10 * VEC;
-  double* red = vec + 11 * VEC;      // [64]: [0,32) wave sums, [40,50) the ten dot products of an iteration
-  double* Cm = red + 64;             // [S16][LD]: A -> L (lower) + L^{-1} blocks (upper, transposed) -> W;  during the covariance: staging
-  double* stg = Cm + (size_t)S16 * LD; // [2176]: mat-vec partials | per-band sums of the 8 waves | the inverses of the diagonal blocks of L
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int P = p.P[g], pitch = p.Ppad[g];
-  if (P <= 0) return;                                     // skipped group (sc_mag1c_layout_columns: too few valid pixels)
-  if (!res_takes(P, S)) return;                           // the streaming kernel of the pair takes this group
-  const float* X = reinterpret_cast<const float*>(p.x) + p.xoff[g];
-  const long long po = p.poff[g];
-  const unsigned char* mk = p.statmask ? p.statmask + po : nullptr;
-  double* C0 = p.workC + (size_t)g * S * S;
-  const double N = (double)P;
-#ifdef STARCOP_MAG1C_PROF
-  long long tprev = wall_clock64();
-#endif
-
-  // ---------------- the tile: 32 float4 loads per thread, all in flight at once (the only trip to memory for the radiances)
-  const int bg = lane & 15, pg = wave * 4 + (lane >> 4), q0 = pg * 16;
-  float xt[16][8];                                          // [pixel q0 + i][band bg + 16*j]
-  {
-    const bool pgok = q0 < pitch;                           // (the pack kernel wrote zeros into [P, pitch), pitch % 64 == 0)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int sj = bg + 16 * j;
-      float4 a[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pgok && sj < S) {
-        const float* src = X + (size_t)sj * pitch + q0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(src + 4 * u);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { xt[4 * u][j] = a[u].x; xt[4 * u + 1][j] = a[u].y; xt[4 * u + 2][j] = a[u].z; xt[4 * u + 3][j] = a[u].w; }
-    }
-  }
-  // bit i: pixel q0 + i exists and counts for the statistics -- every lane looks at ITS pixel q0 + bg, the 16-lane row votes
-  const bool mine_ok = q0 + bg < P && (mk == nullptr || mk[q0 + bg]);
-  const unsigned mbits = (unsigned)(__ballot(mine_ok) >> (lane & 48)) & 0xffffu;
-  for (int s = tid; s < S; s += RNT) tmpl[s] = p.templ[s];
-  PROF(7);
-
-  // ---------------- band means
-  const double nstat = block_sum_n<RNW>(bg == 0 ? (double)__popc(mbits) : 0.0, red);
-  {
-    double aj[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) aj[j] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      ROWBAR(i);
-      const double m = ((mbits >> i) & 1u) ? 1.0 : 0.0;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) aj[j] = fma((double)xt[i][j], m, aj[j]);
-      ACC8BAR(aj);
-    }
-    const double t = res_band_total(aj, stg, tid);
-    if (tid < S) xbar[tid] = t / nstat;
-  }
-  __syncthreads();
-  PROF(8);
-
-  // ---------------- C_0 / N -> global scratch (the LDS matrix region is the staging area meanwhile) -> LDS
-  {
-    double xb[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) xb[j] = (bg + 16 * j < S) ? xbar[bg + 16 * j] : 0.0;
-    const int nb = S16 >> 4;
-    const double invN = 1.0 / N;
-    res_cov_pass<0>(xt, xb, mbits, nb, Cm, C0, S, invN, tid);
-    res_cov_pass<1>(xt, xb, mbits, nb, Cm, C0, S, invN, tid);
-    res_cov_pass<2>(xt, xb, mbits, nb, Cm, C0, S, invN, tid);
-    res_cov_pass<3>(xt, xb, mbits, nb, Cm, C0, S, invN, tid);
-    res_cov_pass<4>(xt, xb, mbits, nb, Cm, C0, S, invN, tid);
-    res_cov_pass<5>(xt, xb, mbits, nb, Cm, C0, S, invN, tid);
-    res_cov_pass<6>(xt, xb, mbits, nb, Cm, C0, S, invN, tid);
-    res_cov_pass<7>(xt, xb, mbits, nb, Cm, C0, S, invN, tid);
-    res_cov_pass<8>(xt, xb, mbits, nb, Cm, C0, S, invN, tid);
-  }
-  __threadfence_block();
-  __syncthreads();
-  for (int e = tid; e < S16 * S16; e += RNT) {
-    const int a = e / S16, b = e - a * S16;
-    Cm[a * LD + b] = (a < S && b < S) ? C0[(size_t)a * S + b] : (a == b ? 1.0 : 0.0);
-  }
-  if (tid == 0) red[60] = 0.0;                            // "not positive definite" flag
-  __syncthreads();
-  PROF(9);
-
-  // ---------------- W = A^{-1}, all of it in 16 x 16 blocks on the fp64 MFMA (the unblocked forms: 125 steps of two barriers for the
-  // factor, 124 dependent dot products for the inverse, 62 LDS reads per element of W -- 0.3 of the 0.67 ms of a group)
-  const int nb = S16 >> 4;
-  double* Dx = stg;                                       // X_kk = L_kk^{-1}, [nb][16][17]
+// A (SPD, S16 x S16 in LDS, lower triangle + diagonal valid, identity beyond S) -> A^{-1} as a full symmetric matrix, in place, all
+// of it in 16 x 16 blocks on the fp64 MFMA.  Dx: [nb][16][17] scratch.  flag: set to 1 when a pivot is not positive.  All threads
+// of the work-group call it; ends with a barrier.  (The unblocked forms it replaces: 125 steps of two barriers for the factor, 124
+// dependent dot products for the inverse, 62 LDS reads per element of the product -- 0.3 of the 0.67 ms of a 125-band group.)
+__device__ __forceinline__ void spd_inverse_blocked(double* Cm, int LD, int nb, double* Dx, double* flag, int tid) {
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S16 = nb * 16;
+  double* red = flag - 60;
   {
     // (1) right-looking Cholesky.  Per block column k: panel L_ik = A_ik X_kk^T, trailing A_ij -= L_ik L_jk^T; wave 0 takes the next
     // diagonal block first and factors it while the others finish the update: two barriers per block column.
@@ -966,7 +857,7 @@ __global__ __launch_bounds__(RNT) void k_mag1c_res(const Mag1cP p) {
       }
       __syncthreads();
     }
-    PROF(10);
+    
     // (2) X = L^{-1}.  First Y_im = X_ii L_im in place (all blocks at once), then block column j by wave j alone:
     //   X_ij = -sum_{m = j .. i-1} Y_im X_mj   (i > j),  stored TRANSPOSED in the free upper block (j, i) -- the form W reads.
     {
@@ -994,7 +885,7 @@ __global__ __launch_bounds__(RNT) void k_mag1c_res(const Mag1cP p) {
       }
     }
     __syncthreads();
-    PROF(11);
+    
     // (3) W_ab = sum_{i >= a} X_ia^T X_ib  (a >= b) into the lower blocks (L is dead), then mirrored
     {
       const int cnt = nb * (nb + 1) / 2;
@@ -1016,23 +907,209 @@ __global__ __launch_bounds__(RNT) void k_mag1c_res(const Mag1cP p) {
       if (b > a && (b >> 4) != (a >> 4)) Cm[a * LD + b] = Cm[b * LD + a];
     }
   }
-  bool notpd = red[60] != 0.0;
+  __syncthreads();
+}
+
+template <int JB> struct TileCfg {
+  static constexpr int NACC = JB == 8 ? 4 : 2;              // covariance blocks accumulated per pass (8 registers each)
+  static constexpr int NBUF = JB == 8 ? 2 : 1;              // staging buffers (JB = 4 keeps the LDS of a group under 80 KB: two groups per CU)
+  static constexpr int NPAIR = JB * (JB + 1) / 2;
+  static constexpr int NPASS = (NPAIR + NACC - 1) / NACC;
+  static constexpr int STAGE = NBUF * RNW * NACC * 256;     // doubles
+};
+
+// one MFMA of the covariance: block pair K (compile-time: the tile and xb are indexed by constants, i.e. stay in registers)
+template <int JB, int K>
+__device__ __forceinline__ void tile_cov_mfma(float (&row)[JB], const double (&xb)[JB], bool bit, doublex4& acc) {
+  constexpr int NP = JB * (JB + 1) / 2, k = K < NP ? K : NP - 1;
+  constexpr int bi = tri_pair_bi(k, JB), bj = tri_pair_bj(k, JB);
+  const double xa = bit ? (double)row[bi] - xb[bi] : 0.0;
+  const double xc = bit ? (double)row[bj] - xb[bj] : 0.0;
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, xc, acc, 0, 0, 0);
+}
+
+// one covariance pass: blocks (pairs) NACC*PASS .. of C_0 over ALL chunks of the group, then the eight partial blocks through LDS
+template <int JB, int PASS>
+__device__ __forceinline__ void tile_cov_pass(float (&xt)[16][JB], unsigned& mbits, bool resident, int nchunk, const float* X, int pitch,
+                                              int P, const unsigned char* mk, const double (&xb)[JB], int nb, double* stage,
+                                              double* __restrict__ C0, int S, double invN, int tid) {
+  using Cfg = TileCfg<JB>;
+  constexpr int NACC = Cfg::NACC;
+  if constexpr (PASS < Cfg::NPASS) {
+    const int lane = tid & 63, wave = tid >> 6;
+    // (a pass is skipped as a whole when S needs none of its blocks; blocks beyond S inside a pass multiply zeros: no branch per MFMA)
+    constexpr int K0 = PASS * NACC, K1 = (K0 + NACC - 1 < Cfg::NPAIR) ? K0 + NACC - 1 : Cfg::NPAIR - 1;
+    if (tri_pair_bi(K0, JB) >= nb || (tri_pair_bi(K0, JB) == tri_pair_bi(K1, JB) && tri_pair_bj(K0, JB) >= nb)) return;
+    doublex4 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = (doublex4){0.0, 0.0, 0.0, 0.0};
+    for (int c = 0; c < nchunk; ++c) {
+      if (!resident) mbits = tile_load<JB>(xt, X, pitch, S, P, mk, c * RNT + (tid >> 4) * 16, tid & 15, lane);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        rowbar<JB>(xt[i]);
+        const bool bit = (mbits >> i) & 1u;
+        tile_cov_mfma<JB, K0 + 0>(xt[i], xb, bit, acc[0]);
+        tile_cov_mfma<JB, K0 + 1>(xt[i], xb, bit, acc[1]);
+        if constexpr (NACC > 2) {
+          tile_cov_mfma<JB, K0 + 2>(xt[i], xb, bit, acc[2]);
+          tile_cov_mfma<JB, K0 + 3>(xt[i], xb, bit, acc[NACC > 2 ? 3 : 0]);
+        }
+      }
+    }
+    double* mine = stage + (size_t)(((PASS % Cfg::NBUF) * RNW + wave) * NACC) * 256;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[a * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[a][r];
+    __syncthreads();
+    const double* buf = stage + (size_t)((PASS % Cfg::NBUF) * RNW * NACC) * 256;
+#pragma unroll
+    for (int h = 0; h < NACC * 256 / RNT; ++h) {
+      const int e = tid + h * RNT, a = e >> 8, idx = e & 255;
+      int k = K0 + a, bi = 0;
+      if (k < Cfg::NPAIR) {
+        while (k >= JB - bi) { k -= JB - bi; ++bi; }
+        const int gi = bi * 16 + (idx >> 4), gj = (bi + k) * 16 + (idx & 15);
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < RNW; ++w) t += buf[(w * NACC + a) * 256 + idx];
+        if (gi < S && gj < S) { C0[(size_t)gi * S + gj] = t * invN; C0[(size_t)gj * S + gi] = t * invN; }
+      }
+    }
+    if constexpr (Cfg::NBUF == 1) __syncthreads();
+  }
+}
+
+// RES: the group's only chunk stays in the tile (JB = 8, P <= 512); launched as a pair with the streaming instantiation, each group
+// is taken by exactly one of the two, decided on the device from P[g].  SHRINK: alpha != 0.
+template <int JB, bool RES, bool SHRINK>
+__global__ __launch_bounds__(RNT, JB == 8 ? 2 : 4) void k_mag1c_tile(const Mag1cP p) {
+  using Cfg = TileCfg<JB>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int g = blockIdx.x;
+  const int S = p.S, S16 = (S + 15) & ~15, LD = S16 | 1;    // the matrix padded to whole 16 x 16 blocks (identity beyond S), odd pitch
+  const int nb = S16 >> 4;
+  double* vec = reinterpret_cast<double*>(smem);
+  double* xbar = vec, *tmpl = vec + VEC, *tau = vec + 2 * VEC, *mu = vec + 3 * VEC, *tnew = vec + 4 * VEC;
+  double* vv = vec + 6 * VEC;
+  double* p1 = vec + 8 * VEC, *p2 = vec + 9 * VEC, *p3 = vec + 10 * VEC;
+  double* red = vec + 11 * VEC;      // [64]: [0,32) wave sums, [32,49) the dot products of an iteration, [60] not-PD flag, [61] nstat, [62] 1/N
+  double* Cm = red + 64;             // [S16][LD]: A -> L (lower) + L^{-1} blocks (upper, transposed) -> W;  during the covariance: staging
+  const size_t matsz = (size_t)S16 * LD;
+  double* stg = Cm + (matsz > (size_t)Cfg::STAGE ? matsz : (size_t)Cfg::STAGE);   // [2176]: mat-vec partials | band sums of the 8 waves | X_kk
+  double* Dx = stg;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int P = p.P[g], pitch = p.Ppad[g];
+  if (P <= 0) return;                                     // skipped group (sc_mag1c_layout_columns: too few valid pixels)
+  const float* X = reinterpret_cast<const float*>(p.x) + p.xoff[g];
+  const long long po = p.poff[g];
+  const unsigned char* mk = p.statmask ? p.statmask + po : nullptr;
+  double* mfw = p.mfw + po; double* Rw = p.Rw + po;
+  double* C0 = p.workC + (size_t)g * S * S;
+  const double N = (double)P;
+  constexpr bool shrink = SHRINK, resident = RES;
+  static_assert(!RES || JB == 8, "JB = 4 runs two groups per CU at 128 registers: the tile is never kept");
+  const int nchunk = (P + RNT - 1) / RNT;
+  if (JB == 8 && (nchunk == 1) != RES) return;            // the other kernel of the pair takes this group
+#ifdef STARCOP_MAG1C_PROF
+  long long tprev = wall_clock64();
+#endif
+
+  const int bg = lane & 15;
+  float xt[16][JB];                                         // [pixel q0 + i][band bg + 16*j]
+  unsigned mbits = 0;
+  if (resident) mbits = tile_load<JB>(xt, X, pitch, S, P, mk, (tid >> 4) * 16, bg, lane);
+  for (int s = tid; s < S; s += RNT) tmpl[s] = p.templ[s];
+  if (tid == 0) { red[60] = 0.0; red[62] = 1.0 / N; }
+  PROF(7);
+
+  // ---------------- band means
+  double nstat;
+  {
+    double aj[JB];
+#pragma unroll
+    for (int j = 0; j < JB; ++j) aj[j] = 0.0;
+    double cnt = 0.0;
+    for (int c = 0; c < nchunk; ++c) {
+      if (!resident) mbits = tile_load<JB>(xt, X, pitch, S, P, mk, c * RNT + (tid >> 4) * 16, bg, lane);
+      if (bg == 0) cnt += (double)__popc(mbits);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        rowbar<JB>(xt[i]);
+        const double m = ((mbits >> i) & 1u) ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < JB; ++j) aj[j] = fma((double)xt[i][j], m, aj[j]);
+        accbar<JB>(aj);
+      }
+    }
+    nstat = block_sum_n<RNW>(cnt, red);
+    const double t = tile_band_total<JB>(aj, stg, tid);
+    if (tid < S) xbar[tid] = t / nstat;
+    if (tid == 0) red[61] = nstat;
+  }
+  __syncthreads();
+  PROF(8);
+
+  // ---------------- C_0 / N -> global scratch (the LDS matrix region is the staging area meanwhile)
+  {
+    double xb[JB];
+#pragma unroll
+    for (int j = 0; j < JB; ++j) xb[j] = (bg + 16 * j < S) ? xbar[bg + 16 * j] : 0.0;
+    const double invN = 1.0 / N;
+#define TILE_COV(K) tile_cov_pass<JB, K>(xt, mbits, resident, nchunk, X, pitch, P, mk, xb, nb, Cm, C0, S, invN, tid)
+    TILE_COV(0); TILE_COV(1); TILE_COV(2); TILE_COV(3); TILE_COV(4); TILE_COV(5); TILE_COV(6); TILE_COV(7); TILE_COV(8);
+#undef TILE_COV
+    static_assert(Cfg::NPASS <= 9, "tile_cov_pass calls");
+  }
+  __threadfence_block();
+  __syncthreads();
+  PROF(9);
+  if constexpr (!shrink) {
+    // alpha == 0: W = (C_0 / N)^{-1} once
+    for (int e = tid; e < S16 * S16; e += RNT) {
+      const int a = e / S16, b = e - a * S16;
+      Cm[a * LD + b] = (a < S && b < S) ? C0[(size_t)a * S + b] : (a == b ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    spd_inverse_blocked(Cm, LD, nb, Dx, red + 60, tid);
+  }
+  PROF(10);
 
   // ---------------- rmf (it == 0) then the reweighted-L1 iterations; lane (pg, bg) keeps the state of pixel q0 + bg.
-  // Four barriers per iteration: W [v t] partials | their sums + the ten dot products | the band sums of X^T w | end.
   double R_sel = 1.0, Rinv_sel = 1.0, mf_sel = 0.0;
   double wbar = 0.0, q = 0.0;
   const int last = p.num_iter < 0 ? 0 : p.num_iter;
-  if (tid == 0) { red[61] = nstat; red[62] = 1.0 / N; }
-  if (tid < S) { const double m = xbar[tid]; p2[tid] = 0.0; vv[tid] = 0.0; tau[tid] = 0.0; mu[tid] = m; tnew[tid] = tmpl[tid] * m; }
+  const double scale = (p.num_iter >= 0 || p.apply_scaling) ? 1e5 : 1.0;
+  if (tid < S) { const double m = xbar[tid]; p1[tid] = 0.0; p2[tid] = 0.0; vv[tid] = 0.0; tau[tid] = 0.0; mu[tid] = m; tnew[tid] = tmpl[tid] * m; }
   __syncthreads();
   PROF(12);
   for (int it = 0; it <= last; ++it) {
     // the lane-dependent addresses of the loop body are rebuilt every iteration from an opaque copy of the thread index: hoisted
-    // out of the loop they would be held in registers (or spilled) beside the 128 of the tile
+    // out of the loop they would be held in registers (or spilled) beside those of the tile
     int tz = tid;
     asm volatile("" : "+v"(tz));
     const int lz = tz & 63, bz = tz & 15;
+    if constexpr (shrink) {
+      // alpha != 0: C_k = (C_0 - v tau^T - tau v^T + q tau tau^T) / N, off-diagonal shrunk by (1 - alpha)  (mag1c.py:246-250), then
+      // W = C_k^{-1}.  (C_0/N is read back from the group's global scratch: 19 KB at 49 bands, L2-resident.)
+      const double invN = red[62], oma = 1.0 - p.alpha;
+      for (int e = tz; e < S16 * S16; e += RNT) {
+        const int r = e / S16, c = e - r * S16;
+        if (c <= r) {
+          double v = (r == c) ? 1.0 : 0.0;
+          if (r < S) {
+            v = C0[(size_t)r * S + c];
+            if (it > 0) v += (-vv[r] * tau[c] - tau[r] * vv[c] + q * tau[r] * tau[c]) * invN;
+            if (c != r) v *= oma;
+          }
+          Cm[r * LD + c] = v;
+        }
+      }
+      __syncthreads();
+      spd_inverse_blocked(Cm, LD, nb, Dx, red + 60, tz);
+    }
     // p1 = W v and p3 = W t_new in one pass over W: wave w takes the columns 16w .. 16w+15 for ALL rows (lane l: rows l and l + 64),
     // so its 16 + 16 vector elements are wave-uniform: one LDS read, then scalar operands from v_readlane -- the pass reads W once
     // and nothing else (125 KB per iteration; rows beyond S read padding or stale LDS, their sums are never used)
@@ -1044,11 +1121,12 @@ __global__ __launch_bounds__(RNT) void k_mag1c_res(const Mag1cP p) {
         if (lz < 16 && c0 + lz < S) { uv = vv[c0 + lz]; ut = tnew[c0 + lz]; }
         const double* w0 = Cm + lz * LD + c0;
         const double* w1 = w0 + 64 * LD;
+        const bool two = S16 > 64;
 #pragma unroll
         for (int h = 0; h < 16; h += 8) {                  // (8 + 8 reads in flight: 16 + 16 would not fit beside the tile)
           double m0[8], m1[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) { m0[i] = w0[h + i]; m1[i] = w1[h + i]; }
+          for (int i = 0; i < 8; ++i) { m0[i] = w0[h + i]; m1[i] = two ? w1[h + i] : 0.0; }
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const double sv = readlane_d(uv, h + i), st = readlane_d(ut, h + i);
@@ -1094,7 +1172,7 @@ __global__ __launch_bounds__(RNT) void k_mag1c_res(const Mag1cP p) {
     const double dtp3 = red[38] + red[41], dmup3 = red[39] + red[42];
     const double dvp2 = red[44], dtaup2 = red[45], dp2t = red[46], dmup2 = red[47];
     double y1 = 0.0, y2 = 0.0;
-    if (it > 0) {
+    if (it > 0 && !shrink) {
       // G = M^{-1} + U^T B0 U,  M^{-1} = [[-q,-1],[-1,0]],  B0 = W/N ;  G y = U^T B0 b
       const double invN = red[62];
       const double g11 = -q + dvp1 * invN, g12 = -1.0 + dvp2 * invN, g22 = dtaup2 * invN;
@@ -1106,58 +1184,70 @@ __global__ __launch_bounds__(RNT) void k_mag1c_res(const Mag1cP p) {
     double norm = dtp3 - y1 * dp1t - y2 * dp2t;                     // normaliser  t . C^{-1} t
     const double mucit = dmup3 - y1 * dmup1 - y2 * dmup2;           // mu . C^{-1} t
     const double mumu = red[48];
-    if (!(norm == norm)) notpd = true;
-    if (it > 0 && norm < 1.0) norm = 1.0;
+    if (it > 0 && norm < 1.0) norm = 1.0;               // normalizer.clamp_(min=1) (mag1c.py:264-266)
     const double inorm = 1.0 / norm;
-    // per-pixel filter: C^{-1} t for the lane's eight bands, 16 x 8 products, a 16-lane row sum per pixel
-    double w_sel = 0.0;
+    // ONE pass over the group's chunks: per-pixel filter (C^{-1} t for the lane's JB bands, 16 x JB products, a reduce-scatter per
+    // pixel row), the weight of the pixel, and its share of v = X^T w, sum w, sum w^2
     {
       const bool need_mu = (it == 0) && !p.albedo_override;
-      double cj[8];
+      double cj[JB];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const int sj = bz + 16 * j; cj[j] = sj < S ? p3[sj] - y1 * p1[sj] - y2 * p2[sj] : 0.0; }
-      const double dsel = res_pixel_dots(xt, cj, bz);
-      double dmu = 0.0;
-      if (need_mu) {
+      for (int j = 0; j < JB; ++j) { const int sj = bz + 16 * j; cj[j] = sj < S ? p3[sj] - y1 * p1[sj] - y2 * p2[sj] : 0.0; }
+      double aj[JB];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const int sj = bz + 16 * j; cj[j] = sj < S ? mu[sj] : 0.0; }
-        dmu = res_pixel_dots(xt, cj, bz);
-      }
-      const int r_q = (tz >> 4) * 16 + bz;
-      if (r_q < P) {
-        const double score = dsel - mucit;
-        double mf;
-        if (it == 0) {
-          R_sel = p.albedo_override ? 1.0 : dmu / mumu;
-          Rinv_sel = 1.0 / R_sel;
-          mf = score * Rinv_sel * inorm;
-          if (!p.zero_override) mf = fmax(mf, 0.0);
-        } else {
-          const double reg = p.sparse_override ? 0.0 : Rinv_sel / (mf_sel + 1e-9);
-          mf = fmax((score - reg) * Rinv_sel * inorm, 0.0);
+      for (int j = 0; j < JB; ++j) aj[j] = 0.0;
+      double s1 = 0.0, s2 = 0.0;
+      for (int c = 0; c < nchunk; ++c) {
+        const int r_q = c * RNT + (tz >> 4) * 16 + bz;
+        if (!resident) mbits = tile_load<JB>(xt, X, pitch, S, P, mk, c * RNT + (tz >> 4) * 16, bz, lz);
+        const double dsel = tile_pixel_dots<JB>(xt, cj, bz);
+        double dmu = 0.0;
+        if (need_mu) {
+          double cm[JB];
+#pragma unroll
+          for (int j = 0; j < JB; ++j) { const int sj = bz + 16 * j; cm[j] = sj < S ? mu[sj] : 0.0; }
+          dmu = tile_pixel_dots<JB>(xt, cm, bz);
         }
-        mf_sel = mf;
-        w_sel = (mk == nullptr || mk[r_q]) ? p.kscale * R_sel * mf : 0.0;
+        double w_sel = 0.0;
+        if (r_q < P) {
+          const double score = dsel - mucit;
+          double R = R_sel, Rinv = Rinv_sel, mfp = mf_sel, mf;
+          if (it == 0) {
+            R = p.albedo_override ? 1.0 : dmu / mumu;
+            Rinv = 1.0 / R;
+            mf = score * Rinv * inorm;
+            if (!p.zero_override) mf = fmax(mf, 0.0);
+            if (!resident) Rw[r_q] = R;
+          } else {
+            if (!resident) { R = Rw[r_q]; Rinv = 1.0 / R; mfp = mfw[r_q]; }
+            const double reg = p.sparse_override ? 0.0 : Rinv / (mfp + 1e-9);
+            mf = fmax((score - reg) * Rinv * inorm, 0.0);
+          }
+          if (resident) { R_sel = R; Rinv_sel = Rinv; mf_sel = mf; } else mfw[r_q] = mf;
+          w_sel = ((mbits >> bz) & 1u) ? p.kscale * R * mf : 0.0;
+          if (it == last) {
+            reinterpret_cast<float*>(p.mf_out)[po + r_q] = (float)(mf * scale);
+            reinterpret_cast<float*>(p.alb_out)[po + r_q] = (float)R;
+          }
+        }
+        if (it != last) {
+          s1 += w_sel; s2 += w_sel * w_sel;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const double wi = __shfl(w_sel, (lz & 48) | i, 64);
+            rowbar<JB>(xt[i]);
+#pragma unroll
+            for (int j = 0; j < JB; ++j) aj[j] = fma((double)xt[i][j], wi, aj[j]);
+            accbar<JB>(aj);
+          }
+        }
       }
-    }
-    PROF(2);
-    if (it == last) break;
-    // v = X^T w - xbar * sum(w);  tau <- current target;  W tau <- W t_new.  The sums of w and w^2 ride on the same barrier.
-    {
-      const double s1 = wave_sum_d(w_sel), s2 = wave_sum_d(w_sel * w_sel);
+      PROF(2);
+      if (it == last) break;
+      // v = X^T w - xbar * sum(w);  the sums of w and w^2 ride on the same barrier
+      s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
       if (lz == 0) { red[tz >> 6] = s1; red[16 + (tz >> 6)] = s2; }
-      double aj[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) aj[j] = 0.0;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const double wi = __shfl(w_sel, (lz & 48) | i, 64);
-        ROWBAR(i);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) aj[j] = fma((double)xt[i][j], wi, aj[j]);
-        ACC8BAR(aj);
-      }
-      const double t = res_band_total(aj, stg, tz);
+      const double t = tile_band_total<JB>(aj, stg, tz);
       double sw = 0.0, sww = 0.0;
 #pragma unroll
       for (int w = 0; w < RNW; ++w) { sw += red[w]; sww += red[16 + w]; }
@@ -1172,20 +1262,13 @@ __global__ __launch_bounds__(RNT) void k_mag1c_res(const Mag1cP p) {
     __syncthreads();
     PROF(3);
   }
-  const double scale = (p.num_iter >= 0 || p.apply_scaling) ? 1e5 : 1.0;
-  {
-    const int r_q = q0 + bg;
-    if (r_q < P) {
-      reinterpret_cast<float*>(p.mf_out)[po + r_q] = (float)(mf_sel * scale);
-      reinterpret_cast<float*>(p.alb_out)[po + r_q] = (float)R_sel;
-    }
-  }
-  if (tid == 0) p.status[g] = notpd ? 1 : 0;
+  if (tid == 0) p.status[g] = red[60] != 0.0 ? 1 : 0;
 }
 
-size_t mag1c_res_lds_bytes(int S) {
-  const size_t S16 = (size_t)((S + 15) & ~15), mat = S16 * (S16 | 1);
-  return (11 * VEC + 64 + (mat > (size_t)RES_STAGE ? mat : (size_t)RES_STAGE) + 8 * 272) * sizeof(double);
+template <int JB>
+size_t mag1c_tile_lds_bytes(int S) {
+  const size_t S16 = (size_t)((S + 15) & ~15), mat = S16 * (S16 | 1), stage = (size_t)TileCfg<JB>::STAGE;
+  return (11 * VEC + 64 + (mat > stage ? mat : stage) + 8 * 272) * sizeof(double);
 }
 
 #ifdef STARCOP_MAG1C_PROF
@@ -1455,32 +1538,39 @@ extern "C" int sc_mag1c_groups(const sc_mag1c_args* a, sc_stream stream) {
   p.workC = a->work;
   p.mfw = a->work + (size_t)a->G * a->S * a->S; p.Rw = p.mfw + a->npix; p.wv = p.Rw + a->npix;
   p.mf_out = a->mf_out; p.alb_out = a->albedo_out; p.status = a->status;
-  const size_t lds = mag1c_lds_bytes(a->S);
+  size_t lds = mag1c_lds_bytes(a->S);
   hipStream_t st = (hipStream_t)stream;
   hipError_t e;
   const bool fast = a->alpha == 0.0;     // no shrinkage: one factorisation per group + Woodbury updates
-  if (fast && a->x_is_f64) {
+  if (!a->x_is_f64) {
+    // fp32 radiances (both drivers of the reference): the register-tile kernel.  Up to 64 bands: two groups per CU, chunks streamed;
+    // more: one group per CU, as a pair of launches (groups of <= 512 pixels stay in registers, larger ones stream), see k_mag1c_tile
+#define SC_TILE_GO(...)                                                                                                        \
+    do {                                                                                                                       \
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c_tile<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e == hipSuccess) hipLaunchKernelGGL((k_mag1c_tile<__VA_ARGS__>), dim3(a->G), dim3(RNT), lds, st, p);                  \
+    } while (0)
+    e = hipSuccess;
+    if (a->S <= 64) {
+      lds = mag1c_tile_lds_bytes<4>(a->S);
+      if (fast) SC_TILE_GO(4, false, false); else SC_TILE_GO(4, false, true);
+    } else {
+      lds = mag1c_tile_lds_bytes<8>(a->S);
+      if (fast) { SC_TILE_GO(8, true, false); SC_TILE_GO(8, false, false); } else { SC_TILE_GO(8, true, true); SC_TILE_GO(8, false, true); }
+    }
+#undef SC_TILE_GO
+  } else if (fast) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c_fast<double, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess) hipLaunchKernelGGL((k_mag1c_fast<double, 1024>), dim3(a->G), dim3(1024), lds, st, p);
-  } else if (fast) {
-    // fp32 radiances: a pair of launches; every group is taken by exactly one of them (k_mag1c_res: P <= 512, from registers)
-    const size_t rlds = mag1c_res_lds_bytes(a->S);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c_res), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c_fast<float, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) {
-      hipLaunchKernelGGL(k_mag1c_res, dim3(a->G), dim3(RNT), rlds, st, p);
-      hipLaunchKernelGGL((k_mag1c_fast<float, 1024, true>), dim3(a->G), dim3(1024), lds, st, p);
-    }
   } else {
-    // general path (alpha != 0: refactorisation every iteration).  Few bands: 512 threads (4 groups per CU);
+    // fp64 radiances, alpha != 0: refactorisation every iteration.  Few bands: 512 threads (3 groups per CU);
     // many bands: the matrix fills the LDS, one group of 1024 threads per CU
 #define SC_MAG1C_GO(T_, NT_)                                                                                                   \
     do {                                                                                                                       \
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c<T_, NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e == hipSuccess) hipLaunchKernelGGL((k_mag1c<T_, NT_>), dim3(a->G), dim3(NT_), lds, st, p);                          \
     } while (0)
-    if (a->S <= 64) { if (a->x_is_f64) SC_MAG1C_GO(double, 512); else SC_MAG1C_GO(float, 512); }
-    else { if (a->x_is_f64) SC_MAG1C_GO(double, 1024); else SC_MAG1C_GO(float, 1024); }
+    if (a->S <= 64) SC_MAG1C_GO(double, 512); else SC_MAG1C_GO(double, 1024);
 #undef SC_MAG1C_GO
   }
   if (e != hipSuccess) { sc_set_error("sc_mag1c_groups: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return SC_ERR_LAUNCH; }
