@@ -30,8 +30,8 @@ mag1c.mag1c_columns(raw, te, -9999.0, column_step=2)
 b0 = snap()
 mag1c.mag1c_columns(raw, te, -9999.0, column_step=2)
 d = (snap() - b0) / 100.0
-names = {16: "band means", 17: "covariance C_0", 18: "it: mu, t, C_k", 19: "it: Cholesky", 20: "it: two solves + dots", 21: "it: pixel sweep",
-         22: "it: block sums", 23: "it: v = X^T w"}
-for k in range(16, 24):
-    print(f"{names[k]:24s} {d[k]:9.1f} us" + (f"   ({d[k] / 31:.2f} us per iteration)" if k >= 18 else ""))
-print(f"{'group total':24s} {d[16:24].sum():9.1f} us")
+names = {7: "prologue", 8: "band means", 9: "covariance C_0", 10: "(alpha = 0: inverse)", 12: "init", 4: "it: C_k build", 5: "it: inverse", 0: "it: W t partials",
+         1: "it: sums + dots", 2: "it: the pass over X", 3: "it: band sums, v, next t"}
+for k in (7, 8, 9, 10, 12, 4, 5, 0, 1, 2, 3):
+    print(f"{names[k]:32s} {d[k]:9.1f} us" + (f"   ({d[k] / 31:.2f} us per iteration)" if k < 7 else ""))
+print(f"{'group total':32s} {d[:13].sum():9.1f} us")
