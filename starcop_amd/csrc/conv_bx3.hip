@@ -1209,16 +1209,21 @@ __device__ __forceinline__ void split_filter(float v, bool half, unsigned short 
 // output, optional statistics rows (SC_STAT_CONV3 layout); anything else stays on the other kernels.
 template <int CIN, bool BNB>
 __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
-  constexpr int PR = 10, PC = 34, NPX = PR * PC;
+  // Tile 8 rows x TW px.  16 input channels: TW = 64 -- the runs a work-group reads and writes per (plane, row) are 264 / 256 B instead
+  // of 136 / 128 B, worth 14-17 % at 16 x 512^2 (forward 177 -> 152 us, backward 269 -> 224 us; these layers run at 3 TB/s and neither the
+  // MFMAs -- removed: same time -- nor exposed latency -- persistent work-groups with the next patch in flight: same time -- limit them:
+  // what is left is how DRAM likes the access pattern).  32 channels: the 85 KB patch would leave one work-group per CU (205 -> 308 us).
+  constexpr int TW = CIN == 16 ? 64 : 32, PBW = TW / 16, NPB = 2 * PBW;
+  constexpr int PR = 10, PC = TW + 2, NPX = PR * PC;
   constexpr int NH = CIN / 8;                 // 8-channel groups
   constexpr int NG = 9 * NH, NS = (NG + 3) / 4;
   __shared__ uintx4 s_p[2][NH][NPX];
-  __shared__ float s_red[4][16][2];
+  __shared__ float s_red[4][TW / 32][16][2];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
   const int H = p.H, W = p.W;
-  const int tiles_x = (W + 31) >> 5;
+  const int tiles_x = (W + TW - 1) / TW;
   int n, tile;
   if (p.xcdmap) {      // each XCD walks a contiguous eighth of the pixel tiles (see k_conv3_bx3): halo lines shared in its L2
     const int per_img = tiles_x * ((H + 7) >> 3), total = per_img * p.N, per_xcd = (total + 7) >> 3;
@@ -1230,7 +1235,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
   }
   n = __builtin_amdgcn_readfirstlane(n); tile = __builtin_amdgcn_readfirstlane(tile);      // uniform (see k_conv3_bx3)
   const int ty = __builtin_amdgcn_readfirstlane(tile / tiles_x), tx = tile - ty * tiles_x;
-  const int y0 = ty * 8, x0 = tx * 32;
+  const int y0 = ty * 8, x0 = tx * TW;
   const float hsx = BNB ? h_grad_scale(p.absmax) : SC_H_SX;
   const float hinv = 1.f / (hsx * SC_H_SW);
 
@@ -1308,9 +1313,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
   __syncthreads();
 
   // ---- MFMAs: four 16-pixel blocks per wave, all K steps from LDS, filters from registers
-  floatx4 acc[4];
+  floatx4 acc[NPB];
 #pragma unroll
-  for (int pb = 0; pb < 4; ++pb) acc[pb] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  for (int pb = 0; pb < NPB; ++pb) acc[pb] = (floatx4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int gi = 4 * s + lg;
@@ -1318,8 +1323,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
     const int tap = gic / NH, half = gic - tap * NH;
     const int kh = tap / 3, kw = tap - 3 * kh;
 #pragma unroll
-    for (int pb = 0; pb < 4; ++pb) {
-      const int e = (2 * wave + (pb >> 1) + kh) * PC + 16 * (pb & 1) + l15 + kw;
+    for (int pb = 0; pb < NPB; ++pb) {
+      const int e = (2 * wave + pb / PBW + kh) * PC + 16 * (pb % PBW) + l15 + kw;
       const halfx8 b0 = __builtin_bit_cast(halfx8, s_p[0][half][e]);
       const halfx8 b1 = __builtin_bit_cast(halfx8, s_p[1][half][e]);
       const halfx8 a0 = __builtin_bit_cast(halfx8, A[s][0]);
@@ -1339,30 +1344,35 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int co = 4 * lg + r;
-    float sv = 0.f, sq = 0.f;
+    float sv[TW / 32], sq[TW / 32];             // per 32-pixel statistics tile (SC_STAT_CONV3 rows are 4 rows x 32 px)
 #pragma unroll
-    for (int pb = 0; pb < 4; ++pb) {
-      const int oy = y0 + 2 * wave + (pb >> 1), ox = x0 + 16 * (pb & 1) + l15;
+    for (int h = 0; h < TW / 32; ++h) { sv[h] = 0.f; sq[h] = 0.f; }
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb) {
+      const int oy = y0 + 2 * wave + pb / PBW, ox = x0 + 16 * (pb % PBW) + l15;
       const bool ok = oy < H && ox < W && co < p.Cout;
       const float v = ok ? acc[pb][r] * hinv : 0.f;
-      sv += v; sq = fmaf(v, v, sq);
+      sv[(pb % PBW) >> 1] += v; sq[(pb % PBW) >> 1] = fmaf(v, v, sq[(pb % PBW) >> 1]);
       if (ok) *reinterpret_cast<float*>(reinterpret_cast<char*>(outn) + ((unsigned)co * HWu + (unsigned)(oy * W + ox)) * 4u) = v;
     }
     if (want_stats) {
 #pragma unroll
-      for (int o = 8; o > 0; o >>= 1) { sv += __shfl_xor(sv, o, 64); sq += __shfl_xor(sq, o, 64); }
-      if (l15 == 0) { s_red[wave][co][0] = sv; s_red[wave][co][1] = sq; }
+      for (int h = 0; h < TW / 32; ++h) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { sv[h] += __shfl_xor(sv[h], o, 64); sq[h] += __shfl_xor(sq[h], o, 64); }
+        if (l15 == 0) { s_red[wave][h][co][0] = sv[h]; s_red[wave][h][co][1] = sq[h]; }
+      }
     }
   }
   if (want_stats) {
     __syncthreads();
-    const int rows4 = (H + 3) >> 2;
-    if (tid < 2 * 16 * 2) {
-      const int hh = tid >> 5, col = (tid >> 1) & 15, k = tid & 1;
-      const int t4 = 2 * ty + hh;
-      if (col < p.Cout && t4 < rows4) {
-        const size_t row = ((size_t)n * rows4 + t4) * tiles_x + tx;
-        p.stats[(row * p.Cout + col) * 2 + k] = s_red[2 * hh][col][k] + s_red[2 * hh + 1][col][k];
+    const int rows4 = (H + 3) >> 2, tiles32 = (W + 31) >> 5;
+    if (tid < 2 * (TW / 32) * 16 * 2) {
+      const int hh = tid / ((TW / 32) * 32), h = (tid >> 5) % (TW / 32), col = (tid >> 1) & 15, k = tid & 1;
+      const int t4 = 2 * ty + hh, t32 = tx * (TW / 32) + h;
+      if (col < p.Cout && t4 < rows4 && t32 < tiles32) {
+        const size_t row = ((size_t)n * rows4 + t4) * tiles32 + t32;
+        p.stats[(row * p.Cout + col) * 2 + k] = s_red[2 * hh][h][col][k] + s_red[2 * hh + 1][h][col][k];
       }
     }
   }
@@ -2480,7 +2490,8 @@ extern "C" int sc_conv3x3_thin16(const sc_conv_args* a, sc_stream stream) {
   p.s0 = to_srcd(s); p.s1 = empty_srcd();
   p.wpk = reinterpret_cast<const uintx4*>(a->wpk); p.N = a->N; p.H = a->H; p.W = a->W; p.Cout = a->Cout;
   p.out0 = a->out0; p.csplit = a->Cout; p.stats = a->stats; p.absmax = a->absmax;
-  dim3 grid(((a->W + 31) / 32) * ((a->H + 7) / 8), 1, a->N);
+  const int tw = Cin == 16 ? 64 : 32;                     // (k_conv3_thin_h: TW)
+  dim3 grid(((a->W + tw - 1) / tw) * ((a->H + 7) / 8), 1, a->N);
   constexpr int xcdmap_env = 2;
   p.xcdmap = xcdmap_env ? 2 : 0;
   if (p.xcdmap) {

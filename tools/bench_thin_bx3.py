@@ -11,7 +11,8 @@ def timeit(fn, reps=5):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-for name, cin, cout, H, up in [("d4a", 32, 16, 512, 1), ("d4b", 16, 16, 512, 0), ("d4b.dgrad", 16, 16, 512, 0)]:
+HH = int(os.environ.get("THIN_H", "512"))
+for name, cin, cout, H, up in [("d4a", 32, 16, HH, 1), ("d4b", 16, 16, HH, 0), ("d4b.dgrad", 16, 16, HH, 0)]:
     W = H
     x = torch.randn(N, cin, H >> up, W >> up, device=DEV)
     y = torch.randn(N, cin, H, W, device=DEV)
