@@ -127,13 +127,18 @@ def bench_extras(model, dev, precision):
     groups = np.arange(1, 513)[None, :].repeat(512, 0)
     dt = _timeit(lambda: mag1c.acrwl1mf_by_groups(x, t125, groups), 5)
     dt0 = _timeit(lambda: mag1c.acrwl1mf_by_groups(x, t125, groups, num_iter=0), 5)
-    it_bytes = 31 * 2 * 512 * 512 * S * 4          # X streamed twice per iteration, 31 rounds
+    # round 4: a group's radiances are loaded ONCE into the registers of its work-group (k_mag1c_tile<8, RES>): HBM sees the cube in
+    # the validity mask, in the pack (read + write of the packed copy) and in the one tile load; the 31 rounds run from registers
+    # and are bound by the fp64 VALU / the fp64 MFMA
+    hbm_bytes = (1 + 1 + 1 + 1) * 512 * 512 * S * 4 + 2 * 4 * 512 * 512
+    it_flop = 31 * 2 * 2 * 512 * 512 * S                     # per-pixel dots + X^T w: two fp64 FMAs (and two f32 -> f64 conversions) per element and round
     out["mag1c_cfg3"] = {"workload": "configs[2]: 512x512 px x 125 bands fp32, 512 column groups, acrwl1mf num_iter=30 alpha=0",
                          "ms_per_tile": round(dt * 1e3, 3), "tiles_s": round(1 / dt, 1), "setup_ms": round(dt0 * 1e3, 3),
-                         "roofline": {"bound": "cache (a group's 256 KB of radiances stay in L2/MALL between its 62 sweeps; HBM sees the cube once)",
-                                      "streamed_bytes_per_tile": it_bytes, "streamed_GBs": round(it_bytes / max(dt - dt0, 1e-9) / 1e9, 1),
-                                      "hbm_min_bytes_per_tile": 512 * 512 * S * 4 + 8 * 512 * 512,
-                                      "note": "iteration time = ms_per_tile - setup_ms (setup: validity mask, layout, pack, means, scatter matrix, Cholesky)"}}
+                         "roofline": {"bound": "fp64 VALU (radiances resident in registers; HBM sees the cube four times: mask, pack read + write, tile load)",
+                                      "hbm_bytes_per_tile": hbm_bytes, "hbm_GBs": round(hbm_bytes / dt / 1e9, 1),
+                                      "iteration_fp64_GFLOPs": round(it_flop / max(dt - dt0, 1e-9) / 1e9, 1), "fp64_vector_peak_GFLOPs": 78600.0,
+                                      "note": "iteration time = ms_per_tile - setup_ms (setup: validity mask, layout, pack, tile load, means, fp64-MFMA "
+                                              "covariance, blocked Cholesky / inverse); every product needs a conversion too, so half of the issue slots at best"}}
     # ---- the same tile with ORTHORECTIFIED groups (process_aviris.py:211-217: |GLT sample index| varies along a row and down; 598
     # detector samples): the layout is a device counting sort (sc_mag1c_layout_ids) instead of torch sort / unique
     gl = ((np.arange(512)[None, :] + np.arange(512)[:, None] // 3) % 598 + 1).astype(np.int64)
@@ -145,13 +150,17 @@ def bench_extras(model, dev, precision):
     te = g3["emit_template_kept"][:, 1]
     raw = cube(1280, 1242, te)
     dt = _timeit(lambda: mag1c.mag1c_columns(raw, te, -9999.0, column_step=2), 3)
-    sw = 62 * 1280 * 1242 * te.size * 4
+    # round 4 (k_mag1c_tile<4, ., SHRINK>): X is streamed ONCE per round (weights and X^T w in the same pass) + once for the means + five
+    # covariance passes (two block pairs per pass at <= 64 bands) + mask and pack
+    sw = (31 + 1 + 5 + 3) * 1280 * 1242 * te.size * 4
     out["mag1c_emit"] = {"workload": "EMIT-like 1280x1242 px x 49 bands fp32 storage / fp64 arithmetic, column_step=2 (621 groups), alpha=1e-4",
                          "ms_per_granule": round(dt * 1e3, 3), "Mpx_s": round(1280 * 1242 / dt / 1e6, 1),
                          "tile_equivalents_s": round(1280 * 1242 / 262144 / dt, 1),
                          "roofline": {"bound": "hbm", "streamed_bytes_per_granule": sw, "achieved_GBs": round(sw / dt / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
                                       "frac": round(sw / dt / 1e9 / HBM_PEAK_GBS, 3),
-                                      "note": "X (float32) is streamed 62 times (refactorisation every iteration); whole-call time incl. mask/layout/pack/scatter"}}
+                                      "note": "X (float32) is streamed 40 times (round 3: 66); what keeps it from the HBM rate: the per-round inverse of "
+                                              "C_k (25 us of 79) and 621 groups on 512 slots (two rounds, the second a quarter full); whole-call time "
+                                              "incl. mask/layout/pack/scatter"}}
     # ---- U-Net inference
     model.eval()
     b16 = synth_batch(16, 512, 512, 77, dev)
