@@ -828,11 +828,10 @@ __device__ __forceinline__ bool res_diag_factor(const double* blk, int LD, doubl
 __device__ __forceinline__ void spd_inverse_blocked(double* Cm, int LD, int nb, double* Dx, double* flag, int tid) {
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S16 = nb * 16;
-  double* red = flag - 60;
   {
     // (1) right-looking Cholesky.  Per block column k: panel L_ik = A_ik X_kk^T, trailing A_ij -= L_ik L_jk^T; wave 0 takes the next
     // diagonal block first and factors it while the others finish the update: two barriers per block column.
-    if (wave == 0 && res_diag_factor(Cm, LD, Dx, lane) && lane == 0) red[60] = 1.0;
+    if (wave == 0 && res_diag_factor(Cm, LD, Dx, lane) && lane == 0) *flag = 1.0;
     __syncthreads();
     for (int k = 0; k < nb; ++k) {
       for (int i = k + 1 + wave; i < nb; i += RNW) {
@@ -856,7 +855,7 @@ __device__ __forceinline__ void spd_inverse_blocked(double* Cm, int LD, int nb, 
       if (wave == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (res_diag_factor(Cm + (size_t)(16 * (k + 1)) * LD + 16 * (k + 1), LD, Dx + (k + 1) * 272, lane) && lane == 0) red[60] = 1.0;
+        if (res_diag_factor(Cm + (size_t)(16 * (k + 1)) * LD + 16 * (k + 1), LD, Dx + (k + 1) * 272, lane) && lane == 0) *flag = 1.0;
       }
       __syncthreads();
     }
