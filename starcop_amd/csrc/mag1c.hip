@@ -825,7 +825,9 @@ __device__ __forceinline__ bool res_diag_factor(const double* blk, int LD, doubl
 // of it in 16 x 16 blocks on the fp64 MFMA.  Dx: [nb][16][17] scratch.  flag: set to 1 when a pivot is not positive.  All threads
 // of the work-group call it; ends with a barrier.  (The unblocked forms it replaces: 125 steps of two barriers for the factor, 124
 // dependent dot products for the inverse, 62 LDS reads per element of the product -- 0.3 of the 0.67 ms of a 125-band group.)
-__device__ __forceinline__ void spd_inverse_blocked(double* Cm, int LD, int nb, double* Dx, double* flag, int tid) {
+// Phase (1) alone: the blocked Cholesky factor L (strict lower blocks of Cm; the diagonal blocks are NOT written back) and the inverses
+// X_kk = L_kk^{-1} of its diagonal blocks (Dx [nb][16][17]).  flag: set to 1 when a pivot is not positive.  Ends with a barrier.
+__device__ __forceinline__ void spd_cholesky_blocked(double* Cm, int LD, int nb, double* Dx, double* flag, int tid) {
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S16 = nb * 16;
   {
@@ -859,7 +861,14 @@ __device__ __forceinline__ void spd_inverse_blocked(double* Cm, int LD, int nb, 
       }
       __syncthreads();
     }
-    
+  }
+}
+
+__device__ __forceinline__ void spd_inverse_blocked(double* Cm, int LD, int nb, double* Dx, double* flag, int tid) {
+  spd_cholesky_blocked(Cm, LD, nb, Dx, flag, tid);
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S16 = nb * 16;
+  {
     // (2) X = L^{-1}.  First Y_im = X_ii L_im in place (all blocks at once), then block column j by wave j alone:
     //   X_ij = -sum_{m = j .. i-1} Y_im X_mj   (i > j),  stored TRANSPOSED in the free upper block (j, i) -- the form W reads.
     {
@@ -910,6 +919,50 @@ __device__ __forceinline__ void spd_inverse_blocked(double* Cm, int LD, int nb, 
     }
   }
   __syncthreads();
+}
+
+
+// z = A^{-1} t from the blocked factor (spd_cholesky_blocked), by ONE wave and without barriers: block forward substitution
+// y_k = X_kk (t_k - sum_{m<k} L_km y_m), block back substitution z_k = X_kk^T (y_k - sum_{m>k} L_mk^T z_m).  Lane (r = l & 15, q = l >> 4)
+// takes the columns q, q+4, q+8, q+12 of every 16-wide block of row r; the four parts meet by lane permutes.  z (in / out: y, then z)
+// is an LDS vector of 16*nb doubles; t is only read.  This is all the alpha != 0 path needs of C_k^{-1} (the explicit inverse --
+// two more block phases, a mirror pass and a mat-vec over the whole work-group -- cost 9 us of its 79 us per iteration).
+__device__ __forceinline__ void spd_solve_wave(const double* Cm, int LD, int nb, const double* Dx, const double* t, double* z, int lane) {
+  const int r = lane & 15, q = lane >> 4;
+  for (int k = 0; k < nb; ++k) {
+    double acc = 0.0;
+    for (int m = 0; m < k; ++m) {
+      const double* lrow = Cm + (size_t)(16 * k + r) * LD + 16 * m;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = fma(lrow[q + 4 * j], z[16 * m + q + 4 * j], acc);
+    }
+    acc += __shfl_xor(acc, 16, 64); acc += __shfl_xor(acc, 32, 64);
+    const double sr = t[16 * k + r] - acc;
+    double y = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int c = q + 4 * j; y = fma(Dx[k * 272 + r * 17 + c], __shfl(sr, c, 64), y); }
+    y += __shfl_xor(y, 16, 64); y += __shfl_xor(y, 32, 64);
+    if (q == 0) z[16 * k + r] = y;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int k = nb - 1; k >= 0; --k) {
+    double acc = 0.0;
+    for (int m = k + 1; m < nb; ++m) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const int c = q + 4 * j; acc = fma(Cm[(size_t)(16 * m + c) * LD + 16 * k + r], z[16 * m + c], acc); }
+    }
+    acc += __shfl_xor(acc, 16, 64); acc += __shfl_xor(acc, 32, 64);
+    const double sr = z[16 * k + r] - acc;
+    __builtin_amdgcn_wave_barrier();
+    double y = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int c = q + 4 * j; y = fma(Dx[k * 272 + c * 17 + r], __shfl(sr, c, 64), y); }
+    y += __shfl_xor(y, 16, 64); y += __shfl_xor(y, 32, 64);
+    if (q == 0) z[16 * k + r] = y;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 template <int JB> struct TileCfg {
@@ -1122,9 +1175,22 @@ __global__ __launch_bounds__(RNT, JB == 8 ? 2 : 4) void k_mag1c_tile(const Mag1c
       }
       __syncthreads();
       PROF(4);
-      spd_inverse_blocked(Cm, LD, nb, Dx, red + 60, tz);
+      spd_cholesky_blocked(Cm, LD, nb, Dx, red + 60, tz);
       PROF(5);
+      // C_k^{-1} t and the three dot products the filter needs of it, by wave 0 (no 2 x 2 solve here: y1 = y2 = 0)
+      if (wave == 0) {
+        for (int s2 = lz; s2 < S16; s2 += 64) p1[s2] = s2 < S ? tnew[s2] : 0.0;          // (p1: unused in this path) t padded to whole blocks
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        spd_solve_wave(Cm, LD, nb, Dx, p1, p3, lz);
+        double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+        for (int s2 = lz; s2 < S; s2 += 64) { const double pv = p3[s2], mv = mu[s2]; e0 = fma(tnew[s2], pv, e0); e1 = fma(mv, pv, e1); e2 = fma(mv, mv, e2); }
+        e0 = wave_sum_d(e0); e1 = wave_sum_d(e1); e2 = wave_sum_d(e2);
+        if (lz == 0) { red[38] = e0; red[41] = 0.0; red[39] = e1; red[42] = 0.0; red[48] = e2; }
+      }
+      __syncthreads();
     }
+    if constexpr (!shrink) {
     // p1 = W v and p3 = W t_new in one pass over W: wave w takes the columns 16w .. 16w+15 for ALL rows (lane l: rows l and l + 64),
     // so its 16 + 16 vector elements are wave-uniform: one LDS read, then scalar operands from v_readlane -- the pass reads W once
     // and nothing else (125 KB per iteration; rows beyond S read padding or stale LDS, their sums are never used)
@@ -1182,6 +1248,7 @@ __global__ __launch_bounds__(RNT, JB == 8 ? 2 : 4) void k_mag1c_tile(const Mag1c
       if (lz == 0) { red[40 + wave] = d; if (wave == 7) red[48] = d2; }
     }
     __syncthreads();
+    }
     PROF(1);
     const double dvp1 = red[32] + red[35], dp1t = red[33] + red[36], dmup1 = red[34] + red[37];
     const double dtp3 = red[38] + red[41], dmup3 = red[39] + red[42];
@@ -1196,8 +1263,9 @@ __global__ __launch_bounds__(RNT, JB == 8 ? 2 : 4) void k_mag1c_tile(const Mag1c
       y1 = (z1 * g22 - z2 * g12) * idet;
       y2 = (g11 * z2 - g12 * z1) * idet;
     }
-    double norm = dtp3 - y1 * dp1t - y2 * dp2t;                     // normaliser  t . C^{-1} t
-    const double mucit = dmup3 - y1 * dmup1 - y2 * dmup2;           // mu . C^{-1} t
+    // (alpha != 0: only dtp3, dmup3 and mu.mu were written -- the other slots are stale LDS and must not enter even as 0 x value)
+    double norm = shrink ? dtp3 : dtp3 - y1 * dp1t - y2 * dp2t;                     // normaliser  t . C^{-1} t
+    const double mucit = shrink ? dmup3 : dmup3 - y1 * dmup1 - y2 * dmup2;           // mu . C^{-1} t
     const double mumu = red[48];
     if (it > 0 && norm < 1.0) norm = 1.0;               // normalizer.clamp_(min=1) (mag1c.py:264-266)
     const double inorm = 1.0 / norm;
@@ -1207,7 +1275,7 @@ __global__ __launch_bounds__(RNT, JB == 8 ? 2 : 4) void k_mag1c_tile(const Mag1c
       const bool need_mu = (it == 0) && !p.albedo_override;
       double cj[JB];
 #pragma unroll
-      for (int j = 0; j < JB; ++j) { const int sj = bz + 16 * j; cj[j] = sj < S ? p3[sj] - y1 * p1[sj] - y2 * p2[sj] : 0.0; }
+      for (int j = 0; j < JB; ++j) { const int sj = bz + 16 * j; cj[j] = sj < S ? (shrink ? p3[sj] : p3[sj] - y1 * p1[sj] - y2 * p2[sj]) : 0.0; }
       double aj[JB];
 #pragma unroll
       for (int j = 0; j < JB; ++j) aj[j] = 0.0;
@@ -1253,7 +1321,9 @@ __global__ __launch_bounds__(RNT, JB == 8 ? 2 : 4) void k_mag1c_tile(const Mag1c
           s1 += w_sel; s2 += w_sel * w_sel;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            const double wi = __shfl(w_sel, (lz & 48) | i, 64);
+            int lq = lz & 48;                            // (opaque per row: the 16 permute addresses are not worth 16 registers --
+            asm volatile("" : "+v"(lq));               //  hoisted out of the chunk loop they were spilled and reloaded once per row)
+            const double wi = __shfl(w_sel, lq | i, 64);
             rowbar<JB>(xt[i]);
 #pragma unroll
             for (int j = 0; j < JB; ++j) aj[j] = fma((double)xt[i][j], wi, aj[j]);

@@ -30,8 +30,8 @@ mag1c.mag1c_columns(raw, te, -9999.0, column_step=2)
 b0 = snap()
 mag1c.mag1c_columns(raw, te, -9999.0, column_step=2)
 d = (snap() - b0) / 100.0
-names = {7: "prologue", 8: "band means", 9: "covariance C_0", 10: "(alpha = 0: inverse)", 12: "init", 4: "it: C_k build", 5: "it: inverse", 0: "it: W t partials",
-         1: "it: sums + dots", 2: "it: the pass over X", 3: "it: band sums, v, next t"}
+names = {7: "prologue", 8: "band means", 9: "covariance C_0", 10: "(alpha = 0: inverse)", 12: "init", 4: "it: C_k build", 5: "it: blocked Cholesky", 0: "(alpha = 0: W [v t])",
+         1: "it: solve by wave 0 + dots", 2: "it: the pass over X", 3: "it: band sums, v, next t"}
 for k in (7, 8, 9, 10, 12, 4, 5, 0, 1, 2, 3):
     print(f"{names[k]:32s} {d[k]:9.1f} us" + (f"   ({d[k] / 31:.2f} us per iteration)" if k < 7 else ""))
 print(f"{'group total':32s} {d[:13].sum():9.1f} us")
