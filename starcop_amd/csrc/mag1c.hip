@@ -695,21 +695,30 @@ __device__ __forceinline__ double tile_row_dot(float (&xt)[16][JB], const double
   asm volatile("" : "+v"(t));
   return t;
 }
+// (rows in ascending order: lane bit 0 first -- quad xor 1, quad xor 2, lane xor 4, row rotation by 8 -- so that the four-row pieces
+// a tile is loaded in are consumed one after the other, which is what lets the streaming kernels refill a piece in place as soon as
+// the X^T w pass is done with it)
 template <int JB>
 __device__ __forceinline__ double tile_pixel_dots(float (&xt)[16][JB], const double (&cj)[JB], int bz) {
   const bool b3 = bz & 8, b2 = bz & 4, b1 = bz & 2, b0 = bz & 1;
-  double r4[4];
+  double r8[2];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    double r8[2];
+  for (int h = 0; h < 2; ++h) {
+    double r4[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const double d0 = tile_row_dot<JB>(xt, cj, a + 4 * h), d1 = tile_row_dot<JB>(xt, cj, a + 4 * h + 8);
-      r8[h] = res_comb<0x140>(b3, d0, d1);
+    for (int a = 0; a < 2; ++a) {
+      double r2[2];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int i = 8 * h + 4 * a + 2 * g;
+        const double d0 = tile_row_dot<JB>(xt, cj, i), d1 = tile_row_dot<JB>(xt, cj, i + 1);
+        r2[g] = res_comb<0xB1>(b0, d0, d1);
+      }
+      r4[a] = res_comb<0x4E>(b1, r2[0], r2[1]);
     }
-    r4[a] = res_comb<0x141>(b2, r8[0], r8[1]);
+    r8[h] = (b2 ? r4[1] : r4[0]) + __shfl_xor(b2 ? r4[0] : r4[1], 4, 64);
   }
-  return res_comb<0xB1>(b0, res_comb<0x4E>(b1, r4[0], r4[2]), res_comb<0x4E>(b1, r4[1], r4[3]));
+  return res_comb<0x128>(b3, r8[0], r8[1]);
 }
 
 // per-band totals of per-lane partial sums aj[j] (band bg + 16*j): over the wave's four pixel groups by lane permutes, over the eight
@@ -1280,13 +1289,28 @@ __global__ __launch_bounds__(RNT, JB == 8 ? 2 : 4) void k_mag1c_tile(const Mag1c
 #pragma unroll
       for (int j = 0; j < JB; ++j) aj[j] = 0.0;
       double s1 = 0.0, s2 = 0.0;
+      // streaming groups: the tile of chunk c + 1 is requested IN PLACE, four rows (one float4 per band) at a time, as soon as the
+      // X^T w pass is done with those rows of chunk c -- a whole tile in flight behind the arithmetic with no second register set
+      // (the first chunk of an iteration is loaded here: held across the factorisation it would cost that phase 64 registers)
+      double R_ld = 1.0, mf_ld = 0.0;
+      if (!resident) {
+        mbits = tile_load<JB>(xt, X, pitch, S, P, mk, (tz >> 4) * 16, bz, lz);
+        if (it > 0 && (tz >> 4) * 16 + bz < P) { R_ld = Rw[(tz >> 4) * 16 + bz]; mf_ld = mfw[(tz >> 4) * 16 + bz]; }
+      }
       for (int c = 0; c < nchunk; ++c) {
-        const int r_q = c * RNT + (tz >> 4) * 16 + bz;
-        double R_ld = 1.0, mf_ld = 0.0;
-        if (!resident) {
-          mbits = tile_load<JB>(xt, X, pitch, S, P, mk, c * RNT + (tz >> 4) * 16, bz, lz);
-          if (it > 0 && r_q < P) { R_ld = Rw[r_q]; mf_ld = mfw[r_q]; }      // (in flight together with the tile)
-        }
+        const int q0c = c * RNT + (tz >> 4) * 16, r_q = q0c + bz;
+        const bool refill = !resident && c + 1 < nchunk;
+        auto request_rows = [&](int u) {               // rows 4u .. 4u+3 of the next chunk
+          const int q0n = q0c + RNT;
+          const bool pgok = q0n < pitch;
+#pragma unroll
+          for (int j = 0; j < JB; ++j) {
+            const int sj = bz + 16 * j;
+            float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pgok && sj < S) a4 = *reinterpret_cast<const float4*>(X + (size_t)sj * pitch + q0n + 4 * u);
+            xt[4 * u][j] = a4.x; xt[4 * u + 1][j] = a4.y; xt[4 * u + 2][j] = a4.z; xt[4 * u + 3][j] = a4.w;
+          }
+        };
         const double dsel = tile_pixel_dots<JB>(xt, cj, bz);
         double dmu = 0.0;
         if (need_mu) {
@@ -1317,18 +1341,28 @@ __global__ __launch_bounds__(RNT, JB == 8 ? 2 : 4) void k_mag1c_tile(const Mag1c
             reinterpret_cast<float*>(p.alb_out)[po + r_q] = (float)R;
           }
         }
-        if (it != last) {
-          s1 += w_sel; s2 += w_sel * w_sel;
+        if (it != last) { s1 += w_sel; s2 += w_sel * w_sel; }
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            int lq = lz & 48;                            // (opaque per row: the 16 permute addresses are not worth 16 registers --
-            asm volatile("" : "+v"(lq));               //  hoisted out of the chunk loop they were spilled and reloaded once per row)
-            const double wi = __shfl(w_sel, lq | i, 64);
-            rowbar<JB>(xt[i]);
+        for (int u = 0; u < 4; ++u) {
+          if (it != last) {
 #pragma unroll
-            for (int j = 0; j < JB; ++j) aj[j] = fma((double)xt[i][j], wi, aj[j]);
-            accbar<JB>(aj);
+            for (int i = 4 * u; i < 4 * u + 4; ++i) {
+              int lq = lz & 48;                            // (opaque per row: the 16 permute addresses are not worth 16 registers --
+              asm volatile("" : "+v"(lq));               //  hoisted out of the chunk loop they were spilled and reloaded once per row)
+              const double wi = __shfl(w_sel, lq | i, 64);
+              rowbar<JB>(xt[i]);
+#pragma unroll
+              for (int j = 0; j < JB; ++j) aj[j] = fma((double)xt[i][j], wi, aj[j]);
+              accbar<JB>(aj);
+            }
           }
+          if (refill) request_rows(u);
+        }
+        if (refill) {
+          const int r_qn = r_q + RNT;
+          const bool mine_ok = r_qn < P && (mk == nullptr || mk[r_qn]);
+          mbits = (unsigned)(__ballot(mine_ok) >> (lz & 48)) & 0xffffu;
+          if (it > 0 && r_qn < P) { R_ld = Rw[r_qn]; mf_ld = mfw[r_qn]; }
         }
       }
       PROF(2);
