@@ -633,7 +633,8 @@ __global__ __launch_bounds__(NT) void k_mag1c_fast(const Mag1cP p) {
 // ------------------------------------------------------------------------------------------
 // k_mag1c_tile<JB>: every fp32 group (any P, S <= 16*JB, alpha = 0 or not) with the radiances held in a REGISTER TILE.
 // 512 threads; thread (pixel group pg = wave*4 + lane/16, band lane bg = lane%16) keeps the 16 x JB tile
-//   x[chunk*512 + pg*16 + i][bg + 16*j],   i < 16, j < JB          (JB = 8: 128 registers, S <= 128;  JB = 4: 64 registers, S <= 64)
+//   x[chunk*512 + pg*16 + i][bg + 16*j],   i < 16, j < JB          (JB = 8: 128 registers, S <= 128;  JB = 4: 64 registers, S <= 64:
+//   half the conversions / products per pixel row for the same reduce-scatter)
 // of one 512-pixel chunk of the group.  A group of P <= 512 pixels (JB = 8) is loaded ONCE and stays on chip for the whole kernel
 // (P x S x 4 B = 256 KB at 512 x 125 does not fit the LDS beside the S x S matrix, but it fits the registers of the work-group);
 // larger groups stream their chunks through the same tile -- once per iteration, not twice: the weight of a pixel needs only that
@@ -976,7 +977,7 @@ __device__ __forceinline__ void spd_solve_wave(const double* Cm, int LD, int nb,
 
 template <int JB> struct TileCfg {
   static constexpr int NACC = JB == 8 ? 4 : 2;              // covariance blocks accumulated per pass (8 registers each)
-  static constexpr int NBUF = JB == 8 ? 2 : 1;              // staging buffers (JB = 4 keeps the LDS of a group under 80 KB: two groups per CU)
+  static constexpr int NBUF = JB == 8 ? 2 : 1;              // staging buffers (JB = 4: 62 KB of LDS per group)
   static constexpr int NPAIR = JB * (JB + 1) / 2;
   static constexpr int NPASS = (NPAIR + NACC - 1) / NACC;
   static constexpr int STAGE = NBUF * RNW * NACC * 256;     // doubles
@@ -1047,8 +1048,11 @@ __device__ __forceinline__ void tile_cov_pass(float (&xt)[16][JB], unsigned& mbi
 
 // RES: the group's only chunk stays in the tile (JB = 8, P <= 512); launched as a pair with the streaming instantiation, each group
 // is taken by exactly one of the two, decided on the device from P[g].  SHRINK: alpha != 0.
+// One work-group per CU (up to 256 registers) for JB = 4 as well: at 128 registers (two groups per CU) the streaming loop kept ~30 values
+// in scratch and a group took 2.5 ms instead of 1.56 ms alone on its CU -- the EMIT granule (621 groups: three rounds of one or two
+// rounds of two) takes 4.9 ms either way, a shard of it (column_range, fewer groups than CUs) only the faster form.
 template <int JB, bool RES, bool SHRINK>
-__global__ __launch_bounds__(RNT, JB == 8 ? 2 : 4) void k_mag1c_tile(const Mag1cP p) {
+__global__ __launch_bounds__(RNT, 2) void k_mag1c_tile(const Mag1cP p) {
   using Cfg = TileCfg<JB>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int g = blockIdx.x;
@@ -1074,7 +1078,7 @@ __global__ __launch_bounds__(RNT, JB == 8 ? 2 : 4) void k_mag1c_tile(const Mag1c
   double* C0 = p.workC + (size_t)g * S * S;
   const double N = (double)P;
   constexpr bool shrink = SHRINK, resident = RES;
-  static_assert(!RES || JB == 8, "JB = 4 runs two groups per CU at 128 registers: the tile is never kept");
+  static_assert(!RES || JB == 8, "the resident form exists for JB = 8 only");
   const int nchunk = (P + RNT - 1) / RNT;
   if (JB == 8 && (nchunk == 1) != RES) return;            // the other kernel of the pair takes this group
 #ifdef STARCOP_MAG1C_PROF
@@ -1699,8 +1703,8 @@ extern "C" int sc_mag1c_groups(const sc_mag1c_args* a, sc_stream stream) {
   hipError_t e;
   const bool fast = a->alpha == 0.0;     // no shrinkage: one factorisation per group + Woodbury updates
   if (!a->x_is_f64) {
-    // fp32 radiances (both drivers of the reference): the register-tile kernel.  Up to 64 bands: two groups per CU, chunks streamed;
-    // more: one group per CU, as a pair of launches (groups of <= 512 pixels stay in registers, larger ones stream), see k_mag1c_tile
+    // fp32 radiances (both drivers of the reference): the register-tile kernel, one group per CU.  Up to 64 bands: chunks streamed;
+    // more: a pair of launches (groups of <= 512 pixels stay in registers, larger ones stream), see k_mag1c_tile
 #define SC_TILE_GO(...)                                                                                                        \
     do {                                                                                                                       \
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c_tile<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
