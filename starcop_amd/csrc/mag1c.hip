@@ -799,10 +799,14 @@ __device__ __forceinline__ double readlane_d(double v, int l) {           // l u
 // X in registers; step j takes the pivot and the column of L from the lanes that own them (v_readlane), no LDS, no barrier.
 // Only X is stored (Dk [16][17], zero above the diagonal): the panel solve, the inverse and W all use X_kk, nothing uses L_kk again.
 __device__ __forceinline__ bool res_diag_factor(const double* blk, int LD, double* Dk, int lane) {
-  const int r = lane & 15;
-  double a[16], x[16];
+  const int r = lane & 15, q = lane >> 4;
+  // every 16-lane group keeps the whole row r of the block (the factor's sweep is replicated: its column of L is then at hand in
+  // every group at no cost); of X the group q keeps the columns q, q+4, q+8, q+12 only -- a quarter of the longest part of the sweep
+  double a[16], x[4];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) { a[c] = blk[r * LD + c]; x[c] = (c == r) ? 1.0 : 0.0; }
+  for (int c = 0; c < 16; ++c) a[c] = blk[r * LD + c];
+#pragma unroll
+  for (int cq = 0; cq < 4; ++cq) x[cq] = (4 * cq + q == r) ? 1.0 : 0.0;
   bool bad = false;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
@@ -814,19 +818,18 @@ __device__ __forceinline__ bool res_diag_factor(const double* blk, int LD, doubl
     const double lr = a[j] * rd;                        // L[r][j] (r >= j)
 #pragma unroll
     for (int c = j + 1; c < 16; ++c) a[c] = fma(-lr, readlane_d(lr, c), a[c]);
-    // [L | I] -> [I | X]: row j scaled (by its own lane), then taken out of the rows below -- with per-step factors (1 or rd, lr or
-    // 0) instead of per-element selects, which were 4 of the 9 instructions per element of this, the longest part of the sweep
+    // [L | I] -> [I | X]: row j scaled (by its own lanes), then taken out of the rows below -- with per-step factors (1 or rd, lr or
+    // 0) instead of per-element selects.  Columns beyond j hold zeros in row j: they take part without effect.
     const double sc = (r == j) ? rd : 1.0, lm = (r > j) ? lr : 0.0;
+    const int src = (lane & 48) | j;                    // row j of this lane group
 #pragma unroll
-    for (int c = 0; c <= j; ++c) {
-      x[c] *= sc;
-      x[c] = fma(-lm, readlane_d(x[c], j), x[c]);
+    for (int cq = 0; cq <= (j >> 2); ++cq) {
+      x[cq] *= sc;
+      x[cq] = fma(-lm, __shfl(x[cq], src, 64), x[cq]);
     }
   }
-  if (lane < 16) {
 #pragma unroll
-    for (int c = 0; c < 16; ++c) Dk[r * 17 + c] = (c <= r) ? x[c] : 0.0;
-  }
+  for (int cq = 0; cq < 4; ++cq) Dk[r * 17 + 4 * cq + q] = (4 * cq + q <= r) ? x[cq] : 0.0;
   return bad;
 }
 
