@@ -158,9 +158,9 @@ def bench_extras(model, dev, precision):
                          "tile_equivalents_s": round(1280 * 1242 / 262144 / dt, 1),
                          "roofline": {"bound": "hbm", "streamed_bytes_per_granule": sw, "achieved_GBs": round(sw / dt / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
                                       "frac": round(sw / dt / 1e9 / HBM_PEAK_GBS, 3),
-                                      "note": "X (float32) is streamed 40 times (round 3: 66); what keeps it from the HBM rate: the per-round inverse of "
-                                              "C_k (25 us of 79) and 621 groups on 512 slots (two rounds, the second a quarter full); whole-call time "
-                                              "incl. mask/layout/pack/scatter"}}
+                                      "note": "X (float32) is streamed 40 times (round 3: 66); what keeps it from the HBM rate: the serial diagonal-block "
+                                              "sweeps of the per-round factorisation of C_k (12 us of 42) and 621 groups on 256 CUs (three rounds, the "
+                                              "third 43 % full); whole-call time incl. mask/layout/pack/scatter"}}
     # ---- U-Net inference
     model.eval()
     b16 = synth_batch(16, 512, 512, 77, dev)
