@@ -41,33 +41,43 @@ def _covariance(m, n_div, alpha, dt):
     return (Cm + dt(alpha) * (np.diag(np.diag(Cm)) - Cm)).astype(dt)
 
 
-def rmf_group(x, template, alpha=0.0, zero_override=False, albedo_override=False, apply_scaling=True, mask=None):
-    """x [P,S], template [S] -> (mf [P], R [P] or scalar 1).  Statistics over ``mask`` pixels, divided by ALL P."""
+def _energy(xmm, Cm):
+    """sum of ALL entries of (x-mu) C^{-1} (x-mu)^T, formed as the reference forms it (mag1c.py:271-275, 338): a P x P matrix."""
+    return float(np.sum(xmm @ _chol_solve(Cm, np.ascontiguousarray(xmm.T))))
+
+
+def rmf_group(x, template, alpha=0.0, zero_override=False, albedo_override=False, apply_scaling=True, mask=None, energy=None):
+    """x [P,S], template [S] -> (mf [P], R [P] or scalar 1).  Statistics over ``mask`` pixels, divided by ALL P.
+    ``energy``: a list; gets (norm residual, N/2 * log(1 / prod diag chol C)) appended (compute_energy, mag1c.py:337-343)."""
     dt = x.dtype.type
     P = x.shape[0]
     t = template.astype(x.dtype)
     stat = x if mask is None else x[mask]
     mu = stat.mean(axis=0, dtype=x.dtype)
     target = t * mu
-    Cit = _chol_solve(_covariance(stat - mu, P, alpha, dt), target)
+    Cm0 = _covariance(stat - mu, P, alpha, dt)
+    Cit = _chol_solve(Cm0, target)
+    if energy is not None:
+        energy.append((_energy(x - mu, Cm0), np.diag(np.linalg.cholesky(Cm0)).astype(x.dtype), P))
     normalizer = target @ Cit
     R = np.ones(P, dtype=x.dtype) if albedo_override else (x @ mu) / (mu @ mu)
     mf = ((x - mu) @ Cit) / (R * normalizer)
     if not zero_override:
         mf = np.maximum(mf, 0)
-    if apply_scaling:
+    if apply_scaling and energy is None:      # (the reference returns (mf, R, energy) BEFORE its scaling line: mag1c.py:337-346)
         mf = mf * dt(SCALING)
     return mf.astype(x.dtype), R.astype(x.dtype)
 
 
 def acrwl1mf_group(x, template, num_iter=30, albedo_override=False, zero_override=False, sparse_override=False,
-                   covariance_update_scaling=1.0, alpha=0.0, mask=None):
-    """Albedo-corrected reweighted-L1 matched filter for one group (mag1c.py:177-280)."""
+                   covariance_update_scaling=1.0, alpha=0.0, mask=None, energy=None):
+    """Albedo-corrected reweighted-L1 matched filter for one group (mag1c.py:177-280).
+    ``energy``: a list; gets the rmf pair first, then one norm residual per iteration (mag1c.py:270-275)."""
     dt = x.dtype.type
     P = x.shape[0]
     t = template.astype(x.dtype)
     mf, R = rmf_group(x, t, alpha=alpha, zero_override=zero_override, albedo_override=albedo_override,
-                      apply_scaling=False, mask=mask)
+                      apply_scaling=False, mask=mask, energy=energy)
     sel = slice(None) if mask is None else mask
     target = t * x[sel].mean(axis=0, dtype=x.dtype)
     k = dt(covariance_update_scaling)
@@ -75,22 +85,45 @@ def acrwl1mf_group(x, template, num_iter=30, albedo_override=False, zero_overrid
         modx = x[sel] - (k * R[sel] * mf[sel])[:, None] * target[None, :]
         mu = modx.mean(axis=0, dtype=x.dtype)
         target = t * mu
-        Cit = _chol_solve(_covariance(modx - mu, P, alpha, dt), target)
+        Cmk = _covariance(modx - mu, P, alpha, dt)
+        Cit = _chol_solve(Cmk, target)
+        if energy is not None:
+            energy.append(_energy(x - mu, Cmk))
         reg = dt(0) if sparse_override else dt(1) / (R * (mf + dt(EPSILON)))
         normalizer = max(target @ Cit, dt(1))            # clamp_(min=1) when < 1  (:264-266)
         mf = np.maximum((((x - mu) @ Cit) - reg) / (R * normalizer), 0).astype(x.dtype)   # relu unconditional (:268)
     return (mf * dt(SCALING)).astype(x.dtype), R
 
 
-def rmf(x, template, **kw):
-    """batched [b,p,s] -> (mf [b,p,1], R [b,p,1])"""
-    outs = [rmf_group(x[b], template, **kw) for b in range(x.shape[0])]
-    return np.stack([o[0] for o in outs])[..., None], np.stack([o[1] for o in outs])[..., None]
+def _rmf_energy(per_group):
+    """the reference's value, a scalar: the norm residuals summed over the WHOLE batch + N/2 log(1 / prod of ALL diagonal entries of all
+    the batch's Cholesky factors), the product taken in the data's dtype (mag1c.py:338-341: torch.prod without a dim; in float32 it
+    underflows to 0 for a few dozen bands and the reference returns inf)"""
+    total = sum(e[0][0] for e in per_group)
+    diags = np.concatenate([e[0][1] for e in per_group])
+    n = per_group[0][0][2]
+    with np.errstate(divide="ignore", over="ignore"):
+        det = diags.dtype.type(1) / np.prod(diags, dtype=diags.dtype)
+        return float(total + n / 2 * np.log(det))
 
 
-def acrwl1mf(x, template, **kw):
-    outs = [acrwl1mf_group(x[b], template, **kw) for b in range(x.shape[0])]
-    return np.stack([o[0] for o in outs])[..., None], np.stack([o[1] for o in outs])[..., None]
+def rmf(x, template, compute_energy=False, **kw):
+    """batched [b,p,s] -> (mf [b,p,1], R [b,p,1])  (+ the scalar energy with compute_energy)"""
+    en = [[] for _ in range(x.shape[0])] if compute_energy else [None] * x.shape[0]
+    outs = [rmf_group(x[b], template, energy=en[b], **kw) for b in range(x.shape[0])]
+    res = np.stack([o[0] for o in outs])[..., None], np.stack([o[1] for o in outs])[..., None]
+    return res + (_rmf_energy(en),) if compute_energy else res
+
+
+def acrwl1mf(x, template, compute_energy=False, **kw):
+    """(+ with compute_energy: the list the reference returns -- [rmf energy, then per iteration the residual summed over the batch])"""
+    en = [[] for _ in range(x.shape[0])] if compute_energy else [None] * x.shape[0]
+    outs = [acrwl1mf_group(x[b], template, energy=en[b], **kw) for b in range(x.shape[0])]
+    res = np.stack([o[0] for o in outs])[..., None], np.stack([o[1] for o in outs])[..., None]
+    if not compute_energy:
+        return res
+    n_it = len(en[0]) - 1
+    return res + ([_rmf_energy(en)] + [sum(e[1 + k] for e in en) for k in range(n_it)],)
 
 
 def func_by_groups(func, x, groups, mask=None, min_pixels=10):

@@ -33,6 +33,8 @@ struct Mag1cP {
   double* mfw; double* Rw; double* wv;   // [npix] per-pixel state
   void* mf_out; void* alb_out;
   int* status;
+  double* energy;    // [G][max(num_iter,0)+1] residual terms (compute_energy), or null
+  double* logdet;    // [G] P/2 * log(1 / prod diag chol C) of the first covariance, or null
 };
 
 #ifdef STARCOP_MAG1C_PROF
@@ -44,15 +46,6 @@ __device__ long long g_prof[32];
 
 constexpr int MAXS = 128;
 constexpr int VEC = 128;
-
-__device__ __forceinline__ double block_sum1(double v, double* red) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  v = wave_sum_d(v);
-  __syncthreads();
-  if (lane == 0) red[wave] = v;
-  __syncthreads();
-  return red[0] + red[1] + red[2] + red[3];
-}
 
 template <int NW>
 __device__ __forceinline__ double block_sum_n(double v, double* red) {
@@ -657,13 +650,6 @@ __device__ __forceinline__ double dpp_mov_d(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double row_sum16_d(double v) {      // every lane of a 16-lane row gets the row's sum
-  v += dpp_mov_d<0xB1>(v);      // quad_perm [1,0,3,2]
-  v += dpp_mov_d<0x4E>(v);      // quad_perm [2,3,0,1]
-  v += dpp_mov_d<0x141>(v);     // row_half_mirror
-  v += dpp_mov_d<0x140>(v);     // row_mirror
-  return v;
-}
 
 // the block pairs (bi <= bj) of the upper triangle of an n x n block matrix, row-major
 constexpr int tri_pair_bi(int k, int n) { int bi = 0; while (k >= n - bi) { k -= n - bi; ++bi; } return bi; }
@@ -842,7 +828,6 @@ __device__ __forceinline__ bool res_diag_factor(const double* blk, int LD, doubl
 // X_kk = L_kk^{-1} of its diagonal blocks (Dx [nb][16][17]).  flag: set to 1 when a pivot is not positive.  Ends with a barrier.
 __device__ __forceinline__ void spd_cholesky_blocked(double* Cm, int LD, int nb, double* Dx, double* flag, int tid) {
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int S16 = nb * 16;
   {
     // (1) right-looking Cholesky.  Per block column k: panel L_ik = A_ik X_kk^T, trailing A_ij -= L_ik L_jk^T; wave 0 takes the next
     // diagonal block first and factors it while the others finish the update: two barriers per block column.
@@ -1054,7 +1039,12 @@ __device__ __forceinline__ void tile_cov_pass(float (&xt)[16][JB], unsigned& mbi
 // One work-group per CU (up to 256 registers) for JB = 4 as well: at 128 registers (two groups per CU) the streaming loop kept ~30 values
 // in scratch and a group took 2.5 ms instead of 1.56 ms alone on its CU -- the EMIT granule (621 groups: three rounds of one or two
 // rounds of two) takes 4.9 ms either way, a shard of it (column_range, fewer groups than CUs) only the faster form.
-template <int JB, bool RES, bool SHRINK>
+// ENERGY: compute_energy of the reference (mag1c.py:270-275, 337-343) -- per iteration the SUM of all entries of the P x P matrix
+// (x-mu) C_k^{-1} (x-mu)^T, which is s^T C_k^{-1} s with s = sum_p (x_p - mu_k) = P (d + wbar tau), d = mean over all pixels - mean over
+// the statistics pixels (zero without a mask): nothing P x P is formed.  alpha = 0: from the dot products the iteration has anyway
+// (+ d.p1, d.p2, and W d once);  alpha != 0: one more substitution per iteration.  Plus, once, the log-determinant term of rmf from
+// the diagonal of the first factor.  Separate instantiations (streaming form only): the default kernels carry none of it.
+template <int JB, bool RES, bool SHRINK, bool ENERGY = false>
 __global__ __launch_bounds__(RNT, 2) void k_mag1c_tile(const Mag1cP p) {
   using Cfg = TileCfg<JB>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1083,7 +1073,8 @@ __global__ __launch_bounds__(RNT, 2) void k_mag1c_tile(const Mag1cP p) {
   constexpr bool shrink = SHRINK, resident = RES;
   static_assert(!RES || JB == 8, "the resident form exists for JB = 8 only");
   const int nchunk = (P + RNT - 1) / RNT;
-  if (JB == 8 && (nchunk == 1) != RES) return;            // the other kernel of the pair takes this group
+  static_assert(!ENERGY || !RES, "the energy instantiations are streaming ones");
+  if (!ENERGY && JB == 8 && (nchunk == 1) != RES) return;  // the other kernel of the pair takes this group (ENERGY: launched alone)
 #ifdef STARCOP_MAG1C_PROF
   long long tprev = wall_clock64();
 #endif
@@ -1121,6 +1112,27 @@ __global__ __launch_bounds__(RNT, 2) void k_mag1c_tile(const Mag1cP p) {
     if (tid == 0) red[61] = nstat;
   }
   __syncthreads();
+  double* dvec = vec + 7 * VEC, *wdv = vec + 5 * VEC;     // (ENERGY) d = mean(all) - mean(statistics pixels);  W d | the second solution
+  if constexpr (ENERGY) {
+    double aj[JB];
+#pragma unroll
+    for (int j = 0; j < JB; ++j) aj[j] = 0.0;
+    if (mk != nullptr) {
+      for (int c = 0; c < nchunk; ++c) {
+        mbits = tile_load<JB>(xt, X, pitch, S, P, nullptr, c * RNT + (tid >> 4) * 16, bg, lane);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          rowbar<JB>(xt[i]);
+#pragma unroll
+          for (int j = 0; j < JB; ++j) aj[j] += (double)xt[i][j];       // (rows beyond P hold zeros)
+          accbar<JB>(aj);
+        }
+      }
+    }
+    const double t = tile_band_total<JB>(aj, stg, tid);
+    if (tid < VEC) dvec[tid] = (mk != nullptr && tid < S) ? t / N - xbar[tid] : 0.0;
+    __syncthreads();
+  }
   PROF(8);
 
   // ---------------- C_0 / N -> global scratch (the LDS matrix region is the staging area meanwhile)
@@ -1145,6 +1157,20 @@ __global__ __launch_bounds__(RNT, 2) void k_mag1c_tile(const Mag1cP p) {
     }
     __syncthreads();
     spd_inverse_blocked(Cm, LD, nb, Dx, red + 60, tid);
+    if constexpr (ENERGY) {
+      // P/2 log(1 / prod diag L) = P/2 sum log diag(L^{-1}) (the diagonal blocks of L^{-1} are still in Dx);  W d and d.W d
+      double lg = 0.0, dw = 0.0;
+      if (tid < S16) lg = log(Dx[(tid >> 4) * 272 + (tid & 15) * 17 + (tid & 15)]);
+      if (tid < S) {
+        double a = 0.0;
+        for (int c = 0; c < S; ++c) a = fma(Cm[tid * LD + c], dvec[c], a);
+        wdv[tid] = a; dw = dvec[tid] * a;
+      }
+      lg = block_sum_n<RNW>(lg, red);
+      dw = block_sum_n<RNW>(dw, red + 16);
+      if (tid == 0) { p.logdet[g] = 0.5 * N * lg; red[50] = dw; }
+      __syncthreads();
+    }
   }
   PROF(10);
 
@@ -1203,6 +1229,18 @@ __global__ __launch_bounds__(RNT, 2) void k_mag1c_tile(const Mag1cP p) {
         for (int s2 = lz; s2 < S; s2 += 64) { const double pv = p3[s2], mv = mu[s2]; e0 = fma(tnew[s2], pv, e0); e1 = fma(mv, pv, e1); e2 = fma(mv, mv, e2); }
         e0 = wave_sum_d(e0); e1 = wave_sum_d(e1); e2 = wave_sum_d(e2);
         if (lz == 0) { red[38] = e0; red[41] = 0.0; red[39] = e1; red[42] = 0.0; red[48] = e2; }
+        if constexpr (ENERGY) {
+          // s^T C_k^{-1} s,  s = P (d + wbar tau): one more substitution;  first iteration: the log-determinant term
+          for (int s2 = lz; s2 < S16; s2 += 64) p1[s2] = s2 < S ? dvec[s2] + wbar * tau[s2] : 0.0;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          spd_solve_wave(Cm, LD, nb, Dx, p1, wdv, lz);
+          double e3 = 0.0, lg = 0.0;
+          for (int s2 = lz; s2 < S; s2 += 64) e3 = fma(p1[s2], wdv[s2], e3);
+          if (it == 0) for (int s2 = lz; s2 < S16; s2 += 64) lg += log(Dx[(s2 >> 4) * 272 + (s2 & 15) * 17 + (s2 & 15)]);
+          e3 = wave_sum_d(e3); lg = wave_sum_d(lg);
+          if (lz == 0) { p.energy[(size_t)g * (last + 1) + it] = N * N * e3; if (it == 0) p.logdet[g] = 0.5 * N * lg; }
+        }
       }
       __syncthreads();
     }
@@ -1253,6 +1291,13 @@ __global__ __launch_bounds__(RNT, 2) void k_mag1c_tile(const Mag1cP p) {
       }
       e0 = wave_sum_d(e0); e1 = wave_sum_d(e1); e2 = wave_sum_d(e2);
       if (lz == 0) { red[32 + 3 * wave] = e0; red[33 + 3 * wave] = e1; red[34 + 3 * wave] = e2; }
+      if constexpr (ENERGY) {
+        if (wave < 2) {                                   // d . p1 (rows of waves 0 and 1)
+          double e3 = (r < S) ? dvec[r] * pv : 0.0;
+          e3 = wave_sum_d(e3);
+          if (lz == 0) red[51 + wave] = e3;
+        }
+      }
     } else {
       // vec slots: tau 2, mu 3, t 4, v 6, p2 9
       const int sa = wave == 4 ? 6 : wave == 5 ? 2 : wave == 6 ? 9 : 3, sb = wave == 6 ? 4 : 9;
@@ -1262,6 +1307,14 @@ __global__ __launch_bounds__(RNT, 2) void k_mag1c_tile(const Mag1cP p) {
       d = wave_sum_d(d);
       if (wave == 7) d2 = wave_sum_d(d2);
       if (lz == 0) { red[40 + wave] = d; if (wave == 7) red[48] = d2; }
+      if constexpr (ENERGY) {
+        if (wave == 5) {                                  // d . p2
+          double e3 = 0.0;
+          for (int s = lz; s < S; s += 64) e3 = fma(dvec[s], p2[s], e3);
+          e3 = wave_sum_d(e3);
+          if (lz == 0) red[53] = e3;
+        }
+      }
     }
     __syncthreads();
     }
@@ -1280,6 +1333,21 @@ __global__ __launch_bounds__(RNT, 2) void k_mag1c_tile(const Mag1cP p) {
       y2 = (g11 * z2 - g12 * z1) * idet;
     }
     // (alpha != 0: only dtp3, dmup3 and mu.mu were written -- the other slots are stale LDS and must not enter even as 0 x value)
+    if constexpr (ENERGY && !shrink) {
+      if (tz == 0) {
+        // s^T C_k^{-1} s = N [ s^T B0 s - b^T G^{-1} b ],  s = P (d + wbar tau),  b = U^T B0 s   (B0 = W / N, U = [v tau], G as above)
+        const double dwd = red[50], dp1 = red[51] + red[52], dp2 = red[53];
+        const double sBs = N * (dwd + 2.0 * wbar * dp2 + wbar * wbar * dtaup2);
+        double bGb = 0.0;
+        if (it > 0) {
+          const double invN = red[62];
+          const double g11 = -q + dvp1 * invN, g12 = -1.0 + dvp2 * invN, g22 = dtaup2 * invN;
+          const double b1 = dp1 + wbar * dvp2, b2 = dp2 + wbar * dtaup2;
+          bGb = (b1 * b1 * g22 - 2.0 * b1 * b2 * g12 + b2 * b2 * g11) / (g11 * g22 - g12 * g12);
+        }
+        p.energy[(size_t)g * (last + 1) + it] = N * (sBs - bGb);
+      }
+    }
     double norm = shrink ? dtp3 : dtp3 - y1 * dp1t - y2 * dp2t;                     // normaliser  t . C^{-1} t
     const double mucit = shrink ? dmup3 : dmup3 - y1 * dmup1 - y2 * dmup2;           // mu . C^{-1} t
     const double mumu = red[48];
@@ -1701,6 +1769,9 @@ extern "C" int sc_mag1c_groups(const sc_mag1c_args* a, sc_stream stream) {
   p.workC = a->work;
   p.mfw = a->work + (size_t)a->G * a->S * a->S; p.Rw = p.mfw + a->npix; p.wv = p.Rw + a->npix;
   p.mf_out = a->mf_out; p.alb_out = a->albedo_out; p.status = a->status;
+  p.energy = a->energy; p.logdet = a->logdet;
+  SC_REQUIRE((a->energy == nullptr) == (a->logdet == nullptr), "sc_mag1c_groups: energy and logdet go together");
+  SC_REQUIRE(a->energy == nullptr || !a->x_is_f64, "sc_mag1c_groups: compute_energy is evaluated on float32 radiances only (the float64 kernels do not carry it)");
   size_t lds = mag1c_lds_bytes(a->S);
   hipStream_t st = (hipStream_t)stream;
   hipError_t e;
@@ -1714,7 +1785,10 @@ extern "C" int sc_mag1c_groups(const sc_mag1c_args* a, sc_stream stream) {
       if (e == hipSuccess) hipLaunchKernelGGL((k_mag1c_tile<__VA_ARGS__>), dim3(a->G), dim3(RNT), lds, st, p);                  \
     } while (0)
     e = hipSuccess;
-    if (a->S <= 64) {
+    if (a->energy) {                 // compute_energy: the streaming instantiations take every group
+      if (a->S <= 64) { lds = mag1c_tile_lds_bytes<4>(a->S); if (fast) SC_TILE_GO(4, false, false, true); else SC_TILE_GO(4, false, true, true); }
+      else { lds = mag1c_tile_lds_bytes<8>(a->S); if (fast) SC_TILE_GO(8, false, false, true); else SC_TILE_GO(8, false, true, true); }
+    } else if (a->S <= 64) {
       lds = mag1c_tile_lds_bytes<4>(a->S);
       if (fast) SC_TILE_GO(4, false, false); else SC_TILE_GO(4, false, true);
     } else {

@@ -26,7 +26,7 @@ DEFAULT_WAVELENGTH_RANGE = (2122, 2488)
 
 
 # ------------------------------------------------------------------------------------------------
-def _run_groups(cube2d, S_total, band0, S, pix_index, counts, template, num_iter, alpha, k, flags, statmask=None):
+def _run_groups(cube2d, S_total, band0, S, pix_index, counts, template, num_iter, alpha, k, flags, statmask=None, energy=False):
     """cube2d: (npixels_image, S_total) device tensor (f32|f64, contiguous); pix_index: int64 device tensor of the packed
     pixels (group after group); counts: python list / cpu tensor of pixels per group.  Returns (mf, albedo) packed."""
     lib = _lib.load()
@@ -67,13 +67,20 @@ def _run_groups(cube2d, S_total, band0, S, pix_index, counts, template, num_iter
     work = torch.empty(lib.sc_mag1c_workspace_doubles(G, S, npix), dtype=torch.float64, device=dev)
     status = torch.zeros(G, dtype=torch.int32, device=dev)
     a.work, a.mf_out, a.albedo_out, a.status = work.data_ptr(), mf.data_ptr(), alb.data_ptr(), status.data_ptr()
+    en = ld = None
+    if energy:          # compute_energy: per group and stage the residual term, per group the log-determinant term of the rmf stage
+        if is64:
+            raise NotImplementedError("compute_energy is evaluated on float32 radiances (fp64 arithmetic); pass x.float()")
+        en = torch.zeros(G, max(int(num_iter), 0) + 1, dtype=torch.float64, device=dev)
+        ld = torch.zeros(G, dtype=torch.float64, device=dev)
+        a.energy, a.logdet = en.data_ptr(), ld.data_ptr()
     check(lib.sc_mag1c_groups(C.byref(a), st))
     bad = torch.nonzero(status).reshape(-1)
     if bad.numel():          # the reference's torch.linalg.cholesky raises (mag1c.py:251,323)
         raise torch.linalg.LinAlgError(
             f"linalg.cholesky: (Batch element {int(bad[0])}): The factorization could not be completed because the "
             "input is not positive-definite")
-    return mf, alb
+    return (mf, alb, en, ld) if energy else (mf, alb)
 
 
 def _column_runs(ids):
@@ -164,7 +171,7 @@ def _run_column_groups(cube3, b0, S, valid_u8, gcol, min_keep, template, num_ite
     return mf_out.reshape(rows, cols), alb_out.reshape(rows, cols)
 
 
-def _batched(x, template, num_iter, alpha, k, flags, mask):
+def _batched(x, template, num_iter, alpha, k, flags, mask, energy=False):
     _lib.require_device(x)
     if x.dim() != 3:
         raise ValueError("x must be [batch, pixels, spectrum]")
@@ -179,25 +186,35 @@ def _batched(x, template, num_iter, alpha, k, flags, mask):
         m = torch.squeeze(m, 0) if m.dim() > 1 else m
         assert m.shape == x.shape[1:2], f"Unexpected shape of mask: {m.shape} expected {x.shape[1:2]}"
         sm = m.to(torch.uint8).repeat(b).contiguous()
-    mf, alb = _run_groups(x2, s, 0, s, pix, [p] * b, template, num_iter, alpha, k, flags, sm)
-    return mf.reshape(b, p, 1), alb.reshape(b, p, 1)
+    out = _run_groups(x2, s, 0, s, pix, [p] * b, template, num_iter, alpha, k, flags, sm, energy=energy)
+    return (out[0].reshape(b, p, 1), out[1].reshape(b, p, 1)) + tuple(out[2:])
 
 
 @torch.no_grad()
 def rmf(x, template, alpha=0., zero_override=False, compute_energy=False, albedo_override=False, apply_scaling=True,
         mask=None):
-    """Classic robust matched filter, [b, p, s] -> (mf [b, p, 1] ppm*m, albedo [b, p, 1])."""
+    """Classic robust matched filter, [b, p, s] -> (mf [b, p, 1] ppm*m, albedo [b, p, 1]).
+    ``compute_energy`` (mag1c.py:337-343): also the reference's scalar -- the residual term summed over the batch + N/2 log(1 / prod of the
+    diagonals of all Cholesky factors) -- and, as there, mf is returned WITHOUT the ppm*m scaling (the reference returns before that line).
+    The residual term is the sum of all entries of (x-mu) C^{-1} (x-mu)^T = s^T C^{-1} s, s = sum_p (x_p - mu): evaluated in that form
+    (fp64, float32 radiances), not as a P x P matrix; without a mask it is exactly zero where the reference returns rounding noise."""
     if compute_energy:
-        raise NotImplementedError("compute_energy is a diagnostic of the reference, not part of the hot path")
+        mf, alb, en, ld = _batched(x, template, -1, alpha, 1.0, (albedo_override, zero_override, False, False), mask, energy=True)
+        return mf, alb, (en[:, 0].sum() + ld.sum()).to(mf.dtype)
     return _batched(x, template, -1, alpha, 1.0, (albedo_override, zero_override, False, apply_scaling), mask)
 
 
 @torch.no_grad()
 def acrwl1mf(x, template, num_iter=30, albedo_override=False, zero_override=False, sparse_override=False,
              covariance_update_scaling=1., alpha=0., compute_energy=False, mask=None):
-    """Albedo-corrected reweighted-L1 matched filter, [b, p, s] -> (mf [b, p, 1], albedo [b, p, 1])."""
+    """Albedo-corrected reweighted-L1 matched filter, [b, p, s] -> (mf [b, p, 1], albedo [b, p, 1]).
+    ``compute_energy`` (mag1c.py:270-275): also the list the reference returns -- [the rmf energy, then one residual term per iteration,
+    each summed over the batch] (see rmf for how the terms are evaluated)."""
     if compute_energy:
-        raise NotImplementedError("compute_energy is a diagnostic of the reference, not part of the hot path")
+        mf, alb, en, ld = _batched(x, template, int(num_iter), alpha, covariance_update_scaling,
+                                   (albedo_override, zero_override, sparse_override, True), mask, energy=True)
+        tot = en.sum(dim=0).to(mf.dtype)
+        return mf, alb, [tot[0] + ld.sum().to(mf.dtype)] + [tot[1 + i] for i in range(int(num_iter))]
     return _batched(x, template, int(num_iter), alpha, covariance_update_scaling,
                     (albedo_override, zero_override, sparse_override, True), mask)
 

@@ -430,6 +430,32 @@ def g10_emit_driver():
     np.savez_compressed(os.path.join(OUT, "g10_emit_driver.npz"), **out)
 
 
+def g11_energy():
+    """compute_energy=True (mag1c.py:270-275, 337-343) of rmf / acrwl1mf: the reference's own numbers for float64 and float32 groups,
+    with and without a statistics mask, alpha = 0 and 1e-4.  Without a mask the residual term is the sum of a P x P matrix whose exact
+    value is zero (rounding noise of the reference's arithmetic): those cases pin the log-det term and the iteration terms."""
+    g3 = np.load(os.path.join(OUT, "g3_templates.npz"))
+    rng = np.random.default_rng(4321)
+    templ24 = g3["aviris_template_kept"][:, 1][::3][:24].copy()
+    out = {}
+    for dt, tag in ((np.float64, "f64"), (np.float32, "f32")):
+        xa = np.stack([synth_group(rng, 200, 24, templ24, dt) for _ in range(2)])
+        mask = rng.uniform(size=200) > 0.3
+        out[f"x_{tag}"], out[f"mask_{tag}"] = xa, mask
+        for alpha, at in ((0.0, "a0"), (1e-4, "a1e4")):
+            for mk, mt in ((None, "nomask"), (mask, "mask")):
+                kw = {} if mk is None else {"mask": torch.tensor(mk)}
+                mf, R, e = ref_mag1c.rmf(torch.tensor(xa), torch.tensor(templ24.astype(dt)), alpha=alpha, compute_energy=True, **kw)
+                out[f"rmf_{tag}_{at}_{mt}_mf"], out[f"rmf_{tag}_{at}_{mt}_e"] = mf.numpy(), np.asarray(e, dtype=np.float64)
+                mf, R, el = ref_mag1c.acrwl1mf(torch.tensor(xa), torch.tensor(templ24.astype(dt)), num_iter=5, alpha=alpha,
+                                               compute_energy=True, **kw)
+                out[f"acr_{tag}_{at}_{mt}_mf"] = mf.numpy()
+                out[f"acr_{tag}_{at}_{mt}_e0"] = np.asarray(el[0], dtype=np.float64)
+                out[f"acr_{tag}_{at}_{mt}_e"] = np.array([float(v) for v in el[1:]], dtype=np.float64)
+    out["t"] = templ24
+    np.savez_compressed(os.path.join(OUT, "g11_energy.npz"), **out)
+
+
 if __name__ == "__main__":
     tpl = g3_templates()
     g1_filters(tpl)
@@ -441,6 +467,7 @@ if __name__ == "__main__":
     g5_masks()
     g9_convblocks()
     g10_emit_driver()
+    g11_energy()
     print("golden vectors written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f))} bytes")

@@ -338,3 +338,36 @@ def test_paired_launch_mixed_group_sizes(hip, S):
         worst[sz] = float(rel(mf[sel], want[sel]).max())
         assert worst[sz] < 1e-5 and rel(alb[sel], walb[sel]).max() < 1e-6, (sz, worst)
     print(f"S={S}: worst relative error per group size {worst}")
+
+
+@pytest.mark.parametrize("S", [24, 73])
+def test_compute_energy(hip, S):
+    """compute_energy=True of rmf / acrwl1mf (mag1c.py:270-275, 337-343) on float32 radiances against oracle/mag1c_ref evaluated in
+    float64 on the same radiances (pinned on the reference's own float64 numbers by golden G11; the reference's float32 value of the rmf
+    term is inf -- its product of Cholesky diagonals underflows -- and its float32 iteration terms carry 1e-5..1e-2 of rounding noise,
+    so the float64 evaluation is the meaningful target).  With and without a statistics mask, alpha = 0 (from the Woodbury scalars)
+    and 1e-4 (one more substitution per iteration); 24 bands (<= 64: four band slots per lane) and 73 (eight).  The residual term is
+    evaluated as s^T C^{-1} s, not as the sum of a P x P matrix: without a mask its rmf-stage value is exactly 0 where the reference
+    returns cancellation noise, so that stage is compared through the log-determinant term that dominates it."""
+    rng = np.random.default_rng(500 + S)
+    P, B = 300, 2
+    t = -np.abs(rng.standard_normal(S)) * 0.3
+    base = rng.uniform(1, 6, size=S)
+    x = (base * (1 + 0.05 * rng.standard_normal((B, P, S))) + 0.2 * rng.standard_normal((B, P, 1)) * base).astype(np.float32)
+    mask = rng.uniform(size=P) > 0.3
+    xd = torch.from_numpy(x).to(DEV)
+    for alpha in (0.0, 1e-4):
+        for mk in (None, mask):
+            kw = {} if mk is None else {"mask": torch.from_numpy(mk).to(DEV)}
+            okw = {} if mk is None else {"mask": mk}
+            mf, R, e = hip_mag1c.rmf(xd, t, alpha=alpha, compute_energy=True, **kw)
+            wmf, wR, we = mag1c_ref.rmf(x.astype(np.float64), t, alpha=alpha, compute_energy=True, **okw)
+            assert rel(mf.cpu().numpy(), wmf).max() < 1e-5                       # unscaled, as the reference returns it there
+            assert abs(float(e) - we) <= 2e-6 * abs(we), (S, alpha, mk is None, float(e), we)
+            mf, R, el = hip_mag1c.acrwl1mf(xd, t, num_iter=6, alpha=alpha, compute_energy=True, **kw)
+            wmf, wR, wel = mag1c_ref.acrwl1mf(x.astype(np.float64), t, num_iter=6, alpha=alpha, compute_energy=True, **okw)
+            assert rel(mf.cpu().numpy(), wmf).max() < 1e-5
+            got = np.array([float(v) for v in el]); want = np.array(wel)
+            assert len(el) == 7 and np.max(np.abs(got - want) / np.abs(want)) < 2e-5, (S, alpha, mk is None, got, want)
+    with pytest.raises(NotImplementedError):
+        hip_mag1c.rmf(xd.double(), t, compute_energy=True)
