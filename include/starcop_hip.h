@@ -413,7 +413,7 @@ typedef struct sc_mag1c_args {
   void* mf_out;             /* [npix] per-pixel outputs, element type of x                                */
   void* albedo_out;         /* [npix]                                                                     */
   int32_t* status;          /* [G] 0 ok, 1 covariance not positive definite (-> torch.linalg.LinAlgError) */
-  /* compute_energy of the reference (starcop/models/mag1c.py:270-275, 337-343), both null or both set; float32 radiances only:
+  /* compute_energy of the reference (starcop/models/mag1c.py:270-275, 337-343), both null or both set:
    * energy [G][max(num_iter,0)+1] = sum of all entries of (x-mu) C_k^{-1} (x-mu)^T per group and iteration (entry 0: the rmf stage),
    * logdet [G] = P/2 * log(1 / prod diag chol C) of the rmf stage */
   double* energy;

@@ -60,7 +60,7 @@ __device__ __forceinline__ double block_sum_n(double v, double* red) {
   return t;
 }
 
-template <typename T, int NT>
+template <typename T, int NT, bool ENERGY = false>
 __global__ __launch_bounds__(NT, NT == 512 ? 6 : 4) void k_mag1c(const Mag1cP p) {      // 512 threads: 3 groups per CU
   constexpr int NW = NT / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -163,6 +163,17 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 4) void k_mag1c(const Mag1cP p)
   __syncthreads();
 
   PROF(17);
+  // compute_energy (see k_mag1c_tile<.., ENERGY>): d = mean over all pixels - mean over the statistics pixels, kept in stg (free now)
+  double* dvec = stg;
+  if constexpr (ENERGY) {
+    for (int s = wave; s < S; s += NW) {
+      double a = 0.0;
+      if (mk != nullptr) for (int q = lane; q < P; q += 64) a += (double)X[(size_t)s * pitch + q];
+      a = wave_sum_d(a);
+      if (lane == 0) dvec[s] = mk != nullptr ? a / N - xbar[s] : 0.0;
+    }
+    __syncthreads();
+  }
   // ---------------- phase C: rmf (it == 0) then the reweighted-L1 iterations
   double sw = 0.0, sww = 0.0;
   bool notpd = false;
@@ -258,6 +269,31 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 4) void k_mag1c(const Mag1cP p)
       if (lane + 64 < S) { a0 += tnew[lane + 64] * b1; a1 += mu[lane + 64] * b1; a2 += mu[lane + 64] * mu[lane + 64]; }
       a0 = wave_sum_d(a0); a1 = wave_sum_d(a1); a2 = wave_sum_d(a2);
       if (lane == 0) { red[32] = a0; red[33] = a1; red[34] = a2; }
+      if constexpr (ENERGY) {
+        // s^T C_k^{-1} s with s = P (d + wbar tau): the same two substitutions for a second right-hand side; first iteration: the
+        // log-determinant term P/2 log(1 / prod diag L)
+        const double r0 = lane < S ? dvec[lane] + wbar * tau[lane] : 0.0;
+        const double r1 = lane + 64 < S ? dvec[lane + 64] + wbar * tau[lane + 64] : 0.0;
+        double c0 = r0, c1 = r1;
+        for (int j = 0; j < S; ++j) {
+          const double bj = __shfl(j < 64 ? c0 : c1, j & 63, 64);
+          const double yj = bj / Cm[j * LDC + j];
+          if (lane == (j & 63)) { if (j < 64) c0 = yj; else c1 = yj; }
+          if (lane > j && lane < S) c0 -= Cm[lane * LDC + j] * yj;
+          if (lane + 64 > j && lane + 64 < S) c1 -= Cm[(lane + 64) * LDC + j] * yj;
+        }
+        for (int j = S - 1; j >= 0; --j) {
+          const double bj = __shfl(j < 64 ? c0 : c1, j & 63, 64);
+          const double zj = bj / Cm[j * LDC + j];
+          if (lane == (j & 63)) { if (j < 64) c0 = zj; else c1 = zj; }
+          if (lane < j) c0 -= Cm[j * LDC + lane] * zj;
+          if (lane + 64 < j) c1 -= Cm[j * LDC + lane + 64] * zj;
+        }
+        double e3 = r0 * c0 + r1 * c1, lg = 0.0;
+        if (it == 0) { if (lane < S) lg += log(Cm[lane * LDC + lane]); if (lane + 64 < S) lg += log(Cm[(lane + 64) * LDC + lane + 64]); }
+        e3 = wave_sum_d(e3); lg = wave_sum_d(lg);
+        if (lane == 0) { p.energy[(size_t)g * (last + 1) + it] = N * N * e3; if (it == 0) p.logdet[g] = -0.5 * N * lg; }
+      }
     }
     __syncthreads();
     PROF(20);
@@ -486,6 +522,29 @@ __global__ __launch_bounds__(NT) void k_mag1c_fast(const Mag1cP p) {
   for (int e = tid; e < S * S; e += NT) { const int a = e / S, b = e - a * S; Cm[a * LDC + b] = C0[e]; }
   for (int s = tid; s < S; s += NT) { p2[s] = 0.0; vv[s] = 0.0; tau[s] = 0.0; }
   __syncthreads();
+  // compute_energy (see k_mag1c_tile<.., ENERGY>): d = mean over all pixels - mean over the statistics pixels; d.W d and the
+  // log-determinant term once; d ends up in the `col` slot (1 / diag L, needed for that term first, is dead afterwards)
+  if (p.energy) {
+    for (int s = wave; s < S; s += NW) {
+      double a = 0.0;
+      if (mk != nullptr) for (int q0 = lane; q0 < P; q0 += 64) a += (double)X[(size_t)s * pitch + q0];
+      a = wave_sum_d(a);
+      if (lane == 0) cit[s] = mk != nullptr ? a / N - xbar[s] : 0.0;
+    }
+    __syncthreads();
+    double dw = 0.0, lg = 0.0;
+    for (int r = tid; r < S; r += NT) {
+      double a = 0.0;
+      for (int c = 0; c < S; ++c) a = fma(Cm[r * LDC + c], cit[c], a);
+      dw += cit[r] * a; lg += log(col[r]);
+    }
+    dw = block_sum_n<NW>(dw, red);
+    lg = block_sum_n<NW>(lg, red + 16);
+    if (tid == 0) { red[50] = dw; p.logdet[g] = 0.5 * N * lg; }
+    __syncthreads();
+    for (int s = tid; s < S; s += NT) col[s] = cit[s];
+    __syncthreads();
+  }
 
   // ---------------- rmf (it == 0) then the reweighted-L1 iterations
   double sw = 0.0, sww = 0.0;
@@ -549,6 +608,20 @@ __global__ __launch_bounds__(NT) void k_mag1c_fast(const Mag1cP p) {
         red[32] = d[5] - y1 * d[3] - y2 * d[4];           // normaliser  t . C^{-1} t
         red[33] = d[8] - y1 * d[6] - y2 * d[7];           // mu . C^{-1} t
         red[34] = mm; red[35] = y1; red[36] = y2;
+      }
+      if (p.energy) {
+        // s^T C_k^{-1} s = N [ s^T B0 s - b^T G^{-1} b ],  s = P (d + wbar tau),  b = U^T B0 s
+        double dp1 = 0.0, dp2 = 0.0;
+        for (int s = lane; s < S; s += 64) { dp1 = fma(col[s], p1[s], dp1); dp2 = fma(col[s], p2[s], dp2); }
+        dp1 = wave_sum_d(dp1); dp2 = wave_sum_d(dp2);
+        const double sBs = N * (red[50] + 2.0 * wbar * dp2 + wbar * wbar * d[2]);
+        double bGb = 0.0;
+        if (it > 0) {
+          const double g11 = -q + d[0] / N, g12 = -1.0 + d[1] / N, g22 = d[2] / N;
+          const double b1 = dp1 + wbar * d[1], b2 = dp2 + wbar * d[2];
+          bGb = (b1 * b1 * g22 - 2.0 * b1 * b2 * g12 + b2 * b2 * g11) / (g11 * g22 - g12 * g12);
+        }
+        if (lane == 0) p.energy[(size_t)g * (last + 1) + it] = N * (sBs - bGb);
       }
     }
     __syncthreads();
@@ -1771,7 +1844,6 @@ extern "C" int sc_mag1c_groups(const sc_mag1c_args* a, sc_stream stream) {
   p.mf_out = a->mf_out; p.alb_out = a->albedo_out; p.status = a->status;
   p.energy = a->energy; p.logdet = a->logdet;
   SC_REQUIRE((a->energy == nullptr) == (a->logdet == nullptr), "sc_mag1c_groups: energy and logdet go together");
-  SC_REQUIRE(a->energy == nullptr || !a->x_is_f64, "sc_mag1c_groups: compute_energy is evaluated on float32 radiances only (the float64 kernels do not carry it)");
   size_t lds = mag1c_lds_bytes(a->S);
   hipStream_t st = (hipStream_t)stream;
   hipError_t e;
@@ -1802,12 +1874,13 @@ extern "C" int sc_mag1c_groups(const sc_mag1c_args* a, sc_stream stream) {
   } else {
     // fp64 radiances, alpha != 0: refactorisation every iteration.  Few bands: 512 threads (3 groups per CU);
     // many bands: the matrix fills the LDS, one group of 1024 threads per CU
-#define SC_MAG1C_GO(T_, NT_)                                                                                                   \
+#define SC_MAG1C_GO(T_, NT_, EN_)                                                                                                 \
     do {                                                                                                                       \
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c<T_, NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      if (e == hipSuccess) hipLaunchKernelGGL((k_mag1c<T_, NT_>), dim3(a->G), dim3(NT_), lds, st, p);                          \
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c<T_, NT_, EN_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e == hipSuccess) hipLaunchKernelGGL((k_mag1c<T_, NT_, EN_>), dim3(a->G), dim3(NT_), lds, st, p);                     \
     } while (0)
-    if (a->S <= 64) SC_MAG1C_GO(double, 512); else SC_MAG1C_GO(double, 1024);
+    if (a->energy) { if (a->S <= 64) SC_MAG1C_GO(double, 512, true); else SC_MAG1C_GO(double, 1024, true); }
+    else { if (a->S <= 64) SC_MAG1C_GO(double, 512, false); else SC_MAG1C_GO(double, 1024, false); }
 #undef SC_MAG1C_GO
   }
   if (e != hipSuccess) { sc_set_error("sc_mag1c_groups: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return SC_ERR_LAUNCH; }

@@ -69,8 +69,6 @@ def _run_groups(cube2d, S_total, band0, S, pix_index, counts, template, num_iter
     a.work, a.mf_out, a.albedo_out, a.status = work.data_ptr(), mf.data_ptr(), alb.data_ptr(), status.data_ptr()
     en = ld = None
     if energy:          # compute_energy: per group and stage the residual term, per group the log-determinant term of the rmf stage
-        if is64:
-            raise NotImplementedError("compute_energy is evaluated on float32 radiances (fp64 arithmetic); pass x.float()")
         en = torch.zeros(G, max(int(num_iter), 0) + 1, dtype=torch.float64, device=dev)
         ld = torch.zeros(G, dtype=torch.float64, device=dev)
         a.energy, a.logdet = en.data_ptr(), ld.data_ptr()
@@ -197,7 +195,7 @@ def rmf(x, template, alpha=0., zero_override=False, compute_energy=False, albedo
     ``compute_energy`` (mag1c.py:337-343): also the reference's scalar -- the residual term summed over the batch + N/2 log(1 / prod of the
     diagonals of all Cholesky factors) -- and, as there, mf is returned WITHOUT the ppm*m scaling (the reference returns before that line).
     The residual term is the sum of all entries of (x-mu) C^{-1} (x-mu)^T = s^T C^{-1} s, s = sum_p (x_p - mu): evaluated in that form
-    (fp64, float32 radiances), not as a P x P matrix; without a mask it is exactly zero where the reference returns rounding noise."""
+    (fp64 arithmetic), not as a P x P matrix; without a mask it is exactly zero where the reference returns rounding noise."""
     if compute_energy:
         mf, alb, en, ld = _batched(x, template, -1, alpha, 1.0, (albedo_override, zero_override, False, False), mask, energy=True)
         return mf, alb, (en[:, 0].sum() + ld.sum()).to(mf.dtype)

@@ -369,5 +369,27 @@ def test_compute_energy(hip, S):
             assert rel(mf.cpu().numpy(), wmf).max() < 1e-5
             got = np.array([float(v) for v in el]); want = np.array(wel)
             assert len(el) == 7 and np.max(np.abs(got - want) / np.abs(want)) < 2e-5, (S, alpha, mk is None, got, want)
-    with pytest.raises(NotImplementedError):
-        hip_mag1c.rmf(xd.double(), t, compute_energy=True)
+
+
+def test_compute_energy_float64_vs_reference_golden(hip):
+    """float64 radiances (k_mag1c_fast for alpha = 0, k_mag1c for alpha != 0) against golden G11 = the numbers the reference itself returned
+    for compute_energy=True: the rmf scalar (dominated by the log-determinant term) and the five iteration terms, with and without a mask."""
+    g = np.load(os.path.join(G, "g11_energy.npz"))
+    x, t, m = g["x_f64"], g["t"], g["mask_f64"]
+    xd = torch.from_numpy(x).to(DEV)
+    worst = 0.0
+    for at, alpha in (("a0", 0.0), ("a1e4", 1e-4)):
+        for mt, mk in (("nomask", None), ("mask", m)):
+            kw = {} if mk is None else {"mask": torch.from_numpy(mk).to(DEV)}
+            mf, R, e = hip_mag1c.rmf(xd, t, alpha=alpha, compute_energy=True, **kw)
+            assert rel(mf.cpu().numpy(), g[f"rmf_f64_{at}_{mt}_mf"]).max() < 1e-9
+            want = float(g[f"rmf_f64_{at}_{mt}_e"])
+            assert abs(float(e) - want) <= 1e-9 * abs(want), (at, mt, float(e), want)
+            mf, R, el = hip_mag1c.acrwl1mf(xd, t, num_iter=5, alpha=alpha, compute_energy=True, **kw)
+            assert rel(mf.cpu().numpy(), g[f"acr_f64_{at}_{mt}_mf"]).max() < 1e-8
+            got, wantl = np.array([float(v) for v in el[1:]]), g[f"acr_f64_{at}_{mt}_e"]
+            assert abs(float(el[0]) - float(g[f"acr_f64_{at}_{mt}_e0"])) <= 1e-9 * abs(want)
+            err = float(np.max(np.abs(got - wantl) / np.abs(wantl)))
+            worst = max(worst, err)
+            assert err < 1e-8, (at, mt, got, wantl)
+    print(f"compute_energy, float64 radiances vs the reference's own values: worst relative error of an iteration term {worst:.1e}")
