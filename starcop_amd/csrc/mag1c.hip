@@ -1820,6 +1820,19 @@ size_t mag1c_lds_bytes(int S) {
   return ((size_t)S * (S + 1) + 11 * VEC + 64 + stg) * sizeof(double);
 }
 
+// the dynamic-LDS limit of a kernel: set once per instantiation (the pointer identifies it); not a stream operation
+template <typename K>
+hipError_t mag1c_lds_attr(K kern, size_t lds) {
+  static const void* done[32];
+  static int ndone = 0;
+  const void* f = reinterpret_cast<const void*>(kern);
+  for (int i = 0; i < ndone; ++i) if (done[i] == f) return hipSuccess;
+  (void)lds;
+  const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess && ndone < 32) done[ndone++] = f;
+  return e;
+}
+
 }  // namespace
 
 extern "C" size_t sc_mag1c_workspace_doubles(int G, int S, int64_t npix) {
@@ -1853,7 +1866,7 @@ extern "C" int sc_mag1c_groups(const sc_mag1c_args* a, sc_stream stream) {
     // more: a pair of launches (groups of <= 512 pixels stay in registers, larger ones stream), see k_mag1c_tile
 #define SC_TILE_GO(...)                                                                                                        \
     do {                                                                                                                       \
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c_tile<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e == hipSuccess) e = mag1c_lds_attr(&k_mag1c_tile<__VA_ARGS__>, lds);                                                  \
       if (e == hipSuccess) hipLaunchKernelGGL((k_mag1c_tile<__VA_ARGS__>), dim3(a->G), dim3(RNT), lds, st, p);                  \
     } while (0)
     e = hipSuccess;
@@ -1869,14 +1882,14 @@ extern "C" int sc_mag1c_groups(const sc_mag1c_args* a, sc_stream stream) {
     }
 #undef SC_TILE_GO
   } else if (fast) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c_fast<double, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = mag1c_lds_attr(&k_mag1c_fast<double, 1024>, lds);
     if (e == hipSuccess) hipLaunchKernelGGL((k_mag1c_fast<double, 1024>), dim3(a->G), dim3(1024), lds, st, p);
   } else {
     // fp64 radiances, alpha != 0: refactorisation every iteration.  Few bands: 512 threads (3 groups per CU);
     // many bands: the matrix fills the LDS, one group of 1024 threads per CU
 #define SC_MAG1C_GO(T_, NT_, EN_)                                                                                                 \
     do {                                                                                                                       \
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mag1c<T_, NT_, EN_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      e = mag1c_lds_attr(&k_mag1c<T_, NT_, EN_>, lds);                                                                          \
       if (e == hipSuccess) hipLaunchKernelGGL((k_mag1c<T_, NT_, EN_>), dim3(a->G), dim3(NT_), lds, st, p);                     \
     } while (0)
     if (a->energy) { if (a->S <= 64) SC_MAG1C_GO(double, 512, true); else SC_MAG1C_GO(double, 1024, true); }
