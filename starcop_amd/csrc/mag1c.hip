@@ -1612,73 +1612,43 @@ __global__ void k_scatter(const TI* __restrict__ val, const long long* __restric
 }
 
 // valid[p] = all(cube[p][band0 .. band0+S) > nodata)  (func_by_groups' default mask, mag1c.py:140-142; NE: != fill, mag1c_emit.py:60-66:
-// pixels with any band equal to the fill value are left out) in one pass over the pixel-major cube.  A WAVE per pixel: its S bands are
-// one or two coalesced row reads, the verdict a wave vote -- no per-element division, no shared-memory flags; eight pixels of a wave
-// in flight at a time (the per-element form ran at 1.7 TB/s: 79 us of the 1.2 ms of a 512 x 512 x 125 tile)
+// pixels with any band equal to the fill value are left out) in one pass over the pixel-major cube.  A block owns 256 consecutive
+// pixels = one contiguous run of the cube and reads it as 16-byte vectors, eight per thread in flight; the pixel of an element comes
+// from a multiply-shift (block-local element index < 2^28, so floor(e * ceil(2^40 / S_total) / 2^40) is the exact quotient), a failing
+// element clears its pixel's flag in LDS (benign race: every writer stores 0).  (History: per element with a 64-bit division 79 us on
+// the 512 x 512 x 125 tile = 1.7 TB/s; a wave per pixel 67 us -- its 500-byte rows straddle lines and leave lanes idle on narrow cubes.)
 template <typename T, bool NE>
 __global__ __launch_bounds__(256) void k_valid_mask(const T* __restrict__ cube, int S_total, int band0, int S, double ref,
-                                                    long long npix, unsigned char* __restrict__ valid) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                                    unsigned long long magic, long long npix, unsigned char* __restrict__ valid) {
+  constexpr int VL = 16 / sizeof(T);              // elements per vector
+  __shared__ int s_ok[256];
   const long long p0 = (long long)blockIdx.x * 256;
-  for (int k0 = wave; k0 < 256; k0 += 32) {               // pixels k0, k0 + 4, .., k0 + 28 of the block
-    bool ok[8];
+  const int np = (int)((npix - p0) < 256 ? (npix - p0) : 256);
+  s_ok[threadIdx.x] = 1;
+  __syncthreads();
+  const T* base = cube + p0 * S_total;            // 256 * S_total elements per block: 16-byte aligned whenever the cube is
+  const int n = np * S_total;
+  auto check = [&](int e, T v) {
+    const int q = (int)(((unsigned long long)(unsigned)e * magic) >> 40), b = e - q * S_total;
+    const bool bad = NE ? ((double)v == ref) : !((double)v > ref);
+    if (b >= band0 && b < band0 + S && bad) s_ok[q] = 0;
+  };
+  const int nv = (reinterpret_cast<uintptr_t>(base) & 15) == 0 ? n / VL : 0;      // (a cube that is not 16-byte aligned: element by element)
+  typedef T vecT __attribute__((ext_vector_type(VL)));
+  for (int i0 = threadIdx.x; i0 < nv; i0 += 256 * 8) {
+    vecT v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) ok[u] = true;
-    for (int b0 = 0; b0 < S; b0 += 64) {
-      T v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const long long q = p0 + k0 + 4 * u;
-        v[u] = (q < npix && b0 + lane < S) ? cube[q * S_total + band0 + b0 + lane] : (T)0;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (b0 + lane < S) ok[u] = ok[u] && (NE ? !((double)v[u] == ref) : ((double)v[u] > ref));
-    }
+    for (int u = 0; u < 8; ++u) { const int i = i0 + 256 * u; v[u] = reinterpret_cast<const vecT*>(base)[i < nv ? i : nv - 1]; }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const long long q = p0 + k0 + 4 * u;
-      const bool all = __ballot(ok[u]) == ~0ull;
-      if (lane == 0 && q < npix) valid[q] = all ? 1 : 0;
+      const int i = i0 + 256 * u;
+      if (i < nv) {
+#pragma unroll
+        for (int k = 0; k < VL; ++k) check(i * VL + k, v[u][k]);
+      }
     }
   }
-}
-
-// the same for narrow cubes (S_total <= 64: a wave per pixel would leave lanes idle), per element:
-// a block owns 256 consecutive pixels = one contiguous run of the pixel-major cube, read with coalesced loads
-template <typename T>
-__global__ __launch_bounds__(256) void k_valid_mask_flat(const T* __restrict__ cube, int S_total, int band0, int S, double nodata,
-                                                    long long npix, unsigned char* __restrict__ valid) {
-  __shared__ int s_ok[256];
-  const long long p0 = (long long)blockIdx.x * 256;
-  const int np = (int)((npix - p0) < 256 ? (npix - p0) : 256);
-  s_ok[threadIdx.x] = 1;
-  __syncthreads();
-  const T* base = cube + p0 * S_total;
-  const long long n = (long long)np * S_total;
-  for (long long e = threadIdx.x; e < n; e += 256) {
-    const int q = (int)(e / S_total), b = (int)(e - (long long)q * S_total);
-    if (b >= band0 && b < band0 + S && !((double)base[e] > nodata)) s_ok[q] = 0;      // benign race: every writer stores 0
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < np) valid[p0 + threadIdx.x] = (unsigned char)s_ok[threadIdx.x];
-}
-
-// valid[p] = all(cube[p][band0 .. band0+S) != fill)   (mag1c_emit.py:60-66: pixels with any band equal to the fill value are left out)
-template <typename T>
-__global__ __launch_bounds__(256) void k_valid_mask_ne_flat(const T* __restrict__ cube, int S_total, int band0, int S, double fill,
-                                                       long long npix, unsigned char* __restrict__ valid) {
-  __shared__ int s_ok[256];
-  const long long p0 = (long long)blockIdx.x * 256;
-  const int np = (int)((npix - p0) < 256 ? (npix - p0) : 256);
-  s_ok[threadIdx.x] = 1;
-  __syncthreads();
-  const T* base = cube + p0 * S_total;
-  const long long n = (long long)np * S_total;
-  for (long long e = threadIdx.x; e < n; e += 256) {
-    const int q = (int)(e / S_total), b = (int)(e - (long long)q * S_total);
-    if (b >= band0 && b < band0 + S && (double)base[e] == fill) s_ok[q] = 0;
-  }
+  for (int e2 = nv * VL + threadIdx.x; e2 < n; e2 += 256) check(e2, base[e2]);
   __syncthreads();
   if ((int)threadIdx.x < np) valid[p0 + threadIdx.x] = (unsigned char)s_ok[threadIdx.x];
 }
@@ -1940,13 +1910,12 @@ extern "C" int sc_scatter(const void* val, int val_is_f64, const int64_t* pix_in
 extern "C" int sc_valid_mask(const void* cube, int cube_is_f64, int S_total, int band0, int S, double nodata, int64_t npix,
                              unsigned char* valid, sc_stream stream) {
   SC_REQUIRE(cube && valid && S_total > 0 && band0 >= 0 && S > 0 && band0 + S <= S_total && npix >= 0, "sc_valid_mask: bad argument");
+  SC_REQUIRE(S_total <= (1 << 20), "sc_valid_mask: at most 2^20 bands per pixel");
   if (npix == 0) return SC_OK;
   const unsigned blocks = (unsigned)((npix + 255) / 256);
-  if (S_total <= 64) {
-    if (cube_is_f64) hipLaunchKernelGGL(k_valid_mask_flat<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)cube, S_total, band0, S, nodata, (long long)npix, valid);
-    else hipLaunchKernelGGL(k_valid_mask_flat<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)cube, S_total, band0, S, nodata, (long long)npix, valid);
-  } else if (cube_is_f64) hipLaunchKernelGGL((k_valid_mask<double, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)cube, S_total, band0, S, nodata, (long long)npix, valid);
-  else hipLaunchKernelGGL((k_valid_mask<float, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)cube, S_total, band0, S, nodata, (long long)npix, valid);
+  const unsigned long long magic = ((1ull << 40) + S_total - 1) / S_total;
+  if (cube_is_f64) hipLaunchKernelGGL((k_valid_mask<double, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)cube, S_total, band0, S, nodata, magic, (long long)npix, valid);
+  else hipLaunchKernelGGL((k_valid_mask<float, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)cube, S_total, band0, S, nodata, magic, (long long)npix, valid);
   SC_LAUNCH_OK("sc_valid_mask");
   return SC_OK;
 }
@@ -1954,13 +1923,12 @@ extern "C" int sc_valid_mask(const void* cube, int cube_is_f64, int S_total, int
 extern "C" int sc_valid_mask_ne(const void* cube, int cube_is_f64, int S_total, int band0, int S, double fill, int64_t npix,
                                 unsigned char* valid, sc_stream stream) {
   SC_REQUIRE(cube && valid && S_total > 0 && band0 >= 0 && S > 0 && band0 + S <= S_total && npix >= 0, "sc_valid_mask_ne: bad argument");
+  SC_REQUIRE(S_total <= (1 << 20), "sc_valid_mask_ne: at most 2^20 bands per pixel");
   if (npix == 0) return SC_OK;
   const unsigned blocks = (unsigned)((npix + 255) / 256);
-  if (S_total <= 64) {
-    if (cube_is_f64) hipLaunchKernelGGL(k_valid_mask_ne_flat<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)cube, S_total, band0, S, fill, (long long)npix, valid);
-    else hipLaunchKernelGGL(k_valid_mask_ne_flat<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)cube, S_total, band0, S, fill, (long long)npix, valid);
-  } else if (cube_is_f64) hipLaunchKernelGGL((k_valid_mask<double, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)cube, S_total, band0, S, fill, (long long)npix, valid);
-  else hipLaunchKernelGGL((k_valid_mask<float, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)cube, S_total, band0, S, fill, (long long)npix, valid);
+  const unsigned long long magic = ((1ull << 40) + S_total - 1) / S_total;
+  if (cube_is_f64) hipLaunchKernelGGL((k_valid_mask<double, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)cube, S_total, band0, S, fill, magic, (long long)npix, valid);
+  else hipLaunchKernelGGL((k_valid_mask<float, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)cube, S_total, band0, S, fill, magic, (long long)npix, valid);
   SC_LAUNCH_OK("sc_valid_mask_ne");
   return SC_OK;
 }
