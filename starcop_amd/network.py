@@ -622,6 +622,19 @@ class HyperStarcopUNet(nn.Module):
                         ent["tf"] = torch.empty(lib.sc_packed_weight_floats_thin16(co, ci, 0), dtype=torch.float32, device=dev)
                     if tb_ == TERMS_F16X2 and ci <= 16 and co in (16, 32):
                         ent["tb"] = torch.empty(lib.sc_packed_weight_floats_thin16(co, ci, 1), dtype=torch.float32, device=dev)
+                # decoder conv1 data gradient (up-sampled channels + skip channels): the two outputs as TWO launches with their own
+                # cout tiles -- 64-wide for the up-sampled part (a multiple of 64), one 32-wide tile for the <= 32 skip channels --
+                # instead of one launch of 32-wide tiles (80 = 64 + 16: 3 x 32; 152 = 128 + 24: 5 x 32): every cout tile stages (loads,
+                # BatchNorm-backward prologue, split) the whole gradient patch again.  Measured at 16 x 512^2: decoder.blocks.2.conv1
+                # 212 -> 197 us (5 -> 3 passes), decoder.blocks.3.conv1 293 -> 288 us (a 64-wide pass costs two 32-wide ones there: the
+                # operand reads and MFMAs, not the staging, are what its work-groups wait for); 288 = 256 + 32, which already runs on
+                # 64-wide tiles, loses 5 us to the second launch and stays as it was.  Step +0.6 % (same-box pairs).
+                if xb and cb == 32 and op.get("up") and len(op["ins"]) == 2 and self.split_dgrad_launch:
+                    cu, cs_ = op["ins"][0].C, op["ins"][1].C
+                    if cu % 64 == 0 and cs_ <= 32 and cu + cs_ == ci:
+                        ent["bA"] = torch.empty(lib.sc_packed_weight_floats_bx3(co, ci, 64, 1, tb_), dtype=torch.float32, device=dev)
+                        ent["bB"] = torch.empty(lib.sc_packed_weight_floats_bx3(co, ci, 32, 1, tb_), dtype=torch.float32, device=dev)
+                        ent["bB_off"] = ent["bB"].numel() // (-(-ci // 32)) * (cu // 32)      # floats before the skip channels' tile
                 self._wpk[i] = ent
                 self._pack_tables = {}
             if op["type"] == "pw":       # the split-bf16 layout of sc_conv1x1_pw3, where a plan runs this layer on it
@@ -651,6 +664,13 @@ class HyperStarcopUNet(nn.Module):
                     total = lib.sc_pack_work_items(co, ci, ks, cot, tflip, int(bx))
                     rows.append((conv.weight.data_ptr(), buf.data_ptr(), co, ci, ks, cot, tflip,
                                  (ent["terms_b"] if tflip else ent["terms_f"]) if bx else 0, total))
+                    starts.append(nblk)
+                    nblk += -(-total // 256)
+                for cot, buf in ((64, ent.get("bA")), (32, ent.get("bB"))):
+                    if buf is None or not need_bwd:
+                        continue
+                    total = lib.sc_pack_work_items(co, ci, ks, cot, 1, 1)
+                    rows.append((conv.weight.data_ptr(), buf.data_ptr(), co, ci, ks, cot, 1, ent["terms_b"], total))
                     starts.append(nblk)
                     nblk += -(-total // 256)
                 for tflip, buf in ((0, ent["tf"]), (1, ent["tb"])):
@@ -883,6 +903,7 @@ class HyperStarcopUNet(nn.Module):
     fuse_dw_bwd = True          # depthwise dgrad + wgrad + the input's BatchNorm-backward sums in one kernel (False: the three separate kernels)
     fuse_irt = _IRT != "0"      # training: expansion + depthwise of the stride-2 blocks the rule picks without the 6x tensor (conv_irt.hip)
     fuse_head_bn = True         # BatchNorm-backward sums of the decoder's last tensor in the head backward
+    split_dgrad_launch = True   # decoder conv1 data gradient: up-sampled and skip channels as two launches with their own cout tiles
     thin16 = True               # decoder.blocks.4 on sc_conv3x3_thin16 (0: the fp32-MFMA thin kernels)
     split_bf16 = True        # 3x3 convs with >= 32 output channels on the 16-bit matrix cores (False: everything on the fp32 MFMA)
     bn_small_max = 16384     # BatchNorm backward in one launch (block per channel) when a channel has at most this many elements
@@ -1174,6 +1195,21 @@ class HyperStarcopUNet(nn.Module):
             if op.get("up"):
                 t_up = ins[0]
                 fused_down = conv_dgrad is lib.sc_conv3x3_bx3      # the split-bf16 kernel stores the 2x2 sums itself
+                if fused_down and ent.get("bA") is not None and self.split_dgrad_launch:
+                    t_sk = ins[1]
+                    a.Cout = a.csplit = t_up.C
+                    a.wpk, a.co_t = ent["bA"].data_ptr(), 64
+                    a.out0, a.out1 = plan.grad[t_up.name].data_ptr(), None
+                    a.accum0, a.down0 = (1 if t_up.name in written else 0), 1
+                    check(conv_dgrad(C.byref(a), st))
+                    a.Cout = a.csplit = t_sk.C
+                    a.wpk, a.co_t = ent["bB"].data_ptr() + 4 * ent["bB_off"], 32
+                    a.out0 = plan.grad[t_sk.name].data_ptr()
+                    a.accum0, a.down0 = (1 if t_sk.name in written else 0), 0
+                    check(conv_dgrad(C.byref(a), st))
+                    self._pe(tok)
+                    written.add(t_sk.name); written.add(t_up.name)
+                    continue
                 a.csplit = t_up.C
                 if fused_down:
                     a.out0 = plan.grad[t_up.name].data_ptr()
