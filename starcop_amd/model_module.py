@@ -201,6 +201,11 @@ def load_weights(path_weights: str, map_location="cpu"):
 
 
 # ----------------------------------------------------------------------------------------------
+def _multi_rank():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 class ModelModule(_Base):
 
     def __init__(self, settings):
@@ -401,7 +406,9 @@ class ModelModule(_Base):
             net._backward_impl(plan, plan.dlogits)
             if grad_sync is not None:
                 scale = grad_sync(net.flat_grads())
-        optimizer.step_flat(grad_scale=scale)
+        # a step without gradient exchange inside an initialised multi-rank job is rank-local by definition (bench.py's
+        # instrumented passes on rank 0): its periodic range check must not enter a collective the other ranks never join
+        optimizer.step_flat(grad_scale=scale, sync_ranks=grad_sync is not None or not _multi_rank())
         plan.loss_n = logits.numel()
         return plan.loss_acc   # device double: sum of weighted per-pixel losses; divide by plan.loss_n for the mean
 

@@ -67,8 +67,9 @@ class FusedAdam(torch.optim.Adam):
             self._lr_host = lr
 
     @torch.no_grad()
-    def step_flat(self, grad_scale=1.0):
-        """Adam update straight from the network's flat gradient buffer."""
+    def step_flat(self, grad_scale=1.0, sync_ranks=True):
+        """Adam update straight from the network's flat gradient buffer.  ``sync_ranks=False``: this step is rank-local (the other
+        ranks of an initialised process group are NOT stepping): it takes no part in the periodic range check."""
         net = self.network
         flat = net.flat_parameters()
         if flat.data_ptr() != self._flat_ptr:
@@ -85,6 +86,9 @@ class FusedAdam(torch.optim.Adam):
                                float(grp["eps"]), float(grp["weight_decay"]), 1.0, 1.0, float(grad_scale),
                                ptr(self._hp_dev), st))
         net.mark_parameters_changed()
+        if not sync_ranks:
+            return      # rank-local step: neither counted nor checked here -- the check's cadence (and its collective) must stay the same on
+                        # every rank; the sticky device-side records it reads keep what this step saw for the next common check
         self._steps_since_check = getattr(self, "_steps_since_check", 0) + 1
         if net.range_check_every and self._steps_since_check >= net.range_check_every and not torch.cuda.is_current_stream_capturing():
             self._steps_since_check = 0

@@ -248,6 +248,13 @@ if backend == "nccl":
 else:
     h = other.cpu(); dist.broadcast(h, src=0); other = h.to(dev)
 assert torch.equal(other, got) or rank == 0
+# a RANK-LOCAL step (no gradient exchange: bench.py's instrumented passes on rank 0) between common steps must not enter -- nor
+# shift -- the periodic range check's collective: with the check due at every step, rank 0 alone steps once, then both step together
+model.network.range_check_every = 1
+if rank == 0:
+    model.fused_train_step(halves[0], opt, grad_sync=None)
+model.fused_train_step(halves[rank], opt, grad_sync=sync)
+torch.cuda.synchronize()
 dist.barrier()
 if rank == 0:
     print("WORLD2_EQUIV_OK", backend, d)
