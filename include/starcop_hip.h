@@ -331,6 +331,13 @@ int sc_bn_bwd_small(const float* g, const float* y, const float* cst_fwd, int ac
                     float* dgamma, float* dbeta, float* cst_bwd, float* absmax, float* act_absmax, sc_stream stream);
 /* out = v(a) + v(b)   (residual add of an inverted-residual block; b may be NULL) */
 int sc_add_srcs(const sc_src* a, const sc_src* b, float* out, int N, int C, int HW, sc_stream stream);
+/* `waiter` does not run anything queued after this call before everything queued on `signaller` up to this call has finished
+ * (both streams of the SAME device; the calling thread owns both).  What torch.cuda.Stream.wait_stream does, with an event created
+ * with hipEventDisableTiming | hipEventDisableSystemFence: no system-scope cache write-back at the fork / join points of the
+ * weight-gradient stream (HyperStarcopUNet's backward, the counterpart of autograd's multi-stream backward under
+ * starcop/models/model_module.py:69-88).  Not for ordering against the host or another device. */
+int sc_stream_wait_stream(sc_stream waiter, sc_stream signaller);
+
 /* same, and *absmax (device float, never lowered) is raised to max |out|: the range evidence for residual sums that feed a
  * two-fp16-term convolution without a BatchNorm in between (smp skip connections taken after an inverted-residual add).
  * out may be NULL (b too): then the call only records max |v(a)| -- the inference-time range check of a BatchNorm'd tensor */

@@ -109,6 +109,7 @@ SIGNATURES = {
     "sc_bn_bwd_small": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sc_bn_bwd_finalize": (_i, [_vp, _i, _d, _vp, _vp, _vp, _vp, _i, _vp]),
     "sc_add_srcs": (_i, [C.POINTER(sc_src), C.POINTER(sc_src), _vp, _i, _i, _i, _vp]),
+    "sc_stream_wait_stream": (_i, [_vp, _vp]),
     "sc_add_srcs_absmax": (_i, [C.POINTER(sc_src), C.POINTER(sc_src), _vp, _i, _i, _i, _vp, _vp]),
     "sc_apply_src": (_i, [C.POINTER(sc_src), _vp, _i, _i, _i, _vp]),
     "sc_downsum2x2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

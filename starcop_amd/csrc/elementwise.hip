@@ -650,6 +650,32 @@ extern "C" int sc_bn_bwd_finalize(const double* sums, int nrows, double count, c
   return SC_OK;
 }
 
+// Cross-stream ordering on ONE device without the system-scope fence of a default event.  torch's Stream.wait_stream records a
+// default-flag event: when it transitions to recorded the runtime performs a system-scope release -- a write-back / invalidate of the
+// eight L2s -- and the next kernels of BOTH queues start 13-25 us later (tools/phase_gaps.py on a rocprofv3 trace: 0.3-0.4 ms of
+// device-idle time per training step behind the ~50 fork points of the weight-gradient stream).  Kernels of the same device only need
+// the device-scope release every dispatch ends with, so the events here are created with hipEventDisableSystemFence.
+extern "C" int sc_stream_wait_stream(sc_stream waiter, sc_stream signaller) {
+  constexpr int NEV = 64;
+  static hipEvent_t ring[NEV];
+  static int made = 0, next = 0;
+  if (!made) {
+    for (int i = 0; i < NEV; ++i)
+      if (hipEventCreateWithFlags(&ring[i], hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
+        sc_set_error("sc_stream_wait_stream: hipEventCreateWithFlags failed");
+        return SC_ERR_LAUNCH;
+      }
+    made = 1;
+  }
+  hipEvent_t e = ring[next];
+  next = (next + 1) % NEV;
+  if (hipEventRecord(e, (hipStream_t)signaller) != hipSuccess || hipStreamWaitEvent((hipStream_t)waiter, e, 0) != hipSuccess) {
+    sc_set_error("sc_stream_wait_stream: %s", hipGetErrorString(hipGetLastError()));
+    return SC_ERR_LAUNCH;
+  }
+  return SC_OK;
+}
+
 extern "C" int sc_add_srcs_absmax(const sc_src* a, const sc_src* b, float* out, int N, int C, int HW, float* absmax,
                                   sc_stream stream) {
   SC_REQUIRE(a && a->C == C && (!b || b->C == C), "sc_add_srcs: channel mismatch");

@@ -903,6 +903,7 @@ class HyperStarcopUNet(nn.Module):
     fuse_dw_bwd = True          # depthwise dgrad + wgrad + the input's BatchNorm-backward sums in one kernel (False: the three separate kernels)
     fuse_irt = _IRT != "0"      # training: expansion + depthwise of the stride-2 blocks the rule picks without the 6x tensor (conv_irt.hip)
     fuse_head_bn = True         # BatchNorm-backward sums of the decoder's last tensor in the head backward
+    light_stream_sync = True    # fork points of the weight-gradient stream: events without the system-scope fence (sc_stream_wait_stream)
     split_dgrad_launch = True   # decoder conv1 data gradient: up-sampled and skip channels as two launches with their own cout tiles
     thin16 = True               # decoder.blocks.4 on sc_conv3x3_thin16 (0: the fp32-MFMA thin kernels)
     split_bf16 = True        # 3x3 convs with >= 32 output channels on the 16-bit matrix cores (False: everything on the fp32 MFMA)
@@ -952,12 +953,21 @@ class HyperStarcopUNet(nn.Module):
                 self._side_stream = torch.cuda.Stream(device=main.device)
             side = self._side_stream
 
+        def wait_stream(waiter, signaller):
+            # same-device ordering without the system-scope fence of a default event (sc_stream_wait_stream)
+            if self.light_stream_sync:
+                check(lib.sc_stream_wait_stream(waiter.cuda_stream, signaller.cuda_stream))
+            else:
+                waiter.wait_stream(signaller)
+
         def wgrad_launch(fn):
-            """run fn(stream_handle) on the weight-gradient stream, ordered after everything queued on the main stream"""
+            """run fn(stream_handle) on the weight-gradient stream, ordered after everything queued on the main stream.  (One fork per
+            launch: serving two to eight launches with one fork -- fewer markers in the main queue -- measured 0.5-2.5 % SLOWER, the
+            weight gradients then start too late to fill the gaps of the data-gradient chain.)"""
             if side is None:
                 fn(st)
             else:
-                side.wait_stream(main)
+                wait_stream(side, main)
                 with torch.cuda.stream(side):
                     fn(stream())
 
@@ -1026,7 +1036,7 @@ class HyperStarcopUNet(nn.Module):
             if tail_pending and (conv is None or (conv.weight.data_ptr() - self._pflat.data_ptr()) // 4 < tail_lo):
                 tail_pending = False            # first encoder op: the decoder/head bucket is complete
                 if side is not None:
-                    side.wait_stream(main)
+                    side.wait_stream(main)      # (a default event: the collective that starts here may leave the device)
                     with torch.cuda.stream(side):
                         on_tail_ready(tail_lo, self._gflat.numel())
                 else:
@@ -1053,7 +1063,7 @@ class HyperStarcopUNet(nn.Module):
                                                plan.ws_floats, ptr(gv(conv.weight)), ptr(gv(conv.bias)), N, conv.in_channels, Ho, Wo,
                                                bns, bna, st))
                 else:
-                    wgrad_launch(lambda sx: check(lib.sc_head_conv_wgrad(
+                    wgrad_launch(lambda sx, s=s, conv=conv, Ho=Ho, Wo=Wo: check(lib.sc_head_conv_wgrad(
                         ptr(dlogits), C.byref(s), ptr(plan.ws), plan.ws_floats, ptr(gv(conv.weight)), ptr(gv(conv.bias)), N,
                         conv.in_channels, Ho, Wo, sx)))
                     check(lib.sc_head_conv_dgrad(ptr(dlogits), ptr(conv.weight), ptr(plan.grad[tin.name]), N,
@@ -1074,8 +1084,8 @@ class HyperStarcopUNet(nn.Module):
             if ty == "stem":
                 s = self._src_of(plan, op["ins"][0], x_cst=plan.x_cst)
                 tok = self._pb("k_stem_*")
-                wgrad_launch(lambda sx: check(lib.sc_stem_conv_wgrad(C.byref(dy), C.byref(s), ptr(plan.ws), plan.ws_floats,
-                                                                     ptr(gv(conv.weight)), N, conv.in_channels, H, W, sx)))
+                wgrad_launch(lambda sx, dy=dy, s=s, conv=conv: check(lib.sc_stem_conv_wgrad(
+                    C.byref(dy), C.byref(s), ptr(plan.ws), plan.ws_floats, ptr(gv(conv.weight)), N, conv.in_channels, H, W, sx)))
                 self._pe(tok)
                 continue
             if ty == "dw" and i in plan.irt_of_dw:
@@ -1264,7 +1274,8 @@ class HyperStarcopUNet(nn.Module):
             wgrad_launch(lambda sx: check(lib.sc_wgrad_reduce_batch(ptr(tab[0]), ptr(tab[1]), tab[2], tab[3], sx)))
             self._pe(tok)
         if side is not None:
-            main.wait_stream(side)          # join: every weight gradient is in the flat buffer before Adam / all-reduce
+            main.wait_stream(side)          # join: every weight gradient is in the flat buffer before Adam / all-reduce (default event: an
+                                            # all-reduce to other devices may follow)
 
     # ------------------------------------------------------------------------------------------
     def forward(self, x, normalizer_consts=None):
