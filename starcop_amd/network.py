@@ -1023,6 +1023,31 @@ class HyperStarcopUNet(nn.Module):
             check(lib.sc_bn_bwd_finalize(ptr(plan.bsums_v[t.name]), plan.brows[t.name], float(N * Ho * Wo), ptr(plan.cst[t.name]),
                                          ptr(gv(t.bn.weight)), ptr(gv(t.bn.bias)), ptr(plan.cstb[t.name]), t.C, st))
 
+        def reduce_pointwise_batch():
+            """ONE launch (weight-gradient stream) sums the K-slice partials of every pointwise weight gradient queued so far"""
+            if not pw_pending:
+                return
+            raw = b"".join(bytes(p_) for p_ in pw_pending)
+            if plan.pw_table is None:
+                plan.pw_table = {}
+            if raw not in plan.pw_table:
+                # descriptors are static for a plan, so the device table is built once -- and another one when a descriptor changes
+                # (parameters re-flattened / moved, a partial backward of the parity tests); earlier tables stay alive because a
+                # launch on the weight-gradient stream may still be reading them
+                import numpy as np
+                starts, nblk = [], 0
+                for p_ in pw_pending:
+                    starts.append(nblk)
+                    nblk += -(-int(p_.total) // 256)
+                plan.pw_table[raw] = (torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(self._pflat.device),
+                                      torch.tensor(starts, dtype=torch.int32).to(self._pflat.device), len(pw_pending), nblk)
+            tab = plan.pw_table[raw]
+            tok = self._pb("k_wgrad_mfma<1> (+reduce)")
+            wgrad_launch(lambda sx: check(lib.sc_wgrad_reduce_batch(ptr(tab[0]), ptr(tab[1]), tab[2], tab[3], sx)))
+            self._pe(tok)
+            pw_pending.clear()
+
+        last_pw = min((k for k, op_ in enumerate(self._ops) if op_["type"] == "pw" and k in plan.pw_part), default=-1)
         tail_lo = sum(p.numel() for p in self.encoder.parameters())
         tail_pending = on_tail_ready is not None
         irt_done = set()
@@ -1168,6 +1193,11 @@ class HyperStarcopUNet(nn.Module):
                         else lib.sc_conv2d_wgrad_mfma_deferred)
                 wgrad_launch(lambda sx, wa=wa, pend=pend, wdef=wdef: check(wdef(C.byref(wa), C.byref(pend), sx)))
                 pw_pending.append(pend)
+                if i == last_pw:
+                    # every pointwise layer has been walked: queue the batched reduction NOW, behind this layer's weight gradient, where it
+                    # runs beside the main stream's last data-gradient kernels (features.1's depthwise backward, 0.16 ms).  At the end of
+                    # the walk it was the side stream's last launch, 67 us exposed behind the stem's weight gradient before Adam.
+                    reduce_pointwise_batch()
             else:
                 wgrad_launch(lambda sx, wfn=wfn, wa=wa: check(wfn(C.byref(wa), sx)))
             self._pe(tok)
@@ -1254,25 +1284,7 @@ class HyperStarcopUNet(nn.Module):
                 check(conv_dgrad(C.byref(a), st))
                 self._pe(tok)
                 written.add(tin.name)
-        if pw_pending:
-            raw = b"".join(bytes(p_) for p_ in pw_pending)
-            if plan.pw_table is None:
-                plan.pw_table = {}
-            if raw not in plan.pw_table:
-                # descriptors are static for a plan, so the device table is built once -- and another one when a descriptor changes
-                # (parameters re-flattened / moved, a partial backward of the parity tests); earlier tables stay alive because a
-                # launch on the weight-gradient stream may still be reading them
-                import numpy as np
-                starts, nblk = [], 0
-                for p_ in pw_pending:
-                    starts.append(nblk)
-                    nblk += -(-int(p_.total) // 256)
-                plan.pw_table[raw] = (torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(self._pflat.device),
-                                      torch.tensor(starts, dtype=torch.int32).to(self._pflat.device), len(pw_pending), nblk)
-            tab = plan.pw_table[raw]
-            tok = self._pb("k_wgrad_mfma<1> (+reduce)")
-            wgrad_launch(lambda sx: check(lib.sc_wgrad_reduce_batch(ptr(tab[0]), ptr(tab[1]), tab[2], tab[3], sx)))
-            self._pe(tok)
+        reduce_pointwise_batch()
         if side is not None:
             main.wait_stream(side)          # join: every weight gradient is in the flat buffer before Adam / all-reduce (default event: an
                                             # all-reduce to other devices may follow)
