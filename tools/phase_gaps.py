@@ -1,5 +1,5 @@
 """Forward / backward split of the eager step in a rocprofv3 --kernel-trace results.db: span, busy union and idle time of each phase
-(forward = after the Adam update of the previous step up to the loss kernel, backward = the rest), and the largest idle gaps with the
+(forward = from the stem convolution up to the loss kernel, backward + update + filter packs = the rest), and the largest idle gaps with the
 kernels on either side.  usage: phase_gaps.py results.db"""
 import re, sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
@@ -7,7 +7,7 @@ cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
 name_col = "name" if "name" in cols else [x for x in cols if "name" in x][0]
 rows = c.execute(f"select start, end, {name_col} from kernels order by start").fetchall()
 rows = rows[len(rows) // 3:]
-adam = [i for i, r in enumerate(rows) if "k_adam(" in r[2]]
+adam = [i - 1 for i, r in enumerate(rows) if "k_stem_fwd" in r[2] and i > 0]      # last kernel before each step's stem forward
 loss = [i for i, r in enumerate(rows) if "k_bce(" in r[2]]
 def union(seg):
     busy, gaps, cs, ce = 0, [], seg[0][0], seg[0][1]
