@@ -1286,8 +1286,12 @@ class HyperStarcopUNet(nn.Module):
                 written.add(tin.name)
         reduce_pointwise_batch()
         if side is not None:
-            main.wait_stream(side)          # join: every weight gradient is in the flat buffer before Adam / all-reduce (default event: an
-                                            # all-reduce to other devices may follow)
+            # join: every weight gradient is in the flat buffer before Adam / all-reduce.  With a gradient exchange to follow
+            # (on_tail_ready: the data-parallel path) a default event, otherwise the device-scope one
+            if on_tail_ready is not None:
+                main.wait_stream(side)
+            else:
+                wait_stream(main, side)
 
     # ------------------------------------------------------------------------------------------
     def forward(self, x, normalizer_consts=None):
