@@ -953,10 +953,12 @@ class HyperStarcopUNet(nn.Module):
                 self._side_stream = torch.cuda.Stream(device=main.device)
             side = self._side_stream
 
+        hnd = {id(s_): C.c_void_p(s_.cuda_stream) for s_ in (main, side) if s_ is not None}      # raw handles, looked up once per walk
+
         def wait_stream(waiter, signaller):
             # same-device ordering without the system-scope fence of a default event (sc_stream_wait_stream)
             if self.light_stream_sync:
-                check(lib.sc_stream_wait_stream(waiter.cuda_stream, signaller.cuda_stream))
+                check(lib.sc_stream_wait_stream(hnd[id(waiter)], hnd[id(signaller)]))
             else:
                 waiter.wait_stream(signaller)
 
@@ -968,8 +970,7 @@ class HyperStarcopUNet(nn.Module):
                 fn(st)
             else:
                 wait_stream(side, main)
-                with torch.cuda.stream(side):
-                    fn(stream())
+                fn(hnd[id(side)])       # (every fn launches through the C ABI with the handle it is given: no stream context switch needed)
 
         N, H, W = plan.N, plan.H, plan.W
         if not getattr(plan, "training", False):

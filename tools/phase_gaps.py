@@ -5,7 +5,7 @@ import re, sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
 name_col = "name" if "name" in cols else [x for x in cols if "name" in x][0]
-rows = c.execute(f"select start, end, {name_col} from kernels order by start").fetchall()
+rows = c.execute(f"select start, end, {name_col}, stream_id from kernels order by start").fetchall()
 rows = rows[len(rows) // 3:]
 adam = [i - 1 for i, r in enumerate(rows) if "k_stem_fwd" in r[2] and i > 0]      # last kernel before each step's stem forward
 loss = [i for i, r in enumerate(rows) if "k_bce(" in r[2]]
@@ -24,6 +24,7 @@ for a0, a1 in zip(adam[:-1], adam[1:]):
     ls = [i for i in loss if a0 < i < a1]
     if not ls: continue
     l = ls[0]
+    if len(set(r[3] for r in rows[a0 + 1:a1 + 1])) < 2: continue      # bench.py's instrumented serial steps (one stream): not the eager step
     f, b = rows[a0 + 1:l + 1], rows[l + 1:a1 + 1]
     fb, fg = union(f); bb, bg = union(b)
     fw += f[-1][1] - f[0][0]; bw += max(r[1] for r in b) - b[0][0]; fwb += fb; bwb += bb; allg += [("fwd",) + g for g in fg] + [("bwd",) + g for g in bg]; n += 1
