@@ -273,6 +273,10 @@ int sc_dwconv3x3_wgrad(const sc_src* dy, const sc_src* in, double* dw_acc /*[C][
 int sc_dwconv3x3_bwd_fused(const sc_src* dy, const sc_src* in, const float* w, float* dx, double* dw_acc, double* in_sums,
                            int N, int C, int Hin, int Win, int stride, sc_stream stream);
 int sc_cast_f64_f32(const double* in, float* out, size_t n, sc_stream stream);
+/* the same for n_descs (in, out, n) triples in one launch; descs_dev: DEVICE array (static for a plan: the caller builds it once).
+ * The depthwise filter gradients of a backward walk (fp64 accumulators of sc_dwconv3x3_bwd_fused -> the flat fp32 gradient). */
+typedef struct sc_cast_desc { const double* in; float* out; uint64_t n; } sc_cast_desc;
+int sc_cast_f64_f32_batch(const sc_cast_desc* descs_dev, int n_descs, sc_stream stream);
 
 /* stem: conv 3x3 stride 2 pad 1, Cin<=8 -> 32, input read through its prologue
  * (SC_SRC_NORM fuses DataNormalizer.normalize_x, starcop/data/normalizer_module.py:134-135) */

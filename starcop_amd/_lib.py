@@ -94,6 +94,7 @@ SIGNATURES = {
     "sc_dwconv3x3_dgrad": (_i, [C.POINTER(sc_src), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sc_dwconv3x3_wgrad": (_i, [C.POINTER(sc_src), C.POINTER(sc_src), _vp, _i, _i, _i, _i, _i, _vp]),
     "sc_cast_f64_f32": (_i, [_vp, _vp, _sz, _vp]),
+    "sc_cast_f64_f32_batch": (_i, [_vp, _i, _vp]),
     "sc_stem_conv_fwd": (_i, [C.POINTER(sc_src), _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sc_stem_wgrad_workspace_floats": (_sz, [_i, _i, _i, _i]),
     "sc_stem_conv_wgrad": (_i, [C.POINTER(sc_src), C.POINTER(sc_src), _vp, _sz, _vp, _i, _i, _i, _i, _vp]),

@@ -1638,6 +1638,19 @@ extern "C" int sc_head_conv_bwd(const float* dlogits, const sc_src* in, const fl
   return SC_OK;
 }
 
+// every depthwise filter gradient of a backward walk in ONE launch (device descriptor table, built once per plan): the 17 per-layer
+// casts each needed their own fork of the weight-gradient stream -- a marker in the main queue that the next kernel waits behind
+__global__ __launch_bounds__(256) void k_cast_f64_f32_batch(const sc_cast_desc* __restrict__ descs) {
+  const sc_cast_desc d = descs[blockIdx.x];
+  for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < d.n; i += (size_t)gridDim.y * 256) d.out[i] = (float)d.in[i];
+}
+extern "C" int sc_cast_f64_f32_batch(const sc_cast_desc* descs_dev, int n_descs, sc_stream stream) {
+  SC_REQUIRE(descs_dev != nullptr && n_descs > 0, "sc_cast_f64_f32_batch: no descriptors");
+  hipLaunchKernelGGL(k_cast_f64_f32_batch, dim3(n_descs, 8), dim3(256), 0, (hipStream_t)stream, descs_dev);
+  SC_LAUNCH_OK("sc_cast_f64_f32_batch");
+  return SC_OK;
+}
+
 extern "C" int sc_cast_f64_f32(const double* in, float* out, size_t n, sc_stream stream) {
   if (n == 0) return SC_OK;
   const int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
