@@ -4,6 +4,8 @@
 #include <stdarg.h>
 #include <string.h>
 #include "sc_common.h"
+#include <atomic>
+#include <mutex>
 
 // ------------------------------------------------------------------------------------------
 // error plumbing (thread-local message)
@@ -656,19 +658,22 @@ extern "C" int sc_bn_bwd_finalize(const double* sums, int nrows, double count, c
 // device-idle time per training step behind the ~50 fork points of the weight-gradient stream).  Kernels of the same device only need
 // the device-scope release every dispatch ends with, so the events here are created with hipEventDisableSystemFence.
 extern "C" int sc_stream_wait_stream(sc_stream waiter, sc_stream signaller) {
+  // (one device per process -- the framework's process model: the events belong to the device that is current at the first call;
+  //  an event may be re-recorded while an earlier wait on it is still pending: a wait captures the record that preceded it)
   constexpr int NEV = 64;
   static hipEvent_t ring[NEV];
-  static int made = 0, next = 0;
-  if (!made) {
-    for (int i = 0; i < NEV; ++i)
-      if (hipEventCreateWithFlags(&ring[i], hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
-        sc_set_error("sc_stream_wait_stream: hipEventCreateWithFlags failed");
-        return SC_ERR_LAUNCH;
-      }
-    made = 1;
+  static std::once_flag once;
+  static bool ok = false;
+  static std::atomic<unsigned> next{0};
+  std::call_once(once, [] {
+    ok = true;
+    for (int i = 0; i < NEV; ++i) ok = ok && hipEventCreateWithFlags(&ring[i], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
+  });
+  if (!ok) {
+    sc_set_error("sc_stream_wait_stream: hipEventCreateWithFlags failed");
+    return SC_ERR_LAUNCH;
   }
-  hipEvent_t e = ring[next];
-  next = (next + 1) % NEV;
+  hipEvent_t e = ring[next.fetch_add(1) % NEV];
   if (hipEventRecord(e, (hipStream_t)signaller) != hipSuccess || hipStreamWaitEvent((hipStream_t)waiter, e, 0) != hipSuccess) {
     sc_set_error("sc_stream_wait_stream: %s", hipGetErrorString(hipGetLastError()));
     return SC_ERR_LAUNCH;
