@@ -916,3 +916,41 @@ def test_conv_pw3_wgrad(hip, cin, cout, N, H, W, deferred):
     assert relerr(dw, ref) < 1e-5
 
 
+
+
+def test_cast_f64_f32_batch(hip):
+    """sc_cast_f64_f32_batch: every (fp64 accumulator -> fp32 gradient view) pair of a backward walk in one launch == the per-layer casts"""
+    import numpy as np
+    g = torch.Generator().manual_seed(3)
+    acc = (torch.randn(5000, generator=g, dtype=torch.float64) * 1e3).to(DEV)
+    out = torch.full((6000,), float("nan"), device=DEV)
+    # (offset in acc, offset in out, n): ragged sizes, one longer than 8 x 256 items, destinations not in source order
+    spans = [(0, 4000, 288), (288, 0, 2700), (2988, 3000, 9), (2997, 5000, 864)]
+    descs = np.array([(acc.data_ptr() + 8 * a, out.data_ptr() + 4 * b, n) for a, b, n in spans], dtype=np.uint64)
+    tab = torch.from_numpy(descs.view(np.uint8).copy()).to(DEV)
+    check(hip.sc_cast_f64_f32_batch(ptr(tab), len(spans), stream()))
+    want = torch.full((6000,), float("nan"), device=DEV)
+    for a, b, n in spans:
+        want[b:b + n] = acc[a:a + n].float()
+    assert torch.equal(torch.nan_to_num(out, nan=-7.0), torch.nan_to_num(want, nan=-7.0))      # nothing else was written
+
+
+def test_stream_wait_stream_orders_two_streams(hip):
+    """sc_stream_wait_stream (events without the system-scope fence): work queued on the waiter after the call sees everything the
+    signaller had queued before it -- a long producer on stream A, a consumer on stream B, 50 rounds, both directions"""
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    x = torch.zeros(1 << 24, device=DEV)
+    y = torch.zeros(1 << 24, device=DEV)
+    bad = torch.zeros((), dtype=torch.int64, device=DEV)
+    torch.cuda.synchronize()
+    ha, hb = C.c_void_p(a.cuda_stream), C.c_void_p(b.cuda_stream)
+    for k in range(50):
+        with torch.cuda.stream(a):
+            x.add_(1.0)                                     # producer (64 MB read + write)
+        check(hip.sc_stream_wait_stream(hb, ha))            # b waits for a
+        with torch.cuda.stream(b):
+            y.copy_(x)                                      # consumer must see round k + 1 everywhere
+            bad += (y != float(k + 1)).sum()
+        check(hip.sc_stream_wait_stream(ha, hb))            # a's next add must not overtake the copy
+    torch.cuda.synchronize()
+    assert int(bad) == 0 and float(y.min()) == 50.0 and float(y.max()) == 50.0
