@@ -7,10 +7,16 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-constexpr int C = 16, TH = 8, TW = 64, PR = TH + 2, PC = TW + 2, NPX = PR * PC;
+#ifndef MB_TH
+#define MB_TH 8
+#endif
+#ifndef MB_TW
+#define MB_TW 64
+#endif
+constexpr int C = 16, TH = MB_TH, TW = MB_TW, PR = TH + 2, PC = TW + 2, NPX = PR * PC;      // -DMB_TH=16 / -DMB_TW=128: other tile shapes
 
 template <bool BLOCKED>
-__global__ __launch_bounds__(256, 2) void k_stage(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W) {
+__global__ __launch_bounds__(256) void k_stage(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W) {
   __shared__ float4 s_p[2][2][NPX];                      // [half of the 8-channel group][group][pixel]: 42 KB like the thin kernel
   const int tid = threadIdx.x, wave = tid >> 6;
   const int tiles_x = W / TW, per_img = tiles_x * (H / TH);
@@ -38,8 +44,9 @@ __global__ __launch_bounds__(256, 2) void k_stage(const float* __restrict__ in, 
   __syncthreads();
   // outputs: the D layout of v_mfma_f32_16x16x32: lane -> pixel l15 of a 16-pixel block, channels 4*(lane>>4) .. +3; wave = 2 rows
   const int lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
-  for (int pb = 0; pb < 8; ++pb) {
-    const int row = 2 * wave + pb / 4, col = 16 * (pb % 4) + l15;
+  constexpr int RPW = TH / 4, BPR = TW / 16;            // rows per wave, 16-pixel blocks per row
+  for (int pb = 0; pb < RPW * BPR; ++pb) {
+    const int row = RPW * wave + pb / BPR, col = 16 * (pb % BPR) + l15;
     const float4 c = s_p[lg & 1][lg >> 1][(row + 1) * PC + col + 1];       // stand-in for the accumulator: depends on the staged patch
     const int oy = y0 + row, ox = x0 + col;
     if (BLOCKED) {
@@ -73,8 +80,8 @@ int main() {
     }
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= R;
-    printf("%s: %.1f us per pass over 16 x 16 x 512 x 512 (read + write 2 x %.0f MB): %.2f TB/s algorithmic\n",
-           blocked ? "[N][C/8][H][W][8]" : "NCHW             ", ms * 1e3, elems * 4 / 1e6, 2.0 * elems * 4 / (ms * 1e-3) / 1e12);
+    printf("tile %d x %d  %s: %.1f us per pass over 16 x 16 x 512 x 512 (read + write 2 x %.0f MB): %.2f TB/s algorithmic\n",
+           TH, TW, blocked ? "[N][C/8][H][W][8]" : "NCHW             ", ms * 1e3, elems * 4 / 1e6, 2.0 * elems * 4 / (ms * 1e-3) / 1e12);
   }
   return 0;
 }
