@@ -6,7 +6,7 @@ from starcop_amd import model_module as mm
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 model = mm.ModelModule(mm.default_settings(pos_weight=1)).to(dev).eval()
-for B in (1, 4):
+for B in (1, 4, 16):
     x = synth_batch(B, 512, 512, 1, dev)["input"]
     def T(fn, n=50):
         fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
