@@ -67,8 +67,61 @@ def cpu_baseline(budget_s=25.0):
         if time.perf_counter() - t0 > budget_s * 0.6 or n >= 8:
             break
     dt = time.perf_counter() - t0
-    return {"value": round(B * n / dt, 4), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} train steps of batch {B} x 4ch 512x512 fp32 (oracle/unet_ref.py + torch.optim.Adam) after 1 warm-up"}
+    out = {"value": round(B * n / dt, 4), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{n} train steps of batch {B} x 4ch 512x512 fp32 (oracle/unet_ref.py + torch.optim.Adam) after 1 warm-up"}
+    out["legs"] = cpu_baseline_legs(net, b, fac)
+    return out
+
+
+def cpu_baseline_legs(net, b, fac):
+    """BASELINE.md section 3, legs B2-B4: the reference's CPU path (oracle restatements) for the workloads `extra` reports on the GPU
+    -- eval forward / scene prediction, acrwl1mf per group (the reference's granularity) and batched, the two-band ratio -- each on a
+    BOUNDED sample (a few seconds of host time), extrapolated to the unit of the matching `extra` entry."""
+    import numpy as np
+    from oracle import host_ref, mag1c_ref         # baseline legs only
+    legs = {}
+    cores = torch.get_num_threads()
+
+    def wall(fn, min_reps=1, budget=3.0):
+        fn()
+        t0 = time.perf_counter(); n = 0
+        while n < min_reps or (time.perf_counter() - t0 < budget and n < 20):
+            fn(); n += 1
+        return (time.perf_counter() - t0) / n, n
+    # ---- B2: eval forward (4 tiles) and the notebook's padded_predict on a 1280 x 1242 scene (padding.py:13-50)
+    net.eval()
+    xin = torch.clamp(b["input"] / fac, 0, 2)
+    with torch.no_grad():
+        dt, n = wall(lambda: net(xin), budget=4.0)
+        scene = np.random.default_rng(5).uniform(0, 2, size=(4, 1280, 1242)).astype(np.float32)
+        dts, ns = wall(lambda: host_ref.padded_predict(scene, lambda a: torch.sigmoid(net(torch.from_numpy(a))).numpy()), budget=4.0)
+    net.train()
+    legs["B2_eval_forward"] = {"tiles_s": round(4 / dt, 3), "sample": f"{n} eval forwards of 4 x 4ch 512x512 (beside extra.infer_b16)", "cores": cores}
+    legs["B2_predict_scene"] = {"ms": round(dts * 1e3, 1), "sample": f"{ns} padded_predict calls on a (4, 1280, 1242) scene (beside extra.predict_scene)", "cores": cores}
+    # ---- B3: acrwl1mf, configs[2] shape (512-pixel column groups x 125 bands, float32, alpha 0, 30 iterations)
+    g3 = np.load(os.path.join(ROOT, "tests", "golden", "g3_templates.npz"))
+    rng = np.random.default_rng(7)
+    S = 125
+    t125 = np.interp(np.linspace(0, 72, S), np.arange(73), g3["aviris_template_kept"][:, 1])
+    base = rng.uniform(1, 6, S)
+    xg = (base * (1 + 0.05 * rng.standard_normal((64, 512, S)))).astype(np.float32)       # 64 of the tile's 512 column groups
+    dt1, n1 = wall(lambda: [mag1c_ref.acrwl1mf_group(xg[i], t125.astype(np.float32)) for i in range(8)], budget=4.0)
+    xt = torch.from_numpy(xg)
+    dtb, nb = wall(lambda: mag1c_ref.acrwl1mf_batched(xt, t125), budget=4.0)
+    legs["B3_mag1c_cfg3_per_group"] = {"tiles_s": round(1 / (dt1 / 8 * 512), 4), "sample": f"{n1} x 8 column groups of 512 px x 125 bands fp32, one call per group "
+                                       "(mag1c.py:166-172 granularity; numpy / LAPACK), x 64 for the tile (beside extra.mag1c_cfg3)", "cores": cores}
+    legs["B3_mag1c_cfg3_batched"] = {"tiles_s": round(1 / (dtb / 64 * 512), 4), "sample": f"{nb} calls on 64 groups at once ([b, P, S] torch CPU ops), x 8 for the tile", "cores": cores}
+    # EMIT shape: 2560-pixel groups (1280 rows x column_step 2) x 49 bands, float64, alpha 1e-4
+    te = g3["emit_template_kept"][:, 1]
+    xe = (rng.uniform(1, 6, te.size) * (1 + 0.05 * rng.standard_normal((4, 2560, te.size)))).astype(np.float64)
+    dte, ne = wall(lambda: [mag1c_ref.acrwl1mf_group(xe[i], te, alpha=1e-4) for i in range(4)], budget=4.0)
+    legs["B3_mag1c_emit_per_group"] = {"ms_per_granule": round(dte / 4 * 621 * 1e3, 0), "sample": f"{ne} x 4 groups of 2560 px x {te.size} bands fp64, alpha 1e-4, x 621 / 4 for the "
+                                       "granule (beside extra.mag1c_emit)", "cores": cores}
+    # ---- B4: two-band ratio (feature_extration.py:42-56), numpy
+    bg, sg = rng.uniform(0, 50, (512, 512)).astype(np.float32), rng.uniform(0, 50, (512, 512)).astype(np.float32)
+    dtr, nr = wall(lambda: host_ref.band_ratio(bg, sg), min_reps=3, budget=2.0)
+    legs["B4_band_ratio"] = {"tiles_s": round(1 / dtr, 2), "sample": f"{nr} calls on 2 x (512, 512) float32 (numpy percentiles; beside extra.band_ratio)", "cores": 1}
+    return legs
 
 
 CONV_ROOFLINE_TILES_S = 1718.0      # SURVEY.md section 8(d)
@@ -161,6 +214,28 @@ def bench_extras(model, dev, precision):
                                       "note": "X (float32) is streamed 40 times (round 3: 66); what keeps it from the HBM rate: the serial diagonal-block "
                                               "sweeps of the per-round factorisation of C_k (12 us of 42) and 621 groups on 256 CUs (three rounds, the "
                                               "third 43 % full); whole-call time incl. mask/layout/pack/scatter"}}
+    # ---- two-band ratio on a batch of 512 x 512 tiles (feature_extration.py:42-56: exact 5 / 95 % trimmed sums + the ratio)
+    from starcop_amd import features
+    bg = torch.rand(16, 512, 512, generator=gen, device=dev) * 50
+    sg = torch.rand(16, 512, 512, generator=gen, device=dev) * 50
+    dtr = _timeit(lambda: features.ratio_2c_match_c_from_sums_outlier(bg, sg), 10)
+    out["band_ratio"] = {"workload": "ratio_2c_match_c_from_sums_outlier on 16 x 2 x (512, 512) float32 tiles (exact radix-select percentiles)",
+                         "tiles_s": round(16 / dtr, 1), "ms_per_16_tiles": round(dtr * 1e3, 3)}
+    # ---- the path pytorch_lightning's Trainer.fit drives (scripts/train.py:140): training_step -> loss.backward() -> optimizer.step()
+    # -> zero_grad(), i.e. the autograd Function + FusedAdam.step -- the timed region above is fused_train_step, asserted equal in results
+    b16t = synth_batch(16, 512, 512, 1234, dev)
+    opt_l = model.configure_optimizers()["optimizer"]
+
+    def lightning_step():
+        loss = model.training_step(b16t, 0)
+        loss.backward()
+        opt_l.step()
+        opt_l.zero_grad()
+    dtl = _timeit(lightning_step, 20)
+    dtf = _timeit(lambda: model.fused_train_step(b16t, opt_l), 20)
+    out["lightning_path"] = {"workload": "training_step + loss.backward() + optimizer.step() + zero_grad() at batch 16 (what Trainer.fit runs per batch)",
+                             "tiles_s": round(16 / dtl, 1), "ms_per_step": round(dtl * 1e3, 3),
+                             "fused_train_step_tiles_s_same_loop": round(16 / dtf, 1), "ratio_to_fused": round(dtf / dtl, 4)}
     # ---- U-Net inference
     model.eval()
     b16 = synth_batch(16, 512, 512, 77, dev)

@@ -190,6 +190,22 @@ size_t sc_packed_weight_floats_thin16(int Cout, int Cin, int transpose_flip);
 int sc_pack_weights_thin16(const float* w_oihw, float* wpk, int Cout, int Cin, int transpose_flip, sc_stream stream);
 int sc_conv3x3_thin16(const sc_conv_args* a, sc_stream stream);
 
+/* Decoder conv1 as a SUB-PIXEL convolution: smp's DecoderBlock runs conv3x3(cat([interpolate(prev, x2, "nearest"), skip]))
+ * (starcop/models/model_module.py:244-251).  For the up-sampled channels, conv3x3(nearest_up2(x)) is exactly four phase-specific
+ * 2x2 convolutions on the LOW-resolution x (phase filter = sum of the taps that land on the same source pixel; zero padding maps
+ * 1:1): 2.25x fewer multiply-adds and every low-resolution value staged once instead of once per high-resolution copy.  The
+ * skip channels join the same launch as four low-resolution "parity planes" each (csrc/conv_sp_pack.h).
+ *   sc_conv3x3_sp: sc_conv_args with src[0] = the half-resolution tensor (up = 1), optional src[1] = the full-resolution skip
+ *   tensor (up = 0), both RAW or AFFINE; H x W = OUTPUT size (even); ks = 3; terms = SC_TERMS_F16X2 (the two-fp16-term arithmetic
+ *   of sc_conv3x3_bx3); csplit = Cout, one plain output (no add / accumulate / down0); co_t ignored (32); `wpk` from
+ *   sc_pack_weights_sp (or a sc_pack_desc with bx3 = SC_PACK_SP, Cin = the filter's total input channels and co_t = how many
+ *   of them, the leading ones, belong to the up-sampled source); statistics rows = sc_sp_stat_rows(N, H, W). */
+#define SC_PACK_SP 7
+size_t sc_packed_weight_floats_sp(int Cout, int Cup, int Cskip);
+int sc_pack_weights_sp(const float* w_oihw, float* wpk, int Cout, int Cup, int Cskip, sc_stream stream);
+int sc_sp_stat_rows(int N, int H, int W);
+int sc_conv3x3_sp(const sc_conv_args* a, sc_stream stream);
+
 /* weight gradient of the same thin layers (Cout <= 16, Cin = 16 | 32, one source which may be upsampled) with two fp16 terms on
  * v_mfma_f32_16x16x32_f16: same sc_wgrad_args as sc_conv2d_wgrad_mfma with terms = SC_TERMS_F16X2 (absmax = the dy range hint),
  * workspace from sc_wgrad_thin16_workspace_floats.  Replaces the fp32-MFMA thin weight gradient (the step's last MFMA-bound fp32 kernel). */

@@ -126,6 +126,36 @@ def acrwl1mf(x, template, compute_energy=False, **kw):
     return res + ([_rmf_energy(en)] + [sum(e[1 + k] for e in en) for k in range(n_it)],)
 
 
+def acrwl1mf_batched(x, template, num_iter=30, alpha=0.0, covariance_update_scaling=1.0):
+    """The same filter for b groups at once in the reference's own tensor formulation -- torch CPU ops on [b, P, S] (bmm for the
+    covariance, torch.linalg.cholesky + cholesky_solve; mag1c.py:203-210 allows the batch dimension, :236-276 is the loop) --
+    used as the BATCHED CPU baseline leg of bench.py and pinned against acrwl1mf_group / golden G1 in
+    tests/test_oracle.py.  Default flags only (no overrides, no pixel mask).  x: torch tensor [b, P, S]; returns (mf, R) [b, P, 1]."""
+    import torch
+    with torch.no_grad():
+        t = torch.as_tensor(template, dtype=x.dtype).reshape(1, 1, -1)
+        b, P, S = x.shape
+
+        def stats(m):
+            mu = m.mean(dim=1, keepdim=True)
+            target = t * mu
+            d = m - mu
+            Cm = torch.bmm(d.transpose(1, 2), d) / P
+            Cm = torch.lerp(Cm, torch.diag_embed(torch.diagonal(Cm, dim1=-2, dim2=-1)), alpha)
+            L = torch.linalg.cholesky(Cm)
+            Cit = torch.cholesky_solve(target.transpose(1, 2), L)                 # [b, S, 1]
+            return mu, target, Cit, torch.bmm(target, Cit)                        # normaliser [b, 1, 1]
+        mu, target, Cit, nrm = stats(x)
+        R = torch.bmm(x, mu.transpose(1, 2)) / torch.bmm(mu, mu.transpose(1, 2))  # [b, P, 1]
+        mf = torch.relu(torch.bmm(x - mu, Cit) / (R * nrm))
+        for _ in range(num_iter):
+            modx = x - covariance_update_scaling * R * mf * target
+            mu, target, Cit, nrm = stats(modx)
+            reg = 1.0 / (R * (mf + EPSILON))
+            mf = torch.relu((torch.bmm(x - mu, Cit) - reg) / (R * nrm.clamp(min=1)))
+        return mf * SCALING, R
+
+
 def func_by_groups(func, x, groups, mask=None, min_pixels=10):
     """AVIRIS driver semantics (mag1c.py:116-174): every group id present under ``mask`` is filtered on its own
     valid pixels; groups with <= 10 valid pixels and invalid pixels keep NODATA.  ``func(xg [P,S]) -> (mf, R)``."""

@@ -25,6 +25,7 @@
 // filters per filter row kh [terms][3 kw][2 halves][32Q couts] x 16 B, double buffered: 51 KB (two terms) / 72 KB (three terms)
 // at Q = 2 -> 2 work-groups per CU (the Q = 2 kernels need 220 VGPRs).
 #include "sc_common.h"
+#include "conv_sp_pack.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -2187,6 +2188,7 @@ __global__ __launch_bounds__(256) void k_pack_batch(const PackDesc* __restrict__
   const size_t i = (size_t)(blockIdx.x - starts[lo]) * 256 + threadIdx.x;
   if (i >= d.total) return;
   if (d.bx3 == SC_PACK_THIN16) { pack_thin_item(d.w, reinterpret_cast<unsigned short*>(d.wpk), i, d.Cout, d.Cin, d.tflip); return; }
+  if (d.bx3 == SC_PACK_SP) { sp_pack_item(d.w, reinterpret_cast<unsigned short*>(d.wpk), i, d.Cout, d.co_t, d.Cin - d.co_t); return; }      // conv_sp.hip: co_t = up-sampled channels
   const int M = d.tflip ? d.Cin : d.Cout, K = d.tflip ? d.Cout : d.Cin;
   if (d.bx3 == SC_PACK_PW3) {
     // pointwise filters for k_pw3 (conv_pw3.hip): [cout block][k step][term][lane][8] bf16, lane -> cout l&31, k = 16*step + 8*(l>>5) + j;
@@ -2508,6 +2510,7 @@ extern "C" int sc_conv3x3_thin16(const sc_conv_args* a, sc_stream stream) {
 
 extern "C" size_t sc_pack_work_items(int Cout, int Cin, int ks, int co_t, int transpose_flip, int bx3) {
   if (bx3 == SC_PACK_THIN16) return (size_t)thin_steps(Cout, Cin, transpose_flip) * 512;
+  if (bx3 == SC_PACK_SP) return sp_pack_items(Cout, co_t, Cin - co_t);      // co_t = up-sampled channels (the leading ones of Cin)
   if (bx3 == SC_PACK_PW3) {
     const int M = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
     return (size_t)(((M + 31) / 32 + 3) / 4 * 4) * ((K + 15) / 16) * 512;

@@ -1,0 +1,401 @@
+// Decoder conv1 of smp.Unet as a SUB-PIXEL convolution (starcop/models/model_module.py:244-251: every DecoderBlock runs
+// conv3x3(cat([F.interpolate(prev, scale_factor=2, mode="nearest"), skip]))).
+//
+// For the up-sampled channels, conv3x3(nearest_up2(x)) is exactly four phase-specific 2x2 convolutions on the LOW-resolution x:
+//   y[co][2i+py][2j+px] = sum_{a,b in {0,1}} sum_ci  Wph[py][px][a][b][co][ci] * x[ci][i + a-1+py][j + b-1+px]
+//   Wph[py][px][a][b] = sum_{kh in S(py,a)} sum_{kw in S(px,b)} w[kh][kw],   S(0,0)={0}  S(0,1)={1,2}  S(1,0)={0,1}  S(1,1)={2}
+// (zero padding maps 1:1: an up-sampled pixel outside the image is a low-resolution pixel outside the image).  The 3x3 form
+// (k_conv3_bx3 with src.up address arithmetic) loads, prologues and splits every low-resolution value once per high-resolution
+// copy and multiplies nine taps where four suffice: 2.25x the MFMAs and, per output, 2-4x the staging of this kernel.
+// The skip channels (full resolution) join the SAME launch as low-resolution "parity planes" (qy,qx) -- pixels (2i+qy, 2j+qx) of a
+// skip channel: slot (py,px,a,b) reads a parity plane at the same offset (a-1+py, b-1+px), with the single tap
+// kh = 2a+py+qy-1, kw = 2b+px+qx-1 as its filter (zero when that is outside the 3x3 window), so one code path serves both kinds
+// of 16-channel chunk (conv_sp_pack.h).
+//
+// Arithmetic: the two-fp16-term split of conv_bx3.hip (a*s = h0 + h1, products h0*g1 + h1*g0 + h0*g0, fp32 accumulation, exact
+// power-of-two operand scales divided out in the epilogue).  The phase filters are sums of up to four taps, so their scale is
+// 2^6 instead of 2^8 (|w| < 255 keeps |sum| * 2^6 < 65504).
+//
+// GEMM view per phase (py,px) and tap (a,b):  D[co][pixel] += Wph[co][ci] * patch[ci][pixel + (a-1+py, b-1+px)],  K step = 16 channels
+//   A (32 x 16): lane l -> Wph[co = l&31][ci = 8*(l>>5) .. +7]   (one 16-byte LDS read per term)
+//   B (16 x 32): lane l -> patch[ci = 8*(l>>5) .. +7][pixel l&31]   (one 16-byte LDS read per term)
+// Work-group = 8 waves; low-resolution tile = 8 groups of 32 pixels (TW = 32: 8 rows x 32 columns; TW = 16: 16 rows x 16 columns,
+// a group = two rows) x 32 output channels x 4 phases = 16 x 64 (32 x 32) output pixels.  Wave w: phase ROW py = w >> 2, groups
+// 2(w&3), 2(w&3)+1, both px: 4 accumulators -- which leaves the registers to request every operand one 12-MFMA step ahead (the
+// first version, 4 waves x 8 accumulators, had none and waited for LDS after every second MFMA).  The two waves of a SIMD share
+// ONE patch and one filter stage in LDS: every low-resolution value is staged once for all four phases.
+// Pipeline: patch and filters double-buffered, ONE barrier per 16-channel chunk; chunk k+1 is converted / stored at the top of
+// chunk k (its global loads were issued a whole chunk earlier) and the loads of chunk k+2 are re-issued into the same registers
+// right behind ("refill": DESIGN.md section 11 rule 2); all loads unconditional (clamped chunk index), so the waits stay exact.
+#include "sc_common.h"
+#include "conv_sp_pack.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(2))) float floatx2;
+typedef __attribute__((ext_vector_type(4))) unsigned int uintx4;
+typedef __attribute__((ext_vector_type(8))) _Float16 halfx8;
+typedef __attribute__((ext_vector_type(2))) _Float16 halfx2;
+
+constexpr float SP_SX = 2.f, SP_HMAX = 65504.f;
+
+__device__ __forceinline__ void sp_split2h(float a, float b, unsigned& t0, unsigned& t1) {
+  const floatx2 v = {a, b};
+  const halfx2 h0 = __builtin_convertvector(v, halfx2);
+  t0 = __builtin_bit_cast(unsigned, h0);
+  float ra, rb;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(t0), "v"(v[0]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(t0), "v"(v[1]));
+  const halfx2 h1 = __builtin_convertvector(floatx2{ra, rb}, halfx2);
+  t1 = __builtin_bit_cast(unsigned, h1);
+}
+
+struct ConvSPP {
+  SrcD s0, s1;             // s0: low-resolution source [N][C0][Hl][Wl]; s1: skip source [N][C1][2 Hl][2 Wl] (C1 = 0: none); AFFINE or RAW
+  const uintx4* wpk;       // sc_pack_weights_sp layout
+  int N, Hl, Wl, Cout;     // output is [N][Cout][2 Hl][2 Wl]
+  float* out;
+  float* stats;            // [rows = N * tiles][Cout][2] or NULL
+};
+
+constexpr int SP_SMEM_W = 2 * SP_WST * 16;               // filter stages, double-buffered (64 KB)
+template <int TW> constexpr int sp_npx() { return (256 / TW + 2) * (TW + 2); }
+template <int TW> constexpr int sp_smem_bytes() { return SP_SMEM_W + 2 * 2 * 2 * sp_npx<TW>() * 16 + 8 * 32 * 2 * 4; }
+
+template <int TW>
+__global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
+  constexpr int NT = 2;
+  constexpr int TH = 256 / TW;
+  constexpr int PC = TW + 2, NPX = sp_npx<TW>();
+  constexpr int NR = 3;
+  constexpr int WST = SP_WST;                // 16-byte filter entries per chunk
+  constexpr int NWV = WST / 512;
+  static_assert(NPX <= 128 * NR, "three staging rounds of 128 threads per channel quarter");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uintx4* const s_w = reinterpret_cast<uintx4*>(smem);                                   // [2][WST]
+  uintx4* const s_p = reinterpret_cast<uintx4*>(smem + SP_SMEM_W);                        // [2 buf][NT][2 halves][NPX]
+  float* const s_red = reinterpret_cast<float*>(smem + SP_SMEM_W + 2 * NT * 2 * NPX * 16);  // [8][32][2]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int py = wave >> 2, wq = wave & 3;
+  const int Hl = p.Hl, Wl = p.Wl;
+  const int tiles_x = (Wl + TW - 1) / TW, tiles_y = (Hl + TH - 1) / TH;
+  const int ncot = (p.Cout + 31) >> 5;
+  int n, cot, tile;
+  {
+    // each XCD (work-groups are dealt to the 8 XCDs round-robin by linear id) walks a contiguous eighth of the pixel tiles, the
+    // cout tiles of a pixel tile back to back: neighbouring patches and the re-read patch are hits in that XCD's L2
+    const int per_img = tiles_x * tiles_y;
+    const int total = per_img * p.N, per_xcd = (total + 7) >> 3;
+    const int slot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int j = slot / ncot;
+    const int pt = xcd * per_xcd + j;
+    if (j >= per_xcd || pt >= total) return;
+    cot = slot - j * ncot;
+    n = pt / per_img; tile = pt - n * per_img;
+  }
+  n = __builtin_amdgcn_readfirstlane(n); cot = __builtin_amdgcn_readfirstlane(cot); tile = __builtin_amdgcn_readfirstlane(tile);
+  const int ty = __builtin_amdgcn_readfirstlane(tile / tiles_x), tx = tile - ty * tiles_x;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int C0 = p.s0.C, C1 = p.s1.C;
+  const int nku = (C0 + 15) >> 4, nkt = nku + 4 * ((C1 + 15) >> 4);
+  const uintx4* wbase = p.wpk + (size_t)cot * nkt * WST;
+
+  const float hsx = SP_SX;
+  const float hinv = 1.f / (hsx * SP_SW);
+
+  floatx16 acc[2][2];      // [group pp][px]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i >> 1][i & 1][r] = 0.f;
+
+  // ---- staging state: thread = (channel quarter q4: half hw, 4-channel sub-block), patch pixels sidx + 128 r ----
+  const int q4 = __builtin_amdgcn_readfirstlane(tid >> 7);
+  const int hw = q4 >> 1, sub = q4 & 1;
+  const int sidx = tid & 127;
+  unsigned pyx[NR];        // patch pixel of round r: (y << 16) | x of the low-resolution plane, 0xFFFFFFFF outside the image / the patch
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int e = sidx + 128 * r;
+    const int pr = e / PC, pc = e - pr * PC;
+    const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+    const bool ok = (e < NPX) && (y >= 0) && (y < Hl) && (x >= 0) && (x < Wl);
+    pyx[r] = ok ? ((unsigned)y << 16) | (unsigned)x : 0xFFFFFFFFu;
+  }
+  float xv[NR][4];
+  uintx4 wv[NWV];
+  float cs0[4], cs1[4];
+  float slo = 0.f, shi = 0.f;
+  int nch = 0;
+
+  // requests chunk kc: its filters first (vmcnt retires in order), the patch values, the per-channel constants
+  auto request = [&](int kc) __attribute__((always_inline)) {
+    const uintx4* wsrc = wbase + (size_t)kc * WST;
+#pragma unroll
+    for (int j = 0; j < NWV; ++j) wv[j] = wsrc[tid + 512 * j];
+    const bool second = kc >= nku;
+    const int c4 = kc - nku;
+    const SrcD& s = second ? p.s1 : p.s0;
+    const int cbase = (second ? (c4 >> 2) : kc) * 16 + hw * 8 + sub * 4;
+    const size_t plane = second ? (size_t)4 * Hl * Wl : (size_t)Hl * Wl;
+    const unsigned qoff = second ? (unsigned)(((c4 >> 1) & 1) * 2 * Wl + (c4 & 1)) : 0u;
+    nch = s.C - cbase;
+    const int cb0 = nch > 0 ? cbase : 0;
+    const float* xb = s.x + ((size_t)n * s.C + cb0) * plane;
+    const int jmax = nch > 0 ? nch - 1 : 0;      // (channels beyond the last re-read it; masked at conversion)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const bool ok = pyx[r] != 0xFFFFFFFFu;
+      const unsigned y = pyx[r] >> 16, x = pyx[r] & 0xFFFFu;
+      const unsigned o = !ok ? 0u : (second ? (4u * y * (unsigned)Wl + 2u * x + qoff) : (y * (unsigned)Wl + x));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xv[r][j] = xb[(size_t)(j < jmax ? j : jmax) * plane + o];
+    }
+    slo = fmaxf(sc_act_lo(s.act) * hsx, -SP_HMAX); shi = fminf(sc_act_hi(s.act) * hsx, SP_HMAX);
+    const float* cb = s.cst + (size_t)cb0 * SC_CST;      // (RAW sources read the host's identity table: no load under a branch)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float2 c = *reinterpret_cast<const float2*>(cb + (size_t)(j < jmax ? j : jmax) * SC_CST);
+      cs0[j] = c.x * hsx; cs1[j] = c.y * hsx;
+    }
+  };
+  // prologue + split of the requested chunk -> patch buffer `buf`, its filters -> filter buffer `buf`
+  auto stage = [&](int buf) __attribute__((always_inline)) {
+    uint2* const sp2 = reinterpret_cast<uint2*>(s_p + (size_t)buf * NT * 2 * NPX);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      uint2 t0, t1;
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        float v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = 2 * jp + h;
+          const float t = __builtin_amdgcn_fmed3f(fmaf(xv[r][j], cs0[j], cs1[j]), slo, shi);
+          v[h] = (pyx[r] != 0xFFFFFFFFu && j < nch) ? t : 0.f;
+        }
+        unsigned a0, a1;
+        sp_split2h(v[0], v[1], a0, a1);
+        if (jp == 0) { t0.x = a0; t1.x = a1; } else { t0.y = a0; t1.y = a1; }
+      }
+      const int e = sidx + 128 * r;
+      if (e < NPX) {
+        sp2[((0 * 2 + hw) * NPX + e) * 2 + sub] = t0;
+        sp2[((1 * 2 + hw) * NPX + e) * 2 + sub] = t1;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NWV; ++j) s_w[buf * WST + tid + 512 * j] = wv[j];
+  };
+
+  // lane -> patch entry of its pixel in group pp (centre tap)
+  int eb[2];
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {
+    const int g = 2 * wq + pp;
+    const int rowt = TW == 32 ? g : 2 * g + (l31 >> 4), colt = TW == 32 ? l31 : (l31 & 15);
+    eb[pp] = (rowt + 1 + py - 1) * PC + colt;           // + a * PC + o   (source row offset a - 1 + py, o = column offset + 1 in 0..2)
+  }
+  const int wlane = py * (NT * 2 * 2 * 2 * 2 * 32) + lhi * 32 + l31;       // + ((((c*2 + px)*2 + a)*2 + b)*2)*32
+
+  // the 48 MFMAs of one chunk: steps (a, pp) of 12 MFMAs, every operand requested one step before its use.  TW = 32: groups are
+  // consecutive patch rows, so step (a = 1, group 0) and step (a = 0, group 1) read the SAME patch row: three row operand sets
+  // instead of four (34 instead of 40 LDS reads per chunk and wave).
+  // (Parity chunks run all 16 slots although 7 of them have zero filters: compile-time slot masks per parity -- 7 variants of this
+  // body -- pushed the kernel from 239 registers to 256 + scratch reloads inside the loop for < 0.5 % of the step: not kept.)
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    const uintx4* const sw = s_w + buf * WST + wlane;
+    const uintx4* const sp = s_p + (size_t)buf * NT * 2 * NPX + lhi * NPX;
+    halfx8 A0[2][2][NT], A1[2][2][NT], B0[3][NT], B1[3][NT];
+    auto load_A = [&](halfx8 (&A)[2][2][NT], int a) {
+#pragma unroll
+      for (int px = 0; px < 2; ++px)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int c = 0; c < NT; ++c) A[px][b][c] = __builtin_bit_cast(halfx8, sw[((((c * 2 + px) * 2 + a) * 2 + b) * 2) * 32]);
+    };
+    auto load_B = [&](halfx8 (&B)[3][NT], int a, int pp) {
+#pragma unroll
+      for (int o = 0; o < 3; ++o)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) B[o][c] = __builtin_bit_cast(halfx8, sp[c * 2 * NPX + eb[pp] + a * PC + o]);
+    };
+    auto mfmas = [&](const halfx8 (&A)[2][2][NT], const halfx8 (&B)[3][NT], auto ppc) {
+      constexpr int pp = decltype(ppc)::value;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int px = 0; px < 2; ++px) {      // the two accumulators alternate: no back-to-back dependent MFMAs
+            const int o = b + px;
+            acc[pp][px] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[px][b][t == 1 ? 1 : 0], B[o][t == 0 ? 1 : 0], acc[pp][px], 0, 0, 0);
+          }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    load_A(A0, 0); load_B(B0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_B(B1, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(A0, B0, P0{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TW == 32) {
+      load_A(A1, 1); load_B(B0, 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(A0, B1, P1{});
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(A1, B1, P0{});            // (a = 1, group 0) reads the patch row of (a = 0, group 1)
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(A1, B0, P1{});
+    } else {
+      load_A(A1, 1); load_B(B0, 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(A0, B1, P1{});
+      __builtin_amdgcn_sched_barrier(0);
+      load_B(B1, 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(A1, B0, P0{});
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(A1, B1, P1{});
+    }
+  };
+
+  // ---- pipeline ----
+  request(0);
+  stage(0);
+  request(nkt > 1 ? 1 : 0);
+  __syncthreads();
+  for (int kc = 0; kc < nkt; ++kc) {
+    if (kc + 1 < nkt) stage((kc + 1) & 1);                 // (chunk kc+1: requested one chunk ago; no loads inside the branch)
+    request(kc + 2 < nkt ? kc + 2 : nkt - 1);              // refill: a whole chunk of flight, same registers
+    __builtin_amdgcn_sched_barrier(0);
+    compute(kc & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: two adjacent output pixels (px = 0, 1) per lane and row -> 8-byte stores, 256-byte runs per (cout, row) ----
+  const int W = 2 * Wl;
+  const unsigned hw32 = (unsigned)((size_t)4 * Hl * Wl);
+  float* const ob = p.out + ((size_t)n * p.Cout + cot * 32) * (size_t)hw32;
+  const bool want_stats = p.stats != nullptr;
+  unsigned loff[2]; bool okp[2];
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {
+    const int g = 2 * wq + pp;
+    const int i = y0 + (TW == 32 ? g : 2 * g + (l31 >> 4)), j = x0 + (TW == 32 ? l31 : (l31 & 15));
+    okp[pp] = i < Hl && j < Wl;
+    loff[pp] = (unsigned)(4 * lhi) * hw32 + (unsigned)(okp[pp] ? (2 * i + py) * W + 2 * j : 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int cu = (r & 3) + 8 * (r >> 2);
+    const int col = cu + 4 * lhi;
+    const bool okc = cot * 32 + col < p.Cout;
+    float sv = 0.f, sq = 0.f;
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      floatx2 v = {acc[pp][0][r] * hinv, acc[pp][1][r] * hinv};
+      if (okp[pp] && okc) *reinterpret_cast<floatx2*>(ob + loff[pp] + (unsigned)cu * hw32) = v;
+      else v = floatx2{0.f, 0.f};
+      sv += v[0] + v[1];
+      sq = fmaf(v[0], v[0], fmaf(v[1], v[1], sq));
+    }
+    if (want_stats) {
+      const float s = half_sum32(sv);
+      const float ss = half_sum32(sq);
+      if (l31 == SC_HALF_SUM_LANE) { s_red[(wave * 32 + col) * 2 + 0] = s; s_red[(wave * 32 + col) * 2 + 1] = ss; }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    if (tid < 64) {
+      const int col = tid >> 1, k = tid & 1;
+      const int co = cot * 32 + col;
+      if (co < p.Cout) {
+        float t = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) t += s_red[(w8 * 32 + col) * 2 + k];
+        const size_t row = (size_t)n * (tiles_x * tiles_y) + tile;
+        p.stats[(row * p.Cout + co) * 2 + k] = t;
+      }
+    }
+  }
+}
+
+__global__ void k_pack_weights_sp(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout, int Cup, int Csk, size_t total) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < total) sp_pack_item(w, wpk, i, Cout, Cup, Csk);
+}
+
+}  // namespace
+
+extern "C" size_t sc_packed_weight_floats_sp(int Cout, int Cup, int Cskip) {
+  return (size_t)((Cout + 31) / 32) * sp_chunks(Cup, Cskip) * SP_WST * 4;      // 16-byte entries -> floats
+}
+
+extern "C" int sc_pack_weights_sp(const float* w, float* wpk, int Cout, int Cup, int Cskip, sc_stream stream) {
+  SC_REQUIRE(w && wpk && Cout > 0 && Cup > 0 && Cskip >= 0, "sc_pack_weights_sp: bad argument");
+  SC_REQUIRE(((uintptr_t)wpk & 15) == 0, "sc_pack_weights_sp: destination must be 16-byte aligned");
+  const size_t total = sp_pack_items(Cout, Cup, Cskip);
+  hipLaunchKernelGGL(k_pack_weights_sp, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     reinterpret_cast<unsigned short*>(wpk), Cout, Cup, Cskip, total);
+  SC_LAUNCH_OK("sc_pack_weights_sp");
+  return SC_OK;
+}
+
+extern "C" int sc_sp_stat_rows(int N, int H, int W) {
+  const int Hl = H / 2, Wl = W / 2;
+  const int TW = Wl >= 32 ? 32 : 16, TH = 256 / TW;
+  return N * ((Wl + TW - 1) / TW) * ((Hl + TH - 1) / TH);
+}
+
+extern "C" int sc_conv3x3_sp(const sc_conv_args* a, sc_stream stream) {
+  SC_REQUIRE(a != nullptr, "sc_conv3x3_sp: null args");
+  SC_REQUIRE(a->ks == 3 && (a->nsrc == 1 || a->nsrc == 2), "sc_conv3x3_sp: ks = 3, one (up-sampled) or two (up-sampled, skip) sources");
+  SC_REQUIRE(a->src[0].up == 1, "sc_conv3x3_sp: src[0] must be the half-resolution tensor (up = 1)");
+  SC_REQUIRE(a->nsrc == 1 || a->src[1].up == 0, "sc_conv3x3_sp: src[1] is the full-resolution skip tensor (up = 0)");
+  for (int s = 0; s < a->nsrc; ++s) {
+    SC_REQUIRE(a->src[s].mode == SC_SRC_RAW || a->src[s].mode == SC_SRC_AFFINE, "sc_conv3x3_sp: RAW or AFFINE sources");
+    SC_REQUIRE(a->src[s].mode == SC_SRC_RAW || a->src[s].cst != nullptr, "sc_conv3x3_sp: source %d needs constants", s);
+    SC_REQUIRE(a->src[s].C > 0, "sc_conv3x3_sp: source %d has no channels", s);
+  }
+  SC_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->Cout > 0, "sc_conv3x3_sp: bad shape");
+  SC_REQUIRE(a->H % 2 == 0 && a->W % 2 == 0, "sc_conv3x3_sp: even output size");
+  SC_REQUIRE(a->terms == SC_TERMS_F16X2, "sc_conv3x3_sp: two-fp16-term arithmetic only (terms = SC_TERMS_F16X2)");
+  SC_REQUIRE(a->csplit == a->Cout && a->out1 == nullptr && a->add0 == nullptr && a->add1 == nullptr && !a->down0 && !a->accum0,
+             "sc_conv3x3_sp: a single plain output");
+  SC_REQUIRE(((uintptr_t)a->wpk & 15) == 0 && ((uintptr_t)a->out0 & 7) == 0, "sc_conv3x3_sp: alignment");
+  SC_REQUIRE((size_t)32 * a->H * a->W < (1ull << 32), "sc_conv3x3_sp: plane too large");
+  ConvSPP p;
+  p.s0 = to_srcd(a->src[0]);
+  p.s1 = a->nsrc == 2 ? to_srcd(a->src[1]) : p.s0;          // (C = 0 below: never selected, but its pointers stay valid)
+  if (a->nsrc != 2) p.s1.C = 0;
+  if (p.s0.mode == SC_SRC_RAW) p.s0.cst = sc_identity_cst_table(p.s0.C);
+  if (p.s1.mode == SC_SRC_RAW) p.s1.cst = sc_identity_cst_table(p.s1.C);
+  SC_REQUIRE(p.s0.cst != nullptr && p.s1.cst != nullptr, "sc_conv3x3_sp: identity constants unavailable");
+  p.wpk = reinterpret_cast<const uintx4*>(a->wpk);
+  p.N = a->N; p.Hl = a->H / 2; p.Wl = a->W / 2; p.Cout = a->Cout;
+  p.out = a->out0; p.stats = a->stats;
+  const int TW = p.Wl >= 32 ? 32 : 16, TH = 256 / TW;
+  const long tiles = (long)((p.Wl + TW - 1) / TW) * ((p.Hl + TH - 1) / TH) * a->N;
+  const long ncot = (a->Cout + 31) / 32;
+  const long grid = (tiles + 7) / 8 * 8 * ncot;
+  SC_REQUIRE(grid < (1L << 31), "sc_conv3x3_sp: grid too large");
+  static const bool attr_ok = [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<32>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<32>()) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<16>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess;
+  }();
+  SC_REQUIRE(attr_ok, "sc_conv3x3_sp: cannot reserve %d bytes of LDS", sp_smem_bytes<32>());
+  if (TW == 32) hipLaunchKernelGGL((k_conv3_sp<32>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<32>(), (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((k_conv3_sp<16>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<16>(), (hipStream_t)stream, p);
+  SC_LAUNCH_OK("sc_conv3x3_sp");
+  return SC_OK;
+}

@@ -658,21 +658,28 @@ extern "C" int sc_bn_bwd_finalize(const double* sums, int nrows, double count, c
 // device-idle time per training step behind the ~50 fork points of the weight-gradient stream).  Kernels of the same device only need
 // the device-scope release every dispatch ends with, so the events here are created with hipEventDisableSystemFence.
 extern "C" int sc_stream_wait_stream(sc_stream waiter, sc_stream signaller) {
-  // (one device per process -- the framework's process model: the events belong to the device that is current at the first call;
-  //  an event may be re-recorded while an earlier wait on it is still pending: a wait captures the record that preceded it)
-  constexpr int NEV = 64;
-  static hipEvent_t ring[NEV];
-  static std::once_flag once;
-  static bool ok = false;
+  // (an event may be re-recorded while an earlier wait on it is still pending: a wait captures the record that preceded it.  One ring
+  //  per device, created on first use there: an event belongs to the device that was current when it was created)
+  constexpr int NEV = 64, MAXDEV = 16;
+  static hipEvent_t rings[MAXDEV][NEV];
+  static std::once_flag once[MAXDEV];
+  static bool oks[MAXDEV] = {};
   static std::atomic<unsigned> next{0};
-  std::call_once(once, [] {
-    ok = true;
-    for (int i = 0; i < NEV; ++i) ok = ok && hipEventCreateWithFlags(&ring[i], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) {
+    sc_set_error("sc_stream_wait_stream: device index outside [0, %d)", MAXDEV);
+    return SC_ERR_LAUNCH;
+  }
+  std::call_once(once[dev], [dev] {
+    bool ok = true;
+    for (int i = 0; i < NEV; ++i) ok = ok && hipEventCreateWithFlags(&rings[dev][i], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
+    oks[dev] = ok;
   });
-  if (!ok) {
+  if (!oks[dev]) {
     sc_set_error("sc_stream_wait_stream: hipEventCreateWithFlags failed");
     return SC_ERR_LAUNCH;
   }
+  hipEvent_t* const ring = rings[dev];
   hipEvent_t e = ring[next.fetch_add(1) % NEV];
   if (hipEventRecord(e, (hipStream_t)signaller) != hipSuccess || hipStreamWaitEvent((hipStream_t)waiter, e, 0) != hipSuccess) {
     sc_set_error("sc_stream_wait_stream: %s", hipGetErrorString(hipGetLastError()));

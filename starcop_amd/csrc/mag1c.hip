@@ -1614,7 +1614,8 @@ __global__ void k_scatter(const TI* __restrict__ val, const long long* __restric
 // valid[p] = all(cube[p][band0 .. band0+S) > nodata)  (func_by_groups' default mask, mag1c.py:140-142; NE: != fill, mag1c_emit.py:60-66:
 // pixels with any band equal to the fill value are left out) in one pass over the pixel-major cube.  A block owns 256 consecutive
 // pixels = one contiguous run of the cube and reads it as 16-byte vectors, eight per thread in flight; the pixel of an element comes
-// from a multiply-shift (block-local element index < 2^28, so floor(e * ceil(2^40 / S_total) / 2^40) is the exact quotient), a failing
+// from a multiply-shift (block-local element index e < 256 S_total and S_total <= 2^16 (host-checked), so e * (ceil(2^40 / S_total) - 2^40 / S_total) < 2^40 / S_total
+// and floor(e * ceil(2^40 / S_total) / 2^40) is the exact quotient), a failing
 // element clears its pixel's flag in LDS (benign race: every writer stores 0).  (History: per element with a 64-bit division 79 us on
 // the 512 x 512 x 125 tile = 1.7 TB/s; a wave per pixel 67 us -- its 500-byte rows straddle lines and leave lanes idle on narrow cubes.)
 template <typename T, bool NE>
@@ -1910,7 +1911,7 @@ extern "C" int sc_scatter(const void* val, int val_is_f64, const int64_t* pix_in
 extern "C" int sc_valid_mask(const void* cube, int cube_is_f64, int S_total, int band0, int S, double nodata, int64_t npix,
                              unsigned char* valid, sc_stream stream) {
   SC_REQUIRE(cube && valid && S_total > 0 && band0 >= 0 && S > 0 && band0 + S <= S_total && npix >= 0, "sc_valid_mask: bad argument");
-  SC_REQUIRE(S_total <= (1 << 20), "sc_valid_mask: at most 2^20 bands per pixel");
+  SC_REQUIRE(S_total <= (1 << 16), "sc_valid_mask: at most 65536 bands per pixel");      // (e < 256 S_total: the multiply-shift quotient is exact only while S_total^2 * 256 <= 2^40)
   if (npix == 0) return SC_OK;
   const unsigned blocks = (unsigned)((npix + 255) / 256);
   const unsigned long long magic = ((1ull << 40) + S_total - 1) / S_total;
@@ -1923,7 +1924,7 @@ extern "C" int sc_valid_mask(const void* cube, int cube_is_f64, int S_total, int
 extern "C" int sc_valid_mask_ne(const void* cube, int cube_is_f64, int S_total, int band0, int S, double fill, int64_t npix,
                                 unsigned char* valid, sc_stream stream) {
   SC_REQUIRE(cube && valid && S_total > 0 && band0 >= 0 && S > 0 && band0 + S <= S_total && npix >= 0, "sc_valid_mask_ne: bad argument");
-  SC_REQUIRE(S_total <= (1 << 20), "sc_valid_mask_ne: at most 2^20 bands per pixel");
+  SC_REQUIRE(S_total <= (1 << 16), "sc_valid_mask_ne: at most 65536 bands per pixel");
   if (npix == 0) return SC_OK;
   const unsigned blocks = (unsigned)((npix + 255) / 256);
   const unsigned long long magic = ((1ull << 40) + S_total - 1) / S_total;

@@ -270,7 +270,7 @@ def func_by_groups(func, x, groups, mask=None, disable_pbar=True, samples_read=5
         # The ids are bounded by the detector width; max_group (or one .max() read-back) sizes the histogram.
         # max_group is a caller's promise: ids above it (or negative ones) would be dropped to NODATA without a word, so the data
         # are checked against it (one read-back either way)
-        gmin, gmax = int(groups_t.min()), int(groups_t.max())
+        gmin, gmax = (int(v) for v in torch.aminmax(groups_t))          # one read-back for both
         if max_group is not None:
             if gmax > int(max_group) or gmin < 0:
                 raise ValueError(f"func_by_groups: group ids span [{gmin}, {gmax}] but max_group={max_group} was given")

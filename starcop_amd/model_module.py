@@ -403,7 +403,7 @@ class ModelModule(_Base):
             lo = started[0][0] if started else g.numel()
             scale = grad_sync.finish(g[:lo], [h for _, h in started])
         else:
-            net._backward_impl(plan, plan.dlogits)
+            net._backward_impl(plan, plan.dlogits, exchange_follows=grad_sync is not None)      # (an all-reduce of these gradients follows)
             if grad_sync is not None:
                 scale = grad_sync(net.flat_grads())
         # a step without gradient exchange inside an initialised multi-rank job is rank-local by definition (bench.py's

@@ -26,7 +26,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, sc_irt_args, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD, sc_wgrad_pending,
-                   PACK_PW3, PACK_THIN16, STAT_PW3, STAT_CONV1, STAT_CONV1K, STAT_CONV3, STAT_DW, STAT_STEM, TERMS_F16X2, check, make_src, ptr,
+                   PACK_PW3, PACK_SP, PACK_THIN16, STAT_PW3, STAT_CONV1, STAT_CONV1K, STAT_CONV3, STAT_DW, STAT_STEM, TERMS_F16X2, check, make_src, ptr,
                    sc_conv_args, sc_wgrad_args, stream)
 
 MBV2_SETTINGS = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2),
@@ -169,6 +169,28 @@ def _use_irt(N, Cin, Hd, Hin, Win, stride):
     return _IRT == "all" or (Hin * Win >= 65536 and 4 * N * Hd * Hin * Win >= (256 << 20))
 
 
+# Decoder conv1 = conv3x3(cat([nearest_up2(prev), skip])) as a SUB-PIXEL convolution (conv_sp.hip: four phase-specific 2x2
+# convolutions on the low-resolution prev, the skip channels as low-resolution parity planes: 2.25x fewer MFMAs for the up-sampled
+# channels, every low-resolution value staged once instead of once per high-resolution copy).  Measured against sc_conv3x3_bx3 with
+# an up-sampled source (tools/bench_sp.py, us per launch, batch 16 / 64): decoder.blocks.1 125 -> 88 / 465 -> 333, blocks.2 146 ->
+# 118 / 544 -> 461, blocks.3 171 -> 131 / 689 -> 542; blocks.0 (16 x 16 low-resolution planes: 128 work-groups of 8 waves at batch 16
+# for 256 CUs) 311 -> 330 at batch 16 but 1131 -> 778 at batch 64; blocks.4 (16 output channels: half-empty MFMA rows) level with
+# sc_conv3x3_thin16.  "1" = that rule, "all" = every decoder conv1 (tests), "0" = off.
+_SP = os.environ.get("STARCOP_SP", "1")
+
+
+def _use_sp(N, Ho, Wo, Cout):
+    """forward of a decoder conv1 with an Ho x Wo output on sc_conv3x3_sp?"""
+    if _SP == "0" or Ho % 2 or Wo % 2:
+        return False
+    if _SP == "all":
+        return True
+    Hl, Wl = Ho // 2, Wo // 2
+    tw = 32 if Wl >= 32 else 16
+    wgs = N * (-(-Wl // tw)) * (-(-Hl // (256 // tw))) * (-(-Cout // 32))
+    return Cout >= 32 and wgs >= 256
+
+
 def _use_ksplit(N, HW, K, M, ks=1):
     """1x1 layers with few pixels and long K: the split-K kernel (sc_conv1x1_ksplit) beats the 128-pixel tiles when
     those leave most CUs idle (measured crossover, tools/bench_pw.py)."""
@@ -269,8 +291,10 @@ class HyperStarcopUNet(nn.Module):
 
         With ``sync_ranks`` the report's all-reduce runs on EVERY rank, also on one that has already switched (or was configured
         with another precision): a rank that skipped it would leave the others waiting in the collective."""
-        if self.precision != "fp32" and not sync_ranks:
-            return True
+        multi = (sync_ranks and torch.distributed.is_available() and torch.distributed.is_initialized()
+                 and torch.distributed.get_world_size() > 1)
+        if self.precision != "fp32" and not multi:
+            return True          # (the report synchronises the device: only taken where its collective is owed to the other ranks)
         rep = self.split_range_report(sync_ranks)
         if self.precision != "fp32":
             return True
@@ -635,6 +659,11 @@ class HyperStarcopUNet(nn.Module):
                         ent["bA"] = torch.empty(lib.sc_packed_weight_floats_bx3(co, ci, 64, 1, tb_), dtype=torch.float32, device=dev)
                         ent["bB"] = torch.empty(lib.sc_packed_weight_floats_bx3(co, ci, 32, 1, tb_), dtype=torch.float32, device=dev)
                         ent["bB_off"] = ent["bB"].numel() // (-(-ci // 32)) * (cu // 32)      # floats before the skip channels' tile
+                # decoder conv1 forward as a sub-pixel convolution (two-fp16-term arithmetic only): phase / parity filters
+                if op.get("up") and xf and tf_ == TERMS_F16X2 and _SP != "0":
+                    cu = op["ins"][0].C
+                    ent["sp"] = torch.empty(lib.sc_packed_weight_floats_sp(co, cu, ci - cu), dtype=torch.float32, device=dev)
+                    ent["sp_cu"] = cu
                 self._wpk[i] = ent
                 self._pack_tables = {}
             if op["type"] == "pw":       # the split-bf16 layout of sc_conv1x1_pw3, where a plan runs this layer on it
@@ -671,6 +700,11 @@ class HyperStarcopUNet(nn.Module):
                         continue
                     total = lib.sc_pack_work_items(co, ci, ks, cot, 1, 1)
                     rows.append((conv.weight.data_ptr(), buf.data_ptr(), co, ci, ks, cot, 1, ent["terms_b"], total))
+                    starts.append(nblk)
+                    nblk += -(-total // 256)
+                if ent.get("sp") is not None:
+                    total = lib.sc_pack_work_items(co, ci, ks, ent["sp_cu"], 0, PACK_SP)
+                    rows.append((conv.weight.data_ptr(), ent["sp"].data_ptr(), co, ci, ks, ent["sp_cu"], 0, PACK_SP, total))
                     starts.append(nblk)
                     nblk += -(-total // 256)
                 for tflip, buf in ((0, ent["tf"]), (1, ent["tb"])):
@@ -768,6 +802,7 @@ class HyperStarcopUNet(nn.Module):
                 skip.add(plan.irt[i])
                 continue
             stats = ptr(plan.stats_v[o.name]) if (training and o.bn is not None) else None
+            srows = plan.srows.get(o.name, 0)
             conv = op.get("conv")
             tok = None
             self._cur_op = o.name + ":fwd"
@@ -808,6 +843,11 @@ class HyperStarcopUNet(nn.Module):
                 if ty == "pw" and _use_pw3(0, N, Ho * Wo, conv.in_channels, conv.out_channels):
                     fconv = lib.sc_conv1x1_pw3
                     a.wpk = ent["pf"].data_ptr()
+                elif (op.get("up") and ent.get("sp") is not None and ent["terms_f"] == TERMS_F16X2 and self.split_bf16
+                      and _use_sp(N, Ho, Wo, o.C)):
+                    fconv = lib.sc_conv3x3_sp
+                    a.wpk = ent["sp"].data_ptr()
+                    srows = lib.sc_sp_stat_rows(N, Ho, Wo)       # one partial row per work-group tile (fewer than SC_STAT_CONV3's)
                 elif ent["tf"] is not None:
                     fconv = lib.sc_conv3x3_thin16
                     a.wpk = ent["tf"].data_ptr()
@@ -832,7 +872,7 @@ class HyperStarcopUNet(nn.Module):
             self._pe(tok)
             if o.bn is not None and training:
                 bn = o.bn
-                check(lib.sc_bn_finalize(stats, plan.srows[o.name], float(N * Ho * Wo), ptr(bn.weight), ptr(bn.bias),
+                check(lib.sc_bn_finalize(stats, srows, float(N * Ho * Wo), ptr(bn.weight), ptr(bn.bias),
                                          ptr(bn.running_mean), ptr(bn.running_var), float(bn.momentum), float(bn.eps),
                                          1 if training else 0, ptr(plan.cst[o.name]), o.C, ptr(plan.bn_scratch) if _BN_PRE else None, st))
         if training:      # one multi-tensor launch for the 62 step counters
@@ -934,12 +974,16 @@ class HyperStarcopUNet(nn.Module):
         return self._TERMS[self.precision]
     _side_stream = None
 
-    def _backward_impl(self, plan, dlogits, on_tail_ready=None, only_ops=None):
+    def _backward_impl(self, plan, dlogits, on_tail_ready=None, only_ops=None, exchange_follows=None):
         """Fills the flat gradient buffer from dL/dlogits.  Needs the plan of a training-mode forward.
 
         ``only_ops`` (a list of indices into ``self._ops``; parity tests): run the backward of just these ops, each from whatever
         ``plan.grad[out]`` / ``plan.buf`` / ``plan.cst`` hold -- the teacher-forced per-layer gates feed every layer the oracle's
         activations and upstream gradient through exactly the launches a training step makes for it.
+
+        ``exchange_follows``: a gradient exchange (any collective that may leave the device) reads the flat gradient buffer right
+        after this call -- the final join of the weight-gradient stream then uses a default (system-fence) event; default: whether
+        ``on_tail_ready`` is given.  Callers with a non-bucketed exchange (a grad_sync object without begin()) pass True.
 
         ``on_tail_ready(lo, hi)`` is called once, when the walk leaves the decoder: every gradient of the decoder and head
         parameters (flat range [lo, hi), two thirds of the buffer) has been queued, so a data-parallel caller can start
@@ -1322,7 +1366,7 @@ class HyperStarcopUNet(nn.Module):
         if side is not None:
             # join: every weight gradient is in the flat buffer before Adam / all-reduce.  With a gradient exchange to follow
             # (on_tail_ready: the data-parallel path) a default event, otherwise the device-scope one
-            if on_tail_ready is not None:
+            if exchange_follows if exchange_follows is not None else on_tail_ready is not None:
                 main.wait_stream(side)
             else:
                 wait_stream(main, side)

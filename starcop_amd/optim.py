@@ -87,8 +87,15 @@ class FusedAdam(torch.optim.Adam):
                                ptr(self._hp_dev), st))
         net.mark_parameters_changed()
         if not sync_ranks:
-            return      # rank-local step: neither counted nor checked here -- the check's cadence (and its collective) must stay the same on
-                        # every rank; the sticky device-side records it reads keep what this step saw for the next common check
+            # rank-local step (the other ranks of an initialised process group are not stepping): it must not enter the common check's
+            # collective, nor shift its cadence -- but a job that ONLY ever takes rank-local steps (independent per-rank fine-tuning
+            # under torchrun) would otherwise never run the range check at all: own counter, local check, no all-reduce
+            self._local_steps_since_check = getattr(self, "_local_steps_since_check", 0) + 1
+            if (net.range_check_every and self._local_steps_since_check >= net.range_check_every
+                    and not torch.cuda.is_current_stream_capturing()):
+                self._local_steps_since_check = 0
+                net.check_split_range(sync_ranks=False)
+            return
         self._steps_since_check = getattr(self, "_steps_since_check", 0) + 1
         if net.range_check_every and self._steps_since_check >= net.range_check_every and not torch.cuda.is_current_stream_capturing():
             self._steps_since_check = 0

@@ -162,3 +162,45 @@ def wgrad_pw3(dy, src, N, H, W, Cout, Cin, deferred=False):
     _KEEP.extend([descs, starts])
     check(lib.sc_wgrad_reduce_batch(ptr(descs), ptr(starts), 1, -(-int(pend.total) // 256), stream()))
     return dw
+
+
+def pack_sp(w, cup, batched=False):
+    """decoder conv1 filter (Cout, Cup + Cskip, 3, 3) -> the phase / parity layout of sc_conv3x3_sp; batched: through the one-launch
+    pack (the network's path)"""
+    import numpy as np
+    from starcop_amd._lib import PACK_SP
+    lib = _lib.load()
+    co, ci = w.shape[0], w.shape[1]
+    out = torch.full((lib.sc_packed_weight_floats_sp(co, cup, ci - cup),), float("nan"), device=DEV)     # every entry must be written
+    if not batched:
+        check(lib.sc_pack_weights_sp(ptr(w), ptr(out), co, cup, ci - cup, stream()))
+        return out
+    total = lib.sc_pack_work_items(co, ci, 3, cup, 0, PACK_SP)
+    dt = np.dtype([("w", "<u8"), ("wpk", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"), ("ks", "<i4"), ("co_t", "<i4"),
+                   ("tflip", "<i4"), ("bx3", "<i4"), ("total", "<u8")])
+    descs = torch.from_numpy(np.array([(w.data_ptr(), out.data_ptr(), co, ci, 3, cup, 0, PACK_SP, total)], dtype=dt).view(np.uint8).copy()).to(DEV)
+    starts = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _KEEP.extend([descs, starts])
+    check(lib.sc_pack_weights_batch(ptr(descs), ptr(starts), 1, -(-total // 256), stream()))
+    return out
+
+
+def conv_sp(srcs, wpk, N, H, W, Cout, want_stats=False):
+    """sc_conv3x3_sp: srcs = [half-resolution source (up = 1)] or [that, full-resolution skip source]; H x W = output size"""
+    from starcop_amd._lib import TERMS_F16X2
+    lib = _lib.load()
+    a = sc_conv_args()
+    a.nsrc = len(srcs)
+    for i, s in enumerate(srcs):
+        a.src[i] = s
+    a.wpk = wpk.data_ptr()
+    a.N, a.H, a.W, a.Cout, a.ks, a.co_t = N, H, W, Cout, 3, 32
+    out = torch.full((N, Cout, H, W), float("nan"), device=DEV)
+    a.out0, a.out1, a.csplit = out.data_ptr(), None, Cout
+    a.accum0 = a.accum1 = 0
+    a.add0 = a.add1 = None
+    a.terms, a.down0, a.absmax = TERMS_F16X2, 0, None
+    stats = torch.full((lib.sc_sp_stat_rows(N, H, W), Cout, 2), float("nan"), device=DEV) if want_stats else None
+    a.stats = stats.data_ptr() if want_stats else None
+    check(lib.sc_conv3x3_sp(C.byref(a), stream()))
+    return out, stats

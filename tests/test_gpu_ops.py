@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from hip_ops import (dev, DEV, conv_mfma, cst_affine, pack, pack_bx3, relerr, wgrad_mfma)  # noqa: E402
+from hip_ops import (dev, DEV, conv_mfma, conv_sp, cst_affine, pack, pack_bx3, pack_sp, relerr, wgrad_mfma)  # noqa: E402
 from starcop_amd import _lib  # noqa: E402
 from starcop_amd._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD, STAT_CONV1,
                               STAT_DW, STAT_STEM, check, make_src, ptr, stream)  # noqa: E402
@@ -198,6 +198,57 @@ def test_conv_bx3_upsample_concat(hip, split_mode):
     for co_t in (32, 64):
         (out,), _ = conv_mfma([s0, s1], pack_bx3(dev(w), co_t, 0), N, H, W, cout, 3, co_t, bx3=True)
         assert relerr(out, ref) < BX3_TOL
+
+
+# ---- decoder conv1 as a sub-pixel convolution (conv_sp.hip): conv3x3(cat([nearest_up2(prev), skip])) from the low-resolution prev ----
+@pytest.mark.parametrize("c0,c1,cout,H,W", [(32, 24, 48, 16, 64), (64, 16, 32, 64, 128), (16, 0, 32, 32, 64), (48, 40, 64, 12, 20),
+                                             (20, 9, 40, 36, 72), (256, 32, 128, 8, 16), (32, 0, 16, 96, 80), (1280, 96, 64, 4, 6)])
+def test_conv_sp_matches_upsample_concat_conv(hip, c0, c1, cout, H, W):
+    """the reference's op sequence (smp DecoderBlock: interpolate(nearest, x2) -> cat -> conv3x3) in float64 against sc_conv3x3_sp:
+    low-resolution planes of both tile shapes (>= 32 wide: 8 x 32 tiles; narrower: 16 x 16), ragged tile edges, channel counts that
+    are not multiples of the 16-channel chunk, with and without skip channels, BatchNorm + ReLU / raw prologues, statistics rows"""
+    from starcop_amd._lib import TERMS_F16X2
+    N = 2
+    prev = rnd(N, c0, H // 2, W // 2, seed=1)
+    w = rnd(cout, c0 + c1, 3, 3, seed=3, scale=0.1)
+    sc0, sh0 = rnd(c0, seed=4) * 0.3 + 1, rnd(c0, seed=5) * 0.2
+    up = F.interpolate(F.relu(prev * sc0[None, :, None, None] + sh0[None, :, None, None]), scale_factor=2, mode="nearest")
+    srcs = [make_src(dev(prev), c0, SRC_AFFINE, act=ACT_RELU, up=1, cst=cst_affine(sc0, sh0))]
+    if c1:
+        skip = rnd(N, c1, H, W, seed=2)
+        sc1, sh1 = rnd(c1, seed=6) * 0.3 + 1, rnd(c1, seed=7) * 0.2
+        xin = torch.cat([up, skip * sc1[None, :, None, None] + sh1[None, :, None, None]], 1)
+        srcs.append(make_src(dev(skip), c1, SRC_AFFINE, act=ACT_NONE, cst=cst_affine(sc1, sh1)))
+    else:
+        xin = up
+    ref = F.conv2d(xin.double(), w.double(), padding=1)
+    wd = dev(w)
+    for batched in (False, True):
+        wpk = pack_sp(wd, c0, batched=batched)
+        assert bool(torch.isfinite(wpk.view(torch.int16).float()).all())
+        out, stats = conv_sp(srcs, wpk, N, H, W, cout, want_stats=True)
+        assert relerr(out, ref) < BX3_TOL
+        st = stats.double().sum(0).cpu()
+        assert relerr(st[:, 0], ref.sum((0, 2, 3))) < 1e-5
+        assert relerr(st[:, 1], (ref ** 2).sum((0, 2, 3))) < 1e-5
+    # as close to float64 as the 3x3 form of the same arithmetic (two fp16 terms per operand)
+    if c0 % 16 == 0 or not c1:           # (the 3x3 kernel's concat needs 16-channel-aligned first sources)
+        co_t = 64 if cout > 32 else 32
+        (out3,), _ = conv_mfma(srcs, pack_bx3(wd, co_t, 0, TERMS_F16X2), N, H, W, cout, 3, co_t, bx3=True, terms=TERMS_F16X2)
+        assert relerr(out, ref) < 3 * relerr(out3, ref) + 1e-7
+
+
+def test_conv_sp_raw_sources_and_filter_range(hip):
+    """RAW sources (the identity constants table), and phase filters at the edge of the fp16 range: |w| up to 250 -> sums of four
+    taps up to 1000, scaled by 2^6 (not the 3x3 kernels' 2^8) before the fp16 split"""
+    N, c0, c1, cout, H, W = 1, 16, 16, 32, 16, 64
+    prev, skip = rnd(N, c0, H // 2, W // 2, seed=11), rnd(N, c1, H, W, seed=12)
+    w = rnd(cout, c0 + c1, 3, 3, seed=13, scale=0.1)
+    w[0, 0] = 250.0
+    w[1, 1] = -250.0
+    ref = F.conv2d(torch.cat([F.interpolate(prev, scale_factor=2, mode="nearest"), skip], 1).double(), w.double(), padding=1)
+    out, _ = conv_sp([make_src(dev(prev), c0, SRC_RAW, up=1), make_src(dev(skip), c1, SRC_RAW)], pack_sp(dev(w), c0), N, H, W, cout)
+    assert relerr(out, ref) < BX3_TOL
 
 
 @pytest.mark.parametrize("cin,cout,H,W", [(32, 16, 32, 32), (16, 32, 20, 40), (80, 32, 16, 32), (256, 128, 4, 6), (152, 64, 24, 32)])

@@ -1,0 +1,71 @@
+"""sub-pixel decoder conv1 (sc_conv3x3_sp [+ skip part on sc_conv3x3_bx3]) against the 3x3 form (sc_conv3x3_bx3 with an up-sampled
+source): python tools/bench_sp.py [batch]  -- results and time per launch on the decoder's conv1 shapes"""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+from hip_ops import DEV, conv_mfma, pack_bx3
+from starcop_amd import _lib
+from starcop_amd._lib import SRC_AFFINE, ACT_RELU, ACT_NONE, SC_CST, TERMS_F16X2, make_src, sc_conv_args, check, ptr, stream
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+lib = _lib.load()
+torch.manual_seed(0)
+
+
+def timeit(fn, reps=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def sp_conv(srcs, wsp, N, H, W, cout, out, stats):
+    a = sc_conv_args()
+    a.nsrc = len(srcs)
+    for i, s_ in enumerate(srcs):
+        a.src[i] = s_
+    a.wpk = wsp.data_ptr(); a.N, a.H, a.W, a.Cout, a.ks, a.co_t = N, H, W, cout, 3, 32
+    a.out0 = out.data_ptr(); a.out1 = None; a.csplit = cout; a.accum0 = 0; a.accum1 = 0
+    a.add0 = None; a.add1 = None; a.stats = stats.data_ptr() if stats is not None else None
+    a.terms = TERMS_F16X2; a.down0 = 0; a.absmax = None
+    check(lib.sc_conv3x3_sp(C.byref(a), stream()))
+
+
+# (name, up channels, skip channels, cout, H out)
+SHAPES = [("d0a", 1280, 96, 256, 32), ("d1a", 256, 32, 128, 64), ("d2a", 128, 24, 64, 128), ("d3a", 64, 16, 32, 256), ("d4a", 32, 0, 16, 512)]
+for name, cu, cs, cout, H in SHAPES:
+    W = H
+    xl = torch.randn(N, cu, H // 2, W // 2, device=DEV)
+    xs = torch.randn(N, max(cs, 1), H, W, device=DEV)
+    w = torch.randn(cout, cu + cs, 3, 3, device=DEV) * 0.05
+    cl = torch.rand(cu, SC_CST, device=DEV); cl[:, 1] -= 0.5
+    csk = torch.rand(max(cs, 1), SC_CST, device=DEV)
+    s_up = make_src(xl, cu, SRC_AFFINE, act=ACT_RELU, up=1, cst=cl)
+    s_sk = make_src(xs, cs, SRC_AFFINE, act=ACT_NONE, cst=csk)
+    co_t = 64 if cout > 32 else 32
+    wb = pack_bx3(w, co_t, 0, TERMS_F16X2)
+    ref = [torch.empty(N, cout, H, W, device=DEV)]
+    srcs = [s_up, s_sk] if cs else [s_up]
+    _, st_ref = conv_mfma(srcs, wb, N, H, W, cout, 3, co_t, want_stats=True, outs=ref, bx3=True, terms=TERMS_F16X2)
+    t_ref = timeit(lambda: conv_mfma(srcs, wb, N, H, W, cout, 3, co_t, want_stats=True, outs=ref, bx3=True, terms=TERMS_F16X2))
+    # sub-pixel: one launch, the skip channels as parity planes
+    wsp = torch.empty(lib.sc_packed_weight_floats_sp(cout, cu, cs), device=DEV)
+    check(lib.sc_pack_weights_sp(ptr(w), ptr(wsp), cout, cu, cs, stream()))
+    out = torch.empty(N, cout, H, W, device=DEV)
+    rows = lib.sc_sp_stat_rows(N, H, W)
+    stats = torch.full((rows, cout, 2), float("nan"), device=DEV)
+    run = lambda: sp_conv(srcs, wsp, N, H, W, cout, out, stats)
+    run()
+    torch.cuda.synchronize()
+    err = float((out - ref[0]).abs().max() / ref[0].abs().max())
+    s0, s1 = stats.double().sum(0), st_ref.double().sum(0)
+    serr = float(((s0 - s1).abs() / s1.abs().clamp_min(1e-3)).max())
+    t_sp = timeit(run)
+    t_up = timeit(lambda: sp_conv(srcs[:1], wsp_up, N, H, W, cout, out, stats)) if cs and (wsp_up := torch.empty(lib.sc_packed_weight_floats_sp(cout, cu, 0), device=DEV)) is not None else t_sp
+    flop = 2.0 * N * H * W * (cu + cs) * cout * 9
+    print(f"{name} {cu}+{cs}->{cout} {H}^2: 3x3 {t_ref:7.1f} us ({flop/t_ref/1e6:6.1f} TF) | sub-pixel {t_sp:7.1f} us ({flop/t_sp/1e6:6.1f} TF alg.; up channels alone {t_up:7.1f}) "
+          f"x{t_ref/t_sp:4.2f} | out diff {err:.1e} stats diff {serr:.1e}", flush=True)
