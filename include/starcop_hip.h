@@ -205,6 +205,17 @@ size_t sc_packed_weight_floats_sp(int Cout, int Cup, int Cskip);
 int sc_pack_weights_sp(const float* w_oihw, float* wpk, int Cout, int Cup, int Cskip, sc_stream stream);
 int sc_sp_stat_rows(int N, int H, int W);
 int sc_conv3x3_sp(const sc_conv_args* a, sc_stream stream);
+/* ... and its data gradient w.r.t. the half-resolution source: a stride-2 4x4 convolution of dy (four parity planes x 2x2 taps), written
+ * at half resolution directly -- no full-resolution gradient of the up-sampled channels, no 2x2 down-sum (replaces
+ * sc_conv3x3_bx3(down0 = 1) on those channels; the skip channels' gradient stays an ordinary 3x3 launch).
+ *   sc_conv3x3_sp_dgrad: sc_conv_args with nsrc = 1, src[0] = the SC_SRC_BNBWD operand of the layer's output (g, y, constants; H x W),
+ *   Cout = csplit = the up-sampled source's channels, out0 = [N, Cout, H/2, W/2] (accum0 allowed), terms = SC_TERMS_F16X2, absmax as
+ *   in sc_conv3x3_bx3; `wpk` from sc_pack_weights_spd (or a sc_pack_desc with bx3 = SC_PACK_SPD, Cin = the filter's total input
+ *   channels, co_t = the up-sampled source's channels). */
+#define SC_PACK_SPD 8
+size_t sc_packed_weight_floats_spd(int Cout, int Cup);
+int sc_pack_weights_spd(const float* w_oihw, float* wpk, int Cout, int CinTotal, int Cup, sc_stream stream);
+int sc_conv3x3_sp_dgrad(const sc_conv_args* a, sc_stream stream);
 
 /* weight gradient of the same thin layers (Cout <= 16, Cin = 16 | 32, one source which may be upsampled) with two fp16 terms on
  * v_mfma_f32_16x16x32_f16: same sc_wgrad_args as sc_conv2d_wgrad_mfma with terms = SC_TERMS_F16X2 (absmax = the dy range hint),

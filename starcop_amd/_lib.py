@@ -141,6 +141,9 @@ SIGNATURES = {
     "sc_pack_weights_sp": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sc_sp_stat_rows": (_i, [_i, _i, _i]),
     "sc_conv3x3_sp": (_i, [C.POINTER(sc_conv_args), _vp]),
+    "sc_packed_weight_floats_spd": (_sz, [_i, _i]),
+    "sc_pack_weights_spd": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "sc_conv3x3_sp_dgrad": (_i, [C.POINTER(sc_conv_args), _vp]),
     "sc_binary_opening": (_i, [_vp, _f, _i, _vp, _vp, _i, _i, _i, _vp]),
     "sc_threshold_confusion": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "sc_gather_augment": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -170,6 +173,7 @@ SIGNATURES = {
     "sc_tiff_lzw_decode": (_i, [_vp, _sz, _vp, _sz, C.POINTER(C.c_size_t)]),
     "sc_tiff_unpredict": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp]),
 }
+PACK_SPD = 8           # ... and of its data gradient sc_conv3x3_sp_dgrad
 PACK_SP = 7            # sc_pack_desc.bx3 code of the phase-filter layout of sc_conv3x3_sp
 PACK_PW3 = 6           # sc_pack_desc.bx3 code of the pointwise layout of sc_conv1x1_pw3
 PACK_THIN16 = 5        # sc_pack_desc.bx3 code of the register layout of sc_conv3x3_thin16

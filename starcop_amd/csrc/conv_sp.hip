@@ -40,6 +40,9 @@ typedef __attribute__((ext_vector_type(8))) _Float16 halfx8;
 typedef __attribute__((ext_vector_type(2))) _Float16 halfx2;
 
 constexpr float SP_SX = 2.f, SP_HMAX = 65504.f;
+#ifndef SP_INTERLEAVE
+#define SP_INTERLEAVE 4
+#endif
 
 __device__ __forceinline__ void sp_split2h(float a, float b, unsigned& t0, unsigned& t1) {
   const floatx2 v = {a, b};
@@ -165,33 +168,37 @@ __global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
       cs0[j] = c.x * hsx; cs1[j] = c.y * hsx;
     }
   };
-  // prologue + split of the requested chunk -> patch buffer `buf`, its filters -> filter buffer `buf`
-  auto stage = [&](int buf) __attribute__((always_inline)) {
+  // prologue + split of round r of the requested chunk -> patch buffer `buf`; its filters -> filter buffer `buf`
+  auto stage_round = [&](int buf, int r) __attribute__((always_inline)) {
     uint2* const sp2 = reinterpret_cast<uint2*>(s_p + (size_t)buf * NT * 2 * NPX);
+    uint2 t0, t1;
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      uint2 t0, t1;
+    for (int jp = 0; jp < 2; ++jp) {
+      float v[2];
 #pragma unroll
-      for (int jp = 0; jp < 2; ++jp) {
-        float v[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int j = 2 * jp + h;
-          const float t = __builtin_amdgcn_fmed3f(fmaf(xv[r][j], cs0[j], cs1[j]), slo, shi);
-          v[h] = (pyx[r] != 0xFFFFFFFFu && j < nch) ? t : 0.f;
-        }
-        unsigned a0, a1;
-        sp_split2h(v[0], v[1], a0, a1);
-        if (jp == 0) { t0.x = a0; t1.x = a1; } else { t0.y = a0; t1.y = a1; }
+      for (int h = 0; h < 2; ++h) {
+        const int j = 2 * jp + h;
+        const float t = __builtin_amdgcn_fmed3f(fmaf(xv[r][j], cs0[j], cs1[j]), slo, shi);
+        v[h] = (pyx[r] != 0xFFFFFFFFu && j < nch) ? t : 0.f;
       }
-      const int e = sidx + 128 * r;
-      if (e < NPX) {
-        sp2[((0 * 2 + hw) * NPX + e) * 2 + sub] = t0;
-        sp2[((1 * 2 + hw) * NPX + e) * 2 + sub] = t1;
-      }
+      unsigned a0, a1;
+      sp_split2h(v[0], v[1], a0, a1);
+      if (jp == 0) { t0.x = a0; t1.x = a1; } else { t0.y = a0; t1.y = a1; }
     }
+    const int e = sidx + 128 * r;
+    if (e < NPX) {
+      sp2[((0 * 2 + hw) * NPX + e) * 2 + sub] = t0;
+      sp2[((1 * 2 + hw) * NPX + e) * 2 + sub] = t1;
+    }
+  };
+  auto stage_w = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < NWV; ++j) s_w[buf * WST + tid + 512 * j] = wv[j];
+  };
+  auto stage = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) stage_round(buf, r);
+    stage_w(buf);
   };
 
   // lane -> patch entry of its pixel in group pp (centre tap)
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
   // instead of four (34 instead of 40 LDS reads per chunk and wave).
   // (Parity chunks run all 16 slots although 7 of them have zero filters: compile-time slot masks per parity -- 7 variants of this
   // body -- pushed the kernel from 239 registers to 256 + scratch reloads inside the loop for < 0.5 % of the step: not kept.)
-  auto compute = [&](int buf) __attribute__((always_inline)) {
+  auto compute = [&](int buf, int knext) __attribute__((always_inline)) {
     const uintx4* const sw = s_w + buf * WST + wlane;
     const uintx4* const sp = s_p + (size_t)buf * NT * 2 * NPX + lhi * NPX;
     halfx8 A0[2][2][NT], A1[2][2][NT], B0[3][NT], B1[3][NT];
@@ -241,43 +248,52 @@ __global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
     };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
+    // one step: 12 MFMAs with a slice of the NEXT chunk's staging (VALU / LDS stores / the refill's loads) issued in their shadows:
+    // the matrix pipe runs an MFMA for 32 cycles while the wave may issue ~5 independent instructions (MI355X_MICROARCH.md); as
+    // separate phases the two cost their sum (elimination builds, decoder.blocks.2.conv1 at batch 16: 116 us, without the MFMAs 72,
+    // without prologue / split / patch stores 86 -- tools/build_exp_sp.sh)
+    auto step = [&](const halfx8 (&A)[2][2][NT], const halfx8 (&B)[3][NT], auto ppc, auto hook) __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_barrier(0);
+      hook();
+      mfmas(A, B, ppc);
+#if SP_INTERLEAVE
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, SP_INTERLEAVE, 0);      // then a few VALU
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // and at most one LDS store
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    const int nb = buf ^ 1;
     load_A(A0, 0); load_B(B0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     load_B(B1, 0, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(A0, B0, P0{});
-    __builtin_amdgcn_sched_barrier(0);
+    step(A0, B0, P0{}, [&]() __attribute__((always_inline)) { stage_round(nb, 0); });
     if constexpr (TW == 32) {
       load_A(A1, 1); load_B(B0, 1, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(A0, B1, P1{});
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(A1, B1, P0{});            // (a = 1, group 0) reads the patch row of (a = 0, group 1)
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(A1, B0, P1{});
+      step(A0, B1, P1{}, [&]() __attribute__((always_inline)) { stage_round(nb, 1); });
+      step(A1, B1, P0{}, [&]() __attribute__((always_inline)) { stage_round(nb, 2); stage_w(nb); });      // (a = 1, group 0) reads the patch row of (a = 0, group 1)
+      step(A1, B0, P1{}, [&]() __attribute__((always_inline)) { request(knext); });
     } else {
       load_A(A1, 1); load_B(B0, 1, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(A0, B1, P1{});
-      __builtin_amdgcn_sched_barrier(0);
+      step(A0, B1, P1{}, [&]() __attribute__((always_inline)) { stage_round(nb, 1); });
       load_B(B1, 1, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(A1, B0, P0{});
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(A1, B1, P1{});
+      step(A1, B0, P0{}, [&]() __attribute__((always_inline)) { stage_round(nb, 2); stage_w(nb); });
+      step(A1, B1, P1{}, [&]() __attribute__((always_inline)) { request(knext); });
     }
   };
 
   // ---- pipeline ----
+  // chunk kc: its MFMAs from buffers kc & 1, with chunk kc+1 (requested one chunk ago) converted / stored into the other buffers and
+  // chunk kc+2 requested into the same registers, all inside the MFMA steps (the last chunk restages / re-requests itself: unused)
   request(0);
   stage(0);
   request(nkt > 1 ? 1 : 0);
   __syncthreads();
   for (int kc = 0; kc < nkt; ++kc) {
-    if (kc + 1 < nkt) stage((kc + 1) & 1);                 // (chunk kc+1: requested one chunk ago; no loads inside the branch)
-    request(kc + 2 < nkt ? kc + 2 : nkt - 1);              // refill: a whole chunk of flight, same registers
-    __builtin_amdgcn_sched_barrier(0);
-    compute(kc & 1);
+    compute(kc & 1, kc + 2 < nkt ? kc + 2 : nkt - 1);
     __syncthreads();
   }
 
@@ -328,6 +344,276 @@ __global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Data gradient of the same layer w.r.t. the LOW-resolution source (the up-sampled channels): the four parity planes of dy are
+// the K chunks, every one with 2 x 2 taps (conv_sp_pack.h); the work-group skeleton, LDS layout and pipeline are the forward
+// kernel's with   phase row py -> wave half h = cin block pair,  px -> cin block mx,  and the source offset of tap (a, b) taken from
+// the chunk's parity: (1 - a - qy, 1 - b - qx).  Tile = 8 groups of 32 low-resolution pixels x 128 input channels; the source is the
+// BatchNorm / activation-backward operand (g, y -> A g' + B y + D) with the gradient range scale of conv_bx3.hip (absmax).
+struct ConvSPD {
+  SrcD dy;                 // SC_SRC_BNBWD source [N][Co][2 Hl][2 Wl]
+  const uintx4* wpk;       // spd pack
+  int N, Hl, Wl, Cup;      // output [N][Cup][Hl][Wl]
+  float* out;
+  int accum;
+  const float* absmax;
+};
+
+__device__ __forceinline__ float spd_grad_scale(const float* absmax) {      // (h_grad_scale of conv_bx3.hip)
+  const float M = absmax ? *absmax : 0.f;
+  if (!(M > 0.f) || !(M < 3.0e38f)) return 1.f;
+  int e;
+  (void)frexpf(M, &e);
+  e = 5 - e;
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  return ldexpf(1.f, e);
+}
+
+template <int TW>
+__global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
+  constexpr int NT = 2;
+  constexpr int TH = 256 / TW;
+  constexpr int PC = TW + 2, NPX = sp_npx<TW>();
+  constexpr int NR = 3;
+  constexpr int WST = SP_WST;
+  constexpr int NWV = WST / 512;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uintx4* const s_w = reinterpret_cast<uintx4*>(smem);                                   // [2][WST]
+  uintx4* const s_p = reinterpret_cast<uintx4*>(smem + SP_SMEM_W);                        // [2 buf][NT][2 halves][NPX]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int hh = wave >> 2, wq = wave & 3;
+  const int Hl = p.Hl, Wl = p.Wl;
+  const int tiles_x = (Wl + TW - 1) / TW, tiles_y = (Hl + TH - 1) / TH;
+  const int ncot = (p.Cup + 127) >> 7;
+  int n, cot, tile;
+  {
+    const int per_img = tiles_x * tiles_y;
+    const int total = per_img * p.N, per_xcd = (total + 7) >> 3;
+    const int slot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int j = slot / ncot;
+    const int pt = xcd * per_xcd + j;
+    if (j >= per_xcd || pt >= total) return;
+    cot = slot - j * ncot;
+    n = pt / per_img; tile = pt - n * per_img;
+  }
+  n = __builtin_amdgcn_readfirstlane(n); cot = __builtin_amdgcn_readfirstlane(cot); tile = __builtin_amdgcn_readfirstlane(tile);
+  const int ty = __builtin_amdgcn_readfirstlane(tile / tiles_x), tx = tile - ty * tiles_x;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int Co = p.dy.C;
+  const int nkt = 4 * ((Co + 15) >> 4);
+  const uintx4* wbase = p.wpk + (size_t)cot * nkt * WST;
+
+  const float hsx = spd_grad_scale(p.absmax);
+  const float hinv = 1.f / (hsx * SP_SW);
+
+  floatx16 acc[2][2];      // [group pp][cin block mx]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i >> 1][i & 1][r] = 0.f;
+
+  const int q4 = __builtin_amdgcn_readfirstlane(tid >> 7);
+  const int hw = q4 >> 1, sub = q4 & 1;
+  const int sidx = tid & 127;
+  unsigned pyx[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int e = sidx + 128 * r;
+    const int pr = e / PC, pc = e - pr * PC;
+    const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+    const bool ok = (e < NPX) && (y >= 0) && (y < Hl) && (x >= 0) && (x < Wl);
+    pyx[r] = ok ? ((unsigned)y << 16) | (unsigned)x : 0xFFFFFFFFu;
+  }
+  float xv[NR][4], av[NR][4];
+  uintx4 wv[NWV];
+  float cs0[4], cs1[4], cs2[4], cs3[4], cs4[4];
+  const float slo = sc_act_lo(p.dy.act), shi = sc_act_hi(p.dy.act);
+  int nch = 0;
+  const size_t plane = (size_t)4 * Hl * Wl;
+
+  auto request = [&](int kc) __attribute__((always_inline)) {
+    const uintx4* wsrc = wbase + (size_t)kc * WST;
+#pragma unroll
+    for (int j = 0; j < NWV; ++j) wv[j] = wsrc[tid + 512 * j];
+    const int cbase = (kc >> 2) * 16 + hw * 8 + sub * 4;
+    const unsigned qoff = (unsigned)(((kc >> 1) & 1) * 2 * Wl + (kc & 1));
+    nch = Co - cbase;
+    const int cb0 = nch > 0 ? cbase : 0;
+    const size_t o0 = ((size_t)n * Co + cb0) * plane;
+    const float* xb = p.dy.x + o0;
+    const float* ab = p.dy.aux + o0;
+    const int jmax = nch > 0 ? nch - 1 : 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const bool ok = pyx[r] != 0xFFFFFFFFu;
+      const unsigned y = pyx[r] >> 16, x = pyx[r] & 0xFFFFu;
+      const unsigned o = !ok ? 0u : (4u * y * (unsigned)Wl + 2u * x + qoff);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const size_t cj = (size_t)(j < jmax ? j : jmax) * plane;
+        xv[r][j] = xb[cj + o];
+        av[r][j] = ab[cj + o];
+      }
+    }
+    const float* cb = p.dy.cst + (size_t)cb0 * SC_CST;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float* cj = cb + (size_t)(j < jmax ? j : jmax) * SC_CST;
+      const float4 c = *reinterpret_cast<const float4*>(cj);
+      cs0[j] = c.x; cs1[j] = c.y; cs2[j] = c.z; cs3[j] = c.w; cs4[j] = cj[4];
+    }
+  };
+  auto stage_round = [&](int buf, int r) __attribute__((always_inline)) {
+    uint2* const sp2 = reinterpret_cast<uint2*>(s_p + (size_t)buf * NT * 2 * NPX);
+    uint2 t0, t1;
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      float v[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = 2 * jp + h;
+        const float t = sc_pro_bnbwd(xv[r][j], av[r][j], cs0[j], cs1[j], cs2[j], cs3[j], cs4[j], slo, shi) * hsx;
+        v[h] = (pyx[r] != 0xFFFFFFFFu && j < nch) ? __builtin_amdgcn_fmed3f(t, -SP_HMAX, SP_HMAX) : 0.f;
+      }
+      unsigned a0, a1;
+      sp_split2h(v[0], v[1], a0, a1);
+      if (jp == 0) { t0.x = a0; t1.x = a1; } else { t0.y = a0; t1.y = a1; }
+    }
+    const int e = sidx + 128 * r;
+    if (e < NPX) {
+      sp2[((0 * 2 + hw) * NPX + e) * 2 + sub] = t0;
+      sp2[((1 * 2 + hw) * NPX + e) * 2 + sub] = t1;
+    }
+  };
+  auto stage_w = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NWV; ++j) s_w[buf * WST + tid + 512 * j] = wv[j];
+  };
+
+  int eb[2];
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {
+    const int g = 2 * wq + pp;
+    const int rowt = TW == 32 ? g : 2 * g + (l31 >> 4), colt = TW == 32 ? l31 : (l31 & 15);
+    eb[pp] = (rowt + 1) * PC + colt;           // + (1 - a - qy) * PC + o,  o = 2 - b - qx
+  }
+  const int wlane = hh * (NT * 2 * 2 * 2 * 2 * 32) + lhi * 32 + l31;
+
+  // chunk kc (parity qy = (kc >> 1) & 1, qx = QX at compile time: it selects the operand registers), 48 MFMAs per wave
+  auto compute = [&](int buf, int kc, int knext, auto qxc) __attribute__((always_inline)) {
+    constexpr int QX = decltype(qxc)::value;
+    const uintx4* const sw = s_w + buf * WST + wlane;
+    const uintx4* const sp = s_p + (size_t)buf * NT * 2 * NPX + lhi * NPX + (1 - ((kc >> 1) & 1)) * PC;
+    halfx8 A0[2][2][NT], A1[2][2][NT], B0[3][NT], B1[3][NT];
+    auto load_A = [&](halfx8 (&A)[2][2][NT], int a) {
+#pragma unroll
+      for (int mx = 0; mx < 2; ++mx)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int c = 0; c < NT; ++c) A[mx][b][c] = __builtin_bit_cast(halfx8, sw[((((c * 2 + mx) * 2 + a) * 2 + b) * 2) * 32]);
+    };
+    auto load_B = [&](halfx8 (&B)[3][NT], int a, int pp) {
+#pragma unroll
+      for (int o = 1 - QX; o < 3 - QX; ++o)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) B[o][c] = __builtin_bit_cast(halfx8, sp[c * 2 * NPX + eb[pp] - a * PC + o]);
+    };
+    auto mfmas = [&](const halfx8 (&A)[2][2][NT], const halfx8 (&B)[3][NT], auto ppc) {
+      constexpr int pp = decltype(ppc)::value;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int mx = 0; mx < 2; ++mx) {
+            const int o = 2 - b - QX;
+            acc[pp][mx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[mx][b][t == 1 ? 1 : 0], B[o][t == 0 ? 1 : 0], acc[pp][mx], 0, 0, 0);
+          }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    auto step = [&](const halfx8 (&A)[2][2][NT], const halfx8 (&B)[3][NT], auto ppc, auto hook) __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_barrier(0);
+      hook();
+      mfmas(A, B, ppc);
+#if SP_INTERLEAVE
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, SP_INTERLEAVE + 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    const int nb = buf ^ 1;
+    // rows: (a, pp) reads patch row g_pp + 2 - a - qy; with TW = 32 (g_1 = g_0 + 1) steps (a = 0, group 0) and (a = 1, group 1) share theirs
+    load_A(A1, 1); load_B(B0, 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_A(A0, 0); load_B(B1, 0, 0);
+    step(A1, B0, P0{}, [&]() __attribute__((always_inline)) { stage_round(nb, 0); });
+    if constexpr (TW == 32) {
+      load_B(B0, 0, 1);
+      step(A0, B1, P0{}, [&]() __attribute__((always_inline)) { stage_round(nb, 1); });
+      step(A1, B1, P1{}, [&]() __attribute__((always_inline)) { stage_round(nb, 2); stage_w(nb); });
+      step(A0, B0, P1{}, [&]() __attribute__((always_inline)) { request(knext); });
+    } else {
+      load_B(B0, 1, 1);
+      step(A0, B1, P0{}, [&]() __attribute__((always_inline)) { stage_round(nb, 1); });
+      load_B(B1, 0, 1);
+      step(A1, B0, P1{}, [&]() __attribute__((always_inline)) { stage_round(nb, 2); stage_w(nb); });
+      step(A0, B1, P1{}, [&]() __attribute__((always_inline)) { request(knext); });
+    }
+  };
+
+  request(0);
+#pragma unroll
+  for (int r = 0; r < NR; ++r) stage_round(0, r);
+  stage_w(0);
+  request(1);
+  __syncthreads();
+  for (int kc = 0; kc < nkt; kc += 2) {          // (nkt is a multiple of 4; the last chunk restages / re-requests itself: unused)
+    compute(0, kc, kc + 2 < nkt ? kc + 2 : nkt - 1, std::integral_constant<int, 0>{});
+    __syncthreads();
+    compute(1, kc + 1, kc + 3 < nkt ? kc + 3 : nkt - 1, std::integral_constant<int, 1>{});
+    __syncthreads();
+  }
+
+  // ---- epilogue: low-resolution stores (the 2x2 sum over the up-sampled copies is in the phase filters)
+  const unsigned pl32 = (unsigned)((size_t)Hl * Wl);
+  const int cb = cot * 128 + hh * 64;
+  float* const ob = p.out + ((size_t)n * p.Cup + cb) * (size_t)pl32;
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {
+    const int g = 2 * wq + pp;
+    const int i = y0 + (TW == 32 ? g : 2 * g + (l31 >> 4)), j = x0 + (TW == 32 ? l31 : (l31 & 15));
+    const bool okp = i < Hl && j < Wl;
+    const unsigned loff = (unsigned)(4 * lhi) * pl32 + (unsigned)(okp ? i * Wl + j : 0);
+#pragma unroll
+    for (int mx = 0; mx < 2; ++mx)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cu = mx * 32 + (r & 3) + 8 * (r >> 2);
+        if (okp && cb + cu + 4 * lhi < p.Cup) {
+          const unsigned off = loff + (unsigned)cu * pl32;
+          float v = acc[pp][mx][r] * hinv;
+          if (p.accum) v += ob[off];
+          ob[off] = v;
+        }
+      }
+  }
+}
+
+__global__ void k_pack_weights_spd(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout, int CinTot, int Cup, size_t total) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < total) spd_pack_item(w, wpk, i, Cout, CinTot, Cup);
 }
 
 __global__ void k_pack_weights_sp(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout, int Cup, int Csk, size_t total) {
@@ -397,5 +683,52 @@ extern "C" int sc_conv3x3_sp(const sc_conv_args* a, sc_stream stream) {
   if (TW == 32) hipLaunchKernelGGL((k_conv3_sp<32>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<32>(), (hipStream_t)stream, p);
   else hipLaunchKernelGGL((k_conv3_sp<16>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<16>(), (hipStream_t)stream, p);
   SC_LAUNCH_OK("sc_conv3x3_sp");
+  return SC_OK;
+}
+
+extern "C" size_t sc_packed_weight_floats_spd(int Cout, int Cup) {
+  return (size_t)((Cup + 127) / 128) * 4 * ((Cout + 15) / 16) * SP_WST * 4;
+}
+
+extern "C" int sc_pack_weights_spd(const float* w, float* wpk, int Cout, int CinTotal, int Cup, sc_stream stream) {
+  SC_REQUIRE(w && wpk && Cout > 0 && Cup > 0 && Cup <= CinTotal, "sc_pack_weights_spd: bad argument");
+  SC_REQUIRE(((uintptr_t)wpk & 15) == 0, "sc_pack_weights_spd: destination must be 16-byte aligned");
+  const size_t total = spd_pack_items(Cout, Cup);
+  hipLaunchKernelGGL(k_pack_weights_spd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     reinterpret_cast<unsigned short*>(wpk), Cout, CinTotal, Cup, total);
+  SC_LAUNCH_OK("sc_pack_weights_spd");
+  return SC_OK;
+}
+
+extern "C" int sc_conv3x3_sp_dgrad(const sc_conv_args* a, sc_stream stream) {
+  SC_REQUIRE(a != nullptr, "sc_conv3x3_sp_dgrad: null args");
+  SC_REQUIRE(a->ks == 3 && a->nsrc == 1, "sc_conv3x3_sp_dgrad: ks = 3, one source (the layer's output gradient)");
+  SC_REQUIRE(a->src[0].mode == SC_SRC_BNBWD && a->src[0].aux != nullptr && a->src[0].cst != nullptr && a->src[0].up == 0,
+             "sc_conv3x3_sp_dgrad: the source is the full-resolution SC_SRC_BNBWD operand (g, y, constants)");
+  SC_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->Cout > 0 && a->src[0].C > 0, "sc_conv3x3_sp_dgrad: bad shape");
+  SC_REQUIRE(a->H % 2 == 0 && a->W % 2 == 0, "sc_conv3x3_sp_dgrad: even gradient size");
+  SC_REQUIRE(a->terms == SC_TERMS_F16X2, "sc_conv3x3_sp_dgrad: two-fp16-term arithmetic only (terms = SC_TERMS_F16X2)");
+  SC_REQUIRE(a->csplit == a->Cout && a->out1 == nullptr && a->add0 == nullptr && a->add1 == nullptr && a->stats == nullptr,
+             "sc_conv3x3_sp_dgrad: a single half-resolution output [N, Cout, H/2, W/2] (accum0 allowed)");
+  SC_REQUIRE(((uintptr_t)a->wpk & 15) == 0, "sc_conv3x3_sp_dgrad: alignment");
+  SC_REQUIRE((size_t)128 * (a->H / 2) * (a->W / 2) < (1ull << 32) && (size_t)a->H * a->W < (1ull << 31), "sc_conv3x3_sp_dgrad: plane too large");
+  ConvSPD p;
+  p.dy = to_srcd(a->src[0]);
+  p.wpk = reinterpret_cast<const uintx4*>(a->wpk);
+  p.N = a->N; p.Hl = a->H / 2; p.Wl = a->W / 2; p.Cup = a->Cout;
+  p.out = a->out0; p.accum = a->accum0; p.absmax = a->absmax;
+  const int TW = p.Wl >= 32 ? 32 : 16, TH = 256 / TW;
+  const long tiles = (long)((p.Wl + TW - 1) / TW) * ((p.Hl + TH - 1) / TH) * a->N;
+  const long ncot = (a->Cout + 127) / 128;
+  const long grid = (tiles + 7) / 8 * 8 * ncot;
+  SC_REQUIRE(grid < (1L << 31), "sc_conv3x3_sp_dgrad: grid too large");
+  static const bool attr_ok = [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<32>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<32>()) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<16>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess;
+  }();
+  SC_REQUIRE(attr_ok, "sc_conv3x3_sp_dgrad: cannot reserve %d bytes of LDS", sp_smem_bytes<32>());
+  if (TW == 32) hipLaunchKernelGGL((k_conv3_spd<32>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<32>(), (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((k_conv3_spd<16>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<16>(), (hipStream_t)stream, p);
+  SC_LAUNCH_OK("sc_conv3x3_sp_dgrad");
   return SC_OK;
 }

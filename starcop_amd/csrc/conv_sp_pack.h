@@ -60,3 +60,42 @@ __device__ __forceinline__ void sp_pack_item(const float* __restrict__ w, unsign
   out[e0 * 8 + j] = __builtin_bit_cast(unsigned short, h0);
   out[e1 * 8 + j] = __builtin_bit_cast(unsigned short, h1);
 }
+
+// ---- data gradient w.r.t. the LOW-resolution (up-sampled) source: dprev[ci][i][j] = sum over the four parity planes (qy,qx) of dy
+// (dy[co][2i'+qy][2j'+qx]) and taps (a,b) of  Wph[qy][qx][a][b][co][ci] * dyP[qy][qx][co][i - (a-1+qy)][j - (b-1+qx)]  (a stride-2 4x4
+// convolution of dy; no full-resolution gradient, no 2x2 down-sum).  Layout: [cin tile of 128][chunk = 4*(16-cout chunk) + 2*qy + qx]
+// stages of SP_WST entries, entry = (((((h*2 + term)*2 + mx)*2 + a)*2 + b)*2 + cout half)*32 + ci  (cin block = 2h + mx of the tile)
+static inline size_t spd_pack_items(int Cout, int Cup) {
+  return (size_t)((Cup + 127) / 128) * 4 * ((Cout + 15) / 16) * (SP_WST / 2) * 8;
+}
+__device__ __forceinline__ void spd_pack_item(const float* __restrict__ w, unsigned short* __restrict__ out, size_t i, int Cout, int CinTot, int Cup) {
+  const int nkt = 4 * ((Cout + 15) / 16);
+  size_t r = i;
+  const int j = (int)(r % 8); r /= 8;
+  const int col = (int)(r % 32); r /= 32;
+  const int half = (int)(r % 2); r /= 2;
+  const int b = (int)(r % 2); r /= 2;
+  const int a = (int)(r % 2); r /= 2;
+  const int mx = (int)(r % 2); r /= 2;
+  const int h = (int)(r % 2); r /= 2;
+  const int chunk = (int)(r % nkt);
+  const int mt = (int)(r / nkt);
+  const int q = chunk & 3, py = q >> 1, px = q & 1;
+  const int co = (chunk >> 2) * 16 + half * 8 + j, ci = mt * 128 + (2 * h + mx) * 32 + col;
+  float v = 0.f;
+  if (co < Cout && ci < Cup) {
+    const float* wp = w + ((size_t)co * CinTot + ci) * 9;
+    const int kh0 = (py == 0) ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), kh1 = (py == 0) ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
+    const int kw0 = (px == 0) ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), kw1 = (px == 0) ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+    for (int kh = kh0; kh <= kh1; ++kh)
+      for (int kw = kw0; kw <= kw1; ++kw) v += wp[kh * 3 + kw];
+  }
+  const float vs = __builtin_amdgcn_fmed3f(v * SP_SW, -65504.f, 65504.f);
+  const _Float16 h0 = (_Float16)vs;
+  const _Float16 h1 = (_Float16)(vs - (float)h0);
+  const size_t base = ((size_t)mt * nkt + chunk) * SP_WST;
+  const size_t e0 = base + (((((size_t)(h * 2 + 0) * 2 + mx) * 2 + a) * 2 + b) * 2 + half) * 32 + col;
+  const size_t e1 = base + (((((size_t)(h * 2 + 1) * 2 + mx) * 2 + a) * 2 + b) * 2 + half) * 32 + col;
+  out[e0 * 8 + j] = __builtin_bit_cast(unsigned short, h0);
+  out[e1 * 8 + j] = __builtin_bit_cast(unsigned short, h1);
+}

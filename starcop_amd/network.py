@@ -26,7 +26,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, sc_irt_args, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD, sc_wgrad_pending,
-                   PACK_PW3, PACK_SP, PACK_THIN16, STAT_PW3, STAT_CONV1, STAT_CONV1K, STAT_CONV3, STAT_DW, STAT_STEM, TERMS_F16X2, check, make_src, ptr,
+                   PACK_PW3, PACK_SP, PACK_SPD, PACK_THIN16, STAT_PW3, STAT_CONV1, STAT_CONV1K, STAT_CONV3, STAT_DW, STAT_STEM, TERMS_F16X2, check, make_src, ptr,
                    sc_conv_args, sc_wgrad_args, stream)
 
 MBV2_SETTINGS = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2),
@@ -172,10 +172,10 @@ def _use_irt(N, Cin, Hd, Hin, Win, stride):
 # Decoder conv1 = conv3x3(cat([nearest_up2(prev), skip])) as a SUB-PIXEL convolution (conv_sp.hip: four phase-specific 2x2
 # convolutions on the low-resolution prev, the skip channels as low-resolution parity planes: 2.25x fewer MFMAs for the up-sampled
 # channels, every low-resolution value staged once instead of once per high-resolution copy).  Measured against sc_conv3x3_bx3 with
-# an up-sampled source (tools/bench_sp.py, us per launch, batch 16 / 64): decoder.blocks.1 125 -> 88 / 465 -> 333, blocks.2 146 ->
-# 118 / 544 -> 461, blocks.3 171 -> 131 / 689 -> 542; blocks.0 (16 x 16 low-resolution planes: 128 work-groups of 8 waves at batch 16
-# for 256 CUs) 311 -> 330 at batch 16 but 1131 -> 778 at batch 64; blocks.4 (16 output channels: half-empty MFMA rows) level with
-# sc_conv3x3_thin16.  "1" = that rule, "all" = every decoder conv1 (tests), "0" = off.
+# an up-sampled source (tools/bench_sp.py, us per launch, batch 16): decoder.blocks.0 311 -> 288 (16 x 16 low-resolution planes: 128
+# work-groups of 8 waves for 256 CUs; 1131 -> 778 at batch 64), blocks.1 125 -> 79, blocks.2 147 -> 104, blocks.3 178 -> 122; blocks.4
+# (16 output channels: half-empty MFMA rows) 196-213, level with sc_conv3x3_thin16's 202, stays there.  "1" = that rule, "all" =
+# every decoder conv1 (tests), "0" = off.
 _SP = os.environ.get("STARCOP_SP", "1")
 
 
@@ -188,7 +188,16 @@ def _use_sp(N, Ho, Wo, Cout):
     Hl, Wl = Ho // 2, Wo // 2
     tw = 32 if Wl >= 32 else 16
     wgs = N * (-(-Wl // tw)) * (-(-Hl // (256 // tw))) * (-(-Cout // 32))
-    return Cout >= 32 and wgs >= 256
+    return Cout >= 32 and wgs >= 128
+
+
+def _use_spd(N, Ho, Wo, Cup):
+    """data gradient of a decoder conv1's up-sampled channels on sc_conv3x3_sp_dgrad?  (tools/bench_sp.py, us, batch 16, against
+    sc_conv3x3_bx3(down0) on the same channels: decoder.blocks.0 336 -> 250, blocks.1 140 -> 129, blocks.2 148 -> 83; blocks.3 / .4 have
+    64 / 32 such channels for the kernel's 128-channel tiles: 176 -> 190, 285 -> 500 -- they keep the 3x3 form)"""
+    if _SP == "0" or Ho % 2 or Wo % 2:
+        return False
+    return _SP == "all" or Cup >= 128
 
 
 def _use_ksplit(N, HW, K, M, ks=1):
@@ -664,6 +673,14 @@ class HyperStarcopUNet(nn.Module):
                     cu = op["ins"][0].C
                     ent["sp"] = torch.empty(lib.sc_packed_weight_floats_sp(co, cu, ci - cu), dtype=torch.float32, device=dev)
                     ent["sp_cu"] = cu
+                # ... and the data gradient of its up-sampled channels (the skip channels' gradient: a 3x3 launch on a 32-wide pack)
+                if op.get("up") and xb and tb_ == TERMS_F16X2 and _SP != "0" and op["ins"][0].C % 32 == 0:
+                    cu = op["ins"][0].C
+                    ent["spd"] = torch.empty(lib.sc_packed_weight_floats_spd(co, cu), dtype=torch.float32, device=dev)
+                    ent["sp_cu"] = cu
+                    if ci > cu and ent.get("bB") is None:
+                        ent["bB"] = torch.empty(lib.sc_packed_weight_floats_bx3(co, ci, 32, 1, tb_), dtype=torch.float32, device=dev)
+                        ent["bB_off"] = ent["bB"].numel() // (-(-ci // 32)) * (cu // 32)
                 self._wpk[i] = ent
                 self._pack_tables = {}
             if op["type"] == "pw":       # the split-bf16 layout of sc_conv1x1_pw3, where a plan runs this layer on it
@@ -700,6 +717,11 @@ class HyperStarcopUNet(nn.Module):
                         continue
                     total = lib.sc_pack_work_items(co, ci, ks, cot, 1, 1)
                     rows.append((conv.weight.data_ptr(), buf.data_ptr(), co, ci, ks, cot, 1, ent["terms_b"], total))
+                    starts.append(nblk)
+                    nblk += -(-total // 256)
+                if ent.get("spd") is not None and need_bwd:
+                    total = lib.sc_pack_work_items(co, ci, ks, ent["sp_cu"], 1, PACK_SPD)
+                    rows.append((conv.weight.data_ptr(), ent["spd"].data_ptr(), co, ci, ks, ent["sp_cu"], 1, PACK_SPD, total))
                     starts.append(nblk)
                     nblk += -(-total // 256)
                 if ent.get("sp") is not None:
@@ -1309,6 +1331,27 @@ class HyperStarcopUNet(nn.Module):
             tok = self._pb("k_conv3_thin_h (fwd+dgrad)" if thin_b else
                            self._bx3_family("dgrad") if ent["bx3_b"] else f"k_conv_mfma<{ks}> (fwd+dgrad)", flop,
                            4.0 * (2 * N * o.C * Ho * Wo + gin_elems + conv.weight.numel()))
+            if (op.get("up") and ent.get("spd") is not None and ent["terms_b"] == TERMS_F16X2 and self.split_bf16
+                    and _use_spd(N, Ho, Wo, ins[0].C)):
+                # sub-pixel form: the up-sampled channels' gradient at half resolution from the four parity planes of dy (2.25x fewer
+                # MFMAs, 128 output channels per staged patch), the skip channels' by the 3x3 kernel on their own 32-wide tiles
+                t_up = ins[0]
+                a.Cout = a.csplit = t_up.C
+                a.wpk = ent["spd"].data_ptr()
+                a.out0, a.out1 = plan.grad[t_up.name].data_ptr(), None
+                a.accum0, a.down0 = (1 if t_up.name in written else 0), 0
+                check(lib.sc_conv3x3_sp_dgrad(C.byref(a), st))
+                written.add(t_up.name)
+                if len(ins) == 2:
+                    t_sk = ins[1]
+                    a.Cout = a.csplit = t_sk.C
+                    a.wpk, a.co_t = ent["bB"].data_ptr() + 4 * ent["bB_off"], 32
+                    a.out0 = plan.grad[t_sk.name].data_ptr()
+                    a.accum0 = 1 if t_sk.name in written else 0
+                    check(lib.sc_conv3x3_bx3(C.byref(a), st))
+                    written.add(t_sk.name)
+                self._pe(tok)
+                continue
             if op.get("up"):
                 t_up = ins[0]
                 fused_down = conv_dgrad is lib.sc_conv3x3_bx3      # the split-bf16 kernel stores the 2x2 sums itself

@@ -204,3 +204,43 @@ def conv_sp(srcs, wpk, N, H, W, Cout, want_stats=False):
     a.stats = stats.data_ptr() if want_stats else None
     check(lib.sc_conv3x3_sp(C.byref(a), stream()))
     return out, stats
+
+
+def pack_spd(w, cup, batched=False):
+    """decoder conv1 filter (Cout, Cup + Cskip, 3, 3) -> the parity / tap layout of sc_conv3x3_sp_dgrad"""
+    import numpy as np
+    from starcop_amd._lib import PACK_SPD
+    lib = _lib.load()
+    co, ci = w.shape[0], w.shape[1]
+    out = torch.full((lib.sc_packed_weight_floats_spd(co, cup),), float("nan"), device=DEV)
+    if not batched:
+        check(lib.sc_pack_weights_spd(ptr(w), ptr(out), co, ci, cup, stream()))
+        return out
+    total = lib.sc_pack_work_items(co, ci, 3, cup, 1, PACK_SPD)
+    dt = np.dtype([("w", "<u8"), ("wpk", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"), ("ks", "<i4"), ("co_t", "<i4"),
+                   ("tflip", "<i4"), ("bx3", "<i4"), ("total", "<u8")])
+    descs = torch.from_numpy(np.array([(w.data_ptr(), out.data_ptr(), co, ci, 3, cup, 1, PACK_SPD, total)], dtype=dt).view(np.uint8).copy()).to(DEV)
+    starts = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _KEEP.extend([descs, starts])
+    check(lib.sc_pack_weights_batch(ptr(descs), ptr(starts), 1, -(-total // 256), stream()))
+    return out
+
+
+def conv_sp_dgrad(dy_src, wpk, N, H, W, Cup, absmax=None, accum_into=None):
+    """sc_conv3x3_sp_dgrad: dy_src = the BNBWD operand of the layer's output (H x W) -> gradient of the half-resolution source"""
+    from starcop_amd._lib import TERMS_F16X2
+    lib = _lib.load()
+    a = sc_conv_args()
+    a.nsrc = 1
+    a.src[0] = dy_src
+    a.wpk = wpk.data_ptr()
+    a.N, a.H, a.W, a.Cout, a.ks, a.co_t = N, H, W, Cup, 3, 32
+    out = accum_into if accum_into is not None else torch.full((N, Cup, H // 2, W // 2), float("nan"), device=DEV)
+    a.out0, a.out1, a.csplit = out.data_ptr(), None, Cup
+    a.accum0, a.accum1 = (1 if accum_into is not None else 0), 0
+    a.add0 = a.add1 = None
+    a.stats = None
+    a.terms, a.down0 = TERMS_F16X2, 0
+    a.absmax = absmax.data_ptr() if absmax is not None else None
+    check(lib.sc_conv3x3_sp_dgrad(C.byref(a), stream()))
+    return out

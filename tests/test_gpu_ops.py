@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from hip_ops import (dev, DEV, conv_mfma, conv_sp, cst_affine, pack, pack_bx3, pack_sp, relerr, wgrad_mfma)  # noqa: E402
+from hip_ops import (dev, DEV, conv_mfma, conv_sp, conv_sp_dgrad, cst_affine, pack, pack_bx3, pack_sp, pack_spd, relerr, wgrad_mfma)  # noqa: E402
 from starcop_amd import _lib  # noqa: E402
 from starcop_amd._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD, STAT_CONV1,
                               STAT_DW, STAT_STEM, check, make_src, ptr, stream)  # noqa: E402
@@ -427,6 +427,35 @@ def test_conv_bx3_dgrad_fused_upsample_backward(hip, split_mode, cin, cout, cs, 
     extra = [torch.empty(N, cin - cs, H, W, device=DEV)] if cs < cin else []
     conv_mfma([src], wpk, N, H, W, cin, 3, co_t, csplit=cs, bx3=True, down0=True, accum=(1, 0), outs=[o0] + extra)
     assert relerr(o0, ref_up + old.double()) < 1e-5
+
+
+@pytest.mark.parametrize("cup,csk,cout,H,W", [(64, 16, 32, 16, 64), (128, 24, 64, 24, 80), (32, 0, 16, 20, 72), (256, 32, 128, 8, 12),
+                                               (40, 9, 24, 36, 70), (200, 8, 48, 64, 64), (1280, 96, 40, 4, 6)])
+def test_conv_sp_dgrad_matches_upsample_backward(hip, cup, csk, cout, H, W):
+    """gradient of conv3x3(cat([nearest_up2(prev), skip])) w.r.t. prev -- autograd of the reference's op sequence in float64 (conv
+    transpose, then F.interpolate's backward = 2x2 sums) -- against sc_conv3x3_sp_dgrad: a stride-2 4x4 convolution of dy at half
+    resolution; BatchNorm / ReLU-backward operand with a range hint, plain operand, accumulation, both pack paths, both tile shapes"""
+    N = 2
+    g, yraw = rnd(N, cout, H, W, seed=1), rnd(N, cout, H, W, seed=2)
+    w = rnd(cout, cup + csk, 3, 3, seed=3, scale=0.2)
+    cst = torch.zeros(cout, SC_CST)
+    cst[:, 0], cst[:, 1] = rnd(cout, seed=4) * 0.3 + 1, rnd(cout, seed=5) * 0.2          # forward BatchNorm scale / shift
+    cst[:, 2], cst[:, 3], cst[:, 4] = rnd(cout, seed=6) * 0.5 + 1, rnd(cout, seed=7) * 0.1, rnd(cout, seed=8) * 0.05   # A, B, D
+    yh = yraw * cst[:, 0][None, :, None, None] + cst[:, 1][None, :, None, None]
+    dy = torch.where(yh > 0, g, torch.zeros_like(g)) * cst[:, 2][None, :, None, None] + yraw * cst[:, 3][None, :, None, None] + cst[:, 4][None, :, None, None]
+    ref = F.avg_pool2d(F.conv_transpose2d(dy.double(), w.double(), padding=1)[:, :cup], 2) * 4
+    amax = torch.tensor([float((cst[:, 2][None, :, None, None] * g).abs().max())], device=DEV)
+    src = make_src(dev(g), cout, SRC_BNBWD, act=ACT_RELU, cst=dev(cst), aux=dev(yraw))
+    wd = dev(w)
+    for batched in (False, True):
+        wpk = pack_spd(wd, cup, batched=batched)
+        assert bool(torch.isfinite(wpk.view(torch.int16).float()).all())
+        out = conv_sp_dgrad(src, wpk, N, H, W, cup, absmax=amax)
+        assert relerr(out, ref) < BX3_TOL
+    old = rnd(N, cup, H // 2, W // 2, seed=9)
+    o0 = dev(old).clone()
+    conv_sp_dgrad(src, wpk, N, H, W, cup, absmax=amax, accum_into=o0)
+    assert relerr(o0, ref + old.double()) < BX3_TOL
 
 
 @pytest.mark.parametrize("cin,cout,H,W,two", [(16, 64, 32, 32, False), (32, 16, 36, 70, True), (32, 32, 24, 40, False), (48, 40, 21, 32, False), (32, 64, 16, 32, True),

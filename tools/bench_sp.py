@@ -51,7 +51,7 @@ for name, cu, cs, cout, H in SHAPES:
     ref = [torch.empty(N, cout, H, W, device=DEV)]
     srcs = [s_up, s_sk] if cs else [s_up]
     _, st_ref = conv_mfma(srcs, wb, N, H, W, cout, 3, co_t, want_stats=True, outs=ref, bx3=True, terms=TERMS_F16X2)
-    t_ref = timeit(lambda: conv_mfma(srcs, wb, N, H, W, cout, 3, co_t, want_stats=True, outs=ref, bx3=True, terms=TERMS_F16X2))
+    t_ref = 0.0 if os.environ.get("SP_ONLY") else timeit(lambda: conv_mfma(srcs, wb, N, H, W, cout, 3, co_t, want_stats=True, outs=ref, bx3=True, terms=TERMS_F16X2))
     # sub-pixel: one launch, the skip channels as parity planes
     wsp = torch.empty(lib.sc_packed_weight_floats_sp(cout, cu, cs), device=DEV)
     check(lib.sc_pack_weights_sp(ptr(w), ptr(wsp), cout, cu, cs, stream()))
@@ -65,7 +65,38 @@ for name, cu, cs, cout, H in SHAPES:
     s0, s1 = stats.double().sum(0), st_ref.double().sum(0)
     serr = float(((s0 - s1).abs() / s1.abs().clamp_min(1e-3)).max())
     t_sp = timeit(run)
-    t_up = timeit(lambda: sp_conv(srcs[:1], wsp_up, N, H, W, cout, out, stats)) if cs and (wsp_up := torch.empty(lib.sc_packed_weight_floats_sp(cout, cu, 0), device=DEV)) is not None else t_sp
+    t_up = t_sp
+    if cs and not os.environ.get("SP_ONLY"):
+        wsp_up = torch.zeros(lib.sc_packed_weight_floats_sp(cout, cu, 0), device=DEV)
+        t_up = timeit(lambda: sp_conv(srcs[:1], wsp_up, N, H, W, cout, out, stats))
+    if os.environ.get("SP_ONLY"):
+        print(f"{name}: sub-pixel {t_sp:7.1f} us", flush=True)
+        continue
     flop = 2.0 * N * H * W * (cu + cs) * cout * 9
     print(f"{name} {cu}+{cs}->{cout} {H}^2: 3x3 {t_ref:7.1f} us ({flop/t_ref/1e6:6.1f} TF) | sub-pixel {t_sp:7.1f} us ({flop/t_sp/1e6:6.1f} TF alg.; up channels alone {t_up:7.1f}) "
           f"x{t_ref/t_sp:4.2f} | out diff {err:.1e} stats diff {serr:.1e}", flush=True)
+
+# ---- data gradient w.r.t. the up-sampled source: sub-pixel (sc_conv3x3_sp_dgrad) against sc_conv3x3_bx3(down0) on those channels
+if not os.environ.get("SP_ONLY"):
+    from hip_ops import conv_sp_dgrad, pack_spd
+    from starcop_amd._lib import SRC_BNBWD
+    print("--- data gradient of the up-sampled channels ---")
+    for name, cu, cs, cout, H in SHAPES:
+        W = H
+        g, yr = torch.randn(N, cout, H, W, device=DEV), torch.randn(N, cout, H, W, device=DEV)
+        w = torch.randn(cout, cu + cs, 3, 3, device=DEV) * 0.05
+        cst = torch.rand(cout, SC_CST, device=DEV)
+        amax = (cst[:, 2][None, :, None, None] * g).abs().max().reshape(1)
+        src = make_src(g, cout, SRC_BNBWD, act=ACT_RELU, cst=cst, aux=yr)
+        co_t = 64 if cu % 64 == 0 else 32
+        wu = pack_bx3(w[:, :cu].contiguous(), co_t, 1, TERMS_F16X2)
+        ref = [torch.empty(N, cu, H // 2, W // 2, device=DEV)]
+        f3 = lambda: conv_mfma([src], wu, N, H, W, cu, 3, co_t, outs=ref, bx3=True, terms=TERMS_F16X2, down0=True, absmax=amax)
+        t_ref = timeit(f3)
+        wsd = pack_spd(w, cu)
+        out = torch.zeros(N, cu, H // 2, W // 2, device=DEV)
+        fs = lambda: conv_sp_dgrad(src, wsd, N, H, W, cu, absmax=amax, accum_into=None)
+        o = fs(); torch.cuda.synchronize()
+        err = float((o - ref[0]).abs().max() / ref[0].abs().max())
+        t_sp = timeit(fs)
+        print(f"{name}.dgrad {cout}->{cu} {H}^2: 3x3 + down-sum {t_ref:7.1f} us | sub-pixel {t_sp:7.1f} us x{t_ref/t_sp:4.2f} | diff {err:.1e}", flush=True)
