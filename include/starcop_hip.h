@@ -124,6 +124,10 @@ typedef struct sc_conv_args {
                           * smp's DecoderBlock fused into the data-gradient store (no full-resolution temporary) */
   const float* absmax;   /* terms == SC_TERMS_F16X2 with a BNBWD source: device float >= the tensor's max |A_c g| (written by
                           * sc_bn_bwd_reduce / sc_bn_bwd_small); NULL: the gradient operand is taken to be O(1)              */
+  const float* xbound[2];/* terms == SC_TERMS_F16X2, forward sources: per source a device float >= max |activation| of that source
+                          * (sc_bn_finalize(act_bound) in training, sc_add_srcs_absmax records) or NULL (ReLU6-bounded / unknown): the
+                          * kernels scale the fp16 operand by 2 when 2 M <= 32752 and by the largest power of two with s M <= 32752
+                          * otherwise, so a BatchNorm'd activation can never reach the +-65504 clamp                         */
 } sc_conv_args;
 int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream);
 /* 1x1 convolution for few-pixel / long-K layers (the <= 64^2 inverted-residual projections and the data gradients of the
@@ -163,6 +167,7 @@ typedef struct sc_wgrad_args {
   float* dw;
   int32_t terms;         /* sc_conv3x3_wgrad_bx3 only: 0 or 3 = fp32-accurate split, 2 = two terms, 1 = plain bf16 operands */
   const float* absmax;   /* terms == SC_TERMS_F16X2: scale hint of dy, as in sc_conv_args                                     */
+  const float* xbound[2];/* terms == SC_TERMS_F16X2: activation bounds of the input sources, as in sc_conv_args               */
 } sc_wgrad_args;
 size_t sc_wgrad_workspace_floats(int N, int H, int W, int Cout, int Cin, int ks);
 int sc_conv2d_wgrad_mfma(const sc_wgrad_args* a, sc_stream stream);
@@ -343,9 +348,12 @@ int sc_stat_rows(int kind, int N, int H, int W);
 /* scratch (optional, SC_BN_FINALIZE_SCRATCH_DOUBLES(C) doubles): with >= 4096 rows the rows of all channels are first summed as
  * one coalesced stream into 64 fp64 partial rows there (the per-channel walk reads a 64-byte sector per 8 useful bytes) */
 #define SC_BN_FINALIZE_SCRATCH_DOUBLES(C) (64 * 2 * (size_t)(C))
+/* act_bound (optional, training=1): device float raised (order-independent atomic max; never lowered) to
+ * max_c |gamma_c| sqrt(count - 1) + |beta_c| -- no normalised sample of `count` can exceed sqrt(count - 1), so this bounds every
+ * |BatchNorm output| of the tensor BY CONSTRUCTION; the SC_TERMS_F16X2 kernels derive their activation scale from it (xbound). */
 int sc_bn_finalize(const float* stats, int nrows, double count, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps,
-                   int training, float* cst_fwd, int C, double* scratch, sc_stream stream);
+                   int training, float* cst_fwd, int C, double* scratch, float* act_bound, sc_stream stream);
 /* sums[row][C][2] = { sum g_bn, sum g_bn * xhat } over the row's pixels, g_bn = g * act'(BN(y));
  * rows = sc_stat_rows(SC_STAT_BNBWD, N, H, W).
  * absmax (optional, device float, zeroed by the caller before the first launch of a step): raised to

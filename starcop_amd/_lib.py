@@ -37,7 +37,7 @@ class sc_conv_args(C.Structure):
                 ("out0", C.c_void_p), ("out1", C.c_void_p),
                 ("csplit", C.c_int32), ("accum0", C.c_int32), ("accum1", C.c_int32),
                 ("add0", C.c_void_p), ("add1", C.c_void_p), ("stats", C.c_void_p), ("terms", C.c_int32), ("down0", C.c_int32),
-                ("absmax", C.c_void_p)]
+                ("absmax", C.c_void_p), ("xbound", C.c_void_p * 2)]
 
 
 class sc_wgrad_args(C.Structure):
@@ -45,7 +45,7 @@ class sc_wgrad_args(C.Structure):
                 ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("Cout", C.c_int32), ("Cin", C.c_int32), ("ks", C.c_int32),
                 ("part", C.c_void_p), ("part_floats", C.c_size_t), ("dw", C.c_void_p), ("terms", C.c_int32),
-                ("absmax", C.c_void_p)]
+                ("absmax", C.c_void_p), ("xbound", C.c_void_p * 2)]
 
 
 class sc_irt_args(C.Structure):
@@ -105,7 +105,7 @@ SIGNATURES = {
     "sc_head_conv_bwd": (_i, [_vp, C.POINTER(sc_src), _vp, _vp, _vp, _sz, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sc_head_bwd_bn_rows": (_i, [_i, _i, _i]),
     "sc_stat_rows": (_i, [_i, _i, _i, _i]),
-    "sc_bn_finalize": (_i, [_vp, _i, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _i, _vp, _vp]),
+    "sc_bn_finalize": (_i, [_vp, _i, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _i, _vp, _vp, _vp]),
     "sc_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "sc_bn_bwd_small": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sc_bn_bwd_finalize": (_i, [_vp, _i, _d, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -60,6 +60,20 @@ __device__ __forceinline__ float h_grad_scale(const float* absmax) {
   e = e < -100 ? -100 : (e > 100 ? 100 : e);
   return ldexpf(1.f, e);                                // M * s in [16, 32)
 }
+// Activation operand scale (round 5: range-safe by construction).  xb0 / xb1: device floats >= max |activation| of the staged
+// source(s) -- in training the bound |gamma| sqrt(n - 1) + |beta| that sc_bn_finalize leaves per BatchNorm'd tensor (no normalised
+// sample of n can exceed sqrt(n - 1)), for residual sums the maximum sc_add_srcs_absmax records in every forward, in inference
+// the sticky record of the streamed maxima; NULL: bounded by ReLU6 / unknown -> the default.  The scale is the default 2 whenever
+// 2 M <= 32752 (bit-identical to the fixed scale of rounds 1-4) and the largest power of two with s M <= 32752 otherwise.
+__device__ __forceinline__ float h_act_scale(const float* xb0, const float* xb1) {
+  float M = fmaxf(xb0 ? *xb0 : 0.f, xb1 ? *xb1 : 0.f);
+  if (!(M * SC_H_SX > 32752.f)) return SC_H_SX;
+  M = fminf(M, 3.0e38f);
+  int e;
+  (void)frexpf(32752.f / M, &e);                        // 32752 / M = m * 2^e, m in [0.5, 1)  ->  2^(e-1) <= 32752 / M
+  e = e - 1 < -120 ? -120 : e - 1;
+  return ldexpf(1.f, e);
+}
 // The operand scale s and (forward sources) the clamp are folded into the prologue constants by the callers: s is a power of
 // two, so  clamp(s * min(max(x*sc + sh, lo), hi))  ==  med3(x*(s*sc) + s*sh, max(s*lo, -65504), min(s*hi, 65504))  bit for bit
 // (h_lo / h_hi / sc_pro_affine_h), and  s * (A g + B y + D)  ==  (sA) g + (sB) y + sD  -- 3 resp. 1 VALU less per staged value.
@@ -127,6 +141,7 @@ struct ConvXP {
   float* stats;
   int down0;
   const float* absmax;
+  const float* xb0; const float* xb1;      // activation bounds of the sources (h_act_scale)
   int xcdmap;          // 1: 1-D grid, the cout tiles of a pixel tile numbered 8 apart (same XCD, back to back: its L2 serves the patch re-reads)
 };
 
@@ -228,7 +243,7 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
   const uintx4* wbase = p.wpk + (size_t)cot * nk * 3 * WENT;
 
   // fp16 mode: operand scale of the staged tensor and the factor that removes it (and the filters' 2^8) again
-  const float hsx = !HF ? 1.f : (BNB ? h_grad_scale(p.absmax) : SC_H_SX);
+  const float hsx = !HF ? 1.f : (BNB ? h_grad_scale(p.absmax) : h_act_scale(p.xb0, p.xb1));
   const float hinv = !HF ? 1.f : 1.f / (hsx * SC_H_SW);
 
   floatx16 acc[2][Q];
@@ -797,7 +812,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_ws(const ConvXP p) {
   const uintx4* wbase = p.wpk + (size_t)cot * nk * 3 * WENT;
 
   // fp16 mode: operand scale of the staged tensor and the factor that removes it (and the filters' 2^8) again
-  const float hsx = !HF ? 1.f : (BNB ? h_grad_scale(p.absmax) : SC_H_SX);
+  const float hsx = !HF ? 1.f : (BNB ? h_grad_scale(p.absmax) : h_act_scale(p.xb0, p.xb1));
   const float hinv = !HF ? 1.f : 1.f / (hsx * SC_H_SW);
 
   const int nst = 3 * nk;
@@ -1237,7 +1252,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
   n = __builtin_amdgcn_readfirstlane(n); tile = __builtin_amdgcn_readfirstlane(tile);      // uniform (see k_conv3_bx3)
   const int ty = __builtin_amdgcn_readfirstlane(tile / tiles_x), tx = tile - ty * tiles_x;
   const int y0 = ty * 8, x0 = tx * TW;
-  const float hsx = BNB ? h_grad_scale(p.absmax) : SC_H_SX;
+  const float hsx = BNB ? h_grad_scale(p.absmax) : h_act_scale(p.xb0, p.xb1);
   const float hinv = 1.f / (hsx * SC_H_SW);
 
   const SrcD& src = p.s0;
@@ -1442,6 +1457,7 @@ __global__ void k_pack_weights_bx3(const float* __restrict__ w, unsigned short* 
 // new rows are fetched per stage, every element is split into its three bf16 terms once.
 struct WgradXP {
   const float* absmax;
+  const float* xb0; const float* xb1;      // activation bounds of the input sources (h_act_scale)
   SrcD dy, s0, s1;
   int N, H, W, Cout, Cin;
   float* part;
@@ -1460,7 +1476,8 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
   static_assert(!PIPE || HF, "the pipelined variant is the fp16 mode's");
   constexpr int NTH = 768;
   const float hsg = HF ? h_grad_scale(p.absmax) : 1.f;          // fp16 mode: scale of the gradient operand
-  const float hinv = HF ? 1.f / (hsg * SC_H_SX) : 1.f;
+  const float hsa = HF ? h_act_scale(p.xb0, p.xb1) : 1.f;        // ... and of the activation operand
+  const float hinv = HF ? 1.f / (hsg * hsa) : 1.f;
   constexpr int COT = 32 * WM, CIT = 32 * NCI, NPAIR = NCI * WM, KP = 4 / NPAIR;     // KP K parts: rows and, at KP = 4, 16-pixel steps
   constexpr int DYP = 72;              // dy pitch per cout in pixels (144 B: conflict-free 16-byte reads)
   constexpr int XRP = 40;              // input row pitch in pixels (34 used)
@@ -1501,7 +1518,7 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
       if (cp && md != SC_SRC_RAW) { sc = cp[(size_t)(second ? ch - C0 : ch) * SC_CST]; sh = cp[(size_t)(second ? ch - C0 : ch) * SC_CST + 1]; }
       lo = sc_act_lo(act); hi = sc_act_hi(act);
     }
-    if constexpr (HF) { sc *= SC_H_SX; sh *= SC_H_SX; lo = h_lo(lo, SC_H_SX); hi = h_hi(hi, SC_H_SX); }      // (see split2h)
+    if constexpr (HF) { sc *= hsa; sh *= hsa; lo = h_lo(lo, hsa); hi = h_hi(hi, hsa); }      // (see split2h)
     s_cb[i * 4] = sc; s_cb[i * 4 + 1] = sh; s_cb[i * 4 + 2] = lo; s_cb[i * 4 + 3] = hi;
   }
 
@@ -1897,7 +1914,8 @@ __global__ __launch_bounds__(256, CIN == 32 ? 2 : 3) void k_wgrad_thin_h(const W
   const int l15 = lane & 15, lg = lane >> 4;
   const int H = p.H, W = p.W;
   const float hsg = h_grad_scale(p.absmax);
-  const float hinv = 1.f / (hsg * SC_H_SX);
+  const float hsa = h_act_scale(p.xb0, p.xb1);
+  const float hinv = 1.f / (hsg * hsa);
 
   for (int i = tid; i < 16 * SC_CST; i += 256) {
     const int ch = i / SC_CST, f = i % SC_CST;          // (operand scales folded into the constants, see split2h)
@@ -1907,8 +1925,8 @@ __global__ __launch_bounds__(256, CIN == 32 ? 2 : 3) void k_wgrad_thin_h(const W
   for (int i = tid; i < CIN; i += 256) {
     float sc = 1.f, sh = 0.f;
     if (p.s0.cst && p.s0.mode != SC_SRC_RAW) { sc = p.s0.cst[(size_t)i * SC_CST]; sh = p.s0.cst[(size_t)i * SC_CST + 1]; }
-    s_cb[i * 4] = sc * SC_H_SX; s_cb[i * 4 + 1] = sh * SC_H_SX;
-    s_cb[i * 4 + 2] = h_lo(sc_act_lo(p.s0.act), SC_H_SX); s_cb[i * 4 + 3] = h_hi(sc_act_hi(p.s0.act), SC_H_SX);
+    s_cb[i * 4] = sc * hsa; s_cb[i * 4 + 1] = sh * hsa;
+    s_cb[i * 4 + 2] = h_lo(sc_act_lo(p.s0.act), hsa); s_cb[i * 4 + 3] = h_hi(sc_act_hi(p.s0.act), hsa);
   }
 
   floatx4 acc[9][NCB];
@@ -2321,7 +2339,7 @@ extern "C" int sc_conv3x3_bx3(const sc_conv_args* a, sc_stream stream) {
   hipStream_t st = (hipStream_t)stream;
   const bool bnb = a->src[0].mode == SC_SRC_BNBWD;
   SC_REQUIRE(a->terms >= 0 && a->terms <= 4, "sc_conv3x3_bx3: terms must be 0 (= 3), 1, 2, 3 or SC_TERMS_F16X2 (got %d)", a->terms);
-  p.absmax = a->absmax;
+  p.absmax = a->absmax; p.xb0 = a->xbound[0]; p.xb1 = a->xbound[1];
 #define SC_LAUNCH_BX3(NT, HF)                                                                                  \
   do {                                                                                                         \
     if (a->co_t == 64 && bnb) hipLaunchKernelGGL((k_conv3_bx3<2, true, NT, HF>), grid, dim3(256), 0, st, p);   \
@@ -2383,7 +2401,7 @@ extern "C" int sc_conv3x3_wgrad_bx3(const sc_wgrad_args* a, sc_stream stream) {
   dim3 grid(pl.nsl, pl.ci_tiles, pl.co_tiles);
   hipStream_t st = (hipStream_t)stream;
   SC_REQUIRE(a->terms >= 0 && a->terms <= 4, "sc_conv3x3_wgrad_bx3: terms must be 0 (= 3), 1, 2, 3 or SC_TERMS_F16X2 (got %d)", a->terms);
-  p.absmax = a->absmax;
+  p.absmax = a->absmax; p.xb0 = a->xbound[0]; p.xb1 = a->xbound[1];
   int nparts = pl.nsl * pl.kp;          // (the pipelined variant sums its K parts in the kernel: pl.nsl)
   constexpr int pipe_env = 1;      // one-barrier refill pipeline (0 = the two-barrier stages it replaced: 1.89 vs 1.63 ms per step)
 #define SC_WGX(WM_, NT_, NCI_, HF_, PIPE_) hipLaunchKernelGGL((k_wgrad3_bx3<WM_, NT_, NCI_, HF_, PIPE_>), grid, dim3(768), 0, st, p)
@@ -2439,7 +2457,7 @@ extern "C" int sc_conv3x3_wgrad_thin16(const sc_wgrad_args* a, sc_stream stream)
   const size_t need = sc_wgrad_thin16_workspace_floats(a->N, a->H, a->W, a->Cout, a->Cin);
   SC_REQUIRE(a->part_floats >= need, "sc_conv3x3_wgrad_thin16: workspace too small (%zu < %zu floats)", a->part_floats, need);
   WgradXP p;
-  p.absmax = a->absmax;
+  p.absmax = a->absmax; p.xb0 = a->xbound[0]; p.xb1 = a->xbound[1];
   p.dy = to_srcd(a->dy); p.s0 = to_srcd(s); p.s1 = empty_srcd();
   p.N = a->N; p.H = a->H; p.W = a->W; p.Cout = a->Cout; p.Cin = a->Cin; p.part = a->part;
   p.nsl = wgrad_thin16_slices(a->N, a->H, a->W, a->Cin); p.CoP = 16; p.CiP = a->Cin;
@@ -2492,7 +2510,7 @@ extern "C" int sc_conv3x3_thin16(const sc_conv_args* a, sc_stream stream) {
   ConvXP p{};
   p.s0 = to_srcd(s); p.s1 = empty_srcd();
   p.wpk = reinterpret_cast<const uintx4*>(a->wpk); p.N = a->N; p.H = a->H; p.W = a->W; p.Cout = a->Cout;
-  p.out0 = a->out0; p.csplit = a->Cout; p.stats = a->stats; p.absmax = a->absmax;
+  p.out0 = a->out0; p.csplit = a->Cout; p.stats = a->stats; p.absmax = a->absmax; p.xb0 = a->xbound[0]; p.xb1 = a->xbound[1];
   const int tw = Cin == 16 ? 64 : 32;                     // (k_conv3_thin_h: TW)
   dim3 grid(((a->W + tw - 1) / tw) * ((a->H + 7) / 8), 1, a->N);
   constexpr int xcdmap_env = 2;

@@ -55,12 +55,24 @@ __device__ __forceinline__ void sp_split2h(float a, float b, unsigned& t0, unsig
   t1 = __builtin_bit_cast(unsigned, h1);
 }
 
+// activation operand scale from the sources' bounds (h_act_scale of conv_bx3.hip: the default 2 unless a bound says 2 M > 32752)
+__device__ __forceinline__ float sp_act_scale(const float* xb0, const float* xb1) {
+  float M = fmaxf(xb0 ? *xb0 : 0.f, xb1 ? *xb1 : 0.f);
+  if (!(M * SP_SX > 32752.f)) return SP_SX;
+  M = fminf(M, 3.0e38f);
+  int e;
+  (void)frexpf(32752.f / M, &e);
+  e = e - 1 < -120 ? -120 : e - 1;
+  return ldexpf(1.f, e);
+}
+
 struct ConvSPP {
   SrcD s0, s1;             // s0: low-resolution source [N][C0][Hl][Wl]; s1: skip source [N][C1][2 Hl][2 Wl] (C1 = 0: none); AFFINE or RAW
   const uintx4* wpk;       // sc_pack_weights_sp layout
   int N, Hl, Wl, Cout;     // output is [N][Cout][2 Hl][2 Wl]
   float* out;
   float* stats;            // [rows = N * tiles][Cout][2] or NULL
+  const float* xb0; const float* xb1;      // activation bounds of the two sources (device floats or NULL)
 };
 
 constexpr int SP_SMEM_W = 2 * SP_WST * 16;               // filter stages, double-buffered (64 KB)
@@ -109,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
   const int nku = (C0 + 15) >> 4, nkt = nku + 4 * ((C1 + 15) >> 4);
   const uintx4* wbase = p.wpk + (size_t)cot * nkt * WST;
 
-  const float hsx = SP_SX;
+  const float hsx = sp_act_scale(p.xb0, p.xb1);
   const float hinv = 1.f / (hsx * SP_SW);
 
   floatx16 acc[2][2];      // [group pp][px]
@@ -670,6 +682,7 @@ extern "C" int sc_conv3x3_sp(const sc_conv_args* a, sc_stream stream) {
   p.wpk = reinterpret_cast<const uintx4*>(a->wpk);
   p.N = a->N; p.Hl = a->H / 2; p.Wl = a->W / 2; p.Cout = a->Cout;
   p.out = a->out0; p.stats = a->stats;
+  p.xb0 = a->xbound[0]; p.xb1 = a->nsrc == 2 ? a->xbound[1] : nullptr;
   const int TW = p.Wl >= 32 ? 32 : 16, TH = 256 / TW;
   const long tiles = (long)((p.Wl + TW - 1) / TW) * ((p.Hl + TH - 1) / TH) * a->N;
   const long ncot = (a->Cout + 31) / 32;

@@ -84,7 +84,7 @@ template <int NW, typename TS = float>
 __global__ __launch_bounds__(64 * NW) void k_bn_finalize(const TS* __restrict__ stats, int nrows, double count,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* running_mean, float* running_var, float momentum, float eps,
-                                                         int training, float* __restrict__ cst, int C) {
+                                                         int training, float* __restrict__ cst, int C, float* act_bound) {
   constexpr int NT = 64 * NW;
   __shared__ double s_tmp[2 * NW];
   const int c = blockIdx.x;
@@ -138,6 +138,13 @@ __global__ __launch_bounds__(64 * NW) void k_bn_finalize(const TS* __restrict__ 
   const float shift = beta[c] - meanf * scale;
   float* o = cst + (size_t)c * SC_CST;
   o[0] = scale; o[1] = shift; o[2] = meanf; o[3] = invstd; o[4] = 0.f; o[5] = 0.f; o[6] = 0.f; o[7] = 0.f;
+  if (act_bound && training) {
+    // |BN(y)| = |gamma x_hat + beta| <= |gamma| sqrt(count - 1) + |beta| for batch statistics (Samuelson): the tensor's bound is the
+    // maximum over its channels; unsigned atomicMax on the bit pattern of a non-negative float is order-independent (reproducible),
+    // and a channel that cannot raise the slot skips the atomic (after the first step almost all do)
+    const float b = fabsf(gamma[c]) * (float)sqrt(count > 1.0 ? count - 1.0 : 1.0) * 1.0000002f + fabsf(beta[c]);
+    if (b < 3.0e38f && b > *(volatile float*)act_bound) atomicMax(reinterpret_cast<unsigned*>(act_bound), __float_as_uint(b));
+  }
 }
 
 // max over the block of m (>= 0), then *slot = max(*slot, m * factor): the order-independent (hence reproducible) unsigned
@@ -608,19 +615,19 @@ extern "C" int sc_stat_rows(int kind, int N, int H, int W) {
 
 extern "C" int sc_bn_finalize(const float* stats, int nrows, double count, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, int training,
-                              float* cst_fwd, int C, double* scratch, sc_stream stream) {
+                              float* cst_fwd, int C, double* scratch, float* act_bound, sc_stream stream) {
   SC_REQUIRE(C > 0 && cst_fwd && gamma && beta && running_mean && running_var, "sc_bn_finalize: null argument");
   SC_REQUIRE(!training || (stats && count > 0 && nrows > 0), "sc_bn_finalize: training needs stats rows and count");
   if (training && nrows >= 4096 && scratch && 2 * C <= 1024) {
     hipLaunchKernelGGL(k_bn_rows_prereduce, dim3(BN_PRE_S), dim3(1024), 0, (hipStream_t)stream, stats, nrows, C, scratch);
     hipLaunchKernelGGL((k_bn_finalize<4, double>), dim3(C), dim3(256), 0, (hipStream_t)stream, (const double*)scratch, BN_PRE_S, count, gamma,
-                       beta, running_mean, running_var, momentum, eps, training, cst_fwd, C);
+                       beta, running_mean, running_var, momentum, eps, training, cst_fwd, C, act_bound);
   } else if (training && nrows >= 4096)
     hipLaunchKernelGGL((k_bn_finalize<16>), dim3(C), dim3(1024), 0, (hipStream_t)stream, stats, nrows, count, gamma, beta,
-                       running_mean, running_var, momentum, eps, training, cst_fwd, C);
+                       running_mean, running_var, momentum, eps, training, cst_fwd, C, act_bound);
   else
     hipLaunchKernelGGL((k_bn_finalize<4>), dim3(C), dim3(256), 0, (hipStream_t)stream, stats, nrows, count, gamma, beta,
-                       running_mean, running_var, momentum, eps, training, cst_fwd, C);
+                       running_mean, running_var, momentum, eps, training, cst_fwd, C, act_bound);
   SC_LAUNCH_OK("sc_bn_finalize");
   return SC_OK;
 }

@@ -288,9 +288,14 @@ class HyperStarcopUNet(nn.Module):
             v = torch.tensor([wmax, amax, rmax, omax, switched], dtype=torch.float32, device=self._pflat.device)
             torch.distributed.all_reduce(v, op=torch.distributed.ReduceOp.MAX)
             wmax, amax, rmax, omax, switched = (float(x) for x in v.tolist())
+        # Round 5: activations can no longer leave the range -- every split convolution scales its fp16 operand from a device-side
+        # bound of its sources (h_act_scale in conv_bx3.hip: |gamma| sqrt(n - 1) + |beta| from sc_bn_finalize in training, the
+        # recorded maxima for residual sums / in inference), so only the FILTERS (scaled by a fixed 2^8 at pack time) decide `ok`;
+        # the activation figures stay in the report (activation_default_scale: the fixed x2 of rounds 1-4 still applies to all).
         return dict(max_abs_filter=wmax, filter_limit=self.FP16_MAX_WEIGHT, activation_bound=amax, activation_observed=omax,
                     activation_limit=self.FP16_MAX_ACT, residual_absmax=rmax, switched=bool(switched),
-                    ok=bool(wmax < self.FP16_MAX_WEIGHT and max(amax, omax, rmax) < self.FP16_MAX_ACT and not switched))
+                    activation_default_scale=bool(max(omax, rmax) < self.FP16_MAX_ACT / 2),
+                    ok=bool(wmax < self.FP16_MAX_WEIGHT and not switched))
 
     _range_switched = False      # this replica left precision "fp32" because of a range check (reported to the other ranks)
 
@@ -309,12 +314,9 @@ class HyperStarcopUNet(nn.Module):
             return True
         if not rep["ok"]:
             import warnings
-            seen = max(rep["activation_observed"], rep["residual_absmax"]) >= self.FP16_MAX_ACT
-            warnings.warn(f"HyperStarcopUNet: operands outside the range of the two-fp16-term kernels ({rep}); "
+            warnings.warn(f"HyperStarcopUNet: filters outside the range of the two-fp16-term kernels ({rep}); "
                           f"switching to precision='fp32-x3' (three bf16 terms, no range limits)"
-                          + ("; another rank of the process group had already switched" if rep["switched"] else "")
-                          + (f"; activations beyond the limit were clamped to +-65504/2 in launches since the previous check "
-                             f"(at most {self.range_check_every} steps)" if seen else ""))
+                          + ("; another rank of the process group had already switched" if rep["switched"] else ""))
             self.precision = "fp32-x3"
             self._range_switched = True
         return rep["ok"]
@@ -761,10 +763,20 @@ class HyperStarcopUNet(nn.Module):
             return make_src(plan.buf[t.name], t.C, SRC_AFFINE, act=t.act, up=up, cst=plan.cst[t.name])
         return make_src(plan.buf[t.name], t.C, SRC_RAW, up=up)
 
+    def _xbound(self, plan, t):
+        """device float >= max |activation| of tensor t as the split convolutions stage it, or None (ReLU6 / input: the default scale
+        covers it): BatchNorm-fed tensors -> their slot of plan.act_amax (raised by sc_bn_finalize to the by-construction bound in
+        training, by the BatchNorm-backward reductions / the streamed record to the observed maximum), residual sums -> plan.fin_amax
+        (recorded by sc_add_srcs_absmax in every forward, before any consumer runs)"""
+        if t.kind == "fin" and t.name in plan.fin_slot:
+            return C.c_void_p(plan.fin_amax.data_ptr() + 4 * plan.fin_slot[t.name])
+        slot = plan.act_slot.get(t.name) if t.kind == "raw" else None
+        return C.c_void_p(plan.act_amax.data_ptr() + 4 * slot) if slot is not None else None
+
     def _dy_src(self, plan, t):
         return make_src(plan.grad[t.name], t.C, SRC_BNBWD, act=t.act, cst=plan.cstb[t.name], aux=plan.buf[t.name])
 
-    def _forward_impl(self, x, x_cst, training, need_grad):
+    def _forward_impl(self, x, x_cst, training, need_grad, _recheck=0):
         """x: (N,C,H,W) fp32 device tensor (raw physical units if x_cst is given, else already normalised)."""
         _lib.require_device(x)
         lib = _lib.load()
@@ -802,7 +814,7 @@ class HyperStarcopUNet(nn.Module):
                 if t.bn is not None:
                     bn = t.bn
                     check(lib.sc_bn_finalize(None, 0, 1.0, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
-                                             float(bn.momentum), float(bn.eps), 0, ptr(plan.cst[t.name]), t.C, None, st))
+                                             float(bn.momentum), float(bn.eps), 0, ptr(plan.cst[t.name]), t.C, None, None, st))
         skip = set()
         for i, op in enumerate(self._ops):
             if i in skip:
@@ -862,6 +874,9 @@ class HyperStarcopUNet(nn.Module):
                 a.add0 = None; a.add1 = None
                 a.stats = plan.stats_v[o.name].data_ptr() if stats is not None else None
                 a.terms = ent["terms_f"]
+                if ty == "conv3":
+                    for k_, t_ in enumerate(ins):
+                        a.xbound[k_] = self._xbound(plan, t_)
                 if ty == "pw" and _use_pw3(0, N, Ho * Wo, conv.in_channels, conv.out_channels):
                     fconv = lib.sc_conv1x1_pw3
                     a.wpk = ent["pf"].data_ptr()
@@ -896,7 +911,8 @@ class HyperStarcopUNet(nn.Module):
                 bn = o.bn
                 check(lib.sc_bn_finalize(stats, srows, float(N * Ho * Wo), ptr(bn.weight), ptr(bn.bias),
                                          ptr(bn.running_mean), ptr(bn.running_var), float(bn.momentum), float(bn.eps),
-                                         1 if training else 0, ptr(plan.cst[o.name]), o.C, ptr(plan.bn_scratch) if _BN_PRE else None, st))
+                                         1 if training else 0, ptr(plan.cst[o.name]), o.C, ptr(plan.bn_scratch) if _BN_PRE else None,
+                                         self._xbound(plan, o), st))
         if training:      # one multi-tensor launch for the 62 step counters
             torch._foreach_add_(self._nbt_list(), 1)
         else:
@@ -904,13 +920,20 @@ class HyperStarcopUNet(nn.Module):
         plan.training = training
         if (not training and self.precision == "fp32" and self.range_check_every and plan.act_slot
                 and not torch.cuda.is_current_stream_capturing()):
-            # inference has no backward pass to leave the activation records: stream the handful of tensors at the check cadence
-            # (first forward of a shape included) and, if one is out of range, redo THIS forward with the three-term split
+            # inference: BatchNorm uses running statistics, so no bound of its output exists before the data has flowed.  The split
+            # convolutions scale their operands from the sticky records of the observed maxima (plan.act_amax); at the check cadence
+            # (first forward of a shape included) the handful of tensors is streamed once more and, if a value was beyond what the
+            # scale in force during THIS forward could carry (it was clamped), the forward is redone -- the records are updated by
+            # then, so the scales adapt; the precision mode does not change.  (Training needs none of this: sc_bn_finalize leaves
+            # the by-construction bound before any consumer runs.)
             plan.n_eval += 1
-            if plan.n_eval % self.range_check_every == 1 or self.range_check_every == 1:
+            if _recheck or plan.n_eval % self.range_check_every == 1 or self.range_check_every == 1:
+                before = plan.act_amax.clone()
                 self._record_activation_range(plan)
-                if not self.check_split_range():
-                    return self._forward_impl(x, x_cst, training, need_grad)
+                used = torch.where(before * 2 > self.FP16_MAX_ACT,
+                                   torch.exp2(torch.floor(torch.log2(self.FP16_MAX_ACT / before.clamp_min(1e-30)))), torch.full_like(before, 2.0))
+                if bool((plan.act_amax * used > 2 * self.FP16_MAX_ACT).any()) and _recheck < 6:
+                    return self._forward_impl(x, x_cst, training, need_grad, _recheck=_recheck + 1)
         return plan
 
     def _irt_args(self, plan, i_e):
@@ -940,7 +963,7 @@ class HyperStarcopUNet(nn.Module):
         bn = te.bn
         check(lib.sc_bn_finalize(ptr(plan.stats_v[te.name]), plan.irt_rows[te.name], cnt_e, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
                                  ptr(bn.running_var), float(bn.momentum), float(bn.eps), 1, ptr(plan.cst[te.name]), te.C,
-                                 ptr(plan.bn_scratch) if _BN_PRE else None, st))
+                                 ptr(plan.bn_scratch) if _BN_PRE else None, None, st))
         self._cur_op = td.name + ":fwd"
         tok = self._pb("k_irt_* (fused expand+dw)")
         check(lib.sc_irt_fwd(C.byref(a), ptr(plan.buf[td.name]), ptr(plan.stats_v[td.name]), st))
@@ -948,7 +971,7 @@ class HyperStarcopUNet(nn.Module):
         bn = td.bn
         check(lib.sc_bn_finalize(ptr(plan.stats_v[td.name]), plan.irt_rows[td.name], float(plan.N * Hd_ * Wd_), ptr(bn.weight), ptr(bn.bias),
                                  ptr(bn.running_mean), ptr(bn.running_var), float(bn.momentum), float(bn.eps), 1, ptr(plan.cst[td.name]), td.C,
-                                 ptr(plan.bn_scratch) if _BN_PRE else None, st))
+                                 ptr(plan.bn_scratch) if _BN_PRE else None, None, st))
 
     def _nbt_list(self):
         nbt = getattr(self, "_nbt", None)
@@ -1277,6 +1300,9 @@ class HyperStarcopUNet(nn.Module):
             wa.dw = gv(conv.weight).data_ptr()
             wa.terms = self._terms[1]
             wa.absmax = gmax_slot.get(o.name)
+            if ty == "conv3":
+                for k_, t_ in enumerate(ins):
+                    wa.xbound[k_] = self._xbound(plan, t_)
             flop = 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * ks * ks
             wfn = (lib.sc_conv3x3_wgrad_bx3 if (self.split_bf16 and ks == 3 and conv.out_channels >= 32 and conv.in_channels >= 32)
                    else lib.sc_conv2d_wgrad_mfma)     # 16-channel layers outside the cases below stay on the fp32 MFMA

@@ -88,7 +88,7 @@ def test_irt_sweeps_vs_fp64(hip, case):
     assert relerr(tot[:, 0], e_ref.sum((0, 2, 3))) < 2e-5 and relerr(tot[:, 1], (e_ref ** 2).sum((0, 2, 3))) < 2e-5
     gd, bd = dev(gam), dev(bet)
     rm, rv = torch.zeros(Hd, device=DEV), torch.ones(Hd, device=DEV)
-    check(lib.sc_bn_finalize(ptr(stats), rows0, float(N * H * W), ptr(gd), ptr(bd), ptr(rm), ptr(rv), 0.1, EPS, 1, ptr(cst_e), Hd, None, st))
+    check(lib.sc_bn_finalize(ptr(stats), rows0, float(N * H * W), ptr(gd), ptr(bd), ptr(rm), ptr(rv), 0.1, EPS, 1, ptr(cst_e), Hd, None, None, st))
     mean_ref, var_ref = e_ref.mean((0, 2, 3)), e_ref.var((0, 2, 3), unbiased=False)
     assert relerr(cst_e[:, 2], mean_ref) < 1e-5 and relerr(cst_e[:, 3], 1.0 / torch.sqrt(var_ref + EPS)) < 1e-5
     # ---- (B) forward: raw depthwise output + its statistics rows

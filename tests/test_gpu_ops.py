@@ -606,8 +606,15 @@ def test_batchnorm_bookkeeping(hip):
     cst = torch.zeros(C_, SC_CST, device=DEV)
     cnt = float(N * H * W)
     check(hip.sc_bn_finalize(ptr(stats), 300, cnt, ptr(dev(gamma)), ptr(dev(beta)), ptr(rmd), ptr(rvd),
-                             0.1, 1e-5, 1, ptr(cst), C_, None, stream()))
+                             0.1, 1e-5, 1, ptr(cst), C_, None, None, stream()))
     assert relerr(rmd, rm) < 1e-5 and relerr(rvd, rv) < 1e-5
+    # act_bound: the tensor's by-construction bound max_c |gamma_c| sqrt(count - 1) + |beta_c| (sticky, never lowered)
+    slot = torch.tensor([3.0], device=DEV)
+    check(hip.sc_bn_finalize(ptr(stats), 300, cnt, ptr(dev(gamma)), ptr(dev(beta)), ptr(rmd.clone()), ptr(rvd.clone()),
+                             0.1, 1e-5, 1, ptr(cst.clone()), C_, None, ptr(slot), stream()))
+    want_b = float((gamma.abs().double() * (cnt - 1) ** 0.5 + beta.abs().double()).max())
+    assert want_b <= float(slot) <= want_b * (1 + 1e-5), (float(slot), want_b)
+    assert float(F.batch_norm(y.detach(), None, None, gamma.detach(), beta.detach(), True).abs().max()) <= float(slot)      # (and far below it)
     # many rows (full-resolution layers): the coalesced pre-reduction into 64 fp64 partial rows gives the same constants
     nr = 5000
     big = torch.zeros(nr, C_, 2, device=DEV)
@@ -616,7 +623,7 @@ def test_batchnorm_bookkeeping(hip):
     outs = []
     for scr in (None, torch.empty(64 * 2 * C_, dtype=torch.float64, device=DEV)):
         rm2, rv2, c2 = torch.zeros(C_, device=DEV), torch.ones(C_, device=DEV), torch.zeros(C_, SC_CST, device=DEV)
-        check(hip.sc_bn_finalize(ptr(big), nr, cnt, ptr(dev(gamma)), ptr(dev(beta)), ptr(rm2), ptr(rv2), 0.1, 1e-5, 1, ptr(c2), C_, ptr(scr), stream()))
+        check(hip.sc_bn_finalize(ptr(big), nr, cnt, ptr(dev(gamma)), ptr(dev(beta)), ptr(rm2), ptr(rv2), 0.1, 1e-5, 1, ptr(c2), C_, ptr(scr), None, stream()))
         outs.append((rm2, rv2, c2))
     assert all(relerr(a, b) < 1e-6 for a, b in zip(outs[0], outs[1]))
     m_want = big[:, :, 0].double().sum(0) / cnt

@@ -306,13 +306,19 @@ def test_checkpoint_outside_fp16_range_falls_back_to_three_term_split(hip):
         want = ref(ref_normalize(batch["input"]))
         got = model(to_dev(batch)["input"])
     assert relerr(got, want) < 1e-4
-    # a huge BatchNorm gain in front of a split convolution does the same
-    model2, _ = make_pair(seed=1, pos_weight=1.0)
+    # a huge BatchNorm gain in front of a split convolution does NOT (round 5): the consumer scales its fp16 operand from the
+    # tensor's device-side bound, the default mode stays and still matches the oracle
+    model2, ref2 = make_pair(seed=1, pos_weight=1.0)
     sd = {k: v.clone() for k, v in model2.network.state_dict().items()}
-    sd["decoder.blocks.0.conv1.1.weight"][7] = 600.0
-    with pytest.warns(UserWarning):
-        model2.network.load_state_dict(sd)
-    assert model2.network.precision == "fp32-x3"
+    sd["decoder.blocks.0.conv1.1.weight"][7] = 6.0e4
+    model2.network.load_state_dict(sd)
+    assert model2.network.precision == "fp32"
+    ref2.load_state_dict({k: v.cpu() for k, v in sd.items()})
+    model2.eval(); ref2.eval()
+    with torch.no_grad():
+        want = ref2(ref_normalize(batch["input"]))
+        got = model2(to_dev(batch)["input"])
+    assert model2.network.precision == "fp32" and relerr(got, want) < 1e-4
 
 
 def test_residual_sums_are_range_checked(hip):
@@ -336,13 +342,18 @@ def test_residual_sums_are_range_checked(hip):
     # a checkpoint whose residual stream explodes: the projection BatchNorm of features.3 gets a huge gain
     sd = {k: v.clone() for k, v in net.state_dict().items()}
     sd["encoder.features.3.conv.3.weight"][:] = 4.0e4
-    net.load_state_dict(sd)                     # static limits still fine (this BatchNorm feeds no split convolution directly)
+    net.load_state_dict(sd)
     assert net.precision == "fp32"
+    ref.load_state_dict({k: v.cpu() for k, v in sd.items()})
     with torch.no_grad():
-        model(to_dev(batch)["input"])
-    with pytest.warns(UserWarning, match="fp32-x3"):
-        assert not net.check_split_range()
-    assert net.precision == "fp32-x3" and net.split_range_report()["residual_absmax"] > net.FP16_MAX_ACT
+        want = ref(ref_normalize(batch["input"]))
+        got = model(to_dev(batch)["input"])
+    # round 5: the record of THIS forward (written by the add kernel before any consumer runs) sets the consumers' operand scale:
+    # no clamp, no precision switch, the oracle's logits
+    rep = net.split_range_report()
+    assert net.check_split_range() and net.precision == "fp32"
+    assert rep["residual_absmax"] > net.FP16_MAX_ACT and not rep["activation_default_scale"]
+    assert relerr(got, want) < 1e-4
 
 
 def test_batchnorm_fed_activations_are_range_recorded_on_the_device(hip):
@@ -363,9 +374,17 @@ def test_batchnorm_fed_activations_are_range_recorded_on_the_device(hip):
     model.fused_train_step(to_dev(batch), opt)
     rep = net.split_range_report()
     want = max(seen.values())
-    assert rep["ok"] and abs(rep["activation_observed"] - want) < 1e-3 * want, (rep, want)
+    # round 5: in training the record is the by-construction BOUND max_c |gamma| sqrt(n - 1) + |beta| that sc_bn_finalize leaves
+    # before any consumer runs (>= the observed maximum, which the BatchNorm-backward reductions still fold in)
+    bounds = []
+    for n_ in feeders:
+        m_ = dict(ref.named_modules())[n_]
+        hw = (H >> (1 if n_.startswith("encoder") else 4 - int(n_.split(".")[2]))) ** 2
+        bounds.append(float((m_.weight.detach().abs() * (B * hw - 1) ** 0.5 + m_.bias.detach().abs()).max()))
+    assert rep["ok"] and want <= rep["activation_observed"] <= max(bounds) * (1 + 1e-5), (rep, want, max(bounds))
+    assert abs(rep["activation_observed"] - max(bounds)) < 1e-4 * max(bounds)
     # inference: a checkpoint whose running variance makes one decoder BatchNorm output explode -- nothing static can see it
-    # (gamma, beta are ordinary); the first forward records it, warns, and is redone with the three-term split
+    # (gamma, beta are ordinary); the first forward records it and is redone with the operand scales adapted (default mode kept)
     model2, ref2 = make_pair(seed=9)
     sd = {k: v.clone() for k, v in model2.network.state_dict().items()}
     sd["decoder.blocks.2.conv1.1.running_var"][:] = 1e-12       # invstd = 1 / sqrt(1e-12 + eps) = 316
@@ -376,13 +395,46 @@ def test_batchnorm_fed_activations_are_range_recorded_on_the_device(hip):
     model2.eval(); ref2.eval()
     with torch.no_grad():
         want = ref2(ref_normalize(batch["input"]))
-        with pytest.warns(UserWarning, match="fp32-x3"):
-            got = model2(to_dev(batch)["input"])
-    assert model2.network.precision == "fp32-x3"
+        got = model2(to_dev(batch)["input"])         # first forward of the shape: records, finds the clamp, redoes with adapted scales
+    assert model2.network.precision == "fp32"
     assert model2.network.split_range_report()["activation_observed"] > model2.network.FP16_MAX_ACT
     assert relerr(got, want) < 1e-4
+    with torch.no_grad():
+        assert relerr(model2(to_dev(batch)["input"]), want) < 1e-4        # (and the following ones, from the sticky record)
     for h in hooks:
         h.remove()
+
+
+def test_training_activations_of_1e5_stay_exact_in_the_default_mode(hip):
+    """|activation| ~ 1e5 in front of split convolutions, in TRAINING, default precision: sc_bn_finalize leaves the
+    by-construction bound |gamma| sqrt(n - 1) + |beta| before any consumer runs, the consumers scale their fp16 operands from it --
+    nothing is clamped, nothing switches, and the train-mode logits / loss match the oracle evaluated in float64."""
+    import copy
+    B, H, W = 2, 64, 64
+    model, ref = make_pair(seed=21, pos_weight=1.0)
+    sd = {k: v.clone() for k, v in model.network.state_dict().items()}
+    for k in ("decoder.blocks.1.conv1.1", "decoder.blocks.2.conv2.1", "encoder.features.1.conv.2"):     # two decoder BatchNorms and the features.1 skip
+        sd[k + ".weight"][:] = 4.0e4
+        sd[k + ".bias"][:] = 1.0e4
+    model.network.load_state_dict(sd)
+    ref.load_state_dict({k: v.cpu() for k, v in sd.items()})
+    assert model.network.precision == "fp32"
+    batch = synth_batch(B, H, W, seed=22)
+    model.train()
+    ref64 = copy.deepcopy(ref).double().train()
+    seen = {}
+    hk = dict(ref64.named_modules())["decoder.blocks.1.conv1.1"].register_forward_hook(lambda m, i_, o: seen.__setitem__("a", float(o.abs().max())))
+    with torch.no_grad():
+        want = ref64(ref_normalize(batch["input"]).double())
+    hk.remove()
+    assert seen["a"] > 6.0e4, seen                         # beyond what the fixed x2 scale of rounds 1-4 could carry (32752)
+    opt = model.configure_optimizers()["optimizer"]
+    model.fused_train_step(to_dev(batch), opt)
+    got = model.network._plans[(B, H, W)].buf["logits"]
+    assert model.network.precision == "fp32"
+    assert relerr(got, want) < 1e-4, relerr(got, want)
+    rep = model.network.split_range_report()
+    assert rep["ok"] and rep["activation_observed"] >= seen["a"] and not rep["activation_default_scale"]
 
 
 def test_inference_constants_are_cached_and_invalidated(hip):

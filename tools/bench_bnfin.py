@@ -25,7 +25,7 @@ for C_, rows in ((384, 512), (96, 2048), (960, 128), (64, 512), (24, 2048), (32,
     g, b, rm, rv = torch.ones(C_, device=dev), torch.zeros(C_, device=dev), torch.zeros(C_, device=dev), torch.ones(C_, device=dev)
     cst = torch.empty(C_, SC_CST, device=dev); scratch = torch.empty(64 * 2 * C_, dtype=torch.float64, device=dev)
     t = timeit(lambda: check(lib.sc_bn_finalize(ptr(stats), rows, float(rows * 32), ptr(g), ptr(b), ptr(rm), ptr(rv), 0.1, 1e-5, 1, ptr(cst), C_,
-                                                ptr(scratch), stream())))
+                                                ptr(scratch), None, stream())))
     sums = torch.rand(min(rows, 4096), C_, 2, device=dev, dtype=torch.float64)
     dg, db, cb = torch.empty(C_, device=dev), torch.empty(C_, device=dev), torch.empty(C_, SC_CST, device=dev)
     t2 = timeit(lambda: check(lib.sc_bn_bwd_finalize(ptr(sums), sums.shape[0], float(rows * 32), ptr(cst), ptr(dg), ptr(db), ptr(cb), C_, stream())))
