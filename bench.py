@@ -460,12 +460,18 @@ def main():
                     "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "peak_note": "HBM3E peak (MI355X_MICROARCH.md); achieved = algorithmic bytes of these launches / their time" if hbm else
                                  (f"fp32-equivalent ceiling of the {'two-fp16-term' if nterms == 4 else str(nterms) + '-bf16-term'} split: dense 16-bit MFMA peak "
-                                  f"2500 TFLOP/s / {int(nprod)} products; the kernel executes {round(nprod * ach, 1)} 16-bit TFLOP/s on the matrix cores; "
+                                  f"2500 TFLOP/s / {int(nprod)} products; `achieved` counts the ALGORITHMIC flops of the reference's 3x3 convolutions "
+                                  f"(2 N H W Cout Cin 9); the kernels EXECUTE {round(nprod * d.get('flop_exec', d['flop']) / (d['ms'] * 1e-3) / 1e12, 1)} 16-bit TFLOP/s on the "
+                                  f"matrix cores = {round(nprod * d.get('flop_exec', d['flop']) / (d['ms'] * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 3)} of the dense 16-bit peak "
+                                  f"({round(d.get('flop_exec', d['flop']) / d['flop'], 3)} of the algorithmic multiply-adds: the decoder conv1 layers run as sub-pixel "
+                                  f"convolutions, 16 instead of 36 taps per low-resolution pixel and up-sampled channel, conv_sp.hip); "
                                   f"{round(ach / FP32_MFMA_PEAK_TFLOPS, 3)} x the fp32 MFMA peak of {FP32_MFMA_PEAK_TFLOPS}") if bx3 else
                                  "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
                     "kernel_templates": ("k_conv3_bx3<Q,BNB,2,true>; launches with K loops of >= 16 chunks (decoder.blocks.0) run the "
-                                         "wave-specialised k_conv3_ws<Q,BNB> of the same contraction (both names appear in the rocprofv3 "
-                                         "kernel traces under profiles/)") if (fam.startswith("k_conv3_bx3") and nterms == 4) else None,
+                                         "wave-specialised k_conv3_ws<Q,BNB> of the same contraction; the decoder conv1 layers run as sub-pixel "
+                                         "convolutions: k_conv3_sp<TW> (forward, decoder.blocks.0-3) and k_conv3_spd<TW> (data gradient of the "
+                                         "up-sampled channels, decoder.blocks.0-2) -- all four names appear in the rocprofv3 kernel traces under "
+                                         "profiles/") if (fam.startswith("k_conv3_bx3") and nterms == 4) else None,
                     "algorithmic_bytes_per_launch": round(d["bytes"] / d["n"]) if d.get("bytes") else None,
                     "algorithmic_flop_per_launch": round(d["flop"] / d["n"]),
                     "launches_per_step": d["n"] // 3, "avg_launch_ms": round(d["ms"] / d["n"], 4),

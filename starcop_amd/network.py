@@ -440,14 +440,17 @@ class HyperStarcopUNet(nn.Module):
     profile_detail = False
     _cur_op = ""
 
-    def _pb(self, fam, flop=0.0, nbytes=0.0):
+    def _pb(self, fam, flop=0.0, nbytes=0.0, flop_exec=None):
+        """flop: ALGORITHMIC flops of the launch(es) (the reference's 3x3 convolution); flop_exec: the multiply-adds the kernels
+        actually execute when that differs (sub-pixel decoder conv1: 16 instead of 36 taps per low-resolution pixel and up-sampled
+        channel), both before the split's products-per-multiply factor"""
         if self.profile is None:
             return None
         if self.profile_detail:
             fam = f"{self._cur_op}|{fam}"
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        return (fam, flop, e0, e1, nbytes)
+        return (fam, flop, e0, e1, nbytes, flop if flop_exec is None else flop_exec)
 
     def _pe(self, tok):
         if tok is not None:
@@ -459,7 +462,7 @@ class HyperStarcopUNet(nn.Module):
         out = {}
         for fam, toks in (self.profile or {}).items():
             out[fam] = {"ms": sum(t[2].elapsed_time(t[3]) for t in toks), "flop": sum(t[1] for t in toks), "n": len(toks),
-                        "bytes": sum(t[4] for t in toks)}
+                        "bytes": sum(t[4] for t in toks), "flop_exec": sum(t[5] for t in toks)}
         return out
 
     _stat_epoch = 0      # bumped whenever parameters / running statistics change through raw pointers (torch's _version does not see those)
@@ -843,10 +846,16 @@ class HyperStarcopUNet(nn.Module):
             if self.profile is not None:
                 if ty in ("pw", "conv3"):
                     src_elems = sum(t.C * (H >> t.shift) * (W >> t.shift) for t in op["ins"])
+                    fl = 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * conv.kernel_size[0] ** 2
+                    fle = None
+                    ent_ = self._wpk[i]
+                    if (op.get("up") and ent_.get("sp") is not None and ent_["terms_f"] == TERMS_F16X2 and self.split_bf16
+                            and ent_["tf"] is None and _use_sp(N, Ho, Wo, o.C)):
+                        cu_ = op["ins"][0].C        # per low-resolution pixel: 16 slots per up-sampled channel, 16 per (skip channel, parity)
+                        fle = 2.0 * N * (Ho // 2) * (Wo // 2) * 16 * (-(-conv.out_channels // 32) * 32) * (cu_ + 4 * (conv.in_channels - cu_))
                     tok = self._pb("k_conv3_thin_h (fwd+dgrad)" if self._wpk[i]["tf"] is not None else
                                    self._bx3_family("fwd") if self._wpk[i]["bx3_f"] else f"k_conv_mfma<{conv.kernel_size[0]}> (fwd+dgrad)",
-                                   2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * conv.kernel_size[0] ** 2,
-                                   4.0 * (N * src_elems + N * o.C * Ho * Wo + conv.weight.numel()))
+                                   fl, 4.0 * (N * src_elems + N * o.C * Ho * Wo + conv.weight.numel()), fle)
                 else:
                     tok = self._pb({"stem": "k_stem_*", "dw": "k_dw_*", "head": "k_head_*", "add": "elementwise/bn"}[ty])
             if ty == "stem":
@@ -1354,9 +1363,15 @@ class HyperStarcopUNet(nn.Module):
             if op.get("up") and ent["bx3_b"]:      # the upsampled source's gradient is stored 2x2-summed (quarter size)
                 gin_elems -= N * ins[0].C * Ho * Wo * 3 // 4
             thin_b = (ent["tb"] is not None and not op.get("up") and ins[0].name not in written and res_of.get(ins[0].name) is None)
+            fle = None
+            if (op.get("up") and ent.get("spd") is not None and ent["terms_b"] == TERMS_F16X2 and self.split_bf16
+                    and _use_spd(N, Ho, Wo, ins[0].C)):
+                cu_ = ins[0].C          # up-sampled channels: 4 parity planes x 4 taps per low-resolution pixel; skip channels: the 3x3 form
+                fle = (2.0 * N * (Ho // 2) * (Wo // 2) * 16 * conv.out_channels * (-(-cu_ // 128) * 128)
+                       + 2.0 * N * Ho * Wo * 9 * conv.out_channels * (conv.in_channels - cu_))
             tok = self._pb("k_conv3_thin_h (fwd+dgrad)" if thin_b else
                            self._bx3_family("dgrad") if ent["bx3_b"] else f"k_conv_mfma<{ks}> (fwd+dgrad)", flop,
-                           4.0 * (2 * N * o.C * Ho * Wo + gin_elems + conv.weight.numel()))
+                           4.0 * (2 * N * o.C * Ho * Wo + gin_elems + conv.weight.numel()), fle)
             if (op.get("up") and ent.get("spd") is not None and ent["terms_b"] == TERMS_F16X2 and self.split_bf16
                     and _use_spd(N, Ho, Wo, ins[0].C)):
                 # sub-pixel form: the up-sampled channels' gradient at half resolution from the four parity planes of dy (2.25x fewer

@@ -16,7 +16,7 @@ cd $ROOT
 python tools/prof_summary.py $(find /tmp/p_eager -name "*.db" | head -1) > $OUT/kernel_trace_stats_bench_b16.txt
 python tools/prof_summary.py $(find /tmp/p_serial -name "*.db" | head -1) > $OUT/kernel_trace_stats_bench_b16_serial.txt
 python tools/gap_analysis.py $(find /tmp/p_eager -name "*.db" | head -1) 0.3 0.7 > $OUT/gap_analysis_eager.txt
-python tools/pmc_traffic.py $(find /tmp/p_fetch -name "*.db" | head -1) $(find /tmp/p_write -name "*.db" | head -1) "k_conv3_bx3|k_conv3_ws" $OUT/pmc_traffic_conv3_bx3.json > /dev/null
+python tools/pmc_traffic.py $(find /tmp/p_fetch -name "*.db" | head -1) $(find /tmp/p_write -name "*.db" | head -1) "k_conv3_bx3|k_conv3_ws|k_conv3_sp" $OUT/pmc_traffic_conv3_bx3.json > /dev/null
 grep "^{" $OUT/bench_eager.log > $OUT/bench_line_under_rocprof.json
 python bench.py > $OUT/bench_full.log 2>&1; grep "^{" $OUT/bench_full.log > $OUT/bench_line.json
 ls -la $OUT
