@@ -216,10 +216,14 @@ int sc_conv3x3_sp(const sc_conv_args* a, sc_stream stream);
  *   sc_conv3x3_sp_dgrad: sc_conv_args with nsrc = 1, src[0] = the SC_SRC_BNBWD operand of the layer's output (g, y, constants; H x W),
  *   Cout = csplit = the up-sampled source's channels, out0 = [N, Cout, H/2, W/2] (accum0 allowed), terms = SC_TERMS_F16X2, absmax as
  *   in sc_conv3x3_bx3; `wpk` from sc_pack_weights_spd (or a sc_pack_desc with bx3 = SC_PACK_SPD, Cin = the filter's total input
- *   channels, co_t = the up-sampled source's channels). */
+ *   channels, co_t = the up-sampled source's channels, transpose_flip = 2 for vskip).
+ *   vskip (sc_spd_vskip_ok: <= 64 up-sampled and <= 16 skip channels, smp's decoder.blocks.3): the skip channels' full-resolution
+ *   gradient rides along in the otherwise idle half of the 128-channel tile -- Cout = all input channels, csplit = the up-sampled ones,
+ *   out1 = [N, Cout - csplit, H, W] (accum1 allowed): ONE launch stages dy for both gradients. */
 #define SC_PACK_SPD 8
 size_t sc_packed_weight_floats_spd(int Cout, int Cup);
-int sc_pack_weights_spd(const float* w_oihw, float* wpk, int Cout, int CinTotal, int Cup, sc_stream stream);
+int sc_spd_vskip_ok(int Cup, int Cskip);
+int sc_pack_weights_spd(const float* w_oihw, float* wpk, int Cout, int CinTotal, int Cup, int vskip, sc_stream stream);
 int sc_conv3x3_sp_dgrad(const sc_conv_args* a, sc_stream stream);
 
 /* weight gradient of the same thin layers (Cout <= 16, Cin = 16 | 32, one source which may be upsampled) with two fp16 terms on

@@ -371,6 +371,8 @@ struct ConvSPD {
   float* out;
   int accum;
   const float* absmax;
+  float* out_skip;         // vskip (Cup <= 64): [N][Cskip <= 16][2 Hl][2 Wl] gradient of the skip channels from wave half 1, or NULL
+  int Cskip, accum_skip;
 };
 
 __device__ __forceinline__ float spd_grad_scale(const float* absmax) {      // (h_grad_scale of conv_bx3.hip)
@@ -598,6 +600,30 @@ __global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
     __syncthreads();
   }
 
+  // ---- epilogue, wave half 1 with virtual skip channels: v = 16 * parity + c -> dskip[c][2i + oy][2j + ox] at full resolution
+  if (p.out_skip != nullptr && hh == 1) {
+    const unsigned W2 = 2u * (unsigned)Wl, ph32 = (unsigned)((size_t)4 * Hl * Wl);
+    float* const os = p.out_skip + (size_t)n * p.Cskip * ph32;
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      const int g = 2 * wq + pp;
+      const int i = y0 + (TW == 32 ? g : 2 * g + (l31 >> 4)), j = x0 + (TW == 32 ? l31 : (l31 & 15));
+      const bool okp = i < Hl && j < Wl;
+#pragma unroll
+      for (int mx = 0; mx < 2; ++mx)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int vch = mx * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi, par = vch >> 4, c = vch & 15;
+          if (okp && c < p.Cskip) {
+            const unsigned off = (unsigned)c * ph32 + (unsigned)(2 * i + (par >> 1)) * W2 + (unsigned)(2 * j + (par & 1));
+            float v = acc[pp][mx][r] * hinv;
+            if (p.accum_skip) v += os[off];
+            os[off] = v;
+          }
+        }
+    }
+    return;
+  }
   // ---- epilogue: low-resolution stores (the 2x2 sum over the up-sampled copies is in the phase filters)
   const unsigned pl32 = (unsigned)((size_t)Hl * Wl);
   const int cb = cot * 128 + hh * 64;
@@ -623,9 +649,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
   }
 }
 
-__global__ void k_pack_weights_spd(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout, int CinTot, int Cup, size_t total) {
+__global__ void k_pack_weights_spd(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout, int CinTot, int Cup, int vskip, size_t total) {
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i < total) spd_pack_item(w, wpk, i, Cout, CinTot, Cup);
+  if (i < total) spd_pack_item(w, wpk, i, Cout, CinTot, Cup, vskip != 0);
 }
 
 __global__ void k_pack_weights_sp(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout, int Cup, int Csk, size_t total) {
@@ -703,12 +729,15 @@ extern "C" size_t sc_packed_weight_floats_spd(int Cout, int Cup) {
   return (size_t)((Cup + 127) / 128) * 4 * ((Cout + 15) / 16) * SP_WST * 4;
 }
 
-extern "C" int sc_pack_weights_spd(const float* w, float* wpk, int Cout, int CinTotal, int Cup, sc_stream stream) {
+extern "C" int sc_spd_vskip_ok(int Cup, int Cskip) { return Cup > 0 && Cup <= 64 && Cskip > 0 && Cskip <= 16; }
+
+extern "C" int sc_pack_weights_spd(const float* w, float* wpk, int Cout, int CinTotal, int Cup, int vskip, sc_stream stream) {
   SC_REQUIRE(w && wpk && Cout > 0 && Cup > 0 && Cup <= CinTotal, "sc_pack_weights_spd: bad argument");
+  SC_REQUIRE(!vskip || sc_spd_vskip_ok(Cup, CinTotal - Cup), "sc_pack_weights_spd: virtual skip channels need Cup <= 64 and 1..16 skip channels");
   SC_REQUIRE(((uintptr_t)wpk & 15) == 0, "sc_pack_weights_spd: destination must be 16-byte aligned");
   const size_t total = spd_pack_items(Cout, Cup);
   hipLaunchKernelGGL(k_pack_weights_spd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
-                     reinterpret_cast<unsigned short*>(wpk), Cout, CinTotal, Cup, total);
+                     reinterpret_cast<unsigned short*>(wpk), Cout, CinTotal, Cup, vskip, total);
   SC_LAUNCH_OK("sc_pack_weights_spd");
   return SC_OK;
 }
@@ -721,18 +750,22 @@ extern "C" int sc_conv3x3_sp_dgrad(const sc_conv_args* a, sc_stream stream) {
   SC_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->Cout > 0 && a->src[0].C > 0, "sc_conv3x3_sp_dgrad: bad shape");
   SC_REQUIRE(a->H % 2 == 0 && a->W % 2 == 0, "sc_conv3x3_sp_dgrad: even gradient size");
   SC_REQUIRE(a->terms == SC_TERMS_F16X2, "sc_conv3x3_sp_dgrad: two-fp16-term arithmetic only (terms = SC_TERMS_F16X2)");
-  SC_REQUIRE(a->csplit == a->Cout && a->out1 == nullptr && a->add0 == nullptr && a->add1 == nullptr && a->stats == nullptr,
-             "sc_conv3x3_sp_dgrad: a single half-resolution output [N, Cout, H/2, W/2] (accum0 allowed)");
+  SC_REQUIRE(a->add0 == nullptr && a->add1 == nullptr && a->stats == nullptr && a->csplit > 0 && a->csplit <= a->Cout,
+             "sc_conv3x3_sp_dgrad: outputs are out0 [N, csplit, H/2, W/2] (+ out1 [N, Cout - csplit, H, W]); no add / stats");
+  SC_REQUIRE((a->csplit == a->Cout) == (a->out1 == nullptr), "sc_conv3x3_sp_dgrad: out1 exactly when csplit < Cout");
+  SC_REQUIRE(a->csplit == a->Cout || sc_spd_vskip_ok(a->csplit, a->Cout - a->csplit),
+             "sc_conv3x3_sp_dgrad: the skip channels' gradient rides along only for csplit <= 64 and <= 16 skip channels (got %d, %d)", a->csplit, a->Cout - a->csplit);
   SC_REQUIRE(((uintptr_t)a->wpk & 15) == 0, "sc_conv3x3_sp_dgrad: alignment");
   SC_REQUIRE((size_t)128 * (a->H / 2) * (a->W / 2) < (1ull << 32) && (size_t)a->H * a->W < (1ull << 31), "sc_conv3x3_sp_dgrad: plane too large");
   ConvSPD p;
   p.dy = to_srcd(a->src[0]);
   p.wpk = reinterpret_cast<const uintx4*>(a->wpk);
-  p.N = a->N; p.Hl = a->H / 2; p.Wl = a->W / 2; p.Cup = a->Cout;
+  p.N = a->N; p.Hl = a->H / 2; p.Wl = a->W / 2; p.Cup = a->csplit;
   p.out = a->out0; p.accum = a->accum0; p.absmax = a->absmax;
+  p.out_skip = a->out1; p.Cskip = a->Cout - a->csplit; p.accum_skip = a->accum1;
   const int TW = p.Wl >= 32 ? 32 : 16, TH = 256 / TW;
   const long tiles = (long)((p.Wl + TW - 1) / TW) * ((p.Hl + TH - 1) / TH) * a->N;
-  const long ncot = (a->Cout + 127) / 128;
+  const long ncot = (a->csplit + 127) / 128;
   const long grid = (tiles + 7) / 8 * 8 * ncot;
   SC_REQUIRE(grid < (1L << 31), "sc_conv3x3_sp_dgrad: grid too large");
   static const bool attr_ok = [] {

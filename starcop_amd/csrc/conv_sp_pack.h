@@ -65,10 +65,15 @@ __device__ __forceinline__ void sp_pack_item(const float* __restrict__ w, unsign
 // (dy[co][2i'+qy][2j'+qx]) and taps (a,b) of  Wph[qy][qx][a][b][co][ci] * dyP[qy][qx][co][i - (a-1+qy)][j - (b-1+qx)]  (a stride-2 4x4
 // convolution of dy; no full-resolution gradient, no 2x2 down-sum).  Layout: [cin tile of 128][chunk = 4*(16-cout chunk) + 2*qy + qx]
 // stages of SP_WST entries, entry = (((((h*2 + term)*2 + mx)*2 + a)*2 + b)*2 + cout half)*32 + ci  (cin block = 2h + mx of the tile)
+// VIRTUAL SKIP CHANNELS (vskip; Cup <= 64 and at most 16 skip channels: decoder.blocks.3): the two cin blocks of wave half h = 1 -- zero
+// filters otherwise -- carry the skip channels' FULL-resolution gradient as 4 output parities x 16 channels: virtual channel
+// v = 16 * (2 oy + ox) + c is dskip[c][2i + oy][2j + ox], whose tap for dy parity chunk (qy, qx) and slot (a, b) is the single filter
+// entry kh = oy + 2a + qy - 1, kw = ox + 2b + qx - 1 (zero outside 0..2): one launch stages dy once for both gradients.
 static inline size_t spd_pack_items(int Cout, int Cup) {
   return (size_t)((Cup + 127) / 128) * 4 * ((Cout + 15) / 16) * (SP_WST / 2) * 8;
 }
-__device__ __forceinline__ void spd_pack_item(const float* __restrict__ w, unsigned short* __restrict__ out, size_t i, int Cout, int CinTot, int Cup) {
+__device__ __forceinline__ void spd_pack_item(const float* __restrict__ w, unsigned short* __restrict__ out, size_t i, int Cout, int CinTot, int Cup,
+                                              bool vskip = false) {
   const int nkt = 4 * ((Cout + 15) / 16);
   size_t r = i;
   const int j = (int)(r % 8); r /= 8;
@@ -83,7 +88,11 @@ __device__ __forceinline__ void spd_pack_item(const float* __restrict__ w, unsig
   const int q = chunk & 3, py = q >> 1, px = q & 1;
   const int co = (chunk >> 2) * 16 + half * 8 + j, ci = mt * 128 + (2 * h + mx) * 32 + col;
   float v = 0.f;
-  if (co < Cout && ci < Cup) {
+  if (vskip && h == 1) {
+    const int vch = mx * 32 + col, par = vch >> 4, c = Cup + (vch & 15);
+    const int kh = (par >> 1) + 2 * a + py - 1, kw = (par & 1) + 2 * b + px - 1;
+    if (co < Cout && c < CinTot && kh >= 0 && kh <= 2 && kw >= 0 && kw <= 2) v = w[((size_t)co * CinTot + c) * 9 + kh * 3 + kw];
+  } else if (co < Cout && ci < Cup) {
     const float* wp = w + ((size_t)co * CinTot + ci) * 9;
     const int kh0 = (py == 0) ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), kh1 = (py == 0) ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
     const int kw0 = (px == 0) ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), kw1 = (px == 0) ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);

@@ -191,13 +191,13 @@ def _use_sp(N, Ho, Wo, Cout):
     return Cout >= 32 and wgs >= 128
 
 
-def _use_spd(N, Ho, Wo, Cup):
+def _use_spd(N, Ho, Wo, Cup, Csk=0):
     """data gradient of a decoder conv1's up-sampled channels on sc_conv3x3_sp_dgrad?  (tools/bench_sp.py, us, batch 16, against
     sc_conv3x3_bx3(down0) on the same channels: decoder.blocks.0 336 -> 250, blocks.1 140 -> 129, blocks.2 148 -> 83; blocks.3 / .4 have
     64 / 32 such channels for the kernel's 128-channel tiles: 176 -> 190, 285 -> 500 -- they keep the 3x3 form)"""
     if _SP == "0" or Ho % 2 or Wo % 2:
         return False
-    return _SP == "all" or Cup >= 128
+    return _SP == "all" or Cup >= 128 or (Csk and _lib.load().sc_spd_vskip_ok(Cup, Csk))       # (.. or ONE launch for both gradients)
 
 
 def _use_ksplit(N, HW, K, M, ks=1):
@@ -683,7 +683,8 @@ class HyperStarcopUNet(nn.Module):
                     cu = op["ins"][0].C
                     ent["spd"] = torch.empty(lib.sc_packed_weight_floats_spd(co, cu), dtype=torch.float32, device=dev)
                     ent["sp_cu"] = cu
-                    if ci > cu and ent.get("bB") is None:
+                    ent["spd_vskip"] = bool(ci > cu and lib.sc_spd_vskip_ok(cu, ci - cu))     # decoder.blocks.3: skip gradient in the same launch
+                    if ci > cu and ent.get("bB") is None and not ent["spd_vskip"]:
                         ent["bB"] = torch.empty(lib.sc_packed_weight_floats_bx3(co, ci, 32, 1, tb_), dtype=torch.float32, device=dev)
                         ent["bB_off"] = ent["bB"].numel() // (-(-ci // 32)) * (cu // 32)
                 self._wpk[i] = ent
@@ -725,8 +726,9 @@ class HyperStarcopUNet(nn.Module):
                     starts.append(nblk)
                     nblk += -(-total // 256)
                 if ent.get("spd") is not None and need_bwd:
-                    total = lib.sc_pack_work_items(co, ci, ks, ent["sp_cu"], 1, PACK_SPD)
-                    rows.append((conv.weight.data_ptr(), ent["spd"].data_ptr(), co, ci, ks, ent["sp_cu"], 1, PACK_SPD, total))
+                    tfl = 2 if ent["spd_vskip"] else 1
+                    total = lib.sc_pack_work_items(co, ci, ks, ent["sp_cu"], tfl, PACK_SPD)
+                    rows.append((conv.weight.data_ptr(), ent["spd"].data_ptr(), co, ci, ks, ent["sp_cu"], tfl, PACK_SPD, total))
                     starts.append(nblk)
                     nblk += -(-total // 256)
                 if ent.get("sp") is not None:
@@ -1365,15 +1367,27 @@ class HyperStarcopUNet(nn.Module):
             thin_b = (ent["tb"] is not None and not op.get("up") and ins[0].name not in written and res_of.get(ins[0].name) is None)
             fle = None
             if (op.get("up") and ent.get("spd") is not None and ent["terms_b"] == TERMS_F16X2 and self.split_bf16
-                    and _use_spd(N, Ho, Wo, ins[0].C)):
+                    and _use_spd(N, Ho, Wo, ins[0].C, conv.in_channels - ins[0].C)):
                 cu_ = ins[0].C          # up-sampled channels: 4 parity planes x 4 taps per low-resolution pixel; skip channels: the 3x3 form
                 fle = (2.0 * N * (Ho // 2) * (Wo // 2) * 16 * conv.out_channels * (-(-cu_ // 128) * 128)
-                       + 2.0 * N * Ho * Wo * 9 * conv.out_channels * (conv.in_channels - cu_))
+                       + (0.0 if ent["spd_vskip"] else 2.0 * N * Ho * Wo * 9 * conv.out_channels * (conv.in_channels - cu_)))
             tok = self._pb("k_conv3_thin_h (fwd+dgrad)" if thin_b else
                            self._bx3_family("dgrad") if ent["bx3_b"] else f"k_conv_mfma<{ks}> (fwd+dgrad)", flop,
                            4.0 * (2 * N * o.C * Ho * Wo + gin_elems + conv.weight.numel()), fle)
             if (op.get("up") and ent.get("spd") is not None and ent["terms_b"] == TERMS_F16X2 and self.split_bf16
-                    and _use_spd(N, Ho, Wo, ins[0].C)):
+                    and _use_spd(N, Ho, Wo, ins[0].C, conv.in_channels - ins[0].C)):
+                if ent["spd_vskip"]:
+                    # <= 64 up-sampled + <= 16 skip channels (decoder.blocks.3): the skip channels' gradient as virtual channels of the
+                    # 128-channel tile's second half -- dy (g, y) is staged ONCE for both gradients (289 us in two 3x3 launches before)
+                    t_up, t_sk = ins
+                    a.Cout, a.csplit = conv.in_channels, t_up.C
+                    a.wpk = ent["spd"].data_ptr()
+                    a.out0, a.out1 = plan.grad[t_up.name].data_ptr(), plan.grad[t_sk.name].data_ptr()
+                    a.accum0, a.accum1, a.down0 = (1 if t_up.name in written else 0), (1 if t_sk.name in written else 0), 0
+                    check(lib.sc_conv3x3_sp_dgrad(C.byref(a), st))
+                    written.add(t_up.name); written.add(t_sk.name)
+                    self._pe(tok)
+                    continue
                 # sub-pixel form: the up-sampled channels' gradient at half resolution from the four parity planes of dy (2.25x fewer
                 # MFMAs, 128 output channels per staged patch), the skip channels' by the 3x3 kernel on their own 32-wide tiles
                 t_up = ins[0]

@@ -206,41 +206,46 @@ def conv_sp(srcs, wpk, N, H, W, Cout, want_stats=False):
     return out, stats
 
 
-def pack_spd(w, cup, batched=False):
-    """decoder conv1 filter (Cout, Cup + Cskip, 3, 3) -> the parity / tap layout of sc_conv3x3_sp_dgrad"""
+def pack_spd(w, cup, batched=False, vskip=False):
+    """decoder conv1 filter (Cout, Cup + Cskip, 3, 3) -> the parity / tap layout of sc_conv3x3_sp_dgrad (vskip: with the skip
+    channels as virtual channels of the tile's second half)"""
     import numpy as np
     from starcop_amd._lib import PACK_SPD
     lib = _lib.load()
     co, ci = w.shape[0], w.shape[1]
     out = torch.full((lib.sc_packed_weight_floats_spd(co, cup),), float("nan"), device=DEV)
     if not batched:
-        check(lib.sc_pack_weights_spd(ptr(w), ptr(out), co, ci, cup, stream()))
+        check(lib.sc_pack_weights_spd(ptr(w), ptr(out), co, ci, cup, int(vskip), stream()))
         return out
-    total = lib.sc_pack_work_items(co, ci, 3, cup, 1, PACK_SPD)
+    total = lib.sc_pack_work_items(co, ci, 3, cup, 2 if vskip else 1, PACK_SPD)
     dt = np.dtype([("w", "<u8"), ("wpk", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"), ("ks", "<i4"), ("co_t", "<i4"),
                    ("tflip", "<i4"), ("bx3", "<i4"), ("total", "<u8")])
-    descs = torch.from_numpy(np.array([(w.data_ptr(), out.data_ptr(), co, ci, 3, cup, 1, PACK_SPD, total)], dtype=dt).view(np.uint8).copy()).to(DEV)
+    descs = torch.from_numpy(np.array([(w.data_ptr(), out.data_ptr(), co, ci, 3, cup, 2 if vskip else 1, PACK_SPD, total)], dtype=dt).view(np.uint8).copy()).to(DEV)
     starts = torch.zeros(1, dtype=torch.int32, device=DEV)
     _KEEP.extend([descs, starts])
     check(lib.sc_pack_weights_batch(ptr(descs), ptr(starts), 1, -(-total // 256), stream()))
     return out
 
 
-def conv_sp_dgrad(dy_src, wpk, N, H, W, Cup, absmax=None, accum_into=None):
-    """sc_conv3x3_sp_dgrad: dy_src = the BNBWD operand of the layer's output (H x W) -> gradient of the half-resolution source"""
+def conv_sp_dgrad(dy_src, wpk, N, H, W, Cup, absmax=None, accum_into=None, cskip=0, skip_into=None):
+    """sc_conv3x3_sp_dgrad: dy_src = the BNBWD operand of the layer's output (H x W) -> gradient of the half-resolution source;
+    cskip > 0 (vskip pack): also the skip channels' full-resolution gradient -> returns (dprev, dskip)"""
     from starcop_amd._lib import TERMS_F16X2
     lib = _lib.load()
     a = sc_conv_args()
     a.nsrc = 1
     a.src[0] = dy_src
     a.wpk = wpk.data_ptr()
-    a.N, a.H, a.W, a.Cout, a.ks, a.co_t = N, H, W, Cup, 3, 32
+    a.N, a.H, a.W, a.Cout, a.ks, a.co_t = N, H, W, Cup + cskip, 3, 32
     out = accum_into if accum_into is not None else torch.full((N, Cup, H // 2, W // 2), float("nan"), device=DEV)
-    a.out0, a.out1, a.csplit = out.data_ptr(), None, Cup
-    a.accum0, a.accum1 = (1 if accum_into is not None else 0), 0
+    osk = None
+    if cskip:
+        osk = skip_into if skip_into is not None else torch.full((N, cskip, H, W), float("nan"), device=DEV)
+    a.out0, a.out1, a.csplit = out.data_ptr(), (osk.data_ptr() if cskip else None), Cup
+    a.accum0, a.accum1 = (1 if accum_into is not None else 0), (1 if skip_into is not None else 0)
     a.add0 = a.add1 = None
     a.stats = None
     a.terms, a.down0 = TERMS_F16X2, 0
     a.absmax = absmax.data_ptr() if absmax is not None else None
     check(lib.sc_conv3x3_sp_dgrad(C.byref(a), stream()))
-    return out
+    return (out, osk) if cskip else out

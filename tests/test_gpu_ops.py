@@ -456,6 +456,17 @@ def test_conv_sp_dgrad_matches_upsample_backward(hip, cup, csk, cout, H, W):
     o0 = dev(old).clone()
     conv_sp_dgrad(src, wpk, N, H, W, cup, absmax=amax, accum_into=o0)
     assert relerr(o0, ref + old.double()) < BX3_TOL
+    # <= 64 up-sampled and <= 16 skip channels (smp's decoder.blocks.3): the skip channels' full-resolution gradient from the same launch
+    if cup <= 64 and 0 < csk <= 16:
+        ref_sk = F.conv_transpose2d(dy.double(), w.double(), padding=1)[:, cup:]
+        for batched in (False, True):
+            wv = pack_spd(wd, cup, batched=batched, vskip=True)
+            o_up, o_sk = conv_sp_dgrad(src, wv, N, H, W, cup, absmax=amax, cskip=csk)
+            assert relerr(o_up, ref) < BX3_TOL and relerr(o_sk, ref_sk) < BX3_TOL
+        olds = rnd(N, csk, H, W, seed=10)
+        o1 = dev(olds).clone()
+        conv_sp_dgrad(src, wv, N, H, W, cup, absmax=amax, accum_into=dev(old).clone(), cskip=csk, skip_into=o1)
+        assert relerr(o1, ref_sk + olds.double()) < BX3_TOL
 
 
 @pytest.mark.parametrize("cin,cout,H,W,two", [(16, 64, 32, 32, False), (32, 16, 36, 70, True), (32, 32, 24, 40, False), (48, 40, 21, 32, False), (32, 64, 16, 32, True),

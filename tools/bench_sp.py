@@ -99,4 +99,18 @@ if not os.environ.get("SP_ONLY"):
         o = fs(); torch.cuda.synchronize()
         err = float((o - ref[0]).abs().max() / ref[0].abs().max())
         t_sp = timeit(fs)
-        print(f"{name}.dgrad {cout}->{cu} {H}^2: 3x3 + down-sum {t_ref:7.1f} us | sub-pixel {t_sp:7.1f} us x{t_ref/t_sp:4.2f} | diff {err:.1e}", flush=True)
+        extra = ""
+        if cs:
+            # the skip channels' gradient: its own 3x3 launch on a 32-wide pack (what the network runs beside either form) ...
+            wsk = pack_bx3(w[:, cu:].contiguous(), 32, 1, TERMS_F16X2)
+            osk = [torch.empty(N, cs, H, W, device=DEV)]
+            t_sk = timeit(lambda: conv_mfma([src], wsk, N, H, W, cs, 3, 32, outs=osk, bx3=True, terms=TERMS_F16X2, absmax=amax))
+            extra = f" | skip channels' 3x3 launch {t_sk:6.1f} us"
+            if lib.sc_spd_vskip_ok(cu, cs):      # ... or riding along as virtual channels of the sub-pixel launch
+                wv = pack_spd(w, cu, vskip=True)
+                fv = lambda: conv_sp_dgrad(src, wv, N, H, W, cu, absmax=amax, cskip=cs)
+                ou, ok_ = fv(); torch.cuda.synchronize()
+                e2 = max(float((ou - ref[0]).abs().max() / ref[0].abs().max()), float((ok_ - osk[0]).abs().max() / osk[0].abs().max()))
+                t_v = timeit(fv)
+                extra += f" | ONE launch for both (virtual skip channels) {t_v:6.1f} us vs {t_ref + t_sk:6.1f} (diff {e2:.1e})"
+        print(f"{name}.dgrad {cout}->{cu} {H}^2: 3x3 + down-sum {t_ref:7.1f} us | sub-pixel {t_sp:7.1f} us x{t_ref/t_sp:4.2f} | diff {err:.1e}{extra}", flush=True)
