@@ -210,3 +210,28 @@ def test_fused_block_rule():
     # rows / workspace are pure functions of the shape
     assert lib.sc_irt_rows(1, 16, 256, 256, 2) == 16 * 32 * 8 and lib.sc_irt_bwd_rows(16, 96, 256, 256) == 512
     assert lib.sc_irt_bwd_workspace_floats(16, 16, 96, 256, 256) > 16 * 16 * 256 * 256
+
+
+def test_sub_pixel_rules():
+    """which decoder conv1 launches run as sub-pixel convolutions (network._use_sp / _use_spd, measured per layer: DESIGN.md 15,
+    profiles/r05_bench_sp_b16.txt): forward from 32 output channels and 128 work-groups, the data gradient of the up-sampled channels
+    from 128 of them -- or, with <= 64 up-sampled and <= 16 skip channels, as ONE launch with the skip channels' gradient
+    (decoder.blocks.3) -- and nothing at odd sizes; pure host logic + the library's host-side helpers"""
+    from starcop_amd import _lib, network as nw
+    if nw._SP != "1":
+        pytest.skip("STARCOP_SP overridden")
+    # forward at 16 x 512^2 tiles: decoder.blocks.0 (32^2 output, 256 couts) .. blocks.3 (256^2, 32 couts) yes; blocks.4 (16 couts) no
+    assert nw._use_sp(16, 32, 32, 256) and nw._use_sp(16, 64, 64, 128) and nw._use_sp(16, 128, 128, 64) and nw._use_sp(16, 256, 256, 32)
+    assert not nw._use_sp(16, 512, 512, 16)
+    assert not nw._use_sp(4, 32, 32, 256)            # batch 4: 32 work-groups of 8 waves for decoder.blocks.0
+    assert nw._use_sp(64, 32, 32, 256)               # batch 64: 512 (1131 -> 778 us)
+    assert not nw._use_sp(16, 33, 64, 64)            # odd output size: no half-resolution source
+    # data gradient: 1280 / 256 / 128 up-sampled channels yes, 64 only together with its <= 16 skip channels, 32 no
+    assert nw._use_spd(16, 32, 32, 1280, 96) and nw._use_spd(16, 64, 64, 256, 32) and nw._use_spd(16, 128, 128, 128, 24)
+    assert nw._use_spd(16, 256, 256, 64, 16) and not nw._use_spd(16, 256, 256, 64, 0) and not nw._use_spd(16, 512, 512, 32, 0)
+    lib = _lib.load()
+    assert lib.sc_spd_vskip_ok(64, 16) == 1 and lib.sc_spd_vskip_ok(128, 16) == 0 and lib.sc_spd_vskip_ok(64, 24) == 0
+    # statistics rows / packed sizes are pure functions of the shape
+    assert lib.sc_sp_stat_rows(16, 64, 64) == 16 * 1 * 4 and lib.sc_sp_stat_rows(16, 32, 32) == 16          # 8 x 32 resp. 16 x 16 low-resolution tiles
+    assert lib.sc_packed_weight_floats_sp(128, 256, 32) == 4 * (16 + 4 * 2) * 2048 * 4
+    assert lib.sc_packed_weight_floats_spd(128, 256) == 2 * 4 * 8 * 2048 * 4
