@@ -76,14 +76,20 @@ struct ConvSPP {
 };
 
 constexpr int SP_SMEM_W = 2 * SP_WST * 16;               // filter stages, double-buffered (64 KB)
-template <int TW> constexpr int sp_npx() { return (256 / TW + 2) * (TW + 2); }
+// patch pitch in 16-byte entries: TW + 2 pixels, padded for the 16-wide tile (SP_PC16) -- its operand reads take two 16-entry row pieces
+// per half-wave, which collide in the LDS banks at the natural pitch 18 (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.35)
+#ifndef SP_PC16
+#define SP_PC16 18
+#endif
+template <int TW> constexpr int sp_pc() { return TW == 16 ? SP_PC16 : TW + 2; }
+template <int TW> constexpr int sp_npx() { return (256 / TW + 2) * sp_pc<TW>(); }
 template <int TW> constexpr int sp_smem_bytes() { return SP_SMEM_W + 2 * 2 * 2 * sp_npx<TW>() * 16 + 8 * 32 * 2 * 4; }
 
 template <int TW>
 __global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
   constexpr int NT = 2;
   constexpr int TH = 256 / TW;
-  constexpr int PC = TW + 2, NPX = sp_npx<TW>();
+  constexpr int PC = sp_pc<TW>(), NPX = sp_npx<TW>();
   constexpr int NR = 3;
   constexpr int WST = SP_WST;                // 16-byte filter entries per chunk
   constexpr int NWV = WST / 512;
@@ -389,7 +395,7 @@ template <int TW>
 __global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
   constexpr int NT = 2;
   constexpr int TH = 256 / TW;
-  constexpr int PC = TW + 2, NPX = sp_npx<TW>();
+  constexpr int PC = sp_pc<TW>(), NPX = sp_npx<TW>();
   constexpr int NR = 3;
   constexpr int WST = SP_WST;
   constexpr int NWV = WST / 512;

@@ -115,3 +115,55 @@ def test_fuzz_concat_upsample(hip, split_mode, seed):
     dys = make_src(dev(g), cout, SRC_RAW)
     assert relerr(wgrad_mfma(dys, [s0, s1], N, H, W, cout, c0 + c1, 3, bx3=True), wz.grad) < 2e-5
     assert relerr(wgrad_mfma(dys, [s0, s1], N, H, W, cout, c0 + c1, 3), wz.grad) < 2e-5
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_conv_sp(hip, seed):
+    """seeded random decoder-conv1 shapes through the sub-pixel kernels (sc_conv3x3_sp, sc_conv3x3_sp_dgrad) against float64 of the
+    reference's op sequence (interpolate(nearest, x2) -> cat -> conv3x3 and its autograd): ragged low-resolution planes of both tile
+    shapes, channel counts off the 16-channel chunk / 32-channel block / 128-channel tile, with and without skip channels"""
+    from hip_ops import conv_sp, conv_sp_dgrad, pack_sp, pack_spd
+    from starcop_amd import _lib
+    from starcop_amd._lib import ACT_NONE
+    rng = np.random.default_rng(5000 + seed)
+    N = int(rng.integers(1, 4))
+    Hl, Wl = int(rng.integers(2, 24)), int(rng.integers(2, 45))
+    H, W = 2 * Hl, 2 * Wl
+    c0 = int(rng.choice([8, 16, 24, 40, 64, 72, 136]))
+    c1 = int(rng.choice([0, 8, 12, 16, 24, 40]))
+    cout = int(rng.choice([16, 24, 32, 40, 64, 72]))
+    prev, w = _rnd(rng, N, c0, Hl, Wl), _rnd(rng, cout, c0 + c1, 3, 3, scale=0.2)
+    sc0, sh0 = _rnd(rng, c0) * 0.3 + 1.0, _rnd(rng, c0) * 0.2
+    up = F.interpolate(F.relu(prev * sc0[None, :, None, None] + sh0[None, :, None, None]), scale_factor=2, mode="nearest")
+    srcs = [make_src(dev(prev), c0, SRC_AFFINE, act=ACT_RELU, up=1, cst=cst_affine(sc0, sh0))]
+    xin = up
+    if c1:
+        skip = _rnd(rng, N, c1, H, W)
+        sc1, sh1 = _rnd(rng, c1) * 0.3 + 1.0, _rnd(rng, c1) * 0.2
+        xin = torch.cat([up, skip * sc1[None, :, None, None] + sh1[None, :, None, None]], 1)
+        srcs.append(make_src(dev(skip), c1, SRC_AFFINE, act=ACT_NONE, cst=cst_affine(sc1, sh1)))
+    ref = F.conv2d(xin.double(), w.double(), padding=1)
+    wd = dev(w)
+    out, stats = conv_sp(srcs, pack_sp(wd, c0, batched=bool(seed & 1)), N, H, W, cout, want_stats=True)
+    assert relerr(out, ref) < 1e-5
+    st = stats.double().sum(0).cpu()
+    assert relerr(st[:, 0], ref.sum((0, 2, 3))) < 1e-4 and relerr(st[:, 1], (ref ** 2).sum((0, 2, 3))) < 1e-4
+    # data gradient of the up-sampled channels (and, where the tile has room, of the skip channels) from a BatchNorm-backward source
+    g, y = _rnd(rng, N, cout, H, W), _rnd(rng, N, cout, H, W)
+    a, b = _rnd(rng, cout) * 0.2 + 1, _rnd(rng, cout) * 0.2
+    A, B, D = _rnd(rng, cout), _rnd(rng, cout) * 0.1, _rnd(rng, cout) * 0.1
+    yh = y * a[None, :, None, None] + b[None, :, None, None]
+    dy = torch.where(yh > 0, g, torch.zeros(())) * A[None, :, None, None] + B[None, :, None, None] * y + D[None, :, None, None]
+    cst = torch.zeros(cout, SC_CST); cst[:, 0], cst[:, 1], cst[:, 2], cst[:, 3], cst[:, 4] = a, b, A, B, D
+    dys = make_src(dev(g), cout, SRC_BNBWD, act=ACT_RELU, cst=dev(cst), aux=dev(y))
+    full = F.conv_transpose2d(dy.double(), w.double(), padding=1)
+    ref_up = F.avg_pool2d(full[:, :c0], 2) * 4
+    amax = torch.tensor([float((A[None, :, None, None] * g).abs().max())], device="cuda")
+    vs = bool(c1) and bool(_lib.load().sc_spd_vskip_ok(c0, c1))
+    wpk = pack_spd(wd, c0, batched=not (seed & 1), vskip=vs)
+    if vs:
+        d_up, d_sk = conv_sp_dgrad(dys, wpk, N, H, W, c0, absmax=amax, cskip=c1)
+        assert relerr(d_sk, full[:, c0:]) < 1e-5
+    else:
+        d_up = conv_sp_dgrad(dys, wpk, N, H, W, c0, absmax=amax)
+    assert relerr(d_up, ref_up) < 1e-5
