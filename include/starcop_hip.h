@@ -225,6 +225,19 @@ size_t sc_packed_weight_floats_spd(int Cout, int Cup);
 int sc_spd_vskip_ok(int Cup, int Cskip);
 int sc_pack_weights_spd(const float* w_oihw, float* wpk, int Cout, int CinTotal, int Cup, int vskip, sc_stream stream);
 int sc_conv3x3_sp_dgrad(const sc_conv_args* a, sc_stream stream);
+/* ... and the weight gradient of its up-sampled channels as a PLAIN GEMM: up(x) is constant over 2x2 blocks of the output grid, so
+ * dW[co][ci][kh][kw] = sum_q x[ci][q] * S_(kh,kw)[co][q] with S the tap-aligned 2x2 box sums of dy -- nine GEMMs over the low-resolution
+ * pixels with no spatial shift, a quarter of the 3x3 form's multiply-adds (csrc/conv_spw.hip: box sums + exact two-fp16-term split in
+ * one pass over (g, y); the activated, split source; a two-term fp16 GEMM; a fixed-order reduction of its K slices).
+ *   sc_conv3x3_sp_wgrad: sc_wgrad_args with nsrc = 1, src[0] = the half-resolution tensor (up = 1; RAW / AFFINE; xbound[0]), dy = the
+ *   layer's output gradient (H x W, even; normally SC_SRC_BNBWD; absmax), Cin = the FILTER's total input channels, terms =
+ *   SC_TERMS_F16X2; writes dw[co][ci][3][3] for ci < src[0].C inside the [Cout][Cin][3][3] gradient (part / part_floats unused);
+ *   `ws`: sc_sp_wgrad_workspace_bytes(N, H, W, Cout, src[0].C) bytes, 256-byte aligned.
+ *   sc_wgrad_scatter_cols: a dense [Cout][Ccols][3][3] gradient (the skip channels', from sc_conv3x3_wgrad_bx3 on the skip source
+ *   alone) into columns [col_off, col_off + Ccols) of the [Cout][CinTotal][3][3] gradient. */
+size_t sc_sp_wgrad_workspace_bytes(int N, int H, int W, int Cout, int Cup);
+int sc_conv3x3_sp_wgrad(const sc_wgrad_args* a, void* ws, size_t ws_bytes, sc_stream stream);
+int sc_wgrad_scatter_cols(const float* src, float* dw, int Cout, int Ccols, int CinTotal, int col_off, sc_stream stream);
 
 /* weight gradient of the same thin layers (Cout <= 16, Cin = 16 | 32, one source which may be upsampled) with two fp16 terms on
  * v_mfma_f32_16x16x32_f16: same sc_wgrad_args as sc_conv2d_wgrad_mfma with terms = SC_TERMS_F16X2 (absmax = the dy range hint),

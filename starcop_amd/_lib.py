@@ -145,6 +145,9 @@ SIGNATURES = {
     "sc_pack_weights_spd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sc_spd_vskip_ok": (_i, [_i, _i]),
     "sc_conv3x3_sp_dgrad": (_i, [C.POINTER(sc_conv_args), _vp]),
+    "sc_sp_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "sc_conv3x3_sp_wgrad": (_i, [C.POINTER(sc_wgrad_args), _vp, _sz, _vp]),
+    "sc_wgrad_scatter_cols": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sc_binary_opening": (_i, [_vp, _f, _i, _vp, _vp, _i, _i, _i, _vp]),
     "sc_threshold_confusion": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "sc_gather_augment": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -177,6 +177,7 @@ def _use_irt(N, Cin, Hd, Hin, Win, stride):
 # (16 output channels: half-empty MFMA rows) 196-213, level with sc_conv3x3_thin16's 202, stays there.  "1" = that rule, "all" =
 # every decoder conv1 (tests), "0" = off.
 _SP = os.environ.get("STARCOP_SP", "1")
+_EXP_NO_WGRAD = os.environ.get("STARCOP_EXP_NO_WGRAD", "0") == "1"      # tools/: elimination experiment only
 
 
 def _use_sp(N, Ho, Wo, Cout):
@@ -198,6 +199,17 @@ def _use_spd(N, Ho, Wo, Cup, Csk=0):
     if _SP == "0" or Ho % 2 or Wo % 2:
         return False
     return _SP == "all" or Cup >= 128 or (Csk and _lib.load().sc_spd_vskip_ok(Cup, Csk))       # (.. or ONE launch for both gradients)
+
+
+def _use_spw(N, Ho, Wo, Cout, Cup):
+    """weight gradient of a decoder conv1's up-sampled channels as the box-sum GEMM of conv_spw.hip?  up(x) is constant over 2x2 output
+    blocks, so dW[kh][kw] = sum_q x[q] S_(kh,kw)[q] with S tap-aligned 2x2 box sums of dy: nine plain GEMMs over the low-resolution
+    pixels, a quarter of the multiply-adds -- but the nine box-sum planes (2.25x the size of dy, as two fp16 terms) are written and
+    read once, which only pays where the layer is matrix-bound (tools/bench_sp.py, us at batch 16, up-sampled channels alone, 3x3 form
+    -> box-sum GEMM: decoder.blocks.0 338 -> 222, blocks.1 143 -> 147, blocks.2 148 -> 228, blocks.3 186 -> 482)"""
+    if _SP == "0" or Ho % 2 or Wo % 2:
+        return False
+    return _SP == "all" or Cup >= 512
 
 
 def _use_ksplit(N, HW, K, M, ks=1):
@@ -587,6 +599,22 @@ class HyperStarcopUNet(nn.Module):
                     ws = max(ws, lib.sc_head_wgrad_workspace_floats(N, conv.in_channels, Ho, Wo))
                 elif op["type"] == "dw":
                     n_dw += conv.out_channels * 9
+            # decoder conv1 weight gradients as box-sum GEMMs (conv_spw.hip): box-sum planes, split source, K-slice partials; the skip
+            # channels' dense gradient before it is scattered into its columns
+            spw_b, spw_sk = 0, 0
+            for op in self._ops:
+                if op["type"] == "conv3" and op.get("up"):
+                    cv, o_ = op["conv"], op["out"]
+                    Hq, Wq = H >> o_.shift, W >> o_.shift
+                    cu_ = op["ins"][0].C
+                    if _use_spw(N, Hq, Wq, cv.out_channels, cu_):
+                        spw_b = max(spw_b, lib.sc_sp_wgrad_workspace_bytes(N, Hq, Wq, cv.out_channels, cu_))
+                        if cv.in_channels > cu_:
+                            spw_sk = max(spw_sk, cv.out_channels * (cv.in_channels - cu_) * 9)
+                            ws = max(ws, lib.sc_wgrad_bx3_workspace_floats(N, Hq, Wq, cv.out_channels, cv.in_channels - cu_),
+                                     lib.sc_wgrad_workspace_floats(N, Hq, Wq, cv.out_channels, cv.in_channels - cu_, 3))
+            plan.spw_ws = torch.empty(spw_b + 256, dtype=torch.uint8, device=dev) if spw_b else None
+            plan.spw_skip = torch.empty(spw_sk, **f32) if spw_sk else None
             plan.ws = torch.empty(ws, **f32)
             plan.ws_floats = ws
             # pointwise weight gradients keep their K-slice partials in buffers of their own until ONE batched reduction at the
@@ -1067,6 +1095,8 @@ class HyperStarcopUNet(nn.Module):
             """run fn(stream_handle) on the weight-gradient stream, ordered after everything queued on the main stream.  (One fork per
             launch: serving two to eight launches with one fork -- fewer markers in the main queue -- measured 0.5-2.5 % SLOWER, the
             weight gradients then start too late to fill the gaps of the data-gradient chain.)"""
+            if _EXP_NO_WGRAD:
+                return           # elimination experiment (results wrong): what the step costs without any weight-gradient launch
             if side is None:
                 fn(st)
             else:
@@ -1315,14 +1345,52 @@ class HyperStarcopUNet(nn.Module):
                 for k_, t_ in enumerate(ins):
                     wa.xbound[k_] = self._xbound(plan, t_)
             flop = 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * ks * ks
-            wfn = (lib.sc_conv3x3_wgrad_bx3 if (self.split_bf16 and ks == 3 and conv.out_channels >= 32 and conv.in_channels >= 32)
-                   else lib.sc_conv2d_wgrad_mfma)     # 16-channel layers outside the cases below stay on the fp32 MFMA
+            if (op.get("up") and plan.spw_ws is not None and self.split_bf16 and self._terms[1] == TERMS_F16X2
+                    and _use_spw(N, Ho, Wo, conv.out_channels, ins[0].C)):
+                # decoder conv1 with many up-sampled channels: their filter gradient as nine plain GEMMs between the low-resolution source
+                # and tap-aligned 2x2 box sums of dy (conv_spw.hip); the skip channels' columns from the 3x3 kernel on the skip source alone
+                cu_ = ins[0].C
+                wu = sc_wgrad_args()
+                wu.dy, wu.nsrc = dy, 1
+                wu.src[0] = wa.src[0]
+                wu.N, wu.H, wu.W, wu.Cout, wu.Cin, wu.ks = N, Ho, Wo, o.C, conv.in_channels, 3
+                wu.part, wu.part_floats, wu.dw = None, 0, gv(conv.weight).data_ptr()
+                wu.terms, wu.absmax = self._terms[1], gmax_slot.get(o.name)
+                wu.xbound[0] = self._xbound(plan, ins[0])
+                wsb = C.c_void_p((plan.spw_ws.data_ptr() + 255) & ~255)
+                nb = plan.spw_ws.numel() - 256
+                tok = self._pb("k_wgrad3_bx3 (+reduce)", flop, 0.0, 2.0 * N * (Ho // 2) * (Wo // 2) * 9 * conv.out_channels * cu_
+                               + 2.0 * N * Ho * Wo * 9 * conv.out_channels * (conv.in_channels - cu_))
+                wgrad_launch(lambda sx, wu=wu, wsb=wsb, nb=nb: check(lib.sc_conv3x3_sp_wgrad(C.byref(wu), wsb, nb, sx)))
+                if len(ins) == 2:
+                    csk_ = ins[1].C
+                    wk = sc_wgrad_args()
+                    wk.dy, wk.nsrc = dy, 1
+                    wk.src[0] = wa.src[1]
+                    wk.N, wk.H, wk.W, wk.Cout, wk.Cin, wk.ks = N, Ho, Wo, o.C, csk_, 3
+                    wk.part, wk.part_floats, wk.dw = plan.ws.data_ptr(), plan.ws_floats, plan.spw_skip.data_ptr()
+                    wk.terms, wk.absmax = self._terms[1], gmax_slot.get(o.name)
+                    wk.xbound[0] = self._xbound(plan, ins[1])
+                    wsk = lib.sc_conv3x3_wgrad_bx3 if (o.C >= 32 and csk_ >= 32) else lib.sc_conv2d_wgrad_mfma
+
+                    def skip_cols(sx, wk=wk, wsk=wsk, csk_=csk_, cu_=cu_, conv=conv, o=o):
+                        check(wsk(C.byref(wk), sx))
+                        check(lib.sc_wgrad_scatter_cols(ptr(plan.spw_skip), ptr(gv(conv.weight)), o.C, csk_, conv.in_channels, cu_, sx))
+                    wgrad_launch(skip_cols)
+                self._pe(tok)
+                wfn = None
+            else:
+                wfn = (lib.sc_conv3x3_wgrad_bx3 if (self.split_bf16 and ks == 3 and conv.out_channels >= 32 and conv.in_channels >= 32)
+                       else lib.sc_conv2d_wgrad_mfma)     # 16-channel layers outside the cases below stay on the fp32 MFMA
             if (self.split_bf16 and self.thin16 and ks == 3 and self._terms[1] == TERMS_F16X2 and len(ins) == 1
                     and conv.out_channels <= 16 and conv.in_channels in (16, 32) and Wo % 2 == 0):
                 wfn = lib.sc_conv3x3_wgrad_thin16     # decoder.blocks.4: two fp16 terms on the 16x16x32 MFMA (was MFMA-bound in fp32)
-            tok = self._pb("k_wgrad3_bx3 (+reduce)" if wfn is lib.sc_conv3x3_wgrad_bx3 else
-                           "k_wgrad_thin_h (+reduce)" if wfn is lib.sc_conv3x3_wgrad_thin16 else f"k_wgrad_mfma<{ks}> (+reduce)", flop)
-            if ty == "pw" and i in plan.pw_part:
+            tok = None if wfn is None else self._pb(
+                "k_wgrad3_bx3 (+reduce)" if wfn is lib.sc_conv3x3_wgrad_bx3 else
+                "k_wgrad_thin_h (+reduce)" if wfn is lib.sc_conv3x3_wgrad_thin16 else f"k_wgrad_mfma<{ks}> (+reduce)", flop)
+            if wfn is None:
+                pass                      # (the box-sum GEMM path above has queued this layer's weight gradient)
+            elif ty == "pw" and i in plan.pw_part:
                 wa.part = plan.pw_part[i].data_ptr(); wa.part_floats = plan.pw_part[i].numel()
                 pend = sc_wgrad_pending()
                 wdef = (lib.sc_conv1x1_wgrad_pw3 if _use_pw3(2, N, Ho * Wo, conv.in_channels, conv.out_channels)

@@ -249,3 +249,25 @@ def conv_sp_dgrad(dy_src, wpk, N, H, W, Cup, absmax=None, accum_into=None, cskip
     a.absmax = absmax.data_ptr() if absmax is not None else None
     check(lib.sc_conv3x3_sp_dgrad(C.byref(a), stream()))
     return (out, osk) if cskip else out
+
+
+def wgrad_sp(dy, src_lo, N, H, W, Cout, CinTotal, absmax=None, dw=None):
+    """sc_conv3x3_sp_wgrad: the up-sampled channels' columns of the (Cout, CinTotal, 3, 3) gradient"""
+    from starcop_amd._lib import TERMS_F16X2
+    lib = _lib.load()
+    a = sc_wgrad_args()
+    a.dy = dy
+    a.nsrc = 1
+    a.src[0] = src_lo
+    a.N, a.H, a.W, a.Cout, a.Cin, a.ks = N, H, W, Cout, CinTotal, 3
+    a.terms = TERMS_F16X2
+    a.absmax = absmax.data_ptr() if absmax is not None else None
+    a.part, a.part_floats = None, 0
+    if dw is None:
+        dw = torch.full((Cout, CinTotal, 3, 3), float("nan"), device=DEV)
+    a.dw = dw.data_ptr()
+    nb = lib.sc_sp_wgrad_workspace_bytes(N, H, W, Cout, src_lo.C)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    _KEEP.append(ws)
+    check(lib.sc_conv3x3_sp_wgrad(C.byref(a), ptr(ws), nb, stream()))
+    return dw

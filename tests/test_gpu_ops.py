@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from hip_ops import (dev, DEV, conv_mfma, conv_sp, conv_sp_dgrad, cst_affine, pack, pack_bx3, pack_sp, pack_spd, relerr, wgrad_mfma)  # noqa: E402
+from hip_ops import (dev, DEV, conv_mfma, conv_sp, conv_sp_dgrad, cst_affine, pack, pack_bx3, pack_sp, pack_spd, relerr, wgrad_mfma, wgrad_sp)  # noqa: E402
 from starcop_amd import _lib  # noqa: E402
 from starcop_amd._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD, STAT_CONV1,
                               STAT_DW, STAT_STEM, check, make_src, ptr, stream)  # noqa: E402
@@ -467,6 +467,41 @@ def test_conv_sp_dgrad_matches_upsample_backward(hip, cup, csk, cout, H, W):
         o1 = dev(olds).clone()
         conv_sp_dgrad(src, wv, N, H, W, cup, absmax=amax, accum_into=dev(old).clone(), cskip=csk, skip_into=o1)
         assert relerr(o1, ref_sk + olds.double()) < BX3_TOL
+
+
+@pytest.mark.parametrize("cup,csk,cout,H,W,N", [(64, 16, 32, 16, 64, 2), (128, 24, 64, 24, 80, 2), (32, 0, 16, 20, 72, 3), (256, 32, 128, 8, 12, 2),
+                                                 (40, 9, 24, 36, 70, 1), (72, 8, 300, 12, 20, 2), (1280, 96, 40, 4, 6, 4)])
+def test_conv_sp_wgrad_matches_upsample_conv_autograd(hip, cup, csk, cout, H, W, N):
+    """filter gradient of conv3x3(cat([nearest_up2(prev), skip])) for the up-sampled channels -- float64 autograd of the reference's op
+    sequence -- against sc_conv3x3_sp_wgrad (nine plain GEMMs between the low-resolution source and tap-aligned 2x2 box sums of dy):
+    BatchNorm / ReLU-backward operand with a range hint, BatchNorm + ReLU input, K not a multiple of the 32-pixel stage, row / column
+    counts off the 256 x 128 tile, both column-block variants; the skip channels' columns through sc_wgrad_scatter_cols"""
+    from starcop_amd._lib import TERMS_F16X2
+    g, yraw = rnd(N, cout, H, W, seed=1), rnd(N, cout, H, W, seed=2)
+    prev = rnd(N, cup, H // 2, W // 2, seed=3)
+    sc0, sh0 = rnd(cup, seed=4) * 0.3 + 1, rnd(cup, seed=5) * 0.2
+    cst = torch.zeros(cout, SC_CST)
+    cst[:, 0], cst[:, 1] = rnd(cout, seed=6) * 0.3 + 1, rnd(cout, seed=7) * 0.2
+    cst[:, 2], cst[:, 3], cst[:, 4] = rnd(cout, seed=8) * 0.5 + 1, rnd(cout, seed=9) * 0.1, rnd(cout, seed=10) * 0.05
+    yh = yraw * cst[:, 0][None, :, None, None] + cst[:, 1][None, :, None, None]
+    dy = torch.where(yh > 0, g, torch.zeros_like(g)) * cst[:, 2][None, :, None, None] + yraw * cst[:, 3][None, :, None, None] + cst[:, 4][None, :, None, None]
+    up = F.interpolate(F.relu(prev * sc0[None, :, None, None] + sh0[None, :, None, None]), scale_factor=2, mode="nearest").double()
+    skip = rnd(N, max(csk, 1), H, W, seed=11)[:, :csk].double()
+    xin = torch.cat([up, skip], 1).requires_grad_(False)
+    w = torch.zeros(cout, cup + csk, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xin, w, padding=1).backward(dy.double())
+    ref = w.grad
+    amax = torch.tensor([float((cst[:, 2][None, :, None, None] * g).abs().max())], device=DEV)
+    dys = make_src(dev(g), cout, SRC_BNBWD, act=ACT_RELU, cst=dev(cst), aux=dev(yraw))
+    src = make_src(dev(prev), cup, SRC_AFFINE, act=ACT_RELU, up=1, cst=cst_affine(sc0, sh0))
+    dw = wgrad_sp(dys, src, N, H, W, cout, cup + csk, absmax=amax)
+    assert relerr(dw[:, :cup], ref[:, :cup]) < BX3_TOL
+    if csk:
+        assert bool(torch.isnan(dw[:, cup:]).all())            # the skip channels' columns are not this entry point's
+        if csk % 8 == 0:
+            dsk = wgrad_mfma(dys, [make_src(dev(skip.float()), csk, SRC_RAW)], N, H, W, cout, csk, 3, bx3=cout >= 32 and csk >= 32, terms=TERMS_F16X2 if (cout >= 32 and csk >= 32) else 0, absmax=amax)
+            check(hip.sc_wgrad_scatter_cols(ptr(dsk), ptr(dw), cout, csk, cup + csk, cup, stream()))
+            assert relerr(dw, ref) < BX3_TOL
 
 
 @pytest.mark.parametrize("cin,cout,H,W,two", [(16, 64, 32, 32, False), (32, 16, 36, 70, True), (32, 32, 24, 40, False), (48, 40, 21, 32, False), (32, 64, 16, 32, True),

@@ -229,6 +229,8 @@ def test_sub_pixel_rules():
     # data gradient: 1280 / 256 / 128 up-sampled channels yes, 64 only together with its <= 16 skip channels, 32 no
     assert nw._use_spd(16, 32, 32, 1280, 96) and nw._use_spd(16, 64, 64, 256, 32) and nw._use_spd(16, 128, 128, 128, 24)
     assert nw._use_spd(16, 256, 256, 64, 16) and not nw._use_spd(16, 256, 256, 64, 0) and not nw._use_spd(16, 512, 512, 32, 0)
+    # weight gradient as the box-sum GEMM: only where the layer is matrix-bound (decoder.blocks.0: 1280 up-sampled channels)
+    assert nw._use_spw(16, 32, 32, 256, 1280) and not nw._use_spw(16, 64, 64, 128, 256) and not nw._use_spw(16, 256, 256, 32, 64)
     lib = _lib.load()
     assert lib.sc_spd_vskip_ok(64, 16) == 1 and lib.sc_spd_vskip_ok(128, 16) == 0 and lib.sc_spd_vskip_ok(64, 24) == 0
     # statistics rows / packed sizes are pure functions of the shape

@@ -37,7 +37,7 @@ def sp_conv(srcs, wsp, N, H, W, cout, out, stats):
 
 # (name, up channels, skip channels, cout, H out)
 SHAPES = [("d0a", 1280, 96, 256, 32), ("d1a", 256, 32, 128, 64), ("d2a", 128, 24, 64, 128), ("d3a", 64, 16, 32, 256), ("d4a", 32, 0, 16, 512)]
-for name, cu, cs, cout, H in SHAPES:
+for name, cu, cs, cout, H in ([] if os.environ.get("SP_WGRAD_ONLY") else SHAPES):
     W = H
     xl = torch.randn(N, cu, H // 2, W // 2, device=DEV)
     xs = torch.randn(N, max(cs, 1), H, W, device=DEV)
@@ -77,7 +77,7 @@ for name, cu, cs, cout, H in SHAPES:
           f"x{t_ref/t_sp:4.2f} | out diff {err:.1e} stats diff {serr:.1e}", flush=True)
 
 # ---- data gradient w.r.t. the up-sampled source: sub-pixel (sc_conv3x3_sp_dgrad) against sc_conv3x3_bx3(down0) on those channels
-if not os.environ.get("SP_ONLY"):
+if not os.environ.get("SP_ONLY") and not os.environ.get("SP_WGRAD_ONLY"):
     from hip_ops import conv_sp_dgrad, pack_spd
     from starcop_amd._lib import SRC_BNBWD
     print("--- data gradient of the up-sampled channels ---")
@@ -114,3 +114,27 @@ if not os.environ.get("SP_ONLY"):
                 t_v = timeit(fv)
                 extra += f" | ONE launch for both (virtual skip channels) {t_v:6.1f} us vs {t_ref + t_sk:6.1f} (diff {e2:.1e})"
         print(f"{name}.dgrad {cout}->{cu} {H}^2: 3x3 + down-sum {t_ref:7.1f} us | sub-pixel {t_sp:7.1f} us x{t_ref/t_sp:4.2f} | diff {err:.1e}{extra}", flush=True)
+
+# ---- weight gradient of the up-sampled channels: box-sum GEMM (sc_conv3x3_sp_wgrad) against sc_conv3x3_wgrad_bx3 with an up-sampled source
+if not os.environ.get("SP_ONLY"):
+    from hip_ops import wgrad_mfma, wgrad_sp
+    from starcop_amd._lib import SRC_BNBWD
+    print("--- weight gradient (up-sampled channels) ---")
+    for name, cu, cs, cout, H in SHAPES:
+        W = H
+        g, yr = torch.randn(N, cout, H, W, device=DEV), torch.randn(N, cout, H, W, device=DEV)
+        xl = torch.randn(N, cu, H // 2, W // 2, device=DEV)
+        cst = torch.rand(cout, SC_CST, device=DEV)
+        cl = torch.rand(cu, SC_CST, device=DEV); cl[:, 1] -= 0.5
+        amax = (cst[:, 2][None, :, None, None] * g).abs().max().reshape(1)
+        dys = make_src(g, cout, SRC_BNBWD, act=ACT_RELU, cst=cst, aux=yr)
+        s_up = make_src(xl, cu, SRC_AFFINE, act=ACT_RELU, up=1, cst=cl)
+        use_bx3 = cout >= 32 and cu >= 32
+        f3 = lambda: wgrad_mfma(dys, [s_up], N, H, W, cout, cu, 3, bx3=use_bx3, terms=TERMS_F16X2 if use_bx3 else 0, absmax=amax)
+        ref = f3(); t_ref = timeit(f3)
+        dw = torch.empty(cout, cu, 3, 3, device=DEV)
+        fs = lambda: wgrad_sp(dys, s_up, N, H, W, cout, cu, absmax=amax, dw=dw)
+        fs(); torch.cuda.synchronize()
+        err = float((dw - ref).abs().max() / ref.abs().max())
+        t_sp = timeit(fs)
+        print(f"{name}.wgrad {cout}x{cu} {H}^2: 3x3 form {t_ref:7.1f} us | box-sum GEMM {t_sp:7.1f} us x{t_ref/t_sp:4.2f} | diff {err:.1e}", flush=True)
