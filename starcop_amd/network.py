@@ -177,7 +177,8 @@ def _use_irt(N, Cin, Hd, Hin, Win, stride):
 # (16 output channels: half-empty MFMA rows) 196-213, level with sc_conv3x3_thin16's 202, stays there.  "1" = that rule, "all" =
 # every decoder conv1 (tests), "0" = off.
 _SP = os.environ.get("STARCOP_SP", "1")
-_EXP_NO_WGRAD = os.environ.get("STARCOP_EXP_NO_WGRAD", "0") == "1"      # tools/: elimination experiment only
+_EXP_NO_WGRAD = os.environ.get("STARCOP_EXP_NO_WGRAD", "0") == "1"
+_EXP_SIDE2 = os.environ.get("STARCOP_EXP_SIDE2", "0") == "1"      # tools/: elimination experiment only
 
 
 def _use_sp(N, Ho, Wo, Cout):
@@ -1082,7 +1083,13 @@ class HyperStarcopUNet(nn.Module):
                 self._side_stream = torch.cuda.Stream(device=main.device)
             side = self._side_stream
 
-        hnd = {id(s_): C.c_void_p(s_.cuda_stream) for s_ in (main, side) if s_ is not None}      # raw handles, looked up once per walk
+        # experiment (STARCOP_EXP_SIDE2=1): the pointwise weight gradients (own partial buffers) on a SECOND weight-gradient stream
+        side2 = None
+        if side is not None and _EXP_SIDE2:
+            if getattr(self, "_side_stream2", None) is None or self._side_stream2.device != main.device:
+                self._side_stream2 = torch.cuda.Stream(device=main.device)
+            side2 = self._side_stream2
+        hnd = {id(s_): C.c_void_p(s_.cuda_stream) for s_ in (main, side, side2) if s_ is not None}      # raw handles, looked up once per walk
 
         def wait_stream(waiter, signaller):
             # same-device ordering without the system-scope fence of a default event (sc_stream_wait_stream)
@@ -1091,7 +1098,7 @@ class HyperStarcopUNet(nn.Module):
             else:
                 waiter.wait_stream(signaller)
 
-        def wgrad_launch(fn):
+        def wgrad_launch(fn, second=False):
             """run fn(stream_handle) on the weight-gradient stream, ordered after everything queued on the main stream.  (One fork per
             launch: serving two to eight launches with one fork -- fewer markers in the main queue -- measured 0.5-2.5 % SLOWER, the
             weight gradients then start too late to fill the gaps of the data-gradient chain.)"""
@@ -1100,8 +1107,9 @@ class HyperStarcopUNet(nn.Module):
             if side is None:
                 fn(st)
             else:
-                wait_stream(side, main)
-                fn(hnd[id(side)])       # (every fn launches through the C ABI with the handle it is given: no stream context switch needed)
+                sd = side2 if (second and side2 is not None) else side
+                wait_stream(sd, main)
+                fn(hnd[id(sd)])       # (every fn launches through the C ABI with the handle it is given: no stream context switch needed)
 
         N, H, W = plan.N, plan.H, plan.W
         if not getattr(plan, "training", False):
@@ -1175,7 +1183,7 @@ class HyperStarcopUNet(nn.Module):
                                       torch.tensor(starts, dtype=torch.int32).to(self._pflat.device), len(pw_pending), nblk)
             tab = plan.pw_table[raw]
             tok = self._pb("k_wgrad_mfma<1> (+reduce)")
-            wgrad_launch(lambda sx: check(lib.sc_wgrad_reduce_batch(ptr(tab[0]), ptr(tab[1]), tab[2], tab[3], sx)))
+            wgrad_launch(lambda sx: check(lib.sc_wgrad_reduce_batch(ptr(tab[0]), ptr(tab[1]), tab[2], tab[3], sx)), second=True)
             self._pe(tok)
             pw_pending.clear()
 
@@ -1395,7 +1403,7 @@ class HyperStarcopUNet(nn.Module):
                 pend = sc_wgrad_pending()
                 wdef = (lib.sc_conv1x1_wgrad_pw3 if _use_pw3(2, N, Ho * Wo, conv.in_channels, conv.out_channels)
                         else lib.sc_conv2d_wgrad_mfma_deferred)
-                wgrad_launch(lambda sx, wa=wa, pend=pend, wdef=wdef: check(wdef(C.byref(wa), C.byref(pend), sx)))
+                wgrad_launch(lambda sx, wa=wa, pend=pend, wdef=wdef: check(wdef(C.byref(wa), C.byref(pend), sx)), second=True)
                 pw_pending.append(pend)
                 if i == last_pw:
                     # every pointwise layer has been walked: queue the batched reduction NOW, behind this layer's weight gradient, where it
@@ -1534,8 +1542,12 @@ class HyperStarcopUNet(nn.Module):
             # (on_tail_ready: the data-parallel path) a default event, otherwise the device-scope one
             if exchange_follows if exchange_follows is not None else on_tail_ready is not None:
                 main.wait_stream(side)
+                if side2 is not None:
+                    main.wait_stream(side2)
             else:
                 wait_stream(main, side)
+                if side2 is not None:
+                    wait_stream(main, side2)
 
     # ------------------------------------------------------------------------------------------
     def forward(self, x, normalizer_consts=None):

@@ -137,4 +137,13 @@ if not os.environ.get("SP_ONLY"):
         fs(); torch.cuda.synchronize()
         err = float((dw - ref).abs().max() / ref.abs().max())
         t_sp = timeit(fs)
-        print(f"{name}.wgrad {cout}x{cu} {H}^2: 3x3 form {t_ref:7.1f} us | box-sum GEMM {t_sp:7.1f} us x{t_ref/t_sp:4.2f} | diff {err:.1e}", flush=True)
+        extra = ""
+        if cs:
+            xs = torch.randn(N, cs, H, W, device=DEV)
+            s_sk = make_src(xs, cs, SRC_AFFINE, act=ACT_NONE, cst=torch.rand(cs, SC_CST, device=DEV))
+            bx_all = cout >= 32 and cu + cs >= 32
+            t_all = timeit(lambda: wgrad_mfma(dys, [s_up, s_sk], N, H, W, cout, cu + cs, 3, bx3=bx_all, terms=TERMS_F16X2 if bx_all else 0, absmax=amax))
+            bx_sk = cout >= 32 and cs >= 32
+            t_sk = timeit(lambda: wgrad_mfma(dys, [s_sk], N, H, W, cout, cs, 3, bx3=bx_sk, terms=TERMS_F16X2 if bx_sk else 0, absmax=amax))
+            extra = f" | in-network: ONE 3x3 launch over all {cu + cs} channels {t_all:6.1f} us; the {cs} skip channels alone {t_sk:6.1f} us"
+        print(f"{name}.wgrad {cout}x{cu} {H}^2: 3x3 form {t_ref:7.1f} us | box-sum GEMM {t_sp:7.1f} us x{t_ref/t_sp:4.2f} | diff {err:.1e}{extra}", flush=True)
