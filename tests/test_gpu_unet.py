@@ -160,6 +160,44 @@ def test_fused_train_step_equals_autograd_path(hip):
         assert relerr(pa, pb) < 1e-5, k
 
 
+def test_sub_pixel_paths_equal_the_3x3_paths_on_the_whole_network(hip, monkeypatch):
+    """every decoder conv1 forced onto the sub-pixel kernels (forward, data gradient incl. the one-launch form with virtual skip
+    channels, box-sum weight gradient: network._SP = "all") against the same network on the 3x3 kernels (_SP = "0"), and against the
+    float64 oracle: eval logits, train-mode logits, and every parameter gradient of one training step -- the dispatch rules pick these
+    kernels by measured speed only, so the small shapes of the other whole-network tests would not reach all of them"""
+    from starcop_amd import network as nw
+    B, H, W = 2, 64, 96
+    batch = synth_batch(B, H, W, seed=31)
+    res = {}
+    for mode in ("0", "all"):
+        monkeypatch.setattr(nw, "_SP", mode)
+        model, ref = make_pair(seed=30)
+        model.eval(); ref.eval()
+        with torch.no_grad():
+            ev = model(to_dev(batch)["input"]).cpu()
+            want_ev = ref(ref_normalize(batch["input"]))
+        assert relerr(ev, want_ev) < 1e-4
+        model.train()
+        loss = model.training_step(to_dev(batch), 0)
+        loss.backward()
+        grads = {k: p.grad.detach().cpu().clone() for k, p in model.network.named_parameters()}
+        res[mode] = (ev, model.network._plans[(B, H, W)].buf["logits"].cpu().clone(), grads, float(loss))
+    # oracle in float64 for the gradients: the two kernel families must be equally close to it
+    ref64 = copy.deepcopy(ref).double().train()
+    x64 = ref_normalize(batch["input"]).double()
+    l64 = (F.binary_cross_entropy_with_logits(ref64(x64), batch["output"].double(), reduction="none") * batch["weight_loss"].double()).mean()
+    l64.backward()
+    g64 = {k: p.grad for k, p in ref64.named_parameters()}
+    assert relerr(res["all"][0], res["0"][0]) < 2e-5 and relerr(res["all"][1], res["0"][1]) < 1e-4
+    assert abs(res["all"][3] - res["0"][3]) < 1e-5 * max(1.0, abs(res["0"][3]))
+    worst = 0.0
+    for k, g in g64.items():
+        e_sp, e_33 = relerr(res["all"][2][k], g), relerr(res["0"][2][k], g)
+        worst = max(worst, e_sp / max(e_33, 1e-4))
+        assert e_sp < max(1e-3, GRAD_RATIO_GATE * e_33), (k, e_sp, e_33)
+    print(f"sub-pixel vs 3x3 whole network: worst gradient error ratio to the 3x3 kernels' own (vs float64) {worst:.2f}")
+
+
 def test_predict_odd_size(hip):
     """predict(): reflect-pad to x32, forward, crop (padding.py:13-50) on a non-multiple-of-32 scene."""
     model, ref = make_pair(seed=11)
