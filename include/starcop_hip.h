@@ -202,28 +202,28 @@ int sc_conv3x3_thin16(const sc_conv_args* a, sc_stream stream);
  * skip channels join the same launch as four low-resolution "parity planes" each (csrc/conv_sp_pack.h).
  *   sc_conv3x3_sp: sc_conv_args with src[0] = the half-resolution tensor (up = 1), optional src[1] = the full-resolution skip
  *   tensor (up = 0), both RAW or AFFINE; H x W = OUTPUT size (even); ks = 3; terms = SC_TERMS_F16X2 (the two-fp16-term arithmetic
- *   of sc_conv3x3_bx3); csplit = Cout, one plain output (no add / accumulate / down0); co_t ignored (32); `wpk` from
+ *   of sc_conv3x3_bx3) or 1 (one bf16 term per operand: the "bf16" precision mode; xbound unused); csplit = Cout, one plain output (no add / accumulate / down0); co_t ignored (32); `wpk` from
  *   sc_pack_weights_sp (or a sc_pack_desc with bx3 = SC_PACK_SP, Cin = the filter's total input channels and co_t = how many
- *   of them, the leading ones, belong to the up-sampled source); statistics rows = sc_sp_stat_rows(N, H, W). */
+ *   of them, the leading ones, belong to the up-sampled source; transpose_flip = 4 for the one-bf16-term layout); statistics rows = sc_sp_stat_rows(N, H, W). */
 #define SC_PACK_SP 7
 size_t sc_packed_weight_floats_sp(int Cout, int Cup, int Cskip);
-int sc_pack_weights_sp(const float* w_oihw, float* wpk, int Cout, int Cup, int Cskip, sc_stream stream);
+int sc_pack_weights_sp(const float* w_oihw, float* wpk, int Cout, int Cup, int Cskip, int terms, sc_stream stream);
 int sc_sp_stat_rows(int N, int H, int W);
 int sc_conv3x3_sp(const sc_conv_args* a, sc_stream stream);
 /* ... and its data gradient w.r.t. the half-resolution source: a stride-2 4x4 convolution of dy (four parity planes x 2x2 taps), written
  * at half resolution directly -- no full-resolution gradient of the up-sampled channels, no 2x2 down-sum (replaces
  * sc_conv3x3_bx3(down0 = 1) on those channels; the skip channels' gradient stays an ordinary 3x3 launch).
  *   sc_conv3x3_sp_dgrad: sc_conv_args with nsrc = 1, src[0] = the SC_SRC_BNBWD operand of the layer's output (g, y, constants; H x W),
- *   Cout = csplit = the up-sampled source's channels, out0 = [N, Cout, H/2, W/2] (accum0 allowed), terms = SC_TERMS_F16X2, absmax as
+ *   Cout = csplit = the up-sampled source's channels, out0 = [N, Cout, H/2, W/2] (accum0 allowed), terms = SC_TERMS_F16X2 or 1, absmax as
  *   in sc_conv3x3_bx3; `wpk` from sc_pack_weights_spd (or a sc_pack_desc with bx3 = SC_PACK_SPD, Cin = the filter's total input
- *   channels, co_t = the up-sampled source's channels, transpose_flip = 2 for vskip).
+ *   channels, co_t = the up-sampled source's channels, transpose_flip = 2 for vskip, | 4 for the one-bf16-term layout).
  *   vskip (sc_spd_vskip_ok: <= 64 up-sampled and <= 16 skip channels, smp's decoder.blocks.3): the skip channels' full-resolution
  *   gradient rides along in the otherwise idle half of the 128-channel tile -- Cout = all input channels, csplit = the up-sampled ones,
  *   out1 = [N, Cout - csplit, H, W] (accum1 allowed): ONE launch stages dy for both gradients. */
 #define SC_PACK_SPD 8
 size_t sc_packed_weight_floats_spd(int Cout, int Cup);
 int sc_spd_vskip_ok(int Cup, int Cskip);
-int sc_pack_weights_spd(const float* w_oihw, float* wpk, int Cout, int CinTotal, int Cup, int vskip, sc_stream stream);
+int sc_pack_weights_spd(const float* w_oihw, float* wpk, int Cout, int CinTotal, int Cup, int vskip, int terms, sc_stream stream);
 int sc_conv3x3_sp_dgrad(const sc_conv_args* a, sc_stream stream);
 /* ... and the weight gradient of its up-sampled channels as a PLAIN GEMM: up(x) is constant over 2x2 blocks of the output grid, so
  * dW[co][ci][kh][kw] = sum_q x[ci][q] * S_(kh,kw)[co][q] with S the tap-aligned 2x2 box sums of dy -- nine GEMMs over the low-resolution

@@ -2206,8 +2206,8 @@ __global__ __launch_bounds__(256) void k_pack_batch(const PackDesc* __restrict__
   const size_t i = (size_t)(blockIdx.x - starts[lo]) * 256 + threadIdx.x;
   if (i >= d.total) return;
   if (d.bx3 == SC_PACK_THIN16) { pack_thin_item(d.w, reinterpret_cast<unsigned short*>(d.wpk), i, d.Cout, d.Cin, d.tflip); return; }
-  if (d.bx3 == SC_PACK_SPD) { spd_pack_item(d.w, reinterpret_cast<unsigned short*>(d.wpk), i, d.Cout, d.Cin, d.co_t, d.tflip == 2); return; }      // tflip 2: + virtual skip channels
-  if (d.bx3 == SC_PACK_SP) { sp_pack_item(d.w, reinterpret_cast<unsigned short*>(d.wpk), i, d.Cout, d.co_t, d.Cin - d.co_t); return; }      // conv_sp.hip: co_t = up-sampled channels
+  if (d.bx3 == SC_PACK_SPD) { spd_pack_item(d.w, reinterpret_cast<unsigned short*>(d.wpk), i, d.Cout, d.Cin, d.co_t, (d.tflip & 3) == 2, (d.tflip & 4) != 0); return; }      // tflip 2: + virtual skip channels; | 4: one bf16 term
+  if (d.bx3 == SC_PACK_SP) { sp_pack_item(d.w, reinterpret_cast<unsigned short*>(d.wpk), i, d.Cout, d.co_t, d.Cin - d.co_t, (d.tflip & 4) != 0); return; }      // conv_sp.hip: co_t = up-sampled channels
   const int M = d.tflip ? d.Cin : d.Cout, K = d.tflip ? d.Cout : d.Cin;
   if (d.bx3 == SC_PACK_PW3) {
     // pointwise filters for k_pw3 (conv_pw3.hip): [cout block][k step][term][lane][8] bf16, lane -> cout l&31, k = 16*step + 8*(l>>5) + j;

@@ -38,6 +38,8 @@ typedef __attribute__((ext_vector_type(2))) float floatx2;
 typedef __attribute__((ext_vector_type(4))) unsigned int uintx4;
 typedef __attribute__((ext_vector_type(8))) _Float16 halfx8;
 typedef __attribute__((ext_vector_type(2))) _Float16 halfx2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
 constexpr float SP_SX = 2.f, SP_HMAX = 65504.f;
 #ifndef SP_INTERLEAVE
@@ -85,13 +87,16 @@ template <int TW> constexpr int sp_pc() { return TW == 16 ? SP_PC16 : TW + 2; }
 template <int TW> constexpr int sp_npx() { return (256 / TW + 2) * sp_pc<TW>(); }
 template <int TW> constexpr int sp_smem_bytes() { return SP_SMEM_W + 2 * 2 * 2 * sp_npx<TW>() * 16 + 8 * 32 * 2 * 4; }
 
-template <int TW>
+// BF: the "bf16" precision mode -- ONE bf16 term per operand (round to nearest even, no range scale), a third of the MFMAs and half
+// the operand reads; the skeleton, LDS layout (term 0 only) and pipeline are the same
+template <int TW, bool BF>
 __global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
-  constexpr int NT = 2;
+  constexpr int NT = BF ? 1 : 2;
+  constexpr int NM = BF ? 4 : 12;            // MFMAs per step
   constexpr int TH = 256 / TW;
   constexpr int PC = sp_pc<TW>(), NPX = sp_npx<TW>();
   constexpr int NR = 3;
-  constexpr int WST = SP_WST;                // 16-byte filter entries per chunk
+  constexpr int WST = SP_WST / 2 * NT;       // 16-byte filter entries per chunk
   constexpr int NWV = WST / 512;
   static_assert(NPX <= 128 * NR, "three staging rounds of 128 threads per channel quarter");
 
@@ -127,8 +132,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
   const int nku = (C0 + 15) >> 4, nkt = nku + 4 * ((C1 + 15) >> 4);
   const uintx4* wbase = p.wpk + (size_t)cot * nkt * WST;
 
-  const float hsx = sp_act_scale(p.xb0, p.xb1);
-  const float hinv = 1.f / (hsx * SP_SW);
+  const float hsx = BF ? 1.f : sp_act_scale(p.xb0, p.xb1);
+  const float hinv = BF ? 1.f : 1.f / (hsx * SP_SW);
 
   floatx16 acc[2][2];      // [group pp][px]
 #pragma unroll
@@ -178,7 +183,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) xv[r][j] = xb[(size_t)(j < jmax ? j : jmax) * plane + o];
     }
-    slo = fmaxf(sc_act_lo(s.act) * hsx, -SP_HMAX); shi = fminf(sc_act_hi(s.act) * hsx, SP_HMAX);
+    if constexpr (BF) { slo = sc_act_lo(s.act); shi = sc_act_hi(s.act); }
+    else { slo = fmaxf(sc_act_lo(s.act) * hsx, -SP_HMAX); shi = fminf(sc_act_hi(s.act) * hsx, SP_HMAX); }
     const float* cb = s.cst + (size_t)cb0 * SC_CST;      // (RAW sources read the host's identity table: no load under a branch)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -199,14 +205,15 @@ __global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
         const float t = __builtin_amdgcn_fmed3f(fmaf(xv[r][j], cs0[j], cs1[j]), slo, shi);
         v[h] = (pyx[r] != 0xFFFFFFFFu && j < nch) ? t : 0.f;
       }
-      unsigned a0, a1;
-      sp_split2h(v[0], v[1], a0, a1);
+      unsigned a0, a1 = 0u;
+      if constexpr (BF) a0 = __builtin_bit_cast(unsigned, __builtin_convertvector((floatx2){v[0], v[1]}, bf16x2));
+      else sp_split2h(v[0], v[1], a0, a1);
       if (jp == 0) { t0.x = a0; t1.x = a1; } else { t0.y = a0; t1.y = a1; }
     }
     const int e = sidx + 128 * r;
     if (e < NPX) {
       sp2[((0 * 2 + hw) * NPX + e) * 2 + sub] = t0;
-      sp2[((1 * 2 + hw) * NPX + e) * 2 + sub] = t1;
+      if constexpr (!BF) sp2[((1 * 2 + hw) * NPX + e) * 2 + sub] = t1;
     }
   };
   auto stage_w = [&](int buf) __attribute__((always_inline)) {
@@ -255,13 +262,16 @@ __global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
     auto mfmas = [&](const halfx8 (&A)[2][2][NT], const halfx8 (&B)[3][NT], auto ppc) {
       constexpr int pp = decltype(ppc)::value;
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
+      for (int t = 0; t < (BF ? 1 : 3); ++t)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
           for (int px = 0; px < 2; ++px) {      // the two accumulators alternate: no back-to-back dependent MFMAs
             const int o = b + px;
-            acc[pp][px] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[px][b][t == 1 ? 1 : 0], B[o][t == 0 ? 1 : 0], acc[pp][px], 0, 0, 0);
+            if constexpr (BF)
+              acc[pp][px] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[px][b][0]), __builtin_bit_cast(bf16x8, B[o][0]), acc[pp][px], 0, 0, 0);
+            else
+              acc[pp][px] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[px][b][t == 1 ? NT - 1 : 0], B[o][t == 0 ? NT - 1 : 0], acc[pp][px], 0, 0, 0);
           }
     };
     using P0 = std::integral_constant<int, 0>;
@@ -276,10 +286,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
       mfmas(A, B, ppc);
 #if SP_INTERLEAVE
 #pragma unroll
-      for (int i = 0; i < 12; ++i) {
+      for (int i = 0; i < NM; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, SP_INTERLEAVE, 0);      // then a few VALU
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // and at most one LDS store
+        __builtin_amdgcn_sched_group_barrier(0x002, SP_INTERLEAVE * (12 / NM), 0);      // then a few VALU
+        __builtin_amdgcn_sched_group_barrier(0x200, 12 / NM, 0);      // and at most one LDS store (BF: three)
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
@@ -391,13 +401,14 @@ __device__ __forceinline__ float spd_grad_scale(const float* absmax) {      // (
   return ldexpf(1.f, e);
 }
 
-template <int TW>
+template <int TW, bool BF>
 __global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
-  constexpr int NT = 2;
+  constexpr int NT = BF ? 1 : 2;
+  constexpr int NM = BF ? 4 : 12;
   constexpr int TH = 256 / TW;
   constexpr int PC = sp_pc<TW>(), NPX = sp_npx<TW>();
   constexpr int NR = 3;
-  constexpr int WST = SP_WST;
+  constexpr int WST = SP_WST / 2 * NT;
   constexpr int NWV = WST / 512;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -429,8 +440,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
   const int nkt = 4 * ((Co + 15) >> 4);
   const uintx4* wbase = p.wpk + (size_t)cot * nkt * WST;
 
-  const float hsx = spd_grad_scale(p.absmax);
-  const float hinv = 1.f / (hsx * SP_SW);
+  const float hsx = BF ? 1.f : spd_grad_scale(p.absmax);
+  const float hinv = BF ? 1.f : 1.f / (hsx * SP_SW);
 
   floatx16 acc[2][2];      // [group pp][cin block mx]
 #pragma unroll
@@ -499,16 +510,17 @@ __global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
       for (int h = 0; h < 2; ++h) {
         const int j = 2 * jp + h;
         const float t = sc_pro_bnbwd(xv[r][j], av[r][j], cs0[j], cs1[j], cs2[j], cs3[j], cs4[j], slo, shi) * hsx;
-        v[h] = (pyx[r] != 0xFFFFFFFFu && j < nch) ? __builtin_amdgcn_fmed3f(t, -SP_HMAX, SP_HMAX) : 0.f;
+        v[h] = (pyx[r] != 0xFFFFFFFFu && j < nch) ? (BF ? t : __builtin_amdgcn_fmed3f(t, -SP_HMAX, SP_HMAX)) : 0.f;
       }
-      unsigned a0, a1;
-      sp_split2h(v[0], v[1], a0, a1);
+      unsigned a0, a1 = 0u;
+      if constexpr (BF) a0 = __builtin_bit_cast(unsigned, __builtin_convertvector((floatx2){v[0], v[1]}, bf16x2));
+      else sp_split2h(v[0], v[1], a0, a1);
       if (jp == 0) { t0.x = a0; t1.x = a1; } else { t0.y = a0; t1.y = a1; }
     }
     const int e = sidx + 128 * r;
     if (e < NPX) {
       sp2[((0 * 2 + hw) * NPX + e) * 2 + sub] = t0;
-      sp2[((1 * 2 + hw) * NPX + e) * 2 + sub] = t1;
+      if constexpr (!BF) sp2[((1 * 2 + hw) * NPX + e) * 2 + sub] = t1;
     }
   };
   auto stage_w = [&](int buf) __attribute__((always_inline)) {
@@ -548,13 +560,16 @@ __global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
     auto mfmas = [&](const halfx8 (&A)[2][2][NT], const halfx8 (&B)[3][NT], auto ppc) {
       constexpr int pp = decltype(ppc)::value;
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
+      for (int t = 0; t < (BF ? 1 : 3); ++t)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
           for (int mx = 0; mx < 2; ++mx) {
             const int o = 2 - b - QX;
-            acc[pp][mx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[mx][b][t == 1 ? 1 : 0], B[o][t == 0 ? 1 : 0], acc[pp][mx], 0, 0, 0);
+            if constexpr (BF)
+              acc[pp][mx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[mx][b][0]), __builtin_bit_cast(bf16x8, B[o][0]), acc[pp][mx], 0, 0, 0);
+            else
+              acc[pp][mx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[mx][b][t == 1 ? NT - 1 : 0], B[o][t == 0 ? NT - 1 : 0], acc[pp][mx], 0, 0, 0);
           }
     };
     using P0 = std::integral_constant<int, 0>;
@@ -565,10 +580,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
       mfmas(A, B, ppc);
 #if SP_INTERLEAVE
 #pragma unroll
-      for (int i = 0; i < 12; ++i) {
+      for (int i = 0; i < NM; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, SP_INTERLEAVE + 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, (SP_INTERLEAVE + 2) * (12 / NM), 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 12 / NM, 0);
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
@@ -655,14 +670,14 @@ __global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
   }
 }
 
-__global__ void k_pack_weights_spd(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout, int CinTot, int Cup, int vskip, size_t total) {
+__global__ void k_pack_weights_spd(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout, int CinTot, int Cup, int vskip, int bf, size_t total) {
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i < total) spd_pack_item(w, wpk, i, Cout, CinTot, Cup, vskip != 0);
+  if (i < total) spd_pack_item(w, wpk, i, Cout, CinTot, Cup, vskip != 0, bf != 0);
 }
 
-__global__ void k_pack_weights_sp(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout, int Cup, int Csk, size_t total) {
+__global__ void k_pack_weights_sp(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout, int Cup, int Csk, int bf, size_t total) {
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i < total) sp_pack_item(w, wpk, i, Cout, Cup, Csk);
+  if (i < total) sp_pack_item(w, wpk, i, Cout, Cup, Csk, bf != 0);
 }
 
 }  // namespace
@@ -671,12 +686,13 @@ extern "C" size_t sc_packed_weight_floats_sp(int Cout, int Cup, int Cskip) {
   return (size_t)((Cout + 31) / 32) * sp_chunks(Cup, Cskip) * SP_WST * 4;      // 16-byte entries -> floats
 }
 
-extern "C" int sc_pack_weights_sp(const float* w, float* wpk, int Cout, int Cup, int Cskip, sc_stream stream) {
+extern "C" int sc_pack_weights_sp(const float* w, float* wpk, int Cout, int Cup, int Cskip, int terms, sc_stream stream) {
   SC_REQUIRE(w && wpk && Cout > 0 && Cup > 0 && Cskip >= 0, "sc_pack_weights_sp: bad argument");
+  SC_REQUIRE(terms == SC_TERMS_F16X2 || terms == 1, "sc_pack_weights_sp: terms must be SC_TERMS_F16X2 or 1 (one bf16 term)");
   SC_REQUIRE(((uintptr_t)wpk & 15) == 0, "sc_pack_weights_sp: destination must be 16-byte aligned");
   const size_t total = sp_pack_items(Cout, Cup, Cskip);
   hipLaunchKernelGGL(k_pack_weights_sp, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
-                     reinterpret_cast<unsigned short*>(wpk), Cout, Cup, Cskip, total);
+                     reinterpret_cast<unsigned short*>(wpk), Cout, Cup, Cskip, terms == 1 ? 1 : 0, total);
   SC_LAUNCH_OK("sc_pack_weights_sp");
   return SC_OK;
 }
@@ -699,7 +715,7 @@ extern "C" int sc_conv3x3_sp(const sc_conv_args* a, sc_stream stream) {
   }
   SC_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->Cout > 0, "sc_conv3x3_sp: bad shape");
   SC_REQUIRE(a->H % 2 == 0 && a->W % 2 == 0, "sc_conv3x3_sp: even output size");
-  SC_REQUIRE(a->terms == SC_TERMS_F16X2, "sc_conv3x3_sp: two-fp16-term arithmetic only (terms = SC_TERMS_F16X2)");
+  SC_REQUIRE(a->terms == SC_TERMS_F16X2 || a->terms == 1, "sc_conv3x3_sp: terms = SC_TERMS_F16X2 (two fp16 terms) or 1 (one bf16 term)");
   SC_REQUIRE(a->csplit == a->Cout && a->out1 == nullptr && a->add0 == nullptr && a->add1 == nullptr && !a->down0 && !a->accum0,
              "sc_conv3x3_sp: a single plain output");
   SC_REQUIRE(((uintptr_t)a->wpk & 15) == 0 && ((uintptr_t)a->out0 & 7) == 0, "sc_conv3x3_sp: alignment");
@@ -721,12 +737,20 @@ extern "C" int sc_conv3x3_sp(const sc_conv_args* a, sc_stream stream) {
   const long grid = (tiles + 7) / 8 * 8 * ncot;
   SC_REQUIRE(grid < (1L << 31), "sc_conv3x3_sp: grid too large");
   static const bool attr_ok = [] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<32>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<32>()) == hipSuccess &&
-           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<16>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<32>()) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<32>()) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess;
   }();
   SC_REQUIRE(attr_ok, "sc_conv3x3_sp: cannot reserve %d bytes of LDS", sp_smem_bytes<32>());
-  if (TW == 32) hipLaunchKernelGGL((k_conv3_sp<32>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<32>(), (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((k_conv3_sp<16>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<16>(), (hipStream_t)stream, p);
+  const bool bf = a->terms == 1;
+  if (TW == 32) {
+    if (bf) hipLaunchKernelGGL((k_conv3_sp<32, true>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<32>(), (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((k_conv3_sp<32, false>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<32>(), (hipStream_t)stream, p);
+  } else {
+    if (bf) hipLaunchKernelGGL((k_conv3_sp<16, true>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<16>(), (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((k_conv3_sp<16, false>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<16>(), (hipStream_t)stream, p);
+  }
   SC_LAUNCH_OK("sc_conv3x3_sp");
   return SC_OK;
 }
@@ -737,13 +761,14 @@ extern "C" size_t sc_packed_weight_floats_spd(int Cout, int Cup) {
 
 extern "C" int sc_spd_vskip_ok(int Cup, int Cskip) { return Cup > 0 && Cup <= 64 && Cskip > 0 && Cskip <= 16; }
 
-extern "C" int sc_pack_weights_spd(const float* w, float* wpk, int Cout, int CinTotal, int Cup, int vskip, sc_stream stream) {
+extern "C" int sc_pack_weights_spd(const float* w, float* wpk, int Cout, int CinTotal, int Cup, int vskip, int terms, sc_stream stream) {
   SC_REQUIRE(w && wpk && Cout > 0 && Cup > 0 && Cup <= CinTotal, "sc_pack_weights_spd: bad argument");
+  SC_REQUIRE(terms == SC_TERMS_F16X2 || terms == 1, "sc_pack_weights_spd: terms must be SC_TERMS_F16X2 or 1 (one bf16 term)");
   SC_REQUIRE(!vskip || sc_spd_vskip_ok(Cup, CinTotal - Cup), "sc_pack_weights_spd: virtual skip channels need Cup <= 64 and 1..16 skip channels");
   SC_REQUIRE(((uintptr_t)wpk & 15) == 0, "sc_pack_weights_spd: destination must be 16-byte aligned");
   const size_t total = spd_pack_items(Cout, Cup);
   hipLaunchKernelGGL(k_pack_weights_spd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
-                     reinterpret_cast<unsigned short*>(wpk), Cout, CinTotal, Cup, vskip, total);
+                     reinterpret_cast<unsigned short*>(wpk), Cout, CinTotal, Cup, vskip, terms == 1 ? 1 : 0, total);
   SC_LAUNCH_OK("sc_pack_weights_spd");
   return SC_OK;
 }
@@ -755,7 +780,7 @@ extern "C" int sc_conv3x3_sp_dgrad(const sc_conv_args* a, sc_stream stream) {
              "sc_conv3x3_sp_dgrad: the source is the full-resolution SC_SRC_BNBWD operand (g, y, constants)");
   SC_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->Cout > 0 && a->src[0].C > 0, "sc_conv3x3_sp_dgrad: bad shape");
   SC_REQUIRE(a->H % 2 == 0 && a->W % 2 == 0, "sc_conv3x3_sp_dgrad: even gradient size");
-  SC_REQUIRE(a->terms == SC_TERMS_F16X2, "sc_conv3x3_sp_dgrad: two-fp16-term arithmetic only (terms = SC_TERMS_F16X2)");
+  SC_REQUIRE(a->terms == SC_TERMS_F16X2 || a->terms == 1, "sc_conv3x3_sp_dgrad: terms = SC_TERMS_F16X2 (two fp16 terms) or 1 (one bf16 term)");
   SC_REQUIRE(a->add0 == nullptr && a->add1 == nullptr && a->stats == nullptr && a->csplit > 0 && a->csplit <= a->Cout,
              "sc_conv3x3_sp_dgrad: outputs are out0 [N, csplit, H/2, W/2] (+ out1 [N, Cout - csplit, H, W]); no add / stats");
   SC_REQUIRE((a->csplit == a->Cout) == (a->out1 == nullptr), "sc_conv3x3_sp_dgrad: out1 exactly when csplit < Cout");
@@ -775,12 +800,20 @@ extern "C" int sc_conv3x3_sp_dgrad(const sc_conv_args* a, sc_stream stream) {
   const long grid = (tiles + 7) / 8 * 8 * ncot;
   SC_REQUIRE(grid < (1L << 31), "sc_conv3x3_sp_dgrad: grid too large");
   static const bool attr_ok = [] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<32>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<32>()) == hipSuccess &&
-           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<16>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<32>()) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<32>()) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess;
   }();
   SC_REQUIRE(attr_ok, "sc_conv3x3_sp_dgrad: cannot reserve %d bytes of LDS", sp_smem_bytes<32>());
-  if (TW == 32) hipLaunchKernelGGL((k_conv3_spd<32>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<32>(), (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((k_conv3_spd<16>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<16>(), (hipStream_t)stream, p);
+  const bool bf = a->terms == 1;
+  if (TW == 32) {
+    if (bf) hipLaunchKernelGGL((k_conv3_spd<32, true>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<32>(), (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((k_conv3_spd<32, false>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<32>(), (hipStream_t)stream, p);
+  } else {
+    if (bf) hipLaunchKernelGGL((k_conv3_spd<16, true>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<16>(), (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((k_conv3_spd<16, false>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<16>(), (hipStream_t)stream, p);
+  }
   SC_LAUNCH_OK("sc_conv3x3_sp_dgrad");
   return SC_OK;
 }

@@ -20,7 +20,9 @@ static inline size_t sp_pack_items(int Cout, int Cup, int Csk) {
 }
 
 // item i -> (cout tile, chunk, py, px, a, b, half, col, j); w is the OIHW filter [Cout][Cup + Csk][3][3]
-__device__ __forceinline__ void sp_pack_item(const float* __restrict__ w, unsigned short* __restrict__ out, size_t i, int Cout, int Cup, int Csk) {
+// bf = true: ONE bf16 term of the plain value (the "bf16" precision mode), stages of SP_WST / 2 entries, entry index without the term
+__device__ __forceinline__ void sp_pack_item(const float* __restrict__ w, unsigned short* __restrict__ out, size_t i, int Cout, int Cup, int Csk,
+                                             bool bf = false) {
   const int nku = (Cup + 15) / 16, nkt = nku + 4 * ((Csk + 15) / 16), CinTot = Cup + Csk;
   size_t r = i;
   const int j = (int)(r % 8); r /= 8;
@@ -51,6 +53,11 @@ __device__ __forceinline__ void sp_pack_item(const float* __restrict__ w, unsign
       if (k < Csk && kh >= 0 && kh <= 2 && kw >= 0 && kw <= 2) v = w[((size_t)m * CinTot + Cup + k) * 9 + kh * 3 + kw];
     }
   }
+  if (bf) {
+    const size_t e = ((size_t)mt * nkt + chunk) * (SP_WST / 2) + (((((size_t)py * 2 + px) * 2 + a) * 2 + b) * 2 + half) * 32 + col;
+    out[e * 8 + j] = __builtin_bit_cast(unsigned short, (__bf16)v);
+    return;
+  }
   const float vs = __builtin_amdgcn_fmed3f(v * SP_SW, -65504.f, 65504.f);
   const _Float16 h0 = (_Float16)vs;
   const _Float16 h1 = (_Float16)(vs - (float)h0);
@@ -73,7 +80,7 @@ static inline size_t spd_pack_items(int Cout, int Cup) {
   return (size_t)((Cup + 127) / 128) * 4 * ((Cout + 15) / 16) * (SP_WST / 2) * 8;
 }
 __device__ __forceinline__ void spd_pack_item(const float* __restrict__ w, unsigned short* __restrict__ out, size_t i, int Cout, int CinTot, int Cup,
-                                              bool vskip = false) {
+                                              bool vskip = false, bool bf = false) {
   const int nkt = 4 * ((Cout + 15) / 16);
   size_t r = i;
   const int j = (int)(r % 8); r /= 8;
@@ -98,6 +105,11 @@ __device__ __forceinline__ void spd_pack_item(const float* __restrict__ w, unsig
     const int kw0 = (px == 0) ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), kw1 = (px == 0) ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
     for (int kh = kh0; kh <= kh1; ++kh)
       for (int kw = kw0; kw <= kw1; ++kw) v += wp[kh * 3 + kw];
+  }
+  if (bf) {
+    const size_t e = ((size_t)mt * nkt + chunk) * (SP_WST / 2) + (((((size_t)h * 2 + mx) * 2 + a) * 2 + b) * 2 + half) * 32 + col;
+    out[e * 8 + j] = __builtin_bit_cast(unsigned short, (__bf16)v);
+    return;
   }
   const float vs = __builtin_amdgcn_fmed3f(v * SP_SW, -65504.f, 65504.f);
   const _Float16 h0 = (_Float16)vs;

@@ -181,6 +181,9 @@ _EXP_NO_WGRAD = os.environ.get("STARCOP_EXP_NO_WGRAD", "0") == "1"
 _EXP_SIDE2 = os.environ.get("STARCOP_EXP_SIDE2", "0") == "1"      # tools/: elimination experiment only
 
 
+_SP_TERMS = (TERMS_F16X2, 1)      # arithmetic modes of the sub-pixel forward / data-gradient kernels (conv_sp.hip)
+
+
 def _use_sp(N, Ho, Wo, Cout):
     """forward of a decoder conv1 with an Ho x Wo output on sc_conv3x3_sp?"""
     if _SP == "0" or Ho % 2 or Wo % 2:
@@ -702,13 +705,14 @@ class HyperStarcopUNet(nn.Module):
                         ent["bA"] = torch.empty(lib.sc_packed_weight_floats_bx3(co, ci, 64, 1, tb_), dtype=torch.float32, device=dev)
                         ent["bB"] = torch.empty(lib.sc_packed_weight_floats_bx3(co, ci, 32, 1, tb_), dtype=torch.float32, device=dev)
                         ent["bB_off"] = ent["bB"].numel() // (-(-ci // 32)) * (cu // 32)      # floats before the skip channels' tile
-                # decoder conv1 forward as a sub-pixel convolution (two-fp16-term arithmetic only): phase / parity filters
-                if op.get("up") and xf and tf_ == TERMS_F16X2 and _SP != "0":
+                # decoder conv1 forward as a sub-pixel convolution (the two-fp16-term arithmetic or, "bf16", one bf16 term): phase /
+                # parity filters
+                if op.get("up") and xf and tf_ in _SP_TERMS and _SP != "0":
                     cu = op["ins"][0].C
                     ent["sp"] = torch.empty(lib.sc_packed_weight_floats_sp(co, cu, ci - cu), dtype=torch.float32, device=dev)
                     ent["sp_cu"] = cu
                 # ... and the data gradient of its up-sampled channels (the skip channels' gradient: a 3x3 launch on a 32-wide pack)
-                if op.get("up") and xb and tb_ == TERMS_F16X2 and _SP != "0" and op["ins"][0].C % 32 == 0:
+                if op.get("up") and xb and tb_ in _SP_TERMS and _SP != "0" and op["ins"][0].C % 32 == 0:
                     cu = op["ins"][0].C
                     ent["spd"] = torch.empty(lib.sc_packed_weight_floats_spd(co, cu), dtype=torch.float32, device=dev)
                     ent["sp_cu"] = cu
@@ -755,14 +759,15 @@ class HyperStarcopUNet(nn.Module):
                     starts.append(nblk)
                     nblk += -(-total // 256)
                 if ent.get("spd") is not None and need_bwd:
-                    tfl = 2 if ent["spd_vskip"] else 1
+                    tfl = (2 if ent["spd_vskip"] else 1) | (4 if ent["terms_b"] == 1 else 0)      # | 4: the one-bf16-term layout
                     total = lib.sc_pack_work_items(co, ci, ks, ent["sp_cu"], tfl, PACK_SPD)
                     rows.append((conv.weight.data_ptr(), ent["spd"].data_ptr(), co, ci, ks, ent["sp_cu"], tfl, PACK_SPD, total))
                     starts.append(nblk)
                     nblk += -(-total // 256)
                 if ent.get("sp") is not None:
-                    total = lib.sc_pack_work_items(co, ci, ks, ent["sp_cu"], 0, PACK_SP)
-                    rows.append((conv.weight.data_ptr(), ent["sp"].data_ptr(), co, ci, ks, ent["sp_cu"], 0, PACK_SP, total))
+                    tfl = 4 if ent["terms_f"] == 1 else 0
+                    total = lib.sc_pack_work_items(co, ci, ks, ent["sp_cu"], tfl, PACK_SP)
+                    rows.append((conv.weight.data_ptr(), ent["sp"].data_ptr(), co, ci, ks, ent["sp_cu"], tfl, PACK_SP, total))
                     starts.append(nblk)
                     nblk += -(-total // 256)
                 for tflip, buf in ((0, ent["tf"]), (1, ent["tb"])):
@@ -880,7 +885,7 @@ class HyperStarcopUNet(nn.Module):
                     fl = 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * conv.kernel_size[0] ** 2
                     fle = None
                     ent_ = self._wpk[i]
-                    if (op.get("up") and ent_.get("sp") is not None and ent_["terms_f"] == TERMS_F16X2 and self.split_bf16
+                    if (op.get("up") and ent_.get("sp") is not None and ent_["terms_f"] in _SP_TERMS and self.split_bf16
                             and ent_["tf"] is None and _use_sp(N, Ho, Wo, o.C)):
                         cu_ = op["ins"][0].C        # per low-resolution pixel: 16 slots per up-sampled channel, 16 per (skip channel, parity)
                         fle = 2.0 * N * (Ho // 2) * (Wo // 2) * 16 * (-(-conv.out_channels // 32) * 32) * (cu_ + 4 * (conv.in_channels - cu_))
@@ -920,7 +925,7 @@ class HyperStarcopUNet(nn.Module):
                 if ty == "pw" and _use_pw3(0, N, Ho * Wo, conv.in_channels, conv.out_channels):
                     fconv = lib.sc_conv1x1_pw3
                     a.wpk = ent["pf"].data_ptr()
-                elif (op.get("up") and ent.get("sp") is not None and ent["terms_f"] == TERMS_F16X2 and self.split_bf16
+                elif (op.get("up") and ent.get("sp") is not None and ent["terms_f"] in _SP_TERMS and self.split_bf16
                       and _use_sp(N, Ho, Wo, o.C)):
                     fconv = lib.sc_conv3x3_sp
                     a.wpk = ent["sp"].data_ptr()
@@ -1442,7 +1447,7 @@ class HyperStarcopUNet(nn.Module):
                 gin_elems -= N * ins[0].C * Ho * Wo * 3 // 4
             thin_b = (ent["tb"] is not None and not op.get("up") and ins[0].name not in written and res_of.get(ins[0].name) is None)
             fle = None
-            if (op.get("up") and ent.get("spd") is not None and ent["terms_b"] == TERMS_F16X2 and self.split_bf16
+            if (op.get("up") and ent.get("spd") is not None and ent["terms_b"] in _SP_TERMS and self.split_bf16
                     and _use_spd(N, Ho, Wo, ins[0].C, conv.in_channels - ins[0].C)):
                 cu_ = ins[0].C          # up-sampled channels: 4 parity planes x 4 taps per low-resolution pixel; skip channels: the 3x3 form
                 fle = (2.0 * N * (Ho // 2) * (Wo // 2) * 16 * conv.out_channels * (-(-cu_ // 128) * 128)
@@ -1450,7 +1455,7 @@ class HyperStarcopUNet(nn.Module):
             tok = self._pb("k_conv3_thin_h (fwd+dgrad)" if thin_b else
                            self._bx3_family("dgrad") if ent["bx3_b"] else f"k_conv_mfma<{ks}> (fwd+dgrad)", flop,
                            4.0 * (2 * N * o.C * Ho * Wo + gin_elems + conv.weight.numel()), fle)
-            if (op.get("up") and ent.get("spd") is not None and ent["terms_b"] == TERMS_F16X2 and self.split_bf16
+            if (op.get("up") and ent.get("spd") is not None and ent["terms_b"] in _SP_TERMS and self.split_bf16
                     and _use_spd(N, Ho, Wo, ins[0].C, conv.in_channels - ins[0].C)):
                 if ent["spd_vskip"]:
                     # <= 64 up-sampled + <= 16 skip channels (decoder.blocks.3): the skip channels' gradient as virtual channels of the

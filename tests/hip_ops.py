@@ -164,28 +164,31 @@ def wgrad_pw3(dy, src, N, H, W, Cout, Cin, deferred=False):
     return dw
 
 
-def pack_sp(w, cup, batched=False):
+def pack_sp(w, cup, batched=False, terms=None):
     """decoder conv1 filter (Cout, Cup + Cskip, 3, 3) -> the phase / parity layout of sc_conv3x3_sp; batched: through the one-launch
     pack (the network's path)"""
     import numpy as np
     from starcop_amd._lib import PACK_SP
     lib = _lib.load()
     co, ci = w.shape[0], w.shape[1]
-    out = torch.full((lib.sc_packed_weight_floats_sp(co, cup, ci - cup),), float("nan"), device=DEV)     # every entry must be written
+    from starcop_amd._lib import TERMS_F16X2
+    terms = TERMS_F16X2 if terms is None else terms
+    tfl = 4 if terms == 1 else 0                      # one bf16 term: half the entries
+    out = torch.full((lib.sc_packed_weight_floats_sp(co, cup, ci - cup) // (2 if terms == 1 else 1),), float("nan"), device=DEV)     # every entry must be written
     if not batched:
-        check(lib.sc_pack_weights_sp(ptr(w), ptr(out), co, cup, ci - cup, stream()))
+        check(lib.sc_pack_weights_sp(ptr(w), ptr(out), co, cup, ci - cup, terms, stream()))
         return out
-    total = lib.sc_pack_work_items(co, ci, 3, cup, 0, PACK_SP)
+    total = lib.sc_pack_work_items(co, ci, 3, cup, tfl, PACK_SP)
     dt = np.dtype([("w", "<u8"), ("wpk", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"), ("ks", "<i4"), ("co_t", "<i4"),
                    ("tflip", "<i4"), ("bx3", "<i4"), ("total", "<u8")])
-    descs = torch.from_numpy(np.array([(w.data_ptr(), out.data_ptr(), co, ci, 3, cup, 0, PACK_SP, total)], dtype=dt).view(np.uint8).copy()).to(DEV)
+    descs = torch.from_numpy(np.array([(w.data_ptr(), out.data_ptr(), co, ci, 3, cup, tfl, PACK_SP, total)], dtype=dt).view(np.uint8).copy()).to(DEV)
     starts = torch.zeros(1, dtype=torch.int32, device=DEV)
     _KEEP.extend([descs, starts])
     check(lib.sc_pack_weights_batch(ptr(descs), ptr(starts), 1, -(-total // 256), stream()))
     return out
 
 
-def conv_sp(srcs, wpk, N, H, W, Cout, want_stats=False):
+def conv_sp(srcs, wpk, N, H, W, Cout, want_stats=False, terms=None):
     """sc_conv3x3_sp: srcs = [half-resolution source (up = 1)] or [that, full-resolution skip source]; H x W = output size"""
     from starcop_amd._lib import TERMS_F16X2
     lib = _lib.load()
@@ -199,35 +202,38 @@ def conv_sp(srcs, wpk, N, H, W, Cout, want_stats=False):
     a.out0, a.out1, a.csplit = out.data_ptr(), None, Cout
     a.accum0 = a.accum1 = 0
     a.add0 = a.add1 = None
-    a.terms, a.down0, a.absmax = TERMS_F16X2, 0, None
+    a.terms, a.down0, a.absmax = (TERMS_F16X2 if terms is None else terms), 0, None
     stats = torch.full((lib.sc_sp_stat_rows(N, H, W), Cout, 2), float("nan"), device=DEV) if want_stats else None
     a.stats = stats.data_ptr() if want_stats else None
     check(lib.sc_conv3x3_sp(C.byref(a), stream()))
     return out, stats
 
 
-def pack_spd(w, cup, batched=False, vskip=False):
+def pack_spd(w, cup, batched=False, vskip=False, terms=None):
     """decoder conv1 filter (Cout, Cup + Cskip, 3, 3) -> the parity / tap layout of sc_conv3x3_sp_dgrad (vskip: with the skip
     channels as virtual channels of the tile's second half)"""
     import numpy as np
     from starcop_amd._lib import PACK_SPD
     lib = _lib.load()
     co, ci = w.shape[0], w.shape[1]
-    out = torch.full((lib.sc_packed_weight_floats_spd(co, cup),), float("nan"), device=DEV)
+    from starcop_amd._lib import TERMS_F16X2
+    terms = TERMS_F16X2 if terms is None else terms
+    tfl = (2 if vskip else 1) | (4 if terms == 1 else 0)
+    out = torch.full((lib.sc_packed_weight_floats_spd(co, cup) // (2 if terms == 1 else 1),), float("nan"), device=DEV)
     if not batched:
-        check(lib.sc_pack_weights_spd(ptr(w), ptr(out), co, ci, cup, int(vskip), stream()))
+        check(lib.sc_pack_weights_spd(ptr(w), ptr(out), co, ci, cup, int(vskip), terms, stream()))
         return out
-    total = lib.sc_pack_work_items(co, ci, 3, cup, 2 if vskip else 1, PACK_SPD)
+    total = lib.sc_pack_work_items(co, ci, 3, cup, tfl, PACK_SPD)
     dt = np.dtype([("w", "<u8"), ("wpk", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"), ("ks", "<i4"), ("co_t", "<i4"),
                    ("tflip", "<i4"), ("bx3", "<i4"), ("total", "<u8")])
-    descs = torch.from_numpy(np.array([(w.data_ptr(), out.data_ptr(), co, ci, 3, cup, 2 if vskip else 1, PACK_SPD, total)], dtype=dt).view(np.uint8).copy()).to(DEV)
+    descs = torch.from_numpy(np.array([(w.data_ptr(), out.data_ptr(), co, ci, 3, cup, tfl, PACK_SPD, total)], dtype=dt).view(np.uint8).copy()).to(DEV)
     starts = torch.zeros(1, dtype=torch.int32, device=DEV)
     _KEEP.extend([descs, starts])
     check(lib.sc_pack_weights_batch(ptr(descs), ptr(starts), 1, -(-total // 256), stream()))
     return out
 
 
-def conv_sp_dgrad(dy_src, wpk, N, H, W, Cup, absmax=None, accum_into=None, cskip=0, skip_into=None):
+def conv_sp_dgrad(dy_src, wpk, N, H, W, Cup, absmax=None, accum_into=None, cskip=0, skip_into=None, terms=None):
     """sc_conv3x3_sp_dgrad: dy_src = the BNBWD operand of the layer's output (H x W) -> gradient of the half-resolution source;
     cskip > 0 (vskip pack): also the skip channels' full-resolution gradient -> returns (dprev, dskip)"""
     from starcop_amd._lib import TERMS_F16X2
@@ -245,7 +251,7 @@ def conv_sp_dgrad(dy_src, wpk, N, H, W, Cup, absmax=None, accum_into=None, cskip
     a.accum0, a.accum1 = (1 if accum_into is not None else 0), (1 if skip_into is not None else 0)
     a.add0 = a.add1 = None
     a.stats = None
-    a.terms, a.down0 = TERMS_F16X2, 0
+    a.terms, a.down0 = (TERMS_F16X2 if terms is None else terms), 0
     a.absmax = absmax.data_ptr() if absmax is not None else None
     check(lib.sc_conv3x3_sp_dgrad(C.byref(a), stream()))
     return (out, osk) if cskip else out

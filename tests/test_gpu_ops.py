@@ -251,6 +251,68 @@ def test_conv_sp_raw_sources_and_filter_range(hip):
     assert relerr(out, ref) < BX3_TOL
 
 
+def _sp_phase_reference(prev, skip, w, rnd_op):
+    """conv3x3(cat([nearest_up2(prev), skip])) written as the sub-pixel convolution of conv_sp_pack.h, in float64, with `rnd_op`
+    applied to the operands the kernel rounds: the activations and the PHASE filters (sums of taps, formed in fp32 in kh, kw order)"""
+    N, cu, Hl, Wl = prev.shape
+    S = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}
+    out = torch.zeros(N, w.shape[0], 2 * Hl, 2 * Wl, dtype=torch.float64)
+    xp = F.pad(rnd_op(prev), (1, 1, 1, 1))
+    for py in range(2):
+        for px in range(2):
+            wph = torch.zeros(w.shape[0], cu, 2, 2)
+            for a in range(2):
+                for b in range(2):
+                    for kh in S[(py, a)]:
+                        for kw in S[(px, b)]:
+                            wph[:, :, a, b] += w[:, :cu, kh, kw]
+            # source offset of tap (a, b): (a - 1 + py, b - 1 + px) -> a 2x2 correlation on the padded plane shifted by (py, px)
+            out[:, :, py::2, px::2] += F.conv2d(xp[:, :, py:py + Hl + 1, px:px + Wl + 1], rnd_op(wph))
+    if skip is not None:
+        out += F.conv2d(rnd_op(skip), rnd_op(w[:, cu:]), padding=1)
+    return out
+
+
+@pytest.mark.parametrize("c0,c1,cout,H,W", [(64, 16, 32, 16, 64), (128, 24, 64, 24, 80), (40, 9, 24, 36, 70), (32, 0, 33, 20, 72)])
+def test_conv_sp_bf16_single_term(hip, c0, c1, cout, H, W):
+    """terms = 1 of the sub-pixel kernels (the "bf16" precision mode): forward and data gradient equal float64 evaluations of the same
+    sub-pixel sums on bf16-rounded operands (activations, dy and the PHASE filters) to fp32-accumulation accuracy, and stay within
+    bf16 rounding of the unrounded layer; both pack paths, statistics rows, the one-launch skip gradient (vskip)"""
+    N = 2
+    prev, w = rnd(N, c0, H // 2, W // 2, seed=1), rnd(cout, c0 + c1, 3, 3, seed=3, scale=0.1)
+    skip = rnd(N, c1, H, W, seed=2) if c1 else None
+    rb = lambda t: t.float().bfloat16().double()
+    ident = lambda t: t.double()
+    full = F.conv2d(torch.cat([F.interpolate(prev, scale_factor=2, mode="nearest")] + ([skip] if c1 else []), 1).double(), w.double(), padding=1)
+    assert relerr(_sp_phase_reference(prev, skip, w, ident), full) < 1e-6          # (the restated sums are the layer)
+    ref_r = _sp_phase_reference(prev, skip, w, rb)
+    srcs = [make_src(dev(prev), c0, SRC_RAW, up=1)] + ([make_src(dev(skip), c1, SRC_RAW)] if c1 else [])
+    wd = dev(w)
+    for batched in (False, True):
+        wpk = pack_sp(wd, c0, batched=batched, terms=1)
+        assert bool(torch.isfinite(wpk.view(torch.int16).float()).all())
+        out, stats = conv_sp(srcs, wpk, N, H, W, cout, want_stats=True, terms=1)
+        assert relerr(out, ref_r) < 5e-6 and relerr(out, full) < 2e-2
+        assert relerr(stats.double().sum(0).cpu()[:, 1], (ref_r ** 2).sum((0, 2, 3))) < 1e-5
+    # data gradient: dy = g exactly (identity BatchNorm-backward constants, no activation), so the rounded operand is rb(g)
+    if c0 % 32:
+        return
+    g = rnd(N, cout, H, W, seed=5)
+    cst = torch.zeros(cout, SC_CST)
+    cst[:, 0], cst[:, 2] = 1.0, 1.0
+    src = make_src(dev(g), cout, SRC_BNBWD, act=ACT_NONE, cst=dev(cst), aux=dev(rnd(N, cout, H, W, seed=6)))
+    pv = prev.double().requires_grad_(True)
+    sk = skip.double().requires_grad_(True) if c1 else None
+    _sp_phase_reference(pv, sk, w, lambda t: t.double() if t.requires_grad or t.grad_fn is not None else rb(t)).backward(rb(g))
+    for batched in (False, True):
+        dx = conv_sp_dgrad(src, pack_spd(wd, c0, batched=batched, terms=1), N, H, W, c0, terms=1)
+        assert relerr(dx, pv.grad) < 5e-6
+    if c0 <= 64 and 0 < c1 <= 16:
+        for batched in (False, True):
+            o_up, o_sk = conv_sp_dgrad(src, pack_spd(wd, c0, batched=batched, vskip=True, terms=1), N, H, W, c0, cskip=c1, terms=1)
+            assert relerr(o_up, pv.grad) < 5e-6 and relerr(o_sk, sk.grad) < 5e-6
+
+
 @pytest.mark.parametrize("cin,cout,H,W", [(32, 16, 32, 32), (16, 32, 20, 40), (80, 32, 16, 32), (256, 128, 4, 6), (152, 64, 24, 32)])
 def test_conv_bx3_dgrad_bnbwd_split_add(hip, split_mode, cin, cout, H, W):
     N = 2

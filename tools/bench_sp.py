@@ -54,7 +54,7 @@ for name, cu, cs, cout, H in ([] if os.environ.get("SP_WGRAD_ONLY") else SHAPES)
     t_ref = 0.0 if os.environ.get("SP_ONLY") else timeit(lambda: conv_mfma(srcs, wb, N, H, W, cout, 3, co_t, want_stats=True, outs=ref, bx3=True, terms=TERMS_F16X2))
     # sub-pixel: one launch, the skip channels as parity planes
     wsp = torch.empty(lib.sc_packed_weight_floats_sp(cout, cu, cs), device=DEV)
-    check(lib.sc_pack_weights_sp(ptr(w), ptr(wsp), cout, cu, cs, stream()))
+    check(lib.sc_pack_weights_sp(ptr(w), ptr(wsp), cout, cu, cs, TERMS_F16X2, stream()))
     out = torch.empty(N, cout, H, W, device=DEV)
     rows = lib.sc_sp_stat_rows(N, H, W)
     stats = torch.full((rows, cout, 2), float("nan"), device=DEV)
