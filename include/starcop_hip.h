@@ -102,6 +102,19 @@ int sc_pack_weights_batch(const sc_pack_desc* descs_dev, const uint32_t* block_s
  *   stats  : if non-NULL, per-channel sum / sum-of-squares of acc over each work-group's pixel tile are written to
  *            stats[row][Cout][2] (float), row = n*tiles + tile, rows = sc_stat_rows(SC_STAT_CONV3|CONV1, N, H, W)
  */
+/* BatchNorm-backward sums of the tensor whose gradient a data-gradient launch writes into out0 (sc_conv3x3_bx3, sc_conv3x3_thin16,
+ * sc_conv3x3_sp_dgrad): what sc_bn_bwd_reduce(out0, y, cst, act, ...) would compute by streaming both tensors again, left by the
+ * launch that produces the gradient -- valid when that launch writes the COMPLETE gradient (single consumer: accum0 = 0, no add
+ * tensors).  rows[sc_stat_rows(SC_STAT_CONV3, N, H, W)][C][2] (float) = {sum g', sum g' x_hat} over each work-group's pixel tile,
+ * g' = out0 * act'(BN(y)), for sc_bn_bwd_finalize_rows32 (sc_conv3x3_sp_dgrad: rows = sc_sp_stat_rows(N, H, W));
+ * absmax (or NULL): raised (atomic max; zeroed by the caller) to max |scale_c g'|, the range hint of the SC_TERMS_F16X2 kernels. */
+typedef struct sc_bnr_args {
+  const float* y;        /* raw (pre-BatchNorm) values of the tensor, same shape as out0   */
+  const float* cst;      /* its forward constants {scale, shift, mean, invstd, ..} [C][SC_CST] */
+  int32_t act;           /* its activation (SC_ACT_*)                                       */
+  float* rows;
+  float* absmax;
+} sc_bnr_args;
 #define SC_TERMS_F16X2 4   /* `terms` code: two fp16 terms per operand with exact power-of-two range scaling (22 significand
                             * bits, three products: fp32-level accuracy at half the MFMA work of the three-term bf16 split) */
 typedef struct sc_conv_args {
@@ -128,6 +141,7 @@ typedef struct sc_conv_args {
                           * (sc_bn_finalize(act_bound) in training, sc_add_srcs_absmax records) or NULL (ReLU6-bounded / unknown): the
                           * kernels scale the fp16 operand by 2 when 2 M <= 32752 and by the largest power of two with s M <= 32752
                           * otherwise, so a BatchNorm'd activation can never reach the +-65504 clamp                         */
+  const sc_bnr_args* bnr;/* data-gradient launches (SC_SRC_BNBWD source): also leave the BatchNorm-backward sums of out0's tensor, or NULL */
 } sc_conv_args;
 int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream);
 /* 1x1 convolution for few-pixel / long-K layers (the <= 64^2 inverted-residual projections and the data gradients of the
@@ -379,9 +393,11 @@ int sc_bn_finalize(const float* stats, int nrows, double count, const float* gam
  * value a consumer of this tensor stages; the two-fp16-term kernels need it below 32752 (HyperStarcopUNet.split_range_report) */
 int sc_bn_bwd_reduce(const float* g, const float* y, const float* cst_fwd, int act,
                      double* sums, int N, int C, int HW, float* absmax, float* act_absmax, sc_stream stream);
-/* dgamma, dbeta and the SC_SRC_BNBWD constants {scale, shift, A, B, D} */
+/* dgamma, dbeta and the SC_SRC_BNBWD constants {scale, shift, A, B, D}  (sc_bn_bwd_finalize_rows32: float rows, sc_bnr_args) */
 int sc_bn_bwd_finalize(const double* sums, int nrows, double count, const float* cst_fwd,
                        float* dgamma, float* dbeta, float* cst_bwd, int C, sc_stream stream);
+int sc_bn_bwd_finalize_rows32(const float* rows, int nrows, double count, const float* cst_fwd,
+                       float* dgamma, float* dbeta, float* cst_bwd, int C, double* scratch /* 64 * 2 * C doubles or NULL: coalesced pre-reduction from 4096 rows up */, sc_stream stream);
 /* both steps in one launch for few-pixel layers (one block per channel over all N*HW elements); same outputs */
 int sc_bn_bwd_small(const float* g, const float* y, const float* cst_fwd, int act, int N, int C, int HW,
                     float* dgamma, float* dbeta, float* cst_bwd, float* absmax, float* act_absmax, sc_stream stream);

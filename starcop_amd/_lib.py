@@ -37,7 +37,12 @@ class sc_conv_args(C.Structure):
                 ("out0", C.c_void_p), ("out1", C.c_void_p),
                 ("csplit", C.c_int32), ("accum0", C.c_int32), ("accum1", C.c_int32),
                 ("add0", C.c_void_p), ("add1", C.c_void_p), ("stats", C.c_void_p), ("terms", C.c_int32), ("down0", C.c_int32),
-                ("absmax", C.c_void_p), ("xbound", C.c_void_p * 2)]
+                ("absmax", C.c_void_p), ("xbound", C.c_void_p * 2), ("bnr", C.c_void_p)]
+
+
+class sc_bnr_args(C.Structure):
+    """BatchNorm-backward sums left by a data-gradient launch (include/starcop_hip.h: sc_bnr_args)"""
+    _fields_ = [("y", C.c_void_p), ("cst", C.c_void_p), ("act", C.c_int32), ("rows", C.c_void_p), ("absmax", C.c_void_p)]
 
 
 class sc_wgrad_args(C.Structure):
@@ -109,6 +114,7 @@ SIGNATURES = {
     "sc_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "sc_bn_bwd_small": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sc_bn_bwd_finalize": (_i, [_vp, _i, _d, _vp, _vp, _vp, _vp, _i, _vp]),
+    "sc_bn_bwd_finalize_rows32": (_i, [_vp, _i, _d, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "sc_add_srcs": (_i, [C.POINTER(sc_src), C.POINTER(sc_src), _vp, _i, _i, _i, _vp]),
     "sc_stream_wait_stream": (_i, [_vp, _vp]),
     "sc_add_srcs_absmax": (_i, [C.POINTER(sc_src), C.POINTER(sc_src), _vp, _i, _i, _i, _vp, _vp]),

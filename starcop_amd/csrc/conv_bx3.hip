@@ -143,7 +143,133 @@ struct ConvXP {
   const float* absmax;
   const float* xb0; const float* xb1;      // activation bounds of the sources (h_act_scale)
   int xcdmap;          // 1: 1-D grid, the cout tiles of a pixel tile numbered 8 apart (same XCD, back to back: its L2 serves the patch re-reads)
+  // sc_bnr_args: BatchNorm-backward sums of out0's tensor from the data-gradient epilogue (bnr_y = NULL: off)
+  const float* bnr_y; const float* bnr_cst; float* bnr_rows; float* bnr_absmax; int bnr_act;
 };
+
+static inline void set_bnr(ConvXP& p, const sc_bnr_args* b) {
+  p.bnr_y = b ? b->y : nullptr; p.bnr_cst = b ? b->cst : nullptr; p.bnr_rows = b ? b->rows : nullptr;
+  p.bnr_absmax = b ? b->absmax : nullptr; p.bnr_act = b ? b->act : SC_ACT_NONE;
+}
+
+__device__ __forceinline__ void wave_absmax_to(float mx, float* slot) {      // one atomic per wave, only when it raises the slot
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0 && mx > __builtin_nontemporal_load(slot)) atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, mx));
+}
+
+// Data-gradient epilogue of k_conv3_bx3 for a cout tile of out0 WITH the BatchNorm-backward sums of out0's tensor (sc_bnr_args): the
+// launch writes that tensor's complete gradient g (host: accum0 = 0, no add tensors), so what sc_bn_bwd_reduce(g, y) would compute
+// in a pass of its own over both tensors -- {sum g', sum g' x_hat}, g' = g act'(BN(y)), and the range hint max |scale g'| -- costs one
+// more read of y here.  Partial rows in the SC_STAT_CONV3 layout (two per work-group), summed in fp64 by sc_bn_bwd_finalize_rows32.
+// The raw values y of a (q) block are requested together (16 or 32 loads in flight per lane) before the stores of the block.
+template <int Q, bool HF>
+__device__ __forceinline__ void bx3_epilogue_bnr(const ConvXP& p, const floatx16 (&acc)[2][Q], float hinv, int n, int cot, int ty, int tx, int y0,
+                                                 int x0, int tiles_x, int wave, int l31, int lhi, int tid, float (&s_red)[4][32 * Q][2]) {
+  constexpr int CO_T = 32 * Q;
+  const int H = p.H, W = p.W, Cs = p.csplit, c0 = cot * CO_T;
+  const int ox = x0 + l31;
+  const float blo = sc_act_lo(p.bnr_act), bhi = sc_act_hi(p.bnr_act);
+  const float* const bc = p.bnr_cst + (size_t)c0 * SC_CST;
+  float mx = 0.f;
+  if (p.down0) {
+    const unsigned hq32 = (unsigned)((H >> 1) * (W >> 1));
+    const size_t cbase = ((size_t)n * Cs + c0) * hq32;
+    float* const ob = p.out0 + cbase;
+    const float* const yb = p.bnr_y + cbase;
+    const int oy = y0 + 2 * wave;
+    const bool st = !(l31 & 1) && oy < H && ox < W;
+    const unsigned loff = (unsigned)(4 * lhi) * hq32 + (unsigned)(st ? (oy >> 1) * (W >> 1) + (ox >> 1) : 0);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      float yv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cu = q * 32 + (r & 3) + 8 * (r >> 2);
+        yv[r] = (st && c0 + cu + 4 * lhi < Cs) ? yb[loff + (unsigned)cu * hq32] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cu = q * 32 + (r & 3) + 8 * (r >> 2);
+        const int col = cu + 4 * lhi;
+        const bool okc = c0 + col < Cs;
+        float v = ((oy < H) && (ox < W)) ? acc[0][q][r] : 0.f;
+        v += ((oy + 1 < H) && (ox < W)) ? acc[1][q][r] : 0.f;
+        if (HF) v *= hinv;
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+        const bool ok = st && okc;
+        if (ok) ob[loff + (unsigned)cu * hq32] = v;
+        const float4 cc = *reinterpret_cast<const float4*>(bc + (size_t)(okc ? col : 0) * SC_CST);
+        const float yh = fmaf(yv[r], cc.x, cc.y);
+        const float gq = (ok && yh > blo && yh < bhi) ? v : 0.f;
+        mx = fmaxf(mx, fabsf(gq * cc.x));
+        const float s = half_sum32(gq);
+        const float ss = half_sum32(gq * ((yv[r] - cc.z) * cc.w));
+        if (l31 == SC_HALF_SUM_LANE) { s_red[wave][col][0] = s; s_red[wave][col][1] = ss; }
+      }
+    }
+  } else {
+    const size_t HWs = (size_t)H * W;
+    const size_t cbase = ((size_t)n * Cs + c0) * HWs;
+    float* const ob = p.out0 + cbase;
+    const float* const yb = p.bnr_y + cbase;
+    const unsigned hw32 = (unsigned)HWs;
+    unsigned loff[2]; bool okp[2];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      const int oy = y0 + 2 * wave + pp;
+      okp[pp] = (oy < H) && (ox < W);
+      loff[pp] = (unsigned)(4 * lhi) * hw32 + (unsigned)(okp[pp] ? oy * W + ox : 0);
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      float yv[2][16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cu = q * 32 + (r & 3) + 8 * (r >> 2);
+        const bool okc = c0 + cu + 4 * lhi < Cs;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) yv[pp][r] = (okp[pp] && okc) ? yb[loff[pp] + (unsigned)cu * hw32] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cu = q * 32 + (r & 3) + 8 * (r >> 2);
+        const int col = cu + 4 * lhi;
+        const bool okc = c0 + col < Cs;
+        const float4 cc = *reinterpret_cast<const float4*>(bc + (size_t)(okc ? col : 0) * SC_CST);
+        float sv = 0.f, sq = 0.f;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+          const bool ok = okp[pp] && okc;
+          float v = ok ? acc[pp][q][r] : 0.f;
+          if (HF) v *= hinv;
+          if (ok) ob[loff[pp] + (unsigned)cu * hw32] = v;
+          const float yh = fmaf(yv[pp][r], cc.x, cc.y);
+          const float gq = (ok && yh > blo && yh < bhi) ? v : 0.f;
+          sv += gq;
+          sq = fmaf(gq, (yv[pp][r] - cc.z) * cc.w, sq);
+          mx = fmaxf(mx, fabsf(gq * cc.x));
+        }
+        const float s = half_sum32(sv);
+        const float ss = half_sum32(sq);
+        if (l31 == SC_HALF_SUM_LANE) { s_red[wave][col][0] = s; s_red[wave][col][1] = ss; }
+      }
+    }
+  }
+  if (p.bnr_absmax) wave_absmax_to(mx, p.bnr_absmax);
+  __syncthreads();
+  const int rows4 = (H + 3) >> 2;
+  for (int i = tid; i < 2 * CO_T * 2; i += 256) {
+    const int hh = i / (CO_T * 2), rem = i - hh * (CO_T * 2);
+    const int col = rem >> 1, k = rem & 1;
+    const int co = c0 + col;
+    const int t4 = 2 * ty + hh;
+    if (co < Cs && t4 < rows4) {
+      const size_t row = ((size_t)n * rows4 + t4) * tiles_x + tx;
+      p.bnr_rows[(row * Cs + co) * 2 + k] = s_red[2 * hh][col][k] + s_red[2 * hh + 1][col][k];
+    }
+  }
+}
 
 // exact three-term bf16 split of two floats; returns packed pairs (low half = first value)
 __device__ __forceinline__ void split3x2(float a, float b, unsigned& t0, unsigned& t1, unsigned& t2) {
@@ -582,6 +708,12 @@ __global__ __launch_bounds__(256, Q == 2 ? 2 : 3) void k_conv3_bx3(const ConvXP 
     const int c0 = first ? cot * CO_T : cot * CO_T - p.csplit;            // first channel of the tile in it
     const bool accum = first ? p.accum0 != 0 : p.accum1 != 0;
     const int Climit = first ? p.csplit : p.Cout;
+    if constexpr (BNB) {
+      if (first && p.bnr_y != nullptr) {       // + the BatchNorm-backward sums of out0's tensor (uniform branch)
+        bx3_epilogue_bnr<Q, HF>(p, acc, hinv, n, cot, ty, tx, y0, x0, tiles_x, wave, l31, lhi, tid, s_red);
+        return;
+      }
+    }
     if (first && p.down0) {
       // backward of nearest x2 upsampling fused into the store: the wave's two rows are a vertical pixel pair, adjacent lanes a
       // horizontal one -> sum the 2x2 block and store it at half resolution (no full-resolution temporary)
@@ -1357,6 +1489,61 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
   // uniform image base + 32-bit lane BYTE offsets (Cout * H * W < 2^30, host-checked): the 64-bit form cost ~60 VALU per thread
   float* const outn = p.out0 + (size_t)n * p.Cout * HWs;
   const unsigned HWu = (unsigned)HWs;
+  if constexpr (BNB) {
+    if (p.bnr_y != nullptr) {
+      // data gradient + the BatchNorm-backward sums of the tensor it belongs to (sc_bnr_args, see bx3_epilogue_bnr): the lane's 4 x NPB
+      // raw values y are requested together, then stores / masks / sums
+      const float* const yn = p.bnr_y + (size_t)n * p.Cout * HWs;
+      const float blo = sc_act_lo(p.bnr_act), bhi = sc_act_hi(p.bnr_act);
+      float yv[4][NPB];
+      float mx = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb) {
+          const int co = 4 * lg + r, oy = y0 + 2 * wave + pb / PBW, ox = x0 + 16 * (pb % PBW) + l15;
+          yv[r][pb] = (oy < H && ox < W && co < p.Cout) ? yn[(unsigned)co * HWu + (unsigned)(oy * W + ox)] : 0.f;
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = 4 * lg + r;
+        const float4 cc = *reinterpret_cast<const float4*>(p.bnr_cst + (size_t)(co < p.Cout ? co : 0) * SC_CST);
+        float sv[TW / 32], sq[TW / 32];
+#pragma unroll
+        for (int h = 0; h < TW / 32; ++h) { sv[h] = 0.f; sq[h] = 0.f; }
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb) {
+          const int oy = y0 + 2 * wave + pb / PBW, ox = x0 + 16 * (pb % PBW) + l15;
+          const bool ok = oy < H && ox < W && co < p.Cout;
+          const float v = ok ? acc[pb][r] * hinv : 0.f;
+          if (ok) *reinterpret_cast<float*>(reinterpret_cast<char*>(outn) + ((unsigned)co * HWu + (unsigned)(oy * W + ox)) * 4u) = v;
+          const float yh = fmaf(yv[r][pb], cc.x, cc.y);
+          const float gq = (ok && yh > blo && yh < bhi) ? v : 0.f;
+          sv[(pb % PBW) >> 1] += gq;
+          sq[(pb % PBW) >> 1] = fmaf(gq, (yv[r][pb] - cc.z) * cc.w, sq[(pb % PBW) >> 1]);
+          mx = fmaxf(mx, fabsf(gq * cc.x));
+        }
+#pragma unroll
+        for (int h = 0; h < TW / 32; ++h) {
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) { sv[h] += __shfl_xor(sv[h], o, 64); sq[h] += __shfl_xor(sq[h], o, 64); }
+          if (l15 == 0) { s_red[wave][h][co][0] = sv[h]; s_red[wave][h][co][1] = sq[h]; }
+        }
+      }
+      if (p.bnr_absmax) wave_absmax_to(mx, p.bnr_absmax);
+      __syncthreads();
+      const int rows4 = (H + 3) >> 2, tiles32 = (W + 31) >> 5;
+      if (tid < 2 * (TW / 32) * 16 * 2) {
+        const int hh = tid / ((TW / 32) * 32), h = (tid >> 5) % (TW / 32), col = (tid >> 1) & 15, k = tid & 1;
+        const int t4 = 2 * ty + hh, t32 = tx * (TW / 32) + h;
+        if (col < p.Cout && t4 < rows4 && t32 < tiles32) {
+          const size_t row = ((size_t)n * rows4 + t4) * tiles32 + t32;
+          p.bnr_rows[(row * p.Cout + col) * 2 + k] = s_red[2 * hh][h][col][k] + s_red[2 * hh + 1][h][col][k];
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int co = 4 * lg + r;
@@ -2340,6 +2527,12 @@ extern "C" int sc_conv3x3_bx3(const sc_conv_args* a, sc_stream stream) {
   const bool bnb = a->src[0].mode == SC_SRC_BNBWD;
   SC_REQUIRE(a->terms >= 0 && a->terms <= 4, "sc_conv3x3_bx3: terms must be 0 (= 3), 1, 2, 3 or SC_TERMS_F16X2 (got %d)", a->terms);
   p.absmax = a->absmax; p.xb0 = a->xbound[0]; p.xb1 = a->xbound[1];
+  set_bnr(p, a->bnr);
+  if (a->bnr) {
+    SC_REQUIRE(bnb && a->bnr->y && a->bnr->cst && a->bnr->rows, "sc_conv3x3_bx3: bnr needs a BNBWD source and y / cst / rows");
+    SC_REQUIRE(!a->accum0 && !a->add0 && !a->add1 && !a->stats, "sc_conv3x3_bx3: bnr: out0 must receive the complete gradient (no accum0 / add / stats)");
+    SC_REQUIRE(a->csplit == a->Cout || a->csplit % a->co_t == 0, "sc_conv3x3_bx3: bnr: csplit must fall on a cout-tile boundary");
+  }
 #define SC_LAUNCH_BX3(NT, HF)                                                                                  \
   do {                                                                                                         \
     if (a->co_t == 64 && bnb) hipLaunchKernelGGL((k_conv3_bx3<2, true, NT, HF>), grid, dim3(256), 0, st, p);   \
@@ -2352,7 +2545,7 @@ extern "C" int sc_conv3x3_bx3(const sc_conv_args* a, sc_stream stream) {
   if (a->terms == 1) SC_LAUNCH_BX3(1, false); else if (a->terms == 2) SC_LAUNCH_BX3(2, false);
   // the wave-specialised kernel pays for its 8-wave work-groups (prologue / epilogue of only two per CU) on short K loops:
   // measured faster from 16 chunks of 16 input channels up (decoder.blocks.0), level at 8-10, slower below
-  else if (a->terms == SC_TERMS_F16X2 && ws_env && (C0 + C1 + 15) / 16 >= ws_env_min && (!bnb || a->src[0].C <= 256)) {
+  else if (a->terms == SC_TERMS_F16X2 && ws_env && (C0 + C1 + 15) / 16 >= ws_env_min && (!bnb || a->src[0].C <= 256) && !a->bnr) {
     if (a->co_t == 64 && bnb) hipLaunchKernelGGL((k_conv3_ws<2, true>), grid, dim3(512), 0, st, p);
     else if (a->co_t == 64) hipLaunchKernelGGL((k_conv3_ws<2, false>), grid, dim3(512), 0, st, p);
     else if (bnb) hipLaunchKernelGGL((k_conv3_ws<1, true>), grid, dim3(512), 0, st, p);
@@ -2511,6 +2704,9 @@ extern "C" int sc_conv3x3_thin16(const sc_conv_args* a, sc_stream stream) {
   p.s0 = to_srcd(s); p.s1 = empty_srcd();
   p.wpk = reinterpret_cast<const uintx4*>(a->wpk); p.N = a->N; p.H = a->H; p.W = a->W; p.Cout = a->Cout;
   p.out0 = a->out0; p.csplit = a->Cout; p.stats = a->stats; p.absmax = a->absmax; p.xb0 = a->xbound[0]; p.xb1 = a->xbound[1];
+  set_bnr(p, a->bnr);
+  SC_REQUIRE(!a->bnr || (s.mode == SC_SRC_BNBWD && a->bnr->y && a->bnr->cst && a->bnr->rows && !a->stats),
+             "sc_conv3x3_thin16: bnr needs a BNBWD source, y / cst / rows and no stats");
   const int tw = Cin == 16 ? 64 : 32;                     // (k_conv3_thin_h: TW)
   dim3 grid(((a->W + tw - 1) / tw) * ((a->H + 7) / 8), 1, a->N);
   constexpr int xcdmap_env = 2;

@@ -301,7 +301,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_small(const float* __restrict__ 
   o[5] = 0.f; o[6] = 0.f; o[7] = 0.f;
 }
 
-__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const double* __restrict__ sums, int nrows, double count,
+template <typename RT>
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const RT* __restrict__ sums, int nrows, double count,
                                                          const float* __restrict__ cst_fwd, float* __restrict__ dgamma,
                                                          float* __restrict__ dbeta, float* __restrict__ cst_bwd, int C) {
   __shared__ double s_tmp[8];
@@ -653,9 +654,23 @@ extern "C" int sc_bn_bwd_small(const float* g, const float* y, const float* cst_
 extern "C" int sc_bn_bwd_finalize(const double* sums, int nrows, double count, const float* cst_fwd, float* dgamma,
                                   float* dbeta, float* cst_bwd, int C, sc_stream stream) {
   SC_REQUIRE(sums && cst_fwd && cst_bwd && C > 0 && count > 0 && nrows > 0, "sc_bn_bwd_finalize: bad argument");
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(C), dim3(256), 0, (hipStream_t)stream, sums, nrows, count, cst_fwd,
+  hipLaunchKernelGGL(k_bn_bwd_finalize<double>, dim3(C), dim3(256), 0, (hipStream_t)stream, sums, nrows, count, cst_fwd,
                      dgamma, dbeta, cst_bwd, C);
   SC_LAUNCH_OK("sc_bn_bwd_finalize");
+  return SC_OK;
+}
+
+extern "C" int sc_bn_bwd_finalize_rows32(const float* rows, int nrows, double count, const float* cst_fwd, float* dgamma,
+                                         float* dbeta, float* cst_bwd, int C, double* scratch, sc_stream stream) {
+  SC_REQUIRE(rows && cst_fwd && cst_bwd && C > 0 && count > 0 && nrows > 0, "sc_bn_bwd_finalize_rows32: bad argument");
+  if (nrows >= 4096 && scratch && 2 * C <= 1024) {       // many rows: the coalesced pre-reduction of sc_bn_finalize first
+    hipLaunchKernelGGL(k_bn_rows_prereduce, dim3(BN_PRE_S), dim3(1024), 0, (hipStream_t)stream, rows, nrows, C, scratch);
+    hipLaunchKernelGGL(k_bn_bwd_finalize<double>, dim3(C), dim3(256), 0, (hipStream_t)stream, (const double*)scratch, BN_PRE_S, count, cst_fwd,
+                       dgamma, dbeta, cst_bwd, C);
+  } else
+  hipLaunchKernelGGL(k_bn_bwd_finalize<float>, dim3(C), dim3(256), 0, (hipStream_t)stream, rows, nrows, count, cst_fwd,
+                     dgamma, dbeta, cst_bwd, C);
+  SC_LAUNCH_OK("sc_bn_bwd_finalize_rows32");
   return SC_OK;
 }
 

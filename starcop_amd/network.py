@@ -26,7 +26,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, sc_irt_args, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD, sc_wgrad_pending,
-                   PACK_PW3, PACK_SP, PACK_SPD, PACK_THIN16, STAT_PW3, STAT_CONV1, STAT_CONV1K, STAT_CONV3, STAT_DW, STAT_STEM, TERMS_F16X2, check, make_src, ptr,
+                   PACK_PW3, PACK_SP, PACK_SPD, PACK_THIN16, STAT_PW3, STAT_CONV1, STAT_CONV1K, STAT_CONV3, STAT_DW, STAT_STEM, TERMS_F16X2, check, make_src, ptr, sc_bnr_args,
                    sc_conv_args, sc_wgrad_args, stream)
 
 MBV2_SETTINGS = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2),
@@ -177,6 +177,13 @@ def _use_irt(N, Cin, Hd, Hin, Win, stride):
 # (16 output channels: half-empty MFMA rows) 196-213, level with sc_conv3x3_thin16's 202, stays there.  "1" = that rule, "all" =
 # every decoder conv1 (tests), "0" = off.
 _SP = os.environ.get("STARCOP_SP", "1")
+# BatchNorm-backward sums of a decoder tensor from the data-gradient launch that writes its gradient (sc_bnr_args) instead of the separate
+# sc_bn_bwd_reduce pass over (gradient, y).  Built, parity-tested and measured in round 5 (tools/bench_layers.py, batch 16, us): the pass it
+# removes streams at 5.3 TB/s, the extra read of y in a convolution epilogue runs at that kernel's 2.3-3 TB/s -- decoder.blocks.4.conv2
+# data gradient 197 -> 302 for a 120 -> 10 BatchNorm pass, blocks.3.conv2 134 -> 193 for 60 -> 10, blocks.4.conv1 (2x2 down-summed store,
+# every other lane idle) 244 -> 392 for 59 -> 13: the step loses 1 % (1444 / 1436 vs 1460 / 1454 tiles/s, same box, alternating).  OFF by
+# default; "1" enables it (tests/test_gpu_unet.py runs the network both ways).
+_BNR = os.environ.get("STARCOP_BNR", "0") == "1"
 _EXP_NO_WGRAD = os.environ.get("STARCOP_EXP_NO_WGRAD", "0") == "1"
 _EXP_SIDE2 = os.environ.get("STARCOP_EXP_SIDE2", "0") == "1"      # tools/: elimination experiment only
 
@@ -1140,6 +1147,7 @@ class HyperStarcopUNet(nn.Module):
                 dw_off += op["conv"].out_channels * 9
 
         reduced = set()      # tensors whose BatchNorm-backward sums were produced by the launch that wrote their gradient
+        reduced32 = {}       # ... by a convolution data-gradient launch (sc_bnr_args): name -> (float rows, number of rows)
         n_cons = {}          # consumers per tensor: a gradient is complete after ONE launch only for single-consumer tensors
         for op in self._ops:
             for t in op["ins"]:
@@ -1153,6 +1161,12 @@ class HyperStarcopUNet(nn.Module):
             if slot is not None:
                 amax = plan.gmax.data_ptr() + 4 * slot
                 gmax_slot[t.name] = amax
+            if t.name in reduced32:        # the data-gradient launch that wrote this gradient left float rows (sc_bnr_args)
+                rows_t, nrows = reduced32[t.name]
+                check(lib.sc_bn_bwd_finalize_rows32(ptr(rows_t), nrows, float(N * Ho * Wo), ptr(plan.cst[t.name]),
+                                                    ptr(gv(t.bn.weight)), ptr(gv(t.bn.bias)), ptr(plan.cstb[t.name]), t.C,
+                                                    ptr(plan.bn_scratch) if _BN_PRE else None, st))
+                return
             if t.name in reduced:          # the launch that wrote this gradient left the sums (and raised the range-hint slot)
                 check(lib.sc_bn_bwd_finalize(ptr(plan.dwsums[t.name]), plan.dwrows[t.name], float(N * Ho * Wo), ptr(plan.cst[t.name]),
                                              ptr(gv(t.bn.weight)), ptr(gv(t.bn.bias)), ptr(plan.cstb[t.name]), t.C, st))
@@ -1167,6 +1181,25 @@ class HyperStarcopUNet(nn.Module):
                                        ptr(plan.bsums_v[t.name]), N, t.C, Ho * Wo, amax, aact, st))
             check(lib.sc_bn_bwd_finalize(ptr(plan.bsums_v[t.name]), plan.brows[t.name], float(N * Ho * Wo), ptr(plan.cst[t.name]),
                                          ptr(gv(t.bn.weight)), ptr(gv(t.bn.bias)), ptr(plan.cstb[t.name]), t.C, st))
+
+        def bnr_for(t, nrows):
+            """sc_bnr_args for the data-gradient launch that is about to write the COMPLETE gradient of tensor t (a single-consumer,
+            BatchNorm'd tensor that nothing wrote or will add to): the launch leaves t's BatchNorm-backward sums (nrows partial rows) and
+            range hint, instead of sc_bn_bwd_reduce streaming (gradient, y) again -- 0.41 ms of such passes per batch-16 step in the decoder"""
+            if (not _BNR or t.bn is None or t.kind != "raw" or n_cons.get(t.name, 0) != 1 or t.name in written
+                    or res_of.get(t.name) is not None):
+                return None
+            if not hasattr(plan, "bnr_rows"):
+                plan.bnr_rows = {}
+            key = (t.name, nrows)
+            if key not in plan.bnr_rows:
+                plan.bnr_rows[key] = torch.empty(nrows * t.C * 2, dtype=torch.float32, device=self._pflat.device)
+            b = sc_bnr_args()
+            b.y, b.cst, b.act = plan.buf[t.name].data_ptr(), plan.cst[t.name].data_ptr(), t.act
+            b.rows = plan.bnr_rows[key].data_ptr()
+            b.absmax = (plan.gmax.data_ptr() + 4 * prod_idx[t.name]) if (half_bwd and self._ops[prod_idx[t.name]]["type"] == "conv3") else None
+            reduced32[t.name] = (plan.bnr_rows[key], nrows)
+            return b
 
         def reduce_pointwise_batch():
             """ONE launch (weight-gradient stream) sums the K-slice partials of every pointwise weight gradient queued so far"""
@@ -1441,6 +1474,8 @@ class HyperStarcopUNet(nn.Module):
                 conv_dgrad = lib.sc_conv2d_mfma
             a.add0 = None; a.add1 = None; a.stats = None
             a.accum0 = a.accum1 = 0
+            # (sc_bnr_args are taken by k_conv3_bx3, not by its wave-specialised variant, which sc_conv3x3_bx3 picks from 16 K chunks up)
+            bx3_plain = ent["bx3_b"] and not (a.terms == TERMS_F16X2 and (conv.out_channels + 15) // 16 >= 16 and conv.out_channels <= 256)
             # algorithmic bytes of the data gradient: g and y of the output once each, the input gradient once, the filter
             gin_elems = N * conv.in_channels * Ho * Wo
             if op.get("up") and ent["bx3_b"]:      # the upsampled source's gradient is stored 2x2-summed (quarter size)
@@ -1497,7 +1532,10 @@ class HyperStarcopUNet(nn.Module):
                     a.wpk, a.co_t = ent["bA"].data_ptr(), 64
                     a.out0, a.out1 = plan.grad[t_up.name].data_ptr(), None
                     a.accum0, a.down0 = (1 if t_up.name in written else 0), 1
+                    b_ = bnr_for(t_up, lib.sc_stat_rows(STAT_CONV3, N, Ho, Wo)) if bx3_plain else None
+                    a.bnr = C.addressof(b_) if b_ is not None else None
                     check(conv_dgrad(C.byref(a), st))
+                    a.bnr = None
                     a.Cout = a.csplit = t_sk.C
                     a.wpk, a.co_t = ent["bB"].data_ptr() + 4 * ent["bB_off"], 32
                     a.out0 = plan.grad[t_sk.name].data_ptr()
@@ -1520,6 +1558,10 @@ class HyperStarcopUNet(nn.Module):
                     written.add(t_sk.name)
                 else:
                     a.out1 = None
+                b_ = None
+                if fused_down and bx3_plain and (a.csplit == a.Cout or a.csplit % a.co_t == 0):
+                    b_ = bnr_for(t_up, lib.sc_stat_rows(STAT_CONV3, N, Ho, Wo))
+                a.bnr = C.addressof(b_) if b_ is not None else None
                 check(conv_dgrad(C.byref(a), st))
                 self._pe(tok)
                 if not fused_down:
@@ -1537,6 +1579,10 @@ class HyperStarcopUNet(nn.Module):
                 if thin_b:
                     conv_dgrad = lib.sc_conv3x3_thin16
                     a.wpk = ent["tb"].data_ptr()
+                b_ = None
+                if ks == 3 and (thin_b or (conv_dgrad is lib.sc_conv3x3_bx3 and bx3_plain)):
+                    b_ = bnr_for(tin, lib.sc_stat_rows(STAT_CONV3, N, Ho, Wo))
+                a.bnr = C.addressof(b_) if b_ is not None else None
                 check(conv_dgrad(C.byref(a), st))
                 self._pe(tok)
                 written.add(tin.name)

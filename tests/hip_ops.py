@@ -48,7 +48,8 @@ def pack_bx3(w, co_t, tflip, terms=None):
 
 
 def conv_mfma(srcs, wpk, N, H, W, Cout, ks, co_t, want_stats=False, csplit=None, add0=None, add1=None,
-              accum=None, outs=None, bx3=False, ksplit=False, terms=0, down0=False, absmax=None):
+              accum=None, outs=None, bx3=False, ksplit=False, terms=0, down0=False, absmax=None, bnr=None):
+    """bnr = (y, cst, act) of out0's tensor: the launch also leaves its BatchNorm-backward partial rows and range hint -> LAST_BNR"""
     lib = _lib.load()
     a = sc_conv_args()
     a.nsrc = len(srcs)
@@ -73,9 +74,28 @@ def conv_mfma(srcs, wpk, N, H, W, Cout, ks, co_t, want_stats=False, csplit=None,
     rows = lib.sc_stat_rows(STAT_CONV3 if ks == 3 else (STAT_CONV1K if ksplit else STAT_CONV1), N, H, W)
     stats = torch.full((rows, Cout, 2), float("nan"), device=DEV) if want_stats else None      # every entry must be written
     a.stats = stats.data_ptr() if want_stats else None
+    if bnr is not None:
+        a.bnr = C.addressof(make_bnr(bnr, rows, csplit))
     fn = lib.sc_conv3x3_bx3 if bx3 else (lib.sc_conv1x1_ksplit if ksplit else lib.sc_conv2d_mfma)
     check(fn(C.byref(a), stream()))
     return outs, stats
+
+
+LAST_BNR = None
+
+
+def make_bnr(bnr, rows, C_):
+    """sc_bnr_args for (y, cst, act); the rows (NaN-filled: every entry must be written) and the zeroed range slot -> LAST_BNR"""
+    global LAST_BNR
+    from starcop_amd._lib import sc_bnr_args
+    y, cst, act = bnr
+    b = sc_bnr_args()
+    r = torch.full((rows, C_, 2), float("nan"), device=DEV)
+    amax = torch.zeros(1, device=DEV)
+    b.y, b.cst, b.act, b.rows, b.absmax = y.data_ptr(), cst.data_ptr(), act, r.data_ptr(), amax.data_ptr()
+    _KEEP.extend([b, y, cst])
+    LAST_BNR = (r, amax)
+    return b
 
 
 def wgrad_mfma(dy, srcs, N, H, W, Cout, Cin, ks, bx3=False, terms=0, absmax=None):

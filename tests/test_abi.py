@@ -46,7 +46,8 @@ def test_pure_host_entry_points(lib):
 def test_struct_layouts_match_header():
     from starcop_amd import _lib
     assert ctypes.sizeof(_lib.sc_src) == 40
-    assert ctypes.sizeof(_lib.sc_conv_args) == 2 * 40 + 8 + 8 + 6 * 4 + 2 * 8 + 3 * 4 + 4 + 3 * 8 + 8 + 8 + 2 * 8     # ..., add0, add1, stats, terms, down0, absmax, xbound[2]
+    assert ctypes.sizeof(_lib.sc_conv_args) == 2 * 40 + 8 + 8 + 6 * 4 + 2 * 8 + 3 * 4 + 4 + 3 * 8 + 8 + 8 + 2 * 8 + 8     # ..., add0, add1, stats, terms, down0, absmax, xbound[2], bnr
+    assert ctypes.sizeof(_lib.sc_bnr_args) == 2 * 8 + 8 + 2 * 8     # y, cst, act (+ padding), rows, absmax
 
 
 def test_struct_sizes_match_the_c_compiler(tmp_path):

@@ -835,6 +835,7 @@ def test_conv_thin16_two_fp16_terms(hip, cin, cout, H, W, up, gscale):
     BatchNorm-backward prologue, against fp64."""
     from starcop_amd._lib import TERMS_F16X2, sc_conv_args
     import ctypes as C
+    import hip_ops
     N = 2
     lib = hip
 
@@ -844,7 +845,7 @@ def test_conv_thin16_two_fp16_terms(hip, cin, cout, H, W, up, gscale):
         check(lib.sc_pack_weights_thin16(ptr(w), ptr(out), co, ci, tflip, stream()))
         return out
 
-    def run(src, wpk, Cout_, want_stats=False, absmax=None):
+    def run(src, wpk, Cout_, want_stats=False, absmax=None, bnr=None):
         a = sc_conv_args()
         a.nsrc = 1; a.src[0] = src
         a.wpk = wpk.data_ptr()
@@ -855,6 +856,8 @@ def test_conv_thin16_two_fp16_terms(hip, cin, cout, H, W, up, gscale):
         st = torch.full((rows, Cout_, 2), float("nan"), device=DEV) if want_stats else None
         a.stats = st.data_ptr() if want_stats else None
         a.absmax = absmax.data_ptr() if absmax is not None else None
+        if bnr is not None:
+            a.bnr = C.addressof(hip_ops.make_bnr(bnr, rows, Cout_))
         check(lib.sc_conv3x3_thin16(C.byref(a), stream()))
         return out, st
 
@@ -886,6 +889,82 @@ def test_conv_thin16_two_fp16_terms(hip, cin, cout, H, W, up, gscale):
     dsrc = make_src(dev(g), cout, SRC_BNBWD, act=ACT_RELU, cst=dev(cstb), aux=dev(y))
     dx, _ = run(dsrc, pack_thin(dev(w), 1), cin, absmax=amax)
     assert relerr(dx, F.conv_transpose2d(dy, w.double(), padding=1)) < 1e-5
+    # ... and with the BatchNorm-backward sums of the tensor that gradient belongs to (sc_bnr_args)
+    import hip_ops
+    y_in = rnd(N, cin, H, W, seed=11)
+    cst_in = torch.zeros(cin, SC_CST)
+    cst_in[:, 0], cst_in[:, 1], cst_in[:, 2], cst_in[:, 3] = rnd(cin, seed=12) * 0.3 + 1, rnd(cin, seed=13) * 0.3, rnd(cin, seed=14) * 0.2, rnd(cin, seed=15).abs() + 0.5
+    dx2, _ = run(dsrc, pack_thin(dev(w), 1), cin, absmax=amax, bnr=(dev(y_in), dev(cst_in), ACT_RELU))
+    assert torch.equal(dx2, dx)
+    _bnr_check(lib, dx2, y_in, cst_in, ACT_RELU, N, H * W)
+
+
+def _bnr_reference(dx, y_in, cst_in, act):
+    """what sc_bn_bwd_reduce computes from a gradient dx of a BatchNorm'd tensor with raw values y_in: (sum g', sum g' x_hat, max |scale g'|)"""
+    sc, sh, mu, isd = (cst_in[:, k].double()[None, :, None, None] for k in range(4))
+    yh = y_in.double() * sc + sh
+    m = (yh > 0) if act == ACT_RELU else ((yh > 0) & (yh < 6))
+    gp = torch.where(m, dx.double().cpu(), torch.zeros((), dtype=torch.float64))
+    return gp.sum((0, 2, 3)), (gp * (y_in.double() - mu) * isd).sum((0, 2, 3)), float((gp * sc).abs().max())
+
+
+def _bnr_check(lib, dx, y_in, cst_in, act, N, HW):
+    """the rows / range hint a data-gradient launch left (hip_ops.LAST_BNR) against the float64 sums, and -- through
+    sc_bn_bwd_finalize_rows32 -- against the separate pass sc_bn_bwd_reduce + sc_bn_bwd_finalize over the same (dx, y)"""
+    import hip_ops
+    rows, amax = hip_ops.LAST_BNR
+    C_ = y_in.shape[1]
+    s1, s2, mx = _bnr_reference(dx, y_in, cst_in, act)
+    assert bool(torch.isfinite(rows).all())
+    got = rows.double().sum(0).cpu()
+    scale = max(float(s1.abs().max()), float(s2.abs().max()), 1e-3)
+    assert float((got[:, 0] - s1).abs().max()) < 2e-5 * scale and float((got[:, 1] - s2).abs().max()) < 2e-5 * scale
+    assert abs(float(amax) - mx) <= 1e-6 * mx
+    out = {}
+    for name in ("fused", "separate"):
+        dg, db, cb = (torch.full((n_,), float("nan"), device=DEV) for n_ in (C_, C_, C_ * SC_CST))
+        if name == "fused":
+            check(lib.sc_bn_bwd_finalize_rows32(ptr(rows), rows.shape[0], float(N * HW), ptr(dev(cst_in)), ptr(dg), ptr(db), ptr(cb), C_,
+                                                ptr(torch.empty(64 * 2 * C_, dtype=torch.float64, device=DEV)) if rows.shape[0] >= 4096 else None, stream()))
+        else:
+            nr = lib.sc_stat_rows(_lib.STAT_BNBWD, N, dx.shape[2], dx.shape[3])
+            sums = torch.empty(nr * C_ * 2, dtype=torch.float64, device=DEV)
+            check(lib.sc_bn_bwd_reduce(ptr(dx), ptr(dev(y_in)), ptr(dev(cst_in)), act, ptr(sums), N, C_, HW, None, None, stream()))
+            check(lib.sc_bn_bwd_finalize(ptr(sums), nr, float(N * HW), ptr(dev(cst_in)), ptr(dg), ptr(db), ptr(cb), C_, stream()))
+        out[name] = (dg.cpu(), db.cpu(), cb.cpu())
+    for a_, b_ in zip(out["fused"], out["separate"]):
+        assert float((a_ - b_).abs().max()) <= 2e-5 * max(float(b_.abs().max()), 1e-3)
+
+
+@pytest.mark.parametrize("cin,cout,co_t,H,W,cs,down0", [(64, 32, 64, 20, 40, None, False), (40, 24, 32, 36, 70, None, False), (80, 32, 32, 16, 64, 64, False),
+                                                     (96, 16, 64, 24, 48, 64, True), (32, 16, 32, 34, 66, None, True), (152, 64, 64, 12, 32, 128, False)])
+def test_conv_bx3_dgrad_leaves_batchnorm_backward_sums(hip, cin, cout, co_t, H, W, cs, down0):
+    """sc_bnr_args on sc_conv3x3_bx3: the data-gradient launch that writes a single-consumer tensor's complete gradient also leaves
+    that tensor's BatchNorm-backward sums and range hint -- plain and 2x2-down-summed out0, with and without a second (skip) output,
+    ragged tiles; the gradient itself is bit-identical to the launch without the sums"""
+    from starcop_amd._lib import TERMS_F16X2
+    N = 2
+    g, y = rnd(N, cout, H, W, seed=1), rnd(N, cout, H, W, seed=2)
+    w = rnd(cout, cin, 3, 3, seed=3, scale=0.2)
+    cst = torch.zeros(cout, SC_CST)
+    cst[:, 0], cst[:, 1] = rnd(cout, seed=4) * 0.2 + 1, rnd(cout, seed=5) * 0.2
+    cst[:, 2], cst[:, 3], cst[:, 4] = rnd(cout, seed=6) * 0.5 + 1, rnd(cout, seed=7) * 0.1, rnd(cout, seed=8) * 0.1
+    src = make_src(dev(g), cout, SRC_BNBWD, act=ACT_RELU, cst=dev(cst), aux=dev(y))
+    c0 = cin if cs is None else cs                      # channels of out0 = of the tensor whose sums are wanted
+    Hq, Wq = (H // 2, W // 2) if down0 else (H, W)
+    y_in = rnd(N, c0, Hq, Wq, seed=11)
+    cst_in = torch.zeros(c0, SC_CST)
+    cst_in[:, 0], cst_in[:, 1] = rnd(c0, seed=12) * 0.3 + 1, rnd(c0, seed=13) * 0.3
+    cst_in[:, 2], cst_in[:, 3] = rnd(c0, seed=14) * 0.2, rnd(c0, seed=15).abs() + 0.5
+    wpk = pack_bx3(dev(w), co_t, 1, TERMS_F16X2)
+    amax = torch.tensor([float((cst[:, 2][None, :, None, None] * g).abs().max())], device=DEV)
+    kw = dict(bx3=True, terms=TERMS_F16X2, csplit=cs, down0=down0, absmax=amax)
+    plain, _ = conv_mfma([src], wpk, N, H, W, cin, 3, co_t, **kw)
+    for act in (ACT_RELU, ACT_RELU6):
+        outs, _ = conv_mfma([src], wpk, N, H, W, cin, 3, co_t, bnr=(dev(y_in), dev(cst_in), act), **kw)
+        for a_, b_ in zip(outs, plain):
+            assert torch.equal(a_, b_)
+        _bnr_check(hip, outs[0], y_in, cst_in, act, N, Hq * Wq)
 
 
 @pytest.mark.parametrize("stride,C_,H,W", [(1, 8, 64, 96), (2, 8, 64, 96), (1, 24, 32, 32), (2, 24, 32, 64), (1, 40, 16, 16), (2, 40, 16, 16),

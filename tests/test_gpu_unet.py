@@ -198,6 +198,26 @@ def test_sub_pixel_paths_equal_the_3x3_paths_on_the_whole_network(hip, monkeypat
     print(f"sub-pixel vs 3x3 whole network: worst gradient error ratio to the 3x3 kernels' own (vs float64) {worst:.2f}")
 
 
+def test_dgrad_side_batchnorm_sums_equal_the_separate_pass_on_the_whole_network(hip, monkeypatch):
+    """network._BNR: the decoder's BatchNorm-backward sums taken from the data-gradient launches (sc_bnr_args; off by default, it measured
+    1 % slower) against the separate sc_bn_bwd_reduce passes: every parameter gradient of one training step agrees to summation-order
+    accuracy, at a size where both the per-channel and the pre-reduced (>= 4096 rows) finalize run"""
+    from starcop_amd import network as nw
+    B, H, W = 2, 256, 288
+    batch = synth_batch(B, H, W, seed=41)
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(nw, "_BNR", on)
+        model, _ = make_pair(seed=40)
+        model.train()
+        loss = model.training_step(to_dev(batch), 0)
+        loss.backward()
+        res[on] = ({k: p.grad.detach().cpu().clone() for k, p in model.network.named_parameters()}, float(loss))
+    assert res[True][1] == res[False][1]
+    for k, g in res[False][0].items():
+        assert relerr(res[True][0][k], g) < 2e-5, k
+
+
 def test_predict_odd_size(hip):
     """predict(): reflect-pad to x32, forward, crop (padding.py:13-50) on a non-multiple-of-32 scene."""
     model, ref = make_pair(seed=11)
