@@ -491,12 +491,23 @@ typedef struct sc_mag1c_args {
   double* work;             /* scratch: sc_mag1c_workspace_doubles(G, S, npix)                            */
   void* mf_out;             /* [npix] per-pixel outputs, element type of x                                */
   void* albedo_out;         /* [npix]                                                                     */
-  int32_t* status;          /* [G] 0 ok, 1 covariance not positive definite (-> torch.linalg.LinAlgError) */
+  int32_t* status;          /* [G] 0 ok, 1 covariance not positive definite (-> torch.linalg.LinAlgError), 2 see DIRECT mode */
   /* compute_energy of the reference (starcop/models/mag1c.py:270-275, 337-343), both null or both set:
    * energy [G][max(num_iter,0)+1] = sum of all entries of (x-mu) C_k^{-1} (x-mu)^T per group and iteration (entry 0: the rmf stage),
    * logdet [G] = P/2 * log(1 / prod diag chol C) of the rmf stage */
   double* energy;
   double* logdet;
+  /* DIRECT mode (cube != NULL; fp32, S > 64, no energy, every group of at most 512 pixels -- a 512-row tile filtered per detector
+   * column, func_by_groups at starcop/models/mag1c.py:116-174): the groups' pixels are read straight from the pixel-major cube through
+   * pix_index (element (s, p) of group g = cube[pix_index[poff[g] + p] * S_total + band0 + s]) into the kernel's register tile, which
+   * holds them for all iterations, and the results go straight to image order (scatter_mf / scatter_alb[pix_index[..]], element type
+   * scatter_is_f64) -- no sc_mag1c_pack pass (one write + one read of the whole tile), no sc_scatter launches.  x / xoff / Ppad /
+   * mf_out / albedo_out are unused (may be NULL); a group with P > 512 gets status 2. */
+  const float* cube;
+  int32_t S_total, band0;
+  const int64_t* pix_index;
+  void* scatter_mf; void* scatter_alb;
+  int32_t scatter_is_f64;
 } sc_mag1c_args;
 size_t sc_mag1c_workspace_doubles(int G, int S, int64_t npix);
 int sc_mag1c_groups(const sc_mag1c_args* a, sc_stream stream);

@@ -72,7 +72,9 @@ class sc_mag1c_args(C.Structure):
                 ("albedo_override", C.c_int32), ("zero_override", C.c_int32),
                 ("sparse_override", C.c_int32), ("apply_scaling", C.c_int32),
                 ("work", C.c_void_p), ("mf_out", C.c_void_p), ("albedo_out", C.c_void_p),
-                ("status", C.c_void_p), ("energy", C.c_void_p), ("logdet", C.c_void_p)]
+                ("status", C.c_void_p), ("energy", C.c_void_p), ("logdet", C.c_void_p),
+                ("cube", C.c_void_p), ("S_total", C.c_int32), ("band0", C.c_int32), ("pix_index", C.c_void_p),
+                ("scatter_mf", C.c_void_p), ("scatter_alb", C.c_void_p), ("scatter_is_f64", C.c_int32)]
 
 
 _vp, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t

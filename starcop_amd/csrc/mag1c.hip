@@ -35,6 +35,8 @@ struct Mag1cP {
   int* status;
   double* energy;    // [G][max(num_iter,0)+1] residual terms (compute_energy), or null
   double* logdet;    // [G] P/2 * log(1 / prod diag chol C) of the first covariance, or null
+  // DIRECT mode of the resident tile kernel (sc_mag1c_args.cube): gather from the pixel-major cube, scatter to image order
+  const float* cube; int S_total, band0; const long long* pix; void* sc_mf; void* sc_alb; int sc_f64;
 };
 
 #ifdef STARCOP_MAG1C_PROF
@@ -825,6 +827,27 @@ __device__ __forceinline__ unsigned tile_load(float (&xt)[16][JB], const float* 
   return (unsigned)(__ballot(mine_ok) >> (lane & 48)) & 0xffffu;
 }
 
+// DIRECT mode: the same tile from the pixel-major cube -- pixel q0 + i is row pg[q0 + i] of the cube, its bands bg + 16 j one 64-byte
+// piece per 16 lanes; the 16 pixel indices of the group in one load, all 16 * JB element loads in flight together.  Read ONCE per group:
+// the resident kernel keeps the tile.  (tools/prof_mag1c_phases.py, configs[2]: this load 8.5-9 us per group against 5.7 us from the
+// packed copy; a pixel-wise variant -- 256 contiguous bytes of ONE pixel per wave instruction, SGPR base, then a 4 x 4 exchange between
+// the row groups by ds_bpermute -- took 22 us: the exchange costs more than the longer runs gain.)
+template <int JB>
+__device__ __forceinline__ unsigned tile_load_direct(float (&xt)[16][JB], const float* __restrict__ cube, int S_total, int band0,
+                                                     const long long* __restrict__ pg, int S, int P, const unsigned char* mk, int q0, int bg,
+                                                     int lane) {
+  const long long myidx = (q0 + bg < P) ? pg[q0 + bg] : -1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const long long idx = __shfl(myidx, (lane & 48) | i, 64);
+    const float* row = cube + (size_t)(idx < 0 ? 0 : idx) * S_total + band0;
+#pragma unroll
+    for (int j = 0; j < JB; ++j) xt[i][j] = (idx >= 0 && bg + 16 * j < S) ? row[bg + 16 * j] : 0.f;
+  }
+  const bool mine_ok = q0 + bg < P && (mk == nullptr || mk[q0 + bg]);
+  return (unsigned)(__ballot(mine_ok) >> (lane & 48)) & 0xffffu;
+}
+
 // ---- 16 x 16 block algebra on the fp64 MFMA (v_mfma_f64_16x16x4: lane l holds A[l & 15][l >> 4], B[l >> 4][l & 15];
 // D[(l >> 4) + 4*r][l & 15] in register r).  Blocks live in LDS with arbitrary row / column strides, so a transposed operand is a
 // swap of two arguments.
@@ -1135,9 +1158,11 @@ __global__ __launch_bounds__(RNT, 2) void k_mag1c_tile(const Mag1cP p) {
   double* Dx = stg;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int P = p.P[g], pitch = p.Ppad[g];
+  const bool direct = RES && p.cube != nullptr;           // (uniform)
+  const int P = p.P[g], pitch = direct ? 0 : p.Ppad[g];
   if (P <= 0) return;                                     // skipped group (sc_mag1c_layout_columns: too few valid pixels)
-  const float* X = reinterpret_cast<const float*>(p.x) + p.xoff[g];
+  if (direct && P > RNT) { if (threadIdx.x == 0) p.status[g] = 2; return; }      // DIRECT mode takes resident groups only
+  const float* X = direct ? nullptr : reinterpret_cast<const float*>(p.x) + p.xoff[g];
   const long long po = p.poff[g];
   const unsigned char* mk = p.statmask ? p.statmask + po : nullptr;
   double* mfw = p.mfw + po; double* Rw = p.Rw + po;
@@ -1155,7 +1180,10 @@ __global__ __launch_bounds__(RNT, 2) void k_mag1c_tile(const Mag1cP p) {
   const int bg = lane & 15;
   float xt[16][JB];                                         // [pixel q0 + i][band bg + 16*j]
   unsigned mbits = 0;
-  if (resident) mbits = tile_load<JB>(xt, X, pitch, S, P, mk, (tid >> 4) * 16, bg, lane);
+  if constexpr (RES) {
+    if (direct) mbits = tile_load_direct<JB>(xt, p.cube, p.S_total, p.band0, p.pix + po, S, P, mk, (tid >> 4) * 16, bg, lane);
+    else mbits = tile_load<JB>(xt, X, pitch, S, P, mk, (tid >> 4) * 16, bg, lane);
+  }
   for (int s = tid; s < S; s += RNT) tmpl[s] = p.templ[s];
   if (tid == 0) { red[60] = 0.0; red[62] = 1.0 / N; }
   PROF(7);
@@ -1485,8 +1513,14 @@ __global__ __launch_bounds__(RNT, 2) void k_mag1c_tile(const Mag1cP p) {
           if (resident) { R_sel = R; Rinv_sel = Rinv; mf_sel = mf; } else mfw[r_q] = mf;
           w_sel = ((mbits >> bz) & 1u) ? p.kscale * R * mf : 0.0;
           if (it == last) {
-            reinterpret_cast<float*>(p.mf_out)[po + r_q] = (float)(mf * scale);
-            reinterpret_cast<float*>(p.alb_out)[po + r_q] = (float)R;
+            if (RES && p.cube != nullptr) {               // DIRECT mode: straight to image order
+              const long long ix = p.pix[po + r_q];
+              if (p.sc_f64) { reinterpret_cast<double*>(p.sc_mf)[ix] = mf * scale; reinterpret_cast<double*>(p.sc_alb)[ix] = R; }
+              else { reinterpret_cast<float*>(p.sc_mf)[ix] = (float)(mf * scale); reinterpret_cast<float*>(p.sc_alb)[ix] = (float)R; }
+            } else {
+              reinterpret_cast<float*>(p.mf_out)[po + r_q] = (float)(mf * scale);
+              reinterpret_cast<float*>(p.alb_out)[po + r_q] = (float)R;
+            }
           }
         }
         if (it != last) { s1 += w_sel; s2 += w_sel * w_sel; }
@@ -1814,10 +1848,19 @@ extern "C" int sc_mag1c_groups(const sc_mag1c_args* a, sc_stream stream) {
   SC_REQUIRE(a != nullptr, "sc_mag1c_groups: null args");
   SC_REQUIRE(a->S >= 1 && a->S <= MAXS, "sc_mag1c_groups: number of bands must be in [1,%d] (got %d)", MAXS, a->S);
   SC_REQUIRE(a->G >= 0 && a->npix >= 0, "sc_mag1c_groups: bad group / pixel count");
+  const bool direct = a->cube != nullptr;
+  if (direct) {
+    SC_REQUIRE(a->P && a->poff && a->templ && a->work && a->status && a->pix_index && a->scatter_mf && a->scatter_alb,
+               "sc_mag1c_groups: DIRECT mode: null pointer argument");
+    SC_REQUIRE(!a->x_is_f64 && a->S > 64 && a->energy == nullptr && a->band0 >= 0 && a->band0 + a->S <= a->S_total,
+               "sc_mag1c_groups: DIRECT mode takes fp32 cubes, 65..128 bands inside the cube's bands, no compute_energy");
+  } else
   SC_REQUIRE(a->x && a->xoff && a->P && a->Ppad && a->poff && a->templ && a->work && a->mf_out && a->albedo_out && a->status,
              "sc_mag1c_groups: null pointer argument");
   if (a->G == 0) return SC_OK;
   Mag1cP p;
+  p.cube = a->cube; p.S_total = a->S_total; p.band0 = a->band0; p.pix = (const long long*)a->pix_index;
+  p.sc_mf = a->scatter_mf; p.sc_alb = a->scatter_alb; p.sc_f64 = a->scatter_is_f64;
   p.x = a->x; p.xoff = (const long long*)a->xoff; p.P = a->P; p.Ppad = a->Ppad; p.poff = (const long long*)a->poff;
   p.statmask = a->statmask; p.G = a->G; p.S = a->S; p.npix = a->npix; p.templ = a->templ; p.num_iter = a->num_iter;
   p.alpha = a->alpha; p.kscale = a->cov_update_scaling;
@@ -1849,7 +1892,9 @@ extern "C" int sc_mag1c_groups(const sc_mag1c_args* a, sc_stream stream) {
       if (fast) SC_TILE_GO(4, false, false); else SC_TILE_GO(4, false, true);
     } else {
       lds = mag1c_tile_lds_bytes<8>(a->S);
-      if (fast) { SC_TILE_GO(8, true, false); SC_TILE_GO(8, false, false); } else { SC_TILE_GO(8, true, true); SC_TILE_GO(8, false, true); }
+      // (DIRECT mode: every group is resident by the caller's promise -- a larger one gets status 2 -- so the streaming launch is dropped)
+      if (fast) { SC_TILE_GO(8, true, false); if (!direct) SC_TILE_GO(8, false, false); }
+      else { SC_TILE_GO(8, true, true); if (!direct) SC_TILE_GO(8, false, true); }
     }
 #undef SC_TILE_GO
   } else if (fast) {

@@ -58,9 +58,7 @@ def _run_groups(cube2d, S_total, band0, S, pix_index, counts, template, num_iter
     a.xoff = xoff_d.data_ptr(); a.P = P_d.data_ptr(); a.Ppad = ppad_d.data_ptr(); a.poff = poff_d.data_ptr()
     a.statmask = statmask.data_ptr() if statmask is not None else None
     a.G, a.S, a.npix = G, S, npix
-    templ = torch.as_tensor(template, dtype=torch.float64).to(dev).contiguous()
-    if templ.numel() != S:
-        raise ValueError(f"mag1c: template has {templ.numel()} bands, data has {S}")
+    templ = _template_on(dev, template, S)
     a.templ = templ.data_ptr()
     a.num_iter, a.alpha, a.cov_update_scaling = int(num_iter), float(alpha), float(k)
     a.albedo_override, a.zero_override, a.sparse_override, a.apply_scaling = (int(bool(f)) for f in flags)
@@ -97,6 +95,24 @@ MAX_SORT_WORK_INTS = 64 << 20        # histogram ints of the device counting sor
 MAX_GROUP_IDS = 1 << 16      # group ids up to this take the device counting sort (detector widths are ~600-1300); larger / negative ids
                              # fall back to the general sort
 COLUMN_FAST_PATH = True      # False: always take the general (device sort) layout path; tests compare the two bit for bit
+DIRECT_TILES = os.environ.get("STARCOP_MAG1C_DIRECT", "1") == "1"    # column groups of <= 512 pixels (a 512-row tile per detector column):
+                             # the filter kernel gathers from the cube and scatters to image order itself (no pack / scatter passes)
+_TEMPLATE_CACHE = {}
+
+
+def _template_on(dev, template, S):
+    """the unit absorption spectrum as a float64 device tensor; the upload is cached by content (drivers pass the same array per tile)"""
+    t_host = template.detach().cpu().numpy() if torch.is_tensor(template) else np.asarray(template)
+    t_host = np.ascontiguousarray(t_host, dtype=np.float64).reshape(-1)
+    if t_host.size != S:
+        raise ValueError(f"mag1c: template has {t_host.size} bands, data has {S}")
+    key = (str(dev), t_host.tobytes())
+    t = _TEMPLATE_CACHE.get(key)
+    if t is None:
+        if len(_TEMPLATE_CACHE) > 16:
+            _TEMPLATE_CACHE.clear()
+        t = _TEMPLATE_CACHE[key] = torch.from_numpy(t_host.copy()).to(dev)
+    return t
 
 
 def _run_column_groups(cube3, b0, S, valid_u8, gcol, min_keep, template, num_iter, alpha, k, flags, fill, out_dtype, ids=None, nids=0):
@@ -112,8 +128,8 @@ def _run_column_groups(cube3, b0, S, valid_u8, gcol, min_keep, template, num_ite
     G = int(gcol.size - 1) if ids is None else int(nids)
     is64 = cube3.dtype == torch.float64
     dt = cube3.dtype
-    mf_out = torch.full((HW,), fill, dtype=out_dtype, device=dev)
-    alb_out = torch.full((HW,), fill, dtype=out_dtype, device=dev)
+    both = torch.full((2, HW), fill, dtype=out_dtype, device=dev)           # (one fill launch for the two products)
+    mf_out, alb_out = both[0], both[1]
     if G == 0:
         return mf_out.reshape(rows, cols), alb_out.reshape(rows, cols)
     if S > MAX_BANDS:
@@ -127,10 +143,11 @@ def _run_column_groups(cube3, b0, S, valid_u8, gcol, min_keep, template, num_ite
                 _LAYOUT_CACHE.clear()
             gcol_d = _LAYOUT_CACHE[key] = torch.from_numpy(gcol).to(dev)
     i32 = dict(dtype=torch.int32, device=dev)
-    i64 = dict(dtype=torch.int64, device=dev)
-    P_d, ppad_d = torch.empty(G, **i32), torch.empty(G, **i32)
-    poff_d, xoff_d, totals = torch.empty(G, **i64), torch.empty(G, **i64), torch.empty(2, **i64)
-    pix = torch.empty(HW, **i64)
+    # the per-group arrays and the pixel list from ONE allocation (every torch.empty is ~5 us of host time in a 0.9 ms call)
+    ibuf = torch.empty(HW + 3 * G + 2, dtype=torch.int64, device=dev)
+    pix, poff_d, xoff_d, totals = ibuf[:HW], ibuf[HW:HW + G], ibuf[HW + G:HW + 2 * G], ibuf[HW + 2 * G:HW + 2 * G + 2]
+    pp = ibuf[HW + 2 * G + 2:].view(torch.int32)
+    P_d, ppad_d = pp[:G], pp[G:2 * G]
     st = stream()
     if ids is None:
         check(lib.sc_mag1c_layout_columns(ptr(valid_u8), rows, cols, ptr(gcol_d), G, S, int(min_keep), ptr(P_d), ptr(ppad_d),
@@ -139,29 +156,41 @@ def _run_column_groups(cube3, b0, S, valid_u8, gcol, min_keep, template, num_ite
         work = torch.empty(lib.sc_mag1c_layout_ids_workspace_ints(HW, G), **i32)
         check(lib.sc_mag1c_layout_ids(ptr(valid_u8), ptr(ids), HW, G, S, int(min_keep), ptr(P_d), ptr(ppad_d), ptr(poff_d), ptr(xoff_d),
                                       ptr(pix), ptr(totals), ptr(work), st))
-    xp = torch.empty((HW + 64 * G) * S, dtype=dt, device=dev)            # upper bound of sum(Ppad) * S: no size read-back, no memset
-    check(lib.sc_mag1c_pack(ptr(cube3), 1 if is64 else 0, S_total, b0, S, ptr(pix), ptr(xoff_d), ptr(ppad_d),
-                            ptr(poff_d), ptr(P_d), G, ptr(xp), 1 if is64 else 0, st))
+    # DIRECT: fp32 cube, 65..128 bands and no group that can exceed the 512 pixels the filter kernel keeps in registers (column groups:
+    # rows x widest run of columns) -- the kernel reads its pixels from the cube through `pix` and writes image order itself
+    direct = (DIRECT_TILES and ids is None and not is64 and S > 64 and out_dtype in (torch.float32, torch.float64)
+              and rows * int(np.diff(gcol).max()) <= 512)
     a = sc_mag1c_args()
-    a.x = xp.data_ptr(); a.x_is_f64 = 1 if is64 else 0
-    a.xoff = xoff_d.data_ptr(); a.P = P_d.data_ptr(); a.Ppad = ppad_d.data_ptr(); a.poff = poff_d.data_ptr()
+    a.x_is_f64 = 1 if is64 else 0
+    a.P = P_d.data_ptr(); a.poff = poff_d.data_ptr()
     a.statmask = None
     a.G, a.S, a.npix = G, S, HW
-    templ = torch.as_tensor(template, dtype=torch.float64).to(dev).contiguous()
-    if templ.numel() != S:
-        raise ValueError(f"mag1c: template has {templ.numel()} bands, data has {S}")
+    templ = _template_on(dev, template, S)
     a.templ = templ.data_ptr()
     a.num_iter, a.alpha, a.cov_update_scaling = int(num_iter), float(alpha), float(k)
     a.albedo_override, a.zero_override, a.sparse_override, a.apply_scaling = (int(bool(f)) for f in flags)
     work = torch.empty(lib.sc_mag1c_workspace_doubles(G, S, HW), dtype=torch.float64, device=dev)
     status = torch.zeros(G, dtype=torch.int32, device=dev)
-    mf, alb = torch.empty(HW, dtype=dt, device=dev), torch.empty(HW, dtype=dt, device=dev)
-    a.work, a.mf_out, a.albedo_out, a.status = work.data_ptr(), mf.data_ptr(), alb.data_ptr(), status.data_ptr()
-    check(lib.sc_mag1c_groups(C.byref(a), st))
+    a.work, a.status = work.data_ptr(), status.data_ptr()
     o64 = 1 if out_dtype == torch.float64 else 0
-    check(lib.sc_scatter_n(ptr(mf), 1 if is64 else 0, ptr(pix), ptr(totals), HW, ptr(mf_out), o64, st))
-    check(lib.sc_scatter_n(ptr(alb), 1 if is64 else 0, ptr(pix), ptr(totals), HW, ptr(alb_out), o64, st))
+    if direct:
+        a.cube, a.S_total, a.band0, a.pix_index = cube3.data_ptr(), S_total, b0, pix.data_ptr()
+        a.scatter_mf, a.scatter_alb, a.scatter_is_f64 = mf_out.data_ptr(), alb_out.data_ptr(), o64
+        check(lib.sc_mag1c_groups(C.byref(a), st))
+    else:
+        xp = torch.empty((HW + 64 * G) * S, dtype=dt, device=dev)            # upper bound of sum(Ppad) * S: no size read-back, no memset
+        check(lib.sc_mag1c_pack(ptr(cube3), 1 if is64 else 0, S_total, b0, S, ptr(pix), ptr(xoff_d), ptr(ppad_d),
+                                ptr(poff_d), ptr(P_d), G, ptr(xp), 1 if is64 else 0, st))
+        a.x = xp.data_ptr()
+        a.xoff = xoff_d.data_ptr(); a.Ppad = ppad_d.data_ptr()
+        mf, alb = torch.empty(HW, dtype=dt, device=dev), torch.empty(HW, dtype=dt, device=dev)
+        a.mf_out, a.albedo_out = mf.data_ptr(), alb.data_ptr()
+        check(lib.sc_mag1c_groups(C.byref(a), st))
+        check(lib.sc_scatter_n(ptr(mf), 1 if is64 else 0, ptr(pix), ptr(totals), HW, ptr(mf_out), o64, st))
+        check(lib.sc_scatter_n(ptr(alb), 1 if is64 else 0, ptr(pix), ptr(totals), HW, ptr(alb_out), o64, st))
     if int(status.max()):          # the reference's torch.linalg.cholesky raises (mag1c.py:251,323)
+        if int((status == 2).sum()):          # (cannot happen: `direct` bounds every group by rows x widest run)
+            raise RuntimeError("mag1c: a group exceeded the 512 pixels of the direct tile path")
         bad = torch.nonzero(status).reshape(-1)
         raise torch.linalg.LinAlgError(
             f"linalg.cholesky: (Batch element {int(bad[0])}): The factorization could not be completed because the "
@@ -246,13 +275,19 @@ def func_by_groups(func, x, groups, mask=None, disable_pbar=True, samples_read=5
         x = x.float()
     H, W, S_total = x.shape
     b0, b1 = (0, S_total) if band_slice is None else (band_slice.start or 0, band_slice.stop or S_total)
-    groups_t = (groups if torch.is_tensor(groups) else torch.as_tensor(np.asarray(groups))).to(dev).reshape(-1).long()
+    groups_dev = None
+
+    def groups_on_device():          # (only the non-column paths need the group map on the device: 2 MB per 512^2 tile)
+        nonlocal groups_dev
+        if groups_dev is None:
+            groups_dev = (groups if torch.is_tensor(groups) else torch.as_tensor(np.asarray(groups))).to(dev).reshape(-1).long()
+        return groups_dev
+    mask_t = None
     if mask is None:
         xc = x.contiguous()
         mask_u8 = torch.empty(H * W, dtype=torch.uint8, device=dev)
         check(_lib.load().sc_valid_mask(ptr(xc), 1 if xc.dtype == torch.float64 else 0, S_total, b0, b1 - b0, float(NODATA),
                                         H * W, ptr(mask_u8), stream()))
-        mask_t = mask_u8.bool()
     else:
         mask_t = (mask if torch.is_tensor(mask) else torch.as_tensor(np.asarray(mask))).to(dev).reshape(-1).bool()
     if isinstance(func, Filter) and COLUMN_FAST_PATH:
@@ -270,6 +305,7 @@ def func_by_groups(func, x, groups, mask=None, disable_pbar=True, samples_read=5
         # The ids are bounded by the detector width; max_group (or one .max() read-back) sizes the histogram.
         # max_group is a caller's promise: ids above it (or negative ones) would be dropped to NODATA without a word, so the data
         # are checked against it (one read-back either way)
+        groups_t = groups_on_device()
         gmin, gmax = (int(v) for v in torch.aminmax(groups_t))          # one read-back for both
         if max_group is not None:
             if gmax > int(max_group) or gmin < 0:
@@ -283,6 +319,9 @@ def func_by_groups(func, x, groups, mask=None, disable_pbar=True, samples_read=5
             return _run_column_groups(xc, b0, b1 - b0, mask_t.to(torch.uint8).contiguous() if mask is not None else mask_u8, None, 10,
                                       func.template, func.num_iter, func.alpha, func.k, func.flags, NODATA, x.dtype,
                                       ids=groups_t.to(torch.int32).contiguous(), nids=gmax + 1)
+    groups_t = groups_on_device()
+    if mask_t is None:
+        mask_t = mask_u8.bool()
     mf_out = torch.full((H * W,), NODATA, dtype=x.dtype, device=dev)
     alb_out = torch.full((H * W,), NODATA, dtype=x.dtype, device=dev)
     valid_idx = torch.nonzero(mask_t).reshape(-1)

@@ -177,6 +177,47 @@ def test_column_layout_equals_sorted_layout(hip):
     assert np.mean(rel(got[ok], want_mf[ok]) > 1e-3) < 2e-3
 
 
+@pytest.mark.parametrize("S,alpha", [(77, 0.0), (125, 0.0), (125, 1e-4)])
+def test_direct_tiles_equal_the_packed_path(hip, S, alpha):
+    """column groups of at most 512 pixels with more than 64 bands (a 512-row tile per detector column: configs[2]): the filter kernel
+    gathers its pixels from the cube and writes image order itself (sc_mag1c_args.cube: no pack / scatter passes) -- bit-identical to the
+    packed path, with invalid pixels inside groups, a skipped group, a user mask, a band slice of a wider cube, both alpha branches;
+    groups that could exceed 512 pixels keep the packed path"""
+    rng = np.random.default_rng(500 + S)
+    H, W, S_total = 256, 13, S + 9                          # (a group needs well more valid pixels than bands)
+    t = -np.abs(rng.standard_normal(S)) * 0.3
+    cube = (rng.uniform(1, 6, size=S_total) * (1 + 0.05 * rng.standard_normal((H, W, S_total)))).astype(np.float32)
+    cube[5:9, 3, 12] = hip_mag1c.NODATA
+    cube[: H - 6, 5, 4] = hip_mag1c.NODATA                   # 6 valid pixels: skipped
+    ids = np.array([1, 2, 3, 4, 5, 6, 7, 7, 8, 8, 9, 9, 10])  # widest run 2 columns: 2 x 256 = 512 pixels
+    groups = np.repeat(ids[None, :], H, 0)
+    x = torch.from_numpy(cube).to(DEV)
+    mask = (rng.random((H, W)) > 0.05) & np.all(cube[..., 4:4 + S] > hip_mag1c.NODATA, axis=-1)
+    sl = slice(4, 4 + S)
+    for m in (None, mask):
+        res = {}
+        for on in (True, False):
+            hip_mag1c.DIRECT_TILES = on
+            try:
+                res[on] = hip_mag1c.acrwl1mf_by_groups(x, t, groups, mask=m, alpha=alpha, band_slice=sl)
+            finally:
+                hip_mag1c.DIRECT_TILES = True
+        assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+        assert bool((res[True][0][:, 5] == hip_mag1c.NODATA).all()) and bool((res[True][0][:, 0] != hip_mag1c.NODATA).any())
+    # against the oracle (float64 on the same float32 radiances)
+    want_mf, _ = mag1c_ref.func_by_groups(lambda xg: mag1c_ref.acrwl1mf_group(xg, t, num_iter=30, alpha=alpha), cube[..., sl], groups)
+    got = hip_mag1c.acrwl1mf_by_groups(x, t, groups, alpha=alpha, band_slice=sl)[0].cpu().numpy()
+    assert np.array_equal(got == hip_mag1c.NODATA, want_mf == hip_mag1c.NODATA)
+    ok = want_mf != hip_mag1c.NODATA
+    assert np.mean(rel(got[ok], want_mf[ok]) > 1e-3) < 2e-3
+    # a 3-column run (768 pixels) is beyond the register tile: the same call takes the packed path and still agrees with the oracle
+    wide = np.repeat(np.array([1, 1, 1, 2, 2, 2, 3, 3, 4, 4, 5, 5, 6])[None, :], H, 0)
+    w_mf = hip_mag1c.acrwl1mf_by_groups(x, t, wide, alpha=alpha, band_slice=sl)[0].cpu().numpy()
+    w_want, _ = mag1c_ref.func_by_groups(lambda xg: mag1c_ref.acrwl1mf_group(xg, t, num_iter=30, alpha=alpha), cube[..., sl], wide)
+    okw = w_want != hip_mag1c.NODATA
+    assert np.array_equal(w_mf == hip_mag1c.NODATA, ~okw) and np.mean(rel(w_mf[okw], w_want[okw]) > 1e-3) < 2e-3
+
+
 @pytest.mark.parametrize("step", [2, 4, None])
 def test_emit_driver_vs_reference_golden(hip, step):
     """a14 pinned: the HIP EMIT driver (band selection, template from the shipped LUT, fill mask, column blocks, fp64 filter,
