@@ -184,6 +184,9 @@ _SP = os.environ.get("STARCOP_SP", "1")
 # every other lane idle) 244 -> 392 for 59 -> 13: the step loses 1 % (1444 / 1436 vs 1460 / 1454 tiles/s, same box, alternating).  OFF by
 # default; "1" enables it (tests/test_gpu_unet.py runs the network both ways).
 _BNR = os.environ.get("STARCOP_BNR", "0") == "1"
+# training steps pack the decoder's / the backward filter layouts on the weight-gradient stream, beside the encoder's forward ("0": on
+# the main stream, ahead of the forward -- A/B)
+_PACK_SIDE = os.environ.get("STARCOP_PACK_SIDE", "1") == "1"
 _EXP_NO_WGRAD = os.environ.get("STARCOP_EXP_NO_WGRAD", "0") == "1"
 _EXP_SIDE2 = os.environ.get("STARCOP_EXP_SIDE2", "0") == "1"      # tools/: elimination experiment only
 
@@ -742,61 +745,76 @@ class HyperStarcopUNet(nn.Module):
             import numpy as np
             dt = np.dtype([("w", "<u8"), ("wpk", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"), ("ks", "<i4"), ("co_t", "<i4"),
                            ("tflip", "<i4"), ("bx3", "<i4"), ("total", "<u8")])
-            rows, starts, nblk = [], [], 0
+            # two tables: the layouts the ENCODER's forward reads (pointwise layers, forward direction), and everything else -- the
+            # decoder's 3x3 layouts and all backward layouts, most of the work -- which a training step packs on the weight-gradient
+            # stream while the encoder runs (see the launches below)
+            early, late = [], []
+
+            def add(is_early, w, buf, co, ci, ks, cot, tflip, code):
+                total = lib.sc_pack_work_items(co, ci, ks, cot, tflip, int(code))
+                (early if is_early else late).append((w.data_ptr(), buf.data_ptr(), co, ci, ks, cot, tflip, int(code), total))
+
             for i, op in enumerate(self._ops):
                 if op["type"] not in ("pw", "conv3"):
                     continue
                 conv, ent = op["conv"], self._wpk[i]
                 co, ci, ks = conv.out_channels, conv.in_channels, conv.kernel_size[0]
+                is_pw = op["type"] == "pw"
                 for tflip, buf, cot, bx in ((0, ent["f"], ent["cot_f"], ent["bx3_f"]), (1, ent["b"], ent["cot_b"], ent["bx3_b"])):
                     if tflip and not need_bwd:
                         continue
-                    if op["type"] == "pw" and "mfma" not in getattr(self, "_pw_need", {}).get((i, tflip), ("mfma",)):
+                    if is_pw and "mfma" not in getattr(self, "_pw_need", {}).get((i, tflip), ("mfma",)):
                         continue        # every plan runs this layer on sc_conv1x1_pw3: the fp32-MFMA layout is not needed
-                    total = lib.sc_pack_work_items(co, ci, ks, cot, tflip, int(bx))
-                    rows.append((conv.weight.data_ptr(), buf.data_ptr(), co, ci, ks, cot, tflip,
-                                 (ent["terms_b"] if tflip else ent["terms_f"]) if bx else 0, total))
-                    starts.append(nblk)
-                    nblk += -(-total // 256)
+                    add(is_pw and not tflip, conv.weight, buf, co, ci, ks, cot, tflip, (ent["terms_b"] if tflip else ent["terms_f"]) if bx else 0)
                 for cot, buf in ((64, ent.get("bA")), (32, ent.get("bB"))):
-                    if buf is None or not need_bwd:
-                        continue
-                    total = lib.sc_pack_work_items(co, ci, ks, cot, 1, 1)
-                    rows.append((conv.weight.data_ptr(), buf.data_ptr(), co, ci, ks, cot, 1, ent["terms_b"], total))
-                    starts.append(nblk)
-                    nblk += -(-total // 256)
+                    if buf is not None and need_bwd:
+                        add(False, conv.weight, buf, co, ci, ks, cot, 1, ent["terms_b"])
                 if ent.get("spd") is not None and need_bwd:
                     tfl = (2 if ent["spd_vskip"] else 1) | (4 if ent["terms_b"] == 1 else 0)      # | 4: the one-bf16-term layout
-                    total = lib.sc_pack_work_items(co, ci, ks, ent["sp_cu"], tfl, PACK_SPD)
-                    rows.append((conv.weight.data_ptr(), ent["spd"].data_ptr(), co, ci, ks, ent["sp_cu"], tfl, PACK_SPD, total))
-                    starts.append(nblk)
-                    nblk += -(-total // 256)
+                    add(False, conv.weight, ent["spd"], co, ci, ks, ent["sp_cu"], tfl, PACK_SPD)
                 if ent.get("sp") is not None:
-                    tfl = 4 if ent["terms_f"] == 1 else 0
-                    total = lib.sc_pack_work_items(co, ci, ks, ent["sp_cu"], tfl, PACK_SP)
-                    rows.append((conv.weight.data_ptr(), ent["sp"].data_ptr(), co, ci, ks, ent["sp_cu"], tfl, PACK_SP, total))
-                    starts.append(nblk)
-                    nblk += -(-total // 256)
+                    add(False, conv.weight, ent["sp"], co, ci, ks, ent["sp_cu"], 4 if ent["terms_f"] == 1 else 0, PACK_SP)
                 for tflip, buf in ((0, ent["tf"]), (1, ent["tb"])):
-                    if buf is None or (tflip and not need_bwd):
-                        continue
-                    total = lib.sc_pack_work_items(co, ci, ks, 16, tflip, PACK_THIN16)
-                    rows.append((conv.weight.data_ptr(), buf.data_ptr(), co, ci, ks, 16, tflip, PACK_THIN16, total))
-                    starts.append(nblk)
-                    nblk += -(-total // 256)
+                    if buf is not None and (not tflip or need_bwd):
+                        add(False, conv.weight, buf, co, ci, ks, 16, tflip, PACK_THIN16)
                 for tflip, buf in ((0, ent.get("pf")), (1, ent.get("pb"))):
-                    if buf is None or (tflip and not need_bwd):
-                        continue
-                    total = lib.sc_pack_work_items(co, ci, 1, 0, tflip, PACK_PW3)
-                    rows.append((conv.weight.data_ptr(), buf.data_ptr(), co, ci, 1, 0, tflip, PACK_PW3, total))
+                    if buf is not None and (not tflip or need_bwd):
+                        add(is_pw and not tflip, conv.weight, buf, co, ci, 1, 0, tflip, PACK_PW3)
+
+            def table(rows):
+                starts, nblk = [], 0
+                for r in rows:
                     starts.append(nblk)
-                    nblk += -(-total // 256)
-            descs = torch.from_numpy(np.array(rows, dtype=dt).view(np.uint8).copy()).to(dev)
-            tab = (descs, torch.tensor(starts, dtype=torch.int32).to(dev), len(rows), nblk)
+                    nblk += -(-r[-1] // 256)
+                if not rows:
+                    return None
+                descs = torch.from_numpy(np.array(rows, dtype=dt).view(np.uint8).copy()).to(dev)
+                return (descs, torch.tensor(starts, dtype=torch.int32).to(dev), len(rows), nblk)
+            tab = (table(early), table(late))
             if not hasattr(self, "_pack_tables"):
                 self._pack_tables = {}
             self._pack_tables[key] = tab
-        check(lib.sc_pack_weights_batch(ptr(tab[0]), ptr(tab[1]), tab[2], tab[3], st))
+        # launches: the encoder's layouts on the current stream; the rest, in a training step, on the weight-gradient stream behind a
+        # device-scope wait (the parameters are final on the current stream) -- the forward walk waits for it before its first 3x3
+        # convolution (_forward_impl), i.e. ~0.12 ms of packing leaves the critical path and runs beside the encoder.  Otherwise
+        # (inference, no overlap stream, graph capture) on the current stream too.
+        self._late_pack_stream = None
+        if tab[0] is not None:
+            check(lib.sc_pack_weights_batch(ptr(tab[0][0]), ptr(tab[0][1]), tab[0][2], tab[0][3], st))
+        if tab[1] is not None:
+            side = None
+            if need_bwd and self.overlap_wgrad and self.light_stream_sync and _PACK_SIDE and not torch.cuda.is_current_stream_capturing():
+                main = torch.cuda.current_stream()
+                if self._side_stream is None or self._side_stream.device != main.device:
+                    self._side_stream = torch.cuda.Stream(device=main.device)
+                side = self._side_stream
+            if side is not None:
+                sh = C.c_void_p(side.cuda_stream)
+                check(lib.sc_stream_wait_stream(sh, st))
+                check(lib.sc_pack_weights_batch(ptr(tab[1][0]), ptr(tab[1][1]), tab[1][2], tab[1][3], sh))
+                self._late_pack_stream = sh
+            else:
+                check(lib.sc_pack_weights_batch(ptr(tab[1][0]), ptr(tab[1][1]), tab[1][2], tab[1][3], st))
         self._pack_version = (ver, bool(need_bwd))
 
     # ------------------------------------------------------------------------------------------
@@ -911,6 +929,9 @@ class HyperStarcopUNet(nn.Module):
                 check(lib.sc_dwconv3x3_fwd(C.byref(s), ptr(conv.weight), ptr(plan.buf[o.name]), N, o.C,
                                            H >> tin.shift, W >> tin.shift, op["stride"], stats, st))
             elif ty in ("pw", "conv3"):
+                if ty == "conv3" and self._late_pack_stream is not None:      # the decoder's filter layouts were packed beside the encoder
+                    check(lib.sc_stream_wait_stream(st, self._late_pack_stream))
+                    self._late_pack_stream = None
                 a = sc_conv_args()
                 ins = op["ins"]
                 a.nsrc = len(ins)
@@ -965,6 +986,9 @@ class HyperStarcopUNet(nn.Module):
                                          ptr(bn.running_mean), ptr(bn.running_var), float(bn.momentum), float(bn.eps),
                                          1 if training else 0, ptr(plan.cst[o.name]), o.C, ptr(plan.bn_scratch) if _BN_PRE else None,
                                          self._xbound(plan, o), st))
+        if self._late_pack_stream is not None:      # (no 3x3 layer ran: still order the main stream after the pack)
+            check(lib.sc_stream_wait_stream(st, self._late_pack_stream))
+            self._late_pack_stream = None
         if training:      # one multi-tensor launch for the 62 step counters
             torch._foreach_add_(self._nbt_list(), 1)
         else:
@@ -1070,6 +1094,7 @@ class HyperStarcopUNet(nn.Module):
             raise ValueError(f"precision must be one of {sorted(self._TERMS)} (got {self.precision!r})")
         return self._TERMS[self.precision]
     _side_stream = None
+    _late_pack_stream = None
 
     def _backward_impl(self, plan, dlogits, on_tail_ready=None, only_ops=None, exchange_follows=None):
         """Fills the flat gradient buffer from dL/dlogits.  Needs the plan of a training-mode forward.
