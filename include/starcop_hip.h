@@ -106,7 +106,7 @@ int sc_pack_weights_batch(const sc_pack_desc* descs_dev, const uint32_t* block_s
  * sc_conv3x3_sp_dgrad): what sc_bn_bwd_reduce(out0, y, cst, act, ...) would compute by streaming both tensors again, left by the
  * launch that produces the gradient -- valid when that launch writes the COMPLETE gradient (single consumer: accum0 = 0, no add
  * tensors).  rows[sc_stat_rows(SC_STAT_CONV3, N, H, W)][C][2] (float) = {sum g', sum g' x_hat} over each work-group's pixel tile,
- * g' = out0 * act'(BN(y)), for sc_bn_bwd_finalize_rows32 (sc_conv3x3_sp_dgrad: rows = sc_sp_stat_rows(N, H, W));
+ * g' = out0 * act'(BN(y)), for sc_bn_bwd_finalize_rows32 (sc_conv3x3_sp_dgrad: not taken);
  * absmax (or NULL): raised (atomic max; zeroed by the caller) to max |scale_c g'|, the range hint of the SC_TERMS_F16X2 kernels. */
 typedef struct sc_bnr_args {
   const float* y;        /* raw (pre-BatchNorm) values of the tensor, same shape as out0   */
@@ -218,11 +218,11 @@ int sc_conv3x3_thin16(const sc_conv_args* a, sc_stream stream);
  *   tensor (up = 0), both RAW or AFFINE; H x W = OUTPUT size (even); ks = 3; terms = SC_TERMS_F16X2 (the two-fp16-term arithmetic
  *   of sc_conv3x3_bx3) or 1 (one bf16 term per operand: the "bf16" precision mode; xbound unused); csplit = Cout, one plain output (no add / accumulate / down0); co_t ignored (32); `wpk` from
  *   sc_pack_weights_sp (or a sc_pack_desc with bx3 = SC_PACK_SP, Cin = the filter's total input channels and co_t = how many
- *   of them, the leading ones, belong to the up-sampled source; transpose_flip = 4 for the one-bf16-term layout); statistics rows = sc_sp_stat_rows(N, H, W). */
+ *   of them, the leading ones, belong to the up-sampled source; transpose_flip = 4 for the one-bf16-term layout); statistics rows = sc_sp_stat_rows(N, H, W, Cout) (one per work-group tile: 8 x 32 low-resolution pixels; 16 x 16 -- or, for launches of at most 128 such work-groups, 8 x 16 -- on planes narrower than 32). */
 #define SC_PACK_SP 7
 size_t sc_packed_weight_floats_sp(int Cout, int Cup, int Cskip);
 int sc_pack_weights_sp(const float* w_oihw, float* wpk, int Cout, int Cup, int Cskip, int terms, sc_stream stream);
-int sc_sp_stat_rows(int N, int H, int W);
+int sc_sp_stat_rows(int N, int H, int W, int Cout);
 int sc_conv3x3_sp(const sc_conv_args* a, sc_stream stream);
 /* ... and its data gradient w.r.t. the half-resolution source: a stride-2 4x4 convolution of dy (four parity planes x 2x2 taps), written
  * at half resolution directly -- no full-resolution gradient of the up-sampled channels, no 2x2 down-sum (replaces

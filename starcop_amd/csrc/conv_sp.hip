@@ -89,16 +89,21 @@ template <int TW> constexpr int sp_smem_bytes() { return SP_SMEM_W + 2 * 2 * 2 *
 
 // BF: the "bf16" precision mode -- ONE bf16 term per operand (round to nearest even, no range scale), a third of the MFMAs and half
 // the operand reads; the skeleton, LDS layout (term 0 only) and pipeline are the same
-template <int TW, bool BF>
+// NPP: pixel groups per wave.  2: the 256-pixel tile above.  1 (16-wide tiles only): a 128-pixel tile (8 x 16), one group per wave --
+// for launches whose 256-pixel tiles do not fill the chip (decoder.blocks.0 at batch 16: 16 planes of 16 x 16 = 128 work-groups for 256
+// CUs); twice the work-groups, each with half the MFMAs per staged filter chunk.
+template <int TW, bool BF, int NPP = 2>
 __global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
+  static_assert(NPP == 2 || (NPP == 1 && TW == 16), "one group per wave: 16-wide tiles only");
   constexpr int NT = BF ? 1 : 2;
   constexpr int NM = BF ? 4 : 12;            // MFMAs per step
-  constexpr int TH = 256 / TW;
-  constexpr int PC = sp_pc<TW>(), NPX = sp_npx<TW>();
-  constexpr int NR = 3;
+  constexpr int TH = 128 * NPP / TW;
+  constexpr int PC = sp_pc<TW>(), NPX = sp_npx<TW>();      // (NPX: the buffer pitch, sized for the two-group tile)
+  constexpr int NPXU = (TH + 2) * PC;        // patch entries of this tile
+  constexpr int NR = (NPXU + 127) / 128;
   constexpr int WST = SP_WST / 2 * NT;       // 16-byte filter entries per chunk
   constexpr int NWV = WST / 512;
-  static_assert(NPX <= 128 * NR, "three staging rounds of 128 threads per channel quarter");
+  static_assert(NPXU <= NPX && NPXU <= 128 * NR, "staging rounds of 128 threads per channel quarter");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uintx4* const s_w = reinterpret_cast<uintx4*>(smem);                                   // [2][WST]
@@ -135,9 +140,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
   const float hsx = BF ? 1.f : sp_act_scale(p.xb0, p.xb1);
   const float hinv = BF ? 1.f : 1.f / (hsx * SP_SW);
 
-  floatx16 acc[2][2];      // [group pp][px]
+  floatx16 acc[NPP][2];    // [group pp][px]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2 * NPP; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i >> 1][i & 1][r] = 0.f;
 
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
     const int e = sidx + 128 * r;
     const int pr = e / PC, pc = e - pr * PC;
     const int y = y0 - 1 + pr, x = x0 - 1 + pc;
-    const bool ok = (e < NPX) && (y >= 0) && (y < Hl) && (x >= 0) && (x < Wl);
+    const bool ok = (e < NPXU) && (y >= 0) && (y < Hl) && (x >= 0) && (x < Wl);
     pyx[r] = ok ? ((unsigned)y << 16) | (unsigned)x : 0xFFFFFFFFu;
   }
   float xv[NR][4];
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
       if (jp == 0) { t0.x = a0; t1.x = a1; } else { t0.y = a0; t1.y = a1; }
     }
     const int e = sidx + 128 * r;
-    if (e < NPX) {
+    if (e < NPXU) {
       sp2[((0 * 2 + hw) * NPX + e) * 2 + sub] = t0;
       if constexpr (!BF) sp2[((1 * 2 + hw) * NPX + e) * 2 + sub] = t1;
     }
@@ -227,10 +232,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
   };
 
   // lane -> patch entry of its pixel in group pp (centre tap)
-  int eb[2];
+  int eb[NPP];
 #pragma unroll
-  for (int pp = 0; pp < 2; ++pp) {
-    const int g = 2 * wq + pp;
+  for (int pp = 0; pp < NPP; ++pp) {
+    const int g = NPP * wq + pp;
     const int rowt = TW == 32 ? g : 2 * g + (l31 >> 4), colt = TW == 32 ? l31 : (l31 & 15);
     eb[pp] = (rowt + 1 + py - 1) * PC + colt;           // + a * PC + o   (source row offset a - 1 + py, o = column offset + 1 in 0..2)
   }
@@ -295,21 +300,30 @@ __global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
       __builtin_amdgcn_sched_barrier(0);
     };
     const int nb = buf ^ 1;
-    load_A(A0, 0); load_B(B0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    load_B(B1, 0, 1);
-    step(A0, B0, P0{}, [&]() __attribute__((always_inline)) { stage_round(nb, 0); });
-    if constexpr (TW == 32) {
-      load_A(A1, 1); load_B(B0, 1, 1);
-      step(A0, B1, P1{}, [&]() __attribute__((always_inline)) { stage_round(nb, 1); });
-      step(A1, B1, P0{}, [&]() __attribute__((always_inline)) { stage_round(nb, 2); stage_w(nb); });      // (a = 1, group 0) reads the patch row of (a = 0, group 1)
-      step(A1, B0, P1{}, [&]() __attribute__((always_inline)) { request(knext); });
+    if constexpr (NPP == 1) {       // one group: two steps (a = 0, 1) of 12 MFMAs; two staging rounds
+      static_assert(NPP == 2 || NR == 2, "two staging rounds");
+      load_A(A0, 0); load_B(B0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_A(A1, 1); load_B(B1, 1, 0);
+      step(A0, B0, P0{}, [&]() __attribute__((always_inline)) { stage_round(nb, 0); });
+      step(A1, B1, P0{}, [&]() __attribute__((always_inline)) { stage_round(nb, 1); stage_w(nb); request(knext); });
     } else {
-      load_A(A1, 1); load_B(B0, 1, 0);
-      step(A0, B1, P1{}, [&]() __attribute__((always_inline)) { stage_round(nb, 1); });
-      load_B(B1, 1, 1);
-      step(A1, B0, P0{}, [&]() __attribute__((always_inline)) { stage_round(nb, 2); stage_w(nb); });
-      step(A1, B1, P1{}, [&]() __attribute__((always_inline)) { request(knext); });
+      load_A(A0, 0); load_B(B0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_B(B1, 0, 1);
+      step(A0, B0, P0{}, [&]() __attribute__((always_inline)) { stage_round(nb, 0); });
+      if constexpr (TW == 32) {
+        load_A(A1, 1); load_B(B0, 1, 1);
+        step(A0, B1, P1{}, [&]() __attribute__((always_inline)) { stage_round(nb, 1); });
+        step(A1, B1, P0{}, [&]() __attribute__((always_inline)) { stage_round(nb, 2); stage_w(nb); });      // (a = 1, group 0) reads the patch row of (a = 0, group 1)
+        step(A1, B0, P1{}, [&]() __attribute__((always_inline)) { request(knext); });
+      } else {
+        load_A(A1, 1); load_B(B0, 1, 0);
+        step(A0, B1, P1{}, [&]() __attribute__((always_inline)) { stage_round(nb, 1); });
+        load_B(B1, 1, 1);
+        step(A1, B0, P0{}, [&]() __attribute__((always_inline)) { stage_round(nb, 2); stage_w(nb); });
+        step(A1, B1, P1{}, [&]() __attribute__((always_inline)) { request(knext); });
+      }
     }
   };
 
@@ -330,10 +344,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
   const unsigned hw32 = (unsigned)((size_t)4 * Hl * Wl);
   float* const ob = p.out + ((size_t)n * p.Cout + cot * 32) * (size_t)hw32;
   const bool want_stats = p.stats != nullptr;
-  unsigned loff[2]; bool okp[2];
+  unsigned loff[NPP]; bool okp[NPP];
 #pragma unroll
-  for (int pp = 0; pp < 2; ++pp) {
-    const int g = 2 * wq + pp;
+  for (int pp = 0; pp < NPP; ++pp) {
+    const int g = NPP * wq + pp;
     const int i = y0 + (TW == 32 ? g : 2 * g + (l31 >> 4)), j = x0 + (TW == 32 ? l31 : (l31 & 15));
     okp[pp] = i < Hl && j < Wl;
     loff[pp] = (unsigned)(4 * lhi) * hw32 + (unsigned)(okp[pp] ? (2 * i + py) * W + 2 * j : 0);
@@ -345,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
     const bool okc = cot * 32 + col < p.Cout;
     float sv = 0.f, sq = 0.f;
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
+    for (int pp = 0; pp < NPP; ++pp) {
       floatx2 v = {acc[pp][0][r] * hinv, acc[pp][1][r] * hinv};
       if (okp[pp] && okc) *reinterpret_cast<floatx2*>(ob + loff[pp] + (unsigned)cu * hw32) = v;
       else v = floatx2{0.f, 0.f};
@@ -401,13 +415,16 @@ __device__ __forceinline__ float spd_grad_scale(const float* absmax) {      // (
   return ldexpf(1.f, e);
 }
 
-template <int TW, bool BF>
+template <int TW, bool BF, int NPP = 2>
 __global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
+  static_assert(NPP == 2 || (NPP == 1 && TW == 16), "one group per wave: 16-wide tiles only (see k_conv3_sp)");
   constexpr int NT = BF ? 1 : 2;
   constexpr int NM = BF ? 4 : 12;
-  constexpr int TH = 256 / TW;
+  constexpr int TH = 128 * NPP / TW;
   constexpr int PC = sp_pc<TW>(), NPX = sp_npx<TW>();
-  constexpr int NR = 3;
+  constexpr int NPXU = (TH + 2) * PC;
+  constexpr int NR = (NPXU + 127) / 128;
+  static_assert(NPXU <= NPX && (NPP == 2 || NR == 2), "staging rounds");
   constexpr int WST = SP_WST / 2 * NT;
   constexpr int NWV = WST / 512;
 
@@ -443,9 +460,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
   const float hsx = BF ? 1.f : spd_grad_scale(p.absmax);
   const float hinv = BF ? 1.f : 1.f / (hsx * SP_SW);
 
-  floatx16 acc[2][2];      // [group pp][cin block mx]
+  floatx16 acc[NPP][2];    // [group pp][cin block mx]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2 * NPP; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i >> 1][i & 1][r] = 0.f;
 
@@ -458,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
     const int e = sidx + 128 * r;
     const int pr = e / PC, pc = e - pr * PC;
     const int y = y0 - 1 + pr, x = x0 - 1 + pc;
-    const bool ok = (e < NPX) && (y >= 0) && (y < Hl) && (x >= 0) && (x < Wl);
+    const bool ok = (e < NPXU) && (y >= 0) && (y < Hl) && (x >= 0) && (x < Wl);
     pyx[r] = ok ? ((unsigned)y << 16) | (unsigned)x : 0xFFFFFFFFu;
   }
   float xv[NR][4], av[NR][4];
@@ -518,7 +535,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
       if (jp == 0) { t0.x = a0; t1.x = a1; } else { t0.y = a0; t1.y = a1; }
     }
     const int e = sidx + 128 * r;
-    if (e < NPX) {
+    if (e < NPXU) {
       sp2[((0 * 2 + hw) * NPX + e) * 2 + sub] = t0;
       if constexpr (!BF) sp2[((1 * 2 + hw) * NPX + e) * 2 + sub] = t1;
     }
@@ -528,10 +545,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
     for (int j = 0; j < NWV; ++j) s_w[buf * WST + tid + 512 * j] = wv[j];
   };
 
-  int eb[2];
+  int eb[NPP];
 #pragma unroll
-  for (int pp = 0; pp < 2; ++pp) {
-    const int g = 2 * wq + pp;
+  for (int pp = 0; pp < NPP; ++pp) {
+    const int g = NPP * wq + pp;
     const int rowt = TW == 32 ? g : 2 * g + (l31 >> 4), colt = TW == 32 ? l31 : (l31 & 15);
     eb[pp] = (rowt + 1) * PC + colt;           // + (1 - a - qy) * PC + o,  o = 2 - b - qx
   }
@@ -594,7 +611,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
     __builtin_amdgcn_sched_barrier(0);
     load_A(A0, 0); load_B(B1, 0, 0);
     step(A1, B0, P0{}, [&]() __attribute__((always_inline)) { stage_round(nb, 0); });
-    if constexpr (TW == 32) {
+    if constexpr (NPP == 1) {       // one group: the second step carries the rest of the staging
+      step(A0, B1, P0{}, [&]() __attribute__((always_inline)) { stage_round(nb, 1); stage_w(nb); request(knext); });
+    } else if constexpr (TW == 32) {
       load_B(B0, 0, 1);
       step(A0, B1, P0{}, [&]() __attribute__((always_inline)) { stage_round(nb, 1); });
       step(A1, B1, P1{}, [&]() __attribute__((always_inline)) { stage_round(nb, 2); stage_w(nb); });
@@ -626,8 +645,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
     const unsigned W2 = 2u * (unsigned)Wl, ph32 = (unsigned)((size_t)4 * Hl * Wl);
     float* const os = p.out_skip + (size_t)n * p.Cskip * ph32;
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-      const int g = 2 * wq + pp;
+    for (int pp = 0; pp < NPP; ++pp) {
+      const int g = NPP * wq + pp;
       const int i = y0 + (TW == 32 ? g : 2 * g + (l31 >> 4)), j = x0 + (TW == 32 ? l31 : (l31 & 15));
       const bool okp = i < Hl && j < Wl;
 #pragma unroll
@@ -650,8 +669,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
   const int cb = cot * 128 + hh * 64;
   float* const ob = p.out + ((size_t)n * p.Cup + cb) * (size_t)pl32;
 #pragma unroll
-  for (int pp = 0; pp < 2; ++pp) {
-    const int g = 2 * wq + pp;
+  for (int pp = 0; pp < NPP; ++pp) {
+    const int g = NPP * wq + pp;
     const int i = y0 + (TW == 32 ? g : 2 * g + (l31 >> 4)), j = x0 + (TW == 32 ? l31 : (l31 & 15));
     const bool okp = i < Hl && j < Wl;
     const unsigned loff = (unsigned)(4 * lhi) * pl32 + (unsigned)(okp ? i * Wl + j : 0);
@@ -697,9 +716,21 @@ extern "C" int sc_pack_weights_sp(const float* w, float* wpk, int Cout, int Cup,
   return SC_OK;
 }
 
-extern "C" int sc_sp_stat_rows(int N, int H, int W) {
+// pixel groups per wave: 2 (256-pixel tiles) unless the launch's 16-wide tiles x channel tiles give at most 128 work-groups -- half the
+// chip or less -- then 1 (128-pixel tiles, twice the work-groups, still one round).  Measured on decoder.blocks.0 at batch 16 (16 planes
+// of 16 x 16; tools/bench_sp.py, us): forward, 8 cout tiles = 128 work-groups: 290 -> 224; data gradient, 10 channel tiles = 160: 232 ->
+// 287 as 320 work-groups (a second, quarter-full round) -- so it keeps the 256-pixel tiles.
+static inline int sp_groups_per_wave(int N, int Hl, int Wl, int ctiles) {
+  if (Wl >= 32) return 2;
+  const long wgs2 = (long)N * ((Wl + 15) / 16) * ((Hl + 15) / 16) * ctiles;
+  static const int force = [] { const char* e = getenv("STARCOP_SP_NPP"); return e ? atoi(e) : 0; }();      // (tests, A/B: 1 or 2)
+  if (force == 1 || force == 2) return force;
+  return wgs2 <= 128 ? 1 : 2;
+}
+
+extern "C" int sc_sp_stat_rows(int N, int H, int W, int Cout) {
   const int Hl = H / 2, Wl = W / 2;
-  const int TW = Wl >= 32 ? 32 : 16, TH = 256 / TW;
+  const int TW = Wl >= 32 ? 32 : 16, TH = 128 * sp_groups_per_wave(N, Hl, Wl, (Cout + 31) / 32) / TW;
   return N * ((Wl + TW - 1) / TW) * ((Hl + TH - 1) / TH);
 }
 
@@ -731,7 +762,8 @@ extern "C" int sc_conv3x3_sp(const sc_conv_args* a, sc_stream stream) {
   p.N = a->N; p.Hl = a->H / 2; p.Wl = a->W / 2; p.Cout = a->Cout;
   p.out = a->out0; p.stats = a->stats;
   p.xb0 = a->xbound[0]; p.xb1 = a->nsrc == 2 ? a->xbound[1] : nullptr;
-  const int TW = p.Wl >= 32 ? 32 : 16, TH = 256 / TW;
+  const int npp = sp_groups_per_wave(a->N, p.Hl, p.Wl, (a->Cout + 31) / 32);
+  const int TW = p.Wl >= 32 ? 32 : 16, TH = 128 * npp / TW;
   const long tiles = (long)((p.Wl + TW - 1) / TW) * ((p.Hl + TH - 1) / TH) * a->N;
   const long ncot = (a->Cout + 31) / 32;
   const long grid = (tiles + 7) / 8 * 8 * ncot;
@@ -740,13 +772,18 @@ extern "C" int sc_conv3x3_sp(const sc_conv_args* a, sc_stream stream) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<32>()) == hipSuccess &&
            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess &&
            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<32>()) == hipSuccess &&
-           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess;
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<16, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<16, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess;
   }();
   SC_REQUIRE(attr_ok, "sc_conv3x3_sp: cannot reserve %d bytes of LDS", sp_smem_bytes<32>());
   const bool bf = a->terms == 1;
   if (TW == 32) {
     if (bf) hipLaunchKernelGGL((k_conv3_sp<32, true>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<32>(), (hipStream_t)stream, p);
     else hipLaunchKernelGGL((k_conv3_sp<32, false>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<32>(), (hipStream_t)stream, p);
+  } else if (npp == 1) {
+    if (bf) hipLaunchKernelGGL((k_conv3_sp<16, true, 1>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<16>(), (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((k_conv3_sp<16, false, 1>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<16>(), (hipStream_t)stream, p);
   } else {
     if (bf) hipLaunchKernelGGL((k_conv3_sp<16, true>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<16>(), (hipStream_t)stream, p);
     else hipLaunchKernelGGL((k_conv3_sp<16, false>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<16>(), (hipStream_t)stream, p);
@@ -794,7 +831,8 @@ extern "C" int sc_conv3x3_sp_dgrad(const sc_conv_args* a, sc_stream stream) {
   p.N = a->N; p.Hl = a->H / 2; p.Wl = a->W / 2; p.Cup = a->csplit;
   p.out = a->out0; p.accum = a->accum0; p.absmax = a->absmax;
   p.out_skip = a->out1; p.Cskip = a->Cout - a->csplit; p.accum_skip = a->accum1;
-  const int TW = p.Wl >= 32 ? 32 : 16, TH = 256 / TW;
+  const int npp = sp_groups_per_wave(a->N, p.Hl, p.Wl, (a->csplit + 127) / 128);
+  const int TW = p.Wl >= 32 ? 32 : 16, TH = 128 * npp / TW;
   const long tiles = (long)((p.Wl + TW - 1) / TW) * ((p.Hl + TH - 1) / TH) * a->N;
   const long ncot = (a->csplit + 127) / 128;
   const long grid = (tiles + 7) / 8 * 8 * ncot;
@@ -803,13 +841,18 @@ extern "C" int sc_conv3x3_sp_dgrad(const sc_conv_args* a, sc_stream stream) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<32>()) == hipSuccess &&
            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess &&
            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<32>()) == hipSuccess &&
-           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess;
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<16, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<16, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess;
   }();
   SC_REQUIRE(attr_ok, "sc_conv3x3_sp_dgrad: cannot reserve %d bytes of LDS", sp_smem_bytes<32>());
   const bool bf = a->terms == 1;
   if (TW == 32) {
     if (bf) hipLaunchKernelGGL((k_conv3_spd<32, true>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<32>(), (hipStream_t)stream, p);
     else hipLaunchKernelGGL((k_conv3_spd<32, false>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<32>(), (hipStream_t)stream, p);
+  } else if (npp == 1) {
+    if (bf) hipLaunchKernelGGL((k_conv3_spd<16, true, 1>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<16>(), (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((k_conv3_spd<16, false, 1>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<16>(), (hipStream_t)stream, p);
   } else {
     if (bf) hipLaunchKernelGGL((k_conv3_spd<16, true>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<16>(), (hipStream_t)stream, p);
     else hipLaunchKernelGGL((k_conv3_spd<16, false>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<16>(), (hipStream_t)stream, p);

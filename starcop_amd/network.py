@@ -957,7 +957,7 @@ class HyperStarcopUNet(nn.Module):
                       and _use_sp(N, Ho, Wo, o.C)):
                     fconv = lib.sc_conv3x3_sp
                     a.wpk = ent["sp"].data_ptr()
-                    srows = lib.sc_sp_stat_rows(N, Ho, Wo)       # one partial row per work-group tile (fewer than SC_STAT_CONV3's)
+                    srows = lib.sc_sp_stat_rows(N, Ho, Wo, o.C)       # one partial row per work-group tile (fewer than SC_STAT_CONV3's)
                 elif ent["tf"] is not None:
                     fconv = lib.sc_conv3x3_thin16
                     a.wpk = ent["tf"].data_ptr()

@@ -223,7 +223,7 @@ def conv_sp(srcs, wpk, N, H, W, Cout, want_stats=False, terms=None):
     a.accum0 = a.accum1 = 0
     a.add0 = a.add1 = None
     a.terms, a.down0, a.absmax = (TERMS_F16X2 if terms is None else terms), 0, None
-    stats = torch.full((lib.sc_sp_stat_rows(N, H, W), Cout, 2), float("nan"), device=DEV) if want_stats else None
+    stats = torch.full((lib.sc_sp_stat_rows(N, H, W, Cout), Cout, 2), float("nan"), device=DEV) if want_stats else None
     a.stats = stats.data_ptr() if want_stats else None
     check(lib.sc_conv3x3_sp(C.byref(a), stream()))
     return out, stats

@@ -1120,6 +1120,20 @@ def test_depthwise_plane_kernels_at_32():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("npp", ["1", "2"])
+def test_sub_pixel_tile_sizes_of_narrow_planes(npp):
+    """16-wide sub-pixel tiles come in two heights: 16 rows (two pixel groups per wave) and, for launches with fewer than 32 such tiles
+    (decoder.blocks.0 at batch 16), 8 rows (one group per wave, twice the work-groups).  The rule would pick the 8-row form for every
+    narrow shape of this file's small-batch tests, so the sub-pixel op tests (forward, bf16 mode, data gradient incl. the one-launch
+    skip gradient, fuzz) are re-run in child processes with either form forced (STARCOP_SP_NPP)."""
+    import subprocess, sys
+    env = dict(os.environ, STARCOP_SP_NPP=npp)
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), os.path.join(here, "test_gpu_fuzz.py"), "-q", "-x", "-k",
+                        "conv_sp and not wgrad and not tile_sizes"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 # ---- pointwise convolutions on the split-bf16 MFMA without LDS staging (conv_pw3.hip)
 PW3_SHAPES = [(16, 96, 2, 64, 64), (64, 384, 3, 32, 32), (384, 64, 2, 32, 32), (160, 960, 2, 16, 16), (960, 320, 2, 16, 16), (24, 144, 2, 24, 40),
               (144, 24, 1, 20, 12), (320, 1280, 2, 4, 6), (32, 16, 1, 2, 2), (96, 576, 5, 2, 3), (40, 8, 2, 1, 1)]

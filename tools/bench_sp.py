@@ -56,7 +56,7 @@ for name, cu, cs, cout, H in ([] if os.environ.get("SP_WGRAD_ONLY") else SHAPES)
     wsp = torch.empty(lib.sc_packed_weight_floats_sp(cout, cu, cs), device=DEV)
     check(lib.sc_pack_weights_sp(ptr(w), ptr(wsp), cout, cu, cs, TERMS_F16X2, stream()))
     out = torch.empty(N, cout, H, W, device=DEV)
-    rows = lib.sc_sp_stat_rows(N, H, W)
+    rows = lib.sc_sp_stat_rows(N, H, W, cout)
     stats = torch.full((rows, cout, 2), float("nan"), device=DEV)
     run = lambda: sp_conv(srcs, wsp, N, H, W, cout, out, stats)
     run()
