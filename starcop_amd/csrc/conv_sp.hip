@@ -89,12 +89,12 @@ template <int TW> constexpr int sp_smem_bytes() { return SP_SMEM_W + 2 * 2 * 2 *
 
 // BF: the "bf16" precision mode -- ONE bf16 term per operand (round to nearest even, no range scale), a third of the MFMAs and half
 // the operand reads; the skeleton, LDS layout (term 0 only) and pipeline are the same
-// NPP: pixel groups per wave.  2: the 256-pixel tile above.  1 (16-wide tiles only): a 128-pixel tile (8 x 16), one group per wave --
-// for launches whose 256-pixel tiles do not fill the chip (decoder.blocks.0 at batch 16: 16 planes of 16 x 16 = 128 work-groups for 256
-// CUs); twice the work-groups, each with half the MFMAs per staged filter chunk.
+// NPP: pixel groups per wave.  2: the 256-pixel tile above.  1: a 128-pixel tile (8 x 16 or 4 x 32), one group per wave -- for launches
+// whose 256-pixel tiles do not fill the chip (decoder.blocks.0 at batch 16: 16 planes of 16 x 16 = 128 work-groups for 256 CUs); twice
+// the work-groups, each with half the MFMAs per staged filter chunk.
 template <int TW, bool BF, int NPP = 2>
 __global__ __launch_bounds__(512, 2) void k_conv3_sp(const ConvSPP p) {
-  static_assert(NPP == 2 || (NPP == 1 && TW == 16), "one group per wave: 16-wide tiles only");
+  static_assert(NPP == 1 || NPP == 2, "one or two pixel groups per wave");
   constexpr int NT = BF ? 1 : 2;
   constexpr int NM = BF ? 4 : 12;            // MFMAs per step
   constexpr int TH = 128 * NPP / TW;
@@ -417,7 +417,7 @@ __device__ __forceinline__ float spd_grad_scale(const float* absmax) {      // (
 
 template <int TW, bool BF, int NPP = 2>
 __global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
-  static_assert(NPP == 2 || (NPP == 1 && TW == 16), "one group per wave: 16-wide tiles only (see k_conv3_sp)");
+  static_assert(NPP == 1 || NPP == 2, "one or two pixel groups per wave (see k_conv3_sp)");
   constexpr int NT = BF ? 1 : 2;
   constexpr int NM = BF ? 4 : 12;
   constexpr int TH = 128 * NPP / TW;
@@ -721,8 +721,7 @@ extern "C" int sc_pack_weights_sp(const float* w, float* wpk, int Cout, int Cup,
 // of 16 x 16; tools/bench_sp.py, us): forward, 8 cout tiles = 128 work-groups: 290 -> 224; data gradient, 10 channel tiles = 160: 232 ->
 // 287 as 320 work-groups (a second, quarter-full round) -- so it keeps the 256-pixel tiles.
 static inline int sp_groups_per_wave(int N, int Hl, int Wl, int ctiles) {
-  if (Wl >= 32) return 2;
-  const long wgs2 = (long)N * ((Wl + 15) / 16) * ((Hl + 15) / 16) * ctiles;
+  const long wgs2 = Wl >= 32 ? (long)N * ((Wl + 31) / 32) * ((Hl + 7) / 8) * ctiles : (long)N * ((Wl + 15) / 16) * ((Hl + 15) / 16) * ctiles;
   static const int force = [] { const char* e = getenv("STARCOP_SP_NPP"); return e ? atoi(e) : 0; }();      // (tests, A/B: 1 or 2)
   if (force == 1 || force == 2) return force;
   return wgs2 <= 128 ? 1 : 2;
@@ -774,11 +773,16 @@ extern "C" int sc_conv3x3_sp(const sc_conv_args* a, sc_stream stream) {
            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<32>()) == hipSuccess &&
            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess &&
            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<16, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess &&
-           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<16, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess;
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<16, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<32, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<32>()) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_sp<32, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<32>()) == hipSuccess;
   }();
   SC_REQUIRE(attr_ok, "sc_conv3x3_sp: cannot reserve %d bytes of LDS", sp_smem_bytes<32>());
   const bool bf = a->terms == 1;
-  if (TW == 32) {
+  if (TW == 32 && npp == 1) {
+    if (bf) hipLaunchKernelGGL((k_conv3_sp<32, true, 1>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<32>(), (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((k_conv3_sp<32, false, 1>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<32>(), (hipStream_t)stream, p);
+  } else if (TW == 32) {
     if (bf) hipLaunchKernelGGL((k_conv3_sp<32, true>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<32>(), (hipStream_t)stream, p);
     else hipLaunchKernelGGL((k_conv3_sp<32, false>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<32>(), (hipStream_t)stream, p);
   } else if (npp == 1) {
@@ -843,11 +847,16 @@ extern "C" int sc_conv3x3_sp_dgrad(const sc_conv_args* a, sc_stream stream) {
            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<32>()) == hipSuccess &&
            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess &&
            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<16, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess &&
-           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<16, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess;
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<16, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<16>()) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<32, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<32>()) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_spd<32, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes<32>()) == hipSuccess;
   }();
   SC_REQUIRE(attr_ok, "sc_conv3x3_sp_dgrad: cannot reserve %d bytes of LDS", sp_smem_bytes<32>());
   const bool bf = a->terms == 1;
-  if (TW == 32) {
+  if (TW == 32 && npp == 1) {
+    if (bf) hipLaunchKernelGGL((k_conv3_spd<32, true, 1>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<32>(), (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((k_conv3_spd<32, false, 1>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<32>(), (hipStream_t)stream, p);
+  } else if (TW == 32) {
     if (bf) hipLaunchKernelGGL((k_conv3_spd<32, true>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<32>(), (hipStream_t)stream, p);
     else hipLaunchKernelGGL((k_conv3_spd<32, false>), dim3((unsigned)grid), dim3(512), sp_smem_bytes<32>(), (hipStream_t)stream, p);
   } else if (npp == 1) {
