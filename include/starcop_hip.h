@@ -233,9 +233,12 @@ int sc_conv3x3_sp(const sc_conv_args* a, sc_stream stream);
  *   channels, co_t = the up-sampled source's channels, transpose_flip = 2 for vskip, | 4 for the one-bf16-term layout).
  *   vskip (sc_spd_vskip_ok: <= 64 up-sampled and <= 16 skip channels, smp's decoder.blocks.3): the skip channels' full-resolution
  *   gradient rides along in the otherwise idle half of the 128-channel tile -- Cout = all input channels, csplit = the up-sampled ones,
- *   out1 = [N, Cout - csplit, H, W] (accum1 allowed): ONE launch stages dy for both gradients. */
+ *   out1 = [N, Cout - csplit, H, W] (accum1 allowed): ONE launch stages dy for both gradients.
+ *   skip tiles (any other channel counts, out1 given; pack with vskip = 2 / transpose_flip = 3): the skip channels' gradient as
+ *   additional 128-channel tiles of the launch (32 skip channels x 4 output parities each) -- same arguments as vskip; which of the two
+ *   forms a launch takes follows from sc_spd_vskip_ok(csplit, Cout - csplit), so the pack must be made with the matching mode. */
 #define SC_PACK_SPD 8
-size_t sc_packed_weight_floats_spd(int Cout, int Cup);
+size_t sc_packed_weight_floats_spd(int Cout, int Cup, int Cskip_tiles /* skip channels packed as skip tiles (vskip = 2), else 0 */);
 int sc_spd_vskip_ok(int Cup, int Cskip);
 int sc_pack_weights_spd(const float* w_oihw, float* wpk, int Cout, int CinTotal, int Cup, int vskip, int terms, sc_stream stream);
 int sc_conv3x3_sp_dgrad(const sc_conv_args* a, sc_stream stream);

@@ -149,7 +149,7 @@ SIGNATURES = {
     "sc_pack_weights_sp": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sc_sp_stat_rows": (_i, [_i, _i, _i, _i]),
     "sc_conv3x3_sp": (_i, [C.POINTER(sc_conv_args), _vp]),
-    "sc_packed_weight_floats_spd": (_sz, [_i, _i]),
+    "sc_packed_weight_floats_spd": (_sz, [_i, _i, _i]),
     "sc_pack_weights_spd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sc_spd_vskip_ok": (_i, [_i, _i]),
     "sc_conv3x3_sp_dgrad": (_i, [C.POINTER(sc_conv_args), _vp]),

@@ -2393,7 +2393,7 @@ __global__ __launch_bounds__(256) void k_pack_batch(const PackDesc* __restrict__
   const size_t i = (size_t)(blockIdx.x - starts[lo]) * 256 + threadIdx.x;
   if (i >= d.total) return;
   if (d.bx3 == SC_PACK_THIN16) { pack_thin_item(d.w, reinterpret_cast<unsigned short*>(d.wpk), i, d.Cout, d.Cin, d.tflip); return; }
-  if (d.bx3 == SC_PACK_SPD) { spd_pack_item(d.w, reinterpret_cast<unsigned short*>(d.wpk), i, d.Cout, d.Cin, d.co_t, (d.tflip & 3) == 2, (d.tflip & 4) != 0); return; }      // tflip 2: + virtual skip channels; | 4: one bf16 term
+  if (d.bx3 == SC_PACK_SPD) { spd_pack_item(d.w, reinterpret_cast<unsigned short*>(d.wpk), i, d.Cout, d.Cin, d.co_t, (d.tflip & 3) == 2, (d.tflip & 4) != 0, (d.tflip & 3) == 3 ? d.Cin - d.co_t : 0); return; }      // tflip 2: + virtual skip channels; 3: + skip tiles; | 4: one bf16 term
   if (d.bx3 == SC_PACK_SP) { sp_pack_item(d.w, reinterpret_cast<unsigned short*>(d.wpk), i, d.Cout, d.co_t, d.Cin - d.co_t, (d.tflip & 4) != 0); return; }      // conv_sp.hip: co_t = up-sampled channels
   const int M = d.tflip ? d.Cin : d.Cout, K = d.tflip ? d.Cout : d.Cin;
   if (d.bx3 == SC_PACK_PW3) {
@@ -2725,7 +2725,7 @@ extern "C" int sc_conv3x3_thin16(const sc_conv_args* a, sc_stream stream) {
 
 extern "C" size_t sc_pack_work_items(int Cout, int Cin, int ks, int co_t, int transpose_flip, int bx3) {
   if (bx3 == SC_PACK_THIN16) return (size_t)thin_steps(Cout, Cin, transpose_flip) * 512;
-  if (bx3 == SC_PACK_SPD) return spd_pack_items(Cout, co_t);
+  if (bx3 == SC_PACK_SPD) return spd_pack_items(Cout, co_t, (transpose_flip & 3) == 3 ? Cin - co_t : 0);
   if (bx3 == SC_PACK_SP) return sp_pack_items(Cout, co_t, Cin - co_t);      // co_t = up-sampled channels (the leading ones of Cin)
   if (bx3 == SC_PACK_PW3) {
     const int M = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;

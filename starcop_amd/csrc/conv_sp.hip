@@ -401,8 +401,9 @@ struct ConvSPD {
   float* out;
   int accum;
   const float* absmax;
-  float* out_skip;         // vskip (Cup <= 64): [N][Cskip <= 16][2 Hl][2 Wl] gradient of the skip channels from wave half 1, or NULL
-  int Cskip, accum_skip;
+  float* out_skip;         // [N][Cskip][2 Hl][2 Wl] gradient of the skip channels, or NULL.  skip_mode 1 (vskip: Cup <= 64, Cskip <= 16): from
+  int Cskip, accum_skip;   // wave half 1 of the one channel tile; skip_mode 2 (skip tiles): from the channel tiles cot >= ntu (conv_sp_pack.h)
+  int skip_mode, ntu, nts; // ntu: tiles of 128 up-sampled channels; nts: skip tiles (mode 2) of 32 skip channels x 4 output parities
 };
 
 __device__ __forceinline__ float spd_grad_scale(const float* absmax) {      // (h_grad_scale of conv_bx3.hip)
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
   const int hh = wave >> 2, wq = wave & 3;
   const int Hl = p.Hl, Wl = p.Wl;
   const int tiles_x = (Wl + TW - 1) / TW, tiles_y = (Hl + TH - 1) / TH;
-  const int ncot = (p.Cup + 127) >> 7;
+  const int ncot = p.ntu + p.nts;
   int n, cot, tile;
   {
     const int per_img = tiles_x * tiles_y;
@@ -640,8 +641,33 @@ __global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
     __syncthreads();
   }
 
+  // ---- epilogue of a skip tile: block (hh, mx) = output parity (oy, ox) of the tile's 32 skip channels -> full resolution
+  if (p.skip_mode == 2 && cot >= p.ntu) {
+    const unsigned W2 = 2u * (unsigned)Wl, ph32 = (unsigned)((size_t)4 * Hl * Wl);
+    float* const os = p.out_skip + (size_t)n * p.Cskip * ph32;
+    const int cb = 32 * (cot - p.ntu);
+#pragma unroll
+    for (int pp = 0; pp < NPP; ++pp) {
+      const int g = NPP * wq + pp;
+      const int i = y0 + (TW == 32 ? g : 2 * g + (l31 >> 4)), j = x0 + (TW == 32 ? l31 : (l31 & 15));
+      const bool okp = i < Hl && j < Wl;
+#pragma unroll
+      for (int mx = 0; mx < 2; ++mx)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = cb + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          if (okp && c < p.Cskip) {
+            const unsigned off = (unsigned)c * ph32 + (unsigned)(2 * i + hh) * W2 + (unsigned)(2 * j + mx);
+            float v = acc[pp][mx][r] * hinv;
+            if (p.accum_skip) v += os[off];
+            os[off] = v;
+          }
+        }
+    }
+    return;
+  }
   // ---- epilogue, wave half 1 with virtual skip channels: v = 16 * parity + c -> dskip[c][2i + oy][2j + ox] at full resolution
-  if (p.out_skip != nullptr && hh == 1) {
+  if (p.skip_mode == 1 && hh == 1) {
     const unsigned W2 = 2u * (unsigned)Wl, ph32 = (unsigned)((size_t)4 * Hl * Wl);
     float* const os = p.out_skip + (size_t)n * p.Cskip * ph32;
 #pragma unroll
@@ -691,7 +717,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3_spd(const ConvSPD p) {
 
 __global__ void k_pack_weights_spd(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout, int CinTot, int Cup, int vskip, int bf, size_t total) {
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i < total) spd_pack_item(w, wpk, i, Cout, CinTot, Cup, vskip != 0, bf != 0);
+  if (i < total) spd_pack_item(w, wpk, i, Cout, CinTot, Cup, vskip == 1, bf != 0, vskip == 2 ? CinTot - Cup : 0);
 }
 
 __global__ void k_pack_weights_sp(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cout, int Cup, int Csk, int bf, size_t total) {
@@ -796,8 +822,8 @@ extern "C" int sc_conv3x3_sp(const sc_conv_args* a, sc_stream stream) {
   return SC_OK;
 }
 
-extern "C" size_t sc_packed_weight_floats_spd(int Cout, int Cup) {
-  return (size_t)((Cup + 127) / 128) * 4 * ((Cout + 15) / 16) * SP_WST * 4;
+extern "C" size_t sc_packed_weight_floats_spd(int Cout, int Cup, int Cskip_tiles) {
+  return (size_t)((Cup + 127) / 128 + (Cskip_tiles + 31) / 32) * 4 * ((Cout + 15) / 16) * SP_WST * 4;
 }
 
 extern "C" int sc_spd_vskip_ok(int Cup, int Cskip) { return Cup > 0 && Cup <= 64 && Cskip > 0 && Cskip <= 16; }
@@ -805,9 +831,11 @@ extern "C" int sc_spd_vskip_ok(int Cup, int Cskip) { return Cup > 0 && Cup <= 64
 extern "C" int sc_pack_weights_spd(const float* w, float* wpk, int Cout, int CinTotal, int Cup, int vskip, int terms, sc_stream stream) {
   SC_REQUIRE(w && wpk && Cout > 0 && Cup > 0 && Cup <= CinTotal, "sc_pack_weights_spd: bad argument");
   SC_REQUIRE(terms == SC_TERMS_F16X2 || terms == 1, "sc_pack_weights_spd: terms must be SC_TERMS_F16X2 or 1 (one bf16 term)");
-  SC_REQUIRE(!vskip || sc_spd_vskip_ok(Cup, CinTotal - Cup), "sc_pack_weights_spd: virtual skip channels need Cup <= 64 and 1..16 skip channels");
+  SC_REQUIRE(vskip >= 0 && vskip <= 2, "sc_pack_weights_spd: vskip must be 0 (up-sampled channels only), 1 (virtual skip channels) or 2 (skip tiles)");
+  SC_REQUIRE(vskip != 1 || sc_spd_vskip_ok(Cup, CinTotal - Cup), "sc_pack_weights_spd: virtual skip channels need Cup <= 64 and 1..16 skip channels");
+  SC_REQUIRE(vskip != 2 || CinTotal > Cup, "sc_pack_weights_spd: skip tiles need skip channels");
   SC_REQUIRE(((uintptr_t)wpk & 15) == 0, "sc_pack_weights_spd: destination must be 16-byte aligned");
-  const size_t total = spd_pack_items(Cout, Cup);
+  const size_t total = spd_pack_items(Cout, Cup, vskip == 2 ? CinTotal - Cup : 0);
   hipLaunchKernelGGL(k_pack_weights_spd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
                      reinterpret_cast<unsigned short*>(wpk), Cout, CinTotal, Cup, vskip, terms == 1 ? 1 : 0, total);
   SC_LAUNCH_OK("sc_pack_weights_spd");
@@ -825,8 +853,6 @@ extern "C" int sc_conv3x3_sp_dgrad(const sc_conv_args* a, sc_stream stream) {
   SC_REQUIRE(a->add0 == nullptr && a->add1 == nullptr && a->stats == nullptr && a->csplit > 0 && a->csplit <= a->Cout,
              "sc_conv3x3_sp_dgrad: outputs are out0 [N, csplit, H/2, W/2] (+ out1 [N, Cout - csplit, H, W]); no add / stats");
   SC_REQUIRE((a->csplit == a->Cout) == (a->out1 == nullptr), "sc_conv3x3_sp_dgrad: out1 exactly when csplit < Cout");
-  SC_REQUIRE(a->csplit == a->Cout || sc_spd_vskip_ok(a->csplit, a->Cout - a->csplit),
-             "sc_conv3x3_sp_dgrad: the skip channels' gradient rides along only for csplit <= 64 and <= 16 skip channels (got %d, %d)", a->csplit, a->Cout - a->csplit);
   SC_REQUIRE(((uintptr_t)a->wpk & 15) == 0, "sc_conv3x3_sp_dgrad: alignment");
   SC_REQUIRE((size_t)128 * (a->H / 2) * (a->W / 2) < (1ull << 32) && (size_t)a->H * a->W < (1ull << 31), "sc_conv3x3_sp_dgrad: plane too large");
   ConvSPD p;
@@ -835,10 +861,14 @@ extern "C" int sc_conv3x3_sp_dgrad(const sc_conv_args* a, sc_stream stream) {
   p.N = a->N; p.Hl = a->H / 2; p.Wl = a->W / 2; p.Cup = a->csplit;
   p.out = a->out0; p.accum = a->accum0; p.absmax = a->absmax;
   p.out_skip = a->out1; p.Cskip = a->Cout - a->csplit; p.accum_skip = a->accum1;
-  const int npp = sp_groups_per_wave(a->N, p.Hl, p.Wl, (a->csplit + 127) / 128);
+  // the skip channels' gradient in the same launch: in the idle half of the one channel tile (vskip) where that fits, else as skip tiles
+  p.skip_mode = a->out1 == nullptr ? 0 : (sc_spd_vskip_ok(a->csplit, a->Cout - a->csplit) ? 1 : 2);
+  p.ntu = (a->csplit + 127) / 128;
+  p.nts = p.skip_mode == 2 ? (p.Cskip + 31) / 32 : 0;
+  const int npp = sp_groups_per_wave(a->N, p.Hl, p.Wl, p.ntu + p.nts);
   const int TW = p.Wl >= 32 ? 32 : 16, TH = 128 * npp / TW;
   const long tiles = (long)((p.Wl + TW - 1) / TW) * ((p.Hl + TH - 1) / TH) * a->N;
-  const long ncot = (a->csplit + 127) / 128;
+  const long ncot = p.ntu + p.nts;
   const long grid = (tiles + 7) / 8 * 8 * ncot;
   SC_REQUIRE(grid < (1L << 31), "sc_conv3x3_sp_dgrad: grid too large");
   static const bool attr_ok = [] {

@@ -76,11 +76,14 @@ __device__ __forceinline__ void sp_pack_item(const float* __restrict__ w, unsign
 // filters otherwise -- carry the skip channels' FULL-resolution gradient as 4 output parities x 16 channels: virtual channel
 // v = 16 * (2 oy + ox) + c is dskip[c][2i + oy][2j + ox], whose tap for dy parity chunk (qy, qx) and slot (a, b) is the single filter
 // entry kh = oy + 2a + qy - 1, kw = ox + 2b + qx - 1 (zero outside 0..2): one launch stages dy once for both gradients.
-static inline size_t spd_pack_items(int Cout, int Cup) {
-  return (size_t)((Cup + 127) / 128) * 4 * ((Cout + 15) / 16) * (SP_WST / 2) * 8;
+// SKIP TILES (skt > 0 skip channels; any Cup): the skip channels' full-resolution gradient as ADDITIONAL 128-channel tiles of the same
+// launch, 32 skip channels x 4 output parities each: block (h, mx) of such a tile is output parity (oy, ox) = (h, mx) of its 32 channels,
+// with the same single-tap filters as above -- the launch stages dy once for the up-sampled channels' and the skip channels' gradient.
+static inline size_t spd_pack_items(int Cout, int Cup, int skt = 0) {
+  return (size_t)((Cup + 127) / 128 + (skt + 31) / 32) * 4 * ((Cout + 15) / 16) * (SP_WST / 2) * 8;
 }
 __device__ __forceinline__ void spd_pack_item(const float* __restrict__ w, unsigned short* __restrict__ out, size_t i, int Cout, int CinTot, int Cup,
-                                              bool vskip = false, bool bf = false) {
+                                              bool vskip = false, bool bf = false, int skt = 0) {
   const int nkt = 4 * ((Cout + 15) / 16);
   size_t r = i;
   const int j = (int)(r % 8); r /= 8;
@@ -95,7 +98,12 @@ __device__ __forceinline__ void spd_pack_item(const float* __restrict__ w, unsig
   const int q = chunk & 3, py = q >> 1, px = q & 1;
   const int co = (chunk >> 2) * 16 + half * 8 + j, ci = mt * 128 + (2 * h + mx) * 32 + col;
   float v = 0.f;
-  if (vskip && h == 1) {
+  const int ntu = (Cup + 127) / 128;
+  if (skt > 0 && mt >= ntu) {
+    const int oy = h, ox = mx, c = Cup + 32 * (mt - ntu) + col;
+    const int kh = oy + 2 * a + py - 1, kw = ox + 2 * b + px - 1;
+    if (co < Cout && c < Cup + skt && c < CinTot && kh >= 0 && kh <= 2 && kw >= 0 && kw <= 2) v = w[((size_t)co * CinTot + c) * 9 + kh * 3 + kw];
+  } else if (vskip && h == 1) {
     const int vch = mx * 32 + col, par = vch >> 4, c = Cup + (vch & 15);
     const int kh = (par >> 1) + 2 * a + py - 1, kw = (par & 1) + 2 * b + px - 1;
     if (co < Cout && c < CinTot && kh >= 0 && kh <= 2 && kw >= 0 && kw <= 2) v = w[((size_t)co * CinTot + c) * 9 + kh * 3 + kw];

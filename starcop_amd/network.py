@@ -187,6 +187,7 @@ _BNR = os.environ.get("STARCOP_BNR", "0") == "1"
 # training steps pack the decoder's / the backward filter layouts on the weight-gradient stream, beside the encoder's forward ("0": on
 # the main stream, ahead of the forward -- A/B)
 _PACK_SIDE = os.environ.get("STARCOP_PACK_SIDE", "1") == "1"
+_SP_SKIPTILES = os.environ.get("STARCOP_SP_SKIPTILES", "1") == "1"      # (same-box A/B of decoder.blocks.0's one-launch data gradient)
 _EXP_NO_WGRAD = os.environ.get("STARCOP_EXP_NO_WGRAD", "0") == "1"
 _EXP_SIDE2 = os.environ.get("STARCOP_EXP_SIDE2", "0") == "1"      # tools/: elimination experiment only
 
@@ -213,6 +214,16 @@ def _use_spd(N, Ho, Wo, Cup, Csk=0):
     if _SP == "0" or Ho % 2 or Wo % 2:
         return False
     return _SP == "all" or Cup >= 128 or (Csk and _lib.load().sc_spd_vskip_ok(Cup, Csk))       # (.. or ONE launch for both gradients)
+
+
+def _use_spd_skip_tiles(Cup, Csk):
+    """the skip channels' gradient of a decoder conv1 as additional channel tiles of its sub-pixel data-gradient launch (instead of a
+    3x3 launch of its own on 32-wide tiles, which stages dy again)?  Each skip tile costs what a tile of 128 up-sampled channels costs,
+    so it pays where the skip channels are few tiles beside many: decoder.blocks.0 (10 + 3 tiles; the 3x3 launch it replaces: 54 us at
+    batch 16).  decoder.blocks.1 (2 + 1): level; blocks.2 (1 + 1: twice the launch for a 50 us one): no."""
+    if _SP == "all":
+        return True
+    return _SP != "0" and _SP_SKIPTILES and Cup >= 1024 and -(-Csk // 32) * 3 <= -(-Cup // 128)
 
 
 def _use_spw(N, Ho, Wo, Cout, Cup):
@@ -724,10 +735,12 @@ class HyperStarcopUNet(nn.Module):
                 # ... and the data gradient of its up-sampled channels (the skip channels' gradient: a 3x3 launch on a 32-wide pack)
                 if op.get("up") and xb and tb_ in _SP_TERMS and _SP != "0" and op["ins"][0].C % 32 == 0:
                     cu = op["ins"][0].C
-                    ent["spd"] = torch.empty(lib.sc_packed_weight_floats_spd(co, cu), dtype=torch.float32, device=dev)
-                    ent["sp_cu"] = cu
                     ent["spd_vskip"] = bool(ci > cu and lib.sc_spd_vskip_ok(cu, ci - cu))     # decoder.blocks.3: skip gradient in the same launch
-                    if ci > cu and ent.get("bB") is None and not ent["spd_vskip"]:
+                    # ... or as additional channel tiles of that launch (skip tiles), where measured faster than a 3x3 launch of its own
+                    ent["spd_stiles"] = bool(ci > cu and not ent["spd_vskip"] and _use_spd_skip_tiles(cu, ci - cu))
+                    ent["spd"] = torch.empty(lib.sc_packed_weight_floats_spd(co, cu, ci - cu if ent["spd_stiles"] else 0), dtype=torch.float32, device=dev)
+                    ent["sp_cu"] = cu
+                    if ci > cu and ent.get("bB") is None and not ent["spd_vskip"] and not ent["spd_stiles"]:
                         ent["bB"] = torch.empty(lib.sc_packed_weight_floats_bx3(co, ci, 32, 1, tb_), dtype=torch.float32, device=dev)
                         ent["bB_off"] = ent["bB"].numel() // (-(-ci // 32)) * (cu // 32)
                 self._wpk[i] = ent
@@ -770,7 +783,7 @@ class HyperStarcopUNet(nn.Module):
                     if buf is not None and need_bwd:
                         add(False, conv.weight, buf, co, ci, ks, cot, 1, ent["terms_b"])
                 if ent.get("spd") is not None and need_bwd:
-                    tfl = (2 if ent["spd_vskip"] else 1) | (4 if ent["terms_b"] == 1 else 0)      # | 4: the one-bf16-term layout
+                    tfl = (3 if ent["spd_stiles"] else (2 if ent["spd_vskip"] else 1)) | (4 if ent["terms_b"] == 1 else 0)      # | 4: the one-bf16-term layout
                     add(False, conv.weight, ent["spd"], co, ci, ks, ent["sp_cu"], tfl, PACK_SPD)
                 if ent.get("sp") is not None:
                     add(False, conv.weight, ent["sp"], co, ci, ks, ent["sp_cu"], 4 if ent["terms_f"] == 1 else 0, PACK_SP)
@@ -1510,16 +1523,17 @@ class HyperStarcopUNet(nn.Module):
             if (op.get("up") and ent.get("spd") is not None and ent["terms_b"] in _SP_TERMS and self.split_bf16
                     and _use_spd(N, Ho, Wo, ins[0].C, conv.in_channels - ins[0].C)):
                 cu_ = ins[0].C          # up-sampled channels: 4 parity planes x 4 taps per low-resolution pixel; skip channels: the 3x3 form
-                fle = (2.0 * N * (Ho // 2) * (Wo // 2) * 16 * conv.out_channels * (-(-cu_ // 128) * 128)
-                       + (0.0 if ent["spd_vskip"] else 2.0 * N * Ho * Wo * 9 * conv.out_channels * (conv.in_channels - cu_)))
+                fle = (2.0 * N * (Ho // 2) * (Wo // 2) * 16 * conv.out_channels * (-(-cu_ // 128) * 128 + (128 * -(-(conv.in_channels - cu_) // 32) if ent["spd_stiles"] else 0))
+                       + (0.0 if (ent["spd_vskip"] or ent["spd_stiles"]) else 2.0 * N * Ho * Wo * 9 * conv.out_channels * (conv.in_channels - cu_)))
             tok = self._pb("k_conv3_thin_h (fwd+dgrad)" if thin_b else
                            self._bx3_family("dgrad") if ent["bx3_b"] else f"k_conv_mfma<{ks}> (fwd+dgrad)", flop,
                            4.0 * (2 * N * o.C * Ho * Wo + gin_elems + conv.weight.numel()), fle)
             if (op.get("up") and ent.get("spd") is not None and ent["terms_b"] in _SP_TERMS and self.split_bf16
                     and _use_spd(N, Ho, Wo, ins[0].C, conv.in_channels - ins[0].C)):
-                if ent["spd_vskip"]:
+                if ent["spd_vskip"] or ent["spd_stiles"]:
                     # <= 64 up-sampled + <= 16 skip channels (decoder.blocks.3): the skip channels' gradient as virtual channels of the
-                    # 128-channel tile's second half -- dy (g, y) is staged ONCE for both gradients (289 us in two 3x3 launches before)
+                    # 128-channel tile's second half -- dy (g, y) is staged ONCE for both gradients (289 us in two 3x3 launches before);
+                    # skip tiles: as additional channel tiles of the launch (32 skip channels x 4 output parities each)
                     t_up, t_sk = ins
                     a.Cout, a.csplit = conv.in_channels, t_up.C
                     a.wpk = ent["spd"].data_ptr()

@@ -229,7 +229,7 @@ def conv_sp(srcs, wpk, N, H, W, Cout, want_stats=False, terms=None):
     return out, stats
 
 
-def pack_spd(w, cup, batched=False, vskip=False, terms=None):
+def pack_spd(w, cup, batched=False, vskip=False, terms=None, skip_tiles=False):
     """decoder conv1 filter (Cout, Cup + Cskip, 3, 3) -> the parity / tap layout of sc_conv3x3_sp_dgrad (vskip: with the skip
     channels as virtual channels of the tile's second half)"""
     import numpy as np
@@ -238,10 +238,11 @@ def pack_spd(w, cup, batched=False, vskip=False, terms=None):
     co, ci = w.shape[0], w.shape[1]
     from starcop_amd._lib import TERMS_F16X2
     terms = TERMS_F16X2 if terms is None else terms
-    tfl = (2 if vskip else 1) | (4 if terms == 1 else 0)
-    out = torch.full((lib.sc_packed_weight_floats_spd(co, cup) // (2 if terms == 1 else 1),), float("nan"), device=DEV)
+    mode = 2 if skip_tiles else (1 if vskip else 0)          # sc_pack_weights_spd's vskip argument; the batch pack's transpose_flip = mode + 1
+    tfl = (mode + 1) | (4 if terms == 1 else 0)
+    out = torch.full((lib.sc_packed_weight_floats_spd(co, cup, ci - cup if skip_tiles else 0) // (2 if terms == 1 else 1),), float("nan"), device=DEV)
     if not batched:
-        check(lib.sc_pack_weights_spd(ptr(w), ptr(out), co, ci, cup, int(vskip), terms, stream()))
+        check(lib.sc_pack_weights_spd(ptr(w), ptr(out), co, ci, cup, mode, terms, stream()))
         return out
     total = lib.sc_pack_work_items(co, ci, 3, cup, tfl, PACK_SPD)
     dt = np.dtype([("w", "<u8"), ("wpk", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"), ("ks", "<i4"), ("co_t", "<i4"),

@@ -529,6 +529,18 @@ def test_conv_sp_dgrad_matches_upsample_backward(hip, cup, csk, cout, H, W):
         o1 = dev(olds).clone()
         conv_sp_dgrad(src, wv, N, H, W, cup, absmax=amax, accum_into=dev(old).clone(), cskip=csk, skip_into=o1)
         assert relerr(o1, ref_sk + olds.double()) < BX3_TOL
+    # any other channel counts: the skip channels' gradient as additional channel tiles of the launch (32 skip channels x 4 parities)
+    if csk and not (cup <= 64 and csk <= 16):
+        ref_sk = F.conv_transpose2d(dy.double(), w.double(), padding=1)[:, cup:]
+        for batched in (False, True):
+            wt = pack_spd(wd, cup, batched=batched, skip_tiles=True)
+            assert bool(torch.isfinite(wt.view(torch.int16).float()).all())
+            o_up, o_sk = conv_sp_dgrad(src, wt, N, H, W, cup, absmax=amax, cskip=csk)
+            assert relerr(o_up, ref) < BX3_TOL and relerr(o_sk, ref_sk) < BX3_TOL
+        olds = rnd(N, csk, H, W, seed=10)
+        o1 = dev(olds).clone()
+        conv_sp_dgrad(src, wt, N, H, W, cup, absmax=amax, accum_into=dev(old).clone(), cskip=csk, skip_into=o1)
+        assert relerr(o1, ref_sk + olds.double()) < BX3_TOL
 
 
 @pytest.mark.parametrize("cup,csk,cout,H,W,N", [(64, 16, 32, 16, 64, 2), (128, 24, 64, 24, 80, 2), (32, 0, 16, 20, 72, 3), (256, 32, 128, 8, 12, 2),

@@ -238,4 +238,4 @@ def test_sub_pixel_rules():
     # 16-wide tiles: 16 rows, or 8 rows when the launch has at most 128 work-groups (decoder.blocks.0 at batch 16: 16 planes x 8 cout tiles)
     assert lib.sc_sp_stat_rows(16, 32, 32, 256) == 32 and lib.sc_sp_stat_rows(64, 32, 32, 256) == 64 and lib.sc_sp_stat_rows(16, 32, 32, 320) == 16
     assert lib.sc_packed_weight_floats_sp(128, 256, 32) == 4 * (16 + 4 * 2) * 2048 * 4
-    assert lib.sc_packed_weight_floats_spd(128, 256) == 2 * 4 * 8 * 2048 * 4
+    assert lib.sc_packed_weight_floats_spd(128, 256, 0) == 2 * 4 * 8 * 2048 * 4 and lib.sc_packed_weight_floats_spd(128, 256, 33) == 4 * 4 * 8 * 2048 * 4

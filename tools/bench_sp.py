@@ -113,6 +113,13 @@ if not os.environ.get("SP_ONLY") and not os.environ.get("SP_WGRAD_ONLY"):
                 e2 = max(float((ou - ref[0]).abs().max() / ref[0].abs().max()), float((ok_ - osk[0]).abs().max() / osk[0].abs().max()))
                 t_v = timeit(fv)
                 extra += f" | ONE launch for both (virtual skip channels) {t_v:6.1f} us vs {t_ref + t_sk:6.1f} (diff {e2:.1e})"
+            else:                                # ... or as additional channel tiles of it (skip tiles)
+                wt = pack_spd(w, cu, skip_tiles=True)
+                ft = lambda: conv_sp_dgrad(src, wt, N, H, W, cu, absmax=amax, cskip=cs)
+                ou, ok_ = ft(); torch.cuda.synchronize()
+                e2 = max(float((ou - ref[0]).abs().max() / ref[0].abs().max()), float((ok_ - osk[0]).abs().max() / osk[0].abs().max()))
+                t_t = timeit(ft)
+                extra += f" | ONE launch for both (skip tiles) {t_t:6.1f} us vs sub-pixel + skip launch {t_sp + t_sk:6.1f} (diff {e2:.1e})"
         print(f"{name}.dgrad {cout}->{cu} {H}^2: 3x3 + down-sum {t_ref:7.1f} us | sub-pixel {t_sp:7.1f} us x{t_ref/t_sp:4.2f} | diff {err:.1e}{extra}", flush=True)
 
 # ---- weight gradient of the up-sampled channels: box-sum GEMM (sc_conv3x3_sp_wgrad) against sc_conv3x3_wgrad_bx3 with an up-sampled source
