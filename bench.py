@@ -417,7 +417,8 @@ def main():
     if rank == 0:
         net.profile = {}
         overlap, net.overlap_wgrad = net.overlap_wgrad, False     # serial launches: a kernel's events bracket only itself
-        for _ in range(3):
+        prof_steps = 3
+        for _ in range(prof_steps):
             model.fused_train_step(batch, opt, grad_sync=None)     # rank-local: the other ranks are past the timed region
         torch.cuda.synchronize()
         prof = net.collect_profile()
@@ -447,12 +448,19 @@ def main():
                     t = json.load(open(pmc))
                     if "hbm_bytes_per_launch_corrected" not in t:
                         continue
+                    # per logical launch (one per layer and direction, the unit of `alg`): the step's bytes / this run's logical launches
+                    # per step.  (Profiles without the per-step figure -- before r05f -- are per PHYSICAL launch: a data gradient cut
+                    # into an up-sampled and a skip-channel launch counts twice there, which understated the ratio by 19-20 / 17.)
+                    per_logical = (t["hbm_bytes_per_step_corrected"] / (d["n"] / max(prof_steps, 1))) if "hbm_bytes_per_step_corrected" in t else None
+                    if per_logical is not None:
+                        t = dict(t, hbm_bytes_per_launch_corrected=per_logical)
                     if t["hbm_bytes_per_launch_corrected"] < 0.98 * alg:
                         traffic_note = (f"{os.path.basename(pmc)} reports {t['hbm_bytes_per_launch_corrected'] / 1e6:.1f} MB per launch, below the "
                                         f"{alg / 1e6:.1f} MB algorithmic bytes of the launches timed here: refused (stale profile or a counter artefact)")
                         break
                     traffic = round(t["hbm_bytes_per_launch_corrected"])
-                    traffic_note = (f"memory-side bytes per launch of {t['kernel_pattern']}* = {traffic / alg:.2f} x the algorithmic bytes; provenance: "
+                    traffic_note = (f"memory-side bytes per {'logical launch (the step total over this family / launches_per_step)' if per_logical is not None else 'physical launch'} "
+                                    f"of {t['kernel_pattern']}* = {traffic / alg:.2f} x the algorithmic bytes; provenance: "
                                     f"profiles/{os.path.basename(pmc)} ({t.get('source', 'rocprofv3 --pmc')}; {t.get('launches', '?')} launches), FETCH_SIZE "
                                     f"(KiB -> bytes) divided by {t['fetch_calibration']['FETCH_SIZE_reported_over_known']:.3f} = what the counter reports of a KNOWN "
                                     "1 GiB stream in this kernel's 4 B/lane access pattern (profiles/r02_pmc_calibration.json), WRITE_SIZE calibrates to 1.000. "
@@ -482,7 +490,7 @@ def main():
                                          "profiles/") if (fam.startswith("k_conv3_bx3") and nterms == 4) else None,
                     "algorithmic_bytes_per_launch": round(d["bytes"] / d["n"]) if d.get("bytes") else None,
                     "algorithmic_flop_per_launch": round(d["flop"] / d["n"]),
-                    "launches_per_step": d["n"] // 3, "avg_launch_ms": round(d["ms"] / d["n"], 4),
+                    "launches_per_step": d["n"] // prof_steps, "avg_launch_ms": round(d["ms"] / d["n"], 4),
                     "share_of_step_gpu_time": round(d["ms"] / tot_ms, 3),
                     "families_ms_per_step": {k: round(v["ms"] / 3, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}
 

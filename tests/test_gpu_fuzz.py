@@ -160,8 +160,9 @@ def test_fuzz_conv_sp(hip, seed):
     ref_up = F.avg_pool2d(full[:, :c0], 2) * 4
     amax = torch.tensor([float((A[None, :, None, None] * g).abs().max())], device="cuda")
     vs = bool(c1) and bool(_lib.load().sc_spd_vskip_ok(c0, c1))
-    wpk = pack_spd(wd, c0, batched=not (seed & 1), vskip=vs)
-    if vs:
+    st_ = bool(c1) and not vs and bool(seed & 2)          # skip tiles: the skip channels as additional channel tiles of the launch
+    wpk = pack_spd(wd, c0, batched=not (seed & 1), vskip=vs, skip_tiles=st_)
+    if vs or st_:
         d_up, d_sk = conv_sp_dgrad(dys, wpk, N, H, W, c0, absmax=amax, cskip=c1)
         assert relerr(d_sk, full[:, c0:]) < 1e-5
     else:

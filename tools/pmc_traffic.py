@@ -17,8 +17,15 @@ def per_launch(db, counter):
     return rows[0], rows[1] * 1024.0 / rows[0]
 
 
+def steps_in(db):
+    """training steps in the profiled run = dispatches of the loss kernel (one per step)"""
+    c = sqlite3.connect(db)
+    return c.execute("select count(distinct dispatch_id) from counters_collection where kernel_name like '%k_bce%'").fetchone()[0]
+
+
 nf, fb = per_launch(fetch_db, "FETCH_SIZE")
 nw, wb = per_launch(write_db, "WRITE_SIZE")
+nsteps = steps_in(fetch_db)
 res = {"kernel_pattern": pat, "launches": nf, "fetch_bytes_per_launch_raw": fb, "fetch_bytes_per_launch_x2": 2 * fb,
        "write_bytes_per_launch": wb, "hbm_bytes_per_launch_raw": fb + wb,
        "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `bench.py --steps 3 --warmup 1 --graph 0`"}
@@ -30,5 +37,12 @@ if os.path.exists(cal_path):
     f = [v["fetch_reported_over_known"] for v in cal.values() if isinstance(v, dict) and "fetch_reported_over_known" in v][0]
     res["fetch_calibration"] = {"FETCH_SIZE_reported_over_known": f, "file": "profiles/r02_pmc_calibration.json"}
     res["hbm_bytes_per_launch_corrected"] = fb / f + wb
+    # A layer's data gradient may be several physical launches (up-sampled / skip channels): per STEP the figure is independent of how the
+    # work is cut into launches -- bench.py divides it by its LOGICAL launches per step (one per layer and direction), the unit of its
+    # algorithmic bytes.
+    if nsteps:
+        res["steps"] = nsteps
+        res["launches_per_step"] = nf / nsteps
+        res["hbm_bytes_per_step_corrected"] = (fb / f + wb) * nf / nsteps
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
