@@ -189,6 +189,9 @@ _BNR = os.environ.get("STARCOP_BNR", "0") == "1"
 _PACK_SIDE = os.environ.get("STARCOP_PACK_SIDE", "1") == "1"
 _SP_SKIPTILES = os.environ.get("STARCOP_SP_SKIPTILES", "1") == "1"      # (same-box A/B of decoder.blocks.0's one-launch data gradient)
 _EXP_NO_WGRAD = os.environ.get("STARCOP_EXP_NO_WGRAD", "0") == "1"
+# elimination experiment (results WRONG after the first steps, timing valid): skip the BatchNorm finalize launches of the training forward
+# ("f"), of the backward ("b") or both ("fb") from the fourth step of a plan on -- what the ~93 dependent ~5 us launches cost the step
+_EXP_NO_BNFIN = os.environ.get("STARCOP_EXP_NO_BNFIN", "")
 _EXP_SIDE2 = os.environ.get("STARCOP_EXP_SIDE2", "0") == "1"      # tools/: elimination experiment only
 
 
@@ -993,7 +996,7 @@ class HyperStarcopUNet(nn.Module):
                 check(lib.sc_head_conv_fwd(C.byref(s), ptr(conv.weight), ptr(conv.bias), ptr(plan.buf[o.name]),
                                            N, conv.in_channels, Ho, Wo, st))
             self._pe(tok)
-            if o.bn is not None and training:
+            if o.bn is not None and training and not ("f" in _EXP_NO_BNFIN and plan.generation > 3):
                 bn = o.bn
                 check(lib.sc_bn_finalize(stats, srows, float(N * Ho * Wo), ptr(bn.weight), ptr(bn.bias),
                                          ptr(bn.running_mean), ptr(bn.running_var), float(bn.momentum), float(bn.eps),
@@ -1206,6 +1209,8 @@ class HyperStarcopUNet(nn.Module):
                                                     ptr(plan.bn_scratch) if _BN_PRE else None, st))
                 return
             if t.name in reduced:          # the launch that wrote this gradient left the sums (and raised the range-hint slot)
+                if "b" in _EXP_NO_BNFIN and plan.generation > 3:
+                    return
                 check(lib.sc_bn_bwd_finalize(ptr(plan.dwsums[t.name]), plan.dwrows[t.name], float(N * Ho * Wo), ptr(plan.cst[t.name]),
                                              ptr(gv(t.bn.weight)), ptr(gv(t.bn.bias)), ptr(plan.cstb[t.name]), t.C, st))
                 return
@@ -1217,6 +1222,8 @@ class HyperStarcopUNet(nn.Module):
                 return
             check(lib.sc_bn_bwd_reduce(ptr(plan.grad[t.name]), ptr(plan.buf[t.name]), ptr(plan.cst[t.name]), t.act,
                                        ptr(plan.bsums_v[t.name]), N, t.C, Ho * Wo, amax, aact, st))
+            if "b" in _EXP_NO_BNFIN and plan.generation > 3:
+                return
             check(lib.sc_bn_bwd_finalize(ptr(plan.bsums_v[t.name]), plan.brows[t.name], float(N * Ho * Wo), ptr(plan.cst[t.name]),
                                          ptr(gv(t.bn.weight)), ptr(gv(t.bn.bias)), ptr(plan.cstb[t.name]), t.C, st))
 
