@@ -1665,7 +1665,11 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
   const float hsg = HF ? h_grad_scale(p.absmax) : 1.f;          // fp16 mode: scale of the gradient operand
   const float hsa = HF ? h_act_scale(p.xb0, p.xb1) : 1.f;        // ... and of the activation operand
   const float hinv = HF ? 1.f / (hsg * hsa) : 1.f;
-  constexpr int COT = 32 * WM, CIT = 32 * NCI, NPAIR = NCI * WM, KP = 4 / NPAIR;     // KP K parts: rows and, at KP = 4, 16-pixel steps
+  // KP K parts: rows and, at KP = 4, 16-pixel steps.  NCI = 3 (WM = 1: a 96-wide cin tile for 65..96 input channels -- decoder.blocks.3.conv1's
+  // 64 up-sampled + 16 skip channels in ONE pass over dy instead of two): 3 pairs x 3 filter rows = 9 computing waves, each both rows and
+  // both 16-pixel steps of a stage (KP = 1); the other three waves only stage
+  constexpr int COT = 32 * WM, CIT = 32 * NCI, NPAIR = NCI * WM, KP = NPAIR == 3 ? 1 : 4 / NPAIR;
+  static_assert(NPAIR == 1 || NPAIR == 2 || NPAIR == 3 || NPAIR == 4, "wave roles");
   constexpr int DYP = 72;              // dy pitch per cout in pixels (144 B: conflict-free 16-byte reads)
   constexpr int XRP = 40;              // input row pitch in pixels (34 used)
   constexpr int RING = PIPE ? 8 : 4;
@@ -1682,6 +1686,7 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int pair = wave % NPAIR, kh = (wave / NPAIR) % 3, kp = wave / (3 * NPAIR);
+  const bool computing = wave < 3 * NPAIR * KP;            // (all twelve waves except for NPAIR = 3)
   const int wm = pair % WM, wn = pair / WM;
   const int cit = blockIdx.y, cot = blockIdx.z;
   const int H = p.H, W = p.W;
@@ -1756,7 +1761,7 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
     for (int k = 0; k < NXI; ++k) {
       int it = tid + NTH * k;
       if (it >= 2 * 17 * CIT) it -= 2 * 17 * CIT;
-      const int cil = ((it / 17) >> 1) & (CIT - 1);
+      const int cil = ((it / 17) >> 1) % CIT;
       const int chr = cit * CIT + cil;
       const int ch = chr < p.Cin ? chr : 0;
       const bool second = ch >= C0;
@@ -1840,7 +1845,7 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
       int it = tid + NTH * k;
       if (PIPE && it >= 2 * 17 * CIT) it -= 2 * 17 * CIT;
       const int rc = it / 17, pr = it - rc * 17;
-      const int rowi = rc & 1, cil = (rc >> 1) & (CIT - 1);
+      const int rowi = rc & 1, cil = (rc >> 1) % CIT;
       if constexpr (PIPE) {
         const bool sec = (xsec >> k) & 1u;
         const int up = sec ? p.s1.up : p.s0.up;
@@ -1876,7 +1881,7 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
       int it = tid + NTH * k;
       if (PIPE && it >= 2 * 17 * CIT) it -= 2 * 17 * CIT;
       const int rc = it / 17, pr = it - rc * 17;
-      const int rowi = rc & 1, cil = (rc >> 1) & (CIT - 1);
+      const int rowi = rc & 1, cil = (rc >> 1) % CIT;
       const int y = R + rowi, x = x0 - 1 + 2 * pr;
       const bool okc = (cit * CIT + cil < p.Cin) && (y >= 0) && (y < H);
       const float4 c = *reinterpret_cast<const float4*>(&s_cb[cil * 4]);
@@ -1901,6 +1906,7 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
   };
 
   auto compute = [&](int sl0, int buf) {          // sl0: ring slot of image row y0 - 1
+    if (NPAIR == 3 && !computing) return;
 #pragma unroll
     for (int rr = 0; rr < (KP == 1 ? 2 : 1); ++rr) {
       const int r = (KP == 1) ? rr : (kp & 1);
@@ -2056,6 +2062,7 @@ __global__ __launch_bounds__(768, 1) void k_wgrad3_bx3(const WgradXP p) {
     }
     if (kp != 0) return;
   }
+  if (NPAIR == 3 && !computing) return;
   // ---- partial store: part[((slice*KPP + kp)*9 + tap)*CoP*CiP + co*CiP + ci] ----
   const int ci = cit * CIT + wn * 32 + l31;
   const size_t plane = (size_t)p.CoP * p.CiP;
@@ -2344,13 +2351,18 @@ __global__ __launch_bounds__(256, CIN == 32 ? 2 : 3) void k_wgrad_thin_h(const W
 }
 
 struct WgradXPlan { int wm, nci, kp, nsl, CoP, CiP, co_tiles, ci_tiles; };
-WgradXPlan plan_wgrad_bx3(int N, int H, int W, int Cout, int Cin) {
+WgradXPlan plan_wgrad_bx3(int N, int H, int W, int Cout, int Cin, bool allow96 = false) {
   WgradXPlan pl;
   pl.wm = Cout > 32 ? 2 : 1;
   // 32-wide cin tiles only for Cin <= 32: for 80 or 152 input channels the emptier 64-wide tiles still win (measured
   // 0.59 vs 0.66 ms and 0.38 vs 0.39 ms): twice the MFMA work per staged dy tile outweighs the padding
   pl.nci = Cin <= 32 ? 1 : 2;
-  pl.kp = 4 / (pl.nci * pl.wm);
+  // <= 32 output and 65..96 input channels (two-fp16-term kernels): ONE 96-wide tile instead of a full and a mostly empty 64-wide one,
+  // each of which stages dy
+  if (allow96 && pl.wm == 1 && Cin > 64 && Cin <= 96) pl.nci = 3;
+  // (measured, not kept: 33..64 output x 129..192 input channels as 32 x 96 tiles -- two passes over dy instead of three, but the input
+  // rows staged twice: decoder.blocks.2.conv1 214 -> 282 us)
+  pl.kp = pl.nci * pl.wm == 3 ? 1 : 4 / (pl.nci * pl.wm);
   pl.CoP = (Cout + 31) / 32 * 32;
   pl.CiP = (Cin + 31) / 32 * 32;
   pl.co_tiles = (Cout + 32 * pl.wm - 1) / (32 * pl.wm);
@@ -2563,11 +2575,15 @@ static bool wgrad3_pipe_reduces(const WgradXPlan& pl) {
   return pl.kp == 1 || 3 * npair * 3072 <= 2 * cit * xcp / 2;
 }
 
-extern "C" size_t sc_wgrad_bx3_workspace_floats(int N, int H, int W, int Cout, int Cin) {
-  const WgradXPlan pl = plan_wgrad_bx3(N, H, W, Cout, Cin);
+static size_t wgrad_bx3_workspace_of(const WgradXPlan& pl) {
   const size_t E = (size_t)9 * pl.CoP * pl.CiP;
   const int nparts = pl.nsl * pl.kp;
   return (size_t)nparts * E + sc_reduce_scratch_floats(nparts, E);
+}
+extern "C" size_t sc_wgrad_bx3_workspace_floats(int N, int H, int W, int Cout, int Cin) {      // (either tiling: `terms` picks it at launch)
+  const size_t a = wgrad_bx3_workspace_of(plan_wgrad_bx3(N, H, W, Cout, Cin, false));
+  const size_t b = wgrad_bx3_workspace_of(plan_wgrad_bx3(N, H, W, Cout, Cin, true));
+  return a > b ? a : b;
 }
 
 extern "C" int sc_conv3x3_wgrad_bx3(const sc_wgrad_args* a, sc_stream stream) {
@@ -2584,7 +2600,13 @@ extern "C" int sc_conv3x3_wgrad_bx3(const sc_wgrad_args* a, sc_stream stream) {
     SC_REQUIRE(a->src[s].mode == SC_SRC_RAW || a->src[s].mode == SC_SRC_AFFINE, "sc_conv3x3_wgrad_bx3: input sources must be RAW or AFFINE");
     SC_REQUIRE(a->src[s].up == 0 || (a->src[s].up == 1 && a->H % 2 == 0 && a->W % 2 == 0), "sc_conv3x3_wgrad_bx3: upsampled source needs even H,W");
   }
-  const WgradXPlan pl = plan_wgrad_bx3(a->N, a->H, a->W, a->Cout, a->Cin);
+  static const bool no96 = [] { const char* e = getenv("STARCOP_WGRAD96"); return e && atoi(e) == 0; }();      // (same-box A/B)
+  constexpr int pipe_env = 1;      // one-barrier refill pipeline (0 = the two-barrier stages it replaced: 1.89 vs 1.63 ms per step)
+  // the pipelined variant: BatchNorm-backward gradients, 8-byte gradient loads (even W), 32-bit byte offsets within a tensor
+  bool pipe = pipe_env && a->terms == SC_TERMS_F16X2 && a->dy.mode == SC_SRC_BNBWD && a->W % 2 == 0 && (((uintptr_t)a->dy.x | (uintptr_t)a->dy.aux) & 7) == 0 &&
+              (size_t)a->Cout * a->H * a->W * 4 < (1ull << 32);
+  for (int s = 0; s < a->nsrc; ++s) pipe = pipe && (size_t)a->N * a->src[s].C * (a->H >> a->src[s].up) * (a->W >> a->src[s].up) * 4 < (1ull << 32);
+  const WgradXPlan pl = plan_wgrad_bx3(a->N, a->H, a->W, a->Cout, a->Cin, pipe && !no96);      // (the 96-wide tile: pipelined kernel only)
   const size_t need = sc_wgrad_bx3_workspace_floats(a->N, a->H, a->W, a->Cout, a->Cin);
   SC_REQUIRE(a->part_floats >= need, "sc_conv3x3_wgrad_bx3: workspace too small (%zu < %zu floats)", a->part_floats, need);
   WgradXP p;
@@ -2596,10 +2618,10 @@ extern "C" int sc_conv3x3_wgrad_bx3(const sc_wgrad_args* a, sc_stream stream) {
   SC_REQUIRE(a->terms >= 0 && a->terms <= 4, "sc_conv3x3_wgrad_bx3: terms must be 0 (= 3), 1, 2, 3 or SC_TERMS_F16X2 (got %d)", a->terms);
   p.absmax = a->absmax; p.xb0 = a->xbound[0]; p.xb1 = a->xbound[1];
   int nparts = pl.nsl * pl.kp;          // (the pipelined variant sums its K parts in the kernel: pl.nsl)
-  constexpr int pipe_env = 1;      // one-barrier refill pipeline (0 = the two-barrier stages it replaced: 1.89 vs 1.63 ms per step)
 #define SC_WGX(WM_, NT_, NCI_, HF_, PIPE_) hipLaunchKernelGGL((k_wgrad3_bx3<WM_, NT_, NCI_, HF_, PIPE_>), grid, dim3(768), 0, st, p)
 #define SC_WGX_NT(NT_, HF_, PIPE_)                                   \
   do {                                                               \
+    if constexpr (HF_ && PIPE_) { if (pl.nci == 3) { SC_WGX(1, NT_, 3, HF_, PIPE_); break; } }      \
     if (pl.wm == 2 && pl.nci == 2) SC_WGX(2, NT_, 2, HF_, PIPE_);    \
     else if (pl.wm == 2) SC_WGX(2, NT_, 1, HF_, PIPE_);              \
     else if (pl.nci == 2) SC_WGX(1, NT_, 2, HF_, PIPE_);             \
@@ -2607,10 +2629,6 @@ extern "C" int sc_conv3x3_wgrad_bx3(const sc_wgrad_args* a, sc_stream stream) {
   } while (0)
   if (a->terms == 1) SC_WGX_NT(1, false, false); else if (a->terms == 2) SC_WGX_NT(2, false, false);
   else if (a->terms == SC_TERMS_F16X2) {
-    // the pipelined variant: BatchNorm-backward gradients, 8-byte gradient loads (even W), 32-bit byte offsets within a tensor
-    bool pipe = pipe_env && a->dy.mode == SC_SRC_BNBWD && a->W % 2 == 0 && (((uintptr_t)a->dy.x | (uintptr_t)a->dy.aux) & 7) == 0 &&
-                (size_t)a->Cout * a->H * a->W * 4 < (1ull << 32);
-    for (int s = 0; s < a->nsrc; ++s) pipe = pipe && (size_t)a->N * a->src[s].C * (a->H >> a->src[s].up) * (a->W >> a->src[s].up) * 4 < (1ull << 32);
     if (pipe) { SC_WGX_NT(2, true, true); if (wgrad3_pipe_reduces(pl)) nparts = pl.nsl; } else SC_WGX_NT(2, true, false);
   }
   else SC_WGX_NT(3, false, false);

@@ -579,7 +579,8 @@ def test_conv_sp_wgrad_matches_upsample_conv_autograd(hip, cup, csk, cout, H, W,
 
 
 @pytest.mark.parametrize("cin,cout,H,W,two", [(16, 64, 32, 32, False), (32, 16, 36, 70, True), (32, 32, 24, 40, False), (48, 40, 21, 32, False), (32, 64, 16, 32, True),
-                                               (80, 32, 20, 36, True), (152, 64, 8, 64, True), (256, 256, 4, 6, False), (72, 136, 10, 33, False)])
+                                               (80, 32, 20, 36, True), (152, 64, 8, 64, True), (256, 256, 4, 6, False), (72, 136, 10, 33, False),
+                                               (96, 32, 16, 32, False), (66, 20, 10, 38, True), (90, 32, 6, 64, False)])      # (65..96 -> <= 32: the 96-wide tile)
 def test_conv_bx3_wgrad(hip, split_mode, cin, cout, H, W, two):
     """3x3 weight gradient with split-bf16 operands: vs fp64, and no worse than the fp32 MFMA kernel."""
     N = 3
