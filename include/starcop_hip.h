@@ -326,6 +326,23 @@ int sc_conv3x3_wgrad_bx3(const sc_wgrad_args* a, sc_stream stream);
 int sc_dwconv3x3_fwd(const sc_src* in, const float* w /*[C][3][3]*/, float* out,
                      int N, int C, int Hin, int Win, int stride, float* stats /* rows: SC_STAT_DW on (Hout,Wout) */,
                      sc_stream stream);
+/* Producer-tail BatchNorm finalize: the launch that writes a tensor's statistics rows also finalizes that tensor's BatchNorm (what
+ * sc_bn_finalize(stats, rows, count, ..) does in a launch of its own, ~5 us of idle chip behind every producer of the training
+ * forward).  The work-group that arrives LAST for a channel -- a ticket per channel: `tickets[C]`, zero-initialised ONCE, counts
+ * monotonically over launches -- sums that channel's rows in a fixed order (fp64) and writes constants, running statistics and the
+ * activation bound: bit-reproducible whichever work-group does it. */
+typedef struct sc_bn_tail {
+  const float* gamma; const float* beta;      /* BatchNorm weight / bias [C]                              */
+  float* running_mean; float* running_var;    /* updated with `momentum` (training semantics)              */
+  float momentum, eps;
+  float* cst;                                 /* [C][SC_CST] forward constants {scale, shift, mean, invstd} */
+  float* act_bound;                           /* as in sc_bn_finalize, or NULL                             */
+  uint32_t* tickets;                          /* [C]                                                       */
+} sc_bn_tail;
+/* sc_dwconv3x3_fwd + the BatchNorm of its output finalized by the launch itself (the depthwise layers of a batch leave 16-32 rows
+ * per channel: the last (image, tile) of a channel reads 128-256 bytes) */
+int sc_dwconv3x3_fwd_bn(const sc_src* in, const float* w, float* out, int N, int C, int Hin, int Win, int stride, float* stats,
+                        const sc_bn_tail* bn, sc_stream stream);
 int sc_dwconv3x3_dgrad(const sc_src* dy, const float* w, float* dx, int accum,
                        int N, int C, int Hin, int Win, int stride, sc_stream stream);
 int sc_dwconv3x3_wgrad(const sc_src* dy, const sc_src* in, double* dw_acc /*[C][9] zeroed*/,

@@ -40,6 +40,12 @@ class sc_conv_args(C.Structure):
                 ("absmax", C.c_void_p), ("xbound", C.c_void_p * 2), ("bnr", C.c_void_p)]
 
 
+class sc_bn_tail(C.Structure):
+    """producer-tail BatchNorm finalize (include/starcop_hip.h: sc_bn_tail)"""
+    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("momentum", C.c_float), ("eps", C.c_float), ("cst", C.c_void_p), ("act_bound", C.c_void_p), ("tickets", C.c_void_p)]
+
+
 class sc_bnr_args(C.Structure):
     """BatchNorm-backward sums left by a data-gradient launch (include/starcop_hip.h: sc_bnr_args)"""
     _fields_ = [("y", C.c_void_p), ("cst", C.c_void_p), ("act", C.c_int32), ("rows", C.c_void_p), ("absmax", C.c_void_p)]
@@ -98,6 +104,7 @@ SIGNATURES = {
     "sc_wgrad_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "sc_conv2d_wgrad_mfma": (_i, [C.POINTER(sc_wgrad_args), _vp]),
     "sc_dwconv3x3_fwd": (_i, [C.POINTER(sc_src), _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sc_dwconv3x3_fwd_bn": (_i, [C.POINTER(sc_src), _vp, _vp, _i, _i, _i, _i, _i, _vp, C.POINTER(sc_bn_tail), _vp]),
     "sc_dwconv3x3_dgrad": (_i, [C.POINTER(sc_src), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sc_dwconv3x3_wgrad": (_i, [C.POINTER(sc_src), C.POINTER(sc_src), _vp, _i, _i, _i, _i, _i, _vp]),
     "sc_cast_f64_f32": (_i, [_vp, _vp, _sz, _vp]),

@@ -106,7 +106,7 @@ __device__ __forceinline__ void dw_stage2(float* s, const float* __restrict__ gb
 // V4: float4 staging of the TW * S aligned interior columns (see k_dw_bwd), interior at LDS column 4
 template <int S, int TW, int R, bool V4>
 __global__ __launch_bounds__(256) void k_dw_fwd(const SrcD in, const float* __restrict__ w, float* __restrict__ out,
-                                                int NC, int C, int Hin, int Win, int Hout, int Wout, float* stats) {
+                                                int NC, int C, int Hin, int Win, int Hout, int Wout, float* stats, const BnTailD tail) {
   constexpr int TB = 256 / TW, TH = TB * R;
   constexpr int CO = V4 ? 3 : 0, IC = TW * S;
   constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PWP = V4 ? IC + 8 : (PW | 1);
@@ -246,7 +246,14 @@ __global__ __launch_bounds__(256) void k_dw_fwd(const SrcD in, const float* __re
   }
   if (stats) {
     block_sum<2>(sv, s_tmp);
-    if (threadIdx.x < 2) stats[(((size_t)n * tiles + tile) * C + c) * 2 + threadIdx.x] = sv[threadIdx.x];
+    if (tail.tickets == nullptr) {
+      if (threadIdx.x < 2) stats[(((size_t)n * tiles + tile) * C + c) * 2 + threadIdx.x] = sv[threadIdx.x];
+    } else {          // producer-tail finalize (sc_common.h): the channel's last (n, tile) arrival writes its BatchNorm constants
+      __shared__ int s_last;
+      if (threadIdx.x == 0) s_last = bn_tail_arrive(tail, stats + (((size_t)n * tiles + tile) * C + c) * 2, sv[0], sv[1], c) ? 1 : 0;
+      __syncthreads();
+      if (s_last && threadIdx.x < 64) bn_tail_channel(tail, stats, C, c, threadIdx.x);
+    }
   }
 }
 
@@ -851,7 +858,7 @@ __global__ __launch_bounds__(256) void k_dw_bwd_plane(const SrcD dy, const SrcD 
 // forward for whole 16x16 / 32x32 planes at stride 1, a wave per plane (see k_dw_bwd_plane)
 template <int PS>
 __global__ __launch_bounds__(256) void k_dw_fwd_plane(const SrcD in, const float* __restrict__ w, float* __restrict__ out, int C,
-                                                      float* __restrict__ stats) {
+                                                      float* __restrict__ stats, const BnTailD tail) {
   constexpr int P = PS + 8, PR = PS + 2;
   constexpr int LPR = (PS == 16) ? 4 : 2, G = PS / (4 * LPR), HW = PS * PS;
   __shared__ __attribute__((aligned(16))) float s_x[4][PR * P];
@@ -904,7 +911,14 @@ __global__ __launch_bounds__(256) void k_dw_fwd_plane(const SrcD in, const float
   }
   if (stats) {
     sv = wave_sum(sv); sq = wave_sum(sq);
-    if (lane == 0) { stats[((size_t)n * C + c) * 2] = sv; stats[((size_t)n * C + c) * 2 + 1] = sq; }
+    if (tail.tickets == nullptr) {
+      if (lane == 0) { stats[((size_t)n * C + c) * 2] = sv; stats[((size_t)n * C + c) * 2 + 1] = sq; }
+    } else {                                // producer-tail finalize: one row per image, the channel's last image arrives here
+      int last = 0;
+      if (lane == 0) last = bn_tail_arrive(tail, stats + ((size_t)n * C + c) * 2, sv, sq, c) ? 1 : 0;
+      last = __builtin_amdgcn_readfirstlane(last);
+      if (last) bn_tail_channel(tail, stats, C, c, lane);
+    }
   }
 }
 
@@ -1518,8 +1532,20 @@ static inline long dw_tiles(int H, int W) {
   return (long)((W + tw - 1) / tw) * ((H + th - 1) / th);
 }
 
+static int dwconv3x3_fwd(const sc_src* in, const float* w, float* out, int N, int C, int Hin, int Win, int stride, float* stats,
+                         const sc_bn_tail* bt, sc_stream stream);
 extern "C" int sc_dwconv3x3_fwd(const sc_src* in, const float* w, float* out, int N, int C, int Hin, int Win,
                                 int stride, float* stats, sc_stream stream) {
+  return dwconv3x3_fwd(in, w, out, N, C, Hin, Win, stride, stats, nullptr, stream);
+}
+extern "C" int sc_dwconv3x3_fwd_bn(const sc_src* in, const float* w, float* out, int N, int C, int Hin, int Win,
+                                   int stride, float* stats, const sc_bn_tail* bn, sc_stream stream) {
+  SC_REQUIRE(bn && stats && bn->gamma && bn->beta && bn->running_mean && bn->running_var && bn->cst && bn->tickets,
+             "sc_dwconv3x3_fwd_bn: statistics rows, BatchNorm parameters, constants and tickets are required");
+  return dwconv3x3_fwd(in, w, out, N, C, Hin, Win, stride, stats, bn, stream);
+}
+static int dwconv3x3_fwd(const sc_src* in, const float* w, float* out, int N, int C, int Hin, int Win, int stride, float* stats,
+                         const sc_bn_tail* bt, sc_stream stream) {
   SC_REQUIRE(in && in->C == C, "sc_dwconv3x3_fwd: source channels != C");
   SC_REQUIRE(stride == 1 || stride == 2, "sc_dwconv3x3_fwd: stride must be 1 or 2");
   SC_REQUIRE((in->mode == SC_SRC_RAW || in->mode == SC_SRC_AFFINE) && in->up == 0, "sc_dwconv3x3_fwd: unsupported source mode");
@@ -1528,22 +1554,30 @@ extern "C" int sc_dwconv3x3_fwd(const sc_src* in, const float* w, float* out, in
   const long planes8 = ((long)N * C + 7) / 8 * 8;
   SC_REQUIRE(planes8 * dw_tiles(Hout, Wout) < (1L << 31), "sc_dwconv3x3_fwd: grid too large");
   dim3 grid((unsigned)(planes8 * dw_tiles(Hout, Wout)));
+  BnTailD tail{};
+  if (bt) {
+    tail.gamma = bt->gamma; tail.beta = bt->beta; tail.running_mean = bt->running_mean; tail.running_var = bt->running_var;
+    tail.momentum = bt->momentum; tail.eps = bt->eps; tail.cst = bt->cst; tail.act_bound = bt->act_bound;
+    tail.tickets = reinterpret_cast<unsigned*>(bt->tickets);
+    tail.arrivals = (int)(N * dw_tiles(Hout, Wout));          // statistics rows per channel (sc_stat_rows(SC_STAT_DW, ..))
+    tail.count = (double)N * Hout * Wout;
+  }
   constexpr bool p16_env = true;
   // (32 x 32 planes through the same kernel measured SLOWER than the work-group-per-plane form -- backward 50 -> 63 us, forward
   // 22 -> 27 us on features.12: 16 pixels per lane, 43 KB of LDS per work-group -- so it is opt-in: STARCOP_DW_P32=1)
   static const bool p32_env = [] { const char* e = getenv("STARCOP_DW_P32"); return e && atoi(e) != 0; }();
   const bool plane_ok = stride == 1 && Hin == Win && ((long)N * C) % 4 == 0 && (((uintptr_t)in->x | (uintptr_t)out) & 15) == 0;
   if (plane_ok && ((p16_env && Hin == 16) || (p16_env && p32_env && Hin == 32))) {      // a wave per plane
-    if (Hin == 16) hipLaunchKernelGGL(k_dw_fwd_plane<16>, dim3((unsigned)((long)N * C / 4)), dim3(256), 0, st, to_srcd(*in), w, out, C, stats);
-    else hipLaunchKernelGGL(k_dw_fwd_plane<32>, dim3((unsigned)((long)N * C / 4)), dim3(256), 0, st, to_srcd(*in), w, out, C, stats);
+    if (Hin == 16) hipLaunchKernelGGL(k_dw_fwd_plane<16>, dim3((unsigned)((long)N * C / 4)), dim3(256), 0, st, to_srcd(*in), w, out, C, stats, tail);
+    else hipLaunchKernelGGL(k_dw_fwd_plane<32>, dim3((unsigned)((long)N * C / 4)), dim3(256), 0, st, to_srcd(*in), w, out, C, stats, tail);
     SC_LAUNCH_OK("sc_dwconv3x3_fwd");
     return SC_OK;
   }
   constexpr bool v4_env = true;
   if (v4_env && Win % 4 == 0 && (((uintptr_t)in->x) & 15) == 0)
-    SC_DW_DISPATCH4(k_dw_fwd, true, Wout, grid, to_srcd(*in), w, out, N * C, C, Hin, Win, Hout, Wout, stats);
+    SC_DW_DISPATCH4(k_dw_fwd, true, Wout, grid, to_srcd(*in), w, out, N * C, C, Hin, Win, Hout, Wout, stats, tail);
   else
-    SC_DW_DISPATCH4(k_dw_fwd, false, Wout, grid, to_srcd(*in), w, out, N * C, C, Hin, Win, Hout, Wout, stats);
+    SC_DW_DISPATCH4(k_dw_fwd, false, Wout, grid, to_srcd(*in), w, out, N * C, C, Hin, Win, Hout, Wout, stats, tail);
   SC_LAUNCH_OK("sc_dwconv3x3_fwd");
   return SC_OK;
 }

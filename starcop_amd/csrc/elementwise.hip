@@ -127,24 +127,7 @@ __global__ __launch_bounds__(64 * NW) void k_bn_finalize(const TS* __restrict__ 
     var = (double)running_var[c];
   }
   if (threadIdx.x != 0) return;
-  if (training) {
-    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
-    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
-  }
-  const float meanf = (float)mean;
-  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float scale = gamma[c] * invstd;
-  const float shift = beta[c] - meanf * scale;
-  float* o = cst + (size_t)c * SC_CST;
-  o[0] = scale; o[1] = shift; o[2] = meanf; o[3] = invstd; o[4] = 0.f; o[5] = 0.f; o[6] = 0.f; o[7] = 0.f;
-  if (act_bound && training) {
-    // |BN(y)| = |gamma x_hat + beta| <= |gamma| sqrt(count - 1) + |beta| for batch statistics (Samuelson): the tensor's bound is the
-    // maximum over its channels; unsigned atomicMax on the bit pattern of a non-negative float is order-independent (reproducible),
-    // and a channel that cannot raise the slot skips the atomic (after the first step almost all do)
-    const float b = fabsf(gamma[c]) * (float)sqrt(count > 1.0 ? count - 1.0 : 1.0) * 1.0000002f + fabsf(beta[c]);
-    if (b < 3.0e38f && b > *(volatile float*)act_bound) atomicMax(reinterpret_cast<unsigned*>(act_bound), __float_as_uint(b));
-  }
+  bn_write_channel(mean, var, count, training, gamma, beta, running_mean, running_var, momentum, eps, cst, c, act_bound);
 }
 
 // max over the block of m (>= 0), then *slot = max(*slot, m * factor): the order-independent (hence reproducible) unsigned

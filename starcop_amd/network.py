@@ -26,7 +26,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, sc_irt_args, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD, sc_wgrad_pending,
-                   PACK_PW3, PACK_SP, PACK_SPD, PACK_THIN16, STAT_PW3, STAT_CONV1, STAT_CONV1K, STAT_CONV3, STAT_DW, STAT_STEM, TERMS_F16X2, check, make_src, ptr, sc_bnr_args,
+                   PACK_PW3, PACK_SP, PACK_SPD, PACK_THIN16, STAT_PW3, STAT_CONV1, STAT_CONV1K, STAT_CONV3, STAT_DW, STAT_STEM, TERMS_F16X2, check, make_src, ptr, sc_bn_tail, sc_bnr_args,
                    sc_conv_args, sc_wgrad_args, stream)
 
 MBV2_SETTINGS = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2),
@@ -187,6 +187,13 @@ _BNR = os.environ.get("STARCOP_BNR", "0") == "1"
 # training steps pack the decoder's / the backward filter layouts on the weight-gradient stream, beside the encoder's forward ("0": on
 # the main stream, ahead of the forward -- A/B)
 _PACK_SIDE = os.environ.get("STARCOP_PACK_SIDE", "1") == "1"
+# depthwise layers finalize their own BatchNorm in the launch's tail (sc_dwconv3x3_fwd_bn: last arrival per channel by ticket) when a
+# channel has at most this many statistics rows (15 of the 17 depthwise layers at batch 16 have 16-32).  Built, parity-tested and
+# measured in round 5: with a device-scope fence before the ticket the step went 1460 -> 1060 tiles/s (every arriving work-group
+# writes back its XCD's L2); with write-through stores + a relaxed ticket it is correct and LEVEL (1470.0 / 1469.2 vs 1473.7 / 1472.4
+# same-box): every work-group now waits ~2-3 us for its ticket to come back from memory, which is what the 15 removed ~6 us launches
+# had cost.  0 = off (default): the separate sc_bn_finalize launch.
+_DW_TAIL_ROWS = int(os.environ.get("STARCOP_DW_TAIL_ROWS", "0"))
 _SP_SKIPTILES = os.environ.get("STARCOP_SP_SKIPTILES", "1") == "1"      # (same-box A/B of decoder.blocks.0's one-launch data gradient)
 _EXP_NO_WGRAD = os.environ.get("STARCOP_EXP_NO_WGRAD", "0") == "1"
 # elimination experiment (results WRONG after the first steps, timing valid): skip the BatchNorm finalize launches of the training forward
@@ -917,6 +924,7 @@ class HyperStarcopUNet(nn.Module):
                 continue
             stats = ptr(plan.stats_v[o.name]) if (training and o.bn is not None) else None
             srows = plan.srows.get(o.name, 0)
+            bn_done = False        # the producer finalized its BatchNorm itself
             conv = op.get("conv")
             tok = None
             self._cur_op = o.name + ":fwd"
@@ -942,8 +950,28 @@ class HyperStarcopUNet(nn.Module):
             elif ty == "dw":
                 tin = op["ins"][0]
                 s = self._src_of(plan, tin)
-                check(lib.sc_dwconv3x3_fwd(C.byref(s), ptr(conv.weight), ptr(plan.buf[o.name]), N, o.C,
-                                           H >> tin.shift, W >> tin.shift, op["stride"], stats, st))
+                if (training and o.bn is not None and stats is not None and 0 < srows <= _DW_TAIL_ROWS
+                        and not torch.cuda.is_current_stream_capturing()):
+                    # few statistics rows per channel: the launch finalizes the BatchNorm itself (last arrival per channel by ticket)
+                    # -- no dependent ~5 us sc_bn_finalize launch behind it
+                    if not hasattr(plan, "bn_tickets"):
+                        plan.bn_tickets = {}
+                    if o.name not in plan.bn_tickets:
+                        plan.bn_tickets[o.name] = torch.zeros(o.C, dtype=torch.int32, device=self._pflat.device)
+                    bn = o.bn
+                    bt = sc_bn_tail()
+                    bt.gamma, bt.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+                    bt.running_mean, bt.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                    bt.momentum, bt.eps = float(bn.momentum), float(bn.eps)
+                    bt.cst, bt.tickets = plan.cst[o.name].data_ptr(), plan.bn_tickets[o.name].data_ptr()
+                    xb_ = self._xbound(plan, o)
+                    bt.act_bound = xb_.value if xb_ is not None else None
+                    check(lib.sc_dwconv3x3_fwd_bn(C.byref(s), ptr(conv.weight), ptr(plan.buf[o.name]), N, o.C,
+                                                  H >> tin.shift, W >> tin.shift, op["stride"], stats, C.byref(bt), st))
+                    bn_done = True
+                else:
+                    check(lib.sc_dwconv3x3_fwd(C.byref(s), ptr(conv.weight), ptr(plan.buf[o.name]), N, o.C,
+                                               H >> tin.shift, W >> tin.shift, op["stride"], stats, st))
             elif ty in ("pw", "conv3"):
                 if ty == "conv3" and self._late_pack_stream is not None:      # the decoder's filter layouts were packed beside the encoder
                     check(lib.sc_stream_wait_stream(st, self._late_pack_stream))
@@ -996,7 +1024,7 @@ class HyperStarcopUNet(nn.Module):
                 check(lib.sc_head_conv_fwd(C.byref(s), ptr(conv.weight), ptr(conv.bias), ptr(plan.buf[o.name]),
                                            N, conv.in_channels, Ho, Wo, st))
             self._pe(tok)
-            if o.bn is not None and training and not ("f" in _EXP_NO_BNFIN and plan.generation > 3):
+            if o.bn is not None and training and not bn_done and not ("f" in _EXP_NO_BNFIN and plan.generation > 3):
                 bn = o.bn
                 check(lib.sc_bn_finalize(stats, srows, float(N * Ho * Wo), ptr(bn.weight), ptr(bn.bias),
                                          ptr(bn.running_mean), ptr(bn.running_var), float(bn.momentum), float(bn.eps),

@@ -638,6 +638,55 @@ def test_depthwise(hip, C_, H, W, stride):
     assert relerr(acc.reshape(C_, 1, 3, 3), wr.grad) < TOL
 
 
+@pytest.mark.parametrize("N,C_,H,W,stride", [(16, 96, 16, 16, 1), (3, 24, 32, 32, 1), (4, 40, 64, 64, 2), (2, 12, 64, 64, 1), (5, 7, 20, 28, 1), (16, 960, 16, 16, 1)])
+def test_depthwise_finalizes_its_batchnorm_in_the_launch(hip, N, C_, H, W, stride):
+    """sc_dwconv3x3_fwd_bn (producer-tail BatchNorm finalize: the last arrival of a channel, by ticket, sums that channel's statistics
+    rows and writes constants / running statistics / the activation bound) against sc_dwconv3x3_fwd + sc_bn_finalize: identical
+    outputs and rows, constants and running statistics equal to summation order, over several launches on the same tickets (the
+    counters are monotone, never reset), bit-identical from launch to launch; wave-per-plane and tile kernels, one and two tiles per
+    plane, ragged planes, stride 2"""
+    from starcop_amd._lib import sc_bn_tail
+    lib = hip
+    x, w = rnd(N, C_, H, W, seed=1), rnd(C_, 1, 3, 3, seed=2, scale=0.3)
+    sc, sh = rnd(C_, seed=3) * 0.3 + 1, rnd(C_, seed=4) * 0.2
+    src = make_src(dev(x), C_, SRC_AFFINE, act=ACT_RELU6, cst=cst_affine(sc, sh))
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    rows = lib.sc_stat_rows(STAT_DW, N, Ho, Wo)
+    wd = dev(w)
+    gamma, beta = dev(rnd(C_, seed=5) * 0.2 + 1), dev(rnd(C_, seed=6) * 0.1)
+    res = {}
+    for mode in ("separate", "tail"):
+        out = torch.empty(N, C_, Ho, Wo, device=DEV)
+        stats = torch.full((rows, C_, 2), float("nan"), device=DEV)
+        rm, rv = torch.zeros(C_, device=DEV), torch.ones(C_, device=DEV)
+        cst = torch.full((C_, SC_CST), float("nan"), device=DEV)
+        bound = torch.zeros(1, device=DEV)
+        tickets = torch.zeros(C_, dtype=torch.int32, device=DEV)
+        snaps = []
+        for rep_ in range(3):
+            if mode == "separate":
+                check(lib.sc_dwconv3x3_fwd(C.byref(src), ptr(wd), ptr(out), N, C_, H, W, stride, ptr(stats), stream()))
+                check(lib.sc_bn_finalize(ptr(stats), rows, float(N * Ho * Wo), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.1, 1e-5, 1, ptr(cst), C_,
+                                         None, ptr(bound), stream()))
+            else:
+                bt = sc_bn_tail()
+                bt.gamma, bt.beta, bt.running_mean, bt.running_var = gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr()
+                bt.momentum, bt.eps, bt.cst, bt.act_bound, bt.tickets = 0.1, 1e-5, cst.data_ptr(), bound.data_ptr(), tickets.data_ptr()
+                check(lib.sc_dwconv3x3_fwd_bn(C.byref(src), ptr(wd), ptr(out), N, C_, H, W, stride, ptr(stats), C.byref(bt), stream()))
+            torch.cuda.synchronize()
+            snaps.append(cst.clone())
+        assert torch.equal(snaps[0], snaps[1]) and torch.equal(snaps[1], snaps[2])          # the constants do not depend on who arrives last
+        if mode == "tail":
+            assert bool((tickets == 3 * rows).all())
+        res[mode] = (out.clone(), stats.clone(), cst.clone(), rm.clone(), rv.clone(), float(bound))
+    a_, b_ = res["separate"], res["tail"]
+    assert torch.equal(a_[0], b_[0]) and torch.equal(a_[1], b_[1])
+    assert bool(torch.isfinite(b_[2]).all())
+    for k in (2, 3, 4):
+        assert relerr(b_[k], a_[k]) < 1e-6, k
+    assert abs(a_[5] - b_[5]) <= 1e-6 * a_[5]
+
+
 def test_stem_fused_normalizer(hip):
     """stem conv reads raw products and applies clamp((x-off)/fac, lo, hi) on load (normalizer_module.py:134)."""
     N, Cin, H, W = 2, 4, 64, 96
