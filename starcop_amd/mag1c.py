@@ -158,8 +158,11 @@ def _run_column_groups(cube3, b0, S, valid_u8, gcol, min_keep, template, num_ite
                                       ptr(pix), ptr(totals), ptr(work), st))
     # DIRECT: fp32 cube, 65..128 bands and no group that can exceed the 512 pixels the filter kernel keeps in registers (column groups:
     # rows x widest run of columns) -- the kernel reads its pixels from the cube through `pix` and writes image order itself
-    direct = (DIRECT_TILES and ids is None and not is64 and S > 64 and out_dtype in (torch.float32, torch.float64)
-              and rows * int(np.diff(gcol).max()) <= 512)
+    # Arbitrary integer groups (the orthorectified |GLT sample| map of the AVIRIS-NG driver): their sizes are known on the device only, so
+    # the direct launch is TRIED when the mean group is small enough (a 512^2 tile of a 598-sample detector: ~438 pixels per group); a
+    # group beyond 512 pixels reports status 2 and the call is redone on the packed path (whole flight lines never try: HW / G > 512).
+    direct = (DIRECT_TILES and not is64 and S > 64 and out_dtype in (torch.float32, torch.float64)
+              and (rows * int(np.diff(gcol).max()) <= 512 if ids is None else HW <= 512 * G))
     a = sc_mag1c_args()
     a.x_is_f64 = 1 if is64 else 0
     a.P = P_d.data_ptr(); a.poff = poff_d.data_ptr()
@@ -177,7 +180,12 @@ def _run_column_groups(cube3, b0, S, valid_u8, gcol, min_keep, template, num_ite
         a.cube, a.S_total, a.band0, a.pix_index = cube3.data_ptr(), S_total, b0, pix.data_ptr()
         a.scatter_mf, a.scatter_alb, a.scatter_is_f64 = mf_out.data_ptr(), alb_out.data_ptr(), o64
         check(lib.sc_mag1c_groups(C.byref(a), st))
-    else:
+        if ids is not None and int(status.max()) == 2:      # a group of more than 512 pixels: the whole call again, packed
+            both.fill_(fill)
+            status.zero_()
+            a.cube = None
+            direct = False
+    if not direct:
         xp = torch.empty((HW + 64 * G) * S, dtype=dt, device=dev)            # upper bound of sum(Ppad) * S: no size read-back, no memset
         check(lib.sc_mag1c_pack(ptr(cube3), 1 if is64 else 0, S_total, b0, S, ptr(pix), ptr(xoff_d), ptr(ppad_d),
                                 ptr(poff_d), ptr(P_d), G, ptr(xp), 1 if is64 else 0, st))

@@ -210,6 +210,21 @@ def test_direct_tiles_equal_the_packed_path(hip, S, alpha):
     assert np.array_equal(got == hip_mag1c.NODATA, want_mf == hip_mag1c.NODATA)
     ok = want_mf != hip_mag1c.NODATA
     assert np.mean(rel(got[ok], want_mf[ok]) > 1e-3) < 2e-3
+    # an arbitrary (non-column) integer group map with every group below 512 pixels: the direct launch is tried and taken; with one
+    # group above (ids2): it reports that group and the call is redone on the packed path -- both bit-identical to the packed path
+    yy, xx = np.mgrid[0:H, 0:W]
+    ids1 = ((yy // 64) * 7 + (xx * 5 + yy) % 7 + 1).astype(np.int64)            # 28 scattered groups of ~120 pixels
+    ids2 = ids1.copy(); ids2[:48, :] = 99                                       # + one group of 624 pixels
+    for ids_ in (ids1, ids2):
+        res = {}
+        for on in (True, False):
+            hip_mag1c.DIRECT_TILES = on
+            try:
+                res[on] = hip_mag1c.acrwl1mf_by_groups(x, t, ids_, alpha=1e-3, band_slice=sl)
+            finally:
+                hip_mag1c.DIRECT_TILES = True
+        assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+        assert bool((res[True][0] != hip_mag1c.NODATA).any())
     # a 3-column run (768 pixels) is beyond the register tile: the same call takes the packed path and still agrees with the oracle
     wide = np.repeat(np.array([1, 1, 1, 2, 2, 2, 3, 3, 4, 4, 5, 5, 6])[None, :], H, 0)
     w_mf = hip_mag1c.acrwl1mf_by_groups(x, t, wide, alpha=alpha, band_slice=sl)[0].cpu().numpy()
