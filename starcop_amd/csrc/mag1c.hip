@@ -1515,7 +1515,8 @@ __global__ __launch_bounds__(RNT, 2) void k_mag1c_tile(const Mag1cP p) {
           if (it == last) {
             if (RES && p.cube != nullptr) {               // DIRECT mode: straight to image order
               const long long ix = p.pix[po + r_q];
-              if (p.sc_f64) { reinterpret_cast<double*>(p.sc_mf)[ix] = mf * scale; reinterpret_cast<double*>(p.sc_alb)[ix] = R; }
+              // (f64 outputs: rounded through float first, exactly what the packed path's float store + sc_scatter_n widening gives)
+              if (p.sc_f64) { reinterpret_cast<double*>(p.sc_mf)[ix] = (double)(float)(mf * scale); reinterpret_cast<double*>(p.sc_alb)[ix] = (double)(float)R; }
               else { reinterpret_cast<float*>(p.sc_mf)[ix] = (float)(mf * scale); reinterpret_cast<float*>(p.sc_alb)[ix] = (float)R; }
             } else {
               reinterpret_cast<float*>(p.mf_out)[po + r_q] = (float)(mf * scale);

@@ -195,11 +195,26 @@ _PACK_SIDE = os.environ.get("STARCOP_PACK_SIDE", "1") == "1"
 # had cost.  0 = off (default): the separate sc_bn_finalize launch.
 _DW_TAIL_ROWS = int(os.environ.get("STARCOP_DW_TAIL_ROWS", "0"))
 _SP_SKIPTILES = os.environ.get("STARCOP_SP_SKIPTILES", "1") == "1"      # (same-box A/B of decoder.blocks.0's one-launch data gradient)
-_EXP_NO_WGRAD = os.environ.get("STARCOP_EXP_NO_WGRAD", "0") == "1"
+
+
+def _experiment(name, default=""):
+    """Elimination experiments (STARCOP_EXP_*: launches skipped or bytes halved -- results WRONG, timing valid) are measuring tools, not
+    product switches: a stray variable must not silently skip weight gradients.  They are honoured only together with
+    STARCOP_EXPERIMENT_OK=1 (tools/ab_*.sh set it); without it the import fails, with it every active one is announced once."""
+    v = os.environ.get(name, default)
+    if v not in ("", "0"):
+        if os.environ.get("STARCOP_EXPERIMENT_OK") != "1":
+            raise RuntimeError(f"{name}={v} is an elimination experiment (wrong results by design); set STARCOP_EXPERIMENT_OK=1 to run it")
+        import warnings
+        warnings.warn(f"starcop_amd: elimination experiment {name}={v} is ACTIVE -- results of this process are wrong by design")
+    return v
+
+
+_EXP_NO_WGRAD = _experiment("STARCOP_EXP_NO_WGRAD", "0") == "1"
 # elimination experiment (results WRONG after the first steps, timing valid): skip the BatchNorm finalize launches of the training forward
 # ("f"), of the backward ("b") or both ("fb") from the fourth step of a plan on -- what the ~93 dependent ~5 us launches cost the step
-_EXP_NO_BNFIN = os.environ.get("STARCOP_EXP_NO_BNFIN", "")
-_EXP_SIDE2 = os.environ.get("STARCOP_EXP_SIDE2", "0") == "1"      # tools/: elimination experiment only
+_EXP_NO_BNFIN = _experiment("STARCOP_EXP_NO_BNFIN", "")
+_EXP_SIDE2 = _experiment("STARCOP_EXP_SIDE2", "0") == "1"      # tools/: elimination experiment only
 
 
 _SP_TERMS = (TERMS_F16X2, 1)      # arithmetic modes of the sub-pixel forward / data-gradient kernels (conv_sp.hip)
@@ -339,12 +354,20 @@ class HyperStarcopUNet(nn.Module):
         # bound of its sources (h_act_scale in conv_bx3.hip: |gamma| sqrt(n - 1) + |beta| from sc_bn_finalize in training, the
         # recorded maxima for residual sums / in inference), so only the FILTERS (scaled by a fixed 2^8 at pack time) decide `ok`;
         # the activation figures stay in the report (activation_default_scale: the fixed x2 of rounds 1-4 still applies to all).
+        #  Inference has no by-construction bound: BatchNorm runs on running statistics and the scales follow the sticky
+        # records, which are refreshed at the range_check_every cadence only.  With the cadence OFF (0) nothing would ever notice a
+        # clamp, so the observed / residual maxima stay part of `ok` there; `inference_clamped` counts the forwards whose recheck found
+        # a tensor beyond the scale that was in force (each of them warned; the last one of a redo chain is NOT repaired).
+        act_ok = bool(self.range_check_every) or max(omax, rmax) * 2.0 <= self.FP16_MAX_ACT
         return dict(max_abs_filter=wmax, filter_limit=self.FP16_MAX_WEIGHT, activation_bound=amax, activation_observed=omax,
                     activation_limit=self.FP16_MAX_ACT, residual_absmax=rmax, switched=bool(switched),
                     activation_default_scale=bool(max(omax, rmax) < self.FP16_MAX_ACT / 2),
-                    ok=bool(wmax < self.FP16_MAX_WEIGHT and not switched))
+                    inference_clamped=int(self._inference_clamped), inference_unrepaired=int(self._inference_unrepaired),
+                    ok=bool(wmax < self.FP16_MAX_WEIGHT and not switched and act_ok and not self._inference_unrepaired))
 
     _range_switched = False      # this replica left precision "fp32" because of a range check (reported to the other ranks)
+    _inference_clamped = 0       # inference forwards whose range recheck found a clamped operand (each was redone with adapted scales)
+    _inference_unrepaired = 0    # ... of which the redo chain gave up (6 re-runs): the returned logits carry clamped operands
 
     def check_split_range(self, sync_ranks=False):
         """A checkpoint (or a training run) whose filters or activations leave the fp16 range of the default split continues with
@@ -1052,8 +1075,22 @@ class HyperStarcopUNet(nn.Module):
                 self._record_activation_range(plan)
                 used = torch.where(before * 2 > self.FP16_MAX_ACT,
                                    torch.exp2(torch.floor(torch.log2(self.FP16_MAX_ACT / before.clamp_min(1e-30)))), torch.full_like(before, 2.0))
-                if bool((plan.act_amax * used > 2 * self.FP16_MAX_ACT).any()) and _recheck < 6:
-                    return self._forward_impl(x, x_cst, training, need_grad, _recheck=_recheck + 1)
+                if bool((plan.act_amax * used > 2 * self.FP16_MAX_ACT).any()):
+                    import warnings
+                    worst = float((plan.act_amax * used).max()) / 2.0
+                    if _recheck < 6:
+                        if _recheck == 0:
+                            self._inference_clamped += 1
+                            warnings.warn(f"HyperStarcopUNet (inference, precision='fp32'): an activation of {worst:.4g} (in units of the "
+                                          f"operand scale in force) exceeded the fp16 range of the split convolutions "
+                                          f"({self.FP16_MAX_ACT:g}) and was clamped; the forward is redone with the adapted scale.  "
+                                          f"Forwards between two checks (range_check_every={self.range_check_every}) are not re-examined: "
+                                          f"set range_check_every=1 for data of unknown range")
+                        return self._forward_impl(x, x_cst, training, need_grad, _recheck=_recheck + 1)
+                    self._inference_unrepaired += 1
+                    warnings.warn(f"HyperStarcopUNet (inference, precision='fp32'): activations still outside the fp16 range after 6 "
+                                  f"re-runs with adapted scales ({worst:.4g}); the returned logits carry operands clamped to "
+                                  f"+-65504/scale.  split_range_report()['ok'] is now False; use precision='fp32-x3' for this input")
         return plan
 
     def _irt_args(self, plan, i_e):
@@ -1501,7 +1538,7 @@ class HyperStarcopUNet(nn.Module):
             else:
                 wfn = (lib.sc_conv3x3_wgrad_bx3 if (self.split_bf16 and ks == 3 and conv.out_channels >= 32 and conv.in_channels >= 32)
                        else lib.sc_conv2d_wgrad_mfma)     # 16-channel layers outside the cases below stay on the fp32 MFMA
-            if (self.split_bf16 and self.thin16 and ks == 3 and self._terms[1] == TERMS_F16X2 and len(ins) == 1
+            if (wfn is not None and self.split_bf16 and self.thin16 and ks == 3 and self._terms[1] == TERMS_F16X2 and len(ins) == 1
                     and conv.out_channels <= 16 and conv.in_channels in (16, 32) and Wo % 2 == 0):
                 wfn = lib.sc_conv3x3_wgrad_thin16     # decoder.blocks.4: two fp16 terms on the 16x16x32 MFMA (was MFMA-bound in fp32)
             tok = None if wfn is None else self._pb(

@@ -453,8 +453,11 @@ def test_batchnorm_fed_activations_are_range_recorded_on_the_device(hip):
     model2.eval(); ref2.eval()
     with torch.no_grad():
         want = ref2(ref_normalize(batch["input"]))
-        got = model2(to_dev(batch)["input"])         # first forward of the shape: records, finds the clamp, redoes with adapted scales
+        with pytest.warns(UserWarning, match="clamped"):      # (the clamp that the recheck repairs is reported)
+            got = model2(to_dev(batch)["input"])     # first forward of the shape: records, finds the clamp, redoes with adapted scales
     assert model2.network.precision == "fp32"
+    rep2 = model2.network.split_range_report()
+    assert rep2["inference_clamped"] == 1 and rep2["inference_unrepaired"] == 0 and rep2["ok"], rep2
     assert model2.network.split_range_report()["activation_observed"] > model2.network.FP16_MAX_ACT
     assert relerr(got, want) < 1e-4
     with torch.no_grad():
