@@ -277,6 +277,31 @@ int sc_conv1x1_pw3(const sc_conv_args* a, sc_stream stream);
 size_t sc_wgrad_pw3_workspace_floats(int N, int H, int W, int Cout, int Cin);
 int sc_conv1x1_wgrad_pw3(const sc_wgrad_args* a, sc_wgrad_pending* pending_host, sc_stream stream);
 
+/* One launch per MobileNetV2 inverted-residual block in INFERENCE (conv_irb.hip; torchvision InvertedResidual.conv inside
+ * smp.Unet('mobilenet_v2').encoder, eval-mode BatchNorm: starcop/models/model_module.py:90-98 forward, :244-251 the network; the
+ * notebook / padded_predict path starcop/models/utils/padding.py:13-50):
+ *     x -> conv1x1 (Cin -> hidden) -> BN_e + ReLU6 -> depthwise 3x3 (stride 1 | 2, pad 1) -> BN_d + ReLU6 -> conv1x1 (hidden -> Cout)
+ *       -> raw p (residual = 0: BN_p is the consumers' business, as for every other convolution here)
+ *       -> z = x + BN_p(p)  (residual = 1: Cin == Cout; z_absmax, if not NULL, is raised to max |z| like sc_add_srcs_absmax does)
+ * The expanded tensors never leave the CU.  Both 1x1 filters come in the sc_conv1x1_pw3 layout (sc_pack_weights_batch with
+ * SC_PACK_PW3, transpose_flip 0); fp32 accuracy (three exact bf16 terms per operand, six MFMA products, fp32 stencil).
+ * Stride 1: 8 <= Cin <= 160, hidden % 32 == 0, Cout <= 384 subject to the accumulator budget; stride 2 (no residual; H, W are the INPUT
+ * plane, the output is ((H - 1) / 2 + 1) x ((W - 1) / 2 + 1)): Cin <= 96, hidden % 64 == 0 (sc_irb_supported). */
+typedef struct sc_irb_args {
+  sc_src x;                  /* block input [N,Cin,H,W]: SC_SRC_RAW or SC_SRC_AFFINE                                  */
+  const float* wpk_expand;   /* PW3 pack of the expansion filter [hidden][Cin]                                         */
+  const float* cst_expand;   /* [hidden][SC_CST]: {scale, shift, ..} of BN_e (sc_bn_finalize, eval)                    */
+  const float* w_dw;         /* [hidden][3][3]                                                                         */
+  const float* cst_dw;       /* [hidden][SC_CST] of BN_d                                                               */
+  const float* wpk_project;  /* PW3 pack of the projection filter [Cout][hidden]                                       */
+  const float* cst_project;  /* [Cout][SC_CST] of BN_p (residual = 1) or NULL                                          */
+  float* out;                /* [N,Cout,Ho,Wo]: raw p, or z                                                            */
+  float* z_absmax;           /* device float raised to max |z| (residual = 1) or NULL                                  */
+  int32_t N, Cin, hidden, Cout, H, W, stride, residual;
+} sc_irb_args;
+int sc_irb_supported(int Cin, int hidden, int Cout, int H, int W, int stride);
+int sc_irb_eval(const sc_irb_args* a, sc_stream stream);
+
 /* Fused TRAINING execution of the expansion + depthwise pair of a STRIDE-2 MobileNetV2 inverted-residual block (torchvision
  * InvertedResidual.conv[0..1] inside smp.Unet('mobilenet_v2'): starcop/models/model_module.py:244-251; train-mode BatchNorm):
  *     e = conv1x1(x, w_expand) -> BN_e + ReLU6 -> depthwise 3x3 (stride 2, pad 1) -> d (raw; BN_d is the consumers' business)

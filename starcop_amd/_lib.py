@@ -64,6 +64,13 @@ class sc_irt_args(C.Structure):
                 ("N", C.c_int32), ("Cin", C.c_int32), ("hidden", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("stride", C.c_int32)]
 
 
+class sc_irb_args(C.Structure):
+    _fields_ = [("x", sc_src), ("wpk_expand", C.c_void_p), ("cst_expand", C.c_void_p), ("w_dw", C.c_void_p), ("cst_dw", C.c_void_p),
+                ("wpk_project", C.c_void_p), ("cst_project", C.c_void_p), ("out", C.c_void_p), ("z_absmax", C.c_void_p),
+                ("N", C.c_int32), ("Cin", C.c_int32), ("hidden", C.c_int32), ("Cout", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("stride", C.c_int32), ("residual", C.c_int32)]
+
+
 class sc_wgrad_pending(C.Structure):
     _fields_ = [("part", C.c_void_p), ("dw", C.c_void_p), ("nparts", C.c_int32), ("taps", C.c_int32), ("Cout", C.c_int32),
                 ("Cin", C.c_int32), ("CoP", C.c_int32), ("CiP", C.c_int32), ("total", C.c_uint64)]
@@ -175,6 +182,8 @@ SIGNATURES = {
     "sc_conv1x1_pw3": (_i, [C.POINTER(sc_conv_args), _vp]),
     "sc_wgrad_pw3_workspace_floats": (_sz, [_i, _i, _i, _i, _i]),
     "sc_conv1x1_wgrad_pw3": (_i, [C.POINTER(sc_wgrad_args), C.POINTER(sc_wgrad_pending), _vp]),
+    "sc_irb_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "sc_irb_eval": (_i, [C.POINTER(sc_irb_args), _vp]),
     "sc_irt_supported": (_i, [_i, _i, _i, _i, _i]),
     "sc_irt_rows": (_i, [_i, _i, _i, _i, _i]),
     "sc_irt_bwd_rows": (_i, [_i, _i, _i, _i]),

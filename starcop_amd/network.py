@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, sc_irt_args, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD, sc_wgrad_pending,
+from ._lib import (ACT_NONE, ACT_RELU, ACT_RELU6, SC_CST, sc_irb_args, sc_irt_args, SRC_AFFINE, SRC_BNBWD, SRC_NORM, SRC_RAW, STAT_BNBWD, sc_wgrad_pending,
                    PACK_PW3, PACK_SP, PACK_SPD, PACK_THIN16, STAT_PW3, STAT_CONV1, STAT_CONV1K, STAT_CONV3, STAT_DW, STAT_STEM, TERMS_F16X2, check, make_src, ptr, sc_bn_tail, sc_bnr_args,
                    sc_conv_args, sc_wgrad_args, stream)
 
@@ -167,6 +167,24 @@ def _use_irt(N, Cin, Hd, Hin, Win, stride):
     if _IRT == "0" or not _lib.load().sc_irt_supported(Cin, Hd, Hin, Win, stride):
         return False
     return _IRT == "all" or (Hin * Win >= 65536 and 4 * N * Hd * Hin * Win >= (256 << 20))
+
+
+# INFERENCE: a stride-1 inverted-residual block (expansion -> depthwise -> projection [-> residual add]) as ONE launch (conv_irb.hip:
+# the expanded tensors never leave the CU).  Eval-mode BatchNorm is a per-channel affine, so nothing batch-wide separates the three
+# convolutions; at 32 x 32 / 16 x 16 planes the separate launches are 10-35 us each for 3-8 us of work (per block, batch 16, us,
+# tools/bench_eval_layers.py, separate -> fused: see DESIGN 16).  "1" = the measured rule, "all" = every supported block (tests),
+# "0" = off.
+_IRB = os.environ.get("STARCOP_IRB", "1")
+
+
+def _use_irb(N, Cin, hidden, Cout, H, W, stride):
+    """The rule: blocks whose patch fits two work-groups per CU (Cin <= 96, hidden % 64 == 0, Cout <= 128: features.5 / .6 / .8-.13) on
+    planes up to 80 x 80, and the stride-2 blocks features.7 / .14 (H, W: the INPUT plane).  features.15-.17 (Cin = 160 at 16 x 16) are NOT taken: every work-group streams the block's whole filter set
+    (1.8 MB as three bf16 terms) for a 4 x 8 pixel tile, 128 work-groups of them -- 80-98 us against 74-86 us for the three launches
+    (tools/bench_irb.py); splitting the hidden channels over work-groups instead of the pixels is what that shape needs."""
+    if _IRB == "0" or not _lib.load().sc_irb_supported(Cin, hidden, Cout, H, W, stride):
+        return False
+    return _IRB == "all" or (Cin <= 96 and hidden % 64 == 0 and Cout <= (128 if stride == 1 else 160) and H * W <= 6400 * stride * stride)
 
 
 # Decoder conv1 = conv3x3(cat([nearest_up2(prev), skip])) as a SUB-PIXEL convolution (conv_sp.hip: four phase-specific 2x2
@@ -598,6 +616,22 @@ class HyperStarcopUNet(nn.Module):
                     plan.stats_v[t.name] = torch.empty(plan.srows[t.name] * t.C * 2, **f32)
                     plan.cst[t.name] = torch.zeros((t.C, SC_CST), **f32)
                     plan.cstb[t.name] = torch.zeros((t.C, SC_CST), **f32)
+            # inference: stride-1 inverted-residual blocks that run as one launch at this resolution: expand op -> (depthwise op,
+            # project op, add op or None); their two 1x1 filters are needed in the PW3 layout (packed for inference forwards only)
+            plan.irb = {}
+            for i_e, (i_dw, i_pr, stride) in self._ir_blocks.items():
+                cv_e, cv_p, tin = self._ops[i_e]["conv"], self._ops[i_pr]["conv"], self._ops[i_e]["ins"][0]
+                if tin.kind != "input" and _use_irb(N, cv_e.in_channels, cv_e.out_channels, cv_p.out_channels, H >> tin.shift, W >> tin.shift, stride):
+                    i_add = i_pr + 1 if (i_pr + 1 < len(self._ops) and self._ops[i_pr + 1]["type"] == "add"
+                                         and self._ops[i_pr + 1]["ins"][1] is self._ops[i_pr]["out"]) else None
+                    plan.irb[i_e] = (i_dw, i_pr, i_add)
+                    lay = getattr(self, "_irb_layers", None)
+                    if lay is None:
+                        lay = self._irb_layers = set()
+                    if not {i_e, i_pr} <= lay:
+                        lay.update((i_e, i_pr))
+                        self._pack_version = None
+                        self._pack_tables = {}
             # which filter layouts the pointwise layers need at this resolution (sticky over all plans of the network)
             need = getattr(self, "_pw_need", None)
             if need is None:
@@ -711,7 +745,8 @@ class HyperStarcopUNet(nn.Module):
         lib = _lib.load()
         ver = (tuple(p._version for p in self.parameters()), self._terms, self.split_bf16, self.thin16)    # a precision switch repacks too
         pv = self._pack_version
-        if pv is not None and pv[0] == ver and (pv[1] or not need_bwd):
+        need_irb = (not need_bwd) and bool(getattr(self, "_irb_layers", None))      # the fused inference blocks' PW3 layouts
+        if pv is not None and pv[0] == ver and (pv[1] or not need_bwd) and (pv[2] or not need_irb):
             return
         st = stream()
         dev = self._pflat.device
@@ -784,8 +819,14 @@ class HyperStarcopUNet(nn.Module):
                     if "pw3" in need.get((i, tflip), ()) and (ent.get(key) is None or ent[key].device != dev):
                         ent[key] = torch.empty(lib.sc_packed_weight_floats_pw3(co, ci, tflip), dtype=torch.float32, device=dev)
                         self._pack_tables = {}
+                # a fused inference block's filter whose layer does not run on sc_conv1x1_pw3 otherwise: a PW3 pack of its own, filled
+                # by inference forwards only (a training step never reads it)
+                if (i in getattr(self, "_irb_layers", ()) and "pw3" not in need.get((i, 0), ())
+                        and (ent.get("pfi") is None or ent["pfi"].device != dev)):
+                    ent["pfi"] = torch.empty(lib.sc_packed_weight_floats_pw3(co, ci, 0), dtype=torch.float32, device=dev)
+                    self._pack_tables = {}
         # one launch for all packs: device-side descriptor table, built once per (need_bwd, parameter storage)
-        key = (bool(need_bwd), self._pflat.data_ptr(), self._terms)
+        key = (bool(need_bwd), self._pflat.data_ptr(), self._terms, need_irb)
         tab = self._pack_tables.get(key) if hasattr(self, "_pack_tables") else None
         if tab is None:
             import numpy as np
@@ -826,6 +867,8 @@ class HyperStarcopUNet(nn.Module):
                 for tflip, buf in ((0, ent.get("pf")), (1, ent.get("pb"))):
                     if buf is not None and (not tflip or need_bwd):
                         add(is_pw and not tflip, conv.weight, buf, co, ci, 1, 0, tflip, PACK_PW3)
+                if need_irb and ent.get("pfi") is not None and "pw3" not in getattr(self, "_pw_need", {}).get((i, 0), ()):
+                    add(True, conv.weight, ent["pfi"], co, ci, 1, 0, 0, PACK_PW3)
 
             def table(rows):
                 starts, nblk = [], 0
@@ -861,7 +904,7 @@ class HyperStarcopUNet(nn.Module):
                 self._late_pack_stream = sh
             else:
                 check(lib.sc_pack_weights_batch(ptr(tab[1][0]), ptr(tab[1][1]), tab[1][2], tab[1][3], st))
-        self._pack_version = (ver, bool(need_bwd))
+        self._pack_version = (ver, bool(need_bwd), need_irb)
 
     # ------------------------------------------------------------------------------------------
     def _src_of(self, plan, t, up=0, x_cst=None):
@@ -944,6 +987,36 @@ class HyperStarcopUNet(nn.Module):
                 check(lib.sc_irt_fwd(C.byref(a_irt), ptr(plan.buf[td.name]), None, st))
                 self._pe(tok)
                 skip.add(plan.irt[i])
+                continue
+            if not training and i in plan.irb:
+                # inference: the whole inverted-residual block in one launch (conv_irb.hip); covers the depthwise, projection and add ops
+                i_dw, i_pr, i_add = plan.irb[i]
+                op_d, op_p = self._ops[i_dw], self._ops[i_pr]
+                tin, te, td, tp = op["ins"][0], o, op_d["out"], op_p["out"]
+                ent_e, ent_p = self._wpk[i], self._wpk[i_pr]
+                pe = ent_e["pf"] if "pw3" in self._pw_need.get((i, 0), ()) else ent_e["pfi"]
+                pp_ = ent_p["pf"] if "pw3" in self._pw_need.get((i_pr, 0), ()) else ent_p["pfi"]
+                a = sc_irb_args()
+                a.x = self._src_of(plan, tin)
+                a.wpk_expand, a.cst_expand = pe.data_ptr(), plan.cst[te.name].data_ptr()
+                a.w_dw, a.cst_dw = op_d["conv"].weight.data_ptr(), plan.cst[td.name].data_ptr()
+                a.wpk_project = pp_.data_ptr()
+                a.N, a.Cin, a.hidden, a.Cout = N, op["conv"].in_channels, op["conv"].out_channels, op_p["conv"].out_channels
+                a.H, a.W, a.stride = H >> tin.shift, W >> tin.shift, self._ir_blocks[i][2]
+                if i_add is not None:
+                    tz = self._ops[i_add]["out"]
+                    a.residual, a.cst_project = 1, plan.cst[tp.name].data_ptr()
+                    a.out = plan.buf[tz.name].data_ptr()
+                    a.z_absmax = plan.fin_amax.data_ptr() + 4 * plan.fin_slot[tz.name]
+                    skip.add(i_add)
+                else:
+                    a.residual, a.cst_project, a.z_absmax = 0, None, None
+                    a.out = plan.buf[tp.name].data_ptr()
+                self._cur_op = tp.name + ":fwd"
+                tok = self._pb("k_irb (fused block, eval)")
+                check(lib.sc_irb_eval(C.byref(a), st))
+                self._pe(tok)
+                skip.update((i_dw, i_pr))
                 continue
             stats = ptr(plan.stats_v[o.name]) if (training and o.bn is not None) else None
             srows = plan.srows.get(o.name, 0)
