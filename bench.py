@@ -263,6 +263,17 @@ def bench_extras(model, dev, precision):
                         "tiles_s": round(16 / dt, 1), "ms": round(dt * 1e3, 3),
                         "tiles_s_mean": round(16 / dt_mean, 1), "tiles_s_median": round(16 / dt_med, 1),
                         "batch_with_preds_tiles_s": round(16 / dtp, 1)}
+    # round 6: inverted-residual blocks as one launch each in inference (csrc/conv_irb.hip) -- the same forward with them OFF, same process
+    from starcop_amd import network as _nw
+    plan16 = model.network._plans.get((16, 512, 512))
+    out["infer_b16"]["fused_inverted_residual_blocks"] = len(getattr(plan16, "irb", {})) if plan16 is not None else None
+    irb_saved, _nw._IRB = _nw._IRB, "0"
+    model.network._plans.pop((16, 512, 512), None)
+    with torch.no_grad():
+        dt_sep = _timeit(lambda: model(b16["input"]), 10, best_of=3)
+    _nw._IRB = irb_saved
+    model.network._plans.pop((16, 512, 512), None)
+    out["infer_b16"]["tiles_s_separate_launches"] = round(16 / dt_sep, 1)
     scene = np.random.default_rng(5).uniform(0, 100, size=(4, 1280, 1242)).astype(np.float32)
     dt = _timeit(lambda: model.predict(scene), 5)
     out["predict_scene"] = {"workload": "ModelModule.predict on a host (4, 1280, 1242) float32 scene: reflect-pad to x32, forward, sigmoid, crop, back to host",

@@ -184,7 +184,11 @@ def _use_irb(N, Cin, hidden, Cout, H, W, stride):
     (tools/bench_irb.py); splitting the hidden channels over work-groups instead of the pixels is what that shape needs."""
     if _IRB == "0" or not _lib.load().sc_irb_supported(Cin, hidden, Cout, H, W, stride):
         return False
-    return _IRB == "all" or (Cin <= 96 and hidden % 64 == 0 and Cout <= (128 if stride == 1 else 160) and H * W <= 6400 * stride * stride)
+    if _IRB == "all":
+        return True
+    if stride == 2:       # features.7 (32 -> 192 -> 64 from 64 x 64): 41 vs 54 us; features.14 (96 -> 576 -> 160 from 32 x 32): 74 vs 75 -- not taken
+        return Cin <= 64 and hidden % 64 == 0 and H * W <= 25600
+    return Cin <= 96 and hidden % 64 == 0 and Cout <= 128 and H * W <= 6400
 
 
 # Decoder conv1 = conv3x3(cat([nearest_up2(prev), skip])) as a SUB-PIXEL convolution (conv_sp.hip: four phase-specific 2x2

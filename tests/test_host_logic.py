@@ -212,6 +212,30 @@ def test_fused_block_rule():
     assert lib.sc_irt_bwd_workspace_floats(16, 16, 96, 256, 256) > 16 * 16 * 256 * 256
 
 
+def test_inference_block_rule():
+    """which inverted-residual blocks run as ONE launch in inference (network._use_irb, measured per block: DESIGN.md 16): features.5 /
+    .6 / .8-.13 (stride 1, Cin <= 96) and the stride-2 features.7 at 512^2 tiles -- not features.3 / .4 (hidden = 144), not features.14
+    (a tie), not features.15-.17 (Cin = 160: slower); the same blocks on the planes of a 1280 x 1248 scene; host logic + sc_irb_supported"""
+    from starcop_amd import _lib, network as nw
+    if nw._IRB != "1":
+        pytest.skip("STARCOP_IRB overridden")
+    net = nw.HyperStarcopUNet(4, 1)
+    def fused(N, H, W):
+        out = []
+        for i_e, (i_dw, i_pr, stride) in net._ir_blocks.items():
+            cv_e, cv_p, tin = net._ops[i_e]["conv"], net._ops[i_pr]["conv"], net._ops[i_e]["ins"][0]
+            if nw._use_irb(N, cv_e.in_channels, cv_e.out_channels, cv_p.out_channels, H >> tin.shift, W >> tin.shift, stride):
+                out.append(net._ops[i_pr]["out"].name)
+        return out
+    want = ["f5p", "f6p", "f7p", "f8p", "f9p", "f10p", "f11p", "f12p", "f13p"]
+    assert fused(16, 512, 512) == want and fused(64, 512, 512) == want
+    assert fused(1, 1280, 1248) == ["f7p", "f8p", "f9p", "f10p", "f11p", "f12p", "f13p"]      # (features.5 / .6 planes are 160 x 156 there: separate launches)
+    lib = _lib.load()
+    assert lib.sc_irb_supported(64, 384, 64, 32, 32, 1) == 1 and lib.sc_irb_supported(160, 960, 320, 16, 16, 1) == 1
+    assert lib.sc_irb_supported(24, 144, 24, 128, 128, 1) == 0            # hidden % 32
+    assert lib.sc_irb_supported(32, 192, 64, 64, 64, 2) == 1 and lib.sc_irb_supported(160, 960, 320, 16, 16, 2) == 0
+
+
 def test_sub_pixel_rules():
     """which decoder conv1 launches run as sub-pixel convolutions (network._use_sp / _use_spd, measured per layer: DESIGN.md 15,
     profiles/r05_bench_sp_b16.txt): forward from 32 output channels and 128 work-groups, the data gradient of the up-sampled channels
