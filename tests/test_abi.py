@@ -61,14 +61,18 @@ def test_struct_sizes_match_the_c_compiler(tmp_path):
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "starcop_hip.h"\nint main(void){'
                    'printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(sc_src), sizeof(sc_conv_args), offsetof(sc_conv_args, terms), '
                    'sizeof(sc_wgrad_args), offsetof(sc_wgrad_args, terms), sizeof(sc_pack_desc), offsetof(sc_pack_desc, total));'
-                   'printf("%zu %zu\\n", sizeof(sc_wgrad_pending), offsetof(sc_wgrad_pending, total));return 0;}\n')
+                   'printf("%zu %zu\\n", sizeof(sc_wgrad_pending), offsetof(sc_wgrad_pending, total));'
+                   'printf("%zu %zu %zu %zu %zu\\n", sizeof(sc_irb_args), offsetof(sc_irb_args, out), offsetof(sc_irb_args, N), offsetof(sc_irb_args, residual), '
+                   'sizeof(sc_irt_args));return 0;}\n')
     exe = tmp_path / "sz"
     inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
     subprocess.run(["gcc", "-I", inc, str(src), "-o", str(exe)], check=True)
     got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     want = [ctypes.sizeof(_lib.sc_src), ctypes.sizeof(_lib.sc_conv_args), _lib.sc_conv_args.terms.offset,
             ctypes.sizeof(_lib.sc_wgrad_args), _lib.sc_wgrad_args.terms.offset, 48, 40,
-            ctypes.sizeof(_lib.sc_wgrad_pending), _lib.sc_wgrad_pending.total.offset]
+            ctypes.sizeof(_lib.sc_wgrad_pending), _lib.sc_wgrad_pending.total.offset,
+            ctypes.sizeof(_lib.sc_irb_args), _lib.sc_irb_args.out.offset, _lib.sc_irb_args.N.offset, _lib.sc_irb_args.residual.offset,
+            ctypes.sizeof(_lib.sc_irt_args)]
     assert got == want
 
 
