@@ -69,6 +69,9 @@ struct PwP {
   const uintx4* wpk;      // [co block][k step][term][lane] 16-byte entries (k_pack item layout below)
   int NP, HW, K, M, nks, npb;
   float* out; const float* add0; int accum; float* stats;
+  // sc_bnr_args (data-gradient launches that write a tensor's COMPLETE gradient): the BatchNorm-backward sums of that tensor from the
+  // epilogue -- rows [pixel block][M][2] = {sum g', sum g' x_hat} -- instead of a sc_bn_bwd_small launch over (gradient, y) behind it
+  const float* bnr_y; const float* bnr_cst; float* bnr_rows; int bnr_act;
 };
 
 // NCB: 32-cout blocks per wave; PD: K steps of global loads in flight (ring depth); BNB: BatchNorm-backward source
@@ -188,6 +191,41 @@ __global__ __launch_bounds__(256) void k_pw3(const PwP p) {
       if (lhi == 0 && cok) *reinterpret_cast<float2*>(p.stats + ((size_t)pb * M + co) * 2) = make_float2(s1, s2);
     }
     if (!cok) continue;
+    if (BNB && p.bnr_y != nullptr) {
+      // the lane's channel `co` of the output tensor: g' = g act'(BN(y)), sums over the wave's 32 pixels (the lane holds 16, its partner
+      // lane + 32 the other 16); the raw values y of the four 16-byte segments are requested together, ahead of the stores
+      const float4 cb = *reinterpret_cast<const float4*>(p.bnr_cst + (size_t)co * SC_CST);      // scale, shift, mean, invstd
+      const float blo = sc_act_lo(p.bnr_act), bhi = sc_act_hi(p.bnr_act);
+      float yv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) yv[r] = 0.f;
+      if (vec4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (!ook[j]) continue;
+          const float4 t = *reinterpret_cast<const float4*>(p.bnr_y + ooff[j] + (unsigned)co * (unsigned)HW);
+          yv[4 * j] = t.x; yv[4 * j + 1] = t.y; yv[4 * j + 2] = t.z; yv[4 * j + 3] = t.w;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int g = pb * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+          if (g < p.NP) { const int n_ = g / HW; yv[r] = p.bnr_y[((size_t)n_ * M + co) * HW + (g - n_ * HW)]; }
+        }
+      }
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int g = pb * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+        const float yh = fmaf(yv[r], cb.x, cb.y);
+        const float gq = (g < p.NP && yh > blo && yh < bhi) ? acc[m][r] : 0.f;
+        s1 += gq;
+        s2 = fmaf(gq, (yv[r] - cb.z) * cb.w, s2);
+      }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lhi == 0) *reinterpret_cast<float2*>(p.bnr_rows + ((size_t)pb * M + co) * 2) = make_float2(s1, s2);
+    }
     if (vec4) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -425,6 +463,12 @@ extern "C" int sc_conv1x1_pw3(const sc_conv_args* a, sc_stream stream) {
   p.nks = (p.K + 15) / 16;
   p.npb = (int)((NP + 31) / 32);
   p.out = a->out0; p.add0 = a->add0; p.accum = a->accum0; p.stats = a->stats;
+  p.bnr_y = nullptr; p.bnr_cst = nullptr; p.bnr_rows = nullptr; p.bnr_act = SC_ACT_NONE;
+  if (a->bnr) {
+    SC_REQUIRE(p.s.mode == SC_SRC_BNBWD && !a->add0 && !a->accum0 && !a->stats, "sc_conv1x1_pw3: sc_bnr_args go with a data-gradient launch that writes the complete gradient");
+    SC_REQUIRE(a->bnr->y && a->bnr->cst && a->bnr->rows && !a->bnr->absmax, "sc_conv1x1_pw3: sc_bnr_args need y, cst and rows (no range hint on this path)");
+    p.bnr_y = a->bnr->y; p.bnr_cst = a->bnr->cst; p.bnr_rows = a->bnr->rows; p.bnr_act = a->bnr->act;
+  }
   const int MB = (p.M + 31) / 32;
   int ncb = 1;
   for (int c = 4; c >= 2; c >>= 1)

@@ -1222,6 +1222,10 @@ class HyperStarcopUNet(nn.Module):
     fuse_dw_bwd = True          # depthwise dgrad + wgrad + the input's BatchNorm-backward sums in one kernel (False: the three separate kernels)
     fuse_irt = _IRT != "0"      # training: expansion + depthwise of the stride-2 blocks the rule picks without the 6x tensor (conv_irt.hip)
     fuse_head_bn = True         # BatchNorm-backward sums of the decoder's last tensor in the head backward
+    # ... and of the <= 32 x 32 depthwise outputs in the projections' data-gradient epilogues (sc_conv1x1_pw3 + sc_bnr_args; VERDICT r5 #1b).
+    # Built and parity-tested in round 6, measured LEVEL on the step (1481.8 / 1482.0 vs 1481.5 / 1481.1 tiles/s, tools/ab_switch.sh pw_bnr:
+    # the pointwise data gradients get 0.06 ms slower, the BatchNorm launches 0.04 ms faster) -- off
+    pw_bnr = False
     batch_dw_cast = True        # the depthwise filter gradients' fp64 -> fp32 rounding in one launch per walk (17 forks fewer)
     light_stream_sync = True    # fork points of the weight-gradient stream: events without the system-scope fence (sc_stream_wait_stream)
     split_dgrad_launch = True   # decoder conv1 data gradient: up-sampled and skip channels as two launches with their own cout tiles
@@ -1369,11 +1373,11 @@ class HyperStarcopUNet(nn.Module):
             check(lib.sc_bn_bwd_finalize(ptr(plan.bsums_v[t.name]), plan.brows[t.name], float(N * Ho * Wo), ptr(plan.cst[t.name]),
                                          ptr(gv(t.bn.weight)), ptr(gv(t.bn.bias)), ptr(plan.cstb[t.name]), t.C, st))
 
-        def bnr_for(t, nrows):
+        def bnr_for(t, nrows, enabled=_BNR):
             """sc_bnr_args for the data-gradient launch that is about to write the COMPLETE gradient of tensor t (a single-consumer,
             BatchNorm'd tensor that nothing wrote or will add to): the launch leaves t's BatchNorm-backward sums (nrows partial rows) and
             range hint, instead of sc_bn_bwd_reduce streaming (gradient, y) again -- 0.41 ms of such passes per batch-16 step in the decoder"""
-            if (not _BNR or t.bn is None or t.kind != "raw" or n_cons.get(t.name, 0) != 1 or t.name in written
+            if (not enabled or t.bn is None or t.kind != "raw" or n_cons.get(t.name, 0) != 1 or t.name in written
                     or res_of.get(t.name) is not None):
                 return None
             if not hasattr(plan, "bnr_rows"):
@@ -1770,6 +1774,12 @@ class HyperStarcopUNet(nn.Module):
                 b_ = None
                 if ks == 3 and (thin_b or (conv_dgrad is lib.sc_conv3x3_bx3 and bx3_plain)):
                     b_ = bnr_for(tin, lib.sc_stat_rows(STAT_CONV3, N, Ho, Wo))
+                elif (conv_dgrad is lib.sc_conv1x1_pw3 and self.pw_bnr and z is None and not a.accum0
+                      and N * Ho * Wo <= self.bn_small_max and tin.C >= 64):
+                    # a projection's data gradient at <= 32 x 32 (the register-only pointwise kernel): it writes the COMPLETE gradient of the
+                    # depthwise output d, so its epilogue leaves d's BatchNorm-backward sums (one row per 32-pixel block) and the dependent
+                    # sc_bn_bwd_small launch over (gradient, d) -- 8 us alone, ~21 us under the weight-gradient stream -- becomes a finalize
+                    b_ = bnr_for(tin, -(-(N * Ho * Wo) // 32), enabled=True)
                 a.bnr = C.addressof(b_) if b_ is not None else None
                 check(conv_dgrad(C.byref(a), st))
                 self._pe(tok)

@@ -139,7 +139,7 @@ def pack_pw3(w, tflip):
     return out
 
 
-def conv_pw3(src, wpk, N, H, W, Cout, want_stats=False, add0=None, accum_into=None):
+def conv_pw3(src, wpk, N, H, W, Cout, want_stats=False, add0=None, accum_into=None, bnr=None):
     from starcop_amd._lib import STAT_PW3
     lib = _lib.load()
     a = sc_conv_args()
@@ -154,6 +154,10 @@ def conv_pw3(src, wpk, N, H, W, Cout, want_stats=False, add0=None, accum_into=No
     rows = lib.sc_stat_rows(STAT_PW3, N, H, W)
     stats = torch.full((rows, Cout, 2), float("nan"), device=DEV) if want_stats else None
     a.stats = stats.data_ptr() if want_stats else None
+    if bnr is not None:      # (y, cst, act) of out0's tensor: the launch leaves its BatchNorm-backward rows (one per 32-pixel block) -> LAST_BNR
+        b = make_bnr(bnr, -(-(N * H * W) // 32), Cout)
+        b.absmax = None      # (no range hint on this path)
+        a.bnr = C.addressof(b)
     check(lib.sc_conv1x1_pw3(C.byref(a), stream()))
     return out, stats
 

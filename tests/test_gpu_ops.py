@@ -1243,6 +1243,47 @@ def test_conv_pw3_dgrad_bnbwd_add_accum(hip, cin, cout, N, H, W):
     assert relerr(dx2, ref + res.double() + old.double()) < 1e-5
 
 
+@pytest.mark.parametrize("cin,cout,N,H,W", PW3_SHAPES)
+def test_conv_pw3_dgrad_leaves_batchnorm_backward_sums(hip, cin, cout, N, H, W):
+    """sc_bnr_args on sc_conv1x1_pw3 (round 6): a projection's data-gradient launch writes the COMPLETE gradient of the depthwise output,
+    so its epilogue leaves that tensor's BatchNorm-backward sums {sum g', sum g' x_hat} (g' = dx relu6'(BN(y_in))), one row per 32-pixel
+    block -- against float64 sums of the launch's own output, the gradient bit-identical to the launch without them, and through
+    sc_bn_bwd_finalize_rows32 against sc_bn_bwd_small (what the network ran before) on the same (dx, y_in)"""
+    import hip_ops
+    from hip_ops import conv_pw3, pack_pw3
+    w = rnd(cout, cin, 1, 1, seed=2, scale=0.3)
+    g, y = rnd(N, cout, H, W, seed=3) * 1e-3, rnd(N, cout, H, W, seed=4)
+    cstb = torch.zeros(cout, SC_CST)
+    cstb[:, 0], cstb[:, 1], cstb[:, 2], cstb[:, 3], cstb[:, 4] = rnd(cout, seed=4) * 0.2 + 1, rnd(cout, seed=5) * 0.2, rnd(cout, seed=6) * 0.3 + 1, rnd(cout, seed=7) * 1e-4, rnd(cout, seed=8) * 1e-4
+    dsrc = make_src(dev(g), cout, SRC_BNBWD, act=ACT_RELU6, cst=dev(cstb), aux=dev(y))
+    wpk = pack_pw3(dev(w), 1)
+    y_in = rnd(N, cin, H, W, seed=11) * 2
+    cst_in = torch.zeros(cin, SC_CST)
+    cst_in[:, 0], cst_in[:, 1], cst_in[:, 2], cst_in[:, 3] = rnd(cin, seed=12) * 0.2 + 1, rnd(cin, seed=13) * 0.5 + 1.5, rnd(cin, seed=14) * 0.1, rnd(cin, seed=15).abs() * 0.2 + 0.8
+    dx0, _ = conv_pw3(dsrc, wpk, N, H, W, cin)
+    dx1, _ = conv_pw3(dsrc, wpk, N, H, W, cin, bnr=(dev(y_in), dev(cst_in), ACT_RELU6))
+    assert torch.equal(dx0, dx1)
+    rows, _ = hip_ops.LAST_BNR
+    assert bool(torch.isfinite(rows).all())
+    sc, sh, mu, isd = (cst_in[:, k].double()[None, :, None, None] for k in range(4))
+    yh = y_in.double() * sc + sh
+    gp = torch.where((yh > 0) & (yh < 6), dx1.double().cpu(), torch.zeros((), dtype=torch.float64))
+    s1, s2 = gp.sum((0, 2, 3)), (gp * (y_in.double() - mu) * isd).sum((0, 2, 3))
+    got = rows.double().sum(0).cpu()
+    scale = max(float(s1.abs().max()), float(s2.abs().max()), 1e-6)
+    assert float((got[:, 0] - s1).abs().max()) < 2e-5 * scale and float((got[:, 1] - s2).abs().max()) < 2e-5 * scale
+    out = {}
+    for name in ("epilogue", "small"):
+        dg, db, cb = (torch.full((n_,), float("nan"), device=DEV) for n_ in (cin, cin, cin * SC_CST))
+        if name == "epilogue":
+            check(hip.sc_bn_bwd_finalize_rows32(ptr(rows), rows.shape[0], float(N * H * W), ptr(dev(cst_in)), ptr(dg), ptr(db), ptr(cb), cin, None, stream()))
+        else:
+            check(hip.sc_bn_bwd_small(ptr(dx1), ptr(dev(y_in)), ptr(dev(cst_in)), ACT_RELU6, N, cin, H * W, ptr(dg), ptr(db), ptr(cb), None, None, stream()))
+        out[name] = (dg.cpu(), db.cpu(), cb.cpu())
+    for a_, b_ in zip(out["epilogue"], out["small"]):
+        assert float((a_ - b_).abs().max()) <= 2e-5 * max(float(b_.abs().max()), 1e-6)
+
+
 @pytest.mark.parametrize("cin,cout,N,H,W", [s for s in PW3_SHAPES if (s[3] * s[4]) % 8 == 0])
 @pytest.mark.parametrize("deferred", [False, True])
 def test_conv_pw3_wgrad(hip, cin, cout, N, H, W, deferred):
