@@ -1277,6 +1277,108 @@ __global__ __launch_bounds__(256, 4) void k_head_fwd16(const SrcD in, const floa
   }
 }
 
+// k_head_fwd16 with 16-byte staging (W % 4 == 0, 16-byte aligned planes): the 4-byte form above waits for memory six times per
+// pass (a wave takes its 36 patch rows in batches of six, one 256-byte request per row) and runs at 2 TB/s of its 268 MB at 16 x 512^2.
+// Here a wave request covers FOUR patch rows (16 lanes x 16 bytes each), a wave's nine requests of a pass are all in flight together,
+// and the second pass's requests are issued before the first pass's stencil.  Patch row layout: left halo at [3], columns at [4, 68)
+// (16-byte aligned), right halo at [68] = slot 0 of the next row (unused there).
+__global__ __launch_bounds__(256, 4) void k_head_fwd16v(const SrcD in, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      float* __restrict__ out, int H, int W) {
+  constexpr int CIN = 16, CP = 8, TR = 16, TC = 64, PR = TR + 2, PC = 68, NROW = CP * PR, QW = NROW / 16, NHALO = NROW * 2;
+  static_assert(NROW % 16 == 0 && NHALO <= 512, "four waves x QW requests of four rows; two halo elements per thread");
+  __shared__ __attribute__((aligned(16))) float s_in[NROW * PC + 4];
+  __shared__ __attribute__((aligned(16))) float s_w[CIN * 12];           // 9 taps per channel, padded to 12
+  __shared__ float s_sc[CIN * 2];
+  const int n = blockIdx.z;
+  const int tiles_x = (W + TC - 1) / TC;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int y0 = ty * TR, x0 = tx * TC;
+  const float lo = sc_act_lo(in.act), hi = sc_act_hi(in.act);
+  const bool raw = in.mode == SC_SRC_RAW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane >> 4, xg = x0 + 4 * (lane & 15);
+  const bool okx = xg < W;                                               // (W % 4 == 0: a 16-byte group is inside or outside as a whole)
+  const float* plane0 = in.x + (size_t)n * CIN * H * W;
+  float4 v[QW];
+  float hv[2];
+  auto issue = [&](int pass) {
+#pragma unroll
+    for (int u = 0; u < QW; ++u) {
+      const int rr = 4 * (wave + 4 * u) + lr, ci = rr / PR, y = y0 - 1 + rr - ci * PR;
+      const bool oky = (y >= 0) && (y < H);
+      v[u] = *reinterpret_cast<const float4*>(plane0 + ((size_t)(pass * CP + ci) * H + (oky ? y : 0)) * W + (okx ? xg : 0));
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int e = threadIdx.x + 256 * h, ec = e < NHALO ? e : 0, rr = ec >> 1, ci = rr / PR, y = y0 - 1 + rr - ci * PR;
+      const int x = (ec & 1) ? x0 + TC : x0 - 1;
+      const bool ok = (y >= 0) && (y < H) && (x >= 0) && (x < W);
+      hv[h] = plane0[((size_t)(pass * CP + ci) * H + (ok ? y : 0)) * W + (ok ? x : 0)];
+    }
+  };
+  auto commit = [&](int pass) {
+#pragma unroll
+    for (int u = 0; u < QW; ++u) {
+      const int rr = 4 * (wave + 4 * u) + lr, ci = rr / PR, y = y0 - 1 + rr - ci * PR;
+      const bool ok = (y >= 0) && (y < H) && okx;
+      const float sc = s_sc[(pass * CP + ci) * 2], sh = s_sc[(pass * CP + ci) * 2 + 1];
+      float4 t;
+      t.x = ok ? sc_pro_affine(v[u].x, sc, sh, lo, hi) : 0.f; t.y = ok ? sc_pro_affine(v[u].y, sc, sh, lo, hi) : 0.f;
+      t.z = ok ? sc_pro_affine(v[u].z, sc, sh, lo, hi) : 0.f; t.w = ok ? sc_pro_affine(v[u].w, sc, sh, lo, hi) : 0.f;
+      *reinterpret_cast<float4*>(&s_in[rr * PC + 4 + 4 * (lane & 15)]) = t;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int e = threadIdx.x + 256 * h;
+      if (e < NHALO) {
+        const int rr = e >> 1, ci = rr / PR, y = y0 - 1 + rr - ci * PR;
+        const int x = (e & 1) ? x0 + TC : x0 - 1;
+        const bool ok = (y >= 0) && (y < H) && (x >= 0) && (x < W);
+        const float sc = s_sc[(pass * CP + ci) * 2], sh = s_sc[(pass * CP + ci) * 2 + 1];
+        s_in[rr * PC + ((e & 1) ? PC : 3)] = ok ? sc_pro_affine(hv[h], sc, sh, lo, hi) : 0.f;
+      }
+    }
+  };
+  issue(0);
+  if (threadIdx.x < CIN * 12) { const int c = threadIdx.x / 12, t = threadIdx.x - 12 * c; s_w[threadIdx.x] = t < 9 ? w[c * 9 + t] : 0.f; }
+  if (threadIdx.x >= 224 && threadIdx.x < 224 + CIN * 2) {
+    const int i = threadIdx.x - 224, c = i >> 1, h = i & 1;
+    s_sc[i] = raw ? (h ? 0.f : 1.f) : in.cst[(size_t)c * SC_CST + h];
+  }
+  __syncthreads();
+  const int py = threadIdx.x >> 4, pxg = threadIdx.x & 15;
+  float acc[4];
+  const float b0 = bias ? bias[0] : 0.f;
+#pragma unroll
+  for (int o = 0; o < 4; ++o) acc[o] = b0;
+#pragma unroll
+  for (int pass = 0; pass < CIN / CP; ++pass) {
+    commit(pass);
+    __syncthreads();
+    if (pass + 1 < CIN / CP) issue(pass + 1);
+#pragma unroll 2
+    for (int ci = 0; ci < CP; ++ci) {
+      const float4* wp = reinterpret_cast<const float4*>(&s_w[(pass * CP + ci) * 12]);     // broadcast reads
+      const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+      const float wk[9] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x};
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const float* rp = &s_in[(ci * PR + py + kh) * PC + 4 * pxg + 3];
+        const float4 a = *reinterpret_cast<const float4*>(rp + 1);
+        const float vv[6] = {rp[0], a.x, a.y, a.z, a.w, rp[5]};
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int o = 0; o < 4; ++o) acc[o] = fmaf(wk[kh * 3 + kw], vv[o + kw], acc[o]);
+      }
+    }
+    if (pass + 1 < CIN / CP) __syncthreads();
+  }
+  const int y = y0 + py, x = x0 + 4 * pxg;
+  if (y >= H || x >= W) return;
+  *reinterpret_cast<float4*>(out + (size_t)n * H * W + (size_t)y * W + x) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
 template <int CIN>
 __global__ __launch_bounds__(256) void k_head_fwd(const SrcD in, const float* __restrict__ w, const float* __restrict__ bias,
                                                   float* __restrict__ out, int Cin_rt, int H, int W) {
@@ -1737,7 +1839,9 @@ extern "C" int sc_head_conv_fwd(const sc_src* in, const float* w, const float* b
   dim3 grid(((W + HT_C - 1) / HT_C) * ((H + HT_R - 1) / HT_R), 1, N);
   if (Cin == 16) {
     dim3 g16(((W + 63) / 64) * ((H + 15) / 16), 1, N);
-    hipLaunchKernelGGL(k_head_fwd16, g16, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), w, bias, out, H, W);
+    const bool vec = (W % 4 == 0) && (((uintptr_t)in->x | (uintptr_t)out) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(k_head_fwd16v, g16, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), w, bias, out, H, W);
+    else hipLaunchKernelGGL(k_head_fwd16, g16, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), w, bias, out, H, W);
   } else {
     hipLaunchKernelGGL((k_head_fwd<0>), grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), w, bias, out, Cin, H, W);
   }

@@ -712,6 +712,30 @@ def test_stem_fused_normalizer(hip):
     assert relerr(dw, wr.grad) < TOL
 
 
+@pytest.mark.parametrize("shape", [(1, 16, 64), (2, 48, 200), (1, 33, 70), (1, 17, 61), (2, 40, 1248 // 8)], ids=lambda s: "x".join(map(str, s)))
+def test_head_forward_shapes(hip, shape):
+    """the two staging forms of the Cin = 16 head forward (16-byte requests when W % 4 == 0 and the planes are 16-byte aligned, 4-byte
+    otherwise) on whole / ragged tiles, and the 4-byte form on the SAME input through a source that is not 16-byte aligned"""
+    N, H, W = shape
+    Cin = 16
+    x, w, b = rnd(N, Cin, H, W, seed=11), rnd(1, Cin, 3, 3, seed=12, scale=0.3), torch.tensor([-0.21])
+    sc, sh = rnd(Cin, seed=13) * 0.3 + 1, rnd(Cin, seed=14) * 0.2
+    ref = F.conv2d(F.relu(x * sc[None, :, None, None] + sh[None, :, None, None]), w, b, padding=1)
+    wd, bd, cst = dev(w), dev(b), cst_affine(sc, sh)
+    buf = torch.zeros(x.numel() + 4, device=DEV)
+    outs = []
+    for off in (0, 1):
+        xv = buf[off:off + x.numel()].view(N, Cin, H, W)
+        xv.copy_(dev(x))
+        assert (xv.data_ptr() % 16 == 0) == (off == 0)
+        src = make_src(xv, Cin, SRC_AFFINE, act=ACT_RELU, cst=cst)
+        out = torch.full((N, 1, H, W), float("nan"), device=DEV)
+        check(hip.sc_head_conv_fwd(C.byref(src), ptr(wd), ptr(bd), ptr(out), N, Cin, H, W, stream()))
+        assert relerr(out, ref) < TOL
+        outs.append(out)
+    assert relerr(outs[0], outs[1]) < 1e-6
+
+
 def test_head(hip):
     N, Cin, H, W = 2, 16, 40, 72
     x, w, b = rnd(N, Cin, H, W, seed=1), rnd(1, Cin, 3, 3, seed=2, scale=0.3), torch.tensor([0.37])
