@@ -684,6 +684,118 @@ __global__ __launch_bounds__(256, 2) void k_conv1_ksplit(const ConvP p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Streaming form of the pointwise FORWARD for the large planes (H*W >= 8192: features.1-.4 at 256^2 / 128^2, where a launch moves
+// 125-200 MB and the LDS-staged kernel above runs at 3-3.7 TB/s).  GEMM on v_mfma_f32_16x16x4_f32 with the PIXELS PERMUTED so that every
+// global access is 16 bytes per lane:
+//   a wave owns 64 consecutive pixels; lane (n = l&15, kq = l>>4) reads ONE float4 per K step -- pixels 4n..4n+3 of channel 4*ks + kq --
+//   and MFMA j (0..3) takes its element j as the B operand: column n of that MFMA is pixel 4n + j.  After the four MFMAs of a cout
+//   block the lane holds, for couts 4*kq + r, the pixels 4n..4n+3: one 16-byte store per (cout block, r), 256-byte runs per cout.
+//   A = the filter, W[16*cb + n][4*ks + kq], NCB x NKS registers per lane, read once per wave from the sc_pack_weights layout.
+// No LDS staging, no barrier before the epilogue; the K loop is straight-line (exact vmcnt) with a ring of PD float4 loads in flight.
+// Work-group = 4 waves: CP = 1: four pixel groups (256 pixels, two statistics rows); CP = 2: two pixel groups x two cout parts.
+// Statistics rows as k_conv_mfma<1> (SC_STAT_CONV1: one row per 128 pixels).  Same fp32 products as v_mfma_f32_32x32x2_f32.
+#ifndef SC_PWS_PD
+#define SC_PWS_PD 8
+#endif
+struct PwsP {
+  const float* x; const float* cst; int act;
+  const float* wpk; int co_t, Kpad;
+  float* out; float* stats;
+  int HW, K, M;
+};
+
+template <int NCB, int NKS, int CP>
+__global__ __launch_bounds__(256) void k_pw_stream(const PwsP p) {
+  constexpr int PD = NKS < SC_PWS_PD ? NKS : SC_PWS_PD;    // float4 loads in flight per lane
+  constexpr int NPG = 4 / CP;                              // pixel groups per work-group
+  __shared__ __attribute__((aligned(8))) float s_cst[NKS * 4 * 2];
+  __shared__ float s_red[4][NCB * 16][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, kq = lane >> 4;
+  const int K = p.K, M = p.M, HW = p.HW;
+  for (int c = tid; c < NKS * 4; c += 256) {
+    float sc = 1.f, sh = 0.f;
+    if (c < K && p.cst != nullptr) { sc = p.cst[(size_t)c * SC_CST]; sh = p.cst[(size_t)c * SC_CST + 1]; }
+    s_cst[2 * c] = sc; s_cst[2 * c + 1] = sh;
+  }
+  const int pg = wave % NPG, part = wave / NPG;
+  const long gpx = ((long)blockIdx.x * NPG + pg) * 64;     // first pixel of the wave's group, over the whole batch (HW % 64 == 0)
+  const int img = (int)(gpx / HW), px0 = (int)(gpx - (long)img * HW) + 4 * n16;
+  const float* xb = p.x + (size_t)img * K * HW + px0;
+  // ---- the ring's first PD requests, then the filter (both in flight while the constants settle)
+  float4 xr[PD];
+#pragma unroll
+  for (int u = 0; u < PD; ++u) {
+    const int k = 4 * u + kq;
+    xr[u] = *reinterpret_cast<const float4*>(xb + (size_t)(k < K ? k : 0) * HW);
+  }
+  float A[NCB][NKS];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int m = (part * NCB + cb) * 16 + n16;
+    const float* wp = p.wpk + ((size_t)(m / p.co_t) * p.Kpad) * p.co_t + (m % p.co_t);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int k = 4 * ks + kq;
+      A[cb][ks] = (m < M && k < K) ? wp[(size_t)k * p.co_t] : 0.f;
+    }
+  }
+  floatx4 acc[NCB][4];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[cb][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  const float lo = sc_act_lo(p.act), hi = sc_act_hi(p.act);
+  __syncthreads();
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const float2 c = *reinterpret_cast<const float2*>(&s_cst[2 * (4 * ks + kq)]);
+    const float4 v = xr[ks % PD];
+    if (ks + PD < NKS) {
+      const int k = 4 * (ks + PD) + kq;
+      xr[ks % PD] = *reinterpret_cast<const float4*>(xb + (size_t)(k < K ? k : 0) * HW);
+    }
+    const float b[4] = {sc_pro_affine(v.x, c.x, c.y, lo, hi), sc_pro_affine(v.y, c.x, c.y, lo, hi),
+                        sc_pro_affine(v.z, c.x, c.y, lo, hi), sc_pro_affine(v.w, c.x, c.y, lo, hi)};
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[cb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[cb][ks], b[j], acc[cb][j], 0, 0, 0);
+  }
+  // ---- store (16 bytes per lane and cout) and the per-cout sums of the wave's 64 pixels
+  float* ob = p.out + (size_t)img * M * HW + px0;
+  const bool want_stats = p.stats != nullptr;
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int col = cb * 16 + 4 * kq + r, co = part * NCB * 16 + col;
+      const float4 o = make_float4(acc[cb][0][r], acc[cb][1][r], acc[cb][2][r], acc[cb][3][r]);
+      if (co < M) *reinterpret_cast<float4*>(ob + (size_t)co * HW) = o;
+      if (want_stats) {
+        float sv = (o.x + o.y) + (o.z + o.w), sq = fmaf(o.x, o.x, fmaf(o.y, o.y, fmaf(o.z, o.z, o.w * o.w)));
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) { sv += __shfl_xor(sv, off, 64); sq += __shfl_xor(sq, off, 64); }
+        if (n16 == 0) { s_red[wave][col][0] = sv; s_red[wave][col][1] = sq; }
+      }
+    }
+  if (want_stats) {
+    __syncthreads();
+    // rows of 128 pixels = two pixel groups: CP = 1: waves (0, 1) and (2, 3); CP = 2: the two groups of each cout part
+    constexpr int NROW = CP == 1 ? 2 : 1, NCOL = NCB * 16 * CP;
+    for (int i = tid; i < NROW * NCOL * 2; i += 256) {
+      const int k = i & 1, cc = (i >> 1) % NCOL, rw = (i >> 1) / NCOL;
+      const int prt = cc / (NCB * 16), col = cc - prt * (NCB * 16);
+      const int w0 = CP == 1 ? 2 * rw : prt * NPG;
+      if (cc < M) {
+        const size_t row = (size_t)blockIdx.x * NROW + rw;
+        p.stats[(row * M + cc) * 2 + k] = s_red[w0][col][k] + s_red[w0 + 1][col][k];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // weight packing
 __global__ void k_pack_weights(const float* __restrict__ w, float* __restrict__ wpk, int Cout, int Cin,
                                int taps, int co_t, int tflip, int Kpad, size_t total) {
@@ -1276,6 +1388,40 @@ extern "C" int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream) {
     SC_REQUIRE(a->src[s].mode == SC_SRC_RAW || a->src[s].cst != nullptr, "sc_conv2d_mfma: source %d needs constants", s);
     SC_REQUIRE(a->src[s].mode != SC_SRC_BNBWD || a->src[s].aux != nullptr, "sc_conv2d_mfma: BNBWD source needs aux");
     SC_REQUIRE(a->src[s].mode != SC_SRC_BNBWD || a->nsrc == 1, "sc_conv2d_mfma: a BNBWD source cannot be part of a concat");
+  }
+  if (a->ks == 1) {
+    // large planes, forward: the streaming kernel (k_pw_stream) where its shape conditions hold
+    static const bool pws_off = [] { const char* e = getenv("STARCOP_PWS"); return e && atoi(e) == 0; }();      // (same-box A/B)
+    const long HWl = (long)a->H * a->W;
+    const int K = a->src[0].C, M = a->Cout;
+    const bool plain = a->nsrc == 1 && (a->src[0].mode == SC_SRC_RAW || a->src[0].mode == SC_SRC_AFFINE) && a->src[0].up == 0 &&
+                       a->csplit == a->Cout && !a->accum0 && a->add0 == nullptr && a->add1 == nullptr && a->out0 != nullptr;
+    const bool aligned = (((uintptr_t)a->src[0].x | (uintptr_t)a->out0) & 15) == 0;
+    const int nks = K / 4;
+    const bool ks_ok = nks == 6 || nks == 8 || nks == 24 || nks == 36;
+    if (!pws_off && plain && aligned && ks_ok && (M <= 32 || (M <= 160 && nks <= 8)) && HWl >= 8192 && HWl % 256 == 0 && HWl < (1L << 30) && a->co_t != 16) {
+      PwsP q;
+      q.x = a->src[0].x; q.cst = a->src[0].mode == SC_SRC_RAW ? nullptr : a->src[0].cst;
+      q.act = a->src[0].mode == SC_SRC_RAW ? (int)SC_ACT_NONE : a->src[0].act;
+      q.wpk = a->wpk; q.co_t = a->co_t; q.Kpad = (K + 15) / 16 * 16;
+      q.out = a->out0; q.stats = a->stats; q.HW = (int)HWl; q.K = K; q.M = M;
+      hipStream_t st = (hipStream_t)stream;
+      const long groups = (long)a->N * HWl / 64;
+#define SC_PWS(NCB_, NKS_, CP_) hipLaunchKernelGGL((k_pw_stream<NCB_, NKS_, CP_>), dim3((unsigned)(groups / (4 / CP_))), dim3(256), 0, st, q)
+#define SC_PWS_K(NCB_, CP_)                                                                      \
+      do {                                                                                       \
+        if (nks == 6) SC_PWS(NCB_, 6, CP_); else if (nks == 8) SC_PWS(NCB_, 8, CP_);             \
+        else if (nks == 24) SC_PWS(NCB_, 24, CP_); else SC_PWS(NCB_, 36, CP_);                   \
+      } while (0)
+      if (M <= 16) SC_PWS_K(1, 1);
+      else if (M <= 32) SC_PWS_K(2, 1);
+      else if (nks == 6) SC_PWS(5, 6, 2);                  // (the expansions: few input channels, up to 160 couts in two parts)
+      else SC_PWS(5, 8, 2);
+#undef SC_PWS_K
+#undef SC_PWS
+      SC_LAUNCH_OK("sc_conv2d_mfma(k_pw_stream)");
+      return SC_OK;
+    }
   }
   ConvP p;
   p.s0 = to_srcd(a->src[0]);

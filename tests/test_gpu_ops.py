@@ -712,6 +712,48 @@ def test_stem_fused_normalizer(hip):
     assert relerr(dw, wr.grad) < TOL
 
 
+# (N, Cin, Cout, H, W, source): the layers the streaming pointwise forward (k_pw_stream) takes in the network -- features.1 / .2
+# projections, features.3 / .4 expansions, features.3 projection -- on planes >= 8192 pixels, with and without statistics
+PWS_CASES = [(2, 32, 16, 128, 128, "affine6"), (1, 96, 24, 96, 96, "affine6"), (2, 24, 144, 96, 96, "raw"), (1, 24, 144, 128, 64, "affine"),
+             (1, 144, 24, 128, 64, "affine6"), (1, 144, 32, 96, 96, "affine6"), (3, 32, 144, 64, 128, "affine")]
+
+
+@pytest.mark.parametrize("case", PWS_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_pointwise_streaming_forward(hip, case):
+    """sc_conv2d_mfma, ks = 1, large planes: the 16-byte streaming kernel against the float64 convolution of the prologue'd source, its
+    statistics rows against the sums of its own output, and against the LDS-staged kernel (which the entry point falls back to for a
+    source that is not 16-byte aligned) on the same input"""
+    N, Cin, Cout, H, W, mode = case
+    x, w = rnd(N, Cin, H, W, seed=21) * 2.0, rnd(Cout, Cin, 1, 1, seed=22, scale=(2.0 / Cin) ** 0.5)
+    sc, sh = rnd(Cin, seed=23) * 0.3 + 1, rnd(Cin, seed=24) * 0.5
+    if mode == "raw":
+        xa = x.double()
+    else:
+        xa = x.double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
+        if mode == "affine6":
+            xa = xa.clamp(0.0, 6.0)
+    ref = F.conv2d(xa, w.double())
+    co_t = 32 if Cout <= 32 else 64
+    wpk = pack(dev(w), co_t, 0)
+    buf = torch.zeros(x.numel() + 4, device=DEV)
+    outs = []
+    for off in (0, 1):
+        xv = buf[off:off + x.numel()].view(N, Cin, H, W)
+        xv.copy_(dev(x))
+        src = (make_src(xv, Cin, SRC_RAW) if mode == "raw"
+               else make_src(xv, Cin, SRC_AFFINE, act=ACT_RELU6 if mode == "affine6" else ACT_NONE, cst=cst_affine(sc, sh)))
+        (out,), stats = conv_mfma([src], wpk, N, H, W, Cout, 1, co_t, want_stats=True)
+        assert relerr(out, ref) < TOL, relerr(out, ref)
+        assert bool(torch.isfinite(stats).all())
+        st = stats.double().sum(0)
+        assert relerr(st[:, 0], out.double().sum((0, 2, 3))) < 1e-5
+        assert relerr(st[:, 1], (out.double() ** 2).sum((0, 2, 3))) < 1e-5
+        (out2,), none = conv_mfma([src], wpk, N, H, W, Cout, 1, co_t, want_stats=False)
+        assert none is None and torch.equal(out, out2)
+        outs.append(out)
+    assert relerr(outs[0], outs[1]) < 1e-6
+
+
 @pytest.mark.parametrize("shape", [(1, 16, 64), (2, 48, 200), (1, 33, 70), (1, 17, 61), (2, 40, 1248 // 8)], ids=lambda s: "x".join(map(str, s)))
 def test_head_forward_shapes(hip, shape):
     """the two staging forms of the Cin = 16 head forward (16-byte requests when W % 4 == 0 and the planes are 16-byte aligned, 4-byte
