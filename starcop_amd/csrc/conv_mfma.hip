@@ -684,8 +684,8 @@ __global__ __launch_bounds__(256, 2) void k_conv1_ksplit(const ConvP p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Streaming form of the pointwise FORWARD for the large planes (H*W >= 8192: features.1-.4 at 256^2 / 128^2, where a launch moves
-// 125-200 MB and the LDS-staged kernel above runs at 3-3.7 TB/s).  GEMM on v_mfma_f32_16x16x4_f32 with the PIXELS PERMUTED so that every
+// Streaming form of the pointwise FORWARD for the large planes (H*W >= 8192) with a SHORT contraction: features.1's projection, the features.3 / .4
+// expansions and the projections' data gradients at 256^2 / 128^2, where a launch moves 150-270 MB and the LDS-staged kernel above runs at 2.8-3.7 TB/s.  GEMM on v_mfma_f32_16x16x4_f32 with the PIXELS PERMUTED so that every
 // global access is 16 bytes per lane:
 //   a wave owns 64 consecutive pixels; lane (n = l&15, kq = l>>4) reads ONE float4 per K step -- pixels 4n..4n+3 of channel 4*ks + kq --
 //   and MFMA j (0..3) takes its element j as the B operand: column n of that MFMA is pixel 4n + j.  After the four MFMAs of a cout
@@ -698,36 +698,46 @@ __global__ __launch_bounds__(256, 2) void k_conv1_ksplit(const ConvP p) {
 #define SC_PWS_PD 8
 #endif
 struct PwsP {
-  const float* x; const float* cst; int act;
+  const float* x; const float* aux; const float* cst; int act;      // aux: the raw tensor y of a BatchNorm-backward source (BNB)
   const float* wpk; int co_t, Kpad;
   float* out; float* stats;
   int HW, K, M;
 };
 
-template <int NCB, int NKS, int CP>
+template <int NCB, int NKS, int CP, bool BNB = false>
 __global__ __launch_bounds__(256) void k_pw_stream(const PwsP p) {
   constexpr int PD = NKS < SC_PWS_PD ? NKS : SC_PWS_PD;    // float4 loads in flight per lane
   constexpr int NPG = 4 / CP;                              // pixel groups per work-group
-  __shared__ __attribute__((aligned(8))) float s_cst[NKS * 4 * 2];
+  constexpr int CW = BNB ? 8 : 2;                          // forward (scale, shift) | backward (scale, shift, A, B, D, -, -, -)
+  __shared__ __attribute__((aligned(16))) float s_cst[NKS * 4 * CW];
   __shared__ float s_red[4][NCB * 16][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, kq = lane >> 4;
   const int K = p.K, M = p.M, HW = p.HW;
   for (int c = tid; c < NKS * 4; c += 256) {
-    float sc = 1.f, sh = 0.f;
-    if (c < K && p.cst != nullptr) { sc = p.cst[(size_t)c * SC_CST]; sh = p.cst[(size_t)c * SC_CST + 1]; }
-    s_cst[2 * c] = sc; s_cst[2 * c + 1] = sh;
+    if constexpr (BNB) {
+      float4 c0 = make_float4(1.f, 0.f, 0.f, 0.f); float c4 = 0.f;        // (channels past K: any finite value, their filter entries are 0)
+      if (c < K) { c0 = *reinterpret_cast<const float4*>(p.cst + (size_t)c * SC_CST); c4 = p.cst[(size_t)c * SC_CST + 4]; }
+      *reinterpret_cast<float4*>(&s_cst[8 * c]) = c0;
+      *reinterpret_cast<float4*>(&s_cst[8 * c + 4]) = make_float4(c4, 0.f, 0.f, 0.f);
+    } else {
+      float sc = 1.f, sh = 0.f;
+      if (c < K && p.cst != nullptr) { sc = p.cst[(size_t)c * SC_CST]; sh = p.cst[(size_t)c * SC_CST + 1]; }
+      s_cst[2 * c] = sc; s_cst[2 * c + 1] = sh;
+    }
   }
   const int pg = wave % NPG, part = wave / NPG;
   const long gpx = ((long)blockIdx.x * NPG + pg) * 64;     // first pixel of the wave's group, over the whole batch (HW % 64 == 0)
   const int img = (int)(gpx / HW), px0 = (int)(gpx - (long)img * HW) + 4 * n16;
   const float* xb = p.x + (size_t)img * K * HW + px0;
   // ---- the ring's first PD requests, then the filter (both in flight while the constants settle)
-  float4 xr[PD];
+  const float* yb = BNB ? p.aux + (size_t)img * K * HW + px0 : nullptr;
+  float4 xr[PD], yr[BNB ? PD : 1];
 #pragma unroll
   for (int u = 0; u < PD; ++u) {
     const int k = 4 * u + kq;
     xr[u] = *reinterpret_cast<const float4*>(xb + (size_t)(k < K ? k : 0) * HW);
+    if constexpr (BNB) yr[u] = *reinterpret_cast<const float4*>(yb + (size_t)(k < K ? k : 0) * HW);
   }
   float A[NCB][NKS];
 #pragma unroll
@@ -749,14 +759,25 @@ __global__ __launch_bounds__(256) void k_pw_stream(const PwsP p) {
   __syncthreads();
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
-    const float2 c = *reinterpret_cast<const float2*>(&s_cst[2 * (4 * ks + kq)]);
     const float4 v = xr[ks % PD];
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (BNB) y = yr[ks % PD];
     if (ks + PD < NKS) {
       const int k = 4 * (ks + PD) + kq;
       xr[ks % PD] = *reinterpret_cast<const float4*>(xb + (size_t)(k < K ? k : 0) * HW);
+      if constexpr (BNB) yr[ks % PD] = *reinterpret_cast<const float4*>(yb + (size_t)(k < K ? k : 0) * HW);
     }
-    const float b[4] = {sc_pro_affine(v.x, c.x, c.y, lo, hi), sc_pro_affine(v.y, c.x, c.y, lo, hi),
-                        sc_pro_affine(v.z, c.x, c.y, lo, hi), sc_pro_affine(v.w, c.x, c.y, lo, hi)};
+    float b[4];
+    if constexpr (BNB) {
+      const float4 c = *reinterpret_cast<const float4*>(&s_cst[8 * (4 * ks + kq)]);
+      const float c4 = s_cst[8 * (4 * ks + kq) + 4];
+      b[0] = sc_pro_bnbwd(v.x, y.x, c.x, c.y, c.z, c.w, c4, lo, hi); b[1] = sc_pro_bnbwd(v.y, y.y, c.x, c.y, c.z, c.w, c4, lo, hi);
+      b[2] = sc_pro_bnbwd(v.z, y.z, c.x, c.y, c.z, c.w, c4, lo, hi); b[3] = sc_pro_bnbwd(v.w, y.w, c.x, c.y, c.z, c.w, c4, lo, hi);
+    } else {
+      const float2 c = *reinterpret_cast<const float2*>(&s_cst[2 * (4 * ks + kq)]);
+      b[0] = sc_pro_affine(v.x, c.x, c.y, lo, hi); b[1] = sc_pro_affine(v.y, c.x, c.y, lo, hi);
+      b[2] = sc_pro_affine(v.z, c.x, c.y, lo, hi); b[3] = sc_pro_affine(v.w, c.x, c.y, lo, hi);
+    }
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
@@ -774,8 +795,7 @@ __global__ __launch_bounds__(256) void k_pw_stream(const PwsP p) {
       if (co < M) *reinterpret_cast<float4*>(ob + (size_t)co * HW) = o;
       if (want_stats) {
         float sv = (o.x + o.y) + (o.z + o.w), sq = fmaf(o.x, o.x, fmaf(o.y, o.y, fmaf(o.z, o.z, o.w * o.w)));
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) { sv += __shfl_xor(sv, off, 64); sq += __shfl_xor(sq, off, 64); }
+        sv = row_sum16(sv); sq = row_sum16(sq);          // (DPP adds: the 16 lanes of a row are the 16 pixel quads of this cout)
         if (n16 == 0) { s_red[wave][col][0] = sv; s_red[wave][col][1] = sq; }
       }
     }
@@ -1394,29 +1414,35 @@ extern "C" int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream) {
     static const bool pws_off = [] { const char* e = getenv("STARCOP_PWS"); return e && atoi(e) == 0; }();      // (same-box A/B)
     const long HWl = (long)a->H * a->W;
     const int K = a->src[0].C, M = a->Cout;
-    const bool plain = a->nsrc == 1 && (a->src[0].mode == SC_SRC_RAW || a->src[0].mode == SC_SRC_AFFINE) && a->src[0].up == 0 &&
-                       a->csplit == a->Cout && !a->accum0 && a->add0 == nullptr && a->add1 == nullptr && a->out0 != nullptr;
-    const bool aligned = (((uintptr_t)a->src[0].x | (uintptr_t)a->out0) & 15) == 0;
+    const bool bnb = a->src[0].mode == SC_SRC_BNBWD;      // data gradients of the projections: few dy channels, many outputs; no bnr epilogue here
+    const bool plain = a->nsrc == 1 && (a->src[0].mode == SC_SRC_RAW || a->src[0].mode == SC_SRC_AFFINE || (bnb && a->bnr == nullptr && a->stats == nullptr)) &&
+                       a->src[0].up == 0 && a->csplit == a->Cout && !a->accum0 && a->add0 == nullptr && a->add1 == nullptr && a->out0 != nullptr;
+    const bool aligned = (((uintptr_t)a->src[0].x | (uintptr_t)a->out0 | (bnb ? (uintptr_t)a->src[0].aux : 0)) & 15) == 0;
     const int nks = K / 4;
-    const bool ks_ok = nks == 6 || nks == 8 || nks == 24 || nks == 36;
+    // short contractions only: the long-K projections (96 / 144 -> 24 at 128^2) measured a tie without and 3-8 us slower with the
+    // statistics epilogue (a lane keeps NKS filter registers per cout block: two waves per SIMD)
+    const bool ks_ok = bnb ? (nks == 4 || nks == 6) : (nks == 6 || nks == 8);
     if (!pws_off && plain && aligned && ks_ok && (M <= 32 || (M <= 160 && nks <= 8)) && HWl >= 8192 && HWl % 256 == 0 && HWl < (1L << 30) && a->co_t != 16) {
       PwsP q;
-      q.x = a->src[0].x; q.cst = a->src[0].mode == SC_SRC_RAW ? nullptr : a->src[0].cst;
+      q.x = a->src[0].x; q.aux = a->src[0].aux; q.cst = a->src[0].mode == SC_SRC_RAW ? nullptr : a->src[0].cst;
       q.act = a->src[0].mode == SC_SRC_RAW ? (int)SC_ACT_NONE : a->src[0].act;
       q.wpk = a->wpk; q.co_t = a->co_t; q.Kpad = (K + 15) / 16 * 16;
       q.out = a->out0; q.stats = a->stats; q.HW = (int)HWl; q.K = K; q.M = M;
       hipStream_t st = (hipStream_t)stream;
       const long groups = (long)a->N * HWl / 64;
 #define SC_PWS(NCB_, NKS_, CP_) hipLaunchKernelGGL((k_pw_stream<NCB_, NKS_, CP_>), dim3((unsigned)(groups / (4 / CP_))), dim3(256), 0, st, q)
-#define SC_PWS_K(NCB_, CP_)                                                                      \
-      do {                                                                                       \
-        if (nks == 6) SC_PWS(NCB_, 6, CP_); else if (nks == 8) SC_PWS(NCB_, 8, CP_);             \
-        else if (nks == 24) SC_PWS(NCB_, 24, CP_); else SC_PWS(NCB_, 36, CP_);                   \
-      } while (0)
-      if (M <= 16) SC_PWS_K(1, 1);
+#define SC_PWS_K(NCB_, CP_) do { if (nks == 6) SC_PWS(NCB_, 6, CP_); else SC_PWS(NCB_, 8, CP_); } while (0)
+      if (bnb) {
+#define SC_PWSB(NCB_, CP_) do { if (nks == 4) hipLaunchKernelGGL((k_pw_stream<NCB_, 4, CP_, true>), dim3((unsigned)(groups / (4 / CP_))), dim3(256), 0, st, q); \
+                                else hipLaunchKernelGGL((k_pw_stream<NCB_, 6, CP_, true>), dim3((unsigned)(groups / (4 / CP_))), dim3(256), 0, st, q); } while (0)
+        if (M <= 32) SC_PWSB(2, 1);
+        else if (M <= 96) SC_PWSB(3, 2);
+        else SC_PWSB(5, 2);
+#undef SC_PWSB
+      }
+      else if (M <= 16) SC_PWS_K(1, 1);
       else if (M <= 32) SC_PWS_K(2, 1);
-      else if (nks == 6) SC_PWS(5, 6, 2);                  // (the expansions: few input channels, up to 160 couts in two parts)
-      else SC_PWS(5, 8, 2);
+      else SC_PWS_K(5, 2);                                 // (the expansions: few input channels, up to 160 couts in two parts)
 #undef SC_PWS_K
 #undef SC_PWS
       SC_LAUNCH_OK("sc_conv2d_mfma(k_pw_stream)");

@@ -712,10 +712,11 @@ def test_stem_fused_normalizer(hip):
     assert relerr(dw, wr.grad) < TOL
 
 
-# (N, Cin, Cout, H, W, source): the layers the streaming pointwise forward (k_pw_stream) takes in the network -- features.1 / .2
-# projections, features.3 / .4 expansions, features.3 projection -- on planes >= 8192 pixels, with and without statistics
-PWS_CASES = [(2, 32, 16, 128, 128, "affine6"), (1, 96, 24, 96, 96, "affine6"), (2, 24, 144, 96, 96, "raw"), (1, 24, 144, 128, 64, "affine"),
-             (1, 144, 24, 128, 64, "affine6"), (1, 144, 32, 96, 96, "affine6"), (3, 32, 144, 64, 128, "affine")]
+# (N, Cin, Cout, H, W, source): the shapes the streaming pointwise forward (k_pw_stream) takes -- <= 32 input channels, up to 160 outputs
+# (features.1's projection, the features.3 / .4 expansions) -- on planes >= 8192 pixels, with and without statistics; one long
+# contraction (144 channels: stays on the LDS-staged kernel either way)
+PWS_CASES = [(2, 32, 16, 128, 128, "affine6"), (1, 24, 24, 96, 96, "affine6"), (2, 24, 144, 96, 96, "raw"), (1, 24, 144, 128, 64, "affine"),
+             (1, 32, 32, 128, 64, "affine6"), (1, 144, 32, 96, 96, "affine6"), (3, 32, 144, 64, 128, "affine")]
 
 
 @pytest.mark.parametrize("case", PWS_CASES, ids=lambda c: "x".join(map(str, c)))
@@ -750,6 +751,41 @@ def test_pointwise_streaming_forward(hip, case):
         assert relerr(st[:, 1], (out.double() ** 2).sum((0, 2, 3))) < 1e-5
         (out2,), none = conv_mfma([src], wpk, N, H, W, Cout, 1, co_t, want_stats=False)
         assert none is None and torch.equal(out, out2)
+        outs.append(out)
+    assert relerr(outs[0], outs[1]) < 1e-6
+
+
+# (N, layer Cin, layer Cout, H, W, act of the BatchNorm the gradient passes): the projections' data gradients the streaming kernel takes
+# (few dy channels -> many outputs: features.1 / .2 / .3 at batch 16 are 16 -> 32 at 256^2, 24 -> 96 and 24 -> 144 at 128^2)
+PWS_DGRAD_CASES = [(2, 32, 16, 128, 128, ACT_NONE), (1, 96, 24, 96, 96, ACT_NONE), (2, 144, 24, 128, 64, ACT_NONE), (1, 144, 24, 96, 96, ACT_RELU6),
+                   (1, 160, 16, 64, 128, ACT_RELU)]
+
+
+@pytest.mark.parametrize("case", PWS_DGRAD_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_pointwise_streaming_dgrad(hip, case):
+    """the same kernel with a BatchNorm-backward source (dy formed on load from (g, y)) against conv_transpose2d in float64, and against
+    the LDS-staged kernel through sources that are not 16-byte aligned"""
+    N, cin, cout, H, W, act = case
+    g, y = rnd(N, cout, H, W, seed=31), rnd(N, cout, H, W, seed=32) * 2.0
+    w = rnd(cout, cin, 1, 1, seed=33, scale=0.2)
+    a, b = rnd(cout, seed=34) * 0.2 + 1, rnd(cout, seed=35) * 0.5
+    A, B, D = rnd(cout, seed=36), rnd(cout, seed=37) * 0.1, rnd(cout, seed=38) * 0.1
+    yh = (y * a[None, :, None, None] + b[None, :, None, None]).double()
+    ok = torch.ones_like(yh, dtype=torch.bool) if act == ACT_NONE else ((yh > 0) if act == ACT_RELU else ((yh > 0) & (yh < 6)))
+    dy = (torch.where(ok, g.double(), torch.zeros((), dtype=torch.float64)) * A.double()[None, :, None, None]
+          + B.double()[None, :, None, None] * y.double() + D.double()[None, :, None, None])
+    ref = F.conv_transpose2d(dy, w.double())
+    cst = torch.zeros(cout, SC_CST); cst[:, 0], cst[:, 1], cst[:, 2], cst[:, 3], cst[:, 4] = a, b, A, B, D
+    co_t = 32 if cin <= 32 else 64
+    wpk = pack(dev(w), co_t, 1)
+    gb, yb = torch.zeros(g.numel() + 4, device=DEV), torch.zeros(g.numel() + 4, device=DEV)
+    outs = []
+    for off in (0, 1):
+        gv, yv = gb[off:off + g.numel()].view_as(g), yb[off:off + g.numel()].view_as(g)
+        gv.copy_(dev(g)); yv.copy_(dev(y))
+        src = make_src(gv, cout, SRC_BNBWD, act=act, cst=dev(cst), aux=yv)
+        (out,), _ = conv_mfma([src], wpk, N, H, W, cin, 1, co_t)
+        assert relerr(out, ref) < TOL, relerr(out, ref)
         outs.append(out)
     assert relerr(outs[0], outs[1]) < 1e-6
 

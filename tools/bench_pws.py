@@ -38,3 +38,31 @@ for name, Cin, Cout, S, act in LAYERS:
     tot[0] += res[0]; tot[1] += res[1]
     print(f"{name:20s} {Cin:4d} -> {Cout:4d} @ {S}^2  {mb:6.0f} MB   streaming {res[0]:6.1f} us ({mb / res[0]:5.2f} TB/s)   LDS-staged {res[1]:6.1f} us ({mb / res[1]:5.2f} TB/s)")
 print(f"sum: streaming {tot[0]:.1f} us, LDS-staged {tot[1]:.1f} us   (the timings include the helper's statistics allocation when stats=1)")
+# ---- the projections' data gradients (BatchNorm-backward source: gradient + raw tensor read, few channels -> many)
+from starcop_amd._lib import SC_CST, SRC_BNBWD
+tot = [0.0, 0.0]
+for name, Cin, Cout, S in [("features.1 project dgrad", 32, 16, 256), ("features.2 project dgrad", 96, 24, 128), ("features.3 project dgrad", 144, 24, 128)]:
+    n = N * Cout * S * S
+    gb, yb = torch.randn(n + 4, generator=g).to(DEV), torch.randn(n + 4, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) * 0.2).to(DEV)
+    co_t = 32 if Cin <= 32 else 64
+    wpk = pack(w, co_t, 1)
+    cst = torch.zeros(Cout, SC_CST); cst[:, 0] = 1.0; cst[:, 2] = 1.0; cst[:, 3] = 0.01
+    cst = cst.to(DEV)
+    out = [torch.empty(N, Cin, S, S, device=DEV)]
+    res = []
+    for off in (0, 1):
+        src = make_src(gb[off:off + n].view(N, Cout, S, S), Cout, SRC_BNBWD, act=ACT_NONE, cst=cst, aux=yb[off:off + n].view(N, Cout, S, S))
+        for _ in range(3):
+            conv_mfma([src], wpk, N, S, S, Cin, 1, co_t, outs=out)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(30):
+            conv_mfma([src], wpk, N, S, S, Cin, 1, co_t, outs=out)
+        e1.record(); torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) / 30 * 1e3)
+    mb = N * (2 * Cout + Cin) * S * S * 4 / 1e6
+    tot[0] += res[0]; tot[1] += res[1]
+    print(f"{name:26s} {Cout:4d} -> {Cin:4d} @ {S}^2  {mb:6.0f} MB   streaming {res[0]:6.1f} us ({mb / res[0]:5.2f} TB/s)   LDS-staged {res[1]:6.1f} us ({mb / res[1]:5.2f} TB/s)")
+print(f"data gradients: streaming {tot[0]:.1f} us, LDS-staged {tot[1]:.1f} us")
