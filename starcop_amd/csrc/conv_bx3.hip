@@ -1355,14 +1355,19 @@ __device__ __forceinline__ void split_filter(float v, bool half, unsigned short 
 //   D: lane -> pixel l&15, couts 4*(l>>4) .. +3
 // Work-group = 4 waves, tile 8 rows x 32 px; wave = 2 rows = four 16-pixel blocks.  Single source (may be upsampled), single
 // output, optional statistics rows (SC_STAT_CONV3 layout); anything else stays on the other kernels.
-template <int CIN, bool BNB>
+// UPS: the source is the nearest-neighbour 2x up-sampling of a half-resolution tensor (decoder.blocks.4.conv1) and the patch is staged
+// AT THE SOURCE RESOLUTION -- 6 x (TW/2 + 2) entries per channel group instead of 10 x (TW + 2): every source value is requested,
+// run through the prologue, split and written to LDS once instead of 3.1 times (the staging was more VALU work than the kernel's MFMAs);
+// the operand reads address the source entry of their output pixel: row (r + 1) >> 1, column (c + 1) >> 1 of the patch (tile origins
+// are even, so output row / column -1 and H / W fall on source -1 and H/2 / W/2: the same zero padding).
+template <int CIN, bool BNB, bool UPS = false>
 __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
   // Tile 8 rows x TW px.  16 input channels: TW = 64 -- the runs a work-group reads and writes per (plane, row) are 264 / 256 B instead
   // of 136 / 128 B, worth 14-17 % at 16 x 512^2 (forward 177 -> 152 us, backward 269 -> 224 us; these layers run at 3 TB/s and neither the
   // MFMAs -- removed: same time -- nor exposed latency -- persistent work-groups with the next patch in flight: same time -- limit them:
   // what is left is how DRAM likes the access pattern).  32 channels: the 85 KB patch would leave one work-group per CU (205 -> 308 us).
   constexpr int TW = CIN == 16 ? 64 : 32, PBW = TW / 16, NPB = 2 * PBW;
-  constexpr int PR = 10, PC = TW + 2, NPX = PR * PC;
+  constexpr int PR = UPS ? 6 : 10, PC = UPS ? TW / 2 + 2 : TW + 2, NPX = PR * PC;
   constexpr int NH = CIN / 8;                 // 8-channel groups
   constexpr int NG = 9 * NH, NS = (NG + 3) / 4;
   // Pitch between the 8-channel groups: a multiple of 16 entries (256 B).  ds_read_b128 is serviced in four NON-contiguous 16-lane
@@ -1408,7 +1413,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
   const int grp = __builtin_amdgcn_readfirstlane(wave / WPG);
   const int g8 = grp * 8;
   const int e0 = tid - grp * TPG;
-  const int up = src.up;
+  const int up = UPS ? 1 : src.up;
   const int Ws = W >> up;
   const size_t plane = (size_t)(H >> up) * Ws;
   // (operand scale -- and for forward sources the clamp -- folded into the constants, see split2h)
@@ -1421,10 +1426,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
   for (int r = 0; r < NR; ++r) {
     const int e = e0 + TPG * r;
     const int pr = e / PC, pc = e - pr * PC;
-    const int y = y0 - 1 + pr, x = x0 - 1 + pc;
-    const bool ok = (e < NPX) && y >= 0 && y < H && x >= 0 && x < W;
+    // (UPS: y, x are SOURCE coordinates and the patch covers source rows y0/2 - 1 .. y0/2 + 4)
+    const int y = UPS ? (y0 >> 1) - 1 + pr : y0 - 1 + pr, x = UPS ? (x0 >> 1) - 1 + pc : x0 - 1 + pc;
+    const bool ok = UPS ? ((e < NPX) && y >= 0 && y < (H >> 1) && x >= 0 && x < Ws) : ((e < NPX) && y >= 0 && y < H && x >= 0 && x < W);
     okv[r] = ok;
-    const unsigned off = ok ? (unsigned)((y >> up) * Ws + (x >> up)) : 0u;
+    const unsigned off = ok ? (UPS ? (unsigned)(y * Ws + x) : (unsigned)((y >> up) * Ws + (x >> up))) : 0u;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       xv[r][j] = xg[(size_t)j * plane + off];
@@ -1478,7 +1484,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
     const int kh = tap / 3, kw = tap - 3 * kh;
 #pragma unroll
     for (int pb = 0; pb < NPB; ++pb) {
-      const int e = (2 * wave + pb / PBW + kh) * PC + 16 * (pb % PBW) + l15 + kw;
+      const int e = UPS ? ((2 * wave + pb / PBW + kh + 1) >> 1) * PC + ((16 * (pb % PBW) + l15 + kw + 1) >> 1)
+                        : (2 * wave + pb / PBW + kh) * PC + 16 * (pb % PBW) + l15 + kw;
       const halfx8 b0 = __builtin_bit_cast(halfx8, s_p[0][half][e]);
       const halfx8 b1 = __builtin_bit_cast(halfx8, s_p[1][half][e]);
       const halfx8 a0 = __builtin_bit_cast(halfx8, A[s][0]);
@@ -1587,6 +1594,167 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// decoder.blocks.4.conv1 (32 -> <= 16 channels, source = nearest 2x up-sampling of a half-resolution tensor) as FOUR 2x2 convolutions
+// on the half-resolution source -- the sub-pixel form of conv_sp.hip on the thin layer's 16x16x32 MFMA.  Output pixel (2y + py, 2x + px)
+// sees, through its 3 x 3 window on the up-sampled image, only the 2 x 2 source pixels (y + py - 1 + sy, x + px - 1 + sx), sy, sx in
+// {0, 1}; the filter of slot (sy, sx) of phase (py, px) is the sum of the taps that land on that source pixel (kh: py = 0 -> {0}, {1, 2};
+// py = 1 -> {0, 1}, {2}; kw alike) -- summed in fp32 and split by the pack (entries behind the 3 x 3 ones, pack_thin_item).
+//   16 MFMA K steps (4 phases x 4 slots) per 16 source pixels = 64 output pixels instead of 4 x 9: 2.25x fewer MFMAs, and each of the
+//   nine source positions is read from LDS ONCE per 16 source pixels for all the phases that use it: 4.5x fewer operand reads
+//   (k_conv3_thin_h spent 61 us of LDS reads and 46 us of MFMAs on this layer at 16 x 512^2 beside its 95 us of memory traffic);
+//   the patch is staged at source resolution (6 x 34 entries per 8-channel group: every source value prologue'd and split once).
+//   B: lane (n = l&15, lg = l>>4) -> source pixel n of the wave's 16-pixel block, channels 8 lg .. +7; D: lane -> couts 4 lg + r of that
+//   source pixel, one accumulator per phase: the two px phases of a row make one 8-byte store (output columns 2x, 2x + 1).
+// Work-group = 4 waves, output tile 8 rows x 64 columns = source 4 x 32; wave w = source row w, two blocks of 16 source pixels.
+// Statistics rows as k_conv3_thin_h (SC_STAT_CONV3: 4 rows x 32 pixels).
+__global__ __launch_bounds__(256, 2) void k_conv3_thin_sp(const ConvXP p) {
+  constexpr int PC = 34, NPX = 6 * PC, NPXP = (NPX + 15) & ~15, NH = 4, NR = (NPX + 63) / 64, STEPS3 = 9;
+  __shared__ uintx4 s_p[2][NH][NPXP];
+  __shared__ float s_red[4][2][16][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int H = p.H, W = p.W, Hs = H >> 1, Ws = W >> 1;
+  const int tiles_x = (W + 63) >> 6;
+  int n, tile;
+  if (p.xcdmap) {      // each XCD walks a contiguous eighth of the pixel tiles (see k_conv3_bx3)
+    const int per_img = tiles_x * ((H + 7) >> 3), total = per_img * p.N, per_xcd = (total + 7) >> 3;
+    const int j = blockIdx.x >> 3, pt = (blockIdx.x & 7) * per_xcd + j;
+    if (j >= per_xcd || pt >= total) return;
+    n = pt / per_img; tile = pt - n * per_img;
+  } else {
+    n = blockIdx.z; tile = blockIdx.x;
+  }
+  n = __builtin_amdgcn_readfirstlane(n); tile = __builtin_amdgcn_readfirstlane(tile);
+  const int ty = __builtin_amdgcn_readfirstlane(tile / tiles_x), tx = tile - ty * tiles_x;
+  const int y0 = ty * 8, x0 = tx * 64;
+  const float hsx = h_act_scale(p.xb0, p.xb1);
+  const float hinv = 1.f / (hsx * SC_H_SW);
+  const SrcD& src = p.s0;
+
+  // ---- stage the source patch: wave = one 8-channel group, lanes = consecutive patch entries (k_conv3_thin_h)
+  const int g8 = wave * 8;
+  const size_t plane = (size_t)Hs * Ws;
+  const float slo = h_lo(sc_act_lo(src.act), hsx), shi = h_hi(sc_act_hi(src.act), hsx);
+  float xv[NR][8];
+  bool okv[NR];
+  const float* const xg = src.x + ((size_t)n * 32 + g8) * plane;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int e = lane + 64 * r;
+    const int pr = e / PC, pc = e - pr * PC;
+    const int y = (y0 >> 1) - 1 + pr, x = (x0 >> 1) - 1 + pc;
+    const bool ok = (e < NPX) && y >= 0 && y < Hs && x >= 0 && x < Ws;
+    okv[r] = ok;
+    const unsigned off = ok ? (unsigned)(y * Ws + x) : 0u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xv[r][j] = xg[(size_t)j * plane + off];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float2 cc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cc[j] = make_float2(hsx, 0.f);
+  if (src.mode != SC_SRC_RAW) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      cc[j] = *reinterpret_cast<const float2*>(src.cst + (size_t)(g8 + j) * SC_CST);
+      cc[j].x *= hsx; cc[j].y *= hsx;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int e = lane + 64 * r;
+    uintx4 t0, t1;
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+      const float v0 = okv[r] ? sc_pro_affine_h(xv[r][2 * jp], cc[2 * jp].x, cc[2 * jp].y, slo, shi) : 0.f;
+      const float v1 = okv[r] ? sc_pro_affine_h(xv[r][2 * jp + 1], cc[2 * jp + 1].x, cc[2 * jp + 1].y, slo, shi) : 0.f;
+      unsigned a0, a1;
+      split2h<false>(v0, v1, a0, a1);
+      t0[jp] = a0; t1[jp] = a1;
+    }
+    if (e < NPX) { s_p[0][wave][e] = t0; s_p[1][wave][e] = t1; }
+  }
+  // the phase filters (16 K steps x 2 terms, behind the 3 x 3 entries of the pack), requested while the patch settles
+  uintx4 A[16][2];
+#pragma unroll
+  for (int s = 0; s < 16; ++s)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) A[s][t] = p.wpk[((STEPS3 + s) * 2 + t) * 64 + lane];
+  __syncthreads();
+
+  floatx4 acc[2][4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) acc[q][ph] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int dyi = 0; dyi < 3; ++dyi)
+#pragma unroll
+    for (int dxi = 0; dxi < 3; ++dxi)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int e = (wave + dyi) * PC + 16 * q + l15 + dxi;
+        const halfx8 b0 = __builtin_bit_cast(halfx8, s_p[0][lg][e]);
+        const halfx8 b1 = __builtin_bit_cast(halfx8, s_p[1][lg][e]);
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+          const int sy = dyi - py;                          // source row offset dyi - 1 = py - 1 + sy
+          if (sy < 0 || sy > 1) continue;
+#pragma unroll
+          for (int px = 0; px < 2; ++px) {
+            const int sx = dxi - px;
+            if (sx < 0 || sx > 1) continue;
+            const int ph = 2 * py + px, s = 4 * ph + 2 * sy + sx;
+            const halfx8 a0 = __builtin_bit_cast(halfx8, A[s][0]);
+            const halfx8 a1 = __builtin_bit_cast(halfx8, A[s][1]);
+            acc[q][ph] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, acc[q][ph], 0, 0, 0);
+            acc[q][ph] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, acc[q][ph], 0, 0, 0);
+            acc[q][ph] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc[q][ph], 0, 0, 0);
+          }
+        }
+      }
+
+  // ---- epilogue: 8-byte stores (the two px phases), per-cout sums of the wave's 2 output rows x 32 columns per block
+  const size_t HWs = (size_t)H * W;
+  const bool want_stats = p.stats != nullptr;
+  float* const outn = p.out0 + (size_t)n * p.Cout * HWs;
+  const unsigned HWu = (unsigned)HWs;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co = 4 * lg + r;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float sv = 0.f, sq = 0.f;
+      const int ox = x0 + 32 * q + 2 * l15;
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+        const int oy = y0 + 2 * wave + py;
+        const bool ok = oy < H && ox < W && co < p.Cout;     // (W is even: columns ox, ox + 1 are inside or outside together)
+        const float v0 = ok ? acc[q][2 * py][r] * hinv : 0.f, v1 = ok ? acc[q][2 * py + 1][r] * hinv : 0.f;
+        sv += v0 + v1; sq = fmaf(v0, v0, fmaf(v1, v1, sq));
+        if (ok) *reinterpret_cast<float2*>(reinterpret_cast<char*>(outn) + ((unsigned)co * HWu + (unsigned)(oy * W + ox)) * 4u) = make_float2(v0, v1);
+      }
+      if (want_stats) {
+        sv = row_sum16(sv); sq = row_sum16(sq);
+        if (l15 == 0) { s_red[wave][q][co][0] = sv; s_red[wave][q][co][1] = sq; }
+      }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    const int rows4 = (H + 3) >> 2, tiles32 = (W + 31) >> 5;
+    if (tid < 2 * 2 * 16 * 2) {
+      const int hh = tid / 64, h = (tid >> 5) & 1, col = (tid >> 1) & 15, k = tid & 1;
+      const int t4 = 2 * ty + hh, t32 = 2 * tx + h;
+      if (col < p.Cout && t4 < rows4 && t32 < tiles32) {
+        const size_t row = ((size_t)n * rows4 + t4) * tiles32 + t32;
+        p.stats[(row * p.Cout + col) * 2 + k] = s_red[2 * hh][h][col][k] + s_red[2 * hh + 1][h][col][k];
+      }
+    }
+  }
+}
+
 // filters of a thin layer in the register layout of k_conv3_thin_h: entry ((s*2 + term)*64 + lane) of 8 halves
 __device__ __forceinline__ void pack_thin_item(const float* __restrict__ w, unsigned short* __restrict__ out, size_t i, int Cout, int Cin,
                                                int tflip) {
@@ -1597,7 +1765,19 @@ __device__ __forceinline__ void pack_thin_item(const float* __restrict__ w, unsi
   const int s = (int)(i >> 9);
   const int m = lane & 15, gi = 4 * s + (lane >> 4);
   float v = 0.f;
-  if (gi < NG && m < M) {
+  const int steps3 = (NG + 3) / 4;
+  if (s >= steps3) {
+    // the 16 phase filters of k_conv3_thin_sp (forward, 32 input channels): step = 4 * (2 py + px) + 2 sy + sx, value = the fp32 sum of the
+    // taps (kh, kw) whose up-sampled position falls on source pixel (py - 1 + sy, px - 1 + sx)
+    const int sp = s - steps3, ph = sp >> 2, py = ph >> 1, px = ph & 1, sy = (sp >> 1) & 1, sx = sp & 1;
+    const int kh0 = (py == 0) ? (sy == 0 ? 0 : 1) : (sy == 0 ? 0 : 2), kh1 = (py == 0) ? (sy == 0 ? 0 : 2) : (sy == 0 ? 1 : 2);
+    const int kw0 = (px == 0) ? (sx == 0 ? 0 : 1) : (sx == 0 ? 0 : 2), kw1 = (px == 0) ? (sx == 0 ? 0 : 2) : (sx == 0 ? 1 : 2);
+    const int k = (lane >> 4) * 8 + j;
+    if (m < M) {
+      for (int kh = kh0; kh <= kh1; ++kh)
+        for (int kw = kw0; kw <= kw1; ++kw) v += w[((size_t)m * K + k) * 9 + kh * 3 + kw];
+    }
+  } else if (gi < NG && m < M) {
     const int tap = gi / NH, k = (gi - tap * NH) * 8 + j;
     v = tflip ? w[((size_t)k * M + m) * 9 + (8 - tap)] : w[((size_t)m * K + k) * 9 + tap];
   }
@@ -2707,7 +2887,11 @@ extern "C" int sc_conv3x3_wgrad_thin16(const sc_wgrad_args* a, sc_stream stream)
   return sc_wgrad_finish(a->part, p.nsl, 9, a->Cout, a->Cin, 16, a->Cin, a->dw, st);
 }
 
-static int thin_steps(int Cout, int Cin, int transpose_flip) { return (9 * ((transpose_flip ? Cout : Cin) / 8) + 3) / 4; }
+// K steps of the pack: the 3 x 3 filter's, and for the forward filter of a 32-channel layer the 16 phase steps of k_conv3_thin_sp behind them
+static int thin_steps(int Cout, int Cin, int transpose_flip) {
+  const int K = transpose_flip ? Cout : Cin;
+  return (9 * (K / 8) + 3) / 4 + ((!transpose_flip && K == 32) ? 16 : 0);
+}
 
 extern "C" size_t sc_packed_weight_floats_thin16(int Cout, int Cin, int transpose_flip) {
   return (size_t)thin_steps(Cout, Cin, transpose_flip) * 2 * 64 * 4;       // 16-byte entries -> floats
@@ -2751,7 +2935,9 @@ extern "C" int sc_conv3x3_thin16(const sc_conv_args* a, sc_stream stream) {
   set_bnr(p, a->bnr);
   SC_REQUIRE(!a->bnr || (s.mode == SC_SRC_BNBWD && a->bnr->y && a->bnr->cst && a->bnr->rows && !a->stats),
              "sc_conv3x3_thin16: bnr needs a BNBWD source, y / cst / rows and no stats");
-  const int tw = Cin == 16 ? 64 : 32;                     // (k_conv3_thin_h: TW)
+  static const bool sp_off = [] { const char* e = getenv("STARCOP_THIN_SP"); return e && atoi(e) == 0; }();       // (same-box A/B)
+  const bool thin_sp = Cin == 32 && s.up == 1 && s.mode != SC_SRC_BNBWD && !sp_off;      // the sub-pixel form (k_conv3_thin_sp)
+  const int tw = (Cin == 16 || thin_sp) ? 64 : 32;        // (k_conv3_thin_h: TW)
   dim3 grid(((a->W + tw - 1) / tw) * ((a->H + 7) / 8), 1, a->N);
   constexpr int xcdmap_env = 2;
   p.xcdmap = xcdmap_env ? 2 : 0;
@@ -2761,7 +2947,10 @@ extern "C" int sc_conv3x3_thin16(const sc_conv_args* a, sc_stream stream) {
   }
   hipStream_t st = (hipStream_t)stream;
   const bool bnb = s.mode == SC_SRC_BNBWD;
-  if (Cin == 16) { if (bnb) hipLaunchKernelGGL((k_conv3_thin_h<16, true>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((k_conv3_thin_h<16, false>), grid, dim3(256), 0, st, p); }
+  static const bool ups_off = [] { const char* e = getenv("STARCOP_THIN_UPS"); return e && atoi(e) == 0; }();      // (same-box A/B)
+  if (thin_sp) hipLaunchKernelGGL(k_conv3_thin_sp, grid, dim3(256), 0, st, p);
+  else if (Cin == 16) { if (bnb) hipLaunchKernelGGL((k_conv3_thin_h<16, true>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((k_conv3_thin_h<16, false>), grid, dim3(256), 0, st, p); }
+  else if (s.up == 1 && !bnb && !ups_off) hipLaunchKernelGGL((k_conv3_thin_h<32, false, true>), grid, dim3(256), 0, st, p);
   else           { if (bnb) hipLaunchKernelGGL((k_conv3_thin_h<32, true>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((k_conv3_thin_h<32, false>), grid, dim3(256), 0, st, p); }
   SC_LAUNCH_OK("sc_conv3x3_thin16");
   return SC_OK;

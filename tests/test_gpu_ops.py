@@ -992,7 +992,7 @@ def test_masks_bit_exact(hip):
 
 
 @pytest.mark.parametrize("gscale", [1.0, 1e-6])
-@pytest.mark.parametrize("cin,cout,H,W,up", [(16, 16, 36, 70, 0), (32, 16, 24, 40, 1), (16, 9, 8, 33, 0), (32, 16, 64, 64, 0)])
+@pytest.mark.parametrize("cin,cout,H,W,up", [(16, 16, 36, 70, 0), (32, 16, 24, 40, 1), (16, 9, 8, 33, 0), (32, 16, 64, 64, 0), (32, 16, 64, 96, 1), (32, 11, 10, 34, 1)])
 def test_conv_thin16_two_fp16_terms(hip, cin, cout, H, W, up, gscale):
     """sc_conv3x3_thin16 (decoder.blocks.4: filters in registers, one staging pass, v_mfma_f32_16x16x32_f16): forward with
     BatchNorm/ReLU prologue (+ nearest x2 upsampling) and statistics rows, and backward-data from transposed filters with the
