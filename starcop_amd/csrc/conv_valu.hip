@@ -1017,6 +1017,105 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const SrcD in, const float* __
   }
 }
 
+// The 4-channel stem (the HyperSTARCOP input) on v_mfma_f32_16x16x4_f32: K step = one filter tap, lane group kq = input channel, and the
+// PIXELS PERMUTED as in k_pw_stream (conv_mfma.hip) -- lane (n, kq): output row 2*wave + (n >> 3), columns 4*(n & 7) + j for MFMA j --
+// so that a lane ends with four consecutive output pixels of its couts: 16-byte stores instead of one 4-byte store per (cout, pixel),
+// and 72 MFMAs per 64 pixels instead of 1152 FMAs per pixel on the VALU (which alone was 31 us at 16 x 512^2 against 25 us of traffic).
+// Same tile (8 x 32 outputs), grid, patch staging and statistics rows as k_stem_fwd<4>; the patch's channel pitch is 1 (mod 64) words
+// so that the 64 lanes of an operand read (stride 8 words along n, two rows, four channels) fall into 64 different banks.
+__global__ __launch_bounds__(256) void k_stem_fwd4m(const SrcD in, const float* __restrict__ w, float* __restrict__ out,
+                                                   int Cin, int Hin, int Win, int Hout, int Wout, float* stats) {
+  constexpr int PS = 65, PSP = 66, NE = 17 * PS, NIT = (NE + 255) / 256, CP = 17 * PSP + 31;       // 1153 = 1 (mod 64)
+  static_assert(CP % 64 == 1, "channel pitch");
+  __shared__ float s_in[4 * CP];
+  __shared__ float s_red[4][STEM_CO][2];
+  const int n = blockIdx.z;
+  const int tiles_x = (Wout + 31) >> 5;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n16 = lane & 15, kq = lane >> 4;
+  // the filter: A[cb][tap] = w[16 cb + n16][kq][tap]  (channels past Cin: zeros)
+  float A[2][9];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) A[cb][t] = kq < Cin ? w[((cb * 16 + n16) * Cin + kq) * 9 + t] : 0.f;
+  {
+    const int iy0 = ty * 16 - 1, ix0 = tx * 64 - 1;
+    float raw[4][NIT];
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+      const float* xb = in.x + ((size_t)n * Cin + (ci < Cin ? ci : 0)) * Hin * Win;
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int e = threadIdx.x + i * 256;
+        const int r = e / PS, cc = e - r * PS;
+        const int iy = iy0 + r, ix = ix0 + cc;
+        const bool inb = (e < NE) && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+        raw[ci][i] = xb[inb ? (size_t)iy * Win + ix : 0];
+      }
+    }
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+      float4 c0 = make_float4(1.f, 0.f, 0.f, 0.f); float c4 = 0.f;
+      if (in.mode != SC_SRC_RAW && ci < Cin) { c0 = *reinterpret_cast<const float4*>(in.cst + (size_t)ci * SC_CST); c4 = in.cst[(size_t)ci * SC_CST + 4]; }
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int e = threadIdx.x + i * 256;
+        const int r = e / PS, cc = e - r * PS;
+        const int iy = iy0 + r, ix = ix0 + cc;
+        const bool inb = iy >= 0 && iy < Hin && ix >= 0 && ix < Win && ci < Cin;
+        const float t = (in.mode == SC_SRC_RAW) ? raw[ci][i] : sc_prologue(in.mode, in.act, raw[ci][i], 0.f, c0, c4);
+        if (e < NE) s_in[ci * CP + r * PSP + cc] = inb ? t : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  const int orow = 2 * wave + (n16 >> 3), ocol = 4 * (n16 & 7);
+  floatx4 acc[2][4];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[cb][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  const float* sp = s_in + kq * CP + (2 * orow) * PSP + 2 * ocol;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      float b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = sp[kh * PSP + 2 * j + kw];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[cb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[cb][kh * 3 + kw], b[j], acc[cb][j], 0, 0, 0);
+    }
+  const int oy = ty * 8 + orow, ox = tx * 32 + ocol;
+  const bool ok = (oy < Hout) && (ox < Wout);                 // (Wout % 4 == 0: the four columns are inside or outside together)
+  const size_t HWo = (size_t)Hout * Wout;
+  float* ob = out + (size_t)n * STEM_CO * HWo + (size_t)oy * Wout + ox;
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = cb * 16 + 4 * kq + r;
+      const float4 o = make_float4(acc[cb][0][r], acc[cb][1][r], acc[cb][2][r], acc[cb][3][r]);
+      if (ok) *reinterpret_cast<float4*>(ob + (size_t)co * HWo) = o;
+      if (stats) {
+        float sv = ok ? (o.x + o.y) + (o.z + o.w) : 0.f;
+        float sq = ok ? fmaf(o.x, o.x, fmaf(o.y, o.y, fmaf(o.z, o.z, o.w * o.w))) : 0.f;
+        sv = row_sum16(sv); sq = row_sum16(sq);
+        if (n16 == 0) { s_red[wave][co][0] = sv; s_red[wave][co][1] = sq; }
+      }
+    }
+  if (stats) {
+    __syncthreads();
+    if (threadIdx.x < STEM_CO * 2) {
+      const int co = threadIdx.x >> 1, k = threadIdx.x & 1;
+      stats[(stat_row() * STEM_CO + co) * 2 + k] = (s_red[0][co][k] + s_red[1][co][k]) + (s_red[2][co][k] + s_red[3][co][k]);
+    }
+  }
+}
+
 // dW[co][ci][tap] = sum dy[co][oy][ox] * in[ci][2oy+kh-1][2ox+kw-1] as a GEMM on v_mfma_f32_16x16x4_f32:
 //   D[co][j] (j = ci*9+tap, padded to 16*NJB) = sum_px A[co][px] * B[px][j];  A = dy tile (BatchNorm/ReLU6 backward
 //   applied on load), B gathered from the normalised input patch (lane j carries its own (ci,kh,kw) offset).
@@ -1802,7 +1901,10 @@ extern "C" int sc_stem_conv_fwd(const sc_src* in, const float* w, float* out, in
   SC_REQUIRE(in->mode != SC_SRC_BNBWD && in->up == 0, "sc_stem_conv_fwd: unsupported source mode");
   const int Hout = (Hin - 1) / 2 + 1, Wout = (Win - 1) / 2 + 1;
   dim3 grid(((Wout + 31) / 32) * ((Hout + 7) / 8), 1, N);
-  if (Cin <= 4) hipLaunchKernelGGL(k_stem_fwd<4>, grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), w, out, Cin, Hin, Win, Hout, Wout, stats);
+  static const bool mfma_off = [] { const char* e = getenv("STARCOP_STEM_MFMA"); return e && atoi(e) == 0; }();      // (same-box A/B)
+  if (Cin <= 4 && !mfma_off && Wout % 4 == 0 && ((uintptr_t)out & 15) == 0)
+    hipLaunchKernelGGL(k_stem_fwd4m, grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), w, out, Cin, Hin, Win, Hout, Wout, stats);
+  else if (Cin <= 4) hipLaunchKernelGGL(k_stem_fwd<4>, grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), w, out, Cin, Hin, Win, Hout, Wout, stats);
   else hipLaunchKernelGGL(k_stem_fwd<STEM_MAXCI>, grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*in), w, out, Cin, Hin, Win, Hout, Wout, stats);
   SC_LAUNCH_OK("sc_stem_conv_fwd");
   return SC_OK;

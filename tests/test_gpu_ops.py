@@ -687,6 +687,45 @@ def test_depthwise_finalizes_its_batchnorm_in_the_launch(hip, N, C_, H, W, strid
     assert abs(a_[5] - b_[5]) <= 1e-6 * a_[5]
 
 
+@pytest.mark.parametrize("case", [(2, 4, 64, 96, "norm"), (1, 4, 130, 80, "raw"), (1, 3, 34, 200, "affine"), (2, 4, 17, 102, "norm"), (1, 1, 64, 64, "raw")],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_stem_forward_shapes(hip, case):
+    """the MFMA form of the <= 4-channel stem (k_stem_fwd4m: permuted pixels, 16-byte stores; taken when the output width is a multiple of
+    4 and the output 16-byte aligned) and the VALU form (the same input through an output that is not 16-byte aligned) against
+    F.conv2d(stride 2) of the prologue'd input in float64; statistics rows against the sums of the output"""
+    N, Cin, H, W, mode = case
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x, w = rnd(N, Cin, H, W, seed=41) * 2.0, rnd(32, Cin, 3, 3, seed=42, scale=0.3)
+    cst = torch.zeros(Cin, SC_CST)
+    if mode == "norm":
+        cst[:, 0], cst[:, 1], cst[:, 2], cst[:, 3] = 0.1, rnd(Cin, seed=43).abs() + 0.5, -1.0, 1.5
+        xa = torch.clamp((x.double() - 0.1) / cst[:, 1].double()[None, :, None, None], -1.0, 1.5)
+        src_of = lambda t: make_src(t, Cin, SRC_NORM, cst=dev(cst))
+    elif mode == "affine":
+        sc, sh = rnd(Cin, seed=44) * 0.3 + 1, rnd(Cin, seed=45) * 0.2
+        xa = F.relu(x.double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+        src_of = lambda t: make_src(t, Cin, SRC_AFFINE, act=ACT_RELU, cst=cst_affine(sc, sh))
+    else:
+        xa = x.double()
+        src_of = lambda t: make_src(t, Cin, SRC_RAW)
+    ref = F.conv2d(xa, w.double(), stride=2, padding=1)
+    xd, wd = dev(x), dev(w)
+    rows = hip.sc_stat_rows(STAT_STEM, N, Ho, Wo)
+    obuf = torch.zeros(N * 32 * Ho * Wo + 4, device=DEV)
+    outs = []
+    for off in (0, 1):
+        out = obuf[off:off + N * 32 * Ho * Wo].view(N, 32, Ho, Wo)
+        out.fill_(float("nan"))
+        stats = torch.full((rows, 32, 2), float("nan"), device=DEV)
+        check(hip.sc_stem_conv_fwd(C.byref(src_of(xd)), ptr(wd), ptr(out), N, Cin, H, W, ptr(stats), stream()))
+        assert relerr(out, ref) < TOL, relerr(out, ref)
+        st = stats.double().sum(0)
+        assert relerr(st[:, 0], out.double().sum((0, 2, 3))) < 1e-5
+        assert relerr(st[:, 1], (out.double() ** 2).sum((0, 2, 3))) < 1e-5
+        outs.append(out.clone())
+    assert relerr(outs[0], outs[1]) < 1e-5
+
+
 def test_stem_fused_normalizer(hip):
     """stem conv reads raw products and applies clamp((x-off)/fac, lo, hi) on load (normalizer_module.py:134)."""
     N, Cin, H, W = 2, 4, 64, 96
