@@ -1755,6 +1755,149 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_sp(const ConvXP p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The data gradient of decoder.blocks.4.conv1 (16 -> 32 channels, stored at HALF resolution: the backward of the nearest 2x up-sampling
+// is the 2 x 2 sum) in the sub-pixel form: a source pixel (ys, xs) feeds the output pixels (2 ys + a', 2 xs + b') through the taps that
+// land on it, so its gradient gathers dy over the 4 x 4 window  a, b in {-1, 0, 1, 2}:
+//     dx[ci][ys][xs] = sum_{a, b, co} Wd[a][b][ci][co] * dy[co][2 ys + a][2 xs + b],   Wd[a][b] = sum_{kh in S(a), kw in S(b)} w[co][ci][kh][kw],
+//     S(-1) = {2}, S(0) = {1, 2}, S(1) = {0, 1}, S(2) = {0}
+// -- K = 16 positions x 16 channels = 8 steps of the 16x16x32 MFMA for 2 x 16 output rows instead of four output pixels x 9 taps
+// (2.25x fewer MFMAs than sc_conv3x3_bx3 with down0, which also leaves every other lane idle in its summing store), and every dy
+// entry is read from LDS once.  The filters Wd are summed in fp32 and split by the pack (pack_thin_item, transpose_flip with 32 input
+// channels).  dy = the BatchNorm-backward source (g, y) formed on load as in k_conv3_thin_h<16, true>.
+//   A: lane (m = l&15, lg) -> Wd[pos = 2 s + (lg >> 1)][ci = 16 mb + m][co = 8 (lg & 1) .. +7];  B: lane (n, lg) -> dy entry of source
+//   pixel n at that position, channel half lg & 1.  The patch (10 rows x 66 columns at full resolution) is stored with its columns
+//   DE-INTERLEAVED by parity, so the 16 source pixels of a block read 16 consecutive entries (stride-2 columns otherwise).
+// Work-group = 4 waves, source tile 4 rows x 32 columns (= 8 x 64 of dy); wave w = source row w, two blocks of 16 source pixels.
+__global__ __launch_bounds__(256, 2) void k_conv3_thin_spd(const ConvXP p) {
+  constexpr int PR = 10, PC = 66, NPX = PR * PC, PCH = 34, NPL = PR * PCH, NPLP = (NPL + 15) & ~15;      // per parity plane: 10 x 34 entries
+  constexpr int TPG = 128, NR = (NPX + TPG - 1) / TPG;
+  __shared__ uintx4 s_p[2][2][2][NPLP];          // [term][channel half][column parity][row * 34 + column / 2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int H = p.H, W = p.W, Hs = H >> 1, Ws = W >> 1;
+  const int tiles_x = (W + 63) >> 6;
+  int n, tile;
+  if (p.xcdmap) {
+    const int per_img = tiles_x * ((H + 7) >> 3), total = per_img * p.N, per_xcd = (total + 7) >> 3;
+    const int j = blockIdx.x >> 3, pt = (blockIdx.x & 7) * per_xcd + j;
+    if (j >= per_xcd || pt >= total) return;
+    n = pt / per_img; tile = pt - n * per_img;
+  } else {
+    n = blockIdx.z; tile = blockIdx.x;
+  }
+  n = __builtin_amdgcn_readfirstlane(n); tile = __builtin_amdgcn_readfirstlane(tile);
+  const int ty = __builtin_amdgcn_readfirstlane(tile / tiles_x), tx = tile - ty * tiles_x;
+  const int y0 = ty * 8, x0 = tx * 64;                       // full-resolution origin of the tile (source origin y0 / 2, x0 / 2)
+  const float hsx = h_grad_scale(p.absmax);
+  const float hinv = 1.f / (hsx * SC_H_SW);
+  const SrcD& src = p.s0;
+
+  // ---- stage dy: two waves per 8-channel group, lanes = consecutive patch pixels (k_conv3_thin_h<16, true>)
+  const int grp = __builtin_amdgcn_readfirstlane(wave >> 1);
+  const int g8 = grp * 8;
+  const int e0 = tid - grp * TPG;
+  const size_t plane = (size_t)H * W;
+  const float slo = sc_act_lo(src.act), shi = sc_act_hi(src.act);
+  float xv[NR][8], av[NR][8];
+  bool okv[NR];
+  const float* const xg = src.x + ((size_t)n * 16 + g8) * plane;
+  const float* const ag = src.aux + ((size_t)n * 16 + g8) * plane;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int e = e0 + TPG * r;
+    const int pr = e / PC, pc = e - pr * PC;
+    const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+    const bool ok = (e < NPX) && y >= 0 && y < H && x >= 0 && x < W;
+    okv[r] = ok;
+    const unsigned off = ok ? (unsigned)(y * W + x) : 0u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { xv[r][j] = xg[(size_t)j * plane + off]; av[r][j] = ag[(size_t)j * plane + off]; }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float4 cc[8]; float c4[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    cc[j] = *reinterpret_cast<const float4*>(src.cst + (size_t)(g8 + j) * SC_CST);
+    c4[j] = src.cst[(size_t)(g8 + j) * SC_CST + 4];
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int e = e0 + TPG * r;
+    const int pr = e / PC, pc = e - pr * PC;
+    uintx4 t0, t1;
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+      float v[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = 2 * jp + h;
+        const float t = sc_pro_bnbwd(xv[r][j], av[r][j], cc[j].x, cc[j].y, cc[j].z, cc[j].w, c4[j], slo, shi);
+        v[h] = okv[r] ? t * hsx : 0.f;
+      }
+      unsigned a0, a1;
+      split2h<true>(v[0], v[1], a0, a1);
+      t0[jp] = a0; t1[jp] = a1;
+    }
+    if (e < NPX) { const int d = pr * PCH + (pc >> 1); s_p[0][grp][pc & 1][d] = t0; s_p[1][grp][pc & 1][d] = t1; }
+  }
+  // the gathered filters: 8 K steps x 2 row blocks x 2 terms
+  uintx4 A[8][2][2];
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) A[s][mb][t] = p.wpk[(((s * 2 + mb) * 2) + t) * 64 + lane];
+  __syncthreads();
+
+  floatx4 acc[2][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) acc[q][mb] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  // step s: positions 2 s, 2 s + 1 -> row a = (s >> 1) - 1, columns b = 2 (s & 1) - 1 + (lg >> 1): patch row 2 w + a + 1, patch column
+  // 32 q + 2 n + b + 1 -> parity lg >> 1 (b = -1, 1: even columns; 0, 2: odd), entry 16 q + n + (s & 1) of that parity plane
+  const int half = lg & 1, par = lg >> 1;
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int d = (2 * wave + (s >> 1)) * PCH + 16 * q + l15 + (s & 1);
+      const halfx8 b0 = __builtin_bit_cast(halfx8, s_p[0][half][par][d]);
+      const halfx8 b1 = __builtin_bit_cast(halfx8, s_p[1][half][par][d]);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const halfx8 a0 = __builtin_bit_cast(halfx8, A[s][mb][0]);
+        const halfx8 a1 = __builtin_bit_cast(halfx8, A[s][mb][1]);
+        acc[q][mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, acc[q][mb], 0, 0, 0);
+        acc[q][mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, acc[q][mb], 0, 0, 0);
+        acc[q][mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc[q][mb], 0, 0, 0);
+      }
+    }
+  // ---- store at half resolution (optionally accumulating)
+  const size_t HWs = (size_t)Hs * Ws;
+  float* const outn = p.out0 + (size_t)n * p.Cout * HWs;
+  const int ys = (y0 >> 1) + wave;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int xs = (x0 >> 1) + 16 * q + l15;
+    if (ys < Hs && xs < Ws) {
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ci = 16 * mb + 4 * lg + r;
+          if (ci < p.Cout) {
+            float* o = outn + (size_t)ci * HWs + (size_t)ys * Ws + xs;
+            const float v = acc[q][mb][r] * hinv;
+            *o = p.accum0 ? *o + v : v;
+          }
+        }
+    }
+  }
+}
+
 // filters of a thin layer in the register layout of k_conv3_thin_h: entry ((s*2 + term)*64 + lane) of 8 halves
 __device__ __forceinline__ void pack_thin_item(const float* __restrict__ w, unsigned short* __restrict__ out, size_t i, int Cout, int Cin,
                                                int tflip) {
@@ -1765,6 +1908,21 @@ __device__ __forceinline__ void pack_thin_item(const float* __restrict__ w, unsi
   const int s = (int)(i >> 9);
   const int m = lane & 15, gi = 4 * s + (lane >> 4);
   float v = 0.f;
+  if (tflip && M == 32) {
+    // k_conv3_thin_spd (decoder.blocks.4.conv1's data gradient: K = 16 dy channels, M = 32 rows): 16 entries (K step, row block) x 2 terms
+    //   value = Wd[pos = 2 ks + (lg >> 1)][ci = 16 mb + m][co = 8 (lg & 1) + j] = sum of the taps kh in S(a), kw in S(b), pos = 4 (a + 1) + b + 1
+    const int ks = s >> 1, mb = s & 1, lgp = lane >> 4, pos = 2 * ks + (lgp >> 1), ai = pos >> 2, bi = pos & 3;
+    const int ci = 16 * mb + m, co = 8 * (lgp & 1) + j;
+    const int kh0 = ai == 0 ? 2 : (ai == 1 ? 1 : 0), kh1 = ai == 0 ? 2 : (ai == 1 ? 2 : (ai == 2 ? 1 : 0));
+    const int kw0 = bi == 0 ? 2 : (bi == 1 ? 1 : 0), kw1 = bi == 0 ? 2 : (bi == 1 ? 2 : (bi == 2 ? 1 : 0));
+    for (int kh = kh0; kh <= kh1; ++kh)
+      for (int kw = kw0; kw <= kw1; ++kw) v += w[((size_t)co * M + ci) * 9 + kh * 3 + kw];
+    unsigned short tq[3];
+    split_filter(v, true, tq);
+    out[((size_t)(s * 2 + 0) * 64 + lane) * 8 + j] = tq[0];
+    out[((size_t)(s * 2 + 1) * 64 + lane) * 8 + j] = tq[1];
+    return;
+  }
   const int steps3 = (NG + 3) / 4;
   if (s >= steps3) {
     // the 16 phase filters of k_conv3_thin_sp (forward, 32 input channels): step = 4 * (2 py + px) + 2 sy + sx, value = the fp32 sum of the
@@ -2890,6 +3048,7 @@ extern "C" int sc_conv3x3_wgrad_thin16(const sc_wgrad_args* a, sc_stream stream)
 // K steps of the pack: the 3 x 3 filter's, and for the forward filter of a 32-channel layer the 16 phase steps of k_conv3_thin_sp behind them
 static int thin_steps(int Cout, int Cin, int transpose_flip) {
   const int K = transpose_flip ? Cout : Cin;
+  if (transpose_flip && Cin == 32) return 16;            // k_conv3_thin_spd: 8 K steps x 2 row blocks
   return (9 * (K / 8) + 3) / 4 + ((!transpose_flip && K == 32) ? 16 : 0);
 }
 
@@ -2899,6 +3058,7 @@ extern "C" size_t sc_packed_weight_floats_thin16(int Cout, int Cin, int transpos
 
 static bool thin16_shape_ok(int Cout, int Cin, int transpose_flip) {
   const int M = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
+  if (transpose_flip && Cin == 32 && Cout == 16) return true;      // the half-resolution data gradient (k_conv3_thin_spd)
   return M >= 1 && M <= 16 && (K == 16 || K == 32);
 }
 
@@ -2916,6 +3076,27 @@ extern "C" int sc_pack_weights_thin16(const float* w, float* wpk, int Cout, int 
 extern "C" int sc_conv3x3_thin16(const sc_conv_args* a, sc_stream stream) {
   SC_REQUIRE(a != nullptr && a->ks == 3 && a->nsrc == 1, "sc_conv3x3_thin16: one source, ks = 3");
   const int Cin = a->src[0].C;
+  if (a->down0) {
+    // the data gradient of a 32 -> 16 channel layer whose source was up-sampled: 32 rows from 16 gradient channels, stored 2x2-summed
+    // at half resolution (k_conv3_thin_spd; filters: sc_pack_weights_thin16(Cout = 16, Cin = 32, transpose_flip = 1))
+    const sc_src& s = a->src[0];
+    SC_REQUIRE(Cin == 16 && a->Cout == 32 && a->csplit == 32 && s.mode == SC_SRC_BNBWD && s.aux && s.cst && s.up == 0,
+               "sc_conv3x3_thin16(down0): needs a 16-channel BatchNorm-backward source and 32 output channels (got %d, %d)", Cin, a->Cout);
+    SC_REQUIRE(a->H % 2 == 0 && a->W % 2 == 0 && a->N > 0 && a->N <= 65535 && a->out0 && !a->add0 && !a->add1 && !a->stats && !a->bnr && !a->out1,
+               "sc_conv3x3_thin16(down0): even H, W; one output, no add / statistics / bnr epilogue");
+    SC_REQUIRE(a->terms == SC_TERMS_F16X2 && ((uintptr_t)a->wpk & 15) == 0, "sc_conv3x3_thin16(down0): terms must be SC_TERMS_F16X2, filters 16-byte aligned");
+    SC_REQUIRE((size_t)16 * a->H * a->W < ((size_t)1 << 30), "sc_conv3x3_thin16(down0): one image of the gradient must stay below 2^30 elements");
+    ConvXP p{};
+    p.s0 = to_srcd(s); p.s1 = empty_srcd();
+    p.wpk = reinterpret_cast<const uintx4*>(a->wpk); p.N = a->N; p.H = a->H; p.W = a->W; p.Cout = a->Cout;
+    p.out0 = a->out0; p.csplit = a->Cout; p.accum0 = a->accum0; p.absmax = a->absmax;
+    set_bnr(p, nullptr);
+    const long total = (long)((a->W + 63) / 64) * ((a->H + 7) / 8) * a->N, per_xcd = (total + 7) / 8;
+    p.xcdmap = 2;
+    hipLaunchKernelGGL(k_conv3_thin_spd, dim3((unsigned)(per_xcd * 8)), dim3(256), 0, (hipStream_t)stream, p);
+    SC_LAUNCH_OK("sc_conv3x3_thin16(down0)");
+    return SC_OK;
+  }
   SC_REQUIRE(a->Cout >= 1 && a->Cout <= 16 && (Cin == 16 || Cin == 32), "sc_conv3x3_thin16: needs <= 16 output and 16 or 32 input channels (got %d, %d)",
              a->Cout, Cin);
   SC_REQUIRE(a->N > 0 && a->N <= 65535 && a->H > 0 && a->W > 0, "sc_conv3x3_thin16: bad shape");

@@ -206,6 +206,7 @@ _SP = os.environ.get("STARCOP_SP", "1")
 # every other lane idle) 244 -> 392 for 59 -> 13: the step loses 1 % (1444 / 1436 vs 1460 / 1454 tiles/s, same box, alternating).  OFF by
 # default; "1" enables it (tests/test_gpu_unet.py runs the network both ways).
 _BNR = os.environ.get("STARCOP_BNR", "0") == "1"
+_THIN_SPD = os.environ.get("STARCOP_THIN_SPD", "1") == "1"      # (same-box A/B of decoder.blocks.4.conv1's sub-pixel data gradient)
 # training steps pack the decoder's / the backward filter layouts on the weight-gradient stream, beside the encoder's forward ("0": on
 # the main stream, ahead of the forward -- A/B)
 _PACK_SIDE = os.environ.get("STARCOP_PACK_SIDE", "1") == "1"
@@ -776,7 +777,7 @@ class HyperStarcopUNet(nn.Module):
                 nb = lib.sc_packed_weight_floats_bx3(co, ci, cb, 1, tb_) if xb else lib.sc_packed_weight_floats(co, ci, ks, cb, 1)
                 ent = dict(cot_f=cf, cot_b=cb, bx3_f=xf, bx3_b=xb, split=(self.split_bf16, tf_, tb_), terms_f=tf_, terms_b=tb_,
                            f=torch.empty(nf, dtype=torch.float32, device=dev),
-                           b=torch.empty(nb, dtype=torch.float32, device=dev), tf=None, tb=None)
+                           b=torch.empty(nb, dtype=torch.float32, device=dev), tf=None, tb=None, tsd=None)
                 # decoder.blocks.4 (<= 16 output channels at full resolution) under the two-fp16-term split: filters in registers
                 # (sc_conv3x3_thin16; 0.20-0.28 vs 0.31-0.51 ms per launch).  The backward-data kernel only takes the plain
                 # epilogue, so the regular pack is kept beside it.
@@ -785,6 +786,9 @@ class HyperStarcopUNet(nn.Module):
                         ent["tf"] = torch.empty(lib.sc_packed_weight_floats_thin16(co, ci, 0), dtype=torch.float32, device=dev)
                     if tb_ == TERMS_F16X2 and ci <= 16 and co in (16, 32):
                         ent["tb"] = torch.empty(lib.sc_packed_weight_floats_thin16(co, ci, 1), dtype=torch.float32, device=dev)
+                    if tb_ == TERMS_F16X2 and op.get("up") and co == 16 and ci == 32:
+                        # decoder.blocks.4.conv1: the half-resolution data gradient in its sub-pixel form (sc_conv3x3_thin16 with down0)
+                        ent["tsd"] = torch.empty(lib.sc_packed_weight_floats_thin16(co, ci, 1), dtype=torch.float32, device=dev)
                 # decoder conv1 data gradient (up-sampled channels + skip channels): the two outputs as TWO launches with their own
                 # cout tiles -- 64-wide for the up-sampled part (a multiple of 64), one 32-wide tile for the <= 32 skip channels --
                 # instead of one launch of 32-wide tiles (80 = 64 + 16: 3 x 32; 152 = 128 + 24: 5 x 32): every cout tile stages (loads,
@@ -865,7 +869,7 @@ class HyperStarcopUNet(nn.Module):
                     add(False, conv.weight, ent["spd"], co, ci, ks, ent["sp_cu"], tfl, PACK_SPD)
                 if ent.get("sp") is not None:
                     add(False, conv.weight, ent["sp"], co, ci, ks, ent["sp_cu"], 4 if ent["terms_f"] == 1 else 0, PACK_SP)
-                for tflip, buf in ((0, ent["tf"]), (1, ent["tb"])):
+                for tflip, buf in ((0, ent["tf"]), (1, ent["tb"]), (1, ent.get("tsd"))):
                     if buf is not None and (not tflip or need_bwd):
                         add(False, conv.weight, buf, co, ci, ks, 16, tflip, PACK_THIN16)
                 for tflip, buf in ((0, ent.get("pf")), (1, ent.get("pb"))):
@@ -1672,13 +1676,17 @@ class HyperStarcopUNet(nn.Module):
             if op.get("up") and ent["bx3_b"]:      # the upsampled source's gradient is stored 2x2-summed (quarter size)
                 gin_elems -= N * ins[0].C * Ho * Wo * 3 // 4
             thin_b = (ent["tb"] is not None and not op.get("up") and ins[0].name not in written and res_of.get(ins[0].name) is None)
+            # decoder.blocks.4.conv1: 16 gradient channels -> 32 channels at half resolution, the sub-pixel form on the thin layer's MFMA
+            # (sc_conv3x3_thin16 with down0: 251 -> see DESIGN 16; STARCOP_THIN_SPD=0: sc_conv3x3_bx3 with its summing store)
+            thin_sd = (ent.get("tsd") is not None and op.get("up") and len(ins) == 1 and a.terms == TERMS_F16X2 and _THIN_SPD and not _BNR
+                       and Ho % 2 == 0 and Wo % 2 == 0)
             fle = None
             if (op.get("up") and ent.get("spd") is not None and ent["terms_b"] in _SP_TERMS and self.split_bf16
                     and _use_spd(N, Ho, Wo, ins[0].C, conv.in_channels - ins[0].C)):
                 cu_ = ins[0].C          # up-sampled channels: 4 parity planes x 4 taps per low-resolution pixel; skip channels: the 3x3 form
                 fle = (2.0 * N * (Ho // 2) * (Wo // 2) * 16 * conv.out_channels * (-(-cu_ // 128) * 128 + (128 * -(-(conv.in_channels - cu_) // 32) if ent["spd_stiles"] else 0))
                        + (0.0 if (ent["spd_vskip"] or ent["spd_stiles"]) else 2.0 * N * Ho * Wo * 9 * conv.out_channels * (conv.in_channels - cu_)))
-            tok = self._pb("k_conv3_thin_h (fwd+dgrad)" if thin_b else
+            tok = self._pb("k_conv3_thin_h (fwd+dgrad)" if (thin_b or thin_sd) else
                            self._bx3_family("dgrad") if ent["bx3_b"] else f"k_conv_mfma<{ks}> (fwd+dgrad)", flop,
                            4.0 * (2 * N * o.C * Ho * Wo + gin_elems + conv.weight.numel()), fle)
             if (op.get("up") and ent.get("spd") is not None and ent["terms_b"] in _SP_TERMS and self.split_bf16
@@ -1714,6 +1722,16 @@ class HyperStarcopUNet(nn.Module):
                     check(lib.sc_conv3x3_bx3(C.byref(a), st))
                     written.add(t_sk.name)
                 self._pe(tok)
+                continue
+            if thin_sd:
+                t_up = ins[0]
+                a.Cout = a.csplit = t_up.C
+                a.wpk, a.co_t = ent["tsd"].data_ptr(), 16
+                a.out0, a.out1 = plan.grad[t_up.name].data_ptr(), None
+                a.accum0, a.down0, a.bnr = (1 if t_up.name in written else 0), 1, None
+                check(lib.sc_conv3x3_thin16(C.byref(a), st))
+                self._pe(tok)
+                written.add(t_up.name)
                 continue
             if op.get("up"):
                 t_up = ins[0]

@@ -1102,6 +1102,39 @@ def test_conv_thin16_two_fp16_terms(hip, cin, cout, H, W, up, gscale):
     _bnr_check(lib, dx2, y_in, cst_in, ACT_RELU, N, H * W)
 
 
+@pytest.mark.parametrize("gscale", [1.0, 1e-6])
+@pytest.mark.parametrize("N,H,W,accum", [(2, 64, 128, 0), (1, 24, 40, 1), (2, 10, 34, 0), (1, 128, 64, 0)])
+def test_conv_thin16_half_resolution_data_gradient(hip, N, H, W, accum, gscale):
+    """sc_conv3x3_thin16 with down0 (k_conv3_thin_spd): the data gradient of a 32 -> 16 channel 3x3 layer whose source was up-sampled 2x,
+    stored 2x2-summed at half resolution, from (g, y) of the 16-channel output -- against conv_transpose2d + the 2x2 sum in float64
+    (whole and ragged tiles; accumulate on / off; tiny gradients through the range hint)"""
+    from starcop_amd._lib import TERMS_F16X2, sc_conv_args
+    cin, cout = 32, 16
+    w = rnd(cout, cin, 3, 3, seed=52, scale=0.2)
+    g, y = rnd(N, cout, H, W, seed=55) * gscale, rnd(N, cout, H, W, seed=56)
+    a_, b_ = rnd(cout, seed=57) * 0.2 + 1, rnd(cout, seed=58) * 0.2
+    A, B, D = a_.clone(), rnd(cout, seed=59) * 0.1 * gscale, rnd(cout, seed=60) * 0.1 * gscale
+    yh = y * a_[None, :, None, None] + b_[None, :, None, None]
+    gm = torch.where(yh > 0, g, torch.zeros(()))
+    dy = gm.double() * A.double()[None, :, None, None] + B.double()[None, :, None, None] * y.double() + D.double()[None, :, None, None]
+    ref = F.conv_transpose2d(dy, w.double(), padding=1)
+    ref = ref.reshape(N, cin, H // 2, 2, W // 2, 2).sum((3, 5))
+    cstb = torch.zeros(cout, SC_CST); cstb[:, 0], cstb[:, 1], cstb[:, 2], cstb[:, 3], cstb[:, 4] = a_, b_, A, B, D
+    amax = torch.tensor([float((gm.abs().amax((0, 2, 3)) * a_.abs()).max())], device=DEV)
+    wpk = torch.empty(hip.sc_packed_weight_floats_thin16(cout, cin, 1), device=DEV)
+    check(hip.sc_pack_weights_thin16(ptr(dev(w)), ptr(wpk), cout, cin, 1, stream()))
+    old = rnd(N, cin, H // 2, W // 2, seed=61) * gscale
+    out = dev(old).clone() if accum else torch.full((N, cin, H // 2, W // 2), float("nan"), device=DEV)
+    a = sc_conv_args()
+    a.nsrc = 1; a.src[0] = make_src(dev(g), cout, SRC_BNBWD, act=ACT_RELU, cst=dev(cstb), aux=dev(y))
+    a.wpk = wpk.data_ptr()
+    a.N, a.H, a.W, a.Cout, a.ks, a.co_t = N, H, W, cin, 3, 16
+    a.out0 = out.data_ptr(); a.csplit = cin; a.terms = TERMS_F16X2; a.down0 = 1; a.accum0 = accum
+    a.absmax = amax.data_ptr()
+    check(hip.sc_conv3x3_thin16(C.byref(a), stream()))
+    assert relerr(out, ref + (old.double() if accum else 0.0)) < 1e-5
+
+
 def _bnr_reference(dx, y_in, cst_in, act):
     """what sc_bn_bwd_reduce computes from a gradient dx of a BatchNorm'd tensor with raw values y_in: (sum g', sum g' x_hat, max |scale g'|)"""
     sc, sh, mu, isd = (cst_in[:, k].double()[None, :, None, None] for k in range(4))
