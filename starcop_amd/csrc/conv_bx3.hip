@@ -1472,6 +1472,24 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
   }
   __syncthreads();
 
+  // (sc_bnr_args) the raw values y of the tensor whose gradient this launch writes -- the lane's 4 x NPB output positions -- are requested
+  // HERE, ahead of the MFMA phase: requested in the epilogue (round 5) their round trip was exposed at the end of every work-group's
+  // life and the launch lost more (197 -> 302 us) than the BatchNorm-backward pass it replaces costs (120 us)
+  float yv[BNB ? 4 : 1][BNB ? NPB : 1];
+  if constexpr (BNB) {
+    if (p.bnr_y != nullptr) {
+      const float* const yn = p.bnr_y + (size_t)n * p.Cout * ((size_t)H * W);
+      const unsigned HWy = (unsigned)((size_t)H * W);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb) {
+          const int co = 4 * lg + r, oy = y0 + 2 * wave + pb / PBW, ox = x0 + 16 * (pb % PBW) + l15;
+          yv[r][pb] = (oy < H && ox < W && co < p.Cout) ? yn[(unsigned)co * HWy + (unsigned)(oy * W + ox)] : 0.f;
+        }
+    }
+  }
+
   // ---- MFMAs: four 16-pixel blocks per wave, all K steps from LDS, filters from registers
   floatx4 acc[NPB];
 #pragma unroll
@@ -1506,17 +1524,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3_thin_h(const ConvXP p) {
     if (p.bnr_y != nullptr) {
       // data gradient + the BatchNorm-backward sums of the tensor it belongs to (sc_bnr_args, see bx3_epilogue_bnr): the lane's 4 x NPB
       // raw values y are requested together, then stores / masks / sums
-      const float* const yn = p.bnr_y + (size_t)n * p.Cout * HWs;
       const float blo = sc_act_lo(p.bnr_act), bhi = sc_act_hi(p.bnr_act);
-      float yv[4][NPB];
       float mx = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int pb = 0; pb < NPB; ++pb) {
-          const int co = 4 * lg + r, oy = y0 + 2 * wave + pb / PBW, ox = x0 + 16 * (pb % PBW) + l15;
-          yv[r][pb] = (oy < H && ox < W && co < p.Cout) ? yn[(unsigned)co * HWu + (unsigned)(oy * W + ox)] : 0.f;
-        }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = 4 * lg + r;

@@ -206,6 +206,8 @@ _SP = os.environ.get("STARCOP_SP", "1")
 # every other lane idle) 244 -> 392 for 59 -> 13: the step loses 1 % (1444 / 1436 vs 1460 / 1454 tiles/s, same box, alternating).  OFF by
 # default; "1" enables it (tests/test_gpu_unet.py runs the network both ways).
 _BNR = os.environ.get("STARCOP_BNR", "0") == "1"
+# ... for the thin layer alone (decoder.blocks.4.conv2's data gradient leaves conv1's sums; y requested ahead of the MFMA phase since round 6)
+_BNR_THIN = os.environ.get("STARCOP_BNR_THIN", "0") == "1"
 _THIN_SPD = os.environ.get("STARCOP_THIN_SPD", "1") == "1"      # (same-box A/B of decoder.blocks.4.conv1's sub-pixel data gradient)
 # training steps pack the decoder's / the backward filter layouts on the weight-gradient stream, beside the encoder's forward ("0": on
 # the main stream, ahead of the forward -- A/B)
@@ -1791,7 +1793,7 @@ class HyperStarcopUNet(nn.Module):
                     a.wpk = ent["tb"].data_ptr()
                 b_ = None
                 if ks == 3 and (thin_b or (conv_dgrad is lib.sc_conv3x3_bx3 and bx3_plain)):
-                    b_ = bnr_for(tin, lib.sc_stat_rows(STAT_CONV3, N, Ho, Wo))
+                    b_ = bnr_for(tin, lib.sc_stat_rows(STAT_CONV3, N, Ho, Wo), enabled=_BNR or (thin_b and _BNR_THIN))
                 elif (conv_dgrad is lib.sc_conv1x1_pw3 and self.pw_bnr and z is None and not a.accum0
                       and N * Ho * Wo <= self.bn_small_max and tin.C >= 64):
                     # a projection's data gradient at <= 32 x 32 (the register-only pointwise kernel): it writes the COMPLETE gradient of the
