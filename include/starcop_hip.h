@@ -101,6 +101,9 @@ int sc_pack_weights_batch(const sc_pack_desc* descs_dev, const uint32_t* block_s
  *            out = acc (+ add0) (+ add1) (+ old out if accum flag)
  *   stats  : if non-NULL, per-channel sum / sum-of-squares of acc over each work-group's pixel tile are written to
  *            stats[row][Cout][2] (float), row = n*tiles + tile, rows = sc_stat_rows(SC_STAT_CONV3|CONV1, N, H, W)
+ * ks = 1 on planes of >= 8192 pixels (H*W % 256 == 0, 16-byte aligned tensors) with a short contraction (16-32 source channels, one plain
+ * output of <= 160 channels, RAW / AFFINE or BNBWD source) runs on a streaming kernel (16-byte loads and stores, same fp32 products,
+ * same statistics rows); everything else on the LDS-staged kernels.
  */
 /* BatchNorm-backward sums of the tensor whose gradient a data-gradient launch writes into out0 (sc_conv3x3_bx3, sc_conv3x3_thin16,
  * sc_conv3x3_sp_dgrad): what sc_bn_bwd_reduce(out0, y, cst, act, ...) would compute by streaming both tensors again, left by the
@@ -202,7 +205,12 @@ int sc_wgrad_reduce_batch(const sc_wgrad_pending* descs_dev, const uint32_t* blo
  * v_mfma_f32_16x16x32_f16: the filter bank stays in registers, all input channels are staged in one pass.  Same arguments as
  * sc_conv3x3_bx3 with terms = SC_TERMS_F16X2, nsrc = 1, a single plain output (csplit = Cout, no add / accumulate / down0);
  * `wpk` from sc_pack_weights_thin16 (or a sc_pack_desc with bx3 = SC_PACK_THIN16); statistics rows SC_STAT_CONV3.
- * Forward, or backward-data with transpose_flip-packed filters (then "Cout" is the layer's input channel count). */
+ * Forward, or backward-data with transpose_flip-packed filters (then "Cout" is the layer's input channel count).
+ * A 32-channel source with up = 1 (decoder.blocks.4.conv1: conv3x3 of a nearest-2x up-sampled tensor) runs as four 2x2 convolutions on
+ * the half-resolution source (sub-pixel form: the pack of a forward filter with Cin = 32 carries the 16 phase filters behind its 3x3
+ * entries).  down0 = 1 (the one exception to "no down0"): the data gradient of that layer -- 16-channel SC_SRC_BNBWD source at H x W,
+ * Cout = csplit = 32 rows stored 2x2-summed into out0 [N,32,H/2,W/2] (accum0 allowed) -- from sc_pack_weights_thin16(Cout = 16,
+ * Cin = 32, transpose_flip = 1), which packs the 4 x 4-position gathered filters of that form (no statistics / bnr / add epilogue). */
 #define SC_PACK_THIN16 5
 #define SC_PACK_PW3 6      /* sc_pack_desc.bx3 code of the pointwise layout of sc_conv1x1_pw3 (ks = 1; co_t ignored) */
 size_t sc_packed_weight_floats_thin16(int Cout, int Cin, int transpose_flip);

@@ -12,10 +12,10 @@ import sys
 FAMILIES = [      # first match wins
     ("k_conv3_bx3 (fwd+dgrad)  [k_conv3_bx3 | k_conv3_ws | k_conv3_sp | k_conv3_spd]", r"k_conv3_bx3<|k_conv3_ws<|k_conv3_sp<|k_conv3_spd<"),
     ("k_wgrad3_bx3 (+ box-sum GEMM: k_spw_*, column scatter)", r"k_wgrad3_bx3<|k_spw_|k_scatter_cols"),
-    ("k_conv3_thin_h (fwd+dgrad)", r"k_conv3_thin_h<"),
+    ("k_conv3_thin_h (fwd+dgrad)  [+ k_conv3_thin_sp / k_conv3_thin_spd: decoder.blocks.4.conv1 in its sub-pixel forms]", r"k_conv3_thin_h<|k_conv3_thin_sp"),
     ("k_wgrad_thin_h", r"k_wgrad_thin_h<"),
     ("fp32-MFMA 3x3 (k_conv_mfma<3>, k_conv_mfma16, k_wgrad_mfma<3>, k_wgrad_mfma16)", r"k_conv_mfma<3|k_conv_mfma16|k_wgrad_mfma<3|k_wgrad_mfma16"),
-    ("pointwise fwd+dgrad (k_conv_mfma<1>, k_pw3, k_conv1_ksplit, k_pwb_*)", r"k_conv_mfma<1|k_pw3<|k_conv1_ksplit|k_ksplit|k_pwb_"),
+    ("pointwise fwd+dgrad (k_conv_mfma<1>, k_pw_stream, k_pw3, k_conv1_ksplit, k_pwb_*)", r"k_conv_mfma<1|k_pw_stream<|k_pw3<|k_conv1_ksplit|k_ksplit|k_pwb_"),
     ("pointwise wgrad (k_wgrad_mfma<1>, k_pw3_wgrad)", r"k_wgrad_mfma<1|k_pw3_wgrad"),
     ("shared weight-gradient reductions (k_reduce16, k_wgrad_reduce*)", r"k_reduce16|k_wgrad_reduce"),
     ("k_irt_* (fused expand+dw)", r"k_irt_"),
