@@ -516,7 +516,10 @@ def main():
                                          "wave-specialised k_conv3_ws<Q,BNB> of the same contraction; the decoder conv1 layers run as sub-pixel "
                                          "convolutions: k_conv3_sp<TW> (forward, decoder.blocks.0-3) and k_conv3_spd<TW> (data gradient of the "
                                          "up-sampled channels, decoder.blocks.0-2) -- all four names appear in the rocprofv3 kernel traces under "
-                                         "profiles/") if (fam.startswith("k_conv3_bx3") and nterms == 4) else None,
+                                         "profiles/.  decoder.blocks.4 (<= 16 output channels) is the thin-layer family (k_conv3_thin_h / "
+                                         "k_conv3_thin_sp / k_conv3_thin_spd) -- since late round 6 including conv1's data gradient, which until then "
+                                         "ran here as this family's slowest launch (153 TFLOP/s): the family is one launch per step smaller than in "
+                                         "BENCH_r05 and its `frac` is not like-for-like with it (DESIGN 16 gives the like-for-like figure)") if (fam.startswith("k_conv3_bx3") and nterms == 4) else None,
                     "algorithmic_bytes_per_launch": round(d["bytes"] / d["n"]) if d.get("bytes") else None,
                     "algorithmic_flop_per_launch": round(d["flop"] / d["n"]),
                     "launches_per_step": d["n"] // prof_steps, "avg_launch_ms": round(d["ms"] / d["n"], 4),

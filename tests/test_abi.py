@@ -41,6 +41,12 @@ def test_pure_host_entry_points(lib):
     assert lib.sc_packed_weight_floats(256, 1376, 3, 64, 1) == 22 * 256 * 9 * 64      # dgrad: 1376 -> 22 tiles of 64
     assert lib.sc_wgrad_workspace_floats(16, 512, 512, 16, 32, 3) > 0
     assert lib.sc_mag1c_workspace_doubles(4, 125, 2048) == 4 * 125 * 125 + 3 * 2048
+    # thin-layer packs: 16-byte entries x 64 lanes x 2 terms per K step; the forward filter of a 32-channel layer carries the 16 phase
+    # steps of its sub-pixel form behind the nine 3x3 ones, the transposed pack of that layer is the 16 entries of its half-resolution
+    # data gradient (8 K steps x 2 row blocks)
+    assert lib.sc_packed_weight_floats_thin16(16, 16, 0) == 5 * 512 and lib.sc_packed_weight_floats_thin16(16, 16, 1) == 5 * 512
+    assert lib.sc_packed_weight_floats_thin16(16, 32, 0) == (9 + 16) * 512 and lib.sc_packed_weight_floats_thin16(16, 32, 1) == 16 * 512
+    assert lib.sc_pack_work_items(16, 32, 3, 16, 0, 5) == (9 + 16) * 512 and lib.sc_pack_work_items(16, 32, 3, 16, 1, 5) == 16 * 512
 
 
 def test_struct_layouts_match_header():
