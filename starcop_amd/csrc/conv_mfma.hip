@@ -1421,8 +1421,8 @@ extern "C" int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream) {
     const int nks = K / 4;
     // short contractions only: the long-K projections (96 / 144 -> 24 at 128^2) measured a tie without and 3-8 us slower with the
     // statistics epilogue (a lane keeps NKS filter registers per cout block: two waves per SIMD)
-    const bool ks_ok = bnb ? (nks == 4 || nks == 6) : (nks == 6 || nks == 8);
-    if (!pws_off && plain && aligned && ks_ok && (M <= 32 || (M <= 160 && nks <= 8)) && HWl >= 8192 && HWl % 256 == 0 && HWl < (1L << 30) && a->co_t != 16) {
+    const bool ks_ok = bnb ? (nks == 4 || nks == 6 || nks == 8) : (nks == 6 || nks == 8);
+    if (!pws_off && plain && aligned && ks_ok && (M <= 32 || (M <= 192 && nks <= 8)) && HWl >= 4096 && HWl % 256 == 0 && HWl < (1L << 30) && a->co_t != 16) {
       PwsP q;
       q.x = a->src[0].x; q.aux = a->src[0].aux; q.cst = a->src[0].mode == SC_SRC_RAW ? nullptr : a->src[0].cst;
       q.act = a->src[0].mode == SC_SRC_RAW ? (int)SC_ACT_NONE : a->src[0].act;
@@ -1434,15 +1434,18 @@ extern "C" int sc_conv2d_mfma(const sc_conv_args* a, sc_stream stream) {
 #define SC_PWS_K(NCB_, CP_) do { if (nks == 6) SC_PWS(NCB_, 6, CP_); else SC_PWS(NCB_, 8, CP_); } while (0)
       if (bnb) {
 #define SC_PWSB(NCB_, CP_) do { if (nks == 4) hipLaunchKernelGGL((k_pw_stream<NCB_, 4, CP_, true>), dim3((unsigned)(groups / (4 / CP_))), dim3(256), 0, st, q); \
-                                else hipLaunchKernelGGL((k_pw_stream<NCB_, 6, CP_, true>), dim3((unsigned)(groups / (4 / CP_))), dim3(256), 0, st, q); } while (0)
+                                else if (nks == 6) hipLaunchKernelGGL((k_pw_stream<NCB_, 6, CP_, true>), dim3((unsigned)(groups / (4 / CP_))), dim3(256), 0, st, q); \
+                                else hipLaunchKernelGGL((k_pw_stream<NCB_, 8, CP_, true>), dim3((unsigned)(groups / (4 / CP_))), dim3(256), 0, st, q); } while (0)
         if (M <= 32) SC_PWSB(2, 1);
         else if (M <= 96) SC_PWSB(3, 2);
-        else SC_PWSB(5, 2);
+        else if (M <= 160) SC_PWSB(5, 2);
+        else SC_PWSB(6, 2);
 #undef SC_PWSB
       }
       else if (M <= 16) SC_PWS_K(1, 1);
       else if (M <= 32) SC_PWS_K(2, 1);
-      else SC_PWS_K(5, 2);                                 // (the expansions: few input channels, up to 160 couts in two parts)
+      else if (M <= 160) SC_PWS_K(5, 2);                   // (the expansions: few input channels, up to 160 / 192 couts in two parts)
+      else SC_PWS_K(6, 2);
 #undef SC_PWS_K
 #undef SC_PWS
       SC_LAUNCH_OK("sc_conv2d_mfma(k_pw_stream)");

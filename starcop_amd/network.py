@@ -130,6 +130,10 @@ def _pick_cot(M, ks=1):
 #   backward-weight  planes up to 32^2 of at most 32768 batch pixels, small filters (K*M bounds as measured at batch 16)
 # "1" = these rules, "all" = every pointwise launch (the tests run both), "0" = off.
 _PW3 = os.environ.get("STARCOP_PW3", "1")
+# 64 x 64 planes with a short contraction on the streaming kernel of sc_conv2d_mfma (k_pw_stream) instead of sc_conv1x1_pw3: the
+# features.5-.7 expansions forward 25-27 -> 21-22 us, the features.4-.6 projections' data gradients 23-30 -> 19-25 us at batch 16
+# (tools/bench_layers.py, same box); step level to +0.6 % (four alternating pairs).  "0": the round-5 rule
+_PWS64 = os.environ.get("STARCOP_PWS64", "1") == "1"
 
 
 def _use_pw3(which, N, HW, Cin, Cout):
@@ -141,6 +145,12 @@ def _use_pw3(which, N, HW, Cin, Cout):
         return True
     NP = N * HW
     npb = -(-NP // 32)
+    if _PWS64 and HW == 4096 and which in (0, 1):
+        # 64 x 64 planes with a short contraction (the features.5-.7 expansions forward, the features.4-.6 projections' data gradients):
+        # the streaming kernel inside sc_conv2d_mfma (k_pw_stream)
+        K_, M_ = (Cin, Cout) if which == 0 else (Cout, Cin)
+        if K_ in (16, 24, 32) and M_ <= 192 and (which == 1 or K_ in (24, 32)):
+            return False
     if which == 0:
         return HW <= 4096 and (Cin <= 320 or npb * (-(-Cout // 32)) >= 1024)
     if which == 1:

@@ -755,7 +755,8 @@ def test_stem_fused_normalizer(hip):
 # (features.1's projection, the features.3 / .4 expansions) -- on planes >= 8192 pixels, with and without statistics; one long
 # contraction (144 channels: stays on the LDS-staged kernel either way)
 PWS_CASES = [(2, 32, 16, 128, 128, "affine6"), (1, 24, 24, 96, 96, "affine6"), (2, 24, 144, 96, 96, "raw"), (1, 24, 144, 128, 64, "affine"),
-             (1, 32, 32, 128, 64, "affine6"), (1, 144, 32, 96, 96, "affine6"), (3, 32, 144, 64, 128, "affine")]
+             (1, 32, 32, 128, 64, "affine6"), (1, 144, 32, 96, 96, "affine6"), (3, 32, 144, 64, 128, "affine"), (2, 32, 192, 64, 64, "raw"),
+             (1, 24, 176, 64, 64, "affine")]
 
 
 @pytest.mark.parametrize("case", PWS_CASES, ids=lambda c: "x".join(map(str, c)))
@@ -797,7 +798,7 @@ def test_pointwise_streaming_forward(hip, case):
 # (N, layer Cin, layer Cout, H, W, act of the BatchNorm the gradient passes): the projections' data gradients the streaming kernel takes
 # (few dy channels -> many outputs: features.1 / .2 / .3 at batch 16 are 16 -> 32 at 256^2, 24 -> 96 and 24 -> 144 at 128^2)
 PWS_DGRAD_CASES = [(2, 32, 16, 128, 128, ACT_NONE), (1, 96, 24, 96, 96, ACT_NONE), (2, 144, 24, 128, 64, ACT_NONE), (1, 144, 24, 96, 96, ACT_RELU6),
-                   (1, 160, 16, 64, 128, ACT_RELU)]
+                   (1, 160, 16, 64, 128, ACT_RELU), (2, 192, 32, 64, 64, ACT_NONE), (1, 144, 32, 64, 64, ACT_NONE), (1, 184, 24, 64, 64, ACT_RELU6)]
 
 
 @pytest.mark.parametrize("case", PWS_DGRAD_CASES, ids=lambda c: "x".join(map(str, c)))

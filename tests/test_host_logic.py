@@ -187,6 +187,11 @@ def test_pointwise_kernel_choice_rules():
     # projections' data gradients and the large-batch weight gradients go back to the LDS-staged kernels
     assert u(0, 64, 256, 960, 160) and u(0, 64, 1024, 576, 96) and u(1, 64, 256, 160, 960) and u(1, 64, 1024, 64, 384)
     assert not u(1, 64, 4096, 192, 32) and u(1, 64, 1024, 384, 64) and not u(2, 64, 1024, 64, 384) and u(2, 64, 256, 160, 960)
+    # 64^2 planes with a short contraction (features.5-.7 expansions forward, features.4-.6 projections' data gradients): the streaming
+    # kernel inside sc_conv2d_mfma since late round 6; the long contractions of those planes stay where they were
+    if nw._PWS64:
+        assert not u(0, 16, 4096, 32, 192) and not u(1, 16, 4096, 192, 32) and not u(1, 16, 4096, 144, 32)
+        assert u(0, 16, 4096, 192, 32) and u(0, 16, 4096, 144, 32)
 
 
 def test_fused_block_rule():
