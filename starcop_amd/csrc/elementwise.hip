@@ -319,6 +319,7 @@ __device__ __forceinline__ float ld_src(const SrcD& s, size_t idx, float4 c0, fl
   return sc_prologue(s.mode, s.act, x, au, c0, c4);
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_add_srcs(const SrcD a, const SrcD b, int has_b, float* __restrict__ out, int C, int HW,
                                                   float* __restrict__ absmax) {
   __shared__ float s_m[4];
@@ -329,11 +330,42 @@ __global__ __launch_bounds__(256) void k_add_srcs(const SrcD a, const SrcD b, in
   if (has_b && b.mode != SC_SRC_RAW) { b0 = *reinterpret_cast<const float4*>(b.cst + (size_t)c * SC_CST); b4 = b.cst[(size_t)c * SC_CST + 4]; }
   const size_t base = ((size_t)n * C + c) * HW;
   const int start = blockIdx.x * 2048, end = min(start + 2048, HW);
-  for (int i = start + threadIdx.x; i < end; i += 256) {
-    float v = ld_src(a, base + i, a0, a4);
-    if (has_b) v += ld_src(b, base + i, b0, b4);
-    if (out) out[base + i] = v;
-    mx = fmaxf(mx, fabsf(v));
+  if (VEC) {
+    // 16 bytes per lane, both 1024-element halves of the chunk requested before any arithmetic (HW % 4 == 0, 16-byte aligned tensors:
+    // the host decides).  The residual add of features.3 at 16 x 128^2 moved 75 MB in 37 us with the 4-byte loop below.
+    float4 xa[2], ya[2], xb[2], yb[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = start + 4 * threadIdx.x + 1024 * u, ic = i < end ? i : start;
+      xa[u] = *reinterpret_cast<const float4*>(a.x + base + ic);
+      ya[u] = (a.mode == SC_SRC_BNBWD) ? *reinterpret_cast<const float4*>(a.aux + base + ic) : make_float4(0.f, 0.f, 0.f, 0.f);
+      xb[u] = has_b ? *reinterpret_cast<const float4*>(b.x + base + ic) : make_float4(0.f, 0.f, 0.f, 0.f);
+      yb[u] = (has_b && b.mode == SC_SRC_BNBWD) ? *reinterpret_cast<const float4*>(b.aux + base + ic) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = start + 4 * threadIdx.x + 1024 * u;
+      if (i < end) {
+        const float xv[4] = {xa[u].x, xa[u].y, xa[u].z, xa[u].w}, yv[4] = {ya[u].x, ya[u].y, ya[u].z, ya[u].w};
+        const float xw[4] = {xb[u].x, xb[u].y, xb[u].z, xb[u].w}, yw[4] = {yb[u].x, yb[u].y, yb[u].z, yb[u].w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float v = a.mode == SC_SRC_RAW ? xv[k] : sc_prologue(a.mode, a.act, xv[k], yv[k], a0, a4);
+          if (has_b) v += b.mode == SC_SRC_RAW ? xw[k] : sc_prologue(b.mode, b.act, xw[k], yw[k], b0, b4);
+          o[k] = v;
+          mx = fmaxf(mx, fabsf(v));
+        }
+        if (out) *reinterpret_cast<float4*>(out + base + i) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  } else {
+    for (int i = start + threadIdx.x; i < end; i += 256) {
+      float v = ld_src(a, base + i, a0, a4);
+      if (has_b) v += ld_src(b, base + i, b0, b4);
+      if (out) out[base + i] = v;
+      mx = fmaxf(mx, fabsf(v));
+    }
   }
   if (absmax) block_absmax_to(mx, 1.f, absmax, s_m);
 }
@@ -699,8 +731,15 @@ extern "C" int sc_add_srcs_absmax(const sc_src* a, const sc_src* b, float* out, 
   SC_REQUIRE(a->up == 0 && (!b || b->up == 0), "sc_add_srcs: upsampled sources unsupported");
   SC_REQUIRE(out || absmax, "sc_add_srcs: neither an output nor an absmax record");
   dim3 grid((HW + 2047) / 2048, C, N);
-  hipLaunchKernelGGL(k_add_srcs, grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*a), b ? to_srcd(*b) : empty_srcd(),
-                     b ? 1 : 0, out, C, HW, absmax);
+  uintptr_t al = (uintptr_t)a->x | (uintptr_t)out;
+  if (a->mode == SC_SRC_BNBWD) al |= (uintptr_t)a->aux;
+  if (b) { al |= (uintptr_t)b->x; if (b->mode == SC_SRC_BNBWD) al |= (uintptr_t)b->aux; }
+  if (HW % 4 == 0 && (al & 15) == 0)
+    hipLaunchKernelGGL(k_add_srcs<true>, grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*a), b ? to_srcd(*b) : empty_srcd(),
+                       b ? 1 : 0, out, C, HW, absmax);
+  else
+    hipLaunchKernelGGL(k_add_srcs<false>, grid, dim3(256), 0, (hipStream_t)stream, to_srcd(*a), b ? to_srcd(*b) : empty_srcd(),
+                       b ? 1 : 0, out, C, HW, absmax);
   SC_LAUNCH_OK("sc_add_srcs");
   return SC_OK;
 }

@@ -977,6 +977,38 @@ def test_downsum_and_add(hip):
     assert relerr(o2, a + b * sc[None, :, None, None] + sh[None, :, None, None]) < 1e-6
 
 
+@pytest.mark.parametrize("N,C_,H,W", [(2, 24, 48, 64), (1, 5, 45, 44), (2, 7, 9, 11), (1, 3, 64, 80)])
+def test_add_srcs_forms_and_range_record(hip, N, C_, H, W):
+    """sc_add_srcs_absmax: the 16-byte form (H*W % 4 == 0, aligned tensors; chunks whose second half is empty or ragged) and the 4-byte form
+    (the same operands through views that are not 16-byte aligned), RAW + AFFINE and BNBWD + RAW operands, with the max |sum| record"""
+    a, b = rnd(N, C_, H, W, seed=71), rnd(N, C_, H, W, seed=72)
+    sc, sh = rnd(C_, seed=73) * 0.3 + 1, rnd(C_, seed=74) * 0.2
+    y = rnd(N, C_, H, W, seed=75)
+    cb = torch.zeros(C_, SC_CST); cb[:, 0], cb[:, 1], cb[:, 2], cb[:, 3], cb[:, 4] = sc, sh, rnd(C_, seed=76), rnd(C_, seed=77) * 0.1, rnd(C_, seed=78) * 0.1
+    want1 = a.double() + F.relu6(b.double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+    yh = y.double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
+    dy = (torch.where((yh > 0) & (yh < 6), a.double(), torch.zeros((), dtype=torch.float64)) * cb[:, 2].double()[None, :, None, None]
+          + cb[:, 3].double()[None, :, None, None] * y.double() + cb[:, 4].double()[None, :, None, None])
+    want2 = dy + b.double()
+    n = a.numel()
+    bufs = [torch.zeros(n + 4, device=DEV) for _ in range(4)]
+    for off in (0, 1):
+        av, bv, yv, ov = (t[off:off + n].view(N, C_, H, W) for t in bufs)
+        av.copy_(dev(a)); bv.copy_(dev(b)); yv.copy_(dev(y))
+        for want, sa, sb in ((want1, make_src(av, C_, SRC_RAW), make_src(bv, C_, SRC_AFFINE, act=ACT_RELU6, cst=cst_affine(sc, sh))),
+                             (want2, make_src(av, C_, SRC_BNBWD, act=ACT_RELU6, cst=dev(cb), aux=yv), make_src(bv, C_, SRC_RAW))):
+            ov.fill_(float("nan"))
+            amax = torch.zeros(1, device=DEV)
+            check(hip.sc_add_srcs_absmax(C.byref(sa), C.byref(sb), ptr(ov), N, C_, H * W, ptr(amax), stream()))
+            assert relerr(ov, want) < 1e-6
+            assert abs(float(amax) - float(want.abs().max())) <= 1e-5 * float(want.abs().max())
+    ad = dev(a)
+    src1 = make_src(ad, C_, SRC_RAW)
+    o1 = torch.empty(N, C_, H, W, device=DEV)
+    check(hip.sc_apply_src(C.byref(src1), ptr(o1), N, C_, H * W, stream()))       # (one operand)
+    assert torch.equal(o1, ad)
+
+
 def test_bce_loss_and_grad(hip):
     n = 5000
     z, t, w = (rnd(n, seed=1) * 3).requires_grad_(True), (rnd(n, seed=2) > 0.5).float(), rnd(n, seed=3).abs().clamp(0.1, 1)
